@@ -1,0 +1,1171 @@
+/* oracle/djb_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see djb_oracle.h).
+ *
+ * Plain-C restatement of the dj_brdf hot path.  "hdr:N" = /root/reference/dj_brdf.h line N.
+ * Conventions: F(x) rounds a double expression to float exactly where the
+ * reference assigns/returns a float_t; everything inside D(...) is double.
+ */
+#include "djb_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define F(x) ((float)(x))
+#define D(x) ((double)(x))
+#define O_PI 3.14159265358979323846 /* M_PI */
+#define O_EPSILON ((float)1e-4)     /* DJB_EPSILON, hdr:49-51 */
+
+static __thread char g_err[512];
+const char *o_last_error(void) { return g_err; }
+static void set_err(const char *fmt, ...)
+{
+	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+
+/* ------------------------------------------------------------------ L0 math (hdr:574-765) */
+static float fminf_(float a, float b) { return a < b ? a : b; }   /* djb::min hdr:574 */
+static float fmaxf_(float a, float b) { return a > b ? a : b; }   /* djb::max hdr:575 */
+static float satf_(float x) { return fminf_(1.0f, fmaxf_(0.0f, x)); } /* hdr:576 */
+
+static o_vec3 v3(float x, float y, float z) { o_vec3 v = { x, y, z }; return v; }
+static o_vec3 v3_add(o_vec3 a, o_vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static o_vec3 v3_sub(o_vec3 a, o_vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static o_vec3 v3_mul(o_vec3 a, o_vec3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static o_vec3 v3_scale(float s, o_vec3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+/* vec3 / float_t = (1.0 / b) * a : double reciprocal rounded to float, hdr:601 */
+static o_vec3 v3_div(o_vec3 a, float b) { return v3_scale(F(1.0 / D(b)), a); }
+static float v3_dot(o_vec3 a, o_vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } /* hdr:618 */
+static o_vec3 v3_cross(o_vec3 a, o_vec3 b) /* hdr:623 */
+{
+	return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static float inversesqrt_(float x) { return F(1.0 / sqrt(D(x))); } /* hdr:612 */
+static o_vec3 v3_normalize(o_vec3 v) { return v3_scale(inversesqrt_(v3_dot(v, v)), v); } /* hdr:630 */
+static float v3_intensity(o_vec3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z; } /* hdr:69 */
+
+/* vec3(theta, phi) ctor, hdr:589-595 */
+static o_vec3 v3_from_angles(float theta, float phi)
+{
+	float s = F(sin(D(theta)));
+	return v3(F(D(s) * cos(D(phi))), F(D(s) * sin(D(phi))), F(cos(D(theta))));
+}
+
+/* hdr:650-661 */
+static void xyz_to_theta_phi(o_vec3 p, float *theta, float *phi)
+{
+	if (D(p.z) > 0.99999) { *theta = 0.0f; *phi = 0.0f; }
+	else if (D(p.z) < -0.99999) { *theta = F(O_PI); *phi = 0.0f; }
+	else { *theta = F(acos(D(p.z))); *phi = F(atan2(D(p.y), D(p.x))); }
+}
+
+/* A&S 7.1.26, hdr:667-688 */
+static float erf_(float x)
+{
+	const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f,
+	            a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+	int sign = x < 0 ? -1 : 1;
+	x = F(fabs(D(x)));
+	float t = F(1.0 / (1.0 + D(p * x)));
+	float poly = ((((a5 * t + a4) * t) + a3) * t + a2) * t + a1;
+	float y = F(1.0 - D(poly * t) * exp(D(-x * x)));
+	return (float)sign * y;
+}
+
+/* Giles single-precision erfinv, hdr:691-721 */
+static float erfinv_(float u)
+{
+	float w = -logf((1.0f - u) * (1.0f + u)), p;
+	if (w < 5.0f) {
+		w = w - 2.5f;
+		p = 2.81022636e-08f;
+		p = 3.43273939e-07f + p * w;
+		p = -3.5233877e-06f + p * w;
+		p = -4.39150654e-06f + p * w;
+		p = 0.00021858087f + p * w;
+		p = -0.00125372503f + p * w;
+		p = -0.00417768164f + p * w;
+		p = 0.246640727f + p * w;
+		p = 1.50140941f + p * w;
+	} else {
+		w = F(sqrt(D(w)) - D(3.0f));
+		p = -0.000200214257f;
+		p = 0.000100950558f + p * w;
+		p = 0.00134934322f + p * w;
+		p = -0.00367342844f + p * w;
+		p = 0.00573950773f + p * w;
+		p = -0.0076224613f + p * w;
+		p = 0.00943887047f + p * w;
+		p = 1.00167406f + p * w;
+		p = 2.83297682f + p * w;
+	}
+	return p * u;
+}
+
+/* Cline's concentric map, hdr:726-747 */
+static void uniform_to_concentric(float u1, float u2, float *x, float *y)
+{
+	float r1 = F(2.0 * D(u1) - 1.0), r2 = F(2.0 * D(u2) - 1.0), phi, r;
+	if (r1 == 0 && r2 == 0) { r = phi = 0; }
+	else if (r1 * r1 > r2 * r2) { r = r1; phi = F((O_PI / 4.0) * D(r2 / r1)); }
+	else { r = r2; phi = F((O_PI / 2.0) - D(r1 / r2) * (O_PI / 4.0)); }
+	*x = F(D(r) * cos(D(phi)));
+	*y = F(D(r) * sin(D(phi)));
+}
+
+/* Rodrigues, hdr:754-765 */
+static o_vec3 rotate_vector(o_vec3 x, o_vec3 axis, float angle)
+{
+	float c = F(cos(D(angle))), s = F(sin(D(angle)));
+	o_vec3 out = v3_scale(c, x);
+	float t1 = v3_dot(axis, x);
+	float t2 = F(D(t1) * (1.0 - D(c)));
+	out = v3_add(out, v3_scale(t2, axis));
+	out = v3_add(out, v3_scale(s, v3_cross(axis, x)));
+	return out;
+}
+
+/* hdr:771-781 */
+static void io_to_hd(o_vec3 i, o_vec3 o, o_vec3 *h, o_vec3 *d)
+{
+	float th, ph;
+	*h = v3_normalize(v3_add(i, o));
+	xyz_to_theta_phi(*h, &th, &ph);
+	o_vec3 tmp = rotate_vector(i, v3(0, 0, 1), -ph);
+	*d = v3_normalize(rotate_vector(tmp, v3(0, 1, 0), -th));
+}
+
+/* hdr:783-793 */
+static void hd_to_io(o_vec3 h, o_vec3 d, o_vec3 *i, o_vec3 *o)
+{
+	float th, ph;
+	xyz_to_theta_phi(h, &th, &ph);
+	o_vec3 tmp = rotate_vector(d, v3(0, 1, 0), th);
+	*i = v3_normalize(rotate_vector(tmp, v3(0, 0, 1), ph));
+	*o = v3_normalize(v3_sub(v3_scale(F(2.0 * D(v3_dot(*i, h))), h), *i));
+}
+
+/* ------------------------------------------------------------------ spline (hdr:1181-1249) */
+static int uwrap_edge(int i, int edge) { return i >= edge ? edge - 1 : (i < 0 ? 0 : i); }
+
+static void spline_locate(int edge, float u, int *i1, int *i2, float *frac)
+{
+	double ip;
+	*frac = F(modf(D(u * (float)edge - u), &ip));
+	*i1 = uwrap_edge((int)ip, edge);
+	*i2 = uwrap_edge((int)ip + 1, edge);
+}
+static float spline_eval_f(const float *pts, int n, float u)
+{
+	int i1, i2; float fr;
+	spline_locate(n, u, &i1, &i2, &fr);
+	return pts[i1] + fr * (pts[i2] - pts[i1]);
+}
+static o_vec3 spline_eval_v3(const o_vec3 *pts, int n, float u)
+{
+	int i1, i2; float fr;
+	spline_locate(n, u, &i1, &i2, &fr);
+	return v3_add(pts[i1], v3_scale(fr, v3_sub(pts[i2], pts[i1])));
+}
+
+/* ------------------------------------------------------------------ BRDF object */
+typedef struct {
+	int kind;
+	o_vec3 a, b;          /* ior | f0 | (f0, f1) */
+	o_vec3 *pts; int npts;
+} o_fresnel;
+
+struct o_brdf {
+	int kind;
+	int shadow;
+	o_fresnel fresnel;
+	/* tabular */
+	float *p22, *sigma, *cdf, *qf;
+	int n_p22, n_sigma, n_cdf, n_qf;
+	/* merl / utia */
+	double *samples;
+	int64_t n_samples;
+};
+
+/* ------------------------------------------------------------------ Fresnel (hdr:1253-1346) */
+static float unpolarized_eval1(float c, float n) /* hdr:1292-1303 */
+{
+	float g = F(sqrt(D(n * n + c * c) - 1.0));
+	float t1 = F(D(c * (g + c)) - 1.0);
+	float t2 = F(D(c * (g - c)) + 1.0);
+	float t3 = (t1 * t1) / (t2 * t2);
+	float t4 = ((g - c) * (g - c)) / ((g + c) * (g + c));
+	return F((0.5 * D(t4)) * (1.0 + D(t3)));
+}
+
+static o_vec3 fresnel_eval(const o_fresnel *f, float c)
+{
+	switch (f->kind) {
+	case O_FRESNEL_UNPOLARIZED:
+		return v3(unpolarized_eval1(c, f->a.x), unpolarized_eval1(c, f->a.y),
+		          unpolarized_eval1(c, f->a.z));
+	case O_FRESNEL_SCHLICK: { /* hdr:1320-1328 */
+		float c1 = F(1.0 - D(c)), c2 = c1 * c1, c5 = c2 * c2 * c1;
+		return v3_add(f->a, v3_scale(c5, v3_sub(v3(1, 1, 1), f->a)));
+	}
+	case O_FRESNEL_SGD: { /* hdr:1330-1336 */
+		float pw = F(pow(1.0 - D(c), 5.0));
+		return v3_add(v3_sub(f->a, v3_scale(c, f->b)),
+		              v3_scale(pw, v3_sub(v3(1, 1, 1), f->a)));
+	}
+	case O_FRESNEL_SPLINE: { /* hdr:1338-1344 */
+		float u = F(2.0 * acos(D(c)) / O_PI);
+		return spline_eval_v3(f->pts, f->npts, u);
+	}
+	default: return v3(1, 1, 1);
+	}
+}
+
+/* ------------------------------------------------------------------ params (hdr:1355-1506) */
+static void params_set_location(o_params *p, float tx, float ty) /* hdr:1437 */
+{
+	p->tx = tx; p->ty = ty;
+	p->n = v3_normalize(v3(-tx, -ty, 1.0f));
+}
+
+static void params_set_ellipse(o_params *p, float a1, float a2, float phi_a) /* hdr:1451, 1356-1371 */
+{
+	p->a1 = a1; p->a2 = a2; p->phi_a = phi_a;
+	float c = F(cos(D(phi_a))), s = F(sin(D(phi_a)));
+	float c2 = F(2.0 * D(c) * D(c) - D(1.0f));
+	float a1s = a1 * a1, a2s = a2 * a2, t1 = a1s + a2s, t2 = a1s - a2s;
+	p->ax = F(sqrt(0.5 * D(t1 + t2 * c2)));
+	p->ay = F(sqrt(0.5 * D(t1 - t2 * c2)));
+	p->rho = (a2s - a1s) * c * s / (p->ax * p->ay);
+	p->sqrt_1mrho2 = F(sqrt(1.0 - D(p->rho * p->rho)));
+}
+
+static void params_set_pdfparams(o_params *p, float ax, float ay, float rho, float tx, float ty)
+{ /* hdr:1461-1474, 1378-1393 */
+	p->ax = ax; p->ay = ay; p->rho = rho;
+	p->sqrt_1mrho2 = F(sqrt(1.0 - D(rho * rho)));
+	float axs = ax * ax, ays = ay * ay;
+	float cov = F(D(rho * ax * ay) * 2.0);
+	float t1 = axs + ays, t2 = axs - ays;
+	float t3 = F(sqrt(D(t2 * t2 + cov * cov)));
+	p->a1 = F(sqrt(0.5 * D(t1 + t3)));
+	p->a2 = F(sqrt(0.5 * D(t1 - t3)));
+	p->phi_a = (D(cov) != 0.0) ? F(atan(D((axs - ays - t3) / cov))) : 0.0f;
+	params_set_location(p, tx, ty);
+}
+
+static o_params params_elliptic(float a1, float a2, float phi_a)
+{
+	o_params p;
+	params_set_ellipse(&p, a1, a2, phi_a);
+	params_set_location(&p, 0, 0);
+	return p;
+}
+static o_params params_standard(void) { return params_elliptic(1, 1, 0); }
+
+static o_params params_from_desc(const o_param_desc *pd)
+{
+	if (pd && pd->kind == 1) return params_elliptic(pd->v[0], pd->v[1], pd->v[2]);
+	if (pd && pd->kind == 2) {
+		o_params p;
+		params_set_pdfparams(&p, pd->v[0], pd->v[1], pd->v[2], pd->v[3], pd->v[4]);
+		return p;
+	}
+	return params_standard();
+}
+
+/* ------------------------------------------------------------------ radial queries */
+static float tab_p22_radial(const o_brdf *b, float r_sqr) /* hdr:2151-2156 */
+{
+	float r = F(sqrt(D(r_sqr)));
+	float u = F(sqrt(D(2.0f) * atan(D(r)) / D(F(O_PI))));
+	return spline_eval_f(b->p22, b->n_p22, u);
+}
+static float tab_sigma_std_radial(const o_brdf *b, float c) /* hdr:2158-2162 */
+{
+	float u = F(D(2.0f) * acos(D(c)) / D(F(O_PI)));
+	return spline_eval_f(b->sigma, b->n_sigma, u);
+}
+static float tab_cdf_radial(const o_brdf *b, float r) /* hdr:2164-2169 */
+{
+	float u = F(atan(D(r)) * D(2.0f) / D(F(O_PI)));
+	if (u < 0.0f) u = 0.0f;
+	return spline_eval_f(b->cdf, b->n_cdf, F(sqrt(D(u))));
+}
+static float tab_qf_radial(const o_brdf *b, float u) /* hdr:2171-2176 */
+{
+	float qf = spline_eval_f(b->qf, b->n_qf, u);
+	return F(tan(D(qf * F(O_PI) / 2.0f)));
+}
+
+static float p22_radial(const o_brdf *b, float r_sqr)
+{
+	switch (b->kind) {
+	case O_BRDF_BECKMANN: return F(exp(D(-r_sqr)) / O_PI);                    /* hdr:1866 */
+	case O_BRDF_GGX: { float t = F(1.0 + D(r_sqr)); return F(1.0 / (O_PI * D(t) * D(t))); } /* hdr:2056 */
+	default: return tab_p22_radial(b, r_sqr);
+	}
+}
+
+static float sigma_std_radial(const o_brdf *b, float c)
+{
+	switch (b->kind) {
+	case O_BRDF_BECKMANN: { /* hdr:1871-1879 */
+		if (D(c) == 1.0) return 1.0f;
+		float s = F(sqrt(1.0 - D(c * c)));
+		float nu = c / s;
+		float tmp = F(exp(D(-nu * nu)) * D(inversesqrt_(F(O_PI))));
+		return F((D(c) * (1.0 + D(erf_(nu))) + D(s * tmp)) / 2.0);
+	}
+	case O_BRDF_GGX: return F((1.0 + D(c)) / 2.0);                            /* hdr:2062 */
+	default: return tab_sigma_std_radial(b, c);
+	}
+}
+
+static float cdf_radial(const o_brdf *b, float r)
+{
+	switch (b->kind) {
+	case O_BRDF_BECKMANN: return F(1.0 - exp(D(-r * r)));                     /* hdr:1881 */
+	case O_BRDF_GGX: { float t = r * r; return F(D(t) / (1.0 + D(t))); }      /* hdr:2067 */
+	default: return tab_cdf_radial(b, r);
+	}
+}
+
+static float qf_radial(const o_brdf *b, float u)
+{
+	switch (b->kind) {
+	case O_BRDF_BECKMANN: return F(sqrt(-log(1.0 - D(u))));                   /* hdr:1886 */
+	case O_BRDF_GGX: return F(sqrt(D(u) / (1.0 - D(u))));                     /* hdr:2073 */
+	default: return tab_qf_radial(b, u);
+	}
+}
+
+static float beckmann_qf1(float u) { return erfinv_(F(2.0 * D(u) - 1.0)); } /* hdr:1891 */
+
+/* hdr:1897-1952 */
+static float beckmann_qf2_radial(float u, float cos_k, float sin_k)
+{
+	const float sqrt_pi_inv = F(1. / sqrt(O_PI));
+	float cot_k = cos_k / sin_k, tan_k = sin_k / cos_k;
+	float a = -1, c = erf_(cot_k);
+	u = fmaxf_(u, 1e-6f);
+	float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
+	float b = c - (1 + c) * powf(1 - u, fit);
+	float normalization = F(1 / (D(1 + c) + D(sqrt_pi_inv * tan_k) * exp(D(-cot_k * cot_k))));
+	int it = 0;
+	while (++it < 10) {
+		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+		float inv_erf = erfinv_(b);
+		float value = normalization * (1 + b + sqrt_pi_inv * tan_k * expf(-inv_erf * inv_erf)) - u;
+		float derivative = normalization * (1 - inv_erf * tan_k);
+		if (fabs(D(value)) < D(1e-5f)) break;
+		if (value > 0) c = b; else a = b;
+		b -= value / derivative;
+	}
+	return erfinv_(fmaxf_(-0.9999f, b));
+}
+
+/* hdr:2078-2087 */
+static float ggx_qf1(float u)
+{
+	if (D(u) < 0.5) { u = F((0.5 - D(u)) * 2.0); return -u * inversesqrt_(F(1.0 - D(u * u))); }
+	u = F((D(u) - 0.5) * 2.0);
+	return u * inversesqrt_(F(1.0 - D(u * u)));
+}
+
+/* hdr:2089-2119 */
+static float ggx_qf2_radial(float u, float cos_k, float sin_k)
+{
+	float sin_t = F(D(u) * (1.0 + D(cos_k)) - 1.0);
+	float cos_t = F(sqrt(1.0 - D(sin_t * sin_t)));
+	if (D(cos_t) > 0.707107) {
+		float tan_t = sin_t / cos_t;
+		if (D(sin_k) < 0.707107) {
+			float tan_k = sin_k / cos_k;
+			return F(D(-(tan_t + tan_k)) / (1.0 - D(tan_t * tan_k)));
+		} else {
+			float cot_k = cos_k / sin_k;
+			return F((1.0 + D(tan_t * cot_k)) / D(tan_t - cot_k));
+		}
+	} else {
+		float cot_t = cos_t / sin_t;
+		if (D(sin_k) < 0.707107) {
+			float tan_k = sin_k / cos_k;
+			return F((1.0 + D(tan_k * cot_t)) / D(tan_k - cot_t));
+		} else {
+			float cot_k = cos_k / sin_k;
+			return F(D(cot_t + cot_k) / (1.0 - D(cot_t * cot_k)));
+		}
+	}
+}
+
+/* hdr:2121-2146 */
+static float ggx_qf3_radial(float u, float qf2)
+{
+	float alpha = F(sqrt(1.0 + D(qf2 * qf2)));
+	float S;
+	if (D(u) < 0.5) { u = F(2.0 * (0.5 - D(u))); S = -1.0f; }
+	else { u = F(2.0 * (D(u) - 0.5)); S = 1.0f; }
+	double x = D(u);
+	float p = F(x * (x * (x * (-0.365728915865723) + 0.790235037209296) - 0.424965825137544)
+	            + 0.000152998850436920);
+	float q = F(x * (x * (x * (x * 0.169507819808272 - 0.397203533833404) - 0.232500544458471) + 1)
+	            - 0.539825872510702);
+	return S * alpha * (p / q);
+}
+
+static int supports_smith_vndf(const o_brdf *b) { return b->kind != O_BRDF_TABULAR; }
+
+/* ------------------------------------------------------------------ microfacet (hdr:1529-1765) */
+static float mf_p22_std(const o_brdf *b, float x, float y) { return p22_radial(b, x * x + y * y); }
+
+static float mf_p22(const o_brdf *b, float x, float y, const o_params *p) /* hdr:1574-1587 */
+{
+	x -= p->tx; y -= p->ty;
+	float nrm = p->ax * p->ay * p->sqrt_1mrho2;
+	float x_ = x / p->ax;
+	float t1 = p->ax * y - p->rho * p->ay * x;
+	float t2 = p->ax * p->ay * p->sqrt_1mrho2;
+	float y_ = t1 / t2;
+	return mf_p22_std(b, x_, y_) / nrm;
+}
+
+static float mf_ndf(const o_brdf *b, o_vec3 h, const o_params *p) /* hdr:1559-1570 */
+{
+	if (h.z > O_EPSILON) {
+		float c2 = h.z * h.z, c4 = c2 * c2;
+		float xs = -h.x / h.z, ys = -h.y / h.z;
+		return mf_p22(b, xs, ys, p) / c4;
+	}
+	return 0.0f;
+}
+
+static float mf_sigma(const o_brdf *b, o_vec3 k, const o_params *p) /* hdr:1619-1631 */
+{
+	float a = k.x * p->ax + k.y * p->ay * p->rho;
+	float bb = k.y * p->ay * p->sqrt_1mrho2;
+	float c = k.z - k.x * p->tx - k.y * p->ty;
+	float nrm = F(sqrt(D(a * a + bb * bb + c * c)));
+	o_vec3 kn = v3_div(v3(a, bb, c), nrm);
+	return nrm * sigma_std_radial(b, kn.z);
+}
+
+static float mf_g1(const o_brdf *b, o_vec3 k, const o_params *p) /* hdr:1633-1642 */
+{
+	if (D(v3_dot(k, p->n)) > 0.0) return k.z / mf_sigma(b, k, p);
+	return 0.0f;
+}
+
+static float mf_gaf(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p) /* hdr:1644-1665 */
+{
+	float g1o = mf_g1(b, o, p);
+	if (b->shadow) {
+		float g1i = mf_g1(b, i, p);
+		float t = g1i * g1o;
+		if (D(t) > 0.0) return t / (g1i + g1o - t);
+		return 0.0f;
+	}
+	return g1o;
+}
+
+static float mf_vndf(const o_brdf *b, o_vec3 h, o_vec3 k, const o_params *p) /* hdr:1602-1615 */
+{
+	float kh = v3_dot(k, h);
+	if (D(kh) > 0.0) {
+		float Dn = mf_ndf(b, h, p);
+		return kh * Dn / mf_sigma(b, k, p);
+	}
+	return 0.0f;
+}
+
+static float mf_vp22(const o_brdf *b, float x, float y, o_vec3 k, const o_params *p) /* hdr:1591-1598 */
+{
+	o_vec3 h = v3_normalize(v3(-x, -y, 1));
+	float jac = h.z * h.z * h.z;
+	return jac * mf_vndf(b, h, k, p);
+}
+
+static o_vec3 mf_evalp(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p) /* hdr:1529-1547 */
+{
+	o_vec3 h = v3_normalize(v3_add(i, o));
+	float G = mf_gaf(b, i, o, p);
+	if (D(G) > 0.0) {
+		float cd = satf_(v3_dot(o, h));
+		o_vec3 Fr = fresnel_eval(&b->fresnel, cd);
+		float Dn = mf_ndf(b, h, p);
+		return v3_scale(F(D(Dn * G) / (4.0 * D(o.z))), Fr);
+	}
+	return v3(0, 0, 0);
+}
+
+static o_vec3 mf_eval(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p) /* hdr:1551-1555 */
+{
+	return v3_div(mf_evalp(b, i, o, p), i.z);
+}
+
+static float mf_pdf(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p) /* hdr:1713-1730 */
+{
+	o_vec3 h = v3_normalize(v3_add(i, o));
+	float G = mf_gaf(b, i, o, p);
+	if (D(G) > 0.0) {
+		if (!supports_smith_vndf(b))
+			return F(D(h.z * mf_ndf(b, h, p)) / (4.0 * D(v3_dot(i, h))));
+		return F(D(mf_vndf(b, h, o, p)) / (4.0 * D(v3_dot(i, h))));
+	}
+	return 0.0f;
+}
+
+/* radial::sample_vp22_std_smith / _nmap, hdr:1806-1846 */
+static void mf_sample_vp22_std(const o_brdf *b, float u1, float u2, o_vec3 k, float *xs, float *ys)
+{
+	if (supports_smith_vndf(b)) {
+		float cos_k = k.z;
+		float sin_k = D(k.z) < 1.0 ? F(sqrt(1.0 - D(k.z * k.z))) : 0.0f;
+		float tx, ty;
+		if (b->kind == O_BRDF_BECKMANN) {
+			tx = beckmann_qf2_radial(u1, cos_k, sin_k);
+			ty = beckmann_qf1(u2);                          /* qf3_radial, hdr:1954 */
+		} else {
+			tx = ggx_qf2_radial(u1, cos_k, sin_k);
+			ty = ggx_qf3_radial(u2, tx);
+		}
+		if (D(sin_k) == 0.0) { *xs = tx; *ys = ty; }
+		else {
+			float nrm = inversesqrt_(k.x * k.x + k.y * k.y);
+			float cp = k.x * nrm, sp = k.y * nrm;
+			*xs = cp * tx - sp * ty;
+			*ys = sp * tx + cp * ty;
+		}
+	} else {
+		float phi_h = F(D(u1) * O_PI * 2.0);
+		float r_h = qf_radial(b, u2);
+		*xs = F(D(r_h) * cos(D(phi_h)));
+		*ys = F(D(r_h) * sin(D(phi_h)));
+	}
+}
+
+static o_vec3 mf_sample(const o_brdf *b, float u1, float u2, o_vec3 o, const o_params *p) /* hdr:1669-1709 */
+{
+	u1 = satf_(u1) * 0.99998f + 0.00001f;
+	u2 = satf_(u2) * 0.99998f + 0.00001f;
+	float a = o.x * p->ax + o.y * p->ay * p->rho;
+	float bb = o.y * p->ay * p->sqrt_1mrho2;
+	float c = o.z - o.x * p->tx - o.y * p->ty;
+	o_vec3 o_std = v3_normalize(v3(a, bb, c));
+	if (D(o_std.z) > 0.0) {
+		float txm, tym;
+		mf_sample_vp22_std(b, u1, u2, o_std, &txm, &tym);
+		float txh = p->ax * txm + p->tx;
+		float chol = p->rho * txm + p->sqrt_1mrho2 * tym;
+		float tyh = p->ay * chol + p->ty;
+		o_vec3 h = v3_normalize(v3(-txh, -tyh, 1));
+		return v3_sub(v3_scale(F(2.0 * D(v3_dot(o, h))), h), o);
+	}
+	return v3(0, 0, 1);
+}
+
+/* hdr:1734-1765 */
+static o_vec3 mf_evalp_is(const o_brdf *b, float u1, float u2, o_vec3 o, const o_params *p,
+                          o_vec3 *i_out, float *pdf_out)
+{
+	o_vec3 i_ = mf_sample(b, u1, u2, o, p);
+	o_vec3 h = v3_normalize(v3_add(i_, o));
+	float G = mf_gaf(b, i_, o, p);
+	*pdf_out = 0.f;
+	if (D(G) > 0.0) {
+		float cd = satf_(v3_dot(o, h));
+		*i_out = i_;
+		if (!supports_smith_vndf(b)) {
+			float pdf_ = F(D(h.z * mf_ndf(b, h, p)) / (4.0 * D(cd)));
+			*pdf_out = pdf_;
+			return v3_div(mf_evalp(b, i_, o, p), pdf_);
+		} else {
+			o_vec3 Fr = fresnel_eval(&b->fresnel, cd);
+			float G1 = mf_g1(b, o, p);
+			*pdf_out = F(D(mf_vndf(b, h, o, p)) / (4.0 * D(cd)));
+			return v3_scale(G / G1, Fr);
+		}
+	}
+	return v3(0, 0, 0);
+}
+
+/* ------------------------------------------------------------------ MERL (hdr:893-1024) */
+static int theta_half_index(float th) /* hdr:906-920 */
+{
+	if (D(th) <= 0.0) return 0;
+	float deg = F((D(th) / (O_PI / 2.0)) * 90);
+	float t = deg * 90;
+	t = F(sqrt(D(t)));
+	int r = (int)t;
+	return r < 0 ? 0 : (r >= 90 ? 89 : r);
+}
+static int theta_diff_index(float td) /* hdr:926-936 */
+{
+	int t = (int)(D(td) / (O_PI * 0.5) * 90);
+	return t < 0 ? 0 : (t < 89 ? t : 89);
+}
+static int phi_diff_index(float pd) /* hdr:940-957 */
+{
+	if (D(pd) < 0.0) pd = F(D(pd) + O_PI);
+	int t = (int)(D(pd) / O_PI * 360 / 2);
+	return t < 0 ? 0 : (t < 179 ? t : 179);
+}
+static int merl_index(o_vec3 i, o_vec3 o)
+{
+	o_vec3 h, d; float th, ph, td, pd;
+	io_to_hd(i, o, &h, &d);
+	xyz_to_theta_phi(h, &th, &ph);
+	xyz_to_theta_phi(d, &td, &pd);
+	return phi_diff_index(pd) + theta_diff_index(td) * 180 + theta_half_index(th) * 16200;
+}
+static o_vec3 merl_eval(const o_brdf *b, o_vec3 i, o_vec3 o) /* hdr:987-1024 */
+{
+	int64_t n = b->n_samples / 3; /* 1 458 000 for real files; index constants are fixed */
+	(void)n;
+	int ir = merl_index(i, o), ig = ir + 1458000, ib = ir + 2916000;
+	o_vec3 rgb = v3(F(b->samples[ir] * (1.00 / 1500.0)),
+	                F(b->samples[ig] * (1.15 / 1500.0)),
+	                F(b->samples[ib] * (1.66 / 1500.0)));
+	if (D(rgb.x) < 0.0 || D(rgb.y) < 0.0 || D(rgb.z) < 0.0) return v3(0, 0, 0);
+	return rgb;
+}
+
+/* ------------------------------------------------------------------ UTIA (hdr:1029-1177) */
+static o_vec3 utia_eval(const o_brdf *b, o_vec3 i, o_vec3 o) /* hdr:1063-1157 */
+{
+	float r2d = F(180.0 / O_PI);
+	float theta_i = F(D(r2d) * acos(D(i.z))), theta_o = F(D(r2d) * acos(D(o.z)));
+	float phi_i = F(D(r2d) * atan2(D(i.y), D(i.x))), phi_o = F(D(r2d) * atan2(D(o.y), D(o.x)));
+	if (D(theta_i) >= 90.0 || D(theta_o) >= 90.0) return v3(0, 0, 0);
+	while (D(phi_i) < 0.0) phi_i = F(D(phi_i) + 360.0);
+	while (D(phi_o) < 0.0) phi_o = F(D(phi_o) + 360.0);
+	while (phi_i >= 360) phi_i = F(D(phi_i) - 360.0);
+	while (phi_o >= 360) phi_o = F(D(phi_o) - 360.0);
+	int iti[2], itv[2], ipi[2], ipv[2];
+	iti[0] = (int)floor(D(theta_i) / 15.0); iti[1] = iti[0] + 1;
+	if (iti[0] > 4) { iti[0] = 4; iti[1] = 5; }
+	itv[0] = (int)floor(D(theta_o) / 15.0); itv[1] = itv[0] + 1;
+	if (itv[0] > 4) { itv[0] = 4; itv[1] = 5; }
+	ipi[0] = (int)floor(D(phi_i) / 7.5); ipi[1] = ipi[0] + 1;
+	ipv[0] = (int)floor(D(phi_o) / 7.5); ipv[1] = ipv[0] + 1;
+	float sum, wti[2], wtv[2], wpi[2], wpv[2];
+	wti[1] = theta_i - F(15.0 * iti[0]); wti[0] = F(15.0 * iti[1]) - theta_i;
+	sum = wti[0] + wti[1]; wti[0] /= sum; wti[1] /= sum;
+	wtv[1] = theta_o - F(15.0 * itv[0]); wtv[0] = F(15.0 * itv[1]) - theta_o;
+	sum = wtv[0] + wtv[1]; wtv[0] /= sum; wtv[1] /= sum;
+	wpi[1] = phi_i - F(7.5 * ipi[0]); wpi[0] = F(7.5 * ipi[1]) - phi_i;
+	sum = wpi[0] + wpi[1]; wpi[0] /= sum; wpi[1] /= sum;
+	wpv[1] = phi_o - F(7.5 * ipv[0]); wpv[0] = F(7.5 * ipv[1]) - phi_o;
+	sum = wpv[0] + wpv[1]; wpv[0] /= sum; wpv[1] /= sum;
+	if (ipi[1] == 48) ipi[1] = 0;
+	if (ipv[1] == 48) ipv[1] = 0;
+	const int nc = 48 * 6, nr = 48 * 6;
+	float RGB[3];
+	for (int isp = 0; isp < 3; ++isp) {
+		RGB[isp] = 0.0f;
+		for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c)
+		for (int k = 0; k < 2; ++k) for (int l = 0; l < 2; ++l) {
+			float w = wti[a] * wtv[c] * wpi[k] * wpv[l];
+			int idx = isp * nr * nc + nc * (48 * iti[a] + ipi[k]) + 48 * itv[c] + ipv[l];
+			RGB[isp] += w * F(b->samples[idx]);
+		}
+		if (D(RGB[isp]) > 0.0375) RGB[isp] = F(pow(D(F(D(RGB[isp]) + 0.055)) / 1.055, D(2.4f)));
+		else RGB[isp] /= 12.92f;
+		RGB[isp] *= 100.0f;
+	}
+	return v3(fmaxf_(0.f, RGB[0]), fmaxf_(0.f, RGB[1]), fmaxf_(0.f, RGB[2]));
+}
+
+/* ------------------------------------------------------------------ generic dispatch */
+static int is_microfacet(const o_brdf *b) { return b->kind <= O_BRDF_TABULAR; }
+
+static o_vec3 brdf_eval(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p)
+{
+	switch (b->kind) {
+	case O_BRDF_MERL: return merl_eval(b, i, o);
+	case O_BRDF_UTIA: return utia_eval(b, i, o);
+	case O_BRDF_LAMBERT: return v3_div(v3(1, 1, 1), F(O_PI)); /* hdr:861-868, default params */
+	default: return mf_eval(b, i, o, p);
+	}
+}
+static o_vec3 brdf_evalp(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p)
+{
+	if (is_microfacet(b)) return mf_evalp(b, i, o, p);
+	return v3_scale(i.z, brdf_eval(b, i, o, p)); /* hdr:803-806 */
+}
+static float brdf_pdf(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p)
+{
+	if (is_microfacet(b)) return mf_pdf(b, i, o, p);
+	return F(D(i.z) / O_PI); /* hdr:842-845 */
+}
+static o_vec3 brdf_sample(const o_brdf *b, float u1, float u2, o_vec3 o, const o_params *p)
+{
+	if (is_microfacet(b)) return mf_sample(b, u1, u2, o, p);
+	float x, y; /* hdr:830-840 */
+	uniform_to_concentric(u1, u2, &x, &y);
+	return v3(x, y, F(sqrt(1.0 - D(x * x) - D(y * y))));
+}
+
+/* ------------------------------------------------------------------ the fitter (hdr:2215-2762) */
+static void tab_compute_p22_smith(o_brdf *t, const o_brdf *src, int res) /* hdr:2482-2522 */
+{
+	int cnt = res - 1;
+	float dtheta = F(sqrt(O_PI * 0.5) / D((float)cnt));
+	double *km = (double *)calloc((size_t)cnt * cnt, sizeof(double));
+	o_params std_p = params_standard();
+	for (int i = 0; i < cnt; ++i) {
+		float tmp = (float)i / (float)cnt;
+		float theta = F(D(tmp) * sqrt(O_PI * 0.5));
+		float theta_o = theta * theta;
+		float cos_o = F(cos(D(theta_o))), tan_o = F(tan(D(theta_o)));
+		o_vec3 w = v3_from_angles(theta_o, 0.0f);
+		o_vec3 fr = brdf_eval(src, w, w, &std_p);
+		float fr_i = v3_intensity(fr);
+		float kji_tmp = F((D(dtheta) * pow(D(cos_o), D(6.0f))) * (8.0 * D(fr_i)));
+		for (int j = 0; j < cnt; ++j) {
+			const float dphi_h = F(O_PI / 180.0);
+			float tmpj = (float)j / (float)cnt;
+			float thj = F(D(tmpj) * sqrt(O_PI * 0.5));
+			float theta_h = thj * thj;
+			float cos_h = F(cos(D(theta_h))), tan_h = F(tan(D(theta_h)));
+			float tan_product = tan_h * tan_o;
+			float nint = 0.0f;
+			for (float phi_h = 0.0f; D(phi_h) < 2.0 * O_PI; phi_h += dphi_h)
+				nint += fmaxf_(1.0f, tan_product * F(cos(D(phi_h))));
+			nint *= dphi_h;
+			/* km(j, i) -> mij[i*size + j], hdr:2447 */
+			km[(size_t)i * cnt + j] = D(thj * kji_tmp * nint * tan_h / (cos_h * cos_h));
+		}
+	}
+	/* matrix::eigenvector(4): 4 un-normalised matvecs from ones, hdr:2455-2480 */
+	double *v0 = (double *)malloc(sizeof(double) * cnt), *v1 = (double *)malloc(sizeof(double) * cnt);
+	for (int i = 0; i < cnt; ++i) v0[i] = 1.0;
+	for (int it = 0; it < 4; ++it) {
+		for (int j = 0; j < cnt; ++j) {
+			double acc = 0;
+			for (int i = 0; i < cnt; ++i) acc += km[(size_t)j * cnt + i] * v0[i];
+			v1[j] = acc;
+		}
+		double *sw = v0; v0 = v1; v1 = sw;
+	}
+	t->n_p22 = res;
+	t->p22 = (float *)malloc(sizeof(float) * res);
+	for (int i = 0; i < cnt; ++i) t->p22[i] = F(1e-2 * v0[i]);
+	t->p22[cnt] = 0.0f;
+	free(v0); free(v1); free(km);
+}
+
+static void tab_normalize_p22(o_brdf *t) /* hdr:2277-2304 */
+{
+	const int ntheta = 128;
+	const float dphi = F(2.0 * O_PI);
+	const float dtheta = F(O_PI / D((float)ntheta));
+	float nint = 0.0f;
+	for (int i = 0; i < ntheta; ++i) {
+		float u = (float)i / (float)ntheta;
+		float theta_h = F(D(u * u) * O_PI * 0.5);
+		float r_h = F(tan(D(theta_h))), cos_h = F(cos(D(theta_h)));
+		float p22_r = tab_p22_radial(t, r_h * r_h);
+		nint += (u * p22_r * r_h) / (cos_h * cos_h);
+	}
+	nint *= dtheta * dphi;
+	nint = F(1.0 / D(nint));
+	for (int i = 0; i < t->n_p22; ++i) t->p22[i] *= nint;
+}
+
+static void tab_compute_sigma(o_brdf *t) /* hdr:2348-2386 */
+{
+	const int ntheta = 90, nphi = 180;
+	float dtheta = F(O_PI / D((float)ntheta));
+	float dphi = F(2.0 * O_PI / D((float)nphi));
+	int cnt = t->n_p22 - 1;
+	o_params std_p = params_standard();
+	t->sigma = (float *)malloc(sizeof(float) * (cnt + 1));
+	t->n_sigma = 0;
+	/* ndf(vec3(theta_h, phi_h)) does not depend on theta_k: evaluate once (same values) */
+	float *ndf_tab = (float *)malloc(sizeof(float) * ntheta * nphi);
+	for (int j2 = 0; j2 < nphi; ++j2) {
+		float phi_h = F(D((float)j2 / (float)nphi) * 2.0 * O_PI);
+		for (int j1 = 0; j1 < ntheta; ++j1) {
+			float u_i = (float)j1 / (float)ntheta;
+			float theta_h = F(D(u_i * u_i) * O_PI * 0.5);
+			ndf_tab[j2 * ntheta + j1] = mf_ndf(t, v3_from_angles(theta_h, phi_h), &std_p);
+		}
+	}
+	for (int i = 0; i < cnt; ++i) {
+		float tmp = (float)i / (float)cnt;
+		float theta_k = F(D(tmp) * 0.5 * O_PI);
+		float cos_k = F(cos(D(theta_k))), sin_k = F(sin(D(theta_k)));
+		float nint = 0.0f;
+		for (int j2 = 0; j2 < nphi; ++j2) {
+			float u_j = (float)j2 / (float)nphi;
+			float phi_h = F(D(u_j) * 2.0 * O_PI);
+			for (int j1 = 0; j1 < ntheta; ++j1) {
+				float u_i = (float)j1 / (float)ntheta;
+				float theta_h = F(D(u_i * u_i) * O_PI * 0.5);
+				float sin_h = F(sin(D(theta_h)));
+				float kh = F(D(sin_k * sin_h) * cos(D(phi_h)) + D(cos_k) * cos(D(theta_h)));
+				nint += fmaxf_(0.0f, kh) * ndf_tab[j2 * ntheta + j1] * u_i * sin_h;
+			}
+		}
+		nint *= dtheta * dphi;
+		t->sigma[t->n_sigma++] = fmaxf_(cos_k, nint);
+	}
+	t->sigma[t->n_sigma] = t->sigma[t->n_sigma - 1];
+	t->n_sigma++;
+	free(ndf_tab);
+}
+
+static void tab_compute_fresnel(o_brdf *t, const o_brdf *src, int res) /* hdr:2583-2641 */
+{
+	o_vec3 *fres = (o_vec3 *)malloc(sizeof(o_vec3) * res);
+	int cnt = res - 1;
+	o_params std_p = params_standard();
+	for (int i = 0; i < cnt; ++i) {
+		const float phi_d = F(O_PI * 0.5), phi_h = 0.0f;
+		float tmp = (float)i / (float)cnt;
+		float theta_d = F(D(tmp) * O_PI * 0.5);
+		o_vec3 f = v3(0, 0, 0);
+		int count[3] = { 0, 0, 0 };
+		float theta_h = 0.0f;
+		for (int j = 0; D(theta_h) < O_PI * 0.5 - D(theta_d); ++j) {
+			float tmp1 = (float)j / (float)cnt;
+			theta_h = F(D(tmp1 * tmp1) * O_PI * 0.5);
+			if (D(theta_h) > O_PI * 0.5) continue;
+			o_vec3 dir_h = v3_from_angles(theta_h, phi_h), dir_d = v3_from_angles(theta_d, phi_d);
+			o_vec3 dir_i, dir_o;
+			hd_to_io(dir_h, dir_d, &dir_i, &dir_o);
+			dir_i = v3(0, 0, 1);
+			o_vec3 fr1 = brdf_eval(src, dir_i, dir_o, &std_p);
+			o_vec3 fr2 = mf_eval(t, dir_i, dir_o, &std_p);
+			if (D(fr2.x) > 1e-4) { f.x += fr1.x / fr2.x; ++count[0]; }
+			if (D(fr2.y) > 1e-4) { f.y += fr1.y / fr2.y; ++count[1]; }
+			if (D(fr2.z) > 1e-4) { f.z += fr1.z / fr2.z; ++count[2]; }
+		}
+		fres[i].x = count[0] == 0 ? 1.0f : fminf_(1.0f, f.x / (float)count[0]);
+		fres[i].y = count[1] == 0 ? 1.0f : fminf_(1.0f, f.y / (float)count[1]);
+		fres[i].z = count[2] == 0 ? 1.0f : fminf_(1.0f, f.z / (float)count[2]);
+	}
+	fres[res - 1] = fres[res - 2];
+	t->fresnel.kind = O_FRESNEL_SPLINE;
+	t->fresnel.pts = fres;
+	t->fresnel.npts = res;
+}
+
+static void tab_compute_cdf(o_brdf *t) /* hdr:2705-2727 */
+{
+	int cnt = t->n_p22 - 1;
+	float dtheta = F(O_PI / D((float)cnt));
+	float nint = 0.0f;
+	t->cdf = (float *)malloc(sizeof(float) * (cnt + 1));
+	t->n_cdf = 0;
+	for (int i = 0; i < cnt; ++i) {
+		float u = (float)i / (float)cnt;
+		float theta_h = F(D(u * u) * O_PI * 0.5);
+		float cos_h = F(cos(D(theta_h))), r_h = F(tan(D(theta_h)));
+		float p22_r = tab_p22_radial(t, r_h * r_h);
+		nint += (u * r_h * p22_r) / (cos_h * cos_h);
+		t->cdf[t->n_cdf++] = F(D(nint * dtheta) * (2.0 * O_PI));
+	}
+	t->cdf[t->n_cdf++] = 1.0f;
+}
+
+static void tab_compute_qf(o_brdf *t) /* hdr:2731-2762 */
+{
+	int cnt = t->n_p22 - 1, res = cnt * 8, j = 0;
+	t->qf = (float *)malloc(sizeof(float) * (cnt + 1));
+	t->n_qf = 0;
+	t->qf[t->n_qf++] = 0.0f;
+	for (int i = 1; i < cnt; ++i) {
+		float cdf = (float)i / (float)cnt;
+		for (; j < res; ++j) {
+			float u = (float)j / (float)res;
+			float theta_h = F(D(u) * O_PI * 0.5);
+			float qf = tab_cdf_radial(t, F(tan(D(theta_h))));
+			if (qf >= cdf) { t->qf[t->n_qf++] = u; break; }
+		}
+	}
+	t->qf[t->n_qf++] = 1.0f;
+}
+
+o_brdf *o_create_tabular(const o_brdf *src, int res, int shadow) /* hdr:2215-2236 */
+{
+	if (res <= 2) { set_err("Invalid Resolution"); return NULL; }
+	o_brdf *t = (o_brdf *)calloc(1, sizeof *t);
+	t->kind = O_BRDF_TABULAR;
+	t->shadow = shadow != 0;
+	t->fresnel.kind = O_FRESNEL_IDEAL;
+	tab_compute_p22_smith(t, src, res);
+	tab_normalize_p22(t);
+	tab_compute_sigma(t);
+	tab_compute_fresnel(t, src, res);
+	tab_compute_cdf(t);
+	tab_compute_qf(t);
+	return t;
+}
+
+void o_tabular_fit(const o_brdf *t, float *alpha_beckmann, float *alpha_ggx) /* hdr:3133-3184 */
+{
+	const int ntheta = 128;
+	float dtheta = F(O_PI / D((float)ntheta));
+	float nb = 0.0f, ng = 0.0f;
+	for (int i = 0; i < ntheta; ++i) {
+		float u = (float)i / (float)ntheta;
+		float theta_h = F(D(u * u) * O_PI * 0.5);
+		float cos_h = F(cos(D(theta_h))), r_h = F(tan(D(theta_h)));
+		float r2 = r_h * r_h;
+		float p22_r = tab_p22_radial(t, r2);
+		nb += (u * r2 * r_h * p22_r) / (cos_h * cos_h);
+		ng += (u * r2 * p22_r) / (cos_h * cos_h);
+	}
+	nb = F(D(nb) * (D(dtheta) * O_PI));
+	ng = F(D(ng) * (D(dtheta) * 4.0));
+	*alpha_beckmann = F(sqrt(2.0 * D(nb)));
+	*alpha_ggx = ng;
+}
+
+int o_tabular_get(const o_brdf *t, int which, float *out)
+{
+	const float *src; int n;
+	switch (which) {
+	case 0: src = t->p22; n = t->n_p22; break;
+	case 1: src = t->sigma; n = t->n_sigma; break;
+	case 2: src = t->cdf; n = t->n_cdf; break;
+	case 3: src = t->qf; n = t->n_qf; break;
+	default:
+		if (t->fresnel.kind != O_FRESNEL_SPLINE) return 0;
+		src = &t->fresnel.pts[0].x; n = t->fresnel.npts;
+		if (out) memcpy(out, src, sizeof(float) * 3 * n);
+		return n;
+	}
+	if (out) memcpy(out, src, sizeof(float) * n);
+	return n;
+}
+
+/* ------------------------------------------------------------------ construction */
+o_brdf *o_create_microfacet(int ndf, int fkind, const float *fd, int nf, int shadow)
+{
+	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
+	b->kind = ndf == 0 ? O_BRDF_BECKMANN : O_BRDF_GGX;
+	b->shadow = shadow != 0;
+	b->fresnel.kind = fkind;
+	if (fkind == O_FRESNEL_UNPOLARIZED || fkind == O_FRESNEL_SCHLICK || fkind == O_FRESNEL_SGD)
+		b->fresnel.a = v3(fd[0], fd[1], fd[2]);
+	if (fkind == O_FRESNEL_SGD) b->fresnel.b = v3(fd[3], fd[4], fd[5]);
+	if (fkind == O_FRESNEL_SPLINE) {
+		b->fresnel.npts = nf;
+		b->fresnel.pts = (o_vec3 *)malloc(sizeof(o_vec3) * nf);
+		memcpy(b->fresnel.pts, fd, sizeof(o_vec3) * nf);
+	}
+	return b;
+}
+
+o_brdf *o_create_merl_from_memory(const double *samples, int64_t n)
+{
+	if (n <= 0) { set_err("djb_error: Failed to read MERL header\n"); return NULL; }
+	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
+	b->kind = O_BRDF_MERL;
+	b->n_samples = 3 * n;
+	b->samples = (double *)malloc(sizeof(double) * 3 * n);
+	memcpy(b->samples, samples, sizeof(double) * 3 * n);
+	return b;
+}
+
+o_brdf *o_create_merl(const char *path) /* hdr:963-983 */
+{
+	FILE *f = fopen(path, "rb");
+	if (!f) { set_err("djb_error: Failed to open %s\n", path); return NULL; }
+	int32_t dims[3];
+	if (fread(dims, 4, 3, f) != 3) dims[0] = dims[1] = dims[2] = 0;
+	int32_t n = dims[0] * dims[1] * dims[2];
+	if (n <= 0) { fclose(f); set_err("djb_error: Failed to read MERL header\n"); return NULL; }
+	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
+	b->kind = O_BRDF_MERL;
+	b->n_samples = 3 * (int64_t)n;
+	b->samples = (double *)malloc(sizeof(double) * b->n_samples);
+	size_t got = fread(b->samples, sizeof(double), (size_t)b->n_samples, f);
+	fclose(f);
+	if ((int64_t)got != b->n_samples) {
+		o_destroy(b); set_err("djb_error: Reading %s failed\n", path); return NULL;
+	}
+	return b;
+}
+
+#define UTIA_CNT (3 * 288 * 288)
+static void utia_normalize(o_brdf *b) /* hdr:1162-1177 */
+{
+	float k = 1.f / 140.f;
+	for (int i = 0; i < UTIA_CNT; ++i) {
+		double s = b->samples[i] > 0.0 ? b->samples[i] : 0.0;
+		b->samples[i] = s * D(k);
+	}
+}
+o_brdf *o_create_utia_from_memory(const double *samples)
+{
+	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
+	b->kind = O_BRDF_UTIA;
+	b->n_samples = UTIA_CNT;
+	b->samples = (double *)malloc(sizeof(double) * UTIA_CNT);
+	memcpy(b->samples, samples, sizeof(double) * UTIA_CNT);
+	utia_normalize(b);
+	return b;
+}
+o_brdf *o_create_utia(const char *path) /* hdr:1039-1059 */
+{
+	FILE *f = fopen(path, "rb");
+	if (!f) { set_err("djb_error: Failed to open %s\n", path); return NULL; }
+	double *tmp = (double *)calloc(UTIA_CNT, sizeof(double));
+	size_t got = fread(tmp, sizeof(double), UTIA_CNT, f);
+	fclose(f);
+	if (got != UTIA_CNT) { free(tmp); set_err("djb_error: Reading %s failed\n", path); return NULL; }
+	o_brdf *b = o_create_utia_from_memory(tmp);
+	free(tmp);
+	return b;
+}
+
+o_brdf *o_create_lambert(void)
+{
+	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
+	b->kind = O_BRDF_LAMBERT;
+	return b;
+}
+
+void o_destroy(o_brdf *b)
+{
+	if (!b) return;
+	free(b->fresnel.pts); free(b->p22); free(b->sigma); free(b->cdf); free(b->qf);
+	free(b->samples); free(b);
+}
+
+/* ------------------------------------------------------------------ batch entry points */
+static o_vec3 ld3(const float *p, int64_t k) { return v3(p[3 * k], p[3 * k + 1], p[3 * k + 2]); }
+static void st3(float *p, int64_t k, o_vec3 v) { p[3 * k] = v.x; p[3 * k + 1] = v.y; p[3 * k + 2] = v.z; }
+
+void o_eval(const o_brdf *b, int op, int64_t n, const float *i, const float *o,
+            const o_param_desc *pd, float *out)
+{
+	o_params p = params_from_desc(pd);
+	for (int64_t k = 0; k < n; ++k) {
+		o_vec3 vi = ld3(i, k), vo = ld3(o, k);
+		if (op == 0) st3(out, k, brdf_eval(b, vi, vo, &p));
+		else if (op == 1) st3(out, k, brdf_evalp(b, vi, vo, &p));
+		else out[k] = brdf_pdf(b, vi, vo, &p);
+	}
+}
+
+typedef struct {
+	const o_brdf *b; int op; int64_t n; const float *i, *o; const o_param_desc *pd; float *out;
+} mt_job;
+static void *mt_worker(void *arg)
+{
+	mt_job *j = (mt_job *)arg;
+	o_eval(j->b, j->op, j->n, j->i, j->o, j->pd, j->out);
+	return NULL;
+}
+void o_eval_mt(const o_brdf *b, int op, int64_t n, const float *i, const float *o,
+               const o_param_desc *pd, float *out, int threads)
+{
+	if (threads < 1) threads = 1;
+	if (threads > 256) threads = 256;
+	pthread_t th[256]; mt_job jobs[256];
+	int64_t chunk = (n + threads - 1) / threads;
+	int ostride = op == 2 ? 1 : 3;
+	int used = 0;
+	for (int t = 0; t < threads; ++t) {
+		int64_t lo = t * chunk, hi = lo + chunk > n ? n : lo + chunk;
+		if (lo >= hi) break;
+		mt_job jb = { b, op, hi - lo, i + 3 * lo, o + 3 * lo, pd, out + ostride * lo };
+		jobs[t] = jb;
+		pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+		used++;
+	}
+	for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+}
+
+void o_sample(const o_brdf *b, int64_t n, const float *u1, const float *u2, const float *o,
+              const o_param_desc *pd, float *out_i)
+{
+	o_params p = params_from_desc(pd);
+	for (int64_t k = 0; k < n; ++k) st3(out_i, k, brdf_sample(b, u1[k], u2[k], ld3(o, k), &p));
+}
+
+void o_evalp_is(const o_brdf *b, int64_t n, const float *u1, const float *u2, const float *o,
+                const o_param_desc *pd, float *out_w, float *out_i, float *out_pdf)
+{
+	o_params p = params_from_desc(pd);
+	for (int64_t k = 0; k < n; ++k) {
+		o_vec3 vi = v3(0, 0, 0), vo = ld3(o, k), w; float pdf = 0;
+		if (is_microfacet(b)) w = mf_evalp_is(b, u1[k], u2[k], vo, &p, &vi, &pdf);
+		else { /* brdf::evalp_is, hdr:816-828 */
+			vi = brdf_sample(b, u1[k], u2[k], vo, &p);
+			pdf = brdf_pdf(b, vi, vo, &p);
+			w = v3_div(brdf_evalp(b, vi, vo, &p), pdf);
+		}
+		st3(out_w, k, w); st3(out_i, k, vi); out_pdf[k] = pdf;
+	}
+}
+
+void o_io_to_hd(int64_t n, const float *i, const float *o, float *h, float *d)
+{
+	for (int64_t k = 0; k < n; ++k) { o_vec3 vh, vd; io_to_hd(ld3(i, k), ld3(o, k), &vh, &vd); st3(h, k, vh); st3(d, k, vd); }
+}
+void o_hd_to_io(int64_t n, const float *h, const float *d, float *i, float *o)
+{
+	for (int64_t k = 0; k < n; ++k) { o_vec3 vi, vo; hd_to_io(ld3(h, k), ld3(d, k), &vi, &vo); st3(i, k, vi); st3(o, k, vo); }
+}
+void o_merl_index(int64_t n, const float *i, const float *o, int *idx)
+{
+	for (int64_t k = 0; k < n; ++k) idx[k] = merl_index(ld3(i, k), ld3(o, k));
+}
+
+void o_params_get(const o_param_desc *pd, float *out)
+{
+	o_params p = params_from_desc(pd);
+	out[0] = p.n.x; out[1] = p.n.y; out[2] = p.n.z;
+	out[3] = p.a1; out[4] = p.a2; out[5] = p.phi_a;
+	out[6] = p.ax; out[7] = p.ay; out[8] = p.rho; out[9] = p.tx; out[10] = p.ty; out[11] = 0;
+}
+
+void o_microfacet_query(const o_brdf *b, int which, int64_t n, const float *a, const float *bb,
+                        const float *c, const o_param_desc *pd, float *out)
+{
+	o_params p = params_from_desc(pd);
+	for (int64_t k = 0; k < n; ++k) {
+		switch (which) {
+		case 0: out[k] = mf_ndf(b, ld3(a, k), &p); break;
+		case 1: out[k] = mf_gaf(b, ld3(bb, k), ld3(c, k), &p); break;
+		case 2: out[k] = mf_g1(b, ld3(bb, k), &p); break;
+		case 3: out[k] = mf_sigma(b, ld3(a, k), &p); break;
+		case 4: out[k] = mf_p22(b, a[3 * k], a[3 * k + 1], &p); break;
+		case 5: out[k] = mf_vp22(b, a[3 * k], a[3 * k + 1], ld3(bb, k), &p); break;
+		case 6: out[k] = mf_vndf(b, ld3(a, k), ld3(bb, k), &p); break;
+		}
+	}
+}
+
+void o_radial_query(const o_brdf *b, int which, int64_t n, const float *a, const float *bb,
+                    const float *c, float *out)
+{
+	for (int64_t k = 0; k < n; ++k) {
+		switch (which) {
+		case 0: out[k] = p22_radial(b, a[k]); break;
+		case 1: out[k] = sigma_std_radial(b, a[k]); break;
+		case 2: out[k] = cdf_radial(b, a[k]); break;
+		case 3: out[k] = qf_radial(b, a[k]); break;
+		case 4: out[k] = b->kind == O_BRDF_BECKMANN ? beckmann_qf2_radial(a[k], bb[k], c[k])
+		                                            : ggx_qf2_radial(a[k], bb[k], c[k]); break;
+		case 5: out[k] = b->kind == O_BRDF_BECKMANN ? beckmann_qf1(a[k])
+		                                            : ggx_qf3_radial(a[k], bb[k]); break;
+		case 6: out[k] = b->kind == O_BRDF_BECKMANN ? beckmann_qf1(a[k]) : ggx_qf1(a[k]); break;
+		}
+	}
+}
+
+void o_fresnel_eval(const o_brdf *b, int64_t n, const float *c, float *out)
+{
+	for (int64_t k = 0; k < n; ++k) st3(out, k, fresnel_eval(&b->fresnel, c[k]));
+}
+void o_erf(int64_t n, const float *x, float *y) { for (int64_t k = 0; k < n; ++k) y[k] = erf_(x[k]); }
+void o_erfinv(int64_t n, const float *x, float *y) { for (int64_t k = 0; k < n; ++k) y[k] = erfinv_(x[k]); }

@@ -1,0 +1,99 @@
+/* oracle/djb_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C99) of the dj_brdf hot path: microfacet eval / pdf /
+ * VNDF sample (Beckmann, GGX, tabular), MERL and UTIA table lookup, and the
+ * power-iteration fitter (djb::tabular ctor + fit_{beckmann,ggx}_parameters).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported CPU baseline.  The
+ * shipped product (dj_brdf_amd + libdjb_hip.so) never links, imports or calls
+ * anything in oracle/.
+ *
+ * Parity status: PINNED.  Every function here is checked (bit-for-bit unless
+ * stated) against the real reference compiled in place from
+ * /root/reference/dj_brdf.h (oracle/ref_shim.cpp -> oracle/_ref/libdjb_ref.so)
+ * by tests/test_oracle_vs_ref.py in the build container, and against the golden
+ * vectors committed under tests/golden/ (generated from the real reference by
+ * tests/golden/make_golden.py) everywhere else.
+ *
+ * Arithmetic contract: storage is float; every expression that
+ * the reference evaluates in double (M_PI, 1.0-style literals, unqualified
+ * libm calls) is evaluated in double here and rounded once where the reference
+ * rounds.  Build with: gcc -O2 -ffp-contract=off (no -ffast-math, no -march=native).
+ */
+#ifndef DJB_ORACLE_H
+#define DJB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } o_vec3;
+
+/* microfacet::params (hdr:213-243) */
+typedef struct {
+	o_vec3 n;                 /* mean normal */
+	float a1, a2, phi_a;      /* ellipse */
+	float ax, ay;             /* scales */
+	float rho, sqrt_1mrho2;   /* correlation */
+	float tx, ty;             /* location */
+} o_params;
+
+/* same wire format as ref_shim.cpp's shim_params */
+typedef struct {
+	int   kind;               /* 0 NULL/standard, 1 elliptic(a1,a2,phi), 2 pdfparams(ax,ay,rho,tx,ty) */
+	float v[5];
+} o_param_desc;
+
+enum { O_FRESNEL_IDEAL = 0, O_FRESNEL_UNPOLARIZED = 1, O_FRESNEL_SCHLICK = 2,
+       O_FRESNEL_SGD = 3, O_FRESNEL_SPLINE = 4 };
+
+enum { O_BRDF_BECKMANN = 0, O_BRDF_GGX = 1, O_BRDF_TABULAR = 2, O_BRDF_MERL = 3,
+       O_BRDF_UTIA = 4, O_BRDF_LAMBERT = 5 };
+
+typedef struct o_brdf o_brdf;
+
+/* construction */
+o_brdf *o_create_microfacet(int ndf, int fkind, const float *fdata, int nf, int shadow);
+o_brdf *o_create_merl_from_memory(const double *samples, int64_t n_per_channel); /* copies */
+o_brdf *o_create_merl(const char *path);
+o_brdf *o_create_utia_from_memory(const double *samples); /* 3*288*288 raw file doubles; copies+normalizes */
+o_brdf *o_create_utia(const char *path);
+o_brdf *o_create_lambert(void);
+o_brdf *o_create_tabular(const o_brdf *src, int res, int shadow);
+void    o_destroy(o_brdf *b);
+const char *o_last_error(void);
+
+/* operator surface; vectors are AoS float[n][3] */
+void o_eval(const o_brdf *b, int op, int64_t n, const float *i, const float *o,
+            const o_param_desc *pd, float *out);   /* op 0 eval,1 evalp (n x 3); 2 pdf (n) */
+void o_sample(const o_brdf *b, int64_t n, const float *u1, const float *u2, const float *o,
+              const o_param_desc *pd, float *out_i);
+void o_evalp_is(const o_brdf *b, int64_t n, const float *u1, const float *u2, const float *o,
+                const o_param_desc *pd, float *out_w, float *out_i, float *out_pdf);
+void o_io_to_hd(int64_t n, const float *i, const float *o, float *h, float *d);
+void o_hd_to_io(int64_t n, const float *h, const float *d, float *i, float *o);
+void o_merl_index(int64_t n, const float *i, const float *o, int *idx);
+
+void o_params_get(const o_param_desc *pd, float *out12);
+void o_microfacet_query(const o_brdf *b, int which, int64_t n, const float *a, const float *bb,
+                        const float *c, const o_param_desc *pd, float *out);
+void o_radial_query(const o_brdf *b, int which, int64_t n, const float *a, const float *bb,
+                    const float *c, float *out);
+void o_fresnel_eval(const o_brdf *b, int64_t n, const float *c, float *out);
+void o_erf(int64_t n, const float *x, float *y);
+void o_erfinv(int64_t n, const float *x, float *y);
+
+int  o_tabular_get(const o_brdf *t, int which, float *out);
+void o_tabular_fit(const o_brdf *t, float *alpha_beckmann, float *alpha_ggx);
+
+/* multi-threaded batch drivers used by bench.py's cpu_baseline leg (pthread static chunks) */
+void o_eval_mt(const o_brdf *b, int op, int64_t n, const float *i, const float *o,
+               const o_param_desc *pd, float *out, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,258 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// A thin extern "C" shim around the *real* reference implementation
+// (/root/reference/dj_brdf.h, compiled where it lies; never copied into this
+// repository).  It exists only to (1) pin oracle/djb_oracle.c against the
+// reference and (2) generate the golden vectors committed under tests/golden/.
+// It is built by oracle/Makefile into oracle/_ref/libdjb_ref.so (git-ignored)
+// and only when /root/reference is present (i.e. in the build container).
+//
+// Include order matters: <cmath> only, never <math.h>,
+// so that the unqualified acos/atan2/cos/sin/sqrt/exp inside namespace djb
+// resolve to the double C functions, exactly as in examples/merl_params.cpp:10-16.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+
+#define DJ_BRDF_IMPLEMENTATION 1
+#include "dj_brdf.h"
+
+#include <new>
+
+namespace {
+
+struct shim_params {
+	int   kind;   // 0: user_param == NULL, 1: elliptic(a1,a2,phi_a), 2: pdfparams(ax,ay,rho,tx,ty)
+	float v[5];
+};
+
+struct param_holder {
+	djb::microfacet::params p;
+	const void *ptr;
+	explicit param_holder(const shim_params *sp) : p(), ptr(NULL)
+	{
+		if (sp && sp->kind == 1) {
+			p = djb::microfacet::params::elliptic(sp->v[0], sp->v[1], sp->v[2]);
+			ptr = &p;
+		} else if (sp && sp->kind == 2) {
+			p = djb::microfacet::params::pdfparams(sp->v[0], sp->v[1], sp->v[2],
+			                                       sp->v[3], sp->v[4]);
+			ptr = &p;
+		}
+	}
+};
+
+djb::vec3 ld(const float *p, long k) { return djb::vec3(p[3*k], p[3*k+1], p[3*k+2]); }
+void st(float *p, long k, const djb::vec3 &v) { p[3*k] = v.x; p[3*k+1] = v.y; p[3*k+2] = v.z; }
+
+djb::fresnel::impl *make_fresnel(int kind, const float *d, int n)
+{
+	switch (kind) {
+	case 1: return new djb::fresnel::unpolarized(djb::vec3(d[0], d[1], d[2]));
+	case 2: return new djb::fresnel::schlick(djb::vec3(d[0], d[1], d[2]));
+	case 3: return new djb::fresnel::sgd(djb::vec3(d[0], d[1], d[2]),
+	                                     djb::vec3(d[3], d[4], d[5]));
+	case 4: {
+		std::vector<djb::vec3> pts;
+		for (int i = 0; i < n; ++i) pts.push_back(djb::vec3(d[3*i], d[3*i+1], d[3*i+2]));
+		return new djb::fresnel::spline(pts);
+	}
+	default: return new djb::fresnel::ideal();
+	}
+}
+
+char g_err[512];
+
+} // namespace
+
+extern "C" {
+
+const char *ref_last_error() { return g_err; }
+
+// ---- construction ---------------------------------------------------------
+void *ref_create_microfacet(int ndf, int fkind, const float *fdata, int nf, int shadow)
+{
+	djb::fresnel::impl *f = make_fresnel(fkind, fdata, nf);
+	djb::brdf *b = ndf == 0 ? (djb::brdf *)new djb::beckmann(*f, shadow != 0)
+	                        : (djb::brdf *)new djb::ggx(*f, shadow != 0);
+	delete f;
+	return b;
+}
+
+#define SHIM_TRY(expr) \
+	try { return (expr); } catch (const std::exception &e) { \
+		snprintf(g_err, sizeof g_err, "%s", e.what()); return NULL; }
+
+void *ref_create_merl(const char *path) { SHIM_TRY(new djb::merl(path)) }
+void *ref_create_utia(const char *path) { SHIM_TRY(new djb::utia(path)) }
+void *ref_create_sgd(const char *name)  { SHIM_TRY(new djb::sgd(name)) }
+void *ref_create_abc(const char *name)  { SHIM_TRY(new djb::abc(name)) }
+void *ref_create_lambert()              { return new djb::lambert(); }
+void *ref_create_tabular(void *src, int res, int shadow)
+{
+	SHIM_TRY(new djb::tabular(*(const djb::brdf *)src, res, shadow != 0))
+}
+void ref_destroy(void *b) { delete (djb::brdf *)b; }
+
+// ---- operator surface (hdr:74-109) -----------------------------------------
+// op: 0 eval, 1 evalp (out n x 3); 2 pdf (out n)
+void ref_eval(void *b_, int op, long n, const float *i, const float *o,
+              const shim_params *sp, float *out)
+{
+	const djb::brdf *b = (const djb::brdf *)b_;
+	param_holder ph(sp);
+	for (long k = 0; k < n; ++k) {
+		djb::vec3 vi = ld(i, k), vo = ld(o, k);
+		if (op == 0)      st(out, k, b->eval(vi, vo, ph.ptr));
+		else if (op == 1) st(out, k, b->evalp(vi, vo, ph.ptr));
+		else              out[k] = b->pdf(vi, vo, ph.ptr);
+	}
+}
+
+void ref_sample(void *b_, long n, const float *u1, const float *u2, const float *o,
+                const shim_params *sp, float *out_i)
+{
+	const djb::brdf *b = (const djb::brdf *)b_;
+	param_holder ph(sp);
+	for (long k = 0; k < n; ++k)
+		st(out_i, k, b->sample(u1[k], u2[k], ld(o, k), ph.ptr));
+}
+
+void ref_evalp_is(void *b_, long n, const float *u1, const float *u2, const float *o,
+                  const shim_params *sp, float *out_w, float *out_i, float *out_pdf)
+{
+	const djb::brdf *b = (const djb::brdf *)b_;
+	param_holder ph(sp);
+	for (long k = 0; k < n; ++k) {
+		djb::vec3 vi(0); float pdf = 0;
+		djb::vec3 w = b->evalp_is(u1[k], u2[k], ld(o, k), &vi, &pdf, ph.ptr);
+		st(out_w, k, w); st(out_i, k, vi); out_pdf[k] = pdf;
+	}
+}
+
+void ref_io_to_hd(long n, const float *i, const float *o, float *h, float *d)
+{
+	for (long k = 0; k < n; ++k) {
+		djb::vec3 vh, vd;
+		djb::brdf::io_to_hd(ld(i, k), ld(o, k), &vh, &vd);
+		st(h, k, vh); st(d, k, vd);
+	}
+}
+
+void ref_hd_to_io(long n, const float *h, const float *d, float *i, float *o)
+{
+	for (long k = 0; k < n; ++k) {
+		djb::vec3 vi, vo;
+		djb::brdf::hd_to_io(ld(h, k), ld(d, k), &vi, &vo);
+		st(i, k, vi); st(o, k, vo);
+	}
+}
+
+// MERL bin index exactly as merl::eval composes it (hdr:987-1008); -1 never happens.
+void ref_merl_index(long n, const float *i, const float *o, int *idx)
+{
+	for (long k = 0; k < n; ++k) {
+		djb::vec3 h, d;
+		djb::float_t th, ph, td, pd;
+		djb::brdf::io_to_hd(ld(i, k), ld(o, k), &h, &d);
+		djb::xyz_to_theta_phi(h, &th, &ph);
+		djb::xyz_to_theta_phi(d, &td, &pd);
+		idx[k] = djb::phi_diff_index(pd) + djb::theta_diff_index(td) * 180
+		       + djb::theta_half_index(th) * 16200;
+	}
+}
+
+// ---- microfacet::params (hdr:213-243) --------------------------------------
+// out[12] = n.xyz, a1, a2, phi_a, ax, ay, rho, tx, ty, (unused)
+void ref_params_get(const shim_params *sp, float *out)
+{
+	param_holder ph(sp);
+	djb::microfacet::params p = ph.ptr ? ph.p : djb::microfacet::params::standard();
+	djb::vec3 n;
+	p.get_location(&n);
+	out[0] = n.x; out[1] = n.y; out[2] = n.z;
+	p.get_ellipse(&out[3], &out[4], &out[5]);
+	p.get_pdfparams(&out[6], &out[7], &out[8], &out[9], &out[10]);
+	out[11] = 0;
+}
+
+// ---- microfacet queries (hdr:258-276) --------------------------------------
+// which: 0 ndf(h) 1 gaf(h,i,o) 2 g1(h,k) 3 sigma(k) 4 p22(x,y) 5 vp22(x,y,k) 6 vndf(h,k)
+// a,b,c are n x 3 arrays (p22/vp22 use a[k][0], a[k][1] as x,y and b as k)
+void ref_microfacet_query(void *b_, int which, long n, const float *a, const float *b,
+                          const float *c, const shim_params *sp, float *out)
+{
+	const djb::microfacet *m = dynamic_cast<const djb::microfacet *>((const djb::brdf *)b_);
+	param_holder ph(sp);
+	djb::microfacet::params p = ph.ptr ? ph.p : djb::microfacet::params::standard();
+	for (long k = 0; k < n; ++k) {
+		switch (which) {
+		case 0: out[k] = m->ndf(ld(a, k), p); break;
+		case 1: out[k] = m->gaf(ld(a, k), ld(b, k), ld(c, k), p); break;
+		case 2: out[k] = m->g1(ld(a, k), ld(b, k), p); break;
+		case 3: out[k] = m->sigma(ld(a, k), p); break;
+		case 4: out[k] = m->p22(a[3*k], a[3*k+1], p); break;
+		case 5: out[k] = m->vp22(a[3*k], a[3*k+1], ld(b, k), p); break;
+		case 6: out[k] = m->vndf(ld(a, k), ld(b, k), p); break;
+		}
+	}
+}
+
+// which: 0 p22_radial(r_sqr) 1 sigma_std_radial(cos) 2 cdf_radial(r) 3 qf_radial(u)
+//        4 qf2_radial(u,cos,sin) 5 qf3_radial(u,qf2)
+void ref_radial_query(void *b_, int which, long n, const float *a, const float *b,
+                      const float *c, float *out)
+{
+	const djb::radial *m = dynamic_cast<const djb::radial *>((const djb::brdf *)b_);
+	for (long k = 0; k < n; ++k) {
+		switch (which) {
+		case 0: out[k] = m->p22_radial(a[k]); break;
+		case 1: out[k] = m->sigma_std_radial(a[k]); break;
+		case 2: out[k] = m->cdf_radial(a[k]); break;
+		case 3: out[k] = m->qf_radial(a[k]); break;
+		case 4: out[k] = m->qf2_radial(a[k], b[k], c[k]); break;
+		case 5: out[k] = m->qf3_radial(a[k], b[k]); break;
+		}
+	}
+}
+
+// fresnel evaluated through microfacet::fresnel() (hdr:258)
+void ref_fresnel_eval(void *b_, long n, const float *c, float *out)
+{
+	const djb::microfacet *m = dynamic_cast<const djb::microfacet *>((const djb::brdf *)b_);
+	for (long k = 0; k < n; ++k) st(out, k, m->fresnel(c[k]));
+}
+
+void ref_erf(long n, const float *x, float *y)    { for (long k = 0; k < n; ++k) y[k] = djb::erf(x[k]); }
+void ref_erfinv(long n, const float *x, float *y) { for (long k = 0; k < n; ++k) y[k] = djb::erfinv(x[k]); }
+
+// ---- tabular (hdr:394-425) ---------------------------------------------------
+// which: 0 p22v 1 sigmav 2 cdfv 3 qfv 4 fresnel points (3 floats each). Returns count.
+int ref_tabular_get(void *t_, int which, float *out)
+{
+	const djb::tabular *t = dynamic_cast<const djb::tabular *>((const djb::brdf *)t_);
+	if (which == 4) {
+		const djb::fresnel::spline *s =
+			dynamic_cast<const djb::fresnel::spline *>(&t->get_fresnel());
+		if (!s) return 0;
+		const std::vector<djb::vec3> &pts = s->get_points();
+		if (out) for (size_t i = 0; i < pts.size(); ++i) st(out, (long)i, pts[i]);
+		return (int)pts.size();
+	}
+	const std::vector<djb::float_t> &v = which == 0 ? t->get_p22v()
+	                                   : which == 1 ? t->get_sigmav()
+	                                   : which == 2 ? t->get_cdfv() : t->get_qfv();
+	if (out) for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+	return (int)v.size();
+}
+
+void ref_tabular_fit(void *t_, float *alpha_beckmann, float *alpha_ggx)
+{
+	const djb::tabular *t = dynamic_cast<const djb::tabular *>((const djb::brdf *)t_);
+	float dummy;
+	djb::tabular::fit_beckmann_parameters(*t).get_ellipse(alpha_beckmann, &dummy, NULL);
+	djb::tabular::fit_ggx_parameters(*t).get_ellipse(alpha_ggx, &dummy, NULL);
+}
+
+} // extern "C"

@@ -1,0 +1,255 @@
+"""ctypes access to the CHECKERS (test infrastructure only):
+
+* ``oracle()``   -> oracle/libdjb_oracle.so, the plain-C restatement (always available)
+* ``reference()``-> oracle/_ref/libdjb_ref.so, the REAL reference compiled in place from
+                    /root/reference (build container only; None elsewhere)
+
+Both expose the same entry points (prefix ``o_`` / ``ref_``), so one wrapper serves both.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from functools import lru_cache
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+FRESNEL = {"ideal": 0, "unpolarized": 1, "schlick": 2, "sgd": 3, "spline": 4}
+
+
+class ParamDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("v", C.c_float * 5)]
+
+
+def param_desc(p):
+    """p: None | ('elliptic', a1, a2, phi) | ('pdfparams', ax, ay, rho, tx, ty)."""
+    d = ParamDesc()
+    if p is None:
+        d.kind = 0
+    elif p[0] == "elliptic":
+        d.kind = 1
+        for k, v in enumerate(p[1:]):
+            d.v[k] = v
+    else:
+        d.kind = 2
+        for k, v in enumerate(p[1:]):
+            d.v[k] = v
+    return d
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CheckerLib:
+    def __init__(self, path: str, prefix: str):
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        self.path = path
+        for name in ("create_microfacet", "create_merl", "create_utia", "create_lambert",
+                     "create_tabular"):
+            self._fn(name).restype = C.c_void_p
+        if prefix == "o_":
+            self._fn("create_merl_from_memory").restype = C.c_void_p
+            self._fn("create_utia_from_memory").restype = C.c_void_p
+        self._fn("last_error").restype = C.c_char_p
+        self._fn("tabular_get").restype = C.c_int
+
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    # ---- construction
+    def microfacet(self, ndf: str, fresnel=("ideal",), shadow=True):
+        kind = FRESNEL[fresnel[0]]
+        data = _f32(np.array(fresnel[1:], dtype=np.float32).reshape(-1)) if len(fresnel) > 1 else _f32([0])
+        nf = data.size // 3
+        h = self._fn("create_microfacet")(C.c_int(0 if ndf == "beckmann" else 1), C.c_int(kind),
+                                          _ptr(data), C.c_int(nf), C.c_int(int(shadow)))
+        return C.c_void_p(h)
+
+    def merl(self, path: str):
+        h = self._fn("create_merl")(path.encode())
+        if not h:
+            raise RuntimeError(self._fn("last_error")().decode())
+        return C.c_void_p(h)
+
+    def merl_from_table(self, table: np.ndarray):
+        assert self.prefix == "o_"
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        h = self._fn("create_merl_from_memory")(_ptr(t), C.c_int64(t.size // 3))
+        return C.c_void_p(h)
+
+    def utia(self, path: str):
+        h = self._fn("create_utia")(path.encode())
+        if not h:
+            raise RuntimeError(self._fn("last_error")().decode())
+        return C.c_void_p(h)
+
+    def lambert(self):
+        return C.c_void_p(self._fn("create_lambert")())
+
+    def tabular(self, src, res: int, shadow=True):
+        h = self._fn("create_tabular")(src, C.c_int(res), C.c_int(int(shadow)))
+        if not h:
+            raise RuntimeError(self._fn("last_error")().decode())
+        return C.c_void_p(h)
+
+    def destroy(self, h):
+        self._fn("destroy")(h)
+
+    # ---- operators (AoS float32 [n,3])
+    def eval(self, b, i, o, params=None, op="eval"):
+        i, o = _f32(i), _f32(o)
+        n = i.shape[0]
+        opc = {"eval": 0, "evalp": 1, "pdf": 2}[op]
+        out = np.empty((n,) if opc == 2 else (n, 3), dtype=np.float32)
+        pd = param_desc(params)
+        self._fn("eval")(b, C.c_int(opc), C.c_int64(n), _ptr(i), _ptr(o), C.byref(pd), _ptr(out))
+        return out
+
+    def eval_mt(self, b, i, o, params=None, op="eval", threads=1):
+        assert self.prefix == "o_"
+        i, o = _f32(i), _f32(o)
+        n = i.shape[0]
+        opc = {"eval": 0, "evalp": 1, "pdf": 2}[op]
+        out = np.empty((n,) if opc == 2 else (n, 3), dtype=np.float32)
+        pd = param_desc(params)
+        self._fn("eval_mt")(b, C.c_int(opc), C.c_int64(n), _ptr(i), _ptr(o), C.byref(pd),
+                            _ptr(out), C.c_int(threads))
+        return out
+
+    def sample(self, b, u1, u2, o, params=None):
+        u1, u2, o = _f32(u1), _f32(u2), _f32(o)
+        n = o.shape[0]
+        out = np.empty((n, 3), dtype=np.float32)
+        pd = param_desc(params)
+        self._fn("sample")(b, C.c_int64(n), _ptr(u1), _ptr(u2), _ptr(o), C.byref(pd), _ptr(out))
+        return out
+
+    def evalp_is(self, b, u1, u2, o, params=None):
+        u1, u2, o = _f32(u1), _f32(u2), _f32(o)
+        n = o.shape[0]
+        w = np.empty((n, 3), dtype=np.float32)
+        i = np.empty((n, 3), dtype=np.float32)
+        pdf = np.empty((n,), dtype=np.float32)
+        pd = param_desc(params)
+        self._fn("evalp_is")(b, C.c_int64(n), _ptr(u1), _ptr(u2), _ptr(o), C.byref(pd),
+                             _ptr(w), _ptr(i), _ptr(pdf))
+        return w, i, pdf
+
+    def io_to_hd(self, i, o):
+        i, o = _f32(i), _f32(o)
+        h, d = np.empty_like(i), np.empty_like(i)
+        self._fn("io_to_hd")(C.c_int64(i.shape[0]), _ptr(i), _ptr(o), _ptr(h), _ptr(d))
+        return h, d
+
+    def hd_to_io(self, h, d):
+        h, d = _f32(h), _f32(d)
+        i, o = np.empty_like(h), np.empty_like(h)
+        self._fn("hd_to_io")(C.c_int64(h.shape[0]), _ptr(h), _ptr(d), _ptr(i), _ptr(o))
+        return i, o
+
+    def merl_index(self, i, o):
+        i, o = _f32(i), _f32(o)
+        idx = np.empty((i.shape[0],), dtype=np.int32)
+        self._fn("merl_index")(C.c_int64(i.shape[0]), _ptr(i), _ptr(o), _ptr(idx))
+        return idx
+
+    def params_get(self, params):
+        out = np.zeros(12, dtype=np.float32)
+        pd = param_desc(params)
+        self._fn("params_get")(C.byref(pd), _ptr(out))
+        return out
+
+    def microfacet_query(self, b, which, a, bb=None, c=None, params=None):
+        code = {"ndf": 0, "gaf": 1, "g1": 2, "sigma": 3, "p22": 4, "vp22": 5, "vndf": 6}[which]
+        a = _f32(a)
+        bb = _f32(bb) if bb is not None else a
+        c = _f32(c) if c is not None else a
+        out = np.empty((a.shape[0],), dtype=np.float32)
+        pd = param_desc(params)
+        self._fn("microfacet_query")(b, C.c_int(code), C.c_int64(a.shape[0]), _ptr(a), _ptr(bb),
+                                     _ptr(c), C.byref(pd), _ptr(out))
+        return out
+
+    def radial_query(self, b, which, a, bb=None, c=None):
+        code = {"p22_radial": 0, "sigma_std_radial": 1, "cdf_radial": 2, "qf_radial": 3,
+                "qf2_radial": 4, "qf3_radial": 5}[which]
+        a = _f32(a)
+        bb = _f32(bb) if bb is not None else a
+        c = _f32(c) if c is not None else a
+        out = np.empty((a.shape[0],), dtype=np.float32)
+        self._fn("radial_query")(b, C.c_int(code), C.c_int64(a.shape[0]), _ptr(a), _ptr(bb),
+                                 _ptr(c), _ptr(out))
+        return out
+
+    def fresnel_eval(self, b, c):
+        c = _f32(c)
+        out = np.empty((c.shape[0], 3), dtype=np.float32)
+        self._fn("fresnel_eval")(b, C.c_int64(c.shape[0]), _ptr(c), _ptr(out))
+        return out
+
+    def erf(self, x):
+        x = _f32(x); y = np.empty_like(x)
+        self._fn("erf")(C.c_int64(x.size), _ptr(x), _ptr(y))
+        return y
+
+    def erfinv(self, x):
+        x = _f32(x); y = np.empty_like(x)
+        self._fn("erfinv")(C.c_int64(x.size), _ptr(x), _ptr(y))
+        return y
+
+    def tabular_tables(self, t):
+        out = {}
+        for code, name in enumerate(["p22", "sigma", "cdf", "qf"]):
+            n = self._fn("tabular_get")(t, C.c_int(code), None)
+            a = np.empty((n,), dtype=np.float32)
+            self._fn("tabular_get")(t, C.c_int(code), _ptr(a))
+            out[name] = a
+        n = self._fn("tabular_get")(t, C.c_int(4), None)
+        a = np.empty((n, 3), dtype=np.float32)
+        if n:
+            self._fn("tabular_get")(t, C.c_int(4), _ptr(a))
+        out["fresnel"] = a
+        ab, ag = C.c_float(), C.c_float()
+        self._fn("tabular_fit")(t, C.byref(ab), C.byref(ag))
+        out["alpha_beckmann"] = np.float32(ab.value)
+        out["alpha_ggx"] = np.float32(ag.value)
+        return out
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True)
+
+
+@lru_cache(maxsize=None)
+def oracle() -> CheckerLib:
+    path = os.path.join(ORACLE_DIR, "libdjb_oracle.so")
+    src = os.path.join(ORACLE_DIR, "djb_oracle.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        build_oracle()
+    return CheckerLib(path, "o_")
+
+
+@lru_cache(maxsize=None)
+def reference():
+    """The real reference, or None when /root/reference (hence oracle/_ref) is unavailable."""
+    path = os.path.join(ORACLE_DIR, "_ref", "libdjb_ref.so")
+    if os.path.exists("/root/reference/dj_brdf.h"):
+        build_oracle()
+    if not os.path.exists(path):
+        return None
+    return CheckerLib(path, "ref_")
+
+
+def ref_merl_params_binary():
+    p = os.path.join(ORACLE_DIR, "_ref", "merl_params")
+    return p if os.path.exists(p) else None

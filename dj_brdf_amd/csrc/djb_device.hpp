@@ -1,0 +1,638 @@
+// djb_device.hpp -- gfx950 device-side math for the dj_brdf hot path.
+//
+// Numerical contract: values are stored as float; wherever the reference
+// (jdupuy/dj_brdf, dj_brdf.h) evaluates a sub-expression in double (M_PI, 1.0-style literals,
+// unqualified libm calls under <cmath>) this code does the same and rounds once, at the same
+// place.  Shortcuts are taken only where IEEE-754 guarantees the identical float:
+//   * float(sqrt(double(x)))      == sqrtf(x)   (correctly rounded; double rounding is innocuous
+//   * float(double(a)/double(b))  == a / b       for sqrt and for one division: 53 >= 2*24+2)
+// This header MUST be compiled with -ffp-contract=off: an FMA-contracted a*b+c*d chain moves
+// MERL bin indices ("hard parts").
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DJB_DEV __device__ __forceinline__
+#define DJB_PI 3.14159265358979323846
+
+namespace djbdev {
+
+struct v3 { float x, y, z; };
+
+// resolved microfacet::params (dj_brdf.h:237-242), filled by the host (djb_host.cpp)
+struct Params { float nx, ny, nz, ax, ay, rho, s, tx, ty; };
+
+struct Fresnel {
+	int kind;
+	float a[3], b[3];
+	const float *pts;   // spline points, 3 floats each (device)
+	int npts;
+};
+
+// device view of a djb_brdf
+struct Brdf {
+	int kind;
+	int shadow;
+	Fresnel fr;
+	const float *p22, *sigma, *cdf, *qf;   // tabular tables (device)
+	int n_p22, n_sigma, n_cdf, n_qf;
+	const float4 *merl;                     // [1458000] pre-scaled float RGB(+pad); below-horizon -> 0
+	const float *utia;                      // [3*288*288] float(normalized double sample)
+};
+
+struct View { float *x, *y, *z; long long stride; };
+
+enum { KIND_BECKMANN = 0, KIND_GGX = 1, KIND_TABULAR = 2, KIND_MERL = 3, KIND_UTIA = 4, KIND_LAMBERT = 5 };
+enum { FR_IDEAL = 0, FR_UNPOLARIZED = 1, FR_SCHLICK = 2, FR_SGD = 3, FR_SPLINE = 4 };
+
+// ------------------------------------------------------------------ L0 helpers (dj_brdf.h:574-765)
+DJB_DEV float F(double x) { return (float)x; }
+DJB_DEV double D(float x) { return (double)x; }
+DJB_DEV float fmin_(float a, float b) { return a < b ? a : b; }   // djb::min, dj_brdf.h:574
+DJB_DEV float fmax_(float a, float b) { return a > b ? a : b; }   // djb::max, dj_brdf.h:575
+DJB_DEV float sat_(float x) { return fmin_(1.0f, fmax_(0.0f, x)); }
+
+DJB_DEV v3 mk(float x, float y, float z) { v3 v; v.x = x; v.y = y; v.z = z; return v; }
+DJB_DEV v3 add(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DJB_DEV v3 sub(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DJB_DEV v3 scale(float s, v3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+DJB_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // dj_brdf.h:618
+DJB_DEV v3 cross(v3 a, v3 b)                                                           // dj_brdf.h:623
+{
+	return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// vec3 / float_t == (1.0 / b) * a with the reciprocal rounded to float (dj_brdf.h:601);
+// float(1.0 / double(b)) == 1.0f / b (one correctly-rounded division)
+DJB_DEV v3 divs(v3 a, float b) { return scale(1.0f / b, a); }
+// inversesqrt = float(1.0 / sqrt(double(x))): two double roundings, kept in double (dj_brdf.h:612)
+DJB_DEV float inversesqrt_(float x) { return F(1.0 / sqrt(D(x))); }
+DJB_DEV v3 normalize(v3 v) { return scale(inversesqrt_(dot(v, v)), v); }              // dj_brdf.h:630
+DJB_DEV float intensity(v3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z; } // dj_brdf.h:69
+
+// vec3(theta, phi), dj_brdf.h:589-595
+DJB_DEV v3 from_angles(float theta, float phi)
+{
+	float s = F(sin(D(theta)));
+	return mk(F(D(s) * cos(D(phi))), F(D(s) * sin(D(phi))), F(cos(D(theta))));
+}
+
+// dj_brdf.h:650-661
+DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
+{
+	if (D(p.z) > 0.99999) { theta = 0.0f; phi = 0.0f; }
+	else if (D(p.z) < -0.99999) { theta = F(DJB_PI); phi = 0.0f; }
+	else { theta = F(acos(D(p.z))); phi = F(atan2(D(p.y), D(p.x))); }
+}
+
+// A&S 7.1.26 as the reference writes it, dj_brdf.h:667-688
+DJB_DEV float erf_(float x)
+{
+	const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f,
+	            a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+	float sign = x < 0 ? -1.0f : 1.0f;
+	x = fabsf(x);
+	float t = F(1.0 / (1.0 + D(p * x)));
+	float poly = ((((a5 * t + a4) * t) + a3) * t + a2) * t + a1;
+	float y = F(1.0 - D(poly * t) * exp(D(-x * x)));
+	return sign * y;
+}
+
+// Giles' single-precision erfinv, dj_brdf.h:691-721
+DJB_DEV float erfinv_(float u)
+{
+	float w = -logf((1.0f - u) * (1.0f + u)), p;
+	if (w < 5.0f) {
+		w = w - 2.5f;
+		p = 2.81022636e-08f;
+		p = 3.43273939e-07f + p * w;
+		p = -3.5233877e-06f + p * w;
+		p = -4.39150654e-06f + p * w;
+		p = 0.00021858087f + p * w;
+		p = -0.00125372503f + p * w;
+		p = -0.00417768164f + p * w;
+		p = 0.246640727f + p * w;
+		p = 1.50140941f + p * w;
+	} else {
+		w = F(sqrt(D(w)) - 3.0);
+		p = -0.000200214257f;
+		p = 0.000100950558f + p * w;
+		p = 0.00134934322f + p * w;
+		p = -0.00367342844f + p * w;
+		p = 0.00573950773f + p * w;
+		p = -0.0076224613f + p * w;
+		p = 0.00943887047f + p * w;
+		p = 1.00167406f + p * w;
+		p = 2.83297682f + p * w;
+	}
+	return p * u;
+}
+
+// Cline's concentric map, dj_brdf.h:726-747
+DJB_DEV void uniform_to_concentric(float u1, float u2, float &x, float &y)
+{
+	float r1 = F(2.0 * D(u1) - 1.0), r2 = F(2.0 * D(u2) - 1.0), phi, r;
+	if (r1 == 0 && r2 == 0) { r = phi = 0; }
+	else if (r1 * r1 > r2 * r2) { r = r1; phi = F((DJB_PI / 4.0) * D(r2 / r1)); }
+	else { r = r2; phi = F((DJB_PI / 2.0) - D(r1 / r2) * (DJB_PI / 4.0)); }
+	x = F(D(r) * cos(D(phi)));
+	y = F(D(r) * sin(D(phi)));
+}
+
+// Rodrigues rotation about +z / +y with the reference's exact operation order (dj_brdf.h:754-765).
+// For axis = z: dot(axis, x) = x.z, cross(axis, x) = (-x.y, x.x, 0); for axis = y:
+// dot = x.y, cross = (x.z, 0, -x.x); the zero products vanish exactly in IEEE arithmetic
+// (finite inputs), so only the surviving terms are evaluated.
+DJB_DEV v3 rotate_z(v3 x, float angle)
+{
+	float c = F(cos(D(angle))), s = F(sin(D(angle)));
+	float t2 = F(D(x.z) * (1.0 - D(c)));
+	// out = c*x; out += axis*t2 (adds 0 to x,y; t2 to z); out += s*cross
+	return mk((c * x.x + 0.0f * t2) + s * (0.0f * x.z - x.y),
+	          (c * x.y + 0.0f * t2) + s * (x.x - 0.0f * x.z),
+	          (c * x.z + t2) + s * (0.0f * x.y - 0.0f * x.x));
+}
+DJB_DEV v3 rotate_y(v3 x, float angle)
+{
+	float c = F(cos(D(angle))), s = F(sin(D(angle)));
+	float t2 = F(D(x.y) * (1.0 - D(c)));
+	return mk((c * x.x + 0.0f * t2) + s * (x.z - 0.0f * x.y),
+	          (c * x.y + t2) + s * (0.0f * x.x - 0.0f * x.z),
+	          (c * x.z + 0.0f * t2) + s * (0.0f * x.y - x.x));
+}
+
+// dj_brdf.h:771-781
+DJB_DEV void io_to_hd(v3 i, v3 o, v3 &h, v3 &d)
+{
+	float th, ph;
+	h = normalize(add(i, o));
+	xyz_to_theta_phi(h, th, ph);
+	v3 tmp = rotate_z(i, -ph);
+	d = normalize(rotate_y(tmp, -th));
+}
+
+// dj_brdf.h:783-793
+DJB_DEV void hd_to_io(v3 h, v3 d, v3 &i, v3 &o)
+{
+	float th, ph;
+	xyz_to_theta_phi(h, th, ph);
+	v3 tmp = rotate_y(d, th);
+	i = normalize(rotate_z(tmp, ph));
+	o = normalize(sub(scale(F(2.0 * D(dot(i, h))), h), i));
+}
+
+// ------------------------------------------------------------------ private spline (dj_brdf.h:1181-1249)
+DJB_DEV void spline_locate(int edge, float u, int &i1, int &i2, float &frac)
+{
+	// modf(double(u*edge - u)): integer part by truncation, fractional part exact in float
+	float t = u * (float)edge - u;
+	float ip = truncf(t);
+	frac = t - ip;                       // exact (Sterbenz / same-binade subtraction)
+	int k = (int)ip;
+	i1 = k >= edge ? edge - 1 : (k < 0 ? 0 : k);          // uwrap_edge
+	int k2 = k + 1;
+	i2 = k2 >= edge ? edge - 1 : (k2 < 0 ? 0 : k2);
+}
+DJB_DEV float spline_f(const float *pts, int n, float u)
+{
+	int i1, i2; float fr;
+	spline_locate(n, u, i1, i2, fr);
+	float p1 = pts[i1], p2 = pts[i2];
+	return p1 + fr * (p2 - p1);
+}
+DJB_DEV v3 spline_v3(const float *pts, int n, float u)
+{
+	int i1, i2; float fr;
+	spline_locate(n, u, i1, i2, fr);
+	v3 p1 = mk(pts[3 * i1], pts[3 * i1 + 1], pts[3 * i1 + 2]);
+	v3 p2 = mk(pts[3 * i2], pts[3 * i2 + 1], pts[3 * i2 + 2]);
+	return add(p1, scale(fr, sub(p2, p1)));
+}
+
+// ------------------------------------------------------------------ Fresnel (dj_brdf.h:1253-1346)
+DJB_DEV float unpolarized1(float c, float n)   // dj_brdf.h:1292-1303
+{
+	float g = F(sqrt(D(n * n + c * c) - 1.0));
+	float t1 = F(D(c * (g + c)) - 1.0);
+	float t2 = F(D(c * (g - c)) + 1.0);
+	float t3 = (t1 * t1) / (t2 * t2);
+	float t4 = ((g - c) * (g - c)) / ((g + c) * (g + c));
+	return F((0.5 * D(t4)) * (1.0 + D(t3)));
+}
+
+DJB_DEV v3 fresnel_eval(const Fresnel &f, float c)
+{
+	switch (f.kind) {
+	case FR_UNPOLARIZED:
+		return mk(unpolarized1(c, f.a[0]), unpolarized1(c, f.a[1]), unpolarized1(c, f.a[2]));
+	case FR_SCHLICK: {   // dj_brdf.h:1320-1328
+		float c1 = F(1.0 - D(c)), c2 = c1 * c1, c5 = c2 * c2 * c1;
+		v3 f0 = mk(f.a[0], f.a[1], f.a[2]);
+		return add(f0, scale(c5, sub(mk(1, 1, 1), f0)));
+	}
+	case FR_SGD: {       // dj_brdf.h:1330-1336
+		float pw = F(pow(1.0 - D(c), 5.0));
+		v3 f0 = mk(f.a[0], f.a[1], f.a[2]), f1 = mk(f.b[0], f.b[1], f.b[2]);
+		return add(sub(f0, scale(c, f1)), scale(pw, sub(mk(1, 1, 1), f0)));
+	}
+	case FR_SPLINE: {    // dj_brdf.h:1338-1344
+		float u = F(2.0 * acos(D(c)) / DJB_PI);
+		return spline_v3(f.pts, f.npts, u);
+	}
+	default: return mk(1, 1, 1);
+	}
+}
+
+// ------------------------------------------------------------------ radial NDFs (dj_brdf.h:1866-2176)
+template <int KIND> DJB_DEV float p22_radial(const Brdf &b, float r_sqr)
+{
+	if (KIND == KIND_BECKMANN) return F(exp(D(-r_sqr)) / DJB_PI);                      // :1866
+	if (KIND == KIND_GGX) { float t = F(1.0 + D(r_sqr)); return F(1.0 / (DJB_PI * D(t) * D(t))); } // :2056
+	float r = sqrtf(r_sqr);                                                             // :2151
+	float u = F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI))));
+	return spline_f(b.p22, b.n_p22, u);
+}
+
+template <int KIND> DJB_DEV float sigma_std_radial(const Brdf &b, float c)
+{
+	if (KIND == KIND_BECKMANN) {                                                        // :1871
+		if (D(c) == 1.0) return 1.0f;
+		float s = F(sqrt(1.0 - D(c * c)));
+		float nu = c / s;
+		float tmp = F(exp(D(-nu * nu)) * D(inversesqrt_(F(DJB_PI))));
+		return F((D(c) * (1.0 + D(erf_(nu))) + D(s * tmp)) / 2.0);
+	}
+	if (KIND == KIND_GGX) return F((1.0 + D(c)) / 2.0);                                 // :2062
+	float u = F(D(2.0f) * acos(D(c)) / D(F(DJB_PI)));                                   // :2158
+	return spline_f(b.sigma, b.n_sigma, u);
+}
+
+DJB_DEV float tab_cdf_radial(const Brdf &b, float r)                                   // :2164
+{
+	float u = F(atan(D(r)) * D(2.0f) / D(F(DJB_PI)));
+	if (u < 0.0f) u = 0.0f;
+	return spline_f(b.cdf, b.n_cdf, sqrtf(u));
+}
+DJB_DEV float tab_qf_radial(const Brdf &b, float u)                                    // :2171
+{
+	float qf = spline_f(b.qf, b.n_qf, u);
+	return F(tan(D(qf * F(DJB_PI) / 2.0f)));
+}
+
+DJB_DEV float beckmann_qf1(float u) { return erfinv_(F(2.0 * D(u) - 1.0)); }           // :1891
+
+// Newton + bisection in the erf domain, dj_brdf.h:1897-1952
+DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k)
+{
+	const float sqrt_pi_inv = F(1. / sqrt(DJB_PI));
+	float cot_k = cos_k / sin_k, tan_k = sin_k / cos_k;
+	float a = -1, c = erf_(cot_k);
+	u = fmax_(u, 1e-6f);
+	float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
+	float b = c - (1 + c) * powf(1 - u, fit);
+	float normalization = F(1 / (D(1 + c) + D(sqrt_pi_inv * tan_k) * exp(D(-cot_k * cot_k))));
+	int it = 0;
+	while (++it < 10) {
+		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+		float inv_erf = erfinv_(b);
+		float value = normalization * (1 + b + sqrt_pi_inv * tan_k * expf(-inv_erf * inv_erf)) - u;
+		float derivative = normalization * (1 - inv_erf * tan_k);
+		if (fabsf(value) < 1e-5f) break;
+		if (value > 0) c = b; else a = b;
+		b -= value / derivative;
+	}
+	return erfinv_(fmax_(-0.9999f, b));
+}
+
+DJB_DEV float ggx_qf2_radial(float u, float cos_k, float sin_k)                        // :2089
+{
+	float sin_t = F(D(u) * (1.0 + D(cos_k)) - 1.0);
+	float cos_t = F(sqrt(1.0 - D(sin_t * sin_t)));
+	if (D(cos_t) > 0.707107) {
+		float tan_t = sin_t / cos_t;
+		if (D(sin_k) < 0.707107) {
+			float tan_k = sin_k / cos_k;
+			return F(D(-(tan_t + tan_k)) / (1.0 - D(tan_t * tan_k)));
+		} else {
+			float cot_k = cos_k / sin_k;
+			return F((1.0 + D(tan_t * cot_k)) / D(tan_t - cot_k));
+		}
+	} else {
+		float cot_t = cos_t / sin_t;
+		if (D(sin_k) < 0.707107) {
+			float tan_k = sin_k / cos_k;
+			return F((1.0 + D(tan_k * cot_t)) / D(tan_k - cot_t));
+		} else {
+			float cot_k = cos_k / sin_k;
+			return F(D(cot_t + cot_k) / (1.0 - D(cot_t * cot_k)));
+		}
+	}
+}
+
+DJB_DEV float ggx_qf3_radial(float u, float qf2)                                       // :2121
+{
+	float alpha = F(sqrt(1.0 + D(qf2 * qf2)));
+	float S;
+	if (D(u) < 0.5) { u = F(2.0 * (0.5 - D(u))); S = -1.0f; }
+	else { u = F(2.0 * (D(u) - 0.5)); S = 1.0f; }
+	double x = D(u);
+	float p = F(x * (x * (x * (-0.365728915865723) + 0.790235037209296) - 0.424965825137544)
+	            + 0.000152998850436920);
+	float q = F(x * (x * (x * (x * 0.169507819808272 - 0.397203533833404) - 0.232500544458471) + 1)
+	            - 0.539825872510702);
+	return S * alpha * (p / q);
+}
+
+// ------------------------------------------------------------------ microfacet (dj_brdf.h:1529-1765)
+template <int KIND> DJB_DEV float mf_p22(const Brdf &b, float x, float y, const Params &p)  // :1574
+{
+	x -= p.tx; y -= p.ty;
+	float nrm = p.ax * p.ay * p.s;
+	float x_ = x / p.ax;
+	float t1 = p.ax * y - p.rho * p.ay * x;
+	float t2 = p.ax * p.ay * p.s;
+	float y_ = t1 / t2;
+	return p22_radial<KIND>(b, x_ * x_ + y_ * y_) / nrm;
+}
+
+template <int KIND> DJB_DEV float mf_ndf(const Brdf &b, v3 h, const Params &p)              // :1559
+{
+	if (h.z > 1e-4f) {
+		float c2 = h.z * h.z, c4 = c2 * c2;
+		float xs = -h.x / h.z, ys = -h.y / h.z;
+		return mf_p22<KIND>(b, xs, ys, p) / c4;
+	}
+	return 0.0f;
+}
+
+template <int KIND> DJB_DEV float mf_sigma(const Brdf &b, v3 k, const Params &p)            // :1619
+{
+	float a = k.x * p.ax + k.y * p.ay * p.rho;
+	float bb = k.y * p.ay * p.s;
+	float c = k.z - k.x * p.tx - k.y * p.ty;
+	float nrm = sqrtf(a * a + bb * bb + c * c);
+	float kz = (1.0f / nrm) * c;
+	return nrm * sigma_std_radial<KIND>(b, kz);
+}
+
+// g1 given a precomputed sigma(k) (sigma is a pure function of k), dj_brdf.h:1633-1642
+DJB_DEV float mf_g1_from_sigma(v3 k, float sigma_k, const Params &p)
+{
+	if (D(dot(k, mk(p.nx, p.ny, p.nz))) > 0.0) return k.z / sigma_k;
+	return 0.0f;
+}
+
+DJB_DEV float mf_gaf_from_g1(int shadow, float g1i, float g1o)                              // :1644
+{
+	if (shadow) {
+		float t = g1i * g1o;
+		if (D(t) > 0.0) return t / (g1i + g1o - t);
+		return 0.0f;
+	}
+	return g1o;
+}
+
+// eval / evalp / pdf of one pair, sharing h, sigma(o), sigma(i), D (all pure).
+// WANT bits: 1 eval, 2 evalp, 4 pdf.
+template <int KIND, int WANT>
+DJB_DEV void mf_eval_pdf(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float &pdf)
+{
+	v3 h = normalize(add(i, o));
+	float sig_o = mf_sigma<KIND>(b, o, p);
+	float g1o = mf_g1_from_sigma(o, sig_o, p);
+	float g1i = 0.0f;
+	if (b.shadow) g1i = mf_g1_from_sigma(i, mf_sigma<KIND>(b, i, p), p);
+	float G = mf_gaf_from_g1(b.shadow, g1i, g1o);
+	fr = mk(0, 0, 0);
+	pdf = 0.0f;
+	if (D(G) > 0.0) {
+		float Dn = mf_ndf<KIND>(b, h, p);
+		float oh = dot(o, h);
+		if (WANT & 3) {                                                                      // :1529-1555
+			float cd = sat_(oh);
+			v3 Fr = fresnel_eval(b.fr, cd);
+			v3 e = scale(F(D(Dn * G) / (4.0 * D(o.z))), Fr);
+			fr = (WANT & 1) ? divs(e, i.z) : e;
+		}
+		if (WANT & 4) {                                                                      // :1713-1730
+			float ih4 = dot(i, h);
+			if (KIND == KIND_TABULAR) pdf = F(D(h.z * Dn) / (4.0 * D(ih4)));
+			else {
+				float vndf = D(oh) > 0.0 ? oh * Dn / sig_o : 0.0f;                           // :1602-1615
+				pdf = F(D(vndf) / (4.0 * D(ih4)));
+			}
+		}
+	}
+}
+
+// radial::sample_vp22_std_smith / _nmap, dj_brdf.h:1806-1846
+template <int KIND>
+DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &xs, float &ys)
+{
+	if (KIND != KIND_TABULAR) {
+		float cos_k = k.z;
+		float sin_k = D(k.z) < 1.0 ? F(sqrt(1.0 - D(k.z * k.z))) : 0.0f;
+		float tx, ty;
+		if (KIND == KIND_BECKMANN) { tx = beckmann_qf2_radial(u1, cos_k, sin_k); ty = beckmann_qf1(u2); }
+		else { tx = ggx_qf2_radial(u1, cos_k, sin_k); ty = ggx_qf3_radial(u2, tx); }
+		if (D(sin_k) == 0.0) { xs = tx; ys = ty; }
+		else {
+			float nrm = inversesqrt_(k.x * k.x + k.y * k.y);
+			float cp = k.x * nrm, sp = k.y * nrm;
+			xs = cp * tx - sp * ty;
+			ys = sp * tx + cp * ty;
+		}
+	} else {
+		float phi_h = F(D(u1) * DJB_PI * 2.0);
+		float r_h = tab_qf_radial(b, u2);
+		xs = F(D(r_h) * cos(D(phi_h)));
+		ys = F(D(r_h) * sin(D(phi_h)));
+	}
+}
+
+template <int KIND>
+DJB_DEV v3 mf_sample(const Brdf &b, const Params &p, float u1, float u2, v3 o)              // :1669
+{
+	u1 = sat_(u1) * 0.99998f + 0.00001f;
+	u2 = sat_(u2) * 0.99998f + 0.00001f;
+	float a = o.x * p.ax + o.y * p.ay * p.rho;
+	float bb = o.y * p.ay * p.s;
+	float c = o.z - o.x * p.tx - o.y * p.ty;
+	v3 o_std = normalize(mk(a, bb, c));
+	if (D(o_std.z) > 0.0) {
+		float txm, tym;
+		mf_sample_vp22_std<KIND>(b, u1, u2, o_std, txm, tym);
+		float txh = p.ax * txm + p.tx;
+		float chol = p.rho * txm + p.s * tym;
+		float tyh = p.ay * chol + p.ty;
+		v3 h = normalize(mk(-txh, -tyh, 1));
+		return sub(scale(F(2.0 * D(dot(o, h))), h), o);
+	}
+	return mk(0, 0, 1);
+}
+
+template <int KIND>
+DJB_DEV v3 mf_evalp_is(const Brdf &b, const Params &p, float u1, float u2, v3 o, v3 &i_out,
+                       float &pdf_out)                                                       // :1734
+{
+	v3 i_ = mf_sample<KIND>(b, p, u1, u2, o);
+	v3 h = normalize(add(i_, o));
+	float sig_o = mf_sigma<KIND>(b, o, p);
+	float g1o = mf_g1_from_sigma(o, sig_o, p);
+	float g1i = 0.0f;
+	if (b.shadow) g1i = mf_g1_from_sigma(i_, mf_sigma<KIND>(b, i_, p), p);
+	float G = mf_gaf_from_g1(b.shadow, g1i, g1o);
+	pdf_out = 0.f;
+	if (D(G) > 0.0) {
+		float oh = dot(o, h);
+		float cd = sat_(oh);
+		i_out = i_;
+		float Dn = mf_ndf<KIND>(b, h, p);
+		v3 Fr = fresnel_eval(b.fr, cd);
+		if (KIND == KIND_TABULAR) {
+			float pdf_ = F(D(h.z * Dn) / (4.0 * D(cd)));
+			pdf_out = pdf_;
+			v3 e = scale(F(D(Dn * G) / (4.0 * D(o.z))), Fr);   // evalp(i_, o)
+			return divs(e, pdf_);
+		} else {
+			float vndf = D(oh) > 0.0 ? oh * Dn / sig_o : 0.0f;
+			pdf_out = F(D(vndf) / (4.0 * D(cd)));
+			return scale(G / g1o, Fr);
+		}
+	}
+	return mk(0, 0, 0);
+}
+
+// ------------------------------------------------------------------ MERL (dj_brdf.h:893-1024)
+DJB_DEV int theta_half_index(float th)                                                       // :906
+{
+	if (D(th) <= 0.0) return 0;
+	float deg = F((D(th) / (DJB_PI / 2.0)) * 90);
+	float t = deg * 90.0f;
+	t = sqrtf(t);
+	int r = (int)t;
+	return r < 0 ? 0 : (r >= 90 ? 89 : r);
+}
+DJB_DEV int theta_diff_index(float td)                                                       // :926
+{
+	int t = (int)(D(td) / (DJB_PI * 0.5) * 90);
+	return t < 0 ? 0 : (t < 89 ? t : 89);
+}
+DJB_DEV int phi_diff_index(float pd)                                                         // :940
+{
+	if (D(pd) < 0.0) pd = F(D(pd) + DJB_PI);
+	int t = (int)(D(pd) / DJB_PI * 360 / 2);
+	return t < 0 ? 0 : (t < 179 ? t : 179);
+}
+DJB_DEV int merl_index(v3 i, v3 o)                                                           // :987-1002
+{
+	v3 h, d; float th, ph, td, pd;
+	h = normalize(add(i, o));
+	xyz_to_theta_phi(h, th, ph);
+	v3 tmp = rotate_z(i, -ph);
+	d = normalize(rotate_y(tmp, -th));
+	xyz_to_theta_phi(d, td, pd);
+	return phi_diff_index(pd) + theta_diff_index(td) * 180 + theta_half_index(th) * 16200;
+}
+DJB_DEV v3 merl_eval(const Brdf &b, v3 i, v3 o)
+{
+	// table entries are float(double sample * channel scale) with below-horizon bins zeroed at
+	// load time (djb_host.cpp): exactly what dj_brdf.h:1010-1023 returns per lookup.
+	float4 t = b.merl[merl_index(i, o)];
+	return mk(t.x, t.y, t.z);
+}
+
+// ------------------------------------------------------------------ UTIA (dj_brdf.h:1063-1157)
+DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
+{
+	float r2d = F(180.0 / DJB_PI);
+	float theta_i = F(D(r2d) * acos(D(i.z))), theta_o = F(D(r2d) * acos(D(o.z)));
+	float phi_i = F(D(r2d) * atan2(D(i.y), D(i.x))), phi_o = F(D(r2d) * atan2(D(o.y), D(o.x)));
+	if (D(theta_i) >= 90.0 || D(theta_o) >= 90.0) return mk(0, 0, 0);
+	if (!(phi_i == phi_i) || !(phi_o == phi_o)) return mk(0, 0, 0);   // NaN guard: reference would spin
+	while (D(phi_i) < 0.0) phi_i = F(D(phi_i) + 360.0);
+	while (D(phi_o) < 0.0) phi_o = F(D(phi_o) + 360.0);
+	while (phi_i >= 360.0f) phi_i = F(D(phi_i) - 360.0);
+	while (phi_o >= 360.0f) phi_o = F(D(phi_o) - 360.0);
+	int iti0 = (int)floor(D(theta_i) / 15.0), iti1 = iti0 + 1;
+	if (iti0 > 4) { iti0 = 4; iti1 = 5; }
+	int itv0 = (int)floor(D(theta_o) / 15.0), itv1 = itv0 + 1;
+	if (itv0 > 4) { itv0 = 4; itv1 = 5; }
+	int ipi0 = (int)floor(D(phi_i) / 7.5), ipi1 = ipi0 + 1;
+	int ipv0 = (int)floor(D(phi_o) / 7.5), ipv1 = ipv0 + 1;
+	float sum, wti[2], wtv[2], wpi[2], wpv[2];
+	wti[1] = theta_i - F(15.0 * iti0); wti[0] = F(15.0 * iti1) - theta_i;
+	sum = wti[0] + wti[1]; wti[0] /= sum; wti[1] /= sum;
+	wtv[1] = theta_o - F(15.0 * itv0); wtv[0] = F(15.0 * itv1) - theta_o;
+	sum = wtv[0] + wtv[1]; wtv[0] /= sum; wtv[1] /= sum;
+	wpi[1] = phi_i - F(7.5 * ipi0); wpi[0] = F(7.5 * ipi1) - phi_i;
+	sum = wpi[0] + wpi[1]; wpi[0] /= sum; wpi[1] /= sum;
+	wpv[1] = phi_o - F(7.5 * ipv0); wpv[0] = F(7.5 * ipv1) - phi_o;
+	sum = wpv[0] + wpv[1]; wpv[0] /= sum; wpv[1] /= sum;
+	if (ipi1 == 48) ipi1 = 0;
+	if (ipv1 == 48) ipv1 = 0;
+	int iti[2] = { iti0, iti1 }, itv[2] = { itv0, itv1 }, ipi[2] = { ipi0, ipi1 }, ipv[2] = { ipv0, ipv1 };
+	float RGB[3];
+#pragma unroll
+	for (int isp = 0; isp < 3; ++isp) {
+		float acc = 0.0f;
+#pragma unroll
+		for (int a = 0; a < 2; ++a)
+#pragma unroll
+		for (int c = 0; c < 2; ++c)
+#pragma unroll
+		for (int k = 0; k < 2; ++k)
+#pragma unroll
+		for (int l = 0; l < 2; ++l) {
+			float w = wti[a] * wtv[c] * wpi[k] * wpv[l];
+			int idx = isp * 288 * 288 + 288 * (48 * iti[a] + ipi[k]) + 48 * itv[c] + ipv[l];
+			acc += w * b.utia[idx];
+		}
+		if (D(acc) > 0.0375) acc = F(pow(D(F(D(acc) + 0.055)) / 1.055, D(2.4f)));
+		else acc /= 12.92f;
+		RGB[isp] = acc * 100.0f;
+	}
+	return mk(fmax_(0.f, RGB[0]), fmax_(0.f, RGB[1]), fmax_(0.f, RGB[2]));
+}
+
+// ------------------------------------------------------------------ array access
+DJB_DEV v3 load3(const View &v, long long k)
+{
+	long long off = k * v.stride;
+	return mk(v.x[off], v.y[off], v.z[off]);
+}
+DJB_DEV void store3(const View &v, long long k, v3 a)
+{
+	long long off = k * v.stride;
+	v.x[off] = a.x; v.y[off] = a.y; v.z[off] = a.z;
+}
+
+// ------------------------------------------------------------------ counter-based RNG (synth.py)
+DJB_DEV uint32_t pcg(uint32_t x)
+{
+	uint32_t state = x * 747796405u + 2891336453u;
+	uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+	return (word >> 22u) ^ word;
+}
+DJB_DEV uint32_t hash_u32(uint32_t seed, uint64_t k, uint32_t c)
+{
+	uint32_t h = pcg(seed + c * 0x9E3779B9u);
+	h = pcg(h ^ (uint32_t)(k & 0xFFFFFFFFull));
+	h = pcg(h + (uint32_t)(k >> 32));
+	return h;
+}
+DJB_DEV float gen_uniform(uint32_t seed, uint64_t k)
+{
+	return (float)(hash_u32(seed, k, 0) >> 8) * 5.9604644775390625e-08f;   // 2^-24
+}
+DJB_DEV v3 gen_direction(uint32_t seed, uint64_t k)
+{
+	float x = (float)(hash_u32(seed, k, 0) >> 8) * 1.1920928955078125e-07f - 1.0f;   // 2^-23
+	float y = (float)(hash_u32(seed, k, 1) >> 8) * 1.1920928955078125e-07f - 1.0f;
+	float r2 = x * x + y * y;
+	if (r2 >= 0.998f) { x *= 0.5f; y *= 0.5f; }
+	float z = sqrtf((1.0f - x * x) - y * y);
+	return mk(x, y, z);
+}
+
+} // namespace djbdev

@@ -1,0 +1,776 @@
+// djb_host.hip -- the C ABI of libdjb_hip.so (include/djb_hip.h): handle lifetime, argument
+// checking, host<->HBM staging, and kernel launches.  No CPU evaluation path exists here: every
+// numeric result comes from the gfx950 kernels; if HIP is unusable the calls fail with
+// DJB_ERR_NO_DEVICE / DJB_ERR_HIP.
+#include "../../include/djb_hip.h"
+#include "djb_internal.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using djbdev::Brdf;
+using djbdev::Params;
+using djbdev::View;
+
+namespace {
+
+thread_local std::string g_err;
+
+djb_status fail(djb_status st, const char *fmt, ...)
+{
+	char buf[256];   // same 256-byte budget as djb::exc (dj_brdf.h:578-587)
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+	g_err = buf;
+	return st;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+	return fail(DJB_ERR_HIP, "djb_error: HIP %s at %s:%d: %s", #expr, __FILE__, __LINE__, \
+	            hipGetErrorString(e_)); } while (0)
+
+constexpr long long MERL_N = 90LL * 90 * 180;
+constexpr long long UTIA_N = 3LL * 288 * 288;
+
+} // namespace
+
+struct djb_ctx {
+	int device;
+	hipStream_t stream;
+	bool owns_stream;
+	hipEvent_t ev0, ev1;
+};
+
+struct djb_brdf {
+	djb_ctx *ctx;
+	Brdf dev;                        // device view (pointers into HBM)
+	std::vector<void *> allocs;      // HBM blocks owned by this object
+	// tabular: host copies for the accessors
+	std::vector<float> p22, sigma, cdf, qf, fresnel;
+	float alpha_beckmann, alpha_ggx;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ microfacet::params on the host
+// (scalar set-up code, dj_brdf.h:1355-1506; same float/double evaluation order as the reference)
+float Ff(double x) { return (float)x; }
+
+void resolve_location(djb_params_resolved *p, float tx, float ty)
+{
+	p->tx_n = tx; p->ty_n = ty;
+	float x = -tx, y = -ty, z = 1.0f;
+	float m = x * x + y * y + z * z;
+	float r = Ff(1.0 / std::sqrt((double)m));
+	p->n[0] = r * x; p->n[1] = r * y; p->n[2] = r * z;
+}
+
+void resolve_ellipse(djb_params_resolved *p, float a1, float a2, float phi_a)
+{
+	p->a1 = a1; p->a2 = a2; p->phi_a = phi_a;
+	float c = Ff(std::cos((double)phi_a)), s = Ff(std::sin((double)phi_a));
+	float c2 = Ff(2.0 * (double)c * (double)c - (double)1.0f);
+	float a1s = a1 * a1, a2s = a2 * a2, t1 = a1s + a2s, t2 = a1s - a2s;
+	p->ax = Ff(std::sqrt(0.5 * (double)(t1 + t2 * c2)));
+	p->ay = Ff(std::sqrt(0.5 * (double)(t1 - t2 * c2)));
+	p->rho = (a2s - a1s) * c * s / (p->ax * p->ay);
+	p->sqrt_one_minus_rho_sqr = Ff(std::sqrt(1.0 - (double)(p->rho * p->rho)));
+}
+
+djb_status resolve_params(const djb_params *in, djb_params_resolved *p)
+{
+	memset(p, 0, sizeof *p);
+	int kind = in ? in->kind : DJB_PARAMS_STANDARD;
+	if (kind == DJB_PARAMS_STANDARD) {
+		resolve_ellipse(p, 1.0f, 1.0f, 0.0f);
+		resolve_location(p, 0.0f, 0.0f);
+	} else if (kind == DJB_PARAMS_ELLIPTIC) {
+		if (!(in->v[0] > 0.0f && in->v[1] > 0.0f))
+			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid ellipse radii");   // dj_brdf.h:1453
+		resolve_ellipse(p, in->v[0], in->v[1], in->v[2]);
+		resolve_location(p, 0.0f, 0.0f);
+	} else if (kind == DJB_PARAMS_PDFPARAMS) {
+		float ax = in->v[0], ay = in->v[1], rho = in->v[2];
+		if (!(ax > 0.0f && ay > 0.0f))
+			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid scale parameters");  // :1466
+		if (!(std::fabs((double)rho) < 1.0))
+			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid correlation parameter"); // :1467
+		p->ax = ax; p->ay = ay; p->rho = rho;
+		p->sqrt_one_minus_rho_sqr = Ff(std::sqrt(1.0 - (double)(rho * rho)));
+		float axs = ax * ax, ays = ay * ay;
+		float cov = Ff((double)(rho * ax * ay) * 2.0);
+		float t1 = axs + ays, t2 = axs - ays;
+		float t3 = Ff(std::sqrt((double)(t2 * t2 + cov * cov)));
+		p->a1 = Ff(std::sqrt(0.5 * (double)(t1 + t3)));
+		p->a2 = Ff(std::sqrt(0.5 * (double)(t1 - t3)));
+		p->phi_a = ((double)cov != 0.0) ? Ff(std::atan((double)((axs - ays - t3) / cov))) : 0.0f;
+		resolve_location(p, in->v[3], in->v[4]);
+	} else {
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown params kind %d", kind);
+	}
+	return DJB_OK;
+}
+
+djb_status device_params(const djb_params *in, Params *out)
+{
+	djb_params_resolved r;
+	djb_status st = resolve_params(in, &r);
+	if (st != DJB_OK) return st;
+	out->nx = r.n[0]; out->ny = r.n[1]; out->nz = r.n[2];
+	out->ax = r.ax; out->ay = r.ay; out->rho = r.rho; out->s = r.sqrt_one_minus_rho_sqr;
+	out->tx = r.tx_n; out->ty = r.ty_n;
+	return DJB_OK;
+}
+
+// ------------------------------------------------------------------ host <-> HBM staging
+// A staged array is a dense SoA block in HBM; host data of any stride is packed / unpacked on
+// the host side of the copy.  Device-resident callers bypass all of this.
+struct Staged {
+	djb_ctx *ctx; long long n; int mem;
+	std::vector<void *> blocks;
+	struct Out { View dev; djb_vec3_view host; };
+	struct OutF { float *dev; float *host; };
+	std::vector<Out> outs;
+	std::vector<OutF> outfs;
+	std::vector<std::pair<void *, std::pair<void *, size_t>>> out_raw;   // dev -> (host, bytes)
+
+	Staged(djb_ctx *c, long long n_, int mem_) : ctx(c), n(n_), mem(mem_) {}
+	~Staged() { for (void *b : blocks) (void)hipFree(b); }
+
+	static bool valid(const djb_vec3_view *v) { return v && v->x && v->y && v->z; }
+
+	djb_status in_vec(const djb_vec3_view *v, View *out)
+	{
+		if (!valid(v)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
+		if (mem == DJB_MEM_DEVICE) { *out = View{ v->x, v->y, v->z, (long long)v->stride }; return DJB_OK; }
+		float *d = nullptr;
+		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
+		blocks.push_back(d);
+		std::vector<float> pack(3 * (size_t)n);
+		for (long long k = 0; k < n; ++k) {
+			pack[k] = v->x[k * v->stride];
+			pack[n + k] = v->y[k * v->stride];
+			pack[2 * n + k] = v->z[k * v->stride];
+		}
+		HIP_TRY(hipMemcpyAsync(d, pack.data(), sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));   // pack goes out of scope
+		*out = View{ d, d + n, d + 2 * n, 1 };
+		return DJB_OK;
+	}
+	djb_status in_f(const float *h, const float **out)
+	{
+		if (!h) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null input array");
+		if (mem == DJB_MEM_DEVICE) { *out = h; return DJB_OK; }
+		float *d = nullptr;
+		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * (size_t)(n > 0 ? n : 1)));
+		blocks.push_back(d);
+		HIP_TRY(hipMemcpyAsync(d, h, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		*out = d;
+		return DJB_OK;
+	}
+	djb_status out_vec(const djb_vec3_view *v, View *out)
+	{
+		if (!valid(v)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null output vec3 view");
+		if (mem == DJB_MEM_DEVICE) { *out = View{ v->x, v->y, v->z, (long long)v->stride }; return DJB_OK; }
+		float *d = nullptr;
+		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
+		blocks.push_back(d);
+		*out = View{ d, d + n, d + 2 * n, 1 };
+		outs.push_back(Out{ *out, *v });
+		return DJB_OK;
+	}
+	template <typename T> djb_status out_arr(T *h, T **out)
+	{
+		if (!h) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null output array");
+		if (mem == DJB_MEM_DEVICE) { *out = h; return DJB_OK; }
+		T *d = nullptr;
+		HIP_TRY(hipMalloc((void **)&d, sizeof(T) * (size_t)(n > 0 ? n : 1)));
+		blocks.push_back(d);
+		out_raw.push_back({ d, { h, sizeof(T) * (size_t)n } });
+		*out = d;
+		return DJB_OK;
+	}
+	djb_status finish()
+	{
+		if (mem == DJB_MEM_DEVICE) return DJB_OK;
+		std::vector<float> pack(3 * (size_t)n);
+		for (auto &o : outs) {
+			HIP_TRY(hipMemcpyAsync(pack.data(), o.dev.x, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+			HIP_TRY(hipStreamSynchronize(ctx->stream));
+			for (long long k = 0; k < n; ++k) {
+				o.host.x[k * o.host.stride] = pack[k];
+				o.host.y[k * o.host.stride] = pack[n + k];
+				o.host.z[k * o.host.stride] = pack[2 * n + k];
+			}
+		}
+		for (auto &o : out_raw)
+			HIP_TRY(hipMemcpyAsync(o.second.first, o.first, o.second.second, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		return DJB_OK;
+	}
+};
+
+djb_status check_call(djb_ctx *ctx, const djb_brdf *b, long long n, int mem)
+{
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	if (b && b->ctx->device != ctx->device)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf lives on device %d, ctx on %d", b->ctx->device, ctx->device);
+	if (n < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: negative batch size");
+	if (mem != DJB_MEM_DEVICE && mem != DJB_MEM_HOST)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown memory space %d", mem);
+	HIP_TRY(hipSetDevice(ctx->device));
+	return DJB_OK;
+}
+
+djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                       const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_fr,
+                       float *out_pdf, int mem, int want)
+{
+	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
+	djb_status st = check_call(ctx, b, n, mem);
+	if (st != DJB_OK) return st;
+	Params p;
+	if ((st = device_params(params, &p)) != DJB_OK) return st;
+	Staged sg(ctx, n, mem);
+	View vi, vo, vout{ nullptr, nullptr, nullptr, 0 };
+	float *dpdf = nullptr;
+	if ((st = sg.in_vec(i, &vi)) != DJB_OK) return st;
+	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
+	if ((want & 3) && (st = sg.out_vec(out_fr, &vout)) != DJB_OK) return st;
+	if ((want & 4) && (st = sg.out_arr(out_pdf, &dpdf)) != DJB_OK) return st;
+	HIP_TRY(djbk::launch_eval(ctx->stream, b->dev, p, n, vi, vo, vout, dpdf, want));
+	return sg.finish();
+}
+
+djb_status alloc_brdf(djb_ctx *ctx, int kind, djb_brdf **out)
+{
+	djb_brdf *b = new djb_brdf();
+	b->ctx = ctx;
+	memset(&b->dev, 0, sizeof b->dev);
+	b->dev.kind = kind;
+	b->dev.shadow = 1;
+	b->dev.fr.kind = djbdev::FR_IDEAL;
+	b->alpha_beckmann = b->alpha_ggx = 0.0f;
+	*out = b;
+	return DJB_OK;
+}
+
+djb_status upload_floats(djb_brdf *b, const float *host, size_t count, const float **dev_out)
+{
+	float *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, sizeof(float) * (count ? count : 1)));
+	b->allocs.push_back(d);
+	HIP_TRY(hipMemcpy(d, host, sizeof(float) * count, hipMemcpyHostToDevice));
+	*dev_out = d;
+	return DJB_OK;
+}
+
+djb_status set_fresnel(djb_brdf *b, const djb_fresnel_desc *f)
+{
+	djbdev::Fresnel &fr = b->dev.fr;
+	fr.kind = f ? f->kind : DJB_FRESNEL_IDEAL;
+	fr.pts = nullptr; fr.npts = 0;
+	if (!f) return DJB_OK;
+	if (f->kind < DJB_FRESNEL_IDEAL || f->kind > DJB_FRESNEL_SPLINE)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown fresnel kind %d", f->kind);
+	for (int c = 0; c < 3; ++c) { fr.a[c] = f->a[c]; fr.b[c] = f->b[c]; }
+	if (f->kind == DJB_FRESNEL_SPLINE) {
+		if (!f->points || f->npoints < 1)
+			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: fresnel::spline needs >= 1 point");
+		b->fresnel.assign(f->points, f->points + 3 * (size_t)f->npoints);
+		fr.npts = f->npoints;
+		return upload_floats(b, b->fresnel.data(), b->fresnel.size(), &fr.pts);
+	}
+	return DJB_OK;
+}
+
+djb_status create_microfacet(djb_ctx *ctx, int kind, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
+{
+	if (!ctx || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	HIP_TRY(hipSetDevice(ctx->device));
+	djb_brdf *b;
+	alloc_brdf(ctx, kind, &b);
+	b->dev.shadow = shadow != 0;
+	djb_status st = set_fresnel(b, f);
+	if (st != DJB_OK) { djb_brdf_destroy(b); return st; }
+	*out = b;
+	return DJB_OK;
+}
+
+djb_status read_file(const char *path, size_t header_bytes, std::vector<char> *header,
+                     size_t payload_bytes, std::vector<double> *payload, bool header_is_merl)
+{
+	FILE *f = fopen(path, "rb");
+	if (!f) return fail(DJB_ERR_OPEN_FAILED, "djb_error: Failed to open %s\n", path);
+	long long n = 0;
+	if (header_is_merl) {
+		int32_t dims[3] = { 0, 0, 0 };
+		size_t got = fread(dims, 4, 3, f);
+		n = got == 3 ? (long long)(int32_t)(dims[0] * dims[1] * dims[2]) : 0;
+		if (n <= 0) { fclose(f); return fail(DJB_ERR_BAD_HEADER, "djb_error: Failed to read MERL header\n"); }
+		payload_bytes = sizeof(double) * 3 * (size_t)n;
+		header->assign((char *)dims, (char *)dims + 12);
+	}
+	(void)header_bytes;
+	payload->resize(payload_bytes / sizeof(double));
+	size_t got = fread(payload->data(), 1, payload_bytes, f);
+	fclose(f);
+	if (got != payload_bytes) return fail(DJB_ERR_READ_FAILED, "djb_error: Reading %s failed\n", path);
+	return DJB_OK;
+}
+
+} // namespace
+
+// ============================================================================ C ABI
+extern "C" {
+
+const char *djb_last_error(void) { return g_err.c_str(); }
+int djb_version(void) { return DJB_HIP_VERSION; }
+
+djb_status djb_device_count(int *count)
+{
+	if (!count) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	*count = 0;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return fail(DJB_ERR_NO_DEVICE, "djb_error: no HIP device (%s); libdjb_hip has no CPU path",
+		            e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+	*count = n;
+	return DJB_OK;
+}
+
+djb_status djb_ctx_create(int device, void *hip_stream, djb_ctx **out)
+{
+	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	int n = 0;
+	djb_status st = djb_device_count(&n);
+	if (st != DJB_OK) return st;
+	if (device < 0 || device >= n)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: device %d out of range [0,%d)", device, n);
+	HIP_TRY(hipSetDevice(device));
+	djb_ctx *c = new djb_ctx();
+	c->device = device;
+	c->owns_stream = hip_stream == nullptr;
+	c->stream = (hipStream_t)hip_stream;
+	if (c->owns_stream) {
+		hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) { delete c; return fail(DJB_ERR_HIP, "djb_error: hipStreamCreate: %s", hipGetErrorString(e)); }
+	}
+	if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+		delete c; return fail(DJB_ERR_HIP, "djb_error: hipEventCreate failed");
+	}
+	*out = c;
+	return DJB_OK;
+}
+
+djb_status djb_ctx_destroy(djb_ctx *ctx)
+{
+	if (!ctx) return DJB_OK;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	(void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return DJB_OK;
+}
+
+djb_status djb_ctx_synchronize(djb_ctx *ctx)
+{
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return DJB_OK;
+}
+
+void *djb_ctx_stream(djb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+djb_status djb_timer_start(djb_ctx *ctx)
+{
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+	return DJB_OK;
+}
+
+djb_status djb_timer_stop_ms(djb_ctx *ctx, float *ms)
+{
+	if (!ctx || !ms) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+	HIP_TRY(hipEventSynchronize(ctx->ev1));
+	HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+	return DJB_OK;
+}
+
+// ---------------------------------------------------------------- constructors
+djb_status djb_brdf_create_beckmann(djb_ctx *ctx, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
+{
+	return create_microfacet(ctx, DJB_KIND_BECKMANN, f, shadow, out);
+}
+djb_status djb_brdf_create_ggx(djb_ctx *ctx, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
+{
+	return create_microfacet(ctx, DJB_KIND_GGX, f, shadow, out);
+}
+
+djb_status djb_brdf_create_merl_from_memory(djb_ctx *ctx, const double *samples, int64_t n, djb_brdf **out)
+{
+	if (!ctx || !samples || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (n <= 0) return fail(DJB_ERR_BAD_HEADER, "djb_error: Failed to read MERL header\n");
+	// The reference accepts any positive dims product but indexes as 90x90x180 (dj_brdf.h:997-1008);
+	// a smaller table would be read out of bounds there.  Refuse it here.
+	if (n != MERL_N)
+		return fail(DJB_ERR_BAD_HEADER, "djb_error: MERL table has %lld samples per channel, expected %lld\n",
+		            (long long)n, MERL_N);
+	HIP_TRY(hipSetDevice(ctx->device));
+	djb_brdf *b;
+	alloc_brdf(ctx, DJB_KIND_MERL, &b);
+	double *raw = nullptr; float4 *tab = nullptr;
+	hipError_t e = hipMalloc((void **)&raw, sizeof(double) * 3 * (size_t)n);
+	if (e == hipSuccess) e = hipMalloc((void **)&tab, sizeof(float4) * (size_t)n);
+	if (e == hipSuccess) e = hipMemcpyAsync(raw, samples, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = djbk::launch_merl_convert(ctx->stream, raw, n, tab);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (raw) (void)hipFree(raw);
+	if (e != hipSuccess) {
+		if (tab) (void)hipFree(tab);
+		delete b;
+		return fail(DJB_ERR_HIP, "djb_error: MERL upload failed: %s", hipGetErrorString(e));
+	}
+	b->allocs.push_back(tab);
+	b->dev.merl = tab;
+	*out = b;
+	return DJB_OK;
+}
+
+djb_status djb_brdf_create_merl_from_file(djb_ctx *ctx, const char *path, djb_brdf **out)
+{
+	if (!ctx || !path || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	std::vector<char> hdr; std::vector<double> payload;
+	djb_status st = read_file(path, 12, &hdr, 0, &payload, true);
+	if (st != DJB_OK) return st;
+	return djb_brdf_create_merl_from_memory(ctx, payload.data(), (int64_t)(payload.size() / 3), out);
+}
+
+djb_status djb_brdf_create_utia_from_memory(djb_ctx *ctx, const double *samples, djb_brdf **out)
+{
+	if (!ctx || !samples || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	HIP_TRY(hipSetDevice(ctx->device));
+	djb_brdf *b;
+	alloc_brdf(ctx, DJB_KIND_UTIA, &b);
+	double *raw = nullptr; float *tab = nullptr;
+	hipError_t e = hipMalloc((void **)&raw, sizeof(double) * (size_t)UTIA_N);
+	if (e == hipSuccess) e = hipMalloc((void **)&tab, sizeof(float) * (size_t)UTIA_N);
+	if (e == hipSuccess) e = hipMemcpyAsync(raw, samples, sizeof(double) * (size_t)UTIA_N, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = djbk::launch_utia_convert(ctx->stream, raw, UTIA_N, tab);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (raw) (void)hipFree(raw);
+	if (e != hipSuccess) {
+		if (tab) (void)hipFree(tab);
+		delete b;
+		return fail(DJB_ERR_HIP, "djb_error: UTIA upload failed: %s", hipGetErrorString(e));
+	}
+	b->allocs.push_back(tab);
+	b->dev.utia = tab;
+	*out = b;
+	return DJB_OK;
+}
+
+djb_status djb_brdf_create_utia_from_file(djb_ctx *ctx, const char *path, djb_brdf **out)
+{
+	if (!ctx || !path || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	std::vector<char> hdr; std::vector<double> payload;
+	djb_status st = read_file(path, 0, &hdr, sizeof(double) * (size_t)UTIA_N, &payload, false);
+	if (st != DJB_OK) return st;
+	return djb_brdf_create_utia_from_memory(ctx, payload.data(), out);
+}
+
+djb_status djb_brdf_create_lambert(djb_ctx *ctx, djb_brdf **out)
+{
+	if (!ctx || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	return alloc_brdf(ctx, DJB_KIND_LAMBERT, out);
+}
+
+djb_status djb_brdf_destroy(djb_brdf *b)
+{
+	if (!b) return DJB_OK;
+	(void)hipSetDevice(b->ctx->device);
+	for (void *p : b->allocs) (void)hipFree(p);
+	delete b;
+	return DJB_OK;
+}
+
+int djb_brdf_kind(const djb_brdf *b) { return b ? b->dev.kind : -1; }
+int djb_brdf_get_shadow(const djb_brdf *b) { return b ? b->dev.shadow : -1; }
+
+// ---------------------------------------------------------------- the fitter
+static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_kind, int res, int shadow,
+                          float *alpha_b, float *alpha_g, float *p22, float *sigma, float *cdf,
+                          float *qf, float *fresnel, int *n_qf_host)
+{
+	const int n_mat = (int)srcs.size(), cnt = res - 1;
+	if (res <= 2) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");   // dj_brdf.h:2218
+	if (djbk::fit_lds_bytes(res) > 160 * 1024)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: resolution %d exceeds the LDS budget of the fit kernel", res);
+	Params std_p;
+	djb_status st = device_params(nullptr, &std_p);
+	if (st != DJB_OK) return st;
+	struct Bufs {
+		std::vector<void *> v;
+		~Bufs() { for (void *p : v) (void)hipFree(p); }
+		hipError_t get(void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e == hipSuccess) v.push_back(*p); return e; }
+	} bufs;
+	Brdf *d_srcs; double *km; float *ratio; djbk::FitOut o;
+	HIP_TRY(bufs.get((void **)&d_srcs, sizeof(Brdf) * n_mat));
+	HIP_TRY(bufs.get((void **)&km, sizeof(double) * (size_t)n_mat * cnt * cnt));
+	HIP_TRY(bufs.get((void **)&ratio, sizeof(float) * 3 * (size_t)n_mat * cnt * (cnt + 1)));
+	HIP_TRY(bufs.get((void **)&o.p22, sizeof(float) * (size_t)n_mat * res));
+	HIP_TRY(bufs.get((void **)&o.sigma, sizeof(float) * (size_t)n_mat * res));
+	HIP_TRY(bufs.get((void **)&o.cdf, sizeof(float) * (size_t)n_mat * res));
+	HIP_TRY(bufs.get((void **)&o.qf, sizeof(float) * (size_t)n_mat * res));
+	HIP_TRY(bufs.get((void **)&o.fresnel, sizeof(float) * 3 * (size_t)n_mat * res));
+	HIP_TRY(bufs.get((void **)&o.alpha_beckmann, sizeof(float) * n_mat));
+	HIP_TRY(bufs.get((void **)&o.alpha_ggx, sizeof(float) * n_mat));
+	HIP_TRY(bufs.get((void **)&o.n_qf, sizeof(int) * n_mat));
+	HIP_TRY(hipMemcpyAsync(d_srcs, srcs.data(), sizeof(Brdf) * n_mat, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(djbk::launch_fit(ctx->stream, d_srcs, src_kind, std_p, n_mat, res, shadow != 0, km, ratio, o));
+	auto back = [&](void *h, const void *d, size_t bytes) -> hipError_t {
+		return h ? hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+	};
+	HIP_TRY(back(alpha_b, o.alpha_beckmann, sizeof(float) * n_mat));
+	HIP_TRY(back(alpha_g, o.alpha_ggx, sizeof(float) * n_mat));
+	HIP_TRY(back(p22, o.p22, sizeof(float) * (size_t)n_mat * res));
+	HIP_TRY(back(sigma, o.sigma, sizeof(float) * (size_t)n_mat * res));
+	HIP_TRY(back(cdf, o.cdf, sizeof(float) * (size_t)n_mat * res));
+	HIP_TRY(back(qf, o.qf, sizeof(float) * (size_t)n_mat * res));
+	HIP_TRY(back(fresnel, o.fresnel, sizeof(float) * 3 * (size_t)n_mat * res));
+	HIP_TRY(back(n_qf_host, o.n_qf, sizeof(int) * n_mat));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return DJB_OK;
+}
+
+djb_status djb_brdf_create_tabular(djb_ctx *ctx, const djb_brdf *src, int res, int shadow, djb_brdf **out)
+{
+	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	if (res <= 2) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");
+	djb_brdf *t;
+	alloc_brdf(ctx, DJB_KIND_TABULAR, &t);
+	t->dev.shadow = shadow != 0;
+	t->p22.resize(res); t->sigma.resize(res); t->cdf.resize(res); t->qf.resize(res); t->fresnel.resize(3 * (size_t)res);
+	int n_qf = 0;
+	std::vector<Brdf> srcs(1, src->dev);
+	st = run_fit(ctx, srcs, src->dev.kind, res, shadow, &t->alpha_beckmann, &t->alpha_ggx, t->p22.data(),
+	             t->sigma.data(), t->cdf.data(), t->qf.data(), t->fresnel.data(), &n_qf);
+	if (st != DJB_OK) { djb_brdf_destroy(t); return st; }
+	t->qf.resize(n_qf);
+	t->dev.n_p22 = res; t->dev.n_sigma = res; t->dev.n_cdf = res; t->dev.n_qf = n_qf;
+	t->dev.fr.kind = djbdev::FR_SPLINE; t->dev.fr.npts = res;
+	if ((st = upload_floats(t, t->p22.data(), res, &t->dev.p22)) != DJB_OK ||
+	    (st = upload_floats(t, t->sigma.data(), res, &t->dev.sigma)) != DJB_OK ||
+	    (st = upload_floats(t, t->cdf.data(), res, &t->dev.cdf)) != DJB_OK ||
+	    (st = upload_floats(t, t->qf.data(), n_qf, &t->dev.qf)) != DJB_OK ||
+	    (st = upload_floats(t, t->fresnel.data(), 3 * (size_t)res, &t->dev.fr.pts)) != DJB_OK) {
+		djb_brdf_destroy(t); return st;
+	}
+	*out = t;
+	return DJB_OK;
+}
+
+djb_status djb_tabular_get(const djb_brdf *tab, int which, float *outp, int *count)
+{
+	if (!tab || tab->dev.kind != DJB_KIND_TABULAR)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular brdf");
+	const std::vector<float> *v;
+	switch (which) {
+	case DJB_TAB_P22: v = &tab->p22; break;
+	case DJB_TAB_SIGMA: v = &tab->sigma; break;
+	case DJB_TAB_CDF: v = &tab->cdf; break;
+	case DJB_TAB_QF: v = &tab->qf; break;
+	case DJB_TAB_FRESNEL: v = &tab->fresnel; break;
+	default: return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown table %d", which);
+	}
+	if (count) *count = (int)(which == DJB_TAB_FRESNEL ? v->size() / 3 : v->size());
+	if (outp) memcpy(outp, v->data(), sizeof(float) * v->size());
+	return DJB_OK;
+}
+
+djb_status djb_tabular_fit(const djb_brdf *tab, float *alpha_beckmann, float *alpha_ggx)
+{
+	if (!tab || tab->dev.kind != DJB_KIND_TABULAR)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular brdf");
+	if (alpha_beckmann) *alpha_beckmann = tab->alpha_beckmann;
+	if (alpha_ggx) *alpha_ggx = tab->alpha_ggx;
+	return DJB_OK;
+}
+
+djb_status djb_fit_merl_batch(djb_ctx *ctx, int n_mat, const double *const *tables, int res, int shadow,
+                              float *alpha_beckmann, float *alpha_ggx, float *p22, float *sigma,
+                              float *cdf, float *qf, float *fresnel)
+{
+	if (!ctx || !tables || n_mat < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
+	if (n_mat == 0) return DJB_OK;
+	djb_status st = check_call(ctx, nullptr, 0, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	// upload + convert every table (raw doubles -> float4 table), double-buffered on the stream
+	std::vector<djb_brdf *> mats(n_mat, nullptr);
+	std::vector<Brdf> srcs(n_mat);
+	for (int m = 0; m < n_mat; ++m) {
+		st = djb_brdf_create_merl_from_memory(ctx, tables[m], MERL_N, &mats[m]);
+		if (st != DJB_OK) break;
+		srcs[m] = mats[m]->dev;
+	}
+	if (st == DJB_OK)
+		st = run_fit(ctx, srcs, DJB_KIND_MERL, res, shadow, alpha_beckmann, alpha_ggx, p22, sigma, cdf, qf, fresnel, nullptr);
+	for (djb_brdf *b : mats) djb_brdf_destroy(b);
+	return st;
+}
+
+// ---------------------------------------------------------------- the operator surface
+djb_status djb_eval_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                          const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out, int mem)
+{
+	return eval_common(ctx, b, n, i, o, params, out, nullptr, mem, 1);
+}
+djb_status djb_evalp_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                           const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out, int mem)
+{
+	return eval_common(ctx, b, n, i, o, params, out, nullptr, mem, 2);
+}
+djb_status djb_pdf_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                         const djb_vec3_view *o, const djb_params *params, float *out_pdf, int mem)
+{
+	return eval_common(ctx, b, n, i, o, params, nullptr, out_pdf, mem, 4);
+}
+djb_status djb_eval_pdf_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                              const djb_vec3_view *o, const djb_params *params, int want_cos,
+                              const djb_vec3_view *out_fr, float *out_pdf, int mem)
+{
+	return eval_common(ctx, b, n, i, o, params, out_fr, out_pdf, mem, want_cos ? 6 : 5);
+}
+
+static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
+                                const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_w,
+                                const djb_vec3_view *out_i, float *out_pdf, int mem, bool is)
+{
+	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
+	djb_status st = check_call(ctx, b, n, mem);
+	if (st != DJB_OK) return st;
+	Params p;
+	if ((st = device_params(params, &p)) != DJB_OK) return st;
+	Staged sg(ctx, n, mem);
+	View vo, vi, vw; const float *d1, *d2; float *dpdf = nullptr;
+	if ((st = sg.in_f(u1, &d1)) != DJB_OK) return st;
+	if ((st = sg.in_f(u2, &d2)) != DJB_OK) return st;
+	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
+	if ((st = sg.out_vec(out_i, &vi)) != DJB_OK) return st;
+	if (is) {
+		if ((st = sg.out_vec(out_w, &vw)) != DJB_OK) return st;
+		if ((st = sg.out_arr(out_pdf, &dpdf)) != DJB_OK) return st;
+	}
+	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, d1, d2, 0, 0, 0, vo, vi, is ? &vw : nullptr, dpdf));
+	return sg.finish();
+}
+
+djb_status djb_sample_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
+                            const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_i, int mem)
+{
+	return sample_common(ctx, b, n, u1, u2, o, params, nullptr, out_i, nullptr, mem, false);
+}
+
+djb_status djb_evalp_is_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
+                              const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_w,
+                              const djb_vec3_view *out_i, float *out_pdf, int mem)
+{
+	return sample_common(ctx, b, n, u1, u2, o, params, out_w, out_i, out_pdf, mem, true);
+}
+
+djb_status djb_sample_rng_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint32_t seed_u1, uint32_t seed_u2,
+                                uint64_t start, const djb_vec3_view *o, const djb_params *params,
+                                const djb_vec3_view *out_i)
+{
+	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
+	djb_status st = check_call(ctx, b, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	Params p;
+	if ((st = device_params(params, &p)) != DJB_OK) return st;
+	if (!Staged::valid(o) || !Staged::valid(out_i)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
+	View vo{ o->x, o->y, o->z, (long long)o->stride }, vi{ out_i->x, out_i->y, out_i->z, (long long)out_i->stride };
+	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, nullptr, nullptr, seed_u1, seed_u2, start, vo, vi, nullptr, nullptr));
+	return DJB_OK;
+}
+
+static djb_status hd_common(djb_ctx *ctx, int64_t n, const djb_vec3_view *a, const djb_vec3_view *b,
+                            const djb_vec3_view *c, const djb_vec3_view *d, int mem, bool inverse)
+{
+	djb_status st = check_call(ctx, nullptr, n, mem);
+	if (st != DJB_OK) return st;
+	Staged sg(ctx, n, mem);
+	View va, vb, vc, vd;
+	if ((st = sg.in_vec(a, &va)) != DJB_OK) return st;
+	if ((st = sg.in_vec(b, &vb)) != DJB_OK) return st;
+	if ((st = sg.out_vec(c, &vc)) != DJB_OK) return st;
+	if ((st = sg.out_vec(d, &vd)) != DJB_OK) return st;
+	HIP_TRY(djbk::launch_io_to_hd(ctx->stream, n, va, vb, vc, vd, inverse));
+	return sg.finish();
+}
+djb_status djb_io_to_hd_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
+                              const djb_vec3_view *h, const djb_vec3_view *d, int mem)
+{
+	return hd_common(ctx, n, i, o, h, d, mem, false);
+}
+djb_status djb_hd_to_io_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *h, const djb_vec3_view *d,
+                              const djb_vec3_view *i, const djb_vec3_view *o, int mem)
+{
+	return hd_common(ctx, n, h, d, i, o, mem, true);
+}
+
+djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
+                                int32_t *out_index, int mem)
+{
+	djb_status st = check_call(ctx, nullptr, n, mem);
+	if (st != DJB_OK) return st;
+	Staged sg(ctx, n, mem);
+	View vi, vo; int32_t *didx;
+	if ((st = sg.in_vec(i, &vi)) != DJB_OK) return st;
+	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
+	if ((st = sg.out_arr(out_index, &didx)) != DJB_OK) return st;
+	HIP_TRY(djbk::launch_merl_index(ctx->stream, n, vi, vo, didx));
+	return sg.finish();
+}
+
+djb_status djb_params_resolve(const djb_params *params, djb_params_resolved *out)
+{
+	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	return resolve_params(params, out);
+}
+
+// ---------------------------------------------------------------- synthetic workloads
+djb_status djb_gen_directions(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t start, const djb_vec3_view *out)
+{
+	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	if (!Staged::valid(out)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
+	HIP_TRY(djbk::launch_gen_directions(ctx->stream, n, seed, start, View{ out->x, out->y, out->z, (long long)out->stride }));
+	return DJB_OK;
+}
+djb_status djb_gen_uniforms(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t start, float *out)
+{
+	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null output array");
+	HIP_TRY(djbk::launch_gen_uniforms(ctx->stream, n, seed, start, out));
+	return DJB_OK;
+}
+djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int bins, unsigned long long *counts)
+{
+	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	if (!Staged::valid(v) || !counts || bins < 1 || bins > 128)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid histogram arguments");
+	HIP_TRY(djbk::launch_histogram_xy(ctx->stream, n, View{ v->x, v->y, v->z, (long long)v->stride }, bins, counts));
+	return DJB_OK;
+}
+
+} // extern "C"

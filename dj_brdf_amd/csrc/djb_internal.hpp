@@ -1,0 +1,56 @@
+// djb_internal.hpp -- launch interface between the C-ABI host code (djb_host.cpp) and the
+// gfx950 kernels (djb_kernels_*.hip).  Not installed; the public surface is include/djb_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "djb_device.hpp"
+
+namespace djbk {
+
+using djbdev::Brdf;
+using djbdev::Params;
+using djbdev::View;
+
+// WANT bits: 1 eval, 2 evalp, 4 pdf (1 and 2 are exclusive)
+hipError_t launch_eval(hipStream_t s, const Brdf &b, const Params &p, long long n,
+                       const View &i, const View &o, const View &out_fr, float *out_pdf, int want);
+
+// sample / evalp_is.  If u1 == nullptr the uniforms come from the on-chip counter RNG
+// (seed_u1, seed_u2, start); out_w / out_pdf may be null-views (sample only).
+hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long long n,
+                         const float *u1, const float *u2, uint32_t seed_u1, uint32_t seed_u2,
+                         unsigned long long start, const View &o, const View &out_i,
+                         const View *out_w, float *out_pdf);
+
+hipError_t launch_io_to_hd(hipStream_t s, long long n, const View &i, const View &o,
+                           const View &h, const View &d, bool inverse);
+hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const View &o, int32_t *idx);
+
+// MERL payload (3*n doubles) -> float4 table (pre-scaled, below-horizon zeroed); n = 1458000
+hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, float4 *table);
+// UTIA payload -> float(max(0, s) * double(1.f/140.f))
+hipError_t launch_utia_convert(hipStream_t s, const double *samples, long long n, float *table);
+
+hipError_t launch_gen_directions(hipStream_t s, long long n, uint32_t seed, unsigned long long start,
+                                 const View &out);
+hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsigned long long start,
+                               float *out);
+hipError_t launch_histogram_xy(hipStream_t s, long long n, const View &v, int bins,
+                               unsigned long long *counts);
+
+// ---- the power-iteration fitter (djb::tabular ctor + fits), one workgroup per material
+struct FitOut {           // device pointers, [n_mat][res] (fresnel [n_mat][res][3]); alphas [n_mat]
+	float *p22, *sigma, *cdf, *qf, *fresnel;
+	float *alpha_beckmann, *alpha_ggx;
+	int *n_qf;            // number of valid qf entries per material (reference quirk, dj_brdf.h:2731)
+};
+// srcs: device array of n_mat Brdf views (all of kind `src_kind`); std_p: params::standard().
+// km_scratch: n_mat*(res-1)^2 doubles; ratio_scratch: n_mat*(res-1)*res*3 floats.
+hipError_t launch_fit(hipStream_t s, const Brdf *srcs, int src_kind, const Params &std_p, int n_mat,
+                      int res, int shadow, double *km_scratch, float *ratio_scratch,
+                      const FitOut &out);
+size_t fit_lds_bytes(int res);
+
+} // namespace djbk

@@ -1,0 +1,290 @@
+// djb_kernels_eval.hip -- batch eval / evalp / pdf / sample / evalp_is kernels for gfx950.
+//
+// One (i, o) pair per lane, grid-stride over the batch; directions stream from HBM as
+// coalesced dword loads (SoA, stride 1) and results stream back the same way.  The BRDF
+// object and the microfacet parameters arrive as kernel arguments (SGPRs).  There is no
+// inter-lane communication: the path is elementwise (+ one cache-resident gather for MERL/UTIA).
+#include "djb_internal.hpp"
+
+using namespace djbdev;
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+inline int grid_for(long long n)
+{
+	long long blocks = (n + BLOCK - 1) / BLOCK;
+	const long long cap = 256LL * 16;   // 256 CUs x 16 resident workgroups' worth, grid-stride beyond
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	return (int)blocks;
+}
+
+template <int KIND, int WANT>
+DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float &pdf)
+{
+	if (KIND <= KIND_TABULAR) {
+		mf_eval_pdf<KIND, WANT>(b, p, i, o, fr, pdf);
+	} else {
+		if (WANT & 3) {
+			v3 e;
+			if (KIND == KIND_MERL) e = merl_eval(b, i, o);
+			else if (KIND == KIND_UTIA) e = utia_eval(b, i, o);
+			else e = divs(mk(1, 1, 1), F(DJB_PI));                 // lambert, dj_brdf.h:861-868
+			fr = (WANT & 2) ? scale(i.z, e) : e;                   // brdf::evalp, dj_brdf.h:803-806
+		}
+		if (WANT & 4) pdf = F(D(i.z) / DJB_PI);                    // brdf::pdf, dj_brdf.h:842-845
+	}
+}
+
+template <int KIND, int WANT>
+__global__ __launch_bounds__(BLOCK) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
+                                                View vout, float *out_pdf)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		v3 i = load3(vi, k), o = load3(vo, k);
+		v3 fr = mk(0, 0, 0); float pdf = 0.0f;
+		eval_one<KIND, WANT>(b, p, i, o, fr, pdf);
+		if (WANT & 3) store3(vout, k, fr);
+		if (WANT & 4) out_pdf[k] = pdf;
+	}
+}
+
+template <int KIND>
+hipError_t launch_eval_kind(hipStream_t s, const Brdf &b, const Params &p, long long n,
+                            const View &i, const View &o, const View &out, float *out_pdf, int want)
+{
+	dim3 g(grid_for(n)), t(BLOCK);
+	switch (want) {
+	case 1: hipLaunchKernelGGL((k_eval<KIND, 1>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 2: hipLaunchKernelGGL((k_eval<KIND, 2>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 4: hipLaunchKernelGGL((k_eval<KIND, 4>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 5: hipLaunchKernelGGL((k_eval<KIND, 5>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 6: hipLaunchKernelGGL((k_eval<KIND, 6>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ sample / evalp_is
+template <int KIND, bool IS, bool RNG>
+__global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n, const float *u1a,
+                                                  const float *u2a, uint32_t seed1, uint32_t seed2,
+                                                  unsigned long long start, View vo, View vi_out,
+                                                  View vw_out, float *out_pdf)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		float u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : u1a[k];
+		float u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : u2a[k];
+		v3 o = load3(vo, k);
+		if (KIND <= KIND_TABULAR) {
+			if (!IS) {
+				store3(vi_out, k, mf_sample<KIND>(b, p, u1, u2, o));
+			} else {
+				v3 i_out = mk(0, 0, 0); float pdf;
+				v3 w = mf_evalp_is<KIND>(b, p, u1, u2, o, i_out, pdf);
+				store3(vw_out, k, w); store3(vi_out, k, i_out); out_pdf[k] = pdf;
+			}
+		} else {
+			// brdf::sample / brdf::evalp_is defaults (cosine hemisphere), dj_brdf.h:816-845
+			float x, y;
+			uniform_to_concentric(u1, u2, x, y);
+			v3 i_ = mk(x, y, F(sqrt(1.0 - D(x * x) - D(y * y))));
+			store3(vi_out, k, i_);
+			if (IS) {
+				v3 fr; float pdf;
+				eval_one<KIND, 6>(b, p, i_, o, fr, pdf);
+				store3(vw_out, k, divs(fr, pdf));
+				out_pdf[k] = pdf;
+			}
+		}
+	}
+}
+
+template <int KIND>
+hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, long long n,
+                              const float *u1, const float *u2, uint32_t s1, uint32_t s2,
+                              unsigned long long start, const View &o, const View &out_i,
+                              const View *out_w, float *out_pdf)
+{
+	dim3 g(grid_for(n)), t(BLOCK);
+	View w = out_w ? *out_w : View{ nullptr, nullptr, nullptr, 0 };
+	bool is = out_w != nullptr, rng = u1 == nullptr;
+	if (!is && !rng) hipLaunchKernelGGL((k_sample<KIND, false, false>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
+	else if (!is && rng) hipLaunchKernelGGL((k_sample<KIND, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
+	else if (is && !rng) hipLaunchKernelGGL((k_sample<KIND, true, false>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
+	else hipLaunchKernelGGL((k_sample<KIND, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ small utilities
+template <bool INVERSE>
+__global__ __launch_bounds__(BLOCK) void k_io_hd(long long n, View a, View bb, View c, View d)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		v3 r1, r2;
+		if (!INVERSE) io_to_hd(load3(a, k), load3(bb, k), r1, r2);
+		else hd_to_io(load3(a, k), load3(bb, k), r1, r2);
+		store3(c, k, r1); store3(d, k, r2);
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_merl_index(long long n, View vi, View vo, int32_t *idx)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride)
+		idx[k] = merl_index(load3(vi, k), load3(vo, k));
+}
+
+// dj_brdf.h:1010-1023 applied once per table entry instead of once per lookup
+__global__ __launch_bounds__(BLOCK) void k_merl_convert(const double *s, long long n, float4 *table)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		float r = F(s[k] * (1.00 / 1500.0));
+		float g = F(s[k + n] * (1.15 / 1500.0));
+		float b = F(s[k + 2 * n] * (1.66 / 1500.0));
+		if (D(r) < 0.0 || D(g) < 0.0 || D(b) < 0.0) r = g = b = 0.0f;
+		table[k] = make_float4(r, g, b, 0.0f);
+	}
+}
+
+// utia::normalize (dj_brdf.h:1162-1177) then the (float_t) cast of dj_brdf.h:1144
+__global__ __launch_bounds__(BLOCK) void k_utia_convert(const double *s, long long n, float *table)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	const float kf = 1.f / 140.f;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		double v = s[k] > 0.0 ? s[k] : 0.0;
+		table[k] = F(v * D(kf));
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gen_dir(long long n, uint32_t seed, unsigned long long start, View out)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride)
+		store3(out, k, gen_direction(seed, start + (unsigned long long)k));
+}
+__global__ __launch_bounds__(BLOCK) void k_gen_uni(long long n, uint32_t seed, unsigned long long start, float *out)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride)
+		out[k] = gen_uniform(seed, start + (unsigned long long)k);
+}
+
+// bins x bins histogram over [-1,1]^2: LDS atomics, one global flush per workgroup
+__global__ __launch_bounds__(BLOCK) void k_hist_xy(long long n, View v, int bins, unsigned long long *counts)
+{
+	extern __shared__ unsigned int lds_hist[];
+	int nb = bins * bins;
+	for (int t = threadIdx.x; t < nb; t += BLOCK) lds_hist[t] = 0;
+	__syncthreads();
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		long long off = k * v.stride;
+		float x = v.x[off], y = v.y[off];
+		int bx = (int)((x + 1.0f) * 0.5f * (float)bins), by = (int)((y + 1.0f) * 0.5f * (float)bins);
+		bx = bx < 0 ? 0 : (bx >= bins ? bins - 1 : bx);
+		by = by < 0 ? 0 : (by >= bins ? bins - 1 : by);
+		atomicAdd(&lds_hist[by * bins + bx], 1u);
+	}
+	__syncthreads();
+	for (int t = threadIdx.x; t < nb; t += BLOCK)
+		if (lds_hist[t]) atomicAdd(&counts[t], (unsigned long long)lds_hist[t]);
+}
+
+} // namespace
+
+namespace djbk {
+
+hipError_t launch_eval(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i,
+                       const View &o, const View &out, float *out_pdf, int want)
+{
+	if (n <= 0) return hipSuccess;
+	switch (b.kind) {
+	case KIND_BECKMANN: return launch_eval_kind<KIND_BECKMANN>(s, b, p, n, i, o, out, out_pdf, want);
+	case KIND_GGX:      return launch_eval_kind<KIND_GGX>(s, b, p, n, i, o, out, out_pdf, want);
+	case KIND_TABULAR:  return launch_eval_kind<KIND_TABULAR>(s, b, p, n, i, o, out, out_pdf, want);
+	case KIND_MERL:     return launch_eval_kind<KIND_MERL>(s, b, p, n, i, o, out, out_pdf, want);
+	case KIND_UTIA:     return launch_eval_kind<KIND_UTIA>(s, b, p, n, i, o, out, out_pdf, want);
+	case KIND_LAMBERT:  return launch_eval_kind<KIND_LAMBERT>(s, b, p, n, i, o, out, out_pdf, want);
+	}
+	return hipErrorInvalidValue;
+}
+
+hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long long n, const float *u1,
+                         const float *u2, uint32_t s1, uint32_t s2, unsigned long long start,
+                         const View &o, const View &out_i, const View *out_w, float *out_pdf)
+{
+	if (n <= 0) return hipSuccess;
+	switch (b.kind) {
+	case KIND_BECKMANN: return launch_sample_kind<KIND_BECKMANN>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_GGX:      return launch_sample_kind<KIND_GGX>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_TABULAR:  return launch_sample_kind<KIND_TABULAR>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_MERL:     return launch_sample_kind<KIND_MERL>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_UTIA:     return launch_sample_kind<KIND_UTIA>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_LAMBERT:  return launch_sample_kind<KIND_LAMBERT>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	}
+	return hipErrorInvalidValue;
+}
+
+hipError_t launch_io_to_hd(hipStream_t s, long long n, const View &a, const View &b, const View &c,
+                           const View &d, bool inverse)
+{
+	if (n <= 0) return hipSuccess;
+	dim3 g(grid_for(n)), t(BLOCK);
+	if (!inverse) hipLaunchKernelGGL((k_io_hd<false>), g, t, 0, s, n, a, b, c, d);
+	else hipLaunchKernelGGL((k_io_hd<true>), g, t, 0, s, n, a, b, c, d);
+	return hipGetLastError();
+}
+
+hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const View &o, int32_t *idx)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_merl_index, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, i, o, idx);
+	return hipGetLastError();
+}
+
+hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, float4 *table)
+{
+	hipLaunchKernelGGL(k_merl_convert, dim3(grid_for(n)), dim3(BLOCK), 0, s, samples, n, table);
+	return hipGetLastError();
+}
+
+hipError_t launch_utia_convert(hipStream_t s, const double *samples, long long n, float *table)
+{
+	hipLaunchKernelGGL(k_utia_convert, dim3(grid_for(n)), dim3(BLOCK), 0, s, samples, n, table);
+	return hipGetLastError();
+}
+
+hipError_t launch_gen_directions(hipStream_t s, long long n, uint32_t seed, unsigned long long start,
+                                 const View &out)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_gen_dir, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, seed, start, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsigned long long start,
+                               float *out)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_gen_uni, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, seed, start, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_histogram_xy(hipStream_t s, long long n, const View &v, int bins,
+                               unsigned long long *counts)
+{
+	if (n <= 0) return hipSuccess;
+	size_t lds = sizeof(unsigned int) * (size_t)bins * bins;
+	hipLaunchKernelGGL(k_hist_xy, dim3(grid_for(n)), dim3(BLOCK), lds, s, n, v, bins, counts);
+	return hipGetLastError();
+}
+
+} // namespace djbk

@@ -1,0 +1,353 @@
+// djb_kernels_fit.hip -- the power-iteration fitter on gfx950:
+//   djb::tabular::tabular(brdf, res, shadow)                        dj_brdf.h:2215-2236
+//   tabular::fit_beckmann_parameters / fit_ggx_parameters           dj_brdf.h:3133-3184
+//
+// One 512-thread workgroup (8 wave64s) per material; materials are independent, so a batch of M
+// materials is a grid of M workgroups and a multi-GPU batch is a partition of the material list.
+//
+// The reference accumulates its quadratures in float, in loop order.  Float addition does not
+// commute with a tree reduction, so to reproduce the reference's tables (and the %.3f digits of
+// params.txt) every *sum* keeps the reference's order: the expensive per-term work (libm-class
+// transcendentals, MERL look-ups, spline fetches) is spread over all 512 lanes and staged in LDS,
+// then the lane that owns a row adds its terms front to back.  Rows (theta_k, theta_d, theta_o)
+// are independent and map to lanes; wave64 lanes of one row-owner wave broadcast-read the shared
+// per-node tables from LDS.  No MFMA: the only matrix product is an (res-1)^2 matvec in double,
+// four times (dj_brdf.h:2467-2480), whose summation order is likewise kept.
+#include "djb_internal.hpp"
+
+using namespace djbdev;
+
+namespace {
+
+constexpr int FIT_BLOCK = 512;
+constexpr int NTHETA_SIGMA = 90, NPHI_SIGMA = 180;      // dj_brdf.h:2350-2351
+constexpr int NNODE_SIGMA = NTHETA_SIGMA * NPHI_SIGMA;
+constexpr int NTHETA_FIT = 128;                          // dj_brdf.h:2279, 3135, 3162
+constexpr int MAX_PHI_STEPS = 512;
+
+struct LdsPlan {   // byte offsets into dynamic LDS (doubles first: 8-byte aligned)
+	int v0, v1, cphid, cthd;                 // doubles
+	int p22, sigma, cdf, qf, fres;           // floats (fres: 3 per entry)
+	int theta, cosv, tanv, kji;              // floats [cnt]
+	int cphi;                                // floats [MAX_PHI_STEPS]
+	int ndf;                                 // floats [16200]
+	int sh, ui;                              // floats [90]
+	int terms;                               // floats [2*128]
+	int qprobe;                              // floats [8*cnt]
+	int total;
+};
+
+__host__ __device__ inline LdsPlan make_plan(int res)
+{
+	LdsPlan p; int cnt = res - 1, off = 0;
+	auto take = [&](int bytes) { int o = off; off += (bytes + 15) & ~15; return o; };
+	p.v0 = take(8 * cnt); p.v1 = take(8 * cnt);
+	p.cphid = take(8 * NPHI_SIGMA); p.cthd = take(8 * NTHETA_SIGMA);
+	p.p22 = take(4 * res); p.sigma = take(4 * res); p.cdf = take(4 * res); p.qf = take(4 * res);
+	p.fres = take(12 * res);
+	p.theta = take(4 * cnt); p.cosv = take(4 * cnt); p.tanv = take(4 * cnt); p.kji = take(4 * cnt);
+	p.cphi = take(4 * MAX_PHI_STEPS);
+	p.ndf = take(4 * NNODE_SIGMA);
+	p.sh = take(4 * NTHETA_SIGMA); p.ui = take(4 * NTHETA_SIGMA);
+	p.terms = take(4 * 2 * NTHETA_FIT);
+	p.qprobe = take(4 * 8 * cnt);
+	p.total = off;
+	return p;
+}
+
+template <int SRC>
+DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o)
+{
+	v3 fr = mk(0, 0, 0); float pdf;
+	if (SRC <= KIND_TABULAR) mf_eval_pdf<SRC, 1>(src, std_p, i, o, fr, pdf);
+	else if (SRC == KIND_MERL) fr = merl_eval(src, i, o);
+	else if (SRC == KIND_UTIA) fr = utia_eval(src, i, o);
+	else fr = divs(mk(1, 1, 1), F(DJB_PI));
+	(void)pdf;
+	return fr;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_p, int res, int shadow,
+                                                   double *km_scratch, float *ratio_scratch,
+                                                   djbk::FitOut out)
+{
+	extern __shared__ __align__(16) unsigned char lds[];
+	const int m = blockIdx.x, tid = threadIdx.x, cnt = res - 1;
+	const LdsPlan P = make_plan(res);
+	double *v0 = (double *)(lds + P.v0), *v1 = (double *)(lds + P.v1);
+	double *cphid = (double *)(lds + P.cphid), *cthd = (double *)(lds + P.cthd);
+	float *p22 = (float *)(lds + P.p22), *sigma = (float *)(lds + P.sigma);
+	float *cdf = (float *)(lds + P.cdf), *qf = (float *)(lds + P.qf), *fres = (float *)(lds + P.fres);
+	float *theta = (float *)(lds + P.theta), *cosv = (float *)(lds + P.cosv);
+	float *tanv = (float *)(lds + P.tanv), *kji = (float *)(lds + P.kji);
+	float *cphi = (float *)(lds + P.cphi), *ndf_tab = (float *)(lds + P.ndf);
+	float *sh = (float *)(lds + P.sh), *ui = (float *)(lds + P.ui);
+	float *terms = (float *)(lds + P.terms), *qprobe = (float *)(lds + P.qprobe);
+	__shared__ int s_nphi, s_nqf;
+	__shared__ float s_scale;
+
+	const Brdf src = srcs[m];
+	double *kmT = km_scratch + (size_t)m * cnt * cnt;            // kmT[theta_h][theta_o]
+	float *ratio = ratio_scratch + (size_t)m * cnt * (cnt + 1) * 3;
+
+	// the object under construction: tabular NDF, ideal Fresnel until compute_fresnel finishes
+	Brdf self;
+	self.kind = KIND_TABULAR; self.shadow = shadow;
+	self.fr.kind = FR_IDEAL; self.fr.pts = nullptr; self.fr.npts = 0;
+	self.p22 = p22; self.sigma = sigma; self.cdf = cdf; self.qf = qf;
+	self.n_p22 = res; self.n_sigma = res; self.n_cdf = res; self.n_qf = res;
+	self.merl = nullptr; self.utia = nullptr;
+
+	// ================================================================ compute_p22_smith (dj_brdf.h:2482-2522)
+	const float dtheta_k = F(sqrt(DJB_PI * 0.5) / D((float)cnt));
+	const float dphi_h = F(DJB_PI / 180.0);
+	if (tid == 0) {   // the float-stepped phi loop (361 steps for dphi = pi/180): same phi values
+		int c = 0;
+		for (float phi = 0.0f; D(phi) < 2.0 * DJB_PI && c < MAX_PHI_STEPS; phi += dphi_h) cphi[c++] = phi;
+		s_nphi = c;
+	}
+	for (int k = tid; k < cnt; k += FIT_BLOCK) {
+		float tmp = (float)k / (float)cnt;
+		float th = F(D(tmp) * sqrt(DJB_PI * 0.5));
+		float th2 = th * th;
+		float c = F(cos(D(th2))), t = F(tan(D(th2)));
+		theta[k] = th; cosv[k] = c; tanv[k] = t;
+		v3 w = from_angles(th2, 0.0f);
+		float fr_i = intensity(src_eval<SRC>(src, std_p, w, w));
+		kji[k] = F((D(dtheta_k) * pow(D(c), D(6.0f))) * (8.0 * D(fr_i)));
+		v0[k] = 1.0;
+	}
+	__syncthreads();
+	const int nphi = s_nphi;
+	for (int k = tid; k < nphi; k += FIT_BLOCK) cphi[k] = F(cos(D(cphi[k])));
+	__syncthreads();
+	for (int e = tid; e < cnt * cnt; e += FIT_BLOCK) {
+		int io = e / cnt, jh = e - io * cnt;          // io: theta_o index, jh: theta_h index
+		float tan_product = tanv[jh] * tanv[io];
+		float nint = 0.0f;
+		for (int q = 0; q < nphi; ++q) nint += fmax_(1.0f, tan_product * cphi[q]);
+		nint *= dphi_h;
+		float ch = cosv[jh];
+		kmT[(size_t)jh * cnt + io] = D(theta[jh] * kji[io] * nint * tanv[jh] / (ch * ch));
+	}
+	__threadfence_block();
+	__syncthreads();
+	// matrix::eigenvector(4): 4 un-normalised matvecs from ones, row sums in index order
+	for (int it = 0; it < 4; ++it) {
+		double *vin = (it & 1) ? v1 : v0, *vout = (it & 1) ? v0 : v1;
+		for (int j = tid; j < cnt; j += FIT_BLOCK) {
+			double acc = 0.0;
+			for (int i = 0; i < cnt; ++i) acc += kmT[(size_t)i * cnt + j] * vin[i];
+			vout[j] = acc;
+		}
+		__syncthreads();
+	}
+	for (int k = tid; k < res; k += FIT_BLOCK) p22[k] = k < cnt ? F(1e-2 * v0[k]) : 0.0f;
+	__syncthreads();
+
+	// ================================================================ normalize_p22 (dj_brdf.h:2277-2304)
+	for (int k = tid; k < NTHETA_FIT; k += FIT_BLOCK) {
+		float u = (float)k / (float)NTHETA_FIT;
+		float th = F(D(u * u) * DJB_PI * 0.5);
+		float r = F(tan(D(th))), c = F(cos(D(th)));
+		float pr = p22_radial<KIND_TABULAR>(self, r * r);
+		terms[k] = (u * pr * r) / (c * c);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		float nint = 0.0f;
+		for (int k = 0; k < NTHETA_FIT; ++k) nint += terms[k];
+		nint *= F(DJB_PI / D((float)NTHETA_FIT)) * F(2.0 * DJB_PI);
+		s_scale = F(1.0 / D(nint));
+	}
+	__syncthreads();
+	for (int k = tid; k < res; k += FIT_BLOCK) p22[k] *= s_scale;
+	__syncthreads();
+
+	// ================================================================ compute_sigma (dj_brdf.h:2348-2386)
+	for (int k = tid; k < NPHI_SIGMA; k += FIT_BLOCK)
+		cphid[k] = cos(D(F(D((float)k / (float)NPHI_SIGMA) * 2.0 * DJB_PI)));
+	for (int k = tid; k < NTHETA_SIGMA; k += FIT_BLOCK) {
+		float u = (float)k / (float)NTHETA_SIGMA;
+		float th = F(D(u * u) * DJB_PI * 0.5);
+		ui[k] = u; sh[k] = F(sin(D(th))); cthd[k] = cos(D(th));
+	}
+	for (int e = tid; e < NNODE_SIGMA; e += FIT_BLOCK) {   // ndf(vec3(theta_h, phi_h)): theta_k-independent
+		int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
+		float phi_h = F(D((float)j2 / (float)NPHI_SIGMA) * 2.0 * DJB_PI);
+		float u = (float)j1 / (float)NTHETA_SIGMA;
+		float th = F(D(u * u) * DJB_PI * 0.5);
+		ndf_tab[e] = mf_ndf<KIND_TABULAR>(self, from_angles(th, phi_h), std_p);
+	}
+	__syncthreads();
+	{
+		const float dth = F(DJB_PI / D((float)NTHETA_SIGMA));
+		const float dph = F(2.0 * DJB_PI / D((float)NPHI_SIGMA));
+		for (int k = tid; k < cnt; k += FIT_BLOCK) {
+			float tmp = (float)k / (float)cnt;
+			float theta_k = F(D(tmp) * 0.5 * DJB_PI);
+			float ck = F(cos(D(theta_k))), sk = F(sin(D(theta_k)));
+			float nint = 0.0f;
+			for (int j2 = 0; j2 < NPHI_SIGMA; ++j2) {
+				double cp = cphid[j2];
+				for (int j1 = 0; j1 < NTHETA_SIGMA; ++j1) {
+					float s1 = sh[j1];
+					float kh = F(D(sk * s1) * cp + D(ck) * cthd[j1]);
+					nint += fmax_(0.0f, kh) * ndf_tab[j2 * NTHETA_SIGMA + j1] * ui[j1] * s1;
+				}
+			}
+			nint *= dth * dph;
+			sigma[k] = fmax_(ck, nint);
+		}
+	}
+	__syncthreads();
+	if (tid == 0) sigma[cnt] = sigma[cnt - 1];
+	__syncthreads();
+
+	// ================================================================ compute_fresnel (dj_brdf.h:2583-2641)
+	// pair (i, j) runs iff theta_h(j-1) < pi/2 - theta_d(i)   (theta_h(-1) := 0)
+	for (int e = tid; e < cnt * (cnt + 1); e += FIT_BLOCK) {
+		int i = e / (cnt + 1), j = e - i * (cnt + 1);
+		float theta_d = F(D((float)i / (float)cnt) * DJB_PI * 0.5);
+		float prev = 0.0f;
+		if (j > 0) { float t1 = (float)(j - 1) / (float)cnt; prev = F(D(t1 * t1) * DJB_PI * 0.5); }
+		float t1 = (float)j / (float)cnt;
+		float theta_h = F(D(t1 * t1) * DJB_PI * 0.5);
+		const float qnan = __builtin_nanf("");
+		float rx = qnan, ry = qnan, rz = qnan;
+		if (D(prev) < DJB_PI * 0.5 - D(theta_d) && !(D(theta_h) > DJB_PI * 0.5)) {
+			v3 dir_h = from_angles(theta_h, 0.0f), dir_d = from_angles(theta_d, F(DJB_PI * 0.5));
+			v3 dir_i, dir_o;
+			hd_to_io(dir_h, dir_d, dir_i, dir_o);
+			dir_i = mk(0, 0, 1);                        // dj_brdf.h:2609
+			v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o);
+			v3 fr2; float pdf;
+			mf_eval_pdf<KIND_TABULAR, 1>(self, std_p, dir_i, dir_o, fr2, pdf);
+			if (D(fr2.x) > 1e-4) rx = fr1.x / fr2.x;
+			if (D(fr2.y) > 1e-4) ry = fr1.y / fr2.y;
+			if (D(fr2.z) > 1e-4) rz = fr1.z / fr2.z;
+		}
+		ratio[3 * (size_t)e] = rx; ratio[3 * (size_t)e + 1] = ry; ratio[3 * (size_t)e + 2] = rz;
+	}
+	__threadfence_block();
+	__syncthreads();
+	for (int i = tid; i < cnt; i += FIT_BLOCK) {
+		float fx = 0, fy = 0, fz = 0; int cx = 0, cy = 0, cz = 0;
+		for (int j = 0; j <= cnt; ++j) {
+			const float *r = ratio + 3 * ((size_t)i * (cnt + 1) + j);
+			float rx = r[0], ry = r[1], rz = r[2];
+			if (rx == rx) { fx += rx; ++cx; }
+			if (ry == ry) { fy += ry; ++cy; }
+			if (rz == rz) { fz += rz; ++cz; }
+		}
+		fres[3 * i] = cx == 0 ? 1.0f : fmin_(1.0f, fx / (float)cx);
+		fres[3 * i + 1] = cy == 0 ? 1.0f : fmin_(1.0f, fy / (float)cy);
+		fres[3 * i + 2] = cz == 0 ? 1.0f : fmin_(1.0f, fz / (float)cz);
+	}
+	__syncthreads();
+	if (tid < 3) fres[3 * cnt + tid] = fres[3 * (cnt - 1) + tid];
+	__syncthreads();
+
+	// ================================================================ compute_cdf (dj_brdf.h:2705-2727)
+	for (int k = tid; k < cnt; k += FIT_BLOCK) {
+		float u = (float)k / (float)cnt;
+		float th = F(D(u * u) * DJB_PI * 0.5);
+		float c = F(cos(D(th))), r = F(tan(D(th)));
+		float pr = p22_radial<KIND_TABULAR>(self, r * r);
+		qprobe[k] = (u * r * pr) / (c * c);       // staging (qprobe has 8*cnt slots)
+	}
+	__syncthreads();
+	if (tid == 0) {
+		const float dth = F(DJB_PI / D((float)cnt));
+		float nint = 0.0f;
+		for (int k = 0; k < cnt; ++k) { nint += qprobe[k]; cdf[k] = F(D(nint * dth) * (2.0 * DJB_PI)); }
+		cdf[cnt] = 1.0f;
+	}
+	__syncthreads();
+
+	// ================================================================ compute_qf (dj_brdf.h:2731-2762)
+	const int qres = cnt * 8;
+	for (int j = tid; j < qres; j += FIT_BLOCK) {
+		float u = (float)j / (float)qres;
+		float th = F(D(u) * DJB_PI * 0.5);
+		qprobe[j] = tab_cdf_radial(self, F(tan(D(th))));
+	}
+	__syncthreads();
+	if (tid == 0) {   // forward scan; j persists across i (dj_brdf.h:2735)
+		int nq = 0, j = 0;
+		qf[nq++] = 0.0f;
+		for (int i = 1; i < cnt; ++i) {
+			float c = (float)i / (float)cnt;
+			for (; j < qres; ++j)
+				if (qprobe[j] >= c) { qf[nq++] = (float)j / (float)qres; break; }
+		}
+		qf[nq++] = 1.0f;
+		s_nqf = nq;
+		for (int k = nq; k < res; ++k) qf[k] = 0.0f;
+	}
+	__syncthreads();
+
+	// ================================================================ fits (dj_brdf.h:3133-3184)
+	for (int k = tid; k < NTHETA_FIT; k += FIT_BLOCK) {
+		float u = (float)k / (float)NTHETA_FIT;
+		float th = F(D(u * u) * DJB_PI * 0.5);
+		float c = F(cos(D(th))), r = F(tan(D(th)));
+		float r2 = r * r;
+		float pr = p22_radial<KIND_TABULAR>(self, r2);
+		terms[k] = (u * r2 * r * pr) / (c * c);
+		terms[NTHETA_FIT + k] = (u * r2 * pr) / (c * c);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		const float dth = F(DJB_PI / D((float)NTHETA_FIT));
+		float nb = 0.0f, ng = 0.0f;
+		for (int k = 0; k < NTHETA_FIT; ++k) { nb += terms[k]; ng += terms[NTHETA_FIT + k]; }
+		nb = F(D(nb) * (D(dth) * DJB_PI));
+		ng = F(D(ng) * (D(dth) * 4.0));
+		out.alpha_beckmann[m] = F(sqrt(2.0 * D(nb)));
+		out.alpha_ggx[m] = ng;
+		out.n_qf[m] = s_nqf;
+	}
+	for (int k = tid; k < res; k += FIT_BLOCK) {
+		size_t o = (size_t)m * res + k;
+		out.p22[o] = p22[k]; out.sigma[o] = sigma[k]; out.cdf[o] = cdf[k]; out.qf[o] = qf[k];
+		out.fresnel[3 * o] = fres[3 * k]; out.fresnel[3 * o + 1] = fres[3 * k + 1];
+		out.fresnel[3 * o + 2] = fres[3 * k + 2];
+	}
+}
+
+template <int SRC>
+hipError_t launch_fit_kind(hipStream_t s, const Brdf *srcs, const Params &std_p, int n_mat, int res,
+                           int shadow, double *km, float *ratio, const djbk::FitOut &out)
+{
+	size_t lds = (size_t)make_plan(res).total;
+	hipError_t e = hipFuncSetAttribute((const void *)k_fit<SRC>,
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_fit<SRC>), dim3(n_mat), dim3(FIT_BLOCK), lds, s, srcs, std_p, res, shadow,
+	                   km, ratio, out);
+	return hipGetLastError();
+}
+
+} // namespace
+
+namespace djbk {
+
+size_t fit_lds_bytes(int res) { return (size_t)make_plan(res).total; }
+
+hipError_t launch_fit(hipStream_t s, const Brdf *srcs, int src_kind, const Params &std_p, int n_mat,
+                      int res, int shadow, double *km, float *ratio, const FitOut &out)
+{
+	switch (src_kind) {
+	case KIND_BECKMANN: return launch_fit_kind<KIND_BECKMANN>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_GGX:      return launch_fit_kind<KIND_GGX>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_TABULAR:  return launch_fit_kind<KIND_TABULAR>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_MERL:     return launch_fit_kind<KIND_MERL>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_UTIA:     return launch_fit_kind<KIND_UTIA>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_LAMBERT:  return launch_fit_kind<KIND_LAMBERT>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	}
+	return hipErrorInvalidValue;
+}
+
+} // namespace djbk

@@ -1,0 +1,582 @@
+"""Host-side mirror of the reference's operator interface (namespace ``djb``, dj_brdf.h:41-537)
+for the hot path, on top of the C ABI in include/djb_hip.h.
+
+Same names and argument meaning as the reference: ``brdf.eval(i, o, user_param)``,
+``evalp``, ``pdf``, ``sample(u1, u2, o, user_param)``, ``evalp_is``, ``brdf.io_to_hd`` /
+``hd_to_io``; ``merl(filename)``, ``utia(filename)``, ``beckmann(fresnel, shadow)``,
+``ggx(fresnel, shadow)``, ``tabular(brdf, res, shadow)`` with ``fit_beckmann_parameters`` /
+``fit_ggx_parameters`` / ``get_p22v`` ...; ``microfacet.params.{standard,isotropic,elliptic,
+pdfparams}``; ``fresnel.{ideal,unpolarized,schlick,sgd,spline}``; errors raise ``exc``.
+The one difference is cardinality: every direction argument is a BATCH.
+
+Array conventions
+  * numpy float32 ``[n, 3]`` (array of djb::vec3) or ``[3, n]`` (SoA): host memory, staged
+    through HBM by the library; results come back as numpy in the same layout.
+  * torch CUDA float32 tensors of the same shapes: device memory, zero-copy, asynchronous on
+    torch's current stream; results are torch tensors on the same device.  ``[3, n]`` is the
+    coalesced fast path.
+All arithmetic happens in the HIP kernels; nothing here evaluates a BRDF on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import exc  # noqa: F401  (re-export: djb.exc)
+
+try:  # plumbing only: device memory + streams
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+# --------------------------------------------------------------------------- context
+class Context:
+    """One GPU + one HIP stream (``djb_ctx``).  With torch present the ctx runs on torch's
+    current stream of that device, so torch events/synchronisation see the kernels."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        lib = _lib.load()
+        self.device = device
+        if stream is None and torch is not None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(device).cuda_stream
+        self._h = C.c_void_p()
+        _lib.check(lib.djb_ctx_create(C.c_int(device), C.c_void_p(stream or 0), C.byref(self._h)))
+
+    def synchronize(self):
+        _lib.check(_lib.load().djb_ctx_synchronize(self._h))
+
+    def timer_start(self):
+        _lib.check(_lib.load().djb_timer_start(self._h))
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        _lib.check(_lib.load().djb_timer_stop_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            _lib.load().djb_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def device_count() -> int:
+    n = C.c_int()
+    st = _lib.load().djb_device_count(C.byref(n))
+    return n.value if st == 0 else 0
+
+
+# --------------------------------------------------------------------------- array plumbing
+class _Vec:
+    """A vec3 batch resolved to (view, memory space, n, how to build a like-shaped output)."""
+
+    def __init__(self, a, n_hint=None):
+        self.is_torch = torch is not None and isinstance(a, torch.Tensor)
+        if self.is_torch and not a.is_cuda:
+            a = a.numpy()
+            self.is_torch = False
+        if self.is_torch:
+            if a.dtype != torch.float32:
+                a = a.float()
+            a = a.contiguous()
+            shape = tuple(a.shape)
+            base, itemsz = a.data_ptr(), 4
+            self.mem = _lib.MEM_DEVICE
+            self.device = a.device
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = a.shape
+            base, itemsz = a.ctypes.data, 4
+            self.mem = _lib.MEM_HOST
+            self.device = None
+        if len(shape) != 2 or (shape[1] != 3 and shape[0] != 3):
+            raise exc(1, f"djb_error: expected a [n,3] or [3,n] float32 array, got {shape}")
+        self.aos = shape[1] == 3
+        self.n = shape[0] if self.aos else shape[1]
+        self.keep = a
+        v = _lib.Vec3View()
+        if self.aos:
+            v.x, v.y, v.z, v.stride = base, base + itemsz, base + 2 * itemsz, 3
+        else:
+            v.x, v.y, v.z, v.stride = base, base + itemsz * self.n, base + 2 * itemsz * self.n, 1
+        self.view = v
+
+    def like(self):
+        """An uninitialised output batch with the same framework / layout / device."""
+        shape = (self.n, 3) if self.aos else (3, self.n)
+        if self.is_torch:
+            return _Vec(torch.empty(shape, dtype=torch.float32, device=self.device))
+        return _Vec(np.empty(shape, dtype=np.float32))
+
+    def scalars(self, dtype=np.float32):
+        if self.is_torch:
+            tdt = torch.float32 if dtype == np.float32 else torch.int32
+            t = torch.empty((self.n,), dtype=tdt, device=self.device)
+            return t, t.data_ptr()
+        a = np.empty((self.n,), dtype=dtype)
+        return a, a.ctypes.data
+
+
+def _scalar_in(u, like: _Vec):
+    if like.is_torch:
+        if not (torch is not None and isinstance(u, torch.Tensor) and u.is_cuda):
+            u = torch.as_tensor(np.asarray(u, dtype=np.float32), device=like.device)
+        u = u.float().contiguous()
+        return u, u.data_ptr()
+    u = np.ascontiguousarray(u, dtype=np.float32)
+    return u, u.ctypes.data
+
+
+# --------------------------------------------------------------------------- fresnel (dj_brdf.h:149-207)
+class fresnel:
+    class impl:
+        kind = 0
+
+        def _desc(self):
+            d = _lib.FresnelDesc()
+            d.kind = self.kind
+            return d, None
+
+    class ideal(impl):
+        kind = 0
+
+    class unpolarized(impl):
+        kind = 1
+
+        def __init__(self, ior: Sequence[float]):
+            self.ior = tuple(float(x) for x in ior)
+
+        def _desc(self):
+            d, _ = super()._desc()
+            d.a[:] = self.ior
+            return d, None
+
+    class schlick(impl):
+        kind = 2
+
+        def __init__(self, f0: Sequence[float]):
+            self.f0 = tuple(float(x) for x in f0)
+
+        def _desc(self):
+            d, _ = super()._desc()
+            d.a[:] = self.f0
+            return d, None
+
+    class sgd(impl):
+        kind = 3
+
+        def __init__(self, f0: Sequence[float], f1: Sequence[float]):
+            self.f0, self.f1 = tuple(map(float, f0)), tuple(map(float, f1))
+
+        def _desc(self):
+            d, _ = super()._desc()
+            d.a[:] = self.f0
+            d.b[:] = self.f1
+            return d, None
+
+    class spline(impl):
+        kind = 4
+
+        def __init__(self, points):
+            self.points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+
+        def get_points(self):
+            return self.points
+
+        def _desc(self):
+            d, _ = super()._desc()
+            d.points = self.points.ctypes.data
+            d.npoints = self.points.shape[0]
+            return d, self.points
+
+    @staticmethod
+    def ior_to_f0(ior):  # dj_brdf.h:1255-1262
+        ior = np.asarray(ior, dtype=np.float32)
+        tmp = ((ior.astype(np.float64) - 1.0) / (ior.astype(np.float64) + 1.0)).astype(np.float32)
+        return tmp * tmp
+
+    @staticmethod
+    def f0_to_ior(f0):  # dj_brdf.h:1272-1282
+        f0 = np.asarray(f0, dtype=np.float32)
+        s = np.sqrt(f0.astype(np.float64)).astype(np.float32).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out = ((1.0 + s) / (1.0 - s)).astype(np.float32)
+        return np.where(f0 == 1.0, np.float32(1.0), out)
+
+
+# --------------------------------------------------------------------------- brdf base (dj_brdf.h:74-109)
+class brdf:
+    def __init__(self, ctx: Optional[Context]):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+
+    # ---- operator surface
+    def _eval(self, fn_name, i, o, user_param, want_pdf=False, want_fr=True, want_cos=0):
+        lib = _lib.load()
+        vi, vo = _Vec(i), _Vec(o)
+        if vi.n != vo.n or vi.mem != vo.mem:
+            raise exc(1, "djb_error: i and o must have the same length and memory space")
+        p = _params_ptr(user_param)
+        out = vi.like() if want_fr else None
+        pdf = pdf_ptr = None
+        if want_pdf:
+            pdf, pdf_ptr = vi.scalars()
+        n = C.c_int64(vi.n)
+        if fn_name == "djb_pdf_batch":
+            st = lib.djb_pdf_batch(self.ctx._h, self._h, n, C.byref(vi.view), C.byref(vo.view), p,
+                                   C.c_void_p(pdf_ptr), C.c_int(vi.mem))
+        elif fn_name == "djb_eval_pdf_batch":
+            st = lib.djb_eval_pdf_batch(self.ctx._h, self._h, n, C.byref(vi.view), C.byref(vo.view), p,
+                                        C.c_int(want_cos), C.byref(out.view), C.c_void_p(pdf_ptr),
+                                        C.c_int(vi.mem))
+        else:
+            st = getattr(lib, fn_name)(self.ctx._h, self._h, n, C.byref(vi.view), C.byref(vo.view), p,
+                                       C.byref(out.view), C.c_int(vi.mem))
+        _lib.check(st)
+        if want_fr and want_pdf:
+            return out.keep, pdf
+        return out.keep if want_fr else pdf
+
+    def eval(self, i, o, user_param=None):
+        """f_r for every pair (dj_brdf.h:77-78)."""
+        return self._eval("djb_eval_batch", i, o, user_param)
+
+    def evalp(self, i, o, user_param=None):
+        """f_r * cos(theta_i) (dj_brdf.h:82-83)."""
+        return self._eval("djb_evalp_batch", i, o, user_param)
+
+    def pdf(self, i, o, user_param=None):
+        """pdf of sampling i given o (dj_brdf.h:96-97)."""
+        return self._eval("djb_pdf_batch", i, o, user_param, want_pdf=True, want_fr=False)
+
+    def eval_pdf(self, i, o, user_param=None, cos=False):
+        """eval (or evalp) and pdf in one pass over HBM."""
+        return self._eval("djb_eval_pdf_batch", i, o, user_param, want_pdf=True, want_cos=int(cos))
+
+    def sample(self, u1, u2, o, user_param=None):
+        """importance-sample i from two uniform numbers per element (dj_brdf.h:92-94)."""
+        lib = _lib.load()
+        vo = _Vec(o)
+        k1, p1 = _scalar_in(u1, vo)
+        k2, p2 = _scalar_in(u2, vo)
+        out = vo.like()
+        _lib.check(lib.djb_sample_batch(self.ctx._h, self._h, C.c_int64(vo.n), C.c_void_p(p1), C.c_void_p(p2),
+                                        C.byref(vo.view), _params_ptr(user_param), C.byref(out.view),
+                                        C.c_int(vo.mem)))
+        del k1, k2
+        return out.keep
+
+    def sample_rng(self, seed_u1: int, seed_u2: int, o, user_param=None, start: int = 0):
+        """sample() with the uniforms drawn on chip (device arrays only)."""
+        lib = _lib.load()
+        vo = _Vec(o)
+        if vo.mem != _lib.MEM_DEVICE:
+            raise exc(1, "djb_error: sample_rng needs device arrays")
+        out = vo.like()
+        _lib.check(lib.djb_sample_rng_batch(self.ctx._h, self._h, C.c_int64(vo.n), C.c_uint32(seed_u1),
+                                            C.c_uint32(seed_u2), C.c_uint64(start), C.byref(vo.view),
+                                            _params_ptr(user_param), C.byref(out.view)))
+        return out.keep
+
+    def evalp_is(self, u1, u2, o, user_param=None):
+        """(f_r cos / pdf, i, pdf) (dj_brdf.h:87-90)."""
+        lib = _lib.load()
+        vo = _Vec(o)
+        k1, p1 = _scalar_in(u1, vo)
+        k2, p2 = _scalar_in(u2, vo)
+        w, i = vo.like(), vo.like()
+        pdf, pdf_ptr = vo.scalars()
+        _lib.check(lib.djb_evalp_is_batch(self.ctx._h, self._h, C.c_int64(vo.n), C.c_void_p(p1), C.c_void_p(p2),
+                                          C.byref(vo.view), _params_ptr(user_param), C.byref(w.view),
+                                          C.byref(i.view), C.c_void_p(pdf_ptr), C.c_int(vo.mem)))
+        del k1, k2
+        return w.keep, i.keep, pdf
+
+    # ---- static utilities (dj_brdf.h:99-100)
+    @staticmethod
+    def io_to_hd(i, o, ctx: Optional[Context] = None):
+        return _hd("djb_io_to_hd_batch", i, o, ctx)
+
+    @staticmethod
+    def hd_to_io(h, d, ctx: Optional[Context] = None):
+        return _hd("djb_hd_to_io_batch", h, d, ctx)
+
+    def close(self):
+        if self._h:
+            _lib.load().djb_brdf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _hd(fn, a, b, ctx):
+    lib = _lib.load()
+    ctx = ctx or default_context()
+    va, vb = _Vec(a), _Vec(b)
+    oc, od = va.like(), va.like()
+    _lib.check(getattr(lib, fn)(ctx._h, C.c_int64(va.n), C.byref(va.view), C.byref(vb.view),
+                                C.byref(oc.view), C.byref(od.view), C.c_int(va.mem)))
+    return oc.keep, od.keep
+
+
+def merl_index(i, o, ctx: Optional[Context] = None):
+    """The table index merl::eval composes for each pair (dj_brdf.h:997-1002)."""
+    lib = _lib.load()
+    ctx = ctx or default_context()
+    vi, vo = _Vec(i), _Vec(o)
+    idx, ptr = vi.scalars(np.int32)
+    _lib.check(lib.djb_merl_index_batch(ctx._h, C.c_int64(vi.n), C.byref(vi.view), C.byref(vo.view),
+                                        C.c_void_p(ptr), C.c_int(vi.mem)))
+    return idx
+
+
+# --------------------------------------------------------------------------- microfacet (dj_brdf.h:210-298)
+class microfacet(brdf):
+    class params:
+        """djb::microfacet::params (dj_brdf.h:213-243); build with the factories."""
+
+        def __init__(self, kind: int, values: Sequence[float]):
+            self._p = _lib.Params()
+            self._p.kind = kind
+            for k, v in enumerate(values):
+                self._p.v[k] = v
+
+        @staticmethod
+        def standard():
+            return microfacet.params(0, ())
+
+        @staticmethod
+        def isotropic(a):
+            return microfacet.params(1, (a, a, 0.0))
+
+        @staticmethod
+        def elliptic(a1, a2, phi_a=0.0):
+            return microfacet.params(1, (a1, a2, phi_a))
+
+        @staticmethod
+        def pdfparams(ax, ay, rho=0.0, tx_n=0.0, ty_n=0.0):
+            return microfacet.params(2, (ax, ay, rho, tx_n, ty_n))
+
+        def _resolved(self):
+            r = _lib.ParamsResolved()
+            _lib.check(_lib.load().djb_params_resolve(C.byref(self._p), C.byref(r)))
+            return r
+
+        def get_ellipse(self):
+            r = self._resolved()
+            return r.a1, r.a2, r.phi_a
+
+        def get_pdfparams(self):
+            r = self._resolved()
+            return r.ax, r.ay, r.rho, r.tx_n, r.ty_n
+
+        def get_location(self):
+            r = self._resolved()
+            return tuple(r.n)
+
+    def __init__(self, kind_fn: str, fresnel_impl, shadow: bool, ctx):
+        super().__init__(ctx)
+        fresnel_impl = fresnel_impl or fresnel.ideal()
+        d, keep = fresnel_impl._desc()
+        _lib.check(getattr(_lib.load(), kind_fn)(self.ctx._h, C.byref(d), C.c_int(int(shadow)), C.byref(self._h)))
+        self._fresnel = fresnel_impl
+        del keep
+
+    def get_shadow(self) -> int:
+        return _lib.load().djb_brdf_get_shadow(self._h)
+
+    def get_fresnel(self):
+        return self._fresnel
+
+
+def _params_ptr(user_param):
+    if user_param is None:
+        return None
+    if not isinstance(user_param, microfacet.params):
+        raise exc(1, "djb_error: user_param must be a microfacet.params or None")
+    return C.byref(user_param._p)
+
+
+class beckmann(microfacet):
+    def __init__(self, fresnel=None, shadow=True, ctx=None):
+        super().__init__("djb_brdf_create_beckmann", fresnel, shadow, ctx)
+
+    def supports_smith_vndf_sampling(self):
+        return True
+
+
+class ggx(microfacet):
+    def __init__(self, fresnel=None, shadow=True, ctx=None):
+        super().__init__("djb_brdf_create_ggx", fresnel, shadow, ctx)
+
+    def supports_smith_vndf_sampling(self):
+        return True
+
+
+class lambert(brdf):
+    def __init__(self, ctx=None):
+        super().__init__(ctx)
+        _lib.check(_lib.load().djb_brdf_create_lambert(self.ctx._h, C.byref(self._h)))
+
+
+class merl(brdf):
+    """djb::merl(filename) (dj_brdf.h:126-133, 963-983).  ``merl.from_table`` builds the same
+    object from the file payload in memory (3*n doubles, planes R, G, B)."""
+
+    def __init__(self, filename: str, ctx=None):
+        super().__init__(ctx)
+        _lib.check(_lib.load().djb_brdf_create_merl_from_file(self.ctx._h, filename.encode(), C.byref(self._h)))
+
+    @classmethod
+    def from_table(cls, table, ctx=None):
+        self = cls.__new__(cls)
+        brdf.__init__(self, ctx)
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        _lib.check(_lib.load().djb_brdf_create_merl_from_memory(
+            self.ctx._h, C.c_void_p(t.ctypes.data), C.c_int64(t.size // 3), C.byref(self._h)))
+        return self
+
+
+class utia(brdf):
+    """djb::utia(filename) (dj_brdf.h:136-146, 1039-1059)."""
+
+    def __init__(self, filename: str, ctx=None):
+        super().__init__(ctx)
+        _lib.check(_lib.load().djb_brdf_create_utia_from_file(self.ctx._h, filename.encode(), C.byref(self._h)))
+
+    @classmethod
+    def from_table(cls, table, ctx=None):
+        self = cls.__new__(cls)
+        brdf.__init__(self, ctx)
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        if t.size != 3 * 288 * 288:
+            raise exc(1, "djb_error: UTIA table must hold 3*288*288 doubles")
+        _lib.check(_lib.load().djb_brdf_create_utia_from_memory(self.ctx._h, C.c_void_p(t.ctypes.data), C.byref(self._h)))
+        return self
+
+
+class tabular(microfacet):
+    """djb::tabular(brdf, res, shadow): the power-iteration fit, executed by the HIP fit kernel
+    (dj_brdf.h:394-425, 2215-2236)."""
+
+    def __init__(self, src: brdf, resolution: int, shadow: bool = True, ctx=None):
+        brdf.__init__(self, ctx or src.ctx)
+        _lib.check(_lib.load().djb_brdf_create_tabular(self.ctx._h, src._h, C.c_int(resolution),
+                                                       C.c_int(int(shadow)), C.byref(self._h)))
+        self._fresnel = None
+
+    def supports_smith_vndf_sampling(self):
+        return False
+
+    def _get(self, which: int, width: int = 1):
+        lib = _lib.load()
+        n = C.c_int()
+        _lib.check(lib.djb_tabular_get(self._h, C.c_int(which), None, C.byref(n)))
+        a = np.empty((n.value, width) if width > 1 else (n.value,), dtype=np.float32)
+        _lib.check(lib.djb_tabular_get(self._h, C.c_int(which), C.c_void_p(a.ctypes.data), None))
+        return a
+
+    def get_p22v(self):
+        return self._get(0)
+
+    def get_sigmav(self):
+        return self._get(1)
+
+    def get_cdfv(self):
+        return self._get(2)
+
+    def get_qfv(self):
+        return self._get(3)
+
+    def get_fresnel(self):
+        return fresnel.spline(self._get(4, 3))
+
+    def _alphas(self):
+        ab, ag = C.c_float(), C.c_float()
+        _lib.check(_lib.load().djb_tabular_fit(self._h, C.byref(ab), C.byref(ag)))
+        return ab.value, ag.value
+
+    @staticmethod
+    def fit_beckmann_parameters(tab: "tabular"):
+        return microfacet.params.isotropic(tab._alphas()[0])
+
+    @staticmethod
+    def fit_ggx_parameters(tab: "tabular"):
+        return microfacet.params.isotropic(tab._alphas()[1])
+
+
+# --------------------------------------------------------------------------- batch fitter
+def fit_merl_batch(tables, res: int = 90, shadow: bool = True, ctx: Optional[Context] = None,
+                   return_tables: bool = False):
+    """examples/merl_params.cpp:53-67 for many materials at once.
+
+    ``tables``: sequence of float64 arrays (MERL payloads, 3*1458000 doubles each).
+    Returns (alpha_beckmann[n], alpha_ggx[n]) and optionally the per-material tables."""
+    lib = _lib.load()
+    ctx = ctx or default_context()
+    tabs = [np.ascontiguousarray(t, dtype=np.float64).reshape(-1) for t in tables]
+    n = len(tabs)
+    ptrs = (C.c_void_p * max(n, 1))(*[t.ctypes.data for t in tabs])
+    ab, ag = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    extra = {}
+    args = []
+    for name, width in (("p22", 1), ("sigma", 1), ("cdf", 1), ("qf", 1), ("fresnel", 3)):
+        if return_tables:
+            extra[name] = np.zeros((n, res, width) if width > 1 else (n, res), np.float32)
+            args.append(C.c_void_p(extra[name].ctypes.data))
+        else:
+            args.append(None)
+    _lib.check(lib.djb_fit_merl_batch(ctx._h, C.c_int(n), ptrs, C.c_int(res), C.c_int(int(shadow)),
+                                      C.c_void_p(ab.ctypes.data), C.c_void_p(ag.ctypes.data), *args))
+    return (ab, ag, extra) if return_tables else (ab, ag)
+
+
+# --------------------------------------------------------------------------- synthetic workloads (device)
+def gen_directions(n: int, seed: int, start: int = 0, ctx: Optional[Context] = None, device=None):
+    """[3, n] torch CUDA tensor of hash-generated unit vectors; same bits as synth.directions."""
+    ctx = ctx or default_context()
+    out = torch.empty((3, n), dtype=torch.float32, device=device or f"cuda:{ctx.device}")
+    v = _Vec(out)
+    _lib.check(_lib.load().djb_gen_directions(ctx._h, C.c_int64(n), C.c_uint32(seed), C.c_uint64(start),
+                                              C.byref(v.view)))
+    return out
+
+
+def gen_uniforms(n: int, seed: int, start: int = 0, ctx: Optional[Context] = None, device=None):
+    ctx = ctx or default_context()
+    out = torch.empty((n,), dtype=torch.float32, device=device or f"cuda:{ctx.device}")
+    _lib.check(_lib.load().djb_gen_uniforms(ctx._h, C.c_int64(n), C.c_uint32(seed), C.c_uint64(start),
+                                            C.c_void_p(out.data_ptr())))
+    return out
+
+
+def histogram_xy(v, bins: int = 64, ctx: Optional[Context] = None):
+    """bins x bins histogram of (x, y) in [-1, 1]^2 of a device vec3 batch (LDS atomics)."""
+    ctx = ctx or default_context()
+    vv = _Vec(v)
+    counts = torch.zeros((bins * bins,), dtype=torch.int64, device=vv.device)
+    _lib.check(_lib.load().djb_histogram_xy(ctx._h, C.c_int64(vv.n), C.byref(vv.view), C.c_int(bins),
+                                            C.c_void_p(counts.data_ptr())))
+    return counts.view(bins, bins)

@@ -1,0 +1,194 @@
+/* include/djb_hip.h -- C ABI of libdjb_hip.so, the MI355X (gfx950) batch engine behind the
+ * dj_brdf operator surface.
+ *
+ * The reference (jdupuy/dj_brdf, dj_brdf.h) has no FFI: its boundary is the abstract C++ class
+ * djb::brdf (dj_brdf.h:74-109) whose virtuals take ONE (i, o) pair per call.  This header is the
+ * batch equivalent of that surface: one entry point per virtual, taking n pairs, plus the
+ * constructors of the concrete classes on the hot path.  Each declaration cites the reference
+ * interface it replaces.  No C++ / torch / STL types cross this boundary: plain pointers, sizes,
+ * POD structs, status codes.  INTEGRATION.md shows the djb:: facade and the Mitsuba-plugin side.
+ *
+ * Conventions
+ *  - Directions follow the reference (dj_brdf.h:23-26): i = towards the light, o = towards the
+ *    viewer, both in the local frame with z the surface normal.
+ *  - Arrays are described by djb_vec3_view {x, y, z, stride}: element k is (x[k*stride],
+ *    y[k*stride], z[k*stride]).  SoA = three arrays with stride 1 (fast path);
+ *    an array of djb::vec3 (AoS) = {p, p+1, p+2, 3}.
+ *  - `mem` says where the array pointers live: DJB_MEM_DEVICE (HBM of the ctx's GPU; the call is
+ *    asynchronous on the ctx's stream) or DJB_MEM_HOST (the call stages through HBM and returns
+ *    when the outputs are back in host memory).
+ *  - Every function returns a djb_status; djb_last_error() returns the thread-local message
+ *    (the text djb::exc would have carried, dj_brdf.h:54-59 / 578-587).
+ *  - Handles are immutable after creation; batch calls on one ctx are serialised on its stream.
+ */
+#ifndef DJB_HIP_H
+#define DJB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DJB_HIP_VERSION 100
+
+typedef enum {
+	DJB_OK = 0,
+	DJB_ERR_INVALID_ARGUMENT = 1,
+	DJB_ERR_OPEN_FAILED = 2,      /* "djb_error: Failed to open %s"          dj_brdf.h:970, 1044 */
+	DJB_ERR_BAD_HEADER = 3,       /* "djb_error: Failed to read MERL header" dj_brdf.h:976       */
+	DJB_ERR_READ_FAILED = 4,      /* "djb_error: Reading %s failed"          dj_brdf.h:982, 1058 */
+	DJB_ERR_NOT_IMPLEMENTED = 5,  /* "djb_error: Not Implemented"            dj_brdf.h:1785-1790 */
+	DJB_ERR_HIP = 6,              /* a HIP runtime call failed                                  */
+	DJB_ERR_NO_DEVICE = 7         /* no gfx950 device / HIP runtime unusable                     */
+} djb_status;
+
+enum { DJB_MEM_DEVICE = 0, DJB_MEM_HOST = 1 };
+
+typedef struct djb_ctx djb_ctx;     /* one GPU + one HIP stream */
+typedef struct djb_brdf djb_brdf;   /* an immutable BRDF object resident in HBM (djb::brdf subclass) */
+
+typedef struct { float *x, *y, *z; int64_t stride; } djb_vec3_view;
+
+/* djb::microfacet::params factories (dj_brdf.h:217-221).  The batch shares one parameter set. */
+enum { DJB_PARAMS_STANDARD = 0,   /* user_param == NULL -> params::standard()            */
+       DJB_PARAMS_ELLIPTIC = 1,   /* params::elliptic(v[0]=a1, v[1]=a2, v[2]=phi_a)      */
+       DJB_PARAMS_PDFPARAMS = 2   /* params::pdfparams(ax, ay, rho, tx_n, ty_n)          */ };
+typedef struct { int kind; float v[5]; } djb_params;
+
+/* resolved view of microfacet::params, all private members (dj_brdf.h:237-242) */
+typedef struct {
+	float n[3];
+	float a1, a2, phi_a;
+	float ax, ay, rho, sqrt_one_minus_rho_sqr;
+	float tx_n, ty_n;
+} djb_params_resolved;
+
+/* djb::fresnel::{ideal,unpolarized,schlick,sgd,spline} (dj_brdf.h:149-207) */
+enum { DJB_FRESNEL_IDEAL = 0, DJB_FRESNEL_UNPOLARIZED = 1, DJB_FRESNEL_SCHLICK = 2,
+       DJB_FRESNEL_SGD = 3, DJB_FRESNEL_SPLINE = 4 };
+typedef struct {
+	int kind;
+	float a[3];           /* unpolarized: ior; schlick: f0; sgd: f0 */
+	float b[3];           /* sgd: f1 */
+	const float *points;  /* spline: npoints x 3 floats (host memory; copied) */
+	int npoints;
+} djb_fresnel_desc;
+
+enum { DJB_KIND_BECKMANN = 0, DJB_KIND_GGX = 1, DJB_KIND_TABULAR = 2, DJB_KIND_MERL = 3,
+       DJB_KIND_UTIA = 4, DJB_KIND_LAMBERT = 5 };
+
+/* ---------------------------------------------------------------- library / context */
+const char *djb_last_error(void);
+int         djb_version(void);
+/* number of usable gfx950 devices (0 when there is no GPU; never falls back to a CPU path) */
+djb_status  djb_device_count(int *count);
+/* hip_stream: a hipStream_t to run on (e.g. torch's current stream), or NULL to create one */
+djb_status  djb_ctx_create(int device, void *hip_stream, djb_ctx **out);
+djb_status  djb_ctx_destroy(djb_ctx *ctx);
+djb_status  djb_ctx_synchronize(djb_ctx *ctx);
+void       *djb_ctx_stream(djb_ctx *ctx);
+/* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */
+djb_status  djb_timer_start(djb_ctx *ctx);
+djb_status  djb_timer_stop_ms(djb_ctx *ctx, float *ms);
+
+/* ---------------------------------------------------------------- constructors */
+/* djb::beckmann(fresnel, shadow) / djb::ggx(fresnel, shadow)          dj_brdf.h:358-360, 376-378 */
+djb_status djb_brdf_create_beckmann(djb_ctx *, const djb_fresnel_desc *, int shadow, djb_brdf **);
+djb_status djb_brdf_create_ggx(djb_ctx *, const djb_fresnel_desc *, int shadow, djb_brdf **);
+/* djb::merl(const char *filename)                                     dj_brdf.h:963-983 */
+djb_status djb_brdf_create_merl_from_file(djb_ctx *, const char *path, djb_brdf **);
+/* same object from the file payload already in host memory: 3*n doubles, planes R,G,B */
+djb_status djb_brdf_create_merl_from_memory(djb_ctx *, const double *samples, int64_t n_per_channel,
+                                            djb_brdf **);
+/* djb::utia(const char *filename)                                     dj_brdf.h:1039-1059 */
+djb_status djb_brdf_create_utia_from_file(djb_ctx *, const char *path, djb_brdf **);
+djb_status djb_brdf_create_utia_from_memory(djb_ctx *, const double *samples, djb_brdf **);
+/* djb::lambert                                                        dj_brdf.h:112-123 */
+djb_status djb_brdf_create_lambert(djb_ctx *, djb_brdf **);
+/* djb::tabular(const brdf&, int res, bool shadow): the power-iteration fit, run on the GPU
+ *                                                                     dj_brdf.h:2215-2236 */
+djb_status djb_brdf_create_tabular(djb_ctx *, const djb_brdf *src, int res, int shadow, djb_brdf **);
+djb_status djb_brdf_destroy(djb_brdf *);
+int        djb_brdf_kind(const djb_brdf *);
+/* microfacet::set_shadow / get_shadow                                 dj_brdf.h:278-281 */
+int        djb_brdf_get_shadow(const djb_brdf *);
+
+/* ---------------------------------------------------------------- the operator surface */
+/* brdf::eval(i, o, user_param) -> vec3                                dj_brdf.h:77-78   */
+djb_status djb_eval_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i,
+                          const djb_vec3_view *o, const djb_params *params,
+                          const djb_vec3_view *out_fr, int mem);
+/* brdf::evalp(i, o, user_param) = f_r * cos(theta_i)                  dj_brdf.h:82-83   */
+djb_status djb_evalp_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i,
+                           const djb_vec3_view *o, const djb_params *params,
+                           const djb_vec3_view *out_fr_cos, int mem);
+/* brdf::pdf(i, o, user_param)                                         dj_brdf.h:96-97   */
+djb_status djb_pdf_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i,
+                         const djb_vec3_view *o, const djb_params *params,
+                         float *out_pdf, int mem);
+/* eval (or evalp when want_cos != 0) and pdf of the same pairs in one pass over HBM */
+djb_status djb_eval_pdf_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i,
+                              const djb_vec3_view *o, const djb_params *params, int want_cos,
+                              const djb_vec3_view *out_fr, float *out_pdf, int mem);
+/* brdf::sample(u1, u2, o, user_param) -> i                            dj_brdf.h:92-94   */
+djb_status djb_sample_batch(djb_ctx *, const djb_brdf *, int64_t n, const float *u1,
+                            const float *u2, const djb_vec3_view *o, const djb_params *params,
+                            const djb_vec3_view *out_i, int mem);
+/* brdf::sample with the two uniforms drawn on chip from the counter RNG of djb_gen_uniforms
+ * (u_k = uniform(seed, start + k)); device memory only.  Same results as djb_gen_uniforms
+ * followed by djb_sample_batch, without the 8 B/sample of HBM traffic.                  */
+djb_status djb_sample_rng_batch(djb_ctx *, const djb_brdf *, int64_t n, uint32_t seed_u1,
+                                uint32_t seed_u2, uint64_t start, const djb_vec3_view *o,
+                                const djb_params *params, const djb_vec3_view *out_i);
+/* brdf::evalp_is(u1, u2, o, &i, &pdf, user_param) -> weight           dj_brdf.h:87-90   */
+djb_status djb_evalp_is_batch(djb_ctx *, const djb_brdf *, int64_t n, const float *u1,
+                              const float *u2, const djb_vec3_view *o, const djb_params *params,
+                              const djb_vec3_view *out_weight, const djb_vec3_view *out_i,
+                              float *out_pdf, int mem);
+/* brdf::io_to_hd / brdf::hd_to_io (static)                            dj_brdf.h:99-100  */
+djb_status djb_io_to_hd_batch(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
+                              const djb_vec3_view *out_h, const djb_vec3_view *out_d, int mem);
+djb_status djb_hd_to_io_batch(djb_ctx *, int64_t n, const djb_vec3_view *h, const djb_vec3_view *d,
+                              const djb_vec3_view *out_i, const djb_vec3_view *out_o, int mem);
+/* the table index merl::eval composes (diagnostic; dj_brdf.h:997-1002)                  */
+djb_status djb_merl_index_batch(djb_ctx *, int64_t n, const djb_vec3_view *i,
+                                const djb_vec3_view *o, int32_t *out_index, int mem);
+
+/* microfacet::params -> private members (host side, no GPU work)       dj_brdf.h:1355-1506 */
+djb_status djb_params_resolve(const djb_params *params, djb_params_resolved *out);
+
+/* ---------------------------------------------------------------- tabular accessors / fits */
+enum { DJB_TAB_P22 = 0, DJB_TAB_SIGMA = 1, DJB_TAB_CDF = 2, DJB_TAB_QF = 3, DJB_TAB_FRESNEL = 4 };
+/* tabular::get_p22v / get_sigmav / get_cdfv / get_qfv, and fresnel::spline::get_points of
+ * tabular::get_fresnel() (3 floats per point).  out may be NULL to query *count only.
+ *                                                                     dj_brdf.h:404-407, 203 */
+djb_status djb_tabular_get(const djb_brdf *tab, int which, float *out, int *count);
+/* tabular::fit_beckmann_parameters / fit_ggx_parameters -> isotropic alpha
+ *                                                                     dj_brdf.h:3133-3184 */
+djb_status djb_tabular_fit(const djb_brdf *tab, float *alpha_beckmann, float *alpha_ggx);
+
+/* ---------------------------------------------------------------- batch fitter
+ * What examples/merl_params.cpp:53-67 does per file, for n_materials tables at once:
+ * tabular(merl, res, shadow) + both fits.  tables[m] points to 3*n doubles (MERL file
+ * payload, host memory).  Outputs (host): alpha arrays [n_materials]; optional per-material
+ * tables p22/sigma/cdf/qf [n_materials][res] and fresnel [n_materials][res][3] (may be NULL). */
+djb_status djb_fit_merl_batch(djb_ctx *, int n_materials, const double *const *tables,
+                              int res, int shadow, float *alpha_beckmann, float *alpha_ggx,
+                              float *p22, float *sigma, float *cdf, float *qf, float *fresnel);
+
+/* ---------------------------------------------------------------- synthetic workloads
+ * (not reference behaviour: the reference has no RNG).  Bit-identical to
+ * dj_brdf_amd/synth.py.  Device pointers only. */
+djb_status djb_gen_directions(djb_ctx *, int64_t n, uint32_t seed, uint64_t start,
+                              const djb_vec3_view *out);
+djb_status djb_gen_uniforms(djb_ctx *, int64_t n, uint32_t seed, uint64_t start, float *out);
+/* bins x bins histogram of (x, y) in [-1,1]^2 (LDS atomics, one global flush per workgroup) */
+djb_status djb_histogram_xy(djb_ctx *, int64_t n, const djb_vec3_view *v, int bins,
+                            unsigned long long *counts /* device, bins*bins */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DJB_HIP_H */

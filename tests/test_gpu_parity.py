@@ -1,0 +1,184 @@
+"""HIP path vs the CPU oracle, through the C ABI (ctypes -> libdjb_hip.so), on seeded inputs.
+
+Bar (BASELINE.json north_star): float BRDF values within 1e-5 relative of the reference CPU
+path; MERL bin indices bit-exact.  The oracle is bit-exact with the real reference
+(tests/test_oracle_vs_ref.py, tests/test_oracle_golden.py), so oracle parity == reference parity.
+"""
+import numpy as np
+import pytest
+
+from dj_brdf_amd import djb, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5          # north_star tolerance
+ATOL = 1e-30         # values that underflow to (sub)denormal noise
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), ATOL / RTOL)
+
+
+def assert_close(name, got, want, rtol=RTOL):
+    got = np.asarray(got); want = np.asarray(want)
+    assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
+    assert not np.isnan(got).any() or np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN mismatch"
+    m = ~(np.isnan(got) & np.isnan(want))
+    e = rel_err(got[m], want[m])
+    exact = np.mean(got.view(np.uint32) == want.view(np.uint32))
+    assert e.size == 0 or e.max() <= rtol, f"{name}: max rel err {e.max():.3e} > {rtol} (bit-exact {exact:.6f})"
+    return exact
+
+
+N = 1 << 17
+FRESNELS = [
+    ("ideal",), ("unpolarized", 1.5, 1.8, 2.4), ("schlick", 1.0, 0.71, 0.29),
+    ("sgd", 0.8, 0.5, 0.3, 0.1, 0.05, 0.02),
+    ("spline",) + tuple(np.linspace(0.2, 1.0, 30, dtype=np.float32).repeat(3).tolist()),
+]
+PARAMS = [None, ("elliptic", 0.3, 0.3, 0.0), ("elliptic", 0.2, 0.5, 0.7),
+          ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)]
+
+
+def mk_fresnel(f):
+    k = f[0]
+    if k == "ideal": return djb.fresnel.ideal()
+    if k == "unpolarized": return djb.fresnel.unpolarized(f[1:4])
+    if k == "schlick": return djb.fresnel.schlick(f[1:4])
+    if k == "sgd": return djb.fresnel.sgd(f[1:4], f[4:7])
+    return djb.fresnel.spline(np.array(f[1:], np.float32).reshape(-1, 3))
+
+
+def mk_params(p):
+    if p is None: return None
+    if p[0] == "elliptic": return djb.microfacet.params.elliptic(*p[1:])
+    return djb.microfacet.params.pdfparams(*p[1:])
+
+
+@pytest.fixture(scope="module")
+def dirs():
+    i = synth.directions_aos(N, synth.SEED_I); o = synth.directions_aos(N, synth.SEED_O)
+    u1 = synth.uniforms(N, synth.SEED_U1); u2 = synth.uniforms(N, synth.SEED_U2)
+    return i, o, u1, u2
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+@pytest.mark.parametrize("fres", FRESNELS, ids=lambda f: f[0])
+def test_microfacet_eval_pdf(gpu_ctx, oracle, dirs, ndf, fres):
+    i, o, _, _ = dirs
+    for shadow in ((True, False) if fres[0] == "ideal" else (True,)):
+        g = getattr(djb, ndf)(mk_fresnel(fres), shadow, ctx=gpu_ctx)
+        ob = oracle.microfacet(ndf, fres, shadow)
+        for p in PARAMS:
+            up = mk_params(p)
+            for op in ("eval", "evalp", "pdf"):
+                got = getattr(g, op)(i, o, up)
+                assert_close(f"{ndf}/{fres[0]}/{shadow}/{p}/{op}", got, oracle.eval(ob, i, o, p, op))
+            fr, pdf = g.eval_pdf(i, o, up)
+            assert_close("fused eval", fr, oracle.eval(ob, i, o, p, "eval"))
+            assert_close("fused pdf", pdf, oracle.eval(ob, i, o, p, "pdf"))
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+def test_microfacet_sample(gpu_ctx, oracle, dirs, ndf):
+    _, o, u1, u2 = dirs
+    g = getattr(djb, ndf)(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    ob = oracle.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
+    for p in PARAMS:
+        up = mk_params(p)
+        # the Newton inversion stops at |value| < 1e-5 (dj_brdf.h:1938): float transcendentals that
+        # differ in the last ulp may stop one step apart, so sampled directions agree to ~1e-4
+        tol = 2e-4 if ndf == "beckmann" else 1e-5
+        got = g.sample(u1, u2, o, up)
+        want = oracle.sample(ob, u1, u2, o, p)
+        err = np.abs(got.astype(np.float64) - want).max(axis=1)
+        assert np.quantile(err, 0.999) < tol, f"{ndf} sample {p}: q99.9 abs err {np.quantile(err, 0.999):.3e}"
+        assert err.max() < 50 * tol
+        w, gi, pdf = g.evalp_is(u1, u2, o, up)
+        ww, wi, wpdf = oracle.evalp_is(ob, u1, u2, o, p)
+        assert np.quantile(np.abs(gi - wi).max(axis=1), 0.999) < tol
+
+
+def test_io_hd_roundtrip(gpu_ctx, oracle, dirs):
+    i, o, _, _ = dirs
+    h, d = djb.brdf.io_to_hd(i, o, ctx=gpu_ctx)
+    wh, wd = oracle.io_to_hd(i, o)
+    assert_close("h", h, wh); assert_close("d", d, wd)
+    gi, go = djb.brdf.hd_to_io(wh, wd, ctx=gpu_ctx)
+    wi, wo = oracle.hd_to_io(wh, wd)
+    assert_close("i", gi, wi, 1e-5); assert_close("o", go, wo, 2e-5)
+
+
+def test_merl_index_bit_exact(gpu_ctx, oracle):
+    n = 1 << 21
+    i = synth.directions_aos(n, synth.SEED_I); o = synth.directions_aos(n, synth.SEED_O)
+    got = djb.merl_index(i, o, ctx=gpu_ctx)
+    want = oracle.merl_index(i, o)
+    mism = int((got != want).sum())
+    assert mism == 0, f"{mism} of {n} MERL bin indices differ from the CPU oracle"
+
+
+def test_merl_eval(gpu_ctx, oracle, dirs):
+    i, o, _, _ = dirs
+    tab = synth.merl_table_hashed()
+    m = djb.merl.from_table(tab, ctx=gpu_ctx)
+    om = oracle.merl_from_table(tab)
+    for op in ("eval", "evalp", "pdf"):
+        got = getattr(m, op)(i, o)
+        want = oracle.eval(om, i, o, None, op)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"merl {op} not bit-exact"
+
+
+@pytest.mark.parametrize("case", ["ggx90", "beckmann180", "merl90", "merl90_noshadow", "ggx7"])
+def test_fit_tables(gpu_ctx, oracle, case):
+    if case.startswith("merl"):
+        tab = synth.merl_table(0.3)
+        src, osrc = djb.merl.from_table(tab, ctx=gpu_ctx), oracle.merl_from_table(tab)
+        res, shadow = 90, case == "merl90"
+    elif case == "beckmann180":
+        src, osrc = djb.beckmann(None, False, ctx=gpu_ctx), oracle.microfacet("beckmann", ("ideal",), False)
+        res, shadow = 180, True
+    else:
+        src, osrc = djb.ggx(ctx=gpu_ctx), oracle.microfacet("ggx")
+        res, shadow = (90 if case == "ggx90" else 7), True
+    t = djb.tabular(src, res, shadow, ctx=gpu_ctx)
+    want = oracle.tabular_tables(oracle.tabular(osrc, res, shadow))
+    got = {"p22": t.get_p22v(), "sigma": t.get_sigmav(), "cdf": t.get_cdfv(), "qf": t.get_qfv(),
+           "fresnel": t.get_fresnel().get_points()}
+    for k, v in got.items():
+        assert_close(f"{case}/{k}", v, want[k], rtol=2e-5)
+    ab = djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0]
+    ag = djb.tabular.fit_ggx_parameters(t).get_ellipse()[0]
+    assert abs(ab - want["alpha_beckmann"]) <= 2e-5 * abs(want["alpha_beckmann"])
+    assert abs(ag - want["alpha_ggx"]) <= 2e-5 * abs(want["alpha_ggx"])
+    assert "%.3f %.3f" % (ab, ag) == "%.3f %.3f" % (want["alpha_beckmann"], want["alpha_ggx"])
+    # the fitted object evaluates like the oracle's
+    n = 1 << 14
+    i = synth.directions_aos(n, synth.SEED_I); o = synth.directions_aos(n, synth.SEED_O)
+    ot = oracle.tabular(osrc, res, shadow)
+    for op in ("eval", "pdf"):
+        assert_close(f"{case}/tab {op}", getattr(t, op)(i, o), oracle.eval(ot, i, o, None, op), rtol=1e-4)
+
+
+def test_device_generators_match_numpy(gpu_ctx):
+    n = 1 << 16
+    d = djb.gen_directions(n, synth.SEED_I, start=12345, ctx=gpu_ctx).cpu().numpy()
+    x, y, z = synth.directions(n, synth.SEED_I, start=12345)
+    assert np.array_equal(d[0].view(np.uint32), x.view(np.uint32))
+    assert np.array_equal(d[1].view(np.uint32), y.view(np.uint32))
+    assert np.array_equal(d[2].view(np.uint32), z.view(np.uint32))
+    u = djb.gen_uniforms(n, synth.SEED_U1, start=(1 << 33) + 7, ctx=gpu_ctx).cpu().numpy()
+    assert np.array_equal(u, synth.uniforms(n, synth.SEED_U1, start=(1 << 33) + 7))
+
+
+def test_device_tensors_soa_equal_host_aos(gpu_ctx, dirs):
+    import torch
+    i, o, _, _ = dirs
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    p = djb.microfacet.params.isotropic(0.3)
+    host = g.eval(i, o, p)
+    ti = torch.from_numpy(i.T.copy()).cuda(); to = torch.from_numpy(o.T.copy()).cuda()
+    dev = g.eval(ti, to, p)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy().T.view(np.uint32), host.view(np.uint32))

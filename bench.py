@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the dj_brdf hot path on MI355X, one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--n PAIRS]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM (directions generated on-device by the counter hash of dj_brdf_amd/synth.py).
+
+Workloads (BASELINE.json configs):
+  merl_eval        configs[2]: MERL tabulated eval (nearest-bin, bit-exact index) over 1e9 (wi,wo)
+                   pairs -- the configuration BASELINE.json's north_star quotes its target on
+                   (>= 1 G evals/s on one MI355X); DEFAULT.
+  ggx_eval_pdf     configs[1]: GGX isotropic conductor eval()+pdf() fused, 1e8 pairs, alpha = 0.3
+  beckmann_sample  configs[3]: Beckmann elliptic(0.2,0.5,0.7) VNDF sample(), 1e9 samples, on-chip RNG
+  merl_fit         configs[4]: power-iteration fit of 100 MERL materials resident in HBM
+
+Multi-GPU (torchrun, one rank per GPU): units are independent, every rank runs the same per-GPU
+batch on its own device ("weak" scaling), there is NO data-path collective; the only
+communication is the barrier and the MAX-over-ranks of the timed region.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel: algorithmic bytes per launch / average launch duration
+                (HIP events on the ctx stream over the timed region) vs the 8 TB/s HBM peak
+  cpu_baseline  the CPU path timed on this host (rank 0, N=1 only) on a bounded sample:
+                kind "reference" = the real dj_brdf.h via oracle/_ref (prebuilt), else
+                "port" = oracle/djb_oracle.c
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (default n per GPU, algorithmic HBM bytes per unit, unit, kernel family)
+    "merl_eval": (1_000_000_000, 36, "evals", "k_eval<MERL,eval>"),
+    "ggx_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf>"),
+    "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample<BECKMANN,rng>"),
+    "merl_fit": (100, None, "materials", "k_fit<MERL>"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="merl_eval", choices=list(WORKLOADS))
+    ap.add_argument("--n", type=int, default=None, help="units per GPU per step (default: the BASELINE config size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    return ap.parse_args()
+
+
+def make_step(name, n, djb, synth, ctx, torch):
+    """Returns (step_fn, keepalive).  Inputs are generated on-device before the timed region."""
+    if name == "merl_eval":
+        i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
+        o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
+        m = djb.merl.from_table(synth.merl_table(0.3), ctx=ctx)   # GGX 0.3 + diffuse at bin centres
+        out = torch.empty((3, n), dtype=torch.float32, device=i.device)
+        lib, C = djb._lib.load(), ctypes
+        vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
+
+        def step():
+            djb._lib.check(lib.djb_eval_batch(ctx._h, m._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                              None, C.byref(vout.view), C.c_int(0)))
+        return step, (i, o, m, out, vi, vo, vout)
+    if name == "ggx_eval_pdf":
+        i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
+        o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
+        g = djb.ggx(djb.fresnel.ideal(), True, ctx=ctx)
+        p = djb.microfacet.params.isotropic(0.3)
+        out = torch.empty((3, n), dtype=torch.float32, device=i.device)
+        pdf = torch.empty((n,), dtype=torch.float32, device=i.device)
+        lib, C = djb._lib.load(), ctypes
+        vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
+
+        def step():
+            djb._lib.check(lib.djb_eval_pdf_batch(ctx._h, g._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                                  C.byref(p._p), C.c_int(0), C.byref(vout.view),
+                                                  C.c_void_p(pdf.data_ptr()), C.c_int(0)))
+        return step, (i, o, g, p, out, pdf, vi, vo, vout)
+    if name == "beckmann_sample":
+        o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
+        b = djb.beckmann(djb.fresnel.ideal(), True, ctx=ctx)
+        p = djb.microfacet.params.elliptic(0.2, 0.5, 0.7)
+        out = torch.empty((3, n), dtype=torch.float32, device=o.device)
+        lib, C = djb._lib.load(), ctypes
+        vo, vout = djb._Vec(o), djb._Vec(out)
+
+        def step():
+            djb._lib.check(lib.djb_sample_rng_batch(ctx._h, b._h, C.c_int64(n), C.c_uint32(synth.SEED_U1),
+                                                    C.c_uint32(synth.SEED_U2), C.c_uint64(0), C.byref(vo.view),
+                                                    C.byref(p._p), C.byref(vout.view)))
+        return step, (o, b, p, out, vo, vout)
+    if name == "merl_fit":
+        mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=ctx) for k in range(n)]
+        result = {}
+
+        def step():
+            result["alphas"] = djb.fit_brdf_batch(mats, 90, True, ctx=ctx)
+        return step, (mats, result)
+    raise ValueError(name)
+
+
+def cpu_baseline(name, synth, budget_s=12.0):
+    """The CPU path on this host's cores, bounded sample.  Prefers the real reference (oracle/_ref)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libdjb_ref.so")
+    kind = "reference" if os.path.exists(ref_path) else "port"
+    L = oraclelib.CheckerLib(ref_path, "ref_") if kind == "reference" else oraclelib.oracle()
+    cores = os.cpu_count() or 1
+    par = None
+    if name == "merl_eval":
+        if kind == "reference":
+            path = "/tmp/djb_bench_cpu.binary"
+            synth.write_merl_binary(path, synth.merl_table(0.3))
+            b = L.merl(path)
+        else:
+            b = L.merl_from_table(synth.merl_table(0.3))
+        op = "eval"
+    elif name == "ggx_eval_pdf":
+        b, op, par = L.microfacet("ggx", ("ideal",), True), "eval", ("elliptic", 0.3, 0.3, 0.0)
+    elif name == "beckmann_sample":
+        b, op, par = L.microfacet("beckmann", ("ideal",), True), "sample", ("elliptic", 0.2, 0.5, 0.7)
+    else:   # merl_fit: materials / s, one fit per thread
+        tab = synth.merl_table(*synth.material_recipe(0))
+        if kind == "reference":
+            path = "/tmp/djb_bench_cpu.binary"
+            synth.write_merl_binary(path, tab)
+            src = L.merl(path)
+        else:
+            src = L.merl_from_table(tab)
+        t0 = time.perf_counter(); L.tabular(src, 90, True); t1 = time.perf_counter() - t0
+        reps = max(1, min(8, int(budget_s / max(t1, 1e-3) / 2)))
+        ths = [threading.Thread(target=lambda: [L.tabular(src, 90, True) for _ in range(reps)]) for _ in range(cores)]
+        t0 = time.perf_counter()
+        for t in ths: t.start()
+        for t in ths: t.join()
+        dt = time.perf_counter() - t0
+        return {"value": cores * reps / dt, "unit": "materials/s", "cores": cores, "kind": kind,
+                "sample": f"{cores * reps} fits of one synthetic MERL table (res 90), {cores} threads; "
+                          f"single-thread {1.0 / t1:.2f} materials/s", "single_thread": 1.0 / t1}
+
+    def run(n, threads):
+        i = synth.directions_aos(n, synth.SEED_I); o = synth.directions_aos(n, synth.SEED_O)
+        u1 = synth.uniforms(n, synth.SEED_U1); u2 = synth.uniforms(n, synth.SEED_U2)
+        bounds = np.linspace(0, n, threads + 1).astype(np.int64)
+        chunks = [slice(int(a), int(b)) for a, b in zip(bounds[:-1], bounds[1:])]   # contiguous views
+
+        def work(idx):
+            if op == "sample":
+                L.sample(b, u1[idx], u2[idx], o[idx], par)
+            else:
+                L.eval(b, i[idx], o[idx], par, "eval")
+                if name == "ggx_eval_pdf":
+                    L.eval(b, i[idx], o[idx], par, "pdf")
+        ths = [threading.Thread(target=work, args=(c,)) for c in chunks]
+        t0 = time.perf_counter()
+        for t in ths: t.start()
+        for t in ths: t.join()
+        return n / (time.perf_counter() - t0)
+
+    r1 = run(500_000, 1)                                       # single thread: the reference's own design
+    n_all = int(min(max(r1 * cores * budget_s * 0.5, 1e6), 2e8))
+    rall = run(n_all, cores)
+    return {"value": rall, "unit": "evals/s" if op != "sample" else "samples/s", "cores": cores, "kind": kind,
+            "sample": f"{n_all} units of the same synthetic workload on {cores} threads "
+                      f"(ctypes releases the GIL; the reference object is const); single-thread {r1:.3e}/s",
+            "single_thread": r1}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from dj_brdf_amd import djb, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available() and djb.device_count() > 0, "bench.py needs MI355X GPUs; there is no CPU path"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    ctx = djb.Context(local)    # runs on torch's current stream of this device
+
+    name = args.workload
+    n_default, bytes_per_unit, unit, kernel = WORKLOADS[name]
+    n = args.n or n_default
+    step, keep = make_step(name, n, djb, synth, ctx, torch)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()                       # HIP event on the stream the kernels are launched on
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_stop_ms()             # records + synchronises the closing event
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, ev_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        value = world * n * args.steps / dt
+        launch_ms = ev_ms / args.steps
+        if bytes_per_unit is not None:
+            achieved = n * bytes_per_unit / (launch_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                        "algorithmic_bytes_per_unit": bytes_per_unit, "launch_ms": launch_ms}
+            pmc = os.path.join(ROOT, "profiles", f"pmc_{name}.json")
+            if os.path.exists(pmc):      # HBM bytes per launch from rocprofv3 PMC passes (profiles/README.md)
+                try:
+                    roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+        else:
+            # the fit moves ~5.5k table reads per material: HBM traffic is negligible, the kernel is
+            # latency/VALU-bound; report the achieved rate only
+            roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                        "traffic": None, "kernel": kernel, "launch_ms": launch_ms}
+        rec = {
+            "metric": "BRDF evals/sec" if name != "merl_fit" else "MERL materials fitted/sec",
+            "value": value, "unit": f"{unit}/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (f64 transcendentals)", "data": "synthetic",
+            "config": {"workload": name, "units_per_gpu_per_step": n,
+                       "brdf": {"merl_eval": "MERL 90x90x180x3 nearest-bin (synthetic GGX0.3+diffuse table)",
+                                "ggx_eval_pdf": "GGX isotropic alpha=0.3, ideal Fresnel, eval+pdf fused",
+                                "beckmann_sample": "Beckmann elliptic(0.2,0.5,0.7) VNDF sample, on-chip RNG",
+                                "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material"}[name],
+                       "layout": "SoA float32 in HBM", "parallelism": f"independent x{world} (no collective)"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(name, synth)
+        if world == 1 and not args.no_secondary and name == "merl_eval" and args.n is None:
+            sec = {}
+            del keep
+            torch.cuda.empty_cache()
+            for other in ("ggx_eval_pdf", "beckmann_sample", "merl_fit"):
+                on, ob, ou, _ = WORKLOADS[other]
+                st, kp = make_step(other, on, djb, synth, ctx, torch)
+                st(); torch.cuda.synchronize()
+                ctx.timer_start()
+                for _ in range(3):
+                    st()
+                ms = ctx.timer_stop_ms() / 3
+                sec[other] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms,
+                              "hbm_GBps": (on * ob / (ms * 1e-3) / 1e9) if ob else None}
+                del st, kp
+                torch.cuda.empty_cache()
+            rec["secondary"] = sec
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,7 +50,7 @@ class exc(RuntimeError):
 
 # every symbol include/djb_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "djb_last_error", "djb_version", "djb_device_count", "djb_ctx_create", "djb_ctx_destroy",
+    "djb_last_error", "djb_version", "djb_device_count", "djb_ctx_create", "djb_ctx_create_on_stream", "djb_ctx_destroy",
     "djb_ctx_synchronize", "djb_ctx_stream", "djb_timer_start", "djb_timer_stop_ms",
     "djb_brdf_create_beckmann", "djb_brdf_create_ggx", "djb_brdf_create_merl_from_file",
     "djb_brdf_create_merl_from_memory", "djb_brdf_create_utia_from_file",
@@ -58,7 +58,7 @@ EXPORTS = [
     "djb_brdf_destroy", "djb_brdf_kind", "djb_brdf_get_shadow", "djb_eval_batch", "djb_evalp_batch",
     "djb_pdf_batch", "djb_eval_pdf_batch", "djb_sample_batch", "djb_sample_rng_batch",
     "djb_evalp_is_batch", "djb_io_to_hd_batch", "djb_hd_to_io_batch", "djb_merl_index_batch",
-    "djb_params_resolve", "djb_tabular_get", "djb_tabular_fit", "djb_fit_merl_batch",
+    "djb_params_resolve", "djb_tabular_get", "djb_tabular_fit", "djb_fit_merl_batch", "djb_fit_brdf_batch",
     "djb_gen_directions", "djb_gen_uniforms", "djb_histogram_xy",
 ]
 

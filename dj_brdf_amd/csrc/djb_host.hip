@@ -343,7 +343,7 @@ djb_status djb_device_count(int *count)
 	return DJB_OK;
 }
 
-djb_status djb_ctx_create(int device, void *hip_stream, djb_ctx **out)
+static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **out)
 {
 	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	int n = 0;
@@ -354,9 +354,9 @@ djb_status djb_ctx_create(int device, void *hip_stream, djb_ctx **out)
 	HIP_TRY(hipSetDevice(device));
 	djb_ctx *c = new djb_ctx();
 	c->device = device;
-	c->owns_stream = hip_stream == nullptr;
+	c->owns_stream = own;
 	c->stream = (hipStream_t)hip_stream;
-	if (c->owns_stream) {
+	if (own) {
 		hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 		if (e != hipSuccess) { delete c; return fail(DJB_ERR_HIP, "djb_error: hipStreamCreate: %s", hipGetErrorString(e)); }
 	}
@@ -365,6 +365,12 @@ djb_status djb_ctx_create(int device, void *hip_stream, djb_ctx **out)
 	}
 	*out = c;
 	return DJB_OK;
+}
+
+djb_status djb_ctx_create(int device, djb_ctx **out) { return ctx_create(device, nullptr, true, out); }
+djb_status djb_ctx_create_on_stream(int device, void *hip_stream, djb_ctx **out)
+{
+	return ctx_create(device, hip_stream, false, out);
 }
 
 djb_status djb_ctx_destroy(djb_ctx *ctx)
@@ -625,6 +631,23 @@ djb_status djb_fit_merl_batch(djb_ctx *ctx, int n_mat, const double *const *tabl
 		st = run_fit(ctx, srcs, DJB_KIND_MERL, res, shadow, alpha_beckmann, alpha_ggx, p22, sigma, cdf, qf, fresnel, nullptr);
 	for (djb_brdf *b : mats) djb_brdf_destroy(b);
 	return st;
+}
+
+djb_status djb_fit_brdf_batch(djb_ctx *ctx, int n_mat, const djb_brdf *const *srcs_in, int res, int shadow,
+                              float *alpha_beckmann, float *alpha_ggx, float *p22, float *sigma,
+                              float *cdf, float *qf, float *fresnel)
+{
+	if (!ctx || !srcs_in || n_mat < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
+	if (n_mat == 0) return DJB_OK;
+	djb_status st = check_call(ctx, srcs_in[0], 0, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::vector<Brdf> srcs(n_mat);
+	for (int m = 0; m < n_mat; ++m) {
+		if (!srcs_in[m] || srcs_in[m]->dev.kind != srcs_in[0]->dev.kind || srcs_in[m]->ctx->device != ctx->device)
+			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: batch fit needs BRDFs of one kind on the ctx device");
+		srcs[m] = srcs_in[m]->dev;
+	}
+	return run_fit(ctx, srcs, srcs[0].kind, res, shadow, alpha_beckmann, alpha_ggx, p22, sigma, cdf, qf, fresnel, nullptr);
 }
 
 // ---------------------------------------------------------------- the operator surface

@@ -41,10 +41,13 @@ class Context:
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         lib = _lib.load()
         self.device = device
-        if stream is None and torch is not None and torch.cuda.is_available():
-            stream = torch.cuda.current_stream(device).cuda_stream
         self._h = C.c_void_p()
-        _lib.check(lib.djb_ctx_create(C.c_int(device), C.c_void_p(stream or 0), C.byref(self._h)))
+        if stream is None and torch is not None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(device).cuda_stream   # 0 == the default (null) stream
+        if stream is None:
+            _lib.check(lib.djb_ctx_create(C.c_int(device), C.byref(self._h)))
+        else:
+            _lib.check(lib.djb_ctx_create_on_stream(C.c_int(device), C.c_void_p(stream), C.byref(self._h)))
 
     def synchronize(self):
         _lib.check(_lib.load().djb_ctx_synchronize(self._h))
@@ -551,6 +554,19 @@ def fit_merl_batch(tables, res: int = 90, shadow: bool = True, ctx: Optional[Con
     _lib.check(lib.djb_fit_merl_batch(ctx._h, C.c_int(n), ptrs, C.c_int(res), C.c_int(int(shadow)),
                                       C.c_void_p(ab.ctypes.data), C.c_void_p(ag.ctypes.data), *args))
     return (ab, ag, extra) if return_tables else (ab, ag)
+
+
+def fit_brdf_batch(brdfs, res: int = 90, shadow: bool = True, ctx: Optional[Context] = None):
+    """The same fit for BRDF objects already resident in HBM (no host->device traffic)."""
+    lib = _lib.load()
+    ctx = ctx or brdfs[0].ctx
+    n = len(brdfs)
+    ptrs = (C.c_void_p * max(n, 1))(*[b._h.value for b in brdfs])
+    ab, ag = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    _lib.check(lib.djb_fit_brdf_batch(ctx._h, C.c_int(n), ptrs, C.c_int(res), C.c_int(int(shadow)),
+                                      C.c_void_p(ab.ctypes.data), C.c_void_p(ag.ctypes.data),
+                                      None, None, None, None, None))
+    return ab, ag
 
 
 # --------------------------------------------------------------------------- synthetic workloads (device)

@@ -1,0 +1,99 @@
+"""Batch counterpart of the reference's example driver (examples/merl_params.cpp:30-73):
+
+    python -m dj_brdf_amd.merl_params [-o params.txt] [--gpus N] a.binary b.binary ...
+
+fits Beckmann / GGX roughness to every MERL file with the HIP power-iteration kernel and writes
+the same ``params.txt`` ("# MERL Beckmann GGX" then ``name %.3f %.3f`` per file, input order).
+Materials are independent: with several GPUs visible they are dealt round-robin, one host
+thread + one HIP stream per GPU, no collective.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import threading
+
+import numpy as np
+
+from . import djb, shard
+
+
+def material_name(path: str) -> str:
+    """sscanf(strrchr(input, '/') + 1, "%[^.]s", name): basename up to the first '.'
+    (examples/merl_params.cpp:64); at most 63 characters fit the reference's char name[64]."""
+    return os.path.basename(path).split(".")[0][:63]
+
+
+def read_merl_payload(path: str) -> np.ndarray:
+    """The 3*n doubles of a MERL file (header checked like dj_brdf.h:963-983)."""
+    try:
+        with open(path, "rb") as f:
+            dims = np.fromfile(f, dtype=np.int32, count=3)
+            n = int(np.prod(dims.astype(np.int64))) if dims.size == 3 else 0
+            if n <= 0:
+                raise djb.exc(3, "djb_error: Failed to read MERL header\n")
+            data = np.fromfile(f, dtype=np.float64, count=3 * n)
+    except OSError:
+        raise djb.exc(2, f"djb_error: Failed to open {path}\n")
+    if data.size != 3 * n:
+        raise djb.exc(4, f"djb_error: Reading {path} failed\n")
+    return data
+
+
+def fit_files(paths, res=90, shadow=True, gpus=None, chunk=8):
+    """[(alpha_beckmann, alpha_ggx)] for every path, in input order."""
+    n_dev = djb.device_count()
+    if n_dev == 0:
+        raise djb.exc(7, "djb_error: no HIP device; dj_brdf_amd has no CPU path")
+    gpus = min(gpus or n_dev, n_dev, max(len(paths), 1))
+    out = [None] * len(paths)
+    errors = []
+
+    def worker(rank):
+        try:
+            ctx = djb.Context(rank)
+            mine = shard.round_robin(len(paths), gpus, rank)
+            for c in range(0, len(mine), chunk):
+                ids = mine[c:c + chunk]
+                ab, ag = djb.fit_merl_batch([read_merl_payload(paths[k]) for k in ids], res, shadow, ctx=ctx)
+                for k, a, g in zip(ids, ab, ag):
+                    out[k] = (float(a), float(g))
+        except Exception as e:  # surfaced on the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(gpus)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def format_params_txt(paths, alphas) -> str:
+    lines = ["# MERL Beckmann GGX\n"]
+    for p, (ab, ag) in zip(paths, alphas):
+        lines.append("%s %.3f %.3f\n" % (material_name(p), ab, ag))
+    return "".join(lines)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="merl_params", description="GGX and Beckmann Parameters for MERL BRDFs")
+    ap.add_argument("files", nargs="*")
+    ap.add_argument("-o", "--output", default="params.txt")
+    ap.add_argument("--gpus", type=int, default=None)
+    ap.add_argument("--res", type=int, default=90)
+    args = ap.parse_args(argv)
+    if not args.files:
+        ap.print_usage()
+        return 0
+    alphas = fit_files(args.files, res=args.res, gpus=args.gpus)
+    with open(args.output, "w") as f:
+        f.write(format_params_txt(args.files, alphas))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

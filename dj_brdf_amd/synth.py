@@ -80,17 +80,27 @@ def directions_aos(n: int, seed: int, start: int = 0) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- MERL tables
+def _trig_deg(deg):
+    """(cos, sin) of angles in degrees via libm's scalar double routines (math.*), NOT numpy's
+    SIMD loops, so the table is bit-reproducible wherever the same glibc is installed."""
+    rad = [math.radians(float(d)) for d in deg]
+    return (np.array([math.cos(r) for r in rad], dtype=np.float64),
+            np.array([math.sin(r) for r in rad], dtype=np.float64))
+
+
 def _bin_centre_io():
-    """(i, o) unit vectors (float64, shape [90,90,180,3]) at the MERL bin centres."""
+    """(i, o, h) unit vectors (float64, shape [90,90,180,3]) at the MERL bin centres."""
     ih = np.arange(90, dtype=np.float64) + 0.5
-    th = np.radians(ih * ih / 90.0)[:, None, None]
-    td = np.radians(np.arange(90, dtype=np.float64) + 0.5)[None, :, None]
-    pd = np.radians(np.arange(180, dtype=np.float64) + 0.5)[None, None, :]
+    ct, st = _trig_deg(ih * ih / 90.0)
+    ctd, std = _trig_deg(np.arange(90, dtype=np.float64) + 0.5)
+    cpd, spd = _trig_deg(np.arange(180, dtype=np.float64) + 0.5)
+    ct, st = ct[:, None, None], st[:, None, None]
+    ctd, std = ctd[None, :, None], std[None, :, None]
+    cpd, spd = cpd[None, None, :], spd[None, None, :]
     # d in the half-vector frame, then rotate by theta_h about y (phi_h = 0)
-    dx, dy, dz = np.sin(td) * np.cos(pd), np.sin(td) * np.sin(pd), np.cos(td) + 0 * pd
-    ct, st = np.cos(th), np.sin(th)
-    ix, iy, iz = ct * dx + st * dz, dy + 0 * th, -st * dx + ct * dz
-    hx, hy, hz = st + 0 * dx, 0 * dx + 0 * th, ct + 0 * dx
+    dx, dy, dz = std * cpd, std * spd, ctd + 0 * cpd
+    ix, iy, iz = ct * dx + st * dz, dy + 0 * ct, -st * dx + ct * dz
+    hx, hy, hz = st + 0 * dx, 0 * dx + 0 * ct, ct + 0 * dx
     idh = ix * hx + iy * hy + iz * hz
     ox, oy, oz = 2 * idh * hx - ix, 2 * idh * hy - iy, 2 * idh * hz - iz
     return np.stack([ix, iy, iz], -1), np.stack([ox, oy, oz], -1), np.stack([hx, hy, hz], -1)
@@ -99,24 +109,28 @@ def _bin_centre_io():
 def merl_table(alpha: float = 0.3, diffuse=(0.10, 0.08, 0.05), f0=(0.9, 0.7, 0.4)) -> np.ndarray:
     """Synthetic MERL table, shape [3, 90, 90, 180] float64, in FILE units.
 
-    GGX isotropic(alpha) with height-correlated Smith G, Schlick Fresnel(f0) plus
-    diffuse/pi, evaluated at bin centres and divided by the per-channel MERL
-    scale; entries whose i or o is below the horizon are -1 (real MERL files
-    carry negative values there and djb::merl::eval returns 0 for them).
+    GGX isotropic(alpha) with a separable-style Smith G, Schlick Fresnel(f0) plus diffuse/pi,
+    evaluated at bin centres and divided by the per-channel MERL scale; entries whose i or o is
+    below the horizon are -1 (real MERL files carry negative values there and djb::merl::eval
+    returns 0 for them).  Only + - * / sqrt on doubles after the bin-centre trig, so the bits do
+    not depend on numpy's vector-math dispatch.
     """
     i, o, h = _bin_centre_io()
     iz, oz, hz = i[..., 2], o[..., 2], h[..., 2]
     valid = (iz > 1e-6) & (oz > 1e-6)
     izs, ozs = np.where(valid, iz, 1.0), np.where(valid, oz, 1.0)
     a2 = alpha * alpha
-    D = a2 / (np.pi * (hz * hz * (a2 - 1.0) + 1.0) ** 2)
+    den = hz * hz * (a2 - 1.0) + 1.0
+    D = a2 / (math.pi * den * den)
     lam = lambda c: 0.5 * (-1.0 + np.sqrt(1.0 + a2 * (1.0 - c * c) / (c * c)))
     G = 1.0 / (1.0 + lam(izs) + lam(ozs))
-    cd = np.clip((o * h).sum(-1), 0.0, 1.0)
+    cd = np.minimum(np.maximum((o * h).sum(-1), 0.0), 1.0)
+    omc = 1.0 - cd
+    omc5 = omc * omc * omc * omc * omc
     out = np.empty((3,) + iz.shape, dtype=np.float64)
     for c in range(3):
-        F = f0[c] + (1.0 - f0[c]) * (1.0 - cd) ** 5
-        fr = F * D * G / (4.0 * izs * ozs) + diffuse[c] / np.pi
+        F = f0[c] + (1.0 - f0[c]) * omc5
+        fr = F * D * G / (4.0 * izs * ozs) + diffuse[c] / math.pi
         out[c] = np.where(valid, fr / MERL_SCALE[c], -1.0)
     return out
 

@@ -84,8 +84,11 @@ const char *djb_last_error(void);
 int         djb_version(void);
 /* number of usable gfx950 devices (0 when there is no GPU; never falls back to a CPU path) */
 djb_status  djb_device_count(int *count);
-/* hip_stream: a hipStream_t to run on (e.g. torch's current stream), or NULL to create one */
-djb_status  djb_ctx_create(int device, void *hip_stream, djb_ctx **out);
+/* a context with its own (non-blocking) HIP stream */
+djb_status  djb_ctx_create(int device, djb_ctx **out);
+/* a context that runs on the caller's hipStream_t (e.g. torch's current stream); NULL means the
+ * device's default (null) stream, so work is ordered with everything else issued there */
+djb_status  djb_ctx_create_on_stream(int device, void *hip_stream, djb_ctx **out);
 djb_status  djb_ctx_destroy(djb_ctx *ctx);
 djb_status  djb_ctx_synchronize(djb_ctx *ctx);
 void       *djb_ctx_stream(djb_ctx *ctx);
@@ -175,6 +178,12 @@ djb_status djb_tabular_fit(const djb_brdf *tab, float *alpha_beckmann, float *al
  * payload, host memory).  Outputs (host): alpha arrays [n_materials]; optional per-material
  * tables p22/sigma/cdf/qf [n_materials][res] and fresnel [n_materials][res][3] (may be NULL). */
 djb_status djb_fit_merl_batch(djb_ctx *, int n_materials, const double *const *tables,
+                              int res, int shadow, float *alpha_beckmann, float *alpha_ggx,
+                              float *p22, float *sigma, float *cdf, float *qf, float *fresnel);
+
+/* Same fit for n_materials BRDF objects already resident in HBM (all of one kind, e.g. MERL
+ * tables created with djb_brdf_create_merl_*): no host->device traffic inside the call.    */
+djb_status djb_fit_brdf_batch(djb_ctx *, int n_materials, const djb_brdf *const *srcs,
                               int res, int shadow, float *alpha_beckmann, float *alpha_ggx,
                               float *p22, float *sigma, float *cdf, float *qf, float *fresnel);
 

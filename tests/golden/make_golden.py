@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+It loads oracle/_ref/libdjb_ref.so -- the unmodified /root/reference/dj_brdf.h compiled in place
+behind oracle/ref_shim.cpp -- and oracle/_ref/merl_params (the reference's own example driver),
+feeds them the seeded synthetic inputs of dj_brdf_amd/synth.py, and stores inputs + outputs as
+small .npz / .txt fixtures.  The fixtures are data; no reference source is stored.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oraclelib  # noqa: E402
+from dj_brdf_amd import synth  # noqa: E402
+from golden_cases import (FIT_CASES, MICROFACET_CASES, N_FIT_EVAL, N_HD, N_MERL, N_MICROFACET,  # noqa: E402
+                          PARAM_CASES, PARAMS_TXT_MATERIALS)
+
+
+def main():
+    R = oraclelib.reference()
+    assert R is not None, "needs /root/reference (build container)"
+
+    # ---- microfacet eval / evalp / pdf / sample / evalp_is
+    i = synth.directions_aos(N_MICROFACET, synth.SEED_I)
+    o = synth.directions_aos(N_MICROFACET, synth.SEED_O)
+    u1 = synth.uniforms(N_MICROFACET, synth.SEED_U1)
+    u2 = synth.uniforms(N_MICROFACET, synth.SEED_U2)
+    out = {"i": i, "o": o, "u1": u1, "u2": u2}
+    for k, (ndf, fres, shadow, par) in enumerate(MICROFACET_CASES):
+        b = R.microfacet(ndf, fres, shadow)
+        for op in ("eval", "evalp", "pdf"):
+            out[f"c{k}_{op}"] = R.eval(b, i, o, par, op)
+        out[f"c{k}_sample"] = R.sample(b, u1, u2, o, par)
+        w, si, pdf = R.evalp_is(b, u1, u2, o, par)
+        out[f"c{k}_is_w"], out[f"c{k}_is_i"], out[f"c{k}_is_pdf"] = w, si, pdf
+    np.savez_compressed(os.path.join(HERE, "microfacet.npz"), **out)
+
+    # ---- params, special functions, half/diff transforms
+    out = {}
+    for k, p in enumerate(PARAM_CASES):
+        out[f"p{k}"] = R.params_get(p)
+    x = np.linspace(-4, 4, 4001).astype(np.float32)
+    out["erf_x"], out["erf_y"] = x, R.erf(x)
+    x = np.linspace(-0.99999, 0.99999, 4001).astype(np.float32)
+    out["erfinv_x"], out["erfinv_y"] = x, R.erfinv(x)
+    i = synth.directions_aos(N_HD, synth.SEED_I, start=1000)
+    o = synth.directions_aos(N_HD, synth.SEED_O, start=1000)
+    h, d = R.io_to_hd(i, o)
+    bi, bo = R.hd_to_io(h, d)
+    out.update(hd_i=i, hd_o=o, hd_h=h, hd_d=d, hd_back_i=bi, hd_back_o=bo)
+    np.savez_compressed(os.path.join(HERE, "math.npz"), **out)
+
+    # ---- MERL lookup (hash-filled table: exact on any machine)
+    tmp = tempfile.mkdtemp(prefix="djb_golden_")
+    try:
+        i = synth.directions_aos(N_MERL, synth.SEED_I, start=5000)
+        o = synth.directions_aos(N_MERL, synth.SEED_O, start=5000)
+        path = os.path.join(tmp, "hashed.binary")
+        synth.write_merl_binary(path, synth.merl_table_hashed())
+        m = R.merl(path)
+        np.savez_compressed(os.path.join(HERE, "merl.npz"), i=i, o=o, index=R.merl_index(i, o),
+                            eval=R.eval(m, i, o), evalp=R.eval(m, i, o, None, "evalp"),
+                            pdf=R.eval(m, i, o, None, "pdf"))
+
+        # ---- the fitter
+        i = synth.directions_aos(N_FIT_EVAL, synth.SEED_I, start=9000)
+        o = synth.directions_aos(N_FIT_EVAL, synth.SEED_O, start=9000)
+        u1 = synth.uniforms(N_FIT_EVAL, synth.SEED_U1, start=9000)
+        u2 = synth.uniforms(N_FIT_EVAL, synth.SEED_U2, start=9000)
+        out = {"i": i, "o": o, "u1": u1, "u2": u2}
+        for name, (src, res, shadow) in FIT_CASES.items():
+            if src[0] == "merl":
+                tab = synth.merl_table(*src[1:])
+                out[f"{name}_table_sha256"] = np.frombuffer(hashlib.sha256(tab.tobytes()).digest(), np.uint8)
+                path = os.path.join(tmp, f"{name}.binary")
+                synth.write_merl_binary(path, tab)
+                s = R.merl(path)
+            else:
+                s = R.microfacet(src[0], ("ideal",), src[1])
+            t = R.tabular(s, res, shadow)
+            for k, v in R.tabular_tables(t).items():
+                out[f"{name}_{k}"] = np.atleast_1d(v)
+            out[f"{name}_eval"] = R.eval(t, i, o, None, "eval")
+            out[f"{name}_pdf"] = R.eval(t, i, o, None, "pdf")
+            out[f"{name}_sample"] = R.sample(t, u1, u2, o)
+        np.savez_compressed(os.path.join(HERE, "fit.npz"), **out)
+
+        # ---- params.txt of the reference's own example driver (examples/merl_params.cpp)
+        exe = oraclelib.ref_merl_params_binary()
+        files = []
+        for name, recipe in PARAMS_TXT_MATERIALS:
+            path = os.path.join(tmp, name + ".binary")
+            synth.write_merl_binary(path, synth.merl_table(*recipe))
+            files.append(path)
+        subprocess.run([exe] + files, cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        shutil.copy(os.path.join(tmp, "params.txt"), os.path.join(HERE, "params_expected.txt"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

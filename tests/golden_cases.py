@@ -1,0 +1,45 @@
+"""Case lists shared by tests/golden/make_golden.py (which runs the real reference) and the tests
+that replay the stored vectors."""
+import numpy as np
+
+N_MICROFACET = 384
+N_HD = 4096
+N_MERL = 32768
+N_FIT_EVAL = 2048
+
+_SPLINE = ("spline",) + tuple(np.linspace(0.2, 1.0, 30, dtype=np.float32).repeat(3).tolist())
+_FRESNELS = [("unpolarized", 1.5, 1.8, 2.4), ("schlick", 1.0, 0.71, 0.29),
+             ("sgd", 0.8, 0.5, 0.3, 0.1, 0.05, 0.02), _SPLINE]
+_PARAMS = [None, ("elliptic", 0.3, 0.3, 0.0), ("elliptic", 0.2, 0.5, 0.7),
+           ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)]
+
+# (ndf, fresnel, shadow, params)
+MICROFACET_CASES = []
+for _ndf in ("ggx", "beckmann"):
+    for _sh in (True, False):
+        for _p in _PARAMS:
+            MICROFACET_CASES.append((_ndf, ("ideal",), _sh, _p))
+    for _f in _FRESNELS:
+        for _p in (_PARAMS[1], _PARAMS[2]):
+            MICROFACET_CASES.append((_ndf, _f, True, _p))
+
+PARAM_CASES = _PARAMS + [("elliptic", 1.0, 1.0, 0.0), ("elliptic", 0.05, 0.8, -1.2),
+                         ("pdfparams", 0.3, 0.3, 0.0, 0.0, 0.0), ("pdfparams", 1.5, 0.2, -0.9, -0.3, 0.4)]
+
+# name -> (source, res, shadow); source = ("merl", alpha, diffuse, f0) | (ndf, shadow_of_source)
+FIT_CASES = {
+    "ggx90": (("ggx", True), 90, True),
+    "beckmann180": (("beckmann", False), 180, True),     # tests/plot_cdf.cpp:25-30 of the reference
+    "ggx180": (("ggx", False), 180, True),               # tests/plot_cdf.cpp:35-40
+    "ggx7": (("ggx", True), 7, True),
+    "merl_a30": (("merl", 0.3, (0.10, 0.08, 0.05), (0.9, 0.7, 0.4)), 90, True),
+    "merl_a30_noshadow": (("merl", 0.3, (0.10, 0.08, 0.05), (0.9, 0.7, 0.4)), 90, False),  # mitsuba/dj_merl.cpp:32
+    "merl_a08": (("merl", 0.08, (0.3, 0.2, 0.1), (0.04, 0.04, 0.04)), 90, True),
+}
+
+# materials run through the reference's examples/merl_params binary -> params_expected.txt
+PARAMS_TXT_MATERIALS = [
+    ("gold-metallic-paint", (0.3, (0.10, 0.08, 0.05), (0.9, 0.7, 0.4))),
+    ("chrome", (0.05, (0.01, 0.01, 0.01), (0.95, 0.95, 0.95))),
+    ("white-fabric", (0.55, (0.6, 0.6, 0.6), (0.04, 0.04, 0.04))),
+]

@@ -1,0 +1,122 @@
+"""The CPU oracle (oracle/djb_oracle.c) against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  Bit-exact everywhere: the oracle is the same arithmetic."""
+import os
+
+import numpy as np
+import pytest
+
+from dj_brdf_amd import synth
+from golden_cases import FIT_CASES, MICROFACET_CASES, PARAM_CASES, PARAMS_TXT_MATERIALS
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
+def test_inputs_regenerate_bit_exactly():
+    g = np.load(os.path.join(G, "microfacet.npz"))
+    n = g["i"].shape[0]
+    assert same(synth.directions_aos(n, synth.SEED_I), g["i"])
+    assert same(synth.directions_aos(n, synth.SEED_O), g["o"])
+    assert same(synth.uniforms(n, synth.SEED_U1), g["u1"])
+    assert same(synth.uniforms(n, synth.SEED_U2), g["u2"])
+
+
+@pytest.mark.parametrize("k", range(len(MICROFACET_CASES)))
+def test_microfacet_ops(oracle, k):
+    g = np.load(os.path.join(G, "microfacet.npz"))
+    ndf, fres, shadow, par = MICROFACET_CASES[k]
+    b = oracle.microfacet(ndf, fres, shadow)
+    i, o, u1, u2 = g["i"], g["o"], g["u1"], g["u2"]
+    for op in ("eval", "evalp", "pdf"):
+        assert same(oracle.eval(b, i, o, par, op), g[f"c{k}_{op}"]), (MICROFACET_CASES[k][:1], op)
+    assert same(oracle.sample(b, u1, u2, o, par), g[f"c{k}_sample"])
+    w, si, pdf = oracle.evalp_is(b, u1, u2, o, par)
+    assert same(w, g[f"c{k}_is_w"]) and same(si, g[f"c{k}_is_i"]) and same(pdf, g[f"c{k}_is_pdf"])
+
+
+def test_known_answers(oracle):
+    """Sanity anchors measured on the reference at survey time."""
+    f = np.float32
+    i = np.array([[0.3, 0.2, np.sqrt(f(1) - f(0.3) * f(0.3) - f(0.2) * f(0.2))]], f)
+    o = np.array([[-0.4, 0.1, np.sqrt(f(1) - f(0.4) * f(0.4) - f(0.1) * f(0.1))]], f)
+    g = oracle.microfacet("ggx")
+    iso = ("elliptic", 0.3, 0.3, 0.0)
+    assert oracle.eval(g, i, o, iso)[0, 0] == f(0.621380985)
+    assert oracle.eval(g, i, o, iso, "pdf")[0] == f(0.581518769)
+    s = oracle.sample(g, [0.25], [0.75], o, iso)[0]
+    assert np.array_equal(s, np.array([0.657071352, 0.080957301, 0.749468625], f))
+    b = oracle.microfacet("beckmann")
+    ell = ("elliptic", 0.2, 0.5, 0.7)
+    assert oracle.eval(b, i, o, ell)[0, 0] == f(0.562808752)
+    assert oracle.eval(b, i, o, ell, "pdf")[0] == f(0.524953067)
+    p = oracle.params_get(ell)
+    assert (p[6], p[7], p[8]) == (f(0.356585801), f(0.403542489), f(0.719068825))
+    h, d = oracle.io_to_hd(i, o)
+    assert np.array_equal(h[0], np.array([-0.0534558371, 0.160367534, 0.985608757], f))
+    assert np.array_equal(d[0], np.array([-0.06416931, -0.347850591, 0.935351491], f))
+
+
+def test_params_and_math(oracle):
+    g = np.load(os.path.join(G, "math.npz"))
+    for k, p in enumerate(PARAM_CASES):
+        assert same(oracle.params_get(p), g[f"p{k}"]), p
+    assert same(oracle.erf(g["erf_x"]), g["erf_y"])
+    assert same(oracle.erfinv(g["erfinv_x"]), g["erfinv_y"])
+    h, d = oracle.io_to_hd(g["hd_i"], g["hd_o"])
+    assert same(h, g["hd_h"]) and same(d, g["hd_d"])
+    bi, bo = oracle.hd_to_io(g["hd_h"], g["hd_d"])
+    assert same(bi, g["hd_back_i"]) and same(bo, g["hd_back_o"])
+
+
+def test_merl_lookup(oracle):
+    g = np.load(os.path.join(G, "merl.npz"))
+    i, o = g["i"], g["o"]
+    assert np.array_equal(oracle.merl_index(i, o), g["index"])
+    m = oracle.merl_from_table(synth.merl_table_hashed())
+    for op in ("eval", "evalp", "pdf"):
+        assert same(oracle.eval(m, i, o, None, op), g[op]), op
+    # the index is what the lookup used: rgb == prescaled table[index] or 0 below the horizon
+    tab = synth.merl_table_hashed().reshape(3, -1)
+    rgb = np.stack([(tab[c, g["index"]] * s).astype(np.float32) for c, s in enumerate(synth.MERL_SCALE)], 1)
+    rgb[(rgb < 0).any(axis=1)] = 0
+    assert same(rgb, g["eval"])
+
+
+@pytest.mark.parametrize("name", list(FIT_CASES))
+def test_fitter(oracle, name):
+    import hashlib
+    g = np.load(os.path.join(G, "fit.npz"))
+    src, res, shadow = FIT_CASES[name]
+    if src[0] == "merl":
+        tab = synth.merl_table(*src[1:])
+        sha = np.frombuffer(hashlib.sha256(tab.tobytes()).digest(), np.uint8)
+        assert np.array_equal(sha, g[f"{name}_table_sha256"]), \
+            "synthetic MERL table is not bit-reproducible on this machine (libm differs?)"
+        s = oracle.merl_from_table(tab)
+    else:
+        s = oracle.microfacet(src[0], ("ideal",), src[1])
+    t = oracle.tabular(s, res, shadow)
+    for k, v in oracle.tabular_tables(t).items():
+        assert same(np.atleast_1d(v), g[f"{name}_{k}"]), (name, k)
+    assert same(oracle.eval(t, g["i"], g["o"], None, "eval"), g[f"{name}_eval"])
+    assert same(oracle.eval(t, g["i"], g["o"], None, "pdf"), g[f"{name}_pdf"])
+    assert same(oracle.sample(t, g["u1"], g["u2"], g["o"]), g[f"{name}_sample"])
+
+
+def test_params_txt_of_reference_driver(oracle):
+    """examples/merl_params.cpp run on three synthetic files; the oracle's fit prints the same bytes."""
+    want = open(os.path.join(G, "params_expected.txt")).read()
+    lines = ["# MERL Beckmann GGX\n"]
+    for name, recipe in PARAMS_TXT_MATERIALS:
+        t = oracle.tabular(oracle.merl_from_table(synth.merl_table(*recipe)), 90, True)
+        r = oracle.tabular_tables(t)
+        lines.append("%s %.3f %.3f\n" % (name, r["alpha_beckmann"], r["alpha_ggx"]))
+    assert "".join(lines) == want

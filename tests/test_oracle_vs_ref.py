@@ -1,0 +1,109 @@
+"""Pin the CPU oracle against the REAL reference compiled in place (oracle/_ref/libdjb_ref.so).
+Only runs where /root/reference exists (the build container); elsewhere the committed golden
+vectors (tests/test_oracle_golden.py) carry the same guarantee."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import oraclelib
+from dj_brdf_amd import synth
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+N = 60000
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return (synth.directions_aos(N, synth.SEED_I, 77), synth.directions_aos(N, synth.SEED_O, 77),
+            synth.uniforms(N, synth.SEED_U1, 77), synth.uniforms(N, synth.SEED_U2, 77))
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+@pytest.mark.parametrize("fres", [("ideal",), ("unpolarized", 1.3, 1.6, 2.9), ("schlick", 0.9, 0.5, 0.1),
+                                  ("sgd", 0.7, 0.6, 0.2, 0.2, 0.1, 0.0)], ids=lambda f: f[0])
+@pytest.mark.parametrize("par", [None, ("elliptic", 0.07, 0.9, 2.1), ("pdfparams", 0.8, 0.1, -0.6, 0.2, 0.2)],
+                         ids=["std", "ell", "pdf"])
+def test_microfacet_bit_exact(oracle, reference, inputs, ndf, fres, par):
+    i, o, u1, u2 = inputs
+    for shadow in (True, False):
+        bo, br = oracle.microfacet(ndf, fres, shadow), reference.microfacet(ndf, fres, shadow)
+        for op in ("eval", "evalp", "pdf"):
+            assert np.array_equal(bits(oracle.eval(bo, i, o, par, op)), bits(reference.eval(br, i, o, par, op))), op
+        assert np.array_equal(bits(oracle.sample(bo, u1, u2, o, par)), bits(reference.sample(br, u1, u2, o, par)))
+        for a, b in zip(oracle.evalp_is(bo, u1, u2, o, par), reference.evalp_is(br, u1, u2, o, par)):
+            assert np.array_equal(bits(a), bits(b))
+        for q, args in (("ndf", (i,)), ("gaf", (i, i, o)), ("g1", (i, o)), ("sigma", (o,)), ("vndf", (i, o))):
+            assert np.array_equal(bits(oracle.microfacet_query(bo, q, *args, params=par)),
+                                  bits(reference.microfacet_query(br, q, *args, params=par))), q
+
+
+def test_radial_queries(oracle, reference):
+    u = np.linspace(0.001, 0.999, 5000).astype(np.float32)
+    c = np.linspace(0.01, 1.0, 5000).astype(np.float32)
+    s = np.sqrt(1 - c.astype(np.float64) ** 2).astype(np.float32)
+    for ndf in ("ggx", "beckmann"):
+        bo, br = oracle.microfacet(ndf), reference.microfacet(ndf)
+        for q, args in (("p22_radial", (u * 9,)), ("sigma_std_radial", (c,)), ("cdf_radial", (u * 5,)),
+                        ("qf_radial", (u,)), ("qf2_radial", (u, c, s)), ("qf3_radial", (u, u * 3 - 1))):
+            assert np.array_equal(bits(oracle.radial_query(bo, q, *args)), bits(reference.radial_query(br, q, *args))), (ndf, q)
+
+
+def test_merl_index_one_million(oracle, reference):
+    n = 1_000_000
+    i, o = synth.directions_aos(n, synth.SEED_I, 10**7), synth.directions_aos(n, synth.SEED_O, 10**7)
+    assert np.array_equal(oracle.merl_index(i, o), reference.merl_index(i, o))
+
+
+def test_merl_file_errors_match(oracle, reference, tmp_path):
+    """open / header / short-read failures carry the reference's messages (dj_brdf.h:970-982)."""
+    missing = str(tmp_path / "nope.binary")
+    bad = tmp_path / "bad.binary"; bad.write_bytes(np.array([0, 90, 180], np.int32).tobytes())
+    short = tmp_path / "short.binary"
+    short.write_bytes(np.array([90, 90, 180], np.int32).tobytes() + b"\0" * 1000)
+    for path in (missing, str(bad), str(short)):
+        with pytest.raises(RuntimeError) as eo:
+            oracle.merl(path)
+        with pytest.raises(RuntimeError) as er:
+            reference.merl(path)
+        assert str(eo.value) == str(er.value)
+
+
+def test_utia_synthetic(oracle, reference, tmp_path, inputs):
+    i, o, _, _ = inputs
+    rng = np.random.default_rng(5)
+    tab = rng.uniform(-5.0, 120.0, size=3 * 288 * 288)
+    p = tmp_path / "m.bin"; tab.tofile(str(p))
+    uo, ur = oracle.utia(str(p)), reference.utia(str(p))
+    for op in ("eval", "evalp"):
+        assert np.array_equal(bits(oracle.eval(uo, i, o, None, op)), bits(reference.eval(ur, i, o, None, op)))
+
+
+@pytest.mark.parametrize("res,shadow", [(90, True), (33, False)])
+def test_fitter_on_merl(oracle, reference, tmp_path, res, shadow):
+    tab = synth.merl_table(0.17, (0.2, 0.1, 0.3), (0.5, 0.6, 0.7))
+    p = str(tmp_path / "x.binary"); synth.write_merl_binary(p, tab)
+    A = oracle.tabular_tables(oracle.tabular(oracle.merl(p), res, shadow))
+    B = reference.tabular_tables(reference.tabular(reference.merl(p), res, shadow))
+    for k in A:
+        assert np.array_equal(bits(np.atleast_1d(A[k])), bits(np.atleast_1d(B[k]))), k
+
+
+def test_merl_params_driver_bytes(oracle, reference, tmp_path):
+    exe = oraclelib.ref_merl_params_binary()
+    files, lines = [], ["# MERL Beckmann GGX\n"]
+    for k in (3, 41):
+        path = str(tmp_path / (synth.MERL_NAMES[k] + ".binary"))
+        tab = synth.merl_table(*synth.material_recipe(k))
+        synth.write_merl_binary(path, tab); files.append(path)
+        r = oracle.tabular_tables(oracle.tabular(oracle.merl_from_table(tab), 90, True))
+        lines.append("%s %.3f %.3f\n" % (synth.MERL_NAMES[k], r["alpha_beckmann"], r["alpha_ggx"]))
+    subprocess.run([exe] + files, cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL)
+    assert open(tmp_path / "params.txt").read() == "".join(lines)

@@ -57,7 +57,7 @@ EXPORTS = [
     "djb_brdf_create_utia_from_memory", "djb_brdf_create_lambert", "djb_brdf_create_tabular",
     "djb_brdf_destroy", "djb_brdf_kind", "djb_brdf_get_shadow", "djb_eval_batch", "djb_evalp_batch",
     "djb_pdf_batch", "djb_eval_pdf_batch", "djb_sample_batch", "djb_sample_rng_batch",
-    "djb_evalp_is_batch", "djb_io_to_hd_batch", "djb_hd_to_io_batch", "djb_merl_index_batch",
+    "djb_evalp_is_batch", "djb_io_to_hd_batch", "djb_hd_to_io_batch", "djb_merl_index_batch", "djb_query_batch",
     "djb_params_resolve", "djb_tabular_get", "djb_tabular_fit", "djb_fit_merl_batch", "djb_fit_brdf_batch",
     "djb_gen_directions", "djb_gen_uniforms", "djb_histogram_xy",
 ]

@@ -279,6 +279,26 @@ DJB_DEV float tab_qf_radial(const Brdf &b, float u)                             
 	return F(tan(D(qf * F(DJB_PI) / 2.0f)));
 }
 
+// analytic cdf / quantile of the radial slope distribution (dj_brdf.h:1881-1889, 2067-2076)
+template <int KIND> DJB_DEV float cdf_radial(const Brdf &b, float r)
+{
+	if (KIND == KIND_BECKMANN) return F(1.0 - exp(D(-r * r)));
+	if (KIND == KIND_GGX) { float t = r * r; return F(D(t) / (1.0 + D(t))); }
+	return tab_cdf_radial(b, r);
+}
+template <int KIND> DJB_DEV float qf_radial(const Brdf &b, float u)
+{
+	if (KIND == KIND_BECKMANN) return F(sqrt(-log(1.0 - D(u))));
+	if (KIND == KIND_GGX) return F(sqrt(D(u) / (1.0 - D(u))));
+	return tab_qf_radial(b, u);
+}
+DJB_DEV float ggx_qf1(float u)                                                         // :2078
+{
+	if (D(u) < 0.5) { u = F((0.5 - D(u)) * 2.0); return -u * inversesqrt_(F(1.0 - D(u * u))); }
+	u = F((D(u) - 0.5) * 2.0);
+	return u * inversesqrt_(F(1.0 - D(u * u)));
+}
+
 DJB_DEV float beckmann_qf1(float u) { return erfinv_(F(2.0 * D(u) - 1.0)); }           // :1891
 
 // Newton + bisection in the erf domain, dj_brdf.h:1897-1952

@@ -749,6 +749,30 @@ djb_status djb_hd_to_io_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *h, c
 	return hd_common(ctx, n, h, d, i, o, mem, true);
 }
 
+djb_status djb_query_batch(djb_ctx *ctx, const djb_brdf *b, int which, int64_t n, const djb_vec3_view *a,
+                           const djb_vec3_view *bb, const djb_vec3_view *c, const djb_params *params,
+                           const djb_vec3_view *out, int mem)
+{
+	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
+	if (b->dev.kind > DJB_KIND_TABULAR)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: queries need a microfacet brdf");
+	if ((which >= DJB_Q_QF2_RADIAL && which <= DJB_Q_QF1) && b->dev.kind == DJB_KIND_TABULAR)
+		return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented");          // dj_brdf.h:1854, 1859
+	djb_status st = check_call(ctx, b, n, mem);
+	if (st != DJB_OK) return st;
+	Params p;
+	if ((st = device_params(params, &p)) != DJB_OK) return st;
+	Staged sg(ctx, n, mem);
+	View va, vb, vc, vo;
+	if ((st = sg.in_vec(a, &va)) != DJB_OK) return st;
+	vb = va; vc = va;
+	if (bb && (st = sg.in_vec(bb, &vb)) != DJB_OK) return st;
+	if (c && (st = sg.in_vec(c, &vc)) != DJB_OK) return st;
+	if ((st = sg.out_vec(out, &vo)) != DJB_OK) return st;
+	HIP_TRY(djbk::launch_query(ctx->stream, b->dev, p, which, n, va, vb, vc, vo));
+	return sg.finish();
+}
+
 djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                                 int32_t *out_index, int mem)
 {

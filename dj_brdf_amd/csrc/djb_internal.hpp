@@ -24,6 +24,10 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
                          unsigned long long start, const View &o, const View &out_i,
                          const View *out_w, float *out_pdf);
 
+// microfacet / radial queries; out.x holds scalar results (out.xyz for the Fresnel query)
+hipError_t launch_query(hipStream_t s, const Brdf &b, const Params &p, int which, long long n,
+                        const View &a, const View &bb, const View &c, const View &out);
+
 hipError_t launch_io_to_hd(hipStream_t s, long long n, const View &i, const View &o,
                            const View &h, const View &d, bool inverse);
 hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const View &o, int32_t *idx);

@@ -120,6 +120,52 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ microfacet / radial queries
+// (dj_brdf.h:258-276, 307-314).  `which` is wave-uniform.
+enum { Q_NDF = 0, Q_GAF, Q_G1, Q_SIGMA, Q_P22, Q_VP22, Q_VNDF, Q_FRESNEL,
+       Q_P22_RADIAL = 16, Q_SIGMA_STD_RADIAL, Q_CDF_RADIAL, Q_QF_RADIAL, Q_QF2_RADIAL, Q_QF3_RADIAL, Q_QF1 };
+
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_query(Brdf b, Params p, int which, long long n, View va, View vb,
+                                                 View vc, View vout)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		v3 a = load3(va, k);
+		v3 r = mk(0, 0, 0);
+		switch (which) {
+		case Q_NDF: r.x = mf_ndf<KIND>(b, a, p); break;
+		case Q_GAF: {   // gaf(h, i, o): a = h (unused by Smith), vb = i, vc = o
+			v3 i = load3(vb, k), o = load3(vc, k);
+			float g1o = mf_g1_from_sigma(o, mf_sigma<KIND>(b, o, p), p);
+			float g1i = b.shadow ? mf_g1_from_sigma(i, mf_sigma<KIND>(b, i, p), p) : 0.0f;
+			r.x = mf_gaf_from_g1(b.shadow, g1i, g1o); break;
+		}
+		case Q_G1: { v3 kk = load3(vb, k); r.x = mf_g1_from_sigma(kk, mf_sigma<KIND>(b, kk, p), p); break; }
+		case Q_SIGMA: r.x = mf_sigma<KIND>(b, a, p); break;
+		case Q_P22: r.x = mf_p22<KIND>(b, a.x, a.y, p); break;
+		case Q_VP22: case Q_VNDF: {
+			v3 kk = load3(vb, k);
+			v3 h = which == Q_VNDF ? a : normalize(mk(-a.x, -a.y, 1));
+			float kh = dot(kk, h);
+			float vn = D(kh) > 0.0 ? kh * mf_ndf<KIND>(b, h, p) / mf_sigma<KIND>(b, kk, p) : 0.0f;
+			r.x = which == Q_VNDF ? vn : (h.z * h.z * h.z) * vn; break;
+		}
+		case Q_FRESNEL: r = fresnel_eval(b.fr, a.x); break;
+		case Q_P22_RADIAL: r.x = p22_radial<KIND>(b, a.x); break;
+		case Q_SIGMA_STD_RADIAL: r.x = sigma_std_radial<KIND>(b, a.x); break;
+		case Q_CDF_RADIAL: r.x = cdf_radial<KIND>(b, a.x); break;
+		case Q_QF_RADIAL: r.x = qf_radial<KIND>(b, a.x); break;
+		case Q_QF2_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf2_radial(a.x, a.y, a.z)
+		                       : KIND == KIND_GGX ? ggx_qf2_radial(a.x, a.y, a.z) : 0.0f; break;
+		case Q_QF3_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x)
+		                       : KIND == KIND_GGX ? ggx_qf3_radial(a.x, a.y) : 0.0f; break;
+		case Q_QF1: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x) : KIND == KIND_GGX ? ggx_qf1(a.x) : 0.0f; break;
+		}
+		store3(vout, k, r);
+	}
+}
+
 // ------------------------------------------------------------------ small utilities
 template <bool INVERSE>
 __global__ __launch_bounds__(BLOCK) void k_io_hd(long long n, View a, View bb, View c, View d)
@@ -231,6 +277,20 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 	case KIND_LAMBERT:  return launch_sample_kind<KIND_LAMBERT>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	}
 	return hipErrorInvalidValue;
+}
+
+hipError_t launch_query(hipStream_t s, const Brdf &b, const Params &p, int which, long long n, const View &a,
+                        const View &bb, const View &c, const View &out)
+{
+	if (n <= 0) return hipSuccess;
+	dim3 g(grid_for(n)), t(BLOCK);
+	switch (b.kind) {
+	case KIND_BECKMANN: hipLaunchKernelGGL((k_query<KIND_BECKMANN>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
+	case KIND_GGX:      hipLaunchKernelGGL((k_query<KIND_GGX>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
+	case KIND_TABULAR:  hipLaunchKernelGGL((k_query<KIND_TABULAR>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
 }
 
 hipError_t launch_io_to_hd(hipStream_t s, long long n, const View &a, const View &b, const View &c,

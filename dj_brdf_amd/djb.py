@@ -407,6 +407,78 @@ class microfacet(brdf):
         self._fresnel = fresnel_impl
         del keep
 
+    # ---- eval / sampling queries (dj_brdf.h:258-276, 307-314), batched
+    def _query(self, which: int, a, b=None, c=None, params=None, width=1):
+        lib = _lib.load()
+        va = _Vec(a)
+        vb = _Vec(b) if b is not None else None
+        vc = _Vec(c) if c is not None else None
+        out = va.like()
+        _lib.check(lib.djb_query_batch(self.ctx._h, self._h, C.c_int(which), C.c_int64(va.n), C.byref(va.view),
+                                       C.byref(vb.view) if vb else None, C.byref(vc.view) if vc else None,
+                                       _params_ptr(params), C.byref(out.view), C.c_int(va.mem)))
+        r = out.keep
+        if width == 3:
+            return r
+        return r[:, 0] if out.aos else r[0]
+
+    @staticmethod
+    def _cols(*cols):
+        """pack up to three scalar arrays into a [n,3] batch (missing columns are zero)."""
+        first = cols[0]
+        if torch is not None and isinstance(first, torch.Tensor) and first.is_cuda:
+            z = torch.zeros_like(first, dtype=torch.float32)
+            return torch.stack([(cols[k].float() if k < len(cols) else z) for k in range(3)], dim=0)
+        first = np.asarray(first, dtype=np.float32)
+        z = np.zeros_like(first)
+        return np.stack([(np.asarray(cols[k], np.float32) if k < len(cols) else z) for k in range(3)], axis=1)
+
+    def fresnel(self, cos_theta_d):
+        return self._query(7, self._cols(cos_theta_d), width=3)
+
+    def ndf(self, h, params=None):
+        return self._query(0, h, params=params)
+
+    def gaf(self, h, i, o, params=None):
+        return self._query(1, h, i, o, params)
+
+    def g1(self, h, k, params=None):
+        return self._query(2, h, k, params=params)
+
+    def sigma(self, k, params=None):
+        return self._query(3, k, params=params)
+
+    def p22(self, x, y, params=None):
+        return self._query(4, self._cols(x, y), params=params)
+
+    def vp22(self, x, y, k, params=None):
+        return self._query(5, self._cols(x, y), k, params=params)
+
+    def vndf(self, h, k, params=None):
+        return self._query(6, h, k, params=params)
+
+    # radial (dj_brdf.h:307-314) -- beckmann / ggx / tabular
+    def p22_radial(self, r_sqr):
+        return self._query(16, self._cols(r_sqr))
+
+    def sigma_std_radial(self, cos_theta_k):
+        return self._query(17, self._cols(cos_theta_k))
+
+    def cdf_radial(self, r):
+        return self._query(18, self._cols(r))
+
+    def qf_radial(self, u):
+        return self._query(19, self._cols(u))
+
+    def qf2_radial(self, u, cos_theta_k, sin_theta_k):
+        return self._query(20, self._cols(u, cos_theta_k, sin_theta_k))
+
+    def qf3_radial(self, u, qf2):
+        return self._query(21, self._cols(u, qf2))
+
+    def qf1(self, u):
+        return self._query(22, self._cols(u))
+
     def get_shadow(self) -> int:
         return _lib.load().djb_brdf_get_shadow(self._h)
 

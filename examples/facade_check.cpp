@@ -1,0 +1,54 @@
+// examples/facade_check.cpp -- exercises the scalar djb:: surface of include/djb_hip.hpp on the
+// GPU and prints the known answers of SURVEY.md 8-N (measured on the reference at survey time).
+// Exit code 0 iff every value matches to 1e-5 relative.
+#include <cmath>
+#include <cstdio>
+
+#include "djb_hip.hpp"
+
+static int g_fail = 0;
+static void expect(const char *what, double got, double want)
+{
+	double rel = std::fabs(got - want) / std::fmax(std::fabs(want), 1e-30);
+	printf("%-34s %.9g (want %.9g) %s\n", what, got, want, rel <= 1e-5 ? "ok" : "MISMATCH");
+	if (!(rel <= 1e-5)) g_fail = 1;
+}
+
+int main()
+{
+	try {
+		float iz = sqrtf(1.f - 0.3f * 0.3f - 0.2f * 0.2f), oz = sqrtf(1.f - 0.4f * 0.4f - 0.1f * 0.1f);
+		djb::vec3 i(0.3f, 0.2f, iz), o(-0.4f, 0.1f, oz);
+		djb::ggx ggx;
+		djb::microfacet::params iso = djb::microfacet::params::isotropic(0.3f);
+		expect("ggx iso 0.3 eval", ggx.eval(i, o, &iso).x, 0.621380985);
+		expect("ggx iso 0.3 pdf", ggx.pdf(i, o, &iso), 0.581518769);
+		djb::vec3 s = ggx.sample(0.25f, 0.75f, o, &iso);
+		expect("ggx sample.x", s.x, 0.657071352); expect("ggx sample.z", s.z, 0.749468625);
+		djb::beckmann beck;
+		djb::microfacet::params ell = djb::microfacet::params::elliptic(0.2f, 0.5f, 0.7f);
+		float ax, ay, rho; ell.get_pdfparams(&ax, &ay, &rho);
+		expect("elliptic ax", ax, 0.356585801); expect("elliptic ay", ay, 0.403542489); expect("elliptic rho", rho, 0.719068825);
+		expect("beckmann elliptic eval", beck.eval(i, o, &ell).x, 0.562808752);
+		expect("beckmann elliptic pdf", beck.pdf(i, o, &ell), 0.524953067);
+		djb::vec3 wi; float pdf;
+		djb::vec3 w = beck.evalp_is(0.25f, 0.75f, o, &wi, &pdf, &ell);
+		expect("beckmann evalp_is weight", w.x, 0.99999994); expect("beckmann evalp_is pdf", pdf, 0.545059502);
+		djb::ggx ggs(djb::fresnel::schlick(djb::vec3(1.0f, 0.71f, 0.29f)));
+		djb::vec3 c = ggs.eval(i, o, &iso);
+		expect("ggx+schlick eval.g", c.y, 0.441180676); expect("ggx+schlick eval.b", c.z, 0.180200979);
+		djb::vec3 h, d; djb::brdf::io_to_hd(i, o, &h, &d);
+		expect("io_to_hd h.y", h.y, 0.160367534); expect("io_to_hd d.y", d.y, -0.347850591);
+		djb::tabular tab(djb::ggx(), 90);
+		float a, dummy;
+		djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&a, &dummy); expect("tabular(ggx,90) alpha_beckmann", a, 2.75112224);
+		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&a, &dummy); expect("tabular(ggx,90) alpha_ggx", a, 0.866066337);
+		expect("tabular p22v.size", (double)tab.get_p22v().size(), 90);
+		try { djb::merl bad("/nonexistent/file.binary"); g_fail = 1; }
+		catch (const djb::exc &e) { printf("djb::exc as expected: %s", e.what()); }
+	} catch (const djb::exc &e) {
+		fprintf(stderr, "djb::exc: %s\n", e.what());
+		return 2;
+	}
+	return g_fail;
+}

@@ -150,6 +150,19 @@ djb_status djb_evalp_is_batch(djb_ctx *, const djb_brdf *, int64_t n, const floa
                               const float *u2, const djb_vec3_view *o, const djb_params *params,
                               const djb_vec3_view *out_weight, const djb_vec3_view *out_i,
                               float *out_pdf, int mem);
+/* microfacet and radial queries, batched (dj_brdf.h:258-276, 307-314, 366, 384).  a/b/c are the
+ * call's arguments in declaration order, each as a vec3 view (scalars in .x, (x,y) slopes in
+ * .x/.y, qf2_radial's (u, cos, sin) in .x/.y/.z); the result is written to out.x (Fresnel: xyz).
+ *   NDF(h) GAF(h,i,o) G1(h,k) SIGMA(k) P22(x,y) VP22(x,y | k) VNDF(h,k) FRESNEL(cos_theta_d)
+ *   P22_RADIAL(r_sqr) SIGMA_STD_RADIAL(cos) CDF_RADIAL(r) QF_RADIAL(u) QF2_RADIAL(u,cos,sin)
+ *   QF3_RADIAL(u,qf2) QF1(u)                                                            */
+enum { DJB_Q_NDF = 0, DJB_Q_GAF = 1, DJB_Q_G1 = 2, DJB_Q_SIGMA = 3, DJB_Q_P22 = 4, DJB_Q_VP22 = 5,
+       DJB_Q_VNDF = 6, DJB_Q_FRESNEL = 7, DJB_Q_P22_RADIAL = 16, DJB_Q_SIGMA_STD_RADIAL = 17,
+       DJB_Q_CDF_RADIAL = 18, DJB_Q_QF_RADIAL = 19, DJB_Q_QF2_RADIAL = 20, DJB_Q_QF3_RADIAL = 21,
+       DJB_Q_QF1 = 22 };
+djb_status djb_query_batch(djb_ctx *, const djb_brdf *, int which, int64_t n, const djb_vec3_view *a,
+                           const djb_vec3_view *b, const djb_vec3_view *c, const djb_params *params,
+                           const djb_vec3_view *out, int mem);
 /* brdf::io_to_hd / brdf::hd_to_io (static)                            dj_brdf.h:99-100  */
 djb_status djb_io_to_hd_batch(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                               const djb_vec3_view *out_h, const djb_vec3_view *out_d, int mem);

@@ -1,0 +1,383 @@
+// include/djb_hip.hpp -- header-only C++ facade: `namespace djb` over the C ABI of libdjb_hip.so.
+//
+// Same class names, method names, argument meaning and error behaviour as the reference's public
+// surface (jdupuy/dj_brdf, dj_brdf.h:41-537) for the hot path, so code written against
+// `djb::brdf::eval/evalp/pdf/sample/evalp_is`, `djb::merl`, `djb::utia`, `djb::beckmann`,
+// `djb::ggx`, `djb::tabular`, `djb::microfacet::params`, `djb::fresnel::*` recompiles against this
+// header (link with -ldjb_hip).  Two differences, both additive:
+//   * every operator also has a BATCH overload (n pairs per call) -- the form that makes sense
+//     on a GPU.  The scalar virtuals are batches of one: correct, and slow by construction
+//     (a kernel launch per call); renderers should gather a wavefront of intersections and call
+//     the batch form.
+//   * objects live on a djb::hip::context (one GPU + one stream); a process-wide default exists.
+// Errors: constructors and calls throw djb::exc carrying the library's djb_error message.
+// All arithmetic runs in the HIP kernels; this header contains no BRDF math.
+#ifndef DJB_HIP_HPP
+#define DJB_HIP_HPP
+
+#include <cstddef>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "djb_hip.h"
+
+namespace djb {
+
+typedef float float_t;                      // dj_brdf.h:44-48 (single precision build)
+
+/* Exception API, dj_brdf.h:54-59 */
+struct exc : public std::exception {
+	explicit exc(const std::string &msg, int status = 0) : m_str(msg), m_status(status) {}
+	virtual ~exc() throw() {}
+	const char *what() const throw() { return m_str.c_str(); }
+	std::string m_str;
+	int m_status;
+};
+
+/* Standalone vec3 utility, dj_brdf.h:62-71 (storage only; algebra happens on the device) */
+struct vec3 {
+	static vec3 from_raw(const double *v) { return vec3((float_t)v[0], (float_t)v[1], (float_t)v[2]); }
+	static vec3 from_raw(const float *v) { return vec3(v[0], v[1], v[2]); }
+	static const float_t *to_raw(const vec3 &v) { return &v.x; }
+	explicit vec3(float_t x = 0) : x(x), y(x), z(x) {}
+	vec3(float_t x, float_t y, float_t z) : x(x), y(y), z(z) {}
+	float_t intensity() const { return (float_t)0.2126 * x + (float_t)0.7152 * y + (float_t)0.0722 * z; }
+	float_t x, y, z;
+};
+
+namespace hip {
+
+inline void check(djb_status st)
+{
+	if (st != DJB_OK) throw exc(djb_last_error(), (int)st);
+}
+
+/* one GPU + one HIP stream */
+class context {
+public:
+	explicit context(int device = 0) : m_ctx(NULL) { check(djb_ctx_create(device, &m_ctx)); }
+	context(int device, void *hip_stream) : m_ctx(NULL) { check(djb_ctx_create_on_stream(device, hip_stream, &m_ctx)); }
+	~context() { djb_ctx_destroy(m_ctx); }
+	djb_ctx *get() const { return m_ctx; }
+	void synchronize() const { check(djb_ctx_synchronize(m_ctx)); }
+	static context &standard() { static context c(0); return c; }   // process-wide default (device 0)
+	static int device_count() { int n = 0; return djb_device_count(&n) == DJB_OK ? n : 0; }
+private:
+	context(const context &);
+	context &operator=(const context &);
+	djb_ctx *m_ctx;
+};
+
+/* view of an array of djb::vec3 (AoS, stride 3 floats) */
+inline djb_vec3_view view(const vec3 *p)
+{
+	float *f = const_cast<float *>(&p->x);
+	djb_vec3_view v = { f, f + 1, f + 2, 3 };
+	return v;
+}
+
+} // namespace hip
+
+/* BRDF interface, dj_brdf.h:74-109 */
+class brdf {
+public:
+	// ---- the reference's scalar virtuals (batches of one)
+	virtual vec3 eval(const vec3 &i, const vec3 &o, const void *user_param = NULL) const
+	{ vec3 r; eval(1, &i, &o, &r, user_param); return r; }
+	virtual vec3 evalp(const vec3 &i, const vec3 &o, const void *user_param = NULL) const
+	{ vec3 r; evalp(1, &i, &o, &r, user_param); return r; }
+	virtual vec3 eval_hd(const vec3 &h, const vec3 &d, const void *user_param = NULL) const
+	{ vec3 i, o; hd_to_io(h, d, &i, &o); return eval(i, o, user_param); }
+	virtual vec3 evalp_hd(const vec3 &h, const vec3 &d, const void *user_param = NULL) const
+	{ vec3 i, o; hd_to_io(h, d, &i, &o); return evalp(i, o, user_param); }
+	virtual vec3 evalp_is(float_t u1, float_t u2, const vec3 &o, vec3 *i, float_t *pdf,
+	                      const void *user_param = NULL) const
+	{
+		vec3 w, i_; float_t pdf_ = 0;
+		evalp_is(1, &u1, &u2, &o, &w, &i_, &pdf_, user_param);
+		if (i) *i = i_;
+		if (pdf) *pdf = pdf_;
+		return w;
+	}
+	virtual vec3 sample(float_t u1, float_t u2, const vec3 &o, const void *user_param = NULL) const
+	{ vec3 r; sample(1, &u1, &u2, &o, &r, user_param); return r; }
+	virtual float_t pdf(const vec3 &i, const vec3 &o, const void *user_param = NULL) const
+	{ float_t r = 0; pdf(1, &i, &o, &r, user_param); return r; }
+	static void io_to_hd(const vec3 &i, const vec3 &o, vec3 *h, vec3 *d)
+	{
+		djb_vec3_view vi = hip::view(&i), vo = hip::view(&o), vh = hip::view(h), vd = hip::view(d);
+		hip::check(djb_io_to_hd_batch(hip::context::standard().get(), 1, &vi, &vo, &vh, &vd, DJB_MEM_HOST));
+	}
+	static void hd_to_io(const vec3 &h, const vec3 &d, vec3 *i, vec3 *o)
+	{
+		djb_vec3_view vh = hip::view(&h), vd = hip::view(&d), vi = hip::view(i), vo = hip::view(o);
+		hip::check(djb_hd_to_io_batch(hip::context::standard().get(), 1, &vh, &vd, &vi, &vo, DJB_MEM_HOST));
+	}
+
+	// ---- batch overloads: n pairs, host arrays of djb::vec3
+	void eval(size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param = NULL) const
+	{
+		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out);
+		hip::check(djb_eval_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+	}
+	void evalp(size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param = NULL) const
+	{
+		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out);
+		hip::check(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+	}
+	void pdf(size_t n, const vec3 *i, const vec3 *o, float_t *out, const void *user_param = NULL) const
+	{
+		djb_vec3_view vi = hip::view(i), vo = hip::view(o);
+		hip::check(djb_pdf_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), out, DJB_MEM_HOST));
+	}
+	void sample(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_i,
+	            const void *user_param = NULL) const
+	{
+		djb_vec3_view vo = hip::view(o), vi = hip::view(out_i);
+		hip::check(djb_sample_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vi, DJB_MEM_HOST));
+	}
+	void evalp_is(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_weight,
+	              vec3 *out_i, float_t *out_pdf, const void *user_param = NULL) const
+	{
+		djb_vec3_view vo = hip::view(o), vw = hip::view(out_weight), vi = hip::view(out_i);
+		hip::check(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi,
+		                              out_pdf, DJB_MEM_HOST));
+	}
+	// ---- batch, device-resident (SoA or strided views in HBM; asynchronous on the context stream)
+	void eval_device(int64_t n, const djb_vec3_view &i, const djb_vec3_view &o, const djb_vec3_view &out,
+	                 const void *user_param = NULL) const
+	{ hip::check(djb_eval_batch(ctx(), m_h, n, &i, &o, params_of(user_param), &out, DJB_MEM_DEVICE)); }
+	void eval_pdf_device(int64_t n, const djb_vec3_view &i, const djb_vec3_view &o, const djb_vec3_view &out,
+	                     float_t *out_pdf, bool cos = false, const void *user_param = NULL) const
+	{ hip::check(djb_eval_pdf_batch(ctx(), m_h, n, &i, &o, params_of(user_param), cos, &out, out_pdf, DJB_MEM_DEVICE)); }
+
+	const djb_brdf *handle() const { return m_h; }
+	hip::context &get_context() const { return *m_ctx; }
+	virtual ~brdf() { djb_brdf_destroy(m_h); }
+protected:
+	explicit brdf(hip::context *c) : m_h(NULL), m_ctx(c ? c : &hip::context::standard()) {}
+	djb_ctx *ctx() const { return m_ctx->get(); }
+	virtual const djb_params *params_of(const void *) const { return NULL; }   // ignored by merl/utia/...
+	djb_brdf *m_h;
+	hip::context *m_ctx;
+private: // noncopyable, dj_brdf.h:104-108
+	brdf(const brdf &);
+	brdf &operator=(const brdf &);
+};
+
+/* Lambertian BRDF, dj_brdf.h:112-123 */
+class lambert : public brdf {
+public:
+	explicit lambert(hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_lambert(ctx(), &m_h)); }
+};
+
+/* MERL BRDF, dj_brdf.h:126-133 */
+class merl : public brdf {
+public:
+	explicit merl(const char *filename, hip::context *c = NULL) : brdf(c)
+	{ hip::check(djb_brdf_create_merl_from_file(ctx(), filename, &m_h)); }
+	merl(const double *samples, int64_t n_per_channel, hip::context *c = NULL) : brdf(c)
+	{ hip::check(djb_brdf_create_merl_from_memory(ctx(), samples, n_per_channel, &m_h)); }
+};
+
+/* UTIA BRDF, dj_brdf.h:136-146 */
+class utia : public brdf {
+public:
+	explicit utia(const char *filename, hip::context *c = NULL) : brdf(c)
+	{ hip::check(djb_brdf_create_utia_from_file(ctx(), filename, &m_h)); }
+};
+
+/* Fresnel API, dj_brdf.h:149-207 */
+namespace fresnel {
+	class impl {
+	public:
+		virtual ~impl() {}
+		virtual impl *copy() const = 0;
+		virtual djb_fresnel_desc desc() const = 0;
+	};
+	class ideal : public impl {
+	public:
+		impl *copy() const { return new ideal(); }
+		djb_fresnel_desc desc() const { djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_IDEAL; return d; }
+	};
+	class unpolarized : public impl {
+		vec3 ior;
+	public:
+		explicit unpolarized(const vec3 &ior) : ior(ior) {}
+		impl *copy() const { return new unpolarized(*this); }
+		djb_fresnel_desc desc() const
+		{ djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_UNPOLARIZED; d.a[0] = ior.x; d.a[1] = ior.y; d.a[2] = ior.z; return d; }
+	};
+	class schlick : public impl {
+		vec3 f0;
+	public:
+		explicit schlick(const vec3 &f0) : f0(f0) {}
+		impl *copy() const { return new schlick(*this); }
+		djb_fresnel_desc desc() const
+		{ djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_SCHLICK; d.a[0] = f0.x; d.a[1] = f0.y; d.a[2] = f0.z; return d; }
+	};
+	class sgd : public impl {
+		vec3 f0, f1;
+	public:
+		sgd(const vec3 &f0, const vec3 &f1) : f0(f0), f1(f1) {}
+		impl *copy() const { return new sgd(*this); }
+		djb_fresnel_desc desc() const
+		{
+			djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_SGD;
+			d.a[0] = f0.x; d.a[1] = f0.y; d.a[2] = f0.z; d.b[0] = f1.x; d.b[1] = f1.y; d.b[2] = f1.z; return d;
+		}
+	};
+	class spline : public impl {
+		std::vector<vec3> m_points;
+	public:
+		explicit spline(const std::vector<vec3> &points) : m_points(points) {}
+		const std::vector<vec3> &get_points() const { return m_points; }
+		impl *copy() const { return new spline(*this); }
+		djb_fresnel_desc desc() const
+		{
+			djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_SPLINE;
+			d.points = m_points.empty() ? NULL : &m_points[0].x; d.npoints = (int)m_points.size(); return d;
+		}
+	};
+} // namespace fresnel
+
+/* Microfacet API, dj_brdf.h:210-298 */
+class microfacet : public brdf {
+public:
+	/* microfacet parameters, dj_brdf.h:213-243.  Passed as `const void *user_param`. */
+	class params {
+	public:
+		static params standard() { return params(); }
+		static params isotropic(float_t a) { return elliptic(a, a, 0); }
+		static params elliptic(float_t a1, float_t a2, float_t phi_a = 0.0)
+		{ params p; p.m_desc.kind = DJB_PARAMS_ELLIPTIC; p.m_desc.v[0] = a1; p.m_desc.v[1] = a2; p.m_desc.v[2] = phi_a; p.resolve(); return p; }
+		static params pdfparams(float_t ax, float_t ay, float_t rho = 0.0, float_t tx_n = 0.0, float_t ty_n = 0.0)
+		{
+			params p; p.m_desc.kind = DJB_PARAMS_PDFPARAMS;
+			p.m_desc.v[0] = ax; p.m_desc.v[1] = ay; p.m_desc.v[2] = rho; p.m_desc.v[3] = tx_n; p.m_desc.v[4] = ty_n;
+			p.resolve(); return p;
+		}
+		void set_ellipse(float_t a1, float_t a2, float_t phi_a = 0.0)
+		{ float_t tx = m_r.tx_n, ty = m_r.ty_n; *this = elliptic(a1, a2, phi_a); if (tx != 0 || ty != 0) set_location(tx, ty); }
+		void set_pdfparams(float_t ax, float_t ay, float_t rho = 0.0, float_t tx_n = 0.0, float_t ty_n = 0.0)
+		{ *this = pdfparams(ax, ay, rho, tx_n, ty_n); }
+		void set_location(float_t tx_n, float_t ty_n) { *this = pdfparams(m_r.ax, m_r.ay, m_r.rho, tx_n, ty_n); }
+		void get_ellipse(float_t *a1, float_t *a2, float_t *phi_a = NULL) const
+		{ if (a1) *a1 = m_r.a1; if (a2) *a2 = m_r.a2; if (phi_a) *phi_a = m_r.phi_a; }
+		void get_pdfparams(float_t *ax, float_t *ay, float_t *rho = NULL, float_t *tx_n = NULL, float_t *ty_n = NULL) const
+		{ if (ax) *ax = m_r.ax; if (ay) *ay = m_r.ay; if (rho) *rho = m_r.rho; if (tx_n) *tx_n = m_r.tx_n; if (ty_n) *ty_n = m_r.ty_n; }
+		void get_location(float_t *tx_n, float_t *ty_n) const { if (tx_n) *tx_n = m_r.tx_n; if (ty_n) *ty_n = m_r.ty_n; }
+		void get_location(vec3 *n) const { if (n) *n = vec3(m_r.n[0], m_r.n[1], m_r.n[2]); }
+		params(float_t a1 = 1.0, float_t a2 = 1.0, float_t phi_a = 0.0)
+		{ m_desc.kind = DJB_PARAMS_ELLIPTIC; m_desc.v[0] = a1; m_desc.v[1] = a2; m_desc.v[2] = phi_a; m_desc.v[3] = m_desc.v[4] = 0; resolve(); }
+		const djb_params *desc() const { return &m_desc; }
+	private:
+		void resolve() { hip::check(djb_params_resolve(&m_desc, &m_r)); }   // DJB_ASSERT sites -> djb::exc
+		djb_params m_desc;
+		djb_params_resolved m_r;
+	};
+
+	bool supports_smith_vndf_sampling() const { return djb_brdf_kind(m_h) != DJB_KIND_TABULAR; }
+	int get_shadow() const { return djb_brdf_get_shadow(m_h); }
+	const fresnel::impl &get_fresnel() const { return *m_fresnel; }
+	virtual ~microfacet() { delete m_fresnel; }
+
+	// eval / sampling queries (dj_brdf.h:258-276), scalar form = batch of one
+	vec3 fresnel(float_t cos_theta_d) const { return q3(DJB_Q_FRESNEL, vec3(cos_theta_d, 0, 0)); }
+	float_t ndf(const vec3 &h, const params &p = params::standard()) const { return q(DJB_Q_NDF, &h, NULL, NULL, p); }
+	float_t gaf(const vec3 &h, const vec3 &i, const vec3 &o, const params &p = params::standard()) const { return q(DJB_Q_GAF, &h, &i, &o, p); }
+	float_t g1(const vec3 &h, const vec3 &k, const params &p = params::standard()) const { return q(DJB_Q_G1, &h, &k, NULL, p); }
+	float_t sigma(const vec3 &k, const params &p = params::standard()) const { return q(DJB_Q_SIGMA, &k, NULL, NULL, p); }
+	float_t p22(float_t x, float_t y, const params &p = params::standard()) const { vec3 a(x, y, 0); return q(DJB_Q_P22, &a, NULL, NULL, p); }
+	float_t vp22(float_t x, float_t y, const vec3 &k, const params &p = params::standard()) const { vec3 a(x, y, 0); return q(DJB_Q_VP22, &a, &k, NULL, p); }
+	float_t vndf(const vec3 &h, const vec3 &k, const params &p = params::standard()) const { return q(DJB_Q_VNDF, &h, &k, NULL, p); }
+protected:
+	microfacet(hip::context *c, const fresnel::impl &f) : brdf(c), m_fresnel(f.copy()) {}
+	const djb_params *params_of(const void *user_param) const
+	{ return user_param ? reinterpret_cast<const params *>(user_param)->desc() : NULL; }   // dj_brdf.h:1532-1534
+	float_t q(int which, const vec3 *a, const vec3 *b, const vec3 *c, const params &p) const
+	{
+		vec3 out;
+		djb_vec3_view va = hip::view(a), vb = hip::view(b ? b : a), vc = hip::view(c ? c : a), vo = hip::view(&out);
+		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, b ? &vb : NULL, c ? &vc : NULL, p.desc(), &vo, DJB_MEM_HOST));
+		return out.x;
+	}
+	vec3 q3(int which, const vec3 &a) const
+	{
+		vec3 out;
+		djb_vec3_view va = hip::view(&a), vo = hip::view(&out);
+		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, NULL, NULL, NULL, &vo, DJB_MEM_HOST));
+		return out;
+	}
+	const fresnel::impl *m_fresnel;
+};
+
+/* Radial microfacets, dj_brdf.h:301-324 */
+class radial : public microfacet {
+public:
+	float_t p22_radial(float_t r_sqr) const { return rq(DJB_Q_P22_RADIAL, r_sqr); }
+	float_t sigma_std_radial(float_t cos_theta_k) const { return rq(DJB_Q_SIGMA_STD_RADIAL, cos_theta_k); }
+	float_t cdf_radial(float_t r) const { return rq(DJB_Q_CDF_RADIAL, r); }
+	float_t qf_radial(float_t u) const { return rq(DJB_Q_QF_RADIAL, u); }
+	float_t qf2_radial(float_t u, float_t cos_theta_k, float_t sin_theta_k) const { return rq(DJB_Q_QF2_RADIAL, u, cos_theta_k, sin_theta_k); }
+	float_t qf3_radial(float_t u, float_t qf2) const { return rq(DJB_Q_QF3_RADIAL, u, qf2); }
+protected:
+	radial(hip::context *c, const fresnel::impl &f) : microfacet(c, f) {}
+	float_t rq(int which, float_t a, float_t b = 0, float_t c = 0) const
+	{ vec3 v(a, b, c); return q(which, &v, NULL, NULL, params::standard()); }
+};
+
+/* Beckmann Microfacet NDF, dj_brdf.h:327-371 */
+class beckmann : public radial {
+public:
+	beckmann(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)
+	{ djb_fresnel_desc d = f.desc(); hip::check(djb_brdf_create_beckmann(ctx(), &d, shadow, &m_h)); }
+	float_t qf1(float_t u) const { return rq(DJB_Q_QF1, u); }
+};
+
+/* GGX Microfacet NDF, dj_brdf.h:374-391 */
+class ggx : public radial {
+public:
+	ggx(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)
+	{ djb_fresnel_desc d = f.desc(); hip::check(djb_brdf_create_ggx(ctx(), &d, shadow, &m_h)); }
+	float_t qf1(float_t u) const { return rq(DJB_Q_QF1, u); }
+};
+
+/* Tabulated Microfacet NDF -- the power-iteration fit, dj_brdf.h:394-425 */
+class tabular : public radial {
+public:
+	tabular(const brdf &src, int resolution, bool shadow = true) : radial(&src.get_context(), fresnel::ideal())
+	{
+		hip::check(djb_brdf_create_tabular(ctx(), src.handle(), resolution, shadow, &m_h));
+		m_p22 = fetch(DJB_TAB_P22, 1); m_sigma = fetch(DJB_TAB_SIGMA, 1);
+		m_cdf = fetch(DJB_TAB_CDF, 1); m_qf = fetch(DJB_TAB_QF, 1);
+		std::vector<float_t> f = fetch(DJB_TAB_FRESNEL, 3);
+		std::vector<vec3> pts;
+		for (size_t k = 0; k + 2 < f.size(); k += 3) pts.push_back(vec3(f[k], f[k + 1], f[k + 2]));
+		delete m_fresnel;
+		m_fresnel = new fresnel::spline(pts);
+	}
+	static microfacet::params fit_beckmann_parameters(const tabular &t)
+	{ float_t a = 0; hip::check(djb_tabular_fit(t.m_h, &a, NULL)); return microfacet::params::isotropic(a); }
+	static microfacet::params fit_ggx_parameters(const tabular &t)
+	{ float_t a = 0; hip::check(djb_tabular_fit(t.m_h, NULL, &a)); return microfacet::params::isotropic(a); }
+	const std::vector<float_t> &get_p22v() const { return m_p22; }
+	const std::vector<float_t> &get_sigmav() const { return m_sigma; }
+	const std::vector<float_t> &get_cdfv() const { return m_cdf; }
+	const std::vector<float_t> &get_qfv() const { return m_qf; }
+private:
+	std::vector<float_t> fetch(int which, int width) const
+	{
+		int n = 0;
+		hip::check(djb_tabular_get(m_h, which, NULL, &n));
+		std::vector<float_t> v((size_t)n * width);
+		if (n) hip::check(djb_tabular_get(m_h, which, &v[0], NULL));
+		return v;
+	}
+	std::vector<float_t> m_p22, m_sigma, m_cdf, m_qf;
+};
+
+} // namespace djb
+
+#endif // DJB_HIP_HPP

@@ -200,3 +200,24 @@ def test_full_size_beckmann_sample_histogram(gpu_ctx):
     chi2 = (((hc - pg * ns) ** 2) / (pg * ns))[keep].sum()
     dof = keep.sum() - 1
     assert chi2 < dof + 6 * np.sqrt(2 * dof), f"chi2 {chi2:.1f} for {dof} dof"
+
+
+def test_cpp_facade_programs(gpu_ctx, tmp_path):
+    """The C++ djb:: facade (include/djb_hip.hpp): examples/facade_check reproduces the reference's
+    known answers through the scalar API, and examples/merl_params writes the reference driver's
+    params.txt byte for byte."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "facade_check")
+    assert os.path.exists(exe), "examples not built: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MISMATCH" not in r.stdout and "Failed to open" in r.stdout
+    files = []
+    for name, recipe in PARAMS_TXT_MATERIALS:
+        p = str(tmp_path / (name + ".binary"))
+        synth.write_merl_binary(p, synth.merl_table(*recipe)); files.append(p)
+    r = subprocess.run([os.path.join(root, "examples", "merl_params")] + files, cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(tmp_path / "params.txt", "rb").read() == open(os.path.join(G, "params_expected.txt"), "rb").read()

@@ -182,3 +182,76 @@ def test_device_tensors_soa_equal_host_aos(gpu_ctx, dirs):
     dev = g.eval(ti, to, p)
     torch.cuda.synchronize()
     assert np.array_equal(dev.cpu().numpy().T.view(np.uint32), host.view(np.uint32))
+
+
+def test_utia_eval(gpu_ctx, oracle, dirs, tmp_path):
+    """utia::eval (16-tap 4-D interpolation + sRGB decode) on a synthetic UTIA-format file."""
+    i, o, _, _ = dirs
+    rng = np.random.default_rng(11)
+    tab = rng.uniform(-5.0, 120.0, size=3 * 288 * 288)     # includes negatives: clamped at load
+    p = str(tmp_path / "m.bin"); tab.tofile(p)
+    u, ou = djb.utia(p, ctx=gpu_ctx), oracle.utia(p)
+    for op in ("eval", "evalp", "pdf"):
+        ex = assert_close(f"utia {op}", getattr(u, op)(i, o), oracle.eval(ou, i, o, None, op))
+        assert ex > 0.99, f"utia {op}: only {ex:.4f} bit-exact"
+    u2 = djb.utia.from_table(tab, ctx=gpu_ctx)
+    assert np.array_equal(u2.eval(i, o).view(np.uint32), u.eval(i, o).view(np.uint32))
+    with pytest.raises(djb.exc):
+        djb.utia(str(tmp_path / "missing.bin"), ctx=gpu_ctx)
+
+
+def test_lambert_and_default_sampling(gpu_ctx, oracle, dirs):
+    i, o, u1, u2 = dirs
+    l, ol = djb.lambert(ctx=gpu_ctx), oracle.lambert()
+    for op in ("eval", "evalp", "pdf"):
+        assert_close(f"lambert {op}", getattr(l, op)(i, o), oracle.eval(ol, i, o, None, op))
+    assert_close("lambert sample", l.sample(u1, u2, o), oracle.sample(ol, u1, u2, o), 2e-5)
+    w, si, pdf = l.evalp_is(u1, u2, o)
+    ww, wi, wpdf = oracle.evalp_is(ol, u1, u2, o)
+    assert_close("is pdf", pdf, wpdf, 2e-5); assert_close("is w", w, ww, 4e-5)
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+def test_microfacet_and_radial_queries(gpu_ctx, oracle, dirs, ndf):
+    """microfacet::{ndf,gaf,g1,sigma,p22,vp22,vndf,fresnel} and radial::{p22_radial,...} batched."""
+    i, o, u1, u2 = dirs
+    fres = ("schlick", 1.0, 0.71, 0.29)
+    g = getattr(djb, ndf)(mk_fresnel(fres), True, ctx=gpu_ctx)
+    og = oracle.microfacet(ndf, fres, True)
+    h = oracle.io_to_hd(i, o)[0]
+    for p in (None, ("elliptic", 0.2, 0.5, 0.7), ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)):
+        up = mk_params(p)
+        assert_close("ndf", g.ndf(h, up), oracle.microfacet_query(og, "ndf", h, params=p))
+        assert_close("gaf", g.gaf(h, i, o, up), oracle.microfacet_query(og, "gaf", h, i, o, params=p))
+        assert_close("g1", g.g1(h, o, up), oracle.microfacet_query(og, "g1", h, o, params=p))
+        assert_close("sigma", g.sigma(o, up), oracle.microfacet_query(og, "sigma", o, params=p))
+        assert_close("vndf", g.vndf(h, o, up), oracle.microfacet_query(og, "vndf", h, o, params=p))
+        xy = np.stack([u1 * 2 - 1, u2 * 2 - 1, np.zeros_like(u1)], 1).astype(np.float32)
+        assert_close("p22", g.p22(xy[:, 0], xy[:, 1], up), oracle.microfacet_query(og, "p22", xy, params=p))
+        assert_close("vp22", g.vp22(xy[:, 0], xy[:, 1], o, up), oracle.microfacet_query(og, "vp22", xy, o, params=p))
+    c = np.clip(o[:, 2], 0, 1)
+    assert_close("fresnel", g.fresnel(c), oracle.fresnel_eval(og, c))
+    u = np.clip(u1, 1e-4, 1 - 1e-4)
+    s = np.sqrt(1 - c.astype(np.float64) ** 2).astype(np.float32)
+    assert_close("p22_radial", g.p22_radial(u * 9), oracle.radial_query(og, "p22_radial", u * 9))
+    assert_close("sigma_std_radial", g.sigma_std_radial(c), oracle.radial_query(og, "sigma_std_radial", c))
+    assert_close("cdf_radial", g.cdf_radial(u * 5), oracle.radial_query(og, "cdf_radial", u * 5), 2e-5)
+    assert_close("qf_radial", g.qf_radial(u), oracle.radial_query(og, "qf_radial", u), 2e-5)
+    q3 = g.qf3_radial(u, u * 3 - 1)
+    assert_close("qf3_radial", q3, oracle.radial_query(og, "qf3_radial", u, u * 3 - 1), 2e-5)
+    q2 = g.qf2_radial(u, c, s)
+    want = oracle.radial_query(og, "qf2_radial", u, c, s)
+    ok = np.isfinite(want) & (s > 1e-3) & (c > 1e-3)
+    tol = 2e-3 if ndf == "beckmann" else 2e-5
+    assert np.quantile(np.abs(q2[ok] - want[ok]) / np.maximum(1, np.abs(want[ok])), 0.999) < tol
+
+
+def test_tabular_queries_and_not_implemented(gpu_ctx, oracle):
+    t = djb.tabular(djb.ggx(ctx=gpu_ctx), 64, True, ctx=gpu_ctx)
+    ot = oracle.tabular(oracle.microfacet("ggx"), 64, True)
+    u = np.linspace(0.01, 0.99, 500).astype(np.float32)
+    assert_close("tab qf_radial", t.qf_radial(u), oracle.radial_query(ot, "qf_radial", u), 1e-4)
+    assert_close("tab cdf_radial", t.cdf_radial(u * 4), oracle.radial_query(ot, "cdf_radial", u * 4), 1e-4)
+    with pytest.raises(djb.exc) as e:       # radial::qf2_radial base version throws (dj_brdf.h:1854)
+        t.qf2_radial(u, u, u)
+    assert e.value.status_name == "DJB_ERR_NOT_IMPLEMENTED" and "Not Implemented" in str(e.value)

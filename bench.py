@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 WORKLOADS = {
     # name: (default n per GPU, algorithmic HBM bytes per unit, unit, kernel family)
-    "merl_eval": (1_000_000_000, 36, "evals", "k_eval<MERL,eval>"),
+    "merl_eval": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval> (two-tier exact)"),
     "ggx_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf>"),
     "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample<BECKMANN,rng>"),
     "merl_fit": (100, None, "materials", "k_fit<MERL>"),
@@ -120,7 +120,7 @@ def cpu_baseline(name, synth, budget_s=12.0):
     ref_path = os.path.join(ROOT, "oracle", "_ref", "libdjb_ref.so")
     kind = "reference" if os.path.exists(ref_path) else "port"
     L = oraclelib.CheckerLib(ref_path, "ref_") if kind == "reference" else oraclelib.oracle()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     par = None
     if name == "merl_eval":
         if kind == "reference":
@@ -173,12 +173,21 @@ def cpu_baseline(name, synth, budget_s=12.0):
         return n / (time.perf_counter() - t0)
 
     r1 = run(500_000, 1)                                       # single thread: the reference's own design
-    n_all = int(min(max(r1 * cores * budget_s * 0.5, 1e6), 2e8))
-    rall = run(n_all, cores)
-    return {"value": rall, "unit": "evals/s" if op != "sample" else "samples/s", "cores": cores, "kind": kind,
-            "sample": f"{n_all} units of the same synthetic workload on {cores} threads "
-                      f"(ctypes releases the GIL; the reference object is const); single-thread {r1:.3e}/s",
-            "single_thread": r1}
+    # thread-scaling probe (same per-thread work): the box may expose more logical CPUs than it lets
+    # one process use, so report the best aggregate rate and the thread count that achieved it
+    best, best_t, probe = r1, 1, {1: r1}
+    t0 = time.perf_counter()
+    for t in sorted({4, 16, 64, cores // 2, cores} - {0, 1}):
+        if t > cores or time.perf_counter() - t0 > budget_s:
+            continue
+        probe[t] = run(int(min(600_000 * t, 1.2e8)), t)
+        if probe[t] > best:
+            best, best_t = probe[t], t
+    return {"value": best, "unit": "evals/s" if op != "sample" else "samples/s", "cores": best_t, "kind": kind,
+            "sample": f"600k units per thread of the same synthetic workload, thread counts {sorted(probe)} of "
+                      f"{cores} usable logical CPUs (ctypes releases the GIL; the reference object is const); "
+                      f"best at {best_t} threads; single-thread {r1:.3e}/s",
+            "single_thread": r1, "scaling_probe": {str(k): v for k, v in probe.items()}}
 
 
 def main():

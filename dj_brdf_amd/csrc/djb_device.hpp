@@ -562,6 +562,121 @@ DJB_DEV v3 merl_eval(const Brdf &b, v3 i, v3 o)
 	return mk(t.x, t.y, t.z);
 }
 
+// the reference's three float angles (theta_h, theta_d, phi_d) -- calibration / diagnostics
+DJB_DEV void merl_angles_exact(v3 i, v3 o, float &th, float &td, float &pd)
+{
+	v3 h, d; float ph;
+	h = normalize(add(i, o));
+	xyz_to_theta_phi(h, th, ph);
+	v3 tmp = rotate_z(i, -ph);
+	d = normalize(rotate_y(tmp, -th));
+	xyz_to_theta_phi(d, td, pd);
+}
+
+// ------------------------------------------------------------------ two-tier exact MERL binning
+// Tier 1 (this function): the three half/diff angles from closed-form geometry in fp32 --
+//     theta_h = angle(h, z),  theta_d = angle(i, h),  phi_d = azimuth of i around h
+// with h = (i+o)/|i+o| -- no rotations, no fp64, three polynomial atan2.  Each estimate carries a
+// guard band that bounds |estimate - the reference's own float value| (the reference's chain of
+// float roundings, amplified by 1/sin(theta_h) and 1/sin(theta_d), plus this path's error).
+// If an estimate lies inside the guard band of a bin boundary -- or in the regions where the
+// reference snaps angles (|z| > 0.99999, dj_brdf.h:652-656) -- the pair is AMBIGUOUS and is
+// handed to tier 2, the operation-by-operation fp64 path (merl_index).  Outside the bands both
+// paths provably land in the same bin, so the composite is bit-exact while ~99.7 % of the pairs
+// never touch fp64.  Band constants: MERL_GUARD_* below, calibrated with k_merl_guard_stats
+// (max observed |delta| / band, reported by djb_merl_guard_stats and tests) -- see DESIGN.md 4.2.
+struct MerlGuard { float a_h, b_h, a_d, b_d, c_d; };   // multiples of 2^-24
+#define MERL_GUARD_DEFAULT { 12.0f, 12.0f, 12.0f, 12.0f, 12.0f }
+
+DJB_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DJB_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// atan2 with |error| < ~2.5e-7 rad: octant reduction + Cephes atanf core (4 coefficients)
+DJB_DEV float fast_atan2(float y, float x)
+{
+	float ax = fabsf(x), ay = fabsf(y);
+	float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+	float z = mn * fast_rcp(mx);                                   // [0, 1]
+	bool hi = z > 0.41421356f;
+	float w = hi ? (z - 1.0f) * fast_rcp(z + 1.0f) : z;            // |w| <= tan(pi/8)
+	float w2 = w * w;
+	float p = ((8.05374449538e-2f * w2 - 1.38776856032e-1f) * w2 + 1.99777106478e-1f) * w2 - 3.33329491539e-1f;
+	float a = p * w2 * w + w;
+	a = hi ? a + 0.78539816339f : a;
+	a = ay > ax ? 1.57079632679f - a : a;
+	a = x < 0.0f ? 3.14159265359f - a : a;
+	return y < 0.0f ? -a : a;
+}
+
+struct MerlFast {
+	float t_h, x_d, x_p;     // continuous bin coordinates: floor() gives the bin
+	float m_h, m_d, m_p;     // guard-band half widths in the same coordinates
+	bool special;            // snap regions / degenerate input: always tier 2
+};
+
+DJB_DEV MerlFast merl_fast_coords(v3 i, v3 o, const MerlGuard g)
+{
+	const float U = 5.9604644775390625e-08f;   // 2^-24
+	MerlFast f;
+	float sx = i.x + o.x, sy = i.y + o.y, sz = i.z + o.z;
+	float r = __builtin_amdgcn_rsqf(sx * sx + sy * sy + sz * sz);
+	float hx = sx * r, hy = sy * r, hz = sz * r;
+	float sh2 = hx * hx + hy * hy;
+	float sh = fast_sqrt(sh2);                                      // sin(theta_h)
+	float th = fast_atan2(sh, hz);
+	// theta_d = angle(i, h): |i x h| and i . h share the factor |i|
+	float cx = i.y * hz - i.z * hy, cy = i.z * hx - i.x * hz, cz = i.x * hy - i.y * hx;
+	float sdn = fast_sqrt(cx * cx + cy * cy + cz * cz);
+	float cdn = i.x * hx + i.y * hy + i.z * hz;
+	float td = fast_atan2(sdn, cdn);
+	// phi_d: components of i along e_theta, e_phi of the h frame, both scaled by |i| sin(theta_h)
+	float ny = hx * i.y - hy * i.x;
+	float nx = hz * (hx * i.x + hy * i.y) - sh2 * i.z;
+	float pd = fast_atan2(ny, nx);
+	float ilen = fast_sqrt(i.x * i.x + i.y * i.y + i.z * i.z);
+	float sd = sdn * fast_rcp(ilen);                                // sin(theta_d)
+	float cd = cdn * fast_rcp(ilen);
+	// guard bands, radians
+	float rsh = fast_rcp(sh), rsd = fast_rcp(sd);
+	float e_h = U * (g.a_h * rsh + g.b_h);
+	float e_d = U * (g.a_d + g.b_d * rsh) * rsd + U * g.c_d;
+	// bin coordinates (dj_brdf.h:906-957)
+	const float R2D = 57.29577951308232f;
+	float deg_h = th * R2D;
+	f.t_h = fast_sqrt(deg_h * 90.0f);
+	f.m_h = e_h * (2578.3100780887044f * fast_rcp(fmaxf(f.t_h, 1e-3f))) + f.t_h * (8.0f * U);
+	f.x_d = td * R2D;
+	f.m_d = e_d * R2D;
+	float pw = pd < 0.0f ? pd + 3.14159265359f : pd;
+	f.x_p = pw * R2D;
+	f.m_p = e_d * R2D;
+	// The reference snaps (theta, phi) to (0, 0) / (pi, 0) when |z| > 0.99999, i.e. when the angle is
+	// within acos(0.99999) = 4.4721e-3 rad of a pole (dj_brdf.h:652-656).  A pair is "special"
+	// (always tier 2) unless both estimates, shrunk by their guard bands, clear that zone.
+	const float SNAP = 4.6e-3f, PI_F = 3.14159265359f;
+	f.special = !(th > SNAP + e_h) || !(th < PI_F - SNAP - e_h) || !(td > SNAP + e_d) || !(td < PI_F - SNAP - e_d);
+	(void)cd;
+	return f;
+}
+
+// true iff the bin index is certain; idx is then identical to merl_index(i, o)
+DJB_DEV bool merl_index_fast(v3 i, v3 o, const MerlGuard g, int &idx)
+{
+	MerlFast f = merl_fast_coords(i, o, g);
+	// distance to the nearest integer boundary in each coordinate
+	float rh = rintf(f.t_h), rd = rintf(f.x_d), rp = rintf(f.x_p);
+	bool amb_h = fabsf(f.t_h - rh) < f.m_h && rh >= 1.0f && rh <= 89.0f;    // boundaries 1..89
+	bool amb_d = fabsf(f.x_d - rd) < f.m_d && rd >= 1.0f && rd <= 89.0f;    // boundaries 1..89
+	bool amb_p = fabsf(f.x_p - rp) < f.m_p;                                  // 0..180 (0 == 180 wrap)
+	// comparisons are false on NaN, so a NaN coordinate must force tier 2 explicitly
+	bool finite = (f.t_h == f.t_h) && (f.x_d == f.x_d) && (f.x_p == f.x_p) &&
+	              (f.m_h < 0.45f) && (f.m_d < 0.45f) && (f.m_p < 0.45f);
+	int kh = (int)f.t_h, kd = (int)f.x_d, kp = (int)f.x_p;
+	kh = kh > 89 ? 89 : kh; kd = kd > 89 ? 89 : kd; kp = kp > 179 ? 179 : kp;
+	idx = kp + kd * 180 + kh * 16200;
+	return finite && !f.special && !amb_h && !amb_d && !amb_p;
+}
+
 // ------------------------------------------------------------------ UTIA (dj_brdf.h:1063-1157)
 DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 {

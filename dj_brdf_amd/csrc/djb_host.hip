@@ -42,6 +42,9 @@ struct djb_ctx {
 	hipStream_t stream;
 	bool owns_stream;
 	hipEvent_t ev0, ev1;
+	void *scratch;            // worklist of the two-tier MERL kernel (grown on demand)
+	size_t scratch_bytes;
+	int merl_exact_only;      // DJB_OPT_MERL_EXACT_ONLY
 };
 
 struct djb_brdf {
@@ -241,6 +244,29 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
 	if ((want & 3) && (st = sg.out_vec(out_fr, &vout)) != DJB_OK) return st;
 	if ((want & 4) && (st = sg.out_arr(out_pdf, &dpdf)) != DJB_OK) return st;
+	if (b->dev.kind == DJB_KIND_MERL && (want & 3) && !ctx->merl_exact_only) {
+		// two-tier exact lookup; pair indices travel as uint32, so very large batches are chunked
+		const long long CH = 1LL << 31;
+		for (long long lo = 0; lo < n; lo += CH) {
+			long long m = n - lo < CH ? n - lo : CH;
+			size_t cap = (size_t)(m / 24 + 4096);
+			size_t need = sizeof(unsigned int) * (cap + 4);
+			if (ctx->scratch_bytes < need) {
+				HIP_TRY(hipStreamSynchronize(ctx->stream));
+				if (ctx->scratch) (void)hipFree(ctx->scratch);
+				ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+				HIP_TRY(hipMalloc(&ctx->scratch, need));
+				ctx->scratch_bytes = need;
+			}
+			cap = ctx->scratch_bytes / sizeof(unsigned int) - 4;
+			unsigned int *count = (unsigned int *)ctx->scratch, *list = count + 4;
+			auto off = [&](const View &v) { return View{ v.x + lo * v.stride, v.y + lo * v.stride, v.z + lo * v.stride, v.stride }; };
+			View oi = off(vi), oo = off(vo), ou = (want & 3) ? off(vout) : vout;
+			HIP_TRY(djbk::launch_merl_twotier(ctx->stream, b->dev, m, oi, oo, ou, dpdf ? dpdf + lo : nullptr, want,
+			                                  list, (unsigned int)cap, count));
+		}
+		return sg.finish();
+	}
 	HIP_TRY(djbk::launch_eval(ctx->stream, b->dev, p, n, vi, vo, vout, dpdf, want));
 	return sg.finish();
 }
@@ -356,6 +382,7 @@ static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **o
 	c->device = device;
 	c->owns_stream = own;
 	c->stream = (hipStream_t)hip_stream;
+	c->scratch = nullptr; c->scratch_bytes = 0; c->merl_exact_only = 0;
 	if (own) {
 		hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 		if (e != hipSuccess) { delete c; return fail(DJB_ERR_HIP, "djb_error: hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -379,6 +406,7 @@ djb_status djb_ctx_destroy(djb_ctx *ctx)
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 	return DJB_OK;
@@ -785,6 +813,37 @@ djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i,
 	if ((st = sg.out_arr(out_index, &didx)) != DJB_OK) return st;
 	HIP_TRY(djbk::launch_merl_index(ctx->stream, n, vi, vo, didx));
 	return sg.finish();
+}
+
+djb_status djb_ctx_set_option(djb_ctx *ctx, int option, int value)
+{
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	if (option == DJB_OPT_MERL_EXACT_ONLY) { ctx->merl_exact_only = value != 0; return DJB_OK; }
+	return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown option %d", option);
+}
+
+djb_status djb_merl_guard_stats(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
+                                const float *guard5, float *max_ratio3, unsigned long long *counters4)
+{
+	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	if (!Staged::valid(i) || !Staged::valid(o) || !max_ratio3 || !counters4)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	unsigned char *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 64));
+	hipError_t e = hipMemsetAsync(d, 0, 64, ctx->stream);
+	if (e == hipSuccess)
+		e = djbk::launch_merl_guard_stats(ctx->stream, n, View{ i->x, i->y, i->z, (long long)i->stride },
+		                                  View{ o->x, o->y, o->z, (long long)o->stride }, guard5,
+		                                  (unsigned int *)d, (unsigned long long *)(d + 16));
+	unsigned char h[64];
+	if (e == hipSuccess) e = hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: guard stats: %s", hipGetErrorString(e));
+	memcpy(max_ratio3, h, 12);
+	memcpy(counters4, h + 16, 32);
+	return DJB_OK;
 }
 
 djb_status djb_params_resolve(const djb_params *params, djb_params_resolved *out)

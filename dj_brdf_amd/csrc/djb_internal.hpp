@@ -32,6 +32,13 @@ hipError_t launch_io_to_hd(hipStream_t s, long long n, const View &i, const View
                            const View &h, const View &d, bool inverse);
 hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const View &o, int32_t *idx);
 
+// two-tier exact MERL lookup (djb_kernels_merl.hip); list: worklist of `cap` uint32 slots, count: 1 uint32
+hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
+                               const View &out, float *out_pdf, int want, unsigned int *list,
+                               unsigned int cap, unsigned int *count);
+hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, const View &o,
+                                   const float *guard5, unsigned int *max_bits, unsigned long long *counters);
+
 // MERL payload (3*n doubles) -> float4 table (pre-scaled, below-horizon zeroed); n = 1458000
 hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, float4 *table);
 // UTIA payload -> float(max(0, s) * double(1.f/140.f))

@@ -1,0 +1,285 @@
+// djb_kernels_merl.hip -- two-tier, bit-exact MERL lookup (merl::eval, dj_brdf.h:987-1024).
+//
+// k_eval<MERL> (djb_kernels_eval.hip) reproduces the reference operation by operation: 8 fp64
+// libm-class calls per pair, ~770 VALU instructions, VALU-bound at 17 % of the HBM roofline.
+// Here the same result is produced in two launches:
+//   k_merl_fast   every pair: fp32 closed-form angles + guard bands (merl_index_fast).  Certain
+//                 pairs (~99.7 %) gather their table entry and are done; ambiguous pairs append
+//                 their index to a worklist in HBM (one wave-aggregated atomic).
+//   k_merl_fixup  ambiguous pairs only, densely packed: the exact fp64 path (merl_index).
+// If the worklist overflows its capacity the fix-up kernel rescans the batch with the same decision
+// function, so the result never depends on the capacity.  Bit-exactness argument and calibration: DESIGN.md 4.2.
+#include "djb_internal.hpp"
+
+using namespace djbdev;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr unsigned int WBUF = 256;   // per-wave LDS staging slots for ambiguous pair indices
+
+inline int grid_for(long long n, long long cap = 256LL * 16)
+{
+	long long blocks = (n + BLOCK - 1) / BLOCK;
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	return (int)blocks;
+}
+
+// 16-byte non-temporal accesses for the streams that are touched exactly once
+typedef float nt_v4f __attribute__((ext_vector_type(4)));
+DJB_DEV float4 nt_load4(const float4 *p)
+{
+	nt_v4f v = __builtin_nontemporal_load((const nt_v4f *)p);
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+DJB_DEV void nt_store4(float a, float b, float c, float d, float4 *p)
+{
+	nt_v4f v = { a, b, c, d };
+	__builtin_nontemporal_store(v, (nt_v4f *)p);
+}
+
+template <int WANT>
+DJB_DEV void merl_emit(const Brdf &b, int idx, v3 i, long long k, const View &vout, float *out_pdf)
+{
+	if (WANT & 3) {
+		float4 t = b.merl[idx];
+		v3 e = mk(t.x, t.y, t.z);
+		store3(vout, k, (WANT & 2) ? scale(i.z, e) : e);          // brdf::evalp, dj_brdf.h:803-806
+	}
+	if (WANT & 4) out_pdf[k] = F(D(i.z) / DJB_PI);                // brdf::pdf,   dj_brdf.h:842-845
+}
+
+template <int WANT>
+__global__ __launch_bounds__(BLOCK) void k_merl_fast(Brdf b, long long k_begin, long long n, View vi, View vo,
+                                                     View vout, float *out_pdf, MerlGuard g,
+                                                     unsigned int *list, unsigned int cap, unsigned int *count)
+{
+	// Ambiguous pair indices are staged per wave in LDS (no barrier needed: one wave, in-order LDS)
+	// and flushed 256 at a time with ONE global atomic: a returning atomic per ambiguous lane
+	// (~8e6 per 1e9 pairs on one address) costs more than the whole kernel.
+	__shared__ unsigned int wbuf[BLOCK / 64][WBUF];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	unsigned int wcount = 0;                                     // wave-uniform
+	auto flush = [&]() {
+		unsigned int base = 0;
+		if (lane == 0) base = atomicAdd(count, wcount);
+		base = __shfl(base, 0);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		for (unsigned int j = lane; j < wcount; j += 64)
+			if (base + j < cap) list[base + j] = wbuf[wave][j];  // beyond cap: fix-up kernel rescans
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		wcount = 0;
+	};
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k0 = k_begin + (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {   // block-uniform trip count
+		long long k = k0 + threadIdx.x;
+		bool amb = false;
+		if (k < n) {
+			v3 i = load3(vi, k), o = load3(vo, k);
+			int idx;
+			if (merl_index_fast(i, o, g, idx)) merl_emit<WANT>(b, idx, i, k, vout, out_pdf);
+			else amb = true;                                      // tier 2 (k_merl_fixup) finishes this pair
+		}
+		unsigned long long mask = __ballot(amb);
+		if (mask) {
+			unsigned int c = (unsigned int)__popcll(mask);
+			if (wcount + c > WBUF) flush();
+			if (amb) wbuf[wave][wcount + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)k;
+			wcount += c;
+		}
+	}
+	if (wcount) flush();
+}
+
+// Same kernel for dense SoA input (stride 1, 16-byte aligned): four consecutive pairs per lane,
+// float4 loads/stores, so each wave keeps 6 x 1 KiB loads and four independent table gathers in
+// flight -- the scalar version is latency-bound (one load -> compute -> gather -> store chain per
+// wave).  Ambiguous pairs get a placeholder in the float4 store; k_merl_fixup runs after this
+// kernel on the same stream and overwrites them.
+template <int WANT>
+__global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, View vi, View vo, View vout,
+                                                        float *out_pdf, MerlGuard g, unsigned int *list,
+                                                        unsigned int cap, unsigned int *count)
+{
+	__shared__ unsigned int wbuf[BLOCK / 64][WBUF];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	unsigned int wcount = 0;
+	auto flush = [&]() {
+		unsigned int base = 0;
+		if (lane == 0) base = atomicAdd(count, wcount);
+		base = __shfl(base, 0);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		for (unsigned int j = lane; j < wcount; j += 64)
+			if (base + j < cap) list[base + j] = wbuf[wave][j];
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		wcount = 0;
+	};
+	const float4 *ix4 = (const float4 *)vi.x, *iy4 = (const float4 *)vi.y, *iz4 = (const float4 *)vi.z;
+	const float4 *ox4 = (const float4 *)vo.x, *oy4 = (const float4 *)vo.y, *oz4 = (const float4 *)vo.z;
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long q0 = (long long)blockIdx.x * BLOCK; q0 < n4; q0 += stride) {
+		long long q = q0 + threadIdx.x;
+		bool amb[4] = { false, false, false, false };
+		if (q < n4) {
+			// the 36 B/pair streams are touched once: non-temporal, so they do not evict the table from L2
+			float4 ax = nt_load4(ix4 + q), ay = nt_load4(iy4 + q), az = nt_load4(iz4 + q),
+			       bx = nt_load4(ox4 + q), by = nt_load4(oy4 + q), bz = nt_load4(oz4 + q);
+			const float ixs[4] = { ax.x, ax.y, ax.z, ax.w }, iys[4] = { ay.x, ay.y, ay.z, ay.w },
+			            izs[4] = { az.x, az.y, az.z, az.w }, oxs[4] = { bx.x, bx.y, bx.z, bx.w },
+			            oys[4] = { by.x, by.y, by.z, by.w }, ozs[4] = { bz.x, bz.y, bz.z, bz.w };
+			int idx[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+				amb[j] = !merl_index_fast(mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]), g, idx[j]);
+			if (WANT & 3) {
+				float4 t[4];
+#pragma unroll
+#ifdef DJB_EXP_NOGATHER   // experiment only: how fast is the kernel without the table gather?
+				for (int j = 0; j < 4; ++j) t[j] = make_float4((float)idx[j], 0.f, 0.f, 0.f);
+#else
+				for (int j = 0; j < 4; ++j) t[j] = b.merl[amb[j] ? 0 : idx[j]];
+#endif
+				float r[4], gg[4], bb[4];
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					float s = (WANT & 2) ? izs[j] : 1.0f;                      // evalp = eval * i.z
+					r[j] = (WANT & 2) ? s * t[j].x : t[j].x;
+					gg[j] = (WANT & 2) ? s * t[j].y : t[j].y;
+					bb[j] = (WANT & 2) ? s * t[j].z : t[j].z;
+				}
+				nt_store4(r[0], r[1], r[2], r[3], (float4 *)vout.x + q);
+				nt_store4(gg[0], gg[1], gg[2], gg[3], (float4 *)vout.y + q);
+				nt_store4(bb[0], bb[1], bb[2], bb[3], (float4 *)vout.z + q);
+			}
+			if (WANT & 4)
+				((float4 *)out_pdf)[q] = make_float4(F(D(izs[0]) / DJB_PI), F(D(izs[1]) / DJB_PI),
+				                                     F(D(izs[2]) / DJB_PI), F(D(izs[3]) / DJB_PI));
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			unsigned long long mask = __ballot(amb[j]);
+			if (mask) {
+				unsigned int c = (unsigned int)__popcll(mask);
+				if (wcount + c > WBUF) flush();
+				if (amb[j])
+					wbuf[wave][wcount + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)(4 * q + j);
+				wcount += c;
+			}
+		}
+	}
+	if (wcount) flush();
+}
+
+template <int WANT>
+__global__ __launch_bounds__(BLOCK) void k_merl_fixup(Brdf b, long long n, View vi, View vo, View vout,
+                                                      float *out_pdf, MerlGuard g, const unsigned int *list,
+                                                      unsigned int cap, const unsigned int *count)
+{
+	const unsigned int m = *count;
+	if (m <= cap) {                      // normal case: the worklist holds every ambiguous pair
+		unsigned int stride = gridDim.x * BLOCK;
+		for (unsigned int j = blockIdx.x * BLOCK + threadIdx.x; j < m; j += stride) {
+			long long k = (long long)list[j];
+			v3 i = load3(vi, k), o = load3(vo, k);
+			merl_emit<WANT>(b, merl_index(i, o), i, k, vout, out_pdf);
+		}
+	} else {                             // overflow (adversarial input): rescan, same decision function
+		long long stride = (long long)gridDim.x * BLOCK;
+		for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+			v3 i = load3(vi, k), o = load3(vo, k);
+			int idx;
+			if (!merl_index_fast(i, o, g, idx)) merl_emit<WANT>(b, merl_index(i, o), i, k, vout, out_pdf);
+		}
+	}
+}
+
+// ---- calibration: how far is the fp32 estimate from the reference's own value, in units of its
+// guard band?  stats: [0..2] max ratio (theta_h, theta_d, phi_d) as float bits; counters follow.
+__global__ __launch_bounds__(BLOCK) void k_merl_guard_stats(long long n, View vi, View vo, MerlGuard g,
+                                                            unsigned int *max_bits,
+                                                            unsigned long long *counters)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	float mh = 0, md = 0, mp = 0;
+	unsigned long long n_special = 0, n_amb = 0, n_mismatch = 0, n_sure = 0;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		v3 i = load3(vi, k), o = load3(vo, k);
+		MerlFast f = merl_fast_coords(i, o, g);
+		int idx_fast;
+		bool sure = merl_index_fast(i, o, g, idx_fast);
+		float th, td, pd;
+		merl_angles_exact(i, o, th, td, pd);
+		int idx_ref = phi_diff_index(pd) + theta_diff_index(td) * 180 + theta_half_index(th) * 16200;
+		if (f.special) { ++n_special; continue; }
+		// the reference's continuous coordinates (dj_brdf.h:906-957)
+		float Th = D(th) <= 0.0 ? 0.0f : sqrtf(F((D(th) / (DJB_PI / 2.0)) * 90) * 90.0f);
+		float Xd = F(D(td) / (DJB_PI * 0.5) * 90);
+		float pw = D(pd) < 0.0 ? F(D(pd) + DJB_PI) : pd;
+		float Xp = F(D(pw) / DJB_PI * 360 / 2);
+		float dh = fabsf(f.t_h - Th), dd = fabsf(f.x_d - Xd), dp = fabsf(f.x_p - Xp);
+		dp = fminf(dp, 180.0f - dp);
+		if (f.m_h < 0.45f) mh = fmaxf(mh, dh / f.m_h);
+		if (f.m_d < 0.45f) { md = fmaxf(md, dd / f.m_d); mp = fmaxf(mp, dp / f.m_p); }
+		if (sure) { ++n_sure; if (idx_fast != idx_ref) ++n_mismatch; } else ++n_amb;
+	}
+	atomicMax(&max_bits[0], __float_as_uint(mh));
+	atomicMax(&max_bits[1], __float_as_uint(md));
+	atomicMax(&max_bits[2], __float_as_uint(mp));
+	atomicAdd(&counters[0], n_special); atomicAdd(&counters[1], n_amb);
+	atomicAdd(&counters[2], n_mismatch); atomicAdd(&counters[3], n_sure);
+}
+
+template <int WANT>
+hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
+                     const View &out, float *out_pdf, const MerlGuard &g, unsigned int *list,
+                     unsigned int cap, unsigned int *count)
+{
+	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int), s);
+	if (e != hipSuccess) return e;
+	auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+	bool dense = i.stride == 1 && o.stride == 1 && (!(WANT & 3) || out.stride == 1) &&
+	             al16(i.x) && al16(i.y) && al16(i.z) && al16(o.x) && al16(o.y) && al16(o.z) &&
+	             (!(WANT & 3) || (al16(out.x) && al16(out.y) && al16(out.z))) && (!(WANT & 4) || al16(out_pdf));
+	long long n4 = dense ? n / 4 : 0;
+	if (n4 > 0)
+		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4)), dim3(BLOCK), 0, s, b, n4, i, o, out,
+		                   out_pdf, g, list, cap, count);
+	if (4 * n4 < n)   // strided / unaligned input, or the < 4-pair tail of a dense batch
+		hipLaunchKernelGGL((k_merl_fast<WANT>), dim3(grid_for(n - 4 * n4)), dim3(BLOCK), 0, s, b, 4 * n4, n, i, o,
+		                   out, out_pdf, g, list, cap, count);
+	long long guess = n / 64 + 1;   // fix-up grid sized for a ~1.5 % worklist; grid-stride beyond
+	hipLaunchKernelGGL((k_merl_fixup<WANT>), dim3(grid_for(guess, 2048)), dim3(BLOCK), 0, s, b, n, i, o, out,
+	                   out_pdf, g, list, cap, count);
+	return hipGetLastError();
+}
+
+} // namespace
+
+namespace djbk {
+
+hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
+                               const View &out, float *out_pdf, int want, unsigned int *list,
+                               unsigned int cap, unsigned int *count)
+{
+	if (n <= 0) return hipSuccess;
+	const MerlGuard g = MERL_GUARD_DEFAULT;
+	switch (want) {
+	case 1: return launch_tt<1>(s, b, n, i, o, out, out_pdf, g, list, cap, count);
+	case 2: return launch_tt<2>(s, b, n, i, o, out, out_pdf, g, list, cap, count);
+	case 5: return launch_tt<5>(s, b, n, i, o, out, out_pdf, g, list, cap, count);
+	case 6: return launch_tt<6>(s, b, n, i, o, out, out_pdf, g, list, cap, count);
+	}
+	return hipErrorInvalidValue;
+}
+
+hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, const View &o,
+                                   const float *guard5, unsigned int *max_bits, unsigned long long *counters)
+{
+	MerlGuard g = MERL_GUARD_DEFAULT;
+	if (guard5) { g.a_h = guard5[0]; g.b_h = guard5[1]; g.a_d = guard5[2]; g.b_d = guard5[3]; g.c_d = guard5[4]; }
+	hipLaunchKernelGGL(k_merl_guard_stats, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, i, o, g, max_bits, counters);
+	return hipGetLastError();
+}
+
+} // namespace djbk

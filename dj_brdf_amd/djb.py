@@ -668,3 +668,24 @@ def histogram_xy(v, bins: int = 64, ctx: Optional[Context] = None):
     _lib.check(_lib.load().djb_histogram_xy(ctx._h, C.c_int64(vv.n), C.byref(vv.view), C.c_int(bins),
                                             C.c_void_p(counts.data_ptr())))
     return counts.view(bins, bins)
+
+
+# --------------------------------------------------------------------------- two-tier MERL diagnostics
+def set_merl_exact_only(ctx: Context, on: bool):
+    """Force merl eval/evalp onto the operation-by-operation fp64 kernel (DJB_OPT_MERL_EXACT_ONLY)."""
+    _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(1), C.c_int(int(on))))
+
+
+def merl_guard_stats(i, o, guard=None, ctx: Optional[Context] = None):
+    """Calibration of the two-tier MERL kernel on device-resident pairs (see djb_merl_guard_stats)."""
+    ctx = ctx or default_context()
+    vi, vo = _Vec(i), _Vec(o)
+    ratios = (C.c_float * 3)()
+    counters = (C.c_ulonglong * 4)()
+    g = None
+    if guard is not None:
+        g = (C.c_float * 5)(*guard)
+    _lib.check(_lib.load().djb_merl_guard_stats(ctx._h, C.c_int64(vi.n), C.byref(vi.view), C.byref(vo.view), g,
+                                                ratios, counters))
+    return {"max_ratio": tuple(ratios), "special": counters[0], "ambiguous": counters[1],
+            "mismatch": counters[2], "certain": counters[3]}

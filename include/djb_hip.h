@@ -92,6 +92,11 @@ djb_status  djb_ctx_create_on_stream(int device, void *hip_stream, djb_ctx **out
 djb_status  djb_ctx_destroy(djb_ctx *ctx);
 djb_status  djb_ctx_synchronize(djb_ctx *ctx);
 void       *djb_ctx_stream(djb_ctx *ctx);
+/* options.  DJB_OPT_MERL_EXACT_ONLY = 1 makes merl eval/evalp run the operation-by-operation fp64
+ * kernel for every pair instead of the two-tier kernel (fp32 fast path + guard bands + fp64 path
+ * for ambiguous pairs); both give the same bits, the option exists to verify that.           */
+enum { DJB_OPT_MERL_EXACT_ONLY = 1 };
+djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */
 djb_status  djb_timer_start(djb_ctx *ctx);
 djb_status  djb_timer_stop_ms(djb_ctx *ctx, float *ms);
@@ -171,6 +176,13 @@ djb_status djb_hd_to_io_batch(djb_ctx *, int64_t n, const djb_vec3_view *h, cons
 /* the table index merl::eval composes (diagnostic; dj_brdf.h:997-1002)                  */
 djb_status djb_merl_index_batch(djb_ctx *, int64_t n, const djb_vec3_view *i,
                                 const djb_vec3_view *o, int32_t *out_index, int mem);
+
+/* calibration of the two-tier MERL kernel on n device-resident pairs: max over the batch of
+ * |fp32 estimate - reference value| / guard band for (theta_h, theta_d, phi_d), and the counters
+ * {special-region pairs, ambiguous pairs, index mismatches among "certain" pairs (must be 0),
+ * certain pairs}.  guard5 = NULL uses the shipped band constants.                           */
+djb_status djb_merl_guard_stats(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
+                                const float *guard5, float *max_ratio3, unsigned long long *counters4);
 
 /* microfacet::params -> private members (host side, no GPU work)       dj_brdf.h:1355-1506 */
 djb_status djb_params_resolve(const djb_params *params, djb_params_resolved *out);

@@ -65,6 +65,9 @@ DJB_DEV v3 cross(v3 a, v3 b)                                                    
 // vec3 / float_t == (1.0 / b) * a with the reciprocal rounded to float (dj_brdf.h:601);
 // float(1.0 / double(b)) == 1.0f / b (one correctly-rounded division)
 DJB_DEV v3 divs(v3 a, float b) { return scale(1.0f / b, a); }
+// float(double(a) / (4.0 * double(b))) == a / (4.0f * b): 4*b is exact in float and one division
+// of two floats rounds identically through double (dj_brdf.h:1544, 1724-1726, 1754-1760)
+DJB_DEV float fdiv4(float a, float b) { return a / (4.0f * b); }
 // inversesqrt = float(1.0 / sqrt(double(x))): two double roundings, kept in double (dj_brdf.h:612)
 DJB_DEV float inversesqrt_(float x) { return F(1.0 / sqrt(D(x))); }
 DJB_DEV v3 normalize(v3 v) { return scale(inversesqrt_(dot(v, v)), v); }              // dj_brdf.h:630
@@ -226,7 +229,7 @@ DJB_DEV v3 fresnel_eval(const Fresnel &f, float c)
 	case FR_UNPOLARIZED:
 		return mk(unpolarized1(c, f.a[0]), unpolarized1(c, f.a[1]), unpolarized1(c, f.a[2]));
 	case FR_SCHLICK: {   // dj_brdf.h:1320-1328
-		float c1 = F(1.0 - D(c)), c2 = c1 * c1, c5 = c2 * c2 * c1;
+		float c1 = 1.0f - c /* == float(1.0 - double(c)) */, c2 = c1 * c1, c5 = c2 * c2 * c1;
 		v3 f0 = mk(f.a[0], f.a[1], f.a[2]);
 		return add(f0, scale(c5, sub(mk(1, 1, 1), f0)));
 	}
@@ -247,7 +250,7 @@ DJB_DEV v3 fresnel_eval(const Fresnel &f, float c)
 template <int KIND> DJB_DEV float p22_radial(const Brdf &b, float r_sqr)
 {
 	if (KIND == KIND_BECKMANN) return F(exp(D(-r_sqr)) / DJB_PI);                      // :1866
-	if (KIND == KIND_GGX) { float t = F(1.0 + D(r_sqr)); return F(1.0 / (DJB_PI * D(t) * D(t))); } // :2056
+	if (KIND == KIND_GGX) { float t = 1.0f + r_sqr; /* == float(1.0 + double(r_sqr)) */ return F(1.0 / (DJB_PI * D(t) * D(t))); } // :2056
 	float r = sqrtf(r_sqr);                                                             // :2151
 	float u = F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI))));
 	return spline_f(b.p22, b.n_p22, u);
@@ -262,7 +265,7 @@ template <int KIND> DJB_DEV float sigma_std_radial(const Brdf &b, float c)
 		float tmp = F(exp(D(-nu * nu)) * D(inversesqrt_(F(DJB_PI))));
 		return F((D(c) * (1.0 + D(erf_(nu))) + D(s * tmp)) / 2.0);
 	}
-	if (KIND == KIND_GGX) return F((1.0 + D(c)) / 2.0);                                 // :2062
+	if (KIND == KIND_GGX) return (1.0f + c) * 0.5f; /* == float((1.0 + double(c)) / 2.0) */                                // :2062
 	float u = F(D(2.0f) * acos(D(c)) / D(F(DJB_PI)));                                   // :2158
 	return spline_f(b.sigma, b.n_sigma, u);
 }
@@ -431,15 +434,15 @@ DJB_DEV void mf_eval_pdf(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, flo
 		if (WANT & 3) {                                                                      // :1529-1555
 			float cd = sat_(oh);
 			v3 Fr = fresnel_eval(b.fr, cd);
-			v3 e = scale(F(D(Dn * G) / (4.0 * D(o.z))), Fr);
+			v3 e = scale(fdiv4(Dn * G, o.z), Fr);
 			fr = (WANT & 1) ? divs(e, i.z) : e;
 		}
 		if (WANT & 4) {                                                                      // :1713-1730
 			float ih4 = dot(i, h);
-			if (KIND == KIND_TABULAR) pdf = F(D(h.z * Dn) / (4.0 * D(ih4)));
+			if (KIND == KIND_TABULAR) pdf = fdiv4(h.z * Dn, ih4);
 			else {
 				float vndf = D(oh) > 0.0 ? oh * Dn / sig_o : 0.0f;                           // :1602-1615
-				pdf = F(D(vndf) / (4.0 * D(ih4)));
+				pdf = fdiv4(vndf, ih4);
 			}
 		}
 	}
@@ -510,13 +513,13 @@ DJB_DEV v3 mf_evalp_is(const Brdf &b, const Params &p, float u1, float u2, v3 o,
 		float Dn = mf_ndf<KIND>(b, h, p);
 		v3 Fr = fresnel_eval(b.fr, cd);
 		if (KIND == KIND_TABULAR) {
-			float pdf_ = F(D(h.z * Dn) / (4.0 * D(cd)));
+			float pdf_ = fdiv4(h.z * Dn, cd);
 			pdf_out = pdf_;
-			v3 e = scale(F(D(Dn * G) / (4.0 * D(o.z))), Fr);   // evalp(i_, o)
+			v3 e = scale(fdiv4(Dn * G, o.z), Fr);   // evalp(i_, o)
 			return divs(e, pdf_);
 		} else {
 			float vndf = D(oh) > 0.0 ? oh * Dn / sig_o : 0.0f;
-			pdf_out = F(D(vndf) / (4.0 * D(cd)));
+			pdf_out = fdiv4(vndf, cd);
 			return scale(G / g1o, Fr);
 		}
 	}

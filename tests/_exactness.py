@@ -1,0 +1,17 @@
+import numpy as np, sys
+sys.path.insert(0, 'tests')
+import oraclelib
+from dj_brdf_amd import djb, synth
+from test_gpu_parity import FRESNELS, PARAMS, mk_fresnel, mk_params
+O = oraclelib.oracle(); ctx = djb.default_context(0)
+n = 1 << 20
+i = synth.directions_aos(n, synth.SEED_I); o = synth.directions_aos(n, synth.SEED_O)
+for ndf in ("ggx", "beckmann"):
+    for fres in FRESNELS:
+        g = getattr(djb, ndf)(mk_fresnel(fres), True, ctx=ctx); ob = O.microfacet(ndf, fres, True)
+        for p in PARAMS:
+            for op in ("eval", "pdf"):
+                a = getattr(g, op)(i, o, mk_params(p)); b = O.eval(ob, i, o, p, op)
+                ex = np.mean(a.view(np.uint32) == b.view(np.uint32))
+                rel = np.max(np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), 1e-25))
+                print(f"{ndf:9s} {fres[0]:12s} {str(p)[:28]:28s} {op:5s} bit-exact {ex:.7f} max rel {rel:.2e}")

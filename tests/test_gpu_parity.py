@@ -74,7 +74,11 @@ def test_microfacet_eval_pdf(gpu_ctx, oracle, dirs, ndf, fres):
             up = mk_params(p)
             for op in ("eval", "evalp", "pdf"):
                 got = getattr(g, op)(i, o, up)
-                assert_close(f"{ndf}/{fres[0]}/{shadow}/{p}/{op}", got, oracle.eval(ob, i, o, p, op))
+                ex = assert_close(f"{ndf}/{fres[0]}/{shadow}/{p}/{op}", got, oracle.eval(ob, i, o, p, op))
+                # stronger than the 1e-5 contract: the kernels keep the reference's float/double
+                # evaluation order, so outputs are bit-identical (measured: 100 % on 2^20 pairs);
+                # allow 1e-5 of the outputs to differ in the last ulp (ocml vs glibc exp/pow)
+                assert ex >= 0.99999, f"{ndf}/{fres[0]}/{p}/{op}: only {ex:.6f} of outputs bit-identical"
             fr, pdf = g.eval_pdf(i, o, up)
             assert_close("fused eval", fr, oracle.eval(ob, i, o, p, "eval"))
             assert_close("fused pdf", pdf, oracle.eval(ob, i, o, p, "pdf"))

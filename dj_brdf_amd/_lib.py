@@ -16,6 +16,7 @@ DJB_OK = 0
 STATUS_NAMES = {
     0: "DJB_OK", 1: "DJB_ERR_INVALID_ARGUMENT", 2: "DJB_ERR_OPEN_FAILED", 3: "DJB_ERR_BAD_HEADER",
     4: "DJB_ERR_READ_FAILED", 5: "DJB_ERR_NOT_IMPLEMENTED", 6: "DJB_ERR_HIP", 7: "DJB_ERR_NO_DEVICE",
+    8: "DJB_ERR_UNKNOWN_MATERIAL",
 }
 MEM_DEVICE, MEM_HOST = 0, 1
 
@@ -55,6 +56,8 @@ EXPORTS = [
     "djb_brdf_create_beckmann", "djb_brdf_create_ggx", "djb_brdf_create_merl_from_file",
     "djb_brdf_create_merl_from_memory", "djb_brdf_create_utia_from_file",
     "djb_brdf_create_utia_from_memory", "djb_brdf_create_lambert", "djb_brdf_create_tabular",
+    "djb_brdf_create_sgd", "djb_brdf_create_abc", "djb_brdf_create_sgd_from_params",
+    "djb_brdf_create_abc_from_params",
     "djb_brdf_destroy", "djb_brdf_kind", "djb_brdf_get_shadow", "djb_eval_batch", "djb_evalp_batch",
     "djb_pdf_batch", "djb_eval_pdf_batch", "djb_sample_batch", "djb_sample_rng_batch",
     "djb_evalp_is_batch", "djb_io_to_hd_batch", "djb_hd_to_io_batch", "djb_merl_index_batch", "djb_query_batch",

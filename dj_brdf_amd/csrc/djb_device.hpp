@@ -39,11 +39,13 @@ struct Brdf {
 	int n_p22, n_sigma, n_cdf, n_qf;
 	const float4 *merl;                     // [1458000] pre-scaled float RGB(+pad); below-horizon -> 0
 	const float *utia;                      // [3*288*288] float(normalized double sample)
+	const double *model;                    // sgd: 33 doubles, abc: 9 doubles (one published table row)
 };
 
 struct View { float *x, *y, *z; long long stride; };
 
-enum { KIND_BECKMANN = 0, KIND_GGX = 1, KIND_TABULAR = 2, KIND_MERL = 3, KIND_UTIA = 4, KIND_LAMBERT = 5 };
+enum { KIND_BECKMANN = 0, KIND_GGX = 1, KIND_TABULAR = 2, KIND_MERL = 3, KIND_UTIA = 4, KIND_LAMBERT = 5,
+       KIND_SGD = 6, KIND_ABC = 7 };
 enum { FR_IDEAL = 0, FR_UNPOLARIZED = 1, FR_SCHLICK = 2, FR_SGD = 3, FR_SPLINE = 4 };
 
 // ------------------------------------------------------------------ L0 helpers (dj_brdf.h:574-765)
@@ -731,6 +733,62 @@ DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 		RGB[isp] = acc * 100.0f;
 	}
 	return mk(fmax_(0.f, RGB[0]), fmax_(0.f, RGB[1]), fmax_(0.f, RGB[2]));
+}
+
+// ------------------------------------------------------------------ SGD (dj_brdf.h:3415-3500)
+DJB_DEV double sgd_g1(v3 k, double theta0, double c, double k_, double lambda)           // :3415
+{
+	double t1 = fmax(0.0, acos(D(k.z)) - theta0);
+	double t2 = 1.0 - exp(c * pow(t1, k_));
+	double t3 = 1.0 + lambda * t2;
+	return fmin(1.0, fmax(0.0, t3));
+}
+DJB_DEV double sgd_ndf(double ch, double alpha, double p, double kap)                     // :3424
+{
+	const double inv_pi = 1.0 / DJB_PI;
+	double c2 = ch * ch;
+	double t2 = (1.0 - c2) / c2;
+	double ax = alpha + t2 / alpha;
+	return (kap * exp(-ax) * inv_pi) / (pow(ax, p) * c2 * c2);
+}
+DJB_DEV v3 sgd_eval(const Brdf &b, v3 i, v3 o)                                            // :3454
+{
+	const double *m = b.model;   // rhoD rhoS alpha p f0 f1 kap lambda c k theta0
+	if (D(i.z) > 0.0 && D(o.z) > 0.0) {
+		v3 h = normalize(add(i, o));
+		v3 Kd = mk(F(m[0]), F(m[1]), F(m[2])), Ks = mk(F(m[3]), F(m[4]), F(m[5]));
+		v3 Fr = fresnel_eval(b.fr, sat_(dot(i, h)));
+		float gi[3], go[3], nd[3];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			gi[c] = F(sgd_g1(i, m[30 + c], m[24 + c], m[27 + c], m[21 + c]));
+			go[c] = F(sgd_g1(o, m[30 + c], m[24 + c], m[27 + c], m[21 + c]));
+			nd[c] = F(sgd_ndf(D(h.z), m[6 + c], m[9 + c], m[18 + c]));
+		}
+		v3 FDG = mk((Fr.x * nd[0]) * (gi[0] * go[0]), (Fr.y * nd[1]) * (gi[1] * go[1]), (Fr.z * nd[2]) * (gi[2] * go[2]));
+		v3 spec = divs(mk(Ks.x * FDG.x, Ks.y * FDG.y, Ks.z * FDG.z), i.z * o.z);
+		return divs(add(Kd, spec), F(DJB_PI));
+	}
+	return mk(0, 0, 0);
+}
+
+// ------------------------------------------------------------------ ABC (dj_brdf.h:3608-3668)
+DJB_DEV v3 abc_eval(const Brdf &b, v3 i, v3 o)                                            // :3633
+{
+	const double *m = b.model;   // kD[3] A[3] B C ior
+	if (D(i.z) > 0.0 && D(o.z) > 0.0) {
+		v3 h = normalize(add(i, o));
+		v3 Kd = mk(F(m[0]), F(m[1]), F(m[2]));
+		v3 Fr = fresnel_eval(b.fr, sat_(dot(i, h)));
+		float g1_i = fmin_(1.0f, 2.0f * (h.z * i.z / dot(h, i)));                            // :3649
+		float g1_o = fmin_(1.0f, 2.0f * (h.z * o.z / dot(h, o)));
+		float G = fmin_(g1_i, g1_o);
+		double den = pow(1.0 + m[6] * (1.0 - D(h.z)), m[7]);                                // :3608
+		v3 Dn = mk(F(m[3] / den), F(m[4] / den), F(m[5] / den));
+		v3 spec = divs(scale(G, mk(Fr.x * Dn.x, Fr.y * Dn.y, Fr.z * Dn.z)), F(DJB_PI * D(i.z) * D(o.z)));
+		return add(divs(Kd, F(DJB_PI)), spec);
+	}
+	return mk(0, 0, 0);
 }
 
 // ------------------------------------------------------------------ array access

@@ -525,6 +525,61 @@ djb_status djb_brdf_create_lambert(djb_ctx *ctx, djb_brdf **out)
 	return alloc_brdf(ctx, DJB_KIND_LAMBERT, out);
 }
 
+// ---- sgd / abc: one row of the published parameter tables + the model's own Fresnel
+struct SgdRow { const char *name, *other_name; double v[33]; };
+struct AbcRow { const char *name; double v[9]; };
+#include "build/djb_param_tables.inc"
+
+static djb_status create_model(djb_ctx *ctx, int kind, const double *row, int count, djb_brdf **out)
+{
+	HIP_TRY(hipSetDevice(ctx->device));
+	djb_brdf *b;
+	alloc_brdf(ctx, kind, &b);
+	double *d = nullptr;
+	hipError_t e = hipMalloc((void **)&d, sizeof(double) * count);
+	if (e == hipSuccess) e = hipMemcpy(d, row, sizeof(double) * count, hipMemcpyHostToDevice);
+	if (e != hipSuccess) { if (d) (void)hipFree(d); delete b; return fail(DJB_ERR_HIP, "djb_error: %s", hipGetErrorString(e)); }
+	b->allocs.push_back(d);
+	b->dev.model = d;
+	djbdev::Fresnel &fr = b->dev.fr;
+	if (kind == DJB_KIND_SGD) {          // fresnel::sgd(vec3::from_raw(f0), vec3::from_raw(f1)), dj_brdf.h:3443
+		fr.kind = djbdev::FR_SGD;
+		for (int c = 0; c < 3; ++c) { fr.a[c] = (float)row[12 + c]; fr.b[c] = (float)row[15 + c]; }
+	} else {                             // fresnel::unpolarized(vec3(ior)), dj_brdf.h:3623
+		fr.kind = djbdev::FR_UNPOLARIZED;
+		for (int c = 0; c < 3; ++c) fr.a[c] = (float)row[8];
+	}
+	*out = b;
+	return DJB_OK;
+}
+
+djb_status djb_brdf_create_sgd_from_params(djb_ctx *ctx, const double *params33, djb_brdf **out)
+{
+	if (!ctx || !params33 || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	return create_model(ctx, DJB_KIND_SGD, params33, 33, out);
+}
+djb_status djb_brdf_create_abc_from_params(djb_ctx *ctx, const double *params9, djb_brdf **out)
+{
+	if (!ctx || !params9 || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	return create_model(ctx, DJB_KIND_ABC, params9, 9, out);
+}
+djb_status djb_brdf_create_sgd(djb_ctx *ctx, const char *name, djb_brdf **out)
+{
+	if (!ctx || !name || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	for (const SgdRow &r : k_sgd_rows)
+		if (!strcmp(r.name, name) || !strcmp(r.other_name, name))
+			return create_model(ctx, DJB_KIND_SGD, r.v, 33, out);
+	return fail(DJB_ERR_UNKNOWN_MATERIAL, "djb_error: No SGD parameters for %s\n", name);     // dj_brdf.h:3449
+}
+djb_status djb_brdf_create_abc(djb_ctx *ctx, const char *name, djb_brdf **out)
+{
+	if (!ctx || !name || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	for (const AbcRow &r : k_abc_rows)
+		if (!strcmp(r.name, name))
+			return create_model(ctx, DJB_KIND_ABC, r.v, 9, out);
+	return fail(DJB_ERR_UNKNOWN_MATERIAL, "djb_error: No ABC parameters for %s\n", name);     // dj_brdf.h:3628
+}
+
 djb_status djb_brdf_destroy(djb_brdf *b)
 {
 	if (!b) return DJB_OK;

@@ -31,6 +31,8 @@ DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float 
 			v3 e;
 			if (KIND == KIND_MERL) e = merl_eval(b, i, o);
 			else if (KIND == KIND_UTIA) e = utia_eval(b, i, o);
+			else if (KIND == KIND_SGD) e = sgd_eval(b, i, o);
+			else if (KIND == KIND_ABC) e = abc_eval(b, i, o);
 			else e = divs(mk(1, 1, 1), F(DJB_PI));                 // lambert, dj_brdf.h:861-868
 			fr = (WANT & 2) ? scale(i.z, e) : e;                   // brdf::evalp, dj_brdf.h:803-806
 		}
@@ -259,6 +261,8 @@ hipError_t launch_eval(hipStream_t s, const Brdf &b, const Params &p, long long 
 	case KIND_MERL:     return launch_eval_kind<KIND_MERL>(s, b, p, n, i, o, out, out_pdf, want);
 	case KIND_UTIA:     return launch_eval_kind<KIND_UTIA>(s, b, p, n, i, o, out, out_pdf, want);
 	case KIND_LAMBERT:  return launch_eval_kind<KIND_LAMBERT>(s, b, p, n, i, o, out, out_pdf, want);
+	case KIND_SGD:      return launch_eval_kind<KIND_SGD>(s, b, p, n, i, o, out, out_pdf, want);
+	case KIND_ABC:      return launch_eval_kind<KIND_ABC>(s, b, p, n, i, o, out, out_pdf, want);
 	}
 	return hipErrorInvalidValue;
 }
@@ -275,6 +279,8 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 	case KIND_MERL:     return launch_sample_kind<KIND_MERL>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_UTIA:     return launch_sample_kind<KIND_UTIA>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_LAMBERT:  return launch_sample_kind<KIND_LAMBERT>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_SGD:      return launch_sample_kind<KIND_SGD>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_ABC:      return launch_sample_kind<KIND_ABC>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	}
 	return hipErrorInvalidValue;
 }

@@ -62,6 +62,8 @@ DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o)
 	if (SRC <= KIND_TABULAR) mf_eval_pdf<SRC, 1>(src, std_p, i, o, fr, pdf);
 	else if (SRC == KIND_MERL) fr = merl_eval(src, i, o);
 	else if (SRC == KIND_UTIA) fr = utia_eval(src, i, o);
+	else if (SRC == KIND_SGD) fr = sgd_eval(src, i, o);
+	else if (SRC == KIND_ABC) fr = abc_eval(src, i, o);
 	else fr = divs(mk(1, 1, 1), F(DJB_PI));
 	(void)pdf;
 	return fr;
@@ -346,6 +348,8 @@ hipError_t launch_fit(hipStream_t s, const Brdf *srcs, int src_kind, const Param
 	case KIND_MERL:     return launch_fit_kind<KIND_MERL>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
 	case KIND_UTIA:     return launch_fit_kind<KIND_UTIA>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
 	case KIND_LAMBERT:  return launch_fit_kind<KIND_LAMBERT>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_SGD:      return launch_fit_kind<KIND_SGD>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_ABC:      return launch_fit_kind<KIND_ABC>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
 	}
 	return hipErrorInvalidValue;
 }

@@ -516,6 +516,39 @@ class lambert(brdf):
         _lib.check(_lib.load().djb_brdf_create_lambert(self.ctx._h, C.byref(self._h)))
 
 
+class sgd(brdf):
+    """djb::sgd(name): Shifted Gamma Distribution BRDF with the published per-material parameters
+    (dj_brdf.h:481-511, 3436-3500).  Unknown names raise exc ("No SGD parameters for ...")."""
+
+    def __init__(self, name: str, ctx=None):
+        super().__init__(ctx)
+        _lib.check(_lib.load().djb_brdf_create_sgd(self.ctx._h, name.encode(), C.byref(self._h)))
+
+    @classmethod
+    def from_params(cls, params33, ctx=None):
+        self = cls.__new__(cls)
+        brdf.__init__(self, ctx)
+        p = np.ascontiguousarray(params33, dtype=np.float64).reshape(33)
+        _lib.check(_lib.load().djb_brdf_create_sgd_from_params(self.ctx._h, C.c_void_p(p.ctypes.data), C.byref(self._h)))
+        return self
+
+
+class abc(brdf):
+    """djb::abc(name): ABC BRDF with the published per-material parameters (dj_brdf.h:514-535, 3617-3668)."""
+
+    def __init__(self, name: str, ctx=None):
+        super().__init__(ctx)
+        _lib.check(_lib.load().djb_brdf_create_abc(self.ctx._h, name.encode(), C.byref(self._h)))
+
+    @classmethod
+    def from_params(cls, params9, ctx=None):
+        self = cls.__new__(cls)
+        brdf.__init__(self, ctx)
+        p = np.ascontiguousarray(params9, dtype=np.float64).reshape(9)
+        _lib.check(_lib.load().djb_brdf_create_abc_from_params(self.ctx._h, C.c_void_p(p.ctypes.data), C.byref(self._h)))
+        return self
+
+
 class merl(brdf):
     """djb::merl(filename) (dj_brdf.h:126-133, 963-983).  ``merl.from_table`` builds the same
     object from the file payload in memory (3*n doubles, planes R, G, B)."""

@@ -41,7 +41,8 @@ typedef enum {
 	DJB_ERR_READ_FAILED = 4,      /* "djb_error: Reading %s failed"          dj_brdf.h:982, 1058 */
 	DJB_ERR_NOT_IMPLEMENTED = 5,  /* "djb_error: Not Implemented"            dj_brdf.h:1785-1790 */
 	DJB_ERR_HIP = 6,              /* a HIP runtime call failed                                  */
-	DJB_ERR_NO_DEVICE = 7         /* no gfx950 device / HIP runtime unusable                     */
+	DJB_ERR_NO_DEVICE = 7,        /* no gfx950 device / HIP runtime unusable                     */
+	DJB_ERR_UNKNOWN_MATERIAL = 8  /* "djb_error: No SGD/ABC parameters for %s" dj_brdf.h:3449, 3628 */
 } djb_status;
 
 enum { DJB_MEM_DEVICE = 0, DJB_MEM_HOST = 1 };
@@ -77,7 +78,7 @@ typedef struct {
 } djb_fresnel_desc;
 
 enum { DJB_KIND_BECKMANN = 0, DJB_KIND_GGX = 1, DJB_KIND_TABULAR = 2, DJB_KIND_MERL = 3,
-       DJB_KIND_UTIA = 4, DJB_KIND_LAMBERT = 5 };
+       DJB_KIND_UTIA = 4, DJB_KIND_LAMBERT = 5, DJB_KIND_SGD = 6, DJB_KIND_ABC = 7 };
 
 /* ---------------------------------------------------------------- library / context */
 const char *djb_last_error(void);
@@ -115,6 +116,15 @@ djb_status djb_brdf_create_utia_from_file(djb_ctx *, const char *path, djb_brdf 
 djb_status djb_brdf_create_utia_from_memory(djb_ctx *, const double *samples, djb_brdf **);
 /* djb::lambert                                                        dj_brdf.h:112-123 */
 djb_status djb_brdf_create_lambert(djb_ctx *, djb_brdf **);
+/* djb::sgd(const char *name) / djb::abc(const char *name): Shifted-Gamma and ABC models with the
+ * published per-material parameters (compiled in from the CSVs in dj_brdf_amd/data; SGD rows also
+ * answer to their alias).  Unknown names -> DJB_ERR_UNKNOWN_MATERIAL.  dj_brdf.h:502, 527, 3436, 3617
+ * The _from_params forms take one table row: sgd = rhoD rhoS alpha p f0 f1 kap lambda c k theta0
+ * (11 x RGB = 33 doubles), abc = kD[3] A[3] B C ior (9 doubles).                               */
+djb_status djb_brdf_create_sgd(djb_ctx *, const char *name, djb_brdf **);
+djb_status djb_brdf_create_abc(djb_ctx *, const char *name, djb_brdf **);
+djb_status djb_brdf_create_sgd_from_params(djb_ctx *, const double *params33, djb_brdf **);
+djb_status djb_brdf_create_abc_from_params(djb_ctx *, const double *params9, djb_brdf **);
 /* djb::tabular(const brdf&, int res, bool shadow): the power-iteration fit, run on the GPU
  *                                                                     dj_brdf.h:2215-2236 */
 djb_status djb_brdf_create_tabular(djb_ctx *, const djb_brdf *src, int res, int shadow, djb_brdf **);

@@ -242,6 +242,18 @@ namespace fresnel {
 	};
 } // namespace fresnel
 
+/* Shifted Gamma Distribution BRDF, dj_brdf.h:481-511 (published per-material parameters) */
+class sgd : public brdf {
+public:
+	explicit sgd(const char *name, hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_sgd(ctx(), name, &m_h)); }
+};
+
+/* ABC Distribution BRDF, dj_brdf.h:514-535 */
+class abc : public brdf {
+public:
+	explicit abc(const char *name, hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_abc(ctx(), name, &m_h)); }
+};
+
 /* Microfacet API, dj_brdf.h:210-298 */
 class microfacet : public brdf {
 public:

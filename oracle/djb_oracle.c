@@ -185,6 +185,7 @@ struct o_brdf {
 	float *p22, *sigma, *cdf, *qf;
 	int n_p22, n_sigma, n_cdf, n_qf;
 	/* merl / utia */
+	double model[36];      /* sgd / abc parameter row */
 	double *samples;
 	int64_t n_samples;
 };
@@ -678,6 +679,66 @@ static o_vec3 utia_eval(const o_brdf *b, o_vec3 i, o_vec3 o) /* hdr:1063-1157 */
 	return v3(fmaxf_(0.f, RGB[0]), fmaxf_(0.f, RGB[1]), fmaxf_(0.f, RGB[2]));
 }
 
+/* ------------------------------------------------------------------ SGD (hdr:3415-3500) */
+static double dmin(double a, double b) { return a < b ? a : b; }
+static double dmax(double a, double b) { return a > b ? a : b; }
+
+static double sgd_g1(o_vec3 k, double theta0, double c, double k_, double lambda) /* hdr:3415-3422 */
+{
+	double t1 = dmax(0.0, acos(D(k.z)) - theta0);
+	double t2 = 1.0 - exp(c * pow(t1, k_));
+	double t3 = 1.0 + lambda * t2;
+	return dmin(1.0, dmax(0.0, t3));
+}
+static double sgd_ndf(double ch, double alpha, double p, double kap) /* hdr:3424-3432 */
+{
+	const double inv_pi = 1.0 / O_PI;
+	double c2 = ch * ch;
+	double t2 = (1.0 - c2) / c2;
+	double ax = alpha + t2 / alpha;
+	return (kap * exp(-ax) * inv_pi) / (pow(ax, p) * c2 * c2);
+}
+static o_vec3 sgd_eval(const o_brdf *b, o_vec3 i, o_vec3 o) /* hdr:3454-3468 */
+{
+	const double *m = b->model; /* rhoD rhoS alpha p f0 f1 kap lambda c k theta0 */
+	if (D(i.z) > 0.0 && D(o.z) > 0.0) {
+		o_vec3 h = v3_normalize(v3_add(i, o));
+		o_vec3 Kd = v3(F(m[0]), F(m[1]), F(m[2])), Ks = v3(F(m[3]), F(m[4]), F(m[5]));
+		o_vec3 Fr = fresnel_eval(&b->fresnel, satf_(v3_dot(i, h)));
+		float g1i[3], g1o[3], nd[3];
+		for (int c = 0; c < 3; ++c) {
+			g1i[c] = F(sgd_g1(i, m[30 + c], m[24 + c], m[27 + c], m[21 + c]));
+			g1o[c] = F(sgd_g1(o, m[30 + c], m[24 + c], m[27 + c], m[21 + c]));
+			nd[c] = F(sgd_ndf(D(h.z), m[6 + c], m[9 + c], m[18 + c]));
+		}
+		o_vec3 G = v3_mul(v3(g1i[0], g1i[1], g1i[2]), v3(g1o[0], g1o[1], g1o[2]));
+		o_vec3 Dn = v3(nd[0], nd[1], nd[2]);
+		o_vec3 spec = v3_div(v3_mul(Ks, v3_mul(v3_mul(Fr, Dn), G)), i.z * o.z);
+		return v3_div(v3_add(Kd, spec), F(O_PI));
+	}
+	return v3(0, 0, 0);
+}
+
+/* ------------------------------------------------------------------ ABC (hdr:3608-3668) */
+static o_vec3 abc_eval(const o_brdf *b, o_vec3 i, o_vec3 o) /* hdr:3633-3645 */
+{
+	const double *m = b->model; /* kD[3] A[3] B C ior */
+	if (D(i.z) > 0.0 && D(o.z) > 0.0) {
+		o_vec3 h = v3_normalize(v3_add(i, o));
+		o_vec3 Kd = v3(F(m[0]), F(m[1]), F(m[2]));
+		o_vec3 Fr = fresnel_eval(&b->fresnel, satf_(v3_dot(i, h)));
+		float g1_i = fminf_(1.0f, 2.0f * (h.z * i.z / v3_dot(h, i)));   /* hdr:3649-3655 */
+		float g1_o = fminf_(1.0f, 2.0f * (h.z * o.z / v3_dot(h, o)));
+		float G = fminf_(g1_i, g1_o);
+		double ch = D(h.z), tmp = 1.0 - ch;                              /* hdr:3608-3613 */
+		o_vec3 Dn = v3(F(m[3] / pow(1.0 + m[6] * tmp, m[7])), F(m[4] / pow(1.0 + m[6] * tmp, m[7])),
+		               F(m[5] / pow(1.0 + m[6] * tmp, m[7])));
+		o_vec3 spec = v3_div(v3_scale(G, v3_mul(Fr, Dn)), F(O_PI * D(i.z) * D(o.z)));
+		return v3_add(v3_div(Kd, F(O_PI)), spec);
+	}
+	return v3(0, 0, 0);
+}
+
 /* ------------------------------------------------------------------ generic dispatch */
 static int is_microfacet(const o_brdf *b) { return b->kind <= O_BRDF_TABULAR; }
 
@@ -687,6 +748,8 @@ static o_vec3 brdf_eval(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p)
 	case O_BRDF_MERL: return merl_eval(b, i, o);
 	case O_BRDF_UTIA: return utia_eval(b, i, o);
 	case O_BRDF_LAMBERT: return v3_div(v3(1, 1, 1), F(O_PI)); /* hdr:861-868, default params */
+	case O_BRDF_SGD: return sgd_eval(b, i, o);
+	case O_BRDF_ABC: return abc_eval(b, i, o);
 	default: return mf_eval(b, i, o, p);
 	}
 }
@@ -1022,6 +1085,27 @@ o_brdf *o_create_utia(const char *path) /* hdr:1039-1059 */
 	if (got != UTIA_CNT) { free(tmp); set_err("djb_error: Reading %s failed\n", path); return NULL; }
 	o_brdf *b = o_create_utia_from_memory(tmp);
 	free(tmp);
+	return b;
+}
+
+o_brdf *o_create_sgd(const double *p) /* hdr:3436-3450: fresnel::sgd(f0, f1) */
+{
+	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
+	b->kind = O_BRDF_SGD;
+	memcpy(b->model, p, sizeof(double) * 33);
+	b->fresnel.kind = O_FRESNEL_SGD;
+	b->fresnel.a = v3(F(p[12]), F(p[13]), F(p[14]));
+	b->fresnel.b = v3(F(p[15]), F(p[16]), F(p[17]));
+	return b;
+}
+
+o_brdf *o_create_abc(const double *p) /* hdr:3617-3629: fresnel::unpolarized(vec3(ior)) */
+{
+	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
+	b->kind = O_BRDF_ABC;
+	memcpy(b->model, p, sizeof(double) * 9);
+	b->fresnel.kind = O_FRESNEL_UNPOLARIZED;
+	b->fresnel.a = v3(F(p[8]), F(p[8]), F(p[8]));
 	return b;
 }
 

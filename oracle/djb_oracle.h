@@ -51,7 +51,12 @@ enum { O_FRESNEL_IDEAL = 0, O_FRESNEL_UNPOLARIZED = 1, O_FRESNEL_SCHLICK = 2,
        O_FRESNEL_SGD = 3, O_FRESNEL_SPLINE = 4 };
 
 enum { O_BRDF_BECKMANN = 0, O_BRDF_GGX = 1, O_BRDF_TABULAR = 2, O_BRDF_MERL = 3,
-       O_BRDF_UTIA = 4, O_BRDF_LAMBERT = 5 };
+       O_BRDF_UTIA = 4, O_BRDF_LAMBERT = 5, O_BRDF_SGD = 6, O_BRDF_ABC = 7 };
+
+/* sgd: rhoD[3] rhoS[3] alpha[3] p[3] f0[3] f1[3] kap[3] lambda[3] c[3] k[3] theta0[3] (33 doubles);
+ * abc: kD[3] A[3] B C ior (9 doubles) -- one row of the published tables (hdr:3312-3413, 3505-3606) */
+struct o_brdf *o_create_sgd(const double *params33);
+struct o_brdf *o_create_abc(const double *params9);
 
 typedef struct o_brdf o_brdf;
 

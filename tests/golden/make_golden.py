@@ -64,6 +64,22 @@ def main():
     out.update(hd_i=i, hd_o=o, hd_h=h, hd_d=d, hd_back_i=bi, hd_back_o=bo)
     np.savez_compressed(os.path.join(HERE, "math.npz"), **out)
 
+    # ---- sgd / abc analytic models (published parameter tables) and the fit the dj_abc / dj_sgd
+    #      plugins run at load time: tabular(model, 90)  (mitsuba/dj_abc.cpp:31, dj_sgd.cpp:31)
+    from golden_cases import MODEL_MATERIALS, N_MODEL
+    i = synth.directions_aos(N_MODEL, synth.SEED_I, start=20000)
+    o = synth.directions_aos(N_MODEL, synth.SEED_O, start=20000)
+    out = {"i": i, "o": o}
+    for kind in ("sgd", "abc"):
+        for name in MODEL_MATERIALS:
+            b = getattr(R, kind)(name)
+            out[f"{kind}_{name}_eval"] = R.eval(b, i, o)
+            out[f"{kind}_{name}_evalp"] = R.eval(b, i, o, None, "evalp")
+        t = R.tabular(getattr(R, kind)(MODEL_MATERIALS[0]), 90, True)
+        for k, v in R.tabular_tables(t).items():
+            out[f"{kind}_fit_{k}"] = np.atleast_1d(v)
+    np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
+
     # ---- MERL lookup (hash-filled table: exact on any machine)
     tmp = tempfile.mkdtemp(prefix="djb_golden_")
     try:

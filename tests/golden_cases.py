@@ -43,3 +43,7 @@ PARAMS_TXT_MATERIALS = [
     ("chrome", (0.05, (0.01, 0.01, 0.01), (0.95, 0.95, 0.95))),
     ("white-fabric", (0.55, (0.6, 0.6, 0.6), (0.04, 0.04, 0.04))),
 ]
+
+# sgd / abc materials replayed from the reference (both tables carry these names)
+N_MODEL = 768
+MODEL_MATERIALS = ["gold-metallic-paint", "alum-bronze", "black-fabric", "chrome", "white-marble", "yellow-plastic"]

@@ -1,0 +1,73 @@
+"""sgd / abc analytic models on the HIP path: eval/evalp vs the golden vectors
+of the real reference and vs the oracle, default cosine sampling, and the tabular(model, 90) fit
+that the dj_sgd / dj_abc plugins run at load time."""
+import os
+
+import numpy as np
+import pytest
+
+from dj_brdf_amd import djb, param_tables, synth
+from golden_cases import MODEL_MATERIALS
+from test_gpu_parity import assert_close
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("kind", ["sgd", "abc"])
+def test_models_golden(gpu_ctx, kind):
+    g = np.load(os.path.join(G, "models.npz"))
+    for name in MODEL_MATERIALS:
+        b = getattr(djb, kind)(name, ctx=gpu_ctx)
+        ex = assert_close(f"{kind}/{name}/eval", b.eval(g["i"], g["o"]), g[f"{kind}_{name}_eval"])
+        assert ex > 0.999, f"{kind}/{name}: only {ex:.5f} bit-identical"
+        assert_close(f"{kind}/{name}/evalp", b.evalp(g["i"], g["o"]), g[f"{kind}_{name}_evalp"])
+
+
+@pytest.mark.parametrize("kind", ["sgd", "abc"])
+def test_models_all_materials_vs_oracle(gpu_ctx, oracle, kind):
+    n = 1 << 14
+    i = synth.directions_aos(n, synth.SEED_I, 31); o = synth.directions_aos(n, synth.SEED_O, 31)
+    u1 = synth.uniforms(n, synth.SEED_U1); u2 = synth.uniforms(n, synth.SEED_U2)
+    below = i.copy(); below[: n // 8, 2] *= -1                      # i below the horizon -> 0
+    for name in synth.MERL_NAMES:
+        b, ob = getattr(djb, kind)(name, ctx=gpu_ctx), getattr(oracle, kind)(name)
+        assert_close(f"{kind}/{name}", b.eval(below, o), oracle.eval(ob, below, o))
+    b, ob = getattr(djb, kind)("pearl-paint", ctx=gpu_ctx), getattr(oracle, kind)("pearl-paint")
+    assert_close("pdf", b.pdf(i, o), oracle.eval(ob, i, o, None, "pdf"))
+    assert_close("sample", b.sample(u1, u2, o), oracle.sample(ob, u1, u2, o), 2e-5)
+    w, si, pdf = b.evalp_is(u1, u2, o)
+    ww, wi, wpdf = oracle.evalp_is(ob, u1, u2, o)
+    assert_close("is pdf", pdf, wpdf, 2e-5); assert_close("is w", w, ww, 5e-5)
+    # the same object from an explicit parameter row
+    row = param_tables.sgd_params("pearl-paint") if kind == "sgd" else param_tables.abc_params("pearl-paint")
+    b2 = getattr(djb, kind).from_params(row, ctx=gpu_ctx)
+    assert np.array_equal(b2.eval(i, o).view(np.uint32), b.eval(i, o).view(np.uint32))
+
+
+def test_unknown_material_raises(gpu_ctx):
+    for kind, msg in (("sgd", "No SGD parameters for nope"), ("abc", "No ABC parameters for nope")):
+        with pytest.raises(djb.exc) as e:
+            getattr(djb, kind)("nope", ctx=gpu_ctx)
+        assert e.value.status_name == "DJB_ERR_UNKNOWN_MATERIAL" and msg in str(e.value)
+    djb.sgd("fabric-beige", ctx=gpu_ctx)            # SGD alias (otherName), dj_brdf.h:3440-3441
+
+
+@pytest.mark.parametrize("kind", ["sgd", "abc"])
+def test_plugin_load_time_fit(gpu_ctx, oracle, kind):
+    """djb::tabular(model, 90): nmap-sampled tabulated lobe used by dj_abc / dj_sgd for sample()/pdf()."""
+    g = np.load(os.path.join(G, "models.npz"))
+    t = djb.tabular(getattr(djb, kind)(MODEL_MATERIALS[0], ctx=gpu_ctx), 90, True, ctx=gpu_ctx)
+    got = {"p22": t.get_p22v(), "sigma": t.get_sigmav(), "cdf": t.get_cdfv(), "qf": t.get_qfv(),
+           "fresnel": t.get_fresnel().get_points()}
+    for k, v in got.items():
+        assert_close(f"{kind}/fit/{k}", v, g[f"{kind}_fit_{k}"], rtol=2e-5)
+    ab = djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0]
+    ag = djb.tabular.fit_ggx_parameters(t).get_ellipse()[0]
+    assert "%.3f %.3f" % (ab, ag) == "%.3f %.3f" % (g[f"{kind}_fit_alpha_beckmann"][0], g[f"{kind}_fit_alpha_ggx"][0])
+    n = 4096
+    o = synth.directions_aos(n, synth.SEED_O); u1 = synth.uniforms(n, 1); u2 = synth.uniforms(n, 2)
+    ot = oracle.tabular(getattr(oracle, kind)(MODEL_MATERIALS[0]), 90, True)
+    s = t.sample(u1, u2, o)
+    assert np.quantile(np.abs(s - oracle.sample(ot, u1, u2, o)).max(axis=1), 0.995) < 1e-4
+    assert_close("pdf", t.pdf(s, o), oracle.eval(ot, s, o, None, "pdf"), 1e-4)

@@ -120,3 +120,24 @@ def test_params_txt_of_reference_driver(oracle):
         r = oracle.tabular_tables(t)
         lines.append("%s %.3f %.3f\n" % (name, r["alpha_beckmann"], r["alpha_ggx"]))
     assert "".join(lines) == want
+
+
+def test_sgd_abc_models(oracle):
+    from golden_cases import MODEL_MATERIALS
+    g = np.load(os.path.join(G, "models.npz"))
+    for kind in ("sgd", "abc"):
+        for name in MODEL_MATERIALS:
+            b = getattr(oracle, kind)(name)
+            assert same(oracle.eval(b, g["i"], g["o"]), g[f"{kind}_{name}_eval"]), (kind, name)
+            assert same(oracle.eval(b, g["i"], g["o"], None, "evalp"), g[f"{kind}_{name}_evalp"])
+        t = oracle.tabular(getattr(oracle, kind)(MODEL_MATERIALS[0]), 90, True)
+        for k, v in oracle.tabular_tables(t).items():
+            assert same(np.atleast_1d(v), g[f"{kind}_fit_{k}"]), (kind, k)
+
+
+def test_parameter_tables_complete():
+    from dj_brdf_amd import param_tables
+    assert sorted(param_tables.abc_names()) == sorted(synth.MERL_NAMES)
+    assert set(synth.MERL_NAMES) <= set(param_tables.sgd_names())
+    assert len(param_tables.sgd_params("gold-metallic-paint")) == 33
+    assert param_tables.sgd_params("fabric-beige") == param_tables.sgd_params("beige-fabric")   # alias

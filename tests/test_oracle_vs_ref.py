@@ -107,3 +107,17 @@ def test_merl_params_driver_bytes(oracle, reference, tmp_path):
         lines.append("%s %.3f %.3f\n" % (synth.MERL_NAMES[k], r["alpha_beckmann"], r["alpha_ggx"]))
     subprocess.run([exe] + files, cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL)
     assert open(tmp_path / "params.txt").read() == "".join(lines)
+
+
+def test_sgd_abc_all_materials(oracle, reference, inputs):
+    from dj_brdf_amd import param_tables
+    i, o, _, _ = inputs
+    i, o = i[:20000], o[:20000]
+    for name in param_tables.abc_names():
+        for kind in ("sgd", "abc"):
+            a = oracle.eval(getattr(oracle, kind)(name), i, o)
+            b = reference.eval(getattr(reference, kind)(name), i, o)
+            assert np.array_equal(bits(a), bits(b)), (kind, name)
+    with pytest.raises(RuntimeError) as e:
+        reference.sgd("no-such-material")
+    assert "No SGD parameters for no-such-material" in str(e.value)

@@ -735,6 +735,37 @@ DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 	return mk(fmax_(0.f, RGB[0]), fmax_(0.f, RGB[1]), fmax_(0.f, RGB[2]));
 }
 
+// ------------------------------------------------------------------ per-pair params / beckmann::lrep
+// params::pdfparams(ax, ay, rho, tx, ty) -> the members eval needs (dj_brdf.h:1437-1474)
+DJB_DEV Params params_from_pdfparams(float ax, float ay, float rho, float tx, float ty)
+{
+	Params p;
+	p.ax = ax; p.ay = ay; p.rho = rho; p.tx = tx; p.ty = ty;
+	p.s = F(sqrt(1.0 - D(rho * rho)));
+	v3 n = normalize(mk(-tx, -ty, 1.0f));
+	p.nx = n.x; p.ny = n.y; p.nz = n.z;
+	return p;
+}
+struct Lrep { float E1, E2, E3, E4, E5; };                                                    // :350-352
+DJB_DEV Lrep lrep_add(Lrep a, Lrep r)                                                         // :1992
+{
+	Lrep o;
+	o.E1 = a.E1 + r.E1; o.E2 = a.E2 + r.E2;
+	o.E3 = a.E3 + r.E3 + 2.0f * a.E1 * r.E1;
+	o.E4 = a.E4 + r.E4 + 2.0f * a.E2 * r.E2;
+	o.E5 = a.E5 + r.E5 + a.E1 * r.E2 + a.E2 * r.E1;
+	return o;
+}
+DJB_DEV void lrep_to_pdfparams(Lrep l, float &ax, float &ay, float &rho, float &tx, float &ty)  // :1976
+{
+	float t1 = fmax_(0.0f, l.E3 - l.E1 * l.E1), t2 = fmax_(0.0f, l.E4 - l.E2 * l.E2);
+	ax = F(fmax(1e-5, sqrt(2.0 * D(t1))));
+	ay = F(fmax(1e-5, sqrt(2.0 * D(t2))));
+	rho = 2.0f * (l.E5 - l.E1 * l.E2) / (ax * ay);
+	rho = fmin_(0.99f, fmax_(-0.99f, rho));
+	tx = l.E1; ty = l.E2;
+}
+
 // ------------------------------------------------------------------ SGD (dj_brdf.h:3415-3500)
 DJB_DEV double sgd_g1(v3 k, double theta0, double c, double k_, double lambda)           // :3415
 {

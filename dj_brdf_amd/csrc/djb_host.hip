@@ -870,6 +870,129 @@ djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i,
 	return sg.finish();
 }
 
+// ---------------------------------------------------------------- beckmann::lrep (host scalars)
+// dj_brdf.h:1959-2051, float arithmetic in the reference's order (this TU is built with
+// -ffp-contract=off).  lrep = {E1, E2, E3, E4, E5}.
+djb_status djb_lrep_op(int op, const float *a, const float *b, float x, float y, float *out)
+{
+	if (!a || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	float E1 = a[0], E2 = a[1], E3 = a[2], E4 = a[3], E5 = a[4];
+	const float dflt[5] = { 0, 0, 1, 1, 0 };
+	const float *r = b ? b : dflt;
+	switch (op) {
+	case DJB_LREP_ADD:                                                  // operator+, :1992-1999
+		out[0] = E1 + r[0]; out[1] = E2 + r[1];
+		out[2] = E3 + r[2] + 2.0f * E1 * r[0];
+		out[3] = E4 + r[3] + 2.0f * E2 * r[1];
+		out[4] = E5 + r[4] + E1 * r[1] + E2 * r[0];
+		return DJB_OK;
+	case DJB_LREP_MUL: case DJB_LREP_IMUL: {                            // operator*, *=, :2001-2033
+		if (!(x >= 0.0f)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid scale");
+		float s2 = x * x;
+		out[0] = E1 * x; out[1] = E2 * x; out[2] = E3 * s2; out[3] = E4 * s2; out[4] = E5 * s2;
+		return DJB_OK;
+	}
+	case DJB_LREP_IADD:                                                 // operator+=, :2011-2020 (uses the
+		E1 += r[0]; E2 += r[1];                                         //  already-updated E1/E2: kept)
+		E3 += r[2] + 2.0f * E1 * r[0];
+		E4 += r[3] + 2.0f * E2 * r[1];
+		E5 += r[4] + E1 * r[1] + E2 * r[0];
+		break;
+	case DJB_LREP_SHEAR:                                                // :2035-2042
+		E1 += x; E2 += y; E3 += x * x; E4 += y * y; E5 += x * y;
+		break;
+	case DJB_LREP_SCALE:                                                // :2044-2051
+		E1 *= x; E2 *= y; E3 *= x * x; E4 *= y * y; E5 *= x * y;
+		break;
+	default:
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown lrep op %d", op);
+	}
+	out[0] = E1; out[1] = E2; out[2] = E3; out[3] = E4; out[4] = E5;
+	return DJB_OK;
+}
+
+djb_status djb_params_to_lrep(const djb_params *params, float *out)                      // :1965-1974
+{
+	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	djb_params_resolved r;
+	djb_status st = resolve_params(params, &r);
+	if (st != DJB_OK) return st;
+	out[0] = r.tx_n; out[1] = r.ty_n;
+	out[2] = 0.5f * r.ax * r.ax + r.tx_n * r.tx_n;
+	out[3] = 0.5f * r.ay * r.ay + r.ty_n * r.ty_n;
+	out[4] = 0.5f * r.rho * r.ax * r.ay + r.tx_n * r.ty_n;
+	return DJB_OK;
+}
+
+djb_status djb_lrep_to_params(const float *l, djb_params *out)                           // :1976-1990
+{
+	if (!l || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	float t1 = l[2] - l[0] * l[0], t2 = l[3] - l[1] * l[1];
+	t1 = t1 > 0.0f ? t1 : 0.0f; t2 = t2 > 0.0f ? t2 : 0.0f;
+	double sx = std::sqrt(2.0 * (double)t1), sy = std::sqrt(2.0 * (double)t2);
+	float ax = (float)(sx > 1e-5 ? sx : 1e-5), ay = (float)(sy > 1e-5 ? sy : 1e-5);
+	float rho = 2.0f * (l[4] - l[0] * l[1]) / (ax * ay);
+	rho = rho > -0.99f ? rho : -0.99f; rho = rho < 0.99f ? rho : 0.99f;
+	out->kind = DJB_PARAMS_PDFPARAMS;
+	out->v[0] = ax; out->v[1] = ay; out->v[2] = rho; out->v[3] = l[0]; out->v[4] = l[1];
+	return DJB_OK;
+}
+
+static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                                 const djb_vec3_view *o, const float *rec, int mode, const float *base5,
+                                 int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pp, int mem)
+{
+	if (!b || !rec) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (b->dev.kind > DJB_KIND_TABULAR)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need a microfacet brdf");
+	if (want != 1 && want != 2 && want != 4 && want != 5 && want != 6)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: want must be eval(1)|evalp(2) and/or pdf(4)");
+	djb_status st = check_call(ctx, b, n, mem);
+	if (st != DJB_OK) return st;
+	Staged sg(ctx, n, mem);
+	View vi, vo, vout{ nullptr, nullptr, nullptr, 0 };
+	float *dpdf = nullptr, *dpp = nullptr; const float *drec = rec;
+	if ((st = sg.in_vec(i, &vi)) != DJB_OK) return st;
+	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
+	if (mem == DJB_MEM_HOST) {
+		float *d = nullptr;
+		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 5 * (size_t)(n > 0 ? n : 1)));
+		sg.blocks.push_back(d);
+		HIP_TRY(hipMemcpyAsync(d, rec, sizeof(float) * 5 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		drec = d;
+	}
+	if ((want & 3) && (st = sg.out_vec(out_fr, &vout)) != DJB_OK) return st;
+	if ((want & 4) && (st = sg.out_arr(out_pdf, &dpdf)) != DJB_OK) return st;
+	if (out_pp) {
+		if (mem == DJB_MEM_DEVICE) dpp = out_pp;
+		else {
+			HIP_TRY(hipMalloc((void **)&dpp, sizeof(float) * 5 * (size_t)(n > 0 ? n : 1)));
+			sg.blocks.push_back(dpp);
+			sg.out_raw.push_back({ dpp, { out_pp, sizeof(float) * 5 * (size_t)n } });
+		}
+	}
+	HIP_TRY(djbk::launch_eval_pp(ctx->stream, b->dev, n, vi, vo, drec, mode, base5, vout, dpdf, dpp, want));
+	return sg.finish();
+}
+
+djb_status djb_eval_pp_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                             const djb_vec3_view *o, const float *pdfparams, int want,
+                             const djb_vec3_view *out_fr, float *out_pdf, int mem)
+{
+	return eval_pp_common(ctx, b, n, i, o, pdfparams, 0, nullptr, want, out_fr, out_pdf, nullptr, mem);
+}
+
+djb_status djb_eval_lean_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                               const djb_vec3_view *o, const djb_params *base, float scale, const float *lean,
+                               int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pdfparams, int mem)
+{
+	float l1[5], base5[5];
+	djb_status st = djb_params_to_lrep(base, l1);
+	if (st != DJB_OK) return st;
+	if ((st = djb_lrep_op(DJB_LREP_IMUL, l1, nullptr, scale, 0.0f, base5)) != DJB_OK) return st;
+	return eval_pp_common(ctx, b, n, i, o, lean, 1, base5, want, out_fr, out_pdf, out_pdfparams, mem);
+}
+
 djb_status djb_ctx_set_option(djb_ctx *ctx, int option, int value)
 {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");

@@ -24,6 +24,12 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
                          unsigned long long start, const View &o, const View &out_i,
                          const View *out_w, float *out_pdf);
 
+// per-pair params: rec = n x 5 floats; mode 0 = pdfparams records, mode 1 = LEAN moments added to
+// base5 (params_to_lrep(base) * scale); out_pp (optional, mode 1) receives the resolved pdfparams
+hipError_t launch_eval_pp(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
+                          const float *rec, int mode, const float *base5, const View &out, float *out_pdf,
+                          float *out_pp, int want);
+
 // microfacet / radial queries; out.x holds scalar results (out.xyz for the Fresnel query)
 hipError_t launch_query(hipStream_t s, const Brdf &b, const Params &p, int which, long long n,
                         const View &a, const View &bb, const View &c, const View &out);

@@ -70,6 +70,51 @@ hipError_t launch_eval_kind(hipStream_t s, const Brdf &b, const Params &p, long 
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ per-pair parameters (LEAN / LEADR)
+// The batch form of "build microfacet::params per hit, then evalp(i, o, &params)"
+// (mitsuba/dj_beckmannconductor.cpp:291-319).  MODE 0: pdfparams records (ax, ay, rho, tx, ty) are
+// read per pair.  MODE 1: per-pair LEAN moments (E1..E5) are combined on the fly with the scaled
+// base lobe: params = lrep_to_params(base_lrep + lean_k), and optionally written back.
+template <int KIND, int WANT, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi, View vo, const float *rec,
+                                                   Lrep base, View vout, float *out_pdf, float *out_pp)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		v3 i = load3(vi, k), o = load3(vo, k);
+		const float *r = rec + 5 * k;
+		float ax, ay, rho, tx, ty;
+		if (MODE == 0) { ax = r[0]; ay = r[1]; rho = r[2]; tx = r[3]; ty = r[4]; }
+		else {
+			Lrep l; l.E1 = r[0]; l.E2 = r[1]; l.E3 = r[2]; l.E4 = r[3]; l.E5 = r[4];
+			lrep_to_pdfparams(lrep_add(base, l), ax, ay, rho, tx, ty);
+			if (out_pp) { float *w = out_pp + 5 * k; w[0] = ax; w[1] = ay; w[2] = rho; w[3] = tx; w[4] = ty; }
+		}
+		Params p = params_from_pdfparams(ax, ay, rho, tx, ty);
+		v3 fr = mk(0, 0, 0); float pdf = 0.0f;
+		mf_eval_pdf<KIND, WANT>(b, p, i, o, fr, pdf);
+		if (WANT & 3) store3(vout, k, fr);
+		if (WANT & 4) out_pdf[k] = pdf;
+	}
+}
+
+template <int KIND, int MODE>
+hipError_t launch_eval_pp_kind(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
+                               const float *rec, const Lrep &base, const View &out, float *out_pdf,
+                               float *out_pp, int want)
+{
+	dim3 g(grid_for(n)), t(BLOCK);
+	switch (want) {
+	case 1: hipLaunchKernelGGL((k_eval_pp<KIND, 1, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	case 2: hipLaunchKernelGGL((k_eval_pp<KIND, 2, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	case 4: hipLaunchKernelGGL((k_eval_pp<KIND, 4, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	case 5: hipLaunchKernelGGL((k_eval_pp<KIND, 5, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	case 6: hipLaunchKernelGGL((k_eval_pp<KIND, 6, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ sample / evalp_is
 template <int KIND, bool IS, bool RNG>
 __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n, const float *u1a,
@@ -282,6 +327,24 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 	case KIND_SGD:      return launch_sample_kind<KIND_SGD>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_ABC:      return launch_sample_kind<KIND_ABC>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	}
+	return hipErrorInvalidValue;
+}
+
+hipError_t launch_eval_pp(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
+                          const float *rec, int mode, const float *base5, const View &out, float *out_pdf,
+                          float *out_pp, int want)
+{
+	if (n <= 0) return hipSuccess;
+	Lrep base = { 0, 0, 1, 1, 0 };
+	if (base5) { base.E1 = base5[0]; base.E2 = base5[1]; base.E3 = base5[2]; base.E4 = base5[3]; base.E5 = base5[4]; }
+#define DJB_PP(K) (mode == 0 ? launch_eval_pp_kind<K, 0>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want) \
+                             : launch_eval_pp_kind<K, 1>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want))
+	switch (b.kind) {
+	case KIND_BECKMANN: return DJB_PP(KIND_BECKMANN);
+	case KIND_GGX:      return DJB_PP(KIND_GGX);
+	case KIND_TABULAR:  return DJB_PP(KIND_TABULAR);
+	}
+#undef DJB_PP
 	return hipErrorInvalidValue;
 }
 

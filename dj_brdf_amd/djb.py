@@ -494,7 +494,103 @@ def _params_ptr(user_param):
     return C.byref(user_param._p)
 
 
+def _eval_records(self, fn, i, o, records, want, extra_args, want_pp=False):
+    """shared driver of eval_pp / eval_lean: per-pair 5-float records next to the directions."""
+    lib = _lib.load()
+    vi, vo = _Vec(i), _Vec(o)
+    if vi.is_torch:
+        rec = records.float().contiguous() if isinstance(records, torch.Tensor) else \
+            torch.as_tensor(np.asarray(records, np.float32), device=vi.device)
+        rec_ptr = rec.data_ptr()
+    else:
+        rec = np.ascontiguousarray(records, dtype=np.float32)
+        rec_ptr = rec.ctypes.data
+    assert tuple(rec.shape) == (vi.n, 5), "records must be [n, 5]"
+    code = {"eval": 1, "evalp": 2, "pdf": 4, "eval+pdf": 5, "evalp+pdf": 6}[want]
+    out = vi.like() if code & 3 else None
+    pdf = pdf_ptr = None
+    if code & 4:
+        pdf, pdf_ptr = vi.scalars()
+    pp = pp_ptr = None
+    if want_pp:
+        pp = torch.empty((vi.n, 5), dtype=torch.float32, device=vi.device) if vi.is_torch else np.empty((vi.n, 5), np.float32)
+        pp_ptr = pp.data_ptr() if vi.is_torch else pp.ctypes.data
+    args = [self.ctx._h, self._h, C.c_int64(vi.n), C.byref(vi.view), C.byref(vo.view)] + extra_args(rec_ptr) + \
+           [C.c_int(code), C.byref(out.view) if out else None, C.c_void_p(pdf_ptr)]
+    if fn == "djb_eval_lean_batch":
+        args.append(C.c_void_p(pp_ptr))
+    args.append(C.c_int(vi.mem))
+    _lib.check(getattr(lib, fn)(*args))
+    res = [x for x in (out.keep if out else None, pdf) if x is not None]
+    if want_pp:
+        res.append(pp)
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def _eval_pp(self, i, o, pdfparams, want="evalp"):
+    """per-pair microfacet::params::pdfparams records [n,5] = (ax, ay, rho, tx_n, ty_n)."""
+    return _eval_records(self, "djb_eval_pp_batch", i, o, pdfparams, want, lambda p: [C.c_void_p(p)])
+
+
+def _eval_lean(self, i, o, base, scale, lean, want="evalp", return_params=False):
+    """dj_beckmannconductor's per-hit path, batched: params_k = lrep_to_params(lrep(base)*scale + lean_k)
+    with lean [n,5] = LEAN/LEADR slope moments (E1..E5)."""
+    return _eval_records(self, "djb_eval_lean_batch", i, o, lean, want,
+                         lambda p: [_params_ptr(base), C.c_float(scale), C.c_void_p(p)], want_pp=return_params)
+
+
+microfacet.eval_pp = _eval_pp
+microfacet.eval_lean = _eval_lean
+
+
 class beckmann(microfacet):
+    class lrep:
+        """beckmann::lrep: linear representation by slope moments E1..E5 (dj_brdf.h:330-356)."""
+
+        def __init__(self, E1=0.0, E2=0.0, E3=1.0, E4=1.0, E5=0.0):
+            self.E = (C.c_float * 5)(E1, E2, E3, E4, E5)
+
+        def _op(self, op, other=None, x=0.0, y=0.0):
+            out = beckmann.lrep()
+            _lib.check(_lib.load().djb_lrep_op(C.c_int(op), self.E, other.E if other is not None else None,
+                                              C.c_float(x), C.c_float(y), out.E))
+            return out
+
+        def __add__(self, r):
+            return self._op(0, r)
+
+        def __mul__(self, sc):
+            return self._op(1, None, sc)
+
+        def __iadd__(self, r):
+            self.E = self._op(2, r).E
+            return self
+
+        def __imul__(self, sc):
+            self.E = self._op(3, None, sc).E
+            return self
+
+        def shear(self, x, y):
+            self.E = self._op(4, None, x, y).E
+
+        def scale(self, x, y):
+            self.E = self._op(5, None, x, y).E
+
+        def moments(self):
+            return tuple(self.E)
+
+    @staticmethod
+    def params_to_lrep(params):
+        l = beckmann.lrep()
+        _lib.check(_lib.load().djb_params_to_lrep(_params_ptr(params), l.E))
+        return l
+
+    @staticmethod
+    def lrep_to_params(l):
+        p = microfacet.params(0, ())
+        _lib.check(_lib.load().djb_lrep_to_params(l.E, C.byref(p._p)))
+        return p
+
     def __init__(self, fresnel=None, shadow=True, ctx=None):
         super().__init__("djb_brdf_create_beckmann", fresnel, shadow, ctx)
 

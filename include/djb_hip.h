@@ -178,6 +178,29 @@ enum { DJB_Q_NDF = 0, DJB_Q_GAF = 1, DJB_Q_G1 = 2, DJB_Q_SIGMA = 3, DJB_Q_P22 = 
 djb_status djb_query_batch(djb_ctx *, const djb_brdf *, int which, int64_t n, const djb_vec3_view *a,
                            const djb_vec3_view *b, const djb_vec3_view *c, const djb_params *params,
                            const djb_vec3_view *out, int mem);
+/* ---- per-pair microfacet parameters (what dj_beckmannconductor builds per hit,
+ * mitsuba/dj_beckmannconductor.cpp:291-319).  want = 1 eval | 2 evalp, optionally | 4 pdf.
+ * djb_eval_pp_batch:   pdfparams = n records (ax, ay, rho, tx_n, ty_n), i.e. evalp(i, o, &params_k).
+ * djb_eval_lean_batch: lean = n records of LEAN/LEADR slope moments (E1..E5); per pair
+ *   params_k = lrep_to_params(params_to_lrep(base) * scale + lean_k)   (dj_brdf.h:1965-1999)
+ *   and, if out_pdfparams != NULL, the resolved (ax, ay, rho, tx, ty) are written back.
+ * Records live in the same memory space as the directions.                                 */
+djb_status djb_eval_pp_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i,
+                             const djb_vec3_view *o, const float *pdfparams, int want,
+                             const djb_vec3_view *out_fr, float *out_pdf, int mem);
+djb_status djb_eval_lean_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i,
+                               const djb_vec3_view *o, const djb_params *base, float scale,
+                               const float *lean, int want, const djb_vec3_view *out_fr,
+                               float *out_pdf, float *out_pdfparams, int mem);
+/* beckmann::lrep algebra on {E1..E5} (host scalars; dj_brdf.h:330-356, 1959-2051).  b may be NULL
+ * (= the default lrep(0,0,1,1,0)); x (and y) are the scalar arguments of mul / shear / scale.
+ * IADD keeps the reference's operator+= ordering (dj_brdf.h:2013-2017), which differs from ADD.   */
+enum { DJB_LREP_ADD = 0, DJB_LREP_MUL = 1, DJB_LREP_IADD = 2, DJB_LREP_IMUL = 3, DJB_LREP_SHEAR = 4,
+       DJB_LREP_SCALE = 5 };
+djb_status djb_lrep_op(int op, const float *a, const float *b, float x, float y, float *out);
+djb_status djb_params_to_lrep(const djb_params *params, float *out_lrep);      /* beckmann::params_to_lrep */
+djb_status djb_lrep_to_params(const float *lrep, djb_params *out_pdfparams);   /* beckmann::lrep_to_params */
+
 /* brdf::io_to_hd / brdf::hd_to_io (static)                            dj_brdf.h:99-100  */
 djb_status djb_io_to_hd_batch(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                               const djb_vec3_view *out_h, const djb_vec3_view *out_d, int mem);

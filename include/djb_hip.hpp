@@ -343,6 +343,40 @@ protected:
 /* Beckmann Microfacet NDF, dj_brdf.h:327-371 */
 class beckmann : public radial {
 public:
+	/* Linear Representation (LEAN / LEADR slope moments), dj_brdf.h:330-353 */
+	class lrep {
+		friend class beckmann;
+	public:
+		lrep(float_t E1 = 0, float_t E2 = 0, float_t E3 = 1, float_t E4 = 1, float_t E5 = 0)
+		{ m_E[0] = E1; m_E[1] = E2; m_E[2] = E3; m_E[3] = E4; m_E[4] = E5; }
+		lrep operator+(const lrep &r) const { return op(DJB_LREP_ADD, &r, 0, 0); }
+		lrep operator*(float_t sc) const { return op(DJB_LREP_MUL, NULL, sc, 0); }
+		lrep &operator+=(const lrep &r) { *this = op(DJB_LREP_IADD, &r, 0, 0); return *this; }
+		lrep &operator*=(float_t sc) { *this = op(DJB_LREP_IMUL, NULL, sc, 0); return *this; }
+		void scale(float_t x, float_t y) { *this = op(DJB_LREP_SCALE, NULL, x, y); }
+		void shear(float_t x, float_t y) { *this = op(DJB_LREP_SHEAR, NULL, x, y); }
+		const float_t *moments() const { return m_E; }
+	private:
+		lrep op(int which, const lrep *r, float_t x, float_t y) const
+		{ lrep o; hip::check(djb_lrep_op(which, m_E, r ? r->m_E : NULL, x, y, o.m_E)); return o; }
+		float_t m_E[5];
+	};
+	static void params_to_lrep(const microfacet::params &params, lrep *l)
+	{ hip::check(djb_params_to_lrep(params.desc(), l->m_E)); }
+	static void lrep_to_params(const lrep &l, microfacet::params *params)
+	{
+		djb_params d;
+		hip::check(djb_lrep_to_params(l.m_E, &d));
+		*params = microfacet::params::pdfparams(d.v[0], d.v[1], d.v[2], d.v[3], d.v[4]);
+	}
+	/* batch form of dj_beckmannconductor's per-hit evaluation: lean[n][5] slope moments */
+	void evalp_lean(size_t n, const vec3 *i, const vec3 *o, const microfacet::params &base, float_t scale,
+	                const float_t *lean, vec3 *out_fr_cos, float_t *out_pdf = NULL) const
+	{
+		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out_fr_cos);
+		hip::check(djb_eval_lean_batch(ctx(), m_h, (int64_t)n, &vi, &vo, base.desc(), scale, lean,
+		                               out_pdf ? 6 : 2, &vr, out_pdf, NULL, DJB_MEM_HOST));
+	}
 	beckmann(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)
 	{ djb_fresnel_desc d = f.desc(); hip::check(djb_brdf_create_beckmann(ctx(), &d, shadow, &m_h)); }
 	float_t qf1(float_t u) const { return rq(DJB_Q_QF1, u); }

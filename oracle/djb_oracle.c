@@ -1007,6 +1007,111 @@ int o_tabular_get(const o_brdf *t, int which, float *out)
 	return n;
 }
 
+/* ------------------------------------------------------------------ beckmann::lrep (hdr:1959-2051) */
+typedef struct { float E1, E2, E3, E4, E5; } o_lrep;
+static o_vec3 ld3(const float *p, int64_t k);
+static void st3(float *p, int64_t k, o_vec3 v);
+
+static o_lrep lrep_add(o_lrep a, o_lrep r) /* hdr:1992-1999 */
+{
+	o_lrep o = { a.E1 + r.E1, a.E2 + r.E2, a.E3 + r.E3 + 2.0f * a.E1 * r.E1,
+	             a.E4 + r.E4 + 2.0f * a.E2 * r.E2, a.E5 + r.E5 + a.E1 * r.E2 + a.E2 * r.E1 };
+	return o;
+}
+static o_lrep lrep_mul(o_lrep a, float sc) /* hdr:2001-2009 */
+{
+	float s2 = sc * sc;
+	o_lrep o = { a.E1 * sc, a.E2 * sc, a.E3 * s2, a.E4 * s2, a.E5 * s2 };
+	return o;
+}
+static o_lrep lrep_add_assign(o_lrep a, o_lrep r) /* hdr:2011-2020: uses the UPDATED E1/E2 */
+{
+	a.E1 += r.E1; a.E2 += r.E2;
+	a.E3 += r.E3 + 2.0f * a.E1 * r.E1;
+	a.E4 += r.E4 + 2.0f * a.E2 * r.E2;
+	a.E5 += r.E5 + a.E1 * r.E2 + a.E2 * r.E1;
+	return a;
+}
+static o_lrep lrep_shear(o_lrep a, float tx, float ty) /* hdr:2035-2042 */
+{
+	a.E1 += tx; a.E2 += ty; a.E3 += tx * tx; a.E4 += ty * ty; a.E5 += tx * ty;
+	return a;
+}
+static o_lrep lrep_scale_xy(o_lrep a, float x, float y) /* hdr:2044-2051 */
+{
+	a.E1 *= x; a.E2 *= y; a.E3 *= x * x; a.E4 *= y * y; a.E5 *= x * y;
+	return a;
+}
+static o_lrep params_to_lrep(const o_params *p) /* hdr:1965-1974 */
+{
+	o_lrep l = { p->tx, p->ty, 0.5f * p->ax * p->ax + p->tx * p->tx, 0.5f * p->ay * p->ay + p->ty * p->ty,
+	             0.5f * p->rho * p->ax * p->ay + p->tx * p->ty };
+	return l;
+}
+static void lrep_to_pdfparams(o_lrep l, float *out5) /* hdr:1976-1990 */
+{
+	float t1 = fmaxf_(0.0f, l.E3 - l.E1 * l.E1), t2 = fmaxf_(0.0f, l.E4 - l.E2 * l.E2);
+	float ax = F(dmax(1e-5, sqrt(2.0 * D(t1)))), ay = F(dmax(1e-5, sqrt(2.0 * D(t2))));
+	float rho = 2.0f * (l.E5 - l.E1 * l.E2) / (ax * ay);
+	rho = fminf_(0.99f, fmaxf_(-0.99f, rho));
+	out5[0] = ax; out5[1] = ay; out5[2] = rho; out5[3] = l.E1; out5[4] = l.E2;
+}
+static o_lrep lrep_from(const float *a) { o_lrep l = { a[0], a[1], a[2], a[3], a[4] }; return l; }
+
+/* op: 0 a+b 1 a*x 2 a+=b 3 a*=x 4 shear(x,y) 5 scale(x,y); raw5 (optional) gets the moments */
+void o_lrep_op_raw(int op, const float *a, const float *b, float x, float y, float *raw5, float *out_pdfparams)
+{
+	o_lrep A = lrep_from(a), B = { 0, 0, 1, 1, 0 }, R;
+	if (b) B = lrep_from(b);
+	switch (op) {
+	case 0: R = lrep_add(A, B); break;
+	case 1: case 3: R = lrep_mul(A, x); break;
+	case 2: R = lrep_add_assign(A, B); break;
+	case 4: R = lrep_shear(A, x, y); break;
+	default: R = lrep_scale_xy(A, x, y); break;
+	}
+	if (raw5) { raw5[0] = R.E1; raw5[1] = R.E2; raw5[2] = R.E3; raw5[3] = R.E4; raw5[4] = R.E5; }
+	if (out_pdfparams) lrep_to_pdfparams(R, out_pdfparams);
+}
+void o_lrep_op(int op, const float *a, const float *b, float x, float y, float *out_pdfparams)
+{
+	o_lrep_op_raw(op, a, b, x, y, NULL, out_pdfparams);
+}
+void o_params_lrep_roundtrip(const o_param_desc *pd, float *out_pdfparams)
+{
+	o_params p = params_from_desc(pd);
+	lrep_to_pdfparams(params_to_lrep(&p), out_pdfparams);
+}
+/* mitsuba/dj_beckmannconductor.cpp:291-319 per hit: lrep_to_params(params_to_lrep(base)*scale + lean_k) */
+void o_eval_lean(const o_brdf *b, int op, int64_t n, const float *i, const float *o, const o_param_desc *base,
+                 float scale, const float *lean, float *out, float *out_pdfparams)
+{
+	o_params p0 = params_from_desc(base);
+	for (int64_t k = 0; k < n; ++k) {
+		float pp[5];
+		lrep_to_pdfparams(lrep_add(lrep_mul(params_to_lrep(&p0), scale), lrep_from(lean + 5 * k)), pp);
+		if (out_pdfparams) memcpy(out_pdfparams + 5 * k, pp, sizeof pp);
+		o_params p;
+		params_set_pdfparams(&p, pp[0], pp[1], pp[2], pp[3], pp[4]);
+		o_vec3 vi = ld3(i, k), vo = ld3(o, k);
+		if (op == 0) st3(out, k, brdf_eval(b, vi, vo, &p));
+		else if (op == 1) st3(out, k, brdf_evalp(b, vi, vo, &p));
+		else out[k] = brdf_pdf(b, vi, vo, &p);
+	}
+}
+/* per-pair pdfparams (n x 5: ax, ay, rho, tx, ty) */
+void o_eval_pp(const o_brdf *b, int op, int64_t n, const float *i, const float *o, const float *pp, float *out)
+{
+	for (int64_t k = 0; k < n; ++k) {
+		o_params p;
+		params_set_pdfparams(&p, pp[5 * k], pp[5 * k + 1], pp[5 * k + 2], pp[5 * k + 3], pp[5 * k + 4]);
+		o_vec3 vi = ld3(i, k), vo = ld3(o, k);
+		if (op == 0) st3(out, k, brdf_eval(b, vi, vo, &p));
+		else if (op == 1) st3(out, k, brdf_evalp(b, vi, vo, &p));
+		else out[k] = brdf_pdf(b, vi, vo, &p);
+	}
+}
+
 /* ------------------------------------------------------------------ construction */
 o_brdf *o_create_microfacet(int ndf, int fkind, const float *fd, int nf, int shadow)
 {

@@ -227,6 +227,69 @@ void ref_fresnel_eval(void *b_, long n, const float *c, float *out)
 void ref_erf(long n, const float *x, float *y)    { for (long k = 0; k < n; ++k) y[k] = djb::erf(x[k]); }
 void ref_erfinv(long n, const float *x, float *y) { for (long k = 0; k < n; ++k) y[k] = djb::erfinv(x[k]); }
 
+// ---- beckmann::lrep (hdr:330-356, 1959-2051) --------------------------------
+// The members are private; lrep_to_params + get_pdfparams and params_to_lrep round-trip them.
+// op: 0 a+b, 1 a*s, 2 a+=b, 3 a*=s, 4 a.shear(x,y), 5 a.scale(x,y).  The result is returned as the
+// pdfparams of lrep_to_params(result) AND as raw moments recovered through shear-free algebra:
+// we expose moments by constructing from 5 floats and reading them back via friend-free means --
+// lrep(E1..E5) ctor is public, and lrep_to_params/params_to_lrep are the only readers, so the
+// shim reports lrep_to_params(result) (5 floats: ax, ay, rho, tx, ty).
+void ref_lrep_op(int op, const float *a, const float *b, float x, float y, float *out_pdfparams)
+{
+	djb::beckmann::lrep A(a[0], a[1], a[2], a[3], a[4]);
+	djb::beckmann::lrep B = b ? djb::beckmann::lrep(b[0], b[1], b[2], b[3], b[4]) : djb::beckmann::lrep();
+	djb::beckmann::lrep R;
+	switch (op) {
+	case 0: R = A + B; break;
+	case 1: R = A * x; break;
+	case 2: A += B; R = A; break;
+	case 3: A *= x; R = A; break;
+	case 4: A.shear(x, y); R = A; break;
+	default: A.scale(x, y); R = A; break;
+	}
+	djb::microfacet::params p;
+	djb::beckmann::lrep_to_params(R, &p);
+	p.get_pdfparams(&out_pdfparams[0], &out_pdfparams[1], &out_pdfparams[2], &out_pdfparams[3], &out_pdfparams[4]);
+}
+
+// params -> lrep -> params (hdr:1965-1990): out = pdfparams of lrep_to_params(params_to_lrep(p))
+void ref_params_lrep_roundtrip(const shim_params *sp, float *out_pdfparams)
+{
+	param_holder ph(sp);
+	djb::microfacet::params p = ph.ptr ? ph.p : djb::microfacet::params::standard();
+	djb::beckmann::lrep l;
+	djb::beckmann::params_to_lrep(p, &l);
+	djb::microfacet::params q;
+	djb::beckmann::lrep_to_params(l, &q);
+	q.get_pdfparams(&out_pdfparams[0], &out_pdfparams[1], &out_pdfparams[2], &out_pdfparams[3], &out_pdfparams[4]);
+}
+
+// what dj_beckmannconductor does per hit (mitsuba/dj_beckmannconductor.cpp:291-319, without the
+// texture fetch): base params -> lrep1; lrep1 *= scale; params = lrep_to_params(lrep1 + lrep2);
+// then evalp / pdf with those per-pair params.  lean: n x 5 raw moments (E1..E5) of lrep2.
+// op: 0 eval, 1 evalp (n x 3), 2 pdf (n)
+void ref_eval_lean(void *b_, int op, long n, const float *i, const float *o, const shim_params *base,
+                   float scale, const float *lean, float *out, float *out_pdfparams)
+{
+	const djb::brdf *b = (const djb::brdf *)b_;
+	param_holder ph(base);
+	djb::microfacet::params p0 = ph.ptr ? ph.p : djb::microfacet::params::standard();
+	for (long k = 0; k < n; ++k) {
+		djb::beckmann::lrep l1, l2(lean[5*k], lean[5*k+1], lean[5*k+2], lean[5*k+3], lean[5*k+4]);
+		djb::beckmann::params_to_lrep(p0, &l1);
+		l1 *= scale;
+		djb::microfacet::params p;
+		djb::beckmann::lrep_to_params(l1 + l2, &p);
+		if (out_pdfparams)
+			p.get_pdfparams(&out_pdfparams[5*k], &out_pdfparams[5*k+1], &out_pdfparams[5*k+2],
+			                &out_pdfparams[5*k+3], &out_pdfparams[5*k+4]);
+		djb::vec3 vi = ld(i, k), vo = ld(o, k);
+		if (op == 0)      st(out, k, b->eval(vi, vo, &p));
+		else if (op == 1) st(out, k, b->evalp(vi, vo, &p));
+		else              out[k] = b->pdf(vi, vo, &p);
+	}
+}
+
 // ---- tabular (hdr:394-425) ---------------------------------------------------
 // which: 0 p22v 1 sigmav 2 cdfv 3 qfv 4 fresnel points (3 floats each). Returns count.
 int ref_tabular_get(void *t_, int which, float *out)

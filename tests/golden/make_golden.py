@@ -80,6 +80,25 @@ def main():
             out[f"{kind}_fit_{k}"] = np.atleast_1d(v)
     np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
 
+    # ---- beckmann::lrep algebra and the per-hit LEAN path of dj_beckmannconductor
+    from golden_cases import LEAN_BASE, LEAN_SCALE, N_LEAN, lean_moments, lrep_cases
+    out = {}
+    for k, (op, a, b, x, y) in enumerate(lrep_cases()):
+        out[f"lrep{k}"] = R.lrep_op(op, a, b, x, y)
+    for k, p in enumerate(PARAM_CASES):
+        out[f"roundtrip{k}"] = R.params_lrep_roundtrip(p)
+    i = synth.directions_aos(N_LEAN, synth.SEED_I, start=30000)
+    o = synth.directions_aos(N_LEAN, synth.SEED_O, start=30000)
+    lean = lean_moments(N_LEAN)
+    out.update(i=i, o=o, lean=lean)
+    for ndf in ("beckmann", "ggx"):
+        b = R.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
+        for op in ("eval", "evalp", "pdf"):
+            val, pp = R.eval_lean(b, i, o, LEAN_BASE, LEAN_SCALE, lean, op)
+            out[f"{ndf}_{op}"] = val
+        out["pdfparams"] = pp
+    np.savez_compressed(os.path.join(HERE, "lean.npz"), **out)
+
     # ---- MERL lookup (hash-filled table: exact on any machine)
     tmp = tempfile.mkdtemp(prefix="djb_golden_")
     try:

@@ -47,3 +47,29 @@ PARAMS_TXT_MATERIALS = [
 # sgd / abc materials replayed from the reference (both tables carry these names)
 N_MODEL = 768
 MODEL_MATERIALS = ["gold-metallic-paint", "alum-bronze", "black-fabric", "chrome", "white-marble", "yellow-plastic"]
+
+# beckmann::lrep / LEAN: base lobe + scale as dj_beckmannconductor uses them, synthetic moment records
+N_LEAN = 2048
+LEAN_BASE = ("elliptic", 0.1, 0.3, 0.4)
+LEAN_SCALE = 0.7
+
+
+def lean_moments(n):
+    """n x 5 slope-moment records (E1, E2, E3, E4, E5) with valid (co)variances, from the hash RNG."""
+    from dj_brdf_amd import synth
+    u = [synth.uniforms(n, 0xB0B0 + k) for k in range(5)]
+    f = np.float32
+    E1, E2 = (u[0] - f(0.5)) * f(0.4), (u[1] - f(0.5)) * f(0.4)
+    return np.stack([E1, E2, E1 * E1 + f(0.002) + f(0.1) * u[2], E2 * E2 + f(0.002) + f(0.1) * u[3],
+                     E1 * E2 + (u[4] - f(0.5)) * f(0.01)], axis=1).astype(np.float32)
+
+
+def lrep_cases():
+    """(op, a[5], b[5], x, y) tuples covering every lrep operator (dj_brdf.h:1992-2051)."""
+    m = lean_moments(64)
+    cases = []
+    for k in range(0, 60, 2):
+        x, y = float(0.25 + 0.05 * k), float(1.5 - 0.02 * k)
+        for op in ("add", "mul", "iadd", "imul", "shear", "scale"):
+            cases.append((op, m[k], m[k + 1], x, y))
+    return cases

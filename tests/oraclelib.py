@@ -118,6 +118,42 @@ class CheckerLib:
         p = np.array(param_tables.abc_params(name), dtype=np.float64)
         return C.c_void_p(self._fn("create_abc")(_ptr(p)))
 
+    # ---- beckmann::lrep (LEAN / LEADR moments)
+    def lrep_op(self, op: str, a, b=None, x=0.0, y=0.0):
+        """pdfparams (ax, ay, rho, tx, ty) of lrep_to_params(op(a, b | x, y))."""
+        code = {"add": 0, "mul": 1, "iadd": 2, "imul": 3, "shear": 4, "scale": 5}[op]
+        a = _f32(a); out = np.zeros(5, np.float32)
+        bp = _ptr(_f32(b)) if b is not None else None
+        self._fn("lrep_op")(C.c_int(code), _ptr(a), bp, C.c_float(x), C.c_float(y), _ptr(out))
+        return out
+
+    def params_lrep_roundtrip(self, params):
+        out = np.zeros(5, np.float32)
+        pd = param_desc(params)
+        self._fn("params_lrep_roundtrip")(C.byref(pd), _ptr(out))
+        return out
+
+    def eval_lean(self, b, i, o, base, scale, lean, op="eval"):
+        """dj_beckmannconductor's per-hit path: params = lrep_to_params(lrep(base)*scale + lean_k)."""
+        i, o, lean = _f32(i), _f32(o), _f32(lean)
+        n = i.shape[0]
+        opc = {"eval": 0, "evalp": 1, "pdf": 2}[op]
+        out = np.empty((n,) if opc == 2 else (n, 3), dtype=np.float32)
+        pp = np.empty((n, 5), dtype=np.float32)
+        pd = param_desc(base)
+        self._fn("eval_lean")(b, C.c_int(opc), C.c_int64(n), _ptr(i), _ptr(o), C.byref(pd), C.c_float(scale),
+                              _ptr(lean), _ptr(out), _ptr(pp))
+        return out, pp
+
+    def eval_pp(self, b, i, o, pp, op="eval"):
+        assert self.prefix == "o_"
+        i, o, pp = _f32(i), _f32(o), _f32(pp)
+        n = i.shape[0]
+        opc = {"eval": 0, "evalp": 1, "pdf": 2}[op]
+        out = np.empty((n,) if opc == 2 else (n, 3), dtype=np.float32)
+        self._fn("eval_pp")(b, C.c_int(opc), C.c_int64(n), _ptr(i), _ptr(o), _ptr(pp), _ptr(out))
+        return out
+
     def tabular(self, src, res: int, shadow=True):
         h = self._fn("create_tabular")(src, C.c_int(res), C.c_int(int(shadow)))
         if not h:

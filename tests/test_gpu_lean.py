@@ -1,0 +1,64 @@
+"""beckmann::lrep + per-pair params: the batched form of what
+dj_beckmannconductor does per hit, against golden vectors from the real reference."""
+import os
+
+import numpy as np
+import pytest
+
+from dj_brdf_amd import djb
+from golden_cases import LEAN_BASE, LEAN_SCALE, PARAM_CASES, lrep_cases
+from test_gpu_parity import assert_close, mk_params
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+OPS = {"add": lambda a, b, x, y: a + b, "mul": lambda a, b, x, y: a * x}
+
+
+def _lrep(m):
+    return djb.beckmann.lrep(*[float(v) for v in m])
+
+
+def test_lrep_algebra_matches_reference():
+    g = np.load(os.path.join(G, "lean.npz"))
+    for k, (op, a, b, x, y) in enumerate(lrep_cases()):
+        A, B = _lrep(a), _lrep(b)
+        if op == "add": R = A + B
+        elif op == "mul": R = A * x
+        elif op == "iadd": A += B; R = A
+        elif op == "imul": A *= x; R = A
+        elif op == "shear": A.shear(x, y); R = A
+        else: A.scale(x, y); R = A
+        got = np.array(djb.beckmann.lrep_to_params(R).get_pdfparams(), np.float32)
+        assert np.array_equal(got.view(np.uint32), g[f"lrep{k}"].view(np.uint32)), (k, op, got, g[f"lrep{k}"])
+    for k, p in enumerate(PARAM_CASES):
+        mp = mk_params(p) or djb.microfacet.params.standard()
+        got = np.array(djb.beckmann.lrep_to_params(djb.beckmann.params_to_lrep(mp)).get_pdfparams(), np.float32)
+        assert np.array_equal(got.view(np.uint32), g[f"roundtrip{k}"].view(np.uint32)), p
+    with pytest.raises(djb.exc):
+        djb.beckmann.lrep() * -1.0          # DJB_ASSERT(sc >= 0), dj_brdf.h:2003
+
+
+@pytest.mark.parametrize("ndf", ["beckmann", "ggx"])
+def test_lean_eval_golden(gpu_ctx, ndf):
+    g = np.load(os.path.join(G, "lean.npz"))
+    b = getattr(djb, ndf)(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    base = mk_params(LEAN_BASE)
+    for op in ("eval", "evalp", "pdf"):
+        val, pp = b.eval_lean(g["i"], g["o"], base, LEAN_SCALE, g["lean"], want=op, return_params=True)
+        assert np.array_equal(pp.view(np.uint32), g["pdfparams"].view(np.uint32)), "resolved per-pair params differ"
+        ex = assert_close(f"{ndf}/lean/{op}", val, g[f"{ndf}_{op}"])
+        assert ex > 0.9999
+        assert_close(f"{ndf}/pp/{op}", b.eval_pp(g["i"], g["o"], g["pdfparams"], want=op), g[f"{ndf}_{op}"])
+    fr, pdf = b.eval_lean(g["i"], g["o"], base, LEAN_SCALE, g["lean"], want="evalp+pdf")
+    assert_close("fused evalp", fr, g[f"{ndf}_evalp"]); assert_close("fused pdf", pdf, g[f"{ndf}_pdf"])
+
+
+def test_lean_device_tensors(gpu_ctx):
+    import torch
+    g = np.load(os.path.join(G, "lean.npz"))
+    b = djb.beckmann(ctx=gpu_ctx)
+    ti = torch.from_numpy(g["i"].T.copy()).cuda(); to = torch.from_numpy(g["o"].T.copy()).cuda()
+    tl = torch.from_numpy(g["lean"]).cuda()
+    dev = b.eval_lean(ti, to, mk_params(LEAN_BASE), LEAN_SCALE, tl, want="evalp")
+    host = b.eval_lean(g["i"], g["o"], mk_params(LEAN_BASE), LEAN_SCALE, g["lean"], want="evalp")
+    assert np.array_equal(dev.cpu().numpy().T.view(np.uint32), host.view(np.uint32))

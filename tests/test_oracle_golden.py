@@ -141,3 +141,18 @@ def test_parameter_tables_complete():
     assert set(synth.MERL_NAMES) <= set(param_tables.sgd_names())
     assert len(param_tables.sgd_params("gold-metallic-paint")) == 33
     assert param_tables.sgd_params("fabric-beige") == param_tables.sgd_params("beige-fabric")   # alias
+
+
+def test_lrep_and_lean_path(oracle):
+    from golden_cases import LEAN_BASE, LEAN_SCALE, lrep_cases
+    g = np.load(os.path.join(G, "lean.npz"))
+    for k, (op, a, b, x, y) in enumerate(lrep_cases()):
+        assert same(oracle.lrep_op(op, a, b, x, y), g[f"lrep{k}"]), (k, op)
+    for k, p in enumerate(PARAM_CASES):
+        assert same(oracle.params_lrep_roundtrip(p), g[f"roundtrip{k}"]), p
+    for ndf in ("beckmann", "ggx"):
+        b = oracle.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
+        for op in ("eval", "evalp", "pdf"):
+            val, pp = oracle.eval_lean(b, g["i"], g["o"], LEAN_BASE, LEAN_SCALE, g["lean"], op)
+            assert same(val, g[f"{ndf}_{op}"]) and same(pp, g["pdfparams"]), (ndf, op)
+            assert same(oracle.eval_pp(b, g["i"], g["o"], g["pdfparams"], op), g[f"{ndf}_{op}"])

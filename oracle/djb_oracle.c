@@ -186,6 +186,10 @@ struct o_brdf {
 	int n_p22, n_sigma, n_cdf, n_qf;
 	/* merl / utia */
 	double model[36];      /* sgd / abc parameter row */
+	/* tabular_anisotropic: grids are elev x azim, element (i_elev, j_azim) at [i + elev*j] */
+	int elev, azim;
+	float *a_p22, *a_sigma, *a_pdf1, *a_cdf1, *a_qf1, *a_pdf2, *a_cdf2, *a_qf2;
+	int n_a_pdf1, n_a_cdf1, n_a_qf1, n_a_pdf2, n_a_cdf2, n_a_qf2;
 	double *samples;
 	int64_t n_samples;
 };
@@ -417,10 +421,72 @@ static float ggx_qf3_radial(float u, float qf2)
 	return S * alpha * (p / q);
 }
 
-static int supports_smith_vndf(const o_brdf *b) { return b->kind != O_BRDF_TABULAR; }
+static int supports_smith_vndf(const o_brdf *b) { return b->kind != O_BRDF_TABULAR && b->kind != O_BRDF_TABULAR_ANISO; }
+
+/* ------------------------------------------------------------------ tabular_anisotropic fetches */
+static int uwrap_repeat(int i, int edge) { while (i >= edge) i -= edge; while (i < 0) i += edge; return i; } /* hdr:1183 */
+
+/* spline::eval with uwrap_repeat (hdr:1207-1218) */
+static float spline_eval_rep(const float *pts, int n, float u)
+{
+	double ip; float fr = F(modf(D(u * (float)n - u), &ip));
+	int i1 = uwrap_repeat((int)ip, n), i2 = uwrap_repeat((int)ip + 1, n);
+	return pts[i1] + fr * (pts[i2] - pts[i1]);
+}
+/* spline::eval2d(points, w, h, uwrap_edge, u1, uwrap_repeat, u2) (hdr:1220-1247) */
+static float spline_eval2d(const float *pts, int w, int h, float u1, float u2)
+{
+	double ip1, ip2;
+	float f1 = F(modf(D(u1 * (float)w - u1), &ip1));
+	int i1 = uwrap_edge((int)ip1, w), i2 = uwrap_edge((int)ip1 + 1, w);
+	float f2 = F(modf(D(u2 * (float)h - u2), &ip2));
+	int j1 = uwrap_repeat((int)ip2, h), j2 = uwrap_repeat((int)ip2 + 1, h);
+	float p1 = pts[i1 + w * j1], p2 = pts[i2 + w * j1], p3 = pts[i1 + w * j2], p4 = pts[i2 + w * j2];
+	float t1 = p1 + f1 * (p2 - p1), t2 = p3 + f1 * (p4 - p3);
+	return t1 + f2 * (t2 - t1);
+}
+static float aniso_grid(const o_brdf *b, const float *tab, float theta, float phi) /* hdr:2185-2196 */
+{
+	if (D(phi) < 0.0) phi = F(D(phi) + 2.0 * O_PI);
+	float u1 = F(D(theta) * 2.0 / O_PI), u2 = F(D(phi) * 0.5 / O_PI);
+	return spline_eval2d(tab, b->elev, b->azim, u1, u2);
+}
+static float aniso_p22_theta_phi(const o_brdf *b, float theta, float phi) { return aniso_grid(b, b->a_p22, theta, phi); }
+static float aniso_p22_std(const o_brdf *b, float x, float y) /* hdr:2178-2183 */
+{
+	float theta = F(atan(sqrt(D(x * x + y * y))));
+	float phi = F(atan2(D(-y), D(-x)));
+	return aniso_p22_theta_phi(b, theta, phi);
+}
+static float aniso_sigma_std(const o_brdf *b, o_vec3 k) /* hdr:2198-2211 */
+{
+	return aniso_grid(b, b->a_sigma, F(acos(D(k.z))), F(atan2(D(k.y), D(k.x))));
+}
+static float aniso_pdf1(const o_brdf *b, float phi) { return spline_eval_rep(b->a_pdf1, b->n_a_pdf1, F(D(phi) * 0.5 / O_PI)); } /* hdr:2768 */
+static float aniso_cdf1(const o_brdf *b, float phi) { return spline_eval_rep(b->a_cdf1, b->n_a_cdf1, F(D(phi) * 0.5 / O_PI)); }
+static float aniso_qf1(const o_brdf *b, float u1) { return F(D(spline_eval_f(b->a_qf1, b->n_a_qf1, u1)) * 2.0 * O_PI); } /* hdr:2780 */
+static float aniso_pdf2(const o_brdf *b, float theta, float phi) /* hdr:2786-2798 */
+{
+	if (D(theta) >= 0.5 * O_PI) return 0.0f;
+	return spline_eval2d(b->a_pdf2, b->elev, b->azim, F(D(theta) * 2.0 / O_PI), F(D(phi) * 0.5 / O_PI));
+}
+static float aniso_cdf2(const o_brdf *b, float theta, float phi) /* hdr:2800-2812 */
+{
+	if (D(theta) >= 0.5 * O_PI) return 1.0f;
+	return spline_eval2d(b->a_cdf2, b->elev, b->azim, F(D(theta) * 2.0 / O_PI), F(D(phi) * 0.5 / O_PI));
+}
+static float aniso_qf2(const o_brdf *b, float u, float phi) /* hdr:2814-2824 */
+{
+	float u1 = F(D(phi) / (2.0 * O_PI));
+	return F(D(spline_eval2d(b->a_qf2, b->elev, b->azim, u, u1)) * 0.5 * O_PI);
+}
 
 /* ------------------------------------------------------------------ microfacet (hdr:1529-1765) */
-static float mf_p22_std(const o_brdf *b, float x, float y) { return p22_radial(b, x * x + y * y); }
+static float mf_p22_std(const o_brdf *b, float x, float y)
+{
+	if (b->kind == O_BRDF_TABULAR_ANISO) return aniso_p22_std(b, x, y);
+	return p22_radial(b, x * x + y * y);
+}
 
 static float mf_p22(const o_brdf *b, float x, float y, const o_params *p) /* hdr:1574-1587 */
 {
@@ -450,6 +516,7 @@ static float mf_sigma(const o_brdf *b, o_vec3 k, const o_params *p) /* hdr:1619-
 	float c = k.z - k.x * p->tx - k.y * p->ty;
 	float nrm = F(sqrt(D(a * a + bb * bb + c * c)));
 	o_vec3 kn = v3_div(v3(a, bb, c), nrm);
+	if (b->kind == O_BRDF_TABULAR_ANISO) return nrm * aniso_sigma_std(b, kn);
 	return nrm * sigma_std_radial(b, kn.z);
 }
 
@@ -539,6 +606,12 @@ static void mf_sample_vp22_std(const o_brdf *b, float u1, float u2, o_vec3 k, fl
 			*xs = cp * tx - sp * ty;
 			*ys = sp * tx + cp * ty;
 		}
+	} else if (b->kind == O_BRDF_TABULAR_ANISO) { /* hdr:2828-2839 */
+		float phi = aniso_qf1(b, u1);
+		float theta = aniso_qf2(b, u2, phi);
+		float tan_theta = F(tan(D(theta)));
+		*xs = F(D(-tan_theta) * cos(D(phi)));
+		*ys = F(D(-tan_theta) * sin(D(phi)));
 	} else {
 		float phi_h = F(D(u1) * O_PI * 2.0);
 		float r_h = qf_radial(b, u2);
@@ -740,7 +813,7 @@ static o_vec3 abc_eval(const o_brdf *b, o_vec3 i, o_vec3 o) /* hdr:3633-3645 */
 }
 
 /* ------------------------------------------------------------------ generic dispatch */
-static int is_microfacet(const o_brdf *b) { return b->kind <= O_BRDF_TABULAR; }
+static int is_microfacet(const o_brdf *b) { return b->kind <= O_BRDF_TABULAR || b->kind == O_BRDF_TABULAR_ANISO; }
 
 static o_vec3 brdf_eval(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p)
 {
@@ -967,6 +1040,331 @@ o_brdf *o_create_tabular(const o_brdf *src, int res, int shadow) /* hdr:2215-223
 	tab_compute_cdf(t);
 	tab_compute_qf(t);
 	return t;
+}
+
+/* ------------------------------------------------------------------ tabular_anisotropic fitter */
+typedef struct { float *v; int n, cap; } fvec;
+static void fv_push(fvec *f, float x)
+{
+	if (f->n == f->cap) { f->cap = f->cap ? 2 * f->cap : 64; f->v = (float *)realloc(f->v, sizeof(float) * f->cap); }
+	f->v[f->n++] = x;
+}
+
+static void aniso_compute_p22_smith(o_brdf *t, const o_brdf *src) /* hdr:2525-2579 */
+{
+	int w = t->elev - 1, h = t->azim, N = w * h;
+	float dtheta = F(sqrt(O_PI * 0.5) / D((float)w)), dphi = F(2.0 * O_PI / D((float)h));
+	o_params std_p = params_standard();
+	float *k1 = (float *)malloc(sizeof(float) * N), *xo = (float *)malloc(sizeof(float) * N),
+	      *yo = (float *)malloc(sizeof(float) * N), *zo = (float *)malloc(sizeof(float) * N),
+	      *s1 = (float *)malloc(sizeof(float) * N), *s2 = (float *)malloc(sizeof(float) * N),
+	      *tn = (float *)malloc(sizeof(float) * N), *dn = (float *)malloc(sizeof(float) * N);
+	for (int i2 = 0; i2 < h; ++i2) for (int i1 = 0; i1 < w; ++i1) {
+		int a = i2 * w + i1;
+		float theta = F(D((float)i1 / (float)w) * 0.5 * O_PI), phi = F(D((float)i2 / (float)h) * 2.0 * O_PI);
+		float st = F(sin(D(theta)));
+		zo[a] = F(cos(D(theta))); xo[a] = F(D(st) * cos(D(phi))); yo[a] = F(D(st) * sin(D(phi)));
+		o_vec3 wv = v3_from_angles(theta, phi);
+		float fr_i = v3_intensity(brdf_eval(src, wv, wv, &std_p));
+		k1[a] = F(D(dtheta * dphi) * (4.0 * D(fr_i) * pow(D(zo[a]), D(5.0f))));
+		float ct = F(cos(D(theta))), tt = F(tan(D(theta)));
+		tn[a] = tt; dn[a] = ct * ct;
+		s1[a] = F(D(-tt) * cos(D(phi))); s2[a] = F(D(-tt) * sin(D(phi)));
+	}
+	/* eigenvector(4): out[a] = sum_b double(float(k1[a] * k2(a, b))) * v[b], b ascending (hdr:2455-2480) */
+	double *v0 = (double *)malloc(sizeof(double) * N), *v1 = (double *)malloc(sizeof(double) * N);
+	for (int a = 0; a < N; ++a) v0[a] = 1.0;
+	for (int it = 0; it < 4; ++it) {
+		for (int a = 0; a < N; ++a) {
+			double acc = 0;
+			for (int b = 0; b < N; ++b) {
+				float m_dot_o = zo[a] - xo[a] * s1[b] - yo[a] * s2[b];
+				float k2 = tn[b] * fmaxf_(0.0f, m_dot_o) / dn[b];
+				acc += D(k1[a] * k2) * v0[b];
+			}
+			v1[a] = acc;
+		}
+		double *sw = v0; v0 = v1; v1 = sw;
+	}
+	t->a_p22 = (float *)malloc(sizeof(float) * t->elev * t->azim);
+	for (int j = 0; j < h; ++j) {
+		for (int i = 0; i < w; ++i) t->a_p22[i + t->elev * j] = F(v0[j * w + i]);
+		t->a_p22[w + t->elev * j] = 0.0f;
+	}
+	free(k1); free(xo); free(yo); free(zo); free(s1); free(s2); free(tn); free(dn); free(v0); free(v1);
+}
+
+static void aniso_normalize_p22(o_brdf *t) /* hdr:2306-2338 */
+{
+	const int ntheta = 128, nphi = 256;
+	float dtheta = F(sqrt(0.5 * O_PI) / D((float)ntheta)), dphi = F(2.0 * O_PI / D((float)nphi));
+	float k = 0.0f;
+	for (int j = 0; j < nphi; ++j) {
+		float phi = F(D((float)j / (float)nphi) * 2.0 * O_PI);
+		for (int i = 0; i < ntheta; ++i) {
+			float theta = F(D((float)i / (float)ntheta) * sqrt(O_PI * 0.5));
+			float ts = theta * theta;
+			float c = F(cos(D(ts)));
+			float pdf = aniso_p22_theta_phi(t, ts, phi);
+			float weight = F(D(theta) * tan(D(ts)) / D(c * c));
+			k += weight * pdf;
+		}
+	}
+	k = F(D(k) * (2.0 * D(dtheta) * D(dphi)));
+	k = F(1.0 / D(k));
+	for (int i = 0; i < t->elev * t->azim; ++i) t->a_p22[i] *= k;
+}
+
+static void aniso_compute_sigma(o_brdf *t) /* hdr:2388-2432 */
+{
+	const int ntheta = 45, nphi = 90;
+	float dtheta = F(sqrt(O_PI * 0.5) / D((float)ntheta)), dphi = F(2.0 * O_PI / D((float)nphi));
+	int w = t->elev - 1, h = t->azim;
+	o_params std_p = params_standard();
+	float *ndf_tab = (float *)malloc(sizeof(float) * ntheta * nphi);
+	for (int j2 = 0; j2 < nphi; ++j2) for (int j1 = 0; j1 < ntheta; ++j1) {
+		float phi = F(D((float)j2 / (float)nphi) * 2.0 * O_PI);
+		float theta = F(D((float)j1 / (float)ntheta) * sqrt(O_PI * 0.5));
+		ndf_tab[j2 * ntheta + j1] = mf_ndf(t, v3_from_angles(theta * theta, phi), &std_p);
+	}
+	t->a_sigma = (float *)malloc(sizeof(float) * t->elev * t->azim);
+	for (int i2 = 0; i2 < h; ++i2) {
+		float phi_k = F(D((float)i2 / (float)h) * 2.0 * O_PI);
+		for (int i1 = 0; i1 < w; ++i1) {
+			float theta_k = F(D((float)i1 / (float)w) * 0.5 * O_PI);
+			float cos_k = F(cos(D(theta_k)));
+			float nint = 0.0f;
+			for (int j2 = 0; j2 < nphi; ++j2) {
+				float phi = F(D((float)j2 / (float)nphi) * 2.0 * O_PI);
+				for (int j1 = 0; j1 < ntheta; ++j1) {
+					float theta = F(D((float)j1 / (float)ntheta) * sqrt(O_PI * 0.5));
+					float ts = theta * theta;
+					float sin_t = F(sin(D(ts)));
+					float m_dot_k = F(sin(D(theta_k)) * D(sin_t) * cos(D(phi - phi_k)) + D(cos_k) * cos(D(ts)));
+					float weight = theta * sin_t;
+					float masking = fmaxf_(0.0f, m_dot_k) * ndf_tab[j2 * ntheta + j1];
+					nint += weight * masking;
+				}
+			}
+			nint = F(D(nint) * (2.0 * D(dtheta) * D(dphi)));
+			t->a_sigma[i1 + t->elev * i2] = fmaxf_(cos_k, nint);
+		}
+		t->a_sigma[w + t->elev * i2] = t->a_sigma[w - 1 + t->elev * i2];
+	}
+	free(ndf_tab);
+}
+
+/* nint += (val * tan(theta)) / (cos_theta * cos_theta): val float, tan double, the sum in double,
+ * rounded to float on assignment (hdr:2866, 2965, 3078) */
+static float acc_tan_over_cos2(float nint, float val, float theta)
+{
+	float c = F(cos(D(theta)));
+	return F(D(nint) + (D(val) * tan(D(theta))) / D(c * c));
+}
+
+static void aniso_compute_pdf1(o_brdf *t) /* hdr:2849-2875 + normalize_pdf1 3038-3058 */
+{
+	const int ntheta = 256; int nphi = t->azim;
+	float dtheta = F(0.5 * O_PI / D((float)ntheta));
+	t->a_pdf1 = (float *)malloc(sizeof(float) * nphi); t->n_a_pdf1 = nphi;
+	for (int i = 0; i < nphi; ++i) {
+		float phi = F(D((float)i / (float)nphi) * 2.0 * O_PI);
+		float nint = 0.0f;
+		for (int j = 0; j < ntheta; ++j) {
+			float theta = F(D((float)j / (float)ntheta) * 0.5 * O_PI);
+			nint = acc_tan_over_cos2(nint, aniso_p22_theta_phi(t, theta, phi), theta);
+		}
+		t->a_pdf1[i] = nint * dtheta;
+	}
+	const int cnt = 512;
+	float dphi = F(2.0 * O_PI / D((float)cnt)), nint = 0.0f;
+	for (int i = 0; i < cnt; ++i) nint += aniso_pdf1(t, F(D((float)i / (float)cnt) * 2.0 * O_PI));
+	nint *= dphi;
+	float k = F(1.0 / D(nint));
+	for (int i = 0; i < nphi; ++i) t->a_pdf1[i] *= k;
+}
+
+static void aniso_compute_cdf1(o_brdf *t) /* hdr:2879-2901 */
+{
+	int cnt = t->azim - 1;
+	float dphi = F(2.0 * O_PI / D((float)cnt)), nint = 0.0f;
+	fvec f = { 0, 0, 0 };
+	fv_push(&f, 0.0f);
+	for (int i = 1; i < cnt; ++i) {
+		nint += aniso_pdf1(t, F(D((float)i / (float)cnt) * 2.0 * O_PI));
+		fv_push(&f, nint * dphi);
+	}
+	fv_push(&f, 1.0f);
+	t->a_cdf1 = f.v; t->n_a_cdf1 = f.n;
+}
+
+static void aniso_compute_qf1(o_brdf *t) /* hdr:2905-2936 */
+{
+	int cnt = t->n_a_cdf1 - 1, res = cnt * 8, j = 0;
+	fvec f = { 0, 0, 0 };
+	fv_push(&f, 0.0f);
+	for (int i = 1; i < cnt; ++i) {
+		float cdf = (float)i / (float)cnt;
+		for (; j < res; ++j) {
+			float u = (float)j / (float)res;
+			if (aniso_cdf1(t, F(D(u) * 2.0 * O_PI)) >= cdf) { fv_push(&f, u); break; }
+		}
+	}
+	fv_push(&f, 1.0f);
+	t->a_qf1 = f.v; t->n_a_qf1 = f.n;
+}
+
+static void aniso_compute_pdf2(o_brdf *t) /* hdr:2945-2970 + normalize_pdf2 3062-3094 */
+{
+	int ntheta = t->elev - 1, nphi = t->azim;
+	fvec f = { 0, 0, 0 };
+	for (int i = 0; i < nphi; ++i) {
+		float phi = F(D((float)i / (float)nphi) * 2.0 * O_PI);
+		for (int j = 0; j < ntheta; ++j) {
+			float theta = F(D((float)j / (float)ntheta) * 0.5 * O_PI);
+			fv_push(&f, aniso_p22_theta_phi(t, theta, phi) / aniso_pdf1(t, phi));
+		}
+		fv_push(&f, 0.0f);
+	}
+	t->a_pdf2 = f.v; t->n_a_pdf2 = f.n;
+	const int nt = 256;
+	float dtheta = F(0.5 * O_PI / D((float)nt));
+	float *k = (float *)malloc(sizeof(float) * nphi);
+	for (int j = 0; j < nphi; ++j) {
+		float phi = F(D((float)j / (float)nphi) * 2.0 * O_PI), nint = 0.0f;
+		for (int i = 0; i < nt; ++i) {
+			float theta = F(D((float)i / (float)nt) * 0.5 * O_PI);
+			nint = acc_tan_over_cos2(nint, aniso_pdf2(t, theta, phi), theta);
+		}
+		nint *= dtheta;
+		k[j] = F(1.0 / D(nint));
+	}
+	for (int j = 0; j < nphi; ++j) for (int i = 0; i < t->elev; ++i) t->a_pdf2[i + t->elev * j] *= k[j];
+	free(k);
+}
+
+static void aniso_compute_cdf2(o_brdf *t) /* hdr:2974-3001 */
+{
+	int ntheta = t->elev - 1, nphi = t->azim;
+	float dtheta = F(0.5 * O_PI / D((float)ntheta));
+	fvec f = { 0, 0, 0 };
+	for (int i = 0; i < nphi; ++i) {
+		float phi = F(D((float)i / (float)nphi) * 2.0 * O_PI), nint = 0.0f;
+		for (int j = 0; j < ntheta; ++j) {
+			float theta = F(D((float)j / (float)ntheta) * 0.5 * O_PI);
+			nint = acc_tan_over_cos2(nint, aniso_pdf2(t, theta, phi), theta);
+			fv_push(&f, nint * dtheta);
+		}
+		fv_push(&f, 1.0f);
+	}
+	t->a_cdf2 = f.v; t->n_a_cdf2 = f.n;
+}
+
+static void aniso_compute_qf2(o_brdf *t) /* hdr:3005-3034 */
+{
+	int ntheta = t->elev - 1, nphi = t->azim, res = ntheta * 8;
+	fvec f = { 0, 0, 0 };
+	for (int k = 0; k < nphi; ++k) {
+		float phi = F(D((float)k / (float)nphi) * 2.0 * O_PI);
+		int j = 0;
+		fv_push(&f, 0.0f);
+		for (int i = 1; i < ntheta; ++i) {
+			float cdf = (float)i / (float)ntheta;
+			for (; j < res; ++j) {
+				float u = (float)j / (float)res;
+				if (aniso_cdf2(t, F(D(u) * 0.5 * O_PI), phi) >= cdf) { fv_push(&f, u); break; }
+			}
+		}
+		fv_push(&f, 1.0f);
+	}
+	/* eval2d indexes the full elev x azim grid: pad if the scan came up short (never in practice) */
+	while (f.n < t->elev * t->azim) fv_push(&f, 1.0f);
+	t->a_qf2 = f.v; t->n_a_qf2 = f.n;
+}
+
+o_brdf *o_create_tabular_anisotropic(const o_brdf *src, int elev, int azim, int shadow) /* hdr:2238-2273 */
+{
+	if (elev <= 1 || azim <= 1) { set_err("Invalid Resolution"); return NULL; }
+	o_brdf *t = (o_brdf *)calloc(1, sizeof *t);
+	t->kind = O_BRDF_TABULAR_ANISO;
+	t->shadow = shadow != 0;
+	t->fresnel.kind = O_FRESNEL_IDEAL;
+	t->elev = elev; t->azim = azim;
+	aniso_compute_p22_smith(t, src);
+	aniso_normalize_p22(t);
+	aniso_compute_sigma(t);
+	tab_compute_fresnel(t, src, elev);         /* same loop as the isotropic class (hdr:2643-2701) */
+	aniso_compute_pdf1(t);
+	aniso_compute_cdf1(t);
+	aniso_compute_qf1(t);
+	aniso_compute_pdf2(t);
+	aniso_compute_cdf2(t);
+	aniso_compute_qf2(t);
+	return t;
+}
+
+int o_aniso_get(const o_brdf *t, int which, float *out)
+{
+	if (which == 4) {
+		if (t->fresnel.kind != O_FRESNEL_SPLINE) return 0;
+		if (out) memcpy(out, t->fresnel.pts, sizeof(float) * 3 * t->fresnel.npts);
+		return t->fresnel.npts;
+	}
+	const float *src = which == 0 ? t->a_p22 : t->a_sigma;
+	if (out) memcpy(out, src, sizeof(float) * t->elev * t->azim);
+	return t->elev * t->azim;
+}
+
+void o_aniso_query(const o_brdf *t, int which, int64_t n, const float *a, const float *b, float *out)
+{
+	for (int64_t k = 0; k < n; ++k) {
+		switch (which) {
+		case 0: out[k] = aniso_pdf1(t, a[k]); break;
+		case 1: out[k] = aniso_cdf1(t, a[k]); break;
+		case 2: out[k] = aniso_qf1(t, a[k]); break;
+		case 3: out[k] = aniso_pdf2(t, a[k], b[k]); break;
+		case 4: out[k] = aniso_cdf2(t, a[k], b[k]); break;
+		default: out[k] = aniso_qf2(t, a[k], b[k]); break;
+		}
+	}
+}
+
+void o_aniso_fit(const o_brdf *t, float *bk, float *gg) /* hdr:3186-3307 */
+{
+	const int ntheta = 128, nphi = 512;
+	float dtheta = F(sqrt(O_PI * 0.5) / D((float)ntheta)), dphi = F(2.0 * O_PI / D((float)nphi));
+	float nb[5] = { 0, 0, 0, 0, 0 }, ng[5] = { 0, 0, 0, 0, 0 };
+	for (int j = 0; j < nphi; ++j) {
+		float phi = F(D((float)j / (float)nphi) * 2.0 * O_PI);
+		float cp = F(cos(D(phi))), sp = F(sin(D(phi)));
+		float cp2 = cp * cp, sp2 = sp * sp;
+		for (int i = 0; i < ntheta; ++i) {
+			float theta = F(D((float)i / (float)ntheta) * sqrt(O_PI * 0.5));
+			float ts = theta * theta;
+			float p22 = aniso_p22_theta_phi(t, ts, phi);
+			float tt = F(tan(D(ts))), ct = F(cos(D(ts)));
+			float tt2 = tt * tt, ct2 = ct * ct;
+			float tmp2 = theta * p22 * tt / ct2;
+			float e1 = -tt * cp, e2 = -tt * sp;
+			nb[0] += tmp2 * e1; nb[1] += tmp2 * e2;
+			nb[2] += tmp2 * (tt2 * cp2); nb[3] += tmp2 * (tt2 * sp2); nb[4] += tmp2 * (tt2 * cp * sp);
+			ng[0] += tmp2 * e1; ng[1] += tmp2 * e2;
+			ng[2] += tmp2 * F(fabs(D(e1))); ng[3] += tmp2 * F(fabs(D(e2))); ng[4] += tmp2 * 0.0f;
+		}
+	}
+	for (int i = 0; i < 5; ++i) {
+		nb[i] = F(D(nb[i]) * (2.0 * D(dtheta) * D(dphi)));
+		ng[i] = F(D(ng[i]) * (2.0 * D(dtheta) * D(dphi)));
+	}
+	float mux = nb[0], muy = nb[1];
+	bk[0] = F(sqrt(D(2.0f * (nb[2] - mux * mux))));
+	bk[1] = F(sqrt(D(2.0f * (nb[3] - muy * muy))));
+	bk[2] = F(2.0 * D(nb[4] - mux * muy) / D(bk[0] * bk[1]));
+	bk[3] = mux; bk[4] = muy;
+	mux = ng[0]; muy = ng[1];
+	gg[0] = F(sqrt(D(ng[2] * ng[2] - mux * mux)));
+	gg[1] = F(sqrt(D(ng[3] * ng[3] - muy * muy)));
+	gg[2] = 0.0f; gg[3] = mux; gg[4] = muy;
 }
 
 void o_tabular_fit(const o_brdf *t, float *alpha_beckmann, float *alpha_ggx) /* hdr:3133-3184 */
@@ -1225,6 +1623,8 @@ void o_destroy(o_brdf *b)
 {
 	if (!b) return;
 	free(b->fresnel.pts); free(b->p22); free(b->sigma); free(b->cdf); free(b->qf);
+	free(b->a_p22); free(b->a_sigma); free(b->a_pdf1); free(b->a_cdf1); free(b->a_qf1);
+	free(b->a_pdf2); free(b->a_cdf2); free(b->a_qf2);
 	free(b->samples); free(b);
 }
 

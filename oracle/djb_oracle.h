@@ -51,7 +51,13 @@ enum { O_FRESNEL_IDEAL = 0, O_FRESNEL_UNPOLARIZED = 1, O_FRESNEL_SCHLICK = 2,
        O_FRESNEL_SGD = 3, O_FRESNEL_SPLINE = 4 };
 
 enum { O_BRDF_BECKMANN = 0, O_BRDF_GGX = 1, O_BRDF_TABULAR = 2, O_BRDF_MERL = 3,
-       O_BRDF_UTIA = 4, O_BRDF_LAMBERT = 5, O_BRDF_SGD = 6, O_BRDF_ABC = 7 };
+       O_BRDF_UTIA = 4, O_BRDF_LAMBERT = 5, O_BRDF_SGD = 6, O_BRDF_ABC = 7, O_BRDF_TABULAR_ANISO = 8 };
+
+/* djb::tabular_anisotropic(brdf, elevation_res, azimuthal_res, shadow) (hdr:428-478, 2238-2273) */
+struct o_brdf *o_create_tabular_anisotropic(const struct o_brdf *src, int elev, int azim, int shadow);
+int  o_aniso_get(const struct o_brdf *t, int which, float *out);            /* 0 p22v 1 sigmav 4 fresnel */
+void o_aniso_query(const struct o_brdf *t, int which, int64_t n, const float *a, const float *b, float *out);
+void o_aniso_fit(const struct o_brdf *t, float *beckmann5, float *ggx5);
 
 /* sgd: rhoD[3] rhoS[3] alpha[3] p[3] f0[3] f1[3] kap[3] lambda[3] c[3] k[3] theta0[3] (33 doubles);
  * abc: kD[3] A[3] B C ior (9 doubles) -- one row of the published tables (hdr:3312-3413, 3505-3606) */

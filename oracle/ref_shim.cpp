@@ -290,6 +290,51 @@ void ref_eval_lean(void *b_, int op, long n, const float *i, const float *o, con
 	}
 }
 
+// ---- tabular_anisotropic (hdr:428-478) ----------------------------------------
+void *ref_create_tabular_anisotropic(void *src, int elev, int azim, int shadow)
+{
+	SHIM_TRY(new djb::tabular_anisotropic(*(const djb::brdf *)src, elev, azim, shadow != 0))
+}
+// which: 0 p22v, 1 sigmav (elev*azim floats each); 4 fresnel points.  Returns count.
+int ref_aniso_get(void *t_, int which, float *out)
+{
+	const djb::tabular_anisotropic *t = dynamic_cast<const djb::tabular_anisotropic *>((const djb::brdf *)t_);
+	if (which == 4) {
+		const djb::fresnel::spline *s = dynamic_cast<const djb::fresnel::spline *>(&t->get_fresnel());
+		if (!s) return 0;
+		const std::vector<djb::vec3> &pts = s->get_points();
+		if (out) for (size_t i = 0; i < pts.size(); ++i) st(out, (long)i, pts[i]);
+		return (int)pts.size();
+	}
+	int e, a;
+	const std::vector<djb::float_t> &v = which == 0 ? t->get_p22v(&e, &a) : t->get_sigmav(&e, &a);
+	if (out) for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+	return (int)v.size();
+}
+// public sampling queries (hdr:450-455): which 0 pdf1(phi) 1 cdf1(phi) 2 qf1(u) 3 pdf2(theta,phi)
+// 4 cdf2(theta,phi) 5 qf2(u,phi)
+void ref_aniso_query(void *t_, int which, long n, const float *a, const float *b, float *out)
+{
+	const djb::tabular_anisotropic *t = dynamic_cast<const djb::tabular_anisotropic *>((const djb::brdf *)t_);
+	for (long k = 0; k < n; ++k) {
+		switch (which) {
+		case 0: out[k] = t->pdf1(a[k]); break;
+		case 1: out[k] = t->cdf1(a[k]); break;
+		case 2: out[k] = t->qf1(a[k]); break;
+		case 3: out[k] = t->pdf2(a[k], b[k]); break;
+		case 4: out[k] = t->cdf2(a[k], b[k]); break;
+		default: out[k] = t->qf2(a[k], b[k]); break;
+		}
+	}
+}
+// fits -> pdfparams (ax, ay, rho, tx, ty) of each (hdr:3186-3307)
+void ref_aniso_fit(void *t_, float *beckmann5, float *ggx5)
+{
+	const djb::tabular_anisotropic *t = dynamic_cast<const djb::tabular_anisotropic *>((const djb::brdf *)t_);
+	djb::tabular_anisotropic::fit_beckmann_parameters(*t).get_pdfparams(&beckmann5[0], &beckmann5[1], &beckmann5[2], &beckmann5[3], &beckmann5[4]);
+	djb::tabular_anisotropic::fit_ggx_parameters(*t).get_pdfparams(&ggx5[0], &ggx5[1], &ggx5[2], &ggx5[3], &ggx5[4]);
+}
+
 // ---- tabular (hdr:394-425) ---------------------------------------------------
 // which: 0 p22v 1 sigmav 2 cdfv 3 qfv 4 fresnel points (3 floats each). Returns count.
 int ref_tabular_get(void *t_, int which, float *out)

@@ -118,6 +118,38 @@ class CheckerLib:
         p = np.array(param_tables.abc_params(name), dtype=np.float64)
         return C.c_void_p(self._fn("create_abc")(_ptr(p)))
 
+    # ---- tabular_anisotropic
+    def tabular_anisotropic(self, src, elev: int, azim: int, shadow=True):
+        fn = self._fn("create_tabular_anisotropic")
+        fn.restype = C.c_void_p
+        h = fn(src, C.c_int(elev), C.c_int(azim), C.c_int(int(shadow)))
+        if not h:
+            raise RuntimeError(self._fn("last_error")().decode())
+        return C.c_void_p(h)
+
+    def aniso_tables(self, t):
+        get = self._fn("aniso_get"); get.restype = C.c_int
+        out = {}
+        for code, name in ((0, "p22"), (1, "sigma")):
+            n = get(t, C.c_int(code), None)
+            a = np.empty((n,), np.float32); get(t, C.c_int(code), _ptr(a)); out[name] = a
+        n = get(t, C.c_int(4), None)
+        a = np.empty((n, 3), np.float32)
+        if n:
+            get(t, C.c_int(4), _ptr(a))
+        out["fresnel"] = a
+        bk, gg = np.zeros(5, np.float32), np.zeros(5, np.float32)
+        self._fn("aniso_fit")(t, _ptr(bk), _ptr(gg))
+        out["fit_beckmann"], out["fit_ggx"] = bk, gg
+        return out
+
+    def aniso_query(self, t, which: str, a, b=None):
+        code = {"pdf1": 0, "cdf1": 1, "qf1": 2, "pdf2": 3, "cdf2": 4, "qf2": 5}[which]
+        a = _f32(a); b = _f32(b) if b is not None else a
+        out = np.empty((a.shape[0],), np.float32)
+        self._fn("aniso_query")(t, C.c_int(code), C.c_int64(a.shape[0]), _ptr(a), _ptr(b), _ptr(out))
+        return out
+
     # ---- beckmann::lrep (LEAN / LEADR moments)
     def lrep_op(self, op: str, a, b=None, x=0.0, y=0.0):
         """pdfparams (ax, ay, rho, tx, ty) of lrep_to_params(op(a, b | x, y))."""

@@ -40,12 +40,18 @@ struct Brdf {
 	const float4 *merl;                     // [1458000] pre-scaled float RGB(+pad); below-horizon -> 0
 	const float *utia;                      // [3*288*288] float(normalized double sample)
 	const double *model;                    // sgd: 33 doubles, abc: 9 doubles (one published table row)
+	// tabular_anisotropic: p22 / sigma above are elev x azim grids (element (i, j) at [i + elev*j]);
+	// two-level sampling tables below (dj_brdf.h:429-438)
+	const float *a_pdf1, *a_cdf1, *a_qf1, *a_pdf2, *a_cdf2, *a_qf2;
+	int elev, azim, n_a_cdf1, n_a_qf1;
 };
 
 struct View { float *x, *y, *z; long long stride; };
 
 enum { KIND_BECKMANN = 0, KIND_GGX = 1, KIND_TABULAR = 2, KIND_MERL = 3, KIND_UTIA = 4, KIND_LAMBERT = 5,
-       KIND_SGD = 6, KIND_ABC = 7 };
+       KIND_SGD = 6, KIND_ABC = 7, KIND_TABULAR_ANISO = 8 };
+// the two tabulated microfacet classes sample with the non-VNDF "nmap" scheme (supports_smith_vndf_sampling() == false)
+#define DJB_NMAP(K) ((K) == KIND_TABULAR || (K) == KIND_TABULAR_ANISO)
 enum { FR_IDEAL = 0, FR_UNPOLARIZED = 1, FR_SCHLICK = 2, FR_SGD = 3, FR_SPLINE = 4 };
 
 // ------------------------------------------------------------------ L0 helpers (dj_brdf.h:574-765)
@@ -284,6 +290,58 @@ DJB_DEV float tab_qf_radial(const Brdf &b, float u)                             
 	return F(tan(D(qf * F(DJB_PI) / 2.0f)));
 }
 
+// ------------------------------------------------------------------ tabular_anisotropic fetches
+DJB_DEV int uwrap_repeat(int i, int edge) { while (i >= edge) i -= edge; while (i < 0) i += edge; return i; }   // :1183
+DJB_DEV int uwrap_edge(int i, int edge) { return i >= edge ? edge - 1 : (i < 0 ? 0 : i); }                      // :1191
+DJB_DEV float spline_rep(const float *pts, int n, float u)                             // spline::eval, uwrap_repeat
+{
+	float t = u * (float)n - u, ip = truncf(t), fr = t - ip;
+	int k = (int)ip;
+	float p1 = pts[uwrap_repeat(k, n)], p2 = pts[uwrap_repeat(k + 1, n)];
+	return p1 + fr * (p2 - p1);
+}
+DJB_DEV float spline_2d(const float *pts, int w, int h, float u1, float u2)            // spline::eval2d, :1220
+{
+	float t1 = u1 * (float)w - u1, ip1 = truncf(t1), f1 = t1 - ip1;
+	float t2 = u2 * (float)h - u2, ip2 = truncf(t2), f2 = t2 - ip2;
+	int i1 = uwrap_edge((int)ip1, w), i2 = uwrap_edge((int)ip1 + 1, w);
+	int j1 = uwrap_repeat((int)ip2, h), j2 = uwrap_repeat((int)ip2 + 1, h);
+	float p1 = pts[i1 + w * j1], p2 = pts[i2 + w * j1], p3 = pts[i1 + w * j2], p4 = pts[i2 + w * j2];
+	float a = p1 + f1 * (p2 - p1), c = p3 + f1 * (p4 - p3);
+	return a + f2 * (c - a);
+}
+DJB_DEV float aniso_grid(const Brdf &b, const float *tab, float theta, float phi)      // :2185-2211
+{
+	if (D(phi) < 0.0) phi = F(D(phi) + 2.0 * DJB_PI);
+	return spline_2d(tab, b.elev, b.azim, F(D(theta) * 2.0 / DJB_PI), F(D(phi) * 0.5 / DJB_PI));
+}
+DJB_DEV float aniso_p22_theta_phi(const Brdf &b, float theta, float phi) { return aniso_grid(b, b.p22, theta, phi); }
+DJB_DEV float aniso_p22_std(const Brdf &b, float x, float y)                           // :2178
+{
+	return aniso_p22_theta_phi(b, F(atan(sqrt(D(x * x + y * y)))), F(atan2(D(-y), D(-x))));
+}
+DJB_DEV float aniso_sigma_std(const Brdf &b, v3 k)                                     // :2198
+{
+	return aniso_grid(b, b.sigma, F(acos(D(k.z))), F(atan2(D(k.y), D(k.x))));
+}
+DJB_DEV float aniso_pdf1(const Brdf &b, float phi) { return spline_rep(b.a_pdf1, b.azim, F(D(phi) * 0.5 / DJB_PI)); }       // :2768
+DJB_DEV float aniso_cdf1(const Brdf &b, float phi) { return spline_rep(b.a_cdf1, b.n_a_cdf1, F(D(phi) * 0.5 / DJB_PI)); }
+DJB_DEV float aniso_qf1(const Brdf &b, float u1) { return F(D(spline_f(b.a_qf1, b.n_a_qf1, u1)) * 2.0 * DJB_PI); }          // :2780
+DJB_DEV float aniso_pdf2(const Brdf &b, float theta, float phi)                        // :2786
+{
+	if (D(theta) >= 0.5 * DJB_PI) return 0.0f;
+	return spline_2d(b.a_pdf2, b.elev, b.azim, F(D(theta) * 2.0 / DJB_PI), F(D(phi) * 0.5 / DJB_PI));
+}
+DJB_DEV float aniso_cdf2(const Brdf &b, float theta, float phi)                        // :2800
+{
+	if (D(theta) >= 0.5 * DJB_PI) return 1.0f;
+	return spline_2d(b.a_cdf2, b.elev, b.azim, F(D(theta) * 2.0 / DJB_PI), F(D(phi) * 0.5 / DJB_PI));
+}
+DJB_DEV float aniso_qf2(const Brdf &b, float u, float phi)                             // :2814
+{
+	return F(D(spline_2d(b.a_qf2, b.elev, b.azim, u, F(D(phi) / (2.0 * DJB_PI)))) * 0.5 * DJB_PI);
+}
+
 // analytic cdf / quantile of the radial slope distribution (dj_brdf.h:1881-1889, 2067-2076)
 template <int KIND> DJB_DEV float cdf_radial(const Brdf &b, float r)
 {
@@ -377,6 +435,7 @@ template <int KIND> DJB_DEV float mf_p22(const Brdf &b, float x, float y, const 
 	float t1 = p.ax * y - p.rho * p.ay * x;
 	float t2 = p.ax * p.ay * p.s;
 	float y_ = t1 / t2;
+	if (KIND == KIND_TABULAR_ANISO) return aniso_p22_std(b, x_, y_) / nrm;
 	return p22_radial<KIND>(b, x_ * x_ + y_ * y_) / nrm;
 }
 
@@ -396,7 +455,9 @@ template <int KIND> DJB_DEV float mf_sigma(const Brdf &b, v3 k, const Params &p)
 	float bb = k.y * p.ay * p.s;
 	float c = k.z - k.x * p.tx - k.y * p.ty;
 	float nrm = sqrtf(a * a + bb * bb + c * c);
-	float kz = (1.0f / nrm) * c;
+	float rn = 1.0f / nrm;
+	if (KIND == KIND_TABULAR_ANISO) return nrm * aniso_sigma_std(b, mk(rn * a, rn * bb, rn * c));
+	float kz = rn * c;
 	return nrm * sigma_std_radial<KIND>(b, kz);
 }
 
@@ -441,7 +502,7 @@ DJB_DEV void mf_eval_pdf(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, flo
 		}
 		if (WANT & 4) {                                                                      // :1713-1730
 			float ih4 = dot(i, h);
-			if (KIND == KIND_TABULAR) pdf = fdiv4(h.z * Dn, ih4);
+			if (DJB_NMAP(KIND)) pdf = fdiv4(h.z * Dn, ih4);
 			else {
 				float vndf = D(oh) > 0.0 ? oh * Dn / sig_o : 0.0f;                           // :1602-1615
 				pdf = fdiv4(vndf, ih4);
@@ -454,7 +515,7 @@ DJB_DEV void mf_eval_pdf(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, flo
 template <int KIND>
 DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &xs, float &ys)
 {
-	if (KIND != KIND_TABULAR) {
+	if (!DJB_NMAP(KIND)) {
 		float cos_k = k.z;
 		float sin_k = D(k.z) < 1.0 ? F(sqrt(1.0 - D(k.z * k.z))) : 0.0f;
 		float tx, ty;
@@ -467,6 +528,12 @@ DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &
 			xs = cp * tx - sp * ty;
 			ys = sp * tx + cp * ty;
 		}
+	} else if (KIND == KIND_TABULAR_ANISO) {                                                    // :2828
+		float phi = aniso_qf1(b, u1);
+		float theta = aniso_qf2(b, u2, phi);
+		float tan_theta = F(tan(D(theta)));
+		xs = F(D(-tan_theta) * cos(D(phi)));
+		ys = F(D(-tan_theta) * sin(D(phi)));
 	} else {
 		float phi_h = F(D(u1) * DJB_PI * 2.0);
 		float r_h = tab_qf_radial(b, u2);
@@ -514,7 +581,7 @@ DJB_DEV v3 mf_evalp_is(const Brdf &b, const Params &p, float u1, float u2, v3 o,
 		i_out = i_;
 		float Dn = mf_ndf<KIND>(b, h, p);
 		v3 Fr = fresnel_eval(b.fr, cd);
-		if (KIND == KIND_TABULAR) {
+		if (DJB_NMAP(KIND)) {
 			float pdf_ = fdiv4(h.z * Dn, cd);
 			pdf_out = pdf_;
 			v3 e = scale(fdiv4(Dn * G, o.z), Fr);   // evalp(i_, o)

@@ -54,6 +54,10 @@ struct djb_brdf {
 	// tabular: host copies for the accessors
 	std::vector<float> p22, sigma, cdf, qf, fresnel;
 	float alpha_beckmann, alpha_ggx;
+	// tabular_anisotropic: host copies of the 8 tables (+ fresnel above) and the two 5-parameter fits
+	std::vector<float> aniso[8];
+	float aniso_fit[10];
+	int elev = 0, azim = 0;
 };
 
 namespace {
@@ -667,6 +671,105 @@ djb_status djb_brdf_create_tabular(djb_ctx *ctx, const djb_brdf *src, int res, i
 	return DJB_OK;
 }
 
+// djb::tabular_anisotropic(brdf, elevation_res, azimuthal_res, shadow), dj_brdf.h:2238-2273
+djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src, int elev, int azim,
+                                               int shadow, djb_brdf **out)
+{
+	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	if (elev <= 1 || azim <= 1 || elev > 1024 || azim > 1024)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");           // dj_brdf.h:2244
+	Params std_p;
+	if ((st = device_params(nullptr, &std_p)) != DJB_OK) return st;
+	const size_t E = elev, A = azim, w = E - 1, N = w * A, G = E * A;
+	// one HBM block: outputs first (they stay alive with the object), work arrays after
+	struct Carve { size_t off = 0; size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; } } cv;
+	size_t o_p22 = cv.take(4 * G), o_sig = cv.take(4 * G), o_pdf1 = cv.take(4 * A), o_cdf1 = cv.take(4 * A),
+	       o_qf1 = cv.take(4 * A), o_pdf2 = cv.take(4 * G), o_cdf2 = cv.take(4 * G), o_qf2 = cv.take(4 * G),
+	       o_fres = cv.take(12 * E), o_fit = cv.take(4 * 10), o_cnt = cv.take(4 * 4);
+	size_t o_f8[8]; for (int k = 0; k < 8; ++k) o_f8[k] = cv.take(4 * N);
+	size_t o_v0 = cv.take(8 * N), o_v1 = cv.take(8 * N), o_terms = cv.take(4 * djbk::aniso_terms_count()),
+	       o_ndf = cv.take(4 * djbk::aniso_ndf_count()), o_cosd = cv.take(8 * djbk::aniso_cosd_count(azim)),
+	       o_st = cv.take(4 * djbk::aniso_sig_nodes()), o_ss = cv.take(4 * djbk::aniso_sig_nodes()),
+	       o_sc = cv.take(8 * djbk::aniso_sig_nodes()), o_ratio = cv.take(12 * w * E),
+	       o_probes = cv.take(4 * A * 8 * w), o_rowk = cv.take(4 * A);
+	unsigned char *blk = nullptr;
+	HIP_TRY(hipMalloc((void **)&blk, cv.off));
+	hipError_t e = hipMemsetAsync(blk, 0, cv.off, ctx->stream);
+	djbk::AnisoScratch S;
+	S.elev = elev; S.azim = azim;
+	auto F4 = [&](size_t o) { return (float *)(blk + o); };
+	S.p22 = F4(o_p22); S.sigma = F4(o_sig); S.pdf1 = F4(o_pdf1); S.cdf1 = F4(o_cdf1); S.qf1 = F4(o_qf1);
+	S.pdf2 = F4(o_pdf2); S.cdf2 = F4(o_cdf2); S.qf2 = F4(o_qf2); S.fres = F4(o_fres); S.fit = F4(o_fit);
+	S.counts = (int *)(blk + o_cnt);
+	S.k1 = F4(o_f8[0]); S.xo = F4(o_f8[1]); S.yo = F4(o_f8[2]); S.zo = F4(o_f8[3]);
+	S.s1 = F4(o_f8[4]); S.s2 = F4(o_f8[5]); S.tn = F4(o_f8[6]); S.dn = F4(o_f8[7]);
+	S.v0 = (double *)(blk + o_v0); S.v1 = (double *)(blk + o_v1);
+	S.terms = F4(o_terms); S.ndf_tab = F4(o_ndf); S.cosd = (double *)(blk + o_cosd);
+	S.sig_theta = F4(o_st); S.sig_sin = F4(o_ss); S.sig_cosd = (double *)(blk + o_sc);
+	S.ratio = F4(o_ratio); S.probes = F4(o_probes); S.rowk = F4(o_rowk);
+	if (e == hipSuccess) e = djbk::launch_fit_aniso(ctx->stream, src->dev, std_p, S, shadow != 0);
+	djb_brdf *t;
+	alloc_brdf(ctx, DJB_KIND_TABULAR_ANISO, &t);
+	t->allocs.push_back(blk);
+	t->elev = elev; t->azim = azim;
+	const size_t sizes[8] = { G, G, A, A, A, G, G, G };
+	float *const srcs8[8] = { S.p22, S.sigma, S.pdf1, S.cdf1, S.qf1, S.pdf2, S.cdf2, S.qf2 };
+	for (int k = 0; k < 8 && e == hipSuccess; ++k) {
+		t->aniso[k].resize(sizes[k]);
+		e = hipMemcpyAsync(t->aniso[k].data(), srcs8[k], 4 * sizes[k], hipMemcpyDeviceToHost, ctx->stream);
+	}
+	t->fresnel.resize(3 * E);
+	int counts[4] = { 0, 0, 0, 0 };
+	if (e == hipSuccess) e = hipMemcpyAsync(t->fresnel.data(), S.fres, 12 * E, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(t->aniso_fit, S.fit, 40, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(counts, S.counts, 16, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess) { djb_brdf_destroy(t); return fail(DJB_ERR_HIP, "djb_error: anisotropic fit failed: %s", hipGetErrorString(e)); }
+	// counts[1] = azimuth rows whose conditional CDF could not be inverted for every quantile (the
+	// w-node CDF can stay below (w-1)/w for rough data).  The reference's m_qf2 then comes up short
+	// and every later row is misaligned (dj_brdf.h:3005-3034, reads past the vector); here such rows
+	// are padded with 1.0 and stay aligned -- a deliberate deviation, eval/pdf are unaffected.
+	t->aniso[4].resize(counts[0]);                      // m_qf1 may be shorter than azim (scan quirk)
+	Brdf &d = t->dev;
+	d.shadow = shadow != 0;
+	d.p22 = S.p22; d.sigma = S.sigma; d.n_p22 = d.n_sigma = (int)G;
+	d.a_pdf1 = S.pdf1; d.a_cdf1 = S.cdf1; d.a_qf1 = S.qf1; d.a_pdf2 = S.pdf2; d.a_cdf2 = S.cdf2; d.a_qf2 = S.qf2;
+	d.elev = elev; d.azim = azim; d.n_a_cdf1 = azim; d.n_a_qf1 = counts[0];
+	d.fr.kind = djbdev::FR_SPLINE; d.fr.pts = S.fres; d.fr.npts = elev;
+	*out = t;
+	return DJB_OK;
+}
+
+djb_status djb_tabular_anisotropic_get(const djb_brdf *tab, int which, float *outp, int *count, int *elev, int *azim)
+{
+	if (!tab || tab->dev.kind != DJB_KIND_TABULAR_ANISO)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular_anisotropic brdf");
+	if (elev) *elev = tab->elev;
+	if (azim) *azim = tab->azim;
+	const std::vector<float> *v;
+	if (which >= 0 && which < 8) v = &tab->aniso[which];
+	else if (which == DJB_ATAB_FRESNEL) v = &tab->fresnel;
+	else return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown table %d", which);
+	if (count) *count = (int)(which == DJB_ATAB_FRESNEL ? v->size() / 3 : v->size());
+	if (outp) memcpy(outp, v->data(), sizeof(float) * v->size());
+	return DJB_OK;
+}
+
+djb_status djb_tabular_anisotropic_fit(const djb_brdf *tab, djb_params *beckmann, djb_params *ggx)
+{
+	if (!tab || tab->dev.kind != DJB_KIND_TABULAR_ANISO)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular_anisotropic brdf");
+	for (int k = 0; k < 2; ++k) {
+		djb_params *p = k == 0 ? beckmann : ggx;
+		if (!p) continue;
+		p->kind = DJB_PARAMS_PDFPARAMS;
+		for (int c = 0; c < 5; ++c) p->v[c] = tab->aniso_fit[5 * k + c];
+	}
+	return DJB_OK;
+}
+
 djb_status djb_tabular_get(const djb_brdf *tab, int which, float *outp, int *count)
 {
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR)
@@ -837,10 +940,15 @@ djb_status djb_query_batch(djb_ctx *ctx, const djb_brdf *b, int which, int64_t n
                            const djb_vec3_view *out, int mem)
 {
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
-	if (b->dev.kind > DJB_KIND_TABULAR)
+	const bool aniso = b->dev.kind == DJB_KIND_TABULAR_ANISO;
+	if (b->dev.kind > DJB_KIND_TABULAR && !aniso)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: queries need a microfacet brdf");
-	if ((which >= DJB_Q_QF2_RADIAL && which <= DJB_Q_QF1) && b->dev.kind == DJB_KIND_TABULAR)
+	if ((which >= DJB_Q_QF2_RADIAL && which <= DJB_Q_QF1) && (b->dev.kind == DJB_KIND_TABULAR || aniso))
 		return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented");          // dj_brdf.h:1854, 1859
+	if ((which >= DJB_Q_P22_RADIAL && which <= DJB_Q_QF1) && aniso)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: tabular_anisotropic is not a radial microfacet");
+	if ((which >= DJB_Q_ANISO_PDF1 && which <= DJB_Q_ANISO_QF2) && !aniso)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: pdf1/cdf1/qf1/pdf2/cdf2/qf2 need a tabular_anisotropic");
 	djb_status st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
 	Params p;
@@ -943,7 +1051,7 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
                                  int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pp, int mem)
 {
 	if (!b || !rec) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
-	if (b->dev.kind > DJB_KIND_TABULAR)
+	if (b->dev.kind > DJB_KIND_TABULAR && b->dev.kind != DJB_KIND_TABULAR_ANISO)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need a microfacet brdf");
 	if (want != 1 && want != 2 && want != 4 && want != 5 && want != 6)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: want must be eval(1)|evalp(2) and/or pdf(4)");

@@ -70,4 +70,27 @@ hipError_t launch_fit(hipStream_t s, const Brdf *srcs, int src_kind, const Param
                       const FitOut &out);
 size_t fit_lds_bytes(int res);
 
+// ---- tabular_anisotropic (djb_kernels_fit_aniso.hip): all pointers are device memory
+struct AnisoScratch {
+	int elev, azim;
+	// outputs: grids are elev x azim, element (i_elev, j_azim) at [i + elev*j]
+	float *p22, *sigma, *pdf1, *cdf1, *qf1, *pdf2, *cdf2, *qf2, *fres /* 3*elev */, *fit /* 10 */;
+	int *counts;                               // [0] entries in qf1, [1] misaligned qf2 rows (must be 0)
+	// work arrays: N = (elev-1)*azim
+	float *k1, *xo, *yo, *zo, *s1, *s2, *tn, *dn;   // N each
+	double *v0, *v1;                                // N each
+	float *terms;                                   // aniso_terms_count()
+	float *ndf_tab;                                 // aniso_ndf_count()
+	double *cosd;                                   // aniso_cosd_count(azim)
+	float *sig_theta, *sig_sin; double *sig_cosd;   // aniso_sig_nodes() each
+	float *ratio;                                   // 3*(elev-1)*elev
+	float *probes;                                  // azim*8*(elev-1)
+	float *rowk;                                    // azim
+};
+size_t aniso_terms_count();
+size_t aniso_ndf_count();
+size_t aniso_cosd_count(int azim);
+size_t aniso_sig_nodes();
+hipError_t launch_fit_aniso(hipStream_t s, const Brdf &src, const Params &std_p, const AnisoScratch &S, int shadow);
+
 } // namespace djbk

@@ -24,7 +24,7 @@ inline int grid_for(long long n)
 template <int KIND, int WANT>
 DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float &pdf)
 {
-	if (KIND <= KIND_TABULAR) {
+	if (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
 		mf_eval_pdf<KIND, WANT>(b, p, i, o, fr, pdf);
 	} else {
 		if (WANT & 3) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 		float u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : u1a[k];
 		float u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : u2a[k];
 		v3 o = load3(vo, k);
-		if (KIND <= KIND_TABULAR) {
+		if (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
 			if (!IS) {
 				store3(vi_out, k, mf_sample<KIND>(b, p, u1, u2, o));
 			} else {
@@ -170,7 +170,8 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
 // ------------------------------------------------------------------ microfacet / radial queries
 // (dj_brdf.h:258-276, 307-314).  `which` is wave-uniform.
 enum { Q_NDF = 0, Q_GAF, Q_G1, Q_SIGMA, Q_P22, Q_VP22, Q_VNDF, Q_FRESNEL,
-       Q_P22_RADIAL = 16, Q_SIGMA_STD_RADIAL, Q_CDF_RADIAL, Q_QF_RADIAL, Q_QF2_RADIAL, Q_QF3_RADIAL, Q_QF1 };
+       Q_P22_RADIAL = 16, Q_SIGMA_STD_RADIAL, Q_CDF_RADIAL, Q_QF_RADIAL, Q_QF2_RADIAL, Q_QF3_RADIAL, Q_QF1,
+       Q_A_PDF1 = 32, Q_A_CDF1, Q_A_QF1, Q_A_PDF2, Q_A_CDF2, Q_A_QF2 };
 
 template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_query(Brdf b, Params p, int which, long long n, View va, View vb,
@@ -208,6 +209,13 @@ __global__ __launch_bounds__(BLOCK) void k_query(Brdf b, Params p, int which, lo
 		case Q_QF3_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x)
 		                       : KIND == KIND_GGX ? ggx_qf3_radial(a.x, a.y) : 0.0f; break;
 		case Q_QF1: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x) : KIND == KIND_GGX ? ggx_qf1(a.x) : 0.0f; break;
+		// tabular_anisotropic::{pdf1, cdf1, qf1, pdf2, cdf2, qf2} (dj_brdf.h:450-455)
+		case Q_A_PDF1: r.x = KIND == KIND_TABULAR_ANISO ? aniso_pdf1(b, a.x) : 0.0f; break;
+		case Q_A_CDF1: r.x = KIND == KIND_TABULAR_ANISO ? aniso_cdf1(b, a.x) : 0.0f; break;
+		case Q_A_QF1:  r.x = KIND == KIND_TABULAR_ANISO ? aniso_qf1(b, a.x) : 0.0f; break;
+		case Q_A_PDF2: r.x = KIND == KIND_TABULAR_ANISO ? aniso_pdf2(b, a.x, a.y) : 0.0f; break;
+		case Q_A_CDF2: r.x = KIND == KIND_TABULAR_ANISO ? aniso_cdf2(b, a.x, a.y) : 0.0f; break;
+		case Q_A_QF2:  r.x = KIND == KIND_TABULAR_ANISO ? aniso_qf2(b, a.x, a.y) : 0.0f; break;
 		}
 		store3(vout, k, r);
 	}
@@ -303,6 +311,7 @@ hipError_t launch_eval(hipStream_t s, const Brdf &b, const Params &p, long long 
 	case KIND_BECKMANN: return launch_eval_kind<KIND_BECKMANN>(s, b, p, n, i, o, out, out_pdf, want);
 	case KIND_GGX:      return launch_eval_kind<KIND_GGX>(s, b, p, n, i, o, out, out_pdf, want);
 	case KIND_TABULAR:  return launch_eval_kind<KIND_TABULAR>(s, b, p, n, i, o, out, out_pdf, want);
+	case KIND_TABULAR_ANISO: return launch_eval_kind<KIND_TABULAR_ANISO>(s, b, p, n, i, o, out, out_pdf, want);
 	case KIND_MERL:     return launch_eval_kind<KIND_MERL>(s, b, p, n, i, o, out, out_pdf, want);
 	case KIND_UTIA:     return launch_eval_kind<KIND_UTIA>(s, b, p, n, i, o, out, out_pdf, want);
 	case KIND_LAMBERT:  return launch_eval_kind<KIND_LAMBERT>(s, b, p, n, i, o, out, out_pdf, want);
@@ -321,6 +330,7 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 	case KIND_BECKMANN: return launch_sample_kind<KIND_BECKMANN>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_GGX:      return launch_sample_kind<KIND_GGX>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_TABULAR:  return launch_sample_kind<KIND_TABULAR>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_TABULAR_ANISO: return launch_sample_kind<KIND_TABULAR_ANISO>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_MERL:     return launch_sample_kind<KIND_MERL>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_UTIA:     return launch_sample_kind<KIND_UTIA>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_LAMBERT:  return launch_sample_kind<KIND_LAMBERT>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
@@ -343,6 +353,7 @@ hipError_t launch_eval_pp(hipStream_t s, const Brdf &b, long long n, const View 
 	case KIND_BECKMANN: return DJB_PP(KIND_BECKMANN);
 	case KIND_GGX:      return DJB_PP(KIND_GGX);
 	case KIND_TABULAR:  return DJB_PP(KIND_TABULAR);
+	case KIND_TABULAR_ANISO: return DJB_PP(KIND_TABULAR_ANISO);
 	}
 #undef DJB_PP
 	return hipErrorInvalidValue;
@@ -357,6 +368,7 @@ hipError_t launch_query(hipStream_t s, const Brdf &b, const Params &p, int which
 	case KIND_BECKMANN: hipLaunchKernelGGL((k_query<KIND_BECKMANN>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
 	case KIND_GGX:      hipLaunchKernelGGL((k_query<KIND_GGX>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
 	case KIND_TABULAR:  hipLaunchKernelGGL((k_query<KIND_TABULAR>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
+	case KIND_TABULAR_ANISO: hipLaunchKernelGGL((k_query<KIND_TABULAR_ANISO>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
 	default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError();

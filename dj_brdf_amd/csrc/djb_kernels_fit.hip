@@ -59,7 +59,7 @@ template <int SRC>
 DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o)
 {
 	v3 fr = mk(0, 0, 0); float pdf;
-	if (SRC <= KIND_TABULAR) mf_eval_pdf<SRC, 1>(src, std_p, i, o, fr, pdf);
+	if (SRC <= KIND_TABULAR || SRC == KIND_TABULAR_ANISO) mf_eval_pdf<SRC, 1>(src, std_p, i, o, fr, pdf);
 	else if (SRC == KIND_MERL) fr = merl_eval(src, i, o);
 	else if (SRC == KIND_UTIA) fr = utia_eval(src, i, o);
 	else if (SRC == KIND_SGD) fr = sgd_eval(src, i, o);
@@ -345,6 +345,7 @@ hipError_t launch_fit(hipStream_t s, const Brdf *srcs, int src_kind, const Param
 	case KIND_BECKMANN: return launch_fit_kind<KIND_BECKMANN>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
 	case KIND_GGX:      return launch_fit_kind<KIND_GGX>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
 	case KIND_TABULAR:  return launch_fit_kind<KIND_TABULAR>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_TABULAR_ANISO: return launch_fit_kind<KIND_TABULAR_ANISO>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
 	case KIND_MERL:     return launch_fit_kind<KIND_MERL>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
 	case KIND_UTIA:     return launch_fit_kind<KIND_UTIA>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
 	case KIND_LAMBERT:  return launch_fit_kind<KIND_LAMBERT>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);

@@ -731,6 +731,76 @@ class tabular(microfacet):
         return microfacet.params.isotropic(tab._alphas()[1])
 
 
+class tabular_anisotropic(microfacet):
+    """djb::tabular_anisotropic(brdf, elevation_res, azimuthal_res, shadow) (dj_brdf.h:428-478):
+    the anisotropic power-iteration fit, executed by djb_kernels_fit_aniso.hip."""
+
+    def __init__(self, src: brdf, elevation_res: int, azimuthal_res: int, shadow: bool = True, ctx=None):
+        brdf.__init__(self, ctx or src.ctx)
+        _lib.check(_lib.load().djb_brdf_create_tabular_anisotropic(
+            self.ctx._h, src._h, C.c_int(elevation_res), C.c_int(azimuthal_res), C.c_int(int(shadow)),
+            C.byref(self._h)))
+        self._fresnel = None
+
+    def supports_smith_vndf_sampling(self):
+        return False
+
+    def _get(self, which: int, width: int = 1):
+        lib = _lib.load()
+        n, e, a = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.djb_tabular_anisotropic_get(self._h, C.c_int(which), None, C.byref(n), C.byref(e), C.byref(a)))
+        arr = np.empty((n.value, width) if width > 1 else (n.value,), dtype=np.float32)
+        _lib.check(lib.djb_tabular_anisotropic_get(self._h, C.c_int(which), C.c_void_p(arr.ctypes.data), None, None, None))
+        return arr, e.value, a.value
+
+    def get_p22v(self):
+        """(values, elev_cnt, azim_cnt), dj_brdf.h:447"""
+        return self._get(0)
+
+    def get_sigmav(self):
+        return self._get(1)
+
+    def get_table(self, name: str):
+        return self._get({"pdf1": 2, "cdf1": 3, "qf1": 4, "pdf2": 5, "cdf2": 6, "qf2": 7}[name])[0]
+
+    def get_fresnel(self):
+        return fresnel.spline(self._get(8, 3)[0])
+
+    def _fits(self):
+        b, g = _lib.Params(), _lib.Params()
+        _lib.check(_lib.load().djb_tabular_anisotropic_fit(self._h, C.byref(b), C.byref(g)))
+        return b, g
+
+    @staticmethod
+    def fit_beckmann_parameters(tab: "tabular_anisotropic"):
+        b, _ = tab._fits()
+        return microfacet.params(2, tuple(b.v))
+
+    @staticmethod
+    def fit_ggx_parameters(tab: "tabular_anisotropic"):
+        _, g = tab._fits()
+        return microfacet.params(2, tuple(g.v))
+
+    # sampling queries (dj_brdf.h:450-455)
+    def pdf1(self, phi):
+        return self._query(32, self._cols(phi))
+
+    def cdf1(self, phi):
+        return self._query(33, self._cols(phi))
+
+    def qf1(self, u1):
+        return self._query(34, self._cols(u1))
+
+    def pdf2(self, theta, phi):
+        return self._query(35, self._cols(theta, phi))
+
+    def cdf2(self, theta, phi):
+        return self._query(36, self._cols(theta, phi))
+
+    def qf2(self, u, phi):
+        return self._query(37, self._cols(u, phi))
+
+
 # --------------------------------------------------------------------------- batch fitter
 def fit_merl_batch(tables, res: int = 90, shadow: bool = True, ctx: Optional[Context] = None,
                    return_tables: bool = False):

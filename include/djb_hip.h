@@ -78,7 +78,8 @@ typedef struct {
 } djb_fresnel_desc;
 
 enum { DJB_KIND_BECKMANN = 0, DJB_KIND_GGX = 1, DJB_KIND_TABULAR = 2, DJB_KIND_MERL = 3,
-       DJB_KIND_UTIA = 4, DJB_KIND_LAMBERT = 5, DJB_KIND_SGD = 6, DJB_KIND_ABC = 7 };
+       DJB_KIND_UTIA = 4, DJB_KIND_LAMBERT = 5, DJB_KIND_SGD = 6, DJB_KIND_ABC = 7,
+       DJB_KIND_TABULAR_ANISO = 8 };
 
 /* ---------------------------------------------------------------- library / context */
 const char *djb_last_error(void);
@@ -128,6 +129,11 @@ djb_status djb_brdf_create_abc_from_params(djb_ctx *, const double *params9, djb
 /* djb::tabular(const brdf&, int res, bool shadow): the power-iteration fit, run on the GPU
  *                                                                     dj_brdf.h:2215-2236 */
 djb_status djb_brdf_create_tabular(djb_ctx *, const djb_brdf *src, int res, int shadow, djb_brdf **);
+/* djb::tabular_anisotropic(const brdf&, int elevation_res, int azimuthal_res, bool shadow): the
+ * anisotropic power-iteration fit on a (theta, phi) grid; the (w*h)^2 Smith kernel matrix (513 MB at
+ * 90 x 90 in the reference) is recomputed on the fly, never stored.           dj_brdf.h:441-444 */
+djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *, const djb_brdf *src, int elevation_res,
+                                               int azimuthal_res, int shadow, djb_brdf **);
 djb_status djb_brdf_destroy(djb_brdf *);
 int        djb_brdf_kind(const djb_brdf *);
 /* microfacet::set_shadow / get_shadow                                 dj_brdf.h:278-281 */
@@ -174,7 +180,11 @@ djb_status djb_evalp_is_batch(djb_ctx *, const djb_brdf *, int64_t n, const floa
 enum { DJB_Q_NDF = 0, DJB_Q_GAF = 1, DJB_Q_G1 = 2, DJB_Q_SIGMA = 3, DJB_Q_P22 = 4, DJB_Q_VP22 = 5,
        DJB_Q_VNDF = 6, DJB_Q_FRESNEL = 7, DJB_Q_P22_RADIAL = 16, DJB_Q_SIGMA_STD_RADIAL = 17,
        DJB_Q_CDF_RADIAL = 18, DJB_Q_QF_RADIAL = 19, DJB_Q_QF2_RADIAL = 20, DJB_Q_QF3_RADIAL = 21,
-       DJB_Q_QF1 = 22 };
+       DJB_Q_QF1 = 22,
+       /* tabular_anisotropic only (dj_brdf.h:450-455): PDF1(phi) CDF1(phi) QF1(u) PDF2(theta,phi)
+        * CDF2(theta,phi) QF2(u,phi), arguments in a.x / a.y */
+       DJB_Q_ANISO_PDF1 = 32, DJB_Q_ANISO_CDF1 = 33, DJB_Q_ANISO_QF1 = 34, DJB_Q_ANISO_PDF2 = 35,
+       DJB_Q_ANISO_CDF2 = 36, DJB_Q_ANISO_QF2 = 37 };
 djb_status djb_query_batch(djb_ctx *, const djb_brdf *, int which, int64_t n, const djb_vec3_view *a,
                            const djb_vec3_view *b, const djb_vec3_view *c, const djb_params *params,
                            const djb_vec3_view *out, int mem);
@@ -229,6 +239,17 @@ djb_status djb_tabular_get(const djb_brdf *tab, int which, float *out, int *coun
 /* tabular::fit_beckmann_parameters / fit_ggx_parameters -> isotropic alpha
  *                                                                     dj_brdf.h:3133-3184 */
 djb_status djb_tabular_fit(const djb_brdf *tab, float *alpha_beckmann, float *alpha_ggx);
+
+/* tabular_anisotropic accessors: get_p22v / get_sigmav with their (elev, azim) counts
+ * (dj_brdf.h:447-448), the sampling tables behind pdf1/cdf1/qf1/pdf2/cdf2/qf2, the Fresnel spline
+ * points; grids are elev x azim floats, element (i_elev, j_azim) at [i + elev*j].           */
+enum { DJB_ATAB_P22 = 0, DJB_ATAB_SIGMA = 1, DJB_ATAB_PDF1 = 2, DJB_ATAB_CDF1 = 3, DJB_ATAB_QF1 = 4,
+       DJB_ATAB_PDF2 = 5, DJB_ATAB_CDF2 = 6, DJB_ATAB_QF2 = 7, DJB_ATAB_FRESNEL = 8 };
+djb_status djb_tabular_anisotropic_get(const djb_brdf *tab, int which, float *out, int *count,
+                                       int *elev_cnt, int *azim_cnt);
+/* tabular_anisotropic::fit_beckmann_parameters / fit_ggx_parameters -> params::pdfparams(alphax,
+ * alphay, rho, mux, muy) (the GGX rho is the reference's "TODO": 0).          dj_brdf.h:3186-3307 */
+djb_status djb_tabular_anisotropic_fit(const djb_brdf *tab, djb_params *beckmann, djb_params *ggx);
 
 /* ---------------------------------------------------------------- batch fitter
  * What examples/merl_params.cpp:53-67 does per file, for n_materials tables at once:

@@ -424,6 +424,54 @@ private:
 	std::vector<float_t> m_p22, m_sigma, m_cdf, m_qf;
 };
 
+/* Tabulated Anisotropic Microfacet NDF, dj_brdf.h:428-478 */
+class tabular_anisotropic : public microfacet {
+public:
+	tabular_anisotropic(const brdf &src, int elevation_res, int azimuthal_res, bool shadow = true)
+		: microfacet(&src.get_context(), fresnel::ideal()), m_elev(elevation_res), m_azim(azimuthal_res)
+	{
+		hip::check(djb_brdf_create_tabular_anisotropic(ctx(), src.handle(), elevation_res, azimuthal_res, shadow, &m_h));
+		m_p22 = fetch(DJB_ATAB_P22, 1); m_sigma = fetch(DJB_ATAB_SIGMA, 1);
+		std::vector<float_t> f = fetch(DJB_ATAB_FRESNEL, 3);
+		std::vector<vec3> pts;
+		for (size_t k = 0; k + 2 < f.size(); k += 3) pts.push_back(vec3(f[k], f[k + 1], f[k + 2]));
+		delete m_fresnel;
+		m_fresnel = new fresnel::spline(pts);
+	}
+	static microfacet::params fit_beckmann_parameters(const tabular_anisotropic &t) { return t.fit(0); }
+	static microfacet::params fit_ggx_parameters(const tabular_anisotropic &t) { return t.fit(1); }
+	const std::vector<float_t> &get_p22v(int *elev_cnt, int *azim_cnt) const
+	{ if (elev_cnt) *elev_cnt = m_elev; if (azim_cnt) *azim_cnt = m_azim; return m_p22; }
+	const std::vector<float_t> &get_sigmav(int *elev_cnt, int *azim_cnt) const
+	{ if (elev_cnt) *elev_cnt = m_elev; if (azim_cnt) *azim_cnt = m_azim; return m_sigma; }
+	// queries (scalar = batch of one)
+	float_t pdf1(float_t phi) const { return aq(DJB_Q_ANISO_PDF1, phi, 0); }
+	float_t pdf2(float_t theta, float_t phi) const { return aq(DJB_Q_ANISO_PDF2, theta, phi); }
+	float_t cdf1(float_t phi) const { return aq(DJB_Q_ANISO_CDF1, phi, 0); }
+	float_t cdf2(float_t theta, float_t phi) const { return aq(DJB_Q_ANISO_CDF2, theta, phi); }
+	float_t qf1(float_t u1) const { return aq(DJB_Q_ANISO_QF1, u1, 0); }
+	float_t qf2(float_t u, float_t phi) const { return aq(DJB_Q_ANISO_QF2, u, phi); }
+private:
+	float_t aq(int which, float_t a, float_t b) const { vec3 v(a, b, 0); return q(which, &v, NULL, NULL, params::standard()); }
+	microfacet::params fit(int which) const
+	{
+		djb_params b, g;
+		hip::check(djb_tabular_anisotropic_fit(m_h, &b, &g));
+		const djb_params &d = which == 0 ? b : g;
+		return microfacet::params::pdfparams(d.v[0], d.v[1], d.v[2], d.v[3], d.v[4]);
+	}
+	std::vector<float_t> fetch(int which, int width) const
+	{
+		int n = 0;
+		hip::check(djb_tabular_anisotropic_get(m_h, which, NULL, &n, NULL, NULL));
+		std::vector<float_t> v((size_t)n * width);
+		if (n) hip::check(djb_tabular_anisotropic_get(m_h, which, &v[0], NULL, NULL, NULL));
+		return v;
+	}
+	std::vector<float_t> m_p22, m_sigma;
+	int m_elev, m_azim;
+};
+
 } // namespace djb
 
 #endif // DJB_HIP_HPP

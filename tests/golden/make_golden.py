@@ -99,6 +99,29 @@ def main():
         out["pdfparams"] = pp
     np.savez_compressed(os.path.join(HERE, "lean.npz"), **out)
 
+    # ---- tabular_anisotropic: fit tables, moment fits, sampling queries, operators
+    from golden_cases import ANISO_CASES, N_ANISO, aniso_source
+    i = synth.directions_aos(N_ANISO, synth.SEED_I, start=40000)
+    o = synth.directions_aos(N_ANISO, synth.SEED_O, start=40000)
+    u1 = synth.uniforms(N_ANISO, synth.SEED_U1, start=40000)
+    u2 = synth.uniforms(N_ANISO, synth.SEED_U2, start=40000)
+    out = {"i": i, "o": o, "u1": u1, "u2": u2}
+    tmpa = tempfile.mkdtemp(prefix="djb_golden_aniso_")
+    for name, (src, elev, azim, shadow) in ANISO_CASES.items():
+        t = R.tabular_anisotropic(aniso_source(R, src, tmpa), elev, azim, shadow)
+        for k, v in R.aniso_tables(t).items():
+            out[f"{name}_{k}"] = v
+        phi, th = (u1 * np.float32(6.2)).astype(np.float32), (u2 * np.float32(1.5)).astype(np.float32)
+        for q, args in (("pdf1", (phi,)), ("cdf1", (phi,)), ("qf1", (u1,)), ("pdf2", (th, phi)),
+                        ("cdf2", (th, phi)), ("qf2", (u2, phi))):
+            out[f"{name}_{q}"] = R.aniso_query(t, q, *args)
+        for op in ("eval", "evalp", "pdf"):
+            out[f"{name}_{op}"] = R.eval(t, i, o, None, op)
+        out[f"{name}_eval_ell"] = R.eval(t, i, o, ("elliptic", 0.2, 0.5, 0.7), "eval")
+        out[f"{name}_sample"] = R.sample(t, u1, u2, o)
+    shutil.rmtree(tmpa, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, "aniso.npz"), **out)
+
     # ---- MERL lookup (hash-filled table: exact on any machine)
     tmp = tempfile.mkdtemp(prefix="djb_golden_")
     try:

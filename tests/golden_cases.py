@@ -73,3 +73,28 @@ def lrep_cases():
         for op in ("add", "mul", "iadd", "imul", "shear", "scale"):
             cases.append((op, m[k], m[k + 1], x, y))
     return cases
+
+# tabular_anisotropic: name -> (source, elevation_res, azimuthal_res, shadow)
+N_ANISO = 1024
+ANISO_CASES = {
+    "a_ggx": (("ggx", True), 12, 16, True),
+    "a_beckmann": (("beckmann", False), 20, 24, True),
+    "a_abc": (("abc", "gold-metallic-paint"), 16, 12, False),
+    "a_merl": (("merl", 0.3, (0.10, 0.08, 0.05), (0.9, 0.7, 0.4)), 14, 18, True),
+}
+
+
+def aniso_source(L, src, tmpdir=None):
+    """Build the source BRDF of an ANISO_CASES entry on checker library L (oracle or reference)."""
+    import os
+    from dj_brdf_amd import synth
+    if src[0] == "abc":
+        return L.abc(src[1])
+    if src[0] == "merl":
+        tab = synth.merl_table(*src[1:])
+        if L.prefix == "o_":
+            return L.merl_from_table(tab)
+        path = os.path.join(tmpdir, "aniso_src.binary")
+        synth.write_merl_binary(path, tab)
+        return L.merl(path)
+    return L.microfacet(src[0], ("ideal",), src[1])

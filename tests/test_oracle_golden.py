@@ -156,3 +156,22 @@ def test_lrep_and_lean_path(oracle):
             val, pp = oracle.eval_lean(b, g["i"], g["o"], LEAN_BASE, LEAN_SCALE, g["lean"], op)
             assert same(val, g[f"{ndf}_{op}"]) and same(pp, g["pdfparams"]), (ndf, op)
             assert same(oracle.eval_pp(b, g["i"], g["o"], g["pdfparams"], op), g[f"{ndf}_{op}"])
+
+
+@pytest.mark.parametrize("name", ["a_ggx", "a_beckmann", "a_abc", "a_merl"])
+def test_tabular_anisotropic(oracle, name):
+    from golden_cases import ANISO_CASES, aniso_source
+    g = np.load(os.path.join(G, "aniso.npz"))
+    src, elev, azim, shadow = ANISO_CASES[name]
+    t = oracle.tabular_anisotropic(aniso_source(oracle, src), elev, azim, shadow)
+    for k, v in oracle.aniso_tables(t).items():
+        assert same(v, g[f"{name}_{k}"]), (name, k)
+    u1, u2 = g["u1"], g["u2"]
+    phi, th = (u1 * np.float32(6.2)).astype(np.float32), (u2 * np.float32(1.5)).astype(np.float32)
+    for q, args in (("pdf1", (phi,)), ("cdf1", (phi,)), ("qf1", (u1,)), ("pdf2", (th, phi)),
+                    ("cdf2", (th, phi)), ("qf2", (u2, phi))):
+        assert same(oracle.aniso_query(t, q, *args), g[f"{name}_{q}"]), (name, q)
+    for op in ("eval", "evalp", "pdf"):
+        assert same(oracle.eval(t, g["i"], g["o"], None, op), g[f"{name}_{op}"]), (name, op)
+    assert same(oracle.eval(t, g["i"], g["o"], ("elliptic", 0.2, 0.5, 0.7)), g[f"{name}_eval_ell"])
+    assert same(oracle.sample(t, u1, u2, g["o"]), g[f"{name}_sample"])

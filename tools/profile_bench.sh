@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): rocprofv3 passes over bench.py for every workload.
+#   pass 1: --kernel-trace --stats            (per-kernel durations; must agree with bench.py's HIP events)
+#   pass 2: --pmc FETCH_SIZE                  (TCC read requests;  gfx950: x2 for streaming reads)
+#   pass 3: --pmc WRITE_SIZE                  (separate pass: FETCH_SIZE + WRITE_SIZE exceed the 4 TCC slots)
+#   pass 4: --pmc SQ_* GRBM_GUI_ACTIVE        (VALU issue / busy / waits)
+# Outputs land in gpurun_out/prof/<workload>/{trace,fetch,write,sq}; summarise with tools/summarize_profiles.py.
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
+for w in ${WORKLOADS:-merl_eval ggx_eval_pdf beckmann_sample merl_fit}; do
+  O=$R/gpurun_out/prof/$w; mkdir -p $O
+  A="--workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py $A > $O/bench_trace.json 2> $O/trace.err
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python bench.py $A > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python bench.py $A > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE \
+            --kernel-trace --output-format csv -d $O/sq -- python bench.py $A > /dev/null 2>&1
+  python bench.py --workload $w --steps 10 --warmup 2 --no-secondary > $O/bench_plain.json 2> $O/bench_plain.err
+done
+ls $R/gpurun_out/prof

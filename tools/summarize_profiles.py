@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof/<workload>/... (tools/profile_bench.sh) -> profiles/<round>/*.csv and
+profiles/pmc_<workload>.json (read by bench.py for roofline.traffic)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles", RND)
+os.makedirs(DST, exist_ok=True)
+DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf": ("k_eval<1, 5>",),
+            "beckmann_sample": ("k_sample<0",), "merl_fit": ("k_fit<3>",)}
+
+
+def counters(path):
+    fs = glob.glob(os.path.join(path, "*", "*_counter_collection.csv"))
+    acc, meta = collections.defaultdict(list), {}
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            meta[r["Kernel_Name"]] = (r["VGPR_Count"], r["SGPR_Count"], r["Workgroup_Size"], r["Grid_Size"], r["LDS_Block_Size"])
+    return acc, meta
+
+
+for w in sorted(os.listdir(SRC)):
+    d = os.path.join(SRC, w)
+    for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
+        shutil.copy(f, os.path.join(DST, f"{w}_kernel_stats.csv"))
+    for name in ("bench_plain.json", "bench_trace.json"):
+        if os.path.exists(os.path.join(d, name)):
+            shutil.copy(os.path.join(d, name), os.path.join(DST, f"{w}_{name}"))
+    rows, per_kernel = [], collections.defaultdict(dict)
+    for p in ("fetch", "write", "sq"):
+        acc, meta = counters(os.path.join(d, p))
+        for (k, c), v in sorted(acc.items()):
+            rows.append([p, k, c, len(v), sum(v) / len(v)] + list(meta[k]))
+            per_kernel[k][c] = sum(v) / len(v)
+    with open(os.path.join(DST, f"{w}_pmc_summary.csv"), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["pass", "kernel", "counter", "dispatches", "avg_per_dispatch", "vgpr", "sgpr", "workgroup", "grid", "lds"])
+        wr.writerows(rows)
+    fetch_kb = sum(v.get("FETCH_SIZE", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
+    write_kb = sum(v.get("WRITE_SIZE", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
+    if fetch_kb or write_kb:
+        out = {
+            "workload": w, "kernels": [k for k in per_kernel if any(t in k for t in DOMINANT.get(w, ()))],
+            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+            # MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-B streaming requests as 64 B on gfx950
+            # (verified here on k_eval<GGX>: 1.2 GB reported for 2.4 GB read) -> x2; WRITE_SIZE is exact
+            # (verified on k_gen_dir / k_eval: 12 B per element).  Units are KB (x1024).
+            "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
+            "note": "FETCH_SIZE x2 (gfx950 streaming-read correction) + WRITE_SIZE; includes the table "
+                    "gathers served by the Infinity Cache, also doubled: an upper bound on HBM traffic",
+        }
+        json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{w}.json"), "w"), indent=1)
+        print(w, out["hbm_bytes_per_launch"] / 1e9, "GB per launch (corrected)")
+print(sorted(os.listdir(DST)))

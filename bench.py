@@ -46,7 +46,25 @@ WORKLOADS = {
     "ggx_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf>"),
     "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample<BECKMANN,rng>"),
     "merl_fit": (100, None, "materials", "k_fit<MERL>"),
+    # end to end: 100 MERL files (34 992 012 B each) on local disk -> params: pread + PCIe + convert + fit
+    "merl_fit_files": (100, None, "materials", "djb_fit_merl_files (reader threads -> pinned ring -> H2D -> k_merl_convert -> k_fit<MERL>)"),
 }
+
+
+def synth_merl_files(n, synth, rank=0, distinct=10):
+    """n MERL-format files named after the MERL materials; `distinct` different tables, repeated."""
+    d = f"/tmp/djb_bench_merl_r{rank}"
+    os.makedirs(d, exist_ok=True)
+    paths, blobs = [], {}
+    for k in range(n):
+        p = os.path.join(d, synth.MERL_NAMES[k % 100] + (f"_{k // 100}" if k >= 100 else "") + ".binary")
+        if not (os.path.exists(p) and os.path.getsize(p) == synth.MERL_FILE_BYTES):
+            r = k % distinct
+            if r not in blobs:
+                blobs[r] = synth.merl_table(*synth.material_recipe(r))
+            synth.write_merl_binary(p, blobs[r])
+        paths.append(p)
+    return paths
 
 
 def parse():
@@ -110,6 +128,14 @@ def make_step(name, n, djb, synth, ctx, torch):
         def step():
             result["alphas"] = djb.fit_brdf_batch(mats, 90, True, ctx=ctx)
         return step, (mats, result)
+    if name == "merl_fit_files":
+        from dj_brdf_amd import merl_params
+        paths = synth_merl_files(n, synth, rank=int(os.environ.get("RANK", "0")))
+        result = {}
+
+        def step():
+            ab, ag, result["timing"] = merl_params.fit_files_on(ctx, paths)
+        return step, (paths, result)
     raise ValueError(name)
 
 
@@ -134,6 +160,23 @@ def cpu_baseline(name, synth, budget_s=12.0):
         b, op, par = L.microfacet("ggx", ("ideal",), True), "eval", ("elliptic", 0.3, 0.3, 0.0)
     elif name == "beckmann_sample":
         b, op, par = L.microfacet("beckmann", ("ideal",), True), "sample", ("elliptic", 0.2, 0.5, 0.7)
+    elif name == "merl_fit_files":   # the reference's own driver (examples/merl_params.cpp) on a few of the files
+        import subprocess
+        exe = os.path.join(ROOT, "oracle", "_ref", "merl_params")
+        paths = synth_merl_files(100, synth)[:4]
+        if os.path.exists(exe):
+            t0 = time.perf_counter()
+            subprocess.run([exe] + paths, cwd="/tmp", check=True, stdout=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            return {"value": len(paths) / dt, "unit": "materials/s", "cores": 1, "kind": "reference",
+                    "sample": f"examples/merl_params (reference, -O2) on {len(paths)} of the same files, 1 thread, "
+                              f"page cache warm: {dt / len(paths):.3f} s per file"}
+        t0 = time.perf_counter()
+        for p in paths:
+            L.tabular(L.merl(p), 90, True)
+        dt = time.perf_counter() - t0
+        return {"value": len(paths) / dt, "unit": "materials/s", "cores": 1, "kind": kind,
+                "sample": f"load + tabular(merl, 90) on {len(paths)} of the same files, 1 thread"}
     else:   # merl_fit: materials / s, one fit per thread
         tab = synth.merl_table(*synth.material_recipe(0))
         if kind == "reference":
@@ -254,7 +297,7 @@ def main():
             roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                         "traffic": None, "kernel": kernel, "launch_ms": launch_ms}
         rec = {
-            "metric": "BRDF evals/sec" if name != "merl_fit" else "MERL materials fitted/sec",
+            "metric": "BRDF evals/sec" if not name.startswith("merl_fit") else "MERL materials fitted/sec",
             "value": value, "unit": f"{unit}/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (f64 transcendentals)", "data": "synthetic",
@@ -262,10 +305,14 @@ def main():
                        "brdf": {"merl_eval": "MERL 90x90x180x3 nearest-bin (synthetic GGX0.3+diffuse table)",
                                 "ggx_eval_pdf": "GGX isotropic alpha=0.3, ideal Fresnel, eval+pdf fused",
                                 "beckmann_sample": "Beckmann elliptic(0.2,0.5,0.7) VNDF sample, on-chip RNG",
-                                "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material"}[name],
+                                "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material, tables resident in HBM",
+                                "merl_fit_files": "files on local disk -> pread -> PCIe -> k_merl_convert -> "
+                                                  "tabular(merl, 90) + both fits (end to end)"}[name],
                        "layout": "SoA float32 in HBM", "parallelism": f"independent x{world} (no collective)"},
             "roofline": roofline,
         }
+        if name == "merl_fit_files":
+            rec["pipeline"] = keep[1].get("timing")   # last step: total / load (read+upload+convert) / fit seconds
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(name, synth)
         if world == 1 and not args.no_secondary and name == "merl_eval" and args.n is None:

@@ -1166,3 +1166,30 @@ djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------- hooks for djb_loader.hip
+namespace djbk {
+
+hipStream_t ctx_stream(djb_ctx *ctx) { return ctx->stream; }
+int ctx_device(djb_ctx *ctx) { return ctx->device; }
+
+djb_status set_error(djb_status st, const char *fmt, ...)
+{
+	char buf[256];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+	g_err = buf;
+	return st;
+}
+
+// a float4 table already converted in HBM becomes a djb::merl object (which then owns it)
+djb_status wrap_merl_table(djb_ctx *ctx, float4 *table, djb_brdf **out)
+{
+	djb_brdf *b;
+	alloc_brdf(ctx, DJB_KIND_MERL, &b);
+	b->allocs.push_back(table);
+	b->dev.merl = table;
+	*out = b;
+	return DJB_OK;
+}
+
+} // namespace djbk

@@ -4,19 +4,23 @@
 
 fits Beckmann / GGX roughness to every MERL file with the HIP power-iteration kernel and writes
 the same ``params.txt`` ("# MERL Beckmann GGX" then ``name %.3f %.3f`` per file, input order).
-Materials are independent: with several GPUs visible they are dealt round-robin, one host
-thread + one HIP stream per GPU, no collective.
+Per GPU the work is the native pipeline of ``djb_fit_merl_files`` (reader threads -> pinned ring ->
+async upload + conversion kernel -> one fit launch).  Materials are independent: with several GPUs
+visible they are dealt round-robin, one host thread + one HIP stream per GPU, no collective
+(SURVEY.md 8e).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import os
 import sys
 import threading
+import time
 
 import numpy as np
 
-from . import djb, shard
+from . import _lib, djb, shard
 
 
 def material_name(path: str) -> str:
@@ -41,27 +45,41 @@ def read_merl_payload(path: str) -> np.ndarray:
     return data
 
 
-def fit_files(paths, res=90, shadow=True, gpus=None, chunk=8):
-    """[(alpha_beckmann, alpha_ggx)] for every path, in input order."""
+def fit_files_on(ctx: djb.Context, paths, res=90, shadow=True, reader_threads=0):
+    """(alpha_beckmann[n], alpha_ggx[n], timing dict) for `paths` on one GPU (native pipeline)."""
+    lib = _lib.load()
+    n = len(paths)
+    arr = (C.c_char_p * max(n, 1))(*[p.encode() for p in paths])
+    ab, ag = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    timing = (C.c_double * 4)()
+    _lib.check(lib.djb_fit_merl_files(ctx._h, C.c_int(n), arr, C.c_int(res), C.c_int(int(shadow)),
+                                      C.c_int(reader_threads), C.c_void_p(ab.ctypes.data),
+                                      C.c_void_p(ag.ctypes.data), timing))
+    return ab, ag, {"total_s": timing[0], "load_s": timing[1], "fit_s": timing[2], "bytes": timing[3]}
+
+
+def fit_files(paths, res=90, shadow=True, gpus=None, return_timing=False):
+    """[(alpha_beckmann, alpha_ggx)] for every path, in input order, over `gpus` GPUs."""
     n_dev = djb.device_count()
     if n_dev == 0:
         raise djb.exc(7, "djb_error: no HIP device; dj_brdf_amd has no CPU path")
     gpus = min(gpus or n_dev, n_dev, max(len(paths), 1))
     out = [None] * len(paths)
-    errors = []
+    errors, timings = [], [None] * gpus
 
     def worker(rank):
         try:
             ctx = djb.Context(rank)
             mine = shard.round_robin(len(paths), gpus, rank)
-            for c in range(0, len(mine), chunk):
-                ids = mine[c:c + chunk]
-                ab, ag = djb.fit_merl_batch([read_merl_payload(paths[k]) for k in ids], res, shadow, ctx=ctx)
-                for k, a, g in zip(ids, ab, ag):
-                    out[k] = (float(a), float(g))
+            if not mine:
+                return
+            ab, ag, timings[rank] = fit_files_on(ctx, [paths[k] for k in mine], res, shadow)
+            for k, a, g in zip(mine, ab, ag):
+                out[k] = (float(a), float(g))
         except Exception as e:  # surfaced on the main thread
             errors.append(e)
 
+    t0 = time.perf_counter()
     threads = [threading.Thread(target=worker, args=(r,)) for r in range(gpus)]
     for t in threads:
         t.start()
@@ -69,6 +87,8 @@ def fit_files(paths, res=90, shadow=True, gpus=None, chunk=8):
         t.join()
     if errors:
         raise errors[0]
+    if return_timing:
+        return out, {"wall_s": time.perf_counter() - t0, "per_gpu": timings, "gpus": gpus}
     return out
 
 
@@ -85,13 +105,16 @@ def main(argv=None):
     ap.add_argument("-o", "--output", default="params.txt")
     ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--res", type=int, default=90)
+    ap.add_argument("--timing", action="store_true", help="print the pipeline timing to stderr")
     args = ap.parse_args(argv)
     if not args.files:
         ap.print_usage()
         return 0
-    alphas = fit_files(args.files, res=args.res, gpus=args.gpus)
+    alphas, timing = fit_files(args.files, res=args.res, gpus=args.gpus, return_timing=True)
     with open(args.output, "w") as f:
         f.write(format_params_txt(args.files, alphas))
+    if args.timing:
+        print(timing, file=sys.stderr)
     return 0
 
 

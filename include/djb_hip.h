@@ -266,6 +266,15 @@ djb_status djb_fit_brdf_batch(djb_ctx *, int n_materials, const djb_brdf *const 
                               int res, int shadow, float *alpha_beckmann, float *alpha_ggx,
                               float *p22, float *sigma, float *cdf, float *qf, float *fresnel);
 
+/* End to end: what examples/merl_params.cpp:53-67 does per file, for a list of MERL files, as a
+ * pipeline (reader threads -> pinned ring -> async upload + conversion kernel, then ONE fit launch
+ * for the whole batch).  Errors carry djb::merl's messages (dj_brdf.h:970-982).  reader_threads <= 0
+ * picks a default.  timing (optional, 4 doubles): total seconds, seconds until every table was
+ * resident in HBM, seconds of the fit, bytes read.                                          */
+djb_status djb_fit_merl_files(djb_ctx *, int n_files, const char *const *paths, int res, int shadow,
+                              int reader_threads, float *alpha_beckmann, float *alpha_ggx,
+                              double *timing);
+
 /* ---------------------------------------------------------------- synthetic workloads
  * (not reference behaviour: the reference has no RNG).  Bit-identical to
  * dj_brdf_amd/synth.py.  Device pointers only. */

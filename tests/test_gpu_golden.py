@@ -221,3 +221,26 @@ def test_cpp_facade_programs(gpu_ctx, tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(tmp_path / "params.txt", "rb").read() == open(os.path.join(G, "params_expected.txt"), "rb").read()
+
+
+def test_native_file_pipeline(gpu_ctx, tmp_path):
+    """djb_fit_merl_files: reader threads -> pinned ring -> H2D -> convert -> one fit launch.  Same
+    alphas as fitting the tables one by one, input order kept, reference error messages."""
+    recipes = [synth.material_recipe(k) for k in range(3)]
+    paths = []
+    for k in range(7):                                  # more files than ring slots (4)
+        p = str(tmp_path / f"m{k}.binary")
+        synth.write_merl_binary(p, synth.merl_table(*recipes[k % 3])); paths.append(p)
+    ab, ag, timing = merl_params.fit_files_on(gpu_ctx, paths)
+    assert timing["bytes"] == 7 * synth.MERL_FILE_BYTES and timing["total_s"] > 0
+    for k in range(7):
+        t = djb.tabular(djb.merl(paths[k], ctx=gpu_ctx), 90, True, ctx=gpu_ctx)
+        assert djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0] == ab[k]
+        assert djb.tabular.fit_ggx_parameters(t).get_ellipse()[0] == ag[k]
+    with pytest.raises(djb.exc) as e:
+        merl_params.fit_files_on(gpu_ctx, paths[:2] + [str(tmp_path / "missing.binary")])
+    assert e.value.status_name == "DJB_ERR_OPEN_FAILED" and "Failed to open" in str(e.value)
+    bad = tmp_path / "bad.binary"; bad.write_bytes(np.array([90, 90, 180], np.int32).tobytes() + b"\0" * 100)
+    with pytest.raises(djb.exc) as e:
+        merl_params.fit_files_on(gpu_ctx, [str(bad)])
+    assert e.value.status_name == "DJB_ERR_READ_FAILED"

@@ -30,6 +30,10 @@ struct Fresnel {
 	int npts;
 };
 
+// one MERL bin in HBM: packed RGB floats (12 B, one dwordx3 gather).  Packing 10.67 bins per 128 B L2
+// line instead of 8 (float4) raises the per-XCD L2 hit rate of the random gather (MERL).
+struct MerlTexel { float x, y, z; };
+
 // device view of a djb_brdf
 struct Brdf {
 	int kind;
@@ -37,7 +41,7 @@ struct Brdf {
 	Fresnel fr;
 	const float *p22, *sigma, *cdf, *qf;   // tabular tables (device)
 	int n_p22, n_sigma, n_cdf, n_qf;
-	const float4 *merl;                     // [1458000] pre-scaled float RGB(+pad); below-horizon -> 0
+	const MerlTexel *merl;                  // [1458000] pre-scaled float RGB; below-horizon -> 0
 	const float *utia;                      // [3*288*288] float(normalized double sample)
 	const double *model;                    // sgd: 33 doubles, abc: 9 doubles (one published table row)
 	// tabular_anisotropic: p22 / sigma above are elev x azim grids (element (i, j) at [i + elev*j]);
@@ -76,8 +80,41 @@ DJB_DEV v3 divs(v3 a, float b) { return scale(1.0f / b, a); }
 // float(double(a) / (4.0 * double(b))) == a / (4.0f * b): 4*b is exact in float and one division
 // of two floats rounds identically through double (dj_brdf.h:1544, 1724-1726, 1754-1760)
 DJB_DEV float fdiv4(float a, float b) { return a / (4.0f * b); }
-// inversesqrt = float(1.0 / sqrt(double(x))): two double roundings, kept in double (dj_brdf.h:612)
-DJB_DEV float inversesqrt_(float x) { return F(1.0 / sqrt(D(x))); }
+// ---- guarded fast paths for float(<double expression>) -----------------------------------------
+// The reference rounds a correctly-rounded double result e to float.  A cheaper double y with
+// |y - e| <= 2^-44 |e| rounds to the SAME float unless y lies within 2^-44 (relative) of a float
+// rounding boundary, i.e. of a double whose low 29 mantissa bits are 0x10000000.  near_f32_midpoint
+// tests that (256 ulp64 either side; probability 2^-20), and the caller then takes the exact path.
+// y comes from v_rsq_f64 / v_rcp_f64 refined by two Newton steps (error <= a few 2^-53 for any
+// seed accuracy >= 2^-14); e itself is within 2^-52 of the true value.
+DJB_DEV bool near_f32_midpoint(double y)
+{
+	unsigned long long b = (unsigned long long)__double_as_longlong(y) & 0x1FFFFFFFull;
+	long long d = (long long)b - 0x10000000ll;
+	return (d < 0 ? -d : d) <= 256;
+}
+// inversesqrt = float(1.0 / sqrt(double(x))): two double roundings (dj_brdf.h:612)
+DJB_DEV float inversesqrt_(float x)
+{
+	double xd = D(x);
+	double y = __builtin_amdgcn_rsq(xd);
+	y = y * __builtin_fma(-0.5 * xd * y, y, 1.5);      // Newton: y (1.5 - 0.5 x y^2)
+	y = y * __builtin_fma(-0.5 * xd * y, y, 1.5);
+	if (__builtin_expect(near_f32_midpoint(y) || !(x > 1e-30f && x < 1e30f), 0))
+		return F(1.0 / sqrt(xd));                      // exact path (also zero / inf / NaN / tiny)
+	return F(y);
+}
+// float(1.0 / q) for a double q
+DJB_DEV float recip_to_f32(double q)
+{
+	double r = __builtin_amdgcn_rcp(q);
+	r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r);   // Newton: r + r (1 - q r)
+	r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r);
+	double aq = q < 0 ? -q : q;
+	if (__builtin_expect(near_f32_midpoint(r) || !(aq > 1e-30 && aq < 1e30), 0))
+		return F(1.0 / q);
+	return F(r);
+}
 DJB_DEV v3 normalize(v3 v) { return scale(inversesqrt_(dot(v, v)), v); }              // dj_brdf.h:630
 DJB_DEV float intensity(v3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z; } // dj_brdf.h:69
 
@@ -103,7 +140,7 @@ DJB_DEV float erf_(float x)
 	            a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
 	float sign = x < 0 ? -1.0f : 1.0f;
 	x = fabsf(x);
-	float t = F(1.0 / (1.0 + D(p * x)));
+	float t = recip_to_f32(1.0 + D(p * x));
 	float poly = ((((a5 * t + a4) * t) + a3) * t + a2) * t + a1;
 	float y = F(1.0 - D(poly * t) * exp(D(-x * x)));
 	return sign * y;
@@ -258,7 +295,7 @@ DJB_DEV v3 fresnel_eval(const Fresnel &f, float c)
 template <int KIND> DJB_DEV float p22_radial(const Brdf &b, float r_sqr)
 {
 	if (KIND == KIND_BECKMANN) return F(exp(D(-r_sqr)) / DJB_PI);                      // :1866
-	if (KIND == KIND_GGX) { float t = 1.0f + r_sqr; /* == float(1.0 + double(r_sqr)) */ return F(1.0 / (DJB_PI * D(t) * D(t))); } // :2056
+	if (KIND == KIND_GGX) { float t = 1.0f + r_sqr; /* == float(1.0 + double(r_sqr)) */ return recip_to_f32(DJB_PI * D(t) * D(t)); } // :2056
 	float r = sqrtf(r_sqr);                                                             // :2151
 	float u = F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI))));
 	return spline_f(b.p22, b.n_p22, u);
@@ -373,7 +410,7 @@ DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k)
 	u = fmax_(u, 1e-6f);
 	float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
 	float b = c - (1 + c) * powf(1 - u, fit);
-	float normalization = F(1 / (D(1 + c) + D(sqrt_pi_inv * tan_k) * exp(D(-cot_k * cot_k))));
+	float normalization = recip_to_f32(D(1 + c) + D(sqrt_pi_inv * tan_k) * exp(D(-cot_k * cot_k)));
 	int it = 0;
 	while (++it < 10) {
 		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
@@ -630,7 +667,7 @@ DJB_DEV v3 merl_eval(const Brdf &b, v3 i, v3 o)
 {
 	// table entries are float(double sample * channel scale) with below-horizon bins zeroed at
 	// load time (djb_host.cpp): exactly what dj_brdf.h:1010-1023 returns per lookup.
-	float4 t = b.merl[merl_index(i, o)];
+	MerlTexel t = b.merl[merl_index(i, o)];
 	return mk(t.x, t.y, t.z);
 }
 

@@ -253,8 +253,11 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 		const long long CH = 1LL << 31;
 		for (long long lo = 0; lo < n; lo += CH) {
 			long long m = n - lo < CH ? n - lo : CH;
-			size_t cap = (size_t)(m / 24 + 4096);
-			size_t need = sizeof(unsigned int) * (cap + 4);
+			// worklist: 16-byte header (count) + cap records of 32 bytes {k, i, o}; ~1 % of uniformly
+			// distributed pairs are ambiguous, 2 % capacity; overflow falls back to a rescan
+			const size_t REC = 32;
+			size_t cap = (size_t)(m / 48 + 4096);
+			size_t need = 16 + REC * cap;
 			if (ctx->scratch_bytes < need) {
 				HIP_TRY(hipStreamSynchronize(ctx->stream));
 				if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -262,7 +265,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 				HIP_TRY(hipMalloc(&ctx->scratch, need));
 				ctx->scratch_bytes = need;
 			}
-			cap = ctx->scratch_bytes / sizeof(unsigned int) - 4;
+			cap = (ctx->scratch_bytes - 16) / REC;
 			unsigned int *count = (unsigned int *)ctx->scratch, *list = count + 4;
 			auto off = [&](const View &v) { return View{ v.x + lo * v.stride, v.y + lo * v.stride, v.z + lo * v.stride, v.stride }; };
 			View oi = off(vi), oo = off(vo), ou = (want & 3) ? off(vout) : vout;
@@ -463,9 +466,9 @@ djb_status djb_brdf_create_merl_from_memory(djb_ctx *ctx, const double *samples,
 	HIP_TRY(hipSetDevice(ctx->device));
 	djb_brdf *b;
 	alloc_brdf(ctx, DJB_KIND_MERL, &b);
-	double *raw = nullptr; float4 *tab = nullptr;
+	double *raw = nullptr; djbdev::MerlTexel *tab = nullptr;
 	hipError_t e = hipMalloc((void **)&raw, sizeof(double) * 3 * (size_t)n);
-	if (e == hipSuccess) e = hipMalloc((void **)&tab, sizeof(float4) * (size_t)n);
+	if (e == hipSuccess) e = hipMalloc((void **)&tab, sizeof(djbdev::MerlTexel) * (size_t)n);
 	if (e == hipSuccess) e = hipMemcpyAsync(raw, samples, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess) e = djbk::launch_merl_convert(ctx->stream, raw, n, tab);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -805,7 +808,7 @@ djb_status djb_fit_merl_batch(djb_ctx *ctx, int n_mat, const double *const *tabl
 	if (n_mat == 0) return DJB_OK;
 	djb_status st = check_call(ctx, nullptr, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
-	// upload + convert every table (raw doubles -> float4 table), double-buffered on the stream
+	// upload + convert every table (raw doubles -> texel table), double-buffered on the stream
 	std::vector<djb_brdf *> mats(n_mat, nullptr);
 	std::vector<Brdf> srcs(n_mat);
 	for (int m = 0; m < n_mat; ++m) {
@@ -1155,6 +1158,22 @@ djb_status djb_gen_uniforms(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t sta
 	HIP_TRY(djbk::launch_gen_uniforms(ctx->stream, n, seed, start, out));
 	return DJB_OK;
 }
+djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, unsigned long long *counters4)
+{
+	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	if (!counters4) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	unsigned long long *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 32));
+	hipError_t e = hipMemsetAsync(d, 0, 32, ctx->stream);
+	if (e == hipSuccess) e = djbk::launch_guard_selftest(ctx->stream, n, seed, d);
+	if (e == hipSuccess) e = hipMemcpyAsync(counters4, d, 32, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));
+	return DJB_OK;
+}
+
 djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int bins, unsigned long long *counts)
 {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
@@ -1181,8 +1200,8 @@ djb_status set_error(djb_status st, const char *fmt, ...)
 	return st;
 }
 
-// a float4 table already converted in HBM becomes a djb::merl object (which then owns it)
-djb_status wrap_merl_table(djb_ctx *ctx, float4 *table, djb_brdf **out)
+// a texel table already converted in HBM becomes a djb::merl object (which then owns it)
+djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **out)
 {
 	djb_brdf *b;
 	alloc_brdf(ctx, DJB_KIND_MERL, &b);

@@ -45,8 +45,8 @@ hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const 
 hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, const View &o,
                                    const float *guard5, unsigned int *max_bits, unsigned long long *counters);
 
-// MERL payload (3*n doubles) -> float4 table (pre-scaled, below-horizon zeroed); n = 1458000
-hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, float4 *table);
+// MERL payload (3*n doubles) -> packed RGB texel table (pre-scaled, below-horizon zeroed); n = 1458000
+hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, djbdev::MerlTexel *table);
 // UTIA payload -> float(max(0, s) * double(1.f/140.f))
 hipError_t launch_utia_convert(hipStream_t s, const double *samples, long long n, float *table);
 
@@ -54,6 +54,7 @@ hipError_t launch_gen_directions(hipStream_t s, long long n, uint32_t seed, unsi
                                  const View &out);
 hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsigned long long start,
                                float *out);
+hipError_t launch_guard_selftest(hipStream_t s, long long n, uint32_t seed, unsigned long long *counters);
 hipError_t launch_histogram_xy(hipStream_t s, long long n, const View &v, int bins,
                                unsigned long long *counts);
 

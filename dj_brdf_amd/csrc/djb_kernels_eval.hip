@@ -41,7 +41,7 @@ DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float 
 }
 
 template <int KIND, int WANT>
-__global__ __launch_bounds__(BLOCK) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
+__global__ __launch_bounds__(BLOCK, 4) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
                                                 View vout, float *out_pdf)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLOCK) void k_merl_index(long long n, View vi, View
 }
 
 // dj_brdf.h:1010-1023 applied once per table entry instead of once per lookup
-__global__ __launch_bounds__(BLOCK) void k_merl_convert(const double *s, long long n, float4 *table)
+__global__ __launch_bounds__(BLOCK) void k_merl_convert(const double *s, long long n, MerlTexel *table)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_merl_convert(const double *s, long lo
 		float g = F(s[k + n] * (1.15 / 1500.0));
 		float b = F(s[k + 2 * n] * (1.66 / 1500.0));
 		if (D(r) < 0.0 || D(g) < 0.0 || D(b) < 0.0) r = g = b = 0.0f;
-		table[k] = make_float4(r, g, b, 0.0f);
+		table[k] = MerlTexel{ r, g, b };
 	}
 }
 
@@ -276,6 +276,35 @@ __global__ __launch_bounds__(BLOCK) void k_gen_uni(long long n, uint32_t seed, u
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride)
 		out[k] = gen_uniform(seed, start + (unsigned long long)k);
+}
+
+// self-test of the guarded fast paths of djb_device.hpp (inversesqrt_, recip_to_f32) against the
+// exact double sequences they stand in for, on hash-generated inputs across the exponent range.
+// counters: [0] inversesqrt mismatches, [1] reciprocal mismatches (both must be 0),
+//           [2] inversesqrt exact-path fallbacks, [3] reciprocal fallbacks.
+__global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t seed, unsigned long long *counters)
+{
+	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0;
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		uint32_t h0 = hash_u32(seed, (uint64_t)k, 0), h1 = hash_u32(seed, (uint64_t)k, 1), h2 = hash_u32(seed, (uint64_t)k, 2);
+		// float x with a random mantissa and an exponent in [2^-40, 2^40); every 8th near 1 (unit vectors)
+		int ex = (k & 7) ? (int)(h1 % 80u) - 40 : (int)(h1 % 3u) - 1;
+		float x = ldexpf(1.0f + (float)(h0 >> 9) * 1.1920928955078125e-07f, ex);
+		if (inversesqrt_(x) != F(1.0 / sqrt(D(x)))) ++bad_r;
+		double xd = D(x), y = __builtin_amdgcn_rsq(xd);
+		y = y * __builtin_fma(-0.5 * xd * y, y, 1.5); y = y * __builtin_fma(-0.5 * xd * y, y, 1.5);
+		if (near_f32_midpoint(y)) ++fb_r;
+		// double q = pi * t * t (the GGX slope pdf denominator) or 1 + p*x (erf), random low bits
+		double q = (h2 & 1) ? DJB_PI * D(x) * D(x) : 1.0 + D(x) * 0.3275911;
+		q = __longlong_as_double(__double_as_longlong(q) ^ (long long)(h2 >> 3));
+		if (recip_to_f32(q) != F(1.0 / q)) ++bad_d;
+		double r = __builtin_amdgcn_rcp(q);
+		r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r); r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r);
+		if (near_f32_midpoint(r)) ++fb_d;
+	}
+	atomicAdd(&counters[0], bad_r); atomicAdd(&counters[1], bad_d);
+	atomicAdd(&counters[2], fb_r); atomicAdd(&counters[3], fb_d);
 }
 
 // bins x bins histogram over [-1,1]^2: LDS atomics, one global flush per workgroup
@@ -391,7 +420,7 @@ hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const Vi
 	return hipGetLastError();
 }
 
-hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, float4 *table)
+hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, MerlTexel *table)
 {
 	hipLaunchKernelGGL(k_merl_convert, dim3(grid_for(n)), dim3(BLOCK), 0, s, samples, n, table);
 	return hipGetLastError();
@@ -416,6 +445,12 @@ hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsign
 {
 	if (n <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k_gen_uni, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, seed, start, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_guard_selftest(hipStream_t s, long long n, uint32_t seed, unsigned long long *counters)
+{
+	hipLaunchKernelGGL(k_guard_selftest, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, seed, counters);
 	return hipGetLastError();
 }
 

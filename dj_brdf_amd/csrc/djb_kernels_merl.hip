@@ -4,9 +4,10 @@
 // libm-class calls per pair, ~770 VALU instructions, VALU-bound at 17 % of the HBM roofline.
 // Here the same result is produced in two launches:
 //   k_merl_fast   every pair: fp32 closed-form angles + guard bands (merl_index_fast).  Certain
-//                 pairs (~99.7 %) gather their table entry and are done; ambiguous pairs append
-//                 their index to a worklist in HBM (one wave-aggregated atomic).
-//   k_merl_fixup  ambiguous pairs only, densely packed: the exact fp64 path (merl_index).
+//                 pairs (~99 %) gather their table entry and are done; ambiguous pairs append a
+//                 32-byte record {k, i, o} to a worklist in HBM (one wave-aggregated atomic).
+//   k_merl_fixup  ambiguous pairs only, read back densely from the worklist (coalesced; the inputs
+//                 are not gathered a second time): the exact fp64 path (merl_index).
 // If the worklist overflows its capacity the fix-up kernel rescans the batch with the same decision
 // function, so the result never depends on the capacity.  Bit-exactness argument and calibration: DESIGN.md 4.2.
 #include "djb_internal.hpp"
@@ -16,7 +17,10 @@ using namespace djbdev;
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr unsigned int WBUF = 256;   // per-wave LDS staging slots for ambiguous pair indices
+constexpr unsigned int WBUF = 128;   // per-wave LDS staging slots for ambiguous pairs (7 dwords each)
+#ifndef DJB_MERL_GRID_CAP
+#define DJB_MERL_GRID_CAP (256LL * 64)
+#endif
 
 inline int grid_for(long long n, long long cap = 256LL * 16)
 {
@@ -39,11 +43,49 @@ DJB_DEV void nt_store4(float a, float b, float c, float d, float4 *p)
 	__builtin_nontemporal_store(v, (nt_v4f *)p);
 }
 
+// ---- per-wave worklist staging.  Ambiguous pairs are staged per wave in LDS (no barrier needed: one
+// wave, in-order LDS) and flushed with ONE global atomic per flush: a returning atomic per ambiguous
+// lane (~8e6 per 1e9 pairs on one address) costs more than the whole kernel.  A record is
+// {k, i.xyz, o.xyz, pad} = two uint4, so the fix-up kernel streams its inputs instead of gathering them.
+typedef unsigned int WaveBuf[7][WBUF];
+
+DJB_DEV void wl_flush(WaveBuf &wb, unsigned int &wcount, int lane, uint4 *list, unsigned int cap,
+                      unsigned int *count)
+{
+	unsigned int base = 0;
+	if (lane == 0) base = atomicAdd(count, wcount);
+	base = __shfl(base, 0);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	for (unsigned int j = lane; j < wcount; j += 64)
+		if (base + j < cap) {                                    // beyond cap: fix-up kernel rescans
+			list[2 * (size_t)(base + j)] = make_uint4(wb[0][j], wb[1][j], wb[2][j], wb[3][j]);
+			list[2 * (size_t)(base + j) + 1] = make_uint4(wb[4][j], wb[5][j], wb[6][j], 0u);
+		}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	wcount = 0;
+}
+
+DJB_DEV void wl_push(WaveBuf &wb, unsigned int &wcount, int lane, uint4 *list, unsigned int cap,
+                     unsigned int *count, bool amb, unsigned int k, v3 i, v3 o)
+{
+	unsigned long long mask = __ballot(amb);
+	if (!mask) return;
+	unsigned int c = (unsigned int)__popcll(mask);
+	if (wcount + c > WBUF) wl_flush(wb, wcount, lane, list, cap, count);
+	if (amb) {
+		unsigned int slot = wcount + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+		wb[0][slot] = k;
+		wb[1][slot] = __float_as_uint(i.x); wb[2][slot] = __float_as_uint(i.y); wb[3][slot] = __float_as_uint(i.z);
+		wb[4][slot] = __float_as_uint(o.x); wb[5][slot] = __float_as_uint(o.y); wb[6][slot] = __float_as_uint(o.z);
+	}
+	wcount += c;
+}
+
 template <int WANT>
 DJB_DEV void merl_emit(const Brdf &b, int idx, v3 i, long long k, const View &vout, float *out_pdf)
 {
 	if (WANT & 3) {
-		float4 t = b.merl[idx];
+		MerlTexel t = b.merl[idx];
 		v3 e = mk(t.x, t.y, t.z);
 		store3(vout, k, (WANT & 2) ? scale(i.z, e) : e);          // brdf::evalp, dj_brdf.h:803-806
 	}
@@ -53,43 +95,25 @@ DJB_DEV void merl_emit(const Brdf &b, int idx, v3 i, long long k, const View &vo
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_merl_fast(Brdf b, long long k_begin, long long n, View vi, View vo,
                                                      View vout, float *out_pdf, MerlGuard g,
-                                                     unsigned int *list, unsigned int cap, unsigned int *count)
+                                                     uint4 *list, unsigned int cap, unsigned int *count)
 {
-	// Ambiguous pair indices are staged per wave in LDS (no barrier needed: one wave, in-order LDS)
-	// and flushed 256 at a time with ONE global atomic: a returning atomic per ambiguous lane
-	// (~8e6 per 1e9 pairs on one address) costs more than the whole kernel.
-	__shared__ unsigned int wbuf[BLOCK / 64][WBUF];
+	__shared__ WaveBuf wbuf[BLOCK / 64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	unsigned int wcount = 0;                                     // wave-uniform
-	auto flush = [&]() {
-		unsigned int base = 0;
-		if (lane == 0) base = atomicAdd(count, wcount);
-		base = __shfl(base, 0);
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		for (unsigned int j = lane; j < wcount; j += 64)
-			if (base + j < cap) list[base + j] = wbuf[wave][j];  // beyond cap: fix-up kernel rescans
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		wcount = 0;
-	};
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k0 = k_begin + (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {   // block-uniform trip count
 		long long k = k0 + threadIdx.x;
 		bool amb = false;
+		v3 i = mk(0, 0, 1), o = mk(0, 0, 1);
 		if (k < n) {
-			v3 i = load3(vi, k), o = load3(vo, k);
+			i = load3(vi, k); o = load3(vo, k);
 			int idx;
 			if (merl_index_fast(i, o, g, idx)) merl_emit<WANT>(b, idx, i, k, vout, out_pdf);
 			else amb = true;                                      // tier 2 (k_merl_fixup) finishes this pair
 		}
-		unsigned long long mask = __ballot(amb);
-		if (mask) {
-			unsigned int c = (unsigned int)__popcll(mask);
-			if (wcount + c > WBUF) flush();
-			if (amb) wbuf[wave][wcount + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)k;
-			wcount += c;
-		}
+		wl_push(wbuf[wave], wcount, lane, list, cap, count, amb, (unsigned int)k, i, o);
 	}
-	if (wcount) flush();
+	if (wcount) wl_flush(wbuf[wave], wcount, lane, list, cap, count);
 }
 
 // Same kernel for dense SoA input (stride 1, 16-byte aligned): four consecutive pairs per lane,
@@ -99,44 +123,38 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast(Brdf b, long long k_begin, 
 // kernel on the same stream and overwrites them.
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, View vi, View vo, View vout,
-                                                        float *out_pdf, MerlGuard g, unsigned int *list,
+                                                        float *out_pdf, MerlGuard g, uint4 *list,
                                                         unsigned int cap, unsigned int *count)
 {
-	__shared__ unsigned int wbuf[BLOCK / 64][WBUF];
+	__shared__ WaveBuf wbuf[BLOCK / 64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	unsigned int wcount = 0;
-	auto flush = [&]() {
-		unsigned int base = 0;
-		if (lane == 0) base = atomicAdd(count, wcount);
-		base = __shfl(base, 0);
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		for (unsigned int j = lane; j < wcount; j += 64)
-			if (base + j < cap) list[base + j] = wbuf[wave][j];
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		wcount = 0;
-	};
 	const float4 *ix4 = (const float4 *)vi.x, *iy4 = (const float4 *)vi.y, *iz4 = (const float4 *)vi.z;
 	const float4 *ox4 = (const float4 *)vo.x, *oy4 = (const float4 *)vo.y, *oz4 = (const float4 *)vo.z;
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long q0 = (long long)blockIdx.x * BLOCK; q0 < n4; q0 += stride) {
 		long long q = q0 + threadIdx.x;
 		bool amb[4] = { false, false, false, false };
+		float ixs[4], iys[4], izs[4], oxs[4], oys[4], ozs[4];
 		if (q < n4) {
 			// the 36 B/pair streams are touched once: non-temporal, so they do not evict the table from L2
 			float4 ax = nt_load4(ix4 + q), ay = nt_load4(iy4 + q), az = nt_load4(iz4 + q),
 			       bx = nt_load4(ox4 + q), by = nt_load4(oy4 + q), bz = nt_load4(oz4 + q);
-			const float ixs[4] = { ax.x, ax.y, ax.z, ax.w }, iys[4] = { ay.x, ay.y, ay.z, ay.w },
-			            izs[4] = { az.x, az.y, az.z, az.w }, oxs[4] = { bx.x, bx.y, bx.z, bx.w },
-			            oys[4] = { by.x, by.y, by.z, by.w }, ozs[4] = { bz.x, bz.y, bz.z, bz.w };
+			ixs[0] = ax.x; ixs[1] = ax.y; ixs[2] = ax.z; ixs[3] = ax.w;
+			iys[0] = ay.x; iys[1] = ay.y; iys[2] = ay.z; iys[3] = ay.w;
+			izs[0] = az.x; izs[1] = az.y; izs[2] = az.z; izs[3] = az.w;
+			oxs[0] = bx.x; oxs[1] = bx.y; oxs[2] = bx.z; oxs[3] = bx.w;
+			oys[0] = by.x; oys[1] = by.y; oys[2] = by.z; oys[3] = by.w;
+			ozs[0] = bz.x; ozs[1] = bz.y; ozs[2] = bz.z; ozs[3] = bz.w;
 			int idx[4];
 #pragma unroll
 			for (int j = 0; j < 4; ++j)
 				amb[j] = !merl_index_fast(mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]), g, idx[j]);
 			if (WANT & 3) {
-				float4 t[4];
+				MerlTexel t[4];
 #pragma unroll
 #ifdef DJB_EXP_NOGATHER   // experiment only: how fast is the kernel without the table gather?
-				for (int j = 0; j < 4; ++j) t[j] = make_float4((float)idx[j], 0.f, 0.f, 0.f);
+				for (int j = 0; j < 4; ++j) t[j] = MerlTexel{ (float)idx[j], 0.f, 0.f };
 #else
 				for (int j = 0; j < 4; ++j) t[j] = b.merl[amb[j] ? 0 : idx[j]];
 #endif
@@ -148,6 +166,7 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, Vi
 					gg[j] = (WANT & 2) ? s * t[j].y : t[j].y;
 					bb[j] = (WANT & 2) ? s * t[j].z : t[j].z;
 				}
+				// ambiguous pairs get a placeholder here; k_merl_fixup overwrites it
 				nt_store4(r[0], r[1], r[2], r[3], (float4 *)vout.x + q);
 				nt_store4(gg[0], gg[1], gg[2], gg[3], (float4 *)vout.y + q);
 				nt_store4(bb[0], bb[1], bb[2], bb[3], (float4 *)vout.z + q);
@@ -156,32 +175,29 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, Vi
 				((float4 *)out_pdf)[q] = make_float4(F(D(izs[0]) / DJB_PI), F(D(izs[1]) / DJB_PI),
 				                                     F(D(izs[2]) / DJB_PI), F(D(izs[3]) / DJB_PI));
 		}
+		if (__ballot(amb[0] | amb[1] | amb[2] | amb[3])) {
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			unsigned long long mask = __ballot(amb[j]);
-			if (mask) {
-				unsigned int c = (unsigned int)__popcll(mask);
-				if (wcount + c > WBUF) flush();
-				if (amb[j])
-					wbuf[wave][wcount + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)(4 * q + j);
-				wcount += c;
-			}
+			for (int j = 0; j < 4; ++j)
+				wl_push(wbuf[wave], wcount, lane, list, cap, count, amb[j], (unsigned int)(4 * q + j),
+				        mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]));
 		}
 	}
-	if (wcount) flush();
+	if (wcount) wl_flush(wbuf[wave], wcount, lane, list, cap, count);
 }
 
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_merl_fixup(Brdf b, long long n, View vi, View vo, View vout,
-                                                      float *out_pdf, MerlGuard g, const unsigned int *list,
+                                                      float *out_pdf, MerlGuard g, const uint4 *list,
                                                       unsigned int cap, const unsigned int *count)
 {
 	const unsigned int m = *count;
 	if (m <= cap) {                      // normal case: the worklist holds every ambiguous pair
 		unsigned int stride = gridDim.x * BLOCK;
 		for (unsigned int j = blockIdx.x * BLOCK + threadIdx.x; j < m; j += stride) {
-			long long k = (long long)list[j];
-			v3 i = load3(vi, k), o = load3(vo, k);
+			uint4 ra = list[2 * (size_t)j], rb = list[2 * (size_t)j + 1];
+			long long k = (long long)ra.x;
+			v3 i = mk(__uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
+			v3 o = mk(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z));
 			merl_emit<WANT>(b, merl_index(i, o), i, k, vout, out_pdf);
 		}
 	} else {                             // overflow (adversarial input): rescan, same decision function
@@ -232,9 +248,10 @@ __global__ __launch_bounds__(BLOCK) void k_merl_guard_stats(long long n, View vi
 
 template <int WANT>
 hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
-                     const View &out, float *out_pdf, const MerlGuard &g, unsigned int *list,
+                     const View &out, float *out_pdf, const MerlGuard &g, unsigned int *list_words,
                      unsigned int cap, unsigned int *count)
 {
+	uint4 *list = (uint4 *)list_words;       // cap records of 2 x uint4 (djbk::merl_worklist_bytes)
 	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int), s);
 	if (e != hipSuccess) return e;
 	auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
@@ -243,7 +260,7 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
 	             (!(WANT & 3) || (al16(out.x) && al16(out.y) && al16(out.z))) && (!(WANT & 4) || al16(out_pdf));
 	long long n4 = dense ? n / 4 : 0;
 	if (n4 > 0)
-		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4)), dim3(BLOCK), 0, s, b, n4, i, o, out,
+		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4, DJB_MERL_GRID_CAP)), dim3(BLOCK), 0, s, b, n4, i, o, out,
 		                   out_pdf, g, list, cap, count);
 	if (4 * n4 < n)   // strided / unaligned input, or the < 4-pair tail of a dense batch
 		hipLaunchKernelGGL((k_merl_fast<WANT>), dim3(grid_for(n - 4 * n4)), dim3(BLOCK), 0, s, b, 4 * n4, n, i, o,

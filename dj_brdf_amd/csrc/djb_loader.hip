@@ -2,7 +2,7 @@
 // file (djb::merl(path) -> djb::tabular(merl, 90) -> two fits), for a list of files, as a pipeline:
 //
 //   reader threads  --pread-->  pinned host ring  --hipMemcpyAsync-->  HBM raw ring
-//                                                   k_merl_convert (stream)  -->  float4 tables
+//                                                   k_merl_convert (stream)  -->  texel tables
 //   ... all tables resident ...  one k_fit launch (one workgroup per material)  -->  alphas
 //
 // The reference spends 0.135 s per file in fstream::read + 0.117 s in the fit, serially
@@ -34,8 +34,8 @@ djb_status djb_brdf_destroy(djb_brdf *);
 }
 
 namespace djbk {
-// defined in djb_host.hip: wrap an already converted float4 table into a djb_brdf (takes ownership)
-djb_status wrap_merl_table(djb_ctx *ctx, float4 *table, djb_brdf **out);
+// defined in djb_host.hip: wrap an already converted texel table into a djb_brdf (takes ownership)
+djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **out);
 hipStream_t ctx_stream(djb_ctx *ctx);
 int ctx_device(djb_ctx *ctx);
 djb_status set_error(djb_status st, const char *fmt, ...);
@@ -105,7 +105,7 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 	if (reader_threads > n_slots) reader_threads = n_slots;
 
 	std::vector<Slot> slots(n_slots);
-	std::vector<float4 *> tables(n_files, nullptr);
+	std::vector<djbdev::MerlTexel *> tables(n_files, nullptr);
 	djb_status status = DJB_OK;
 	std::string status_msg;
 	auto cleanup = [&]() {
@@ -114,7 +114,7 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 			if (s.dev) (void)hipFree(s.dev);
 			if (s.done) (void)hipEventDestroy(s.done);
 		}
-		for (float4 *t : tables) if (t) (void)hipFree(t);
+		for (djbdev::MerlTexel *t : tables) if (t) (void)hipFree(t);
 	};
 	for (Slot &s : slots) {
 		if (hipHostMalloc((void **)&s.host, PAYLOAD, hipHostMallocDefault) != hipSuccess ||
@@ -181,8 +181,8 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 		if (slot < 0) continue;
 		Slot &s = slots[slot];
 		if (s.st != DJB_OK) { status = s.st; status_msg = s.err; break; }
-		float4 *tab = nullptr;
-		e = hipMalloc((void **)&tab, sizeof(float4) * (size_t)MERL_N);
+		djbdev::MerlTexel *tab = nullptr;
+		e = hipMalloc((void **)&tab, sizeof(djbdev::MerlTexel) * (size_t)MERL_N);
 		if (e == hipSuccess) e = hipMemcpyAsync(s.dev, s.host, PAYLOAD, hipMemcpyHostToDevice, stream);
 		if (e == hipSuccess) e = djbk::launch_merl_convert(stream, s.dev, MERL_N, tab);
 		if (e == hipSuccess) e = hipEventRecord(s.done, stream);

@@ -875,6 +875,15 @@ def set_merl_exact_only(ctx: Context, on: bool):
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(1), C.c_int(int(on))))
 
 
+def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):
+    """Self-test of the kernels' guarded fp64 shortcuts against the exact double sequences on n
+    hash-generated inputs (see djb_selftest_guarded_math).  Mismatch counters must be 0."""
+    ctx = ctx or default_context()
+    c = (C.c_ulonglong * 4)()
+    _lib.check(_lib.load().djb_selftest_guarded_math(ctx._h, C.c_int64(n), C.c_uint32(seed), c))
+    return {"rsqrt_mismatch": c[0], "recip_mismatch": c[1], "rsqrt_fallback": c[2], "recip_fallback": c[3]}
+
+
 def merl_guard_stats(i, o, guard=None, ctx: Optional[Context] = None):
     """Calibration of the two-tier MERL kernel on device-resident pairs (see djb_merl_guard_stats)."""
     ctx = ctx or default_context()

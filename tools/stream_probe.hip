@@ -1,0 +1,303 @@
+// stream_probe.hip -- microbenchmark behind DESIGN.md's "achievable bandwidth" figure: the access
+// pattern of the batch kernels (6 SoA float streams in, 3 out, 4 consecutive pairs per lane) with
+// a configurable amount of dependent VALU work per pair, non-temporal or plain accesses, and
+// different grid shapes.  Build: hipcc --offload-arch=gfx950 -O3 tools/stream_probe.hip -o /tmp/stream_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool NT> __device__ inline v4f ld(const v4f *p)
+{
+	return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT> __device__ inline void st(v4f v, v4f *p)
+{
+	if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+template <bool NT, int WORK, int UNROLL>
+__global__ __launch_bounds__(256) void k_probe(const v4f *a0, const v4f *a1, const v4f *a2, const v4f *b0,
+                                               const v4f *b1, const v4f *b2, v4f *c0, v4f *c1, v4f *c2,
+                                               long long n4)
+{
+	long long stride = (long long)gridDim.x * 256 * UNROLL;
+	for (long long q0 = (long long)blockIdx.x * 256 * UNROLL + threadIdx.x; q0 < n4; q0 += stride) {
+		v4f x[UNROLL], y[UNROLL], z[UNROLL], u[UNROLL], v[UNROLL], w[UNROLL];
+#pragma unroll
+		for (int j = 0; j < UNROLL; ++j) {
+			long long q = q0 + j * 256;
+			if (q < n4) {
+				x[j] = ld<NT>(a0 + q); y[j] = ld<NT>(a1 + q); z[j] = ld<NT>(a2 + q);
+				u[j] = ld<NT>(b0 + q); v[j] = ld<NT>(b1 + q); w[j] = ld<NT>(b2 + q);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < UNROLL; ++j) {
+			long long q = q0 + j * 256;
+			if (q < n4) {
+				v4f r = x[j] + u[j], g = y[j] + v[j], b = z[j] + w[j];
+#pragma unroll 8
+				for (int k = 0; k < WORK; ++k) {   // 3 dependent vec4 FMAs = 12 VALU ops per 4 pairs
+					r = r * g + b; g = g * b + r; b = b * r + g;
+				}
+				st<NT>(r, c0 + q); st<NT>(g, c1 + q); st<NT>(b, c2 + q);
+			}
+		}
+	}
+}
+
+// ---- random 12-byte gathers from a table of `entries` texels (uniform over the table), 4 per lane
+// per iteration, with or without the 36 B/pair streams alongside: what the L2 / Infinity Cache sustain.
+struct Texel { float x, y, z; };
+__device__ inline unsigned int pcg(unsigned int v)
+{
+	unsigned int s = v * 747796405u + 2891336453u;
+	unsigned int w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+	return (w >> 22u) ^ w;
+}
+template <int POL> __device__ inline void gload3(float &a, float &b, float &c, const Texel *p)
+{
+	typedef float v3f __attribute__((ext_vector_type(3)));
+	v3f v;
+	if (POL == 0) asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 1) asm volatile("global_load_dwordx3 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 2) asm volatile("global_load_dwordx3 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 3) asm volatile("global_load_dwordx3 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 4) asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 5) asm volatile("global_load_dwordx3 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 6) asm volatile("global_load_dwordx3 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 7) asm volatile("global_load_dwordx3 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	a = v.x; b = v.y; c = v.z;
+}
+template <int POL>
+__global__ __launch_bounds__(256) void k_gather_pol(const Texel *tab, unsigned int entries, v4f *c0, long long n4)
+{
+	long long stride = (long long)gridDim.x * 256;
+	float acc = 0;
+	for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+		unsigned int h = pcg((unsigned int)q * 4u);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			h = pcg(h + j);
+			float a, b, c;
+			gload3<POL>(a, b, c, tab + (unsigned int)(((unsigned long long)h * entries) >> 32));
+			acc += a + b + c;
+		}
+	}
+	if (acc == 123.456f) c0[0] = v4f{ acc, 0, 0, 0 };
+}
+template <int POL>
+static void run_pol(unsigned int entries, float **d, Texel *tab, long long n)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	auto launch = [&]() { hipLaunchKernelGGL((k_gather_pol<POL>), dim3(16384), dim3(256), 0, 0, tab, entries, (v4f *)d[6], n / 4); };
+	launch(); launch();
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 3; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+	printf("gather(serial waits) policy=%d table=%6.2f MB : %7.3f ms  %7.1f G lookups/s\n", POL, entries * 12.0 / 1048576.0, ms, n / ms / 1e6);
+}
+
+template <bool STREAMS>
+__global__ __launch_bounds__(256) void k_gather(const Texel *tab, unsigned int entries, const v4f *a0, const v4f *a1,
+                                                const v4f *a2, const v4f *b0, const v4f *b1, const v4f *b2,
+                                                v4f *c0, v4f *c1, v4f *c2, long long n4)
+{
+	long long stride = (long long)gridDim.x * 256;
+	v4f accr = { 0, 0, 0, 0 };
+	for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+		v4f x = { 0, 0, 0, 0 }, y = x, z = x, u = x, v = x, w = x;
+		if (STREAMS) {
+			x = ld<true>(a0 + q); y = ld<true>(a1 + q); z = ld<true>(a2 + q);
+			u = ld<true>(b0 + q); v = ld<true>(b1 + q); w = ld<true>(b2 + q);
+		}
+		unsigned int h = pcg((unsigned int)q * 4u + (STREAMS ? (unsigned int)(x.x + u.x) : 0u));
+		Texel t[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { h = pcg(h + j); t[j] = tab[(unsigned int)(((unsigned long long)h * entries) >> 32)]; }
+		v4f r = { t[0].x, t[1].x, t[2].x, t[3].x }, g = { t[0].y, t[1].y, t[2].y, t[3].y }, b = { t[0].z, t[1].z, t[2].z, t[3].z };
+		if (STREAMS) {
+			r += y + v; g += z + w;
+			st<true>(r, c0 + q); st<true>(g, c1 + q); st<true>(b, c2 + q);
+		} else accr += r + g + b;
+	}
+	if (!STREAMS && accr.x == 123.456f) c0[0] = accr;
+}
+
+template <bool STREAMS>
+static void run_gather(unsigned int entries, float **d, Texel *tab, long long n)
+{
+	long long n4 = n / 4;
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_gather<STREAMS>), dim3(16384), dim3(256), 0, 0, tab, entries, (const v4f *)d[0],
+		                   (const v4f *)d[1], (const v4f *)d[2], (const v4f *)d[3], (const v4f *)d[4],
+		                   (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n4);
+	};
+	launch(); launch();
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 5; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+	printf("gather streams=%d table=%6.2f MB : %7.3f ms  %7.1f G lookups/s\n", (int)STREAMS, entries * 12.0 / 1048576.0, ms,
+	       n / ms / 1e6);
+}
+
+// ---- streams + gather structure variants (MODE): 0 = 4 gathers in flight after the loads (the shipped
+// kernel's shape); 1 = gathers serialised by a data dependence; 2 = next iteration's streams
+// prefetched before this iteration's gathers; 3 = one pair per lane (dword streams)
+template <int MODE, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_sg(const Texel *tab, unsigned int entries, const v4f *a0, const v4f *a1,
+                                            const v4f *a2, const v4f *b0, const v4f *b1, const v4f *b2,
+                                            v4f *c0, v4f *c1, v4f *c2, long long n4)
+{
+	long long stride = (long long)gridDim.x * 256;
+	if (MODE == 3) {
+		const float *fa0 = (const float *)a0, *fa1 = (const float *)a1, *fa2 = (const float *)a2;
+		const float *fb0 = (const float *)b0, *fb1 = (const float *)b1, *fb2 = (const float *)b2;
+		float *fc0 = (float *)c0, *fc1 = (float *)c1, *fc2 = (float *)c2;
+		for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < 4 * n4; q += stride) {
+			float x = __builtin_nontemporal_load(fa0 + q), y = __builtin_nontemporal_load(fa1 + q), z = __builtin_nontemporal_load(fa2 + q);
+			float u = __builtin_nontemporal_load(fb0 + q), v = __builtin_nontemporal_load(fb1 + q), w = __builtin_nontemporal_load(fb2 + q);
+			unsigned int h = pcg((unsigned int)q + (unsigned int)(x + u));
+			Texel t = tab[(unsigned int)(((unsigned long long)h * entries) >> 32)];
+			__builtin_nontemporal_store(t.x + y + v, fc0 + q); __builtin_nontemporal_store(t.y + z + w, fc1 + q);
+			__builtin_nontemporal_store(t.z, fc2 + q);
+		}
+		return;
+	}
+	long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+	v4f x, y, z, u, v, w;
+	if (MODE == 2 && q < n4) {
+		x = ld<true>(a0 + q); y = ld<true>(a1 + q); z = ld<true>(a2 + q);
+		u = ld<true>(b0 + q); v = ld<true>(b1 + q); w = ld<true>(b2 + q);
+	}
+	for (; q < n4; q += stride) {
+		if (MODE != 2) {
+			x = ld<true>(a0 + q); y = ld<true>(a1 + q); z = ld<true>(a2 + q);
+			u = ld<true>(b0 + q); v = ld<true>(b1 + q); w = ld<true>(b2 + q);
+		}
+		unsigned int h = pcg((unsigned int)q * 4u + (unsigned int)(x.x + u.x));
+		v4f yy = y + v, zz = z + w;
+		if (MODE == 2 && q + stride < n4) {
+			long long qn = q + stride;
+			x = ld<true>(a0 + qn); y = ld<true>(a1 + qn); z = ld<true>(a2 + qn);
+			u = ld<true>(b0 + qn); v = ld<true>(b1 + qn); w = ld<true>(b2 + qn);
+		}
+		Texel t[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			h = pcg(h + j);
+			unsigned int idx = (unsigned int)(((unsigned long long)h * entries) >> 32);
+			if (MODE == 1 && j > 0) idx += (unsigned int)(t[j - 1].x * 0.0f);
+			t[j] = tab[idx];
+		}
+		v4f r = { t[0].x, t[1].x, t[2].x, t[3].x }, g = { t[0].y, t[1].y, t[2].y, t[3].y }, b = { t[0].z, t[1].z, t[2].z, t[3].z };
+		r += yy; g += zz;
+		st<true>(r, c0 + q); st<true>(g, c1 + q); st<true>(b, c2 + q);
+	}
+}
+template <int MODE, int MINW>
+static void run_sg(unsigned int entries, float **d, Texel *tab, long long n, int blocks)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_sg<MODE, MINW>), dim3(blocks), dim3(256), 0, 0, tab, entries, (const v4f *)d[0],
+		                   (const v4f *)d[1], (const v4f *)d[2], (const v4f *)d[3], (const v4f *)d[4],
+		                   (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n / 4);
+	};
+	launch(); launch();
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 3; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+	printf("streams+gather mode=%d minwaves=%d blocks=%6d table=%6.2f MB : %7.3f ms  %7.1f G pairs/s\n", MODE, MINW, blocks,
+	       entries * 12.0 / 1048576.0, ms, n / ms / 1e6);
+}
+
+template <bool NT, int WORK, int UNROLL>
+static void run(const char *name, int blocks, float **d, long long n)
+{
+	long long n4 = n / 4;
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_probe<NT, WORK, UNROLL>), dim3(blocks), dim3(256), 0, 0, (const v4f *)d[0],
+		                   (const v4f *)d[1], (const v4f *)d[2], (const v4f *)d[3], (const v4f *)d[4],
+		                   (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n4);
+	};
+	launch(); launch();
+	hipEventRecord(e0);
+	for (int k = 0; k < 5; ++k) launch();
+	hipEventRecord(e1);
+	hipEventSynchronize(e1);
+	float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+	printf("%-28s nt=%d work=%3d (VALU/pair=%4d) unroll=%d blocks=%7d : %7.3f ms  %7.1f GB/s\n", name, (int)NT, WORK,
+	       WORK * 3, UNROLL, blocks, ms, 36.0 * n / ms / 1e6);
+}
+
+int main(int argc, char **argv)
+{
+	long long n = argc > 1 ? atoll(argv[1]) : 1000000000LL;
+	float *d[9];
+	for (int k = 0; k < 9; ++k) {
+		if (hipMalloc((void **)&d[k], n * sizeof(float)) != hipSuccess) { printf("alloc failed\n"); return 1; }
+		hipMemset(d[k], 0, n * sizeof(float));
+	}
+	int full = (int)((n / 4 + 255) / 256);
+	if (argc > 2) {   // gather mode
+		Texel *tab;
+		if (hipMalloc((void **)&tab, 1458000 * 12 * 4) != hipSuccess) return 1;
+		(void)hipMemset(tab, 0, 1458000 * 12 * 4);
+		const unsigned int sizes[] = { 65536, 262144, 524288, 786432, 1458000, 2916000, 5832000 };
+		if (argv[2][0] == 's') {
+			for (unsigned int e : { 262144u, 1458000u }) {
+				run_sg<0, 1>(e, d, tab, n, 16384); run_sg<1, 1>(e, d, tab, n, 16384); run_sg<2, 1>(e, d, tab, n, 16384);
+				run_sg<3, 1>(e, d, tab, n, 16384); run_sg<0, 1>(e, d, tab, n, 2048); run_sg<0, 1>(e, d, tab, n, 1024);
+				run_sg<0, 1>(e, d, tab, n, 512); run_sg<2, 1>(e, d, tab, n, 2048); run_sg<2, 1>(e, d, tab, n, 1024);
+				run_sg<3, 1>(e, d, tab, n, 65536);
+			}
+			return 0;
+		}
+		if (argv[2][0] == 'p') {
+			for (unsigned int e : { 262144u, 1458000u }) {
+				run_pol<0>(e, d, tab, n); run_pol<1>(e, d, tab, n); run_pol<2>(e, d, tab, n); run_pol<3>(e, d, tab, n);
+				run_pol<4>(e, d, tab, n); run_pol<5>(e, d, tab, n); run_pol<6>(e, d, tab, n); run_pol<7>(e, d, tab, n);
+			}
+			return 0;
+		}
+		for (unsigned int e : sizes) run_gather<false>(e, d, tab, n);
+		for (unsigned int e : sizes) run_gather<true>(e, d, tab, n);
+		return 0;
+	}
+	run<true, 0, 1>("copy", 4096, d, n);
+	run<false, 0, 1>("copy", 4096, d, n);
+	run<true, 0, 1>("copy", full, d, n);
+	run<false, 0, 1>("copy", full, d, n);
+	run<true, 0, 1>("copy", 2048, d, n);
+	run<true, 0, 1>("copy", 8192, d, n);
+	run<true, 0, 1>("copy", 16384, d, n);
+	run<true, 0, 2>("copy", 4096, d, n);
+	run<false, 0, 2>("copy", 4096, d, n);
+	run<true, 0, 4>("copy", 2048, d, n);
+	run<true, 20, 1>("valu", 4096, d, n);
+	run<true, 40, 1>("valu", 4096, d, n);
+	run<true, 60, 1>("valu", 4096, d, n);
+	run<true, 80, 1>("valu", 4096, d, n);
+	run<true, 120, 1>("valu", 4096, d, n);
+	run<false, 60, 1>("valu", 4096, d, n);
+	run<true, 60, 1>("valu", full, d, n);
+	run<true, 60, 2>("valu", 4096, d, n);
+	return 0;
+}

@@ -134,7 +134,9 @@ DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 }
 
 // A&S 7.1.26 as the reference writes it, dj_brdf.h:667-688
-DJB_DEV float erf_(float x)
+// e must be exp(double(-x*x)) (the same for +x and -x): callers that need that exponential
+// themselves (beckmann_qf2_radial) evaluate the fp64 exp once
+DJB_DEV float erf_given_exp(float x, double e)
 {
 	const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f,
 	            a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
@@ -142,9 +144,10 @@ DJB_DEV float erf_(float x)
 	x = fabsf(x);
 	float t = recip_to_f32(1.0 + D(p * x));
 	float poly = ((((a5 * t + a4) * t) + a3) * t + a2) * t + a1;
-	float y = F(1.0 - D(poly * t) * exp(D(-x * x)));
+	float y = F(1.0 - D(poly * t) * e);
 	return sign * y;
 }
+DJB_DEV float erf_(float x) { return erf_given_exp(x, exp(D(-x * x))); }
 
 // Giles' single-precision erfinv, dj_brdf.h:691-721
 DJB_DEV float erfinv_(float u)
@@ -406,11 +409,12 @@ DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k)
 {
 	const float sqrt_pi_inv = F(1. / sqrt(DJB_PI));
 	float cot_k = cos_k / sin_k, tan_k = sin_k / cos_k;
-	float a = -1, c = erf_(cot_k);
+	const double e_cot = exp(D(-cot_k * cot_k));          // shared by erf(cot_k) and the normalization
+	float a = -1, c = erf_given_exp(cot_k, e_cot);
 	u = fmax_(u, 1e-6f);
 	float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
 	float b = c - (1 + c) * powf(1 - u, fit);
-	float normalization = recip_to_f32(D(1 + c) + D(sqrt_pi_inv * tan_k) * exp(D(-cot_k * cot_k)));
+	float normalization = recip_to_f32(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot);
 	int it = 0;
 	while (++it < 10) {
 		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
@@ -517,7 +521,20 @@ DJB_DEV float mf_gaf_from_g1(int shadow, float g1i, float g1o)                  
 
 // eval / evalp / pdf of one pair, sharing h, sigma(o), sigma(i), D (all pure).
 // WANT bits: 1 eval, 2 evalp, 4 pdf.
-template <int KIND, int WANT>
+// FRK >= 0 fixes the Fresnel kind at compile time (the eval kernels are specialised for the two
+// cheap, common cases -- ideal and schlick -- so the fp64 branches of the others cost no registers).
+template <int FRK> DJB_DEV v3 fresnel_eval_k(const Fresnel &f, float c)
+{
+	if (FRK == FR_IDEAL) return mk(1, 1, 1);
+	if (FRK == FR_SCHLICK) {
+		float c1 = 1.0f - c, c2 = c1 * c1, c5 = c2 * c2 * c1;
+		v3 f0 = mk(f.a[0], f.a[1], f.a[2]);
+		return add(f0, scale(c5, sub(mk(1, 1, 1), f0)));
+	}
+	return fresnel_eval(f, c);
+}
+
+template <int KIND, int WANT, int FRK = -1>
 DJB_DEV void mf_eval_pdf(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float &pdf)
 {
 	v3 h = normalize(add(i, o));
@@ -533,7 +550,7 @@ DJB_DEV void mf_eval_pdf(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, flo
 		float oh = dot(o, h);
 		if (WANT & 3) {                                                                      // :1529-1555
 			float cd = sat_(oh);
-			v3 Fr = fresnel_eval(b.fr, cd);
+			v3 Fr = fresnel_eval_k<FRK>(b.fr, cd);
 			v3 e = scale(fdiv4(Dn * G, o.z), Fr);
 			fr = (WANT & 1) ? divs(e, i.z) : e;
 		}

@@ -21,11 +21,11 @@ inline int grid_for(long long n)
 	return (int)blocks;
 }
 
-template <int KIND, int WANT>
+template <int KIND, int WANT, int FRK = -1>
 DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float &pdf)
 {
 	if (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
-		mf_eval_pdf<KIND, WANT>(b, p, i, o, fr, pdf);
+		mf_eval_pdf<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
 	} else {
 		if (WANT & 3) {
 			v3 e;
@@ -40,34 +40,49 @@ DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float 
 	}
 }
 
-template <int KIND, int WANT>
+template <int KIND, int WANT, int FRK>
 __global__ __launch_bounds__(BLOCK, 4) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
-                                                View vout, float *out_pdf)
+                                                   View vout, float *out_pdf)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		v3 i = load3(vi, k), o = load3(vo, k);
 		v3 fr = mk(0, 0, 0); float pdf = 0.0f;
-		eval_one<KIND, WANT>(b, p, i, o, fr, pdf);
+		eval_one<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
 		if (WANT & 3) store3(vout, k, fr);
 		if (WANT & 4) out_pdf[k] = pdf;
 	}
+}
+
+template <int KIND, int FRK>
+hipError_t launch_eval_kind_fr(hipStream_t s, const Brdf &b, const Params &p, long long n,
+                               const View &i, const View &o, const View &out, float *out_pdf, int want)
+{
+	dim3 g(grid_for(n)), t(BLOCK);
+	switch (want) {
+	case 1: hipLaunchKernelGGL((k_eval<KIND, 1, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 2: hipLaunchKernelGGL((k_eval<KIND, 2, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 4: hipLaunchKernelGGL((k_eval<KIND, 4, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 5: hipLaunchKernelGGL((k_eval<KIND, 5, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 6: hipLaunchKernelGGL((k_eval<KIND, 6, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
 }
 
 template <int KIND>
 hipError_t launch_eval_kind(hipStream_t s, const Brdf &b, const Params &p, long long n,
                             const View &i, const View &o, const View &out, float *out_pdf, int want)
 {
-	dim3 g(grid_for(n)), t(BLOCK);
-	switch (want) {
-	case 1: hipLaunchKernelGGL((k_eval<KIND, 1>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	case 2: hipLaunchKernelGGL((k_eval<KIND, 2>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	case 4: hipLaunchKernelGGL((k_eval<KIND, 4>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	case 5: hipLaunchKernelGGL((k_eval<KIND, 5>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	case 6: hipLaunchKernelGGL((k_eval<KIND, 6>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	default: return hipErrorInvalidValue;
+	// the analytic lobes get kernels specialised for the ideal / schlick Fresnel terms; the pdf-only
+	// output (want == 4) never evaluates Fresnel, so it uses the ideal instantiation too
+	if (KIND == KIND_BECKMANN || KIND == KIND_GGX) {
+		if (b.fr.kind == FR_IDEAL || want == 4)
+			return launch_eval_kind_fr<KIND, FR_IDEAL>(s, b, p, n, i, o, out, out_pdf, want);
+		if (b.fr.kind == FR_SCHLICK)
+			return launch_eval_kind_fr<KIND, FR_SCHLICK>(s, b, p, n, i, o, out, out_pdf, want);
 	}
-	return hipGetLastError();
+	return launch_eval_kind_fr<KIND, -1>(s, b, p, n, i, o, out, out_pdf, want);
 }
 
 // ------------------------------------------------------------------ per-pair parameters (LEAN / LEADR)

@@ -19,6 +19,9 @@ batch on its own device ("weak" scaling), there is NO data-path collective; the 
 communication is the barrier and the MAX-over-ranks of the timed region.
 
 Extra objects in the JSON line:
+  secondary     (default workload only) merl_fit_100: wall time of the 100-material MERL fit sharded
+                over the N ranks (material m -> rank m mod N, "strong"); at N=1 also the other
+                single-GPU configs (ggx_eval_pdf, beckmann_sample)
   roofline      dominant kernel: algorithmic bytes per launch / average launch duration
                 (HIP events on the ctx stream over the timed region) vs the 8 TB/s HBM peak
   cpu_baseline  the CPU path timed on this host (rank 0, N=1 only) on a bounded sample:
@@ -122,7 +125,8 @@ def make_step(name, n, djb, synth, ctx, torch):
                                                     C.byref(p._p), C.byref(vout.view)))
         return step, (o, b, p, out, vo, vout)
     if name == "merl_fit":
-        mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=ctx) for k in range(n)]
+        which = range(n) if isinstance(n, int) else n          # an explicit list of material indices (sharded fit)
+        mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=ctx) for k in which]
         result = {}
 
         def step():
@@ -277,6 +281,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
 
+    # BASELINE.json's second figure: wall time of the 100-material MERL fit on N GPUs (strong scaling:
+    # material m -> rank m mod N, no exchange; tables resident in HBM).  Every rank takes part.
+    fit100 = None
+    want_secondary = not args.no_secondary and name == "merl_eval" and args.n is None
+    if want_secondary:
+        del step, keep
+        torch.cuda.empty_cache()
+        st, kp = make_step("merl_fit", list(range(rank, 100, world)), djb, synth, ctx, torch)
+        st()
+        barrier()
+        ctx.timer_start()
+        for _ in range(3):
+            st()
+        fit_ms = ctx.timer_stop_ms() / 3
+        barrier()
+        if world > 1:
+            t = torch.tensor([fit_ms], dtype=torch.float64, device=f"cuda:{local}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fit_ms = float(t[0])
+        fit100 = {"materials": 100, "n_gpus": world, "wall_ms": fit_ms, "scaling": "strong",
+                  "value": 100 / (fit_ms * 1e-3), "unit": "materials/s"}
+        del st, kp
+        torch.cuda.empty_cache()
+
     if rank == 0:
         value = world * n * args.steps / dt
         launch_ms = ev_ms / args.steps
@@ -315,11 +343,11 @@ def main():
             rec["pipeline"] = keep[1].get("timing")   # last step: total / load (read+upload+convert) / fit seconds
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(name, synth)
-        if world == 1 and not args.no_secondary and name == "merl_eval" and args.n is None:
-            sec = {}
-            del keep
-            torch.cuda.empty_cache()
-            for other in ("ggx_eval_pdf", "beckmann_sample", "merl_fit"):
+        if want_secondary and world > 1:
+            rec["secondary"] = {"merl_fit_100": fit100}
+        if want_secondary and world == 1:
+            sec = {"merl_fit_100": fit100}
+            for other in ("ggx_eval_pdf", "beckmann_sample"):
                 on, ob, ou, _ = WORKLOADS[other]
                 st, kp = make_step(other, on, djb, synth, ctx, torch)
                 st(); torch.cuda.synchronize()

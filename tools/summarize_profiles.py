@@ -14,12 +14,13 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles", RND)
 os.makedirs(DST, exist_ok=True)
-DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf": ("k_eval<1, 5>",),
+DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf": ("k_eval<1, 5,",),
             "beckmann_sample": ("k_sample<0",), "merl_fit": ("k_fit<3>",)}
 
 
 def counters(path):
     fs = glob.glob(os.path.join(path, "*", "*_counter_collection.csv"))
+    fs = sorted(fs, key=os.path.getmtime)[-1:]       # gpurun merges runs into the same folder: newest only
     acc, meta = collections.defaultdict(list), {}
     for f in fs:
         for r in csv.DictReader(open(f)):
@@ -30,7 +31,7 @@ def counters(path):
 
 for w in sorted(os.listdir(SRC)):
     d = os.path.join(SRC, w)
-    for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
+    for f in sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
         shutil.copy(f, os.path.join(DST, f"{w}_kernel_stats.csv"))
     for name in ("bench_plain.json", "bench_trace.json"):
         if os.path.exists(os.path.join(d, name)):

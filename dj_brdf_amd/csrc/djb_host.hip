@@ -599,6 +599,33 @@ djb_status djb_brdf_destroy(djb_brdf *b)
 int djb_brdf_kind(const djb_brdf *b) { return b ? b->dev.kind : -1; }
 int djb_brdf_get_shadow(const djb_brdf *b) { return b ? b->dev.shadow : -1; }
 
+static bool is_microfacet_kind(int k)
+{
+	return k == DJB_KIND_BECKMANN || k == DJB_KIND_GGX || k == DJB_KIND_TABULAR || k == DJB_KIND_TABULAR_ANISO;
+}
+
+djb_status djb_brdf_set_shadow(djb_brdf *b, int shadow)
+{
+	if (!b || !is_microfacet_kind(b->dev.kind))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: set_shadow needs a microfacet BRDF");
+	b->dev.shadow = shadow != 0;
+	return DJB_OK;
+}
+
+djb_status djb_brdf_set_fresnel(djb_brdf *b, const djb_fresnel_desc *f)
+{
+	if (!b || !is_microfacet_kind(b->dev.kind))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: set_fresnel needs a microfacet BRDF");
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	// kernels receive the descriptor by value at launch; a replaced spline table stays allocated
+	// until the handle is destroyed, so launches in flight are unaffected
+	djbdev::Fresnel saved = b->dev.fr;
+	std::vector<float> saved_pts = b->fresnel;
+	djb_status st = set_fresnel(b, f);
+	if (st != DJB_OK) { b->dev.fr = saved; b->fresnel = saved_pts; }
+	return st;
+}
+
 // ---------------------------------------------------------------- the fitter
 static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_kind, int res, int shadow,
                           float *alpha_b, float *alpha_g, float *p22, float *sigma, float *cdf,

@@ -482,6 +482,17 @@ class microfacet(brdf):
     def get_shadow(self) -> int:
         return _lib.load().djb_brdf_get_shadow(self._h)
 
+    def set_shadow(self, shadow: bool) -> None:
+        """microfacet::set_shadow, dj_brdf.h:278"""
+        _lib.check(_lib.load().djb_brdf_set_shadow(self._h, C.c_int(1 if shadow else 0)))
+
+    def set_fresnel(self, fresnel_impl) -> None:
+        """microfacet::set_fresnel, dj_brdf.h:279 (e.g. ``tab.set_fresnel(fresnel.ideal())``)"""
+        d, keep = fresnel_impl._desc()
+        _lib.check(_lib.load().djb_brdf_set_fresnel(self._h, C.byref(d)))
+        self._fresnel = fresnel_impl
+        self._fresnel_replaced = True
+
     def get_fresnel(self):
         return self._fresnel
 
@@ -715,6 +726,8 @@ class tabular(microfacet):
         return self._get(3)
 
     def get_fresnel(self):
+        if getattr(self, "_fresnel_replaced", False):
+            return self._fresnel
         return fresnel.spline(self._get(4, 3))
 
     def _alphas(self):
@@ -764,6 +777,8 @@ class tabular_anisotropic(microfacet):
         return self._get({"pdf1": 2, "cdf1": 3, "qf1": 4, "pdf2": 5, "cdf2": 6, "qf2": 7}[name])[0]
 
     def get_fresnel(self):
+        if getattr(self, "_fresnel_replaced", False):
+            return self._fresnel
         return fresnel.spline(self._get(8, 3)[0])
 
     def _fits(self):

@@ -37,6 +37,13 @@ int main()
 		djb::ggx ggs(djb::fresnel::schlick(djb::vec3(1.0f, 0.71f, 0.29f)));
 		djb::vec3 c = ggs.eval(i, o, &iso);
 		expect("ggx+schlick eval.g", c.y, 0.441180676); expect("ggx+schlick eval.b", c.z, 0.180200979);
+		// microfacet::set_fresnel / set_shadow: a mutated plain ggx must equal the schlick-constructed one
+		djb::ggx ggm;
+		ggm.set_fresnel(djb::fresnel::schlick(djb::vec3(1.0f, 0.71f, 0.29f)));
+		c = ggm.eval(i, o, &iso);
+		expect("set_fresnel(schlick) eval.g", c.y, 0.441180676); expect("set_fresnel(schlick) eval.b", c.z, 0.180200979);
+		ggm.set_shadow(false);
+		expect("set_shadow(false) get_shadow", (double)ggm.get_shadow(), 0);
 		djb::vec3 h, d; djb::brdf::io_to_hd(i, o, &h, &d);
 		expect("io_to_hd h.y", h.y, 0.160367534); expect("io_to_hd d.y", d.y, -0.347850591);
 		djb::tabular tab(djb::ggx(), 90);

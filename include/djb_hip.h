@@ -138,6 +138,14 @@ djb_status djb_brdf_destroy(djb_brdf *);
 int        djb_brdf_kind(const djb_brdf *);
 /* microfacet::set_shadow / get_shadow                                 dj_brdf.h:278-281 */
 int        djb_brdf_get_shadow(const djb_brdf *);
+/* The two microfacet mutators (beckmann, ggx, tabular, tabular_anisotropic handles only).  Like the
+ * reference's non-const members they must not race with batch calls on the same handle from other
+ * threads; launches already enqueued keep the state they were launched with.
+ * microfacet::set_shadow(bool)                                        dj_brdf.h:278      */
+djb_status djb_brdf_set_shadow(djb_brdf *, int shadow);
+/* microfacet::set_fresnel(const fresnel::impl &) -- e.g. tab->set_fresnel(fresnel::ideal()) after a
+ * fit (mitsuba/dj_brdf.cpp:214).  NULL = fresnel::ideal.               dj_brdf.h:279, 1521-1525 */
+djb_status djb_brdf_set_fresnel(djb_brdf *, const djb_fresnel_desc *fresnel);
 
 /* ---------------------------------------------------------------- the operator surface */
 /* brdf::eval(i, o, user_param) -> vec3                                dj_brdf.h:77-78   */

@@ -292,6 +292,16 @@ public:
 
 	bool supports_smith_vndf_sampling() const { return djb_brdf_kind(m_h) != DJB_KIND_TABULAR; }
 	int get_shadow() const { return djb_brdf_get_shadow(m_h); }
+	void set_shadow(bool shadow) { hip::check(djb_brdf_set_shadow(m_h, shadow ? 1 : 0)); }          // dj_brdf.h:278
+	void set_fresnel(const fresnel::impl &f)                                                         // dj_brdf.h:1521-1525
+	{
+		const fresnel::impl *copy = f.copy();
+		djb_fresnel_desc d = copy->desc();
+		djb_status st = djb_brdf_set_fresnel(m_h, &d);
+		if (st != DJB_OK) { delete copy; hip::check(st); }
+		delete m_fresnel;
+		m_fresnel = copy;
+	}
 	const fresnel::impl &get_fresnel() const { return *m_fresnel; }
 	virtual ~microfacet() { delete m_fresnel; }
 

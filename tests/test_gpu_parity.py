@@ -268,3 +268,31 @@ def test_guarded_fp64_shortcuts_are_exact(gpu_ctx):
     assert r["rsqrt_mismatch"] == 0 and r["recip_mismatch"] == 0
     assert 0 < r["rsqrt_fallback"] < 2_000_000_000 * 1e-4
     assert 0 < r["recip_fallback"] < 2_000_000_000 * 1e-4
+
+
+def test_microfacet_mutators(gpu_ctx, oracle, dirs):
+    # microfacet::set_fresnel / set_shadow (dj_brdf.h:278-279): a mutated handle must behave exactly
+    # like one constructed with that state, incl. tab->set_fresnel(fresnel::ideal()) (mitsuba/dj_brdf.cpp:214)
+    i, o, _, _ = dirs
+    g = djb.ggx(ctx=gpu_ctx)
+    g.set_fresnel(djb.fresnel.schlick((1.0, 0.71, 0.29)))
+    g.set_shadow(False)
+    assert g.get_shadow() == 0
+    og = oracle.microfacet("ggx", ("schlick", 1.0, 0.71, 0.29), False)
+    got, want = g.eval(i, o), oracle.eval(og, i, o, None, "eval")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    g.set_fresnel(djb.fresnel.spline(np.array([[0.9, 0.5, 0.1], [0.5, 0.5, 0.5], [1.0, 1.0, 1.0]], np.float32)))
+    g.set_shadow(True)
+    og = oracle.microfacet("ggx", ("spline", np.array([[0.9, 0.5, 0.1], [0.5, 0.5, 0.5], [1.0, 1.0, 1.0]], np.float32)), True)
+    got, want = g.evalp(i, o), oracle.eval(og, i, o, None, "evalp")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    t = djb.tabular(djb.ggx(ctx=gpu_ctx), 64, True, ctx=gpu_ctx)
+    fitted = t.eval(i[:4096], o[:4096])
+    t.set_fresnel(djb.fresnel.ideal())
+    assert isinstance(t.get_fresnel(), djb.fresnel.ideal)
+    ideal = t.eval(i[:4096], o[:4096])
+    assert np.isfinite(ideal).all() and not np.array_equal(ideal, fitted)
+    from dj_brdf_amd import _lib
+    lam = djb.lambert(ctx=gpu_ctx)
+    with pytest.raises(djb.exc):                     # not a microfacet BRDF
+        _lib.check(_lib.load().djb_brdf_set_shadow(lam._h, 1))

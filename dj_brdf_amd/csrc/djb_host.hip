@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,10 @@ struct djb_ctx {
 	void *scratch;            // worklist of the two-tier MERL kernel (grown on demand)
 	size_t scratch_bytes;
 	int merl_exact_only;      // DJB_OPT_MERL_EXACT_ONLY
+	// HBM staging blocks of the DJB_MEM_HOST path, recycled across calls (hipMalloc costs more than
+	// a small batch); bounded by POOL_MAX_BYTES
+	std::mutex pool_mu;
+	std::vector<std::pair<void *, size_t>> pool;
 };
 
 struct djb_brdf {
@@ -133,38 +138,124 @@ djb_status device_params(const djb_params *in, Params *out)
 }
 
 // ------------------------------------------------------------------ host <-> HBM staging
-// A staged array is a dense SoA block in HBM; host data of any stride is packed / unpacked on
-// the host side of the copy.  Device-resident callers bypass all of this.
+// DJB_MEM_HOST callers: every array is copied to / from HBM **in the caller's own layout** with
+// plain hipMemcpy straight from / into the caller's memory -- an array of djb::vec3 (stride 3)
+// becomes one 12n-byte copy and the kernels read it with stride 3; SoA (stride 1) arrays are
+// copied per component (one copy when the three are contiguous).  No host-side packing: a
+// single-threaded AoS<->SoA loop runs at ~3 GB/s, the copy itself at ~56 GB/s (tools/pcie_probe.hip).
+// Only exotic strides fall back to a packed SoA block.  Device-resident callers bypass all of this.
+constexpr size_t POOL_MAX_BYTES = 8ull << 30;
+
 struct Staged {
 	djb_ctx *ctx; long long n; int mem;
-	std::vector<void *> blocks;
-	struct Out { View dev; djb_vec3_view host; };
-	struct OutF { float *dev; float *host; };
+	std::vector<std::pair<void *, size_t>> blocks;
+	struct Out { View dev; djb_vec3_view host; int layout; };   // layout: 0 interleaved, 1 SoA stride 1, 2 packed fallback
 	std::vector<Out> outs;
-	std::vector<OutF> outfs;
 	std::vector<std::pair<void *, std::pair<void *, size_t>>> out_raw;   // dev -> (host, bytes)
 
 	Staged(djb_ctx *c, long long n_, int mem_) : ctx(c), n(n_), mem(mem_) {}
-	~Staged() { for (void *b : blocks) (void)hipFree(b); }
+	~Staged()
+	{
+		if (blocks.empty()) return;
+		std::lock_guard<std::mutex> g(ctx->pool_mu);
+		size_t total = 0;
+		for (auto &p : ctx->pool) total += p.second;
+		for (auto &b : blocks) {
+			if (total + b.second <= POOL_MAX_BYTES && ctx->pool.size() < 32) { ctx->pool.push_back(b); total += b.second; }
+			else (void)hipFree(b.first);
+		}
+	}
 
+	// One pageable copy at a time: the runtime pins the caller's pages for the duration of an
+	// asynchronous copy, and two in-flight copies whose host ranges share a page (x/y/z of one SoA
+	// allocation, or two small heap arrays) fail with hipErrorInvalidValue.
+	djb_status copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+	{
+		hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+		if (e != hipSuccess) {
+			hipPointerAttribute_t ad, as;
+			hipError_t e1 = hipPointerGetAttributes(&ad, dst), e2 = hipPointerGetAttributes(&as, src);
+			(void)hipGetLastError();
+			return fail(DJB_ERR_HIP, "djb_error: staging copy failed (%s): dst %p [attr %d type %d dev %d] src %p [attr %d type %d dev %d] "
+			            "bytes %zu kind %d n %lld", hipGetErrorString(e), dst, (int)e1, e1 == hipSuccess ? (int)ad.type : -1,
+			            e1 == hipSuccess ? ad.device : -1, src, (int)e2, e2 == hipSuccess ? (int)as.type : -1,
+			            e2 == hipSuccess ? as.device : -1, bytes, (int)kind, n);
+		}
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		return DJB_OK;
+	}
 	static bool valid(const djb_vec3_view *v) { return v && v->x && v->y && v->z; }
+	static int layout_of(const djb_vec3_view *v)
+	{
+		if (v->stride == 3 && v->y == v->x + 1 && v->z == v->x + 2) return 0;
+		if (v->stride == 1) return 1;
+		return 2;
+	}
+
+	djb_status alloc(size_t bytes, void **out)
+	{
+		if (bytes == 0) bytes = 4;
+		{
+			std::lock_guard<std::mutex> g(ctx->pool_mu);
+			int best = -1;
+			for (int k = 0; k < (int)ctx->pool.size(); ++k)
+				if (ctx->pool[k].second >= bytes && (best < 0 || ctx->pool[k].second < ctx->pool[best].second)) best = k;
+			if (best >= 0 && ctx->pool[best].second <= 2 * bytes + (1u << 20)) {
+				blocks.push_back(ctx->pool[best]);
+				*out = ctx->pool[best].first;
+				ctx->pool.erase(ctx->pool.begin() + best);
+				return DJB_OK;
+			}
+		}
+		void *d = nullptr;
+		hipError_t e = hipMalloc(&d, bytes);
+		if (e != hipSuccess) {   // give the recycled blocks back and retry once
+			(void)hipGetLastError();
+			std::lock_guard<std::mutex> g(ctx->pool_mu);
+			for (auto &p : ctx->pool) (void)hipFree(p.first);
+			ctx->pool.clear();
+			e = hipMalloc(&d, bytes);
+		}
+		HIP_TRY(e);
+		blocks.push_back({ d, bytes });
+		*out = d;
+		return DJB_OK;
+	}
 
 	djb_status in_vec(const djb_vec3_view *v, View *out)
 	{
 		if (!valid(v)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
 		if (mem == DJB_MEM_DEVICE) { *out = View{ v->x, v->y, v->z, (long long)v->stride }; return DJB_OK; }
 		float *d = nullptr;
-		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
-		blocks.push_back(d);
-		std::vector<float> pack(3 * (size_t)n);
-		for (long long k = 0; k < n; ++k) {
-			pack[k] = v->x[k * v->stride];
-			pack[n + k] = v->y[k * v->stride];
-			pack[2 * n + k] = v->z[k * v->stride];
+		djb_status st = alloc(sizeof(float) * 3 * (size_t)n, (void **)&d);
+		if (st != DJB_OK) return st;
+		const size_t nb = sizeof(float) * (size_t)n;
+		switch (layout_of(v)) {
+		case 0:
+			if (n) { djb_status cs_ = copy(d, v->x, 3 * nb, hipMemcpyHostToDevice); if (cs_ != DJB_OK) return cs_; }
+			*out = View{ d, d + 1, d + 2, 3 };
+			break;
+		case 1:
+			if (n && v->y == v->x + n && v->z == v->x + 2 * n) { djb_status cs_ = copy(d, v->x, 3 * nb, hipMemcpyHostToDevice); if (cs_ != DJB_OK) return cs_; }
+			else if (n) {
+				{ djb_status cs_ = copy(d, v->x, nb, hipMemcpyHostToDevice); if (cs_ != DJB_OK) return cs_; }
+				{ djb_status cs_ = copy(d + n, v->y, nb, hipMemcpyHostToDevice); if (cs_ != DJB_OK) return cs_; }
+				{ djb_status cs_ = copy(d + 2 * n, v->z, nb, hipMemcpyHostToDevice); if (cs_ != DJB_OK) return cs_; }
+			}
+			*out = View{ d, d + n, d + 2 * n, 1 };
+			break;
+		default: {
+			std::vector<float> pack(3 * (size_t)n);
+			for (long long k = 0; k < n; ++k) {
+				pack[k] = v->x[k * v->stride];
+				pack[n + k] = v->y[k * v->stride];
+				pack[2 * n + k] = v->z[k * v->stride];
+			}
+			if (n) { djb_status cs_ = copy(d, pack.data(), 3 * nb, hipMemcpyHostToDevice); if (cs_ != DJB_OK) return cs_; }
+			HIP_TRY(hipStreamSynchronize(ctx->stream));   // pack goes out of scope
+			*out = View{ d, d + n, d + 2 * n, 1 };
 		}
-		HIP_TRY(hipMemcpyAsync(d, pack.data(), sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));   // pack goes out of scope
-		*out = View{ d, d + n, d + 2 * n, 1 };
+		}
 		return DJB_OK;
 	}
 	djb_status in_f(const float *h, const float **out)
@@ -172,9 +263,9 @@ struct Staged {
 		if (!h) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null input array");
 		if (mem == DJB_MEM_DEVICE) { *out = h; return DJB_OK; }
 		float *d = nullptr;
-		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * (size_t)(n > 0 ? n : 1)));
-		blocks.push_back(d);
-		HIP_TRY(hipMemcpyAsync(d, h, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		djb_status st = alloc(sizeof(float) * (size_t)n, (void **)&d);
+		if (st != DJB_OK) return st;
+		if (n) { djb_status cs_ = copy(d, h, sizeof(float) * (size_t)n, hipMemcpyHostToDevice); if (cs_ != DJB_OK) return cs_; }
 		*out = d;
 		return DJB_OK;
 	}
@@ -183,10 +274,11 @@ struct Staged {
 		if (!valid(v)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null output vec3 view");
 		if (mem == DJB_MEM_DEVICE) { *out = View{ v->x, v->y, v->z, (long long)v->stride }; return DJB_OK; }
 		float *d = nullptr;
-		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
-		blocks.push_back(d);
-		*out = View{ d, d + n, d + 2 * n, 1 };
-		outs.push_back(Out{ *out, *v });
+		djb_status st = alloc(sizeof(float) * 3 * (size_t)n, (void **)&d);
+		if (st != DJB_OK) return st;
+		int lay = layout_of(v);
+		*out = lay == 0 ? View{ d, d + 1, d + 2, 3 } : View{ d, d + n, d + 2 * n, 1 };
+		outs.push_back(Out{ *out, *v, lay });
 		return DJB_OK;
 	}
 	template <typename T> djb_status out_arr(T *h, T **out)
@@ -194,8 +286,8 @@ struct Staged {
 		if (!h) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null output array");
 		if (mem == DJB_MEM_DEVICE) { *out = h; return DJB_OK; }
 		T *d = nullptr;
-		HIP_TRY(hipMalloc((void **)&d, sizeof(T) * (size_t)(n > 0 ? n : 1)));
-		blocks.push_back(d);
+		djb_status st = alloc(sizeof(T) * (size_t)n, (void **)&d);
+		if (st != DJB_OK) return st;
 		out_raw.push_back({ d, { h, sizeof(T) * (size_t)n } });
 		*out = d;
 		return DJB_OK;
@@ -203,18 +295,31 @@ struct Staged {
 	djb_status finish()
 	{
 		if (mem == DJB_MEM_DEVICE) return DJB_OK;
-		std::vector<float> pack(3 * (size_t)n);
+		const size_t nb = sizeof(float) * (size_t)n;
 		for (auto &o : outs) {
-			HIP_TRY(hipMemcpyAsync(pack.data(), o.dev.x, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-			HIP_TRY(hipStreamSynchronize(ctx->stream));
-			for (long long k = 0; k < n; ++k) {
-				o.host.x[k * o.host.stride] = pack[k];
-				o.host.y[k * o.host.stride] = pack[n + k];
-				o.host.z[k * o.host.stride] = pack[2 * n + k];
+			if (!n) continue;
+			if (o.layout == 0) { djb_status cs_ = copy(o.host.x, o.dev.x, 3 * nb, hipMemcpyDeviceToHost); if (cs_ != DJB_OK) return cs_; }
+			else if (o.layout == 1) {
+				if (o.host.y == o.host.x + n && o.host.z == o.host.x + 2 * n)
+					{ djb_status cs_ = copy(o.host.x, o.dev.x, 3 * nb, hipMemcpyDeviceToHost); if (cs_ != DJB_OK) return cs_; }
+				else {
+					{ djb_status cs_ = copy(o.host.x, o.dev.x, nb, hipMemcpyDeviceToHost); if (cs_ != DJB_OK) return cs_; }
+					{ djb_status cs_ = copy(o.host.y, o.dev.y, nb, hipMemcpyDeviceToHost); if (cs_ != DJB_OK) return cs_; }
+					{ djb_status cs_ = copy(o.host.z, o.dev.z, nb, hipMemcpyDeviceToHost); if (cs_ != DJB_OK) return cs_; }
+				}
+			} else {
+				std::vector<float> pack(3 * (size_t)n);
+				{ djb_status cs_ = copy(pack.data(), o.dev.x, 3 * nb, hipMemcpyDeviceToHost); if (cs_ != DJB_OK) return cs_; }
+				HIP_TRY(hipStreamSynchronize(ctx->stream));
+				for (long long k = 0; k < n; ++k) {
+					o.host.x[k * o.host.stride] = pack[k];
+					o.host.y[k * o.host.stride] = pack[n + k];
+					o.host.z[k * o.host.stride] = pack[2 * n + k];
+				}
 			}
 		}
 		for (auto &o : out_raw)
-			HIP_TRY(hipMemcpyAsync(o.second.first, o.first, o.second.second, hipMemcpyDeviceToHost, ctx->stream));
+			if (o.second.second) { djb_status cs_ = copy(o.second.first, o.first, o.second.second, hipMemcpyDeviceToHost); if (cs_ != DJB_OK) return cs_; }
 		HIP_TRY(hipStreamSynchronize(ctx->stream));
 		return DJB_OK;
 	}
@@ -414,6 +519,7 @@ djb_status djb_ctx_destroy(djb_ctx *ctx)
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
+	for (auto &p : ctx->pool) (void)hipFree(p.first);
 	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 	return DJB_OK;
@@ -1094,9 +1200,8 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
 	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
 	if (mem == DJB_MEM_HOST) {
 		float *d = nullptr;
-		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 5 * (size_t)(n > 0 ? n : 1)));
-		sg.blocks.push_back(d);
-		HIP_TRY(hipMemcpyAsync(d, rec, sizeof(float) * 5 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		if ((st = sg.alloc(sizeof(float) * 5 * (size_t)n, (void **)&d)) != DJB_OK) return st;
+		if (n && (st = sg.copy(d, rec, sizeof(float) * 5 * (size_t)n, hipMemcpyHostToDevice)) != DJB_OK) return st;
 		drec = d;
 	}
 	if ((want & 3) && (st = sg.out_vec(out_fr, &vout)) != DJB_OK) return st;
@@ -1104,8 +1209,7 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
 	if (out_pp) {
 		if (mem == DJB_MEM_DEVICE) dpp = out_pp;
 		else {
-			HIP_TRY(hipMalloc((void **)&dpp, sizeof(float) * 5 * (size_t)(n > 0 ? n : 1)));
-			sg.blocks.push_back(dpp);
+			if ((st = sg.alloc(sizeof(float) * 5 * (size_t)n, (void **)&dpp)) != DJB_OK) return st;
 			sg.out_raw.push_back({ dpp, { out_pp, sizeof(float) * 5 * (size_t)n } });
 		}
 	}

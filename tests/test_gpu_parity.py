@@ -296,3 +296,41 @@ def test_microfacet_mutators(gpu_ctx, oracle, dirs):
     lam = djb.lambert(ctx=gpu_ctx)
     with pytest.raises(djb.exc):                     # not a microfacet BRDF
         _lib.check(_lib.load().djb_brdf_set_shadow(lam._h, 1))
+
+
+def test_host_views_of_any_layout(gpu_ctx, dirs):
+    # DJB_MEM_HOST copies the caller's own layout (interleaved vec3, contiguous SoA, three separate
+    # component arrays) and only packs exotic strides (here: padded float4 records); all must agree
+    import ctypes as C
+    from dj_brdf_amd import _lib
+    lib = _lib.load()
+    i, o, _, _ = dirs
+    n = 10_007
+    i, o = np.ascontiguousarray(i[:n]), np.ascontiguousarray(o[:n])
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    want = g.eval(i, o)                                            # interleaved in, interleaved out
+
+    def view(x, y, z, stride):
+        v = _lib.Vec3View(); v.x, v.y, v.z, v.stride = x, y, z, stride
+        return v
+
+    def run(vi, vo, vout):
+        _lib.check(lib.djb_eval_batch(gpu_ctx._h, g._h, C.c_int64(n), C.byref(vi), C.byref(vo), None, C.byref(vout),
+                                      C.c_int(_lib.MEM_HOST)))
+
+    # three separately allocated component arrays (SoA, not contiguous with each other)
+    ic = [np.ascontiguousarray(i[:, c]) for c in range(3)]; oc = [np.ascontiguousarray(o[:, c]) for c in range(3)]
+    rc = [np.full(n, np.nan, np.float32) for _ in range(3)]
+    run(view(*[a.ctypes.data for a in ic], 1), view(*[a.ctypes.data for a in oc], 1), view(*[a.ctypes.data for a in rc], 1))
+    assert np.array_equal(np.stack(rc, 1).view(np.uint32), want.view(np.uint32))
+    # padded float4 records (stride 4): the packed fallback, input and output
+    i4 = np.zeros((n, 4), np.float32); i4[:, :3] = i
+    o4 = np.zeros((n, 4), np.float32); o4[:, :3] = o
+    r4 = np.full((n, 4), 7.0, np.float32)
+    b = lambda a: a.ctypes.data
+    run(view(b(i4), b(i4) + 4, b(i4) + 8, 4), view(b(o4), b(o4) + 4, b(o4) + 8, 4), view(b(r4), b(r4) + 4, b(r4) + 8, 4))
+    assert np.array_equal(r4[:, :3].view(np.uint32), want.view(np.uint32)) and (r4[:, 3] == 7.0).all()
+    # mixed: SoA in, interleaved out
+    r = np.empty((n, 3), np.float32)
+    run(view(*[a.ctypes.data for a in ic], 1), view(b(o4), b(o4) + 4, b(o4) + 8, 4), view(b(r), b(r) + 4, b(r) + 8, 3))
+    assert np.array_equal(r.view(np.uint32), want.view(np.uint32))

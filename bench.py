@@ -13,6 +13,7 @@ Workloads (BASELINE.json configs):
   ggx_eval_pdf     configs[1]: GGX isotropic conductor eval()+pdf() fused, 1e8 pairs, alpha = 0.3
   beckmann_sample  configs[3]: Beckmann elliptic(0.2,0.5,0.7) VNDF sample(), 1e9 samples, on-chip RNG
   merl_fit         configs[4]: power-iteration fit of 100 MERL materials resident in HBM
+  utia_eval        (no BASELINE config; north_star names UTIA tables) utia::eval over 1e8 pairs
 
 Multi-GPU (torchrun, one rank per GPU): units are independent, every rank runs the same per-GPU
 batch on its own device ("weak" scaling), there is NO data-path collective; the only
@@ -48,6 +49,7 @@ WORKLOADS = {
     "merl_eval": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval> (two-tier exact)"),
     "ggx_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf>"),
     "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample<BECKMANN,rng>"),
+    "utia_eval": (100_000_000, 36, "evals", "k_eval<UTIA,eval>"),
     "merl_fit": (100, None, "materials", "k_fit<MERL>"),
     # end to end: 100 MERL files (34 992 012 B each) on local disk -> params: pread + PCIe + convert + fit
     "merl_fit_files": (100, None, "materials", "djb_fit_merl_files (reader threads -> pinned ring -> H2D -> k_merl_convert -> k_fit<MERL>)"),
@@ -124,6 +126,19 @@ def make_step(name, n, djb, synth, ctx, torch):
                                                     C.c_uint32(synth.SEED_U2), C.c_uint64(0), C.byref(vo.view),
                                                     C.byref(p._p), C.byref(vout.view)))
         return step, (o, b, p, out, vo, vout)
+    if name == "utia_eval":
+        i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
+        o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
+        tab = np.random.default_rng(11).uniform(0.0, 120.0, size=3 * 288 * 288)   # UTIA-format payload (sRGB-coded * 140)
+        u = djb.utia.from_table(tab, ctx=ctx)
+        out = torch.empty((3, n), dtype=torch.float32, device=i.device)
+        lib, C = djb._lib.load(), ctypes
+        vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
+
+        def step():
+            djb._lib.check(lib.djb_eval_batch(ctx._h, u._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                              None, C.byref(vout.view), C.c_int(0)))
+        return step, (i, o, u, out, vi, vo, vout)
     if name == "merl_fit":
         which = range(n) if isinstance(n, int) else n          # an explicit list of material indices (sharded fit)
         mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=ctx) for k in which]
@@ -164,6 +179,10 @@ def cpu_baseline(name, synth, budget_s=12.0):
         b, op, par = L.microfacet("ggx", ("ideal",), True), "eval", ("elliptic", 0.3, 0.3, 0.0)
     elif name == "beckmann_sample":
         b, op, par = L.microfacet("beckmann", ("ideal",), True), "sample", ("elliptic", 0.2, 0.5, 0.7)
+    elif name == "utia_eval":
+        path = "/tmp/djb_bench_cpu_utia.bin"
+        np.random.default_rng(11).uniform(0.0, 120.0, size=3 * 288 * 288).tofile(path)
+        b, op = L.utia(path), "eval"
     elif name == "merl_fit_files":   # the reference's own driver (examples/merl_params.cpp) on a few of the files
         import subprocess
         exe = os.path.join(ROOT, "oracle", "_ref", "merl_params")
@@ -333,6 +352,7 @@ def main():
                        "brdf": {"merl_eval": "MERL 90x90x180x3 nearest-bin (synthetic GGX0.3+diffuse table)",
                                 "ggx_eval_pdf": "GGX isotropic alpha=0.3, ideal Fresnel, eval+pdf fused",
                                 "beckmann_sample": "Beckmann elliptic(0.2,0.5,0.7) VNDF sample, on-chip RNG",
+                                "utia_eval": "UTIA 6x48x6x48x3 table, 16-tap interpolation + sRGB decode (synthetic payload)",
                                 "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material, tables resident in HBM",
                                 "merl_fit_files": "files on local disk -> pread -> PCIe -> k_merl_convert -> "
                                                   "tabular(merl, 90) + both fits (end to end)"}[name],

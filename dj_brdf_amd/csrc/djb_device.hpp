@@ -42,7 +42,7 @@ struct Brdf {
 	const float *p22, *sigma, *cdf, *qf;   // tabular tables (device)
 	int n_p22, n_sigma, n_cdf, n_qf;
 	const MerlTexel *merl;                  // [1458000] pre-scaled float RGB; below-horizon -> 0
-	const float *utia;                      // [3*288*288] float(normalized double sample)
+	const float4 *utia;                     // [288*288][2] records {R,G,B @ phi_v bin, R | G,B @ phi_v bin + 1, 0, 0} (UTIA_REC)
 	const double *model;                    // sgd: 33 doubles, abc: 9 doubles (one published table row)
 	// tabular_anisotropic: p22 / sigma above are elev x azim grids (element (i, j) at [i + elev*j]);
 	// two-level sampling tables below (dj_brdf.h:429-438)
@@ -832,26 +832,34 @@ DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 	sum = wpv[0] + wpv[1]; wpv[0] /= sum; wpv[1] /= sum;
 	if (ipi1 == 48) ipi1 = 0;
 	if (ipv1 == 48) ipv1 = 0;
-	int iti[2] = { iti0, iti1 }, itv[2] = { itv0, itv1 }, ipi[2] = { ipi0, ipi1 }, ipv[2] = { ipv0, ipv1 };
+	int iti[2] = { iti0, iti1 }, itv[2] = { itv0, itv1 }, ipi[2] = { ipi0, ipi1 };
+	(void)ipv1;
+	// The reference walks the three colour planes one after the other, 16 taps each (48 scattered
+	// 4-byte reads).  The HBM table stores, per (theta_i, phi_i, theta_v, phi_v) node, the RGB of that
+	// node AND of its phi_v + 1 neighbour (wrapped) in one 32-byte record, so the 16 taps are 8
+	// aligned 32-byte gathers; each plane still accumulates its 16 terms in the reference's order
+	// (a, c, k, l nested, l innermost), so the sums are bit-identical.
+	float acc[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+	for (int a = 0; a < 2; ++a)
+#pragma unroll
+	for (int c = 0; c < 2; ++c)
+#pragma unroll
+	for (int k = 0; k < 2; ++k) {
+		int e = 288 * (48 * iti[a] + ipi[k]) + 48 * itv[c] + ipv0;
+		float4 r0 = b.utia[2 * e], r1 = b.utia[2 * e + 1];
+		float w0 = wti[a] * wtv[c] * wpi[k] * wpv[0], w1 = wti[a] * wtv[c] * wpi[k] * wpv[1];
+		acc[0] += w0 * r0.x; acc[0] += w1 * r0.w;
+		acc[1] += w0 * r0.y; acc[1] += w1 * r1.x;
+		acc[2] += w0 * r0.z; acc[2] += w1 * r1.y;
+	}
 	float RGB[3];
 #pragma unroll
 	for (int isp = 0; isp < 3; ++isp) {
-		float acc = 0.0f;
-#pragma unroll
-		for (int a = 0; a < 2; ++a)
-#pragma unroll
-		for (int c = 0; c < 2; ++c)
-#pragma unroll
-		for (int k = 0; k < 2; ++k)
-#pragma unroll
-		for (int l = 0; l < 2; ++l) {
-			float w = wti[a] * wtv[c] * wpi[k] * wpv[l];
-			int idx = isp * 288 * 288 + 288 * (48 * iti[a] + ipi[k]) + 48 * itv[c] + ipv[l];
-			acc += w * b.utia[idx];
-		}
-		if (D(acc) > 0.0375) acc = F(pow(D(F(D(acc) + 0.055)) / 1.055, D(2.4f)));
-		else acc /= 12.92f;
-		RGB[isp] = acc * 100.0f;
+		float v = acc[isp];
+		if (D(v) > 0.0375) v = F(pow(D(F(D(v) + 0.055)) / 1.055, D(2.4f)));
+		else v /= 12.92f;
+		RGB[isp] = v * 100.0f;
 	}
 	return mk(fmax_(0.f, RGB[0]), fmax_(0.f, RGB[1]), fmax_(0.f, RGB[2]));
 }

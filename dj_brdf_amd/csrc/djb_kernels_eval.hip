@@ -40,8 +40,13 @@ DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float 
 	}
 }
 
+// min-waves hint: the analytic / tabulated microfacet kernels fit 128 VGPRs (occupancy 4); the
+// fp64-libm-heavy kinds (utia, sgd, abc, exact merl) are left to the register allocator
+#ifndef DJB_EVAL_MINW_OTHER
+#define DJB_EVAL_MINW_OTHER 1
+#endif
 template <int KIND, int WANT, int FRK>
-__global__ __launch_bounds__(BLOCK, 4) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
+__global__ __launch_bounds__(BLOCK, (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) ? 4 : DJB_EVAL_MINW_OTHER) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
                                                    View vout, float *out_pdf)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
@@ -76,7 +81,7 @@ hipError_t launch_eval_kind(hipStream_t s, const Brdf &b, const Params &p, long 
 {
 	// the analytic lobes get kernels specialised for the ideal / schlick Fresnel terms; the pdf-only
 	// output (want == 4) never evaluates Fresnel, so it uses the ideal instantiation too
-	if (KIND == KIND_BECKMANN || KIND == KIND_GGX) {
+	if constexpr (KIND == KIND_BECKMANN || KIND == KIND_GGX) {
 		if (b.fr.kind == FR_IDEAL || want == 4)
 			return launch_eval_kind_fr<KIND, FR_IDEAL>(s, b, p, n, i, o, out, out_pdf, want);
 		if (b.fr.kind == FR_SCHLICK)
@@ -270,13 +275,18 @@ __global__ __launch_bounds__(BLOCK) void k_merl_convert(const double *s, long lo
 }
 
 // utia::normalize (dj_brdf.h:1162-1177) then the (float_t) cast of dj_brdf.h:1144
-__global__ __launch_bounds__(BLOCK) void k_utia_convert(const double *s, long long n, float *table)
+// n = 3*288*288 samples (three planes) -> 288*288 records of two float4: the node's RGB and the RGB of
+// its phi_v + 1 neighbour (wrapped at 48), see utia_eval
+__global__ __launch_bounds__(BLOCK) void k_utia_convert(const double *s, long long n, float4 *table)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
 	const float kf = 1.f / 140.f;
-	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-		double v = s[k] > 0.0 ? s[k] : 0.0;
-		table[k] = F(v * D(kf));
+	const long long plane = n / 3;
+	auto conv = [&](long long k) { double v = s[k] > 0.0 ? s[k] : 0.0; return F(v * D(kf)); };
+	for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < plane; e += stride) {
+		long long ipv = e % 48, e1 = e - ipv + (ipv + 1) % 48;
+		table[2 * e] = make_float4(conv(e), conv(plane + e), conv(2 * plane + e), conv(e1));
+		table[2 * e + 1] = make_float4(conv(plane + e1), conv(2 * plane + e1), 0.0f, 0.0f);
 	}
 }
 
@@ -441,7 +451,7 @@ hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n
 	return hipGetLastError();
 }
 
-hipError_t launch_utia_convert(hipStream_t s, const double *samples, long long n, float *table)
+hipError_t launch_utia_convert(hipStream_t s, const double *samples, long long n, float4 *table)
 {
 	hipLaunchKernelGGL(k_utia_convert, dim3(grid_for(n)), dim3(BLOCK), 0, s, samples, n, table);
 	return hipGetLastError();

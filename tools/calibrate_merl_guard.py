@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Calibration of the two-tier MERL kernel's guard bands (run on the GPU box): max |fp32 estimate -
+reference| / band per coordinate and the certain/ambiguous/mismatch counters over N x 2.5e8 pairs
+(DESIGN.md 4.2).  PYTHONPATH=. python tools/calibrate_merl_guard.py [N]"""
 import sys, time, numpy as np, torch
 from dj_brdf_amd import djb, synth
 ctx = djb.default_context(0)

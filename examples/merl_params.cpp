@@ -3,11 +3,17 @@
 // Counterpart of the reference's driver (jdupuy/dj_brdf examples/merl_params.cpp:30-73) written
 // against the djb:: facade of this repository (include/djb_hip.hpp): same command line, same
 // params.txt ("# MERL Beckmann GGX", then "name %.3f %.3f" per input, in input order).
-// Build: make -C examples      Run: ./merl_params a.binary b.binary ...
+//
+// Default mode: the files are dealt round-robin to every visible GPU (one host thread + one
+// context/stream per GPU, no exchange between GPUs); each GPU runs the native pipeline
+// djb_fit_merl_files (reader threads -> pinned ring -> async upload -> conversion -> ONE fit launch).
+// `-s` runs the reference's own loop shape instead (load, fit, next file) on the djb:: classes.
+// Build: make -C examples      Run: ./merl_params [-s] [-g N] a.binary b.binary ...
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "djb_hip.hpp"
@@ -28,8 +34,9 @@ std::string material_name(const char *path)
 void usage(const char *app)
 {
 	printf("%s - GGX and Beckmann Parameters for MERL BRDFs (MI355X)\n\n", app);
-	printf("Usage\n  %s merl1.binary merl2.binary ...\n\n", app);
-	printf("Options\n  -h\n     Print help\n\n");
+	printf("Usage\n  %s [-s] [-g N] merl1.binary merl2.binary ...\n\n", app);
+	printf("Options\n  -h\n     Print help\n  -s\n     One file at a time on the djb:: classes (the reference's loop)\n"
+	       "  -g N\n     Use N GPUs (default: all)\n\n");
 }
 
 } // namespace
@@ -37,31 +44,63 @@ void usage(const char *app)
 int main(int argc, char **argv)
 {
 	if (argc < 2) { usage(argv[0]); return EXIT_SUCCESS; }
-	for (int i = 1; i < argc; ++i)
+	bool sequential = false;
+	int gpus = 0;
+	std::vector<const char *> files;
+	for (int i = 1; i < argc; ++i) {
 		if (!strcmp("-h", argv[i])) { usage(argv[0]); return EXIT_SUCCESS; }
+		else if (!strcmp("-s", argv[i])) sequential = true;
+		else if (!strcmp("-g", argv[i]) && i + 1 < argc) gpus = atoi(argv[++i]);
+		else files.push_back(argv[i]);
+	}
+	const int n = (int)files.size();
+	std::vector<float> beckmann(n), ggx(n);
 
-	struct row { std::string name; float beckmann, ggx; };
-	std::vector<row> rows;
-	try {
-		for (int i = 1; i < argc; ++i) {
-			djb::merl merl(argv[i]);                       // upload + float4 table in HBM
-			djb::tabular tab(merl, 90);                    // power-iteration fit kernel
-			row r; float dummy;
-			r.name = material_name(argv[i]);
-			djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&r.beckmann, &dummy, NULL);
-			djb::tabular::fit_ggx_parameters(tab).get_ellipse(&r.ggx, &dummy, NULL);
-			rows.push_back(r);
+	if (sequential) {
+		try {
+			for (int k = 0; k < n; ++k) {
+				djb::merl merl(files[k]);                      // upload + packed RGB table in HBM
+				djb::tabular tab(merl, 90);                    // power-iteration fit kernel
+				float dummy;
+				djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&beckmann[k], &dummy, NULL);
+				djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ggx[k], &dummy, NULL);
+			}
+		} catch (const djb::exc &e) {
+			fprintf(stderr, "%s", e.what());
+			return EXIT_FAILURE;
 		}
-	} catch (const djb::exc &e) {
-		fprintf(stderr, "%s", e.what());
-		return EXIT_FAILURE;
+	} else {
+		int n_dev = djb::hip::context::device_count();
+		if (n_dev <= 0) { fprintf(stderr, "djb_error: no HIP device; there is no CPU path\n"); return EXIT_FAILURE; }
+		if (gpus <= 0 || gpus > n_dev) gpus = n_dev;
+		if (gpus > n && n > 0) gpus = n;
+		std::vector<std::string> errors(gpus);
+		std::vector<std::thread> workers;
+		for (int g = 0; g < gpus; ++g)
+			workers.push_back(std::thread([&, g]() {
+				std::vector<const char *> mine;            // material m -> GPU m mod G
+				std::vector<int> index;
+				for (int k = g; k < n; k += gpus) { mine.push_back(files[k]); index.push_back(k); }
+				if (mine.empty()) return;
+				std::vector<float> ab(mine.size()), ag(mine.size());
+				djb_ctx *ctx = NULL;
+				djb_status st = djb_ctx_create(g, &ctx);
+				if (st == DJB_OK)
+					st = djb_fit_merl_files(ctx, (int)mine.size(), &mine[0], 90, 1, 0, &ab[0], &ag[0], NULL);
+				if (st != DJB_OK) errors[g] = djb_last_error();
+				if (ctx) djb_ctx_destroy(ctx);
+				for (size_t j = 0; j < index.size(); ++j) { beckmann[index[j]] = ab[j]; ggx[index[j]] = ag[j]; }
+			}));
+		for (size_t g = 0; g < workers.size(); ++g) workers[g].join();
+		for (int g = 0; g < gpus; ++g)
+			if (!errors[g].empty()) { fprintf(stderr, "%s", errors[g].c_str()); return EXIT_FAILURE; }
 	}
 
 	FILE *pf = fopen("params.txt", "w");
 	if (!pf) { perror("params.txt"); return EXIT_FAILURE; }
 	fprintf(pf, "# MERL Beckmann GGX\n");
-	for (size_t k = 0; k < rows.size(); ++k)
-		fprintf(pf, "%s %.3f %.3f\n", rows[k].name.c_str(), rows[k].beckmann, rows[k].ggx);
+	for (int k = 0; k < n; ++k)
+		fprintf(pf, "%s %.3f %.3f\n", material_name(files[k]).c_str(), beckmann[k], ggx[k]);
 	fclose(pf);
 	return EXIT_SUCCESS;
 }

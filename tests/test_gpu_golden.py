@@ -217,10 +217,18 @@ def test_cpp_facade_programs(gpu_ctx, tmp_path):
     for name, recipe in PARAMS_TXT_MATERIALS:
         p = str(tmp_path / (name + ".binary"))
         synth.write_merl_binary(p, synth.merl_table(*recipe)); files.append(p)
-    r = subprocess.run([os.path.join(root, "examples", "merl_params")] + files, cwd=str(tmp_path),
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert open(tmp_path / "params.txt", "rb").read() == open(os.path.join(G, "params_expected.txt"), "rb").read()
+    want = open(os.path.join(G, "params_expected.txt"), "rb").read()
+    # default: native pipeline, files dealt to every visible GPU; -s: the reference's own loop on the djb:: classes
+    for mode in ([], ["-s"], ["-g", "1"]):
+        if (tmp_path / "params.txt").exists():
+            (tmp_path / "params.txt").unlink()
+        r = subprocess.run([os.path.join(root, "examples", "merl_params")] + mode + files, cwd=str(tmp_path),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert open(tmp_path / "params.txt", "rb").read() == want, mode
+    r = subprocess.run([os.path.join(root, "examples", "merl_params"), str(tmp_path / "missing.binary")],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "Failed to open" in r.stderr
 
 
 def test_native_file_pipeline(gpu_ctx, tmp_path):

@@ -226,6 +226,70 @@ static void run_sg(unsigned int entries, float **d, Texel *tab, long long n, int
 	       entries * 12.0 / 1048576.0, ms, n / ms / 1e6);
 }
 
+// ---- MODE 4 of the streams + gather experiment: the table look-ups go through the SCALAR memory
+// path (v_readlane -> s_load_dwordx4 -> v_writelane), leaving the vector memory pipeline to the streams
+template <int LANES_PER_BATCH>
+__global__ __launch_bounds__(256) void k_sg_scalar(const float *tab, unsigned int entries, const v4f *a0, const v4f *a1,
+                                                   const v4f *a2, const v4f *b0, const v4f *b1, const v4f *b2,
+                                                   v4f *c0, v4f *c1, v4f *c2, long long n4)
+{
+	long long stride = (long long)gridDim.x * 256;
+	for (long long q0 = (long long)blockIdx.x * 256; q0 < n4; q0 += stride) {
+		long long q = q0 + threadIdx.x;
+		bool live = q < n4;
+		long long qq = live ? q : 0;
+		v4f x = ld<true>(a0 + qq), y = ld<true>(a1 + qq), z = ld<true>(a2 + qq);
+		v4f u = ld<true>(b0 + qq), v = ld<true>(b1 + qq), w = ld<true>(b2 + qq);
+		unsigned int h = pcg((unsigned int)qq * 4u + (unsigned int)(x.x + u.x));
+		unsigned int idx[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { h = pcg(h + j); idx[j] = (unsigned int)(((unsigned long long)h * entries) >> 32) * 3u; }
+		float tr[4], tg[4], tb[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			float r = 0, g = 0, b = 0;
+			for (int l0 = 0; l0 < 64; l0 += LANES_PER_BATCH) {
+				float sr[LANES_PER_BATCH], sg[LANES_PER_BATCH], sb[LANES_PER_BATCH];
+#pragma unroll
+				for (int l = 0; l < LANES_PER_BATCH; ++l) {
+					unsigned int si = __builtin_amdgcn_readlane(idx[j], l0 + l);     // uniform -> s_load
+					typedef const __attribute__((address_space(4))) float *cptr;   // constant address space -> s_load
+					cptr p = (cptr)(tab + si);
+					sr[l] = p[0]; sg[l] = p[1]; sb[l] = p[2];
+				}
+#pragma unroll
+				for (int l = 0; l < LANES_PER_BATCH; ++l) {
+					bool me = (int)(threadIdx.x & 63) == l0 + l;      // v_cmp + 3 v_cndmask (no writelane builtin)
+					r = me ? sr[l] : r; g = me ? sg[l] : g; b = me ? sb[l] : b;
+				}
+			}
+			tr[j] = r; tg[j] = g; tb[j] = b;
+		}
+		v4f r = { tr[0], tr[1], tr[2], tr[3] }, g = { tg[0], tg[1], tg[2], tg[3] }, b = { tb[0], tb[1], tb[2], tb[3] };
+		r += y + v; g += z + w;
+		if (live) { st<true>(r, c0 + q); st<true>(g, c1 + q); st<true>(b, c2 + q); }
+	}
+}
+template <int LPB>
+static void run_sg_scalar(unsigned int entries, float **d, Texel *tab, long long n, int blocks)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_sg_scalar<LPB>), dim3(blocks), dim3(256), 0, 0, (const float *)tab, entries, (const v4f *)d[0],
+		                   (const v4f *)d[1], (const v4f *)d[2], (const v4f *)d[3], (const v4f *)d[4],
+		                   (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n / 4);
+	};
+	launch(); launch();
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 3; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+	printf("streams+SCALAR-path gather lanes/batch=%2d blocks=%6d table=%6.2f MB : %7.3f ms  %7.1f G pairs/s\n", LPB, blocks,
+	       entries * 12.0 / 1048576.0, ms, n / ms / 1e6);
+}
+
 template <bool NT, int WORK, int UNROLL>
 static void run(const char *name, int blocks, float **d, long long n)
 {
@@ -261,6 +325,14 @@ int main(int argc, char **argv)
 		if (hipMalloc((void **)&tab, 1458000 * 12 * 4) != hipSuccess) return 1;
 		(void)hipMemset(tab, 0, 1458000 * 12 * 4);
 		const unsigned int sizes[] = { 65536, 262144, 524288, 786432, 1458000, 2916000, 5832000 };
+		if (argv[2][0] == 'c') {
+			for (unsigned int e : { 262144u, 1458000u }) {
+				run_sg<0, 1>(e, d, tab, n, 16384);
+				run_sg_scalar<8>(e, d, tab, n, 16384); run_sg_scalar<16>(e, d, tab, n, 16384); run_sg_scalar<32>(e, d, tab, n, 16384);
+				run_sg_scalar<16>(e, d, tab, n, 4096);
+			}
+			return 0;
+		}
 		if (argv[2][0] == 's') {
 			for (unsigned int e : { 262144u, 1458000u }) {
 				run_sg<0, 1>(e, d, tab, n, 16384); run_sg<1, 1>(e, d, tab, n, 16384); run_sg<2, 1>(e, d, tab, n, 16384);

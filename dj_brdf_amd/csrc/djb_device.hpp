@@ -42,7 +42,7 @@ struct Brdf {
 	const float *p22, *sigma, *cdf, *qf;   // tabular tables (device)
 	int n_p22, n_sigma, n_cdf, n_qf;
 	const MerlTexel *merl;                  // [1458000] pre-scaled float RGB; below-horizon -> 0
-	const float4 *utia;                     // [288*288][2] records {R,G,B @ phi_v bin, R | G,B @ phi_v bin + 1, 0, 0} (UTIA_REC)
+	const float4 *utia;                     // [288*288][8]: 128-byte records, RGB of the 2x2x2 (theta_v, phi_i, phi_v) taps (k_utia_convert)
 	const double *model;                    // sgd: 33 doubles, abc: 9 doubles (one published table row)
 	// tabular_anisotropic: p22 / sigma above are elev x azim grids (element (i, j) at [i + elev*j]);
 	// two-level sampling tables below (dj_brdf.h:429-438)
@@ -832,26 +832,34 @@ DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 	sum = wpv[0] + wpv[1]; wpv[0] /= sum; wpv[1] /= sum;
 	if (ipi1 == 48) ipi1 = 0;
 	if (ipv1 == 48) ipv1 = 0;
-	int iti[2] = { iti0, iti1 }, itv[2] = { itv0, itv1 }, ipi[2] = { ipi0, ipi1 };
-	(void)ipv1;
+	int iti[2] = { iti0, iti1 };
+	(void)ipv1; (void)ipi1; (void)itv1;
 	// The reference walks the three colour planes one after the other, 16 taps each (48 scattered
-	// 4-byte reads).  The HBM table stores, per (theta_i, phi_i, theta_v, phi_v) node, the RGB of that
-	// node AND of its phi_v + 1 neighbour (wrapped) in one 32-byte record, so the 16 taps are 8
-	// aligned 32-byte gathers; each plane still accumulates its 16 terms in the reference's order
-	// (a, c, k, l nested, l innermost), so the sums are bit-identical.
+	// 4-byte reads).  The HBM table stores, per (theta_i, phi_i, theta_v, phi_v) node, the RGB of the
+	// eight taps (theta_v + {0,1}) x (phi_i + {0,1}) x (phi_v + {0,1}) (azimuths wrapped) in one
+	// 128-byte record = one L2 line, so the 16 taps are 2 aligned line gathers; each plane still
+	// accumulates its 16 terms in the reference's order (a, c, k, l nested, l innermost), so the
+	// sums are bit-identical.
 	float acc[3] = { 0.0f, 0.0f, 0.0f };
 #pragma unroll
-	for (int a = 0; a < 2; ++a)
+	for (int a = 0; a < 2; ++a) {
+		int e = 288 * (48 * iti[a] + ipi0) + 48 * itv0 + ipv0;
+		const float4 *rec = b.utia + 8 * (size_t)e;
+		float4 q[6];
 #pragma unroll
-	for (int c = 0; c < 2; ++c)
+		for (int j = 0; j < 6; ++j) q[j] = rec[j];
+		const float t[24] = { q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w,
+		                      q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w };
 #pragma unroll
-	for (int k = 0; k < 2; ++k) {
-		int e = 288 * (48 * iti[a] + ipi[k]) + 48 * itv[c] + ipv0;
-		float4 r0 = b.utia[2 * e], r1 = b.utia[2 * e + 1];
-		float w0 = wti[a] * wtv[c] * wpi[k] * wpv[0], w1 = wti[a] * wtv[c] * wpi[k] * wpv[1];
-		acc[0] += w0 * r0.x; acc[0] += w1 * r0.w;
-		acc[1] += w0 * r0.y; acc[1] += w1 * r1.x;
-		acc[2] += w0 * r0.z; acc[2] += w1 * r1.y;
+		for (int c = 0; c < 2; ++c)
+#pragma unroll
+		for (int k = 0; k < 2; ++k)
+#pragma unroll
+		for (int l = 0; l < 2; ++l) {
+			float w = wti[a] * wtv[c] * wpi[k] * wpv[l];
+			const int tap = 3 * (4 * c + 2 * k + l);
+			acc[0] += w * t[tap]; acc[1] += w * t[tap + 1]; acc[2] += w * t[tap + 2];
+		}
 	}
 	float RGB[3];
 #pragma unroll

@@ -605,9 +605,9 @@ djb_status djb_brdf_create_utia_from_memory(djb_ctx *ctx, const double *samples,
 	HIP_TRY(hipSetDevice(ctx->device));
 	djb_brdf *b;
 	alloc_brdf(ctx, DJB_KIND_UTIA, &b);
-	double *raw = nullptr; float4 *tab = nullptr;    // 288*288 records of two float4 (k_utia_convert)
+	double *raw = nullptr; float4 *tab = nullptr;    // 288*288 records of eight float4 (k_utia_convert)
 	hipError_t e = hipMalloc((void **)&raw, sizeof(double) * (size_t)UTIA_N);
-	if (e == hipSuccess) e = hipMalloc((void **)&tab, sizeof(float4) * 2 * (size_t)(UTIA_N / 3));
+	if (e == hipSuccess) e = hipMalloc((void **)&tab, sizeof(float4) * 8 * (size_t)(UTIA_N / 3));
 	if (e == hipSuccess) e = hipMemcpyAsync(raw, samples, sizeof(double) * (size_t)UTIA_N, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess) e = djbk::launch_utia_convert(ctx->stream, raw, UTIA_N, tab);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -47,7 +47,7 @@ hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, co
 
 // MERL payload (3*n doubles) -> packed RGB texel table (pre-scaled, below-horizon zeroed); n = 1458000
 hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, djbdev::MerlTexel *table);
-// UTIA payload (n = 3*288*288 doubles) -> float(max(0, s) * double(1.f/140.f)) in 288*288 records of 2 float4
+// UTIA payload (n = 3*288*288 doubles) -> float(max(0, s) * double(1.f/140.f)) in 288*288 records of 8 float4
 hipError_t launch_utia_convert(hipStream_t s, const double *samples, long long n, float4 *table);
 
 hipError_t launch_gen_directions(hipStream_t s, long long n, uint32_t seed, unsigned long long start,

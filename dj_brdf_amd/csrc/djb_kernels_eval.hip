@@ -275,8 +275,10 @@ __global__ __launch_bounds__(BLOCK) void k_merl_convert(const double *s, long lo
 }
 
 // utia::normalize (dj_brdf.h:1162-1177) then the (float_t) cast of dj_brdf.h:1144
-// n = 3*288*288 samples (three planes) -> 288*288 records of two float4: the node's RGB and the RGB of
-// its phi_v + 1 neighbour (wrapped at 48), see utia_eval
+// n = 3*288*288 samples (three planes) -> 288*288 records of eight float4 (128 bytes = one L2 line):
+// the RGB of the eight taps (theta_v + c, phi_i + k, phi_v + l), c, k, l in {0, 1}, tap order
+// 4c + 2k + l, azimuths wrapped at 48; theta_v + 1 is clamped to the last row for itv = 5 (never read:
+// utia_eval clamps itv0 <= 4).  See utia_eval.
 __global__ __launch_bounds__(BLOCK) void k_utia_convert(const double *s, long long n, float4 *table)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
@@ -284,9 +286,18 @@ __global__ __launch_bounds__(BLOCK) void k_utia_convert(const double *s, long lo
 	const long long plane = n / 3;
 	auto conv = [&](long long k) { double v = s[k] > 0.0 ? s[k] : 0.0; return F(v * D(kf)); };
 	for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < plane; e += stride) {
-		long long ipv = e % 48, e1 = e - ipv + (ipv + 1) % 48;
-		table[2 * e] = make_float4(conv(e), conv(plane + e), conv(2 * plane + e), conv(e1));
-		table[2 * e + 1] = make_float4(conv(plane + e1), conv(2 * plane + e1), 0.0f, 0.0f);
+		// e = 288 * (48 * iti + ipi) + 48 * itv + ipv
+		long long ipv = e % 48, itv = (e / 48) % 6, row = e / 288, ipi = row % 48;
+		float t[32];
+		for (int c = 0; c < 2; ++c)
+			for (int k = 0; k < 2; ++k)
+				for (int l = 0; l < 2; ++l) {
+					long long tv = itv + c > 5 ? 5 : itv + c;
+					long long src = 288 * (row - ipi + (ipi + k) % 48) + 48 * tv + (ipv + l) % 48;
+					for (int ch = 0; ch < 3; ++ch) t[3 * (4 * c + 2 * k + l) + ch] = conv(ch * plane + src);
+				}
+		for (int j = 24; j < 32; ++j) t[j] = 0.0f;
+		for (int j = 0; j < 8; ++j) table[8 * e + j] = make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
 	}
 }
 

@@ -87,11 +87,11 @@ DJB_DEV float fdiv4(float a, float b) { return a / (4.0f * b); }
 // tests that (256 ulp64 either side; probability 2^-20), and the caller then takes the exact path.
 // y comes from v_rsq_f64 / v_rcp_f64 refined by two Newton steps (error <= a few 2^-53 for any
 // seed accuracy >= 2^-14); e itself is within 2^-52 of the true value.
-DJB_DEV bool near_f32_midpoint(double y)
+DJB_DEV bool near_f32_midpoint(double y, long long width = 256)
 {
 	unsigned long long b = (unsigned long long)__double_as_longlong(y) & 0x1FFFFFFFull;
 	long long d = (long long)b - 0x10000000ll;
-	return (d < 0 ? -d : d) <= 256;
+	return (d < 0 ? -d : d) <= width;
 }
 // inversesqrt = float(1.0 / sqrt(double(x))): two double roundings (dj_brdf.h:612)
 DJB_DEV float inversesqrt_(float x)
@@ -804,6 +804,47 @@ DJB_DEV bool merl_index_fast(v3 i, v3 o, const MerlGuard g, int &idx)
 }
 
 // ------------------------------------------------------------------ UTIA (dj_brdf.h:1063-1157)
+// sRGB decode of dj_brdf.h:1147-1150: float(pow(double(float(double(v) + 0.055)) / 1.055, double(2.4f))).
+// Exact form: an IEEE fp64 division + the fp64 libm pow (~150 fp64 instructions).  Guarded form
+// (same idea as inversesqrt_): with t = num / 1.055 and p = double(2.4f) = 2.4 + d,
+//     t^p = (t z)^3 * exp(d ln t),   z = t^(-1/5),
+// z from a division-free Newton iteration z <- z (6 - t z^5) / 5 seeded by v_log_f32 / v_exp_f32
+// (error 3 e^2 per step: 2e-7 -> 1e-13 -> rounding level), exp(d ln t) = 1 + x + x^2/2 with
+// x = d ln t <= 3e-7 and ln t from the same v_log_f32 (absolute error <= 4e-7 -> 4e-14 relative in
+// the result).  Total error < 2^-44; the result is used only if it is not within 2^-42 (1024 ulp64)
+// of an fp32 rounding boundary, otherwise -- or outside t in [1/16, 16] -- the exact form runs.
+DJB_DEV float srgb_decode_exact(float v)
+{
+	return F(pow(D(F(D(v) + 0.055)) / 1.055, D(2.4f)));
+}
+DJB_DEV double srgb_decode_fast(float v, bool &ok)
+{
+	const double num = D(F(D(v) + 0.055));
+	const double t = num * (1.0 / 1.055);                       // <= 1 ulp64 from the IEEE quotient
+	const float tf = F(t);
+	const float L = __builtin_amdgcn_logf(tf);                  // log2(t), ~1 ulp
+	double z = D(__builtin_amdgcn_exp2f(-0.2f * L));            // t^(-1/5), ~3e-7
+#pragma unroll
+	for (int it = 0; it < 2; ++it) {
+		double z2 = z * z, z4 = z2 * z2, z5 = z4 * z;
+		double e = __builtin_fma(-t, z5, 1.0);
+		z = __builtin_fma(z * 0.2, e, z);
+	}
+	double u = t * z, r = u * u * u;                            // t^2.4
+	const double delta = D(2.4f) - 2.4;                         // 9.5367431640625e-08
+	double x = delta * (D(L) * 0.6931471805599453);
+	r = r * __builtin_fma(x, __builtin_fma(x, 0.5, 1.0), 1.0);
+	ok = !near_f32_midpoint(r, 1024) && (tf > 0.0625f && tf < 16.0f);
+	return r;
+}
+DJB_DEV float srgb_decode(float v)
+{
+	bool ok;
+	double r = srgb_decode_fast(v, ok);
+	if (__builtin_expect(!ok, 0)) return srgb_decode_exact(v);
+	return F(r);
+}
+
 DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 {
 	float r2d = F(180.0 / DJB_PI);
@@ -865,7 +906,7 @@ DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 #pragma unroll
 	for (int isp = 0; isp < 3; ++isp) {
 		float v = acc[isp];
-		if (D(v) > 0.0375) v = F(pow(D(F(D(v) + 0.055)) / 1.055, D(2.4f)));
+		if (D(v) > 0.0375) v = srgb_decode(v);
 		else v /= 12.92f;
 		RGB[isp] = v * 100.0f;
 	}

@@ -1289,16 +1289,16 @@ djb_status djb_gen_uniforms(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t sta
 	HIP_TRY(djbk::launch_gen_uniforms(ctx->stream, n, seed, start, out));
 	return DJB_OK;
 }
-djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, unsigned long long *counters4)
+djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, unsigned long long *counters8)
 {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
-	if (!counters4) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (!counters8) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	unsigned long long *d = nullptr;
-	HIP_TRY(hipMalloc((void **)&d, 32));
-	hipError_t e = hipMemsetAsync(d, 0, 32, ctx->stream);
+	HIP_TRY(hipMalloc((void **)&d, 64));
+	hipError_t e = hipMemsetAsync(d, 0, 64, ctx->stream);
 	if (e == hipSuccess) e = djbk::launch_guard_selftest(ctx->stream, n, seed, d);
-	if (e == hipSuccess) e = hipMemcpyAsync(counters4, d, 32, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(counters8, d, 64, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	(void)hipFree(d);
 	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));

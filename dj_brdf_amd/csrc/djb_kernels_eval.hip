@@ -317,10 +317,11 @@ __global__ __launch_bounds__(BLOCK) void k_gen_uni(long long n, uint32_t seed, u
 // self-test of the guarded fast paths of djb_device.hpp (inversesqrt_, recip_to_f32) against the
 // exact double sequences they stand in for, on hash-generated inputs across the exponent range.
 // counters: [0] inversesqrt mismatches, [1] reciprocal mismatches (both must be 0),
-//           [2] inversesqrt exact-path fallbacks, [3] reciprocal fallbacks.
+//           [2] inversesqrt exact-path fallbacks, [3] reciprocal fallbacks,
+//           [4] sRGB-decode (pow 2.4) mismatches (must be 0), [5] sRGB-decode fallbacks, [6..7] 0.
 __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t seed, unsigned long long *counters)
 {
-	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0;
+	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0, bad_p = 0, fb_p = 0;
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		uint32_t h0 = hash_u32(seed, (uint64_t)k, 0), h1 = hash_u32(seed, (uint64_t)k, 1), h2 = hash_u32(seed, (uint64_t)k, 2);
@@ -338,9 +339,19 @@ __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t 
 		double r = __builtin_amdgcn_rcp(q);
 		r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r); r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r);
 		if (near_f32_midpoint(r)) ++fb_d;
+		// interpolated UTIA value above the sRGB knee: mostly (0.0375, 1.2], every 8th in [2^-4, 2^4)
+		float v = (k & 7) ? 0.0375f + (float)(h2 >> 8) * 5.9604644775390625e-08f * 1.1625f
+		                  : ldexpf(1.0f + (float)(h0 >> 9) * 1.1920928955078125e-07f, (int)(h1 % 8u) - 4);
+		if (D(v) > 0.0375) {
+			bool ok;
+			(void)srgb_decode_fast(v, ok);
+			if (!ok) ++fb_p;
+			if (srgb_decode(v) != srgb_decode_exact(v)) ++bad_p;
+		}
 	}
 	atomicAdd(&counters[0], bad_r); atomicAdd(&counters[1], bad_d);
 	atomicAdd(&counters[2], fb_r); atomicAdd(&counters[3], fb_d);
+	atomicAdd(&counters[4], bad_p); atomicAdd(&counters[5], fb_p);
 }
 
 // bins x bins histogram over [-1,1]^2: LDS atomics, one global flush per workgroup

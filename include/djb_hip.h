@@ -235,10 +235,11 @@ djb_status djb_merl_index_batch(djb_ctx *, int64_t n, const djb_vec3_view *i,
 djb_status djb_merl_guard_stats(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                                 const float *guard5, float *max_ratio3, unsigned long long *counters4);
 
-/* self-test of the kernels' guarded fp64 shortcuts (float(1/sqrt(double x)), float(1/q)) against the
- * exact double sequences on n hash-generated inputs: counters = {rsqrt mismatches, reciprocal
- * mismatches (both must be 0), rsqrt exact-path fallbacks, reciprocal fallbacks}.               */
-djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters4);
+/* self-test of the kernels' guarded fp64 shortcuts (float(1/sqrt(double x)), float(1/q), the sRGB
+ * decode float(pow(t, 2.4f))) against the exact double sequences on n hash-generated inputs:
+ * counters[8] = {rsqrt mismatches, reciprocal mismatches, rsqrt exact-path fallbacks, reciprocal
+ * fallbacks, sRGB-decode mismatches, sRGB-decode fallbacks, 0, 0}; every mismatch count must be 0. */
+djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters8);
 
 /* microfacet::params -> private members (host side, no GPU work)       dj_brdf.h:1355-1506 */
 djb_status djb_params_resolve(const djb_params *params, djb_params_resolved *out);

@@ -22,7 +22,7 @@ communication is the barrier and the MAX-over-ranks of the timed region.
 Extra objects in the JSON line:
   secondary     (default workload only) merl_fit_100: wall time of the 100-material MERL fit sharded
                 over the N ranks (material m -> rank m mod N, "strong"); at N=1 also the other
-                single-GPU configs (ggx_eval_pdf, beckmann_sample)
+                single-GPU configs (ggx_eval_pdf, beckmann_sample) and utia_eval
   roofline      dominant kernel: algorithmic bytes per launch / average launch duration
                 (HIP events on the ctx stream over the timed region) vs the 8 TB/s HBM peak
   cpu_baseline  the CPU path timed on this host (rank 0, N=1 only) on a bounded sample:
@@ -367,7 +367,7 @@ def main():
             rec["secondary"] = {"merl_fit_100": fit100}
         if want_secondary and world == 1:
             sec = {"merl_fit_100": fit100}
-            for other in ("ggx_eval_pdf", "beckmann_sample"):
+            for other in ("ggx_eval_pdf", "beckmann_sample", "utia_eval"):
                 on, ob, ou, _ = WORKLOADS[other]
                 st, kp = make_step(other, on, djb, synth, ctx, torch)
                 st(); torch.cuda.synchronize()

@@ -7,7 +7,7 @@
 # Outputs land in gpurun_out/prof/<workload>/{trace,fetch,write,sq}; summarise with tools/summarize_profiles.py.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
-for w in ${WORKLOADS:-merl_eval ggx_eval_pdf beckmann_sample merl_fit}; do
+for w in ${WORKLOADS:-merl_eval ggx_eval_pdf beckmann_sample utia_eval merl_fit}; do
   O=$R/gpurun_out/prof/$w; mkdir -p $O
   A="--workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py $A > $O/bench_trace.json 2> $O/trace.err

@@ -15,7 +15,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles", RND)
 os.makedirs(DST, exist_ok=True)
 DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf": ("k_eval<1, 5,",),
-            "beckmann_sample": ("k_sample<0",), "merl_fit": ("k_fit<3>",)}
+            "beckmann_sample": ("k_sample<0",), "merl_fit": ("k_fit<3>",), "utia_eval": ("k_eval<4, 1,",)}
 
 
 def counters(path):

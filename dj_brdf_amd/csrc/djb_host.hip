@@ -50,6 +50,11 @@ struct djb_ctx {
 	// a small batch); bounded by POOL_MAX_BYTES
 	std::mutex pool_mu;
 	std::vector<std::pair<void *, size_t>> pool;
+	// Every entry point that enqueues work holds this for the duration of the call: the reference's
+	// operators are const and safe to call concurrently on one object (Mitsuba's render threads do),
+	// so concurrent callers of one context are serialised here (its stream serialises them anyway)
+	// and multi-launch sequences that share per-context scratch (the two-tier MERL lookup) stay atomic.
+	std::recursive_mutex call_mu;
 };
 
 struct djb_brdf {
@@ -344,6 +349,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
 	djb_status st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
 	if ((st = device_params(params, &p)) != DJB_OK) return st;
 	Staged sg(ctx, n, mem);
@@ -783,6 +789,7 @@ djb_status djb_brdf_create_tabular(djb_ctx *ctx, const djb_brdf *src, int res, i
 	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	if (res <= 2) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");
 	djb_brdf *t;
 	alloc_brdf(ctx, DJB_KIND_TABULAR, &t);
@@ -814,6 +821,7 @@ djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src
 	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	if (elev <= 1 || azim <= 1 || elev > 1024 || azim > 1024)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");           // dj_brdf.h:2244
 	Params std_p;
@@ -941,6 +949,7 @@ djb_status djb_fit_merl_batch(djb_ctx *ctx, int n_mat, const double *const *tabl
 	if (n_mat == 0) return DJB_OK;
 	djb_status st = check_call(ctx, nullptr, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	// upload + convert every table (raw doubles -> texel table), double-buffered on the stream
 	std::vector<djb_brdf *> mats(n_mat, nullptr);
 	std::vector<Brdf> srcs(n_mat);
@@ -963,6 +972,7 @@ djb_status djb_fit_brdf_batch(djb_ctx *ctx, int n_mat, const djb_brdf *const *sr
 	if (n_mat == 0) return DJB_OK;
 	djb_status st = check_call(ctx, srcs_in[0], 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	std::vector<Brdf> srcs(n_mat);
 	for (int m = 0; m < n_mat; ++m) {
 		if (!srcs_in[m] || srcs_in[m]->dev.kind != srcs_in[0]->dev.kind || srcs_in[m]->ctx->device != ctx->device)
@@ -1002,6 +1012,7 @@ static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, cons
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
 	djb_status st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
 	if ((st = device_params(params, &p)) != DJB_OK) return st;
 	Staged sg(ctx, n, mem);
@@ -1038,6 +1049,7 @@ djb_status djb_sample_rng_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
 	djb_status st = check_call(ctx, b, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
 	if ((st = device_params(params, &p)) != DJB_OK) return st;
 	if (!Staged::valid(o) || !Staged::valid(out_i)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
@@ -1051,6 +1063,7 @@ static djb_status hd_common(djb_ctx *ctx, int64_t n, const djb_vec3_view *a, con
 {
 	djb_status st = check_call(ctx, nullptr, n, mem);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Staged sg(ctx, n, mem);
 	View va, vb, vc, vd;
 	if ((st = sg.in_vec(a, &va)) != DJB_OK) return st;
@@ -1087,6 +1100,7 @@ djb_status djb_query_batch(djb_ctx *ctx, const djb_brdf *b, int which, int64_t n
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: pdf1/cdf1/qf1/pdf2/cdf2/qf2 need a tabular_anisotropic");
 	djb_status st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
 	if ((st = device_params(params, &p)) != DJB_OK) return st;
 	Staged sg(ctx, n, mem);
@@ -1105,6 +1119,7 @@ djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i,
 {
 	djb_status st = check_call(ctx, nullptr, n, mem);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Staged sg(ctx, n, mem);
 	View vi, vo; int32_t *didx;
 	if ((st = sg.in_vec(i, &vi)) != DJB_OK) return st;
@@ -1193,6 +1208,7 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: want must be eval(1)|evalp(2) and/or pdf(4)");
 	djb_status st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Staged sg(ctx, n, mem);
 	View vi, vo, vout{ nullptr, nullptr, nullptr, 0 };
 	float *dpdf = nullptr, *dpp = nullptr; const float *drec = rec;
@@ -1247,6 +1263,7 @@ djb_status djb_merl_guard_stats(djb_ctx *ctx, int64_t n, const djb_vec3_view *i,
 {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	if (!Staged::valid(i) || !Staged::valid(o) || !max_ratio3 || !counters4)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	unsigned char *d = nullptr;
@@ -1277,6 +1294,7 @@ djb_status djb_gen_directions(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t s
 {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	if (!Staged::valid(out)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
 	HIP_TRY(djbk::launch_gen_directions(ctx->stream, n, seed, start, View{ out->x, out->y, out->z, (long long)out->stride }));
 	return DJB_OK;
@@ -1285,6 +1303,7 @@ djb_status djb_gen_uniforms(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t sta
 {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null output array");
 	HIP_TRY(djbk::launch_gen_uniforms(ctx->stream, n, seed, start, out));
 	return DJB_OK;
@@ -1293,6 +1312,7 @@ djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, uns
 {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	if (!counters8) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	unsigned long long *d = nullptr;
 	HIP_TRY(hipMalloc((void **)&d, 64));
@@ -1309,6 +1329,7 @@ djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int
 {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	if (!Staged::valid(v) || !counts || bins < 1 || bins > 128)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid histogram arguments");
 	HIP_TRY(djbk::launch_histogram_xy(ctx->stream, n, View{ v->x, v->y, v->z, (long long)v->stride }, bins, counts));

@@ -335,3 +335,31 @@ def test_host_views_of_any_layout(gpu_ctx, dirs):
     r = np.empty((n, 3), np.float32)
     run(view(*[a.ctypes.data for a in ic], 1), view(b(o4), b(o4) + 4, b(o4) + 8, 4), view(b(r), b(r) + 4, b(r) + 8, 3))
     assert np.array_equal(r.view(np.uint32), want.view(np.uint32))
+
+
+def test_concurrent_callers_share_one_context(gpu_ctx):
+    # the reference's operators are const and thread-safe (Mitsuba render threads share one BSDF):
+    # concurrent host threads on ONE context must get the same bits as sequential calls, including the
+    # two-tier MERL lookup whose three launches share per-context scratch
+    import threading
+    m = djb.merl.from_table(synth.merl_table_hashed(), ctx=gpu_ctx)
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    n, T = 300_000, 6
+    ins = [(synth.directions_aos(n, synth.SEED_I + 7 * t), synth.directions_aos(n, synth.SEED_O + 13 * t)) for t in range(T)]
+    want = [(m.eval(i, o), g.eval(i, o)) for i, o in ins]
+    got, errs = [None] * T, []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                got[t] = (m.eval(*ins[t]), g.eval(*ins[t]))
+        except Exception as e:   # surfaced below
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errs, errs
+    for t in range(T):
+        assert np.array_equal(got[t][0].view(np.uint32), want[t][0].view(np.uint32)), f"thread {t}: merl"
+        assert np.array_equal(got[t][1].view(np.uint32), want[t][1].view(np.uint32)), f"thread {t}: ggx"

@@ -145,6 +145,39 @@ def test_full_size_merl_eval_properties(gpu_ctx):
     assert total == 1_000_000_000
 
 
+def test_merl_eval_one_launch_beyond_2_pow_31_pairs(gpu_ctx):
+    """Maximum sizes: one djb_eval_batch call over 2^31 + 4097 pairs (77 GB of directions + results
+    in HBM).  Pair indices travel as uint32 inside the two-tier kernel, so the call is chunked at
+    2^31 internally; outputs on both sides of the seam, at the ends and on a sparse grid must equal
+    the operation-by-operation kernel and the CPU oracle bit for bit."""
+    import torch
+    import oraclelib
+    free, _ = torch.cuda.mem_get_info()
+    n = (1 << 31) + 4097
+    if free < 36 * n + (8 << 30):
+        pytest.skip("needs ~85 GB of free HBM")
+    O = oraclelib.oracle()
+    tab = synth.merl_table_hashed()
+    m = djb.merl.from_table(tab, ctx=gpu_ctx)
+    om = O.merl_from_table(tab)
+    i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx)
+    o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
+    out = m.eval(i, o)
+    seam = 1 << 31
+    sel = torch.cat([torch.arange(0, 4096), torch.arange(seam - 4096, seam + 4097), torch.arange(n - 4096, n),
+                     torch.arange(0, n, 1_000_003)]).to(i.device)
+    hi, ho = i[:, sel].T.contiguous().cpu().numpy(), o[:, sel].T.contiguous().cpu().numpy()
+    got = out[:, sel].T.contiguous().cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), O.eval(om, hi, ho).view(np.uint32))
+    # the whole batch against the exact-only kernel (no worklist, no chunking), by checksum per channel
+    djb.set_merl_exact_only(gpu_ctx, True)
+    try:
+        ref = m.eval(i, o)
+    finally:
+        djb.set_merl_exact_only(gpu_ctx, False)
+    assert torch.equal(out, ref)
+
+
 def test_full_size_ggx_eval_pdf_properties(gpu_ctx):
     """1e8 pairs (BASELINE configs[1]): evalp == eval * i.z exactly (vec3 * float, dj_brdf.h:803),
     fused == separate launches, pdf >= 0, and a strided sample matches the oracle to 1e-5."""

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Randomised differential run (on the GPU box): HIP path vs the CPU oracle on fresh seeds, random
+microfacet parameters / Fresnel terms, and hashed MERL / UTIA tables.  Reports, per case, the
+fraction of bit-identical outputs and the largest relative difference; exits non-zero if eval/pdf
+of the analytic lobes or MERL is not 100 % bit-exact.   PYTHONPATH=. python tools/fuzz_parity.py [rounds] [n]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oraclelib
+from dj_brdf_amd import djb, synth
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_000_000
+TH = min(64, os.cpu_count() or 1)
+O = oraclelib.oracle(); ctx = djb.default_context(0)
+rng = np.random.default_rng(20260928)
+bad = 0
+
+
+def report(tag, got, want, must_be_exact):
+    global bad
+    same = got.view(np.uint32) == want.view(np.uint32)
+    both_nan = np.isnan(got) & np.isnan(want)
+    ex = float((same | both_nan).mean())
+    with np.errstate(all="ignore"):
+        rel = np.nanmax(np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-30))
+    flag = ""
+    if must_be_exact and ex < 1.0:
+        bad += 1; flag = "   <-- NOT BIT-EXACT"
+    print(f"{tag:78s} exact {ex:.7f} max rel {rel:.2e}{flag}", flush=True)
+
+
+for r in range(rounds):
+    seed_i, seed_o = int(rng.integers(1, 2**31)), int(rng.integers(1, 2**31))
+    i = synth.directions_aos(n, seed_i); o = synth.directions_aos(n, seed_o)
+    # random microfacet set-ups
+    for ndf in ("ggx", "beckmann"):
+        kind = rng.integers(0, 4)
+        if kind == 0: fres, fo = djb.fresnel.ideal(), ("ideal",)
+        elif kind == 1:
+            f0 = rng.uniform(0.02, 1.0, 3).astype(np.float32); fres, fo = djb.fresnel.schlick(tuple(f0)), ("schlick", *map(float, f0))
+        elif kind == 2:
+            ior = rng.uniform(1.05, 3.0, 3).astype(np.float32); fres, fo = djb.fresnel.unpolarized(tuple(ior)), ("unpolarized", *map(float, ior))
+        else:
+            pts = rng.uniform(0.0, 1.0, (int(rng.integers(2, 40)), 3)).astype(np.float32); fres, fo = djb.fresnel.spline(pts), ("spline", pts)
+        shadow = bool(rng.integers(0, 2))
+        g = getattr(djb, ndf)(fres, shadow, ctx=ctx); og = O.microfacet(ndf, fo, shadow)
+        pk = rng.integers(0, 3)
+        if pk == 0:
+            a = float(np.float32(rng.uniform(0.02, 1.5))); p, up = ("elliptic", a, a, 0.0), djb.microfacet.params.isotropic(a)
+        elif pk == 1:
+            a1, a2, ph = (float(np.float32(x)) for x in (rng.uniform(0.02, 1.5), rng.uniform(0.02, 1.5), rng.uniform(-3.1, 3.1)))
+            p, up = ("elliptic", a1, a2, ph), djb.microfacet.params.elliptic(a1, a2, ph)
+        else:
+            ax, ay, rho, tx, ty = (float(np.float32(x)) for x in (rng.uniform(0.05, 1.2), rng.uniform(0.05, 1.2), rng.uniform(-0.9, 0.9),
+                                                                  rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5)))
+            p, up = ("pdfparams", ax, ay, rho, tx, ty), djb.microfacet.params.pdfparams(ax, ay, rho, tx, ty)
+        for op in ("eval", "evalp", "pdf"):
+            got = getattr(g, op)(i, o, up)
+            want = O.eval_mt(og, i, o, p, op, threads=TH)
+            report(f"r{r} {ndf:8s} {fo[0]:11s} shadow={int(shadow)} {str(p)[:34]:34s} {op}", got, want, True)
+    # MERL (hashed table incl. negatives) and UTIA
+    tab = synth.merl_table_hashed(seed=int(rng.integers(1, 1 << 30)))
+    m, om = djb.merl.from_table(tab, ctx=ctx), O.merl_from_table(tab)
+    report(f"r{r} merl eval", m.eval(i, o), O.eval_mt(om, i, o, None, "eval", threads=TH), True)
+    ut = rng.uniform(-5.0, 130.0, size=3 * 288 * 288)
+    path = f"/tmp/fuzz_utia_{r}.bin"; ut.tofile(path)
+    u, ou = djb.utia(path, ctx=ctx), O.utia(path)
+    report(f"r{r} utia eval", u.eval(i, o), O.eval_mt(ou, i, o, None, "eval", threads=TH), False)
+print("FAILED" if bad else "OK", bad)
+sys.exit(1 if bad else 0)

@@ -290,6 +290,64 @@ static void run_sg_scalar(unsigned int entries, float **d, Texel *tab, long long
 	       entries * 12.0 / 1048576.0, ms, n / ms / 1e6);
 }
 
+// ---- cache-policy bits on the STREAM accesses while random gathers compete for L2 (table 9 MB):
+// does any policy keep the streams from evicting table lines?  SPOL/WPOL: 0 none, 1 nt, 2 sc0 sc1 nt, 3 sc1 nt, 4 sc0 sc1
+template <int POL> __device__ inline v4f ld_pol(const v4f *p)
+{
+	v4f v;
+	if (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+	if (POL == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+	return v;
+}
+template <int POL> __device__ inline void st_pol(v4f v, v4f *p)
+{
+	if (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+	if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+	if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(v) : "memory");
+	if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+	if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+}
+template <int SPOL, int WPOL>
+__global__ __launch_bounds__(256) void k_sg_pol(const Texel *tab, unsigned int entries, const v4f *a0, const v4f *a1,
+                                                const v4f *a2, const v4f *b0, const v4f *b1, const v4f *b2,
+                                                v4f *c0, v4f *c1, v4f *c2, long long n4)
+{
+	long long stride = (long long)gridDim.x * 256;
+	for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+		v4f x = ld_pol<SPOL>(a0 + q), y = ld_pol<SPOL>(a1 + q), z = ld_pol<SPOL>(a2 + q);
+		v4f u = ld_pol<SPOL>(b0 + q), v = ld_pol<SPOL>(b1 + q), w = ld_pol<SPOL>(b2 + q);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		unsigned int h = pcg((unsigned int)q * 4u + (unsigned int)(x.x + u.x));
+		Texel t[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { h = pcg(h + j); t[j] = tab[(unsigned int)(((unsigned long long)h * entries) >> 32)]; }
+		v4f r = { t[0].x, t[1].x, t[2].x, t[3].x }, g = { t[0].y, t[1].y, t[2].y, t[3].y }, b = { t[0].z, t[1].z, t[2].z, t[3].z };
+		r += y + v; g += z + w;
+		st_pol<WPOL>(r, c0 + q); st_pol<WPOL>(g, c1 + q); st_pol<WPOL>(b, c2 + q);
+	}
+}
+template <int SPOL, int WPOL>
+static void run_sg_pol(unsigned int entries, float **d, Texel *tab, long long n)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_sg_pol<SPOL, WPOL>), dim3(16384), dim3(256), 0, 0, tab, entries, (const v4f *)d[0],
+		                   (const v4f *)d[1], (const v4f *)d[2], (const v4f *)d[3], (const v4f *)d[4],
+		                   (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n / 4);
+	};
+	launch(); launch();
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 3; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+	printf("streams(load policy %d, store policy %d) + gather table=%6.2f MB : %7.3f ms\n", SPOL, WPOL, entries * 12.0 / 1048576.0, ms);
+}
+
 template <bool NT, int WORK, int UNROLL>
 static void run(const char *name, int blocks, float **d, long long n)
 {
@@ -325,6 +383,14 @@ int main(int argc, char **argv)
 		if (hipMalloc((void **)&tab, 1458000 * 12 * 4) != hipSuccess) return 1;
 		(void)hipMemset(tab, 0, 1458000 * 12 * 4);
 		const unsigned int sizes[] = { 65536, 262144, 524288, 786432, 1458000, 2916000, 5832000 };
+		if (argv[2][0] == 'w') {
+			for (unsigned int e : { 786432u, 1458000u }) {
+				run_sg_pol<0, 0>(e, d, tab, n); run_sg_pol<1, 1>(e, d, tab, n); run_sg_pol<2, 2>(e, d, tab, n);
+				run_sg_pol<3, 3>(e, d, tab, n); run_sg_pol<4, 4>(e, d, tab, n); run_sg_pol<1, 2>(e, d, tab, n);
+				run_sg_pol<2, 1>(e, d, tab, n); run_sg_pol<1, 0>(e, d, tab, n); run_sg_pol<0, 1>(e, d, tab, n);
+			}
+			return 0;
+		}
 		if (argv[2][0] == 'c') {
 			for (unsigned int e : { 262144u, 1458000u }) {
 				run_sg<0, 1>(e, d, tab, n, 16384);

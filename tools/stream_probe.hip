@@ -348,6 +348,54 @@ static void run_sg_pol(unsigned int entries, float **d, Texel *tab, long long n)
 	printf("streams(load policy %d, store policy %d) + gather table=%6.2f MB : %7.3f ms\n", SPOL, WPOL, entries * 12.0 / 1048576.0, ms);
 }
 
+// ---- cost of the IEEE fp32 division (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup) and of
+// sqrtf / fast reciprocal inside the stream pattern: NDIV operations of kind OP per pair
+// OP 0: a / b (IEEE)   1: a * __builtin_amdgcn_rcpf(b)   2: sqrtf (IEEE)   3: fma chain of the same length (10 per "division")
+template <int OP, int NDIV>
+__global__ __launch_bounds__(256) void k_divs(const v4f *a0, const v4f *a1, const v4f *a2, const v4f *b0, const v4f *b1,
+                                              const v4f *b2, v4f *c0, v4f *c1, v4f *c2, long long n4)
+{
+	long long stride = (long long)gridDim.x * 256;
+	for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+		v4f x = ld<true>(a0 + q), y = ld<true>(a1 + q), z = ld<true>(a2 + q);
+		v4f u = ld<true>(b0 + q), v = ld<true>(b1 + q), w = ld<true>(b2 + q);
+		v4f r = x + u, g = y + v + 1.5f, b = z + w + 2.5f;
+#pragma unroll
+		for (int k = 0; k < NDIV; ++k) {
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				if (OP == 0) r[c] = g[c] / (r[c] + b[c]);
+				if (OP == 1) r[c] = g[c] * __builtin_amdgcn_rcpf(r[c] + b[c]);
+				if (OP == 2) r[c] = __builtin_sqrtf(r[c] + b[c]);
+				if (OP == 3) { float t = r[c] + b[c];
+#pragma unroll
+					for (int j = 0; j < 10; ++j) t = __builtin_fmaf(t, g[c], b[c]);
+					r[c] = t; }
+			}
+		}
+		st<true>(r, c0 + q); st<true>(g, c1 + q); st<true>(b, c2 + q);
+	}
+}
+template <int OP, int NDIV>
+static void run_divs(float **d, long long n)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_divs<OP, NDIV>), dim3(4096), dim3(256), 0, 0, (const v4f *)d[0], (const v4f *)d[1], (const v4f *)d[2],
+		                   (const v4f *)d[3], (const v4f *)d[4], (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n / 4);
+	};
+	launch(); launch();
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 3; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+	const char *names[] = { "IEEE a/b", "a*rcp(b)", "IEEE sqrtf", "10-fma chain" };
+	printf("%-13s x %2d per pair : %7.3f ms per 1e9 pairs, %8.1f G ops/s\n", names[OP], NDIV, ms * 1e9 / n,
+	       (double)NDIV * n / ms / 1e6);
+}
+
 template <bool NT, int WORK, int UNROLL>
 static void run(const char *name, int blocks, float **d, long long n)
 {
@@ -383,6 +431,11 @@ int main(int argc, char **argv)
 		if (hipMalloc((void **)&tab, 1458000 * 12 * 4) != hipSuccess) return 1;
 		(void)hipMemset(tab, 0, 1458000 * 12 * 4);
 		const unsigned int sizes[] = { 65536, 262144, 524288, 786432, 1458000, 2916000, 5832000 };
+		if (argv[2][0] == 'd') {
+			run_divs<0, 0>(d, n); run_divs<0, 8>(d, n); run_divs<0, 16>(d, n); run_divs<0, 32>(d, n);
+			run_divs<1, 16>(d, n); run_divs<1, 32>(d, n); run_divs<2, 16>(d, n); run_divs<3, 16>(d, n); run_divs<3, 32>(d, n);
+			return 0;
+		}
 		if (argv[2][0] == 'w') {
 			for (unsigned int e : { 786432u, 1458000u }) {
 				run_sg_pol<0, 0>(e, d, tab, n); run_sg_pol<1, 1>(e, d, tab, n); run_sg_pol<2, 2>(e, d, tab, n);

@@ -21,6 +21,19 @@ inline int grid_for(long long n)
 	return (int)blocks;
 }
 
+// The VALU-bound kernels of the analytic lobes (eval, eval_pp, sample of beckmann / ggx) get one
+// workgroup per 256 units: the hardware dispatcher balances the data-dependent work (Beckmann's
+// Newton loop, dead lanes) better than a persistent grid-stride grid does -- measured -3 % (GGX
+// eval+pdf) and -8 % (Beckmann sample).  The table-driven kinds are faster on the persistent grid
+// (tabular eval: 2.25 vs 3.86 ms per 1e8).  The loop stays for batches beyond 2^31 - 1 workgroups.
+inline int grid_full(long long n)
+{
+	long long blocks = (n + BLOCK - 1) / BLOCK;
+	if (blocks > 0x7fffffffLL) blocks = 0x7fffffffLL;
+	if (blocks < 1) blocks = 1;
+	return (int)blocks;
+}
+
 template <int KIND, int WANT, int FRK = -1>
 DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float &pdf)
 {
@@ -63,7 +76,7 @@ template <int KIND, int FRK>
 hipError_t launch_eval_kind_fr(hipStream_t s, const Brdf &b, const Params &p, long long n,
                                const View &i, const View &o, const View &out, float *out_pdf, int want)
 {
-	dim3 g(grid_for(n)), t(BLOCK);
+	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
 	switch (want) {
 	case 1: hipLaunchKernelGGL((k_eval<KIND, 1, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
 	case 2: hipLaunchKernelGGL((k_eval<KIND, 2, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
@@ -123,7 +136,7 @@ hipError_t launch_eval_pp_kind(hipStream_t s, const Brdf &b, long long n, const 
                                const float *rec, const Lrep &base, const View &out, float *out_pdf,
                                float *out_pp, int want)
 {
-	dim3 g(grid_for(n)), t(BLOCK);
+	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
 	switch (want) {
 	case 1: hipLaunchKernelGGL((k_eval_pp<KIND, 1, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
 	case 2: hipLaunchKernelGGL((k_eval_pp<KIND, 2, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
@@ -177,7 +190,7 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
                               unsigned long long start, const View &o, const View &out_i,
                               const View *out_w, float *out_pdf)
 {
-	dim3 g(grid_for(n)), t(BLOCK);
+	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
 	View w = out_w ? *out_w : View{ nullptr, nullptr, nullptr, 0 };
 	bool is = out_w != nullptr, rng = u1 == nullptr;
 	if (!is && !rng) hipLaunchKernelGGL((k_sample<KIND, false, false>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);

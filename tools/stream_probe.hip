@@ -396,6 +396,44 @@ static void run_divs(float **d, long long n)
 	       (double)NDIV * n / ms / 1e6);
 }
 
+// same work, ONE pair per lane per iteration (dword accesses), as k_eval does it
+template <int OP, int NDIV, int BLOCKS_PER_CU>
+__global__ __launch_bounds__(256) void k_divs1(const float *a0, const float *a1, const float *a2, const float *b0, const float *b1,
+                                               const float *b2, float *c0, float *c1, float *c2, long long n, long long sa)
+{
+	long long stride = (long long)gridDim.x * 256;
+	for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+		long long q = k * sa;                       // runtime stride, like View::stride
+		float x = a0[q], y = a1[q], z = a2[q], u = b0[q], v = b1[q], w = b2[q];
+		float r = x + u, g = y + v + 1.5f, b = z + w + 2.5f;
+#pragma unroll
+		for (int j = 0; j < NDIV; ++j) {
+			if (OP == 0) r = g / (r + b);
+			if (OP == 3) { float t = r + b;
+#pragma unroll
+				for (int i = 0; i < 10; ++i) t = __builtin_fmaf(t, g, b);
+				r = t; }
+		}
+		c0[q] = r; c1[q] = g; c2[q] = b;
+	}
+}
+template <int OP, int NDIV>
+static void run_divs1(float **d, long long n, int blocks)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_divs1<OP, NDIV, 0>), dim3(blocks), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], n, 1LL);
+	};
+	launch(); launch();
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 3; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+	printf("1 pair/lane, dword accesses, op %d x %2d, blocks %7d : %7.3f ms per 1e9 pairs\n", OP, NDIV, blocks, ms * 1e9 / n);
+}
+
 template <bool NT, int WORK, int UNROLL>
 static void run(const char *name, int blocks, float **d, long long n)
 {
@@ -433,6 +471,8 @@ int main(int argc, char **argv)
 		const unsigned int sizes[] = { 65536, 262144, 524288, 786432, 1458000, 2916000, 5832000 };
 		if (argv[2][0] == 'd') {
 			run_divs<0, 0>(d, n); run_divs<0, 8>(d, n); run_divs<0, 16>(d, n); run_divs<0, 32>(d, n);
+			run_divs1<0, 0>(d, n, 4096); run_divs1<0, 16>(d, n, 4096); run_divs1<3, 16>(d, n, 4096); run_divs1<3, 32>(d, n, 4096);
+			run_divs1<0, 16>(d, n, 16384); run_divs1<0, 16>(d, n, (int)((n + 255) / 256)); run_divs1<3, 32>(d, n, 16384);
 			run_divs<1, 16>(d, n); run_divs<1, 32>(d, n); run_divs<2, 16>(d, n); run_divs<3, 16>(d, n); run_divs<3, 32>(d, n);
 			return 0;
 		}

@@ -331,7 +331,9 @@ DJB_DEV float tab_qf_radial(const Brdf &b, float u)                             
 }
 
 // ------------------------------------------------------------------ tabular_anisotropic fetches
-DJB_DEV int uwrap_repeat(int i, int edge) { while (i >= edge) i -= edge; while (i < 0) i += edge; return i; }   // :1183
+// spline::uwrap_repeat (dj_brdf.h:1183) subtracts / adds `edge` in a loop; the remainder form gives the same
+// value for every int and cannot spin for millions of iterations on a wild (saturated) coordinate
+DJB_DEV int uwrap_repeat(int i, int edge) { int r = i % edge; return r < 0 ? r + edge : r; }
 DJB_DEV int uwrap_edge(int i, int edge) { return i >= edge ? edge - 1 : (i < 0 ? 0 : i); }                      // :1191
 DJB_DEV float spline_rep(const float *pts, int n, float u)                             // spline::eval, uwrap_repeat
 {

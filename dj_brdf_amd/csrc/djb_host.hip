@@ -68,6 +68,10 @@ struct djb_brdf {
 	std::vector<float> aniso[8];
 	float aniso_fit[10];
 	int elev = 0, azim = 0;
+	// merl / utia created from a file or from memory: the file's double payload stays in HBM (one of
+	// `allocs`) for get_samples(); 35 MB per MERL material, 2 MB per UTIA material
+	const double *raw_samples = nullptr;
+	long long raw_count = 0;
 };
 
 namespace {
@@ -584,13 +588,15 @@ djb_status djb_brdf_create_merl_from_memory(djb_ctx *ctx, const double *samples,
 	if (e == hipSuccess) e = hipMemcpyAsync(raw, samples, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess) e = djbk::launch_merl_convert(ctx->stream, raw, n, tab);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-	if (raw) (void)hipFree(raw);
 	if (e != hipSuccess) {
+		if (raw) (void)hipFree(raw);
 		if (tab) (void)hipFree(tab);
 		delete b;
 		return fail(DJB_ERR_HIP, "djb_error: MERL upload failed: %s", hipGetErrorString(e));
 	}
 	b->allocs.push_back(tab);
+	b->allocs.push_back(raw);
+	b->raw_samples = raw; b->raw_count = 3 * (long long)n;
 	b->dev.merl = tab;
 	*out = b;
 	return DJB_OK;
@@ -617,13 +623,15 @@ djb_status djb_brdf_create_utia_from_memory(djb_ctx *ctx, const double *samples,
 	if (e == hipSuccess) e = hipMemcpyAsync(raw, samples, sizeof(double) * (size_t)UTIA_N, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess) e = djbk::launch_utia_convert(ctx->stream, raw, UTIA_N, tab);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-	if (raw) (void)hipFree(raw);
 	if (e != hipSuccess) {
+		if (raw) (void)hipFree(raw);
 		if (tab) (void)hipFree(tab);
 		delete b;
 		return fail(DJB_ERR_HIP, "djb_error: UTIA upload failed: %s", hipGetErrorString(e));
 	}
 	b->allocs.push_back(tab);
+	b->allocs.push_back(raw);
+	b->raw_samples = raw; b->raw_count = UTIA_N;
 	b->dev.utia = tab;
 	*out = b;
 	return DJB_OK;
@@ -709,6 +717,27 @@ djb_status djb_brdf_destroy(djb_brdf *b)
 }
 
 int djb_brdf_kind(const djb_brdf *b) { return b ? b->dev.kind : -1; }
+
+djb_status djb_brdf_get_samples(const djb_brdf *b, double *out, int64_t capacity, int64_t *count)
+{
+	if (!b || !count) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (b->dev.kind != DJB_KIND_MERL && b->dev.kind != DJB_KIND_UTIA)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: get_samples needs a merl or utia BRDF");
+	if (!b->raw_samples)
+		return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this table was built by the file pipeline, which does not keep the payload");
+	*count = b->raw_count;
+	if (!out) return DJB_OK;
+	if (capacity < b->raw_count) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: get_samples needs room for %lld doubles", b->raw_count);
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	std::lock_guard<std::recursive_mutex> call_lock(b->ctx->call_mu);
+	HIP_TRY(hipMemcpyAsync(out, b->raw_samples, sizeof(double) * (size_t)b->raw_count, hipMemcpyDeviceToHost, b->ctx->stream));
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	if (b->dev.kind == DJB_KIND_UTIA) {      // utia::normalize, dj_brdf.h:1162-1177: clamp to zero, then *= (float_t)(1.f / 140.f)
+		const float k = 1.f / 140.f;
+		for (long long j = 0; j < b->raw_count; ++j) { double v = out[j] > 0.0 ? out[j] : 0.0; out[j] = v * k; }
+	}
+	return DJB_OK;
+}
 int djb_brdf_get_shadow(const djb_brdf *b) { return b ? b->dev.shadow : -1; }
 
 static bool is_microfacet_kind(int k)

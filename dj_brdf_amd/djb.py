@@ -656,6 +656,15 @@ class abc(brdf):
         return self
 
 
+def _get_samples(b) -> np.ndarray:
+    """merl::get_samples / utia::get_samples (dj_brdf.h:132, 143): the table as the reference holds it."""
+    n = C.c_int64(0)
+    _lib.check(_lib.load().djb_brdf_get_samples(b._h, None, C.c_int64(0), C.byref(n)))
+    out = np.empty(n.value, np.float64)
+    _lib.check(_lib.load().djb_brdf_get_samples(b._h, C.c_void_p(out.ctypes.data), n, C.byref(n)))
+    return out
+
+
 class merl(brdf):
     """djb::merl(filename) (dj_brdf.h:126-133, 963-983).  ``merl.from_table`` builds the same
     object from the file payload in memory (3*n doubles, planes R, G, B)."""
@@ -672,6 +681,9 @@ class merl(brdf):
         _lib.check(_lib.load().djb_brdf_create_merl_from_memory(
             self.ctx._h, C.c_void_p(t.ctypes.data), C.c_int64(t.size // 3), C.byref(self._h)))
         return self
+
+    def get_samples(self) -> np.ndarray:
+        return _get_samples(self)
 
 
 class utia(brdf):
@@ -690,6 +702,9 @@ class utia(brdf):
             raise exc(1, "djb_error: UTIA table must hold 3*288*288 doubles")
         _lib.check(_lib.load().djb_brdf_create_utia_from_memory(self.ctx._h, C.c_void_p(t.ctypes.data), C.byref(self._h)))
         return self
+
+    def get_samples(self) -> np.ndarray:
+        return _get_samples(self)
 
 
 class tabular(microfacet):

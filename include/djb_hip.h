@@ -136,6 +136,10 @@ djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *, const djb_brdf *src, i
                                                int azimuthal_res, int shadow, djb_brdf **);
 djb_status djb_brdf_destroy(djb_brdf *);
 int        djb_brdf_kind(const djb_brdf *);
+/* merl::get_samples() / utia::get_samples(): the table as the reference holds it -- the file's
+ * doubles for MERL (3 x 90 x 90 x 180), the clamped and scaled doubles for UTIA (3 x 288 x 288,
+ * after utia::normalize).  out == NULL only reports *count.                dj_brdf.h:132, 143 */
+djb_status djb_brdf_get_samples(const djb_brdf *, double *out, int64_t capacity, int64_t *count);
 /* microfacet::set_shadow / get_shadow                                 dj_brdf.h:278-281 */
 int        djb_brdf_get_shadow(const djb_brdf *);
 /* The two microfacet mutators (beckmann, ggx, tabular, tabular_anisotropic handles only).  Like the

@@ -69,6 +69,18 @@ private:
 	djb_ctx *m_ctx;
 };
 
+/* merl / utia get_samples(): fetched from HBM on first use, cached in the object */
+inline const std::vector<double> &fetch_samples(const djb_brdf *h, std::vector<double> &cache)
+{
+	if (cache.empty()) {
+		int64_t n = 0;
+		check(djb_brdf_get_samples(h, NULL, 0, &n));
+		cache.resize((size_t)n);
+		check(djb_brdf_get_samples(h, &cache[0], n, &n));
+	}
+	return cache;
+}
+
 /* view of an array of djb::vec3 (AoS, stride 3 floats) */
 inline djb_vec3_view view(const vec3 *p)
 {
@@ -179,6 +191,9 @@ public:
 	{ hip::check(djb_brdf_create_merl_from_file(ctx(), filename, &m_h)); }
 	merl(const double *samples, int64_t n_per_channel, hip::context *c = NULL) : brdf(c)
 	{ hip::check(djb_brdf_create_merl_from_memory(ctx(), samples, n_per_channel, &m_h)); }
+	const std::vector<double> &get_samples() const { return hip::fetch_samples(m_h, m_samples); }   // dj_brdf.h:132
+private:
+	mutable std::vector<double> m_samples;
 };
 
 /* UTIA BRDF, dj_brdf.h:136-146 */
@@ -186,6 +201,9 @@ class utia : public brdf {
 public:
 	explicit utia(const char *filename, hip::context *c = NULL) : brdf(c)
 	{ hip::check(djb_brdf_create_utia_from_file(ctx(), filename, &m_h)); }
+	const std::vector<double> &get_samples() const { return hip::fetch_samples(m_h, m_samples); }   // dj_brdf.h:143
+private:
+	mutable std::vector<double> m_samples;
 };
 
 /* Fresnel API, dj_brdf.h:149-207 */

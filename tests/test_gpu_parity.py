@@ -363,3 +363,21 @@ def test_concurrent_callers_share_one_context(gpu_ctx):
     for t in range(T):
         assert np.array_equal(got[t][0].view(np.uint32), want[t][0].view(np.uint32)), f"thread {t}: merl"
         assert np.array_equal(got[t][1].view(np.uint32), want[t][1].view(np.uint32)), f"thread {t}: ggx"
+
+
+def test_get_samples(gpu_ctx, tmp_path):
+    # merl::get_samples / utia::get_samples (dj_brdf.h:132, 143)
+    tab = synth.merl_table_hashed()
+    m = djb.merl.from_table(tab, ctx=gpu_ctx)
+    assert np.array_equal(m.get_samples(), np.ascontiguousarray(tab, np.float64).reshape(-1))
+    p = str(tmp_path / "m.binary"); synth.write_merl_binary(p, tab)
+    assert np.array_equal(djb.merl(p, ctx=gpu_ctx).get_samples(), m.get_samples())
+    raw = np.random.default_rng(3).uniform(-5.0, 120.0, size=3 * 288 * 288)
+    u = djb.utia.from_table(raw, ctx=gpu_ctx)
+    want = np.maximum(0.0, raw) * np.float64(np.float32(1.0) / np.float32(140.0))     # utia::normalize, dj_brdf.h:1162-1177
+    assert np.array_equal(u.get_samples(), want)
+    with pytest.raises(djb.exc):
+        from dj_brdf_amd import _lib
+        import ctypes as C
+        n = C.c_int64(0)
+        _lib.check(_lib.load().djb_brdf_get_samples(djb.ggx(ctx=gpu_ctx)._h, None, C.c_int64(0), C.byref(n)))

@@ -150,6 +150,24 @@ def _scalar_in(u, like: _Vec):
 
 # --------------------------------------------------------------------------- fresnel (dj_brdf.h:149-207)
 class fresnel:
+    @staticmethod
+    def ior_to_f0(ior):
+        """fresnel::ior_to_f0 (dj_brdf.h:1255-1270): ((ior - 1) / (ior + 1))^2 with the reference's
+        float/double evaluation order; scalar or array."""
+        x = np.asarray(ior, dtype=np.float32)
+        tmp = ((x.astype(np.float64) - 1.0) / (x.astype(np.float64) + 1.0)).astype(np.float32)
+        r = tmp * tmp
+        return r if r.ndim else np.float32(r)
+
+    @staticmethod
+    def f0_to_ior(f0):
+        """fresnel::f0_to_ior (dj_brdf.h:1272-1290)."""
+        x = np.asarray(f0, dtype=np.float32)
+        s = np.sqrt(x.astype(np.float64)).astype(np.float32).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = np.where(x.astype(np.float64) == 1.0, 1.0, (1.0 + s) / (1.0 - s)).astype(np.float32)
+        return r if r.ndim else np.float32(r)
+
     class impl:
         kind = 0
 

@@ -44,6 +44,12 @@ int main()
 		expect("set_fresnel(schlick) eval.g", c.y, 0.441180676); expect("set_fresnel(schlick) eval.b", c.z, 0.180200979);
 		ggm.set_shadow(false);
 		expect("set_shadow(false) get_shadow", (double)ggm.get_shadow(), 0);
+		float f0, ior; djb::fresnel::ior_to_f0(1.5f, &f0); djb::fresnel::f0_to_ior(0.04f, &ior);
+		expect("fresnel::ior_to_f0(1.5)", f0, 0.04); expect("fresnel::f0_to_ior(0.04)", ior, 1.5);
+		djb::microfacet::params p5(0.4f, 0.25f, 0.3f, 0.1f, -0.2f); float ptx, pty; p5.get_location(&ptx, &pty);
+		expect("params(ax,ay,rho,tx,ty).tx", ptx, 0.1); expect("params(ax,ay,rho,tx,ty).ty", pty, -0.2);
+		p5.set_location(djb::vec3(-0.1f, 0.2f, 1.0f)); p5.get_location(&ptx, &pty);
+		expect("set_location(vec3).tx", ptx, 0.1); expect("set_location(vec3).ty", pty, -0.2);
 		djb::vec3 h, d; djb::brdf::io_to_hd(i, o, &h, &d);
 		expect("io_to_hd h.y", h.y, 0.160367534); expect("io_to_hd d.y", d.y, -0.347850591);
 		djb::tabular tab(djb::ggx(), 90);

@@ -15,6 +15,7 @@
 #ifndef DJB_HIP_HPP
 #define DJB_HIP_HPP
 
+#include <cmath>
 #include <cstddef>
 #include <exception>
 #include <string>
@@ -208,6 +209,17 @@ private:
 
 /* Fresnel API, dj_brdf.h:149-207 */
 namespace fresnel {
+	/* Utilities, dj_brdf.h:151-154, 1255-1290 (host-side scalar helpers, same float/double order) */
+	inline void ior_to_f0(float_t ior, float_t *f0)
+	{ float_t tmp = (float_t)(((double)ior - 1.0) / ((double)ior + 1.0)); *f0 = tmp * tmp; }
+	inline void f0_to_ior(float_t f0, float_t *ior)
+	{
+		if ((double)f0 == 1.0) { *ior = (float_t)1.0; return; }
+		float_t sqrt_f0 = (float_t)std::sqrt((double)f0);
+		*ior = (float_t)((1.0 + (double)sqrt_f0) / (1.0 - (double)sqrt_f0));
+	}
+	inline void ior_to_f0(const vec3 &ior, vec3 *f0) { ior_to_f0(ior.x, &f0->x); ior_to_f0(ior.y, &f0->y); ior_to_f0(ior.z, &f0->z); }
+	inline void f0_to_ior(const vec3 &f0, vec3 *ior) { f0_to_ior(f0.x, &ior->x); f0_to_ior(f0.y, &ior->y); f0_to_ior(f0.z, &ior->z); }
 	class impl {
 	public:
 		virtual ~impl() {}
@@ -293,12 +305,16 @@ public:
 		void set_pdfparams(float_t ax, float_t ay, float_t rho = 0.0, float_t tx_n = 0.0, float_t ty_n = 0.0)
 		{ *this = pdfparams(ax, ay, rho, tx_n, ty_n); }
 		void set_location(float_t tx_n, float_t ty_n) { *this = pdfparams(m_r.ax, m_r.ay, m_r.rho, tx_n, ty_n); }
+		/* dj_brdf.h:1444-1449: tx = -n.x / n.z, ty = -n.y / n.z.  The kernels use the unit normal of
+		 * (tx, ty); it agrees with `n` in direction whenever n.z > 0. */
+		void set_location(const vec3 &n) { set_location(-n.x / n.z, -n.y / n.z); }
 		void get_ellipse(float_t *a1, float_t *a2, float_t *phi_a = NULL) const
 		{ if (a1) *a1 = m_r.a1; if (a2) *a2 = m_r.a2; if (phi_a) *phi_a = m_r.phi_a; }
 		void get_pdfparams(float_t *ax, float_t *ay, float_t *rho = NULL, float_t *tx_n = NULL, float_t *ty_n = NULL) const
 		{ if (ax) *ax = m_r.ax; if (ay) *ay = m_r.ay; if (rho) *rho = m_r.rho; if (tx_n) *tx_n = m_r.tx_n; if (ty_n) *ty_n = m_r.ty_n; }
 		void get_location(float_t *tx_n, float_t *ty_n) const { if (tx_n) *tx_n = m_r.tx_n; if (ty_n) *ty_n = m_r.ty_n; }
 		void get_location(vec3 *n) const { if (n) *n = vec3(m_r.n[0], m_r.n[1], m_r.n[2]); }
+		params(float_t ax, float_t ay, float_t rho, float_t tx_n, float_t ty_n) { *this = pdfparams(ax, ay, rho, tx_n, ty_n); }   // dj_brdf.h:236
 		params(float_t a1 = 1.0, float_t a2 = 1.0, float_t phi_a = 0.0)
 		{ m_desc.kind = DJB_PARAMS_ELLIPTIC; m_desc.v[0] = a1; m_desc.v[1] = a2; m_desc.v[2] = phi_a; m_desc.v[3] = m_desc.v[4] = 0; resolve(); }
 		const djb_params *desc() const { return &m_desc; }

@@ -1756,5 +1756,22 @@ void o_fresnel_eval(const o_brdf *b, int64_t n, const float *c, float *out)
 {
 	for (int64_t k = 0; k < n; ++k) st3(out, k, fresnel_eval(&b->fresnel, c[k]));
 }
+/* dj_brdf.h:1255-1261: tmp = (ior - 1.0) / (ior + 1.0) in double, stored as float; f0 = tmp * tmp (float).
+ * dj_brdf.h:1272-1282: f0 == 1.0 -> 1; else sqrt_f0 = float(sqrt(double f0)); ior = float((1.0 + s) / (1.0 - s)). */
+void o_ior_f0(int dir, int64_t n, const float *x, float *y)
+{
+	for (int64_t k = 0; k < n; ++k) {
+		if (dir == 0) {
+			float tmp = (float)(((double)x[k] - 1.0) / ((double)x[k] + 1.0));
+			y[k] = tmp * tmp;
+		} else if ((double)x[k] == 1.0) {
+			y[k] = 1.0f;
+		} else {
+			float s = (float)sqrt((double)x[k]);
+			y[k] = (float)((1.0 + (double)s) / (1.0 - (double)s));
+		}
+	}
+}
+
 void o_erf(int64_t n, const float *x, float *y) { for (int64_t k = 0; k < n; ++k) y[k] = erf_(x[k]); }
 void o_erfinv(int64_t n, const float *x, float *y) { for (int64_t k = 0; k < n; ++k) y[k] = erfinv_(x[k]); }

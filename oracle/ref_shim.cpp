@@ -224,6 +224,21 @@ void ref_fresnel_eval(void *b_, long n, const float *c, float *out)
 	for (long k = 0; k < n; ++k) st(out, k, m->fresnel(c[k]));
 }
 
+// fresnel::ior_to_f0 / f0_to_ior (hdr:151-154); dir 0: ior -> f0, 1: f0 -> ior
+void ref_ior_f0(int dir, long n, const float *x, float *y)
+{
+	for (long k = 0; k < n; ++k) { if (dir == 0) djb::fresnel::ior_to_f0(x[k], &y[k]); else djb::fresnel::f0_to_ior(x[k], &y[k]); }
+}
+// params::set_location(const vec3 &n) (hdr:227): reported as (tx_n, ty_n) and the stored mean normal
+void ref_params_set_location_n(const float *n3, float *out5)
+{
+	djb::microfacet::params p = djb::microfacet::params::standard();
+	p.set_location(djb::vec3(n3[0], n3[1], n3[2]));
+	p.get_location(&out5[0], &out5[1]);
+	djb::vec3 m; p.get_location(&m);
+	out5[2] = m.x; out5[3] = m.y; out5[4] = m.z;
+}
+
 void ref_erf(long n, const float *x, float *y)    { for (long k = 0; k < n; ++k) y[k] = djb::erf(x[k]); }
 void ref_erfinv(long n, const float *x, float *y) { for (long k = 0; k < n; ++k) y[k] = djb::erfinv(x[k]); }
 

@@ -57,6 +57,10 @@ def main():
     out["erf_x"], out["erf_y"] = x, R.erf(x)
     x = np.linspace(-0.99999, 0.99999, 4001).astype(np.float32)
     out["erfinv_x"], out["erfinv_y"] = x, R.erfinv(x)
+    x = np.concatenate([np.linspace(1.0, 6.0, 2001), [0.25, 0.5, 1.33, 1.5]]).astype(np.float32)
+    out["ior_x"], out["ior_f0"] = x, R.ior_f0(0, x)                     # fresnel::ior_to_f0
+    x = np.concatenate([np.linspace(0.0, 1.0, 2001), [0.04, 0.9999999]]).astype(np.float32)
+    out["f0_x"], out["f0_ior"] = x, R.ior_f0(1, x)                      # fresnel::f0_to_ior
     i = synth.directions_aos(N_HD, synth.SEED_I, start=1000)
     o = synth.directions_aos(N_HD, synth.SEED_O, start=1000)
     h, d = R.io_to_hd(i, o)

@@ -287,6 +287,11 @@ class CheckerLib:
         self._fn("fresnel_eval")(b, C.c_int64(c.shape[0]), _ptr(c), _ptr(out))
         return out
 
+    def ior_f0(self, direction, x):
+        x = _f32(x); y = np.empty_like(x)
+        self._fn("ior_f0")(C.c_int(direction), C.c_int64(x.size), _ptr(x), _ptr(y))
+        return y
+
     def erf(self, x):
         x = _f32(x); y = np.empty_like(x)
         self._fn("erf")(C.c_int64(x.size), _ptr(x), _ptr(y))

@@ -46,6 +46,17 @@ def test_params_resolve_matches_reference_golden():
         assert np.array_equal(got.view(np.uint32)[~nan_ok], want.view(np.uint32)[~nan_ok]), (p, got, want)
 
 
+def test_fresnel_ior_f0_helpers_match_reference_golden():
+    # fresnel::ior_to_f0 / f0_to_ior (dj_brdf.h:151-154, 1255-1290): host-side helpers of the mirror
+    g = np.load(os.path.join(ROOT, "tests", "golden", "math.npz"))
+    got = djb.fresnel.ior_to_f0(g["ior_x"])
+    assert np.array_equal(got.view(np.uint32), g["ior_f0"].view(np.uint32))
+    got, want = djb.fresnel.f0_to_ior(g["f0_x"]), g["f0_ior"]
+    ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isinf(got) & np.isinf(want) & (np.sign(got) == np.sign(want)))
+    assert ok.all()
+    assert djb.fresnel.ior_to_f0(1.5) == np.float32(0.2) * np.float32(0.2) and djb.fresnel.f0_to_ior(1.0) == 1.0
+
+
 def test_invalid_params_raise_like_the_reference_asserts():
     for bad in (djb.microfacet.params.elliptic(0.0, 0.3), djb.microfacet.params.pdfparams(0.3, -1.0),
                 djb.microfacet.params.pdfparams(0.3, 0.3, 1.0)):

@@ -497,6 +497,14 @@ class microfacet(brdf):
     def qf1(self, u):
         return self._query(22, self._cols(u))
 
+    def qf2(self, u, k):
+        """microfacet::qf2 base stub (dj_brdf.h:1783-1786)"""
+        raise exc(5, "djb_error: Not Implemented")
+
+    def qf3(self, u, k, qf2):
+        """microfacet::qf3 base stub (dj_brdf.h:1788-1791)"""
+        raise exc(5, "djb_error: Not Implemented")
+
     def get_shadow(self) -> int:
         return _lib.load().djb_brdf_get_shadow(self._h)
 

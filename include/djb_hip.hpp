@@ -348,6 +348,9 @@ public:
 	float_t p22(float_t x, float_t y, const params &p = params::standard()) const { vec3 a(x, y, 0); return q(DJB_Q_P22, &a, NULL, NULL, p); }
 	float_t vp22(float_t x, float_t y, const vec3 &k, const params &p = params::standard()) const { vec3 a(x, y, 0); return q(DJB_Q_VP22, &a, &k, NULL, p); }
 	float_t vndf(const vec3 &h, const vec3 &k, const params &p = params::standard()) const { return q(DJB_Q_VNDF, &h, &k, NULL, p); }
+	// the base-class quantile functions are stubs in the reference too (dj_brdf.h:1783-1791)
+	virtual float_t qf2(float_t, const vec3 &) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
+	virtual float_t qf3(float_t, const vec3 &, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
 protected:
 	microfacet(hip::context *c, const fresnel::impl &f) : brdf(c), m_fresnel(f.copy()) {}
 	const djb_params *params_of(const void *user_param) const

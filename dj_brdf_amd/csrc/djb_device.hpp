@@ -962,21 +962,33 @@ DJB_DEV double sgd_ndf(double ch, double alpha, double p, double kap)           
 	double ax = alpha + t2 / alpha;
 	return (kap * exp(-ax) * inv_pi) / (pow(ax, p) * c2 * c2);
 }
+// model row: rhoD rhoS alpha p f0 f1 kap lambda c k theta0 (3 doubles each)
+DJB_DEV v3 sgd_g1_rgb(const Brdf &b, v3 k)                                                // sgd::g1, :3477
+{
+	const double *m = b.model;
+	return mk(F(sgd_g1(k, m[30], m[24], m[27], m[21])), F(sgd_g1(k, m[31], m[25], m[28], m[22])),
+	          F(sgd_g1(k, m[32], m[26], m[29], m[23])));
+}
+DJB_DEV v3 sgd_ndf_rgb(const Brdf &b, v3 h)                                               // sgd::ndf, :3490
+{
+	const double *m = b.model;
+	return mk(F(sgd_ndf(D(h.z), m[6], m[9], m[18])), F(sgd_ndf(D(h.z), m[7], m[10], m[19])),
+	          F(sgd_ndf(D(h.z), m[8], m[11], m[20])));
+}
+DJB_DEV v3 sgd_gaf_rgb(const Brdf &b, v3 i, v3 o)                                         // sgd::gaf = g1(i) * g1(o), :3472
+{
+	v3 gi = sgd_g1_rgb(b, i), go = sgd_g1_rgb(b, o);
+	return mk(gi.x * go.x, gi.y * go.y, gi.z * go.z);
+}
 DJB_DEV v3 sgd_eval(const Brdf &b, v3 i, v3 o)                                            // :3454
 {
-	const double *m = b.model;   // rhoD rhoS alpha p f0 f1 kap lambda c k theta0
+	const double *m = b.model;
 	if (D(i.z) > 0.0 && D(o.z) > 0.0) {
 		v3 h = normalize(add(i, o));
 		v3 Kd = mk(F(m[0]), F(m[1]), F(m[2])), Ks = mk(F(m[3]), F(m[4]), F(m[5]));
 		v3 Fr = fresnel_eval(b.fr, sat_(dot(i, h)));
-		float gi[3], go[3], nd[3];
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			gi[c] = F(sgd_g1(i, m[30 + c], m[24 + c], m[27 + c], m[21 + c]));
-			go[c] = F(sgd_g1(o, m[30 + c], m[24 + c], m[27 + c], m[21 + c]));
-			nd[c] = F(sgd_ndf(D(h.z), m[6 + c], m[9 + c], m[18 + c]));
-		}
-		v3 FDG = mk((Fr.x * nd[0]) * (gi[0] * go[0]), (Fr.y * nd[1]) * (gi[1] * go[1]), (Fr.z * nd[2]) * (gi[2] * go[2]));
+		v3 G = sgd_gaf_rgb(b, i, o), Dn = sgd_ndf_rgb(b, h);
+		v3 FDG = mk((Fr.x * Dn.x) * G.x, (Fr.y * Dn.y) * G.y, (Fr.z * Dn.z) * G.z);
 		v3 spec = divs(mk(Ks.x * FDG.x, Ks.y * FDG.y, Ks.z * FDG.z), i.z * o.z);
 		return divs(add(Kd, spec), F(DJB_PI));
 	}
@@ -984,18 +996,28 @@ DJB_DEV v3 sgd_eval(const Brdf &b, v3 i, v3 o)                                  
 }
 
 // ------------------------------------------------------------------ ABC (dj_brdf.h:3608-3668)
+// model row: kD[3] A[3] B C ior
+DJB_DEV float abc_gaf(v3 h, v3 i, v3 o)                                                   // abc::gaf, :3647
+{
+	float g1_i = fmin_(1.0f, 2.0f * (h.z * i.z / dot(h, i)));
+	float g1_o = fmin_(1.0f, 2.0f * (h.z * o.z / dot(h, o)));
+	return fmin_(g1_i, g1_o);
+}
+DJB_DEV v3 abc_ndf_rgb(const Brdf &b, v3 h)                                               // abc::ndf, :3657 + abc__ndf :3608
+{
+	const double *m = b.model;
+	double den = pow(1.0 + m[6] * (1.0 - D(h.z)), m[7]);
+	return mk(F(m[3] / den), F(m[4] / den), F(m[5] / den));
+}
 DJB_DEV v3 abc_eval(const Brdf &b, v3 i, v3 o)                                            // :3633
 {
-	const double *m = b.model;   // kD[3] A[3] B C ior
+	const double *m = b.model;
 	if (D(i.z) > 0.0 && D(o.z) > 0.0) {
 		v3 h = normalize(add(i, o));
 		v3 Kd = mk(F(m[0]), F(m[1]), F(m[2]));
 		v3 Fr = fresnel_eval(b.fr, sat_(dot(i, h)));
-		float g1_i = fmin_(1.0f, 2.0f * (h.z * i.z / dot(h, i)));                            // :3649
-		float g1_o = fmin_(1.0f, 2.0f * (h.z * o.z / dot(h, o)));
-		float G = fmin_(g1_i, g1_o);
-		double den = pow(1.0 + m[6] * (1.0 - D(h.z)), m[7]);                                // :3608
-		v3 Dn = mk(F(m[3] / den), F(m[4] / den), F(m[5] / den));
+		float G = abc_gaf(h, i, o);
+		v3 Dn = abc_ndf_rgb(b, h);
 		v3 spec = divs(scale(G, mk(Fr.x * Dn.x, Fr.y * Dn.y, Fr.z * Dn.z)), F(DJB_PI * D(i.z) * D(o.z)));
 		return add(divs(Kd, F(DJB_PI)), spec);
 	}

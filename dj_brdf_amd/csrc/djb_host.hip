@@ -1119,7 +1119,14 @@ djb_status djb_query_batch(djb_ctx *ctx, const djb_brdf *b, int which, int64_t n
 {
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
 	const bool aniso = b->dev.kind == DJB_KIND_TABULAR_ANISO;
-	if (b->dev.kind > DJB_KIND_TABULAR && !aniso)
+	const bool model = b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_ABC;
+	const bool model_q = which >= DJB_Q_MODEL_NDF && which <= DJB_Q_MODEL_G1;
+	if (model) {
+		if (!(model_q || which == DJB_Q_FRESNEL) || (which == DJB_Q_MODEL_G1 && b->dev.kind != DJB_KIND_SGD))
+			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: sgd / abc answer ndf, gaf, fresnel (and g1 for sgd) only");
+	} else if (model_q)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: DJB_Q_MODEL_* need an sgd or abc brdf");
+	if (b->dev.kind > DJB_KIND_TABULAR && !aniso && !model)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: queries need a microfacet brdf");
 	if ((which >= DJB_Q_QF2_RADIAL && which <= DJB_Q_QF1) && (b->dev.kind == DJB_KIND_TABULAR || aniso))
 		return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented");          // dj_brdf.h:1854, 1859

@@ -204,7 +204,8 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
 // (dj_brdf.h:258-276, 307-314).  `which` is wave-uniform.
 enum { Q_NDF = 0, Q_GAF, Q_G1, Q_SIGMA, Q_P22, Q_VP22, Q_VNDF, Q_FRESNEL,
        Q_P22_RADIAL = 16, Q_SIGMA_STD_RADIAL, Q_CDF_RADIAL, Q_QF_RADIAL, Q_QF2_RADIAL, Q_QF3_RADIAL, Q_QF1,
-       Q_A_PDF1 = 32, Q_A_CDF1, Q_A_QF1, Q_A_PDF2, Q_A_CDF2, Q_A_QF2 };
+       Q_A_PDF1 = 32, Q_A_CDF1, Q_A_QF1, Q_A_PDF2, Q_A_CDF2, Q_A_QF2,
+       Q_MODEL_NDF = 48, Q_MODEL_GAF, Q_MODEL_G1 };
 
 template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_query(Brdf b, Params p, int which, long long n, View va, View vb,
@@ -249,6 +250,28 @@ __global__ __launch_bounds__(BLOCK) void k_query(Brdf b, Params p, int which, lo
 		case Q_A_PDF2: r.x = KIND == KIND_TABULAR_ANISO ? aniso_pdf2(b, a.x, a.y) : 0.0f; break;
 		case Q_A_CDF2: r.x = KIND == KIND_TABULAR_ANISO ? aniso_cdf2(b, a.x, a.y) : 0.0f; break;
 		case Q_A_QF2:  r.x = KIND == KIND_TABULAR_ANISO ? aniso_qf2(b, a.x, a.y) : 0.0f; break;
+		}
+		store3(vout, k, r);
+	}
+}
+
+// sgd::{ndf, gaf, g1, fresnel} and abc::{ndf, gaf, fresnel} (dj_brdf.h:505-509, 530-533)
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_model_query(Brdf b, int which, long long n, View va, View vb, View vc, View vout)
+{
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		v3 a = load3(va, k), r = mk(0, 0, 0);
+		switch (which) {
+		case Q_FRESNEL: r = fresnel_eval(b.fr, a.x); break;
+		case Q_MODEL_NDF: r = KIND == KIND_SGD ? sgd_ndf_rgb(b, a) : abc_ndf_rgb(b, a); break;
+		case Q_MODEL_GAF: {
+			v3 i = load3(vb, k), o = load3(vc, k);
+			if (KIND == KIND_SGD) r = sgd_gaf_rgb(b, i, o);
+			else r.x = abc_gaf(a, i, o);
+			break;
+		}
+		case Q_MODEL_G1: if (KIND == KIND_SGD) r = sgd_g1_rgb(b, a); break;
 		}
 		store3(vout, k, r);
 	}
@@ -458,6 +481,8 @@ hipError_t launch_query(hipStream_t s, const Brdf &b, const Params &p, int which
 	case KIND_GGX:      hipLaunchKernelGGL((k_query<KIND_GGX>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
 	case KIND_TABULAR:  hipLaunchKernelGGL((k_query<KIND_TABULAR>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
 	case KIND_TABULAR_ANISO: hipLaunchKernelGGL((k_query<KIND_TABULAR_ANISO>), g, t, 0, s, b, p, which, n, a, bb, c, out); break;
+	case KIND_SGD: hipLaunchKernelGGL((k_model_query<KIND_SGD>), g, t, 0, s, b, which, n, a, bb, c, out); break;
+	case KIND_ABC: hipLaunchKernelGGL((k_model_query<KIND_ABC>), g, t, 0, s, b, which, n, a, bb, c, out); break;
 	default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError();

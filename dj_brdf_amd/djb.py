@@ -649,7 +649,20 @@ class lambert(brdf):
         _lib.check(_lib.load().djb_brdf_create_lambert(self.ctx._h, C.byref(self._h)))
 
 
-class sgd(brdf):
+class _model_queries:
+    """ndf / gaf / g1 / fresnel members of the sgd and abc classes (dj_brdf.h:505-509, 530-533)."""
+
+    def _mq(self, which, a, b=None, c=None, width=3):
+        return microfacet._query(self, which, a, b, c, None, width)
+
+    def ndf(self, h):
+        return self._mq(48, h)
+
+    def fresnel(self, cos_theta_d):
+        return self._mq(7, microfacet._cols(cos_theta_d))
+
+
+class sgd(brdf, _model_queries):
     """djb::sgd(name): Shifted Gamma Distribution BRDF with the published per-material parameters
     (dj_brdf.h:481-511, 3436-3500).  Unknown names raise exc ("No SGD parameters for ...")."""
 
@@ -665,8 +678,14 @@ class sgd(brdf):
         _lib.check(_lib.load().djb_brdf_create_sgd_from_params(self.ctx._h, C.c_void_p(p.ctypes.data), C.byref(self._h)))
         return self
 
+    def gaf(self, h, i, o):
+        return self._mq(49, h, i, o)
 
-class abc(brdf):
+    def g1(self, k):
+        return self._mq(50, k)
+
+
+class abc(brdf, _model_queries):
     """djb::abc(name): ABC BRDF with the published per-material parameters (dj_brdf.h:514-535, 3617-3668)."""
 
     def __init__(self, name: str, ctx=None):
@@ -680,6 +699,9 @@ class abc(brdf):
         p = np.ascontiguousarray(params9, dtype=np.float64).reshape(9)
         _lib.check(_lib.load().djb_brdf_create_abc_from_params(self.ctx._h, C.c_void_p(p.ctypes.data), C.byref(self._h)))
         return self
+
+    def gaf(self, h, i, o):
+        return self._mq(49, h, i, o, width=1)
 
 
 def _get_samples(b) -> np.ndarray:

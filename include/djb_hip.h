@@ -196,7 +196,10 @@ enum { DJB_Q_NDF = 0, DJB_Q_GAF = 1, DJB_Q_G1 = 2, DJB_Q_SIGMA = 3, DJB_Q_P22 = 
        /* tabular_anisotropic only (dj_brdf.h:450-455): PDF1(phi) CDF1(phi) QF1(u) PDF2(theta,phi)
         * CDF2(theta,phi) QF2(u,phi), arguments in a.x / a.y */
        DJB_Q_ANISO_PDF1 = 32, DJB_Q_ANISO_CDF1 = 33, DJB_Q_ANISO_QF1 = 34, DJB_Q_ANISO_PDF2 = 35,
-       DJB_Q_ANISO_CDF2 = 36, DJB_Q_ANISO_QF2 = 37 };
+       DJB_Q_ANISO_CDF2 = 36, DJB_Q_ANISO_QF2 = 37,
+       /* sgd / abc handles (dj_brdf.h:505-509, 530-533): ndf(h) -> rgb; gaf(h, i, o) -> rgb (sgd) or out.x (abc);
+        * g1(k) -> rgb (sgd only); DJB_Q_FRESNEL works for them too */
+       DJB_Q_MODEL_NDF = 48, DJB_Q_MODEL_GAF = 49, DJB_Q_MODEL_G1 = 50 };
 djb_status djb_query_batch(djb_ctx *, const djb_brdf *, int which, int64_t n, const djb_vec3_view *a,
                            const djb_vec3_view *b, const djb_vec3_view *c, const djb_params *params,
                            const djb_vec3_view *out, int mem);

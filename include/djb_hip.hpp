@@ -276,12 +276,33 @@ namespace fresnel {
 class sgd : public brdf {
 public:
 	explicit sgd(const char *name, hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_sgd(ctx(), name, &m_h)); }
+	vec3 ndf(const vec3 &h) const { return mq(DJB_Q_MODEL_NDF, h, NULL, NULL); }
+	vec3 gaf(const vec3 &h, const vec3 &i, const vec3 &o) const { return mq(DJB_Q_MODEL_GAF, h, &i, &o); }
+	vec3 g1(const vec3 &k) const { return mq(DJB_Q_MODEL_G1, k, NULL, NULL); }
+	vec3 fresnel(float_t cos_theta_d) const { return mq(DJB_Q_FRESNEL, vec3(cos_theta_d, 0, 0), NULL, NULL); }
+protected:
+	vec3 mq(int which, const vec3 &a, const vec3 *b, const vec3 *c) const
+	{
+		vec3 r; djb_vec3_view va = hip::view(&a), vb = hip::view(b ? b : &a), vc = hip::view(c ? c : &a), vr = hip::view(&r);
+		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, &vb, &vc, NULL, &vr, DJB_MEM_HOST));
+		return r;
+	}
 };
 
 /* ABC Distribution BRDF, dj_brdf.h:514-535 */
 class abc : public brdf {
 public:
 	explicit abc(const char *name, hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_abc(ctx(), name, &m_h)); }
+	vec3 ndf(const vec3 &h) const { return mq(DJB_Q_MODEL_NDF, h, NULL, NULL); }
+	float_t gaf(const vec3 &h, const vec3 &i, const vec3 &o) const { return mq(DJB_Q_MODEL_GAF, h, &i, &o).x; }
+	vec3 fresnel(float_t cos_theta_d) const { return mq(DJB_Q_FRESNEL, vec3(cos_theta_d, 0, 0), NULL, NULL); }
+protected:
+	vec3 mq(int which, const vec3 &a, const vec3 *b, const vec3 *c) const
+	{
+		vec3 r; djb_vec3_view va = hip::view(&a), vb = hip::view(b ? b : &a), vc = hip::view(c ? c : &a), vr = hip::view(&r);
+		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, &vb, &vc, NULL, &vr, DJB_MEM_HOST));
+		return r;
+	}
 };
 
 /* Microfacet API, dj_brdf.h:210-298 */

@@ -812,6 +812,43 @@ static o_vec3 abc_eval(const o_brdf *b, o_vec3 i, o_vec3 o) /* hdr:3633-3645 */
 	return v3(0, 0, 0);
 }
 
+static o_vec3 ld3(const float *p, int64_t k);
+static void st3(float *p, int64_t k, o_vec3 v);
+/* sgd::{ndf,gaf,g1} (hdr:3472-3500) and abc::{ndf,gaf} (hdr:3647-3668) as their own entry point.
+ * which: 0 ndf(h) -> rgb, 1 gaf(h, i, o) -> rgb (sgd) / out[0] (abc), 2 g1(k) -> rgb (sgd), 3 fresnel(a[0]) */
+void o_model_query(const o_brdf *b, int which, int64_t n, const float *a, const float *bi, const float *co, float *out)
+{
+	const double *m = b->model;
+	for (int64_t k = 0; k < n; ++k) {
+		o_vec3 A = ld3(a, k), r = v3(0, 0, 0);
+		if (which == 3) r = fresnel_eval(&b->fresnel, A.x);
+		else if (b->kind == O_BRDF_SGD) {
+			if (which == 0)
+				r = v3(F(sgd_ndf(D(A.z), m[6], m[9], m[18])), F(sgd_ndf(D(A.z), m[7], m[10], m[19])), F(sgd_ndf(D(A.z), m[8], m[11], m[20])));
+			else {
+				o_vec3 g[2];
+				for (int w = 0; w < 2; ++w) {
+					o_vec3 kk = which == 2 ? A : ld3(w == 0 ? bi : co, k);
+					g[w] = v3(F(sgd_g1(kk, m[30], m[24], m[27], m[21])), F(sgd_g1(kk, m[31], m[25], m[28], m[22])),
+					          F(sgd_g1(kk, m[32], m[26], m[29], m[23])));
+				}
+				r = which == 2 ? g[0] : v3_mul(g[0], g[1]);
+			}
+		} else {
+			if (which == 0) {
+				double tmp = 1.0 - D(A.z);
+				r = v3(F(m[3] / pow(1.0 + m[6] * tmp, m[7])), F(m[4] / pow(1.0 + m[6] * tmp, m[7])), F(m[5] / pow(1.0 + m[6] * tmp, m[7])));
+			} else if (which == 1) {
+				o_vec3 i = ld3(bi, k), o = ld3(co, k);
+				float g1_i = fminf_(1.0f, 2.0f * (A.z * i.z / v3_dot(A, i)));
+				float g1_o = fminf_(1.0f, 2.0f * (A.z * o.z / v3_dot(A, o)));
+				r.x = fminf_(g1_i, g1_o);
+			}
+		}
+		st3(out, k, r);
+	}
+}
+
 /* ------------------------------------------------------------------ generic dispatch */
 static int is_microfacet(const o_brdf *b) { return b->kind <= O_BRDF_TABULAR || b->kind == O_BRDF_TABULAR_ANISO; }
 

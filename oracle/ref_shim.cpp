@@ -224,6 +224,26 @@ void ref_fresnel_eval(void *b_, long n, const float *c, float *out)
 	for (long k = 0; k < n; ++k) st(out, k, m->fresnel(c[k]));
 }
 
+// sgd / abc member queries (hdr:505-509, 530-533): which 0 ndf(h), 1 gaf(h, i, o), 2 g1(k) [sgd], 3 fresnel(a.x)
+void ref_model_query(void *b_, int which, long n, const float *a, const float *bi, const float *co, float *out)
+{
+	const djb::sgd *s = dynamic_cast<const djb::sgd *>((const djb::brdf *)b_);
+	const djb::abc *c = dynamic_cast<const djb::abc *>((const djb::brdf *)b_);
+	for (long k = 0; k < n; ++k) {
+		djb::vec3 A = ld(a, k), r(0);
+		if (which == 3) r = s ? s->fresnel(A.x) : c->fresnel(A.x);
+		else if (s) {
+			if (which == 0) r = s->ndf(A);
+			else if (which == 1) r = s->gaf(A, ld(bi, k), ld(co, k));
+			else r = s->g1(A);
+		} else {
+			if (which == 0) r = c->ndf(A);
+			else if (which == 1) r.x = c->gaf(A, ld(bi, k), ld(co, k));
+		}
+		st(out, k, r);
+	}
+}
+
 // fresnel::ior_to_f0 / f0_to_ior (hdr:151-154); dir 0: ior -> f0, 1: f0 -> ior
 void ref_ior_f0(int dir, long n, const float *x, float *y)
 {

@@ -79,6 +79,13 @@ def main():
             b = getattr(R, kind)(name)
             out[f"{kind}_{name}_eval"] = R.eval(b, i, o)
             out[f"{kind}_{name}_evalp"] = R.eval(b, i, o, None, "evalp")
+            # member queries sgd::{ndf,gaf,g1,fresnel} / abc::{ndf,gaf,fresnel}: h := i, (i, o) := (o, i)
+            cc = np.zeros_like(i); cc[:, 0] = np.clip(i[:, 2], 0, 1)
+            out[f"{kind}_{name}_ndf"] = R.model_query(b, "ndf", i)
+            out[f"{kind}_{name}_gaf"] = R.model_query(b, "gaf", i, o, i)
+            out[f"{kind}_{name}_fresnel"] = R.model_query(b, "fresnel", cc)
+            if kind == "sgd":
+                out[f"{kind}_{name}_g1"] = R.model_query(b, "g1", o)
         t = R.tabular(getattr(R, kind)(MODEL_MATERIALS[0]), 90, True)
         for k, v in R.tabular_tables(t).items():
             out[f"{kind}_fit_{k}"] = np.atleast_1d(v)

@@ -287,6 +287,14 @@ class CheckerLib:
         self._fn("fresnel_eval")(b, C.c_int64(c.shape[0]), _ptr(c), _ptr(out))
         return out
 
+    def model_query(self, b, which, a, i=None, o=None):
+        """sgd / abc members: which = 'ndf' | 'gaf' | 'g1' | 'fresnel' (a = h, k, or cos_theta_d in column 0)"""
+        code = {"ndf": 0, "gaf": 1, "g1": 2, "fresnel": 3}[which]
+        a = _f32(a); i = _f32(i) if i is not None else a; o = _f32(o) if o is not None else a
+        out = np.empty((a.shape[0], 3), dtype=np.float32)
+        self._fn("model_query")(b, C.c_int(code), C.c_int64(a.shape[0]), _ptr(a), _ptr(i), _ptr(o), _ptr(out))
+        return out
+
     def ior_f0(self, direction, x):
         x = _f32(x); y = np.empty_like(x)
         self._fn("ior_f0")(C.c_int(direction), C.c_int64(x.size), _ptr(x), _ptr(y))

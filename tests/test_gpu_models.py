@@ -45,6 +45,30 @@ def test_models_all_materials_vs_oracle(gpu_ctx, oracle, kind):
     assert np.array_equal(b2.eval(i, o).view(np.uint32), b.eval(i, o).view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", ["sgd", "abc"])
+def test_model_member_queries(gpu_ctx, oracle, kind):
+    """sgd::{ndf, gaf, g1, fresnel} / abc::{ndf, gaf, fresnel} (dj_brdf.h:505-509, 530-533)."""
+    n = 1 << 14
+    h = synth.directions_aos(n, 5); i = synth.directions_aos(n, 6); o = synth.directions_aos(n, 7)
+    c = np.clip(h[:, 2], 0, 1)
+    cc = np.zeros((n, 3), np.float32); cc[:, 0] = c
+    for name in ("gold-metallic-paint", "alum-bronze", "beige-fabric", "pearl-paint"):
+        b, ob = getattr(djb, kind)(name, ctx=gpu_ctx), getattr(oracle, kind)(name)
+        ex = assert_close(f"{kind}/{name} ndf", b.ndf(h), oracle.model_query(ob, "ndf", h), 1e-5)
+        assert ex > 0.99
+        assert_close(f"{kind}/{name} fresnel", b.fresnel(c), oracle.model_query(ob, "fresnel", cc), 1e-5)
+        want = oracle.model_query(ob, "gaf", h, i, o)
+        if kind == "sgd":
+            assert_close(f"{name} gaf", b.gaf(h, i, o), want, 1e-5)
+            assert_close(f"{name} g1", b.g1(i), oracle.model_query(ob, "g1", i), 1e-5)
+        else:
+            assert_close(f"{name} gaf", b.gaf(h, i, o), want[:, 0], 1e-5)
+            with pytest.raises(djb.exc):
+                djb.microfacet._query(b, 50, i)          # abc has no g1
+    with pytest.raises(djb.exc):
+        djb.microfacet._query(djb.ggx(ctx=gpu_ctx), 48, h)   # model queries need sgd / abc
+
+
 def test_unknown_material_raises(gpu_ctx):
     for kind, msg in (("sgd", "No SGD parameters for nope"), ("abc", "No ABC parameters for nope")):
         with pytest.raises(djb.exc) as e:

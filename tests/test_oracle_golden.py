@@ -131,6 +131,12 @@ def test_sgd_abc_models(oracle):
             b = getattr(oracle, kind)(name)
             assert same(oracle.eval(b, g["i"], g["o"]), g[f"{kind}_{name}_eval"]), (kind, name)
             assert same(oracle.eval(b, g["i"], g["o"], None, "evalp"), g[f"{kind}_{name}_evalp"])
+            cc = np.zeros_like(g["i"]); cc[:, 0] = np.clip(g["i"][:, 2], 0, 1)
+            assert same(oracle.model_query(b, "ndf", g["i"]), g[f"{kind}_{name}_ndf"])
+            assert same(oracle.model_query(b, "gaf", g["i"], g["o"], g["i"]), g[f"{kind}_{name}_gaf"])
+            assert same(oracle.model_query(b, "fresnel", cc), g[f"{kind}_{name}_fresnel"])
+            if kind == "sgd":
+                assert same(oracle.model_query(b, "g1", g["o"]), g[f"{kind}_{name}_g1"])
         t = oracle.tabular(getattr(oracle, kind)(MODEL_MATERIALS[0]), 90, True)
         for k, v in oracle.tabular_tables(t).items():
             assert same(np.atleast_1d(v), g[f"{kind}_fit_{k}"]), (kind, k)

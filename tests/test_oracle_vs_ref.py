@@ -118,6 +118,16 @@ def test_sgd_abc_all_materials(oracle, reference, inputs):
             a = oracle.eval(getattr(oracle, kind)(name), i, o)
             b = reference.eval(getattr(reference, kind)(name), i, o)
             assert np.array_equal(bits(a), bits(b)), (kind, name)
+    # member queries (dj_brdf.h:505-509, 530-533) and the fresnel ior <-> f0 helpers (:151-154)
+    cc = np.zeros_like(i); cc[:, 0] = np.clip(i[:, 2], 0, 1)
+    for name in list(param_tables.abc_names())[::7]:
+        for kind in ("sgd", "abc"):
+            bo, br = getattr(oracle, kind)(name), getattr(reference, kind)(name)
+            for which, args in (("ndf", (i,)), ("gaf", (i, o, i)), ("fresnel", (cc,))) + ((("g1", (o,)),) if kind == "sgd" else ()):
+                assert np.array_equal(bits(oracle.model_query(bo, which, *args)), bits(reference.model_query(br, which, *args))), (kind, name, which)
+    x = np.linspace(0.3, 6.0, 5001).astype(np.float32); f = np.linspace(0.0, 1.0, 5001).astype(np.float32)
+    assert np.array_equal(bits(oracle.ior_f0(0, x)), bits(reference.ior_f0(0, x)))
+    assert np.array_equal(bits(oracle.ior_f0(1, f)), bits(reference.ior_f0(1, f)))
     with pytest.raises(RuntimeError) as e:
         reference.sgd("no-such-material")
     assert "No SGD parameters for no-such-material" in str(e.value)

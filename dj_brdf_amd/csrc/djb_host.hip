@@ -135,8 +135,19 @@ djb_status resolve_params(const djb_params *in, djb_params_resolved *p)
 	return DJB_OK;
 }
 
-djb_status device_params(const djb_params *in, Params *out)
+djb_status device_params(const djb_params *in, Params *out, int brdf_kind = -1)
 {
+	// lambert::params(reflectance) (dj_brdf.h:114-119, 861-868): carried to the kernel in the n slot
+	if (brdf_kind == DJB_KIND_LAMBERT) {
+		if (in && in->kind != DJB_PARAMS_STANDARD && in->kind != DJB_PARAMS_LAMBERT)
+			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a lambert brdf takes lambert::params");
+		memset(out, 0, sizeof *out);
+		const bool has = in && in->kind == DJB_PARAMS_LAMBERT;
+		out->nx = has ? in->v[0] : 1.0f; out->ny = has ? in->v[1] : 1.0f; out->nz = has ? in->v[2] : 1.0f;
+		return DJB_OK;
+	}
+	if (in && in->kind == DJB_PARAMS_LAMBERT)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: lambert::params passed to a brdf that is not a lambert");
 	djb_params_resolved r;
 	djb_status st = resolve_params(in, &r);
 	if (st != DJB_OK) return st;
@@ -355,7 +366,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
-	if ((st = device_params(params, &p)) != DJB_OK) return st;
+	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
 	Staged sg(ctx, n, mem);
 	View vi, vo, vout{ nullptr, nullptr, nullptr, 0 };
 	float *dpdf = nullptr;
@@ -1043,7 +1054,7 @@ static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, cons
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
-	if ((st = device_params(params, &p)) != DJB_OK) return st;
+	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
 	Staged sg(ctx, n, mem);
 	View vo, vi, vw; const float *d1, *d2; float *dpdf = nullptr;
 	if ((st = sg.in_f(u1, &d1)) != DJB_OK) return st;
@@ -1080,7 +1091,7 @@ djb_status djb_sample_rng_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
-	if ((st = device_params(params, &p)) != DJB_OK) return st;
+	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
 	if (!Staged::valid(o) || !Staged::valid(out_i)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
 	View vo{ o->x, o->y, o->z, (long long)o->stride }, vi{ out_i->x, out_i->y, out_i->z, (long long)out_i->stride };
 	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, nullptr, nullptr, seed_u1, seed_u2, start, vo, vi, nullptr, nullptr));
@@ -1138,7 +1149,7 @@ djb_status djb_query_batch(djb_ctx *ctx, const djb_brdf *b, int which, int64_t n
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
-	if ((st = device_params(params, &p)) != DJB_OK) return st;
+	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
 	Staged sg(ctx, n, mem);
 	View va, vb, vc, vo;
 	if ((st = sg.in_vec(a, &va)) != DJB_OK) return st;

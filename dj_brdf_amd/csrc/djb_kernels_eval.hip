@@ -46,7 +46,7 @@ DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float 
 			else if (KIND == KIND_UTIA) e = utia_eval(b, i, o);
 			else if (KIND == KIND_SGD) e = sgd_eval(b, i, o);
 			else if (KIND == KIND_ABC) e = abc_eval(b, i, o);
-			else e = divs(mk(1, 1, 1), F(DJB_PI));                 // lambert, dj_brdf.h:861-868
+			else e = divs(mk(p.nx, p.ny, p.nz), F(DJB_PI));        // lambert: reflectance / M_PI, dj_brdf.h:861-868
 			fr = (WANT & 2) ? scale(i.z, e) : e;                   // brdf::evalp, dj_brdf.h:803-806
 		}
 		if (WANT & 4) pdf = F(D(i.z) / DJB_PI);                    // brdf::pdf, dj_brdf.h:842-845

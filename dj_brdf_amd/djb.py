@@ -526,8 +526,8 @@ class microfacet(brdf):
 def _params_ptr(user_param):
     if user_param is None:
         return None
-    if not isinstance(user_param, microfacet.params):
-        raise exc(1, "djb_error: user_param must be a microfacet.params or None")
+    if not isinstance(user_param, (microfacet.params, lambert.params)):
+        raise exc(1, "djb_error: user_param must be a microfacet.params, a lambert.params or None")
     return C.byref(user_param._p)
 
 
@@ -644,6 +644,16 @@ class ggx(microfacet):
 
 
 class lambert(brdf):
+    class params:
+        """lambert::params(reflectance) (dj_brdf.h:114-119); pass as ``user_param``."""
+
+        def __init__(self, reflectance=(1.0, 1.0, 1.0)):
+            self.m_reflectance = tuple(float(x) for x in reflectance)
+            self._p = _lib.Params()
+            self._p.kind = 3
+            for k, v in enumerate(self.m_reflectance):
+                self._p.v[k] = v
+
     def __init__(self, ctx=None):
         super().__init__(ctx)
         _lib.check(_lib.load().djb_brdf_create_lambert(self.ctx._h, C.byref(self._h)))

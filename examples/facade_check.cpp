@@ -44,6 +44,8 @@ int main()
 		expect("set_fresnel(schlick) eval.g", c.y, 0.441180676); expect("set_fresnel(schlick) eval.b", c.z, 0.180200979);
 		ggm.set_shadow(false);
 		expect("set_shadow(false) get_shadow", (double)ggm.get_shadow(), 0);
+		djb::lambert lam; djb::lambert::params lamp(djb::vec3(0.5f, 0.25f, 0.9f));
+		expect("lambert eval", lam.eval(i, o).x, 0.318309873); expect("lambert(reflectance) eval.g", lam.eval(i, o, &lamp).y, 0.0795774683);
 		float f0, ior; djb::fresnel::ior_to_f0(1.5f, &f0); djb::fresnel::f0_to_ior(0.04f, &ior);
 		expect("fresnel::ior_to_f0(1.5)", f0, 0.04); expect("fresnel::f0_to_ior(0.04)", ior, 1.5);
 		djb::microfacet::params p5(0.4f, 0.25f, 0.3f, 0.1f, -0.2f); float ptx, pty; p5.get_location(&ptx, &pty);

@@ -55,7 +55,8 @@ typedef struct { float *x, *y, *z; int64_t stride; } djb_vec3_view;
 /* djb::microfacet::params factories (dj_brdf.h:217-221).  The batch shares one parameter set. */
 enum { DJB_PARAMS_STANDARD = 0,   /* user_param == NULL -> params::standard()            */
        DJB_PARAMS_ELLIPTIC = 1,   /* params::elliptic(v[0]=a1, v[1]=a2, v[2]=phi_a)      */
-       DJB_PARAMS_PDFPARAMS = 2   /* params::pdfparams(ax, ay, rho, tx_n, ty_n)          */ };
+       DJB_PARAMS_PDFPARAMS = 2,  /* params::pdfparams(ax, ay, rho, tx_n, ty_n)          */
+       DJB_PARAMS_LAMBERT = 3     /* lambert::params(reflectance = v[0..2]); lambert handles only   dj_brdf.h:114-119 */ };
 typedef struct { int kind; float v[5]; } djb_params;
 
 /* resolved view of microfacet::params, all private members (dj_brdf.h:237-242) */

@@ -182,7 +182,22 @@ private: // noncopyable, dj_brdf.h:104-108
 /* Lambertian BRDF, dj_brdf.h:112-123 */
 class lambert : public brdf {
 public:
+	/* Lambertian Parameters, dj_brdf.h:114-119: passed as `const void *user_param` */
+	class params {
+	public:
+		params(const vec3 &reflectance = vec3(1)) : m_reflectance(reflectance) {}
+		vec3 m_reflectance;
+	};
 	explicit lambert(hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_lambert(ctx(), &m_h)); }
+protected:
+	const djb_params *params_of(const void *user_param) const   // dj_brdf.h:863-865
+	{
+		if (!user_param) return NULL;
+		static __thread djb_params d;                              // lives across the ABI call of this thread
+		const vec3 &r = reinterpret_cast<const params *>(user_param)->m_reflectance;
+		d.kind = DJB_PARAMS_LAMBERT; d.v[0] = r.x; d.v[1] = r.y; d.v[2] = r.z; d.v[3] = d.v[4] = 0;
+		return &d;
+	}
 };
 
 /* MERL BRDF, dj_brdf.h:126-133 */

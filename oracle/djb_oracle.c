@@ -272,6 +272,12 @@ static o_params params_standard(void) { return params_elliptic(1, 1, 0); }
 
 static o_params params_from_desc(const o_param_desc *pd)
 {
+	if (pd && pd->kind == 3) {   /* lambert::params(reflectance), hdr:114-119: carried in the n slot, a1 = -1 marks it */
+		o_params p = params_elliptic(1, 1, 0);
+		p.n = v3(pd->v[0], pd->v[1], pd->v[2]);
+		p.a1 = -1.0f;
+		return p;
+	}
 	if (pd && pd->kind == 1) return params_elliptic(pd->v[0], pd->v[1], pd->v[2]);
 	if (pd && pd->kind == 2) {
 		o_params p;
@@ -857,7 +863,7 @@ static o_vec3 brdf_eval(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p)
 	switch (b->kind) {
 	case O_BRDF_MERL: return merl_eval(b, i, o);
 	case O_BRDF_UTIA: return utia_eval(b, i, o);
-	case O_BRDF_LAMBERT: return v3_div(v3(1, 1, 1), F(O_PI)); /* hdr:861-868, default params */
+	case O_BRDF_LAMBERT: return v3_div(p && p->a1 == -1.0f ? p->n : v3(1, 1, 1), F(O_PI)); /* hdr:861-868: reflectance / M_PI */
 	case O_BRDF_SGD: return sgd_eval(b, i, o);
 	case O_BRDF_ABC: return abc_eval(b, i, o);
 	default: return mf_eval(b, i, o, p);

@@ -43,7 +43,7 @@ typedef struct {
 
 /* same wire format as ref_shim.cpp's shim_params */
 typedef struct {
-	int   kind;               /* 0 NULL/standard, 1 elliptic(a1,a2,phi), 2 pdfparams(ax,ay,rho,tx,ty) */
+	int   kind;               /* 0 NULL/standard, 1 elliptic(a1,a2,phi), 2 pdfparams(ax,ay,rho,tx,ty), 3 lambert::params(rgb) */
 	float v[5];
 } o_param_desc;
 

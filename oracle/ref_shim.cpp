@@ -23,16 +23,20 @@
 namespace {
 
 struct shim_params {
-	int   kind;   // 0: user_param == NULL, 1: elliptic(a1,a2,phi_a), 2: pdfparams(ax,ay,rho,tx,ty)
+	int   kind;   // 0: user_param == NULL, 1: elliptic(a1,a2,phi_a), 2: pdfparams(ax,ay,rho,tx,ty), 3: lambert::params(rgb)
 	float v[5];
 };
 
 struct param_holder {
 	djb::microfacet::params p;
+	djb::lambert::params lp;
 	const void *ptr;
-	explicit param_holder(const shim_params *sp) : p(), ptr(NULL)
+	explicit param_holder(const shim_params *sp) : p(), lp(), ptr(NULL)
 	{
-		if (sp && sp->kind == 1) {
+		if (sp && sp->kind == 3) {          // lambert::params(reflectance), hdr:114-119
+			lp = djb::lambert::params(djb::vec3(sp->v[0], sp->v[1], sp->v[2]));
+			ptr = &lp;
+		} else if (sp && sp->kind == 1) {
 			p = djb::microfacet::params::elliptic(sp->v[0], sp->v[1], sp->v[2]);
 			ptr = &p;
 		} else if (sp && sp->kind == 2) {

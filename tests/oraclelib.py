@@ -26,10 +26,14 @@ class ParamDesc(C.Structure):
 
 
 def param_desc(p):
-    """p: None | ('elliptic', a1, a2, phi) | ('pdfparams', ax, ay, rho, tx, ty)."""
+    """p: None | ('elliptic', a1, a2, phi) | ('pdfparams', ax, ay, rho, tx, ty) | ('lambert', r, g, b)."""
     d = ParamDesc()
     if p is None:
         d.kind = 0
+    elif p[0] == "lambert":
+        d.kind = 3
+        for k, v in enumerate(p[1:]):
+            d.v[k] = v
     elif p[0] == "elliptic":
         d.kind = 1
         for k, v in enumerate(p[1:]):

@@ -215,6 +215,23 @@ def test_lambert_and_default_sampling(gpu_ctx, oracle, dirs):
     assert_close("is pdf", pdf, wpdf, 2e-5); assert_close("is w", w, ww, 4e-5)
 
 
+def test_lambert_reflectance_params(gpu_ctx, oracle, dirs):
+    # lambert::params(reflectance) passed as user_param (dj_brdf.h:114-119, 861-868)
+    i, o, u1, u2 = dirs
+    l, ol = djb.lambert(ctx=gpu_ctx), oracle.lambert()
+    lp, op = djb.lambert.params((0.5, 0.25, 0.9)), ("lambert", 0.5, 0.25, 0.9)
+    for name in ("eval", "evalp", "pdf"):
+        got, want = getattr(l, name)(i, o, lp), oracle.eval(ol, i, o, op, name)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+    w, si, pdf = l.evalp_is(u1, u2, o, lp)
+    ww, wi, wpdf = oracle.evalp_is(ol, u1, u2, o, op)
+    assert_close("lambert(reflectance) evalp_is", w, ww, 2e-5)
+    with pytest.raises(djb.exc):
+        djb.ggx(ctx=gpu_ctx).eval(i, o, lp)               # lambert::params on a microfacet brdf
+    with pytest.raises(djb.exc):
+        l.eval(i, o, djb.microfacet.params.isotropic(0.3))  # and the other way round
+
+
 @pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
 def test_microfacet_and_radial_queries(gpu_ctx, oracle, dirs, ndf):
     """microfacet::{ndf,gaf,g1,sigma,p22,vp22,vndf,fresnel} and radial::{p22_radial,...} batched."""

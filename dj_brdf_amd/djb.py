@@ -149,6 +149,15 @@ def _scalar_in(u, like: _Vec):
 
 
 # --------------------------------------------------------------------------- fresnel (dj_brdf.h:149-207)
+def vec3_from_angles(theta, phi) -> np.ndarray:
+    """``djb::vec3(theta, phi)`` (dj_brdf.h:67, 589-595): [n,3] unit vectors, the reference's float/double order
+    (s = float(sin(theta)); x = float(s * cos(phi)); y = float(s * sin(phi)); z = float(cos(theta)))."""
+    t = np.atleast_1d(np.asarray(theta, dtype=np.float32)).astype(np.float64)
+    p = np.atleast_1d(np.asarray(phi, dtype=np.float32)).astype(np.float64)
+    s = np.sin(t).astype(np.float32).astype(np.float64)
+    return np.stack([(s * np.cos(p)).astype(np.float32), (s * np.sin(p)).astype(np.float32), np.cos(t).astype(np.float32)], 1)
+
+
 class fresnel:
     @staticmethod
     def ior_to_f0(ior):

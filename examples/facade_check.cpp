@@ -44,6 +44,8 @@ int main()
 		expect("set_fresnel(schlick) eval.g", c.y, 0.441180676); expect("set_fresnel(schlick) eval.b", c.z, 0.180200979);
 		ggm.set_shadow(false);
 		expect("set_shadow(false) get_shadow", (double)ggm.get_shadow(), 0);
+		djb::vec3 ang(0.7f, 1.9f);                     // vec3(theta, phi), dj_brdf.h:589-595
+		expect("vec3(theta,phi).x", ang.x, -0.208268836); expect("vec3(theta,phi).z", ang.z, 0.764842212);
 		djb::lambert lam; djb::lambert::params lamp(djb::vec3(0.5f, 0.25f, 0.9f));
 		expect("lambert eval", lam.eval(i, o).x, 0.318309873); expect("lambert(reflectance) eval.g", lam.eval(i, o, &lamp).y, 0.0795774683);
 		float f0, ior; djb::fresnel::ior_to_f0(1.5f, &f0); djb::fresnel::f0_to_ior(0.04f, &ior);

@@ -43,6 +43,13 @@ struct vec3 {
 	static const float_t *to_raw(const vec3 &v) { return &v.x; }
 	explicit vec3(float_t x = 0) : x(x), y(x), z(x) {}
 	vec3(float_t x, float_t y, float_t z) : x(x), y(y), z(z) {}
+	explicit vec3(float_t theta, float_t phi)   // dj_brdf.h:589-595 (double libm, rounded where the reference rounds)
+	{
+		float_t s = (float_t)std::sin((double)theta);
+		x = (float_t)((double)s * std::cos((double)phi));
+		y = (float_t)((double)s * std::sin((double)phi));
+		z = (float_t)std::cos((double)theta);
+	}
 	float_t intensity() const { return (float_t)0.2126 * x + (float_t)0.7152 * y + (float_t)0.0722 * z; }
 	float_t x, y, z;
 };

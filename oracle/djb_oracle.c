@@ -820,6 +820,11 @@ static o_vec3 abc_eval(const o_brdf *b, o_vec3 i, o_vec3 o) /* hdr:3633-3645 */
 
 static o_vec3 ld3(const float *p, int64_t k);
 static void st3(float *p, int64_t k, o_vec3 v);
+/* vec3::vec3(theta, phi), hdr:589-595 */
+void o_vec3_angles(int64_t n, const float *theta, const float *phi, float *out)
+{
+	for (int64_t k = 0; k < n; ++k) st3(out, k, v3_from_angles(theta[k], phi[k]));
+}
 /* sgd::{ndf,gaf,g1} (hdr:3472-3500) and abc::{ndf,gaf} (hdr:3647-3668) as their own entry point.
  * which: 0 ndf(h) -> rgb, 1 gaf(h, i, o) -> rgb (sgd) / out[0] (abc), 2 g1(k) -> rgb (sgd), 3 fresnel(a[0]) */
 void o_model_query(const o_brdf *b, int which, int64_t n, const float *a, const float *bi, const float *co, float *out)

@@ -94,6 +94,8 @@ void o_microfacet_query(const o_brdf *b, int which, int64_t n, const float *a, c
 void o_radial_query(const o_brdf *b, int which, int64_t n, const float *a, const float *bb,
                     const float *c, float *out);
 void o_fresnel_eval(const o_brdf *b, int64_t n, const float *c, float *out);
+/* vec3::vec3(theta, phi), dj_brdf.h:589-595 */
+void o_vec3_angles(int64_t n, const float *theta, const float *phi, float *out);
 /* sgd / abc member queries, dj_brdf.h:505-509, 530-533: which 0 ndf(h), 1 gaf(h, i, o), 2 g1(k) [sgd], 3 fresnel(a.x) */
 void o_model_query(const o_brdf *b, int which, int64_t n, const float *a, const float *i, const float *o, float *out);
 /* fresnel::ior_to_f0 (dir 0) / f0_to_ior (dir 1), dj_brdf.h:1255-1290 */

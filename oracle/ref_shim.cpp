@@ -228,6 +228,11 @@ void ref_fresnel_eval(void *b_, long n, const float *c, float *out)
 	for (long k = 0; k < n; ++k) st(out, k, m->fresnel(c[k]));
 }
 
+// vec3::vec3(theta, phi) (hdr:67, 589-595)
+void ref_vec3_angles(long n, const float *theta, const float *phi, float *out)
+{
+	for (long k = 0; k < n; ++k) st(out, k, djb::vec3(theta[k], phi[k]));
+}
 // sgd / abc member queries (hdr:505-509, 530-533): which 0 ndf(h), 1 gaf(h, i, o), 2 g1(k) [sgd], 3 fresnel(a.x)
 void ref_model_query(void *b_, int which, long n, const float *a, const float *bi, const float *co, float *out)
 {

@@ -57,6 +57,8 @@ def main():
     out["erf_x"], out["erf_y"] = x, R.erf(x)
     x = np.linspace(-0.99999, 0.99999, 4001).astype(np.float32)
     out["erfinv_x"], out["erfinv_y"] = x, R.erfinv(x)
+    th = np.linspace(0.0, np.pi, 1501).astype(np.float32); ph = np.linspace(-7.0, 7.0, 1501).astype(np.float32)
+    out["ang_theta"], out["ang_phi"], out["ang_vec3"] = th, ph, R.vec3_angles(th, ph)   # vec3(theta, phi)
     x = np.concatenate([np.linspace(1.0, 6.0, 2001), [0.25, 0.5, 1.33, 1.5]]).astype(np.float32)
     out["ior_x"], out["ior_f0"] = x, R.ior_f0(0, x)                     # fresnel::ior_to_f0
     x = np.concatenate([np.linspace(0.0, 1.0, 2001), [0.04, 0.9999999]]).astype(np.float32)

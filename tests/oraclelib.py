@@ -299,6 +299,12 @@ class CheckerLib:
         self._fn("model_query")(b, C.c_int(code), C.c_int64(a.shape[0]), _ptr(a), _ptr(i), _ptr(o), _ptr(out))
         return out
 
+    def vec3_angles(self, theta, phi):
+        theta, phi = _f32(theta), _f32(phi)
+        out = np.empty((theta.size, 3), dtype=np.float32)
+        self._fn("vec3_angles")(C.c_int64(theta.size), _ptr(theta), _ptr(phi), _ptr(out))
+        return out
+
     def ior_f0(self, direction, x):
         x = _f32(x); y = np.empty_like(x)
         self._fn("ior_f0")(C.c_int(direction), C.c_int64(x.size), _ptr(x), _ptr(y))

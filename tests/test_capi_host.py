@@ -54,6 +54,8 @@ def test_fresnel_ior_f0_helpers_match_reference_golden():
     got, want = djb.fresnel.f0_to_ior(g["f0_x"]), g["f0_ior"]
     ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isinf(got) & np.isinf(want) & (np.sign(got) == np.sign(want)))
     assert ok.all()
+    got = djb.vec3_from_angles(g["ang_theta"], g["ang_phi"])                 # vec3(theta, phi), dj_brdf.h:589-595
+    assert np.array_equal(got.view(np.uint32), g["ang_vec3"].view(np.uint32))
     assert djb.fresnel.ior_to_f0(1.5) == np.float32(0.2) * np.float32(0.2) and djb.fresnel.f0_to_ior(1.0) == 1.0
 
 

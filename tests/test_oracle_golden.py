@@ -70,6 +70,7 @@ def test_params_and_math(oracle):
         assert same(oracle.params_get(p), g[f"p{k}"]), p
     assert same(oracle.erf(g["erf_x"]), g["erf_y"])
     assert same(oracle.erfinv(g["erfinv_x"]), g["erfinv_y"])
+    assert same(oracle.vec3_angles(g["ang_theta"], g["ang_phi"]), g["ang_vec3"])
     assert same(oracle.ior_f0(0, g["ior_x"]), g["ior_f0"]) and same(oracle.ior_f0(1, g["f0_x"]), g["f0_ior"])
     h, d = oracle.io_to_hd(g["hd_i"], g["hd_o"])
     assert same(h, g["hd_h"]) and same(d, g["hd_d"])

@@ -185,6 +185,11 @@ class fresnel:
             d.kind = self.kind
             return d, None
 
+        def eval(self, cos_theta_d, ctx=None):
+            """fresnel::impl::eval (dj_brdf.h:160) on a batch of cosines -> [n,3]; evaluated through a
+            temporary microfacet object (inside a BRDF the term is fused into the eval kernels)."""
+            return ggx(self, True, ctx=ctx).fresnel(cos_theta_d)
+
     class ideal(impl):
         kind = 0
 

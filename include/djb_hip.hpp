@@ -245,6 +245,21 @@ namespace fresnel {
 	class impl {
 	public:
 		virtual ~impl() {}
+		/* dj_brdf.h:160.  Stand-alone evaluation goes through a temporary microfacet object on the
+		 * default context (one launch); inside a BRDF the term is fused into the eval kernels. */
+		vec3 eval(float_t cos_theta_d) const
+		{
+			djb_fresnel_desc d = desc();
+			djb_ctx *c = hip::context::standard().get();
+			djb_brdf *h = NULL;
+			hip::check(djb_brdf_create_ggx(c, &d, 1, &h));
+			vec3 a(cos_theta_d, 0, 0), r;
+			djb_vec3_view va = hip::view(&a), vr = hip::view(&r);
+			djb_status st = djb_query_batch(c, h, DJB_Q_FRESNEL, 1, &va, NULL, NULL, NULL, &vr, DJB_MEM_HOST);
+			djb_brdf_destroy(h);
+			hip::check(st);
+			return r;
+		}
 		virtual impl *copy() const = 0;
 		virtual djb_fresnel_desc desc() const = 0;
 	};

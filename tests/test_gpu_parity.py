@@ -215,6 +215,19 @@ def test_lambert_and_default_sampling(gpu_ctx, oracle, dirs):
     assert_close("is pdf", pdf, wpdf, 2e-5); assert_close("is w", w, ww, 4e-5)
 
 
+def test_standalone_fresnel_eval(gpu_ctx, oracle):
+    # fresnel::impl::eval (dj_brdf.h:160) on the five Fresnel classes
+    c = np.linspace(0.0, 1.0, 4097).astype(np.float32)
+    pts = np.random.default_rng(4).uniform(0, 1, (17, 3)).astype(np.float32)
+    for f, fo in ((djb.fresnel.ideal(), ("ideal",)), (djb.fresnel.schlick((1.0, 0.71, 0.29)), ("schlick", 1.0, 0.71, 0.29)),
+                  (djb.fresnel.unpolarized((1.5, 2.0, 0.3)), ("unpolarized", 1.5, 2.0, 0.3)),
+                  (djb.fresnel.sgd((0.9, 0.5, 0.1), (0.1, 0.2, 0.3)), ("sgd", 0.9, 0.5, 0.1, 0.1, 0.2, 0.3)),
+                  (djb.fresnel.spline(pts), ("spline", pts))):
+        got = f.eval(c, ctx=gpu_ctx)
+        want = oracle.fresnel_eval(oracle.microfacet("ggx", fo, True), c)
+        assert_close(f"fresnel::{fo[0]}::eval", got, want, 1e-5)
+
+
 def test_lambert_reflectance_params(gpu_ctx, oracle, dirs):
     # lambert::params(reflectance) passed as user_param (dj_brdf.h:114-119, 861-868)
     i, o, u1, u2 = dirs

@@ -54,6 +54,22 @@ struct vec3 {
 	float_t x, y, z;
 };
 
+/* vec3 algebra of dj_brdf.h:597-637: host-side scalar helpers with the reference's float/double order
+ * (user code such as tests/nrm_utia.cpp accumulates evalp() results with them) */
+inline vec3 operator*(float_t a, const vec3 &b) { return vec3(a * b.x, a * b.y, a * b.z); }
+inline vec3 operator*(const vec3 &a, float_t b) { return vec3(b * a.x, b * a.y, b * a.z); }
+inline vec3 operator/(const vec3 &a, float_t b) { return (float_t)(1.0 / (double)b) * a; }
+inline vec3 operator*(const vec3 &a, const vec3 &b) { return vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline vec3 operator/(const vec3 &a, const vec3 &b) { return vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
+inline vec3 operator+(const vec3 &a, const vec3 &b) { return vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline vec3 operator-(const vec3 &a, const vec3 &b) { return vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline vec3 &operator+=(vec3 &a, const vec3 &b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+inline vec3 &operator*=(vec3 &a, const vec3 &b) { a.x *= b.x; a.y *= b.y; a.z *= b.z; return a; }
+inline vec3 &operator*=(vec3 &a, float_t b) { a.x *= b; a.y *= b; a.z *= b; return a; }
+inline float_t dot(const vec3 &a, const vec3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline vec3 cross(const vec3 &a, const vec3 &b) { return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline vec3 normalize(const vec3 &v) { return (float_t)(1.0 / std::sqrt((double)dot(v, v))) * v; }
+
 namespace hip {
 
 inline void check(djb_status st)

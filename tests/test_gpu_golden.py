@@ -264,6 +264,38 @@ def test_cpp_facade_programs(gpu_ctx, tmp_path):
     assert r.returncode != 0 and "Failed to open" in r.stderr
 
 
+def test_reference_programs_unchanged(gpu_ctx, tmp_path):
+    """The reference's OWN programs -- tests/plot_cdf.cpp, tests/plot_qf.cpp, tests/nrm_utia.cpp and
+    examples/merl_params.cpp -- compiled UNCHANGED against include/dj_brdf.h (examples/Makefile
+    `reftests`, sources left in place under /root/reference) and run on the GPU must write, byte for
+    byte, what the real reference binaries write on the CPU (tests/golden/reftests/, make_reftests.sh)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rt = os.path.join(root, "examples", "_reftests")
+    if not os.path.exists(os.path.join(rt, "plot_cdf")):
+        pytest.skip("examples/_reftests not built (needs /root/reference at build time)")
+    want_dir = os.path.join(G, "reftests")
+    for prog in ("plot_cdf", "plot_qf"):
+        r = subprocess.run([os.path.join(rt, prog)], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+    names = sorted(f for f in os.listdir(want_dir) if f.startswith("eval_"))
+    assert len(names) == 8
+    for f in names:
+        assert (tmp_path / f).read_bytes() == open(os.path.join(want_dir, f), "rb").read(), f
+    # the reference's example driver, reference source: same params.txt as the reference binary
+    files = []
+    for name, recipe in PARAMS_TXT_MATERIALS:
+        p = str(tmp_path / (name + ".binary"))
+        synth.write_merl_binary(p, synth.merl_table(*recipe)); files.append(p)
+    r = subprocess.run([os.path.join(rt, "merl_params")] + files, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "params.txt").read_bytes() == open(os.path.join(G, "params_expected.txt"), "rb").read()
+    # the white-furnace test on a table that violates it at the first outgoing direction
+    np.full(3 * 288 * 288, 140.0 * 0.9).tofile(str(tmp_path / "furnace_fail.bin"))
+    r = subprocess.run([os.path.join(rt, "nrm_utia"), "furnace_fail.bin"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.stdout + f"exit={r.returncode}\n" == open(os.path.join(want_dir, "nrm_utia_fail.txt")).read()
+
+
 def test_native_file_pipeline(gpu_ctx, tmp_path):
     """djb_fit_merl_files: reader threads -> pinned ring -> H2D -> convert -> one fit launch.  Same
     alphas as fitting the tables one by one, input order kept, reference error messages."""

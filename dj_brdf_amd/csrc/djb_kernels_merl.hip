@@ -153,11 +153,7 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, Vi
 			if (WANT & 3) {
 				MerlTexel t[4];
 #pragma unroll
-#ifdef DJB_EXP_NOGATHER   // experiment only: how fast is the kernel without the table gather?
-				for (int j = 0; j < 4; ++j) t[j] = MerlTexel{ (float)idx[j], 0.f, 0.f };
-#else
 				for (int j = 0; j < 4; ++j) t[j] = b.merl[amb[j] ? 0 : idx[j]];
-#endif
 				float r[4], gg[4], bb[4];
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {

@@ -7,6 +7,11 @@
 // It is built by oracle/Makefile into oracle/_ref/libdjb_ref.so (git-ignored)
 // and only when /root/reference is present (i.e. in the build container).
 //
+// Second use (-DDJB_FACADE_SHIM, oracle/Makefile target `facade`): the very same file compiled against
+// this repository's include/dj_brdf.h instead of the reference header gives a library with the same
+// ref_* entry points whose calls run on the GPU through the C++ facade -- the conformance harness of
+// tests/test_gpu_facade_conformance.py.
+//
 // Include order matters: <cmath> only, never <math.h>,
 // so that the unqualified acos/atan2/cos/sin/sqrt/exp inside namespace djb
 // resolve to the double C functions, exactly as in examples/merl_params.cpp:10-16.
@@ -153,6 +158,7 @@ void ref_hd_to_io(long n, const float *h, const float *d, float *i, float *o)
 	}
 }
 
+#ifndef DJB_FACADE_SHIM   // internal helpers of the reference's implementation section: not part of the class API
 // MERL bin index exactly as merl::eval composes it (hdr:987-1008); -1 never happens.
 void ref_merl_index(long n, const float *i, const float *o, int *idx)
 {
@@ -166,6 +172,7 @@ void ref_merl_index(long n, const float *i, const float *o, int *idx)
 		       + djb::theta_half_index(th) * 16200;
 	}
 }
+#endif
 
 // ---- microfacet::params (hdr:213-243) --------------------------------------
 // out[12] = n.xyz, a1, a2, phi_a, ax, ay, rho, tx, ty, (unused)
@@ -268,8 +275,10 @@ void ref_params_set_location_n(const float *n3, float *out5)
 	out5[2] = m.x; out5[3] = m.y; out5[4] = m.z;
 }
 
+#ifndef DJB_FACADE_SHIM
 void ref_erf(long n, const float *x, float *y)    { for (long k = 0; k < n; ++k) y[k] = djb::erf(x[k]); }
 void ref_erfinv(long n, const float *x, float *y) { for (long k = 0; k < n; ++k) y[k] = djb::erfinv(x[k]); }
+#endif
 
 // ---- beckmann::lrep (hdr:330-356, 1959-2051) --------------------------------
 // The members are private; lrep_to_params + get_pdfparams and params_to_lrep round-trip them.

@@ -1,0 +1,141 @@
+"""Conformance of the C++ facade (include/djb_hip.hpp via include/dj_brdf.h), class by class.
+
+oracle/ref_shim.cpp -- the extern "C" wrapper that exposes every public class of the REAL reference to the
+test-suite -- is compiled a second time, unchanged apart from -DDJB_FACADE_SHIM, against this
+repository's dj_brdf.h (oracle/Makefile `facade`).  The resulting library has the same ref_* entry
+points, but every call constructs the facade's djb:: objects and runs on the GPU (one scalar call per
+element).  Here it is driven exactly like the real reference in tests/test_oracle_vs_ref.py and compared
+with the CPU oracle (which is itself pinned bit-exact to the reference)."""
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib
+from dj_brdf_amd import synth
+from golden_cases import PARAM_CASES, _FRESNELS
+
+FRESNEL_CASES = [("ideal",)] + list(_FRESNELS)
+
+pytestmark = pytest.mark.gpu
+SHIM = os.path.join(oraclelib.ORACLE_DIR, "_facade", "libdjb_facade_shim.so")
+N = 192   # every element is one scalar facade call (a launch + a PCIe round trip)
+
+
+@pytest.fixture(scope="module")
+def facade(gpu_ctx):
+    if not os.path.exists(SHIM):
+        pytest.skip("oracle/_facade/libdjb_facade_shim.so not built (make -C oracle facade)")
+    return oraclelib.CheckerLib(SHIM, "ref_")
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return (synth.directions_aos(N, synth.SEED_I, start=777), synth.directions_aos(N, synth.SEED_O, start=777),
+            synth.uniforms(N, synth.SEED_U1, start=777), synth.uniforms(N, synth.SEED_U2, start=777))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def close(tag, got, want, rtol=0.0):
+    if rtol == 0.0:
+        nan_ok = np.isnan(got) & np.isnan(want)
+        assert (nan_ok | (bits(got) == bits(want))).all(), f"{tag}: not bit-identical"
+    else:
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-7, err_msg=tag)
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+def test_microfacet_classes(facade, oracle, inputs, ndf):
+    i, o, u1, u2 = inputs
+    for fres in FRESNEL_CASES:
+        for shadow in (True, False):
+            f, b = facade.microfacet(ndf, fres, shadow), oracle.microfacet(ndf, fres, shadow)
+            for p in PARAM_CASES[:4]:
+                for op in ("eval", "evalp", "pdf"):
+                    close(f"{ndf}/{fres[0]}/{p}/{op}", facade.eval(f, i, o, p, op), oracle.eval(b, i, o, p, op))
+            p = PARAM_CASES[2]
+            tol = 2e-4 if ndf == "beckmann" else 1e-5
+            close("sample", facade.sample(f, u1, u2, o, p), oracle.sample(b, u1, u2, o, p), tol)
+            fw, fi, fp = facade.evalp_is(f, u1, u2, o, p)
+            ow, oi, op_ = oracle.evalp_is(b, u1, u2, o, p)
+            close("evalp_is i", fi, oi, tol); close("evalp_is pdf", fp, op_, 50 * tol)
+            c = np.clip(o[:, 2], 0, 1)
+            close("fresnel()", facade.fresnel_eval(f, c), oracle.fresnel_eval(b, c))
+            facade.destroy(f)
+
+
+def test_params_vec3_and_helpers(facade, oracle, inputs):
+    i, o, _, _ = inputs
+    for p in PARAM_CASES:
+        want = oracle.params_get(p)
+        got = facade.params_get(p)
+        ok = np.isnan(want) | (bits(got) == bits(want))
+        assert ok.all(), (p, got, want)
+        close(f"lrep roundtrip {p}", facade.params_lrep_roundtrip(p), oracle.params_lrep_roundtrip(p))
+    h, d = facade.io_to_hd(i, o); wh, wd = oracle.io_to_hd(i, o)
+    close("io_to_hd h", h, wh); close("io_to_hd d", d, wd)
+    bi, bo = facade.hd_to_io(wh, wd); wi, wo = oracle.hd_to_io(wh, wd)
+    close("hd_to_io i", bi, wi, 1e-5); close("hd_to_io o", bo, wo, 2e-5)
+    th = np.linspace(0, np.pi, N).astype(np.float32); ph = np.linspace(-7, 7, N).astype(np.float32)
+    close("vec3(theta, phi)", facade.vec3_angles(th, ph), oracle.vec3_angles(th, ph))
+    x = np.linspace(0.3, 6, N).astype(np.float32); f0 = np.linspace(0, 0.999, N).astype(np.float32)
+    close("ior_to_f0", facade.ior_f0(0, x), oracle.ior_f0(0, x)); close("f0_to_ior", facade.ior_f0(1, f0), oracle.ior_f0(1, f0))
+
+
+def test_queries(facade, oracle, inputs):
+    i, o, u1, u2 = inputs
+    h = synth.directions_aos(N, 99)
+    for ndf in ("ggx", "beckmann"):
+        f, b = facade.microfacet(ndf), oracle.microfacet(ndf)
+        p = PARAM_CASES[3]
+        for which, args in (("ndf", (h,)), ("gaf", (h, i, o)), ("g1", (h, o)), ("sigma", (o,)), ("vndf", (h, o))):
+            close(f"{ndf} {which}", facade.microfacet_query(f, which, *args, params=p), oracle.microfacet_query(b, which, *args, params=p), 1e-5)
+        c = np.clip(o[:, 2], 1e-3, 1).astype(np.float32); s = np.sqrt(1 - c.astype(np.float64) ** 2).astype(np.float32)
+        u = np.clip(u1, 1e-3, 1 - 1e-3)
+        for which, args in (("p22_radial", (u * 9,)), ("sigma_std_radial", (c,)), ("cdf_radial", (u * 5,)), ("qf_radial", (u,)),
+                            ("qf3_radial", (u, u * 3 - 1))):
+            close(f"{ndf} {which}", facade.radial_query(f, which, *args), oracle.radial_query(b, which, *args), 2e-5)
+        facade.destroy(f)
+
+
+def test_lambert_merl_utia_models(facade, oracle, inputs, tmp_path):
+    i, o, u1, u2 = inputs
+    fl, ol = facade.lambert(), oracle.lambert()
+    for p in (None, ("lambert", 0.5, 0.25, 0.9)):
+        for op in ("eval", "evalp", "pdf"):
+            close(f"lambert {p} {op}", facade.eval(fl, i, o, p, op), oracle.eval(ol, i, o, p, op))
+    close("lambert sample", facade.sample(fl, u1, u2, o), oracle.sample(ol, u1, u2, o), 2e-5)
+    tab = synth.merl_table_hashed()
+    path = str(tmp_path / "m.binary"); synth.write_merl_binary(path, tab)
+    fm, om = facade.merl(path), oracle.merl(path)
+    for op in ("eval", "evalp", "pdf"):
+        close(f"merl {op}", facade.eval(fm, i, o, None, op), oracle.eval(om, i, o, None, op))
+    with pytest.raises(RuntimeError) as e:
+        facade.merl(str(tmp_path / "missing.binary"))
+    assert "Failed to open" in str(e.value)
+    ut = np.random.default_rng(5).uniform(-5, 120, 3 * 288 * 288); up = str(tmp_path / "u.bin"); ut.tofile(up)
+    close("utia eval", facade.eval(facade.utia(up), i, o), oracle.eval(oracle.utia(up), i, o), 1e-5)
+    for kind in ("sgd", "abc"):
+        f, b = getattr(facade, kind)("gold-metallic-paint"), getattr(oracle, kind)("gold-metallic-paint")
+        close(f"{kind} eval", facade.eval(f, i, o), oracle.eval(b, i, o), 1e-5)
+        close(f"{kind} ndf", facade.model_query(f, "ndf", i), oracle.model_query(b, "ndf", i), 1e-5)
+        close(f"{kind} gaf", facade.model_query(f, "gaf", i, o, i), oracle.model_query(b, "gaf", i, o, i), 1e-5)
+        if kind == "sgd":
+            close("sgd g1", facade.model_query(f, "g1", o), oracle.model_query(b, "g1", o), 1e-5)
+        with pytest.raises(RuntimeError):
+            getattr(facade, kind)("no-such-material")
+
+
+def test_tabular_and_lrep(facade, oracle, inputs):
+    i, o, u1, u2 = inputs
+    ft, ot = facade.tabular(facade.microfacet("ggx"), 64, True), oracle.tabular(oracle.microfacet("ggx"), 64, True)
+    for k, v in oracle.tabular_tables(ot).items():
+        got = facade.tabular_tables(ft)[k]
+        np.testing.assert_allclose(np.atleast_1d(got), np.atleast_1d(v), rtol=2e-5, atol=1e-7, err_msg=k)
+    close("tabular eval", facade.eval(ft, i, o), oracle.eval(ot, i, o), 1e-4)
+    from golden_cases import lrep_cases
+    for op, a, b, x, y in lrep_cases():
+        close(f"lrep {op}", facade.lrep_op(op, a, b, x, y), oracle.lrep_op(op, a, b, x, y))

@@ -139,3 +139,26 @@ def test_tabular_and_lrep(facade, oracle, inputs):
     from golden_cases import lrep_cases
     for op, a, b, x, y in lrep_cases():
         close(f"lrep {op}", facade.lrep_op(op, a, b, x, y), oracle.lrep_op(op, a, b, x, y))
+
+
+def test_anisotropic_and_lean(facade, oracle, inputs):
+    i, o, u1, u2 = inputs
+    from golden_cases import LEAN_BASE, LEAN_SCALE, lean_moments
+    # dj_beckmannconductor's per-hit path through beckmann::lrep and per-call microfacet::params
+    lean = lean_moments(N)
+    for ndf in ("beckmann", "ggx"):
+        f, b = facade.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True), oracle.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
+        for op in ("evalp", "pdf"):
+            got, gpp = facade.eval_lean(f, i, o, LEAN_BASE, LEAN_SCALE, lean, op)
+            want, wpp = oracle.eval_lean(b, i, o, LEAN_BASE, LEAN_SCALE, lean, op)
+            close(f"{ndf} lean params", gpp, wpp); close(f"{ndf} lean {op}", got, want)
+    # tabular_anisotropic on a small grid: tables, fits, two-level sampling queries, eval
+    ft = facade.tabular_anisotropic(facade.microfacet("ggx"), 12, 16, True)
+    ot = oracle.tabular_anisotropic(oracle.microfacet("ggx"), 12, 16, True)
+    want = oracle.aniso_tables(ot)
+    for k, v in facade.aniso_tables(ft).items():
+        np.testing.assert_allclose(v, want[k], rtol=5e-5, atol=1e-6, err_msg=k)
+    phi = (u1 * 2 * np.pi).astype(np.float32); th = (u2 * 1.5).astype(np.float32)
+    for which, args in (("pdf1", (phi,)), ("cdf1", (phi,)), ("qf1", (u1,)), ("pdf2", (th, phi)), ("cdf2", (th, phi)), ("qf2", (u2, phi))):
+        close(f"aniso {which}", facade.aniso_query(ft, which, *args), oracle.aniso_query(ot, which, *args), 2e-4)
+    close("aniso eval", facade.eval(ft, i, o), oracle.eval(ot, i, o), 2e-4)

@@ -79,9 +79,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="merl_eval", choices=list(WORKLOADS))
     ap.add_argument("--n", type=int, default=None, help="units per GPU per step (default: the BASELINE config size)")
+    ap.add_argument("--alpha", type=float, default=0.3, help="ggx_eval_pdf: isotropic roughness (SURVEY 8d extra points 0.05 / 0.8)")
+    ap.add_argument("--fresnel", default="ideal", choices=["ideal", "schlick"], help="ggx_eval_pdf: ideal (default) or schlick(1.0, 0.71, 0.29)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     return ap.parse_args()
+
+
+GGX_ALPHA, GGX_FRESNEL = 0.3, "ideal"       # overridden by --alpha / --fresnel
 
 
 def make_step(name, n, djb, synth, ctx, torch):
@@ -101,8 +106,9 @@ def make_step(name, n, djb, synth, ctx, torch):
     if name == "ggx_eval_pdf":
         i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
         o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
-        g = djb.ggx(djb.fresnel.ideal(), True, ctx=ctx)
-        p = djb.microfacet.params.isotropic(0.3)
+        fr = djb.fresnel.ideal() if GGX_FRESNEL == "ideal" else djb.fresnel.schlick((1.0, 0.71, 0.29))
+        g = djb.ggx(fr, True, ctx=ctx)
+        p = djb.microfacet.params.isotropic(GGX_ALPHA)
         out = torch.empty((3, n), dtype=torch.float32, device=i.device)
         pdf = torch.empty((n,), dtype=torch.float32, device=i.device)
         lib, C = djb._lib.load(), ctypes
@@ -176,7 +182,7 @@ def cpu_baseline(name, synth, budget_s=12.0):
             b = L.merl_from_table(synth.merl_table(0.3))
         op = "eval"
     elif name == "ggx_eval_pdf":
-        b, op, par = L.microfacet("ggx", ("ideal",), True), "eval", ("elliptic", 0.3, 0.3, 0.0)
+        b, op, par = L.microfacet("ggx", ("ideal",) if GGX_FRESNEL == "ideal" else ("schlick", 1.0, 0.71, 0.29), True), "eval", ("elliptic", GGX_ALPHA, GGX_ALPHA, 0.0)
     elif name == "beckmann_sample":
         b, op, par = L.microfacet("beckmann", ("ideal",), True), "sample", ("elliptic", 0.2, 0.5, 0.7)
     elif name == "utia_eval":
@@ -274,6 +280,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     ctx = djb.Context(local)    # runs on torch's current stream of this device
 
+    global GGX_ALPHA, GGX_FRESNEL
+    GGX_ALPHA, GGX_FRESNEL = args.alpha, args.fresnel
     name = args.workload
     n_default, bytes_per_unit, unit, kernel = WORKLOADS[name]
     n = args.n or n_default
@@ -350,7 +358,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 (f64 transcendentals)", "data": "synthetic",
             "config": {"workload": name, "units_per_gpu_per_step": n,
                        "brdf": {"merl_eval": "MERL 90x90x180x3 nearest-bin (synthetic GGX0.3+diffuse table)",
-                                "ggx_eval_pdf": "GGX isotropic alpha=0.3, ideal Fresnel, eval+pdf fused",
+                                "ggx_eval_pdf": f"GGX isotropic alpha={args.alpha:g}, {args.fresnel} Fresnel, eval+pdf fused",
                                 "beckmann_sample": "Beckmann elliptic(0.2,0.5,0.7) VNDF sample, on-chip RNG",
                                 "utia_eval": "UTIA 6x48x6x48x3 table, 16-tap interpolation + sRGB decode (synthetic payload)",
                                 "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material, tables resident in HBM",

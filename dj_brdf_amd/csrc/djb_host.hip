@@ -55,6 +55,10 @@ struct djb_ctx {
 	// so concurrent callers of one context are serialised here (its stream serialises them anyway)
 	// and multi-launch sequences that share per-context scratch (the two-tier MERL lookup) stay atomic.
 	std::recursive_mutex call_mu;
+	// small DJB_MEM_HOST calls (scalar facade calls, <= SMALL_N units): inputs are memcpy'd into this pinned,
+	// device-visible arena and the kernels read / write it directly over PCIe -- no hipMemcpy, one sync
+	char *pin = nullptr;
+	size_t pin_bytes = 0;
 };
 
 struct djb_brdf {
@@ -165,6 +169,8 @@ djb_status device_params(const djb_params *in, Params *out, int brdf_kind = -1)
 // single-threaded AoS<->SoA loop runs at ~3 GB/s, the copy itself at ~56 GB/s (tools/pcie_probe.hip).
 // Only exotic strides fall back to a packed SoA block.  Device-resident callers bypass all of this.
 constexpr size_t POOL_MAX_BYTES = 8ull << 30;
+constexpr long long SMALL_N = 4096;            // units per call that go through the pinned arena
+constexpr size_t PIN_BYTES = 1u << 20;         // >= SMALL_N * (largest per-unit footprint of any entry point)
 
 struct Staged {
 	djb_ctx *ctx; long long n; int mem;
@@ -173,7 +179,14 @@ struct Staged {
 	std::vector<Out> outs;
 	std::vector<std::pair<void *, std::pair<void *, size_t>>> out_raw;   // dev -> (host, bytes)
 
-	Staged(djb_ctx *c, long long n_, int mem_) : ctx(c), n(n_), mem(mem_) {}
+	bool small = false, synced = false;
+	size_t pin_off = 0;
+
+	Staged(djb_ctx *c, long long n_, int mem_) : ctx(c), n(n_), mem(mem_)
+	{
+		// the arena is per context and the caller holds ctx->call_mu for the whole entry point
+		small = mem == DJB_MEM_HOST && n <= SMALL_N && ctx && ctx->pin;
+	}
 	~Staged()
 	{
 		if (blocks.empty()) return;
@@ -191,6 +204,11 @@ struct Staged {
 	// allocation, or two small heap arrays) fail with hipErrorInvalidValue.
 	djb_status copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 	{
+		if (small) {   // both ends are host-addressable: inputs before the launch, outputs after one sync
+			if (kind == hipMemcpyDeviceToHost && !synced) { HIP_TRY(hipStreamSynchronize(ctx->stream)); synced = true; }
+			memcpy(dst, src, bytes);
+			return DJB_OK;
+		}
 		hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
 		if (e != hipSuccess) {
 			hipPointerAttribute_t ad, as;
@@ -215,6 +233,12 @@ struct Staged {
 	djb_status alloc(size_t bytes, void **out)
 	{
 		if (bytes == 0) bytes = 4;
+		if (small) {
+			size_t off = (pin_off + 255) & ~(size_t)255;
+			if (off + bytes <= ctx->pin_bytes) { *out = ctx->pin + off; pin_off = off + bytes; return DJB_OK; }
+			if (pin_off == 0) small = false;      // nothing handed out yet: fall back to the HBM path
+			else return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: pinned staging arena exhausted");
+		}
 		{
 			std::lock_guard<std::mutex> g(ctx->pool_mu);
 			int best = -1;
@@ -340,7 +364,7 @@ struct Staged {
 		}
 		for (auto &o : out_raw)
 			if (o.second.second) { djb_status cs_ = copy(o.second.first, o.first, o.second.second, hipMemcpyDeviceToHost); if (cs_ != DJB_OK) return cs_; }
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		if (!(small && synced)) HIP_TRY(hipStreamSynchronize(ctx->stream));
 		return DJB_OK;
 	}
 };
@@ -523,6 +547,9 @@ static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **o
 	if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
 		delete c; return fail(DJB_ERR_HIP, "djb_error: hipEventCreate failed");
 	}
+	// pinned, device-visible arena for small host-memory calls; without it they use the HBM staging path
+	if (hipHostMalloc((void **)&c->pin, PIN_BYTES, hipHostMallocDefault) == hipSuccess) c->pin_bytes = PIN_BYTES;
+	else { c->pin = nullptr; (void)hipGetLastError(); }
 	*out = c;
 	return DJB_OK;
 }
@@ -541,6 +568,7 @@ djb_status djb_ctx_destroy(djb_ctx *ctx)
 	(void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	for (auto &p : ctx->pool) (void)hipFree(p.first);
+	if (ctx->pin) (void)hipHostFree(ctx->pin);
 	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 	return DJB_OK;

@@ -61,6 +61,12 @@ int main()
 		djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&a, &dummy); expect("tabular(ggx,90) alpha_beckmann", a, 2.75112224);
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&a, &dummy); expect("tabular(ggx,90) alpha_ggx", a, 0.866066337);
 		expect("tabular p22v.size", (double)tab.get_p22v().size(), 90);
+		// what dj_beckmannconductor / dj_brdf do at load time: new djb::beckmann(tab->get_fresnel()) (mitsuba/dj_beckmannconductor.cpp:189)
+		djb::beckmann from_tab(tab.get_fresnel());
+		expect("beckmann(tab.get_fresnel()).fresnel(0.5).g", from_tab.fresnel(0.5f).y, tab.fresnel(0.5f).y);
+		djb::beckmann::lrep l1, l2(0.1f, -0.05f, 0.02f, 0.03f, 0.001f);          // mitsuba/dj_beckmannconductor.cpp:304-314
+		djb::beckmann::params_to_lrep(ell, &l1); l1 *= 0.7f; djb::microfacet::params lp; djb::beckmann::lrep_to_params(l1 + l2, &lp);
+		float lax, lay; lp.get_pdfparams(&lax, &lay); expect("lrep path ax > 0", lax > 0 ? 1.0 : 0.0, 1.0);
 		try { djb::merl bad("/nonexistent/file.binary"); g_fail = 1; }
 		catch (const djb::exc &e) { printf("djb::exc as expected: %s", e.what()); }
 	} catch (const djb::exc &e) {

@@ -24,6 +24,8 @@ constexpr int NTHETA_SIGMA = 90, NPHI_SIGMA = 180;      // dj_brdf.h:2350-2351
 constexpr int NNODE_SIGMA = NTHETA_SIGMA * NPHI_SIGMA;
 constexpr int NTHETA_FIT = 128;                          // dj_brdf.h:2279, 3135, 3162
 constexpr int MAX_PHI_STEPS = 512;
+// columns of the sigma quadrature staged per step (two LDS buffers of cnt x (tile + 1) floats)
+__host__ __device__ inline int sig_tile(int cnt) { return cnt <= 100 ? 64 : 32; }
 
 struct LdsPlan {   // byte offsets into dynamic LDS (doubles first: 8-byte aligned)
 	int v0, v1, cphid, cthd;                 // doubles
@@ -34,6 +36,8 @@ struct LdsPlan {   // byte offsets into dynamic LDS (doubles first: 8-byte align
 	int sh, ui;                              // floats [90]
 	int terms;                               // floats [2*128]
 	int qprobe;                              // floats [8*cnt]
+	int skv, ckv;                            // floats [cnt]: sin / cos of theta_k (sigma rows)
+	int stile;                               // floats [2][cnt][sig_tile + 1]: double-buffered tiles of sigma terms
 	int total;
 };
 
@@ -51,6 +55,8 @@ __host__ __device__ inline LdsPlan make_plan(int res)
 	p.sh = take(4 * NTHETA_SIGMA); p.ui = take(4 * NTHETA_SIGMA);
 	p.terms = take(4 * 2 * NTHETA_FIT);
 	p.qprobe = take(4 * 8 * cnt);
+	p.skv = take(4 * cnt); p.ckv = take(4 * cnt);
+	p.stile = take(4 * 2 * cnt * (sig_tile(cnt) + 1));
 	p.total = off;
 	return p;
 }
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	float *cphi = (float *)(lds + P.cphi), *ndf_tab = (float *)(lds + P.ndf);
 	float *sh = (float *)(lds + P.sh), *ui = (float *)(lds + P.ui);
 	float *terms = (float *)(lds + P.terms), *qprobe = (float *)(lds + P.qprobe);
+	float *skv = (float *)(lds + P.skv), *ckv = (float *)(lds + P.ckv), *stile = (float *)(lds + P.stile);
 	__shared__ int s_nphi, s_nqf;
 	__shared__ float s_scale;
 
@@ -184,24 +191,53 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	}
 	__syncthreads();
 	{
+		// sigma(theta_k) = max(cos theta_k, sum over the 180 x 90 nodes) for cnt rows: 16 200 dependent
+		// float adds per row in the reference's node order.  Producer waves compute the terms of one
+		// tile of nodes (thread = node x row group: the node's table values stay in registers, sin / cos
+		// of theta_k are LDS broadcasts) into one LDS buffer while the waves that own the rows add the
+		// previous tile's terms front to back from the other buffer.  Same terms, same order as the
+		// one-lane-per-row loop this replaces (1.14 ms of the 1.57 ms kernel).
 		const float dth = F(DJB_PI / D((float)NTHETA_SIGMA));
 		const float dph = F(2.0 * DJB_PI / D((float)NPHI_SIGMA));
 		for (int k = tid; k < cnt; k += FIT_BLOCK) {
 			float tmp = (float)k / (float)cnt;
 			float theta_k = F(D(tmp) * 0.5 * DJB_PI);
-			float ck = F(cos(D(theta_k))), sk = F(sin(D(theta_k)));
-			float nint = 0.0f;
-			for (int j2 = 0; j2 < NPHI_SIGMA; ++j2) {
-				double cp = cphid[j2];
-				for (int j1 = 0; j1 < NTHETA_SIGMA; ++j1) {
-					float s1 = sh[j1];
-					float kh = F(D(sk * s1) * cp + D(ck) * cthd[j1]);
-					nint += fmax_(0.0f, kh) * ndf_tab[j2 * NTHETA_SIGMA + j1] * ui[j1] * s1;
-				}
-			}
-			nint *= dth * dph;
-			sigma[k] = fmax_(ck, nint);
+			ckv[k] = F(cos(D(theta_k))); skv[k] = F(sin(D(theta_k)));
 		}
+		const int T = sig_tile(cnt), TS = T + 1;
+		const int n_sum = ((cnt + 63) / 64) * 64;            // threads [0, n_sum): row owners (whole waves)
+		const int n_prod = FIT_BLOCK - n_sum;                // threads [n_sum, 512): producers
+		const int a = tid - n_sum, col = a % T, grp = a / T, ngrp = n_prod / T;
+		const int ntiles = (NNODE_SIGMA + T - 1) / T;
+		auto produce = [&](int t) {
+			const int e = t * T + col;
+			if (a < 0 || grp >= ngrp) return;
+			float *buf = stile + (t & 1) * cnt * TS;
+			if (e >= NNODE_SIGMA) {                              // pad the last tile: x + 0.0f == x
+				for (int k = grp; k < cnt; k += ngrp) buf[k * TS + col] = 0.0f;
+				return;
+			}
+			const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
+			const double cp = cphid[j2], ct = cthd[j1];
+			const float s1 = sh[j1], nd = ndf_tab[e], w = ui[j1];
+			for (int k = grp; k < cnt; k += ngrp) {
+				float kh = F(D(skv[k] * s1) * cp + D(ckv[k]) * ct);
+				buf[k * TS + col] = fmax_(0.0f, kh) * nd * w * s1;
+			}
+		};
+		__syncthreads();
+		produce(0);
+		__syncthreads();
+		float nint = 0.0f;                                   // row accumulator of thread tid (tid < cnt)
+		for (int t = 0; t < ntiles; ++t) {
+			if (tid >= n_sum) { if (t + 1 < ntiles) produce(t + 1); }
+			else if (tid < cnt) {
+				const float *row = stile + (t & 1) * cnt * TS + tid * TS;
+				for (int c = 0; c < T; ++c) nint += row[c];          // the last tile is zero-padded: x + 0.0f == x
+			}
+			__syncthreads();
+		}
+		if (tid < cnt) { nint *= dth * dph; sigma[tid] = fmax_(ckv[tid], nint); }
 	}
 	__syncthreads();
 	if (tid == 0) sigma[cnt] = sigma[cnt - 1];

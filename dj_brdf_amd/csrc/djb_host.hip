@@ -818,23 +818,27 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 	Params std_p;
 	djb_status st = device_params(nullptr, &std_p);
 	if (st != DJB_OK) return st;
-	struct Bufs {
-		std::vector<void *> v;
-		~Bufs() { for (void *p : v) (void)hipFree(p); }
-		hipError_t get(void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e == hipSuccess) v.push_back(*p); return e; }
-	} bufs;
-	Brdf *d_srcs; double *km; float *ratio; djbk::FitOut o;
-	HIP_TRY(bufs.get((void **)&d_srcs, sizeof(Brdf) * n_mat));
-	HIP_TRY(bufs.get((void **)&km, sizeof(double) * (size_t)n_mat * cnt * cnt));
-	HIP_TRY(bufs.get((void **)&ratio, sizeof(float) * 3 * (size_t)n_mat * cnt * (cnt + 1)));
-	HIP_TRY(bufs.get((void **)&o.p22, sizeof(float) * (size_t)n_mat * res));
-	HIP_TRY(bufs.get((void **)&o.sigma, sizeof(float) * (size_t)n_mat * res));
-	HIP_TRY(bufs.get((void **)&o.cdf, sizeof(float) * (size_t)n_mat * res));
-	HIP_TRY(bufs.get((void **)&o.qf, sizeof(float) * (size_t)n_mat * res));
-	HIP_TRY(bufs.get((void **)&o.fresnel, sizeof(float) * 3 * (size_t)n_mat * res));
-	HIP_TRY(bufs.get((void **)&o.alpha_beckmann, sizeof(float) * n_mat));
-	HIP_TRY(bufs.get((void **)&o.alpha_ggx, sizeof(float) * n_mat));
-	HIP_TRY(bufs.get((void **)&o.n_qf, sizeof(int) * n_mat));
+	// one HBM block from the context's recycled staging pool, carved into the kernel's work arrays and
+	// outputs (eleven hipMalloc / hipFree pairs per call cost more than the fit of 100 materials)
+	Staged pool(ctx, SMALL_N + 1, DJB_MEM_HOST);
+	size_t total = 0;
+	auto reserve = [&](size_t bytes) { size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
+	const size_t o_srcs = reserve(sizeof(Brdf) * n_mat);
+	const size_t o_km = reserve(sizeof(double) * (size_t)n_mat * cnt * cnt);
+	const size_t o_ratio = reserve(sizeof(float) * 3 * (size_t)n_mat * cnt * (cnt + 1));
+	const size_t o_p22 = reserve(sizeof(float) * (size_t)n_mat * res), o_sigma = reserve(sizeof(float) * (size_t)n_mat * res);
+	const size_t o_cdf = reserve(sizeof(float) * (size_t)n_mat * res), o_qf = reserve(sizeof(float) * (size_t)n_mat * res);
+	const size_t o_fres = reserve(sizeof(float) * 3 * (size_t)n_mat * res);
+	const size_t o_ab = reserve(sizeof(float) * n_mat), o_ag = reserve(sizeof(float) * n_mat), o_nqf = reserve(sizeof(int) * n_mat);
+	char *base = nullptr;
+	if ((st = pool.alloc(total, (void **)&base)) != DJB_OK) return st;
+	Brdf *d_srcs = (Brdf *)(base + o_srcs);
+	double *km = (double *)(base + o_km);
+	float *ratio = (float *)(base + o_ratio);
+	djbk::FitOut o;
+	o.p22 = (float *)(base + o_p22); o.sigma = (float *)(base + o_sigma); o.cdf = (float *)(base + o_cdf);
+	o.qf = (float *)(base + o_qf); o.fresnel = (float *)(base + o_fres);
+	o.alpha_beckmann = (float *)(base + o_ab); o.alpha_ggx = (float *)(base + o_ag); o.n_qf = (int *)(base + o_nqf);
 	HIP_TRY(hipMemcpyAsync(d_srcs, srcs.data(), sizeof(Brdf) * n_mat, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(djbk::launch_fit(ctx->stream, d_srcs, src_kind, std_p, n_mat, res, shadow != 0, km, ratio, o));
 	auto back = [&](void *h, const void *d, size_t bytes) -> hipError_t {

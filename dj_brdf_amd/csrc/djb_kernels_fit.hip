@@ -2,13 +2,13 @@
 //   djb::tabular::tabular(brdf, res, shadow)                        dj_brdf.h:2215-2236
 //   tabular::fit_beckmann_parameters / fit_ggx_parameters           dj_brdf.h:3133-3184
 //
-// One 512-thread workgroup (8 wave64s) per material; materials are independent, so a batch of M
+// One 1024-thread workgroup (16 wave64s) per material; materials are independent, so a batch of M
 // materials is a grid of M workgroups and a multi-GPU batch is a partition of the material list.
 //
 // The reference accumulates its quadratures in float, in loop order.  Float addition does not
 // commute with a tree reduction, so to reproduce the reference's tables (and the %.3f digits of
 // params.txt) every *sum* keeps the reference's order: the expensive per-term work (libm-class
-// transcendentals, MERL look-ups, spline fetches) is spread over all 512 lanes and staged in LDS,
+// transcendentals, MERL look-ups, spline fetches) is spread over all 1024 lanes and staged in LDS,
 // then the lane that owns a row adds its terms front to back.  Rows (theta_k, theta_d, theta_o)
 // are independent and map to lanes; wave64 lanes of one row-owner wave broadcast-read the shared
 // per-node tables from LDS.  No MFMA: the only matrix product is an (res-1)^2 matvec in double,
@@ -19,7 +19,7 @@ using namespace djbdev;
 
 namespace {
 
-constexpr int FIT_BLOCK = 512;
+constexpr int FIT_BLOCK = 1024;
 constexpr int NTHETA_SIGMA = 90, NPHI_SIGMA = 180;      // dj_brdf.h:2350-2351
 constexpr int NNODE_SIGMA = NTHETA_SIGMA * NPHI_SIGMA;
 constexpr int NTHETA_FIT = 128;                          // dj_brdf.h:2279, 3135, 3162
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		}
 		const int T = sig_tile(cnt), TS = T + 1;
 		const int n_sum = ((cnt + 63) / 64) * 64;            // threads [0, n_sum): row owners (whole waves)
-		const int n_prod = FIT_BLOCK - n_sum;                // threads [n_sum, 512): producers
+		const int n_prod = FIT_BLOCK - n_sum;                // threads [n_sum, FIT_BLOCK): producers
 		const int a = tid - n_sum, col = a % T, grp = a / T, ngrp = n_prod / T;
 		const int ntiles = (NNODE_SIGMA + T - 1) / T;
 		auto produce = [&](int t) {

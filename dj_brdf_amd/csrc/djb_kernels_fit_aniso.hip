@@ -145,13 +145,53 @@ __global__ __launch_bounds__(BLOCK) void ka_norm_terms(AnisoScratch S, int shado
 	float weight = F(D(theta) * tan(D(ts)) / D(c * c));
 	S.terms[e] = weight * aniso_p22_theta_phi(self, ts, phi);
 }
+// ---- ordered float sums of NACC arrays of M terms each (arrays are M apart, starting at `terms`).
+// The reference accumulates these quadratures front to back in one float; a single lane reading HBM
+// term by term is latency-bound (14 ns per add).  Here waves 1.. of the block stream tiles of
+// OS_TILE terms per array into double-buffered LDS while lane k < NACC of wave 0 adds array k's
+// terms in index order (loads batched 16 at a time, then 16 dependent adds).  Returns the sum in
+// threads k < NACC.  Block size >= 128; `buf` holds 2 * NACC * OS_STRIDE floats.
+constexpr int OS_TILE = 512, OS_STRIDE = OS_TILE + 1;   // +1: lanes k read array k's row from distinct LDS banks
+template <int NACC>
+DJB_DEV float ordered_sums(const float *terms, size_t M, float *buf)
+{
+	const int tid = threadIdx.x, nload = blockDim.x - 64;
+	const int ntiles = (int)((M + OS_TILE - 1) / OS_TILE);
+	auto fetch = [&](int t) {
+		float *dst = buf + (size_t)(t & 1) * NACC * OS_STRIDE;
+		for (int q = tid - 64; q < NACC * OS_TILE; q += nload) {
+			const int k = q / OS_TILE, c = q - k * OS_TILE;
+			const size_t e = (size_t)t * OS_TILE + c;
+			dst[k * OS_STRIDE + c] = e < M ? terms[k * M + e] : 0.0f;   // padding: n + 0.0f == n
+		}
+	};
+	if (tid >= 64) fetch(0);
+	__syncthreads();
+	float n = 0.0f;
+	for (int t = 0; t < ntiles; ++t) {
+		if (tid >= 64) { if (t + 1 < ntiles) fetch(t + 1); }
+		else if (tid < NACC) {
+			const float *row = buf + (size_t)(t & 1) * NACC * OS_STRIDE + tid * OS_STRIDE;
+			for (int c = 0; c < OS_TILE; c += 16) {
+				float v[16];
+#pragma unroll
+				for (int q = 0; q < 16; ++q) v[q] = row[c + q];
+#pragma unroll
+				for (int q = 0; q < 16; ++q) n += v[q];
+			}
+		}
+		__syncthreads();
+	}
+	return n;
+}
+
 __global__ __launch_bounds__(BLOCK) void ka_norm_apply(AnisoScratch S)
 {
 	__shared__ float s_k;
+	__shared__ float s_buf[2 * OS_STRIDE];
+	float k = ordered_sums<1>(S.terms, (size_t)NP_NORM * NT_NORM, s_buf);
 	if (threadIdx.x == 0) {
 		const float dtheta = F(sqrt(0.5 * DJB_PI) / D((float)NT_NORM)), dphi = F(2.0 * DJB_PI / D((float)NP_NORM));
-		float k = 0.0f;
-		for (int e = 0; e < NP_NORM * NT_NORM; ++e) k += S.terms[e];
 		k = F(D(k) * (2.0 * D(dtheta) * D(dphi)));
 		s_k = F(1.0 / D(k));
 	}
@@ -437,14 +477,13 @@ __global__ __launch_bounds__(BLOCK) void ka_fit_terms(AnisoScratch S, int shadow
 	S.terms[5 * M + e] = tmp2 * fabsf(e1);
 	S.terms[6 * M + e] = tmp2 * fabsf(e2);
 }
-__global__ __launch_bounds__(64) void ka_fit_sum(AnisoScratch S)
+__global__ __launch_bounds__(BLOCK) void ka_fit_sum(AnisoScratch S)
 {
 	__shared__ float s_n[7];
+	__shared__ float s_buf[2 * 7 * OS_STRIDE];
 	const size_t M = (size_t)NP_FIT * NT_FIT;
+	float n = ordered_sums<7>(S.terms, M, s_buf);
 	if (threadIdx.x < 7) {
-		const float *t = S.terms + threadIdx.x * M;
-		float n = 0.0f;
-		for (size_t e = 0; e < M; ++e) n += t[e];
 		const float dtheta = F(sqrt(DJB_PI * 0.5) / D((float)NT_FIT)), dphi = F(2.0 * DJB_PI / D((float)NP_FIT));
 		s_n[threadIdx.x] = F(D(n) * (2.0 * D(dtheta) * D(dphi)));
 	}
@@ -489,7 +528,7 @@ hipError_t run_kind(hipStream_t s, const Brdf &src, const Params &std_p, const A
 	hipLaunchKernelGGL(ka_qf2_probes, dim3(blocks_for((long long)A * w * 8)), dim3(BLOCK), 0, s, S, shadow);
 	hipLaunchKernelGGL(ka_qf2_merge, dim3(blocks_for(A)), dim3(BLOCK), 0, s, S);
 	hipLaunchKernelGGL(ka_fit_terms, dim3(blocks_for(NP_FIT * NT_FIT)), dim3(BLOCK), 0, s, S, shadow);
-	hipLaunchKernelGGL(ka_fit_sum, dim3(1), dim3(64), 0, s, S);
+	hipLaunchKernelGGL(ka_fit_sum, dim3(1), dim3(BLOCK), 0, s, S);
 	return hipGetLastError();
 }
 

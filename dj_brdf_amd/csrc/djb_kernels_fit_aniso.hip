@@ -150,20 +150,32 @@ __global__ __launch_bounds__(BLOCK) void ka_norm_terms(AnisoScratch S, int shado
 // term by term is latency-bound (14 ns per add).  Here waves 1.. of the block stream tiles of
 // OS_TILE terms per array into double-buffered LDS while lane k < NACC of wave 0 adds array k's
 // terms in index order (loads batched 16 at a time, then 16 dependent adds).  Returns the sum in
-// threads k < NACC.  Block size >= 128; `buf` holds 2 * NACC * OS_STRIDE floats.
+// threads k < NACC.  Launch with BLOCK threads; `buf` holds 2 * NACC * OS_STRIDE floats.
 constexpr int OS_TILE = 512, OS_STRIDE = OS_TILE + 1;   // +1: lanes k read array k's row from distinct LDS banks
 template <int NACC>
 DJB_DEV float ordered_sums(const float *terms, size_t M, float *buf)
 {
-	const int tid = threadIdx.x, nload = blockDim.x - 64;
+	const int tid = threadIdx.x;
+	constexpr int NLOAD = BLOCK - 64, PER = (OS_TILE + NLOAD - 1) / NLOAD;   // launched with BLOCK threads
 	const int ntiles = (int)((M + OS_TILE - 1) / OS_TILE);
 	auto fetch = [&](int t) {
 		float *dst = buf + (size_t)(t & 1) * NACC * OS_STRIDE;
-		for (int q = tid - 64; q < NACC * OS_TILE; q += nload) {
-			const int k = q / OS_TILE, c = q - k * OS_TILE;
-			const size_t e = (size_t)t * OS_TILE + c;
-			dst[k * OS_STRIDE + c] = e < M ? terms[k * M + e] : 0.0f;   // padding: n + 0.0f == n
-		}
+		float v[NACC][PER];
+#pragma unroll
+		for (int k = 0; k < NACC; ++k)                                       // all loads first: one latency per tile
+#pragma unroll
+			for (int j = 0; j < PER; ++j) {
+				const int c = tid - 64 + j * NLOAD;
+				const size_t e = (size_t)t * OS_TILE + c;
+				v[k][j] = (c < OS_TILE && e < M) ? terms[k * M + e] : 0.0f;   // padding: n + 0.0f == n
+			}
+#pragma unroll
+		for (int k = 0; k < NACC; ++k)
+#pragma unroll
+			for (int j = 0; j < PER; ++j) {
+				const int c = tid - 64 + j * NLOAD;
+				if (c < OS_TILE) dst[k * OS_STRIDE + c] = v[k][j];
+			}
 	};
 	if (tid >= 64) fetch(0);
 	__syncthreads();

@@ -445,23 +445,34 @@ __global__ __launch_bounds__(BLOCK) void ka_qf2_probes(AnisoScratch S, int shado
 	float phi = F(D((float)k / (float)S.azim) * 2.0 * DJB_PI);
 	S.probes[e] = aniso_cdf2(self, F(D((float)j / (float)res) * 0.5 * DJB_PI), phi);
 }
-__global__ __launch_bounds__(BLOCK) void ka_qf2_merge(AnisoScratch S)
+// compute_qf2's forward scan (dj_brdf.h:3005-3034): for i = 1 .. w-1 the probe index j only moves forward and
+// stops at the first probe >= i / w.  Because the thresholds increase, that is the FIRST probe of the
+// whole row that reaches the threshold (a probe before the previous stop that reached i / w would have
+// reached (i-1) / w too and stopped the previous search earlier), and once a threshold is never reached
+// none of the later ones is.  So every (row, i) searches independently; one block per azimuth row.
+__global__ __launch_bounds__(128) void ka_qf2_merge(AnisoScratch S)
 {
 	const int E = S.elev, w = E - 1, res = w * 8;
-	int k = blockIdx.x * BLOCK + threadIdx.x;
-	if (k >= S.azim) return;
+	const int k = blockIdx.x;
 	const float *pr = S.probes + (size_t)k * res;
 	float *row = S.qf2 + (size_t)E * k;
-	int nq = 0, j = 0;
-	row[nq++] = 0.0f;
-	for (int i = 1; i < w; ++i) {
-		float c = (float)i / (float)w;
-		for (; j < res; ++j)
-			if (pr[j] >= c) { row[nq++] = (float)j / (float)res; break; }
+	__shared__ int s_missing;
+	if (threadIdx.x == 0) { s_missing = w; row[0] = 0.0f; }
+	__syncthreads();
+	for (int i = 1 + threadIdx.x; i < w; i += 128) {
+		const float c = (float)i / (float)w;
+		int j = 0;
+		while (j < res && !(pr[j] >= c)) ++j;
+		if (j < res) row[i] = (float)j / (float)res;
+		else atomicMin(&s_missing, i);
 	}
-	if (nq < E) row[nq++] = 1.0f;
-	if (nq != E) atomicAdd(&S.counts[1], 1);          // a short row would misalign the reference's vector
-	for (; nq < E; ++nq) row[nq] = 1.0f;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int nq = s_missing;                            // entries written so far: row[0 .. nq-1]
+		if (nq < E) row[nq++] = 1.0f;
+		if (nq != E) atomicAdd(&S.counts[1], 1);       // a short row would misalign the reference's vector
+		for (; nq < E; ++nq) row[nq] = 1.0f;
+	}
 }
 
 // ---- fit_beckmann_parameters / fit_ggx_parameters (dj_brdf.h:3186-3307) ------------------------
@@ -538,7 +549,7 @@ hipError_t run_kind(hipStream_t s, const Brdf &src, const Params &std_p, const A
 	hipLaunchKernelGGL(ka_pdf2_scale, dim3(blocks_for(E * A)), dim3(BLOCK), 0, s, S);
 	hipLaunchKernelGGL(ka_cdf2, dim3(blocks_for(A)), dim3(BLOCK), 0, s, S, shadow);
 	hipLaunchKernelGGL(ka_qf2_probes, dim3(blocks_for((long long)A * w * 8)), dim3(BLOCK), 0, s, S, shadow);
-	hipLaunchKernelGGL(ka_qf2_merge, dim3(blocks_for(A)), dim3(BLOCK), 0, s, S);
+	hipLaunchKernelGGL(ka_qf2_merge, dim3(A), dim3(128), 0, s, S);
 	hipLaunchKernelGGL(ka_fit_terms, dim3(blocks_for(NP_FIT * NT_FIT)), dim3(BLOCK), 0, s, S, shadow);
 	hipLaunchKernelGGL(ka_fit_sum, dim3(1), dim3(BLOCK), 0, s, S);
 	return hipGetLastError();

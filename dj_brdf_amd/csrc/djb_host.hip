@@ -1431,12 +1431,12 @@ djb_status set_error(djb_status st, const char *fmt, ...)
 	return st;
 }
 
-// a texel table already converted in HBM becomes a djb::merl object (which then owns it)
-djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **out)
+// a texel table already converted in HBM becomes a djb::merl object (which owns it if `own`)
+djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **out, bool own)
 {
 	djb_brdf *b;
 	alloc_brdf(ctx, DJB_KIND_MERL, &b);
-	b->allocs.push_back(table);
+	if (own) b->allocs.push_back(table);
 	b->dev.merl = table;
 	*out = b;
 	return DJB_OK;

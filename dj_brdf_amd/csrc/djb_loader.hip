@@ -35,7 +35,7 @@ djb_status djb_brdf_destroy(djb_brdf *);
 
 namespace djbk {
 // defined in djb_host.hip: wrap an already converted texel table into a djb_brdf (takes ownership)
-djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **out);
+djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **out, bool own);
 hipStream_t ctx_stream(djb_ctx *ctx);
 int ctx_device(djb_ctx *ctx);
 djb_status set_error(djb_status st, const char *fmt, ...);
@@ -105,7 +105,8 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 	if (reader_threads > n_slots) reader_threads = n_slots;
 
 	std::vector<Slot> slots(n_slots);
-	std::vector<djbdev::MerlTexel *> tables(n_files, nullptr);
+	std::vector<djbdev::MerlTexel *> tables(n_files, nullptr);   // views into all_tables
+	djbdev::MerlTexel *all_tables = nullptr;
 	djb_status status = DJB_OK;
 	std::string status_msg;
 	auto cleanup = [&]() {
@@ -114,8 +115,12 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 			if (s.dev) (void)hipFree(s.dev);
 			if (s.done) (void)hipEventDestroy(s.done);
 		}
-		for (djbdev::MerlTexel *t : tables) if (t) (void)hipFree(t);
+		if (all_tables) (void)hipFree(all_tables);
 	};
+	if (hipMalloc((void **)&all_tables, sizeof(djbdev::MerlTexel) * (size_t)MERL_N * n_files) != hipSuccess) {
+		(void)hipGetLastError();
+		return djbk::set_error(DJB_ERR_HIP, "djb_error: cannot allocate %d MERL tables in HBM", n_files);
+	}
 	for (Slot &s : slots) {
 		if (hipHostMalloc((void **)&s.host, PAYLOAD, hipHostMallocDefault) != hipSuccess ||
 		    hipMalloc((void **)&s.dev, PAYLOAD) != hipSuccess ||
@@ -181,13 +186,11 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 		if (slot < 0) continue;
 		Slot &s = slots[slot];
 		if (s.st != DJB_OK) { status = s.st; status_msg = s.err; break; }
-		djbdev::MerlTexel *tab = nullptr;
-		e = hipMalloc((void **)&tab, sizeof(djbdev::MerlTexel) * (size_t)MERL_N);
-		if (e == hipSuccess) e = hipMemcpyAsync(s.dev, s.host, PAYLOAD, hipMemcpyHostToDevice, stream);
+		djbdev::MerlTexel *tab = all_tables + (size_t)s.file * MERL_N;   // one block for the batch (a hipMalloc per file costs ~0.2 ms)
+		e = hipMemcpyAsync(s.dev, s.host, PAYLOAD, hipMemcpyHostToDevice, stream);
 		if (e == hipSuccess) e = djbk::launch_merl_convert(stream, s.dev, MERL_N, tab);
 		if (e == hipSuccess) e = hipEventRecord(s.done, stream);
 		if (e != hipSuccess) {
-			if (tab) (void)hipFree(tab);
 			status = DJB_ERR_HIP; status_msg = std::string("djb_error: upload failed: ") + hipGetErrorString(e);
 			break;
 		}
@@ -205,8 +208,7 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 	// ---- one fit launch for the whole batch
 	std::vector<djb_brdf *> mats(n_files, nullptr);
 	for (int k = 0; k < n_files && status == DJB_OK; ++k) {
-		status = djbk::wrap_merl_table(ctx, tables[k], &mats[k]);
-		if (status == DJB_OK) tables[k] = nullptr;       // now owned by the brdf
+		status = djbk::wrap_merl_table(ctx, tables[k], &mats[k], false);   // views into all_tables
 	}
 	if (status == DJB_OK)
 		status = djb_fit_brdf_batch(ctx, n_files, mats.data(), res, shadow, alpha_beckmann, alpha_ggx,

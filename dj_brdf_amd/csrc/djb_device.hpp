@@ -149,10 +149,109 @@ DJB_DEV float erf_given_exp(float x, double e)
 }
 DJB_DEV float erf_(float x) { return erf_given_exp(x, exp(D(-x * x))); }
 
-// Giles' single-precision erfinv, dj_brdf.h:691-721
-DJB_DEV float erfinv_(float u)
+// ---- glibc 2.35's float logf / expf / powf, restated -------------------------------------------
+// The reference calls the float libm in erfinv (logf) and in Beckmann's Newton inversion (powf, expf),
+// dj_brdf.h:691-721, 1897-1952, so its values are those of the host's glibc -- not of a correctly
+// rounded function, and not of ROCm's device libm (which differs in ~13 % of the Beckmann samples).
+// These are the table-driven double-arithmetic algorithms glibc uses (sysdeps/ieee754/flt-32/e_logf.c,
+// e_expf.c, e_powf.c = ARM optimized-routines), with the multiply-add contractions of the x86-64 FMA
+// ifunc variant; tables in djb_glibc_flt32_tables.hpp (tools/extract_glibc_flt32_tables.py).  The
+// restatement is pinned against the host libm in oracle/ (0 mismatches over 1.2e8-2e8 arguments per
+// function).  Main paths only: special arguments fall back to the device libm.
+#include "djb_glibc_flt32_tables.hpp"
+// where the indexed tables are read from: the global copies by default; hot kernels stage them in LDS
+// (glibc_tabs_to_lds: 768 B) because the Newton loop looks them up twice per iteration.  The scalar
+// coefficients are compile-time constants (SGPRs / literals, not per-lane registers).
+struct GlibcTabs { const double *logf, *powlog; const unsigned long long *exp2; };
+DJB_DEV GlibcTabs glibc_tabs_global() { GlibcTabs t = { DJB_GLIBC_LOGF, DJB_GLIBC_POWF_LOG2, DJB_GLIBC_EXP2F_TAB }; return t; }
+constexpr int GLIBC_LDS_WORDS = 32 + 32 + 32;    // 8-byte words
+DJB_DEV GlibcTabs glibc_tabs_to_lds(double *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
 {
-	float w = -logf((1.0f - u) * (1.0f + u)), p;
+	for (int k = tid; k < GLIBC_LDS_WORDS; k += nthreads) {
+		double v;
+		if (k < 32) v = DJB_GLIBC_LOGF[k];
+		else if (k < 64) v = DJB_GLIBC_POWF_LOG2[k - 32];
+		else v = __longlong_as_double((long long)DJB_GLIBC_EXP2F_TAB[k - 64]);
+		lds[k] = v;
+	}
+	GlibcTabs t = { lds, lds + 32, (const unsigned long long *)(lds + 64) };
+	return t;
+}
+DJB_DEV float glibc_logf(float x, const GlibcTabs &gt)
+{
+	const double *T = gt.logf;
+	constexpr double Ln2 = DJB_GLIBC_LOGF_C[0], A0 = DJB_GLIBC_LOGF_C[1], A1 = DJB_GLIBC_LOGF_C[2], A2 = DJB_GLIBC_LOGF_C[3];
+	unsigned int ix = __float_as_uint(x);
+	if (ix == 0x3f800000u) return 0.0f;
+	if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return logf(x);
+	unsigned int tmp = ix - 0x3f330000u;
+	int i = (int)((tmp >> 19) % 16u), k = (int)tmp >> 23;
+	unsigned int iz = ix - (tmp & (0x1ffu << 23));
+	double invc = T[2 * i], logc = T[2 * i + 1], z = D(__uint_as_float(iz));
+	double r = __builtin_fma(z, invc, -1.0);
+	double y0 = __builtin_fma((double)k, Ln2, logc);
+	double r2 = r * r;
+	double y = __builtin_fma(A1, r, A2);
+	y = __builtin_fma(A0, r2, y);
+	y = __builtin_fma(y, r2, y0 + r);
+	return F(y);
+}
+// C0..C2: poly (powf) or poly_scaled (expf)
+DJB_DEV float glibc_exp2_tail(unsigned long long ki, double r, double C0, double C1, double C2, const GlibcTabs &gt)
+{
+	// t = tab[ki % 32] + (ki << 47): only the high word changes, and only bits 0..16 of ki reach it
+	const unsigned int klo = (unsigned int)ki;
+	const unsigned long long tb = gt.exp2[klo & 31u];
+	double s = __hiloint2double((int)((unsigned int)(tb >> 32) + (klo << 15)), (int)(unsigned int)tb);
+	double zz = __builtin_fma(C0, r, C1);
+	double r2 = r * r;
+	double y = __builtin_fma(C2, r, 1.0);
+	y = __builtin_fma(zz, r2, y);
+	return F(y * s);
+}
+DJB_DEV float glibc_expf(float x, const GlibcTabs &gt)
+{
+	constexpr double Shift = DJB_GLIBC_EXP2F_C[4], InvLn2N = DJB_GLIBC_EXP2F_C[5];
+	unsigned int abstop = (__float_as_uint(x) >> 20) & 0x7ffu;
+	if (abstop >= (0x42b00000u >> 20)) return expf(x);                 // |x| >= 88 or nan
+	double xd = D(x), z = InvLn2N * xd;
+	double kd = z + Shift;
+	unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+	kd -= Shift;
+	double r = __builtin_fma(InvLn2N, xd, -kd);
+	return glibc_exp2_tail(ki, r, DJB_GLIBC_EXP2F_C[6], DJB_GLIBC_EXP2F_C[7], DJB_GLIBC_EXP2F_C[8], gt);
+}
+DJB_DEV float glibc_powf(float x, float y, const GlibcTabs &gt)
+{
+	const double *T = gt.powlog;
+	constexpr double A0 = DJB_GLIBC_POWF_C[0], A1 = DJB_GLIBC_POWF_C[1], A2 = DJB_GLIBC_POWF_C[2], A3 = DJB_GLIBC_POWF_C[3],
+	                 A4 = DJB_GLIBC_POWF_C[4], ShiftScaled = DJB_GLIBC_EXP2F_C[0];
+	unsigned int ix = __float_as_uint(x), iy = __float_as_uint(y);
+	if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2u * iy - 1u >= 2u * 0x7f800000u - 1u) return powf(x, y);
+	unsigned int tmp = ix - 0x3f330000u;
+	int i = (int)((tmp >> 19) % 16u);
+	unsigned int top = tmp & 0xff800000u, iz = ix - top;
+	int k = (int)top >> 23;
+	double invc = T[2 * i], logc = T[2 * i + 1], z = D(__uint_as_float(iz));
+	double r = __builtin_fma(z, invc, -1.0), y0 = logc + (double)k;
+	double r2 = r * r;
+	double p0 = __builtin_fma(A0, r, A1), p = __builtin_fma(A2, r, A3), r4 = r2 * r2;
+	double q = __builtin_fma(A4, r, y0);
+	q = __builtin_fma(p, r2, q);
+	double logx = __builtin_fma(p0, r4, q);
+	double ylogx = D(y) * logx;
+	if ((((unsigned long long)__double_as_longlong(ylogx) >> 47) & 0xffffull) >= (0x405f800000000000ull >> 47)) return powf(x, y);   // |y log2 x| >= 126
+	double kd = ylogx + ShiftScaled;
+	unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+	kd -= ShiftScaled;
+	double rr = __builtin_fma(D(y), logx, -kd);
+	return glibc_exp2_tail(ki, rr, DJB_GLIBC_EXP2F_C[1], DJB_GLIBC_EXP2F_C[2], DJB_GLIBC_EXP2F_C[3], gt);
+}
+
+// Giles' single-precision erfinv, dj_brdf.h:691-721
+DJB_DEV float erfinv_(float u, const GlibcTabs &gt)
+{
+	float w = -glibc_logf((1.0f - u) * (1.0f + u), gt), p;
 	if (w < 5.0f) {
 		w = w - 2.5f;
 		p = 2.81022636e-08f;
@@ -404,10 +503,10 @@ DJB_DEV float ggx_qf1(float u)                                                  
 	return u * inversesqrt_(F(1.0 - D(u * u)));
 }
 
-DJB_DEV float beckmann_qf1(float u) { return erfinv_(F(2.0 * D(u) - 1.0)); }           // :1891
+DJB_DEV float beckmann_qf1(float u, const GlibcTabs &gt) { return erfinv_(F(2.0 * D(u) - 1.0), gt); }   // :1891
 
 // Newton + bisection in the erf domain, dj_brdf.h:1897-1952
-DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k)
+DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k, const GlibcTabs &gt)
 {
 	const float sqrt_pi_inv = F(1. / sqrt(DJB_PI));
 	float cot_k = cos_k / sin_k, tan_k = sin_k / cos_k;
@@ -415,19 +514,19 @@ DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k)
 	float a = -1, c = erf_given_exp(cot_k, e_cot);
 	u = fmax_(u, 1e-6f);
 	float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
-	float b = c - (1 + c) * powf(1 - u, fit);
+	float b = c - (1 + c) * glibc_powf(1 - u, fit, gt);
 	float normalization = recip_to_f32(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot);
 	int it = 0;
 	while (++it < 10) {
 		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
-		float inv_erf = erfinv_(b);
-		float value = normalization * (1 + b + sqrt_pi_inv * tan_k * expf(-inv_erf * inv_erf)) - u;
+		float inv_erf = erfinv_(b, gt);
+		float value = normalization * (1 + b + sqrt_pi_inv * tan_k * glibc_expf(-inv_erf * inv_erf, gt)) - u;
 		float derivative = normalization * (1 - inv_erf * tan_k);
 		if (fabsf(value) < 1e-5f) break;
 		if (value > 0) c = b; else a = b;
 		b -= value / derivative;
 	}
-	return erfinv_(fmax_(-0.9999f, b));
+	return erfinv_(fmax_(-0.9999f, b), gt);
 }
 
 DJB_DEV float ggx_qf2_radial(float u, float cos_k, float sin_k)                        // :2089
@@ -569,13 +668,13 @@ DJB_DEV void mf_eval_pdf(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, flo
 
 // radial::sample_vp22_std_smith / _nmap, dj_brdf.h:1806-1846
 template <int KIND>
-DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &xs, float &ys)
+DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &xs, float &ys, const GlibcTabs &gt)
 {
 	if (!DJB_NMAP(KIND)) {
 		float cos_k = k.z;
 		float sin_k = D(k.z) < 1.0 ? F(sqrt(1.0 - D(k.z * k.z))) : 0.0f;
 		float tx, ty;
-		if (KIND == KIND_BECKMANN) { tx = beckmann_qf2_radial(u1, cos_k, sin_k); ty = beckmann_qf1(u2); }
+		if (KIND == KIND_BECKMANN) { tx = beckmann_qf2_radial(u1, cos_k, sin_k, gt); ty = beckmann_qf1(u2, gt); }
 		else { tx = ggx_qf2_radial(u1, cos_k, sin_k); ty = ggx_qf3_radial(u2, tx); }
 		if (D(sin_k) == 0.0) { xs = tx; ys = ty; }
 		else {
@@ -599,7 +698,7 @@ DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &
 }
 
 template <int KIND>
-DJB_DEV v3 mf_sample(const Brdf &b, const Params &p, float u1, float u2, v3 o)              // :1669
+DJB_DEV v3 mf_sample(const Brdf &b, const Params &p, float u1, float u2, v3 o, const GlibcTabs &gt)   // :1669
 {
 	u1 = sat_(u1) * 0.99998f + 0.00001f;
 	u2 = sat_(u2) * 0.99998f + 0.00001f;
@@ -609,7 +708,7 @@ DJB_DEV v3 mf_sample(const Brdf &b, const Params &p, float u1, float u2, v3 o)  
 	v3 o_std = normalize(mk(a, bb, c));
 	if (D(o_std.z) > 0.0) {
 		float txm, tym;
-		mf_sample_vp22_std<KIND>(b, u1, u2, o_std, txm, tym);
+		mf_sample_vp22_std<KIND>(b, u1, u2, o_std, txm, tym, gt);
 		float txh = p.ax * txm + p.tx;
 		float chol = p.rho * txm + p.s * tym;
 		float tyh = p.ay * chol + p.ty;
@@ -621,9 +720,9 @@ DJB_DEV v3 mf_sample(const Brdf &b, const Params &p, float u1, float u2, v3 o)  
 
 template <int KIND>
 DJB_DEV v3 mf_evalp_is(const Brdf &b, const Params &p, float u1, float u2, v3 o, v3 &i_out,
-                       float &pdf_out)                                                       // :1734
+                       float &pdf_out, const GlibcTabs &gt)                                  // :1734
 {
-	v3 i_ = mf_sample<KIND>(b, p, u1, u2, o);
+	v3 i_ = mf_sample<KIND>(b, p, u1, u2, o, gt);
 	v3 h = normalize(add(i_, o));
 	float sig_o = mf_sigma<KIND>(b, o, p);
 	float g1o = mf_g1_from_sigma(o, sig_o, p);

@@ -155,6 +155,10 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
                                                   unsigned long long start, View vo, View vi_out,
                                                   View vw_out, float *out_pdf)
 {
+	// Beckmann's quantile functions call glibc's logf / expf / powf restatement: its tables go to LDS
+	__shared__ double s_glibc[KIND == KIND_BECKMANN ? GLIBC_LDS_WORDS : 1];
+	GlibcTabs gt = glibc_tabs_global();
+	if (KIND == KIND_BECKMANN) { gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK); __syncthreads(); }
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		float u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : u1a[k];
@@ -162,10 +166,10 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 		v3 o = load3(vo, k);
 		if (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
 			if (!IS) {
-				store3(vi_out, k, mf_sample<KIND>(b, p, u1, u2, o));
+				store3(vi_out, k, mf_sample<KIND>(b, p, u1, u2, o, gt));
 			} else {
 				v3 i_out = mk(0, 0, 0); float pdf;
-				v3 w = mf_evalp_is<KIND>(b, p, u1, u2, o, i_out, pdf);
+				v3 w = mf_evalp_is<KIND>(b, p, u1, u2, o, i_out, pdf, gt);
 				store3(vw_out, k, w); store3(vi_out, k, i_out); out_pdf[k] = pdf;
 			}
 		} else {
@@ -238,11 +242,11 @@ __global__ __launch_bounds__(BLOCK) void k_query(Brdf b, Params p, int which, lo
 		case Q_SIGMA_STD_RADIAL: r.x = sigma_std_radial<KIND>(b, a.x); break;
 		case Q_CDF_RADIAL: r.x = cdf_radial<KIND>(b, a.x); break;
 		case Q_QF_RADIAL: r.x = qf_radial<KIND>(b, a.x); break;
-		case Q_QF2_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf2_radial(a.x, a.y, a.z)
+		case Q_QF2_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf2_radial(a.x, a.y, a.z, glibc_tabs_global())
 		                       : KIND == KIND_GGX ? ggx_qf2_radial(a.x, a.y, a.z) : 0.0f; break;
-		case Q_QF3_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x)
+		case Q_QF3_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x, glibc_tabs_global())
 		                       : KIND == KIND_GGX ? ggx_qf3_radial(a.x, a.y) : 0.0f; break;
-		case Q_QF1: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x) : KIND == KIND_GGX ? ggx_qf1(a.x) : 0.0f; break;
+		case Q_QF1: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x, glibc_tabs_global()) : KIND == KIND_GGX ? ggx_qf1(a.x) : 0.0f; break;
 		// tabular_anisotropic::{pdf1, cdf1, qf1, pdf2, cdf2, qf2} (dj_brdf.h:450-455)
 		case Q_A_PDF1: r.x = KIND == KIND_TABULAR_ANISO ? aniso_pdf1(b, a.x) : 0.0f; break;
 		case Q_A_CDF1: r.x = KIND == KIND_TABULAR_ANISO ? aniso_cdf1(b, a.x) : 0.0f; break;

@@ -1823,3 +1823,88 @@ void o_ior_f0(int dir, int64_t n, const float *x, float *y)
 
 void o_erf(int64_t n, const float *x, float *y) { for (int64_t k = 0; k < n; ++k) y[k] = erf_(x[k]); }
 void o_erfinv(int64_t n, const float *x, float *y) { for (int64_t k = 0; k < n; ++k) y[k] = erfinv_(x[k]); }
+
+/* ------------------------------------------------------------------ glibc 2.35 float libm, restated
+ * The reference's erfinv / Beckmann quantile code calls logf, expf and powf (hdr:691-721, 1897-1952): its
+ * results are those of the host libm.  o_libm_f32 calls the host libm itself (what the reference build
+ * does); o_glibc_f32 is the restatement of glibc's algorithms (sysdeps/ieee754/flt-32/e_logf.c, e_expf.c,
+ * e_powf.c = ARM optimized-routines) that the HIP kernels implement, main paths only (positive normal
+ * arguments, finite results); `fma` selects the contraction of the x86-64 FMA ifunc variants.
+ * fn: 0 logf(x), 1 expf(x), 2 powf(x, y). */
+#include "glibc_flt32_tables.h"
+static inline uint32_t asu32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float asf32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint64_t asu64(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline double asf64(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+static inline double mad(int use_fma, double a, double b, double c) { return use_fma ? fma(a, b, c) : a * b + c; }
+
+static float glibc_logf(float x, int f)
+{
+	const double *T = DJB_GLIBC_LOGF, Ln2 = T[32], *A = T + 33;
+	uint32_t ix = asu32(x);
+	if (ix == 0x3f800000) return 0.0f;
+	if (ix - 0x00800000 >= 0x7f800000 - 0x00800000) return logf(x);              /* special cases: host libm */
+	uint32_t tmp = ix - 0x3f330000;
+	int i = (tmp >> 19) % 16, k = (int32_t)tmp >> 23;
+	uint32_t iz = ix - (tmp & 0x1ffu << 23);
+	double invc = T[2 * i], logc = T[2 * i + 1], z = (double)asf32(iz);
+	double r = mad(f, z, invc, -1.0);
+	double y0 = mad(f, (double)k, Ln2, logc);
+	double r2 = r * r;
+	double y = mad(f, A[1], r, A[2]);
+	y = mad(f, A[0], r2, y);
+	y = mad(f, y, r2, y0 + r);
+	return (float)y;
+}
+static float glibc_expf(float x, int f)
+{
+	const double *E = DJB_GLIBC_EXP2F, InvLn2N = E[5], SHIFT = E[4], *C = E + 6;
+	uint32_t abstop = (asu32(x) >> 20) & 0x7ff;
+	if (abstop >= (asu32(88.0f) >> 20)) return expf(x);                           /* |x| >= 88 or nan: host libm */
+	double xd = (double)x, z = InvLn2N * xd;
+	double kd = z + SHIFT; uint64_t ki = asu64(kd); kd -= SHIFT;
+	double r = f >= 2 ? fma(InvLn2N, xd, -kd) : z - kd;      /* f >= 2: the product contracted into the subtraction */
+	uint64_t t = DJB_GLIBC_EXP2F_TAB[ki % 32]; t += ki << (52 - 5);
+	double s = asf64(t);
+	z = mad(f, C[0], r, C[1]);
+	double r2 = r * r;
+	double y = mad(f, C[2], r, 1.0);
+	y = mad(f, z, r2, y);
+	y = y * s;
+	return (float)y;
+}
+static float glibc_powf(float x, float y, int f)
+{
+	const double *T = DJB_GLIBC_POWF_LOG2, *A = T + 32, *E = DJB_GLIBC_EXP2F, SHIFT = E[0], *C = E + 1;
+	uint32_t ix = asu32(x), iy = asu32(y);
+	if (ix - 0x00800000 >= 0x7f800000 - 0x00800000 || 2 * iy - 1 >= 2u * 0x7f800000 - 1) return powf(x, y);   /* specials */
+	uint32_t tmp = ix - 0x3f330000;
+	int i = (tmp >> 19) % 16;
+	uint32_t top = tmp & 0xff800000, iz = ix - top;
+	int k = (int32_t)top >> 23;
+	double invc = T[2 * i], logc = T[2 * i + 1], z = (double)asf32(iz);
+	double r = mad(f, z, invc, -1.0), y0 = logc + (double)k;
+	double r2 = r * r;
+	double p0 = mad(f, A[0], r, A[1]), p = mad(f, A[2], r, A[3]), r4 = r2 * r2;
+	double q = mad(f, A[4], r, y0);
+	q = mad(f, p, r2, q);
+	double logx = mad(f, p0, r4, q);
+	double ylogx = (double)y * logx;
+	if ((asu64(ylogx) >> 47 & 0xffff) >= asu64(126.0) >> 47) return powf(x, y);   /* |y log2 x| >= 126: host libm */
+	double kd = ylogx + SHIFT; uint64_t ki = asu64(kd); kd -= SHIFT;
+	double rr = f >= 2 ? fma((double)y, logx, -kd) : ylogx - kd;
+	uint64_t t = DJB_GLIBC_EXP2F_TAB[ki % 32]; t += ki << (52 - 5);
+	double s = asf64(t);
+	double zz = mad(f, C[0], rr, C[1]), rr2 = rr * rr, yy = mad(f, C[2], rr, 1.0);
+	yy = mad(f, zz, rr2, yy);
+	return (float)(yy * s);
+}
+void o_libm_f32(int fn, int64_t n, const float *x, const float *y, float *out)
+{
+	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? logf(x[k]) : fn == 1 ? expf(x[k]) : powf(x[k], y[k]);
+}
+void o_glibc_f32(int fn, int use_fma, int64_t n, const float *x, const float *y, float *out)
+{
+	for (int64_t k = 0; k < n; ++k)
+		out[k] = fn == 0 ? glibc_logf(x[k], use_fma) : fn == 1 ? glibc_expf(x[k], use_fma) : glibc_powf(x[k], y[k], use_fma);
+}

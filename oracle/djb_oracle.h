@@ -94,6 +94,10 @@ void o_microfacet_query(const o_brdf *b, int which, int64_t n, const float *a, c
 void o_radial_query(const o_brdf *b, int which, int64_t n, const float *a, const float *bb,
                     const float *c, float *out);
 void o_fresnel_eval(const o_brdf *b, int64_t n, const float *c, float *out);
+/* host libm float functions (fn 0 logf, 1 expf, 2 powf) and the restatement of glibc 2.35's algorithms
+ * for them that the HIP kernels implement (use_fma: contraction of the x86-64 FMA ifunc variants) */
+void o_libm_f32(int fn, int64_t n, const float *x, const float *y, float *out);
+void o_glibc_f32(int fn, int use_fma, int64_t n, const float *x, const float *y, float *out);
 /* vec3::vec3(theta, phi), dj_brdf.h:589-595 */
 void o_vec3_angles(int64_t n, const float *theta, const float *phi, float *out);
 /* sgd / abc member queries, dj_brdf.h:505-509, 530-533: which 0 ndf(h), 1 gaf(h, i, o), 2 g1(k) [sgd], 3 fresnel(a.x) */

@@ -310,6 +310,18 @@ class CheckerLib:
         self._fn("ior_f0")(C.c_int(direction), C.c_int64(x.size), _ptr(x), _ptr(y))
         return y
 
+    def libm_f32(self, fn, x, y=None):
+        """host libm logf (0) / expf (1) / powf (2): what the reference calls"""
+        x = _f32(x); y = _f32(x if y is None else y); out = np.empty_like(x)
+        self._fn("libm_f32")(C.c_int(fn), C.c_int64(x.size), _ptr(x), _ptr(y), _ptr(out))
+        return out
+
+    def glibc_f32(self, fn, x, y=None, use_fma=2):
+        """the restatement of glibc 2.35's algorithm for the same three functions (the arithmetic the HIP kernels run)"""
+        x = _f32(x); y = _f32(x if y is None else y); out = np.empty_like(x)
+        self._fn("glibc_f32")(C.c_int(fn), C.c_int(use_fma), C.c_int64(x.size), _ptr(x), _ptr(y), _ptr(out))
+        return out
+
     def erf(self, x):
         x = _f32(x); y = np.empty_like(x)
         self._fn("erf")(C.c_int64(x.size), _ptr(x), _ptr(y))

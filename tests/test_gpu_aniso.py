@@ -34,10 +34,9 @@ def test_anisotropic_fit_golden(gpu_ctx, name):
     assert_close(f"{name}/fresnel", t.get_fresnel().get_points(), g[f"{name}_fresnel"], 2e-5)
     fb = np.array(djb.tabular_anisotropic.fit_beckmann_parameters(t).get_pdfparams(), np.float32)
     fg = np.array(djb.tabular_anisotropic.fit_ggx_parameters(t).get_pdfparams(), np.float32)
-    # alphas to 2e-5; rho / mux / muy are ~1e-7 residues of cancelling sums: absolute tolerance
-    for got, want in ((fb, g[f"{name}_fit_beckmann"]), (fg, g[f"{name}_fit_ggx"])):
-        assert np.allclose(got[:2], want[:2], rtol=2e-5), (name, got, want)
-        assert np.allclose(got[2:], want[2:], rtol=1e-3, atol=2e-6), (name, got, want)
+    # rho / mux / muy are ~1e-7 residues of cancelling sums: only the reference's summation order gives them
+    assert_close(f"{name}/fit_beckmann", fb, g[f"{name}_fit_beckmann"])
+    assert_close(f"{name}/fit_ggx", fg, g[f"{name}_fit_ggx"])
     u1, u2 = g["u1"], g["u2"]
     phi, th = (u1 * np.float32(6.2)).astype(np.float32), (u2 * np.float32(1.5)).astype(np.float32)
     for q, args in (("pdf1", (phi,)), ("cdf1", (phi,)), ("qf1", (u1,)), ("pdf2", (th, phi)),
@@ -47,8 +46,7 @@ def test_anisotropic_fit_golden(gpu_ctx, name):
         assert_close(f"{name}/{op}", getattr(t, op)(g["i"], g["o"]), g[f"{name}_{op}"], 1e-4)
     assert_close(f"{name}/eval elliptic", t.eval(g["i"], g["o"], djb.microfacet.params.elliptic(0.2, 0.5, 0.7)),
                  g[f"{name}_eval_ell"], 1e-4)
-    s = t.sample(u1, u2, g["o"])
-    assert np.quantile(np.abs(s - g[f"{name}_sample"]).max(axis=1), 0.995) < 2e-4
+    assert_close(f"{name}/sample", t.sample(u1, u2, g["o"]), g[f"{name}_sample"])
 
 
 def test_anisotropic_full_resolution_vs_oracle(gpu_ctx, oracle):
@@ -61,7 +59,7 @@ def test_anisotropic_full_resolution_vs_oracle(gpu_ctx, oracle):
     assert_close("p22", t.get_p22v()[0], want["p22"], 2e-5)
     assert_close("sigma", t.get_sigmav()[0], want["sigma"], 2e-5)
     fb = np.array(djb.tabular_anisotropic.fit_beckmann_parameters(t).get_pdfparams(), np.float32)
-    assert np.allclose(fb[:2], want["fit_beckmann"][:2], rtol=2e-5)
+    assert_close("fit_beckmann", fb, np.asarray(want["fit_beckmann"], np.float32))
 
 
 def test_anisotropic_queries_reject_other_kinds(gpu_ctx):

@@ -40,11 +40,14 @@ def bits(a):
 
 
 def close(tag, got, want, rtol=0.0):
-    if rtol == 0.0:
-        nan_ok = np.isnan(got) & np.isnan(want)
-        assert (nan_ok | (bits(got) == bits(want))).all(), f"{tag}: not bit-identical"
-    else:
-        np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-7, err_msg=tag)
+    """rtol: the contract at that call site (north_star 1e-5 and up); asserted: identical bits, which is
+    what the GPU path delivers everywhere -- the figure only classifies a failure."""
+    got, want = np.atleast_1d(np.asarray(got, np.float32)), np.atleast_1d(np.asarray(want, np.float32))
+    assert got.shape == want.shape, tag
+    same = (np.isnan(got) & np.isnan(want)) | (bits(got) == bits(want))
+    if not same.all():
+        rel = np.nanmax(np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-30))
+        raise AssertionError(f"{tag}: {np.mean(~same):.2e} of values not bit-identical; max rel {rel:.2e} (contract {rtol or 1e-5})")
 
 
 @pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
@@ -57,11 +60,10 @@ def test_microfacet_classes(facade, oracle, inputs, ndf):
                 for op in ("eval", "evalp", "pdf"):
                     close(f"{ndf}/{fres[0]}/{p}/{op}", facade.eval(f, i, o, p, op), oracle.eval(b, i, o, p, op))
             p = PARAM_CASES[2]
-            tol = 2e-4 if ndf == "beckmann" else 1e-5
-            close("sample", facade.sample(f, u1, u2, o, p), oracle.sample(b, u1, u2, o, p), tol)
+            close("sample", facade.sample(f, u1, u2, o, p), oracle.sample(b, u1, u2, o, p))
             fw, fi, fp = facade.evalp_is(f, u1, u2, o, p)
             ow, oi, op_ = oracle.evalp_is(b, u1, u2, o, p)
-            close("evalp_is i", fi, oi, tol); close("evalp_is pdf", fp, op_, 50 * tol)
+            close("evalp_is i", fi, oi); close("evalp_is pdf", fp, op_); close("evalp_is weight", fw, ow)
             c = np.clip(o[:, 2], 0, 1)
             close("fresnel()", facade.fresnel_eval(f, c), oracle.fresnel_eval(b, c))
             facade.destroy(f)
@@ -134,7 +136,7 @@ def test_tabular_and_lrep(facade, oracle, inputs):
     ft, ot = facade.tabular(facade.microfacet("ggx"), 64, True), oracle.tabular(oracle.microfacet("ggx"), 64, True)
     for k, v in oracle.tabular_tables(ot).items():
         got = facade.tabular_tables(ft)[k]
-        np.testing.assert_allclose(np.atleast_1d(got), np.atleast_1d(v), rtol=2e-5, atol=1e-7, err_msg=k)
+        close(f"tabular table {k}", got, v)
     close("tabular eval", facade.eval(ft, i, o), oracle.eval(ot, i, o), 1e-4)
     from golden_cases import lrep_cases
     for op, a, b, x, y in lrep_cases():
@@ -157,7 +159,7 @@ def test_anisotropic_and_lean(facade, oracle, inputs):
     ot = oracle.tabular_anisotropic(oracle.microfacet("ggx"), 12, 16, True)
     want = oracle.aniso_tables(ot)
     for k, v in facade.aniso_tables(ft).items():
-        np.testing.assert_allclose(v, want[k], rtol=5e-5, atol=1e-6, err_msg=k)
+        close(f"aniso table {k}", v, want[k])
     phi = (u1 * 2 * np.pi).astype(np.float32); th = (u2 * 1.5).astype(np.float32)
     for which, args in (("pdf1", (phi,)), ("cdf1", (phi,)), ("qf1", (u1,)), ("pdf2", (th, phi)), ("cdf2", (th, phi)), ("qf2", (u2, phi))):
         close(f"aniso {which}", facade.aniso_query(ft, which, *args), oracle.aniso_query(ot, which, *args), 2e-4)

@@ -22,13 +22,15 @@ def test_microfacet_golden(gpu_ctx, k):
     i, o, u1, u2 = g["i"], g["o"], g["u1"], g["u2"]
     for op in ("eval", "evalp", "pdf"):
         assert_close(f"case {k} {op}", getattr(b, op)(i, o, up), g[f"c{k}_{op}"])
-    tol = 2e-4 if ndf == "beckmann" else 1e-5      # Newton stop criterion 1e-5 (dj_brdf.h:1938)
-    s = b.sample(u1, u2, o, up)
-    assert np.quantile(np.abs(s - g[f"c{k}_sample"]).max(axis=1), 0.995) < tol
+    def identical(tag, a, b):
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), f"case {k} {tag}: {np.mean(~same):.2e} of values differ from the reference's"
+    # sampling is bit-identical to the reference as well: the kernels run glibc's float logf/expf/powf
+    identical("sample", b.sample(u1, u2, o, up), g[f"c{k}_sample"])
     w, si, pdf = b.evalp_is(u1, u2, o, up)
-    assert np.quantile(np.abs(si - g[f"c{k}_is_i"]).max(axis=1), 0.995) < tol
-    ok = np.isfinite(g[f"c{k}_is_w"]).all(axis=1) & (g[f"c{k}_is_pdf"] > 0)
-    assert np.quantile(np.abs(w[ok] - g[f"c{k}_is_w"][ok]).max(axis=1), 0.995) < 50 * tol
+    identical("evalp_is i", si, g[f"c{k}_is_i"])
+    identical("evalp_is weight", w, g[f"c{k}_is_w"])
+    identical("evalp_is pdf", pdf, g[f"c{k}_is_pdf"])
 
 
 def test_half_diff_golden(gpu_ctx):
@@ -61,11 +63,10 @@ def test_fit_golden(gpu_ctx, name):
         assert_close(f"{name}/{k}", v, g[f"{name}_{k}"], rtol=2e-5)
     ab = djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0]
     ag = djb.tabular.fit_ggx_parameters(t).get_ellipse()[0]
-    assert "%.3f %.3f" % (ab, ag) == "%.3f %.3f" % (g[f"{name}_alpha_beckmann"][0], g[f"{name}_alpha_ggx"][0])
+    assert (np.float32(ab), np.float32(ag)) == (g[f"{name}_alpha_beckmann"][0], g[f"{name}_alpha_ggx"][0])
     assert_close(f"{name}/eval", t.eval(g["i"], g["o"]), g[f"{name}_eval"], rtol=1e-4)
     assert_close(f"{name}/pdf", t.pdf(g["i"], g["o"]), g[f"{name}_pdf"], rtol=1e-4)
-    s_ = t.sample(g["u1"], g["u2"], g["o"])
-    assert np.quantile(np.abs(s_ - g[f"{name}_sample"]).max(axis=1), 0.995) < 1e-4
+    assert_close(f"{name}/sample", t.sample(g["u1"], g["u2"], g["o"]), g[f"{name}_sample"])
 
 
 def test_params_txt_bytes(gpu_ctx, tmp_path):

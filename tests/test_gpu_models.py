@@ -88,10 +88,10 @@ def test_plugin_load_time_fit(gpu_ctx, oracle, kind):
         assert_close(f"{kind}/fit/{k}", v, g[f"{kind}_fit_{k}"], rtol=2e-5)
     ab = djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0]
     ag = djb.tabular.fit_ggx_parameters(t).get_ellipse()[0]
-    assert "%.3f %.3f" % (ab, ag) == "%.3f %.3f" % (g[f"{kind}_fit_alpha_beckmann"][0], g[f"{kind}_fit_alpha_ggx"][0])
+    assert (np.float32(ab), np.float32(ag)) == (g[f"{kind}_fit_alpha_beckmann"][0], g[f"{kind}_fit_alpha_ggx"][0])
     n = 4096
     o = synth.directions_aos(n, synth.SEED_O); u1 = synth.uniforms(n, 1); u2 = synth.uniforms(n, 2)
     ot = oracle.tabular(getattr(oracle, kind)(MODEL_MATERIALS[0]), 90, True)
     s = t.sample(u1, u2, o)
-    assert np.quantile(np.abs(s - oracle.sample(ot, u1, u2, o)).max(axis=1), 0.995) < 1e-4
+    assert_close("sample", s, oracle.sample(ot, u1, u2, o))
     assert_close("pdf", t.pdf(s, o), oracle.eval(ot, s, o, None, "pdf"), 1e-4)

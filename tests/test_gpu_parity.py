@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): float BRDF values within 1e-5 relative of the re
 path; MERL bin indices bit-exact.  The oracle is bit-exact with the real reference
 (tests/test_oracle_vs_ref.py, tests/test_oracle_golden.py), so oracle parity == reference parity.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -21,14 +23,19 @@ def rel_err(a, b):
 
 
 def assert_close(name, got, want, rtol=RTOL):
+    """The contract is `rtol` relative (north_star: 1e-5; looser figures at call sites date from before the
+    kernels matched the reference's arithmetic operation for operation).  Measured on MI355X: every comparison
+    in this suite is bit-identical, so THAT is what is asserted; `rtol` only classifies the failure message."""
     got = np.asarray(got); want = np.asarray(want)
     assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
-    assert not np.isnan(got).any() or np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN mismatch"
-    m = ~(np.isnan(got) & np.isnan(want))
-    e = rel_err(got[m], want[m])
-    exact = np.mean(got.view(np.uint32) == want.view(np.uint32))
-    assert e.size == 0 or e.max() <= rtol, f"{name}: max rel err {e.max():.3e} > {rtol} (bit-exact {exact:.6f})"
-    return exact
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN mismatch"
+    m = ~np.isnan(want)
+    same = got.view(np.uint32)[m] == want.view(np.uint32)[m]
+    if not same.all():
+        e = rel_err(got[m], want[m])
+        raise AssertionError(f"{name}: {np.mean(~same):.3e} of values not bit-identical to the reference's; max rel err "
+                             f"{e.max():.3e} ({'within' if e.max() <= rtol else 'OUTSIDE'} the {rtol} contract)")
+    return 1.0
 
 
 N = 1 << 17
@@ -76,9 +83,8 @@ def test_microfacet_eval_pdf(gpu_ctx, oracle, dirs, ndf, fres):
                 got = getattr(g, op)(i, o, up)
                 ex = assert_close(f"{ndf}/{fres[0]}/{shadow}/{p}/{op}", got, oracle.eval(ob, i, o, p, op))
                 # stronger than the 1e-5 contract: the kernels keep the reference's float/double
-                # evaluation order, so outputs are bit-identical (measured: 100 % on 2^20 pairs);
-                # allow 1e-5 of the outputs to differ in the last ulp (ocml vs glibc exp/pow)
-                assert ex >= 0.99999, f"{ndf}/{fres[0]}/{p}/{op}: only {ex:.6f} of outputs bit-identical"
+                # evaluation order, so outputs are bit-identical
+                assert ex == 1.0
             fr, pdf = g.eval_pdf(i, o, up)
             assert_close("fused eval", fr, oracle.eval(ob, i, o, p, "eval"))
             assert_close("fused pdf", pdf, oracle.eval(ob, i, o, p, "pdf"))
@@ -91,17 +97,20 @@ def test_microfacet_sample(gpu_ctx, oracle, dirs, ndf):
     ob = oracle.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
     for p in PARAMS:
         up = mk_params(p)
-        # the Newton inversion stops at |value| < 1e-5 (dj_brdf.h:1938): float transcendentals that
-        # differ in the last ulp may stop one step apart, so sampled directions agree to ~1e-4
-        tol = 2e-4 if ndf == "beckmann" else 1e-5
+        # the Newton inversion stops at |value| < 1e-5 (dj_brdf.h:1938), so one differing ulp in a float
+        # transcendental can move a sample by ~1e-4.  The kernels therefore run glibc's own logf / expf /
+        # powf algorithms (djb_device.hpp glibc_*; pinned to the host libm by
+        # test_oracle_golden.py::test_glibc_float_libm_restatement): every sample is bit-identical.
         got = g.sample(u1, u2, o, up)
         want = oracle.sample(ob, u1, u2, o, p)
-        err = np.abs(got.astype(np.float64) - want).max(axis=1)
-        assert np.quantile(err, 0.999) < tol, f"{ndf} sample {p}: q99.9 abs err {np.quantile(err, 0.999):.3e}"
-        assert err.max() < 50 * tol
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), \
+            f"{ndf} sample {p}: {np.mean(got.view(np.uint32) != want.view(np.uint32)):.2e} of components differ"
         w, gi, pdf = g.evalp_is(u1, u2, o, up)
         ww, wi, wpdf = oracle.evalp_is(ob, u1, u2, o, p)
-        assert np.quantile(np.abs(gi - wi).max(axis=1), 0.999) < tol
+        assert np.array_equal(gi.view(np.uint32), wi.view(np.uint32)), f"{ndf} evalp_is direction {p}"
+        for name, a, b in (("weight", w, ww), ("pdf", pdf, wpdf)):
+            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), f"{ndf} evalp_is {name} {p}: {np.mean(~same):.2e} differ"
 
 
 def test_io_hd_roundtrip(gpu_ctx, oracle, dirs):
@@ -276,8 +285,7 @@ def test_microfacet_and_radial_queries(gpu_ctx, oracle, dirs, ndf):
     q2 = g.qf2_radial(u, c, s)
     want = oracle.radial_query(og, "qf2_radial", u, c, s)
     ok = np.isfinite(want) & (s > 1e-3) & (c > 1e-3)
-    tol = 2e-3 if ndf == "beckmann" else 2e-5
-    assert np.quantile(np.abs(q2[ok] - want[ok]) / np.maximum(1, np.abs(want[ok])), 0.999) < tol
+    assert_close("qf2_radial", q2[ok], want[ok])
 
 
 def test_tabular_queries_and_not_implemented(gpu_ctx, oracle):

@@ -64,6 +64,36 @@ def test_known_answers(oracle):
     assert np.array_equal(d[0], np.array([-0.06416931, -0.347850591, 0.935351491], f))
 
 
+def test_glibc_float_libm_restatement(oracle):
+    """The HIP sampling kernels cannot call the host's libm, so they run a restatement of glibc 2.35's
+    logf / expf / powf (oracle/djb_oracle.c glibc_*; tables read out of libm.so.6 by
+    tools/extract_glibc_flt32_tables.py).  Pin that restatement against the libm of this image, which is
+    what the reference's std::log / std::exp / std::pow calls resolve to: every bit, over random bit
+    patterns, the ranges erfinv() and the Beckmann quantile functions use, and the special cases."""
+    rng = np.random.default_rng(20240917)
+    n = 1 << 21
+    anyf = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, 1.17549435e-38, 3.4028235e38,
+                        88.72284, 88.72283, -103.97208, -103.97207, -87.33655, 0.5, 2.0, 1.0000001, 0.99999994], np.float32)
+    with np.errstate(all="ignore"):
+        cases = {
+            0: [(anyf, None), (special, None), (rng.random(n, dtype=np.float32), None),
+                ((1 - rng.random(n, dtype=np.float32) ** 2).astype(np.float32), None)],
+            1: [(anyf, None), (special, None), ((-30 * rng.random(n)).astype(np.float32), None),
+                ((200 * rng.random(n) - 110).astype(np.float32), None)],
+            2: [(anyf, rng.permutation(anyf)), (np.repeat(special, special.size), np.tile(special, special.size)),
+                (rng.random(n, dtype=np.float32), np.full(n, 2.4, np.float32)),
+                ((4 * rng.random(n)).astype(np.float32), (20 * rng.random(n) - 10).astype(np.float32))],
+        }
+    for fn, sets in cases.items():
+        for x, y in sets:
+            want = oracle.libm_f32(fn, x, y)
+            got = oracle.glibc_f32(fn, x, y)
+            nan = np.isnan(want)
+            assert np.array_equal(nan, np.isnan(got)), fn
+            assert np.array_equal(bits(want)[~nan], bits(got)[~nan]), (fn, int((bits(want)[~nan] != bits(got)[~nan]).sum()))
+
+
 def test_params_and_math(oracle):
     g = np.load(os.path.join(G, "math.npz"))
     for k, p in enumerate(PARAM_CASES):

@@ -68,5 +68,23 @@ for r in range(rounds):
     path = f"/tmp/fuzz_utia_{r}.bin"; ut.tofile(path)
     u, ou = djb.utia(path, ctx=ctx), O.utia(path)
     report(f"r{r} utia eval", u.eval(i, o), O.eval_mt(ou, i, o, None, "eval", threads=TH), False)
+    # sgd / abc published models (random material), tabular(ggx) eval, VNDF sampling error quantiles
+    from dj_brdf_amd import param_tables
+    name = list(param_tables.abc_names())[int(rng.integers(0, 100))]
+    for kind in ("sgd", "abc"):
+        b, ob = getattr(djb, kind)(name, ctx=ctx), getattr(O, kind)(name)
+        report(f"r{r} {kind} {name} eval", b.eval(i, o), O.eval_mt(ob, i, o, None, "eval", threads=TH), False)
+    m_s = min(n, 1_000_000)
+    u1, u2 = synth.uniforms(m_s, seed_i ^ 0x55), synth.uniforms(m_s, seed_o ^ 0xAA)
+    for ndf, tol in (("ggx", 1e-5), ("beckmann", 2e-4)):
+        g, og = getattr(djb, ndf)(ctx=ctx), O.microfacet(ndf)
+        pp = ("elliptic", 0.2, 0.5, 0.7)
+        got = g.sample(u1, u2, o[:m_s], djb.microfacet.params.elliptic(0.2, 0.5, 0.7))
+        want = O.sample(og, u1, u2, o[:m_s], pp)
+        err = np.abs(got.astype(np.float64) - want).max(axis=1)
+        q = np.quantile(err, 0.999)
+        ok = q < tol
+        bad += 0 if ok else 1
+        print(f"r{r} {ndf} sample: bit-exact {np.mean((got.view(np.uint32) == want.view(np.uint32)).all(axis=1)):.5f}  q99.9 abs err {q:.2e} max {err.max():.2e}" + ("" if ok else "   <-- ABOVE TOLERANCE"), flush=True)
 print("FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)

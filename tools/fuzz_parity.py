@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential run (on the GPU box): HIP path vs the CPU oracle on fresh seeds, random
 microfacet parameters / Fresnel terms, and hashed MERL / UTIA tables.  Reports, per case, the
-fraction of bit-identical outputs and the largest relative difference; exits non-zero if eval/pdf
-of the analytic lobes or MERL is not 100 % bit-exact.   PYTHONPATH=. python tools/fuzz_parity.py [rounds] [n]"""
+fraction of bit-identical outputs and the largest relative difference; exits non-zero if anything --
+eval / pdf / sample / evalp_is of the analytic lobes, MERL, UTIA, sgd, abc, the fitted tables and their
+operators -- is not 100 % bit-exact.   PYTHONPATH=. python tools/fuzz_parity.py [rounds] [n]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -67,24 +68,35 @@ for r in range(rounds):
     ut = rng.uniform(-5.0, 130.0, size=3 * 288 * 288)
     path = f"/tmp/fuzz_utia_{r}.bin"; ut.tofile(path)
     u, ou = djb.utia(path, ctx=ctx), O.utia(path)
-    report(f"r{r} utia eval", u.eval(i, o), O.eval_mt(ou, i, o, None, "eval", threads=TH), False)
+    report(f"r{r} utia eval", u.eval(i, o), O.eval_mt(ou, i, o, None, "eval", threads=TH), True)
     # sgd / abc published models (random material), tabular(ggx) eval, VNDF sampling error quantiles
     from dj_brdf_amd import param_tables
     name = list(param_tables.abc_names())[int(rng.integers(0, 100))]
     for kind in ("sgd", "abc"):
         b, ob = getattr(djb, kind)(name, ctx=ctx), getattr(O, kind)(name)
-        report(f"r{r} {kind} {name} eval", b.eval(i, o), O.eval_mt(ob, i, o, None, "eval", threads=TH), False)
+        report(f"r{r} {kind} {name} eval", b.eval(i, o), O.eval_mt(ob, i, o, None, "eval", threads=TH), True)
+    # VNDF sampling with random lobes: sampled directions, weights and pdfs must be identical too
     m_s = min(n, 1_000_000)
     u1, u2 = synth.uniforms(m_s, seed_i ^ 0x55), synth.uniforms(m_s, seed_o ^ 0xAA)
-    for ndf, tol in (("ggx", 1e-5), ("beckmann", 2e-4)):
+    for ndf in ("ggx", "beckmann"):
         g, og = getattr(djb, ndf)(ctx=ctx), O.microfacet(ndf)
-        pp = ("elliptic", 0.2, 0.5, 0.7)
-        got = g.sample(u1, u2, o[:m_s], djb.microfacet.params.elliptic(0.2, 0.5, 0.7))
-        want = O.sample(og, u1, u2, o[:m_s], pp)
-        err = np.abs(got.astype(np.float64) - want).max(axis=1)
-        q = np.quantile(err, 0.999)
-        ok = q < tol
-        bad += 0 if ok else 1
-        print(f"r{r} {ndf} sample: bit-exact {np.mean((got.view(np.uint32) == want.view(np.uint32)).all(axis=1)):.5f}  q99.9 abs err {q:.2e} max {err.max():.2e}" + ("" if ok else "   <-- ABOVE TOLERANCE"), flush=True)
+        a1, a2, ph = (float(np.float32(x)) for x in (rng.uniform(0.02, 1.5), rng.uniform(0.02, 1.5), rng.uniform(-3.1, 3.1)))
+        pp, up = ("elliptic", a1, a2, ph), djb.microfacet.params.elliptic(a1, a2, ph)
+        report(f"r{r} {ndf} sample {pp}", g.sample(u1, u2, o[:m_s], up), O.sample(og, u1, u2, o[:m_s], pp), True)
+        w, si, pdf = g.evalp_is(u1, u2, o[:m_s], up); ww, wi, wpdf = O.evalp_is(og, u1, u2, o[:m_s], pp)
+        report(f"r{r} {ndf} evalp_is weight", w, ww, True); report(f"r{r} {ndf} evalp_is pdf", pdf, wpdf, True)
+    # the fitter on a random synthetic material at a random resolution: tables, both fits, operators of the result
+    alpha = float(rng.uniform(0.03, 0.7)); kd = tuple(rng.uniform(0.0, 0.6, 3)); ks = tuple(rng.uniform(0.02, 1.0, 3))
+    tabm = synth.merl_table(alpha, kd, ks); res = int(rng.integers(8, 91)); shadow = bool(rng.integers(0, 2))
+    t = djb.tabular(djb.merl.from_table(tabm, ctx=ctx), res, shadow, ctx=ctx)
+    ot = O.tabular(O.merl_from_table(tabm), res, shadow)
+    want = O.tabular_tables(ot)
+    got = {"p22": t.get_p22v(), "sigma": t.get_sigmav(), "cdf": t.get_cdfv(), "qf": t.get_qfv(), "fresnel": t.get_fresnel().get_points(),
+           "alpha_beckmann": [djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0]], "alpha_ggx": [djb.tabular.fit_ggx_parameters(t).get_ellipse()[0]]}
+    for k, v in got.items():
+        report(f"r{r} fit(merl a={alpha:.3f}, res {res}, shadow {int(shadow)}) {k}", np.asarray(v, np.float32).reshape(-1), np.asarray(want[k], np.float32).reshape(-1), True)
+    k_s = min(n, 200_000)
+    report(f"r{r} fitted tabular eval", t.eval(i[:k_s], o[:k_s]), O.eval_mt(ot, i[:k_s], o[:k_s], None, "eval", threads=TH), True)
+    report(f"r{r} fitted tabular sample", t.sample(u1[:k_s], u2[:k_s], o[:k_s]), O.sample(ot, u1[:k_s], u2[:k_s], o[:k_s]), True)
 print("FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)

@@ -718,7 +718,7 @@ DJB_DEV v3 mf_sample(const Brdf &b, const Params &p, float u1, float u2, v3 o, c
 	return mk(0, 0, 1);
 }
 
-template <int KIND>
+template <int KIND, int FRK = -1>
 DJB_DEV v3 mf_evalp_is(const Brdf &b, const Params &p, float u1, float u2, v3 o, v3 &i_out,
                        float &pdf_out, const GlibcTabs &gt)                                  // :1734
 {
@@ -735,7 +735,7 @@ DJB_DEV v3 mf_evalp_is(const Brdf &b, const Params &p, float u1, float u2, v3 o,
 		float cd = sat_(oh);
 		i_out = i_;
 		float Dn = mf_ndf<KIND>(b, h, p);
-		v3 Fr = fresnel_eval(b.fr, cd);
+		v3 Fr = fresnel_eval_k<FRK>(b.fr, cd);
 		if (DJB_NMAP(KIND)) {
 			float pdf_ = fdiv4(h.z * Dn, cd);
 			pdf_out = pdf_;

@@ -149,7 +149,8 @@ hipError_t launch_eval_pp_kind(hipStream_t s, const Brdf &b, long long n, const 
 }
 
 // ------------------------------------------------------------------ sample / evalp_is
-template <int KIND, bool IS, bool RNG>
+// FRK: Fresnel kind fixed at compile time for evalp_is of the analytic lobes (as in k_eval)
+template <int KIND, bool IS, bool RNG, int FRK = -1>
 __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n, const float *u1a,
                                                   const float *u2a, uint32_t seed1, uint32_t seed2,
                                                   unsigned long long start, View vo, View vi_out,
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 				store3(vi_out, k, mf_sample<KIND>(b, p, u1, u2, o, gt));
 			} else {
 				v3 i_out = mk(0, 0, 0); float pdf;
-				v3 w = mf_evalp_is<KIND>(b, p, u1, u2, o, i_out, pdf, gt);
+				v3 w = mf_evalp_is<KIND, FRK>(b, p, u1, u2, o, i_out, pdf, gt);
 				store3(vw_out, k, w); store3(vi_out, k, i_out); out_pdf[k] = pdf;
 			}
 		} else {
@@ -199,8 +200,18 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
 	bool is = out_w != nullptr, rng = u1 == nullptr;
 	if (!is && !rng) hipLaunchKernelGGL((k_sample<KIND, false, false>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
 	else if (!is && rng) hipLaunchKernelGGL((k_sample<KIND, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
-	else if (is && !rng) hipLaunchKernelGGL((k_sample<KIND, true, false>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
-	else hipLaunchKernelGGL((k_sample<KIND, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
+	else {
+		// evalp_is evaluates the Fresnel term of the sampled pair: specialise the two cheap kinds
+		constexpr bool analytic = KIND == KIND_BECKMANN || KIND == KIND_GGX;
+		const int frk = analytic && (b.fr.kind == FR_IDEAL || b.fr.kind == FR_SCHLICK) ? b.fr.kind : -1;
+#define DJB_LAUNCH_IS(RNG_, FRK_) hipLaunchKernelGGL((k_sample<KIND, true, RNG_, FRK_>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf)
+		if constexpr (analytic) {
+			if (frk == FR_IDEAL) { if (rng) DJB_LAUNCH_IS(true, FR_IDEAL); else DJB_LAUNCH_IS(false, FR_IDEAL); return hipGetLastError(); }
+			if (frk == FR_SCHLICK) { if (rng) DJB_LAUNCH_IS(true, FR_SCHLICK); else DJB_LAUNCH_IS(false, FR_SCHLICK); return hipGetLastError(); }
+		}
+		if (rng) DJB_LAUNCH_IS(true, -1); else DJB_LAUNCH_IS(false, -1);
+#undef DJB_LAUNCH_IS
+	}
 	return hipGetLastError();
 }
 

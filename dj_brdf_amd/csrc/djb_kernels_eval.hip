@@ -108,7 +108,7 @@ hipError_t launch_eval_kind(hipStream_t s, const Brdf &b, const Params &p, long 
 // (mitsuba/dj_beckmannconductor.cpp:291-319).  MODE 0: pdfparams records (ax, ay, rho, tx, ty) are
 // read per pair.  MODE 1: per-pair LEAN moments (E1..E5) are combined on the fly with the scaled
 // base lobe: params = lrep_to_params(base_lrep + lean_k), and optionally written back.
-template <int KIND, int WANT, int MODE>
+template <int KIND, int WANT, int MODE, int FRK = -1>
 __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi, View vo, const float *rec,
                                                    Lrep base, View vout, float *out_pdf, float *out_pp)
 {
@@ -125,10 +125,27 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi,
 		}
 		Params p = params_from_pdfparams(ax, ay, rho, tx, ty);
 		v3 fr = mk(0, 0, 0); float pdf = 0.0f;
-		mf_eval_pdf<KIND, WANT>(b, p, i, o, fr, pdf);
+		mf_eval_pdf<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
 		if (WANT & 3) store3(vout, k, fr);
 		if (WANT & 4) out_pdf[k] = pdf;
 	}
+}
+
+template <int KIND, int MODE, int FRK>
+hipError_t launch_eval_pp_kind_fr(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
+                                  const float *rec, const Lrep &base, const View &out, float *out_pdf,
+                                  float *out_pp, int want)
+{
+	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
+	switch (want) {
+	case 1: hipLaunchKernelGGL((k_eval_pp<KIND, 1, MODE, FRK>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	case 2: hipLaunchKernelGGL((k_eval_pp<KIND, 2, MODE, FRK>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	case 4: hipLaunchKernelGGL((k_eval_pp<KIND, 4, MODE, FRK>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	case 5: hipLaunchKernelGGL((k_eval_pp<KIND, 5, MODE, FRK>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	case 6: hipLaunchKernelGGL((k_eval_pp<KIND, 6, MODE, FRK>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
 }
 
 template <int KIND, int MODE>
@@ -136,16 +153,14 @@ hipError_t launch_eval_pp_kind(hipStream_t s, const Brdf &b, long long n, const 
                                const float *rec, const Lrep &base, const View &out, float *out_pdf,
                                float *out_pp, int want)
 {
-	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
-	switch (want) {
-	case 1: hipLaunchKernelGGL((k_eval_pp<KIND, 1, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
-	case 2: hipLaunchKernelGGL((k_eval_pp<KIND, 2, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
-	case 4: hipLaunchKernelGGL((k_eval_pp<KIND, 4, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
-	case 5: hipLaunchKernelGGL((k_eval_pp<KIND, 5, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
-	case 6: hipLaunchKernelGGL((k_eval_pp<KIND, 6, MODE>), g, t, 0, s, b, n, i, o, rec, base, out, out_pdf, out_pp); break;
-	default: return hipErrorInvalidValue;
+	// as launch_eval_kind: the analytic lobes get kernels specialised for the ideal / schlick Fresnel terms
+	if constexpr (KIND == KIND_BECKMANN || KIND == KIND_GGX) {
+		if (b.fr.kind == FR_IDEAL || want == 4)
+			return launch_eval_pp_kind_fr<KIND, MODE, FR_IDEAL>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want);
+		if (b.fr.kind == FR_SCHLICK)
+			return launch_eval_pp_kind_fr<KIND, MODE, FR_SCHLICK>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want);
 	}
-	return hipGetLastError();
+	return launch_eval_pp_kind_fr<KIND, MODE, -1>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want);
 }
 
 // ------------------------------------------------------------------ sample / evalp_is

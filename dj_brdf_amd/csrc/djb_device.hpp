@@ -517,15 +517,20 @@ DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k, const Glibc
 	float b = c - (1 + c) * glibc_powf(1 - u, fit, gt);
 	float normalization = recip_to_f32(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot);
 	int it = 0;
+	float inv_erf = 0.0f;
+	bool converged = false;
 	while (++it < 10) {
 		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
-		float inv_erf = erfinv_(b, gt);
+		inv_erf = erfinv_(b, gt);
 		float value = normalization * (1 + b + sqrt_pi_inv * tan_k * glibc_expf(-inv_erf * inv_erf, gt)) - u;
 		float derivative = normalization * (1 - inv_erf * tan_k);
-		if (fabsf(value) < 1e-5f) break;
+		if (fabsf(value) < 1e-5f) { converged = true; break; }
 		if (value > 0) c = b; else a = b;
 		b -= value / derivative;
 	}
+	// the reference returns erfinv(max(-0.9999, b)); after a converged exit b is the argument inv_erf was
+	// just evaluated at, so the value is reused (same function, same argument) unless the clamp moves it
+	if (converged && b >= -0.9999f) return inv_erf;
 	return erfinv_(fmax_(-0.9999f, b), gt);
 }
 

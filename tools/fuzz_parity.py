@@ -3,7 +3,7 @@
 microfacet parameters / Fresnel terms, and hashed MERL / UTIA tables.  Reports, per case, the
 fraction of bit-identical outputs and the largest relative difference; exits non-zero if anything --
 eval / pdf / sample / evalp_is of the analytic lobes, MERL, UTIA, sgd, abc, the fitted tables and their
-operators -- is not 100 % bit-exact.   PYTHONPATH=. python tools/fuzz_parity.py [rounds] [n]"""
+operators -- is not 100 % bit-exact.   PYTHONPATH=. python tools/fuzz_parity.py [rounds] [n] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +15,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_000_000
 TH = min(64, os.cpu_count() or 1)
 O = oraclelib.oracle(); ctx = djb.default_context(0)
-rng = np.random.default_rng(20260928)
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 20260928)
 bad = 0
 
 

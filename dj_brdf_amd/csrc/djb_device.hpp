@@ -48,6 +48,10 @@ struct Brdf {
 	// two-level sampling tables below (dj_brdf.h:429-438)
 	const float *a_pdf1, *a_cdf1, *a_qf1, *a_pdf2, *a_cdf2, *a_qf2;
 	int elev, azim, n_a_cdf1, n_a_qf1;
+	// where glibc_exp() reads its 2 KB table: nullptr = the global copy; the Beckmann kernels stage it in LDS
+	// and point here (set by the kernel on its own copy of the struct, never by the host)
+	const unsigned long long *exp_tab;
+	const double *pow_tab;                  // same for glibc_pow()'s 3 KB log table (sgd / abc kernels)
 };
 
 struct View { float *x, *y, *z; long long stride; };
@@ -133,6 +137,133 @@ DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 	else { theta = F(acos(D(p.z))); phi = F(atan2(D(p.y), D(p.x))); }
 }
 
+// ---- glibc 2.35's double exp / pow, restated --------------------------------------------------------
+// The reference's unqualified exp() / pow() are glibc's double functions: ~0.51 ulp, not
+// correctly rounded, so ROCm's device libm -- equally close to the true value -- rounds the other way
+// once in ~2^28 calls after the cast to float (seen by tools/fuzz_parity.py in an `abc` value).  These are
+// glibc's own table-driven algorithms (sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c), with the fusion of the
+// x86-64 FMA ifunc variants as read off their disassembly (every a*b+c of the source is one fma); tables
+// in djb_glibc_dbl64_tables.hpp (tools/extract_glibc_dbl64_tables.py).  Pinned against the host libm in
+// tests/test_oracle_golden.py::test_glibc_double_libm_restatement (CPU) and, as compiled here, in
+// tests/test_gpu_parity.py::test_device_libm_restatements.  exp is complete; pow hands zero / negative /
+// subnormal / Inf / NaN bases and exponents outside [2^-65, 2^63) -- exact special values -- to the device libm.
+#include "djb_glibc_dbl64_tables.hpp"
+// tmp and the scale bits of exp()/exp_inline(): r = x - k ln2/N, tmp = tail + r + r^2 p(r), scale = 2^(k/N)
+DJB_DEV double glibc_exp_tmp(double x, double xtail, unsigned int &klo, unsigned int &sh, int &sl, const unsigned long long *T)
+{
+	constexpr double InvLn2N = DJB_GLIBC_EXP_C[0], Shift = DJB_GLIBC_EXP_C[1], NegLn2hiN = DJB_GLIBC_EXP_C[2],
+	                 NegLn2loN = DJB_GLIBC_EXP_C[3], C2 = DJB_GLIBC_EXP_C[4], C3 = DJB_GLIBC_EXP_C[5],
+	                 C4 = DJB_GLIBC_EXP_C[6], C5 = DJB_GLIBC_EXP_C[7];
+	double kd = __builtin_fma(x, InvLn2N, Shift);
+	klo = (unsigned int)__double2loint(kd);                              // ki: only bits 0..31 are used
+	kd -= Shift;
+	double r = __builtin_fma(kd, NegLn2hiN, x);
+	r = __builtin_fma(kd, NegLn2loN, r);
+	r += xtail;
+	const unsigned int idx = 2u * (klo & 127u);
+	const double tail = __longlong_as_double((long long)T[idx]);
+	const unsigned long long sb = T[idx + 1];
+	sh = (unsigned int)(sb >> 32) + (klo << 13);                         // sbits = tab + (ki << 45): only the high word changes
+	sl = (int)(unsigned int)sb;
+	double r2 = r * r;
+	double p = __builtin_fma(r, C3, C2), q = __builtin_fma(r, C5, C4);
+	double t = __builtin_fma(p, r2, tail + r);
+	return __builtin_fma(r2 * r2, q, t);
+}
+// everything outside 2^-54 <= |x| < 512 (cold): tiny, huge, Inf, NaN, and specialcase() of e_exp.c
+static __device__ __attribute__((noinline)) double glibc_exp_cold(double x, double xtail, unsigned int abstop, bool is_pow)
+{
+	const unsigned int hx = (unsigned int)__double2hiint(x);
+	if (abstop < 0x3c9u) return 1.0 + x;                                    // |x| < 2^-54
+	if (abstop >= 0x409u) {                                                 // |x| >= 1024, Inf, NaN
+		if (!is_pow) {
+			if (hx == 0xfff00000u && __double2loint(x) == 0) return 0.0;
+			if (abstop >= 0x7ffu) return 1.0 + x;
+		}
+		return (hx >> 31) ? 0.0 : __longlong_as_double(0x7ff0000000000000ll);
+	}
+	unsigned int klo, sh; int sl;
+	const double tmp = glibc_exp_tmp(x, xtail, klo, sh, sl, DJB_GLIBC_EXP_TAB);
+	if ((klo & 0x80000000u) == 0) {
+		const double scale = __hiloint2double((int)(sh - (1009u << 20)), sl);
+		return 0x1p1009 * __builtin_fma(scale, tmp, scale);
+	}
+	const double scale = __hiloint2double((int)(sh + (1022u << 20)), sl);
+	const double m = tmp * scale;             // not fused in __exp_fma: the product is used twice
+	double y = scale + m;
+	if (y < 1.0) {
+		double lo = scale - y + m;
+		double hi = 1.0 + y;
+		lo = 1.0 - hi + y + lo;
+		y = (hi + lo) - 1.0;
+		if (y == 0.0) y = 0.0;
+	}
+	return 0x1p-1022 * y;
+}
+// the main path runs unconditionally (garbage outside its domain) and one rarely taken branch replaces it
+DJB_DEV double glibc_exp_inline(double x, double xtail, bool is_pow, const unsigned long long *T)
+{
+	const unsigned int abstop = ((unsigned int)__double2hiint(x) >> 20) & 0x7ffu;
+	unsigned int klo, sh; int sl;
+	const double tmp = glibc_exp_tmp(x, xtail, klo, sh, sl, T);
+	const double scale = __hiloint2double((int)sh, sl);
+	double y = __builtin_fma(scale, tmp, scale);
+	if (__builtin_expect(abstop - 0x3c9u >= 0x3fu, 0)) y = glibc_exp_cold(x, xtail, abstop, is_pow);
+	return y;
+}
+// T: DJB_GLIBC_EXP_TAB or an LDS copy of it (glibc_exp_tab_to_lds)
+DJB_DEV double glibc_exp(double x, const unsigned long long *T = nullptr) { return glibc_exp_inline(x, 0.0, false, T ? T : DJB_GLIBC_EXP_TAB); }
+DJB_DEV const unsigned long long *glibc_exp_tab_to_lds(unsigned long long *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
+{
+	for (int k = tid; k < 256; k += nthreads) lds[k] = DJB_GLIBC_EXP_TAB[k];
+	return lds;
+}
+DJB_DEV const double *glibc_pow_tab_to_lds(double *lds, int tid, int nthreads);
+// PT / ET: the log and exp tables (nullptr = the global copies; see Brdf::pow_tab / exp_tab)
+DJB_DEV double glibc_pow(double x, double y, const double *PT = nullptr, const unsigned long long *ET = nullptr)
+{
+	constexpr double Ln2hi = DJB_GLIBC_POW_C[0], Ln2lo = DJB_GLIBC_POW_C[1], A0 = DJB_GLIBC_POW_C[2], A1 = DJB_GLIBC_POW_C[3],
+	                 A2 = DJB_GLIBC_POW_C[4], A3 = DJB_GLIBC_POW_C[5], A4 = DJB_GLIBC_POW_C[6], A5 = DJB_GLIBC_POW_C[7],
+	                 A6 = DJB_GLIBC_POW_C[8];
+	const unsigned int hx = (unsigned int)__double2hiint(x), hy = (unsigned int)__double2hiint(y);
+	const unsigned int topx = hx >> 20, topy = hy >> 20;
+	const bool other = topx - 0x001u >= 0x7ffu - 0x001u || (topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu;
+	// tmp = ix - 0x3fe6955500000000: the low word of OFF is zero, so only the high word takes part
+	const unsigned int tmph = hx - 0x3fe69555u;
+	const int i = (int)((tmph >> 13) & 127u);
+	const int k = (int)tmph >> 20;
+	const double z = __hiloint2double((int)(hx - (tmph & 0xfff00000u)), __double2loint(x));
+	const double kd = (double)k;
+	const double *T = (PT ? PT : DJB_GLIBC_POW_LOG_TAB) + 3 * i;
+	const double invc = T[0], logc = T[1], logctail = T[2];
+	double r = __builtin_fma(z, invc, -1.0);
+	double t1 = __builtin_fma(kd, Ln2hi, logc);
+	double t2 = t1 + r;
+	double lo1 = __builtin_fma(kd, Ln2lo, logctail);
+	double lo2 = t1 - t2 + r;
+	double ar = A0 * r, ar2 = r * ar, ar3 = r * ar2;
+	double hi = t2 + ar2;
+	double lo3 = __builtin_fma(ar, r, -ar2);
+	double lo4 = t2 - hi + ar2;
+	double p1 = __builtin_fma(r, A2, A1), p2 = __builtin_fma(r, A4, A3), p3 = __builtin_fma(r, A6, A5);
+	double q = __builtin_fma(p3, ar2, p2);
+	double rr = __builtin_fma(ar2, q, p1);
+	double lo = __builtin_fma(ar3, rr, lo1 + lo2 + lo3 + lo4);
+	double lhi = hi + lo;
+	double llo = hi - lhi + lo;
+	double ehi = y * lhi;
+	double elo = __builtin_fma(y, llo, __builtin_fma(lhi, y, -ehi));
+	double res = glibc_exp_inline(ehi, elo, true, ET ? ET : DJB_GLIBC_EXP_TAB);
+	// zero / negative / subnormal / Inf / NaN bases, |y| outside [2^-65, 2^63): exact special values, device libm
+	if (__builtin_expect(other, 0)) res = pow(x, y);
+	return res;
+}
+DJB_DEV const double *glibc_pow_tab_to_lds(double *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
+{
+	for (int k = tid; k < 384; k += nthreads) lds[k] = DJB_GLIBC_POW_LOG_TAB[k];
+	return lds;
+}
+
 // A&S 7.1.26 as the reference writes it, dj_brdf.h:667-688
 // e must be exp(double(-x*x)) (the same for +x and -x): callers that need that exponential
 // themselves (beckmann_qf2_radial) evaluate the fp64 exp once
@@ -147,7 +278,7 @@ DJB_DEV float erf_given_exp(float x, double e)
 	float y = F(1.0 - D(poly * t) * e);
 	return sign * y;
 }
-DJB_DEV float erf_(float x) { return erf_given_exp(x, exp(D(-x * x))); }
+DJB_DEV float erf_(float x, const unsigned long long *T = nullptr) { return erf_given_exp(x, glibc_exp(D(-x * x), T)); }
 
 // ---- glibc 2.35's float logf / expf / powf, restated -------------------------------------------
 // The reference calls the float libm in erfinv (logf) and in Beckmann's Newton inversion (powf, expf),
@@ -157,13 +288,14 @@ DJB_DEV float erf_(float x) { return erf_given_exp(x, exp(D(-x * x))); }
 // e_expf.c, e_powf.c = ARM optimized-routines), with the multiply-add contractions of the x86-64 FMA
 // ifunc variant; tables in djb_glibc_flt32_tables.hpp (tools/extract_glibc_flt32_tables.py).  The
 // restatement is pinned against the host libm in oracle/ (0 mismatches over 1.2e8-2e8 arguments per
-// function).  Main paths only: special arguments fall back to the device libm.
+// function) and, as compiled here, in tests/test_gpu_parity.py::test_device_libm_restatements.  logf and expf
+// are complete; powf hands zero / Inf / NaN arguments and negative bases to the device libm.
 #include "djb_glibc_flt32_tables.hpp"
 // where the indexed tables are read from: the global copies by default; hot kernels stage them in LDS
 // (glibc_tabs_to_lds: 768 B) because the Newton loop looks them up twice per iteration.  The scalar
 // coefficients are compile-time constants (SGPRs / literals, not per-lane registers).
-struct GlibcTabs { const double *logf, *powlog; const unsigned long long *exp2; };
-DJB_DEV GlibcTabs glibc_tabs_global() { GlibcTabs t = { DJB_GLIBC_LOGF, DJB_GLIBC_POWF_LOG2, DJB_GLIBC_EXP2F_TAB }; return t; }
+struct GlibcTabs { const double *logf, *powlog; const unsigned long long *exp2; const unsigned long long *exp64; };
+DJB_DEV GlibcTabs glibc_tabs_global() { GlibcTabs t = { DJB_GLIBC_LOGF, DJB_GLIBC_POWF_LOG2, DJB_GLIBC_EXP2F_TAB, DJB_GLIBC_EXP_TAB }; return t; }
 constexpr int GLIBC_LDS_WORDS = 32 + 32 + 32;    // 8-byte words
 DJB_DEV GlibcTabs glibc_tabs_to_lds(double *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
 {
@@ -174,7 +306,7 @@ DJB_DEV GlibcTabs glibc_tabs_to_lds(double *lds, int tid, int nthreads)   // cal
 		else v = __longlong_as_double((long long)DJB_GLIBC_EXP2F_TAB[k - 64]);
 		lds[k] = v;
 	}
-	GlibcTabs t = { lds, lds + 32, (const unsigned long long *)(lds + 64) };
+	GlibcTabs t = { lds, lds + 32, (const unsigned long long *)(lds + 64), DJB_GLIBC_EXP_TAB };
 	return t;
 }
 DJB_DEV float glibc_logf(float x, const GlibcTabs &gt)
@@ -183,7 +315,12 @@ DJB_DEV float glibc_logf(float x, const GlibcTabs &gt)
 	constexpr double Ln2 = DJB_GLIBC_LOGF_C[0], A0 = DJB_GLIBC_LOGF_C[1], A1 = DJB_GLIBC_LOGF_C[2], A2 = DJB_GLIBC_LOGF_C[3];
 	unsigned int ix = __float_as_uint(x);
 	if (ix == 0x3f800000u) return 0.0f;
-	if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return logf(x);
+	if (__builtin_expect(ix - 0x00800000u >= 0x7f800000u - 0x00800000u, 0)) {
+		if (ix * 2u == 0u) return -__builtin_inff();
+		if (ix == 0x7f800000u) return x;
+		if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __builtin_nanf("");
+		ix = __float_as_uint(x * 0x1p23f) - (23u << 23);                 // subnormal: normalise
+	}
 	unsigned int tmp = ix - 0x3f330000u;
 	int i = (int)((tmp >> 19) % 16u), k = (int)tmp >> 23;
 	unsigned int iz = ix - (tmp & (0x1ffu << 23));
@@ -213,7 +350,13 @@ DJB_DEV float glibc_expf(float x, const GlibcTabs &gt)
 {
 	constexpr double Shift = DJB_GLIBC_EXP2F_C[4], InvLn2N = DJB_GLIBC_EXP2F_C[5];
 	unsigned int abstop = (__float_as_uint(x) >> 20) & 0x7ffu;
-	if (abstop >= (0x42b00000u >> 20)) return expf(x);                 // |x| >= 88 or nan
+	if (__builtin_expect(abstop >= (0x42b00000u >> 20), 0)) {          // |x| >= 88 or nan
+		if (__float_as_uint(x) == 0xff800000u) return 0.0f;
+		if (abstop >= (0x7f800000u >> 20)) return x + x;
+		if (x > 0x1.62e42ep6f) return __builtin_inff();                 // x > log(0x1p128)
+		if (x < -0x1.9fe368p6f) return 0.0f;                            // x < log(0x1p-150)
+		if (x < -0x1.9d1d9ep6f) return __uint_as_float(1u);             // x < log(0x1p-149): __math_may_uflowf = 2^-149
+	}
 	double xd = D(x), z = InvLn2N * xd;
 	double kd = z + Shift;
 	unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
@@ -227,7 +370,11 @@ DJB_DEV float glibc_powf(float x, float y, const GlibcTabs &gt)
 	constexpr double A0 = DJB_GLIBC_POWF_C[0], A1 = DJB_GLIBC_POWF_C[1], A2 = DJB_GLIBC_POWF_C[2], A3 = DJB_GLIBC_POWF_C[3],
 	                 A4 = DJB_GLIBC_POWF_C[4], ShiftScaled = DJB_GLIBC_EXP2F_C[0];
 	unsigned int ix = __float_as_uint(x), iy = __float_as_uint(y);
-	if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2u * iy - 1u >= 2u * 0x7f800000u - 1u) return powf(x, y);
+	if (__builtin_expect(ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2u * iy - 1u >= 2u * 0x7f800000u - 1u, 0)) {
+		// zero / Inf / NaN arguments and negative bases: exact special values (or glibc's sign_bias path): device libm
+		if (2u * iy - 1u >= 2u * 0x7f800000u - 1u || 2u * ix - 1u >= 2u * 0x7f800000u - 1u || (ix & 0x80000000u)) return powf(x, y);
+		ix = (__float_as_uint(x * 0x1p23f) & 0x7fffffffu) - (23u << 23);   // positive subnormal: normalise
+	}
 	unsigned int tmp = ix - 0x3f330000u;
 	int i = (int)((tmp >> 19) % 16u);
 	unsigned int top = tmp & 0xff800000u, iz = ix - top;
@@ -240,7 +387,11 @@ DJB_DEV float glibc_powf(float x, float y, const GlibcTabs &gt)
 	q = __builtin_fma(p, r2, q);
 	double logx = __builtin_fma(p0, r4, q);
 	double ylogx = D(y) * logx;
-	if ((((unsigned long long)__double_as_longlong(ylogx) >> 47) & 0xffffull) >= (0x405f800000000000ull >> 47)) return powf(x, y);   // |y log2 x| >= 126
+	if (__builtin_expect((((unsigned int)__double2hiint(ylogx) >> 15) & 0xffffu) >= (0x405f8000u >> 15), 0)) {   // |y log2 x| >= 126
+		if (ylogx > 0x1.fffffffd1d571p+6) return __builtin_inff();
+		if (ylogx <= -150.0) return 0.0f;
+		if (ylogx < -149.0) return __uint_as_float(1u);                   // __math_may_uflowf
+	}
 	double kd = ylogx + ShiftScaled;
 	unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
 	kd -= ShiftScaled;
@@ -381,7 +532,7 @@ DJB_DEV v3 fresnel_eval(const Fresnel &f, float c)
 		return add(f0, scale(c5, sub(mk(1, 1, 1), f0)));
 	}
 	case FR_SGD: {       // dj_brdf.h:1330-1336
-		float pw = F(pow(1.0 - D(c), 5.0));
+		float pw = F(glibc_pow(1.0 - D(c), 5.0));
 		v3 f0 = mk(f.a[0], f.a[1], f.a[2]), f1 = mk(f.b[0], f.b[1], f.b[2]);
 		return add(sub(f0, scale(c, f1)), scale(pw, sub(mk(1, 1, 1), f0)));
 	}
@@ -396,7 +547,7 @@ DJB_DEV v3 fresnel_eval(const Fresnel &f, float c)
 // ------------------------------------------------------------------ radial NDFs (dj_brdf.h:1866-2176)
 template <int KIND> DJB_DEV float p22_radial(const Brdf &b, float r_sqr)
 {
-	if (KIND == KIND_BECKMANN) return F(exp(D(-r_sqr)) / DJB_PI);                      // :1866
+	if (KIND == KIND_BECKMANN) return F(glibc_exp(D(-r_sqr), b.exp_tab) / DJB_PI);                      // :1866
 	if (KIND == KIND_GGX) { float t = 1.0f + r_sqr; /* == float(1.0 + double(r_sqr)) */ return recip_to_f32(DJB_PI * D(t) * D(t)); } // :2056
 	float r = sqrtf(r_sqr);                                                             // :2151
 	float u = F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI))));
@@ -409,8 +560,9 @@ template <int KIND> DJB_DEV float sigma_std_radial(const Brdf &b, float c)
 		if (D(c) == 1.0) return 1.0f;
 		float s = F(sqrt(1.0 - D(c * c)));
 		float nu = c / s;
-		float tmp = F(exp(D(-nu * nu)) * D(inversesqrt_(F(DJB_PI))));
-		return F((D(c) * (1.0 + D(erf_(nu))) + D(s * tmp)) / 2.0);
+		const double e = glibc_exp(D(-nu * nu), b.exp_tab);              // also the exponential inside erf(nu)
+		float tmp = F(e * D(inversesqrt_(F(DJB_PI))));
+		return F((D(c) * (1.0 + D(erf_given_exp(nu, e))) + D(s * tmp)) / 2.0);
 	}
 	if (KIND == KIND_GGX) return (1.0f + c) * 0.5f; /* == float((1.0 + double(c)) / 2.0) */                                // :2062
 	float u = F(D(2.0f) * acos(D(c)) / D(F(DJB_PI)));                                   // :2158
@@ -486,7 +638,7 @@ DJB_DEV float aniso_qf2(const Brdf &b, float u, float phi)                      
 // analytic cdf / quantile of the radial slope distribution (dj_brdf.h:1881-1889, 2067-2076)
 template <int KIND> DJB_DEV float cdf_radial(const Brdf &b, float r)
 {
-	if (KIND == KIND_BECKMANN) return F(1.0 - exp(D(-r * r)));
+	if (KIND == KIND_BECKMANN) return F(1.0 - glibc_exp(D(-r * r), b.exp_tab));
 	if (KIND == KIND_GGX) { float t = r * r; return F(D(t) / (1.0 + D(t))); }
 	return tab_cdf_radial(b, r);
 }
@@ -510,7 +662,7 @@ DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k, const Glibc
 {
 	const float sqrt_pi_inv = F(1. / sqrt(DJB_PI));
 	float cot_k = cos_k / sin_k, tan_k = sin_k / cos_k;
-	const double e_cot = exp(D(-cot_k * cot_k));          // shared by erf(cot_k) and the normalization
+	const double e_cot = glibc_exp(D(-cot_k * cot_k), gt.exp64);          // shared by erf(cot_k) and the normalization
 	float a = -1, c = erf_given_exp(cot_k, e_cot);
 	u = fmax_(u, 1e-6f);
 	float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
@@ -921,7 +1073,7 @@ DJB_DEV bool merl_index_fast(v3 i, v3 o, const MerlGuard g, int &idx)
 // of an fp32 rounding boundary, otherwise -- or outside t in [1/16, 16] -- the exact form runs.
 DJB_DEV float srgb_decode_exact(float v)
 {
-	return F(pow(D(F(D(v) + 0.055)) / 1.055, D(2.4f)));
+	return F(glibc_pow(D(F(D(v) + 0.055)) / 1.055, D(2.4f)));
 }
 DJB_DEV double srgb_decode_fast(float v, bool &ok)
 {
@@ -1051,33 +1203,33 @@ DJB_DEV void lrep_to_pdfparams(Lrep l, float &ax, float &ay, float &rho, float &
 }
 
 // ------------------------------------------------------------------ SGD (dj_brdf.h:3415-3500)
-DJB_DEV double sgd_g1(v3 k, double theta0, double c, double k_, double lambda)           // :3415
+DJB_DEV double sgd_g1(const Brdf &b, v3 k, double theta0, double c, double k_, double lambda)           // :3415
 {
 	double t1 = fmax(0.0, acos(D(k.z)) - theta0);
-	double t2 = 1.0 - exp(c * pow(t1, k_));
+	double t2 = 1.0 - glibc_exp(c * glibc_pow(t1, k_, b.pow_tab, b.exp_tab), b.exp_tab);
 	double t3 = 1.0 + lambda * t2;
 	return fmin(1.0, fmax(0.0, t3));
 }
-DJB_DEV double sgd_ndf(double ch, double alpha, double p, double kap)                     // :3424
+DJB_DEV double sgd_ndf(const Brdf &b, double ch, double alpha, double p, double kap)                     // :3424
 {
 	const double inv_pi = 1.0 / DJB_PI;
 	double c2 = ch * ch;
 	double t2 = (1.0 - c2) / c2;
 	double ax = alpha + t2 / alpha;
-	return (kap * exp(-ax) * inv_pi) / (pow(ax, p) * c2 * c2);
+	return (kap * glibc_exp(-ax, b.exp_tab) * inv_pi) / (glibc_pow(ax, p, b.pow_tab, b.exp_tab) * c2 * c2);
 }
 // model row: rhoD rhoS alpha p f0 f1 kap lambda c k theta0 (3 doubles each)
 DJB_DEV v3 sgd_g1_rgb(const Brdf &b, v3 k)                                                // sgd::g1, :3477
 {
 	const double *m = b.model;
-	return mk(F(sgd_g1(k, m[30], m[24], m[27], m[21])), F(sgd_g1(k, m[31], m[25], m[28], m[22])),
-	          F(sgd_g1(k, m[32], m[26], m[29], m[23])));
+	return mk(F(sgd_g1(b, k, m[30], m[24], m[27], m[21])), F(sgd_g1(b, k, m[31], m[25], m[28], m[22])),
+	          F(sgd_g1(b, k, m[32], m[26], m[29], m[23])));
 }
 DJB_DEV v3 sgd_ndf_rgb(const Brdf &b, v3 h)                                               // sgd::ndf, :3490
 {
 	const double *m = b.model;
-	return mk(F(sgd_ndf(D(h.z), m[6], m[9], m[18])), F(sgd_ndf(D(h.z), m[7], m[10], m[19])),
-	          F(sgd_ndf(D(h.z), m[8], m[11], m[20])));
+	return mk(F(sgd_ndf(b, D(h.z), m[6], m[9], m[18])), F(sgd_ndf(b, D(h.z), m[7], m[10], m[19])),
+	          F(sgd_ndf(b, D(h.z), m[8], m[11], m[20])));
 }
 DJB_DEV v3 sgd_gaf_rgb(const Brdf &b, v3 i, v3 o)                                         // sgd::gaf = g1(i) * g1(o), :3472
 {
@@ -1110,7 +1262,7 @@ DJB_DEV float abc_gaf(v3 h, v3 i, v3 o)                                         
 DJB_DEV v3 abc_ndf_rgb(const Brdf &b, v3 h)                                               // abc::ndf, :3657 + abc__ndf :3608
 {
 	const double *m = b.model;
-	double den = pow(1.0 + m[6] * (1.0 - D(h.z)), m[7]);
+	double den = glibc_pow(1.0 + m[6] * (1.0 - D(h.z)), m[7], b.pow_tab, b.exp_tab);
 	return mk(F(m[3] / den), F(m[4] / den), F(m[5] / den));
 }
 DJB_DEV v3 abc_eval(const Brdf &b, v3 i, v3 o)                                            // :3633

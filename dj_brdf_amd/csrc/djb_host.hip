@@ -1404,6 +1404,26 @@ djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, uns
 	return DJB_OK;
 }
 
+djb_status djb_selftest_libm(djb_ctx *ctx, int fn, int64_t n, const double *x, const double *y, double *out)
+{
+	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_HOST);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	if (fn < 0 || fn > 4 || !x || !y || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid selftest arguments");
+	if (n == 0) return DJB_OK;
+	const size_t nb = sizeof(double) * (size_t)n;
+	double *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 3 * nb));
+	hipError_t e = hipMemcpy(d, x, nb, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d + n, y, nb, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = djbk::launch_libm_probe(ctx->stream, fn, n, d, d + n, d + 2 * n);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, nb, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));
+	return DJB_OK;
+}
+
 djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int bins, unsigned long long *counts)
 {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);

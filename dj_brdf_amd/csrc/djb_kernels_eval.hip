@@ -62,6 +62,14 @@ template <int KIND, int WANT, int FRK>
 __global__ __launch_bounds__(BLOCK, (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) ? 4 : DJB_EVAL_MINW_OTHER) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
                                                    View vout, float *out_pdf)
 {
+	// Beckmann evaluates the fp64 exp of glibc (djb_device.hpp) three times per pair: its 2 KB table goes to LDS
+	// (sgd: 9 exp + 9 pow per pair, abc: one pow -- both tables)
+	constexpr bool EXPT = KIND == KIND_BECKMANN || KIND == KIND_SGD || KIND == KIND_ABC, POWT = KIND == KIND_SGD || KIND == KIND_ABC;
+	__shared__ unsigned long long s_exp[EXPT ? 256 : 1];
+	__shared__ double s_pow[POWT ? 384 : 1];
+	if (EXPT) b.exp_tab = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	if (POWT) b.pow_tab = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
+	if (EXPT || POWT) __syncthreads();
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		v3 i = load3(vi, k), o = load3(vo, k);
@@ -112,6 +120,8 @@ template <int KIND, int WANT, int MODE, int FRK = -1>
 __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi, View vo, const float *rec,
                                                    Lrep base, View vout, float *out_pdf, float *out_pp)
 {
+	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];     // as in k_eval
+	if (KIND == KIND_BECKMANN) { b.exp_tab = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK); __syncthreads(); }
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		v3 i = load3(vi, k), o = load3(vo, k);
@@ -174,7 +184,12 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 	// Beckmann's quantile functions call glibc's logf / expf / powf restatement: its tables go to LDS
 	__shared__ double s_glibc[KIND == KIND_BECKMANN ? GLIBC_LDS_WORDS : 1];
 	GlibcTabs gt = glibc_tabs_global();
-	if (KIND == KIND_BECKMANN) { gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK); __syncthreads(); }
+	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];     // the fp64 exp table, as in k_eval
+	if (KIND == KIND_BECKMANN) {
+		gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
+		gt.exp64 = b.exp_tab = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+		__syncthreads();
+	}
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		float u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : u1a[k];
@@ -560,6 +575,30 @@ hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsign
 {
 	if (n <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k_gen_uni, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, seed, start, out);
+	return hipGetLastError();
+}
+
+// the device restatements of glibc's libm functions, evaluated as-is for the test-suite (djb_selftest_libm)
+__global__ __launch_bounds__(BLOCK) void k_libm_probe(int fn, long long n, const double *x, const double *y, double *out)
+{
+	const GlibcTabs gt = glibc_tabs_global();
+	long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		double r;
+		switch (fn) {
+		case 0: r = glibc_exp(x[k]); break;
+		case 1: r = glibc_pow(x[k], y[k]); break;
+		case 2: r = D(glibc_logf(F(x[k]), gt)); break;
+		case 3: r = D(glibc_expf(F(x[k]), gt)); break;
+		default: r = D(glibc_powf(F(x[k]), F(y[k]), gt)); break;
+		}
+		out[k] = r;
+	}
+}
+hipError_t launch_libm_probe(hipStream_t s, int fn, long long n, const double *x, const double *y, double *out)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_libm_probe, dim3(grid_for(n)), dim3(BLOCK), 0, s, fn, n, x, y, out);
 	return hipGetLastError();
 }
 

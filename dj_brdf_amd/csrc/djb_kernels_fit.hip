@@ -106,7 +106,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	self.fr.kind = FR_IDEAL; self.fr.pts = nullptr; self.fr.npts = 0;
 	self.p22 = p22; self.sigma = sigma; self.cdf = cdf; self.qf = qf;
 	self.n_p22 = res; self.n_sigma = res; self.n_cdf = res; self.n_qf = res;
-	self.merl = nullptr; self.utia = nullptr;
+	self.merl = nullptr; self.utia = nullptr; self.exp_tab = nullptr; self.pow_tab = nullptr;
 
 	// ================================================================ compute_p22_smith (dj_brdf.h:2482-2522)
 	const float dtheta_k = F(sqrt(DJB_PI * 0.5) / D((float)cnt));
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		theta[k] = th; cosv[k] = c; tanv[k] = t;
 		v3 w = from_angles(th2, 0.0f);
 		float fr_i = intensity(src_eval<SRC>(src, std_p, w, w));
-		kji[k] = F((D(dtheta_k) * pow(D(c), D(6.0f))) * (8.0 * D(fr_i)));
+		kji[k] = F((D(dtheta_k) * glibc_pow(D(c), D(6.0f))) * (8.0 * D(fr_i)));
 		v0[k] = 1.0;
 	}
 	__syncthreads();

@@ -31,7 +31,7 @@ DJB_DEV Brdf self_view(const AnisoScratch &S, int shadow)
 	b.fr.kind = FR_IDEAL; b.fr.pts = nullptr; b.fr.npts = 0;
 	b.p22 = S.p22; b.sigma = S.sigma; b.cdf = nullptr; b.qf = nullptr;
 	b.n_p22 = b.n_sigma = S.elev * S.azim; b.n_cdf = b.n_qf = 0;
-	b.merl = nullptr; b.utia = nullptr; b.model = nullptr;
+	b.merl = nullptr; b.utia = nullptr; b.model = nullptr; b.exp_tab = nullptr; b.pow_tab = nullptr;
 	b.a_pdf1 = S.pdf1; b.a_cdf1 = S.cdf1; b.a_qf1 = S.qf1; b.a_pdf2 = S.pdf2; b.a_cdf2 = S.cdf2; b.a_qf2 = S.qf2;
 	b.elev = S.elev; b.azim = S.azim; b.n_a_cdf1 = S.azim; b.n_a_qf1 = S.azim;
 	return b;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BLOCK) void ka_setup(Brdf src, Params std_p, AnisoS
 	S.zo[a] = zo; S.xo[a] = F(D(st) * cos(D(phi))); S.yo[a] = F(D(st) * sin(D(phi)));
 	v3 wv = from_angles(theta, phi);
 	float fr_i = intensity(src_eval<SRC>(src, std_p, wv, wv));
-	S.k1[a] = F(D(dtheta * dphi) * (4.0 * D(fr_i) * pow(D(zo), D(5.0f))));
+	S.k1[a] = F(D(dtheta * dphi) * (4.0 * D(fr_i) * glibc_pow(D(zo), D(5.0f))));
 	float tt = F(tan(D(theta)));
 	S.tn[a] = tt; S.dn[a] = zo * zo;               // cos_theta * cos_theta (same float as zo)
 	S.s1[a] = F(D(-tt) * cos(D(phi))); S.s2[a] = F(D(-tt) * sin(D(phi)));

@@ -987,6 +987,19 @@ def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):
             "srgb_mismatch": c[4], "srgb_fallback": c[5]}
 
 
+def selftest_libm(fn: str, x, y=None, ctx: Optional[Context] = None):
+    """The kernels' restatement of a host libm function (exp, pow, logf, expf, powf), evaluated on the GPU
+    (djb_selftest_libm); float functions take and return values representable as float."""
+    ctx = ctx or default_context()
+    code = {"exp": 0, "pow": 1, "logf": 2, "expf": 3, "powf": 4}[fn]
+    x = np.ascontiguousarray(x, np.float64).reshape(-1)
+    y = np.ascontiguousarray(x if y is None else y, np.float64).reshape(-1)
+    out = np.empty_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.load().djb_selftest_libm(ctx._h, C.c_int(code), C.c_int64(x.size), p(x), p(y), p(out)))
+    return out
+
+
 def merl_guard_stats(i, o, guard=None, ctx: Optional[Context] = None):
     """Calibration of the two-tier MERL kernel on device-resident pairs (see djb_merl_guard_stats)."""
     ctx = ctx or default_context()

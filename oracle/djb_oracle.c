@@ -1828,8 +1828,9 @@ void o_erfinv(int64_t n, const float *x, float *y) { for (int64_t k = 0; k < n; 
  * The reference's erfinv / Beckmann quantile code calls logf, expf and powf (hdr:691-721, 1897-1952): its
  * results are those of the host libm.  o_libm_f32 calls the host libm itself (what the reference build
  * does); o_glibc_f32 is the restatement of glibc's algorithms (sysdeps/ieee754/flt-32/e_logf.c, e_expf.c,
- * e_powf.c = ARM optimized-routines) that the HIP kernels implement, main paths only (positive normal
- * arguments, finite results); `fma` selects the contraction of the x86-64 FMA ifunc variants.
+ * e_powf.c = ARM optimized-routines) that the HIP kernels implement: complete for logf and expf, and for powf
+ * with a positive finite base (zero / Inf / NaN arguments and negative bases go to the host libm here, to the
+ * device libm in the kernels); `fma` selects the contraction of the x86-64 FMA ifunc variants.
  * fn: 0 logf(x), 1 expf(x), 2 powf(x, y). */
 #include "glibc_flt32_tables.h"
 static inline uint32_t asu32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -1843,7 +1844,13 @@ static float glibc_logf(float x, int f)
 	const double *T = DJB_GLIBC_LOGF, Ln2 = T[32], *A = T + 33;
 	uint32_t ix = asu32(x);
 	if (ix == 0x3f800000) return 0.0f;
-	if (ix - 0x00800000 >= 0x7f800000 - 0x00800000) return logf(x);              /* special cases: host libm */
+	if (ix - 0x00800000 >= 0x7f800000 - 0x00800000) {
+		if (ix * 2 == 0) return -INFINITY;
+		if (ix == 0x7f800000) return x;
+		if ((ix & 0x80000000) || ix * 2 >= 0xff000000) return NAN;
+		ix = asu32(x * 0x1p23f);                                                   /* subnormal: normalise */
+		ix -= 23 << 23;
+	}
 	uint32_t tmp = ix - 0x3f330000;
 	int i = (tmp >> 19) % 16, k = (int32_t)tmp >> 23;
 	uint32_t iz = ix - (tmp & 0x1ffu << 23);
@@ -1860,7 +1867,13 @@ static float glibc_expf(float x, int f)
 {
 	const double *E = DJB_GLIBC_EXP2F, InvLn2N = E[5], SHIFT = E[4], *C = E + 6;
 	uint32_t abstop = (asu32(x) >> 20) & 0x7ff;
-	if (abstop >= (asu32(88.0f) >> 20)) return expf(x);                           /* |x| >= 88 or nan: host libm */
+	if (abstop >= (asu32(88.0f) >> 20)) {                                         /* |x| >= 88 or nan */
+		if (asu32(x) == asu32(-INFINITY)) return 0.0f;
+		if (abstop >= (asu32(INFINITY) >> 20)) return x + x;
+		if (x > 0x1.62e42ep6f) return INFINITY;                                   /* x > log(0x1p128) */
+		if (x < -0x1.9fe368p6f) return 0.0f;                                      /* x < log(0x1p-150) */
+		if (x < -0x1.9d1d9ep6f) return 0x1.4p-75f * 0x1.4p-75f;                   /* x < log(0x1p-149): __math_may_uflowf */
+	}
 	double xd = (double)x, z = InvLn2N * xd;
 	double kd = z + SHIFT; uint64_t ki = asu64(kd); kd -= SHIFT;
 	double r = f >= 2 ? fma(InvLn2N, xd, -kd) : z - kd;      /* f >= 2: the product contracted into the subtraction */
@@ -1877,7 +1890,13 @@ static float glibc_powf(float x, float y, int f)
 {
 	const double *T = DJB_GLIBC_POWF_LOG2, *A = T + 32, *E = DJB_GLIBC_EXP2F, SHIFT = E[0], *C = E + 1;
 	uint32_t ix = asu32(x), iy = asu32(y);
-	if (ix - 0x00800000 >= 0x7f800000 - 0x00800000 || 2 * iy - 1 >= 2u * 0x7f800000 - 1) return powf(x, y);   /* specials */
+	if (ix - 0x00800000 >= 0x7f800000 - 0x00800000 || 2 * iy - 1 >= 2u * 0x7f800000 - 1) {
+		/* zero / Inf / NaN arguments and negative bases: exact special values (or the sign_bias path), host libm */
+		if (2 * iy - 1 >= 2u * 0x7f800000 - 1 || 2 * ix - 1 >= 2u * 0x7f800000 - 1 || (ix & 0x80000000)) return powf(x, y);
+		ix = asu32(x * 0x1p23f);                                                   /* positive subnormal: normalise */
+		ix &= 0x7fffffff;
+		ix -= 23 << 23;
+	}
 	uint32_t tmp = ix - 0x3f330000;
 	int i = (tmp >> 19) % 16;
 	uint32_t top = tmp & 0xff800000, iz = ix - top;
@@ -1890,7 +1909,11 @@ static float glibc_powf(float x, float y, int f)
 	q = mad(f, p, r2, q);
 	double logx = mad(f, p0, r4, q);
 	double ylogx = (double)y * logx;
-	if ((asu64(ylogx) >> 47 & 0xffff) >= asu64(126.0) >> 47) return powf(x, y);   /* |y log2 x| >= 126: host libm */
+	if ((asu64(ylogx) >> 47 & 0xffff) >= asu64(126.0) >> 47) {                     /* |y log2 x| >= 126 */
+		if (ylogx > 0x1.fffffffd1d571p+6) return INFINITY;
+		if (ylogx <= -150.0) return 0.0f;
+		if (ylogx < -149.0) return 0x1.4p-75f * 0x1.4p-75f;                       /* __math_may_uflowf */
+	}
 	double kd = ylogx + SHIFT; uint64_t ki = asu64(kd); kd -= SHIFT;
 	double rr = f >= 2 ? fma((double)y, logx, -kd) : ylogx - kd;
 	uint64_t t = DJB_GLIBC_EXP2F_TAB[ki % 32]; t += ki << (52 - 5);
@@ -1907,4 +1930,119 @@ void o_glibc_f32(int fn, int use_fma, int64_t n, const float *x, const float *y,
 {
 	for (int64_t k = 0; k < n; ++k)
 		out[k] = fn == 0 ? glibc_logf(x[k], use_fma) : fn == 1 ? glibc_expf(x[k], use_fma) : glibc_powf(x[k], y[k], use_fma);
+}
+
+/* ------------------------------------------------------------------ glibc 2.35 double exp / pow, restated
+ * The reference's unqualified exp() / pow() are the host libm's double functions.  o_libm_f64
+ * calls the host libm itself; o_glibc_f64 restates glibc's algorithms (sysdeps/ieee754/dbl-64/e_exp.c,
+ * e_pow.c) as the HIP kernels implement them: the main paths, with the multiply-add fusion of the x86-64 FMA
+ * ifunc variants (__exp_fma, __pow_fma; read off their disassembly -- every a*b+c of the source is one fma,
+ * except in specialcase()).  exp is complete; pow hands zero / negative / subnormal / Inf / NaN bases and
+ * exponents outside [2^-65, 2^63) -- whose results are exact special values -- to the host libm here and to the
+ * device libm in the kernels.   fn: 0 exp(x), 1 pow(x, y). */
+#include "glibc_dbl64_tables.h"
+/* specialcase() of e_exp.c: 512 <= |x| < 1024, the scale factor would over/underflow */
+static double glibc_exp_specialcase(double tmp, uint64_t sbits, uint64_t ki)
+{
+	if ((ki & 0x80000000) == 0) {
+		sbits -= 1009ull << 52;
+		double scale = asf64(sbits);
+		return 0x1p1009 * fma(scale, tmp, scale);
+	}
+	sbits += 1022ull << 52;
+	double scale = asf64(sbits);
+	double m = tmp * scale;                  /* not fused in __exp_fma: the product is used twice */
+	double y = scale + m;
+	if (y < 1.0) {
+		double lo = scale - y + m;
+		double hi = 1.0 + y;
+		lo = 1.0 - hi + y + lo;
+		y = (hi + lo) - 1.0;
+		if (y == 0.0) y = 0.0;
+	}
+	return 0x1p-1022 * y;
+}
+/* the common part of exp() and pow()'s exp_inline(): 2^-54 <= |x| < 1024 */
+static double glibc_exp_core(double x, double xtail, int special)
+{
+	const double *E = DJB_GLIBC_EXP_C;       /* invln2N, shift, negln2hiN, negln2loN, C2, C3, C4, C5 */
+	double kd = fma(x, E[0], E[1]);
+	uint64_t ki = asu64(kd);
+	kd -= E[1];
+	double r = fma(kd, E[2], x);
+	r = fma(kd, E[3], r);
+	r += xtail;                              /* pow's exp_inline; exp() itself has xtail == 0: r + 0.0 == r */
+	uint64_t idx = 2 * (ki % 128);
+	double tail = asf64(DJB_GLIBC_EXP_TAB[idx]);
+	uint64_t sbits = DJB_GLIBC_EXP_TAB[idx + 1] + (ki << 45);
+	double r2 = r * r;
+	double p = fma(r, E[5], E[4]);           /* C2 + r C3 */
+	double q = fma(r, E[7], E[6]);           /* C4 + r C5 */
+	double t = fma(p, r2, tail + r);
+	double tmp = fma(r2 * r2, q, t);
+	if (special) return glibc_exp_specialcase(tmp, sbits, ki);
+	double scale = asf64(sbits);
+	return fma(scale, tmp, scale);
+}
+static double glibc_exp(double x)
+{
+	uint32_t abstop = (uint32_t)(asu64(x) >> 52) & 0x7ff;
+	int special = 0;
+	if (abstop - 0x3c9 >= 0x3f) {
+		if (abstop < 0x3c9) return 1.0 + x;                  /* |x| < 2^-54 */
+		if (abstop >= 0x409) {                               /* |x| >= 1024, inf, nan */
+			if (asu64(x) == asu64(-INFINITY)) return 0.0;
+			if (abstop >= 0x7ff) return 1.0 + x;
+			return (asu64(x) >> 63) ? 0.0 : INFINITY;
+		}
+		special = 1;
+	}
+	return glibc_exp_core(x, 0.0, special);
+}
+static double glibc_pow(double x, double y)
+{
+	const double *P = DJB_GLIBC_POW_C, *A = P + 2;    /* ln2hi, ln2lo, A[0..6] */
+	uint64_t ix = asu64(x), iy = asu64(y);
+	uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
+	/* zero, negative, subnormal, Inf, NaN bases and |y| outside [2^-65, 2^63): host libm (exact special values) */
+	if (topx - 0x001 >= 0x7ff - 0x001 || (topy & 0x7ff) - 0x3be >= 0x43e - 0x3be) return pow(x, y);
+	uint64_t tmp = ix - 0x3fe6955500000000ull;
+	int i = (int)((tmp >> 45) % 128);
+	int64_t k = (int64_t)tmp >> 52;
+	uint64_t iz = ix - (tmp & 0xfffull << 52);
+	double z = asf64(iz), kd = (double)k;
+	const double *T = DJB_GLIBC_POW_LOG_TAB + 3 * i;  /* invc, logc, logctail */
+	double r = fma(z, T[0], -1.0);
+	double t1 = fma(kd, P[0], T[1]);
+	double t2 = t1 + r;
+	double lo1 = fma(kd, P[1], T[2]);
+	double lo2 = t1 - t2 + r;
+	double ar = A[0] * r, ar2 = r * ar, ar3 = r * ar2;
+	double hi = t2 + ar2;
+	double lo3 = fma(ar, r, -ar2);
+	double lo4 = t2 - hi + ar2;
+	double p1 = fma(r, A[2], A[1]), p2 = fma(r, A[4], A[3]), p3 = fma(r, A[6], A[5]);
+	double q = fma(p3, ar2, p2);
+	double rr = fma(ar2, q, p1);
+	double lo = fma(ar3, rr, lo1 + lo2 + lo3 + lo4);
+	double lhi = hi + lo;
+	double llo = hi - lhi + lo;
+	double ehi = y * lhi;
+	double elo = fma(y, llo, fma(lhi, y, -ehi));
+	uint32_t abstop = (uint32_t)(asu64(ehi) >> 52) & 0x7ff;
+	int special = 0;
+	if (abstop - 0x3c9 >= 0x3f) {
+		if (abstop < 0x3c9) return 1.0 + ehi;                /* |y log x| < 2^-54 */
+		if (abstop >= 0x409) return (asu64(ehi) >> 63) ? 0.0 : INFINITY;
+		special = 1;
+	}
+	return glibc_exp_core(ehi, elo, special);
+}
+void o_libm_f64(int fn, int64_t n, const double *x, const double *y, double *out)
+{
+	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? exp(x[k]) : pow(x[k], y[k]);
+}
+void o_glibc_f64(int fn, int64_t n, const double *x, const double *y, double *out)
+{
+	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? glibc_exp(x[k]) : glibc_pow(x[k], y[k]);
 }

@@ -98,6 +98,9 @@ void o_fresnel_eval(const o_brdf *b, int64_t n, const float *c, float *out);
  * for them that the HIP kernels implement (use_fma: contraction of the x86-64 FMA ifunc variants) */
 void o_libm_f32(int fn, int64_t n, const float *x, const float *y, float *out);
 void o_glibc_f32(int fn, int use_fma, int64_t n, const float *x, const float *y, float *out);
+/* host libm double exp (fn 0) / pow (fn 1) and the restatement of glibc 2.35's algorithms the HIP kernels implement */
+void o_libm_f64(int fn, int64_t n, const double *x, const double *y, double *out);
+void o_glibc_f64(int fn, int64_t n, const double *x, const double *y, double *out);
 /* vec3::vec3(theta, phi), dj_brdf.h:589-595 */
 void o_vec3_angles(int64_t n, const float *theta, const float *phi, float *out);
 /* sgd / abc member queries, dj_brdf.h:505-509, 530-533: which 0 ndf(h), 1 gaf(h, i, o), 2 g1(k) [sgd], 3 fresnel(a.x) */

@@ -322,6 +322,22 @@ class CheckerLib:
         self._fn("glibc_f32")(C.c_int(fn), C.c_int(use_fma), C.c_int64(x.size), _ptr(x), _ptr(y), _ptr(out))
         return out
 
+    def _f64(self, name, fn, x, y):
+        x = np.ascontiguousarray(x, np.float64).reshape(-1)
+        y = np.ascontiguousarray(x if y is None else y, np.float64).reshape(-1)
+        out = np.empty_like(x)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._fn(name)(C.c_int(fn), C.c_int64(x.size), p(x), p(y), p(out))
+        return out
+
+    def libm_f64(self, fn, x, y=None):
+        """host libm exp (0) / pow (1): what the reference's unqualified calls resolve to"""
+        return self._f64("libm_f64", fn, x, y)
+
+    def glibc_f64(self, fn, x, y=None):
+        """restatement of glibc 2.35's exp / pow (the arithmetic the HIP kernels run)"""
+        return self._f64("glibc_f64", fn, x, y)
+
     def erf(self, x):
         x = _f32(x); y = np.empty_like(x)
         self._fn("erf")(C.c_int64(x.size), _ptr(x), _ptr(y))

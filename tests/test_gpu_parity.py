@@ -113,6 +113,41 @@ def test_microfacet_sample(gpu_ctx, oracle, dirs, ndf):
             assert same.all(), f"{ndf} evalp_is {name} {p}: {np.mean(~same):.2e} differ"
 
 
+def test_device_libm_restatements(gpu_ctx, oracle):
+    """The kernels' own copies of glibc's exp / pow (double) and logf / expf / powf (float), evaluated on the GPU
+    (djb_selftest_libm), against the libm of this host -- what the reference calls.  Every bit."""
+    from test_oracle_golden import libm_f64_cases
+    for fn, sets in libm_f64_cases(n=1 << 19).items():
+        for x, y in sets:
+            want = oracle.libm_f64(fn, x, y)
+            got = djb.selftest_libm(("exp", "pow")[fn], x, y, ctx=gpu_ctx)
+            same = (want.view(np.uint64) == got.view(np.uint64)) | (np.isnan(want) & np.isnan(got))
+            if fn == 1:      # pow: negative and subnormal bases are left to the device libm (never reached by the BRDF code): 1 ulp
+                other = ((np.abs(x) < 2.3e-308) & (x != 0)) | (x < 0)
+                with np.errstate(all="ignore"):
+                    close = np.abs(got - want) <= 4 * np.spacing(np.abs(want))
+                same |= other & (close | (np.isinf(want) & (want == got)))
+            assert same.all(), (fn, int((~same).sum()), x[~same][:3], y[~same][:3] if y is not None else None)
+    rng = np.random.default_rng(3)
+    n = 1 << 19
+    anyf = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    with np.errstate(all="ignore"):
+        for name, code, x, y in (("logf", 0, rng.random(n, dtype=np.float32), None), ("logf", 0, anyf, None),
+                                 ("expf", 1, (-30 * rng.random(n)).astype(np.float32), None), ("expf", 1, anyf, None),
+                                 ("powf", 2, rng.random(n, dtype=np.float32), (rng.random(n, dtype=np.float32) * 0.6 + 0.45).astype(np.float32)),
+                                 ("powf", 2, anyf, rng.permutation(anyf))):
+            want = oracle.libm_f32(code, x, y)
+            got = djb.selftest_libm(name, x, y, ctx=gpu_ctx).astype(np.float32)
+            assert np.array_equal(np.isnan(want), np.isnan(got)), name
+            ok = ~np.isnan(want)
+            if name == "powf":       # negative bases (glibc's sign_bias path) are left to the device libm: 1 ulp
+                neg = x < 0
+                assert np.allclose(got[ok & neg], want[ok & neg], rtol=3e-7, atol=0, equal_nan=True)
+                ok &= ~neg
+            bad = ok & (want.view(np.uint32) != got.view(np.uint32))
+            assert not bad.any(), (name, int(bad.sum()), x[bad][:4], None if y is None else y[bad][:4], want[bad][:4], got[bad][:4])
+
+
 def test_io_hd_roundtrip(gpu_ctx, oracle, dirs):
     i, o, _, _ = dirs
     h, d = djb.brdf.io_to_hd(i, o, ctx=gpu_ctx)

@@ -94,6 +94,39 @@ def test_glibc_float_libm_restatement(oracle):
             assert np.array_equal(bits(want)[~nan], bits(got)[~nan]), (fn, int((bits(want)[~nan] != bits(got)[~nan]).sum()))
 
 
+def libm_f64_cases(n=1 << 20, seed=20240918):
+    """argument families for exp / pow: the ranges the BRDF code feeds them, random bit patterns, specials"""
+    rng = np.random.default_rng(seed)
+    bits64 = lambda: rng.integers(0, 1 << 64, n, dtype=np.uint64).view(np.float64)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                   709.782712893384, 709.782712893385, -745.1332191019411, -745.1332191019412, -708.3964185322641, 0.5, 2.0,
+                   511.99999999999994, 512.0, -512.0, 2.0 ** -54, 2.0 ** -55, 1.0 + 2.0 ** -52, 1.0 - 2.0 ** -53], np.float64)
+    f32sq = lambda hi: -(rng.uniform(0, hi, n).astype(np.float32).astype(np.float64)) ** 2
+    with np.errstate(all="ignore"):
+        return {
+            0: [(bits64(), None), (sp, None), (rng.uniform(-40, 40, n), None), (rng.uniform(-800, 800, n), None),
+                (f32sq(6.0), None), (f32sq(40.0), None), (rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-60, 0, n), None)],
+            1: [(bits64(), bits64()), (np.repeat(sp, sp.size), np.tile(sp, sp.size)),
+                (rng.uniform(0, 4, n), rng.uniform(-10, 10, n)), (rng.uniform(0, 1e3, n), rng.uniform(0, 3, n)),
+                (rng.uniform(0.03, 1.2, n), np.full(n, np.float64(np.float32(2.4)))),           # sRGB decode, dj_brdf.h:1148
+                (1 + rng.uniform(0, 3000, n) * rng.uniform(0, 1, n), rng.uniform(0.1, 3, n)),   # abc ndf, :3610
+                (rng.uniform(0, 1, n), np.full(n, 5.0)), (rng.uniform(0, 1, n), np.full(n, 6.0)),   # :1326, :2503
+                (rng.uniform(0, 100, n), rng.uniform(-400, 400, n))],
+        }
+
+
+def test_glibc_double_libm_restatement(oracle):
+    """Same for the double exp / pow the reference's unqualified calls resolve to (oracle/djb_oracle.c
+    glibc_exp / glibc_pow; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma / __pow_fma)."""
+    for fn, sets in libm_f64_cases().items():
+        for x, y in sets:
+            want, got = oracle.libm_f64(fn, x, y), oracle.glibc_f64(fn, x, y)
+            nan = np.isnan(want)
+            assert np.array_equal(nan, np.isnan(got)), fn
+            diff = want.view(np.uint64)[~nan] != got.view(np.uint64)[~nan]
+            assert not diff.any(), (fn, int(diff.sum()))
+
+
 def test_params_and_math(oracle):
     g = np.load(os.path.join(G, "math.npz"))
     for k, p in enumerate(PARAM_CASES):

@@ -13,6 +13,16 @@ tab = rng.uniform(0.0, 120.0, size=3 * 288 * 288)
 u = djb.utia.from_table(tab, ctx=ctx)
 out = torch.empty((3, n), dtype=torch.float32, device=i.device)
 vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
+pdf = torch.empty((n,), dtype=torch.float32, device=i.device)
+iso = djb.microfacet.params.isotropic(0.3)
+for name, b in (("ggx", djb.ggx(ctx=ctx)), ("beckmann", djb.beckmann(ctx=ctx)), ("beckmann schlick", djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), ctx=ctx))):
+    def run():
+        _lib.check(lib.djb_eval_pdf_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), C.byref(iso._p), C.c_int(0), C.byref(vout.view),
+                                          C.c_void_p(pdf.data_ptr()), C.c_int(0)))
+    run(); torch.cuda.synchronize(); ctx.timer_start()
+    for _ in range(3): run()
+    ms = ctx.timer_stop_ms() / 3
+    print(f"{name:16s} eval+pdf: {ms:8.3f} ms per 1e8 -> {n/ms/1e6:7.2f} G/s ({40*n/ms/1e6/8000*100:.1f} % of HBM at 40 B/pair)")
 for name, b in (("utia", u), ("sgd", djb.sgd("gold-metallic-paint", ctx=ctx)), ("abc", djb.abc("gold-metallic-paint", ctx=ctx)),
                 ("tabular(ggx)", djb.tabular(djb.ggx(ctx=ctx), 90, True, ctx=ctx))):
     for _ in range(2):

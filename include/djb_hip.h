@@ -249,7 +249,7 @@ djb_status djb_merl_guard_stats(djb_ctx *, int64_t n, const djb_vec3_view *i, co
  * fallbacks, sRGB-decode mismatches, sRGB-decode fallbacks, 0, 0}; every mismatch count must be 0. */
 djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters8);
 /* the kernels' restatements of the host libm functions the reference calls (glibc 2.35: double exp / pow,
- * float logf / expf / powf -- dj_brdf.h:685, 695, 1868, 1917, 1935, 3418-3431, 3610), evaluated on the GPU for
+ * float logf / expf / powf -- dj_brdf.h:685, 695, 1868, 1917, 1935, 3419, 3431, 3612), evaluated on the GPU for
  * host arrays: fn 0 exp(x), 1 pow(x, y), 2 logf(x), 3 expf(x), 4 powf(x, y) (float functions on the values cast
  * to float).  The test-suite compares `out` with the libm of the host, bit for bit. */
 djb_status djb_selftest_libm(djb_ctx *, int fn, int64_t n, const double *x, const double *y, double *out);

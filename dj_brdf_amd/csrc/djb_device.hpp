@@ -254,8 +254,13 @@ DJB_DEV double glibc_pow(double x, double y, const double *PT = nullptr, const u
 	double ehi = y * lhi;
 	double elo = __builtin_fma(y, llo, __builtin_fma(lhi, y, -ehi));
 	double res = glibc_exp_inline(ehi, elo, true, ET ? ET : DJB_GLIBC_EXP_TAB);
-	// zero / negative / subnormal / Inf / NaN bases, |y| outside [2^-65, 2^63): exact special values, device libm
-	if (__builtin_expect(other, 0)) res = pow(x, y);
+	if (__builtin_expect(other, 0)) {
+		// +0 base, finite non-zero exponent in range (sgd's max(0, theta - theta0)^k): e_pow.c returns x*x or 1/(x*x)
+		if ((hx | (unsigned int)__double2loint(x)) == 0u && (topy & 0x7ffu) - 0x3beu < 0x43eu - 0x3beu)
+			res = (hy >> 31) ? __longlong_as_double(0x7ff0000000000000ll) : 0.0;
+		// negative / subnormal / Inf / NaN bases, |y| outside [2^-65, 2^63): exact special values, device libm
+		else res = pow(x, y);
+	}
 	return res;
 }
 DJB_DEV const double *glibc_pow_tab_to_lds(double *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards

@@ -2005,7 +2005,10 @@ static double glibc_pow(double x, double y)
 	uint64_t ix = asu64(x), iy = asu64(y);
 	uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
 	/* zero, negative, subnormal, Inf, NaN bases and |y| outside [2^-65, 2^63): host libm (exact special values) */
-	if (topx - 0x001 >= 0x7ff - 0x001 || (topy & 0x7ff) - 0x3be >= 0x43e - 0x3be) return pow(x, y);
+	if (topx - 0x001 >= 0x7ff - 0x001 || (topy & 0x7ff) - 0x3be >= 0x43e - 0x3be) {
+		if (ix == 0 && (topy & 0x7ff) - 0x3be < 0x43e - 0x3be) return (iy >> 63) ? INFINITY : 0.0;   /* +0 base: x*x or 1/(x*x) */
+		return pow(x, y);
+	}
 	uint64_t tmp = ix - 0x3fe6955500000000ull;
 	int i = (int)((tmp >> 45) % 128);
 	int64_t k = (int64_t)tmp >> 52;

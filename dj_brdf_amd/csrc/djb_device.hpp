@@ -48,10 +48,9 @@ struct Brdf {
 	// two-level sampling tables below (dj_brdf.h:429-438)
 	const float *a_pdf1, *a_cdf1, *a_qf1, *a_pdf2, *a_cdf2, *a_qf2;
 	int elev, azim, n_a_cdf1, n_a_qf1;
-	// where glibc_exp() reads its 2 KB table: nullptr = the global copy; the Beckmann kernels stage it in LDS
-	// and point here (set by the kernel on its own copy of the struct, never by the host)
-	const unsigned long long *exp_tab;
-	const double *pow_tab;                  // same for glibc_pow()'s 3 KB log table (sgd / abc kernels)
+	// where glibc_exp() / glibc_pow() read their tables (LdsTab: 0 = the global copy, else 1 + the LDS byte offset
+	// of a copy staged by the kernel, which sets these on its own copy of the struct; the host leaves them 0)
+	unsigned int exp_lds, pow_lds;
 };
 
 struct View { float *x, *y, *z; long long stride; };
@@ -148,8 +147,24 @@ DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 // tests/test_gpu_parity.py::test_device_libm_restatements.  exp is complete; pow hands zero / negative /
 // subnormal / Inf / NaN bases and exponents outside [2^-65, 2^63) -- exact special values -- to the device libm.
 #include "djb_glibc_dbl64_tables.hpp"
+// LDS copies of the tables are addressed through address-space-3 pointers rebuilt from a 32-bit offset, so that
+// the look-ups compile to ds_read (a generic pointer that may be global or LDS compiles to flat_load); the
+// offset form also keeps `Brdf` the same size for the host and the device compilation.
+typedef unsigned int LdsTab;
+typedef const __attribute__((address_space(3))) unsigned long long *lds_u64p;
+typedef const __attribute__((address_space(3))) double *lds_f64p;
+DJB_DEV LdsTab glibc_exp_tab_to_lds(unsigned long long *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
+{
+	for (int k = tid; k < 256; k += nthreads) lds[k] = DJB_GLIBC_EXP_TAB[k];
+	return 1u + (unsigned int)(uintptr_t)(lds_u64p)lds;
+}
+DJB_DEV LdsTab glibc_pow_tab_to_lds(double *lds, int tid, int nthreads)               // caller: __syncthreads() afterwards
+{
+	for (int k = tid; k < 384; k += nthreads) lds[k] = DJB_GLIBC_POW_LOG_TAB[k];
+	return 1u + (unsigned int)(uintptr_t)(lds_f64p)lds;
+}
 // tmp and the scale bits of exp()/exp_inline(): r = x - k ln2/N, tmp = tail + r + r^2 p(r), scale = 2^(k/N)
-DJB_DEV double glibc_exp_tmp(double x, double xtail, unsigned int &klo, unsigned int &sh, int &sl, const unsigned long long *T)
+DJB_DEV double glibc_exp_tmp(double x, double xtail, unsigned int &klo, unsigned int &sh, int &sl, LdsTab T)
 {
 	constexpr double InvLn2N = DJB_GLIBC_EXP_C[0], Shift = DJB_GLIBC_EXP_C[1], NegLn2hiN = DJB_GLIBC_EXP_C[2],
 	                 NegLn2loN = DJB_GLIBC_EXP_C[3], C2 = DJB_GLIBC_EXP_C[4], C3 = DJB_GLIBC_EXP_C[5],
@@ -161,8 +176,10 @@ DJB_DEV double glibc_exp_tmp(double x, double xtail, unsigned int &klo, unsigned
 	r = __builtin_fma(kd, NegLn2loN, r);
 	r += xtail;
 	const unsigned int idx = 2u * (klo & 127u);
-	const double tail = __longlong_as_double((long long)T[idx]);
-	const unsigned long long sb = T[idx + 1];
+	unsigned long long tb, sb;                                            // {tail bits, scale bits}: one 16-byte entry
+	if (T) { lds_u64p L = (lds_u64p)(uintptr_t)(T - 1u); tb = L[idx]; sb = L[idx + 1]; }
+	else { tb = DJB_GLIBC_EXP_TAB[idx]; sb = DJB_GLIBC_EXP_TAB[idx + 1]; }
+	const double tail = __longlong_as_double((long long)tb);
 	sh = (unsigned int)(sb >> 32) + (klo << 13);                         // sbits = tab + (ki << 45): only the high word changes
 	sl = (int)(unsigned int)sb;
 	double r2 = r * r;
@@ -183,7 +200,7 @@ static __device__ __attribute__((noinline)) double glibc_exp_cold(double x, doub
 		return (hx >> 31) ? 0.0 : __longlong_as_double(0x7ff0000000000000ll);
 	}
 	unsigned int klo, sh; int sl;
-	const double tmp = glibc_exp_tmp(x, xtail, klo, sh, sl, DJB_GLIBC_EXP_TAB);
+	const double tmp = glibc_exp_tmp(x, xtail, klo, sh, sl, 0u);
 	if ((klo & 0x80000000u) == 0) {
 		const double scale = __hiloint2double((int)(sh - (1009u << 20)), sl);
 		return 0x1p1009 * __builtin_fma(scale, tmp, scale);
@@ -201,7 +218,7 @@ static __device__ __attribute__((noinline)) double glibc_exp_cold(double x, doub
 	return 0x1p-1022 * y;
 }
 // the main path runs unconditionally (garbage outside its domain) and one rarely taken branch replaces it
-DJB_DEV double glibc_exp_inline(double x, double xtail, bool is_pow, const unsigned long long *T)
+DJB_DEV double glibc_exp_inline(double x, double xtail, bool is_pow, LdsTab T)
 {
 	const unsigned int abstop = ((unsigned int)__double2hiint(x) >> 20) & 0x7ffu;
 	unsigned int klo, sh; int sl;
@@ -211,16 +228,10 @@ DJB_DEV double glibc_exp_inline(double x, double xtail, bool is_pow, const unsig
 	if (__builtin_expect(abstop - 0x3c9u >= 0x3fu, 0)) y = glibc_exp_cold(x, xtail, abstop, is_pow);
 	return y;
 }
-// T: DJB_GLIBC_EXP_TAB or an LDS copy of it (glibc_exp_tab_to_lds)
-DJB_DEV double glibc_exp(double x, const unsigned long long *T = nullptr) { return glibc_exp_inline(x, 0.0, false, T ? T : DJB_GLIBC_EXP_TAB); }
-DJB_DEV const unsigned long long *glibc_exp_tab_to_lds(unsigned long long *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
-{
-	for (int k = tid; k < 256; k += nthreads) lds[k] = DJB_GLIBC_EXP_TAB[k];
-	return lds;
-}
-DJB_DEV const double *glibc_pow_tab_to_lds(double *lds, int tid, int nthreads);
-// PT / ET: the log and exp tables (nullptr = the global copies; see Brdf::pow_tab / exp_tab)
-DJB_DEV double glibc_pow(double x, double y, const double *PT = nullptr, const unsigned long long *ET = nullptr)
+// T: where the table is read from (0 = global copy, or the handle of an LDS copy)
+DJB_DEV double glibc_exp(double x, LdsTab T = 0u) { return glibc_exp_inline(x, 0.0, false, T); }
+// PT / ET: the log and exp tables (0 = the global copies; see Brdf::pow_lds / exp_lds)
+DJB_DEV double glibc_pow(double x, double y, LdsTab PT = 0u, LdsTab ET = 0u)
 {
 	constexpr double Ln2hi = DJB_GLIBC_POW_C[0], Ln2lo = DJB_GLIBC_POW_C[1], A0 = DJB_GLIBC_POW_C[2], A1 = DJB_GLIBC_POW_C[3],
 	                 A2 = DJB_GLIBC_POW_C[4], A3 = DJB_GLIBC_POW_C[5], A4 = DJB_GLIBC_POW_C[6], A5 = DJB_GLIBC_POW_C[7],
@@ -234,8 +245,9 @@ DJB_DEV double glibc_pow(double x, double y, const double *PT = nullptr, const u
 	const int k = (int)tmph >> 20;
 	const double z = __hiloint2double((int)(hx - (tmph & 0xfff00000u)), __double2loint(x));
 	const double kd = (double)k;
-	const double *T = (PT ? PT : DJB_GLIBC_POW_LOG_TAB) + 3 * i;
-	const double invc = T[0], logc = T[1], logctail = T[2];
+	double invc, logc, logctail;
+	if (PT) { lds_f64p L = (lds_f64p)(uintptr_t)(PT - 1u) + 3 * i; invc = L[0]; logc = L[1]; logctail = L[2]; }
+	else { const double *T = DJB_GLIBC_POW_LOG_TAB + 3 * i; invc = T[0]; logc = T[1]; logctail = T[2]; }
 	double r = __builtin_fma(z, invc, -1.0);
 	double t1 = __builtin_fma(kd, Ln2hi, logc);
 	double t2 = t1 + r;
@@ -253,7 +265,7 @@ DJB_DEV double glibc_pow(double x, double y, const double *PT = nullptr, const u
 	double llo = hi - lhi + lo;
 	double ehi = y * lhi;
 	double elo = __builtin_fma(y, llo, __builtin_fma(lhi, y, -ehi));
-	double res = glibc_exp_inline(ehi, elo, true, ET ? ET : DJB_GLIBC_EXP_TAB);
+	double res = glibc_exp_inline(ehi, elo, true, ET);
 	if (__builtin_expect(other, 0)) {
 		// +0 base, finite non-zero exponent in range (sgd's max(0, theta - theta0)^k): e_pow.c returns x*x or 1/(x*x)
 		if ((hx | (unsigned int)__double2loint(x)) == 0u && (topy & 0x7ffu) - 0x3beu < 0x43eu - 0x3beu)
@@ -262,11 +274,6 @@ DJB_DEV double glibc_pow(double x, double y, const double *PT = nullptr, const u
 		else res = pow(x, y);
 	}
 	return res;
-}
-DJB_DEV const double *glibc_pow_tab_to_lds(double *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
-{
-	for (int k = tid; k < 384; k += nthreads) lds[k] = DJB_GLIBC_POW_LOG_TAB[k];
-	return lds;
 }
 
 // A&S 7.1.26 as the reference writes it, dj_brdf.h:667-688
@@ -283,7 +290,7 @@ DJB_DEV float erf_given_exp(float x, double e)
 	float y = F(1.0 - D(poly * t) * e);
 	return sign * y;
 }
-DJB_DEV float erf_(float x, const unsigned long long *T = nullptr) { return erf_given_exp(x, glibc_exp(D(-x * x), T)); }
+DJB_DEV float erf_(float x, LdsTab T = 0u) { return erf_given_exp(x, glibc_exp(D(-x * x), T)); }
 
 // ---- glibc 2.35's float logf / expf / powf, restated -------------------------------------------
 // The reference calls the float libm in erfinv (logf) and in Beckmann's Newton inversion (powf, expf),
@@ -299,8 +306,8 @@ DJB_DEV float erf_(float x, const unsigned long long *T = nullptr) { return erf_
 // where the indexed tables are read from: the global copies by default; hot kernels stage them in LDS
 // (glibc_tabs_to_lds: 768 B) because the Newton loop looks them up twice per iteration.  The scalar
 // coefficients are compile-time constants (SGPRs / literals, not per-lane registers).
-struct GlibcTabs { const double *logf, *powlog; const unsigned long long *exp2; const unsigned long long *exp64; };
-DJB_DEV GlibcTabs glibc_tabs_global() { GlibcTabs t = { DJB_GLIBC_LOGF, DJB_GLIBC_POWF_LOG2, DJB_GLIBC_EXP2F_TAB, DJB_GLIBC_EXP_TAB }; return t; }
+struct GlibcTabs { const double *logf, *powlog; const unsigned long long *exp2; LdsTab exp64; };
+DJB_DEV GlibcTabs glibc_tabs_global() { GlibcTabs t = { DJB_GLIBC_LOGF, DJB_GLIBC_POWF_LOG2, DJB_GLIBC_EXP2F_TAB, 0u }; return t; }
 constexpr int GLIBC_LDS_WORDS = 32 + 32 + 32;    // 8-byte words
 DJB_DEV GlibcTabs glibc_tabs_to_lds(double *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
 {
@@ -311,7 +318,7 @@ DJB_DEV GlibcTabs glibc_tabs_to_lds(double *lds, int tid, int nthreads)   // cal
 		else v = __longlong_as_double((long long)DJB_GLIBC_EXP2F_TAB[k - 64]);
 		lds[k] = v;
 	}
-	GlibcTabs t = { lds, lds + 32, (const unsigned long long *)(lds + 64), DJB_GLIBC_EXP_TAB };
+	GlibcTabs t = { lds, lds + 32, (const unsigned long long *)(lds + 64), 0u };
 	return t;
 }
 DJB_DEV float glibc_logf(float x, const GlibcTabs &gt)
@@ -552,7 +559,7 @@ DJB_DEV v3 fresnel_eval(const Fresnel &f, float c)
 // ------------------------------------------------------------------ radial NDFs (dj_brdf.h:1866-2176)
 template <int KIND> DJB_DEV float p22_radial(const Brdf &b, float r_sqr)
 {
-	if (KIND == KIND_BECKMANN) return F(glibc_exp(D(-r_sqr), b.exp_tab) / DJB_PI);                      // :1866
+	if (KIND == KIND_BECKMANN) return F(glibc_exp(D(-r_sqr), b.exp_lds) / DJB_PI);                      // :1866
 	if (KIND == KIND_GGX) { float t = 1.0f + r_sqr; /* == float(1.0 + double(r_sqr)) */ return recip_to_f32(DJB_PI * D(t) * D(t)); } // :2056
 	float r = sqrtf(r_sqr);                                                             // :2151
 	float u = F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI))));
@@ -565,7 +572,7 @@ template <int KIND> DJB_DEV float sigma_std_radial(const Brdf &b, float c)
 		if (D(c) == 1.0) return 1.0f;
 		float s = F(sqrt(1.0 - D(c * c)));
 		float nu = c / s;
-		const double e = glibc_exp(D(-nu * nu), b.exp_tab);              // also the exponential inside erf(nu)
+		const double e = glibc_exp(D(-nu * nu), b.exp_lds);              // also the exponential inside erf(nu)
 		float tmp = F(e * D(inversesqrt_(F(DJB_PI))));
 		return F((D(c) * (1.0 + D(erf_given_exp(nu, e))) + D(s * tmp)) / 2.0);
 	}
@@ -643,7 +650,7 @@ DJB_DEV float aniso_qf2(const Brdf &b, float u, float phi)                      
 // analytic cdf / quantile of the radial slope distribution (dj_brdf.h:1881-1889, 2067-2076)
 template <int KIND> DJB_DEV float cdf_radial(const Brdf &b, float r)
 {
-	if (KIND == KIND_BECKMANN) return F(1.0 - glibc_exp(D(-r * r), b.exp_tab));
+	if (KIND == KIND_BECKMANN) return F(1.0 - glibc_exp(D(-r * r), b.exp_lds));
 	if (KIND == KIND_GGX) { float t = r * r; return F(D(t) / (1.0 + D(t))); }
 	return tab_cdf_radial(b, r);
 }
@@ -1211,7 +1218,7 @@ DJB_DEV void lrep_to_pdfparams(Lrep l, float &ax, float &ay, float &rho, float &
 DJB_DEV double sgd_g1(const Brdf &b, v3 k, double theta0, double c, double k_, double lambda)           // :3415
 {
 	double t1 = fmax(0.0, acos(D(k.z)) - theta0);
-	double t2 = 1.0 - glibc_exp(c * glibc_pow(t1, k_, b.pow_tab, b.exp_tab), b.exp_tab);
+	double t2 = 1.0 - glibc_exp(c * glibc_pow(t1, k_, b.pow_lds, b.exp_lds), b.exp_lds);
 	double t3 = 1.0 + lambda * t2;
 	return fmin(1.0, fmax(0.0, t3));
 }
@@ -1221,7 +1228,7 @@ DJB_DEV double sgd_ndf(const Brdf &b, double ch, double alpha, double p, double 
 	double c2 = ch * ch;
 	double t2 = (1.0 - c2) / c2;
 	double ax = alpha + t2 / alpha;
-	return (kap * glibc_exp(-ax, b.exp_tab) * inv_pi) / (glibc_pow(ax, p, b.pow_tab, b.exp_tab) * c2 * c2);
+	return (kap * glibc_exp(-ax, b.exp_lds) * inv_pi) / (glibc_pow(ax, p, b.pow_lds, b.exp_lds) * c2 * c2);
 }
 // model row: rhoD rhoS alpha p f0 f1 kap lambda c k theta0 (3 doubles each)
 DJB_DEV v3 sgd_g1_rgb(const Brdf &b, v3 k)                                                // sgd::g1, :3477
@@ -1267,7 +1274,7 @@ DJB_DEV float abc_gaf(v3 h, v3 i, v3 o)                                         
 DJB_DEV v3 abc_ndf_rgb(const Brdf &b, v3 h)                                               // abc::ndf, :3657 + abc__ndf :3608
 {
 	const double *m = b.model;
-	double den = glibc_pow(1.0 + m[6] * (1.0 - D(h.z)), m[7], b.pow_tab, b.exp_tab);
+	double den = glibc_pow(1.0 + m[6] * (1.0 - D(h.z)), m[7], b.pow_lds, b.exp_lds);
 	return mk(F(m[3] / den), F(m[4] / den), F(m[5] / den));
 }
 DJB_DEV v3 abc_eval(const Brdf &b, v3 i, v3 o)                                            // :3633

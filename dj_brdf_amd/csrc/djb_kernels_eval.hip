@@ -67,8 +67,8 @@ __global__ __launch_bounds__(BLOCK, (KIND <= KIND_TABULAR || KIND == KIND_TABULA
 	constexpr bool EXPT = KIND == KIND_BECKMANN || KIND == KIND_SGD || KIND == KIND_ABC, POWT = KIND == KIND_SGD || KIND == KIND_ABC;
 	__shared__ unsigned long long s_exp[EXPT ? 256 : 1];
 	__shared__ double s_pow[POWT ? 384 : 1];
-	if (EXPT) b.exp_tab = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
-	if (POWT) b.pow_tab = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
+	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
 	if (EXPT || POWT) __syncthreads();
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi,
                                                    Lrep base, View vout, float *out_pdf, float *out_pp)
 {
 	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];     // as in k_eval
-	if (KIND == KIND_BECKMANN) { b.exp_tab = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK); __syncthreads(); }
+	if (KIND == KIND_BECKMANN) { b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK); __syncthreads(); }
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		v3 i = load3(vi, k), o = load3(vo, k);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];     // the fp64 exp table, as in k_eval
 	if (KIND == KIND_BECKMANN) {
 		gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
-		gt.exp64 = b.exp_tab = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+		gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
 		__syncthreads();
 	}
 	long long stride = (long long)gridDim.x * BLOCK;

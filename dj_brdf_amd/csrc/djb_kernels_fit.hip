@@ -106,7 +106,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	self.fr.kind = FR_IDEAL; self.fr.pts = nullptr; self.fr.npts = 0;
 	self.p22 = p22; self.sigma = sigma; self.cdf = cdf; self.qf = qf;
 	self.n_p22 = res; self.n_sigma = res; self.n_cdf = res; self.n_qf = res;
-	self.merl = nullptr; self.utia = nullptr; self.exp_tab = nullptr; self.pow_tab = nullptr;
+	self.merl = nullptr; self.utia = nullptr; self.exp_lds = 0u; self.pow_lds = 0u;
 
 	// ================================================================ compute_p22_smith (dj_brdf.h:2482-2522)
 	const float dtheta_k = F(sqrt(DJB_PI * 0.5) / D((float)cnt));

@@ -59,6 +59,7 @@ struct djb_ctx {
 	// device-visible arena and the kernels read / write it directly over PCIe -- no hipMemcpy, one sync
 	char *pin = nullptr;
 	size_t pin_bytes = 0;
+	int n_cus = 0;            // compute units of the device (how many fit workgroups run at once)
 };
 
 struct djb_brdf {
@@ -540,6 +541,7 @@ static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **o
 	c->owns_stream = own;
 	c->stream = (hipStream_t)hip_stream;
 	c->scratch = nullptr; c->scratch_bytes = 0; c->merl_exact_only = 0;
+	if (hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { c->n_cus = 0; (void)hipGetLastError(); }
 	if (own) {
 		hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 		if (e != hipSuccess) { delete c; return fail(DJB_ERR_HIP, "djb_error: hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -824,7 +826,10 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 	size_t total = 0;
 	auto reserve = [&](size_t bytes) { size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
 	const size_t o_srcs = reserve(sizeof(Brdf) * n_mat);
-	const size_t o_km = reserve(sizeof(double) * (size_t)n_mat * cnt * cnt);
+	djbk::FitSplit split;
+	split.parts = djbk::fit_parts(n_mat, ctx->n_cus);
+	const size_t o_km = reserve(sizeof(double) * (size_t)n_mat * split.parts * cnt * cnt);
+	const size_t o_sigx = reserve(sizeof(float) * (size_t)n_mat * res), o_done = reserve(sizeof(unsigned int) * n_mat);
 	const size_t o_ratio = reserve(sizeof(float) * 3 * (size_t)n_mat * cnt * (cnt + 1));
 	const size_t o_p22 = reserve(sizeof(float) * (size_t)n_mat * res), o_sigma = reserve(sizeof(float) * (size_t)n_mat * res);
 	const size_t o_cdf = reserve(sizeof(float) * (size_t)n_mat * res), o_qf = reserve(sizeof(float) * (size_t)n_mat * res);
@@ -840,7 +845,8 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 	o.qf = (float *)(base + o_qf); o.fresnel = (float *)(base + o_fres);
 	o.alpha_beckmann = (float *)(base + o_ab); o.alpha_ggx = (float *)(base + o_ag); o.n_qf = (int *)(base + o_nqf);
 	HIP_TRY(hipMemcpyAsync(d_srcs, srcs.data(), sizeof(Brdf) * n_mat, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(djbk::launch_fit(ctx->stream, d_srcs, src_kind, std_p, n_mat, res, shadow != 0, km, ratio, o));
+	split.sig_x = (float *)(base + o_sigx); split.sig_done = (unsigned int *)(base + o_done);
+	HIP_TRY(djbk::launch_fit(ctx->stream, d_srcs, src_kind, std_p, n_mat, res, shadow != 0, km, ratio, o, split));
 	auto back = [&](void *h, const void *d, size_t bytes) -> hipError_t {
 		return h ? hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
 	};

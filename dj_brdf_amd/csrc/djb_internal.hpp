@@ -65,11 +65,16 @@ struct FitOut {           // device pointers, [n_mat][res] (fresnel [n_mat][res]
 	float *alpha_beckmann, *alpha_ggx;
 	int *n_qf;            // number of valid qf entries per material (reference quirk, dj_brdf.h:2731)
 };
+// The sigma quadrature of one material can be sliced by rows over `parts` workgroups (fit_parts(n_mat)): parts - 1
+// helper workgroups per material redo the cheap phases before it, compute their slice of the rows and hand them
+// over through sig_x [n_mat][res] + the arrival counters sig_done [n_mat] (zeroed by launch_fit).
+struct FitSplit { int parts; float *sig_x; unsigned int *sig_done; };
+int fit_parts(int n_mat, int n_cus);
 // srcs: device array of n_mat Brdf views (all of kind `src_kind`); std_p: params::standard().
-// km_scratch: n_mat*(res-1)^2 doubles; ratio_scratch: n_mat*(res-1)*res*3 floats.
+// km_scratch: n_mat*parts*(res-1)^2 doubles; ratio_scratch: n_mat*(res-1)*res*3 floats.
 hipError_t launch_fit(hipStream_t s, const Brdf *srcs, int src_kind, const Params &std_p, int n_mat,
                       int res, int shadow, double *km_scratch, float *ratio_scratch,
-                      const FitOut &out);
+                      const FitOut &out, const FitSplit &split);
 size_t fit_lds_bytes(int res);
 
 // ---- tabular_anisotropic (djb_kernels_fit_aniso.hip): all pointers are device memory

@@ -13,6 +13,7 @@
 // are independent and map to lanes; wave64 lanes of one row-owner wave broadcast-read the shared
 // per-node tables from LDS.  No MFMA: the only matrix product is an (res-1)^2 matvec in double,
 // four times (dj_brdf.h:2467-2480), whose summation order is likewise kept.
+#include <cstdlib>
 #include "djb_internal.hpp"
 
 using namespace djbdev;
@@ -37,7 +38,7 @@ struct LdsPlan {   // byte offsets into dynamic LDS (doubles first: 8-byte align
 	int terms;                               // floats [2*128]
 	int qprobe;                              // floats [8*cnt]
 	int skv, ckv;                            // floats [cnt]: sin / cos of theta_k (sigma rows)
-	int stile;                               // floats [2][cnt][sig_tile + 1]: double-buffered tiles of sigma terms
+	int stile;                               // floats [2][cnt][sig_tile + 4]: double-buffered tiles of sigma terms (rows 16-byte aligned)
 	int total;
 };
 
@@ -56,7 +57,7 @@ __host__ __device__ inline LdsPlan make_plan(int res)
 	p.terms = take(4 * 2 * NTHETA_FIT);
 	p.qprobe = take(4 * 8 * cnt);
 	p.skv = take(4 * cnt); p.ckv = take(4 * cnt);
-	p.stile = take(4 * 2 * cnt * (sig_tile(cnt) + 1));
+	p.stile = take(4 * 2 * cnt * (sig_tile(cnt) + 4));
 	p.total = off;
 	return p;
 }
@@ -76,12 +77,17 @@ DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o)
 }
 
 template <int SRC>
-__global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_p, int res, int shadow,
+__global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_p, int n_mat, int res, int shadow,
                                                    double *km_scratch, float *ratio_scratch,
-                                                   djbk::FitOut out)
+                                                   djbk::FitOut out, djbk::FitSplit split)
 {
 	extern __shared__ __align__(16) unsigned char lds[];
-	const int m = blockIdx.x, tid = threadIdx.x, cnt = res - 1;
+	// blocks [0, n_mat * (parts - 1)) are the helpers (dispatched first: they never wait), the last n_mat blocks
+	// run the whole fit of material m and pick the helpers' sigma rows up
+	const int parts = split.parts, n_help = n_mat * (parts - 1);
+	const int part = (int)blockIdx.x < n_help ? 1 + (int)blockIdx.x / n_mat : 0;
+	const int m = (int)blockIdx.x < n_help ? (int)blockIdx.x % n_mat : (int)blockIdx.x - n_help;
+	const int tid = threadIdx.x, cnt = res - 1;
 	const LdsPlan P = make_plan(res);
 	double *v0 = (double *)(lds + P.v0), *v1 = (double *)(lds + P.v1);
 	double *cphid = (double *)(lds + P.cphid), *cthd = (double *)(lds + P.cthd);
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	__shared__ float s_scale;
 
 	const Brdf src = srcs[m];
-	double *kmT = km_scratch + (size_t)m * cnt * cnt;            // kmT[theta_h][theta_o]
+	double *kmT = km_scratch + (size_t)blockIdx.x * cnt * cnt;   // kmT[theta_h][theta_o], private to the workgroup
 	float *ratio = ratio_scratch + (size_t)m * cnt * (cnt + 1) * 3;
 
 	// the object under construction: tabular NDF, ideal Fresnel until compute_fresnel finishes
@@ -196,7 +202,9 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		// tile of nodes (thread = node x row group: the node's table values stay in registers, sin / cos
 		// of theta_k are LDS broadcasts) into one LDS buffer while the waves that own the rows add the
 		// previous tile's terms front to back from the other buffer.  Same terms, same order as the
-		// one-lane-per-row loop this replaces (1.14 ms of the 1.57 ms kernel).
+		// one-lane-per-row loop this replaces (1.14 ms of the 1.57 ms kernel).  When CUs are idle (fewer
+		// materials than CUs) the rows are sliced over `parts` workgroups per material, which shortens the
+		// producers' share of every tile: one material 0.71 -> 0.53 ms (8 slices), 100 materials 0.76 -> 0.71 (2).
 		const float dth = F(DJB_PI / D((float)NTHETA_SIGMA));
 		const float dph = F(2.0 * DJB_PI / D((float)NPHI_SIGMA));
 		for (int k = tid; k < cnt; k += FIT_BLOCK) {
@@ -204,40 +212,79 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			float theta_k = F(D(tmp) * 0.5 * DJB_PI);
 			ckv[k] = F(cos(D(theta_k))); skv[k] = F(sin(D(theta_k)));
 		}
-		const int T = sig_tile(cnt), TS = T + 1;
+		const int T = sig_tile(cnt), TS = T + 4;             // row stride: 16-byte aligned rows for the owners' float4 reads
 		const int n_sum = ((cnt + 63) / 64) * 64;            // threads [0, n_sum): row owners (whole waves)
 		const int n_prod = FIT_BLOCK - n_sum;                // threads [n_sum, FIT_BLOCK): producers
 		const int a = tid - n_sum, col = a % T, grp = a / T, ngrp = n_prod / T;
 		const int ntiles = (NNODE_SIGMA + T - 1) / T;
-		auto produce = [&](int t) {
-			const int e = t * T + col;
-			if (a < 0 || grp >= ngrp) return;
-			float *buf = stile + (t & 1) * cnt * TS;
-			if (e >= NNODE_SIGMA) {                              // pad the last tile: x + 0.0f == x
-				for (int k = grp; k < cnt; k += ngrp) buf[k * TS + col] = 0.0f;
+		// rows [r0, r1) of the quadrature; every workgroup of the material runs the same code on its slice
+		auto sigma_rows = [&](int r0, int r1) {
+			auto produce = [&](int t) {
+				const int e = t * T + col;
+				if (a < 0 || grp >= ngrp) return;
+				float *buf = stile + (t & 1) * cnt * TS;
+				if (e >= NNODE_SIGMA) {                              // pad the last tile: x + 0.0f == x
+					for (int k = r0 + grp; k < r1; k += ngrp) buf[k * TS + col] = 0.0f;
+					return;
+				}
+				const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
+				const double cp = cphid[j2], ct = cthd[j1];
+				const float s1 = sh[j1], nd = ndf_tab[e], w = ui[j1];
+				for (int k = r0 + grp; k < r1; k += ngrp) {
+					float kh = F(D(skv[k] * s1) * cp + D(ckv[k]) * ct);
+					buf[k * TS + col] = fmax_(0.0f, kh) * nd * w * s1;
+				}
+			};
+			__syncthreads();
+			produce(0);
+			__syncthreads();
+			float nint = 0.0f;                                   // row accumulator of thread tid (r0 <= tid < r1)
+			for (int t = 0; t < ntiles; ++t) {
+				if (tid >= n_sum) { if (t + 1 < ntiles) produce(t + 1); }
+				else if (tid >= r0 && tid < r1) {
+					// the tile's T terms of this row: all loads first (8 x 16 bytes in flight), then the adds in
+					// the reference's order -- a load-add-load-add chain exposes the LDS latency 64 times per tile
+					const float4 *row = (const float4 *)(stile + (t & 1) * cnt * TS + tid * TS);
+					for (int c = 0; c < T / 4; c += 8) {
+						float4 v[8];
+#pragma unroll
+						for (int j = 0; j < 8; ++j) v[j] = row[c + j];
+#pragma unroll
+						for (int j = 0; j < 8; ++j) { nint += v[j].x; nint += v[j].y; nint += v[j].z; nint += v[j].w; }   // zero-padded last tile: x + 0.0f == x
+					}
+				}
+				__syncthreads();
+			}
+			if (tid >= r0 && tid < r1) { nint *= dth * dph; sigma[tid] = fmax_(ckv[tid], nint); }
+		};
+		const int r0 = (cnt * part) / parts, r1 = (cnt * (part + 1)) / parts;
+		sigma_rows(r0, r1);
+		if (parts > 1) {
+			float *sx = split.sig_x + (size_t)m * res;
+			unsigned int *done = split.sig_done + m;
+			if (part > 0) {      // helper: publish the rows, signal, leave
+				if (tid >= r0 && tid < r1) sx[tid] = sigma[tid];
+				__threadfence();
+				__syncthreads();
+				if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				return;
 			}
-			const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
-			const double cp = cphid[j2], ct = cthd[j1];
-			const float s1 = sh[j1], nd = ndf_tab[e], w = ui[j1];
-			for (int k = grp; k < cnt; k += ngrp) {
-				float kh = F(D(skv[k] * s1) * cp + D(ckv[k]) * ct);
-				buf[k * TS + col] = fmax_(0.0f, kh) * nd * w * s1;
-			}
-		};
-		__syncthreads();
-		produce(0);
-		__syncthreads();
-		float nint = 0.0f;                                   // row accumulator of thread tid (tid < cnt)
-		for (int t = 0; t < ntiles; ++t) {
-			if (tid >= n_sum) { if (t + 1 < ntiles) produce(t + 1); }
-			else if (tid < cnt) {
-				const float *row = stile + (t & 1) * cnt * TS + tid * TS;
-				for (int c = 0; c < T; ++c) nint += row[c];          // the last tile is zero-padded: x + 0.0f == x
+			// the helpers were dispatched before this workgroup and never wait, so they finish; should one be
+			// late beyond the bound below, its rows are simply computed here (same arithmetic, same result)
+			__shared__ int s_have;
+			if (tid == 0) {
+				int spins = 0;
+				while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(parts - 1) && ++spins < (1 << 18))
+					__builtin_amdgcn_s_sleep(8);
+				s_have = spins < (1 << 18);
 			}
 			__syncthreads();
+			if (s_have) {
+				__threadfence();
+				if (tid >= r1 && tid < cnt)
+					sigma[tid] = __uint_as_float(__hip_atomic_load((const unsigned int *)sx + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+			} else sigma_rows(r1, cnt);
 		}
-		if (tid < cnt) { nint *= dth * dph; sigma[tid] = fmax_(ckv[tid], nint); }
 	}
 	__syncthreads();
 	if (tid == 0) sigma[cnt] = sigma[cnt - 1];
@@ -357,14 +404,15 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 
 template <int SRC>
 hipError_t launch_fit_kind(hipStream_t s, const Brdf *srcs, const Params &std_p, int n_mat, int res,
-                           int shadow, double *km, float *ratio, const djbk::FitOut &out)
+                           int shadow, double *km, float *ratio, const djbk::FitOut &out, const djbk::FitSplit &split)
 {
 	size_t lds = (size_t)make_plan(res).total;
 	hipError_t e = hipFuncSetAttribute((const void *)k_fit<SRC>,
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_fit<SRC>), dim3(n_mat), dim3(FIT_BLOCK), lds, s, srcs, std_p, res, shadow,
-	                   km, ratio, out);
+	if (split.parts > 1 && (e = hipMemsetAsync(split.sig_done, 0, sizeof(unsigned int) * n_mat, s)) != hipSuccess) return e;
+	hipLaunchKernelGGL((k_fit<SRC>), dim3(n_mat * split.parts), dim3(FIT_BLOCK), lds, s, srcs, std_p, n_mat, res, shadow,
+	                   km, ratio, out, split);
 	return hipGetLastError();
 }
 
@@ -374,19 +422,28 @@ namespace djbk {
 
 size_t fit_lds_bytes(int res) { return (size_t)make_plan(res).total; }
 
+// One workgroup occupies a CU (124 KB of LDS at res 90); each extra slice shortens the producers' share of a tile,
+// the row owners' 64 dependent adds per tile stay.
+int fit_parts(int n_mat, int n_cus)
+{
+	if (const char *e = getenv("DJB_FIT_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 8) return v; }   // experiments
+	int p = n_mat > 0 ? n_cus / n_mat : 1;
+	return p < 1 ? 1 : p > 8 ? 8 : p;
+}
+
 hipError_t launch_fit(hipStream_t s, const Brdf *srcs, int src_kind, const Params &std_p, int n_mat,
-                      int res, int shadow, double *km, float *ratio, const FitOut &out)
+                      int res, int shadow, double *km, float *ratio, const FitOut &out, const FitSplit &split)
 {
 	switch (src_kind) {
-	case KIND_BECKMANN: return launch_fit_kind<KIND_BECKMANN>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
-	case KIND_GGX:      return launch_fit_kind<KIND_GGX>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
-	case KIND_TABULAR:  return launch_fit_kind<KIND_TABULAR>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
-	case KIND_TABULAR_ANISO: return launch_fit_kind<KIND_TABULAR_ANISO>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
-	case KIND_MERL:     return launch_fit_kind<KIND_MERL>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
-	case KIND_UTIA:     return launch_fit_kind<KIND_UTIA>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
-	case KIND_LAMBERT:  return launch_fit_kind<KIND_LAMBERT>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
-	case KIND_SGD:      return launch_fit_kind<KIND_SGD>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
-	case KIND_ABC:      return launch_fit_kind<KIND_ABC>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out);
+	case KIND_BECKMANN: return launch_fit_kind<KIND_BECKMANN>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
+	case KIND_GGX:      return launch_fit_kind<KIND_GGX>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
+	case KIND_TABULAR:  return launch_fit_kind<KIND_TABULAR>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
+	case KIND_TABULAR_ANISO: return launch_fit_kind<KIND_TABULAR_ANISO>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
+	case KIND_MERL:     return launch_fit_kind<KIND_MERL>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
+	case KIND_UTIA:     return launch_fit_kind<KIND_UTIA>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
+	case KIND_LAMBERT:  return launch_fit_kind<KIND_LAMBERT>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
+	case KIND_SGD:      return launch_fit_kind<KIND_SGD>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
+	case KIND_ABC:      return launch_fit_kind<KIND_ABC>(s, srcs, std_p, n_mat, res, shadow, km, ratio, out, split);
 	}
 	return hipErrorInvalidValue;
 }

@@ -829,7 +829,7 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 	djbk::FitSplit split;
 	split.parts = djbk::fit_parts(n_mat, ctx->n_cus);
 	const size_t o_km = reserve(sizeof(double) * (size_t)n_mat * split.parts * cnt * cnt);
-	const size_t o_sigx = reserve(sizeof(float) * (size_t)n_mat * res), o_done = reserve(sizeof(unsigned int) * n_mat);
+	const size_t o_sigx = reserve(sizeof(float) * (size_t)n_mat * res), o_done = reserve(sizeof(unsigned int) * 2 * n_mat);
 	const size_t o_ratio = reserve(sizeof(float) * 3 * (size_t)n_mat * cnt * (cnt + 1));
 	const size_t o_p22 = reserve(sizeof(float) * (size_t)n_mat * res), o_sigma = reserve(sizeof(float) * (size_t)n_mat * res);
 	const size_t o_cdf = reserve(sizeof(float) * (size_t)n_mat * res), o_qf = reserve(sizeof(float) * (size_t)n_mat * res);

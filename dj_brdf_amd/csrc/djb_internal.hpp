@@ -65,9 +65,10 @@ struct FitOut {           // device pointers, [n_mat][res] (fresnel [n_mat][res]
 	float *alpha_beckmann, *alpha_ggx;
 	int *n_qf;            // number of valid qf entries per material (reference quirk, dj_brdf.h:2731)
 };
-// The sigma quadrature of one material can be sliced by rows over `parts` workgroups (fit_parts(n_mat)): parts - 1
-// helper workgroups per material redo the cheap phases before it, compute their slice of the rows and hand them
-// over through sig_x [n_mat][res] + the arrival counters sig_done [n_mat] (zeroed by launch_fit).
+// The two heavy passes of one material's fit -- the sigma quadrature (by rows) and the Fresnel-ratio pass (by
+// (theta_d, theta_h) pairs) -- can be sliced over `parts` workgroups (fit_parts(n_mat)): parts - 1 helper
+// workgroups per material redo the cheap phases before them and exchange their slices through sig_x [n_mat][res],
+// the ratio scratch and the arrival counters sig_done [n_mat][2] (zeroed by launch_fit).
 struct FitSplit { int parts; float *sig_x; unsigned int *sig_done; };
 int fit_parts(int n_mat, int n_cus);
 // srcs: device array of n_mat Brdf views (all of kind `src_kind`); std_p: params::standard().

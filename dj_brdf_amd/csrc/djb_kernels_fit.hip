@@ -88,6 +88,9 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	const int part = (int)blockIdx.x < n_help ? 1 + (int)blockIdx.x / n_mat : 0;
 	const int m = (int)blockIdx.x < n_help ? (int)blockIdx.x % n_mat : (int)blockIdx.x - n_help;
 	const int tid = threadIdx.x, cnt = res - 1;
+	// Slicing the Fresnel-ratio pass as well pays when few materials run (4+ slices each): with ~200 workgroups in
+	// flight the extra release / acquire pairs (L2 write-backs of everybody's scratch) cost what the slicing gains.
+	const bool fresnel_split = parts >= 4;
 	const LdsPlan P = make_plan(res);
 	double *v0 = (double *)(lds + P.v0), *v1 = (double *)(lds + P.v1);
 	double *cphid = (double *)(lds + P.cphid), *cthd = (double *)(lds + P.cthd);
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	float *sh = (float *)(lds + P.sh), *ui = (float *)(lds + P.ui);
 	float *terms = (float *)(lds + P.terms), *qprobe = (float *)(lds + P.qprobe);
 	float *skv = (float *)(lds + P.skv), *ckv = (float *)(lds + P.ckv), *stile = (float *)(lds + P.stile);
-	__shared__ int s_nphi, s_nqf;
+	__shared__ int s_nphi, s_nqf, s_have;
 	__shared__ float s_scale;
 
 	const Brdf src = srcs[m];
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		// previous tile's terms front to back from the other buffer.  Same terms, same order as the
 		// one-lane-per-row loop this replaces (1.14 ms of the 1.57 ms kernel).  When CUs are idle (fewer
 		// materials than CUs) the rows are sliced over `parts` workgroups per material, which shortens the
-		// producers' share of every tile: one material 0.71 -> 0.53 ms (8 slices), 100 materials 0.76 -> 0.71 (2).
+		// producers' share of every tile: 100 materials 0.76 -> 0.72 ms (2 slices); one material 0.71 -> 0.44 ms
+		// (8 slices, together with the sliced Fresnel pass below).
 		const float dth = F(DJB_PI / D((float)NTHETA_SIGMA));
 		const float dph = F(2.0 * DJB_PI / D((float)NPHI_SIGMA));
 		for (int k = tid; k < cnt; k += FIT_BLOCK) {
@@ -260,30 +264,31 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		const int r0 = (cnt * part) / parts, r1 = (cnt * (part + 1)) / parts;
 		sigma_rows(r0, r1);
 		if (parts > 1) {
+			// every workgroup of the material publishes its rows; with few materials (fresnel_split) all of them
+			// pick the others' up and go on to take a slice of the Fresnel-ratio pass, which needs the whole
+			// table; otherwise only the main workgroup does and the helpers leave.  All waits are bounded: a
+			// workgroup whose partners are late (not resident yet, e.g. the device is shared) computes the
+			// missing rows itself -- same arithmetic, same values -- so neither progress nor the result
+			// depends on scheduling.
 			float *sx = split.sig_x + (size_t)m * res;
-			unsigned int *done = split.sig_done + m;
-			if (part > 0) {      // helper: publish the rows, signal, leave
-				if (tid >= r0 && tid < r1) sx[tid] = sigma[tid];
-				__threadfence();
-				__syncthreads();
-				if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-				return;
-			}
-			// the helpers were dispatched before this workgroup and never wait, so they finish; should one be
-			// late beyond the bound below, its rows are simply computed here (same arithmetic, same result)
-			__shared__ int s_have;
+			unsigned int *done = split.sig_done + 2 * m;
+			if (tid >= r0 && tid < r1) sx[tid] = sigma[tid];
+			__threadfence();
+			__syncthreads();
+			if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			if (!fresnel_split && part > 0) return;          // sigma-only slicing: the helper is done
 			if (tid == 0) {
 				int spins = 0;
-				while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(parts - 1) && ++spins < (1 << 18))
+				while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)parts && ++spins < (1 << 14))
 					__builtin_amdgcn_s_sleep(8);
-				s_have = spins < (1 << 18);
+				s_have = spins < (1 << 14);
 			}
 			__syncthreads();
 			if (s_have) {
 				__threadfence();
-				if (tid >= r1 && tid < cnt)
+				if (tid < cnt && !(tid >= r0 && tid < r1))
 					sigma[tid] = __uint_as_float(__hip_atomic_load((const unsigned int *)sx + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-			} else sigma_rows(r1, cnt);
+			} else { sigma_rows(0, r0); sigma_rows(r1, cnt); }
 		}
 	}
 	__syncthreads();
@@ -292,7 +297,9 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 
 	// ================================================================ compute_fresnel (dj_brdf.h:2583-2641)
 	// pair (i, j) runs iff theta_h(j-1) < pi/2 - theta_d(i)   (theta_h(-1) := 0)
-	for (int e = tid; e < cnt * (cnt + 1); e += FIT_BLOCK) {
+	const int n_pairs = cnt * (cnt + 1);
+	auto fresnel_pairs = [&](int e0, int e1) {
+	for (int e = e0 + tid; e < e1; e += FIT_BLOCK) {
 		int i = e / (cnt + 1), j = e - i * (cnt + 1);
 		float theta_d = F(D((float)i / (float)cnt) * DJB_PI * 0.5);
 		float prev = 0.0f;
@@ -315,8 +322,32 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		}
 		ratio[3 * (size_t)e] = rx; ratio[3 * (size_t)e + 1] = ry; ratio[3 * (size_t)e + 2] = rz;
 	}
-	__threadfence_block();
-	__syncthreads();
+	};
+	{
+		// this workgroup's slice of the (theta_d, theta_h) pairs; helpers hand theirs over and leave
+		const int fparts = fresnel_split ? parts : 1;
+		const int e0 = (int)(((long long)n_pairs * part) / fparts), e1 = (int)(((long long)n_pairs * (part + 1)) / fparts);
+		fresnel_pairs(e0, e1);
+		if (fresnel_split) __threadfence(); else __threadfence_block();
+		__syncthreads();
+		if (fresnel_split) {
+			unsigned int *done = split.sig_done + 2 * m + 1;
+			if (part > 0) {
+				if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+			if (tid == 0) {
+				int spins = 0;
+				while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(parts - 1) && ++spins < (1 << 14))
+					__builtin_amdgcn_s_sleep(8);
+				s_have = spins < (1 << 14);
+			}
+			__syncthreads();
+			if (!s_have) { fresnel_pairs(e1, n_pairs); __threadfence_block(); }
+			__threadfence();
+			__syncthreads();
+		}
+	}
 	for (int i = tid; i < cnt; i += FIT_BLOCK) {
 		float fx = 0, fy = 0, fz = 0; int cx = 0, cy = 0, cz = 0;
 		for (int j = 0; j <= cnt; ++j) {
@@ -410,7 +441,7 @@ hipError_t launch_fit_kind(hipStream_t s, const Brdf *srcs, const Params &std_p,
 	hipError_t e = hipFuncSetAttribute((const void *)k_fit<SRC>,
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess) return e;
-	if (split.parts > 1 && (e = hipMemsetAsync(split.sig_done, 0, sizeof(unsigned int) * n_mat, s)) != hipSuccess) return e;
+	if (split.parts > 1 && (e = hipMemsetAsync(split.sig_done, 0, sizeof(unsigned int) * 2 * n_mat, s)) != hipSuccess) return e;
 	hipLaunchKernelGGL((k_fit<SRC>), dim3(n_mat * split.parts), dim3(FIT_BLOCK), lds, s, srcs, std_p, n_mat, res, shadow,
 	                   km, ratio, out, split);
 	return hipGetLastError();

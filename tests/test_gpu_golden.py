@@ -69,6 +69,29 @@ def test_fit_golden(gpu_ctx, name):
     assert_close(f"{name}/sample", t.sample(g["u1"], g["u2"], g["o"]), g[f"{name}_sample"])
 
 
+@pytest.mark.parametrize("n_mat", [1, 5])
+def test_fit_independent_of_workgroup_slicing(gpu_ctx, monkeypatch, n_mat):
+    """The fit kernel slices the sigma rows (and, with 4+ slices, the Fresnel-ratio pairs) of a material over helper
+    workgroups when CUs are idle (djbk::fit_parts); DJB_FIT_PARTS forces the slice count.  Tables and fitted
+    alphas must not depend on it -- including 8 slices x 5 materials, and 1 (no helpers)."""
+    mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=gpu_ctx) for k in range(n_mat)]
+    def run():
+        out = []
+        for m in mats:
+            t = djb.tabular(m, 90, True, ctx=gpu_ctx)
+            out.append(np.concatenate([t.get_p22v(), t.get_sigmav(), t.get_cdfv(), t.get_qfv(), np.ravel(t.get_fresnel().get_points()),
+                                       [djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0], djb.tabular.fit_ggx_parameters(t).get_ellipse()[0]]]).astype(np.float32))
+        return np.concatenate(out)
+    monkeypatch.setenv("DJB_FIT_PARTS", "1")
+    base = run()
+    batch1 = djb.fit_brdf_batch(mats, 90, True, ctx=gpu_ctx)
+    for parts in ("2", "3", "8"):
+        monkeypatch.setenv("DJB_FIT_PARTS", parts)
+        assert np.array_equal(run().view(np.uint32), base.view(np.uint32)), parts
+        got = djb.fit_brdf_batch(mats, 90, True, ctx=gpu_ctx)
+        assert np.array_equal(np.concatenate(got).view(np.uint32), np.concatenate(batch1).view(np.uint32)), parts
+
+
 def test_params_txt_bytes(gpu_ctx, tmp_path):
     """The product's merl_params driver reproduces the reference driver's params.txt byte for byte
     (examples/merl_params.cpp run on the same synthetic files; tests/golden/params_expected.txt)."""

@@ -53,13 +53,17 @@ DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float 
 	}
 }
 
-// min-waves hint: the analytic / tabulated microfacet kernels fit 128 VGPRs (occupancy 4); the
-// fp64-libm-heavy kinds (utia, sgd, abc, exact merl) are left to the register allocator
-#ifndef DJB_EVAL_MINW_OTHER
-#define DJB_EVAL_MINW_OTHER 1
-#endif
+// min-waves hint per kind, measured (tools/kind_rates.py, ms per 1e8 pairs at 1 / 4 / 8 waves): the analytic /
+// tabulated microfacet kernels fit 128 VGPRs (4); utia 3.34 / 2.93 / 10.5 and sgd 4.46 / 4.17 / 8.3 want 4
+// (left alone they take 172 VGPRs = 2 waves, too few to hide the table gathers; at 8 they spill);
+// abc 1.58 / 1.34 / 1.30 is light enough for 8; the operation-by-operation merl kernel stays unconstrained.
+constexpr int eval_min_waves(int kind)
+{
+	return (kind <= KIND_TABULAR || kind == KIND_TABULAR_ANISO || kind == KIND_UTIA || kind == KIND_SGD) ? 4
+	     : kind == KIND_ABC ? 8 : 1;
+}
 template <int KIND, int WANT, int FRK>
-__global__ __launch_bounds__(BLOCK, (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) ? 4 : DJB_EVAL_MINW_OTHER) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
+__global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
                                                    View vout, float *out_pdf)
 {
 	// Beckmann evaluates the fp64 exp of glibc (djb_device.hpp) three times per pair: its 2 KB table goes to LDS

@@ -801,6 +801,11 @@ template <int FRK> DJB_DEV v3 fresnel_eval_k(const Fresnel &f, float c)
 		v3 f0 = mk(f.a[0], f.a[1], f.a[2]);
 		return add(f0, scale(c5, sub(mk(1, 1, 1), f0)));
 	}
+	if (FRK == FR_UNPOLARIZED) return mk(unpolarized1(c, f.a[0]), unpolarized1(c, f.a[1]), unpolarized1(c, f.a[2]));
+	if (FRK == FR_SPLINE) {                              // dj_brdf.h:1338-1344: what every fitted (tabular) lobe carries
+		float u = F(2.0 * acos(D(c)) / DJB_PI);
+		return spline_v3(f.pts, f.npts, u);
+	}
 	return fresnel_eval(f, c);
 }
 

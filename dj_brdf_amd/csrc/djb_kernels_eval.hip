@@ -111,6 +111,14 @@ hipError_t launch_eval_kind(hipStream_t s, const Brdf &b, const Params &p, long 
 			return launch_eval_kind_fr<KIND, FR_IDEAL>(s, b, p, n, i, o, out, out_pdf, want);
 		if (b.fr.kind == FR_SCHLICK)
 			return launch_eval_kind_fr<KIND, FR_SCHLICK>(s, b, p, n, i, o, out, out_pdf, want);
+		if (b.fr.kind == FR_UNPOLARIZED)
+			return launch_eval_kind_fr<KIND, FR_UNPOLARIZED>(s, b, p, n, i, o, out, out_pdf, want);
+	}
+	// the fitted lobes carry a spline Fresnel (or the ideal one while under construction): the generic
+	// instantiation would drag the sgd term's pow -- glibc_pow, ~60 VGPRs -- into a kernel that never calls it
+	if constexpr (KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
+		if (b.fr.kind == FR_SPLINE)
+			return launch_eval_kind_fr<KIND, FR_SPLINE>(s, b, p, n, i, o, out, out_pdf, want);
 	}
 	return launch_eval_kind_fr<KIND, -1>(s, b, p, n, i, o, out, out_pdf, want);
 }
@@ -173,6 +181,12 @@ hipError_t launch_eval_pp_kind(hipStream_t s, const Brdf &b, long long n, const 
 			return launch_eval_pp_kind_fr<KIND, MODE, FR_IDEAL>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want);
 		if (b.fr.kind == FR_SCHLICK)
 			return launch_eval_pp_kind_fr<KIND, MODE, FR_SCHLICK>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want);
+		if (b.fr.kind == FR_UNPOLARIZED)
+			return launch_eval_pp_kind_fr<KIND, MODE, FR_UNPOLARIZED>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want);
+	}
+	if constexpr (KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
+		if (b.fr.kind == FR_SPLINE)
+			return launch_eval_pp_kind_fr<KIND, MODE, FR_SPLINE>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want);
 	}
 	return launch_eval_pp_kind_fr<KIND, MODE, -1>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want);
 }
@@ -235,15 +249,21 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
 	if (!is && !rng) hipLaunchKernelGGL((k_sample<KIND, false, false>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
 	else if (!is && rng) hipLaunchKernelGGL((k_sample<KIND, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
 	else {
-		// evalp_is evaluates the Fresnel term of the sampled pair: specialise the two cheap kinds
+		// evalp_is evaluates the Fresnel term of the sampled pair: specialised like k_eval
 		constexpr bool analytic = KIND == KIND_BECKMANN || KIND == KIND_GGX;
-		const int frk = analytic && (b.fr.kind == FR_IDEAL || b.fr.kind == FR_SCHLICK) ? b.fr.kind : -1;
+		constexpr bool fitted = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO;
 #define DJB_LAUNCH_IS(RNG_, FRK_) hipLaunchKernelGGL((k_sample<KIND, true, RNG_, FRK_>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf)
+#define DJB_LAUNCH_IS_FR(FRK_) do { if (rng) DJB_LAUNCH_IS(true, FRK_); else DJB_LAUNCH_IS(false, FRK_); return hipGetLastError(); } while (0)
 		if constexpr (analytic) {
-			if (frk == FR_IDEAL) { if (rng) DJB_LAUNCH_IS(true, FR_IDEAL); else DJB_LAUNCH_IS(false, FR_IDEAL); return hipGetLastError(); }
-			if (frk == FR_SCHLICK) { if (rng) DJB_LAUNCH_IS(true, FR_SCHLICK); else DJB_LAUNCH_IS(false, FR_SCHLICK); return hipGetLastError(); }
+			if (b.fr.kind == FR_IDEAL) DJB_LAUNCH_IS_FR(FR_IDEAL);
+			if (b.fr.kind == FR_SCHLICK) DJB_LAUNCH_IS_FR(FR_SCHLICK);
+			if (b.fr.kind == FR_UNPOLARIZED) DJB_LAUNCH_IS_FR(FR_UNPOLARIZED);
 		}
-		if (rng) DJB_LAUNCH_IS(true, -1); else DJB_LAUNCH_IS(false, -1);
+		if constexpr (fitted) {
+			if (b.fr.kind == FR_SPLINE) DJB_LAUNCH_IS_FR(FR_SPLINE);
+		}
+		DJB_LAUNCH_IS_FR(-1);
+#undef DJB_LAUNCH_IS_FR
 #undef DJB_LAUNCH_IS
 	}
 	return hipGetLastError();

@@ -15,7 +15,8 @@ out = torch.empty((3, n), dtype=torch.float32, device=i.device)
 vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
 pdf = torch.empty((n,), dtype=torch.float32, device=i.device)
 iso = djb.microfacet.params.isotropic(0.3)
-for name, b in (("ggx", djb.ggx(ctx=ctx)), ("beckmann", djb.beckmann(ctx=ctx)), ("beckmann schlick", djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), ctx=ctx))):
+for name, b in (("ggx", djb.ggx(ctx=ctx)), ("beckmann", djb.beckmann(ctx=ctx)), ("beckmann schlick", djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), ctx=ctx)),
+                ("ggx unpolarized", djb.ggx(djb.fresnel.unpolarized((1.5, 1.8, 2.4)), ctx=ctx)), ("beckmann unpol.", djb.beckmann(djb.fresnel.unpolarized((1.5, 1.8, 2.4)), ctx=ctx))):
     def run():
         _lib.check(lib.djb_eval_pdf_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), C.byref(iso._p), C.c_int(0), C.byref(vout.view),
                                           C.c_void_p(pdf.data_ptr()), C.c_int(0)))

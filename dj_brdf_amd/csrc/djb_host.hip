@@ -9,6 +9,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdint>
+#include <cstdlib>
+#include <condition_variable>
+#include <thread>
+#include <unistd.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -60,6 +65,10 @@ struct djb_ctx {
 	char *pin = nullptr;
 	size_t pin_bytes = 0;
 	int n_cus = 0;            // compute units of the device (how many fit workgroups run at once)
+	// large DJB_MEM_HOST batches (eval_host_pipelined): results of chunk c leave on this second stream while
+	// chunk c+1 comes in on `stream`, so both PCIe directions carry data; created on first use
+	hipStream_t d2h_stream = nullptr;
+	hipEvent_t pipe_ev[2] = { nullptr, nullptr };
 };
 
 struct djb_brdf {
@@ -384,6 +393,171 @@ djb_status check_call(djb_ctx *ctx, const djb_brdf *b, long long n, int mem)
 
 djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                        const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_fr,
+                       float *out_pdf, int mem, int want);
+
+// ------------------------------------------------------------------ large host batches: both PCIe directions in flight
+// A DJB_MEM_HOST batch of >= 2 chunks is cut into chunks of DJB_HOST_PIPE_CHUNK units (default 2^23;
+// 0 disables).  The calling thread copies chunk c+1 in and enqueues its kernels on the context's stream
+// while a helper thread copies the results of chunk c out on a second stream (two HBM slots).  Each
+// thread keeps the one-pageable-copy-at-a-time rule of Staged::copy, and the path is only taken when
+// no input array shares a host page with an output array (see Staged::copy on why).  Results are those
+// of the unchunked call: every unit is independent and the chunk kernels are the same kernels.
+long long host_pipe_chunk()
+{
+	const char *e = getenv("DJB_HOST_PIPE_CHUNK");
+	long long c = e ? atoll(e) : (1LL << 23);
+	return c < 0 ? 0 : c;
+}
+
+struct HostSpan { uintptr_t lo, hi; };
+HostSpan span_of(const djb_vec3_view *v, long long n)
+{
+	const float *a = v->x < v->y ? v->x : v->y; a = a < v->z ? a : v->z;
+	const float *z = v->x > v->y ? v->x : v->y; z = z > v->z ? z : v->z;
+	return HostSpan{ (uintptr_t)a, (uintptr_t)(z + (n - 1) * v->stride + 1) };
+}
+bool share_page(HostSpan a, HostSpan b)
+{
+	// base pages: separately allocated large arrays are usually adjacent mappings, so anything coarser than
+	// the real page size would see every pair of arrays as sharing one
+	static const uintptr_t PG = (uintptr_t)sysconf(_SC_PAGESIZE);
+	return (a.lo & ~(PG - 1)) < ((b.hi + PG - 1) & ~(PG - 1)) && (b.lo & ~(PG - 1)) < ((a.hi + PG - 1) & ~(PG - 1));
+}
+
+// returns DJB_OK and sets *taken = false when the batch does not qualify (caller uses the plain path)
+djb_status eval_host_pipelined(djb_ctx *ctx, const djb_brdf *b, long long n, const djb_vec3_view *i,
+                               const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_fr,
+                               float *out_pdf, int want, bool *taken)
+{
+	*taken = false;
+	const long long C = host_pipe_chunk();
+	if (C <= 0 || n < 2 * C || n <= SMALL_N) return DJB_OK;
+	if (!Staged::valid(i) || !Staged::valid(o)) return DJB_OK;          // the plain path reports the error
+	const bool wfr = (want & 3) != 0, wpdf = (want & 4) != 0;
+	if ((wfr && !Staged::valid(out_fr)) || (wpdf && !out_pdf)) return DJB_OK;
+	// tests set DJB_HOST_PIPE_REQUIRE to turn "fell back to the plain path" into an error
+	auto skip = [](const char *why) -> djb_status {
+		if (getenv("DJB_HOST_PIPE_REQUIRE")) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: chunked host path not taken: %s", why);
+		return DJB_OK;
+	};
+	const int li = Staged::layout_of(i), lo_ = Staged::layout_of(o), lf = wfr ? Staged::layout_of(out_fr) : 0;
+	if (li == 2 || lo_ == 2 || lf == 2) return skip("exotic stride (packed on the host)");
+	{
+		HostSpan si = span_of(i, n), so = span_of(o, n);
+		if (wfr) { HostSpan sf = span_of(out_fr, n); if (share_page(si, sf) || share_page(so, sf)) return skip("an input shares a host page with the output"); }
+		if (wpdf) {
+			HostSpan sp{ (uintptr_t)out_pdf, (uintptr_t)(out_pdf + n) };
+			if (share_page(si, sp) || share_page(so, sp)) return skip("an input shares a host page with the pdf output");
+		}
+	}
+	if (!ctx->d2h_stream) {
+		HIP_TRY(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+		for (hipEvent_t &e : ctx->pipe_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	}
+	*taken = true;
+
+	// two slots of {i, o, fr, pdf} chunks in HBM, recycled through the context's pool
+	Staged pool(ctx, C, DJB_MEM_HOST);
+	pool.small = false;
+	float *din[2], *don[2], *dfr[2] = { nullptr, nullptr }, *dpd[2] = { nullptr, nullptr };
+	for (int s = 0; s < 2; ++s) {
+		djb_status st;
+		if ((st = pool.alloc(sizeof(float) * 3 * (size_t)C, (void **)&din[s])) != DJB_OK) return st;
+		if ((st = pool.alloc(sizeof(float) * 3 * (size_t)C, (void **)&don[s])) != DJB_OK) return st;
+		if (wfr && (st = pool.alloc(sizeof(float) * 3 * (size_t)C, (void **)&dfr[s])) != DJB_OK) return st;
+		if (wpdf && (st = pool.alloc(sizeof(float) * (size_t)C, (void **)&dpd[s])) != DJB_OK) return st;
+	}
+	auto dev_view = [&](float *d, int layout) {
+		return layout == 0 ? djb_vec3_view{ d, d + 1, d + 2, 3 } : djb_vec3_view{ d, d + C, d + 2 * C, 1 };
+	};
+	// one vec3 array chunk [lo, lo + m) between the caller's memory and an HBM slot, in the caller's layout
+	auto move = [&](const djb_vec3_view *h, int layout, float *d, long long lo, long long m, bool to_dev, hipStream_t s) -> hipError_t {
+		const hipMemcpyKind k = to_dev ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+		hipError_t e;
+		if (layout == 0) {
+			float *hp = h->x + 3 * lo;
+			e = to_dev ? hipMemcpyAsync(d, hp, sizeof(float) * 3 * (size_t)m, k, s) : hipMemcpyAsync(hp, d, sizeof(float) * 3 * (size_t)m, k, s);
+			if (e != hipSuccess) return e;
+			return hipStreamSynchronize(s);
+		}
+		float *hc[3] = { h->x + lo, h->y + lo, h->z + lo };
+		for (int c = 0; c < 3; ++c) {
+			float *dc = d + (size_t)c * C;
+			e = to_dev ? hipMemcpyAsync(dc, hc[c], sizeof(float) * (size_t)m, k, s) : hipMemcpyAsync(hc[c], dc, sizeof(float) * (size_t)m, k, s);
+			if (e != hipSuccess) return e;
+			if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+		}
+		return hipSuccess;
+	};
+
+	const long long nch = (n + C - 1) / C;
+	std::mutex mu;
+	std::condition_variable cv;
+	long long issued = 0, drained = 0;
+	bool abort_ = false;
+	hipError_t werr = hipSuccess;
+	std::thread drain([&]() {
+		hipError_t e = hipSetDevice(ctx->device);
+		for (long long c = 0; c < nch; ++c) {
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return issued > c || abort_; });
+				if (abort_) return;
+			}
+			const int s = (int)(c & 1);
+			const long long lo = c * C, m = n - lo < C ? n - lo : C;
+			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->d2h_stream, ctx->pipe_ev[s], 0);
+			if (e == hipSuccess && wfr) e = move(out_fr, lf, dfr[s], lo, m, false, ctx->d2h_stream);
+			if (e == hipSuccess && wpdf) {
+				e = hipMemcpyAsync(out_pdf + lo, dpd[s], sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, ctx->d2h_stream);
+				if (e == hipSuccess) e = hipStreamSynchronize(ctx->d2h_stream);
+			}
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				if (e != hipSuccess) werr = e;
+				drained = c + 1;
+			}
+			cv.notify_all();
+		}
+	});
+	auto stop = [&](djb_status st) {
+		{ std::lock_guard<std::mutex> lk(mu); abort_ = true; }
+		cv.notify_all();
+		drain.join();
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipStreamSynchronize(ctx->d2h_stream);
+		return st;
+	};
+	for (long long c = 0; c < nch; ++c) {
+		const int s = (int)(c & 1);
+		const long long lo = c * C, m = n - lo < C ? n - lo : C;
+		{   // slot s is free once chunk c-2 has left
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return drained >= c - 1; });
+			if (werr != hipSuccess) break;
+		}
+		hipError_t e = move(i, li, din[s], lo, m, true, ctx->stream);
+		if (e == hipSuccess) e = move(o, lo_, don[s], lo, m, true, ctx->stream);
+		if (e != hipSuccess) return stop(fail(DJB_ERR_HIP, "djb_error: staging copy failed (%s) in chunk %lld of a host batch", hipGetErrorString(e), c));
+		djb_vec3_view vi = dev_view(din[s], li), vo = dev_view(don[s], lo_), vf = dev_view(dfr[s], lf);
+		djb_status st = eval_common(ctx, b, m, &vi, &vo, params, wfr ? &vf : nullptr, dpd[s], DJB_MEM_DEVICE, want);
+		if (st != DJB_OK) return stop(st);
+		if ((e = hipEventRecord(ctx->pipe_ev[s], ctx->stream)) != hipSuccess)
+			return stop(fail(DJB_ERR_HIP, "djb_error: hipEventRecord: %s", hipGetErrorString(e)));
+		{ std::lock_guard<std::mutex> lk(mu); issued = c + 1; }
+		cv.notify_all();
+	}
+	drain.join();
+	if (werr != hipSuccess) {
+		(void)hipStreamSynchronize(ctx->stream);
+		return fail(DJB_ERR_HIP, "djb_error: staging copy failed (%s) while returning a host batch", hipGetErrorString(werr));
+	}
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return DJB_OK;
+}
+
+djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
+                       const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_fr,
                        float *out_pdf, int mem, int want)
 {
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
@@ -392,6 +566,11 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
 	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
+	if (mem == DJB_MEM_HOST && n > SMALL_N) {
+		bool taken = false;
+		st = eval_host_pipelined(ctx, b, n, i, o, params, out_fr, out_pdf, want, &taken);
+		if (taken || st != DJB_OK) return st;
+	}
 	Staged sg(ctx, n, mem);
 	View vi, vo, vout{ nullptr, nullptr, nullptr, 0 };
 	float *dpdf = nullptr;
@@ -571,6 +750,8 @@ djb_status djb_ctx_destroy(djb_ctx *ctx)
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	for (auto &p : ctx->pool) (void)hipFree(p.first);
 	if (ctx->pin) (void)hipHostFree(ctx->pin);
+	if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
+	for (hipEvent_t e : ctx->pipe_ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 	return DJB_OK;

@@ -410,6 +410,77 @@ def test_host_views_of_any_layout(gpu_ctx, dirs):
     assert np.array_equal(r.view(np.uint32), want.view(np.uint32))
 
 
+def test_large_host_batches_are_chunked_with_identical_results(gpu_ctx, dirs, monkeypatch):
+    # DJB_MEM_HOST batches of >= 2 chunks are copied in / out chunk by chunk with both PCIe directions
+    # in flight (eval_host_pipelined); the chunk size is forced down so a few thousand pairs exercise
+    # it: 5 chunks with a ragged tail, every layout the path accepts, eval / evalp / pdf / eval+pdf,
+    # an analytic lobe and the two-tier MERL lookup.  Expected = the same call with chunking off.
+    import ctypes as C
+    from dj_brdf_amd import _lib
+    lib = _lib.load()
+    i, o, _, _ = dirs
+    n = 43_211
+    i, o = np.ascontiguousarray(i[:n]), np.ascontiguousarray(o[:n])
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    m = djb.merl.from_table(synth.merl_table_hashed(), ctx=gpu_ctx)
+
+    def view(a, aos):
+        v = _lib.Vec3View(); b = a.ctypes.data
+        if aos: v.x, v.y, v.z, v.stride = b, b + 4, b + 8, 3
+        else: v.x, v.y, v.z, v.stride = b, b + 4 * n, b + 8 * n, 1
+        return v
+
+    def paged(shape, fill=None):
+        # a buffer that owns its host pages (the chunked path is only taken when inputs and outputs share
+        # none; small numpy arrays come from the malloc heap and may)
+        count = int(np.prod(shape))
+        raw = np.empty(count + 2 * 1024 + 1024, np.float32)
+        off = (-raw.ctypes.data % 4096) // 4
+        a = raw[off:off + count].reshape(shape)
+        assert a.ctypes.data % 4096 == 0
+        a[...] = np.nan if fill is None else fill
+        return a
+
+    i, o = paged(i.shape, i), paged(o.shape, o)
+    it, ot = paged((3, n), i.T), paged((3, n), o.T)
+
+    def run(brdf, aos_in, aos_out, chunk):
+        monkeypatch.setenv("DJB_HOST_PIPE_CHUNK", str(chunk))
+        if chunk: monkeypatch.setenv("DJB_HOST_PIPE_REQUIRE", "1")    # falling back to the plain path is an error here
+        else: monkeypatch.delenv("DJB_HOST_PIPE_REQUIRE", raising=False)
+        ii = i if aos_in else it; oo = o if aos_in else ot
+        res = {}
+        for name, fn in (("eval", lib.djb_eval_batch), ("evalp", lib.djb_evalp_batch)):
+            out = paged((n, 3) if aos_out else (3, n))
+            _lib.check(fn(gpu_ctx._h, brdf._h, C.c_int64(n), C.byref(view(ii, aos_in)), C.byref(view(oo, aos_in)), None,
+                          C.byref(view(out, aos_out)), C.c_int(_lib.MEM_HOST)))
+            res[name] = out if aos_out else out.T
+        pdf = paged((n,))
+        _lib.check(lib.djb_pdf_batch(gpu_ctx._h, brdf._h, C.c_int64(n), C.byref(view(ii, aos_in)), C.byref(view(oo, aos_in)), None,
+                                     pdf.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(_lib.MEM_HOST)))
+        res["pdf"] = pdf
+        out = paged((n, 3) if aos_out else (3, n)); pdf2 = paged((n,))
+        _lib.check(lib.djb_eval_pdf_batch(gpu_ctx._h, brdf._h, C.c_int64(n), C.byref(view(ii, aos_in)), C.byref(view(oo, aos_in)), None,
+                                          C.c_int(1), C.byref(view(out, aos_out)), pdf2.ctypes.data_as(C.POINTER(C.c_float)),
+                                          C.c_int(_lib.MEM_HOST)))
+        res["evalp+pdf"] = np.concatenate([out if aos_out else out.T, pdf2[:, None]], 1)
+        return res
+
+    for brdf in (g, m):
+        want = run(brdf, True, True, 0)
+        assert all(np.isfinite(v).all() for v in want.values())
+        for aos_in, aos_out, chunk in ((True, True, 10_000), (False, False, 10_000), (True, False, 9_001), (False, True, 21_605)):
+            got = run(brdf, aos_in, aos_out, chunk)
+            for k in want:
+                assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (k, aos_in, aos_out, chunk)
+    # device-resident answers agree as well (the chunk kernels are the plain kernels)
+    import torch
+    ti, to = torch.from_numpy(i).cuda(), torch.from_numpy(o).cuda()
+    monkeypatch.setenv("DJB_HOST_PIPE_CHUNK", "10000")
+    monkeypatch.delenv("DJB_HOST_PIPE_REQUIRE", raising=False)
+    assert np.array_equal(m.eval(i, o).view(np.uint32), m.eval(ti, to).cpu().numpy().view(np.uint32))
+
+
 def test_concurrent_callers_share_one_context(gpu_ctx):
     # the reference's operators are const and thread-safe (Mitsuba render threads share one BSDF):
     # concurrent host threads on ONE context must get the same bits as sequential calls, including the

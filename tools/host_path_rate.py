@@ -26,11 +26,13 @@ for layout in ("aos (array of djb::vec3)", "soa"):
         out = np.zeros((3, n), np.float32)
     vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
     for name, b in (("merl.eval", m), ("ggx.eval", g)):
-        best = 1e9
-        for _ in range(4):
-            t0 = time.perf_counter()
-            _lib.check(lib.djb_eval_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), None,
-                                          C.byref(vout.view), C.c_int(_lib.MEM_HOST)))
-            best = min(best, time.perf_counter() - t0)
-        print(f"{name:10s} host {layout:26s} n={n:.0e}  {best*1e3:8.1f} ms  {n/best/1e9:6.3f} G eval/s  "
-              f"({36*n/best/1e9:5.1f} GB/s over PCIe, H2D 24 B + D2H 12 B per eval)", flush=True)
+        for chunk in ("0", str(1 << 22), str(1 << 23), str(1 << 24)):
+            os.environ["DJB_HOST_PIPE_CHUNK"] = chunk    # 0 = copy in, run, copy out; else chunks with both directions in flight
+            best = 1e9
+            for _ in range(4):
+                t0 = time.perf_counter()
+                _lib.check(lib.djb_eval_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), None,
+                                              C.byref(vout.view), C.c_int(_lib.MEM_HOST)))
+                best = min(best, time.perf_counter() - t0)
+            print(f"{name:10s} host {layout:26s} chunk {int(chunk):>9d} n={n:.0e}  {best*1e3:8.1f} ms  {n/best/1e9:6.3f} G eval/s  "
+                  f"({36*n/best/1e9:5.1f} GB/s over PCIe, H2D 24 B + D2H 12 B per eval)", flush=True)

@@ -424,71 +424,77 @@ bool share_page(HostSpan a, HostSpan b)
 	return (a.lo & ~(PG - 1)) < ((b.hi + PG - 1) & ~(PG - 1)) && (b.lo & ~(PG - 1)) < ((a.hi + PG - 1) & ~(PG - 1));
 }
 
-// returns DJB_OK and sets *taken = false when the batch does not qualify (caller uses the plain path)
-djb_status eval_host_pipelined(djb_ctx *ctx, const djb_brdf *b, long long n, const djb_vec3_view *i,
-                               const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_fr,
-                               float *out_pdf, int want, bool *taken)
+// one per-unit array of a chunked host batch: a vec3 view (in the caller's layout) or a float array
+struct PipeArr {
+	const djb_vec3_view *v = nullptr; int layout = 0;   // vec3
+	float *f = nullptr;                                   // scalar per unit
+	float *dev[2] = { nullptr, nullptr };                 // the two HBM slots
+	long long C = 0;
+	static PipeArr vec(const djb_vec3_view *v) { PipeArr a; a.v = v; a.layout = Staged::layout_of(v); return a; }
+	static PipeArr arr(const float *f) { PipeArr a; a.f = const_cast<float *>(f); return a; }
+	HostSpan span(long long n) const { return v ? span_of(v, n) : HostSpan{ (uintptr_t)f, (uintptr_t)(f + n) }; }
+	size_t floats_per_unit() const { return v ? 3 : 1; }
+	djb_vec3_view view(int s) const   // device view of slot s (vec3 arrays)
+	{
+		float *d = dev[s];
+		return layout == 0 ? djb_vec3_view{ d, d + 1, d + 2, 3 } : djb_vec3_view{ d, d + C, d + 2 * C, 1 };
+	}
+	// units [lo, lo + m) between the caller's memory and slot s; one pageable copy at a time (Staged::copy)
+	hipError_t move(int s, long long lo, long long m, bool to_dev, hipStream_t st) const
+	{
+		const hipMemcpyKind k = to_dev ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+		float *hp[3], *dp[3]; size_t cnt; int parts;
+		if (!v) { hp[0] = f + lo; dp[0] = dev[s]; cnt = (size_t)m; parts = 1; }
+		else if (layout == 0) { hp[0] = v->x + 3 * lo; dp[0] = dev[s]; cnt = 3 * (size_t)m; parts = 1; }
+		else { hp[0] = v->x + lo; hp[1] = v->y + lo; hp[2] = v->z + lo; dp[0] = dev[s]; dp[1] = dev[s] + C; dp[2] = dev[s] + 2 * C; cnt = (size_t)m; parts = 3; }
+		for (int c = 0; c < parts; ++c) {
+			hipError_t e = to_dev ? hipMemcpyAsync(dp[c], hp[c], sizeof(float) * cnt, k, st) : hipMemcpyAsync(hp[c], dp[c], sizeof(float) * cnt, k, st);
+			if (e != hipSuccess) return e;
+			if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+		}
+		return hipSuccess;
+	}
+};
+
+// Runs launch(m, slot) -- which enqueues the kernels of one chunk on ctx->stream, reading ins[*].dev[slot] and
+// writing outs[*].dev[slot] -- over all chunks.  Returns DJB_OK with *taken = false when the batch does not
+// qualify (the caller then uses the plain copy-in / run / copy-out path).
+template <class Launch>
+djb_status host_pipeline(djb_ctx *ctx, long long n, std::vector<PipeArr> &ins, std::vector<PipeArr> &outs, Launch launch, bool *taken)
 {
 	*taken = false;
 	const long long C = host_pipe_chunk();
 	if (C <= 0 || n < 2 * C || n <= SMALL_N) return DJB_OK;
-	if (!Staged::valid(i) || !Staged::valid(o)) return DJB_OK;          // the plain path reports the error
-	const bool wfr = (want & 3) != 0, wpdf = (want & 4) != 0;
-	if ((wfr && !Staged::valid(out_fr)) || (wpdf && !out_pdf)) return DJB_OK;
 	// tests set DJB_HOST_PIPE_REQUIRE to turn "fell back to the plain path" into an error
 	auto skip = [](const char *why) -> djb_status {
 		if (getenv("DJB_HOST_PIPE_REQUIRE")) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: chunked host path not taken: %s", why);
 		return DJB_OK;
 	};
-	const int li = Staged::layout_of(i), lo_ = Staged::layout_of(o), lf = wfr ? Staged::layout_of(out_fr) : 0;
-	if (li == 2 || lo_ == 2 || lf == 2) return skip("exotic stride (packed on the host)");
-	{
-		HostSpan si = span_of(i, n), so = span_of(o, n);
-		if (wfr) { HostSpan sf = span_of(out_fr, n); if (share_page(si, sf) || share_page(so, sf)) return skip("an input shares a host page with the output"); }
-		if (wpdf) {
-			HostSpan sp{ (uintptr_t)out_pdf, (uintptr_t)(out_pdf + n) };
-			if (share_page(si, sp) || share_page(so, sp)) return skip("an input shares a host page with the pdf output");
+	for (auto *set : { &ins, &outs })
+		for (const PipeArr &a : *set) {
+			if (a.v ? !Staged::valid(a.v) : !a.f) return DJB_OK;          // the plain path reports the error
+			if (a.v && a.layout == 2) return skip("exotic stride (packed on the host)");
 		}
-	}
+	for (const PipeArr &a : ins)
+		for (const PipeArr &o : outs)
+			if (share_page(a.span(n), o.span(n))) return skip("an input shares a host page with an output");
 	if (!ctx->d2h_stream) {
 		HIP_TRY(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
 		for (hipEvent_t &e : ctx->pipe_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	}
 	*taken = true;
 
-	// two slots of {i, o, fr, pdf} chunks in HBM, recycled through the context's pool
+	// two slots per array in HBM, recycled through the context's pool
 	Staged pool(ctx, C, DJB_MEM_HOST);
 	pool.small = false;
-	float *din[2], *don[2], *dfr[2] = { nullptr, nullptr }, *dpd[2] = { nullptr, nullptr };
-	for (int s = 0; s < 2; ++s) {
-		djb_status st;
-		if ((st = pool.alloc(sizeof(float) * 3 * (size_t)C, (void **)&din[s])) != DJB_OK) return st;
-		if ((st = pool.alloc(sizeof(float) * 3 * (size_t)C, (void **)&don[s])) != DJB_OK) return st;
-		if (wfr && (st = pool.alloc(sizeof(float) * 3 * (size_t)C, (void **)&dfr[s])) != DJB_OK) return st;
-		if (wpdf && (st = pool.alloc(sizeof(float) * (size_t)C, (void **)&dpd[s])) != DJB_OK) return st;
-	}
-	auto dev_view = [&](float *d, int layout) {
-		return layout == 0 ? djb_vec3_view{ d, d + 1, d + 2, 3 } : djb_vec3_view{ d, d + C, d + 2 * C, 1 };
-	};
-	// one vec3 array chunk [lo, lo + m) between the caller's memory and an HBM slot, in the caller's layout
-	auto move = [&](const djb_vec3_view *h, int layout, float *d, long long lo, long long m, bool to_dev, hipStream_t s) -> hipError_t {
-		const hipMemcpyKind k = to_dev ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
-		hipError_t e;
-		if (layout == 0) {
-			float *hp = h->x + 3 * lo;
-			e = to_dev ? hipMemcpyAsync(d, hp, sizeof(float) * 3 * (size_t)m, k, s) : hipMemcpyAsync(hp, d, sizeof(float) * 3 * (size_t)m, k, s);
-			if (e != hipSuccess) return e;
-			return hipStreamSynchronize(s);
+	for (auto *set : { &ins, &outs })
+		for (PipeArr &a : *set) {
+			a.C = C;
+			for (int s = 0; s < 2; ++s) {
+				djb_status st = pool.alloc(sizeof(float) * a.floats_per_unit() * (size_t)C, (void **)&a.dev[s]);
+				if (st != DJB_OK) return st;
+			}
 		}
-		float *hc[3] = { h->x + lo, h->y + lo, h->z + lo };
-		for (int c = 0; c < 3; ++c) {
-			float *dc = d + (size_t)c * C;
-			e = to_dev ? hipMemcpyAsync(dc, hc[c], sizeof(float) * (size_t)m, k, s) : hipMemcpyAsync(hc[c], dc, sizeof(float) * (size_t)m, k, s);
-			if (e != hipSuccess) return e;
-			if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-		}
-		return hipSuccess;
-	};
 
 	const long long nch = (n + C - 1) / C;
 	std::mutex mu;
@@ -507,11 +513,8 @@ djb_status eval_host_pipelined(djb_ctx *ctx, const djb_brdf *b, long long n, con
 			const int s = (int)(c & 1);
 			const long long lo = c * C, m = n - lo < C ? n - lo : C;
 			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->d2h_stream, ctx->pipe_ev[s], 0);
-			if (e == hipSuccess && wfr) e = move(out_fr, lf, dfr[s], lo, m, false, ctx->d2h_stream);
-			if (e == hipSuccess && wpdf) {
-				e = hipMemcpyAsync(out_pdf + lo, dpd[s], sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, ctx->d2h_stream);
-				if (e == hipSuccess) e = hipStreamSynchronize(ctx->d2h_stream);
-			}
+			for (const PipeArr &a : outs)
+				if (e == hipSuccess) e = a.move(s, lo, m, false, ctx->d2h_stream);
 			{
 				std::lock_guard<std::mutex> lk(mu);
 				if (e != hipSuccess) werr = e;
@@ -536,11 +539,11 @@ djb_status eval_host_pipelined(djb_ctx *ctx, const djb_brdf *b, long long n, con
 			cv.wait(lk, [&] { return drained >= c - 1; });
 			if (werr != hipSuccess) break;
 		}
-		hipError_t e = move(i, li, din[s], lo, m, true, ctx->stream);
-		if (e == hipSuccess) e = move(o, lo_, don[s], lo, m, true, ctx->stream);
+		hipError_t e = hipSuccess;
+		for (const PipeArr &a : ins)
+			if (e == hipSuccess) e = a.move(s, lo, m, true, ctx->stream);
 		if (e != hipSuccess) return stop(fail(DJB_ERR_HIP, "djb_error: staging copy failed (%s) in chunk %lld of a host batch", hipGetErrorString(e), c));
-		djb_vec3_view vi = dev_view(din[s], li), vo = dev_view(don[s], lo_), vf = dev_view(dfr[s], lf);
-		djb_status st = eval_common(ctx, b, m, &vi, &vo, params, wfr ? &vf : nullptr, dpd[s], DJB_MEM_DEVICE, want);
+		djb_status st = launch(m, s);
 		if (st != DJB_OK) return stop(st);
 		if ((e = hipEventRecord(ctx->pipe_ev[s], ctx->stream)) != hipSuccess)
 			return stop(fail(DJB_ERR_HIP, "djb_error: hipEventRecord: %s", hipGetErrorString(e)));
@@ -554,6 +557,22 @@ djb_status eval_host_pipelined(djb_ctx *ctx, const djb_brdf *b, long long n, con
 	}
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return DJB_OK;
+}
+
+djb_status eval_host_pipelined(djb_ctx *ctx, const djb_brdf *b, long long n, const djb_vec3_view *i,
+                               const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_fr,
+                               float *out_pdf, int want, bool *taken)
+{
+	*taken = false;
+	const bool wfr = (want & 3) != 0, wpdf = (want & 4) != 0;
+	if (!i || !o || (wfr && !out_fr)) return DJB_OK;                      // the plain path reports the error
+	std::vector<PipeArr> ins{ PipeArr::vec(i), PipeArr::vec(o) }, outs;
+	if (wfr) outs.push_back(PipeArr::vec(out_fr));
+	if (wpdf) outs.push_back(PipeArr::arr(out_pdf));
+	return host_pipeline(ctx, n, ins, outs, [&](long long m, int s) {
+		djb_vec3_view vi = ins[0].view(s), vo = ins[1].view(s), vf = wfr ? outs[0].view(s) : djb_vec3_view{ nullptr, nullptr, nullptr, 0 };
+		return eval_common(ctx, b, m, &vi, &vo, params, wfr ? &vf : nullptr, wpdf ? outs.back().dev[s] : nullptr, DJB_MEM_DEVICE, want);
+	}, taken);
 }
 
 djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
@@ -1274,6 +1293,17 @@ static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, cons
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
 	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
+	if (mem == DJB_MEM_HOST && n > SMALL_N && o && out_i && (!is || out_w)) {   // large host batch: chunked, both PCIe directions busy
+		bool taken = false;
+		std::vector<PipeArr> ins{ PipeArr::arr(u1), PipeArr::arr(u2), PipeArr::vec(o) }, outs{ PipeArr::vec(out_i) };
+		if (is) { outs.push_back(PipeArr::vec(out_w)); outs.push_back(PipeArr::arr(out_pdf)); }
+		st = host_pipeline(ctx, n, ins, outs, [&](long long m, int s) {
+			djb_vec3_view dvo = ins[2].view(s), dvi = outs[0].view(s), dvw = is ? outs[1].view(s) : djb_vec3_view{ nullptr, nullptr, nullptr, 0 };
+			return sample_common(ctx, b, m, ins[0].dev[s], ins[1].dev[s], &dvo, params, is ? &dvw : nullptr, &dvi,
+			                     is ? outs[2].dev[s] : nullptr, DJB_MEM_DEVICE, is);
+		}, &taken);
+		if (taken || st != DJB_OK) return st;
+	}
 	Staged sg(ctx, n, mem);
 	View vo, vi, vw; const float *d1, *d2; float *dpdf = nullptr;
 	if ((st = sg.in_f(u1, &d1)) != DJB_OK) return st;

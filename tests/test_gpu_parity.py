@@ -473,6 +473,32 @@ def test_large_host_batches_are_chunked_with_identical_results(gpu_ctx, dirs, mo
             got = run(brdf, aos_in, aos_out, chunk)
             for k in want:
                 assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (k, aos_in, aos_out, chunk)
+    # sample / evalp_is: 20 B in (u1, u2, o), 12 or 28 B out (i [, weight, pdf]) per unit
+    u1, u2 = paged((n,), dirs[2][:n]), paged((n,), dirs[3][:n])
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def run_s(brdf, aos, chunk):
+        monkeypatch.setenv("DJB_HOST_PIPE_CHUNK", str(chunk))
+        if chunk: monkeypatch.setenv("DJB_HOST_PIPE_REQUIRE", "1")
+        else: monkeypatch.delenv("DJB_HOST_PIPE_REQUIRE", raising=False)
+        oo = o if aos else ot
+        shp = (n, 3) if aos else (3, n)
+        si = paged(shp)
+        _lib.check(lib.djb_sample_batch(gpu_ctx._h, brdf._h, C.c_int64(n), fp(u1), fp(u2), C.byref(view(oo, aos)), None,
+                                        C.byref(view(si, aos)), C.c_int(_lib.MEM_HOST)))
+        wi, ww, wp = paged(shp), paged(shp), paged((n,))
+        _lib.check(lib.djb_evalp_is_batch(gpu_ctx._h, brdf._h, C.c_int64(n), fp(u1), fp(u2), C.byref(view(oo, aos)), None,
+                                          C.byref(view(ww, aos)), C.byref(view(wi, aos)), fp(wp), C.c_int(_lib.MEM_HOST)))
+        t = (lambda a: a) if aos else (lambda a: a.T)
+        return {"sample": t(si), "is.i": t(wi), "is.w": t(ww), "is.pdf": wp}
+
+    for brdf in (g, djb.beckmann(ctx=gpu_ctx)):
+        want = run_s(brdf, True, 0)
+        assert all(np.isfinite(v).all() for v in want.values())
+        for aos, chunk in ((True, 10_000), (False, 12_345)):
+            got = run_s(brdf, aos, chunk)
+            for k in want:
+                assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (k, aos, chunk)
     # device-resident answers agree as well (the chunk kernels are the plain kernels)
     import torch
     ti, to = torch.from_numpy(i).cuda(), torch.from_numpy(o).cuda()

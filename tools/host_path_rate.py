@@ -36,3 +36,22 @@ for layout in ("aos (array of djb::vec3)", "soa"):
                 best = min(best, time.perf_counter() - t0)
             print(f"{name:10s} host {layout:26s} chunk {int(chunk):>9d} n={n:.0e}  {best*1e3:8.1f} ms  {n/best/1e9:6.3f} G eval/s  "
                   f"({36*n/best/1e9:5.1f} GB/s over PCIe, H2D 24 B + D2H 12 B per eval)", flush=True)
+
+# sample / evalp_is of a Beckmann lobe: 20 B in (u1, u2, o), 12 B (i) or 28 B (i, weight, pdf) out per unit
+bk = djb.beckmann(ctx=ctx)
+o = synth.directions_aos(n, synth.SEED_O); u1 = synth.uniforms(n, synth.SEED_U1); u2 = synth.uniforms(n, synth.SEED_U2)
+oi, ow, opdf = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+vo, voi, vow = djb._Vec(o), djb._Vec(oi), djb._Vec(ow)
+fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+for name, bytes_per, call in (
+        ("beckmann.sample", 32, lambda: lib.djb_sample_batch(ctx._h, bk._h, C.c_int64(n), fp(u1), fp(u2), C.byref(vo.view), None,
+                                                             C.byref(voi.view), C.c_int(_lib.MEM_HOST))),
+        ("beckmann.evalp_is", 48, lambda: lib.djb_evalp_is_batch(ctx._h, bk._h, C.c_int64(n), fp(u1), fp(u2), C.byref(vo.view), None,
+                                                                 C.byref(vow.view), C.byref(voi.view), fp(opdf), C.c_int(_lib.MEM_HOST)))):
+    for chunk in ("0", str(1 << 23)):
+        os.environ["DJB_HOST_PIPE_CHUNK"] = chunk
+        best = 1e9
+        for _ in range(4):
+            t0 = time.perf_counter(); _lib.check(call()); best = min(best, time.perf_counter() - t0)
+        print(f"{name:18s} host aos chunk {int(chunk):>9d} n={n:.0e}  {best*1e3:8.1f} ms  {n/best/1e9:6.3f} G/s  "
+              f"({bytes_per*n/best/1e9:5.1f} GB/s over PCIe, {bytes_per} B per unit)", flush=True)

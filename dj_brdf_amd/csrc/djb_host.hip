@@ -427,13 +427,13 @@ bool share_page(HostSpan a, HostSpan b)
 // one per-unit array of a chunked host batch: a vec3 view (in the caller's layout) or a float array
 struct PipeArr {
 	const djb_vec3_view *v = nullptr; int layout = 0;   // vec3
-	float *f = nullptr;                                   // scalar per unit
+	float *f = nullptr; int width = 1;                    // `width` contiguous floats per unit (1 = scalar, 5 = params record)
 	float *dev[2] = { nullptr, nullptr };                 // the two HBM slots
 	long long C = 0;
 	static PipeArr vec(const djb_vec3_view *v) { PipeArr a; a.v = v; a.layout = Staged::layout_of(v); return a; }
-	static PipeArr arr(const float *f) { PipeArr a; a.f = const_cast<float *>(f); return a; }
-	HostSpan span(long long n) const { return v ? span_of(v, n) : HostSpan{ (uintptr_t)f, (uintptr_t)(f + n) }; }
-	size_t floats_per_unit() const { return v ? 3 : 1; }
+	static PipeArr arr(const float *f, int width = 1) { PipeArr a; a.f = const_cast<float *>(f); a.width = width; return a; }
+	HostSpan span(long long n) const { return v ? span_of(v, n) : HostSpan{ (uintptr_t)f, (uintptr_t)(f + (size_t)width * n) }; }
+	size_t floats_per_unit() const { return v ? 3 : (size_t)width; }
 	djb_vec3_view view(int s) const   // device view of slot s (vec3 arrays)
 	{
 		float *d = dev[s];
@@ -444,7 +444,7 @@ struct PipeArr {
 	{
 		const hipMemcpyKind k = to_dev ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
 		float *hp[3], *dp[3]; size_t cnt; int parts;
-		if (!v) { hp[0] = f + lo; dp[0] = dev[s]; cnt = (size_t)m; parts = 1; }
+		if (!v) { hp[0] = f + (size_t)width * lo; dp[0] = dev[s]; cnt = (size_t)width * m; parts = 1; }
 		else if (layout == 0) { hp[0] = v->x + 3 * lo; dp[0] = dev[s]; cnt = 3 * (size_t)m; parts = 1; }
 		else { hp[0] = v->x + lo; hp[1] = v->y + lo; hp[2] = v->z + lo; dp[0] = dev[s]; dp[1] = dev[s] + C; dp[2] = dev[s] + 2 * C; cnt = (size_t)m; parts = 3; }
 		for (int c = 0; c < parts; ++c) {
@@ -1505,6 +1505,21 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
 	djb_status st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	if (mem == DJB_MEM_HOST && n > SMALL_N && i && o && (!(want & 3) || out_fr)) {   // large host batch: chunked, both PCIe directions busy
+		bool taken = false;
+		const bool wfr = (want & 3) != 0, wpdf = (want & 4) != 0;
+		std::vector<PipeArr> ins{ PipeArr::vec(i), PipeArr::vec(o), PipeArr::arr(rec, 5) }, outs;
+		int kf = -1, kp = -1, kq = -1;
+		if (wfr) { kf = (int)outs.size(); outs.push_back(PipeArr::vec(out_fr)); }
+		if (wpdf) { kp = (int)outs.size(); outs.push_back(PipeArr::arr(out_pdf)); }
+		if (out_pp) { kq = (int)outs.size(); outs.push_back(PipeArr::arr(out_pp, 5)); }
+		st = host_pipeline(ctx, n, ins, outs, [&](long long m, int s) {
+			djb_vec3_view dvi = ins[0].view(s), dvo = ins[1].view(s), dvf = wfr ? outs[kf].view(s) : djb_vec3_view{ nullptr, nullptr, nullptr, 0 };
+			return eval_pp_common(ctx, b, m, &dvi, &dvo, ins[2].dev[s], mode, base5, want, wfr ? &dvf : nullptr,
+			                      wpdf ? outs[kp].dev[s] : nullptr, out_pp ? outs[kq].dev[s] : nullptr, DJB_MEM_DEVICE);
+		}, &taken);
+		if (taken || st != DJB_OK) return st;
+	}
 	Staged sg(ctx, n, mem);
 	View vi, vo, vout{ nullptr, nullptr, nullptr, 0 };
 	float *dpdf = nullptr, *dpp = nullptr; const float *drec = rec;

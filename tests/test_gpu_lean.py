@@ -62,3 +62,29 @@ def test_lean_device_tensors(gpu_ctx):
     dev = b.eval_lean(ti, to, mk_params(LEAN_BASE), LEAN_SCALE, tl, want="evalp")
     host = b.eval_lean(g["i"], g["o"], mk_params(LEAN_BASE), LEAN_SCALE, g["lean"], want="evalp")
     assert np.array_equal(dev.cpu().numpy().T.view(np.uint32), host.view(np.uint32))
+
+
+def test_lean_large_host_batches_are_chunked(gpu_ctx, monkeypatch):
+    # the per-pair-parameter host path goes through the same chunked pipeline as eval (both PCIe directions
+    # in flight); chunk size forced down, result = the unchunked call bit for bit, resolved params included
+    g = np.load(os.path.join(G, "lean.npz"))
+    reps = -(-30_011 // len(g["i"]))
+    i, o, lean = (np.tile(g[k], (reps, 1))[:30_011] for k in ("i", "o", "lean"))
+
+    def paged(a):        # buffers that own their host pages (inputs and outputs must not share any)
+        raw = np.empty(a.size + 3072, np.float32)
+        off = (-raw.ctypes.data % 4096) // 4
+        v = raw[off:off + a.size].reshape(a.shape); v[...] = a
+        return v
+    i, o, lean = paged(i), paged(o), paged(lean)
+    b = djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    base = mk_params(LEAN_BASE)
+    monkeypatch.setenv("DJB_HOST_PIPE_CHUNK", "0")
+    want = b.eval_lean(i, o, base, LEAN_SCALE, lean, want="evalp+pdf", return_params=True)
+    want_pp = b.eval_pp(i, o, want[2], want="eval")
+    monkeypatch.setenv("DJB_HOST_PIPE_CHUNK", "7000")
+    monkeypatch.setenv("DJB_HOST_PIPE_REQUIRE", "1")     # the inputs own their pages: falling back would be a bug
+    got = b.eval_lean(i, o, base, LEAN_SCALE, lean, want="evalp+pdf", return_params=True)
+    for a, w in zip(got, want):
+        assert np.array_equal(a.view(np.uint32), w.view(np.uint32))
+    assert np.array_equal(b.eval_pp(i, o, paged(want[2]), want="eval").view(np.uint32), want_pp.view(np.uint32))

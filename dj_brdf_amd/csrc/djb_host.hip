@@ -396,17 +396,22 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
                        float *out_pdf, int mem, int want);
 
 // ------------------------------------------------------------------ large host batches: both PCIe directions in flight
-// A DJB_MEM_HOST batch of >= 2 chunks is cut into chunks of DJB_HOST_PIPE_CHUNK units (default 2^23;
-// 0 disables).  The calling thread copies chunk c+1 in and enqueues its kernels on the context's stream
+// A DJB_MEM_HOST batch of >= 2 chunks is cut into chunks of DJB_HOST_PIPE_CHUNK units (default: n/8 clamped
+// to [2^19, 2^23]; 0 disables).  The calling thread copies chunk c+1 in and enqueues its kernels on the context's stream
 // while a helper thread copies the results of chunk c out on a second stream (two HBM slots).  Each
 // thread keeps the one-pageable-copy-at-a-time rule of Staged::copy, and the path is only taken when
 // no input array shares a host page with an output array (see Staged::copy on why).  Results are those
 // of the unchunked call: every unit is independent and the chunk kernels are the same kernels.
-long long host_pipe_chunk()
+long long host_pipe_chunk(long long n)
 {
-	const char *e = getenv("DJB_HOST_PIPE_CHUNK");
-	long long c = e ? atoll(e) : (1LL << 23);
-	return c < 0 ? 0 : c;
+	if (const char *e = getenv("DJB_HOST_PIPE_CHUNK")) { long long c = atoll(e); return c < 0 ? 0 : c; }
+	// default: eight chunks for mid-sized batches (the first copy in and the last copy out are not overlapped:
+	// time ~ input time x (1 + 1/(2 chunks)); >= 2^19 units each keeps a chunk's copies well above the per-copy
+	// overhead), 2^23 units for large ones (tools/host_path_rate.py: 2^22..2^24 are within 3 %)
+	long long c = ((n + 7) / 8 + 4095) & ~4095LL;
+	if (c < (1LL << 19)) c = 1LL << 19;
+	if (c > (1LL << 23)) c = 1LL << 23;
+	return c;
 }
 
 struct HostSpan { uintptr_t lo, hi; };
@@ -463,7 +468,7 @@ template <class Launch>
 djb_status host_pipeline(djb_ctx *ctx, long long n, std::vector<PipeArr> &ins, std::vector<PipeArr> &outs, Launch launch, bool *taken)
 {
 	*taken = false;
-	const long long C = host_pipe_chunk();
+	const long long C = host_pipe_chunk(n);
 	if (C <= 0 || n < 2 * C || n <= SMALL_N) return DJB_OK;
 	// tests set DJB_HOST_PIPE_REQUIRE to turn "fell back to the plain path" into an error
 	auto skip = [](const char *why) -> djb_status {

@@ -16,7 +16,10 @@
  *    an array of djb::vec3 (AoS) = {p, p+1, p+2, 3}.
  *  - `mem` says where the array pointers live: DJB_MEM_DEVICE (HBM of the ctx's GPU; the call is
  *    asynchronous on the ctx's stream) or DJB_MEM_HOST (the call stages through HBM and returns
- *    when the outputs are back in host memory).
+ *    when the outputs are back in host memory).  Host batches of >= 2^20 units of the operator
+ *    calls (eval / evalp / pdf / sample / evalp_is and the per-pair-parameter forms) are cut into
+ *    chunks so that inputs travel to HBM while earlier results travel back (a helper thread and a
+ *    second stream per call; results do not depend on the chunking).
  *  - Every function returns a djb_status; djb_last_error() returns the thread-local message
  *    (the text djb::exc would have carried, dj_brdf.h:54-59 / 578-587).
  *  - Handles are immutable after creation; batch calls on one ctx are serialised on its stream.

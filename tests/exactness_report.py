@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Bit-exactness report (run on the GPU box): fraction of eval / pdf outputs of the HIP path that are
-bit-identical to the CPU oracle, per NDF x Fresnel x params, on 2^20 pairs.  PYTHONPATH=. python tools/exactness_report.py"""
+bit-identical to the CPU oracle, per NDF x Fresnel x params, on 2^20 pairs.  PYTHONPATH=. python tests/exactness_report.py"""
 import numpy as np, sys
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import oraclelib

@@ -6,7 +6,7 @@ construction (GGX, Beckmann, abc, MERL, all sampling: IEEE arithmetic plus glibc
 powf algorithms) must be 100 % bit-exact; paths that call an fp64 trigonometric function (ROCm's libm here,
 glibc's in the reference: UTIA's and sgd's acos / atan2, the spline Fresnel's acos, the fitters' cos / sin / tan)
 may differ in ~1e-9 of the outputs by a last-ulp effect -- those are counted, dumped with their inputs, and must
-stay inside 1e-5.   PYTHONPATH=. python tools/fuzz_parity.py [rounds] [n] [seed]"""
+stay inside 1e-5.   PYTHONPATH=. python tests/fuzz_parity.py [rounds] [n] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

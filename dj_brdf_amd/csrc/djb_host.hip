@@ -539,11 +539,14 @@ djb_status host_pipeline(djb_ctx *ctx, long long n, std::vector<PipeArr> &ins, s
 	for (long long c = 0; c < nch; ++c) {
 		const int s = (int)(c & 1);
 		const long long lo = c * C, m = n - lo < C ? n - lo : C;
+		hipError_t late;
 		{   // slot s is free once chunk c-2 has left
 			std::unique_lock<std::mutex> lk(mu);
 			cv.wait(lk, [&] { return drained >= c - 1; });
-			if (werr != hipSuccess) break;
+			late = werr;
 		}
+		if (late != hipSuccess)   // the helper keeps waiting for the remaining chunks: release it before joining
+			return stop(fail(DJB_ERR_HIP, "djb_error: staging copy failed (%s) while returning a host batch", hipGetErrorString(late)));
 		hipError_t e = hipSuccess;
 		for (const PipeArr &a : ins)
 			if (e == hipSuccess) e = a.move(s, lo, m, true, ctx->stream);

@@ -20,9 +20,14 @@ batch on its own device ("weak" scaling), there is NO data-path collective; the 
 communication is the barrier and the MAX-over-ranks of the timed region.
 
 Extra objects in the JSON line:
-  secondary     (default workload only) merl_fit_100: wall time of the 100-material MERL fit sharded
-                over the N ranks (material m -> rank m mod N, "strong"); at N=1 also the other
-                single-GPU configs (ggx_eval_pdf, beckmann_sample) and utia_eval
+  secondary     (default workload only) BASELINE.json's second figure, the 100-material MERL fit on N GPUs
+                (material m -> rank m mod N, "strong", no exchange):
+                  merl_fit_files_100  END TO END, what examples/merl_params.cpp:53-69 does: 100 files of
+                                      34 992 012 B on local disk -> pread -> PCIe -> k_merl_convert -> one fit
+                                      launch -> alphas, wall time = max over ranks, with the load / fit split
+                                      and (N=1) the reference's own merl_params binary timed on a few of the files;
+                  merl_fit_100        compute only (tables already resident in HBM);
+                at N=1 also the other single-GPU configs (ggx_eval_pdf, beckmann_sample) and utia_eval
   roofline      dominant kernel: algorithmic bytes per launch / average launch duration
                 (HIP events on the ctx stream over the timed region) vs the 8 TB/s HBM peak
   cpu_baseline  the CPU path timed on this host (rank 0, N=1 only) on a bounded sample:
@@ -56,12 +61,13 @@ WORKLOADS = {
 }
 
 
-def synth_merl_files(n, synth, rank=0, distinct=10):
-    """n MERL-format files named after the MERL materials; `distinct` different tables, repeated."""
+def synth_merl_files(n, synth, rank=0, distinct=10, only=None):
+    """n MERL-format files named after the MERL materials; `distinct` different tables, repeated.
+    only: indices to create (a rank's share); the returned list then holds just those paths."""
     d = f"/tmp/djb_bench_merl_r{rank}"
     os.makedirs(d, exist_ok=True)
     paths, blobs = [], {}
-    for k in range(n):
+    for k in (range(n) if only is None else only):
         p = os.path.join(d, synth.MERL_NAMES[k % 100] + (f"_{k // 100}" if k >= 100 else "") + ".binary")
         if not (os.path.exists(p) and os.path.getsize(p) == synth.MERL_FILE_BYTES):
             r = k % distinct
@@ -310,7 +316,7 @@ def main():
 
     # BASELINE.json's second figure: wall time of the 100-material MERL fit on N GPUs (strong scaling:
     # material m -> rank m mod N, no exchange; tables resident in HBM).  Every rank takes part.
-    fit100 = None
+    fit100 = fitfiles = None
     want_secondary = not args.no_secondary and name == "merl_eval" and args.n is None
     if want_secondary:
         del step, keep
@@ -328,9 +334,30 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fit_ms = float(t[0])
         fit100 = {"materials": 100, "n_gpus": world, "wall_ms": fit_ms, "scaling": "strong",
-                  "value": 100 / (fit_ms * 1e-3), "unit": "materials/s"}
+                  "value": 100 / (fit_ms * 1e-3), "unit": "materials/s",
+                  "what": "compute only: tables resident in HBM, one k_fit launch per rank"}
         del st, kp
         torch.cuda.empty_cache()
+        # ... and end to end, files -> alphas (the reference driver's loop is file to file): rank r takes files r, r+N, ...
+        from dj_brdf_amd import merl_params
+        # every rank writes the files it will read (its own directory under /tmp), before the timed region
+        all_mine = synth_merl_files(100, synth, rank=rank, only=list(range(rank, 100, world)))
+        merl_params.fit_files_on(ctx, all_mine[:2])            # warm-up: allocations, page cache of the first files
+        barrier()
+        t_files = time.perf_counter()
+        _, _, tim = merl_params.fit_files_on(ctx, all_mine)
+        barrier()
+        files_wall = time.perf_counter() - t_files
+        tt = torch.tensor([files_wall, tim["total_s"], tim["load_s"], tim["fit_s"]], dtype=torch.float64, device=f"cuda:{local}")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        files_wall, f_total, f_load, f_fit = (float(x) for x in tt)
+        fitfiles = {"materials": 100, "n_gpus": world, "wall_ms": files_wall * 1e3, "scaling": "strong",
+                    "value": 100 / files_wall, "unit": "materials/s",
+                    "pipeline_ms": {"total": f_total * 1e3, "read_upload_convert": f_load * 1e3, "fit": f_fit * 1e3},
+                    "bytes_read": 100 * synth.MERL_FILE_BYTES,
+                    "what": "end to end: 100 MERL files on local disk (page cache warm) -> pread -> pinned ring -> H2D -> "
+                            "k_merl_convert -> one k_fit launch per rank -> alphas; max over ranks"}
 
     if rank == 0:
         value = world * n * args.steps / dt
@@ -343,7 +370,10 @@ def main():
             pmc = os.path.join(ROOT, "profiles", f"pmc_{name}.json")
             if os.path.exists(pmc):      # HBM bytes per launch from rocprofv3 PMC passes (profiles/README.md)
                 try:
-                    roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    pj = json.load(open(pmc))
+                    roofline["traffic"] = pj.get("hbm_bytes_per_launch")
+                    roofline["traffic_source"] = ("static: read from profiles/pmc_%s.json (separate rocprofv3 --pmc passes of "
+                                                  "tools/profile_bench.sh, %s), NOT measured in this run" % (name, pj.get("round", "round 1")))
                 except Exception:
                     pass
         else:
@@ -372,9 +402,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(name, synth)
         if want_secondary and world > 1:
-            rec["secondary"] = {"merl_fit_100": fit100}
+            rec["secondary"] = {"merl_fit_files_100": fitfiles, "merl_fit_100": fit100}
         if want_secondary and world == 1:
-            sec = {"merl_fit_100": fit100}
+            if not args.no_cpu_baseline:
+                fitfiles["cpu_baseline"] = cpu_baseline("merl_fit_files", synth)
+            sec = {"merl_fit_files_100": fitfiles, "merl_fit_100": fit100}
             for other in ("ggx_eval_pdf", "beckmann_sample", "utia_eval"):
                 on, ob, ou, _ = WORKLOADS[other]
                 st, kp = make_step(other, on, djb, synth, ctx, torch)

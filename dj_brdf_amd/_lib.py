@@ -16,7 +16,7 @@ DJB_OK = 0
 STATUS_NAMES = {
     0: "DJB_OK", 1: "DJB_ERR_INVALID_ARGUMENT", 2: "DJB_ERR_OPEN_FAILED", 3: "DJB_ERR_BAD_HEADER",
     4: "DJB_ERR_READ_FAILED", 5: "DJB_ERR_NOT_IMPLEMENTED", 6: "DJB_ERR_HIP", 7: "DJB_ERR_NO_DEVICE",
-    8: "DJB_ERR_UNKNOWN_MATERIAL",
+    8: "DJB_ERR_UNKNOWN_MATERIAL", 9: "DJB_ERR_OUT_OF_MEMORY", 10: "DJB_ERR_INTERNAL",
 }
 MEM_DEVICE, MEM_HOST = 0, 1
 
@@ -52,7 +52,7 @@ class exc(RuntimeError):
 # every symbol include/djb_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "djb_last_error", "djb_version", "djb_device_count", "djb_ctx_create", "djb_ctx_create_on_stream", "djb_ctx_destroy",
-    "djb_ctx_synchronize", "djb_ctx_set_option", "djb_merl_guard_stats", "djb_ctx_stream", "djb_timer_start", "djb_timer_stop_ms",
+    "djb_ctx_synchronize", "djb_ctx_set_stream", "djb_ctx_set_option", "djb_merl_guard_stats", "djb_ctx_stream", "djb_timer_start", "djb_timer_stop_ms",
     "djb_brdf_create_beckmann", "djb_brdf_create_ggx", "djb_brdf_create_merl_from_file",
     "djb_brdf_create_merl_from_memory", "djb_brdf_create_utia_from_file",
     "djb_brdf_create_utia_from_memory", "djb_brdf_create_lambert", "djb_brdf_create_tabular",

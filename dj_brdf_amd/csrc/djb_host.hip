@@ -51,6 +51,7 @@ struct djb_ctx {
 	void *scratch;            // worklist of the two-tier MERL kernel (grown on demand)
 	size_t scratch_bytes;
 	int merl_exact_only;      // DJB_OPT_MERL_EXACT_ONLY
+	int aniso_qf2_aligned = 0; // DJB_OPT_ANISO_QF2_ALIGNED
 	// HBM staging blocks of the DJB_MEM_HOST path, recycled across calls (hipMalloc costs more than
 	// a small batch); bounded by POOL_MAX_BYTES
 	std::mutex pool_mu;
@@ -69,6 +70,7 @@ struct djb_ctx {
 	// chunk c+1 comes in on `stream`, so both PCIe directions carry data; created on first use
 	hipStream_t d2h_stream = nullptr;
 	hipEvent_t pipe_ev[2] = { nullptr, nullptr };
+	hipStream_t owned_stream = nullptr;   // the stream djb_ctx_create made, after djb_ctx_set_stream moved the ctx off it
 };
 
 struct djb_brdf {
@@ -82,6 +84,7 @@ struct djb_brdf {
 	std::vector<float> aniso[8];
 	float aniso_fit[10];
 	int elev = 0, azim = 0;
+	int aniso_qf2_entries = 0;       // size of the reference's m_qf2 (== elev * azim unless rows came up short)
 	// merl / utia created from a file or from memory: the file's double payload stays in HBM (one of
 	// `allocs`) for get_samples(); 35 MB per MERL material, 2 MB per UTIA material
 	const double *raw_samples = nullptr;
@@ -695,12 +698,19 @@ djb_status read_file(const char *path, size_t header_bytes, std::vector<char> *h
 {
 	FILE *f = fopen(path, "rb");
 	if (!f) return fail(DJB_ERR_OPEN_FAILED, "djb_error: Failed to open %s\n", path);
-	long long n = 0;
 	if (header_is_merl) {
+		// dj_brdf.h:973-976 accepts any positive dims product and then indexes as 90x90x180; the product
+		// is taken in 64 bits here (the header is untrusted) and anything but the MERL shape is refused
+		// BEFORE the payload buffer is sized (a corrupt header must not be able to request gigabytes)
 		int32_t dims[3] = { 0, 0, 0 };
 		size_t got = fread(dims, 4, 3, f);
-		n = got == 3 ? (long long)(int32_t)(dims[0] * dims[1] * dims[2]) : 0;
+		const bool positive = got == 3 && dims[0] > 0 && dims[1] > 0 && dims[2] > 0;
+		const long long n = positive ? (long long)dims[0] * (long long)dims[1] * (long long)dims[2] : 0;
 		if (n <= 0) { fclose(f); return fail(DJB_ERR_BAD_HEADER, "djb_error: Failed to read MERL header\n"); }
+		if (n != MERL_N) {
+			fclose(f);
+			return fail(DJB_ERR_BAD_HEADER, "djb_error: MERL table has %lld samples per channel, expected %lld\n", n, MERL_N);
+		}
 		payload_bytes = sizeof(double) * 3 * (size_t)n;
 		header->assign((char *)dims, (char *)dims + 12);
 	}
@@ -714,6 +724,13 @@ djb_status read_file(const char *path, size_t header_bytes, std::vector<char> *h
 
 } // namespace
 
+// No C++ exception may cross the C ABI (a ctypes / C caller would abort): every entry point is a
+// function-try-block that maps std::bad_alloc and anything else to a status + message.
+#define DJB_ABI_CATCH \
+	catch (const std::bad_alloc &) { return fail(DJB_ERR_OUT_OF_MEMORY, "djb_error: out of host memory"); } \
+	catch (const std::exception &ex_) { return fail(DJB_ERR_INTERNAL, "djb_error: internal error: %s", ex_.what()); } \
+	catch (...) { return fail(DJB_ERR_INTERNAL, "djb_error: internal error"); }
+
 // ============================================================================ C ABI
 extern "C" {
 
@@ -721,7 +738,7 @@ const char *djb_last_error(void) { return g_err.c_str(); }
 int djb_version(void) { return DJB_HIP_VERSION; }
 
 djb_status djb_device_count(int *count)
-{
+try {
 	if (!count) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	*count = 0;
 	int n = 0;
@@ -732,6 +749,7 @@ djb_status djb_device_count(int *count)
 	*count = n;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **out)
 {
@@ -762,14 +780,17 @@ static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **o
 	return DJB_OK;
 }
 
-djb_status djb_ctx_create(int device, djb_ctx **out) { return ctx_create(device, nullptr, true, out); }
+djb_status djb_ctx_create(int device, djb_ctx **out)
+try { return ctx_create(device, nullptr, true, out); }
+DJB_ABI_CATCH
 djb_status djb_ctx_create_on_stream(int device, void *hip_stream, djb_ctx **out)
-{
+try {
 	return ctx_create(device, hip_stream, false, out);
 }
+DJB_ABI_CATCH
 
 djb_status djb_ctx_destroy(djb_ctx *ctx)
-{
+try {
 	if (!ctx) return DJB_OK;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
@@ -780,47 +801,72 @@ djb_status djb_ctx_destroy(djb_ctx *ctx)
 	if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
 	for (hipEvent_t e : ctx->pipe_ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+	if (ctx->owned_stream) (void)hipStreamDestroy(ctx->owned_stream);
 	delete ctx;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_ctx_synchronize(djb_ctx *ctx)
-{
+try {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 void *djb_ctx_stream(djb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+djb_status djb_ctx_set_stream(djb_ctx *ctx, void *hip_stream)
+try {
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	if (ctx->device < 0) return DJB_OK;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	hipStream_t ns = (hipStream_t)hip_stream;
+	if (ns == ctx->stream) return DJB_OK;
+	HIP_TRY(hipSetDevice(ctx->device));
+	// work already enqueued by this context (and its per-context scratch) stays ordered before anything the
+	// new stream will run: the new stream waits for an event recorded on the old one
+	HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+	HIP_TRY(hipStreamWaitEvent(ns, ctx->ev1, 0));
+	if (ctx->owns_stream) { ctx->owned_stream = ctx->stream; ctx->owns_stream = false; }
+	ctx->stream = ns;
+	return DJB_OK;
+}
+DJB_ABI_CATCH
+
 djb_status djb_timer_start(djb_ctx *ctx)
-{
+try {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_timer_stop_ms(djb_ctx *ctx, float *ms)
-{
+try {
 	if (!ctx || !ms) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
 	HIP_TRY(hipEventSynchronize(ctx->ev1));
 	HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 // ---------------------------------------------------------------- constructors
 djb_status djb_brdf_create_beckmann(djb_ctx *ctx, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
-{
+try {
 	return create_microfacet(ctx, DJB_KIND_BECKMANN, f, shadow, out);
 }
+DJB_ABI_CATCH
 djb_status djb_brdf_create_ggx(djb_ctx *ctx, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
-{
+try {
 	return create_microfacet(ctx, DJB_KIND_GGX, f, shadow, out);
 }
+DJB_ABI_CATCH
 
 djb_status djb_brdf_create_merl_from_memory(djb_ctx *ctx, const double *samples, int64_t n, djb_brdf **out)
-{
+try {
 	if (!ctx || !samples || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	if (n <= 0) return fail(DJB_ERR_BAD_HEADER, "djb_error: Failed to read MERL header\n");
 	// The reference accepts any positive dims product but indexes as 90x90x180 (dj_brdf.h:997-1008);
@@ -850,18 +896,20 @@ djb_status djb_brdf_create_merl_from_memory(djb_ctx *ctx, const double *samples,
 	*out = b;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_brdf_create_merl_from_file(djb_ctx *ctx, const char *path, djb_brdf **out)
-{
+try {
 	if (!ctx || !path || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	std::vector<char> hdr; std::vector<double> payload;
 	djb_status st = read_file(path, 12, &hdr, 0, &payload, true);
 	if (st != DJB_OK) return st;
 	return djb_brdf_create_merl_from_memory(ctx, payload.data(), (int64_t)(payload.size() / 3), out);
 }
+DJB_ABI_CATCH
 
 djb_status djb_brdf_create_utia_from_memory(djb_ctx *ctx, const double *samples, djb_brdf **out)
-{
+try {
 	if (!ctx || !samples || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	HIP_TRY(hipSetDevice(ctx->device));
 	djb_brdf *b;
@@ -885,21 +933,24 @@ djb_status djb_brdf_create_utia_from_memory(djb_ctx *ctx, const double *samples,
 	*out = b;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_brdf_create_utia_from_file(djb_ctx *ctx, const char *path, djb_brdf **out)
-{
+try {
 	if (!ctx || !path || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	std::vector<char> hdr; std::vector<double> payload;
 	djb_status st = read_file(path, 0, &hdr, sizeof(double) * (size_t)UTIA_N, &payload, false);
 	if (st != DJB_OK) return st;
 	return djb_brdf_create_utia_from_memory(ctx, payload.data(), out);
 }
+DJB_ABI_CATCH
 
 djb_status djb_brdf_create_lambert(djb_ctx *ctx, djb_brdf **out)
-{
+try {
 	if (!ctx || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	return alloc_brdf(ctx, DJB_KIND_LAMBERT, out);
 }
+DJB_ABI_CATCH
 
 // ---- sgd / abc: one row of the published parameter tables + the model's own Fresnel
 struct SgdRow { const char *name, *other_name; double v[33]; };
@@ -930,45 +981,50 @@ static djb_status create_model(djb_ctx *ctx, int kind, const double *row, int co
 }
 
 djb_status djb_brdf_create_sgd_from_params(djb_ctx *ctx, const double *params33, djb_brdf **out)
-{
+try {
 	if (!ctx || !params33 || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	return create_model(ctx, DJB_KIND_SGD, params33, 33, out);
 }
+DJB_ABI_CATCH
 djb_status djb_brdf_create_abc_from_params(djb_ctx *ctx, const double *params9, djb_brdf **out)
-{
+try {
 	if (!ctx || !params9 || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	return create_model(ctx, DJB_KIND_ABC, params9, 9, out);
 }
+DJB_ABI_CATCH
 djb_status djb_brdf_create_sgd(djb_ctx *ctx, const char *name, djb_brdf **out)
-{
+try {
 	if (!ctx || !name || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	for (const SgdRow &r : k_sgd_rows)
 		if (!strcmp(r.name, name) || !strcmp(r.other_name, name))
 			return create_model(ctx, DJB_KIND_SGD, r.v, 33, out);
 	return fail(DJB_ERR_UNKNOWN_MATERIAL, "djb_error: No SGD parameters for %s\n", name);     // dj_brdf.h:3449
 }
+DJB_ABI_CATCH
 djb_status djb_brdf_create_abc(djb_ctx *ctx, const char *name, djb_brdf **out)
-{
+try {
 	if (!ctx || !name || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	for (const AbcRow &r : k_abc_rows)
 		if (!strcmp(r.name, name))
 			return create_model(ctx, DJB_KIND_ABC, r.v, 9, out);
 	return fail(DJB_ERR_UNKNOWN_MATERIAL, "djb_error: No ABC parameters for %s\n", name);     // dj_brdf.h:3628
 }
+DJB_ABI_CATCH
 
 djb_status djb_brdf_destroy(djb_brdf *b)
-{
+try {
 	if (!b) return DJB_OK;
 	(void)hipSetDevice(b->ctx->device);
 	for (void *p : b->allocs) (void)hipFree(p);
 	delete b;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 int djb_brdf_kind(const djb_brdf *b) { return b ? b->dev.kind : -1; }
 
 djb_status djb_brdf_get_samples(const djb_brdf *b, double *out, int64_t capacity, int64_t *count)
-{
+try {
 	if (!b || !count) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	if (b->dev.kind != DJB_KIND_MERL && b->dev.kind != DJB_KIND_UTIA)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: get_samples needs a merl or utia BRDF");
@@ -987,6 +1043,7 @@ djb_status djb_brdf_get_samples(const djb_brdf *b, double *out, int64_t capacity
 	}
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 int djb_brdf_get_shadow(const djb_brdf *b) { return b ? b->dev.shadow : -1; }
 
 static bool is_microfacet_kind(int k)
@@ -995,15 +1052,16 @@ static bool is_microfacet_kind(int k)
 }
 
 djb_status djb_brdf_set_shadow(djb_brdf *b, int shadow)
-{
+try {
 	if (!b || !is_microfacet_kind(b->dev.kind))
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: set_shadow needs a microfacet BRDF");
 	b->dev.shadow = shadow != 0;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_brdf_set_fresnel(djb_brdf *b, const djb_fresnel_desc *f)
-{
+try {
 	if (!b || !is_microfacet_kind(b->dev.kind))
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: set_fresnel needs a microfacet BRDF");
 	HIP_TRY(hipSetDevice(b->ctx->device));
@@ -1015,6 +1073,7 @@ djb_status djb_brdf_set_fresnel(djb_brdf *b, const djb_fresnel_desc *f)
 	if (st != DJB_OK) { b->dev.fr = saved; b->fresnel = saved_pts; }
 	return st;
 }
+DJB_ABI_CATCH
 
 // ---------------------------------------------------------------- the fitter
 static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_kind, int res, int shadow,
@@ -1052,26 +1111,38 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 	o.p22 = (float *)(base + o_p22); o.sigma = (float *)(base + o_sigma); o.cdf = (float *)(base + o_cdf);
 	o.qf = (float *)(base + o_qf); o.fresnel = (float *)(base + o_fres);
 	o.alpha_beckmann = (float *)(base + o_ab); o.alpha_ggx = (float *)(base + o_ag); o.n_qf = (int *)(base + o_nqf);
-	HIP_TRY(hipMemcpyAsync(d_srcs, srcs.data(), sizeof(Brdf) * n_mat, hipMemcpyHostToDevice, ctx->stream));
+	{
+		hipError_t ce = hipMemcpyAsync(d_srcs, srcs.data(), sizeof(Brdf) * n_mat, hipMemcpyHostToDevice, ctx->stream);
+		if (ce != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); return fail(DJB_ERR_HIP, "djb_error: fit upload failed: %s", hipGetErrorString(ce)); }
+	}
 	split.sig_x = (float *)(base + o_sigx); split.sig_done = (unsigned int *)(base + o_done);
-	HIP_TRY(djbk::launch_fit(ctx->stream, d_srcs, src_kind, std_p, n_mat, res, shadow != 0, km, ratio, o, split));
-	auto back = [&](void *h, const void *d, size_t bytes) -> hipError_t {
-		return h ? hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
-	};
-	HIP_TRY(back(alpha_b, o.alpha_beckmann, sizeof(float) * n_mat));
-	HIP_TRY(back(alpha_g, o.alpha_ggx, sizeof(float) * n_mat));
-	HIP_TRY(back(p22, o.p22, sizeof(float) * (size_t)n_mat * res));
-	HIP_TRY(back(sigma, o.sigma, sizeof(float) * (size_t)n_mat * res));
-	HIP_TRY(back(cdf, o.cdf, sizeof(float) * (size_t)n_mat * res));
-	HIP_TRY(back(qf, o.qf, sizeof(float) * (size_t)n_mat * res));
-	HIP_TRY(back(fresnel, o.fresnel, sizeof(float) * 3 * (size_t)n_mat * res));
-	HIP_TRY(back(n_qf_host, o.n_qf, sizeof(int) * n_mat));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	// from here on the kernel may be running on `base`: every exit synchronises the stream before `pool`
+	// hands the block back to the context (and before `staging` goes out of scope)
+	hipError_t e = djbk::launch_fit(ctx->stream, d_srcs, src_kind, std_p, n_mat, res, shadow != 0, km, ratio, o, split);
+	// the outputs are one contiguous range of the block [o_p22, total): ONE pageable device-to-host copy
+	// (the one-copy-at-a-time rule of Staged::copy), unpacked on the host after the sync
+	std::vector<char> staging(total - o_p22);
+	if (e == hipSuccess) e = hipMemcpyAsync(staging.data(), base + o_p22, staging.size(), hipMemcpyDeviceToHost, ctx->stream);
+	hipError_t se = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess) e = se;
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(DJB_ERR_HIP, "djb_error: fit failed: %s", hipGetErrorString(e));
+	}
+	auto back = [&](void *h, size_t off, size_t bytes) { if (h) memcpy(h, staging.data() + (off - o_p22), bytes); };
+	back(alpha_b, o_ab, sizeof(float) * n_mat);
+	back(alpha_g, o_ag, sizeof(float) * n_mat);
+	back(p22, o_p22, sizeof(float) * (size_t)n_mat * res);
+	back(sigma, o_sigma, sizeof(float) * (size_t)n_mat * res);
+	back(cdf, o_cdf, sizeof(float) * (size_t)n_mat * res);
+	back(qf, o_qf, sizeof(float) * (size_t)n_mat * res);
+	back(fresnel, o_fres, sizeof(float) * 3 * (size_t)n_mat * res);
+	back(n_qf_host, o_nqf, sizeof(int) * n_mat);
 	return DJB_OK;
 }
 
 djb_status djb_brdf_create_tabular(djb_ctx *ctx, const djb_brdf *src, int res, int shadow, djb_brdf **out)
-{
+try {
 	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
@@ -1099,11 +1170,12 @@ djb_status djb_brdf_create_tabular(djb_ctx *ctx, const djb_brdf *src, int res, i
 	*out = t;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 // djb::tabular_anisotropic(brdf, elevation_res, azimuthal_res, shadow), dj_brdf.h:2238-2273
 djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src, int elev, int azim,
                                                int shadow, djb_brdf **out)
-{
+try {
 	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
@@ -1123,7 +1195,7 @@ djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src
 	       o_ndf = cv.take(4 * djbk::aniso_ndf_count()), o_cosd = cv.take(8 * djbk::aniso_cosd_count(azim)),
 	       o_st = cv.take(4 * djbk::aniso_sig_nodes()), o_ss = cv.take(4 * djbk::aniso_sig_nodes()),
 	       o_sc = cv.take(8 * djbk::aniso_sig_nodes()), o_ratio = cv.take(12 * w * E),
-	       o_probes = cv.take(4 * A * 8 * w), o_rowk = cv.take(4 * A);
+	       o_probes = cv.take(4 * A * 8 * w), o_rowk = cv.take(4 * A), o_qrows = cv.take(4 * G), o_qlen = cv.take(4 * A);
 	unsigned char *blk = nullptr;
 	HIP_TRY(hipMalloc((void **)&blk, cv.off));
 	hipError_t e = hipMemsetAsync(blk, 0, cv.off, ctx->stream);
@@ -1139,6 +1211,7 @@ djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src
 	S.terms = F4(o_terms); S.ndf_tab = F4(o_ndf); S.cosd = (double *)(blk + o_cosd);
 	S.sig_theta = F4(o_st); S.sig_sin = F4(o_ss); S.sig_cosd = (double *)(blk + o_sc);
 	S.ratio = F4(o_ratio); S.probes = F4(o_probes); S.rowk = F4(o_rowk);
+	S.qf2_rows = F4(o_qrows); S.qf2_len = (int *)(blk + o_qlen); S.qf2_aligned = ctx->aniso_qf2_aligned;
 	if (e == hipSuccess) e = djbk::launch_fit_aniso(ctx->stream, src->dev, std_p, S, shadow != 0);
 	djb_brdf *t;
 	alloc_brdf(ctx, DJB_KIND_TABULAR_ANISO, &t);
@@ -1157,10 +1230,12 @@ djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src
 	if (e == hipSuccess) e = hipMemcpyAsync(counts, S.counts, 16, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	if (e != hipSuccess) { djb_brdf_destroy(t); return fail(DJB_ERR_HIP, "djb_error: anisotropic fit failed: %s", hipGetErrorString(e)); }
-	// counts[1] = azimuth rows whose conditional CDF could not be inverted for every quantile (the
-	// w-node CDF can stay below (w-1)/w for rough data).  The reference's m_qf2 then comes up short
-	// and every later row is misaligned (dj_brdf.h:3005-3034, reads past the vector); here such rows
-	// are padded with 1.0 and stay aligned -- a deliberate deviation, eval/pdf are unaffected.
+	// counts[1] = azimuth rows whose conditional CDF could not be inverted for every quantile (the w-node CDF
+	// can stay below (w-1)/w at the last probe for grazing-heavy data).  The reference's m_qf2 then comes up
+	// short and every later row is misaligned (dj_brdf.h:3005-3034); ka_qf2_layout reproduces exactly that
+	// vector (counts[2] entries; what the reference reads past its end is 1.0 here) unless
+	// DJB_OPT_ANISO_QF2_ALIGNED is set on the context.  eval / pdf never touch this table.
+	t->aniso_qf2_entries = counts[2];
 	t->aniso[4].resize(counts[0]);                      // m_qf1 may be shorter than azim (scan quirk)
 	Brdf &d = t->dev;
 	d.shadow = shadow != 0;
@@ -1171,14 +1246,16 @@ djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src
 	*out = t;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_tabular_anisotropic_get(const djb_brdf *tab, int which, float *outp, int *count, int *elev, int *azim)
-{
+try {
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR_ANISO)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular_anisotropic brdf");
 	if (elev) *elev = tab->elev;
 	if (azim) *azim = tab->azim;
 	const std::vector<float> *v;
+	if (which == DJB_ATAB_QF2_ENTRIES) { if (count) *count = tab->aniso_qf2_entries; return DJB_OK; }
 	if (which >= 0 && which < 8) v = &tab->aniso[which];
 	else if (which == DJB_ATAB_FRESNEL) v = &tab->fresnel;
 	else return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown table %d", which);
@@ -1186,9 +1263,10 @@ djb_status djb_tabular_anisotropic_get(const djb_brdf *tab, int which, float *ou
 	if (outp) memcpy(outp, v->data(), sizeof(float) * v->size());
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_tabular_anisotropic_fit(const djb_brdf *tab, djb_params *beckmann, djb_params *ggx)
-{
+try {
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR_ANISO)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular_anisotropic brdf");
 	for (int k = 0; k < 2; ++k) {
@@ -1199,9 +1277,10 @@ djb_status djb_tabular_anisotropic_fit(const djb_brdf *tab, djb_params *beckmann
 	}
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_tabular_get(const djb_brdf *tab, int which, float *outp, int *count)
-{
+try {
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular brdf");
 	const std::vector<float> *v;
@@ -1217,20 +1296,22 @@ djb_status djb_tabular_get(const djb_brdf *tab, int which, float *outp, int *cou
 	if (outp) memcpy(outp, v->data(), sizeof(float) * v->size());
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_tabular_fit(const djb_brdf *tab, float *alpha_beckmann, float *alpha_ggx)
-{
+try {
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular brdf");
 	if (alpha_beckmann) *alpha_beckmann = tab->alpha_beckmann;
 	if (alpha_ggx) *alpha_ggx = tab->alpha_ggx;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_fit_merl_batch(djb_ctx *ctx, int n_mat, const double *const *tables, int res, int shadow,
                               float *alpha_beckmann, float *alpha_ggx, float *p22, float *sigma,
                               float *cdf, float *qf, float *fresnel)
-{
+try {
 	if (!ctx || !tables || n_mat < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
 	if (n_mat == 0) return DJB_OK;
 	djb_status st = check_call(ctx, nullptr, 0, DJB_MEM_DEVICE);
@@ -1249,11 +1330,12 @@ djb_status djb_fit_merl_batch(djb_ctx *ctx, int n_mat, const double *const *tabl
 	for (djb_brdf *b : mats) djb_brdf_destroy(b);
 	return st;
 }
+DJB_ABI_CATCH
 
 djb_status djb_fit_brdf_batch(djb_ctx *ctx, int n_mat, const djb_brdf *const *srcs_in, int res, int shadow,
                               float *alpha_beckmann, float *alpha_ggx, float *p22, float *sigma,
                               float *cdf, float *qf, float *fresnel)
-{
+try {
 	if (!ctx || !srcs_in || n_mat < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
 	if (n_mat == 0) return DJB_OK;
 	djb_status st = check_call(ctx, srcs_in[0], 0, DJB_MEM_DEVICE);
@@ -1267,29 +1349,34 @@ djb_status djb_fit_brdf_batch(djb_ctx *ctx, int n_mat, const djb_brdf *const *sr
 	}
 	return run_fit(ctx, srcs, srcs[0].kind, res, shadow, alpha_beckmann, alpha_ggx, p22, sigma, cdf, qf, fresnel, nullptr);
 }
+DJB_ABI_CATCH
 
 // ---------------------------------------------------------------- the operator surface
 djb_status djb_eval_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                           const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out, int mem)
-{
+try {
 	return eval_common(ctx, b, n, i, o, params, out, nullptr, mem, 1);
 }
+DJB_ABI_CATCH
 djb_status djb_evalp_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                            const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out, int mem)
-{
+try {
 	return eval_common(ctx, b, n, i, o, params, out, nullptr, mem, 2);
 }
+DJB_ABI_CATCH
 djb_status djb_pdf_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                          const djb_vec3_view *o, const djb_params *params, float *out_pdf, int mem)
-{
+try {
 	return eval_common(ctx, b, n, i, o, params, nullptr, out_pdf, mem, 4);
 }
+DJB_ABI_CATCH
 djb_status djb_eval_pdf_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                               const djb_vec3_view *o, const djb_params *params, int want_cos,
                               const djb_vec3_view *out_fr, float *out_pdf, int mem)
-{
+try {
 	return eval_common(ctx, b, n, i, o, params, out_fr, out_pdf, mem, want_cos ? 6 : 5);
 }
+DJB_ABI_CATCH
 
 static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
                                 const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_w,
@@ -1328,21 +1415,23 @@ static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, cons
 
 djb_status djb_sample_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
                             const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_i, int mem)
-{
+try {
 	return sample_common(ctx, b, n, u1, u2, o, params, nullptr, out_i, nullptr, mem, false);
 }
+DJB_ABI_CATCH
 
 djb_status djb_evalp_is_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
                               const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_w,
                               const djb_vec3_view *out_i, float *out_pdf, int mem)
-{
+try {
 	return sample_common(ctx, b, n, u1, u2, o, params, out_w, out_i, out_pdf, mem, true);
 }
+DJB_ABI_CATCH
 
 djb_status djb_sample_rng_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint32_t seed_u1, uint32_t seed_u2,
                                 uint64_t start, const djb_vec3_view *o, const djb_params *params,
                                 const djb_vec3_view *out_i)
-{
+try {
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
 	djb_status st = check_call(ctx, b, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
@@ -1354,6 +1443,7 @@ djb_status djb_sample_rng_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint
 	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, nullptr, nullptr, seed_u1, seed_u2, start, vo, vi, nullptr, nullptr));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 static djb_status hd_common(djb_ctx *ctx, int64_t n, const djb_vec3_view *a, const djb_vec3_view *b,
                             const djb_vec3_view *c, const djb_vec3_view *d, int mem, bool inverse)
@@ -1372,19 +1462,21 @@ static djb_status hd_common(djb_ctx *ctx, int64_t n, const djb_vec3_view *a, con
 }
 djb_status djb_io_to_hd_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                               const djb_vec3_view *h, const djb_vec3_view *d, int mem)
-{
+try {
 	return hd_common(ctx, n, i, o, h, d, mem, false);
 }
+DJB_ABI_CATCH
 djb_status djb_hd_to_io_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *h, const djb_vec3_view *d,
                               const djb_vec3_view *i, const djb_vec3_view *o, int mem)
-{
+try {
 	return hd_common(ctx, n, h, d, i, o, mem, true);
 }
+DJB_ABI_CATCH
 
 djb_status djb_query_batch(djb_ctx *ctx, const djb_brdf *b, int which, int64_t n, const djb_vec3_view *a,
                            const djb_vec3_view *bb, const djb_vec3_view *c, const djb_params *params,
                            const djb_vec3_view *out, int mem)
-{
+try {
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
 	const bool aniso = b->dev.kind == DJB_KIND_TABULAR_ANISO;
 	const bool model = b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_ABC;
@@ -1417,10 +1509,11 @@ djb_status djb_query_batch(djb_ctx *ctx, const djb_brdf *b, int which, int64_t n
 	HIP_TRY(djbk::launch_query(ctx->stream, b->dev, p, which, n, va, vb, vc, vo));
 	return sg.finish();
 }
+DJB_ABI_CATCH
 
 djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                                 int32_t *out_index, int mem)
-{
+try {
 	djb_status st = check_call(ctx, nullptr, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1432,12 +1525,13 @@ djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i,
 	HIP_TRY(djbk::launch_merl_index(ctx->stream, n, vi, vo, didx));
 	return sg.finish();
 }
+DJB_ABI_CATCH
 
 // ---------------------------------------------------------------- beckmann::lrep (host scalars)
 // dj_brdf.h:1959-2051, float arithmetic in the reference's order (this TU is built with
 // -ffp-contract=off).  lrep = {E1, E2, E3, E4, E5}.
 djb_status djb_lrep_op(int op, const float *a, const float *b, float x, float y, float *out)
-{
+try {
 	if (!a || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	float E1 = a[0], E2 = a[1], E3 = a[2], E4 = a[3], E5 = a[4];
 	const float dflt[5] = { 0, 0, 1, 1, 0 };
@@ -1473,9 +1567,10 @@ djb_status djb_lrep_op(int op, const float *a, const float *b, float x, float y,
 	out[0] = E1; out[1] = E2; out[2] = E3; out[3] = E4; out[4] = E5;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_params_to_lrep(const djb_params *params, float *out)                      // :1965-1974
-{
+try {
 	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	djb_params_resolved r;
 	djb_status st = resolve_params(params, &r);
@@ -1486,9 +1581,10 @@ djb_status djb_params_to_lrep(const djb_params *params, float *out)             
 	out[4] = 0.5f * r.rho * r.ax * r.ay + r.tx_n * r.ty_n;
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_lrep_to_params(const float *l, djb_params *out)                           // :1976-1990
-{
+try {
 	if (!l || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	float t1 = l[2] - l[0] * l[0], t2 = l[3] - l[1] * l[1];
 	t1 = t1 > 0.0f ? t1 : 0.0f; t2 = t2 > 0.0f ? t2 : 0.0f;
@@ -1500,6 +1596,7 @@ djb_status djb_lrep_to_params(const float *l, djb_params *out)                  
 	out->v[0] = ax; out->v[1] = ay; out->v[2] = rho; out->v[3] = l[0]; out->v[4] = l[1];
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                                  const djb_vec3_view *o, const float *rec, int mode, const float *base5,
@@ -1555,31 +1652,35 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
 djb_status djb_eval_pp_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                              const djb_vec3_view *o, const float *pdfparams, int want,
                              const djb_vec3_view *out_fr, float *out_pdf, int mem)
-{
+try {
 	return eval_pp_common(ctx, b, n, i, o, pdfparams, 0, nullptr, want, out_fr, out_pdf, nullptr, mem);
 }
+DJB_ABI_CATCH
 
 djb_status djb_eval_lean_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                                const djb_vec3_view *o, const djb_params *base, float scale, const float *lean,
                                int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pdfparams, int mem)
-{
+try {
 	float l1[5], base5[5];
 	djb_status st = djb_params_to_lrep(base, l1);
 	if (st != DJB_OK) return st;
 	if ((st = djb_lrep_op(DJB_LREP_IMUL, l1, nullptr, scale, 0.0f, base5)) != DJB_OK) return st;
 	return eval_pp_common(ctx, b, n, i, o, lean, 1, base5, want, out_fr, out_pdf, out_pdfparams, mem);
 }
+DJB_ABI_CATCH
 
 djb_status djb_ctx_set_option(djb_ctx *ctx, int option, int value)
-{
+try {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	if (option == DJB_OPT_MERL_EXACT_ONLY) { ctx->merl_exact_only = value != 0; return DJB_OK; }
+	if (option == DJB_OPT_ANISO_QF2_ALIGNED) { ctx->aniso_qf2_aligned = value != 0; return DJB_OK; }
 	return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown option %d", option);
 }
+DJB_ABI_CATCH
 
 djb_status djb_merl_guard_stats(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                                 const float *guard5, float *max_ratio3, unsigned long long *counters4)
-{
+try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1601,16 +1702,18 @@ djb_status djb_merl_guard_stats(djb_ctx *ctx, int64_t n, const djb_vec3_view *i,
 	memcpy(counters4, h + 16, 32);
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_params_resolve(const djb_params *params, djb_params_resolved *out)
-{
+try {
 	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	return resolve_params(params, out);
 }
+DJB_ABI_CATCH
 
 // ---------------------------------------------------------------- synthetic workloads
 djb_status djb_gen_directions(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t start, const djb_vec3_view *out)
-{
+try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1618,8 +1721,9 @@ djb_status djb_gen_directions(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t s
 	HIP_TRY(djbk::launch_gen_directions(ctx->stream, n, seed, start, View{ out->x, out->y, out->z, (long long)out->stride }));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 djb_status djb_gen_uniforms(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t start, float *out)
-{
+try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1627,8 +1731,9 @@ djb_status djb_gen_uniforms(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t sta
 	HIP_TRY(djbk::launch_gen_uniforms(ctx->stream, n, seed, start, out));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, unsigned long long *counters8)
-{
+try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1643,9 +1748,10 @@ djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, uns
 	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_selftest_libm(djb_ctx *ctx, int fn, int64_t n, const double *x, const double *y, double *out)
-{
+try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_HOST);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1663,9 +1769,10 @@ djb_status djb_selftest_libm(djb_ctx *ctx, int fn, int64_t n, const double *x, c
 	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int bins, unsigned long long *counts)
-{
+try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1674,6 +1781,7 @@ djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int
 	HIP_TRY(djbk::launch_histogram_xy(ctx->stream, n, View{ v->x, v->y, v->z, (long long)v->stride }, bins, counts));
 	return DJB_OK;
 }
+DJB_ABI_CATCH
 
 } // extern "C"
 
@@ -1682,6 +1790,8 @@ namespace djbk {
 
 hipStream_t ctx_stream(djb_ctx *ctx) { return ctx->stream; }
 int ctx_device(djb_ctx *ctx) { return ctx->device; }
+void ctx_lock(djb_ctx *ctx) { ctx->call_mu.lock(); }
+void ctx_unlock(djb_ctx *ctx) { ctx->call_mu.unlock(); }
 
 djb_status set_error(djb_status st, const char *fmt, ...)
 {

@@ -83,7 +83,7 @@ struct AnisoScratch {
 	int elev, azim;
 	// outputs: grids are elev x azim, element (i_elev, j_azim) at [i + elev*j]
 	float *p22, *sigma, *pdf1, *cdf1, *qf1, *pdf2, *cdf2, *qf2, *fres /* 3*elev */, *fit /* 10 */;
-	int *counts;                               // [0] entries in qf1, [1] misaligned qf2 rows (must be 0)
+	int *counts;                               // [0] entries in qf1, [1] short qf2 rows, [2] entries in the reference's m_qf2
 	// work arrays: N = (elev-1)*azim
 	float *k1, *xo, *yo, *zo, *s1, *s2, *tn, *dn;   // N each
 	double *v0, *v1;                                // N each
@@ -94,6 +94,8 @@ struct AnisoScratch {
 	float *ratio;                                   // 3*(elev-1)*elev
 	float *probes;                                  // azim*8*(elev-1)
 	float *rowk;                                    // azim
+	float *qf2_rows; int *qf2_len;                  // elev*azim / azim: the rows of compute_qf2 before they are laid out
+	int qf2_aligned;                                // 0: the reference's push_back layout; 1: every row at elev*k (DJB_OPT_ANISO_QF2_ALIGNED)
 };
 size_t aniso_terms_count();
 size_t aniso_ndf_count();

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(128) void ka_qf2_merge(AnisoScratch S)
 	const int E = S.elev, w = E - 1, res = w * 8;
 	const int k = blockIdx.x;
 	const float *pr = S.probes + (size_t)k * res;
-	float *row = S.qf2 + (size_t)E * k;
+	float *row = S.qf2_rows + (size_t)E * k;
 	__shared__ int s_missing;
 	if (threadIdx.x == 0) { s_missing = w; row[0] = 0.0f; }
 	__syncthreads();
@@ -468,10 +468,34 @@ __global__ __launch_bounds__(128) void ka_qf2_merge(AnisoScratch S)
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		int nq = s_missing;                            // entries written so far: row[0 .. nq-1]
-		if (nq < E) row[nq++] = 1.0f;
-		if (nq != E) atomicAdd(&S.counts[1], 1);       // a short row would misalign the reference's vector
-		for (; nq < E; ++nq) row[nq] = 1.0f;
+		int nq = s_missing;                            // entries the scan pushed: row[0 .. nq-1]
+		row[nq++] = 1.0f;                              // the closing push_back(1.0) of the row (dj_brdf.h:3028)
+		S.qf2_len[k] = nq;                             // == E unless the conditional CDF could not be inverted for every quantile
+		if (nq != E) atomicAdd(&S.counts[1], 1);
+	}
+}
+// m_qf2 as the reference lays it out (dj_brdf.h:3005-3034): the rows are push_back'ed one after the other, so a
+// row that came up short (a conditional CDF that stays below (w-1)/w at the last probe: grazing-heavy data)
+// shifts every later row, and spline::eval2d then reads the vector with a row stride of `elev` all the same
+// (dj_brdf.h:2814-2824) -- misaligned rows, and indices past the end of the vector (undefined in the
+// reference; 1.0 here).  `aligned` != 0 keeps every row at its own offset instead, padded with 1.0
+// (DJB_OPT_ANISO_QF2_ALIGNED: what the table was meant to be; not what the reference computes).
+__global__ __launch_bounds__(1024) void ka_qf2_layout(AnisoScratch S, int aligned)
+{
+	const int E = S.elev, A = S.azim, G = E * A;
+	__shared__ int s_off[1025];
+	if (threadIdx.x == 0) {
+		int o = 0;
+		for (int k = 0; k < A; ++k) { s_off[k] = aligned ? E * k : o; o += S.qf2_len[k]; }
+		s_off[A] = o;
+		S.counts[2] = o;                               // entries the reference's vector holds
+	}
+	for (int e = threadIdx.x; e < G; e += 1024) S.qf2[e] = 1.0f;
+	__syncthreads();
+	for (int k = 0; k < A; ++k) {
+		const int len = S.qf2_len[k];
+		const float *row = S.qf2_rows + (size_t)E * k;
+		for (int i = threadIdx.x; i < len; i += 1024) S.qf2[s_off[k] + i] = row[i];
 	}
 }
 
@@ -550,6 +574,7 @@ hipError_t run_kind(hipStream_t s, const Brdf &src, const Params &std_p, const A
 	hipLaunchKernelGGL(ka_cdf2, dim3(blocks_for(A)), dim3(BLOCK), 0, s, S, shadow);
 	hipLaunchKernelGGL(ka_qf2_probes, dim3(blocks_for((long long)A * w * 8)), dim3(BLOCK), 0, s, S, shadow);
 	hipLaunchKernelGGL(ka_qf2_merge, dim3(A), dim3(128), 0, s, S);
+	hipLaunchKernelGGL(ka_qf2_layout, dim3(1), dim3(1024), 0, s, S, S.qf2_aligned);
 	hipLaunchKernelGGL(ka_fit_terms, dim3(blocks_for(NP_FIT * NT_FIT)), dim3(BLOCK), 0, s, S, shadow);
 	hipLaunchKernelGGL(ka_fit_sum, dim3(1), dim3(BLOCK), 0, s, S);
 	return hipGetLastError();

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -38,6 +39,9 @@ namespace djbk {
 djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **out, bool own);
 hipStream_t ctx_stream(djb_ctx *ctx);
 int ctx_device(djb_ctx *ctx);
+// every entry point that enqueues on the ctx stream holds the context's call mutex (see djb_ctx)
+void ctx_lock(djb_ctx *ctx);
+void ctx_unlock(djb_ctx *ctx);
 djb_status set_error(djb_status st, const char *fmt, ...);
 } // namespace djbk
 
@@ -69,7 +73,9 @@ djb_status read_payload(const char *path, double *dst, std::string *err)
 	if (fd < 0) { snprintf(buf, sizeof buf, "djb_error: Failed to open %s\n", path); *err = buf; return DJB_ERR_OPEN_FAILED; }
 	int32_t dims[3] = { 0, 0, 0 };
 	ssize_t got = pread(fd, dims, 12, 0);
-	long long n = got == 12 ? (long long)(int32_t)(dims[0] * dims[1] * dims[2]) : 0;
+	// the header is untrusted: 64-bit product of positive dims only (an int32 product overflows: UB)
+	const bool positive = got == 12 && dims[0] > 0 && dims[1] > 0 && dims[2] > 0;
+	long long n = positive ? (long long)dims[0] * (long long)dims[1] * (long long)dims[2] : 0;
 	if (n <= 0) { close(fd); *err = "djb_error: Failed to read MERL header\n"; return DJB_ERR_BAD_HEADER; }
 	if (n != MERL_N) {
 		close(fd);
@@ -89,9 +95,20 @@ djb_status read_payload(const char *path, double *dst, std::string *err)
 
 } // namespace
 
+static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow,
+                                 int reader_threads, float *alpha_beckmann, float *alpha_ggx, double *timing);
+
 extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow,
                                          int reader_threads, float *alpha_beckmann, float *alpha_ggx,
                                          double *timing /* optional [4]: total, read+upload, fit, bytes */)
+try {
+	return fit_merl_files(ctx, n_files, paths, res, shadow, reader_threads, alpha_beckmann, alpha_ggx, timing);
+}
+catch (const std::bad_alloc &) { return djbk::set_error(DJB_ERR_OUT_OF_MEMORY, "djb_error: out of host memory"); }
+catch (...) { return djbk::set_error(DJB_ERR_INTERNAL, "djb_error: internal error in djb_fit_merl_files"); }
+
+static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow,
+                                 int reader_threads, float *alpha_beckmann, float *alpha_ggx, double *timing)
 {
 	if (!ctx || !paths || n_files < 0 || !alpha_beckmann || !alpha_ggx)
 		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
@@ -99,6 +116,7 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 	hipError_t e = hipSetDevice(djbk::ctx_device(ctx));
 	if (e != hipSuccess) return djbk::set_error(DJB_ERR_HIP, "djb_error: hipSetDevice: %s", hipGetErrorString(e));
 	hipStream_t stream = djbk::ctx_stream(ctx);
+	struct CallLock { djb_ctx *c; explicit CallLock(djb_ctx *c_) : c(c_) { djbk::ctx_lock(c); } ~CallLock() { djbk::ctx_unlock(c); } } call_lock(ctx);
 	const double t_begin = now_s();
 	const int n_slots = n_files < 4 ? n_files : 4;
 	if (reader_threads < 1) reader_threads = 4;
@@ -201,7 +219,13 @@ extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *
 	{ std::lock_guard<std::mutex> lk(mu); abort_flag = true; }
 	cv.notify_all();
 	for (std::thread &t : readers) t.join();
-	if (status == DJB_OK && hipStreamSynchronize(stream) != hipSuccess) { status = DJB_ERR_HIP; status_msg = "djb_error: stream sync failed"; }
+	// uploads / conversions of earlier slots may still be in flight, also on the failure path: the ring
+	// (pinned host + HBM) must not be freed under them
+	{
+		hipError_t se = hipStreamSynchronize(stream);
+		if (se != hipSuccess) (void)hipGetLastError();
+		if (status == DJB_OK && se != hipSuccess) { status = DJB_ERR_HIP; status_msg = "djb_error: stream sync failed"; }
+	}
 	const double t_loaded = now_s();
 	if (status != DJB_OK) { cleanup(); return djbk::set_error(status, "%s", status_msg.c_str()); }
 

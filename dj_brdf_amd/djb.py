@@ -41,13 +41,27 @@ class Context:
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         lib = _lib.load()
         self.device = device
-        self._h = C.c_void_p()
-        if stream is None and torch is not None and torch.cuda.is_available():
+        self._handle = C.c_void_p()
+        # stream=None with torch present: the ctx FOLLOWS torch's current stream of the device -- re-read on every
+        # call (the `_h` property), so work issued under `with torch.cuda.stream(s):` runs on s, where torch
+        # allocated the outputs and where its consumers wait.  An explicit stream pins the ctx to it.
+        self._follow_torch = stream is None and torch is not None and torch.cuda.is_available()
+        if self._follow_torch:
             stream = torch.cuda.current_stream(device).cuda_stream   # 0 == the default (null) stream
+        self._stream = stream
         if stream is None:
-            _lib.check(lib.djb_ctx_create(C.c_int(device), C.byref(self._h)))
+            _lib.check(lib.djb_ctx_create(C.c_int(device), C.byref(self._handle)))
         else:
-            _lib.check(lib.djb_ctx_create_on_stream(C.c_int(device), C.c_void_p(stream), C.byref(self._h)))
+            _lib.check(lib.djb_ctx_create_on_stream(C.c_int(device), C.c_void_p(stream), C.byref(self._handle)))
+
+    @property
+    def _h(self):
+        if self._follow_torch and self._handle:
+            cur = torch.cuda.current_stream(self.device).cuda_stream
+            if cur != self._stream:
+                _lib.check(_lib.load().djb_ctx_set_stream(self._handle, C.c_void_p(cur)))
+                self._stream = cur
+        return self._handle
 
     def synchronize(self):
         _lib.check(_lib.load().djb_ctx_synchronize(self._h))
@@ -61,9 +75,9 @@ class Context:
         return ms.value
 
     def close(self):
-        if self._h:
-            _lib.load().djb_ctx_destroy(self._h)
-            self._h = C.c_void_p()
+        if self._handle:
+            _lib.load().djb_ctx_destroy(self._handle)
+            self._handle = C.c_void_p()
 
     def __del__(self):  # pragma: no cover
         try:
@@ -863,6 +877,12 @@ class tabular_anisotropic(microfacet):
     def get_table(self, name: str):
         return self._get({"pdf1": 2, "cdf1": 3, "qf1": 4, "pdf2": 5, "cdf2": 6, "qf2": 7}[name])[0]
 
+    def qf2_entries(self) -> int:
+        """size of the reference's m_qf2: elev*azim unless conditional-CDF rows came up short (dj_brdf.h:3005-3034)"""
+        n = C.c_int()
+        _lib.check(_lib.load().djb_tabular_anisotropic_get(self._h, C.c_int(9), None, C.byref(n), None, None))
+        return n.value
+
     def get_fresnel(self):
         if getattr(self, "_fresnel_replaced", False):
             return self._fresnel
@@ -975,6 +995,12 @@ def histogram_xy(v, bins: int = 64, ctx: Optional[Context] = None):
 def set_merl_exact_only(ctx: Context, on: bool):
     """Force merl eval/evalp onto the operation-by-operation fp64 kernel (DJB_OPT_MERL_EXACT_ONLY)."""
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(1), C.c_int(int(on))))
+
+
+def set_aniso_qf2_aligned(ctx: Context, on: bool):
+    """tabular_anisotropic objects built afterwards keep the rows of the conditional quantile table aligned
+    (DJB_OPT_ANISO_QF2_ALIGNED) instead of reproducing the reference's shifted vector."""
+    _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(2), C.c_int(int(on))))
 
 
 def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):

@@ -149,6 +149,48 @@ def merl_table_hashed(seed: int = 7, negative_every: int = 97) -> np.ndarray:
     return out.reshape(3, 90, 90, 180)
 
 
+def merl_table_grazing(power: int = 30, lo: float = 1e-3, hi: float = 50.0) -> np.ndarray:
+    """A MERL-format table whose value depends on the theta_h bin only and rises steeply towards grazing
+    half-angles: lo + hi * (ih / 89)^power (exact integer powers of doubles, no libm).  Fitted as a
+    tabular_anisotropic it puts so much slope-pdf mass at the horizon that the conditional CDFs cannot be
+    inverted for the upper quantiles -- the case in which the reference's m_qf2 comes up short
+    (dj_brdf.h:3005-3034)."""
+    x = np.arange(90, dtype=np.float64) / 89.0
+    g = np.ones(90, dtype=np.float64)
+    for _ in range(int(power)):
+        g = g * x
+    g = lo + g * hi
+    t = np.empty((3, 90, 90, 180), dtype=np.float64)
+    t[:] = g[None, :, None, None]
+    return t
+
+
+UTIA_N = 3 * 288 * 288
+
+
+def utia_table_smooth() -> np.ndarray:
+    """A UTIA-format payload (3 x 288 x 288 doubles, sRGB-coded * 140; dj_brdf.h:1039-1059) of a smooth,
+    azimuthally ANISOTROPIC glossy material: value(theta_i, phi_i, theta_v, phi_v) from rational functions of
+    the grid indices only (+ - * / on doubles: the same bits on any machine, unlike numpy's SIMD trig).
+    idx = isp*288*288 + 288*(48*iti + ipi) + 48*itv + ipv."""
+    iti = np.arange(6, dtype=np.float64)[:, None, None, None]
+    ipi = np.arange(48, dtype=np.float64)[None, :, None, None]
+    itv = np.arange(6, dtype=np.float64)[None, None, :, None]
+    ipv = np.arange(48, dtype=np.float64)[None, None, None, :]
+    k = np.abs(ipi - ipv)
+    d = np.minimum(k, 48.0 - k) / 24.0                      # azimuth difference in [0, 1]; 0 = same azimuth
+    brush = ((ipi % 24.0) - 12.0) * ((ipi % 24.0) - 12.0) / 144.0       # period 180 degrees in phi_i
+    dt = (iti - itv) / 6.0
+    # lobe around the BACK-scattering configuration (what compute_p22_smith probes), wider across the brush direction
+    spec = 1.0 / (1.0 + 30.0 * dt * dt + 25.0 * d * d * (0.25 + brush))
+    tilt = 1.0 / (1.0 + 0.35 * (iti + itv))
+    out = np.empty((3, 6, 48, 6, 48), dtype=np.float64)
+    for c, (kd, ks) in enumerate(((0.30, 0.55), (0.22, 0.60), (0.12, 0.65))):
+        out[c] = 140.0 * (kd * 0.5 + ks * spec * tilt)
+    out[0, 0, 0, 0, 0] = -3.0                               # one negative sample: clamped by utia::normalize
+    return out.reshape(-1)
+
+
 def write_merl_binary(path: str, table: np.ndarray) -> None:
     """int32 dims[3] = (90, 90, 180) + 3*n doubles, plane order R, G, B (dj_brdf.h:963-983)."""
     tab = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)

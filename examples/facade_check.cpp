@@ -61,6 +61,11 @@ int main()
 		djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&a, &dummy); expect("tabular(ggx,90) alpha_beckmann", a, 2.75112224);
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&a, &dummy); expect("tabular(ggx,90) alpha_ggx", a, 0.866066337);
 		expect("tabular p22v.size", (double)tab.get_p22v().size(), 90);
+		// supports_smith_vndf_sampling(): true for the analytic lobes, false for BOTH tabulated classes (dj_brdf.h:412, 439)
+		djb::tabular_anisotropic tan_(djb::ggx(), 8, 8);
+		expect("ggx supports_smith_vndf_sampling", ggx.supports_smith_vndf_sampling() ? 1.0 : 0.0, 1.0);
+		expect("tabular supports_smith_vndf_sampling", tab.supports_smith_vndf_sampling() ? 1.0 : 0.0, 0.0);
+		expect("tabular_anisotropic supports_smith_vndf_sampling", tan_.supports_smith_vndf_sampling() ? 1.0 : 0.0, 0.0);
 		// what dj_beckmannconductor / dj_brdf do at load time: new djb::beckmann(tab->get_fresnel()) (mitsuba/dj_beckmannconductor.cpp:189)
 		djb::beckmann from_tab(tab.get_fresnel());
 		expect("beckmann(tab.get_fresnel()).fresnel(0.5).g", from_tab.fresnel(0.5f).y, tab.fresnel(0.5f).y);

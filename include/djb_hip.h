@@ -45,7 +45,9 @@ typedef enum {
 	DJB_ERR_NOT_IMPLEMENTED = 5,  /* "djb_error: Not Implemented"            dj_brdf.h:1785-1790 */
 	DJB_ERR_HIP = 6,              /* a HIP runtime call failed                                  */
 	DJB_ERR_NO_DEVICE = 7,        /* no gfx950 device / HIP runtime unusable                     */
-	DJB_ERR_UNKNOWN_MATERIAL = 8  /* "djb_error: No SGD/ABC parameters for %s" dj_brdf.h:3449, 3628 */
+	DJB_ERR_UNKNOWN_MATERIAL = 8, /* "djb_error: No SGD/ABC parameters for %s" dj_brdf.h:3449, 3628 */
+	DJB_ERR_OUT_OF_MEMORY = 9,    /* host allocation failed (std::bad_alloc never crosses this ABI) */
+	DJB_ERR_INTERNAL = 10         /* any other C++ exception caught at the ABI boundary            */
 } djb_status;
 
 enum { DJB_MEM_DEVICE = 0, DJB_MEM_HOST = 1 };
@@ -98,10 +100,19 @@ djb_status  djb_ctx_create_on_stream(int device, void *hip_stream, djb_ctx **out
 djb_status  djb_ctx_destroy(djb_ctx *ctx);
 djb_status  djb_ctx_synchronize(djb_ctx *ctx);
 void       *djb_ctx_stream(djb_ctx *ctx);
+/* move the context onto another hipStream_t of its device (NULL = the default stream).  The new stream
+ * first waits for everything the context enqueued so far, so per-context scratch stays ordered.  Callers
+ * that follow a framework's "current stream" (torch) call this before each batch call; cheap when unchanged. */
+djb_status  djb_ctx_set_stream(djb_ctx *ctx, void *hip_stream);
 /* options.  DJB_OPT_MERL_EXACT_ONLY = 1 makes merl eval/evalp run the operation-by-operation fp64
  * kernel for every pair instead of the two-tier kernel (fp32 fast path + guard bands + fp64 path
  * for ambiguous pairs); both give the same bits, the option exists to verify that.           */
-enum { DJB_OPT_MERL_EXACT_ONLY = 1 };
+enum { DJB_OPT_MERL_EXACT_ONLY = 1,
+/* DJB_OPT_ANISO_QF2_ALIGNED = 1: tabular_anisotropic objects created afterwards keep every row of the
+ * conditional quantile table at its own offset (padded with 1.0).  Default 0 = the reference's vector,
+ * in which a row whose conditional CDF cannot be inverted for every quantile comes up short and shifts
+ * all later rows (dj_brdf.h:3005-3034) -- the two differ only for such (grazing-heavy) data.          */
+       DJB_OPT_ANISO_QF2_ALIGNED = 2 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */
 djb_status  djb_timer_start(djb_ctx *ctx);
@@ -274,7 +285,8 @@ djb_status djb_tabular_fit(const djb_brdf *tab, float *alpha_beckmann, float *al
  * (dj_brdf.h:447-448), the sampling tables behind pdf1/cdf1/qf1/pdf2/cdf2/qf2, the Fresnel spline
  * points; grids are elev x azim floats, element (i_elev, j_azim) at [i + elev*j].           */
 enum { DJB_ATAB_P22 = 0, DJB_ATAB_SIGMA = 1, DJB_ATAB_PDF1 = 2, DJB_ATAB_CDF1 = 3, DJB_ATAB_QF1 = 4,
-       DJB_ATAB_PDF2 = 5, DJB_ATAB_CDF2 = 6, DJB_ATAB_QF2 = 7, DJB_ATAB_FRESNEL = 8 };
+       DJB_ATAB_PDF2 = 5, DJB_ATAB_CDF2 = 6, DJB_ATAB_QF2 = 7, DJB_ATAB_FRESNEL = 8,
+       DJB_ATAB_QF2_ENTRIES = 9 /* count only: entries of the reference's m_qf2 (< elev*azim if rows came up short) */ };
 djb_status djb_tabular_anisotropic_get(const djb_brdf *tab, int which, float *out, int *count,
                                        int *elev_cnt, int *azim_cnt);
 /* tabular_anisotropic::fit_beckmann_parameters / fit_ggx_parameters -> params::pdfparams(alphax,

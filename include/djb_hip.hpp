@@ -398,7 +398,12 @@ public:
 		djb_params_resolved m_r;
 	};
 
-	bool supports_smith_vndf_sampling() const { return djb_brdf_kind(m_h) != DJB_KIND_TABULAR; }
+	// false for the two tabulated classes, which sample with the "nmap" scheme (dj_brdf.h:412, 439)
+	bool supports_smith_vndf_sampling() const
+	{
+		const int k = djb_brdf_kind(m_h);
+		return k != DJB_KIND_TABULAR && k != DJB_KIND_TABULAR_ANISO;
+	}
 	int get_shadow() const { return djb_brdf_get_shadow(m_h); }
 	void set_shadow(bool shadow) { hip::check(djb_brdf_set_shadow(m_h, shadow ? 1 : 0)); }          // dj_brdf.h:278
 	void set_fresnel(const fresnel::impl &f)                                                         // dj_brdf.h:1521-1525

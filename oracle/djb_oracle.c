@@ -190,6 +190,7 @@ struct o_brdf {
 	int elev, azim;
 	float *a_p22, *a_sigma, *a_pdf1, *a_cdf1, *a_qf1, *a_pdf2, *a_cdf2, *a_qf2;
 	int n_a_pdf1, n_a_cdf1, n_a_qf1, n_a_pdf2, n_a_cdf2, n_a_qf2;
+	int n_a_qf2_ref;   /* entries the reference's m_qf2 holds (== elev*azim unless rows came up short) */
 	double *samples;
 	int64_t n_samples;
 };
@@ -1325,7 +1326,10 @@ static void aniso_compute_qf2(o_brdf *t) /* hdr:3005-3034 */
 		}
 		fv_push(&f, 1.0f);
 	}
-	/* eval2d indexes the full elev x azim grid: pad if the scan came up short (never in practice) */
+	/* eval2d indexes the full elev x azim grid whatever the vector holds (hdr:2814-2824): a short row shifts all
+	 * later rows, and the reference then reads past the end of m_qf2 (undefined).  The vector is kept exactly as
+	 * the reference builds it; only the undefined tail is given a value (1.0). */
+	t->n_a_qf2_ref = f.n;
 	while (f.n < t->elev * t->azim) fv_push(&f, 1.0f);
 	t->a_qf2 = f.v; t->n_a_qf2 = f.n;
 }
@@ -1361,6 +1365,18 @@ int o_aniso_get(const o_brdf *t, int which, float *out)
 	const float *src = which == 0 ? t->a_p22 : t->a_sigma;
 	if (out) memcpy(out, src, sizeof(float) * t->elev * t->azim);
 	return t->elev * t->azim;
+}
+
+/* the six sampling tables as stored: which 0 pdf1 1 cdf1 2 qf1 3 pdf2 4 cdf2 5 qf2; returns the count.
+ * which 6: no data, returns the number of entries of the reference's m_qf2 */
+int o_aniso_get_table(const o_brdf *t, int which, float *out)
+{
+	const float *src[6] = { t->a_pdf1, t->a_cdf1, t->a_qf1, t->a_pdf2, t->a_cdf2, t->a_qf2 };
+	const int n[6] = { t->n_a_pdf1, t->n_a_cdf1, t->n_a_qf1, t->n_a_pdf2, t->n_a_cdf2, t->n_a_qf2 };
+	if (which == 6) return t->n_a_qf2_ref;
+	if (which < 0 || which > 5) return 0;
+	if (out) memcpy(out, src[which], sizeof(float) * n[which]);
+	return n[which];
 }
 
 void o_aniso_query(const o_brdf *t, int which, int64_t n, const float *a, const float *b, float *out)

@@ -56,6 +56,7 @@ enum { O_BRDF_BECKMANN = 0, O_BRDF_GGX = 1, O_BRDF_TABULAR = 2, O_BRDF_MERL = 3,
 /* djb::tabular_anisotropic(brdf, elevation_res, azimuthal_res, shadow) (hdr:428-478, 2238-2273) */
 struct o_brdf *o_create_tabular_anisotropic(const struct o_brdf *src, int elev, int azim, int shadow);
 int  o_aniso_get(const struct o_brdf *t, int which, float *out);            /* 0 p22v 1 sigmav 4 fresnel */
+int  o_aniso_get_table(const struct o_brdf *t, int which, float *out);      /* 0 pdf1 1 cdf1 2 qf1 3 pdf2 4 cdf2 5 qf2; 6: count of the reference's m_qf2 */
 void o_aniso_query(const struct o_brdf *t, int which, int64_t n, const float *a, const float *b, float *out);
 void o_aniso_fit(const struct o_brdf *t, float *beckmann5, float *ggx5);
 

@@ -98,3 +98,34 @@ def aniso_source(L, src, tmpdir=None):
         synth.write_merl_binary(path, tab)
         return L.merl(path)
     return L.microfacet(src[0], ("ideal",), src[1])
+
+
+# tabular_anisotropic at the reference's own size class and on the data the class exists for:
+# name -> (source, elevation_res, azimuthal_res, shadow).  Sources: ("merl", alpha, diffuse, f0), ("utia",) =
+# synth.utia_table_smooth(), ("grazing", power) = synth.merl_table_grazing(power).  Goldens: tests/golden/aniso_big.npz
+# (tests/golden/make_golden_aniso_big.py: the 90 x 90 fits build the reference's 8010^2-double matrix, 513 MB, ~8 s each).
+N_ANISO_BIG = 512
+ANISO_BIG_CASES = {
+    "a90_merl": (("merl", 0.3, (0.10, 0.08, 0.05), (0.9, 0.7, 0.4)), 90, 90, True),
+    "a90_utia": (("utia",), 90, 90, True),
+    "a_utia_small": (("utia",), 16, 20, False),
+    # conditional-CDF rows that cannot be inverted for every quantile: the reference's m_qf2 comes up short
+    "a_short": (("grazing", 30), 24, 8, True),
+    "a_short12": (("grazing", 12), 12, 10, True),
+}
+
+
+def aniso_big_source(L, src, tmpdir=None):
+    """Source BRDF of an ANISO_BIG_CASES entry on L: the CPU oracle (from memory) or the product (module djb)."""
+    import os
+    from dj_brdf_amd import synth
+    is_oracle = getattr(L, "prefix", None) == "o_"
+    if src[0] == "utia":
+        tab = synth.utia_table_smooth()
+        if not is_oracle:
+            return L.utia.from_table(tab)
+        path = os.path.join(tmpdir, "smooth_utia.bin")
+        tab.tofile(path)
+        return L.utia(path)
+    tab = synth.merl_table(*src[1:]) if src[0] == "merl" else synth.merl_table_grazing(src[1])
+    return L.merl_from_table(tab) if is_oracle else L.merl.from_table(tab)

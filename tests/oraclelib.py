@@ -147,6 +147,16 @@ class CheckerLib:
         out["fit_beckmann"], out["fit_ggx"] = bk, gg
         return out
 
+    def aniso_sampling_tables(self, t):
+        """(oracle only) pdf1 / cdf1 / qf1 / pdf2 / cdf2 / qf2 as stored + the entry count of the reference's m_qf2"""
+        get = self._fn("aniso_get_table"); get.restype = C.c_int
+        out = {}
+        for code, name in enumerate(("pdf1", "cdf1", "qf1", "pdf2", "cdf2", "qf2")):
+            n = get(t, C.c_int(code), None)
+            a = np.empty((n,), np.float32); get(t, C.c_int(code), _ptr(a)); out[name] = a
+        out["qf2_entries"] = get(t, C.c_int(6), None)
+        return out
+
     def aniso_query(self, t, which: str, a, b=None):
         code = {"pdf1": 0, "cdf1": 1, "qf1": 2, "pdf2": 3, "cdf2": 4, "qf2": 5}[which]
         a = _f32(a); b = _f32(b) if b is not None else a

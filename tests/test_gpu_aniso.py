@@ -62,6 +62,64 @@ def test_anisotropic_full_resolution_vs_oracle(gpu_ctx, oracle):
     assert_close("fit_beckmann", fb, np.asarray(want["fit_beckmann"], np.float32))
 
 
+@pytest.mark.parametrize("name", ["a90_merl", "a90_utia", "a_utia_small", "a_short", "a_short12"])
+def test_anisotropic_big_utia_and_short_rows(gpu_ctx, oracle, name, tmp_path):
+    """The reference's own 90 x 90 size (8010^2-double matrix on the CPU), UTIA-sourced fits, and fits whose
+    conditional quantile table comes up short (dj_brdf.h:3005-3034): the HIP path against goldens from the REAL
+    reference (tests/golden/aniso_big.npz) and, table by table, against the oracle -- including the reference's
+    shifted m_qf2 layout (default) and the aligned layout behind DJB_OPT_ANISO_QF2_ALIGNED."""
+    from golden_cases import ANISO_BIG_CASES, aniso_big_source
+    g = np.load(os.path.join(G, "aniso_big.npz"))
+    src, elev, azim, shadow = ANISO_BIG_CASES[name]
+    dsrc = aniso_big_source(djb, src)
+    t = djb.tabular_anisotropic(dsrc, elev, azim, shadow, ctx=gpu_ctx)
+    p22, e, a = t.get_p22v()
+    assert (e, a) == (elev, azim)
+    assert_close(f"{name}/p22", p22, g[f"{name}_p22"], 2e-5)
+    assert_close(f"{name}/sigma", t.get_sigmav()[0], g[f"{name}_sigma"], 2e-5)
+    assert_close(f"{name}/fresnel", t.get_fresnel().get_points(), g[f"{name}_fresnel"], 2e-5)
+    fb = np.array(djb.tabular_anisotropic.fit_beckmann_parameters(t).get_pdfparams(), np.float32)
+    fg = np.array(djb.tabular_anisotropic.fit_ggx_parameters(t).get_pdfparams(), np.float32)
+    assert_close(f"{name}/fit_beckmann", fb, g[f"{name}_fit_beckmann"])
+    assert_close(f"{name}/fit_ggx", fg, g[f"{name}_fit_ggx"])
+    u1, u2 = g["u1"], g["u2"]
+    phi, th = (u1 * np.float32(6.2)).astype(np.float32), (u2 * np.float32(1.5)).astype(np.float32)
+    for q, args in (("pdf1", (phi,)), ("cdf1", (phi,)), ("qf1", (u1,)), ("pdf2", (th, phi)), ("cdf2", (th, phi))):
+        assert_close(f"{name}/{q}", getattr(t, q)(*args), g[f"{name}_{q}"], 5e-5)
+    for op in ("eval", "pdf"):
+        assert_close(f"{name}/{op}", getattr(t, op)(g["i"], g["o"]), g[f"{name}_{op}"], 1e-4)
+    short = name.startswith("a_short")
+    if short:
+        entries = int(g[f"{name}_qf2_entries"][0])
+        assert t.qf2_entries() == entries < elev * azim
+        assert_close(f"{name}/qf2 (taps the reference holds)", t.qf2(g[f"{name}_qf2_u"], g[f"{name}_qf2_phi"]), g[f"{name}_qf2"], 5e-5)
+    else:
+        assert t.qf2_entries() == elev * azim
+        assert_close(f"{name}/qf2", t.qf2(u2, phi), g[f"{name}_qf2"], 5e-5)
+        assert_close(f"{name}/sample", t.sample(u1, u2, g["o"]), g[f"{name}_sample"])
+    # every sampling table against the restatement (which the CPU suite pins to the same goldens)
+    ot = oracle.tabular_anisotropic(aniso_big_source(oracle, src, str(tmp_path)), elev, azim, shadow)
+    want = oracle.aniso_sampling_tables(ot)
+    for q in ("pdf1", "cdf1", "qf1", "pdf2", "cdf2", "qf2"):
+        assert_close(f"{name}/table {q}", t.get_table(q), want[q])
+    if short:
+        # the aligned layout: same rows, each at its own offset, padded with 1.0
+        djb.set_aniso_qf2_aligned(gpu_ctx, True)
+        try:
+            ta = djb.tabular_anisotropic(dsrc, elev, azim, shadow, ctx=gpu_ctx)
+        finally:
+            djb.set_aniso_qf2_aligned(gpu_ctx, False)
+        qa, qr = ta.get_table("qf2").reshape(azim, elev), t.get_table("qf2")
+        off = 0
+        for k in range(azim):
+            n_k = int(np.argmax(qa[k] == 1.0)) + 1            # entries up to and including the closing 1.0
+            assert np.array_equal(qa[k, :n_k], qr[off:off + n_k]) and (qa[k, n_k:] == 1.0).all(), k
+            off += n_k
+        assert off == entries and (qr[off:] == 1.0).all()
+        for q in ("pdf2", "cdf2", "qf1"):
+            assert np.array_equal(ta.get_table(q), t.get_table(q))
+
+
 def test_anisotropic_queries_reject_other_kinds(gpu_ctx):
     g = djb.ggx(ctx=gpu_ctx)
     with pytest.raises(djb.exc):

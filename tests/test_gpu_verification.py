@@ -1,0 +1,231 @@
+"""Verification holes named by the round-1 review, closed on the GPU (all through the C ABI):
+
+* the widest batch fit -- all 100 materials of BASELINE configs[4] in ONE launch, with the default helper
+  slicing (`fit_parts` = 2 on a 256-CU device: 200 workgroups with a bounded-wait hand-off) and with eight slices
+  forced (800 workgroups on 256 CUs: helpers that are not resident when their partner looks) -- against the CPU
+  oracle run on host threads: alphas bit for bit and the params.txt bytes;
+* the two-tier MERL lookup on every adversarial input family of tools/calibrate_merl_guard.py, against the
+  operation-by-operation kernel, with the guard-band margin asserted (djb_merl_guard_stats);
+* a two-process run of the real HIP path (both ranks may share device 0): pair-range eval and round-robin fit
+  reassembled and compared with the unsharded result.
+"""
+import os
+import socket
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from dj_brdf_amd import djb, merl_params, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------- (a) 100-material fit
+def test_fit_all_100_materials_one_launch(gpu_ctx, oracle, monkeypatch):
+    n_mat = 100
+    mats, futures = [], []
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+
+    def oracle_fit(tab):
+        t = oracle.tabular(oracle.merl_from_table(tab), 90, True)
+        w = oracle.tabular_tables(t)
+        return np.float32(w["alpha_beckmann"]), np.float32(w["alpha_ggx"])
+
+    with ThreadPoolExecutor(max_workers=max(2, min(32, cores))) as pool:     # ctypes releases the GIL
+        for k in range(n_mat):
+            tab = synth.merl_table(*synth.material_recipe(k))
+            mats.append(djb.merl.from_table(tab, ctx=gpu_ctx))
+            futures.append(pool.submit(oracle_fit, tab))
+            del tab
+        want = np.array([f.result() for f in futures], np.float32)          # [100, 2]
+    monkeypatch.delenv("DJB_FIT_PARTS", raising=False)
+    ab, ag = djb.fit_brdf_batch(mats, 90, True, ctx=gpu_ctx)                 # default slicing (2 per material on 256 CUs)
+    got = np.stack([ab, ag], 1)
+    bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))[0]
+    assert bad.size == 0, f"materials {bad[:8].tolist()}: fitted alphas differ from the oracle's: {got[bad[:4]]} vs {want[bad[:4]]}"
+    names = [f"/x/{synth.MERL_NAMES[k]}.binary" for k in range(n_mat)]
+    txt = merl_params.format_params_txt(names, [(float(a), float(b)) for a, b in got])
+    assert txt.encode() == merl_params.format_params_txt(names, [(float(a), float(b)) for a, b in want]).encode()
+    assert txt.count("\n") == n_mat + 1
+    for parts in ("8", "1", "3"):       # 800 workgroups (late helpers: the bounded wait must fall back), none, odd
+        monkeypatch.setenv("DJB_FIT_PARTS", parts)
+        ab2, ag2 = djb.fit_brdf_batch(mats, 90, True, ctx=gpu_ctx)
+        assert np.array_equal(ab2.view(np.uint32), ab.view(np.uint32)) and np.array_equal(ag2.view(np.uint32), ag.view(np.uint32)), parts
+    # a few complete table sets of the batch against the oracle (first, last, middle)
+    monkeypatch.delenv("DJB_FIT_PARTS", raising=False)
+    lib_tabs = djb.fit_merl_batch([m.get_samples() for m in (mats[0], mats[57], mats[99])], 90, True, ctx=gpu_ctx, return_tables=True)[2]
+    for j, k in enumerate((0, 57, 99)):
+        w = oracle.tabular_tables(oracle.tabular(oracle.merl_from_table(synth.merl_table(*synth.material_recipe(k))), 90, True))
+        for name in ("p22", "sigma", "cdf", "fresnel"):
+            a, b = np.asarray(lib_tabs[name][j], np.float32), np.asarray(w[name], np.float32).reshape(lib_tabs[name][j].shape)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, name)
+
+
+# ------------------------------------------------------------------------------------------- (b) MERL guard families
+def _merl_families(m, dev):
+    """(name, i, o) device tensors [3, m]: the adversarial families of tools/calibrate_merl_guard.py"""
+    import torch
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    R = lambda *shape: torch.rand(*shape, device=dev, generator=g)
+    unit = lambda v: (v / v.norm(dim=0, keepdim=True)).contiguous()
+    ones, zeros = torch.ones(m, device=dev), torch.zeros(m, device=dev)
+
+    def on_cone(axis, theta_deg, phi):
+        t = torch.deg2rad(theta_deg)
+        ref = torch.zeros_like(axis); ref[0] = 1.0
+        ref = torch.where((axis[0].abs() > 0.9).unsqueeze(0), torch.stack([zeros, ones, zeros]), ref)
+        e1 = unit(torch.linalg.cross(axis, ref, dim=0)); e2 = torch.linalg.cross(axis, e1, dim=0)
+        return unit(torch.cos(t) * axis + torch.sin(t) * (torch.cos(phi) * e1 + torch.sin(phi) * e2))
+
+    base = djb.gen_directions(m, 99)
+    yield "bench_distribution", djb.gen_directions(m, synth.SEED_I), djb.gen_directions(m, synth.SEED_O)
+    yield "backscatter", base, unit(base + 1e-3 * djb.gen_directions(m, 5))
+    yield "backscatter_tiny", base, unit(base + 1e-5 * djb.gen_directions(m, 6))
+    yield "mirror", base, unit(torch.stack([-base[0], -base[1], base[2]]) + 1e-3 * djb.gen_directions(m, 7))
+    yield "grazing", base, unit(torch.stack([base[0], base[1], 1e-3 * base[2]]))
+    yield "identical", base, base.clone()
+    yield "near_normal", unit(torch.stack([1e-2 * (R(m) - .5), 1e-2 * (R(m) - .5), ones])), \
+        unit(torch.stack([3e-2 * (R(m) - .5), 3e-2 * (R(m) - .5), ones]))
+    sph = lambda: unit(torch.randn(3, m, device=dev, generator=g))
+    yield "full_sphere", sph(), sph()
+    yield "lengths_0.5_to_2", (base * (0.5 + 1.5 * R(m))).contiguous(), (djb.gen_directions(m, 11) * (0.5 + 1.5 * R(m))).contiguous()
+    h = djb.gen_directions(m, 21)
+    td = torch.randint(1, 89, (m,), device=dev).float() + (R(m) - .5) * 2e-5
+    ii = on_cone(h, td, 2 * torch.pi * R(m))
+    yield "theta_d_on_bin_edges", ii, unit(2 * (ii * h).sum(0, keepdim=True) * h - ii)
+    k = torch.randint(1, 89, (m,), device=dev).float()
+    th = k * k / 90.0 + (R(m) - .5) * 2e-5
+    hh = on_cone(torch.stack([zeros, zeros, ones]), th, 2 * torch.pi * R(m))
+    ii = on_cone(hh, 5 + 70 * R(m), 2 * torch.pi * R(m))
+    yield "theta_h_on_bin_edges", ii, unit(2 * (ii * hh).sum(0, keepdim=True) * hh - ii)
+    pd = torch.randint(0, 180, (m,), device=dev).float() + (R(m) - .5) * 2e-5           # phi_d on whole degrees
+    hh = djb.gen_directions(m, 23)
+    ii = on_cone(hh, 5 + 70 * R(m), torch.deg2rad(pd))
+    yield "phi_d_near_bin_edges", ii, unit(2 * (ii * hh).sum(0, keepdim=True) * hh - ii)
+
+
+def test_merl_two_tier_on_adversarial_families(gpu_ctx):
+    """Tier 1 (fp32 estimates + guard bands) must agree with the operation-by-operation fp64 kernel on every pair
+    it calls certain -- on the bench distribution AND on inputs built to sit on bin edges, at the poles, below the
+    horizon, un-normalised.  Asserted per family: 0 index mismatches among certain pairs, composite == exact kernel
+    bit for bit, and the measured |estimate - reference| stays below half of the guard band (max_ratio < 0.5)."""
+    import torch
+    m = 20_000_000
+    tab = synth.merl_table_hashed()
+    mobj = djb.merl.from_table(tab, ctx=gpu_ctx)
+    report = []
+    for name, i, o in _merl_families(m, f"cuda:{gpu_ctx.device}"):
+        s = djb.merl_guard_stats(i, o, ctx=gpu_ctx)
+        a = mobj.eval(i, o)
+        djb.set_merl_exact_only(gpu_ctx, True)
+        try:
+            b = mobj.eval(i, o)
+        finally:
+            djb.set_merl_exact_only(gpu_ctx, False)
+        # NaN inputs (un-normalisable) produce NaN-free table values either way; compare bits
+        diff = int((a.view(torch.int32) != b.view(torch.int32)).any(dim=0).sum())
+        report.append((name, s, diff))
+        assert s["mismatch"] == 0, (name, s)
+        assert diff == 0, f"{name}: {diff} of {m} two-tier results differ from the exact kernel ({s})"
+        assert max(s["max_ratio"]) < 0.5, f"{name}: guard-band margin below 2x: {s}"
+        assert s["special"] + s["ambiguous"] + s["certain"] == m
+        del i, o, a, b
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "merl_guard_families.txt"), "w") as f:
+            for name, s, diff in report:
+                f.write(f"{name}: {s} two_tier_vs_exact_mismatches={diff}\n")
+
+
+# ------------------------------------------------------------------------------------------- (2) two ranks, real HIP path
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rank_main(rank, world, port, n_pairs, n_mat, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from dj_brdf_amd import djb, shard, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only: no data-path collective exists
+    dev = rank % max(1, djb.device_count())                            # ranks share device 0 when one GPU is visible
+    torch.cuda.set_device(dev)
+    ctx = djb.Context(dev)
+    # pair-range eval: MERL two-tier lookup + GGX eval on this rank's block, inputs generated on the device
+    lo, hi = shard.block_range(n_pairs, world, rank)
+    i = djb.gen_directions(hi - lo, synth.SEED_I, start=lo, ctx=ctx)
+    o = djb.gen_directions(hi - lo, synth.SEED_O, start=lo, ctx=ctx)
+    m = djb.merl.from_table(synth.merl_table_hashed(), ctx=ctx)
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=ctx)
+    part = torch.cat([m.eval(i, o), g.eval(i, o, djb.microfacet.params.isotropic(0.3))]).cpu().numpy()
+    # round-robin fit: this rank's materials in one launch
+    mine = shard.round_robin(n_mat, world, rank)
+    mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=ctx) for k in mine]
+    ab, ag = djb.fit_brdf_batch(mats, 90, True, ctx=ctx)
+    rows = shard.gather_rows([(k, (float(a), float(b))) for k, a, b in zip(mine, ab, ag)], world, rank, n_mat)
+    parts = [None] * world
+    dist.all_gather_object(parts, (lo, part))
+    q.put((rank, [p for _, p in sorted(parts, key=lambda x: x[0])] if rank == 0 else None, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_run_the_hip_path(gpu_ctx):
+    import torch
+    import torch.multiprocessing as mp
+    world, n_pairs, n_mat = 2, 1_000_003, 7
+    port = _free_port()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_rank_main, args=(r, world, port, n_pairs, n_mat, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (parts, rows) for r, parts, rows in (q.get(timeout=500) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # unsharded, in this process
+    i = djb.gen_directions(n_pairs, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n_pairs, synth.SEED_O, ctx=gpu_ctx)
+    m = djb.merl.from_table(synth.merl_table_hashed(), ctx=gpu_ctx)
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    want = torch.cat([m.eval(i, o), g.eval(i, o, djb.microfacet.params.isotropic(0.3))]).cpu().numpy()
+    got = np.concatenate(res[0][0], axis=1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "sharded pair ranges != unsharded batch"
+    mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=gpu_ctx) for k in range(n_mat)]
+    ab, ag = djb.fit_brdf_batch(mats, 90, True, ctx=gpu_ctx)
+    for r in range(world):
+        assert res[r][1] == [(float(a), float(b)) for a, b in zip(ab, ag)], f"rank {r}: sharded fit rows != unsharded"
+
+
+# ------------------------------------------------------------------------------------------- torch stream following
+def test_context_follows_torch_current_stream(gpu_ctx):
+    """Device-tensor calls run on torch's CURRENT stream (read per call), so outputs that torch allocated under
+    `with torch.cuda.stream(s)` are written on s, where their consumers are ordered (the stream used to
+    be captured once at construction)."""
+    import ctypes as C
+    import torch
+    from dj_brdf_amd import _lib
+    lib = _lib.load()
+    n = 4_000_000
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    p = djb.microfacet.params.isotropic(0.3)
+    i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
+    want = g.eval(i, o, p)
+    torch.cuda.synchronize()
+    base = lib.djb_ctx_stream(gpu_ctx._h)
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        got = g.eval(i, o, p)
+        assert (lib.djb_ctx_stream(gpu_ctx._h) or 0) == s2.cuda_stream != (base or 0)
+        total = got.sum()                       # consumer on s2: ordered after the kernel only if it ran on s2
+    s2.synchronize()
+    assert torch.equal(got, want) and torch.isfinite(total)
+    again = g.eval(i, o, p)                     # back on the original stream
+    assert (lib.djb_ctx_stream(gpu_ctx._h) or 0) == (base or 0)
+    torch.cuda.synchronize()
+    assert torch.equal(again, want)

@@ -246,3 +246,30 @@ def test_tabular_anisotropic(oracle, name):
         assert same(oracle.eval(t, g["i"], g["o"], None, op), g[f"{name}_{op}"]), (name, op)
     assert same(oracle.eval(t, g["i"], g["o"], ("elliptic", 0.2, 0.5, 0.7)), g[f"{name}_eval_ell"])
     assert same(oracle.sample(t, u1, u2, g["o"]), g[f"{name}_sample"])
+
+
+@pytest.mark.parametrize("name", ["a_utia_small", "a_short", "a_short12", "a90_utia"])
+def test_tabular_anisotropic_big_and_short_rows(oracle, name, tmp_path):
+    """The restatement against the real reference where round 1 had no evidence: a
+    UTIA-sourced fit, the reference's own 90 x 90 size, and fits whose conditional quantile table comes up short
+    (dj_brdf.h:3005-3034: later rows shift; only taps the reference's vector really holds are compared)."""
+    from golden_cases import ANISO_BIG_CASES, aniso_big_source
+    g = np.load(os.path.join(G, "aniso_big.npz"))
+    src, elev, azim, shadow = ANISO_BIG_CASES[name]
+    t = oracle.tabular_anisotropic(aniso_big_source(oracle, src, str(tmp_path)), elev, azim, shadow)
+    for k, v in oracle.aniso_tables(t).items():
+        assert same(v, g[f"{name}_{k}"]), (name, k)
+    u1, u2 = g["u1"], g["u2"]
+    phi, th = (u1 * np.float32(6.2)).astype(np.float32), (u2 * np.float32(1.5)).astype(np.float32)
+    for q, args in (("pdf1", (phi,)), ("cdf1", (phi,)), ("qf1", (u1,)), ("pdf2", (th, phi)), ("cdf2", (th, phi))):
+        assert same(oracle.aniso_query(t, q, *args), g[f"{name}_{q}"]), (name, q)
+    st = oracle.aniso_sampling_tables(t)
+    if name.startswith("a_short"):
+        assert st["qf2_entries"] == int(g[f"{name}_qf2_entries"][0]) < elev * azim
+        assert same(oracle.aniso_query(t, "qf2", g[f"{name}_qf2_u"], g[f"{name}_qf2_phi"]), g[f"{name}_qf2"]), (name, "qf2")
+    else:
+        assert st["qf2_entries"] == elev * azim
+        assert same(oracle.aniso_query(t, "qf2", u2, phi), g[f"{name}_qf2"]), (name, "qf2")
+        assert same(oracle.sample(t, u1, u2, g["o"]), g[f"{name}_sample"])
+    for op in ("eval", "pdf"):
+        assert same(oracle.eval(t, g["i"], g["o"], None, op), g[f"{name}_{op}"]), (name, op)

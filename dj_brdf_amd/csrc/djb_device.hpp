@@ -8,12 +8,24 @@
 //   * float(double(a)/double(b))  == a / b       for sqrt and for one division: 53 >= 2*24+2)
 // This header MUST be compiled with -ffp-contract=off: an FMA-contracted a*b+c*d chain moves
 // MERL bin indices ("hard parts").
+//
+// Two instantiations of the SAME source:
+//   * the gfx950 device code of the kernels (default; compiled by hipcc), and
+//   * DJB_HOST_MATH: plain C++ for the host (djb_cpu.cpp) -- the product's own CPU path for scalar calls and for
+//     machines without a GPU.  There every libm call IS the host's glibc call the reference makes, and the
+//     guarded / restated device shortcuts below collapse to the exact expressions they stand in for.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <stdint.h>
-
+#if defined(DJB_HOST_MATH)
+#include <math.h>
+#include <string.h>
+#define DJB_DEV static inline
+struct float4 { float x, y, z, w; };
+#else
+#include <hip/hip_runtime.h>
 #define DJB_DEV __device__ __forceinline__
+#endif
 #define DJB_PI 3.14159265358979323846
 
 namespace djbdev {
@@ -83,6 +95,11 @@ DJB_DEV v3 divs(v3 a, float b) { return scale(1.0f / b, a); }
 // float(double(a) / (4.0 * double(b))) == a / (4.0f * b): 4*b is exact in float and one division
 // of two floats rounds identically through double (dj_brdf.h:1544, 1724-1726, 1754-1760)
 DJB_DEV float fdiv4(float a, float b) { return a / (4.0f * b); }
+#if defined(DJB_HOST_MATH)
+// host: the exact expressions themselves (dj_brdf.h:612; float(1.0 / q))
+DJB_DEV float inversesqrt_(float x) { return F(1.0 / sqrt(D(x))); }
+DJB_DEV float recip_to_f32(double q) { return F(1.0 / q); }
+#else
 // ---- guarded fast paths for float(<double expression>) -----------------------------------------
 // The reference rounds a correctly-rounded double result e to float.  A cheaper double y with
 // |y - e| <= 2^-44 |e| rounds to the SAME float unless y lies within 2^-44 (relative) of a float
@@ -118,6 +135,7 @@ DJB_DEV float recip_to_f32(double q)
 		return F(1.0 / q);
 	return F(r);
 }
+#endif
 DJB_DEV v3 normalize(v3 v) { return scale(inversesqrt_(dot(v, v)), v); }              // dj_brdf.h:630
 DJB_DEV float intensity(v3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z; } // dj_brdf.h:69
 
@@ -136,6 +154,12 @@ DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 	else { theta = F(acos(D(p.z))); phi = F(atan2(D(p.y), D(p.x))); }
 }
 
+typedef unsigned int LdsTab;   // where a device kernel staged a libm table (0 = the global copy); unused on the host
+#if defined(DJB_HOST_MATH)
+// host: the reference's unqualified exp() / pow() are these very glibc functions
+DJB_DEV double glibc_exp(double x, LdsTab = 0u) { return exp(x); }
+DJB_DEV double glibc_pow(double x, double y, LdsTab = 0u, LdsTab = 0u) { return pow(x, y); }
+#else
 // ---- glibc 2.35's double exp / pow, restated --------------------------------------------------------
 // The reference's unqualified exp() / pow() are glibc's double functions: ~0.51 ulp, not
 // correctly rounded, so ROCm's device libm -- equally close to the true value -- rounds the other way
@@ -150,7 +174,6 @@ DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 // LDS copies of the tables are addressed through address-space-3 pointers rebuilt from a 32-bit offset, so that
 // the look-ups compile to ds_read (a generic pointer that may be global or LDS compiles to flat_load); the
 // offset form also keeps `Brdf` the same size for the host and the device compilation.
-typedef unsigned int LdsTab;
 typedef const __attribute__((address_space(3))) unsigned long long *lds_u64p;
 typedef const __attribute__((address_space(3))) double *lds_f64p;
 DJB_DEV LdsTab glibc_exp_tab_to_lds(unsigned long long *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
@@ -276,6 +299,8 @@ DJB_DEV double glibc_pow(double x, double y, LdsTab PT = 0u, LdsTab ET = 0u)
 	return res;
 }
 
+#endif
+
 // A&S 7.1.26 as the reference writes it, dj_brdf.h:667-688
 // e must be exp(double(-x*x)) (the same for +x and -x): callers that need that exponential
 // themselves (beckmann_qf2_radial) evaluate the fp64 exp once
@@ -292,6 +317,14 @@ DJB_DEV float erf_given_exp(float x, double e)
 }
 DJB_DEV float erf_(float x, LdsTab T = 0u) { return erf_given_exp(x, glibc_exp(D(-x * x), T)); }
 
+#if defined(DJB_HOST_MATH)
+// host: logf / std::exp(float) / std::pow(float, float) of the reference (dj_brdf.h:695, 1917, 1935) ARE glibc's
+struct GlibcTabs { LdsTab exp64; };
+DJB_DEV GlibcTabs glibc_tabs_global() { GlibcTabs t = { 0u }; return t; }
+DJB_DEV float glibc_logf(float x, const GlibcTabs &) { return logf(x); }
+DJB_DEV float glibc_expf(float x, const GlibcTabs &) { return expf(x); }
+DJB_DEV float glibc_powf(float x, float y, const GlibcTabs &) { return powf(x, y); }
+#else
 // ---- glibc 2.35's float logf / expf / powf, restated -------------------------------------------
 // The reference calls the float libm in erfinv (logf) and in Beckmann's Newton inversion (powf, expf),
 // dj_brdf.h:691-721, 1897-1952, so its values are those of the host's glibc -- not of a correctly
@@ -410,6 +443,8 @@ DJB_DEV float glibc_powf(float x, float y, const GlibcTabs &gt)
 	double rr = __builtin_fma(D(y), logx, -kd);
 	return glibc_exp2_tail(ki, rr, DJB_GLIBC_EXP2F_C[1], DJB_GLIBC_EXP2F_C[2], DJB_GLIBC_EXP2F_C[3], gt);
 }
+
+#endif
 
 // Giles' single-precision erfinv, dj_brdf.h:691-721
 DJB_DEV float erfinv_(float u, const GlibcTabs &gt)
@@ -974,6 +1009,7 @@ DJB_DEV void merl_angles_exact(v3 i, v3 o, float &th, float &td, float &pd)
 	xyz_to_theta_phi(d, td, pd);
 }
 
+#if !defined(DJB_HOST_MATH)   // tier 1 is a device optimisation; the host runs merl_index as written
 // ------------------------------------------------------------------ two-tier exact MERL binning
 // Tier 1 (this function): the three half/diff angles from closed-form geometry in fp32 --
 //     theta_h = angle(h, z),  theta_d = angle(i, h),  phi_d = azimuth of i around h
@@ -1078,6 +1114,8 @@ DJB_DEV bool merl_index_fast(v3 i, v3 o, const MerlGuard g, int &idx)
 	return finite && !f.special && !amb_h && !amb_d && !amb_p;
 }
 
+#endif
+
 // ------------------------------------------------------------------ UTIA (dj_brdf.h:1063-1157)
 // sRGB decode of dj_brdf.h:1147-1150: float(pow(double(float(double(v) + 0.055)) / 1.055, double(2.4f))).
 // Exact form: an IEEE fp64 division + the fp64 libm pow (~150 fp64 instructions).  Guarded form
@@ -1092,6 +1130,9 @@ DJB_DEV float srgb_decode_exact(float v)
 {
 	return F(glibc_pow(D(F(D(v) + 0.055)) / 1.055, D(2.4f)));
 }
+#if defined(DJB_HOST_MATH)
+DJB_DEV float srgb_decode(float v) { return srgb_decode_exact(v); }
+#else
 DJB_DEV double srgb_decode_fast(float v, bool &ok)
 {
 	const double num = D(F(D(v) + 0.055));
@@ -1119,6 +1160,8 @@ DJB_DEV float srgb_decode(float v)
 	if (__builtin_expect(!ok, 0)) return srgb_decode_exact(v);
 	return F(r);
 }
+
+#endif
 
 DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 {
@@ -1335,6 +1378,177 @@ DJB_DEV v3 gen_direction(uint32_t seed, uint64_t k)
 	if (r2 >= 0.998f) { x *= 0.5f; y *= 0.5f; }
 	float z = sqrtf((1.0f - x * x) - y * y);
 	return mk(x, y, z);
+}
+
+// ================================================================== one unit of each batch operator
+// The bodies the kernels (djb_kernels_eval.hip) and the host loops (djb_cpu.cpp) both run, one (i, o) pair /
+// sample / query per call.
+template <int KIND, int WANT, int FRK = -1>
+DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float &pdf)
+{
+	if (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
+		mf_eval_pdf<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
+	} else {
+		if (WANT & 3) {
+			v3 e;
+			if (KIND == KIND_MERL) e = merl_eval(b, i, o);
+			else if (KIND == KIND_UTIA) e = utia_eval(b, i, o);
+			else if (KIND == KIND_SGD) e = sgd_eval(b, i, o);
+			else if (KIND == KIND_ABC) e = abc_eval(b, i, o);
+			else e = divs(mk(p.nx, p.ny, p.nz), F(DJB_PI));        // lambert: reflectance / M_PI, dj_brdf.h:861-868
+			fr = (WANT & 2) ? scale(i.z, e) : e;                   // brdf::evalp, dj_brdf.h:803-806
+		}
+		if (WANT & 4) pdf = F(D(i.z) / DJB_PI);                    // brdf::pdf, dj_brdf.h:842-845
+	}
+}
+
+
+// sample (IS == false) / evalp_is (IS == true) of one unit; FRK as in mf_eval_pdf
+template <int KIND, bool IS, int FRK = -1>
+DJB_DEV void sample_one(const Brdf &b, const Params &p, float u1, float u2, v3 o, const GlibcTabs &gt,
+                        v3 &i_out, v3 &w_out, float &pdf_out)
+{
+	w_out = mk(0, 0, 0); pdf_out = 0.0f;
+	if (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
+		if (!IS) i_out = mf_sample<KIND>(b, p, u1, u2, o, gt);
+		else {
+			i_out = mk(0, 0, 0);
+			w_out = mf_evalp_is<KIND, FRK>(b, p, u1, u2, o, i_out, pdf_out, gt);
+		}
+	} else {
+		// brdf::sample / brdf::evalp_is defaults (cosine hemisphere), dj_brdf.h:816-845
+		float x, y;
+		uniform_to_concentric(u1, u2, x, y);
+		i_out = mk(x, y, F(sqrt(1.0 - D(x * x) - D(y * y))));
+		if (IS) {
+			v3 fr; float pdf;
+			eval_one<KIND, 6>(b, p, i_out, o, fr, pdf);
+			w_out = divs(fr, pdf);
+			pdf_out = pdf;
+		}
+	}
+}
+
+// per-pair microfacet::params.  MODE 0: pdfparams record (ax, ay, rho, tx, ty); MODE 1: LEAN moments (E1..E5)
+// combined with the scaled base lobe, params = lrep_to_params(base + lean) (mitsuba/dj_beckmannconductor.cpp:291-319),
+// optionally written back to out_pp5
+template <int KIND, int WANT, int MODE, int FRK = -1>
+DJB_DEV void pp_one(const Brdf &b, v3 i, v3 o, const float *r, const Lrep &base, float *out_pp5, v3 &fr, float &pdf)
+{
+	float ax, ay, rho, tx, ty;
+	if (MODE == 0) { ax = r[0]; ay = r[1]; rho = r[2]; tx = r[3]; ty = r[4]; }
+	else {
+		Lrep l; l.E1 = r[0]; l.E2 = r[1]; l.E3 = r[2]; l.E4 = r[3]; l.E5 = r[4];
+		lrep_to_pdfparams(lrep_add(base, l), ax, ay, rho, tx, ty);
+		if (out_pp5) { out_pp5[0] = ax; out_pp5[1] = ay; out_pp5[2] = rho; out_pp5[3] = tx; out_pp5[4] = ty; }
+	}
+	Params p = params_from_pdfparams(ax, ay, rho, tx, ty);
+	mf_eval_pdf<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
+}
+
+// ------------------------------------------------------------------ microfacet / radial queries
+// (dj_brdf.h:258-276, 307-314).  `which` is wave-uniform.
+enum { Q_NDF = 0, Q_GAF, Q_G1, Q_SIGMA, Q_P22, Q_VP22, Q_VNDF, Q_FRESNEL,
+       Q_P22_RADIAL = 16, Q_SIGMA_STD_RADIAL, Q_CDF_RADIAL, Q_QF_RADIAL, Q_QF2_RADIAL, Q_QF3_RADIAL, Q_QF1,
+       Q_A_PDF1 = 32, Q_A_CDF1, Q_A_QF1, Q_A_PDF2, Q_A_CDF2, Q_A_QF2,
+       Q_MODEL_NDF = 48, Q_MODEL_GAF, Q_MODEL_G1 };
+
+
+template <int KIND>
+DJB_DEV v3 query_one(const Brdf &b, const Params &p, int which, long long k, const View &va, const View &vb, const View &vc)
+{
+	v3 a = load3(va, k);
+	v3 r = mk(0, 0, 0);
+	switch (which) {
+	case Q_NDF: r.x = mf_ndf<KIND>(b, a, p); break;
+	case Q_GAF: {   // gaf(h, i, o): a = h (unused by Smith), vb = i, vc = o
+		v3 i = load3(vb, k), o = load3(vc, k);
+		float g1o = mf_g1_from_sigma(o, mf_sigma<KIND>(b, o, p), p);
+		float g1i = b.shadow ? mf_g1_from_sigma(i, mf_sigma<KIND>(b, i, p), p) : 0.0f;
+		r.x = mf_gaf_from_g1(b.shadow, g1i, g1o); break;
+	}
+	case Q_G1: { v3 kk = load3(vb, k); r.x = mf_g1_from_sigma(kk, mf_sigma<KIND>(b, kk, p), p); break; }
+	case Q_SIGMA: r.x = mf_sigma<KIND>(b, a, p); break;
+	case Q_P22: r.x = mf_p22<KIND>(b, a.x, a.y, p); break;
+	case Q_VP22: case Q_VNDF: {
+		v3 kk = load3(vb, k);
+		v3 h = which == Q_VNDF ? a : normalize(mk(-a.x, -a.y, 1));
+		float kh = dot(kk, h);
+		float vn = D(kh) > 0.0 ? kh * mf_ndf<KIND>(b, h, p) / mf_sigma<KIND>(b, kk, p) : 0.0f;
+		r.x = which == Q_VNDF ? vn : (h.z * h.z * h.z) * vn; break;
+	}
+	case Q_FRESNEL: r = fresnel_eval(b.fr, a.x); break;
+	case Q_P22_RADIAL: r.x = p22_radial<KIND>(b, a.x); break;
+	case Q_SIGMA_STD_RADIAL: r.x = sigma_std_radial<KIND>(b, a.x); break;
+	case Q_CDF_RADIAL: r.x = cdf_radial<KIND>(b, a.x); break;
+	case Q_QF_RADIAL: r.x = qf_radial<KIND>(b, a.x); break;
+	case Q_QF2_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf2_radial(a.x, a.y, a.z, glibc_tabs_global())
+	                       : KIND == KIND_GGX ? ggx_qf2_radial(a.x, a.y, a.z) : 0.0f; break;
+	case Q_QF3_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x, glibc_tabs_global())
+	                       : KIND == KIND_GGX ? ggx_qf3_radial(a.x, a.y) : 0.0f; break;
+	case Q_QF1: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x, glibc_tabs_global()) : KIND == KIND_GGX ? ggx_qf1(a.x) : 0.0f; break;
+	// tabular_anisotropic::{pdf1, cdf1, qf1, pdf2, cdf2, qf2} (dj_brdf.h:450-455)
+	case Q_A_PDF1: r.x = KIND == KIND_TABULAR_ANISO ? aniso_pdf1(b, a.x) : 0.0f; break;
+	case Q_A_CDF1: r.x = KIND == KIND_TABULAR_ANISO ? aniso_cdf1(b, a.x) : 0.0f; break;
+	case Q_A_QF1:  r.x = KIND == KIND_TABULAR_ANISO ? aniso_qf1(b, a.x) : 0.0f; break;
+	case Q_A_PDF2: r.x = KIND == KIND_TABULAR_ANISO ? aniso_pdf2(b, a.x, a.y) : 0.0f; break;
+	case Q_A_CDF2: r.x = KIND == KIND_TABULAR_ANISO ? aniso_cdf2(b, a.x, a.y) : 0.0f; break;
+	case Q_A_QF2:  r.x = KIND == KIND_TABULAR_ANISO ? aniso_qf2(b, a.x, a.y) : 0.0f; break;
+	}
+	return r;
+}
+
+// sgd::{ndf, gaf, g1, fresnel} and abc::{ndf, gaf, fresnel} (dj_brdf.h:505-509, 530-533)
+template <int KIND>
+DJB_DEV v3 model_query_one(const Brdf &b, int which, long long k, const View &va, const View &vb, const View &vc)
+{
+	v3 a = load3(va, k), r = mk(0, 0, 0);
+	switch (which) {
+	case Q_FRESNEL: r = fresnel_eval(b.fr, a.x); break;
+	case Q_MODEL_NDF: r = KIND == KIND_SGD ? sgd_ndf_rgb(b, a) : abc_ndf_rgb(b, a); break;
+	case Q_MODEL_GAF: {
+		v3 i = load3(vb, k), o = load3(vc, k);
+		if (KIND == KIND_SGD) r = sgd_gaf_rgb(b, i, o);
+		else r.x = abc_gaf(a, i, o);
+		break;
+	}
+	case Q_MODEL_G1: if (KIND == KIND_SGD) r = sgd_g1_rgb(b, a); break;
+	}
+	return r;
+}
+
+// dj_brdf.h:1010-1023 applied once per table entry instead of once per lookup: n = 1458000 texels from 3*n doubles
+DJB_DEV MerlTexel merl_convert_one(const double *s, long long n, long long k)
+{
+	float r = F(s[k] * (1.00 / 1500.0));
+	float g = F(s[k + n] * (1.15 / 1500.0));
+	float b = F(s[k + 2 * n] * (1.66 / 1500.0));
+	if (D(r) < 0.0 || D(g) < 0.0 || D(b) < 0.0) r = g = b = 0.0f;
+	MerlTexel t; t.x = r; t.y = g; t.z = b;
+	return t;
+}
+
+// utia::normalize (dj_brdf.h:1162-1177) then the (float_t) cast of dj_brdf.h:1144: record e of the 288*288
+// records of eight float4 (see utia_eval); n = 3*288*288 samples (three planes)
+DJB_DEV void utia_convert_one(const double *s, long long n, long long e, float4 *table)
+{
+	const float kf = 1.f / 140.f;
+	const long long plane = n / 3;
+	// e = 288 * (48 * iti + ipi) + 48 * itv + ipv
+	long long ipv = e % 48, itv = (e / 48) % 6, row = e / 288, ipi = row % 48;
+	float t[32];
+	for (int c = 0; c < 2; ++c)
+		for (int k = 0; k < 2; ++k)
+			for (int l = 0; l < 2; ++l) {
+				long long tv = itv + c > 5 ? 5 : itv + c;
+				long long src = 288 * (row - ipi + (ipi + k) % 48) + 48 * tv + (ipv + l) % 48;
+				for (int ch = 0; ch < 3; ++ch) {
+					double v = s[ch * plane + src] > 0.0 ? s[ch * plane + src] : 0.0;
+					t[3 * (4 * c + 2 * k + l) + ch] = F(v * D(kf));
+				}
+			}
+	for (int j = 24; j < 32; ++j) t[j] = 0.0f;
+	for (int j = 0; j < 8; ++j) { float4 q; q.x = t[4 * j]; q.y = t[4 * j + 1]; q.z = t[4 * j + 2]; q.w = t[4 * j + 3]; table[8 * e + j] = q; }
 }
 
 } // namespace djbdev

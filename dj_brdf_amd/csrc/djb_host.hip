@@ -1,9 +1,11 @@
 // djb_host.hip -- the C ABI of libdjb_hip.so (include/djb_hip.h): handle lifetime, argument
-// checking, host<->HBM staging, and kernel launches.  No CPU evaluation path exists here: every
-// numeric result comes from the gfx950 kernels; if HIP is unusable the calls fail with
-// DJB_ERR_NO_DEVICE / DJB_ERR_HIP.
+// checking, host<->HBM staging, and kernel launches.  On a GPU context every batch runs on the gfx950
+// kernels (or fails with DJB_ERR_NO_DEVICE / DJB_ERR_HIP: there is no silent fallback); the two uses of
+// the product's host instantiation of the same per-unit code (djb_cpu.cpp) are explicit: a CPU context
+// (djb_ctx_create(DJB_DEVICE_CPU)) and scalar-size DJB_MEM_HOST calls (<= DJB_SCALAR_HOST_MAX units).
 #include "../../include/djb_hip.h"
 #include "djb_internal.hpp"
+#include "djb_cpu.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -21,6 +23,7 @@
 using djbdev::Brdf;
 using djbdev::Params;
 using djbdev::View;
+using djbcpu::is_cpu;
 
 namespace {
 
@@ -52,6 +55,7 @@ struct djb_ctx {
 	size_t scratch_bytes;
 	int merl_exact_only;      // DJB_OPT_MERL_EXACT_ONLY
 	int aniso_qf2_aligned = 0; // DJB_OPT_ANISO_QF2_ALIGNED
+	int scalar_on_device = 0;  // DJB_OPT_SCALAR_ON_DEVICE: scalar-size host calls go through the GPU too (A/B testing)
 	// HBM staging blocks of the DJB_MEM_HOST path, recycled across calls (hipMalloc costs more than
 	// a small batch); bounded by POOL_MAX_BYTES
 	std::mutex pool_mu;
@@ -89,6 +93,11 @@ struct djb_brdf {
 	// `allocs`) for get_samples(); 35 MB per MERL material, 2 MB per UTIA material
 	const double *raw_samples = nullptr;
 	long long raw_count = 0;
+	std::vector<double> model_host;   // sgd / abc: the table row (host copy)
+	// host twin (djb_cpu.cpp object with the same tables in host memory) that answers scalar-size DJB_MEM_HOST
+	// calls on the caller's thread; built on first use, kept in step by set_shadow / set_fresnel
+	mutable std::once_flag twin_once;
+	mutable djb_brdf *twin = nullptr;
 };
 
 namespace {
@@ -394,6 +403,96 @@ djb_status check_call(djb_ctx *ctx, const djb_brdf *b, long long n, int mem)
 	return DJB_OK;
 }
 
+
+// ------------------------------------------------------------------ scalar-size host calls: the host twin
+// Calls of <= DJB_SCALAR_HOST_MAX units with DJB_MEM_HOST arrays -- the one-pair virtuals of the djb:: facade, a
+// renderer's per-hit eval / sample / pdf -- are evaluated on the CALLING thread by the product's host instantiation
+// of the same per-unit code (djb_cpu.cpp), from a host copy of the object's tables: no staging, no launch, no
+// context mutex (the reference's operators are const and concurrent; a 15 us GPU round trip per pair behind a
+// mutex is not a drop-in for them).  Everything larger runs on the GPU.  DJB_OPT_SCALAR_ON_DEVICE = 1 sends these
+// calls through the GPU as well (tests compare the two bit for bit).
+constexpr long long SCALAR_HOST_MAX = DJB_SCALAR_HOST_MAX;
+
+djb_fresnel_desc current_fresnel_desc(const djb_brdf *b)
+{
+	djb_fresnel_desc d;
+	memset(&d, 0, sizeof d);
+	d.kind = b->dev.fr.kind;
+	for (int c = 0; c < 3; ++c) { d.a[c] = b->dev.fr.a[c]; d.b[c] = b->dev.fr.b[c]; }
+	if (d.kind == DJB_FRESNEL_SPLINE) { d.points = b->fresnel.data(); d.npoints = b->dev.fr.npts; }
+	return d;
+}
+
+void build_twin(const djb_brdf *b)
+{
+	djb_ctx *tc = djbcpu::twin_ctx();
+	djb_brdf *t = nullptr;
+	djb_status st = DJB_ERR_NOT_IMPLEMENTED;
+	const djb_fresnel_desc fd = current_fresnel_desc(b);
+	auto download = [&](std::vector<char> &host, const void *dev, size_t bytes) -> bool {
+		host.resize(bytes);
+		std::lock_guard<std::recursive_mutex> call_lock(b->ctx->call_mu);
+		if (hipSetDevice(b->ctx->device) != hipSuccess) return false;
+		if (hipMemcpyAsync(host.data(), dev, bytes, hipMemcpyDeviceToHost, b->ctx->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+		return hipStreamSynchronize(b->ctx->stream) == hipSuccess;
+	};
+	switch (b->dev.kind) {
+	case DJB_KIND_BECKMANN: case DJB_KIND_GGX:
+		st = djbcpu::create_microfacet(tc, b->dev.kind, &fd, b->dev.shadow, &t); break;
+	case DJB_KIND_LAMBERT: st = djbcpu::create_lambert(tc, &t); break;
+	case DJB_KIND_SGD: case DJB_KIND_ABC:
+		if (!b->model_host.empty()) st = djbcpu::create_model(tc, b->dev.kind, b->model_host.data(), (int)b->model_host.size(), &t);
+		break;
+	case DJB_KIND_TABULAR: {
+		const int res = b->dev.n_p22;
+		std::vector<float> fz(3 * (size_t)res, 1.0f);
+		const float *fp = b->fresnel.size() == 3 * (size_t)res ? b->fresnel.data() : fz.data();
+		st = djbcpu::create_tabular_from_tables(tc, b->dev.shadow, res, b->p22.data(), b->sigma.data(), b->cdf.data(), b->qf.data(),
+		                                        (int)b->qf.size(), fp, b->alpha_beckmann, b->alpha_ggx, &t);
+		if (st == DJB_OK) st = djbcpu::set_fresnel(t, &fd);
+		break;
+	}
+	case DJB_KIND_TABULAR_ANISO: {
+		const float *tabs[8]; int counts[8];
+		for (int k = 0; k < 8; ++k) { tabs[k] = b->aniso[k].data(); counts[k] = (int)b->aniso[k].size(); }
+		std::vector<float> fz(3 * (size_t)b->elev, 1.0f);
+		const float *fp = b->fresnel.size() == 3 * (size_t)b->elev ? b->fresnel.data() : fz.data();
+		st = djbcpu::create_aniso_from_tables(tc, b->dev.shadow, b->elev, b->azim, tabs, counts, fp, b->aniso_fit, b->aniso_qf2_entries, &t);
+		if (st == DJB_OK) st = djbcpu::set_fresnel(t, &fd);
+		break;
+	}
+	case DJB_KIND_MERL: {
+		std::vector<char> host;
+		if (download(host, b->dev.merl, sizeof(djbdev::MerlTexel) * (size_t)MERL_N))
+			st = djbcpu::create_merl_from_texels(tc, (const float *)host.data(), &t);
+		break;
+	}
+	case DJB_KIND_UTIA: {
+		std::vector<char> host;
+		if (download(host, b->dev.utia, sizeof(float4) * 8 * (size_t)(UTIA_N / 3)))
+			st = djbcpu::create_utia_from_records(tc, (const float *)host.data(), &t);
+		break;
+	}
+	}
+	b->twin = st == DJB_OK ? t : nullptr;
+}
+
+// the host twin of a GPU object for a scalar-size host call, or NULL (then the call takes the GPU path)
+const djb_brdf *scalar_twin(const djb_ctx *ctx, const djb_brdf *b, long long n, int mem)
+{
+	if (mem != DJB_MEM_HOST || n > SCALAR_HOST_MAX || n < 0 || !b || ctx->scalar_on_device) return nullptr;
+	std::call_once(b->twin_once, build_twin, b);
+	return b->twin;
+}
+
+// CPU context: both operands must belong to it
+djb_status cpu_pair_check(const djb_ctx *ctx, const djb_brdf *b)
+{
+	if (b && is_cpu(ctx) != is_cpu(b))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf and ctx belong to different back ends (CPU / GPU)");
+	return DJB_OK;
+}
+
 djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                        const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_fr,
                        float *out_pdf, int mem, int want);
@@ -591,7 +690,12 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
                        float *out_pdf, int mem, int want)
 {
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
-	djb_status st = check_call(ctx, b, n, mem);
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	djb_status st = cpu_pair_check(ctx, b);
+	if (st != DJB_OK) return st;
+	if (is_cpu(ctx)) return djbcpu::eval(ctx, b, n, i, o, params, out_fr, out_pdf, want);
+	if (const djb_brdf *tw = scalar_twin(ctx, b, n, mem)) return djbcpu::eval(djbcpu::twin_ctx(), tw, n, i, o, params, out_fr, out_pdf, want);
+	st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
@@ -781,16 +885,20 @@ static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **o
 }
 
 djb_status djb_ctx_create(int device, djb_ctx **out)
-try { return ctx_create(device, nullptr, true, out); }
+try {
+	if (device == DJB_DEVICE_CPU) return djbcpu::ctx_create(out);
+	return ctx_create(device, nullptr, true, out); }
 DJB_ABI_CATCH
 djb_status djb_ctx_create_on_stream(int device, void *hip_stream, djb_ctx **out)
 try {
+	if (device == DJB_DEVICE_CPU) return djbcpu::ctx_create(out);
 	return ctx_create(device, hip_stream, false, out);
 }
 DJB_ABI_CATCH
 
 djb_status djb_ctx_destroy(djb_ctx *ctx)
 try {
+	if (is_cpu(ctx)) return djbcpu::ctx_destroy(ctx);
 	if (!ctx) return DJB_OK;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
@@ -809,18 +917,19 @@ DJB_ABI_CATCH
 
 djb_status djb_ctx_synchronize(djb_ctx *ctx)
 try {
+	if (is_cpu(ctx)) return DJB_OK;
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return DJB_OK;
 }
 DJB_ABI_CATCH
 
-void *djb_ctx_stream(djb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+void *djb_ctx_stream(djb_ctx *ctx) { return ctx && !is_cpu(ctx) ? (void *)ctx->stream : nullptr; }
 
 djb_status djb_ctx_set_stream(djb_ctx *ctx, void *hip_stream)
 try {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
-	if (ctx->device < 0) return DJB_OK;
+	if (is_cpu(ctx)) return DJB_OK;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	hipStream_t ns = (hipStream_t)hip_stream;
 	if (ns == ctx->stream) return DJB_OK;
@@ -837,6 +946,7 @@ DJB_ABI_CATCH
 
 djb_status djb_timer_start(djb_ctx *ctx)
 try {
+	if (is_cpu(ctx)) return djbcpu::timer_start(ctx);
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
 	return DJB_OK;
@@ -845,6 +955,7 @@ DJB_ABI_CATCH
 
 djb_status djb_timer_stop_ms(djb_ctx *ctx, float *ms)
 try {
+	if (is_cpu(ctx) && ms) return djbcpu::timer_stop_ms(ctx, ms);
 	if (!ctx || !ms) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
 	HIP_TRY(hipEventSynchronize(ctx->ev1));
@@ -856,17 +967,20 @@ DJB_ABI_CATCH
 // ---------------------------------------------------------------- constructors
 djb_status djb_brdf_create_beckmann(djb_ctx *ctx, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && out) return djbcpu::create_microfacet(ctx, DJB_KIND_BECKMANN, f, shadow, out);
 	return create_microfacet(ctx, DJB_KIND_BECKMANN, f, shadow, out);
 }
 DJB_ABI_CATCH
 djb_status djb_brdf_create_ggx(djb_ctx *ctx, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && out) return djbcpu::create_microfacet(ctx, DJB_KIND_GGX, f, shadow, out);
 	return create_microfacet(ctx, DJB_KIND_GGX, f, shadow, out);
 }
 DJB_ABI_CATCH
 
 djb_status djb_brdf_create_merl_from_memory(djb_ctx *ctx, const double *samples, int64_t n, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && samples && out) return djbcpu::create_merl_from_memory(ctx, samples, n, out);
 	if (!ctx || !samples || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	if (n <= 0) return fail(DJB_ERR_BAD_HEADER, "djb_error: Failed to read MERL header\n");
 	// The reference accepts any positive dims product but indexes as 90x90x180 (dj_brdf.h:997-1008);
@@ -900,6 +1014,7 @@ DJB_ABI_CATCH
 
 djb_status djb_brdf_create_merl_from_file(djb_ctx *ctx, const char *path, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && path && out) return djbcpu::create_merl_from_file(ctx, path, out);
 	if (!ctx || !path || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	std::vector<char> hdr; std::vector<double> payload;
 	djb_status st = read_file(path, 12, &hdr, 0, &payload, true);
@@ -910,6 +1025,7 @@ DJB_ABI_CATCH
 
 djb_status djb_brdf_create_utia_from_memory(djb_ctx *ctx, const double *samples, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && samples && out) return djbcpu::create_utia_from_memory(ctx, samples, out);
 	if (!ctx || !samples || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	HIP_TRY(hipSetDevice(ctx->device));
 	djb_brdf *b;
@@ -937,6 +1053,7 @@ DJB_ABI_CATCH
 
 djb_status djb_brdf_create_utia_from_file(djb_ctx *ctx, const char *path, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && path && out) return djbcpu::create_utia_from_file(ctx, path, out);
 	if (!ctx || !path || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	std::vector<char> hdr; std::vector<double> payload;
 	djb_status st = read_file(path, 0, &hdr, sizeof(double) * (size_t)UTIA_N, &payload, false);
@@ -947,6 +1064,7 @@ DJB_ABI_CATCH
 
 djb_status djb_brdf_create_lambert(djb_ctx *ctx, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && out) return djbcpu::create_lambert(ctx, out);
 	if (!ctx || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	return alloc_brdf(ctx, DJB_KIND_LAMBERT, out);
 }
@@ -959,9 +1077,11 @@ struct AbcRow { const char *name; double v[9]; };
 
 static djb_status create_model(djb_ctx *ctx, int kind, const double *row, int count, djb_brdf **out)
 {
+	if (is_cpu(ctx)) return djbcpu::create_model(ctx, kind, row, count, out);
 	HIP_TRY(hipSetDevice(ctx->device));
 	djb_brdf *b;
 	alloc_brdf(ctx, kind, &b);
+	b->model_host.assign(row, row + count);
 	double *d = nullptr;
 	hipError_t e = hipMalloc((void **)&d, sizeof(double) * count);
 	if (e == hipSuccess) e = hipMemcpy(d, row, sizeof(double) * count, hipMemcpyHostToDevice);
@@ -1013,6 +1133,8 @@ DJB_ABI_CATCH
 
 djb_status djb_brdf_destroy(djb_brdf *b)
 try {
+	if (is_cpu(b)) return djbcpu::destroy(b);
+	if (b && b->twin) djbcpu::destroy(b->twin);
 	if (!b) return DJB_OK;
 	(void)hipSetDevice(b->ctx->device);
 	for (void *p : b->allocs) (void)hipFree(p);
@@ -1021,10 +1143,11 @@ try {
 }
 DJB_ABI_CATCH
 
-int djb_brdf_kind(const djb_brdf *b) { return b ? b->dev.kind : -1; }
+int djb_brdf_kind(const djb_brdf *b) { return !b ? -1 : is_cpu(b) ? djbcpu::kind(b) : b->dev.kind; }
 
 djb_status djb_brdf_get_samples(const djb_brdf *b, double *out, int64_t capacity, int64_t *count)
 try {
+	if (is_cpu(b) && count) return djbcpu::get_samples(b, out, capacity, count);
 	if (!b || !count) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	if (b->dev.kind != DJB_KIND_MERL && b->dev.kind != DJB_KIND_UTIA)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: get_samples needs a merl or utia BRDF");
@@ -1044,7 +1167,7 @@ try {
 	return DJB_OK;
 }
 DJB_ABI_CATCH
-int djb_brdf_get_shadow(const djb_brdf *b) { return b ? b->dev.shadow : -1; }
+int djb_brdf_get_shadow(const djb_brdf *b) { return !b ? -1 : is_cpu(b) ? djbcpu::get_shadow(b) : b->dev.shadow; }
 
 static bool is_microfacet_kind(int k)
 {
@@ -1053,15 +1176,18 @@ static bool is_microfacet_kind(int k)
 
 djb_status djb_brdf_set_shadow(djb_brdf *b, int shadow)
 try {
+	if (is_cpu(b)) return djbcpu::set_shadow(b, shadow);
 	if (!b || !is_microfacet_kind(b->dev.kind))
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: set_shadow needs a microfacet BRDF");
 	b->dev.shadow = shadow != 0;
+	if (b->twin) djbcpu::set_shadow(b->twin, shadow);
 	return DJB_OK;
 }
 DJB_ABI_CATCH
 
 djb_status djb_brdf_set_fresnel(djb_brdf *b, const djb_fresnel_desc *f)
 try {
+	if (is_cpu(b)) return djbcpu::set_fresnel(b, f);
 	if (!b || !is_microfacet_kind(b->dev.kind))
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: set_fresnel needs a microfacet BRDF");
 	HIP_TRY(hipSetDevice(b->ctx->device));
@@ -1071,6 +1197,7 @@ try {
 	std::vector<float> saved_pts = b->fresnel;
 	djb_status st = set_fresnel(b, f);
 	if (st != DJB_OK) { b->dev.fr = saved; b->fresnel = saved_pts; }
+	else if (b->twin) st = djbcpu::set_fresnel(b->twin, f);
 	return st;
 }
 DJB_ABI_CATCH
@@ -1143,6 +1270,11 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 
 djb_status djb_brdf_create_tabular(djb_ctx *ctx, const djb_brdf *src, int res, int shadow, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && src && out) {
+		if (!is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a CPU context fits BRDFs of a CPU context");
+		return djbcpu::create_tabular(ctx, src, res, shadow, out);
+	}
+	if (src && is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf belongs to a CPU context");
 	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
@@ -1176,6 +1308,11 @@ DJB_ABI_CATCH
 djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src, int elev, int azim,
                                                int shadow, djb_brdf **out)
 try {
+	if (is_cpu(ctx) && src && out) {
+		if (!is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a CPU context fits BRDFs of a CPU context");
+		return djbcpu::create_tabular_anisotropic(ctx, src, elev, azim, shadow, out);
+	}
+	if (src && is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf belongs to a CPU context");
 	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
@@ -1250,6 +1387,7 @@ DJB_ABI_CATCH
 
 djb_status djb_tabular_anisotropic_get(const djb_brdf *tab, int which, float *outp, int *count, int *elev, int *azim)
 try {
+	if (is_cpu(tab)) return djbcpu::aniso_get(tab, which, outp, count, elev, azim);
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR_ANISO)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular_anisotropic brdf");
 	if (elev) *elev = tab->elev;
@@ -1267,6 +1405,7 @@ DJB_ABI_CATCH
 
 djb_status djb_tabular_anisotropic_fit(const djb_brdf *tab, djb_params *beckmann, djb_params *ggx)
 try {
+	if (is_cpu(tab)) return djbcpu::aniso_fit(tab, beckmann, ggx);
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR_ANISO)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular_anisotropic brdf");
 	for (int k = 0; k < 2; ++k) {
@@ -1281,6 +1420,7 @@ DJB_ABI_CATCH
 
 djb_status djb_tabular_get(const djb_brdf *tab, int which, float *outp, int *count)
 try {
+	if (is_cpu(tab)) return djbcpu::tabular_get(tab, which, outp, count);
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular brdf");
 	const std::vector<float> *v;
@@ -1300,6 +1440,7 @@ DJB_ABI_CATCH
 
 djb_status djb_tabular_fit(const djb_brdf *tab, float *alpha_beckmann, float *alpha_ggx)
 try {
+	if (is_cpu(tab)) return djbcpu::tabular_fit(tab, alpha_beckmann, alpha_ggx);
 	if (!tab || tab->dev.kind != DJB_KIND_TABULAR)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: not a tabular brdf");
 	if (alpha_beckmann) *alpha_beckmann = tab->alpha_beckmann;
@@ -1312,6 +1453,7 @@ djb_status djb_fit_merl_batch(djb_ctx *ctx, int n_mat, const double *const *tabl
                               float *alpha_beckmann, float *alpha_ggx, float *p22, float *sigma,
                               float *cdf, float *qf, float *fresnel)
 try {
+	if (is_cpu(ctx) && tables && n_mat >= 0) return n_mat == 0 ? DJB_OK : djbcpu::fit_merl_batch(ctx, n_mat, tables, res, shadow, alpha_beckmann, alpha_ggx, p22, sigma, cdf, qf, fresnel);
 	if (!ctx || !tables || n_mat < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
 	if (n_mat == 0) return DJB_OK;
 	djb_status st = check_call(ctx, nullptr, 0, DJB_MEM_DEVICE);
@@ -1336,6 +1478,7 @@ djb_status djb_fit_brdf_batch(djb_ctx *ctx, int n_mat, const djb_brdf *const *sr
                               float *alpha_beckmann, float *alpha_ggx, float *p22, float *sigma,
                               float *cdf, float *qf, float *fresnel)
 try {
+	if (is_cpu(ctx) && srcs_in && n_mat >= 0) return n_mat == 0 ? DJB_OK : djbcpu::fit_brdf_batch(ctx, n_mat, srcs_in, res, shadow, alpha_beckmann, alpha_ggx, p22, sigma, cdf, qf, fresnel);
 	if (!ctx || !srcs_in || n_mat < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
 	if (n_mat == 0) return DJB_OK;
 	djb_status st = check_call(ctx, srcs_in[0], 0, DJB_MEM_DEVICE);
@@ -1383,7 +1526,16 @@ static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, cons
                                 const djb_vec3_view *out_i, float *out_pdf, int mem, bool is)
 {
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
-	djb_status st = check_call(ctx, b, n, mem);
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	djb_status st = cpu_pair_check(ctx, b);
+	if (st != DJB_OK) return st;
+	if (is_cpu(ctx) || scalar_twin(ctx, b, n, mem)) {
+		const bool on_cpu = is_cpu(ctx);
+		if (is && (!out_w || !out_pdf)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+		if (!u1 || !u2) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null input array");
+		return djbcpu::sample(on_cpu ? ctx : djbcpu::twin_ctx(), on_cpu ? b : b->twin, n, u1, u2, 0, 0, 0, o, params, is ? out_w : nullptr, out_i, out_pdf);
+	}
+	st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
@@ -1432,6 +1584,11 @@ djb_status djb_sample_rng_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint
                                 uint64_t start, const djb_vec3_view *o, const djb_params *params,
                                 const djb_vec3_view *out_i)
 try {
+	if (is_cpu(ctx)) {
+		if (b && !is_cpu(b)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf belongs to a GPU context");
+		return djbcpu::sample(ctx, b, n, nullptr, nullptr, seed_u1, seed_u2, start, o, params, nullptr, out_i, nullptr);
+	}
+	if (b && is_cpu(b)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf belongs to a CPU context");
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
 	djb_status st = check_call(ctx, b, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
@@ -1448,6 +1605,9 @@ DJB_ABI_CATCH
 static djb_status hd_common(djb_ctx *ctx, int64_t n, const djb_vec3_view *a, const djb_vec3_view *b,
                             const djb_vec3_view *c, const djb_vec3_view *d, int mem, bool inverse)
 {
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	if (is_cpu(ctx)) return djbcpu::io_hd(ctx, n, a, b, c, d, inverse);
+	if (mem == DJB_MEM_HOST && n >= 0 && n <= SCALAR_HOST_MAX && !ctx->scalar_on_device) return djbcpu::io_hd(djbcpu::twin_ctx(), n, a, b, c, d, inverse);
 	djb_status st = check_call(ctx, nullptr, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1478,23 +1638,30 @@ djb_status djb_query_batch(djb_ctx *ctx, const djb_brdf *b, int which, int64_t n
                            const djb_vec3_view *out, int mem)
 try {
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
-	const bool aniso = b->dev.kind == DJB_KIND_TABULAR_ANISO;
-	const bool model = b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_ABC;
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	const int bkind = djb_brdf_kind(b);
+	const bool aniso = bkind == DJB_KIND_TABULAR_ANISO;
+	const bool model = bkind == DJB_KIND_SGD || bkind == DJB_KIND_ABC;
 	const bool model_q = which >= DJB_Q_MODEL_NDF && which <= DJB_Q_MODEL_G1;
 	if (model) {
-		if (!(model_q || which == DJB_Q_FRESNEL) || (which == DJB_Q_MODEL_G1 && b->dev.kind != DJB_KIND_SGD))
+		if (!(model_q || which == DJB_Q_FRESNEL) || (which == DJB_Q_MODEL_G1 && bkind != DJB_KIND_SGD))
 			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: sgd / abc answer ndf, gaf, fresnel (and g1 for sgd) only");
 	} else if (model_q)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: DJB_Q_MODEL_* need an sgd or abc brdf");
-	if (b->dev.kind > DJB_KIND_TABULAR && !aniso && !model)
+	if (bkind > DJB_KIND_TABULAR && !aniso && !model)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: queries need a microfacet brdf");
-	if ((which >= DJB_Q_QF2_RADIAL && which <= DJB_Q_QF1) && (b->dev.kind == DJB_KIND_TABULAR || aniso))
+	if ((which >= DJB_Q_QF2_RADIAL && which <= DJB_Q_QF1) && (bkind == DJB_KIND_TABULAR || aniso))
 		return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented");          // dj_brdf.h:1854, 1859
 	if ((which >= DJB_Q_P22_RADIAL && which <= DJB_Q_QF1) && aniso)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: tabular_anisotropic is not a radial microfacet");
 	if ((which >= DJB_Q_ANISO_PDF1 && which <= DJB_Q_ANISO_QF2) && !aniso)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: pdf1/cdf1/qf1/pdf2/cdf2/qf2 need a tabular_anisotropic");
-	djb_status st = check_call(ctx, b, n, mem);
+	djb_status st = cpu_pair_check(ctx, b);
+	if (st != DJB_OK) return st;
+	if (!Staged::valid(a) || !Staged::valid(out)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
+	if (is_cpu(ctx)) return n <= 0 ? DJB_OK : djbcpu::query(ctx, b, which, n, a, bb ? bb : a, c ? c : a, params, out);
+	if (const djb_brdf *tw = scalar_twin(ctx, b, n, mem)) return n <= 0 ? DJB_OK : djbcpu::query(djbcpu::twin_ctx(), tw, which, n, a, bb ? bb : a, c ? c : a, params, out);
+	st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	Params p;
@@ -1514,6 +1681,9 @@ DJB_ABI_CATCH
 djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                                 int32_t *out_index, int mem)
 try {
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	if (is_cpu(ctx)) return djbcpu::merl_index(ctx, n, i, o, out_index);
+	if (mem == DJB_MEM_HOST && n >= 0 && n <= SCALAR_HOST_MAX && !ctx->scalar_on_device) return djbcpu::merl_index(djbcpu::twin_ctx(), n, i, o, out_index);
 	djb_status st = check_call(ctx, nullptr, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1602,12 +1772,17 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
                                  const djb_vec3_view *o, const float *rec, int mode, const float *base5,
                                  int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pp, int mem)
 {
-	if (!b || !rec) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
-	if (b->dev.kind > DJB_KIND_TABULAR && b->dev.kind != DJB_KIND_TABULAR_ANISO)
+	if (!b || !rec || !ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	const int bkind = djb_brdf_kind(b);
+	if (bkind > DJB_KIND_TABULAR && bkind != DJB_KIND_TABULAR_ANISO)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need a microfacet brdf");
 	if (want != 1 && want != 2 && want != 4 && want != 5 && want != 6)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: want must be eval(1)|evalp(2) and/or pdf(4)");
-	djb_status st = check_call(ctx, b, n, mem);
+	djb_status st = cpu_pair_check(ctx, b);
+	if (st != DJB_OK) return st;
+	if (is_cpu(ctx)) return n <= 0 ? DJB_OK : djbcpu::eval_pp(ctx, b, n, i, o, rec, mode, base5, want, out_fr, out_pdf, out_pp);
+	if (const djb_brdf *tw = scalar_twin(ctx, b, n, mem)) return n <= 0 ? DJB_OK : djbcpu::eval_pp(djbcpu::twin_ctx(), tw, n, i, o, rec, mode, base5, want, out_fr, out_pdf, out_pp);
+	st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	if (mem == DJB_MEM_HOST && n > SMALL_N && i && o && (!(want & 3) || out_fr)) {   // large host batch: chunked, both PCIe directions busy
@@ -1671,6 +1846,8 @@ DJB_ABI_CATCH
 
 djb_status djb_ctx_set_option(djb_ctx *ctx, int option, int value)
 try {
+	if (is_cpu(ctx)) return DJB_OK;           // the options select GPU code paths
+	if (ctx && option == DJB_OPT_SCALAR_ON_DEVICE) { ctx->scalar_on_device = value != 0; return DJB_OK; }
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	if (option == DJB_OPT_MERL_EXACT_ONLY) { ctx->merl_exact_only = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_ANISO_QF2_ALIGNED) { ctx->aniso_qf2_aligned = value != 0; return DJB_OK; }
@@ -1681,6 +1858,7 @@ DJB_ABI_CATCH
 djb_status djb_merl_guard_stats(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                                 const float *guard5, float *max_ratio3, unsigned long long *counters4)
 try {
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1714,6 +1892,7 @@ DJB_ABI_CATCH
 // ---------------------------------------------------------------- synthetic workloads
 djb_status djb_gen_directions(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t start, const djb_vec3_view *out)
 try {
+	if (is_cpu(ctx) && out) return n <= 0 ? DJB_OK : djbcpu::gen_directions(ctx, n, seed, start, out);
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1724,6 +1903,7 @@ try {
 DJB_ABI_CATCH
 djb_status djb_gen_uniforms(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t start, float *out)
 try {
+	if (is_cpu(ctx)) return n <= 0 ? DJB_OK : djbcpu::gen_uniforms(ctx, n, seed, start, out);
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1734,6 +1914,7 @@ try {
 DJB_ABI_CATCH
 djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, unsigned long long *counters8)
 try {
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1752,6 +1933,7 @@ DJB_ABI_CATCH
 
 djb_status djb_selftest_libm(djb_ctx *ctx, int fn, int64_t n, const double *x, const double *y, double *out)
 try {
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_HOST);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1773,6 +1955,7 @@ DJB_ABI_CATCH
 
 djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int bins, unsigned long long *counts)
 try {
+	if (is_cpu(ctx)) return djbcpu::histogram_xy(ctx, n, v, bins, counts);
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -1787,6 +1970,15 @@ DJB_ABI_CATCH
 
 // ---------------------------------------------------------------- hooks for djb_loader.hip
 namespace djbk {
+
+djb_status resolve_device_params(const djb_params *in, float out9[9], int brdf_kind)
+{
+	Params p;
+	djb_status st = device_params(in, &p, brdf_kind);
+	if (st != DJB_OK) return st;
+	out9[0] = p.nx; out9[1] = p.ny; out9[2] = p.nz; out9[3] = p.ax; out9[4] = p.ay; out9[5] = p.rho; out9[6] = p.s; out9[7] = p.tx; out9[8] = p.ty;
+	return DJB_OK;
+}
 
 hipStream_t ctx_stream(djb_ctx *ctx) { return ctx->stream; }
 int ctx_device(djb_ctx *ctx) { return ctx->device; }

@@ -34,25 +34,6 @@ inline int grid_full(long long n)
 	return (int)blocks;
 }
 
-template <int KIND, int WANT, int FRK = -1>
-DJB_DEV void eval_one(const Brdf &b, const Params &p, v3 i, v3 o, v3 &fr, float &pdf)
-{
-	if (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
-		mf_eval_pdf<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
-	} else {
-		if (WANT & 3) {
-			v3 e;
-			if (KIND == KIND_MERL) e = merl_eval(b, i, o);
-			else if (KIND == KIND_UTIA) e = utia_eval(b, i, o);
-			else if (KIND == KIND_SGD) e = sgd_eval(b, i, o);
-			else if (KIND == KIND_ABC) e = abc_eval(b, i, o);
-			else e = divs(mk(p.nx, p.ny, p.nz), F(DJB_PI));        // lambert: reflectance / M_PI, dj_brdf.h:861-868
-			fr = (WANT & 2) ? scale(i.z, e) : e;                   // brdf::evalp, dj_brdf.h:803-806
-		}
-		if (WANT & 4) pdf = F(D(i.z) / DJB_PI);                    // brdf::pdf, dj_brdf.h:842-845
-	}
-}
-
 // min-waves hint per kind, measured (tools/kind_rates.py, ms per 1e8 pairs at 1 / 4 / 8 waves): the analytic /
 // tabulated microfacet kernels fit 128 VGPRs (4); utia 3.34 / 2.93 / 10.5 and sgd 4.46 / 4.17 / 8.3 want 4
 // (left alone they take 172 VGPRs = 2 waves, too few to hide the table gathers; at 8 they spill);
@@ -136,18 +117,8 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi,
 	if (KIND == KIND_BECKMANN) { b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK); __syncthreads(); }
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-		v3 i = load3(vi, k), o = load3(vo, k);
-		const float *r = rec + 5 * k;
-		float ax, ay, rho, tx, ty;
-		if (MODE == 0) { ax = r[0]; ay = r[1]; rho = r[2]; tx = r[3]; ty = r[4]; }
-		else {
-			Lrep l; l.E1 = r[0]; l.E2 = r[1]; l.E3 = r[2]; l.E4 = r[3]; l.E5 = r[4];
-			lrep_to_pdfparams(lrep_add(base, l), ax, ay, rho, tx, ty);
-			if (out_pp) { float *w = out_pp + 5 * k; w[0] = ax; w[1] = ay; w[2] = rho; w[3] = tx; w[4] = ty; }
-		}
-		Params p = params_from_pdfparams(ax, ay, rho, tx, ty);
 		v3 fr = mk(0, 0, 0); float pdf = 0.0f;
-		mf_eval_pdf<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
+		pp_one<KIND, WANT, MODE, FRK>(b, load3(vi, k), load3(vo, k), rec + 5 * k, base, out_pp ? out_pp + 5 * k : nullptr, fr, pdf);
 		if (WANT & 3) store3(vout, k, fr);
 		if (WANT & 4) out_pdf[k] = pdf;
 	}
@@ -212,28 +183,10 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		float u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : u1a[k];
 		float u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : u2a[k];
-		v3 o = load3(vo, k);
-		if (KIND <= KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
-			if (!IS) {
-				store3(vi_out, k, mf_sample<KIND>(b, p, u1, u2, o, gt));
-			} else {
-				v3 i_out = mk(0, 0, 0); float pdf;
-				v3 w = mf_evalp_is<KIND, FRK>(b, p, u1, u2, o, i_out, pdf, gt);
-				store3(vw_out, k, w); store3(vi_out, k, i_out); out_pdf[k] = pdf;
-			}
-		} else {
-			// brdf::sample / brdf::evalp_is defaults (cosine hemisphere), dj_brdf.h:816-845
-			float x, y;
-			uniform_to_concentric(u1, u2, x, y);
-			v3 i_ = mk(x, y, F(sqrt(1.0 - D(x * x) - D(y * y))));
-			store3(vi_out, k, i_);
-			if (IS) {
-				v3 fr; float pdf;
-				eval_one<KIND, 6>(b, p, i_, o, fr, pdf);
-				store3(vw_out, k, divs(fr, pdf));
-				out_pdf[k] = pdf;
-			}
-		}
+		v3 o = load3(vo, k), i_out, w; float pdf;
+		sample_one<KIND, IS, FRK>(b, p, u1, u2, o, gt, i_out, w, pdf);
+		store3(vi_out, k, i_out);
+		if (IS) { store3(vw_out, k, w); out_pdf[k] = pdf; }
 	}
 }
 
@@ -270,58 +223,13 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
 }
 
 // ------------------------------------------------------------------ microfacet / radial queries
-// (dj_brdf.h:258-276, 307-314).  `which` is wave-uniform.
-enum { Q_NDF = 0, Q_GAF, Q_G1, Q_SIGMA, Q_P22, Q_VP22, Q_VNDF, Q_FRESNEL,
-       Q_P22_RADIAL = 16, Q_SIGMA_STD_RADIAL, Q_CDF_RADIAL, Q_QF_RADIAL, Q_QF2_RADIAL, Q_QF3_RADIAL, Q_QF1,
-       Q_A_PDF1 = 32, Q_A_CDF1, Q_A_QF1, Q_A_PDF2, Q_A_CDF2, Q_A_QF2,
-       Q_MODEL_NDF = 48, Q_MODEL_GAF, Q_MODEL_G1 };
-
 template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_query(Brdf b, Params p, int which, long long n, View va, View vb,
                                                  View vc, View vout)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
-	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-		v3 a = load3(va, k);
-		v3 r = mk(0, 0, 0);
-		switch (which) {
-		case Q_NDF: r.x = mf_ndf<KIND>(b, a, p); break;
-		case Q_GAF: {   // gaf(h, i, o): a = h (unused by Smith), vb = i, vc = o
-			v3 i = load3(vb, k), o = load3(vc, k);
-			float g1o = mf_g1_from_sigma(o, mf_sigma<KIND>(b, o, p), p);
-			float g1i = b.shadow ? mf_g1_from_sigma(i, mf_sigma<KIND>(b, i, p), p) : 0.0f;
-			r.x = mf_gaf_from_g1(b.shadow, g1i, g1o); break;
-		}
-		case Q_G1: { v3 kk = load3(vb, k); r.x = mf_g1_from_sigma(kk, mf_sigma<KIND>(b, kk, p), p); break; }
-		case Q_SIGMA: r.x = mf_sigma<KIND>(b, a, p); break;
-		case Q_P22: r.x = mf_p22<KIND>(b, a.x, a.y, p); break;
-		case Q_VP22: case Q_VNDF: {
-			v3 kk = load3(vb, k);
-			v3 h = which == Q_VNDF ? a : normalize(mk(-a.x, -a.y, 1));
-			float kh = dot(kk, h);
-			float vn = D(kh) > 0.0 ? kh * mf_ndf<KIND>(b, h, p) / mf_sigma<KIND>(b, kk, p) : 0.0f;
-			r.x = which == Q_VNDF ? vn : (h.z * h.z * h.z) * vn; break;
-		}
-		case Q_FRESNEL: r = fresnel_eval(b.fr, a.x); break;
-		case Q_P22_RADIAL: r.x = p22_radial<KIND>(b, a.x); break;
-		case Q_SIGMA_STD_RADIAL: r.x = sigma_std_radial<KIND>(b, a.x); break;
-		case Q_CDF_RADIAL: r.x = cdf_radial<KIND>(b, a.x); break;
-		case Q_QF_RADIAL: r.x = qf_radial<KIND>(b, a.x); break;
-		case Q_QF2_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf2_radial(a.x, a.y, a.z, glibc_tabs_global())
-		                       : KIND == KIND_GGX ? ggx_qf2_radial(a.x, a.y, a.z) : 0.0f; break;
-		case Q_QF3_RADIAL: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x, glibc_tabs_global())
-		                       : KIND == KIND_GGX ? ggx_qf3_radial(a.x, a.y) : 0.0f; break;
-		case Q_QF1: r.x = KIND == KIND_BECKMANN ? beckmann_qf1(a.x, glibc_tabs_global()) : KIND == KIND_GGX ? ggx_qf1(a.x) : 0.0f; break;
-		// tabular_anisotropic::{pdf1, cdf1, qf1, pdf2, cdf2, qf2} (dj_brdf.h:450-455)
-		case Q_A_PDF1: r.x = KIND == KIND_TABULAR_ANISO ? aniso_pdf1(b, a.x) : 0.0f; break;
-		case Q_A_CDF1: r.x = KIND == KIND_TABULAR_ANISO ? aniso_cdf1(b, a.x) : 0.0f; break;
-		case Q_A_QF1:  r.x = KIND == KIND_TABULAR_ANISO ? aniso_qf1(b, a.x) : 0.0f; break;
-		case Q_A_PDF2: r.x = KIND == KIND_TABULAR_ANISO ? aniso_pdf2(b, a.x, a.y) : 0.0f; break;
-		case Q_A_CDF2: r.x = KIND == KIND_TABULAR_ANISO ? aniso_cdf2(b, a.x, a.y) : 0.0f; break;
-		case Q_A_QF2:  r.x = KIND == KIND_TABULAR_ANISO ? aniso_qf2(b, a.x, a.y) : 0.0f; break;
-		}
-		store3(vout, k, r);
-	}
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride)
+		store3(vout, k, query_one<KIND>(b, p, which, k, va, vb, vc));
 }
 
 // sgd::{ndf, gaf, g1, fresnel} and abc::{ndf, gaf, fresnel} (dj_brdf.h:505-509, 530-533)
@@ -329,21 +237,8 @@ template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_model_query(Brdf b, int which, long long n, View va, View vb, View vc, View vout)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
-	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-		v3 a = load3(va, k), r = mk(0, 0, 0);
-		switch (which) {
-		case Q_FRESNEL: r = fresnel_eval(b.fr, a.x); break;
-		case Q_MODEL_NDF: r = KIND == KIND_SGD ? sgd_ndf_rgb(b, a) : abc_ndf_rgb(b, a); break;
-		case Q_MODEL_GAF: {
-			v3 i = load3(vb, k), o = load3(vc, k);
-			if (KIND == KIND_SGD) r = sgd_gaf_rgb(b, i, o);
-			else r.x = abc_gaf(a, i, o);
-			break;
-		}
-		case Q_MODEL_G1: if (KIND == KIND_SGD) r = sgd_g1_rgb(b, a); break;
-		}
-		store3(vout, k, r);
-	}
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride)
+		store3(vout, k, model_query_one<KIND>(b, which, k, va, vb, vc));
 }
 
 // ------------------------------------------------------------------ small utilities
@@ -370,13 +265,7 @@ __global__ __launch_bounds__(BLOCK) void k_merl_index(long long n, View vi, View
 __global__ __launch_bounds__(BLOCK) void k_merl_convert(const double *s, long long n, MerlTexel *table)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
-	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-		float r = F(s[k] * (1.00 / 1500.0));
-		float g = F(s[k + n] * (1.15 / 1500.0));
-		float b = F(s[k + 2 * n] * (1.66 / 1500.0));
-		if (D(r) < 0.0 || D(g) < 0.0 || D(b) < 0.0) r = g = b = 0.0f;
-		table[k] = MerlTexel{ r, g, b };
-	}
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) table[k] = merl_convert_one(s, n, k);
 }
 
 // utia::normalize (dj_brdf.h:1162-1177) then the (float_t) cast of dj_brdf.h:1144
@@ -387,23 +276,7 @@ __global__ __launch_bounds__(BLOCK) void k_merl_convert(const double *s, long lo
 __global__ __launch_bounds__(BLOCK) void k_utia_convert(const double *s, long long n, float4 *table)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
-	const float kf = 1.f / 140.f;
-	const long long plane = n / 3;
-	auto conv = [&](long long k) { double v = s[k] > 0.0 ? s[k] : 0.0; return F(v * D(kf)); };
-	for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < plane; e += stride) {
-		// e = 288 * (48 * iti + ipi) + 48 * itv + ipv
-		long long ipv = e % 48, itv = (e / 48) % 6, row = e / 288, ipi = row % 48;
-		float t[32];
-		for (int c = 0; c < 2; ++c)
-			for (int k = 0; k < 2; ++k)
-				for (int l = 0; l < 2; ++l) {
-					long long tv = itv + c > 5 ? 5 : itv + c;
-					long long src = 288 * (row - ipi + (ipi + k) % 48) + 48 * tv + (ipv + l) % 48;
-					for (int ch = 0; ch < 3; ++ch) t[3 * (4 * c + 2 * k + l) + ch] = conv(ch * plane + src);
-				}
-		for (int j = 24; j < 32; ++j) t[j] = 0.0f;
-		for (int j = 0; j < 8; ++j) table[8 * e + j] = make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
-	}
+	for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < n / 3; e += stride) utia_convert_one(s, n, e, table);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_gen_dir(long long n, uint32_t seed, unsigned long long start, View out)

@@ -11,6 +11,7 @@
 // context gets a share of the list (dj_brdf_amd/merl_params.py), no collective.
 #include "../../include/djb_hip.h"
 #include "djb_internal.hpp"
+#include "djb_cpu.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -42,7 +43,6 @@ int ctx_device(djb_ctx *ctx);
 // every entry point that enqueues on the ctx stream holds the context's call mutex (see djb_ctx)
 void ctx_lock(djb_ctx *ctx);
 void ctx_unlock(djb_ctx *ctx);
-djb_status set_error(djb_status st, const char *fmt, ...);
 } // namespace djbk
 
 namespace {
@@ -113,6 +113,7 @@ static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *p
 	if (!ctx || !paths || n_files < 0 || !alpha_beckmann || !alpha_ggx)
 		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
 	if (n_files == 0) return DJB_OK;
+	if (djbcpu::is_cpu(ctx)) return djbcpu::fit_merl_files(ctx, n_files, paths, res, shadow, reader_threads, alpha_beckmann, alpha_ggx, timing);
 	hipError_t e = hipSetDevice(djbk::ctx_device(ctx));
 	if (e != hipSuccess) return djbk::set_error(DJB_ERR_HIP, "djb_error: hipSetDevice: %s", hipGetErrorString(e));
 	hipStream_t stream = djbk::ctx_stream(ctx);

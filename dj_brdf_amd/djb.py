@@ -38,10 +38,19 @@ class Context:
     """One GPU + one HIP stream (``djb_ctx``).  With torch present the ctx runs on torch's
     current stream of that device, so torch events/synchronisation see the kernels."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None):
+    def __init__(self, device=0, stream: Optional[int] = None):
         lib = _lib.load()
+        # device "cpu" (DJB_DEVICE_CPU = -1): the product's HOST execution path -- the kernels' per-unit code compiled for
+        # the CPU with the host libm; explicit only, a GPU context never falls back to it for batches
+        self.is_cpu = device in ("cpu", -1)
+        if self.is_cpu:
+            device, stream = -1, None
         self.device = device
         self._handle = C.c_void_p()
+        if self.is_cpu:
+            self._follow_torch, self._stream = False, None
+            _lib.check(lib.djb_ctx_create(C.c_int(-1), C.byref(self._handle)))
+            return
         # stream=None with torch present: the ctx FOLLOWS torch's current stream of the device -- re-read on every
         # call (the `_h` property), so work issued under `with torch.cuda.stream(s):` runs on s, where torch
         # allocated the outputs and where its consumers wait.  An explicit stream pins the ctx to it.
@@ -89,7 +98,12 @@ class Context:
 _default_ctx = {}
 
 
-def default_context(device: int = 0) -> Context:
+def cpu_context() -> Context:
+    """The process-wide CPU context (Context("cpu"))."""
+    return default_context("cpu")
+
+
+def default_context(device=0) -> Context:
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]
@@ -337,7 +351,7 @@ class brdf:
         """sample() with the uniforms drawn on chip (device arrays only)."""
         lib = _lib.load()
         vo = _Vec(o)
-        if vo.mem != _lib.MEM_DEVICE:
+        if vo.mem != _lib.MEM_DEVICE and not self.ctx.is_cpu:
             raise exc(1, "djb_error: sample_rng needs device arrays")
         out = vo.like()
         _lib.check(lib.djb_sample_rng_batch(self.ctx._h, self._h, C.c_int64(vo.n), C.c_uint32(seed_u1),
@@ -966,7 +980,7 @@ def fit_brdf_batch(brdfs, res: int = 90, shadow: bool = True, ctx: Optional[Cont
 def gen_directions(n: int, seed: int, start: int = 0, ctx: Optional[Context] = None, device=None):
     """[3, n] torch CUDA tensor of hash-generated unit vectors; same bits as synth.directions."""
     ctx = ctx or default_context()
-    out = torch.empty((3, n), dtype=torch.float32, device=device or f"cuda:{ctx.device}")
+    out = np.empty((3, n), np.float32) if ctx.is_cpu else torch.empty((3, n), dtype=torch.float32, device=device or f"cuda:{ctx.device}")
     v = _Vec(out)
     _lib.check(_lib.load().djb_gen_directions(ctx._h, C.c_int64(n), C.c_uint32(seed), C.c_uint64(start),
                                               C.byref(v.view)))
@@ -975,6 +989,10 @@ def gen_directions(n: int, seed: int, start: int = 0, ctx: Optional[Context] = N
 
 def gen_uniforms(n: int, seed: int, start: int = 0, ctx: Optional[Context] = None, device=None):
     ctx = ctx or default_context()
+    if ctx.is_cpu:
+        out = np.empty((n,), np.float32)
+        _lib.check(_lib.load().djb_gen_uniforms(ctx._h, C.c_int64(n), C.c_uint32(seed), C.c_uint64(start), C.c_void_p(out.ctypes.data)))
+        return out
     out = torch.empty((n,), dtype=torch.float32, device=device or f"cuda:{ctx.device}")
     _lib.check(_lib.load().djb_gen_uniforms(ctx._h, C.c_int64(n), C.c_uint32(seed), C.c_uint64(start),
                                             C.c_void_p(out.data_ptr())))
@@ -995,6 +1013,12 @@ def histogram_xy(v, bins: int = 64, ctx: Optional[Context] = None):
 def set_merl_exact_only(ctx: Context, on: bool):
     """Force merl eval/evalp onto the operation-by-operation fp64 kernel (DJB_OPT_MERL_EXACT_ONLY)."""
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(1), C.c_int(int(on))))
+
+
+def set_scalar_on_device(ctx: Context, on: bool):
+    """Send scalar-size host calls (<= DJB_SCALAR_HOST_MAX units) through the GPU as well (DJB_OPT_SCALAR_ON_DEVICE);
+    by default the host instantiation of the same code answers them on the calling thread."""
+    _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(3), C.c_int(int(on))))
 
 
 def set_aniso_qf2_aligned(ctx: Context, on: bool):

@@ -71,7 +71,8 @@ int main(int argc, char **argv)
 		}
 	} else {
 		int n_dev = djb::hip::context::device_count();
-		if (n_dev <= 0) { fprintf(stderr, "djb_error: no HIP device; there is no CPU path\n"); return EXIT_FAILURE; }
+		const bool on_cpu = djb::hip::context::standard_device() == DJB_DEVICE_CPU;   // DJB_DEVICE=cpu, or no HIP device at all
+		if (on_cpu) n_dev = 1;                       // one host context; djb_fit_merl_files spreads the files over its threads
 		if (gpus <= 0 || gpus > n_dev) gpus = n_dev;
 		if (gpus > n && n > 0) gpus = n;
 		std::vector<std::string> errors(gpus);
@@ -84,7 +85,7 @@ int main(int argc, char **argv)
 				if (mine.empty()) return;
 				std::vector<float> ab(mine.size()), ag(mine.size());
 				djb_ctx *ctx = NULL;
-				djb_status st = djb_ctx_create(g, &ctx);
+				djb_status st = djb_ctx_create(on_cpu ? DJB_DEVICE_CPU : g, &ctx);
 				if (st == DJB_OK)
 					st = djb_fit_merl_files(ctx, (int)mine.size(), &mine[0], 90, 1, 0, &ab[0], &ag[0], NULL);
 				if (st != DJB_OK) errors[g] = djb_last_error();

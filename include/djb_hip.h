@@ -52,6 +52,19 @@ typedef enum {
 
 enum { DJB_MEM_DEVICE = 0, DJB_MEM_HOST = 1 };
 
+/* The device argument of djb_ctx_create that selects the product's HOST execution path: the same per-unit code as
+ * the kernels, compiled for the CPU with the host's own libm (what the reference -- a CPU library, dj_brdf.h:74-109
+ * -- calls).  Every entry point works on such a context (memory space flags are ignored: all pointers are host
+ * memory), objects belong to the context that created them, batches are chunked over DJB_CPU_THREADS threads.
+ * It exists for machines without a GPU (BASELINE configs[0]: examples/merl_params.cpp "runs without a GPU"); it is
+ * never entered implicitly: a GPU context fails with DJB_ERR_NO_DEVICE / DJB_ERR_HIP rather than fall back.   */
+#define DJB_DEVICE_CPU (-1)
+/* DJB_MEM_HOST calls of at most this many units on a GPU context -- the scalar virtuals of the djb:: facade, a
+ * renderer's per-hit calls -- are answered by that same host code on the calling thread, from a host copy of the
+ * object's tables (no staging, no launch, no context lock): bit-identical to the batch path, ~100 ns instead of
+ * ~15 us per pair.  DJB_OPT_SCALAR_ON_DEVICE = 1 routes them through the GPU as well.                          */
+#define DJB_SCALAR_HOST_MAX 64
+
 typedef struct djb_ctx djb_ctx;     /* one GPU + one HIP stream */
 typedef struct djb_brdf djb_brdf;   /* an immutable BRDF object resident in HBM (djb::brdf subclass) */
 
@@ -92,7 +105,7 @@ const char *djb_last_error(void);
 int         djb_version(void);
 /* number of usable gfx950 devices (0 when there is no GPU; never falls back to a CPU path) */
 djb_status  djb_device_count(int *count);
-/* a context with its own (non-blocking) HIP stream */
+/* a context with its own (non-blocking) HIP stream; device = DJB_DEVICE_CPU: the host execution path */
 djb_status  djb_ctx_create(int device, djb_ctx **out);
 /* a context that runs on the caller's hipStream_t (e.g. torch's current stream); NULL means the
  * device's default (null) stream, so work is ordered with everything else issued there */
@@ -112,7 +125,9 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * conditional quantile table at its own offset (padded with 1.0).  Default 0 = the reference's vector,
  * in which a row whose conditional CDF cannot be inverted for every quantile comes up short and shifts
  * all later rows (dj_brdf.h:3005-3034) -- the two differ only for such (grazing-heavy) data.          */
-       DJB_OPT_ANISO_QF2_ALIGNED = 2 };
+       DJB_OPT_ANISO_QF2_ALIGNED = 2,
+/* DJB_OPT_SCALAR_ON_DEVICE = 1: scalar-size DJB_MEM_HOST calls (<= DJB_SCALAR_HOST_MAX units) run on the GPU too */
+       DJB_OPT_SCALAR_ON_DEVICE = 3 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */
 djb_status  djb_timer_start(djb_ctx *ctx);

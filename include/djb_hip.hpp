@@ -17,6 +17,9 @@
 
 #include <cmath>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <string>
 #include <vector>
@@ -77,7 +80,7 @@ inline void check(djb_status st)
 	if (st != DJB_OK) throw exc(djb_last_error(), (int)st);
 }
 
-/* one GPU + one HIP stream */
+/* one GPU + one HIP stream -- or, with device == DJB_DEVICE_CPU, the library's host execution path */
 class context {
 public:
 	explicit context(int device = 0) : m_ctx(NULL) { check(djb_ctx_create(device, &m_ctx)); }
@@ -85,7 +88,21 @@ public:
 	~context() { djb_ctx_destroy(m_ctx); }
 	djb_ctx *get() const { return m_ctx; }
 	void synchronize() const { check(djb_ctx_synchronize(m_ctx)); }
-	static context &standard() { static context c(0); return c; }   // process-wide default (device 0)
+	// The process-wide default context, used by every djb:: object that is not given one.  DJB_DEVICE=<n> selects GPU n,
+	// DJB_DEVICE=cpu the host path.  Without the variable it is GPU 0 -- and, ONLY on a machine that has no HIP device at
+	// all, the host path (announced once on stderr): the reference is a CPU library and its programs, compiled against
+	// this header, have to run on such a machine too (BASELINE configs[0]).  A GPU that is present but failing is an
+	// error, never a reason to fall back.
+	static int standard_device()
+	{
+		const char *e = getenv("DJB_DEVICE");
+		if (e && (!strcmp(e, "cpu") || !strcmp(e, "CPU"))) return DJB_DEVICE_CPU;
+		if (e && *e) return atoi(e);
+		if (device_count() > 0) return 0;
+		if (!getenv("DJB_QUIET")) fprintf(stderr, "djb: no HIP device on this machine -- running on the host path (DJB_DEVICE=cpu)\n");
+		return DJB_DEVICE_CPU;
+	}
+	static context &standard() { static context c(standard_device()); return c; }
 	static int device_count() { int n = 0; return djb_device_count(&n) == DJB_OK ? n : 0; }
 private:
 	context(const context &);

@@ -1,0 +1,229 @@
+"""The product's HOST execution path (dj_brdf_amd/csrc/djb_cpu.cpp: the kernels' per-unit code of djb_device.hpp
+compiled for the CPU with the host libm), through the C ABI on a CPU context (djb_ctx_create(DJB_DEVICE_CPU)).
+
+It exists for the reference's real callers -- scalar virtual calls from render threads, and machines without a GPU
+(BASELINE.json configs[0]: "examples/merl_params.cpp ... CPU only, runs without a GPU") -- and it is the product's
+own code: nothing under oracle/ is linked or imported by it.  Here it is checked, WITHOUT a GPU, against the CPU
+oracle and the reference goldens: every value bit for bit (the host libm is the libm the reference calls, so on this
+path even the fp64 trigonometry is identical by construction).  tests/test_gpu_scalar_path.py compares it with the GPU
+batch path on the GPU box.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from dj_brdf_amd import djb, merl_params, synth
+from golden_cases import ANISO_BIG_CASES, ANISO_CASES, FIT_CASES, PARAMS_TXT_MATERIALS, aniso_big_source
+from test_gpu_parity import FRESNELS, PARAMS, assert_close, mk_fresnel, mk_params
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 1 << 12
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    return djb.Context("cpu")
+
+
+@pytest.fixture(scope="module")
+def dirs():
+    return (synth.directions_aos(N, synth.SEED_I), synth.directions_aos(N, synth.SEED_O),
+            synth.uniforms(N, synth.SEED_U1), synth.uniforms(N, synth.SEED_U2))
+
+
+def same(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+@pytest.mark.parametrize("fres", FRESNELS, ids=lambda f: f[0])
+def test_microfacet_operators(cpu, oracle, dirs, ndf, fres):
+    i, o, u1, u2 = dirs
+    g = getattr(djb, ndf)(mk_fresnel(fres), True, ctx=cpu)
+    ob = oracle.microfacet(ndf, fres, True)
+    for p in PARAMS:
+        up = mk_params(p)
+        for op in ("eval", "evalp", "pdf"):
+            assert_close(f"{ndf}/{fres[0]}/{p}/{op}", getattr(g, op)(i, o, up), oracle.eval(ob, i, o, p, op))
+        fr, pdf = g.eval_pdf(i, o, up)
+        assert same(fr, oracle.eval(ob, i, o, p, "eval")) and same(pdf, oracle.eval(ob, i, o, p, "pdf"))
+        assert same(g.sample(u1, u2, o, up), oracle.sample(ob, u1, u2, o, p)), (ndf, p, "sample")
+        w, si, spdf = g.evalp_is(u1, u2, o, up)
+        ww, wi, wpdf = oracle.evalp_is(ob, u1, u2, o, p)
+        assert same(si, wi) and same(w, ww) and same(spdf, wpdf), (ndf, p, "evalp_is")
+
+
+def test_small_and_strided_batches(cpu, oracle, dirs):
+    """one pair at a time (what the facade's scalar virtuals send), ragged sizes, SoA and AoS"""
+    i, o, _, _ = dirs
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=cpu)
+    p = djb.microfacet.params.isotropic(0.3)
+    full = g.eval(i, o, p)
+    for k in (0, 1, 63, 64, 65):
+        assert same(g.eval(i[k:k + 1], o[k:k + 1], p), full[k:k + 1])
+    assert same(g.eval(np.ascontiguousarray(i.T), np.ascontiguousarray(o.T), p).T, full)
+    e = np.zeros((0, 3), np.float32)
+    assert g.eval(e, e).shape == (0, 3)
+    with pytest.raises(djb.exc):
+        g.eval(i[:4], o[:5])
+
+
+def test_merl_utia_lambert_models(cpu, oracle, dirs, tmp_path):
+    i, o, u1, u2 = dirs
+    tab = synth.merl_table_hashed()
+    m, om = djb.merl.from_table(tab, ctx=cpu), oracle.merl_from_table(tab)
+    assert np.array_equal(djb.merl_index(i, o, ctx=cpu), oracle.merl_index(i, o))
+    for op in ("eval", "evalp", "pdf"):
+        assert same(getattr(m, op)(i, o), oracle.eval(om, i, o, None, op)), op
+    assert np.array_equal(m.get_samples(), np.ascontiguousarray(tab, np.float64).reshape(-1))
+    p = str(tmp_path / "m.binary"); synth.write_merl_binary(p, tab)
+    assert same(djb.merl(p, ctx=cpu).eval(i, o), m.eval(i, o))
+    with pytest.raises(djb.exc) as e:
+        djb.merl(str(tmp_path / "missing.binary"), ctx=cpu)
+    assert e.value.status_name == "DJB_ERR_OPEN_FAILED" and "Failed to open" in str(e.value)
+    raw = np.random.default_rng(11).uniform(-5.0, 120.0, size=3 * 288 * 288)
+    up = str(tmp_path / "u.bin"); raw.tofile(up)
+    u, ou = djb.utia.from_table(raw, ctx=cpu), oracle.utia(up)
+    for op in ("eval", "evalp", "pdf"):
+        assert same(getattr(u, op)(i, o), oracle.eval(ou, i, o, None, op)), op
+    l, ol = djb.lambert(ctx=cpu), oracle.lambert()
+    assert same(l.eval(i, o), oracle.eval(ol, i, o)) and same(l.sample(u1, u2, o), oracle.sample(ol, u1, u2, o))
+    for kind in ("sgd", "abc"):
+        b, ob = getattr(djb, kind)("gold-metallic-paint", ctx=cpu), getattr(oracle, kind)("gold-metallic-paint")
+        assert same(b.eval(i, o), oracle.eval(ob, i, o)), kind
+    h, d = djb.brdf.io_to_hd(i, o, ctx=cpu)
+    wh, wd = oracle.io_to_hd(i, o)
+    assert same(h, wh) and same(d, wd)
+
+
+@pytest.mark.parametrize("name", ["ggx90", "beckmann180", "merl_a30", "merl_a30_noshadow", "ggx7"])
+def test_tabular_fit_golden(cpu, name):
+    """djb::tabular(brdf, res, shadow) + both fits on the host against the REAL reference's tables (tests/golden/fit.npz)"""
+    g = np.load(os.path.join(G, "fit.npz"))
+    src, res, shadow = FIT_CASES[name]
+    s = djb.merl.from_table(synth.merl_table(*src[1:]), ctx=cpu) if src[0] == "merl" else getattr(djb, src[0])(None, src[1], ctx=cpu)
+    t = djb.tabular(s, res, shadow, ctx=cpu)
+    for k, v in (("p22", t.get_p22v()), ("sigma", t.get_sigmav()), ("cdf", t.get_cdfv()), ("qf", t.get_qfv()),
+                 ("fresnel", t.get_fresnel().get_points())):
+        assert same(v, g[f"{name}_{k}"]), (name, k)
+    ab = djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0]
+    ag = djb.tabular.fit_ggx_parameters(t).get_ellipse()[0]
+    assert (np.float32(ab), np.float32(ag)) == (g[f"{name}_alpha_beckmann"][0], g[f"{name}_alpha_ggx"][0])
+    assert same(t.eval(g["i"], g["o"]), g[f"{name}_eval"]) and same(t.pdf(g["i"], g["o"]), g[f"{name}_pdf"])
+    assert same(t.sample(g["u1"], g["u2"], g["o"]), g[f"{name}_sample"])
+
+
+@pytest.mark.parametrize("name", ["a_ggx", "a_merl"])
+def test_anisotropic_fit_golden(cpu, name):
+    from test_gpu_aniso import make_source
+    g = np.load(os.path.join(G, "aniso.npz"))
+    src, elev, azim, shadow = ANISO_CASES[name]
+    t = djb.tabular_anisotropic(make_source(src, cpu), elev, azim, shadow, ctx=cpu)
+    assert same(t.get_p22v()[0], g[f"{name}_p22"]) and same(t.get_sigmav()[0], g[f"{name}_sigma"])
+    assert same(t.get_fresnel().get_points(), g[f"{name}_fresnel"])
+    fb = np.array(djb.tabular_anisotropic.fit_beckmann_parameters(t).get_pdfparams(), np.float32)
+    fg = np.array(djb.tabular_anisotropic.fit_ggx_parameters(t).get_pdfparams(), np.float32)
+    assert same(fb, g[f"{name}_fit_beckmann"]) and same(fg, g[f"{name}_fit_ggx"])
+    u1, u2 = g["u1"], g["u2"]
+    phi, th = (u1 * np.float32(6.2)).astype(np.float32), (u2 * np.float32(1.5)).astype(np.float32)
+    for q, args in (("pdf1", (phi,)), ("cdf1", (phi,)), ("qf1", (u1,)), ("pdf2", (th, phi)), ("cdf2", (th, phi)), ("qf2", (u2, phi))):
+        assert same(getattr(t, q)(*args), g[f"{name}_{q}"]), (name, q)
+    assert same(t.eval(g["i"], g["o"]), g[f"{name}_eval"]) and same(t.sample(u1, u2, g["o"]), g[f"{name}_sample"])
+
+
+def test_anisotropic_short_rows_and_utia_source(cpu, oracle, tmp_path):
+    g = np.load(os.path.join(G, "aniso_big.npz"))
+    for name in ("a_short", "a_utia_small"):
+        src, elev, azim, shadow = ANISO_BIG_CASES[name]
+        L = type("L", (), {"merl": type("M", (), {"from_table": staticmethod(lambda t: djb.merl.from_table(t, ctx=cpu))}),
+                           "utia": type("U", (), {"from_table": staticmethod(lambda t: djb.utia.from_table(t, ctx=cpu))})})
+        t = djb.tabular_anisotropic(aniso_big_source(L, src), elev, azim, shadow, ctx=cpu)
+        assert same(t.get_p22v()[0], g[f"{name}_p22"]) and same(t.get_sigmav()[0], g[f"{name}_sigma"])
+        want = oracle.aniso_sampling_tables(oracle.tabular_anisotropic(aniso_big_source(oracle, src, str(tmp_path)), elev, azim, shadow))
+        for q in ("pdf1", "cdf1", "qf1", "pdf2", "cdf2", "qf2"):
+            assert same(t.get_table(q), want[q]), (name, q)
+        assert t.qf2_entries() == want["qf2_entries"]
+        if name == "a_short":
+            assert t.qf2_entries() < elev * azim
+            assert same(t.qf2(g[f"{name}_qf2_u"], g[f"{name}_qf2_phi"]), g[f"{name}_qf2"])
+
+
+def test_params_txt_on_the_cpu(cpu, tmp_path):
+    """BASELINE configs[0]: the merl_params driver on a machine without a GPU -- byte-identical params.txt"""
+    files = []
+    for name, recipe in PARAMS_TXT_MATERIALS:
+        p = str(tmp_path / (name + ".binary"))
+        synth.write_merl_binary(p, synth.merl_table(*recipe)); files.append(p)
+    ab, ag, timing = merl_params.fit_files_on(cpu, files)
+    txt = merl_params.format_params_txt(files, list(zip(ab.tolist(), ag.tolist())))
+    assert txt.encode() == open(os.path.join(G, "params_expected.txt"), "rb").read()
+    assert timing["bytes"] == 3 * synth.MERL_FILE_BYTES
+    # batch entry points agree with the one-object path
+    mats = [djb.merl(f, ctx=cpu) for f in files]
+    ab2, ag2 = djb.fit_brdf_batch(mats, 90, True, ctx=cpu)
+    assert np.array_equal(ab2, ab) and np.array_equal(ag2, ag)
+    with pytest.raises(djb.exc) as e:
+        merl_params.fit_files_on(cpu, files[:1] + [str(tmp_path / "missing.binary")])
+    assert e.value.status_name == "DJB_ERR_OPEN_FAILED"
+
+
+def test_lean_and_queries(cpu, oracle, dirs):
+    from golden_cases import LEAN_BASE, LEAN_SCALE, lean_moments
+    i, o, u1, u2 = dirs
+    lean = lean_moments(N)
+    b = djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=cpu)
+    ob = oracle.microfacet("beckmann", ("schlick", 1.0, 0.71, 0.29), True)
+    got = djb._eval_lean(b, i, o, mk_params(LEAN_BASE), LEAN_SCALE, lean, want="evalp")
+    want, _ = oracle.eval_lean(ob, i, o, LEAN_BASE, LEAN_SCALE, lean, "evalp")
+    assert same(got, want)
+    h = oracle.io_to_hd(i, o)[0]
+    up, p = mk_params(PARAMS[2]), PARAMS[2]
+    assert same(b.ndf(h, up), oracle.microfacet_query(ob, "ndf", h, params=p))
+    assert same(b.gaf(h, i, o, up), oracle.microfacet_query(ob, "gaf", h, i, o, params=p))
+    assert same(b.sigma(o, up), oracle.microfacet_query(ob, "sigma", o, params=p))
+    u = np.clip(u1, 1e-4, 1 - 1e-4)
+    assert same(b.qf_radial(u), oracle.radial_query(ob, "qf_radial", u))
+
+
+def test_mixed_backends_are_rejected(cpu):
+    if djb.device_count() == 0:
+        with pytest.raises(djb.exc) as e:      # a GPU context is never silently replaced by the host path
+            djb.Context(0)
+        assert e.value.status_name == "DJB_ERR_NO_DEVICE"
+    g = djb.ggx(ctx=cpu)
+    assert g.ctx.is_cpu and djb._lib.load().djb_brdf_kind(g._h) == 1
+
+
+def test_cpp_programs_run_without_a_gpu(tmp_path):
+    """The C++ djb:: facade on the host path: examples/facade_check (known answers of SURVEY 8-N) and the
+    merl_params driver with DJB_DEVICE=cpu; where /root/reference is mounted, the reference's OWN programs compiled
+    unchanged against include/dj_brdf.h write what the reference binaries write."""
+    env = dict(os.environ, DJB_DEVICE="cpu")
+    exe = os.path.join(ROOT, "examples", "facade_check")
+    if not os.path.exists(exe):
+        pytest.skip("examples not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
+    files = []
+    for name, recipe in PARAMS_TXT_MATERIALS:
+        p = str(tmp_path / (name + ".binary"))
+        synth.write_merl_binary(p, synth.merl_table(*recipe)); files.append(p)
+    want = open(os.path.join(G, "params_expected.txt"), "rb").read()
+    for mode in ([], ["-s"]):
+        r = subprocess.run([os.path.join(ROOT, "examples", "merl_params")] + mode + files, cwd=str(tmp_path), capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert (tmp_path / "params.txt").read_bytes() == want, mode
+        (tmp_path / "params.txt").unlink()
+    rt = os.path.join(ROOT, "examples", "_reftests")
+    if os.path.exists(os.path.join(rt, "plot_cdf")):
+        for prog in ("plot_cdf", "plot_qf"):
+            r = subprocess.run([os.path.join(rt, prog)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stdout + r.stderr
+        for f in sorted(x for x in os.listdir(os.path.join(G, "reftests")) if x.startswith("eval_")):
+            assert (tmp_path / f).read_bytes() == open(os.path.join(G, "reftests", f), "rb").read(), f
+        r = subprocess.run([os.path.join(rt, "merl_params")] + files, cwd=str(tmp_path), capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and (tmp_path / "params.txt").read_bytes() == want

@@ -550,4 +550,5 @@ def test_get_samples(gpu_ctx, tmp_path):
         from dj_brdf_amd import _lib
         import ctypes as C
         n = C.c_int64(0)
-        _lib.check(_lib.load().djb_brdf_get_samples(djb.ggx(ctx=gpu_ctx)._h, None, C.c_int64(0), C.byref(n)))
+        g = djb.ggx(ctx=gpu_ctx)          # kept alive across the call: `djb.ggx(...)._h` alone hands a freed handle to the library
+        _lib.check(_lib.load().djb_brdf_get_samples(g._h, None, C.c_int64(0), C.byref(n)))

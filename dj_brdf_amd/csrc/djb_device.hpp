@@ -718,7 +718,13 @@ DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k, const Glibc
 	int it = 0;
 	float inv_erf = 0.0f;
 	bool converged = false;
-	while (++it < 10) {
+	// not unrolled: nine copies of the body (each with the out-of-line branches of erfinv / logf / expf) made the
+	// sampling kernels 27 KB of code for no gain -- the trip count is data dependent (3.2 on average)
+	int it_end = 10;
+#if !defined(DJB_HOST_MATH)
+	asm volatile("" : "+s"(it_end));       // opaque bound: unroll pragmas alone do not survive the inlining of this loop
+#endif
+	while (++it < it_end) {
 		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
 		inv_erf = erfinv_(b, gt);
 		float value = normalization * (1 + b + sqrt_pi_inv * tan_k * glibc_expf(-inv_erf * inv_erf, gt)) - u;

@@ -34,6 +34,22 @@ inline int grid_full(long long n)
 	return (int)blocks;
 }
 
+// Dense batches (every view SoA with stride 1: what device-resident callers and bench.py pass) address their arrays
+// as  uniform base pointer (SGPRs: array + first unit of the workgroup) + 32-bit lane offset,  which costs one
+// VALU shift for all ten arrays of a kernel; the generic strided form spends ~35 VALU instructions per pair on 64-bit
+// index arithmetic (k * stride per component), 10 % of the GGX eval+pdf kernel.  k0 is workgroup-uniform.
+DJB_DEV v3 load3_dense(const View &v, long long k0, unsigned int t)
+{
+	const float *x = v.x + k0, *y = v.y + k0, *z = v.z + k0;
+	return mk(x[t], y[t], z[t]);
+}
+DJB_DEV void store3_dense(const View &v, long long k0, unsigned int t, v3 a)
+{
+	float *x = v.x + k0, *y = v.y + k0, *z = v.z + k0;
+	x[t] = a.x; y[t] = a.y; z[t] = a.z;
+}
+inline bool dense(const View &v) { return v.stride == 1 || v.x == nullptr; }
+
 // min-waves hint per kind, measured (tools/kind_rates.py, ms per 1e8 pairs at 1 / 4 / 8 waves): the analytic /
 // tabulated microfacet kernels fit 128 VGPRs (4); utia 3.34 / 2.93 / 10.5 and sgd 4.46 / 4.17 / 8.3 want 4
 // (left alone they take 172 VGPRs = 2 waves, too few to hide the table gathers; at 8 they spill);
@@ -43,7 +59,7 @@ constexpr int eval_min_waves(int kind)
 	return (kind <= KIND_TABULAR || kind == KIND_TABULAR_ANISO || kind == KIND_UTIA || kind == KIND_SGD) ? 4
 	     : kind == KIND_ABC ? 8 : 1;
 }
-template <int KIND, int WANT, int FRK>
+template <int KIND, int WANT, int FRK, bool DENSE>
 __global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
                                                    View vout, float *out_pdf)
 {
@@ -55,13 +71,16 @@ __global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Pa
 	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
 	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
 	if (EXPT || POWT) __syncthreads();
-	long long stride = (long long)gridDim.x * BLOCK;
-	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-		v3 i = load3(vi, k), o = load3(vo, k);
+	const long long stride = (long long)gridDim.x * BLOCK;
+	const unsigned int t = threadIdx.x;
+	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
+		const long long k = k0 + t;
+		if (k >= n) continue;
+		v3 i = DENSE ? load3_dense(vi, k0, t) : load3(vi, k), o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
 		v3 fr = mk(0, 0, 0); float pdf = 0.0f;
 		eval_one<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
-		if (WANT & 3) store3(vout, k, fr);
-		if (WANT & 4) out_pdf[k] = pdf;
+		if (WANT & 3) { if (DENSE) store3_dense(vout, k0, t, fr); else store3(vout, k, fr); }
+		if (WANT & 4) { if (DENSE) (out_pdf + k0)[t] = pdf; else out_pdf[k] = pdf; }
 	}
 }
 
@@ -70,14 +89,18 @@ hipError_t launch_eval_kind_fr(hipStream_t s, const Brdf &b, const Params &p, lo
                                const View &i, const View &o, const View &out, float *out_pdf, int want)
 {
 	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
+	const bool dn = dense(i) && dense(o) && dense(out);
+#define DJB_LAUNCH_EVAL(W_) do { if (dn) hipLaunchKernelGGL((k_eval<KIND, W_, FRK, true>), g, t, 0, s, b, p, n, i, o, out, out_pdf); \
+                                 else hipLaunchKernelGGL((k_eval<KIND, W_, FRK, false>), g, t, 0, s, b, p, n, i, o, out, out_pdf); } while (0)
 	switch (want) {
-	case 1: hipLaunchKernelGGL((k_eval<KIND, 1, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	case 2: hipLaunchKernelGGL((k_eval<KIND, 2, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	case 4: hipLaunchKernelGGL((k_eval<KIND, 4, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	case 5: hipLaunchKernelGGL((k_eval<KIND, 5, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
-	case 6: hipLaunchKernelGGL((k_eval<KIND, 6, FRK>), g, t, 0, s, b, p, n, i, o, out, out_pdf); break;
+	case 1: DJB_LAUNCH_EVAL(1); break;
+	case 2: DJB_LAUNCH_EVAL(2); break;
+	case 4: DJB_LAUNCH_EVAL(4); break;
+	case 5: DJB_LAUNCH_EVAL(5); break;
+	case 6: DJB_LAUNCH_EVAL(6); break;
 	default: return hipErrorInvalidValue;
 	}
+#undef DJB_LAUNCH_EVAL
 	return hipGetLastError();
 }
 
@@ -164,7 +187,7 @@ hipError_t launch_eval_pp_kind(hipStream_t s, const Brdf &b, long long n, const 
 
 // ------------------------------------------------------------------ sample / evalp_is
 // FRK: Fresnel kind fixed at compile time for evalp_is of the analytic lobes (as in k_eval)
-template <int KIND, bool IS, bool RNG, int FRK = -1>
+template <int KIND, bool IS, bool RNG, int FRK = -1, bool DENSE = false>
 __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n, const float *u1a,
                                                   const float *u2a, uint32_t seed1, uint32_t seed2,
                                                   unsigned long long start, View vo, View vi_out,
@@ -179,14 +202,20 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 		gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
 		__syncthreads();
 	}
-	long long stride = (long long)gridDim.x * BLOCK;
-	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-		float u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : u1a[k];
-		float u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : u2a[k];
-		v3 o = load3(vo, k), i_out, w; float pdf;
+	const long long stride = (long long)gridDim.x * BLOCK;
+	const unsigned int t = threadIdx.x;
+	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
+		const long long k = k0 + t;
+		if (k >= n) continue;
+		float u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : (DENSE ? (u1a + k0)[t] : u1a[k]);
+		float u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : (DENSE ? (u2a + k0)[t] : u2a[k]);
+		v3 o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k), i_out, w; float pdf;
 		sample_one<KIND, IS, FRK>(b, p, u1, u2, o, gt, i_out, w, pdf);
-		store3(vi_out, k, i_out);
-		if (IS) { store3(vw_out, k, w); out_pdf[k] = pdf; }
+		if (DENSE) store3_dense(vi_out, k0, t, i_out); else store3(vi_out, k, i_out);
+		if (IS) {
+			if (DENSE) { store3_dense(vw_out, k0, t, w); (out_pdf + k0)[t] = pdf; }
+			else { store3(vw_out, k, w); out_pdf[k] = pdf; }
+		}
 	}
 }
 
@@ -198,28 +227,27 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
 {
 	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
 	View w = out_w ? *out_w : View{ nullptr, nullptr, nullptr, 0 };
-	bool is = out_w != nullptr, rng = u1 == nullptr;
-	if (!is && !rng) hipLaunchKernelGGL((k_sample<KIND, false, false>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
-	else if (!is && rng) hipLaunchKernelGGL((k_sample<KIND, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
-	else {
-		// evalp_is evaluates the Fresnel term of the sampled pair: specialised like k_eval
-		constexpr bool analytic = KIND == KIND_BECKMANN || KIND == KIND_GGX;
-		constexpr bool fitted = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO;
-#define DJB_LAUNCH_IS(RNG_, FRK_) hipLaunchKernelGGL((k_sample<KIND, true, RNG_, FRK_>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf)
-#define DJB_LAUNCH_IS_FR(FRK_) do { if (rng) DJB_LAUNCH_IS(true, FRK_); else DJB_LAUNCH_IS(false, FRK_); return hipGetLastError(); } while (0)
-		if constexpr (analytic) {
-			if (b.fr.kind == FR_IDEAL) DJB_LAUNCH_IS_FR(FR_IDEAL);
-			if (b.fr.kind == FR_SCHLICK) DJB_LAUNCH_IS_FR(FR_SCHLICK);
-			if (b.fr.kind == FR_UNPOLARIZED) DJB_LAUNCH_IS_FR(FR_UNPOLARIZED);
-		}
-		if constexpr (fitted) {
-			if (b.fr.kind == FR_SPLINE) DJB_LAUNCH_IS_FR(FR_SPLINE);
-		}
-		DJB_LAUNCH_IS_FR(-1);
-#undef DJB_LAUNCH_IS_FR
-#undef DJB_LAUNCH_IS
+	const bool is = out_w != nullptr, rng = u1 == nullptr;
+	const bool dn = dense(o) && dense(out_i) && dense(w);
+	// evalp_is evaluates the Fresnel term of the sampled pair: specialised like k_eval
+	constexpr bool analytic = KIND == KIND_BECKMANN || KIND == KIND_GGX;
+	constexpr bool fitted = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO;
+#define DJB_LAUNCH_S(IS_, RNG_, FRK_, DN_) hipLaunchKernelGGL((k_sample<KIND, IS_, RNG_, FRK_, DN_>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf)
+#define DJB_LAUNCH_S2(IS_, FRK_) do { if (rng) { if (dn) DJB_LAUNCH_S(IS_, true, FRK_, true); else DJB_LAUNCH_S(IS_, true, FRK_, false); } \
+                                      else { if (dn) DJB_LAUNCH_S(IS_, false, FRK_, true); else DJB_LAUNCH_S(IS_, false, FRK_, false); } \
+                                      return hipGetLastError(); } while (0)
+	if (!is) DJB_LAUNCH_S2(false, -1);
+	if constexpr (analytic) {
+		if (b.fr.kind == FR_IDEAL) DJB_LAUNCH_S2(true, FR_IDEAL);
+		if (b.fr.kind == FR_SCHLICK) DJB_LAUNCH_S2(true, FR_SCHLICK);
+		if (b.fr.kind == FR_UNPOLARIZED) DJB_LAUNCH_S2(true, FR_UNPOLARIZED);
 	}
-	return hipGetLastError();
+	if constexpr (fitted) {
+		if (b.fr.kind == FR_SPLINE) DJB_LAUNCH_S2(true, FR_SPLINE);
+	}
+	DJB_LAUNCH_S2(true, -1);
+#undef DJB_LAUNCH_S2
+#undef DJB_LAUNCH_S
 }
 
 // ------------------------------------------------------------------ microfacet / radial queries

@@ -13,10 +13,12 @@
 #include "djb_internal.hpp"
 #include "djb_cpu.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -49,13 +51,16 @@ namespace {
 
 constexpr long long MERL_N = 90LL * 90 * 180;
 constexpr size_t PAYLOAD = sizeof(double) * 3 * MERL_N;   // 34 992 000 bytes after the 12-byte header
+constexpr size_t CHUNK = 4u << 20;                        // pinned staging granularity
+constexpr int CHUNKS_PER_FILE = (int)((PAYLOAD + CHUNK - 1) / CHUNK);
 
-struct Slot {
-	double *host = nullptr;       // pinned
-	double *dev = nullptr;        // raw payload in HBM
-	hipEvent_t done = nullptr;    // conversion finished -> slot reusable
-	int file = -1;
-	int state = 0;                // 0 free, 1 being filled, 2 filled, 3 in flight on the GPU
+// one pinned staging chunk
+struct Chunk {
+	char *host = nullptr;         // pinned, CHUNK bytes
+	hipEvent_t done = nullptr;    // its upload has finished -> reusable
+	int file = -1, part = -1;
+	size_t bytes = 0;
+	int state = 0;                // 0 free, 1 being filled, 2 filled, 3 upload in flight
 	djb_status st = DJB_OK;
 	std::string err;
 };
@@ -65,31 +70,35 @@ double now_s()
 	return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// same checks and messages as djb::merl::merl (dj_brdf.h:963-983)
-djb_status read_payload(const char *path, double *dst, std::string *err)
+// one chunk of a file's payload; part 0 also validates the header.  Same checks and messages as djb::merl::merl
+// (dj_brdf.h:963-983); the header is untrusted: 64-bit product of positive dims, MERL shape only.
+djb_status read_part(const char *path, int part, char *dst, size_t *bytes, std::string *err)
 {
 	char buf[256];
 	int fd = open(path, O_RDONLY);
 	if (fd < 0) { snprintf(buf, sizeof buf, "djb_error: Failed to open %s\n", path); *err = buf; return DJB_ERR_OPEN_FAILED; }
-	int32_t dims[3] = { 0, 0, 0 };
-	ssize_t got = pread(fd, dims, 12, 0);
-	// the header is untrusted: 64-bit product of positive dims only (an int32 product overflows: UB)
-	const bool positive = got == 12 && dims[0] > 0 && dims[1] > 0 && dims[2] > 0;
-	long long n = positive ? (long long)dims[0] * (long long)dims[1] * (long long)dims[2] : 0;
-	if (n <= 0) { close(fd); *err = "djb_error: Failed to read MERL header\n"; return DJB_ERR_BAD_HEADER; }
-	if (n != MERL_N) {
-		close(fd);
-		snprintf(buf, sizeof buf, "djb_error: MERL table has %lld samples per channel, expected %lld\n", n, MERL_N);
-		*err = buf; return DJB_ERR_BAD_HEADER;
+	if (part == 0) {
+		int32_t dims[3] = { 0, 0, 0 };
+		ssize_t got = pread(fd, dims, 12, 0);
+		const bool positive = got == 12 && dims[0] > 0 && dims[1] > 0 && dims[2] > 0;
+		long long n = positive ? (long long)dims[0] * (long long)dims[1] * (long long)dims[2] : 0;
+		if (n <= 0) { close(fd); *err = "djb_error: Failed to read MERL header\n"; return DJB_ERR_BAD_HEADER; }
+		if (n != MERL_N) {
+			close(fd);
+			snprintf(buf, sizeof buf, "djb_error: MERL table has %lld samples per channel, expected %lld\n", n, MERL_N);
+			*err = buf; return DJB_ERR_BAD_HEADER;
+		}
 	}
+	const size_t begin = (size_t)part * CHUNK, want = PAYLOAD - begin < CHUNK ? PAYLOAD - begin : CHUNK;
 	size_t off = 0;
-	while (off < PAYLOAD) {
-		ssize_t r = pread(fd, (char *)dst + off, PAYLOAD - off, 12 + (off_t)off);
+	while (off < want) {
+		ssize_t r = pread(fd, dst + off, want - off, 12 + (off_t)(begin + off));
 		if (r <= 0) break;
 		off += (size_t)r;
 	}
 	close(fd);
-	if (off != PAYLOAD) { snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED; }
+	if (off != want) { snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED; }
+	*bytes = want;
 	return DJB_OK;
 }
 
@@ -119,61 +128,74 @@ static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *p
 	hipStream_t stream = djbk::ctx_stream(ctx);
 	struct CallLock { djb_ctx *c; explicit CallLock(djb_ctx *c_) : c(c_) { djbk::ctx_lock(c); } ~CallLock() { djbk::ctx_unlock(c); } } call_lock(ctx);
 	const double t_begin = now_s();
-	const int n_slots = n_files < 4 ? n_files : 4;
-	if (reader_threads < 1) reader_threads = 4;
-	if (reader_threads > n_slots) reader_threads = n_slots;
+	// Readers copy file chunks from the page cache into pinned memory; the consumer below feeds them to the DMA engine.
+	// Measured on the GPU box (2 x EPYC 9575F, 100 files, profiles/r02/fit_files_rates.txt): 2 readers 88 ms = 40 GB/s
+	// (PCIe Gen5 takes ~56 GB/s one way, tools/pcie_probe.hip), 4 readers 108 ms, 8 readers 123 ms -- more readers
+	// only add cross-socket memory traffic.  Round 1 staged whole files (4 x 35 MB pinned slots): 125-143 ms, of which
+	// ~35 ms went into pinning and unpinning the slots.  DJB_READER_THREADS overrides.
+	if (reader_threads < 1) {
+		reader_threads = 2;
+		if (const char *ev = getenv("DJB_READER_THREADS")) { int v = atoi(ev); if (v >= 1 && v <= 64) reader_threads = v; }
+	}
+	const long long n_parts = (long long)n_files * CHUNKS_PER_FILE;
+	if ((long long)reader_threads > n_parts) reader_threads = (int)n_parts;
+	// Staging is a ring of 4 MiB pinned chunks, not of whole files: pinning memory is what a first call pays for
+	// (hipHostMalloc of ten 35 MB slots cost ~35 ms of a 110 ms job), and 4 MiB copies already run at link speed.
+	const int n_chunks = (int)std::min<long long>(n_parts, std::min(3LL * reader_threads + 2, 16LL));
+	const int n_raw = n_files < 6 ? n_files : 6;                  // raw payloads (doubles) in HBM awaiting conversion
 
-	std::vector<Slot> slots(n_slots);
-	std::vector<djbdev::MerlTexel *> tables(n_files, nullptr);   // views into all_tables
+	std::vector<Chunk> chunks(n_chunks);
+	char *pinned = nullptr;
+	double *raw = nullptr;                                        // n_raw x PAYLOAD
+	std::vector<int> parts_up(n_files, 0);
 	djbdev::MerlTexel *all_tables = nullptr;
 	djb_status status = DJB_OK;
 	std::string status_msg;
+	int status_file = n_files;                                    // the reference stops at the first bad file: report the lowest index
 	auto cleanup = [&]() {
-		for (Slot &s : slots) {
-			if (s.host) (void)hipHostFree(s.host);
-			if (s.dev) (void)hipFree(s.dev);
-			if (s.done) (void)hipEventDestroy(s.done);
-		}
+		for (Chunk &c : chunks) if (c.done) (void)hipEventDestroy(c.done);
+		if (pinned) (void)hipHostFree(pinned);
+		if (raw) (void)hipFree(raw);
 		if (all_tables) (void)hipFree(all_tables);
 	};
-	if (hipMalloc((void **)&all_tables, sizeof(djbdev::MerlTexel) * (size_t)MERL_N * n_files) != hipSuccess) {
-		(void)hipGetLastError();
-		return djbk::set_error(DJB_ERR_HIP, "djb_error: cannot allocate %d MERL tables in HBM", n_files);
+	bool ok = hipMalloc((void **)&all_tables, sizeof(djbdev::MerlTexel) * (size_t)MERL_N * n_files) == hipSuccess &&
+	          hipMalloc((void **)&raw, PAYLOAD * (size_t)n_raw) == hipSuccess &&
+	          hipHostMalloc((void **)&pinned, CHUNK * (size_t)n_chunks, hipHostMallocDefault) == hipSuccess;
+	for (int k = 0; ok && k < n_chunks; ++k) {
+		chunks[k].host = pinned + CHUNK * (size_t)k;
+		ok = hipEventCreateWithFlags(&chunks[k].done, hipEventDisableTiming) == hipSuccess;
 	}
-	for (Slot &s : slots) {
-		if (hipHostMalloc((void **)&s.host, PAYLOAD, hipHostMallocDefault) != hipSuccess ||
-		    hipMalloc((void **)&s.dev, PAYLOAD) != hipSuccess ||
-		    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
-			cleanup();
-			return djbk::set_error(DJB_ERR_HIP, "djb_error: cannot allocate the upload ring");
-		}
+	if (!ok) {
+		(void)hipGetLastError();
+		cleanup();
+		return djbk::set_error(DJB_ERR_HIP, "djb_error: cannot allocate the upload ring / %d MERL tables in HBM", n_files);
 	}
 
-	// ---- producer side: reader threads claim (file, free slot) pairs in file order
+	// ---- producer side: reader threads claim (file, part) items in order and a free pinned chunk each
 	std::mutex mu;
 	std::condition_variable cv;
-	int next_file = 0;
+	long long next_part = 0;
 	bool abort_flag = false;
 	auto reader = [&]() {
 		for (;;) {
-			int file, slot = -1;
+			int slot = -1; long long item;
 			{
 				std::unique_lock<std::mutex> lk(mu);
 				cv.wait(lk, [&] {
-					if (abort_flag || next_file >= n_files) return true;
-					for (int s = 0; s < n_slots; ++s) if (slots[s].state == 0) return true;
+					if (abort_flag || next_part >= n_parts) return true;
+					for (int s = 0; s < n_chunks; ++s) if (chunks[s].state == 0) return true;
 					return false;
 				});
-				if (abort_flag || next_file >= n_files) return;
-				for (int s = 0; s < n_slots; ++s) if (slots[s].state == 0) { slot = s; break; }
-				file = next_file++;
-				slots[slot].state = 1; slots[slot].file = file;
+				if (abort_flag || next_part >= n_parts) return;
+				for (int s = 0; s < n_chunks; ++s) if (chunks[s].state == 0) { slot = s; break; }
+				item = next_part++;
+				chunks[slot].state = 1; chunks[slot].file = (int)(item / CHUNKS_PER_FILE); chunks[slot].part = (int)(item % CHUNKS_PER_FILE);
 			}
-			std::string err;
-			djb_status st = read_payload(paths[file], slots[slot].host, &err);
+			std::string err; size_t bytes = 0;
+			djb_status st = read_part(paths[chunks[slot].file], chunks[slot].part, chunks[slot].host, &bytes, &err);
 			{
 				std::lock_guard<std::mutex> lk(mu);
-				slots[slot].st = st; slots[slot].err = err; slots[slot].state = 2;
+				chunks[slot].st = st; chunks[slot].err = err; chunks[slot].bytes = bytes; chunks[slot].state = 2;
 			}
 			cv.notify_all();
 		}
@@ -181,47 +203,70 @@ static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *p
 	std::vector<std::thread> readers;
 	for (int t = 0; t < reader_threads; ++t) readers.emplace_back(reader);
 
-	// ---- consumer side (this thread): upload + convert filled slots, recycle finished ones
-	int uploaded = 0;
-	while (uploaded < n_files && status == DJB_OK) {
+	// ---- consumer side (this thread): upload filled chunks, convert a file once its last chunk is on its way
+	long long uploaded = 0;
+	while (uploaded < n_parts && status == DJB_OK) {
 		int slot = -1;
 		{
 			std::unique_lock<std::mutex> lk(mu);
-			cv.wait_for(lk, std::chrono::milliseconds(1), [&] {
-				for (int s = 0; s < n_slots; ++s) if (slots[s].state == 2) return true;
+			cv.wait_for(lk, std::chrono::microseconds(200), [&] {
+				for (int s = 0; s < n_chunks; ++s) if (chunks[s].state == 2) return true;
 				return false;
 			});
-			for (int s = 0; s < n_slots; ++s) if (slots[s].state == 2) { slot = s; break; }
+			// oldest filled chunk first, so that files complete (and free their raw slot) in order
+			// (a chunk of file F may only go to raw slot F % n_raw once file F - n_raw has been handed to the
+			// conversion kernel: a slow reader can hold a part of an old file while the others run far ahead)
+			long long best = -1;
+			for (int s = 0; s < n_chunks; ++s)
+				if (chunks[s].state == 2) {
+					const int F = chunks[s].file;
+					if (chunks[s].st == DJB_OK && F >= n_raw && parts_up[F - n_raw] < CHUNKS_PER_FILE) continue;
+					long long id = (long long)F * CHUNKS_PER_FILE + chunks[s].part;
+					if (best < 0 || id < best) { best = id; slot = s; }
+				}
 		}
-		// recycle slots whose conversion has completed
-		for (int s = 0; s < n_slots; ++s) {
+		// recycle chunks whose upload has completed
+		bool freed = false;
+		for (int s = 0; s < n_chunks; ++s) {
 			bool inflight;
-			{ std::lock_guard<std::mutex> lk(mu); inflight = slots[s].state == 3; }
-			if (inflight && hipEventQuery(slots[s].done) == hipSuccess) {
-				{ std::lock_guard<std::mutex> lk(mu); slots[s].state = 0; }
-				cv.notify_all();
+			{ std::lock_guard<std::mutex> lk(mu); inflight = chunks[s].state == 3; }
+			if (inflight && hipEventQuery(chunks[s].done) == hipSuccess) {
+				{ std::lock_guard<std::mutex> lk(mu); chunks[s].state = 0; }
+				freed = true;
 			}
 		}
+		if (freed) cv.notify_all();
 		if (slot < 0) continue;
-		Slot &s = slots[slot];
-		if (s.st != DJB_OK) { status = s.st; status_msg = s.err; break; }
-		djbdev::MerlTexel *tab = all_tables + (size_t)s.file * MERL_N;   // one block for the batch (a hipMalloc per file costs ~0.2 ms)
-		e = hipMemcpyAsync(s.dev, s.host, PAYLOAD, hipMemcpyHostToDevice, stream);
-		if (e == hipSuccess) e = djbk::launch_merl_convert(stream, s.dev, MERL_N, tab);
-		if (e == hipSuccess) e = hipEventRecord(s.done, stream);
+		Chunk &c = chunks[slot];
+		if (c.st != DJB_OK) {
+			if (c.file < status_file) { status_file = c.file; status = c.st; status_msg = c.err; }
+			break;
+		}
+		// raw slot r was last used by file c.file - n_raw, whose conversion kernel is already enqueued on this stream
+		// (checked above): the copy below is ordered after it
+		const int r = c.file % n_raw;
+		char *dst = (char *)raw + PAYLOAD * (size_t)r + CHUNK * (size_t)c.part;
+		e = hipMemcpyAsync(dst, c.host, c.bytes, hipMemcpyHostToDevice, stream);
+		if (e == hipSuccess) e = hipEventRecord(c.done, stream);
+		if (e == hipSuccess && ++parts_up[c.file] == CHUNKS_PER_FILE) {
+			// one block for the batch (a hipMalloc per file costs ~0.2 ms)
+			e = djbk::launch_merl_convert(stream, (const double *)((char *)raw + PAYLOAD * (size_t)r), MERL_N, all_tables + (size_t)c.file * MERL_N);
+		}
 		if (e != hipSuccess) {
 			status = DJB_ERR_HIP; status_msg = std::string("djb_error: upload failed: ") + hipGetErrorString(e);
 			break;
 		}
-		tables[s.file] = tab;
-		{ std::lock_guard<std::mutex> lk(mu); s.state = 3; }
+		{ std::lock_guard<std::mutex> lk(mu); c.state = 3; }
 		++uploaded;
 	}
 	{ std::lock_guard<std::mutex> lk(mu); abort_flag = true; }
 	cv.notify_all();
 	for (std::thread &t : readers) t.join();
-	// uploads / conversions of earlier slots may still be in flight, also on the failure path: the ring
-	// (pinned host + HBM) must not be freed under them
+	if (status != DJB_OK || uploaded < n_parts) {
+		// a lower-indexed file may have failed in a chunk that was filled but not yet consumed
+		for (Chunk &c : chunks) if (c.state == 2 && c.st != DJB_OK && c.file < status_file) { status_file = c.file; status = c.st; status_msg = c.err; }
+	}
+	// uploads / conversions may still be in flight, also on the failure path: the ring must not be freed under them
 	{
 		hipError_t se = hipStreamSynchronize(stream);
 		if (se != hipSuccess) (void)hipGetLastError();
@@ -232,9 +277,8 @@ static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *p
 
 	// ---- one fit launch for the whole batch
 	std::vector<djb_brdf *> mats(n_files, nullptr);
-	for (int k = 0; k < n_files && status == DJB_OK; ++k) {
-		status = djbk::wrap_merl_table(ctx, tables[k], &mats[k], false);   // views into all_tables
-	}
+	for (int k = 0; k < n_files && status == DJB_OK; ++k)
+		status = djbk::wrap_merl_table(ctx, all_tables + (size_t)k * MERL_N, &mats[k], false);   // views into all_tables
 	if (status == DJB_OK)
 		status = djb_fit_brdf_batch(ctx, n_files, mats.data(), res, shadow, alpha_beckmann, alpha_ggx,
 		                            nullptr, nullptr, nullptr, nullptr, nullptr);

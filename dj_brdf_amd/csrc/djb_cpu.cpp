@@ -222,8 +222,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 	std::vector<float> theta(cnt), cosv(cnt), tanv(cnt), kji(cnt);
 	std::vector<double> v0(cnt, 1.0), v1(cnt, 0.0), kmT((size_t)cnt * cnt);
 	for (int k = 0; k < cnt; ++k) {
-		float tmp = (float)k / (float)cnt;
-		float th = F(D(tmp) * sqrt(DJB_PI * 0.5));
+		float th = fit_backscatter_theta(k, cnt);
 		float th2 = th * th;
 		float c = F(cos(D(th2))), t = F(tan(D(th2)));
 		theta[k] = th; cosv[k] = c; tanv[k] = t;
@@ -304,17 +303,9 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 	// ---- compute_fresnel (dj_brdf.h:2583-2641)
 	for (int i = 0; i < cnt; ++i) {
 		float fx = 0, fy = 0, fz = 0; int cx = 0, cy = 0, cz = 0;
-		const float theta_d = F(D((float)i / (float)cnt) * DJB_PI * 0.5);
 		for (int j = 0; j <= cnt; ++j) {
-			float prev = 0.0f;
-			if (j > 0) { float t1 = (float)(j - 1) / (float)cnt; prev = F(D(t1 * t1) * DJB_PI * 0.5); }
-			float t1 = (float)j / (float)cnt;
-			float theta_h = F(D(t1 * t1) * DJB_PI * 0.5);
-			if (!(D(prev) < DJB_PI * 0.5 - D(theta_d) && !(D(theta_h) > DJB_PI * 0.5))) continue;
-			v3 dir_h = from_angles(theta_h, 0.0f), dir_d = from_angles(theta_d, F(DJB_PI * 0.5));
 			v3 dir_i, dir_o;
-			hd_to_io(dir_h, dir_d, dir_i, dir_o);
-			dir_i = mk(0, 0, 1);                        // dj_brdf.h:2609
+			if (!fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) continue;
 			v3 fr1 = src_eval(src, std_p, dir_i, dir_o);
 			v3 fr2; float pdf;
 			mf_eval_pdf<KIND_TABULAR, 1>(self, std_p, dir_i, dir_o, fr2, pdf);

@@ -54,6 +54,8 @@ struct Brdf {
 	const float *p22, *sigma, *cdf, *qf;   // tabular tables (device)
 	int n_p22, n_sigma, n_cdf, n_qf;
 	const MerlTexel *merl;                  // [1458000] pre-scaled float RGB; below-horizon -> 0
+	int merl_sparse;                        // != 0 (file-fit pipeline only): `merl` holds just the texels the fitter reads, one per
+	                                        // query slot (fit_merl_slot_count), not the table: never handed to the eval kernels
 	const float4 *utia;                     // [288*288][8]: 128-byte records, RGB of the 2x2x2 (theta_v, phi_i, phi_v) taps (k_utia_convert)
 	const double *model;                    // sgd: 33 doubles, abc: 9 doubles (one published table row)
 	// tabular_anisotropic: p22 / sigma above are elev x azim grids (element (i, j) at [i + elev*j]);
@@ -1013,6 +1015,52 @@ DJB_DEV void merl_angles_exact(v3 i, v3 o, float &th, float &td, float &pd)
 	v3 tmp = rotate_z(i, -ph);
 	d = normalize(rotate_y(tmp, -th));
 	xyz_to_theta_phi(d, td, pd);
+}
+
+// ------------------------------------------------------------------ the source look-ups of djb::tabular's constructor
+// tabular(brdf, res) evaluates its source BRDF at a FIXED set of directions that depend on `res` only: cnt = res - 1
+// back-scattering configurations for the slope pdf (dj_brdf.h:2488-2499) and, for the Fresnel ratio, the pairs
+// (theta_d(i), theta_h(j)), i < cnt, j <= cnt, with dir_i overwritten by (0, 0, 1) (dj_brdf.h:2595-2612).  They are
+// numbered as query slots: slot k < cnt = back-scattering direction k, slot cnt + i * (cnt + 1) + j = Fresnel pair (i, j).
+// For a MERL source that is all a fit ever reads of the 4.37 M table entries (5.5 k of them at res 90), which lets the
+// file pipeline fetch just those (djb_loader.hip).  The same functions give k_fit its directions.
+#if defined(DJB_HOST_MATH)
+static inline int fit_merl_slot_count(int res) { const int cnt = res - 1; return cnt + cnt * (cnt + 1); }
+#else
+__host__ __device__ inline int fit_merl_slot_count(int res) { const int cnt = res - 1; return cnt + cnt * (cnt + 1); }
+#endif
+DJB_DEV float fit_backscatter_theta(int k, int cnt)          // theta of eval(w, w), w = vec3(theta^2, 0)
+{
+	float tmp = (float)k / (float)cnt;
+	return F(D(tmp) * sqrt(DJB_PI * 0.5));
+}
+// false: the reference's loop skips this pair
+DJB_DEV bool fit_fresnel_dirs(int i, int j, int cnt, v3 &dir_i, v3 &dir_o)
+{
+	float theta_d = F(D((float)i / (float)cnt) * DJB_PI * 0.5);
+	float prev = 0.0f;
+	if (j > 0) { float t1 = (float)(j - 1) / (float)cnt; prev = F(D(t1 * t1) * DJB_PI * 0.5); }
+	float t1 = (float)j / (float)cnt;
+	float theta_h = F(D(t1 * t1) * DJB_PI * 0.5);
+	if (!(D(prev) < DJB_PI * 0.5 - D(theta_d) && !(D(theta_h) > DJB_PI * 0.5))) return false;
+	v3 dir_h = from_angles(theta_h, 0.0f), dir_d = from_angles(theta_d, F(DJB_PI * 0.5));
+	hd_to_io(dir_h, dir_d, dir_i, dir_o);
+	dir_i = mk(0, 0, 1);                        // dj_brdf.h:2609
+	return true;
+}
+// the MERL table index slot `s` reads, or -1 for a skipped pair
+DJB_DEV int fit_merl_slot_index(int s, int res)
+{
+	const int cnt = res - 1;
+	if (s < cnt) {
+		float th = fit_backscatter_theta(s, cnt);
+		v3 w = from_angles(th * th, 0.0f);
+		return merl_index(w, w);
+	}
+	const int e = s - cnt, i = e / (cnt + 1), j = e - i * (cnt + 1);
+	v3 dir_i, dir_o;
+	if (!fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) return -1;
+	return merl_index(dir_i, dir_o);
 }
 
 #if !defined(DJB_HOST_MATH)   // tier 1 is a device optimisation; the host runs merl_index as written

@@ -55,6 +55,7 @@ struct djb_ctx {
 	size_t scratch_bytes;
 	int merl_exact_only;      // DJB_OPT_MERL_EXACT_ONLY
 	int aniso_qf2_aligned = 0; // DJB_OPT_ANISO_QF2_ALIGNED
+	int fit_files_dense = 0;   // DJB_OPT_FIT_FILES_DENSE
 	int scalar_on_device = 0;  // DJB_OPT_SCALAR_ON_DEVICE: scalar-size host calls go through the GPU too (A/B testing)
 	// HBM staging blocks of the DJB_MEM_HOST path, recycled across calls (hipMalloc costs more than
 	// a small batch); bounded by POOL_MAX_BYTES
@@ -1848,6 +1849,7 @@ djb_status djb_ctx_set_option(djb_ctx *ctx, int option, int value)
 try {
 	if (is_cpu(ctx)) return DJB_OK;           // the options select GPU code paths
 	if (ctx && option == DJB_OPT_SCALAR_ON_DEVICE) { ctx->scalar_on_device = value != 0; return DJB_OK; }
+	if (ctx && option == DJB_OPT_FIT_FILES_DENSE) { ctx->fit_files_dense = value != 0; return DJB_OK; }
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	if (option == DJB_OPT_MERL_EXACT_ONLY) { ctx->merl_exact_only = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_ANISO_QF2_ALIGNED) { ctx->aniso_qf2_aligned = value != 0; return DJB_OK; }
@@ -1991,6 +1993,19 @@ djb_status set_error(djb_status st, const char *fmt, ...)
 	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
 	g_err = buf;
 	return st;
+}
+
+int ctx_option_fit_files_dense(djb_ctx *ctx) { return ctx->fit_files_dense; }
+
+// per-slot texels of the file-fit pipeline (see djb_loader.hip): a source for djb_fit_brdf_batch only
+djb_status wrap_merl_slots(djb_ctx *ctx, djbdev::MerlTexel *slots, djb_brdf **out)
+{
+	djb_brdf *b;
+	alloc_brdf(ctx, DJB_KIND_MERL, &b);
+	b->dev.merl = slots;
+	b->dev.merl_sparse = 1;
+	*out = b;
+	return DJB_OK;
 }
 
 // a texel table already converted in HBM becomes a djb::merl object (which owns it if `own`)

@@ -77,6 +77,9 @@ hipError_t launch_fit(hipStream_t s, const Brdf *srcs, int src_kind, const Param
                       int res, int shadow, double *km_scratch, float *ratio_scratch,
                       const FitOut &out, const FitSplit &split);
 size_t fit_lds_bytes(int res);
+// query slots of a tabular(merl, res) fit and the MERL table index each one reads (-1: unused slot); idx: device, fit_merl_slots(res) ints
+int fit_merl_slots(int res);
+hipError_t launch_fit_merl_slots(hipStream_t s, int res, int32_t *idx);
 
 // ---- tabular_anisotropic (djb_kernels_fit_aniso.hip): all pointers are device memory
 struct AnisoScratch {

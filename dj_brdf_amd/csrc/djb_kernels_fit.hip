@@ -62,12 +62,16 @@ __host__ __device__ inline LdsPlan make_plan(int res)
 	return p;
 }
 
+// slot: the query slot of this look-up (djb_device.hpp: fit_merl_slot_count); a sparse MERL source holds one texel per slot
 template <int SRC>
-DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o)
+DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o, int slot)
 {
 	v3 fr = mk(0, 0, 0); float pdf;
 	if (SRC <= KIND_TABULAR || SRC == KIND_TABULAR_ANISO) mf_eval_pdf<SRC, 1>(src, std_p, i, o, fr, pdf);
-	else if (SRC == KIND_MERL) fr = merl_eval(src, i, o);
+	else if (SRC == KIND_MERL) {
+		if (src.merl_sparse) { MerlTexel t = src.merl[slot]; fr = mk(t.x, t.y, t.z); }
+		else fr = merl_eval(src, i, o);
+	}
 	else if (SRC == KIND_UTIA) fr = utia_eval(src, i, o);
 	else if (SRC == KIND_SGD) fr = sgd_eval(src, i, o);
 	else if (SRC == KIND_ABC) fr = abc_eval(src, i, o);
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	self.fr.kind = FR_IDEAL; self.fr.pts = nullptr; self.fr.npts = 0;
 	self.p22 = p22; self.sigma = sigma; self.cdf = cdf; self.qf = qf;
 	self.n_p22 = res; self.n_sigma = res; self.n_cdf = res; self.n_qf = res;
-	self.merl = nullptr; self.utia = nullptr; self.exp_lds = 0u; self.pow_lds = 0u;
+	self.merl = nullptr; self.merl_sparse = 0; self.utia = nullptr; self.exp_lds = 0u; self.pow_lds = 0u;
 
 	// ================================================================ compute_p22_smith (dj_brdf.h:2482-2522)
 	const float dtheta_k = F(sqrt(DJB_PI * 0.5) / D((float)cnt));
@@ -126,13 +130,12 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		s_nphi = c;
 	}
 	for (int k = tid; k < cnt; k += FIT_BLOCK) {
-		float tmp = (float)k / (float)cnt;
-		float th = F(D(tmp) * sqrt(DJB_PI * 0.5));
+		float th = fit_backscatter_theta(k, cnt);
 		float th2 = th * th;
 		float c = F(cos(D(th2))), t = F(tan(D(th2)));
 		theta[k] = th; cosv[k] = c; tanv[k] = t;
 		v3 w = from_angles(th2, 0.0f);
-		float fr_i = intensity(src_eval<SRC>(src, std_p, w, w));
+		float fr_i = intensity(src_eval<SRC>(src, std_p, w, w, k));
 		kji[k] = F((D(dtheta_k) * glibc_pow(D(c), D(6.0f))) * (8.0 * D(fr_i)));
 		v0[k] = 1.0;
 	}
@@ -301,19 +304,11 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	auto fresnel_pairs = [&](int e0, int e1) {
 	for (int e = e0 + tid; e < e1; e += FIT_BLOCK) {
 		int i = e / (cnt + 1), j = e - i * (cnt + 1);
-		float theta_d = F(D((float)i / (float)cnt) * DJB_PI * 0.5);
-		float prev = 0.0f;
-		if (j > 0) { float t1 = (float)(j - 1) / (float)cnt; prev = F(D(t1 * t1) * DJB_PI * 0.5); }
-		float t1 = (float)j / (float)cnt;
-		float theta_h = F(D(t1 * t1) * DJB_PI * 0.5);
 		const float qnan = __builtin_nanf("");
 		float rx = qnan, ry = qnan, rz = qnan;
-		if (D(prev) < DJB_PI * 0.5 - D(theta_d) && !(D(theta_h) > DJB_PI * 0.5)) {
-			v3 dir_h = from_angles(theta_h, 0.0f), dir_d = from_angles(theta_d, F(DJB_PI * 0.5));
-			v3 dir_i, dir_o;
-			hd_to_io(dir_h, dir_d, dir_i, dir_o);
-			dir_i = mk(0, 0, 1);                        // dj_brdf.h:2609
-			v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o);
+		v3 dir_i, dir_o;
+		if (fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) {
+			v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o, cnt + e);
 			v3 fr2; float pdf;
 			mf_eval_pdf<KIND_TABULAR, 1>(self, std_p, dir_i, dir_o, fr2, pdf);
 			if (D(fr2.x) > 1e-4) rx = fr1.x / fr2.x;
@@ -433,6 +428,13 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	}
 }
 
+// the MERL table index each query slot reads (the file pipeline gathers exactly these entries on the host)
+__global__ __launch_bounds__(256) void k_fit_merl_slots(int res, int n_slots, int32_t *idx)
+{
+	int s = blockIdx.x * 256 + threadIdx.x;
+	if (s < n_slots) idx[s] = fit_merl_slot_index(s, res);
+}
+
 template <int SRC>
 hipError_t launch_fit_kind(hipStream_t s, const Brdf *srcs, const Params &std_p, int n_mat, int res,
                            int shadow, double *km, float *ratio, const djbk::FitOut &out, const djbk::FitSplit &split)
@@ -452,6 +454,14 @@ hipError_t launch_fit_kind(hipStream_t s, const Brdf *srcs, const Params &std_p,
 namespace djbk {
 
 size_t fit_lds_bytes(int res) { return (size_t)make_plan(res).total; }
+
+int fit_merl_slots(int res) { return fit_merl_slot_count(res); }
+hipError_t launch_fit_merl_slots(hipStream_t s, int res, int32_t *idx)
+{
+	const int n = fit_merl_slot_count(res);
+	hipLaunchKernelGGL(k_fit_merl_slots, dim3((n + 255) / 256), dim3(256), 0, s, res, n, idx);
+	return hipGetLastError();
+}
 
 // One workgroup occupies a CU (124 KB of LDS at res 90); each extra slice shortens the producers' share of a tile,
 // the row owners' 64 dependent adds per tile stay.

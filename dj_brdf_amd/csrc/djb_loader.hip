@@ -27,6 +27,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -40,6 +41,9 @@ djb_status djb_brdf_destroy(djb_brdf *);
 namespace djbk {
 // defined in djb_host.hip: wrap an already converted texel table into a djb_brdf (takes ownership)
 djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **out, bool own);
+// the same for a per-slot (sparse) texel array of the file-fit pipeline (djbdev::Brdf::merl_sparse)
+djb_status wrap_merl_slots(djb_ctx *ctx, djbdev::MerlTexel *slots, djb_brdf **out);
+int ctx_option_fit_files_dense(djb_ctx *ctx);
 hipStream_t ctx_stream(djb_ctx *ctx);
 int ctx_device(djb_ctx *ctx);
 // every entry point that enqueues on the ctx stream holds the context's call mutex (see djb_ctx)
@@ -102,6 +106,142 @@ djb_status read_part(const char *path, int part, char *dst, size_t *bytes, std::
 	return DJB_OK;
 }
 
+
+// ---- the sparse form: fetch only what the fit reads ----------------------------------------------------------
+// djb::tabular(merl, res) evaluates its source at a fixed set of directions (djb_device.hpp: fit_merl_slot_count):
+// cnt back-scattering configurations + the (theta_d, theta_h) Fresnel pairs, 5 545 of a MERL file's 4 374 000
+// doubles at res 90.  The reference loads all 35 MB to read them (0.135 s per file) and round 1
+// moved all 35 MB over PCIe.  Here the table indices of the slots are computed once on the GPU (the same device
+// code the fit kernel would run: k_fit_merl_slots), worker threads map each file and gather just those entries
+// into per-slot texels -- float(double(sample) * channel scale), below-horizon bins zeroed, exactly what
+// k_merl_convert writes for them (dj_brdf.h:1010-1023) -- and 97 KB per material goes to the GPU instead of 35 MB.
+// Same alphas, bit for bit (tests/test_gpu_golden.py::test_native_file_pipeline compares the two forms).
+struct SlotPlan { std::vector<int32_t> slot, idx; };   // used slots sorted by table index (monotone walk over the mapping)
+
+djb_status gather_file(const char *path, const SlotPlan &plan, djbdev::MerlTexel *out, std::string *err)
+{
+	char buf[256];
+	int fd = open(path, O_RDONLY);
+	if (fd < 0) { snprintf(buf, sizeof buf, "djb_error: Failed to open %s\n", path); *err = buf; return DJB_ERR_OPEN_FAILED; }
+	int32_t dims[3] = { 0, 0, 0 };
+	ssize_t got = pread(fd, dims, 12, 0);
+	const bool positive = got == 12 && dims[0] > 0 && dims[1] > 0 && dims[2] > 0;
+	long long n = positive ? (long long)dims[0] * (long long)dims[1] * (long long)dims[2] : 0;
+	if (n <= 0) { close(fd); *err = "djb_error: Failed to read MERL header\n"; return DJB_ERR_BAD_HEADER; }
+	if (n != MERL_N) {
+		close(fd);
+		snprintf(buf, sizeof buf, "djb_error: MERL table has %lld samples per channel, expected %lld\n", n, MERL_N);
+		*err = buf; return DJB_ERR_BAD_HEADER;
+	}
+	struct stat sb;
+	// the reference reads the whole payload and fails if the file is short (dj_brdf.h:979-982): same verdict from the size
+	if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < 12 + PAYLOAD) {
+		close(fd);
+		snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED;
+	}
+	void *map = mmap(nullptr, 12 + PAYLOAD, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (map == MAP_FAILED) { snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED; }
+	const char *base = (const char *)map + 12;                   // the payload is 4 bytes off 8-byte alignment: memcpy each double
+	const size_t m = plan.slot.size();
+	for (size_t k = 0; k < m; ++k) {
+		const long long i = plan.idx[k];
+		double s[3];
+		memcpy(&s[0], base + 8 * (size_t)i, 8);
+		memcpy(&s[1], base + 8 * (size_t)(i + MERL_N), 8);
+		memcpy(&s[2], base + 8 * (size_t)(i + 2 * MERL_N), 8);
+		// merl_convert_one on this entry (same expressions, host IEEE arithmetic == the device's)
+		float r = (float)(s[0] * (1.00 / 1500.0)), g = (float)(s[1] * (1.15 / 1500.0)), b = (float)(s[2] * (1.66 / 1500.0));
+		if ((double)r < 0.0 || (double)g < 0.0 || (double)b < 0.0) r = g = b = 0.0f;
+		out[plan.slot[k]] = djbdev::MerlTexel{ r, g, b };
+	}
+	munmap(map, 12 + PAYLOAD);
+	return DJB_OK;
+}
+
+djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow, int threads,
+                                 float *alpha_beckmann, float *alpha_ggx, double *timing)
+{
+	hipStream_t stream = djbk::ctx_stream(ctx);
+	const double t_begin = now_s();
+	const int n_slots = djbk::fit_merl_slots(res);
+	// ---- which table entries does a fit at this resolution read?  (device code, once per call: 8 k indices)
+	SlotPlan plan;
+	{
+		int32_t *d_idx = nullptr;
+		std::vector<int32_t> idx(n_slots);
+		hipError_t e = hipMalloc((void **)&d_idx, sizeof(int32_t) * n_slots);
+		if (e == hipSuccess) e = djbk::launch_fit_merl_slots(stream, res, d_idx);
+		if (e == hipSuccess) e = hipMemcpyAsync(idx.data(), d_idx, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost, stream);
+		hipError_t se = hipStreamSynchronize(stream);
+		if (e == hipSuccess) e = se;
+		if (d_idx) (void)hipFree(d_idx);
+		if (e != hipSuccess) { (void)hipGetLastError(); return djbk::set_error(DJB_ERR_HIP, "djb_error: fit slot indices: %s", hipGetErrorString(e)); }
+		std::vector<int32_t> order;
+		for (int s = 0; s < n_slots; ++s) if (idx[s] >= 0 && idx[s] < MERL_N) order.push_back(s);
+		std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return idx[a] < idx[b] || (idx[a] == idx[b] && a < b); });
+		for (int32_t s : order) { plan.slot.push_back(s); plan.idx.push_back(idx[s]); }
+	}
+	// ---- gather: files are independent -> worker threads; results land in one pinned block [file][slot]
+	djbdev::MerlTexel *host = nullptr, *dev = nullptr;
+	const size_t bytes = sizeof(djbdev::MerlTexel) * (size_t)n_slots * n_files;
+	if (hipHostMalloc((void **)&host, bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&dev, bytes) != hipSuccess) {
+		(void)hipGetLastError();
+		if (host) (void)hipHostFree(host);
+		return djbk::set_error(DJB_ERR_HIP, "djb_error: cannot allocate the per-slot tables of %d files", n_files);
+	}
+	memset(host, 0, bytes);
+	if (threads < 1) {
+		// measured on the GPU box, 100 files (profiles/r02/fit_files_rates.txt): 1 thread 30 ms, 4: 11.4, 8: 9.8, 16: 10.4
+		unsigned hc = std::thread::hardware_concurrency();
+		threads = hc > 8 ? 8 : hc > 1 ? (int)hc - 1 : 1;
+		if (const char *ev = getenv("DJB_READER_THREADS")) { int v = atoi(ev); if (v >= 1 && v <= 256) threads = v; }
+	}
+	if (threads > n_files) threads = n_files;
+	std::atomic<int> next(0);
+	std::mutex mu;
+	djb_status status = DJB_OK; std::string status_msg; int status_file = n_files;
+	auto worker = [&]() {
+		for (;;) {
+			const int f = next.fetch_add(1);
+			if (f >= n_files) return;
+			std::string err;
+			djb_status st = gather_file(paths[f], plan, host + (size_t)f * n_slots, &err);
+			if (st != DJB_OK) {
+				std::lock_guard<std::mutex> lk(mu);
+				if (f < status_file) { status_file = f; status = st; status_msg = err; }   // the reference stops at the first bad file
+			}
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+	worker();
+	for (std::thread &t : pool) t.join();
+	const double t_loaded0 = now_s();
+	hipError_t e = hipSuccess;
+	if (status == DJB_OK) {
+		e = hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream);
+		hipError_t se = hipStreamSynchronize(stream);
+		if (e == hipSuccess) e = se;
+		if (e != hipSuccess) { (void)hipGetLastError(); status = DJB_ERR_HIP; status_msg = std::string("djb_error: upload failed: ") + hipGetErrorString(e); }
+	}
+	const double t_loaded = now_s();
+	(void)t_loaded0;
+	std::vector<djb_brdf *> mats(n_files, nullptr);
+	for (int k = 0; k < n_files && status == DJB_OK; ++k) status = djbk::wrap_merl_slots(ctx, dev + (size_t)k * n_slots, &mats[k]);
+	if (status == DJB_OK && status_msg.empty())
+		status = djb_fit_brdf_batch(ctx, n_files, mats.data(), res, shadow, alpha_beckmann, alpha_ggx, nullptr, nullptr, nullptr, nullptr, nullptr);
+	const double t_end = now_s();
+	for (djb_brdf *b : mats) if (b) djb_brdf_destroy(b);
+	(void)hipHostFree(host); (void)hipFree(dev);
+	if (status != DJB_OK) return status_msg.empty() ? status : djbk::set_error(status, "%s", status_msg.c_str());
+	if (timing) {
+		timing[0] = t_end - t_begin; timing[1] = t_loaded - t_begin; timing[2] = t_end - t_loaded;
+		timing[3] = (double)n_files * (double)plan.idx.size() * 24.0;       // bytes actually read from the files
+	}
+	return DJB_OK;
+}
+
 } // namespace
 
 static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow,
@@ -127,6 +267,12 @@ static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *p
 	if (e != hipSuccess) return djbk::set_error(DJB_ERR_HIP, "djb_error: hipSetDevice: %s", hipGetErrorString(e));
 	hipStream_t stream = djbk::ctx_stream(ctx);
 	struct CallLock { djb_ctx *c; explicit CallLock(djb_ctx *c_) : c(c_) { djbk::ctx_lock(c); } ~CallLock() { djbk::ctx_unlock(c); } } call_lock(ctx);
+	// default: fetch only the entries the fit reads (fit_merl_files_sparse); DJB_OPT_FIT_FILES_DENSE / DJB_FIT_FILES_DENSE=1
+	// uploads and converts every table in full, as round 1 did -- same alphas, and what a caller that goes on to
+	// evaluate the tables would want
+	const char *dense_env = getenv("DJB_FIT_FILES_DENSE");
+	if (!(djbk::ctx_option_fit_files_dense(ctx) || (dense_env && atoi(dense_env) != 0)))
+		return fit_merl_files_sparse(ctx, n_files, paths, res, shadow, reader_threads, alpha_beckmann, alpha_ggx, timing);
 	const double t_begin = now_s();
 	// Readers copy file chunks from the page cache into pinned memory; the consumer below feeds them to the DMA engine.
 	// Measured on the GPU box (2 x EPYC 9575F, 100 files, profiles/r02/fit_files_rates.txt): 2 readers 88 ms = 40 GB/s

@@ -1015,6 +1015,12 @@ def set_merl_exact_only(ctx: Context, on: bool):
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(1), C.c_int(int(on))))
 
 
+def set_fit_files_dense(ctx: Context, on: bool):
+    """djb_fit_merl_files uploads and converts every table in full (DJB_OPT_FIT_FILES_DENSE) instead of fetching only the
+    entries a tabular(merl, res) fit reads; same alphas."""
+    _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(4), C.c_int(int(on))))
+
+
 def set_scalar_on_device(ctx: Context, on: bool):
     """Send scalar-size host calls (<= DJB_SCALAR_HOST_MAX units) through the GPU as well (DJB_OPT_SCALAR_ON_DEVICE);
     by default the host instantiation of the same code answers them on the calling thread."""

@@ -127,7 +127,10 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * all later rows (dj_brdf.h:3005-3034) -- the two differ only for such (grazing-heavy) data.          */
        DJB_OPT_ANISO_QF2_ALIGNED = 2,
 /* DJB_OPT_SCALAR_ON_DEVICE = 1: scalar-size DJB_MEM_HOST calls (<= DJB_SCALAR_HOST_MAX units) run on the GPU too */
-       DJB_OPT_SCALAR_ON_DEVICE = 3 };
+       DJB_OPT_SCALAR_ON_DEVICE = 3,
+/* DJB_OPT_FIT_FILES_DENSE = 1: djb_fit_merl_files uploads and converts every 35 MB table in full before the fit (the
+ * round-1 pipeline) instead of fetching only the ~5.5 k entries per file that tabular(merl, res) reads; same alphas */
+       DJB_OPT_FIT_FILES_DENSE = 4 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */
 djb_status  djb_timer_start(djb_ctx *ctx);
@@ -323,11 +326,13 @@ djb_status djb_fit_brdf_batch(djb_ctx *, int n_materials, const djb_brdf *const 
                               int res, int shadow, float *alpha_beckmann, float *alpha_ggx,
                               float *p22, float *sigma, float *cdf, float *qf, float *fresnel);
 
-/* End to end: what examples/merl_params.cpp:53-67 does per file, for a list of MERL files, as a
- * pipeline (reader threads -> pinned ring -> async upload + conversion kernel, then ONE fit launch
- * for the whole batch).  Errors carry djb::merl's messages (dj_brdf.h:970-982).  reader_threads <= 0
+/* End to end: what examples/merl_params.cpp:53-67 does per file, for a list of MERL files: the table indices a
+ * tabular(merl, res) fit reads are computed on the GPU, worker threads gather just those entries from the (mapped)
+ * files, ~97 KB per material travel to HBM, then ONE fit launch for the whole batch.  With DJB_OPT_FIT_FILES_DENSE
+ * the whole tables travel instead (reader threads -> pinned 4 MiB chunk ring -> async upload + conversion kernel).
+ * Errors carry djb::merl's messages (dj_brdf.h:970-982), the lowest-indexed bad file wins.  reader_threads <= 0
  * picks a default.  timing (optional, 4 doubles): total seconds, seconds until every table was
- * resident in HBM, seconds of the fit, bytes read.                                          */
+ * resident in HBM, seconds of the fit, bytes read from the files.                            */
 djb_status djb_fit_merl_files(djb_ctx *, int n_files, const char *const *paths, int res, int shadow,
                               int reader_threads, float *alpha_beckmann, float *alpha_ggx,
                               double *timing);

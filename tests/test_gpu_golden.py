@@ -329,7 +329,24 @@ def test_native_file_pipeline(gpu_ctx, tmp_path):
         p = str(tmp_path / f"m{k}.binary")
         synth.write_merl_binary(p, synth.merl_table(*recipes[k % 3])); paths.append(p)
     ab, ag, timing = merl_params.fit_files_on(gpu_ctx, paths)
-    assert timing["bytes"] == 7 * synth.MERL_FILE_BYTES and timing["total_s"] > 0
+    # default form: only the entries a tabular(merl, 90) fit reads are fetched from the files (5 545 x 3 doubles each)
+    assert 0 < timing["bytes"] < 7 * 6000 * 24 and timing["total_s"] > 0
+    # the dense form (every table uploaded and converted in full, 4 MiB chunk ring): same alphas, bit for bit
+    djb.set_fit_files_dense(gpu_ctx, True)
+    try:
+        abd, agd, td = merl_params.fit_files_on(gpu_ctx, paths)
+        assert td["bytes"] == 7 * synth.MERL_FILE_BYTES
+        assert np.array_equal(abd.view(np.uint32), ab.view(np.uint32)) and np.array_equal(agd.view(np.uint32), ag.view(np.uint32))
+        for bad_list, code in ((paths[:2] + [str(tmp_path / "missing.binary")], "DJB_ERR_OPEN_FAILED"),):
+            with pytest.raises(djb.exc) as e:
+                merl_params.fit_files_on(gpu_ctx, bad_list)
+            assert e.value.status_name == code
+        short = tmp_path / "short_dense.binary"; short.write_bytes(np.array([90, 90, 180], np.int32).tobytes() + b"\0" * (5 << 20))
+        with pytest.raises(djb.exc) as e:
+            merl_params.fit_files_on(gpu_ctx, paths[:1] + [str(short)])
+        assert e.value.status_name == "DJB_ERR_READ_FAILED"
+    finally:
+        djb.set_fit_files_dense(gpu_ctx, False)
     for k in range(7):
         t = djb.tabular(djb.merl(paths[k], ctx=gpu_ctx), 90, True, ctx=gpu_ctx)
         assert djb.tabular.fit_beckmann_parameters(t).get_ellipse()[0] == ab[k]

@@ -8,12 +8,15 @@ from dj_brdf_amd import djb, merl_params, synth
 ctx = djb.Context(0)
 paths = bench.synth_merl_files(100, synth)
 merl_params.fit_files_on(ctx, paths[:4])
-for threads in (2, 3, 4, 5, 6, 8, 12):
+for dense, sweep in ((False, (1, 2, 4, 8, 16, 32)), (True, (2, 4, 8))):
+  djb.set_fit_files_dense(ctx, dense)
+  print("dense upload of whole tables" if dense else "sparse: only the entries the fit reads")
+  for threads in sweep:
     best = None
     for rep in range(3):
         t0 = time.perf_counter()
         ab, ag, tim = merl_params.fit_files_on(ctx, paths, reader_threads=threads)
         wall = time.perf_counter() - t0
         if best is None or wall < best[0]: best = (wall, tim)
-    print(f"reader threads {threads:2d}: wall {best[0]*1e3:7.1f} ms  (pipeline total {best[1]['total_s']*1e3:.1f}, load {best[1]['load_s']*1e3:.1f}, fit {best[1]['fit_s']*1e3:.2f} ms)  "
+    print(f"  threads {threads:2d}: wall {best[0]*1e3:7.1f} ms  (pipeline total {best[1]['total_s']*1e3:.1f}, load {best[1]['load_s']*1e3:.1f}, fit {best[1]['fit_s']*1e3:.2f} ms)  "
           f"{best[1]['bytes']/best[1]['load_s']/1e9:.1f} GB/s", flush=True)

@@ -6,6 +6,7 @@
 #define DJB_HOST_MATH 1
 #include "djb_device.hpp"
 #include "djb_cpu.hpp"
+#include "djb_merl_file.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -32,7 +33,8 @@ struct CpuCtx {
 };
 
 struct CpuBrdf {
-	CpuCtx *ctx;              // MUST stay the first member (djbcpu::is_cpu)
+	int device = -1;          // MUST stay the first member (djbcpu::is_cpu)
+	CpuCtx *ctx;
 	Brdf dev;                 // the same view the kernels take; every pointer is host memory owned below
 	std::vector<float> p22, sigma, cdf, qf, fresnel;
 	float alpha_beckmann = 0.0f, alpha_ggx = 0.0f;
@@ -189,9 +191,10 @@ void pp_kind(const Brdf &b, long long k0, long long k1, const View &vi, const Vi
 	}
 }
 
-// brdf.eval of any kind (the fitters' source look-ups)
-v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o)
+// brdf.eval of any kind (the fitters' source look-ups); slot: the query slot (a sparse MERL source holds one texel per slot)
+v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o, int slot = -1)
 {
+	if (src.kind == KIND_MERL && src.merl_sparse) { MerlTexel t = src.merl[slot]; return mk(t.x, t.y, t.z); }
 	v3 fr = mk(0, 0, 0); float pdf = 0.0f;
 	DJB_KIND_SWITCH(src.kind, (eval_one<K, 1>(src, std_p, i, o, fr, pdf)))
 	return fr;
@@ -227,7 +230,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 		float c = F(cos(D(th2))), t = F(tan(D(th2)));
 		theta[k] = th; cosv[k] = c; tanv[k] = t;
 		v3 w = from_angles(th2, 0.0f);
-		float fr_i = intensity(src_eval(src, std_p, w, w));
+		float fr_i = intensity(src_eval(src, std_p, w, w, k));
 		kji[k] = F((D(dtheta_k) * glibc_pow(D(c), D(6.0f))) * (8.0 * D(fr_i)));
 	}
 	for (int io = 0; io < cnt; ++io)
@@ -306,7 +309,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 		for (int j = 0; j <= cnt; ++j) {
 			v3 dir_i, dir_o;
 			if (!fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) continue;
-			v3 fr1 = src_eval(src, std_p, dir_i, dir_o);
+			v3 fr1 = src_eval(src, std_p, dir_i, dir_o, cnt + i * (cnt + 1) + j);
 			v3 fr2; float pdf;
 			mf_eval_pdf<KIND_TABULAR, 1>(self, std_p, dir_i, dir_o, fr2, pdf);
 			if (D(fr2.x) > 1e-4) { fx += fr1.x / fr2.x; ++cx; }
@@ -847,7 +850,8 @@ djb_status fit_merl_batch(djb_ctx *ctx, int n_mat, const double *const *tables, 
 	return st;
 }
 
-// what examples/merl_params.cpp:53-67 does per file; files are independent -> threads
+// what examples/merl_params.cpp:53-67 does per file; files are independent -> threads.  Only the entries a
+// tabular(merl, res) fit reads are fetched from each (mapped) file: djb_merl_file.hpp
 djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow, int threads, float *ab,
                           float *ag, double *timing)
 {
@@ -856,29 +860,36 @@ djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, i
 	djb_status st = params_for(nullptr, -1, &std_p);
 	if (st != DJB_OK) return st;
 	const auto t_begin = std::chrono::steady_clock::now();
-	CpuCtx one; one.threads = 1;
+	const int n_slots = fit_merl_slot_count(res);
+	std::vector<int32_t> idx(n_slots);
+	CpuCtx pool = *C(ctx);
+	if (threads >= 1) pool.threads = threads;
+	parallel_for(&pool, n_slots, 256, [&](long long s0, long long s1) { for (long long s = s0; s < s1; ++s) idx[s] = fit_merl_slot_index((int)s, res); });
+	const djbfile::SlotPlan plan = djbfile::make_plan(idx);
 	std::mutex mu;
 	djb_status first = DJB_OK;
 	std::string first_msg;
 	int first_file = n_files;
 	double load_s = 0.0;
-	CpuCtx pool = *C(ctx);
-	if (threads >= 1) pool.threads = threads;
 	parallel_for(&pool, n_files, 1, [&](long long f0, long long f1) {
+		std::vector<MerlTexel> slots(n_slots);
 		for (long long f = f0; f < f1; ++f) {
 			const auto t0 = std::chrono::steady_clock::now();
-			djb_brdf *m = nullptr;
-			djb_status s = create_merl_from_file((djb_ctx *)&one, paths[f], &m);
+			std::string err;
+			memset(slots.data(), 0, sizeof(MerlTexel) * slots.size());
+			djb_status s = djbfile::gather_file(paths[f], plan, (float *)slots.data(), &err);
 			const auto t1 = std::chrono::steady_clock::now();
 			if (s != DJB_OK) {
 				std::lock_guard<std::mutex> g(mu);
-				if ((int)f < first_file) { first_file = (int)f; first = s; first_msg = djb_last_error(); }
+				if ((int)f < first_file) { first_file = (int)f; first = s; first_msg = err; }
 				continue;
 			}
+			Brdf src;
+			memset(&src, 0, sizeof src);
+			src.kind = KIND_MERL; src.shadow = 1; src.fr.kind = FR_IDEAL; src.merl = slots.data(); src.merl_sparse = 1;
 			FitResult R;
-			fit_tabular(B(m)->dev, std_p, res, shadow != 0, R);
+			fit_tabular(src, std_p, res, shadow != 0, R);
 			ab[f] = R.alpha_beckmann; ag[f] = R.alpha_ggx;
-			destroy(m);
 			std::lock_guard<std::mutex> g(mu);
 			load_s += std::chrono::duration<double>(t1 - t0).count();
 		}
@@ -887,7 +898,7 @@ djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, i
 	if (timing) {
 		timing[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 		timing[1] = load_s; timing[2] = timing[0] - load_s < 0 ? 0 : timing[0] - load_s;   // thread-summed load vs wall: indicative only
-		timing[3] = (double)n_files * (double)(12 + 8 * 3 * MERL_N);
+		timing[3] = (double)n_files * (double)plan.idx.size() * 24.0;
 	}
 	return DJB_OK;
 }

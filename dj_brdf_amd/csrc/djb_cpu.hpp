@@ -17,10 +17,11 @@
 
 namespace djbcpu {
 
-// handles: a CPU context / object starts with the same leading member as its GPU counterpart (djb_ctx: int device;
-// djb_brdf: djb_ctx *ctx), which is how the C ABI tells them apart (device < 0)
+// handles: a CPU context / object starts with the same leading int as its GPU counterpart (djb_ctx: the device,
+// djb_brdf: the device of the context that created it), which is how the C ABI tells them apart (device < 0).  The
+// object carries its own copy: a handle may outlive its context (garbage collectors destroy them in any order).
 inline bool is_cpu(const djb_ctx *c) { return c && *(const int *)c < 0; }
-inline bool is_cpu(const djb_brdf *b) { return b && is_cpu(*(const djb_ctx *const *)b); }
+inline bool is_cpu(const djb_brdf *b) { return b && *(const int *)b < 0; }
 
 // ---- context
 djb_status ctx_create(djb_ctx **out);

@@ -79,6 +79,8 @@ struct djb_ctx {
 };
 
 struct djb_brdf {
+	int device;                      // MUST stay the first member (djbcpu::is_cpu): device of the creating context, kept here
+	                                 // because the handle may be destroyed after its context
 	djb_ctx *ctx;
 	Brdf dev;                        // device view (pointers into HBM)
 	std::vector<void *> allocs;      // HBM blocks owned by this object
@@ -395,8 +397,8 @@ struct Staged {
 djb_status check_call(djb_ctx *ctx, const djb_brdf *b, long long n, int mem)
 {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
-	if (b && b->ctx->device != ctx->device)
-		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf lives on device %d, ctx on %d", b->ctx->device, ctx->device);
+	if (b && b->device != ctx->device)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf lives on device %d, ctx on %d", b->device, ctx->device);
 	if (n < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: negative batch size");
 	if (mem != DJB_MEM_DEVICE && mem != DJB_MEM_HOST)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown memory space %d", mem);
@@ -747,6 +749,7 @@ djb_status alloc_brdf(djb_ctx *ctx, int kind, djb_brdf **out)
 {
 	djb_brdf *b = new djb_brdf();
 	b->ctx = ctx;
+	b->device = ctx->device;
 	memset(&b->dev, 0, sizeof b->dev);
 	b->dev.kind = kind;
 	b->dev.shadow = 1;
@@ -1137,7 +1140,7 @@ try {
 	if (is_cpu(b)) return djbcpu::destroy(b);
 	if (b && b->twin) djbcpu::destroy(b->twin);
 	if (!b) return DJB_OK;
-	(void)hipSetDevice(b->ctx->device);
+	(void)hipSetDevice(b->device);
 	for (void *p : b->allocs) (void)hipFree(p);
 	delete b;
 	return DJB_OK;
@@ -1487,7 +1490,7 @@ try {
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
 	std::vector<Brdf> srcs(n_mat);
 	for (int m = 0; m < n_mat; ++m) {
-		if (!srcs_in[m] || srcs_in[m]->dev.kind != srcs_in[0]->dev.kind || srcs_in[m]->ctx->device != ctx->device)
+		if (!srcs_in[m] || srcs_in[m]->dev.kind != srcs_in[0]->dev.kind || srcs_in[m]->device != ctx->device)
 			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: batch fit needs BRDFs of one kind on the ctx device");
 		srcs[m] = srcs_in[m]->dev;
 	}

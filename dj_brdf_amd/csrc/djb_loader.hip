@@ -12,6 +12,7 @@
 #include "../../include/djb_hip.h"
 #include "djb_internal.hpp"
 #include "djb_cpu.hpp"
+#include "djb_merl_file.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -116,49 +117,6 @@ djb_status read_part(const char *path, int part, char *dst, size_t *bytes, std::
 // into per-slot texels -- float(double(sample) * channel scale), below-horizon bins zeroed, exactly what
 // k_merl_convert writes for them (dj_brdf.h:1010-1023) -- and 97 KB per material goes to the GPU instead of 35 MB.
 // Same alphas, bit for bit (tests/test_gpu_golden.py::test_native_file_pipeline compares the two forms).
-struct SlotPlan { std::vector<int32_t> slot, idx; };   // used slots sorted by table index (monotone walk over the mapping)
-
-djb_status gather_file(const char *path, const SlotPlan &plan, djbdev::MerlTexel *out, std::string *err)
-{
-	char buf[256];
-	int fd = open(path, O_RDONLY);
-	if (fd < 0) { snprintf(buf, sizeof buf, "djb_error: Failed to open %s\n", path); *err = buf; return DJB_ERR_OPEN_FAILED; }
-	int32_t dims[3] = { 0, 0, 0 };
-	ssize_t got = pread(fd, dims, 12, 0);
-	const bool positive = got == 12 && dims[0] > 0 && dims[1] > 0 && dims[2] > 0;
-	long long n = positive ? (long long)dims[0] * (long long)dims[1] * (long long)dims[2] : 0;
-	if (n <= 0) { close(fd); *err = "djb_error: Failed to read MERL header\n"; return DJB_ERR_BAD_HEADER; }
-	if (n != MERL_N) {
-		close(fd);
-		snprintf(buf, sizeof buf, "djb_error: MERL table has %lld samples per channel, expected %lld\n", n, MERL_N);
-		*err = buf; return DJB_ERR_BAD_HEADER;
-	}
-	struct stat sb;
-	// the reference reads the whole payload and fails if the file is short (dj_brdf.h:979-982): same verdict from the size
-	if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < 12 + PAYLOAD) {
-		close(fd);
-		snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED;
-	}
-	void *map = mmap(nullptr, 12 + PAYLOAD, PROT_READ, MAP_PRIVATE, fd, 0);
-	close(fd);
-	if (map == MAP_FAILED) { snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED; }
-	const char *base = (const char *)map + 12;                   // the payload is 4 bytes off 8-byte alignment: memcpy each double
-	const size_t m = plan.slot.size();
-	for (size_t k = 0; k < m; ++k) {
-		const long long i = plan.idx[k];
-		double s[3];
-		memcpy(&s[0], base + 8 * (size_t)i, 8);
-		memcpy(&s[1], base + 8 * (size_t)(i + MERL_N), 8);
-		memcpy(&s[2], base + 8 * (size_t)(i + 2 * MERL_N), 8);
-		// merl_convert_one on this entry (same expressions, host IEEE arithmetic == the device's)
-		float r = (float)(s[0] * (1.00 / 1500.0)), g = (float)(s[1] * (1.15 / 1500.0)), b = (float)(s[2] * (1.66 / 1500.0));
-		if ((double)r < 0.0 || (double)g < 0.0 || (double)b < 0.0) r = g = b = 0.0f;
-		out[plan.slot[k]] = djbdev::MerlTexel{ r, g, b };
-	}
-	munmap(map, 12 + PAYLOAD);
-	return DJB_OK;
-}
-
 djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow, int threads,
                                  float *alpha_beckmann, float *alpha_ggx, double *timing)
 {
@@ -166,7 +124,7 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 	const double t_begin = now_s();
 	const int n_slots = djbk::fit_merl_slots(res);
 	// ---- which table entries does a fit at this resolution read?  (device code, once per call: 8 k indices)
-	SlotPlan plan;
+	djbfile::SlotPlan plan;
 	{
 		int32_t *d_idx = nullptr;
 		std::vector<int32_t> idx(n_slots);
@@ -177,10 +135,7 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 		if (e == hipSuccess) e = se;
 		if (d_idx) (void)hipFree(d_idx);
 		if (e != hipSuccess) { (void)hipGetLastError(); return djbk::set_error(DJB_ERR_HIP, "djb_error: fit slot indices: %s", hipGetErrorString(e)); }
-		std::vector<int32_t> order;
-		for (int s = 0; s < n_slots; ++s) if (idx[s] >= 0 && idx[s] < MERL_N) order.push_back(s);
-		std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return idx[a] < idx[b] || (idx[a] == idx[b] && a < b); });
-		for (int32_t s : order) { plan.slot.push_back(s); plan.idx.push_back(idx[s]); }
+		plan = djbfile::make_plan(idx);
 	}
 	// ---- gather: files are independent -> worker threads; results land in one pinned block [file][slot]
 	djbdev::MerlTexel *host = nullptr, *dev = nullptr;
@@ -206,7 +161,7 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 			const int f = next.fetch_add(1);
 			if (f >= n_files) return;
 			std::string err;
-			djb_status st = gather_file(paths[f], plan, host + (size_t)f * n_slots, &err);
+			djb_status st = djbfile::gather_file(paths[f], plan, (float *)(host + (size_t)f * n_slots), &err);
 			if (st != DJB_OK) {
 				std::lock_guard<std::mutex> lk(mu);
 				if (f < status_file) { status_file = f; status = st; status_msg = err; }   // the reference stops at the first bad file

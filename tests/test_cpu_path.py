@@ -161,7 +161,7 @@ def test_params_txt_on_the_cpu(cpu, tmp_path):
     ab, ag, timing = merl_params.fit_files_on(cpu, files)
     txt = merl_params.format_params_txt(files, list(zip(ab.tolist(), ag.tolist())))
     assert txt.encode() == open(os.path.join(G, "params_expected.txt"), "rb").read()
-    assert timing["bytes"] == 3 * synth.MERL_FILE_BYTES
+    assert 0 < timing["bytes"] < 3 * 6000 * 24          # only the entries the fit reads are fetched from the files
     # batch entry points agree with the one-object path
     mats = [djb.merl(f, ctx=cpu) for f in files]
     ab2, ag2 = djb.fit_brdf_batch(mats, 90, True, ctx=cpu)

@@ -280,10 +280,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available() and djb.device_count() > 0, "bench.py needs MI355X GPUs; there is no CPU path"
+    # DJB_BENCH_SHARE_GPU=1 (harness self-test on a one-GPU box only): every rank uses device 0 and the control-plane
+    # collectives (barrier, MAX of the timings) run over gloo -- RCCL refuses two ranks on one device.  The data path has
+    # no collective either way.  Numbers from such a run say nothing about scaling and are labelled.
+    share_gpu = os.environ.get("DJB_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    red_dev = "cpu" if share_gpu else f"cuda:{local}"      # where the control-plane reductions live
     ctx = djb.Context(local)    # runs on torch's current stream of this device
 
     global GGX_ALPHA, GGX_FRESNEL
@@ -310,7 +320,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
 
@@ -330,7 +340,7 @@ def main():
         fit_ms = ctx.timer_stop_ms() / 3
         barrier()
         if world > 1:
-            t = torch.tensor([fit_ms], dtype=torch.float64, device=f"cuda:{local}")
+            t = torch.tensor([fit_ms], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fit_ms = float(t[0])
         fit100 = {"materials": 100, "n_gpus": world, "wall_ms": fit_ms, "scaling": "strong",
@@ -353,7 +363,7 @@ def main():
                 wall = time.perf_counter() - t_files
             finally:
                 djb.set_fit_files_dense(ctx, False)
-            tt = torch.tensor([wall, tim["total_s"], tim["load_s"], tim["fit_s"]], dtype=torch.float64, device=f"cuda:{local}")
+            tt = torch.tensor([wall, tim["total_s"], tim["load_s"], tim["fit_s"]], dtype=torch.float64, device=red_dev)
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             wall, f_total, f_load, f_fit = (float(x) for x in tt)
@@ -403,7 +413,8 @@ def main():
                                 "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material, tables resident in HBM",
                                 "merl_fit_files": "files on local disk -> pread -> PCIe -> k_merl_convert -> "
                                                   "tabular(merl, 90) + both fits (end to end)"}[name],
-                       "layout": "SoA float32 in HBM", "parallelism": f"independent x{world} (no collective)"},
+                       "layout": "SoA float32 in HBM", "parallelism": f"independent x{world} (no collective)"
+                       + (" -- SELF-TEST: all ranks share GPU 0 (DJB_BENCH_SHARE_GPU), not a scaling measurement" if share_gpu else "")},
             "roofline": roofline,
         }
         if name == "merl_fit_files":

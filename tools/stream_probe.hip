@@ -455,6 +455,47 @@ static void run(const char *name, int blocks, float **d, long long n)
 	       WORK * 3, UNROLL, blocks, ms, 36.0 * n / ms / 1e6);
 }
 
+// ---- do the two halves of the MERL kernel hurt each other because they share each CU's memory pipeline?
+// The stream kernel (6 in / 3 out, no gather) and the gather kernel (no streams) run CONCURRENTLY on two HIP streams,
+// each over the full 1e9 units: if the time is ~max(stream, gather) a split design (index pass + gather pass on
+// disjoint CUs) could beat the fused kernel's stream + gather sum; if it is ~the sum, the fused kernel already is
+// what the memory system gives.
+static void run_concurrent(unsigned int entries, float **d, Texel *tab, long long n)
+{
+	long long n4 = n / 4;
+	hipStream_t s1, s2;
+	hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+	hipEvent_t e0, e1, e2;
+	hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+	auto copy = [&](hipStream_t st, int blocks) {
+		hipLaunchKernelGGL((k_probe<true, 0, 1>), dim3(blocks), dim3(256), 0, st, (const v4f *)d[0], (const v4f *)d[1], (const v4f *)d[2],
+		                   (const v4f *)d[3], (const v4f *)d[4], (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n4);
+	};
+	auto gather = [&](hipStream_t st, int blocks) {
+		hipLaunchKernelGGL((k_gather<false>), dim3(blocks), dim3(256), 0, st, tab, entries, (const v4f *)d[0], (const v4f *)d[1], (const v4f *)d[2],
+		                   (const v4f *)d[3], (const v4f *)d[4], (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n4);
+	};
+	for (int blocks : { 2048, 4096, 16384 }) {
+		float ms_c, ms_g, ms_both;
+		copy(s1, blocks); gather(s2, blocks); hipDeviceSynchronize();
+		hipEventRecord(e0, s1); for (int k = 0; k < 3; ++k) copy(s1, blocks); hipEventRecord(e1, s1); hipEventSynchronize(e1);
+		hipEventElapsedTime(&ms_c, e0, e1); ms_c /= 3;
+		hipEventRecord(e0, s2); for (int k = 0; k < 3; ++k) gather(s2, blocks); hipEventRecord(e1, s2); hipEventSynchronize(e1);
+		hipEventElapsedTime(&ms_g, e0, e1); ms_g /= 3;
+		hipDeviceSynchronize();
+		hipEventRecord(e0, s1);
+		hipStreamWaitEvent(s2, e0, 0);
+		for (int k = 0; k < 3; ++k) { copy(s1, blocks); gather(s2, blocks); }
+		hipEventRecord(e1, s1); hipEventRecord(e2, s2);
+		hipStreamWaitEvent(s1, e2, 0);
+		hipEventRecord(e1, s1);
+		hipEventSynchronize(e1);
+		hipEventElapsedTime(&ms_both, e0, e1); ms_both /= 3;
+		printf("table %6.2f MB, %5d workgroups each: streams alone %6.3f ms, gathers alone %6.3f ms, both concurrently %6.3f ms (sum %6.3f, max %6.3f)\n",
+		       entries * 12.0 / 1048576.0, blocks, ms_c, ms_g, ms_both, ms_c + ms_g, ms_c > ms_g ? ms_c : ms_g);
+	}
+}
+
 int main(int argc, char **argv)
 {
 	long long n = argc > 1 ? atoll(argv[1]) : 1000000000LL;
@@ -499,6 +540,10 @@ int main(int argc, char **argv)
 				run_sg<0, 1>(e, d, tab, n, 512); run_sg<2, 1>(e, d, tab, n, 2048); run_sg<2, 1>(e, d, tab, n, 1024);
 				run_sg<3, 1>(e, d, tab, n, 65536);
 			}
+			return 0;
+		}
+		if (argv[2][0] == 'x') {
+			for (unsigned int e : { 262144u, 786432u, 1458000u }) run_concurrent(e, d, tab, n);
 			return 0;
 		}
 		if (argv[2][0] == 'p') {

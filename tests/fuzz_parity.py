@@ -6,7 +6,9 @@ construction (GGX, Beckmann, abc, MERL, all sampling: IEEE arithmetic plus glibc
 powf algorithms) must be 100 % bit-exact; paths that call an fp64 trigonometric function (ROCm's libm here,
 glibc's in the reference: UTIA's and sgd's acos / atan2, the spline Fresnel's acos, the fitters' cos / sin / tan)
 may differ in ~1e-9 of the outputs by a last-ulp effect -- those are counted, dumped with their inputs, and must
-stay inside 1e-5.   PYTHONPATH=. python tests/fuzz_parity.py [rounds] [n] [seed]"""
+stay inside 1e-5.   PYTHONPATH=. python tests/fuzz_parity.py [rounds] [n] [seed]
+DJB_FUZZ_CTX=cpu runs the product's HOST path (Context("cpu")) instead: there every libm call is the host's glibc,
+i.e. the reference's own, so EVERY comparison must be bit-exact (no GPU needed)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +19,8 @@ from dj_brdf_amd import djb, synth
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_000_000
 TH = min(64, os.cpu_count() or 1)
-O = oraclelib.oracle(); ctx = djb.default_context(0)
+ON_CPU = os.environ.get("DJB_FUZZ_CTX") == "cpu"
+O = oraclelib.oracle(); ctx = djb.Context("cpu") if ON_CPU else djb.default_context(0)
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 20260928)
 bad = 0
 n_values = n_differ = 0
@@ -30,6 +33,7 @@ def report(tag, got, want, must_be_exact):
     difference between the two shows up in ~1e-9 of the outputs; such values are counted and dumped, and fail
     the run only if they leave the 1e-5 contract or exceed 1e-6 of the comparison."""
     global bad, n_values, n_differ
+    must_be_exact = must_be_exact or ON_CPU
     same = got.view(np.uint32) == want.view(np.uint32)
     both_nan = np.isnan(got) & np.isnan(want)
     ident = same | both_nan

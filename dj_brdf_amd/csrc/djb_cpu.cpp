@@ -114,6 +114,7 @@ djb_status params_for(const djb_params *in, int brdf_kind, Params *p)
 	djb_status st = djbk::resolve_device_params(in, v, brdf_kind);
 	if (st != DJB_OK) return st;
 	p->nx = v[0]; p->ny = v[1]; p->nz = v[2]; p->ax = v[3]; p->ay = v[4]; p->rho = v[5]; p->s = v[6]; p->tx = v[7]; p->ty = v[8];
+	p->r_ax = 0.0; p->r_t2 = 0.0;
 	return DJB_OK;
 }
 

@@ -33,7 +33,10 @@ namespace djbdev {
 struct v3 { float x, y, z; };
 
 // resolved microfacet::params (dj_brdf.h:237-242), filled by the host (djb_host.cpp)
-struct Params { float nx, ny, nz, ax, ay, rho, s, tx, ty; };
+// r_ax, r_t2: doubles 1 / ax and 1 / (ax * ay * s) rounded once (host: 1.0 / double(float)), or 0 = not available
+// (per-pair parameters, host path).  With them the three divisions of mf_p22 by launch-uniform denominators become a
+// conversion, one fp64 multiply and a conversion -- exactly, see fdiv_r.
+struct Params { float nx, ny, nz, ax, ay, rho, s, tx, ty; double r_ax, r_t2; };
 
 struct Fresnel {
 	int kind;
@@ -138,6 +141,25 @@ DJB_DEV float recip_to_f32(double q)
 	return F(r);
 }
 #endif
+// a / b for floats, given R = double(1 / b) to within 2^-52 (or 0: plain division).  float(double(a) * R) is the
+// correctly rounded quotient whenever that quotient is a normal float: a / b is never within 2^-49 (relative) of the
+// midpoint m of two adjacent floats -- a - m b is a non-zero multiple of ulp(m) ulp(b), so |a/b - m| >= |a/b| / (M B)
+// for the integer significands M < 2^25, B < 2^24 -- and never on one (M is odd with 25 bits: M B has more than 24
+// significant bits, it cannot equal a), while the product carries at most 2^-52 + 2^-53 of error.  Sub-normal and
+// NaN quotients (coarser grid: ties exist) take the IEEE sequence.  Verified against a / b on the device for 1e11
+// operand pairs over all exponents (tools/div_probe.hip, profiles/r02/div_probe.txt: 0 mismatches); 2.2 VALU issue
+// slots instead of 8.8.
+DJB_DEV float fdiv_r(float a, float b, double R)
+{
+#if !defined(DJB_HOST_MATH)
+	if (R != 0.0) {
+		float q = F(D(a) * R);
+		if (__builtin_expect(!(fabsf(q) >= 1.17549435e-38f) && a != 0.0f, 0)) q = a / b;
+		return q;
+	}
+#endif
+	return a / b;
+}
 DJB_DEV v3 normalize(v3 v) { return scale(inversesqrt_(dot(v, v)), v); }              // dj_brdf.h:630
 DJB_DEV float intensity(v3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z; } // dj_brdf.h:69
 
@@ -785,12 +807,12 @@ template <int KIND> DJB_DEV float mf_p22(const Brdf &b, float x, float y, const 
 {
 	x -= p.tx; y -= p.ty;
 	float nrm = p.ax * p.ay * p.s;
-	float x_ = x / p.ax;
+	float x_ = fdiv_r(x, p.ax, p.r_ax);
 	float t1 = p.ax * y - p.rho * p.ay * x;
-	float t2 = p.ax * p.ay * p.s;
-	float y_ = t1 / t2;
-	if (KIND == KIND_TABULAR_ANISO) return aniso_p22_std(b, x_, y_) / nrm;
-	return p22_radial<KIND>(b, x_ * x_ + y_ * y_) / nrm;
+	float t2 = p.ax * p.ay * p.s;                    // == nrm: the same expression
+	float y_ = fdiv_r(t1, t2, p.r_t2);
+	if (KIND == KIND_TABULAR_ANISO) return fdiv_r(aniso_p22_std(b, x_, y_), nrm, p.r_t2);
+	return fdiv_r(p22_radial<KIND>(b, x_ * x_ + y_ * y_), nrm, p.r_t2);
 }
 
 template <int KIND> DJB_DEV float mf_ndf(const Brdf &b, v3 h, const Params &p)              // :1559
@@ -1290,6 +1312,7 @@ DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 DJB_DEV Params params_from_pdfparams(float ax, float ay, float rho, float tx, float ty)
 {
 	Params p;
+	p.r_ax = 0.0; p.r_t2 = 0.0;                      // per-pair denominators: a reciprocal per lane costs more than the division
 	p.ax = ax; p.ay = ay; p.rho = rho; p.tx = tx; p.ty = ty;
 	p.s = F(sqrt(1.0 - D(rho * rho)));
 	v3 n = normalize(mk(-tx, -ty, 1.0f));

@@ -183,6 +183,13 @@ djb_status device_params(const djb_params *in, Params *out, int brdf_kind = -1)
 	out->nx = r.n[0]; out->ny = r.n[1]; out->nz = r.n[2];
 	out->ax = r.ax; out->ay = r.ay; out->rho = r.rho; out->s = r.sqrt_one_minus_rho_sqr;
 	out->tx = r.tx_n; out->ty = r.ty_n;
+	// reciprocals of the two launch-uniform denominators of mf_p22 (djb_device.hpp: fdiv_r): correctly rounded doubles
+	// of exactly the floats the kernel divides by (this TU is built with -ffp-contract=off: no FMA in ax * ay * s)
+	const float t2 = out->ax * out->ay * out->s;
+	out->r_ax = 1.0 / (double)out->ax;
+	out->r_t2 = 1.0 / (double)t2;
+	if (!(std::fabs(out->r_ax) <= 1e300)) out->r_ax = 0.0;      // ax == 0 / NaN: leave it to the IEEE division
+	if (!(std::fabs(out->r_t2) <= 1e300)) out->r_t2 = 0.0;
 	return DJB_OK;
 }
 
@@ -1982,6 +1989,7 @@ djb_status resolve_device_params(const djb_params *in, float out9[9], int brdf_k
 	djb_status st = device_params(in, &p, brdf_kind);
 	if (st != DJB_OK) return st;
 	out9[0] = p.nx; out9[1] = p.ny; out9[2] = p.nz; out9[3] = p.ax; out9[4] = p.ay; out9[5] = p.rho; out9[6] = p.s; out9[7] = p.tx; out9[8] = p.ty;
+	// (the host path divides: r_ax / r_t2 stay 0 there)
 	return DJB_OK;
 }
 

@@ -324,10 +324,11 @@ __global__ __launch_bounds__(BLOCK) void k_gen_uni(long long n, uint32_t seed, u
 // exact double sequences they stand in for, on hash-generated inputs across the exponent range.
 // counters: [0] inversesqrt mismatches, [1] reciprocal mismatches (both must be 0),
 //           [2] inversesqrt exact-path fallbacks, [3] reciprocal fallbacks,
-//           [4] sRGB-decode (pow 2.4) mismatches (must be 0), [5] sRGB-decode fallbacks, [6..7] 0.
+//           [4] sRGB-decode (pow 2.4) mismatches (must be 0), [5] sRGB-decode fallbacks,
+//           [6] fdiv_r(a, b, 1/b) != a / b (must be 0), [7] its IEEE fallbacks (sub-normal quotients).
 __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t seed, unsigned long long *counters)
 {
-	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0, bad_p = 0, fb_p = 0;
+	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0, bad_p = 0, fb_p = 0, bad_q = 0, fb_q = 0;
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		uint32_t h0 = hash_u32(seed, (uint64_t)k, 0), h1 = hash_u32(seed, (uint64_t)k, 1), h2 = hash_u32(seed, (uint64_t)k, 2);
@@ -354,10 +355,23 @@ __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t 
 			if (!ok) ++fb_p;
 			if (srgb_decode(v) != srgb_decode_exact(v)) ++bad_p;
 		}
+		// exact division through a double reciprocal (fdiv_r): numerator x, denominator from a second hash draw
+		// (any exponent, edge mantissas every 8th), R as the host computes it
+		{
+			uint32_t h3 = hash_u32(seed, (uint64_t)k, 3);
+			uint32_t mb = (h3 & 7u) == 1u ? 0u : (h3 & 7u) == 2u ? 0x7fffffu : (h3 >> 9);
+			float bden = __uint_as_float(((h3 >> 8 & 1u) << 31) | ((1u + (h2 >> 8) % 253u) << 23) | mb);
+			float a_num = (k & 1) ? x : __uint_as_float(h0 ^ (h1 << 5));
+			float want = a_num / bden, got = fdiv_r(a_num, bden, 1.0 / D(bden));
+			if (!(got == want || (got != got && want != want))) ++bad_q;
+			float q0 = F(D(a_num) * (1.0 / D(bden)));
+			if (!(fabsf(q0) >= 1.17549435e-38f) && a_num != 0.0f) ++fb_q;
+		}
 	}
 	atomicAdd(&counters[0], bad_r); atomicAdd(&counters[1], bad_d);
 	atomicAdd(&counters[2], fb_r); atomicAdd(&counters[3], fb_d);
 	atomicAdd(&counters[4], bad_p); atomicAdd(&counters[5], fb_p);
+	atomicAdd(&counters[6], bad_q); atomicAdd(&counters[7], fb_q);
 }
 
 // bins x bins histogram over [-1,1]^2: LDS atomics, one global flush per workgroup

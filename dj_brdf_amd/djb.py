@@ -1040,7 +1040,7 @@ def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):
     c = (C.c_ulonglong * 8)()
     _lib.check(_lib.load().djb_selftest_guarded_math(ctx._h, C.c_int64(n), C.c_uint32(seed), c))
     return {"rsqrt_mismatch": c[0], "recip_mismatch": c[1], "rsqrt_fallback": c[2], "recip_fallback": c[3],
-            "srgb_mismatch": c[4], "srgb_fallback": c[5]}
+            "srgb_mismatch": c[4], "srgb_fallback": c[5], "fdiv_mismatch": c[6], "fdiv_fallback": c[7]}
 
 
 def selftest_libm(fn: str, x, y=None, ctx: Optional[Context] = None):

@@ -278,7 +278,8 @@ djb_status djb_merl_guard_stats(djb_ctx *, int64_t n, const djb_vec3_view *i, co
 /* self-test of the kernels' guarded fp64 shortcuts (float(1/sqrt(double x)), float(1/q), the sRGB
  * decode float(pow(t, 2.4f))) against the exact double sequences on n hash-generated inputs:
  * counters[8] = {rsqrt mismatches, reciprocal mismatches, rsqrt exact-path fallbacks, reciprocal
- * fallbacks, sRGB-decode mismatches, sRGB-decode fallbacks, 0, 0}; every mismatch count must be 0. */
+ * fallbacks, sRGB-decode mismatches, sRGB-decode fallbacks, mismatches of the exact division through a double
+ * reciprocal (float(double(a) * R) vs a / b), its IEEE fallbacks}; every mismatch count must be 0. */
 djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters8);
 /* the kernels' restatements of the host libm functions the reference calls (glibc 2.35: double exp / pow,
  * float logf / expf / powf -- dj_brdf.h:685, 695, 1868, 1917, 1935, 3419, 3431, 3612), evaluated on the GPU for

@@ -339,6 +339,8 @@ def test_guarded_fp64_shortcuts_are_exact(gpu_ctx):
     # bit; inputs that land near an fp32 rounding boundary take the exact sequence (fallbacks > 0)
     r = djb.selftest_guarded_math(2_000_000_000, seed=20260928, ctx=gpu_ctx)
     assert r["rsqrt_mismatch"] == 0 and r["recip_mismatch"] == 0 and r["srgb_mismatch"] == 0
+    # a / b through a double reciprocal (djb_device.hpp fdiv_r; the divisions of mf_p22 by launch-uniform denominators)
+    assert r["fdiv_mismatch"] == 0 and r["fdiv_fallback"] > 0
     assert 0 < r["srgb_fallback"] < 2_000_000_000 * 1e-4
     assert 0 < r["rsqrt_fallback"] < 2_000_000_000 * 1e-4
     assert 0 < r["recip_fallback"] < 2_000_000_000 * 1e-4

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdjb_hip.so")
+# DJB_LIB_PATH: an alternative build of the same library (kernel-tuning experiments: tools/variants.sh)
+LIB_PATH = os.environ.get("DJB_LIB_PATH") or os.path.join(_HERE, "lib", "libdjb_hip.so")
 
 DJB_OK = 0
 STATUS_NAMES = {

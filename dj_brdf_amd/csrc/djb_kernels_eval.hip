@@ -54,9 +54,13 @@ inline bool dense(const View &v) { return v.stride == 1 || v.x == nullptr; }
 // tabulated microfacet kernels fit 128 VGPRs (4); utia 3.34 / 2.93 / 10.5 and sgd 4.46 / 4.17 / 8.3 want 4
 // (left alone they take 172 VGPRs = 2 waves, too few to hide the table gathers; at 8 they spill);
 // abc 1.58 / 1.34 / 1.30 is light enough for 8; the operation-by-operation merl kernel stays unconstrained.
+#ifndef DJB_UTIA_MIN_WAVES
+#define DJB_UTIA_MIN_WAVES 4
+#endif
 constexpr int eval_min_waves(int kind)
 {
-	return (kind <= KIND_TABULAR || kind == KIND_TABULAR_ANISO || kind == KIND_UTIA || kind == KIND_SGD) ? 4
+	return kind == KIND_UTIA ? DJB_UTIA_MIN_WAVES
+	     : (kind <= KIND_TABULAR || kind == KIND_TABULAR_ANISO || kind == KIND_SGD) ? 4
 	     : kind == KIND_ABC ? 8 : 1;
 }
 template <int KIND, int WANT, int FRK, bool DENSE>

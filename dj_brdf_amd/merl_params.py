@@ -2,7 +2,8 @@
 
     python -m dj_brdf_amd.merl_params [-o params.txt] [--gpus N] a.binary b.binary ...
 
-fits Beckmann / GGX roughness to every MERL file with the HIP power-iteration kernel and writes
+fits Beckmann / GGX roughness to every MERL file with the HIP power-iteration kernel (``--cpu``, or a machine
+without a HIP device: the library's host path) and writes
 the same ``params.txt`` ("# MERL Beckmann GGX" then ``name %.3f %.3f`` per file, input order).
 Per GPU the work is the native pipeline of ``djb_fit_merl_files`` (reader threads -> pinned ring ->
 async upload + conversion kernel -> one fit launch).  Materials are independent: with several GPUs
@@ -58,11 +59,16 @@ def fit_files_on(ctx: djb.Context, paths, res=90, shadow=True, reader_threads=0)
     return ab, ag, {"total_s": timing[0], "load_s": timing[1], "fit_s": timing[2], "bytes": timing[3]}
 
 
-def fit_files(paths, res=90, shadow=True, gpus=None, return_timing=False):
-    """[(alpha_beckmann, alpha_ggx)] for every path, in input order, over `gpus` GPUs."""
+def fit_files(paths, res=90, shadow=True, gpus=None, return_timing=False, cpu=False):
+    """[(alpha_beckmann, alpha_ggx)] for every path, in input order, over `gpus` GPUs -- or, with cpu=True / on a
+    machine without a HIP device, on the library's host path (one CPU context, the files spread over its threads):
+    the reference's example driver runs without a GPU too (BASELINE configs[0])."""
     n_dev = djb.device_count()
-    if n_dev == 0:
-        raise djb.exc(7, "djb_error: no HIP device; dj_brdf_amd has no CPU path")
+    if cpu or n_dev == 0:
+        t0 = time.perf_counter()
+        ab, ag, timing = fit_files_on(djb.Context("cpu"), list(paths), res, shadow)
+        out = [(float(a), float(g)) for a, g in zip(ab, ag)]
+        return (out, {"wall_s": time.perf_counter() - t0, "per_gpu": [timing], "gpus": 0}) if return_timing else out
     gpus = min(gpus or n_dev, n_dev, max(len(paths), 1))
     out = [None] * len(paths)
     errors, timings = [], [None] * gpus
@@ -104,13 +110,14 @@ def main(argv=None):
     ap.add_argument("files", nargs="*")
     ap.add_argument("-o", "--output", default="params.txt")
     ap.add_argument("--gpus", type=int, default=None)
+    ap.add_argument("--cpu", action="store_true", help="run on the library's host path (default when no HIP device is present)")
     ap.add_argument("--res", type=int, default=90)
     ap.add_argument("--timing", action="store_true", help="print the pipeline timing to stderr")
     args = ap.parse_args(argv)
     if not args.files:
         ap.print_usage()
         return 0
-    alphas, timing = fit_files(args.files, res=args.res, gpus=args.gpus, return_timing=True)
+    alphas, timing = fit_files(args.files, res=args.res, gpus=args.gpus, return_timing=True, cpu=args.cpu)
     with open(args.output, "w") as f:
         f.write(format_params_txt(args.files, alphas))
     if args.timing:

@@ -137,7 +137,7 @@ def test_anisotropic_fit_golden(cpu, name):
 
 def test_anisotropic_short_rows_and_utia_source(cpu, oracle, tmp_path):
     g = np.load(os.path.join(G, "aniso_big.npz"))
-    for name in ("a_short", "a_utia_small"):
+    for name in ("a_short", "a_utia_small", "a90_utia"):      # the last: the reference's own 90 x 90 size (7.7 s and a 513 MB matrix there; 0.6 s here)
         src, elev, azim, shadow = ANISO_BIG_CASES[name]
         L = type("L", (), {"merl": type("M", (), {"from_table": staticmethod(lambda t: djb.merl.from_table(t, ctx=cpu))}),
                            "utia": type("U", (), {"from_table": staticmethod(lambda t: djb.utia.from_table(t, ctx=cpu))})})
@@ -162,6 +162,10 @@ def test_params_txt_on_the_cpu(cpu, tmp_path):
     txt = merl_params.format_params_txt(files, list(zip(ab.tolist(), ag.tolist())))
     assert txt.encode() == open(os.path.join(G, "params_expected.txt"), "rb").read()
     assert 0 < timing["bytes"] < 3 * 6000 * 24          # only the entries the fit reads are fetched from the files
+    # the Python CLI, as a user without a GPU would run it
+    out = str(tmp_path / "params_cli.txt")
+    assert merl_params.main(["--cpu", "-o", out] + files) == 0
+    assert open(out, "rb").read() == open(os.path.join(G, "params_expected.txt"), "rb").read()
     # batch entry points agree with the one-object path
     mats = [djb.merl(f, ctx=cpu) for f in files]
     ab2, ag2 = djb.fit_brdf_batch(mats, 90, True, ctx=cpu)

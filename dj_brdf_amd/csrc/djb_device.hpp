@@ -1095,9 +1095,13 @@ DJB_DEV int fit_merl_slot_index(int s, int res)
 // If an estimate lies inside the guard band of a bin boundary -- or in the regions where the
 // reference snaps angles (|z| > 0.99999, dj_brdf.h:652-656) -- the pair is AMBIGUOUS and is
 // handed to tier 2, the operation-by-operation fp64 path (merl_index).  Outside the bands both
-// paths provably land in the same bin, so the composite is bit-exact while ~99.7 % of the pairs
-// never touch fp64.  Band constants: MERL_GUARD_* below, calibrated with k_merl_guard_stats
-// (max observed |delta| / band, reported by djb_merl_guard_stats and tests) -- see DESIGN.md 4.2.
+// paths land in the same bin AS LONG AS the band really bounds |estimate - reference|, so the composite is
+// bit-exact while ~99.7 % of the pairs never touch fp64.  That bound is an error model (first-order
+// propagation of the float roundings) with constants fixed by measurement, not a proof: k_merl_guard_stats
+// reports max |estimate - reference| / band, and tests/test_gpu_verification.py asserts it stays below 0.5
+// (observed <= 0.25: a 4x margin) with 0 index mismatches on the bench distribution and on eleven adversarial
+// input families (bin-edge hugging in all three coordinates, poles, grazing, full sphere, un-normalised),
+// 2.4e8 pairs per run; the composite is also compared with the exact kernel over 1e9 pairs -- DESIGN.md 4.2.
 struct MerlGuard { float a_h, b_h, a_d, b_d, c_d; };   // multiples of 2^-24
 #define MERL_GUARD_DEFAULT { 12.0f, 12.0f, 12.0f, 12.0f, 12.0f }
 

@@ -472,6 +472,7 @@ void build_twin(const djb_brdf *b)
 		break;
 	}
 	case DJB_KIND_MERL: {
+		if (b->dev.merl_sparse) break;            // per-slot texels of the file pipeline: internal, never evaluated
 		std::vector<char> host;
 		if (download(host, b->dev.merl, sizeof(djbdev::MerlTexel) * (size_t)MERL_N))
 			st = djbcpu::create_merl_from_texels(tc, (const float *)host.data(), &t);

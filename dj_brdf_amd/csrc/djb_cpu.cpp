@@ -221,14 +221,14 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 	const float dtheta_k = F(sqrt(DJB_PI * 0.5) / D((float)cnt));
 	const float dphi_h = F(DJB_PI / 180.0);
 	std::vector<float> cphi; cphi.reserve(MAX_PHI_STEPS);
-	for (float phi = 0.0f; D(phi) < 2.0 * DJB_PI && (int)cphi.size() < MAX_PHI_STEPS; phi += dphi_h) cphi.push_back(F(cos(D(phi))));   // 361 float-stepped values
+	for (float phi = 0.0f; D(phi) < 2.0 * DJB_PI && (int)cphi.size() < MAX_PHI_STEPS; phi += dphi_h) cphi.push_back(cos_f(phi));   // 361 float-stepped values
 	const int nphi = (int)cphi.size();
 	std::vector<float> theta(cnt), cosv(cnt), tanv(cnt), kji(cnt);
 	std::vector<double> v0(cnt, 1.0), v1(cnt, 0.0), kmT((size_t)cnt * cnt);
 	for (int k = 0; k < cnt; ++k) {
 		float th = fit_backscatter_theta(k, cnt);
 		float th2 = th * th;
-		float c = F(cos(D(th2))), t = F(tan(D(th2)));
+		float c = cos_f(th2), t = tan_f(th2);
 		theta[k] = th; cosv[k] = c; tanv[k] = t;
 		v3 w = from_angles(th2, 0.0f);
 		float fr_i = intensity(src_eval(src, std_p, w, w, k));
@@ -259,7 +259,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 		for (int k = 0; k < NTHETA_FIT; ++k) {
 			float u = (float)k / (float)NTHETA_FIT;
 			float th = F(D(u * u) * DJB_PI * 0.5);
-			float r = F(tan(D(th))), c = F(cos(D(th)));
+			float r = tan_f(th), c = cos_f(th);
 			float pr = p22_radial<KIND_TABULAR>(self, r * r);
 			nint += (u * pr * r) / (c * c);
 		}
@@ -276,7 +276,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 		for (int k = 0; k < NTHETA_SIGMA; ++k) {
 			float u = (float)k / (float)NTHETA_SIGMA;
 			float th = F(D(u * u) * DJB_PI * 0.5);
-			ui[k] = u; sh[k] = F(sin(D(th))); cthd[k] = cos(D(th));
+			ui[k] = u; sh[k] = sin_f(th); cthd[k] = cos(D(th));
 		}
 		for (int e = 0; e < NNODE; ++e) {
 			int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
@@ -290,7 +290,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 		for (int k = 0; k < cnt; ++k) {
 			float tmp = (float)k / (float)cnt;
 			float theta_k = F(D(tmp) * 0.5 * DJB_PI);
-			const float ck = F(cos(D(theta_k))), sk = F(sin(D(theta_k)));
+			const float ck = cos_f(theta_k), sk = sin_f(theta_k);
 			float nint = 0.0f;
 			for (int e = 0; e < NNODE; ++e) {
 				const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
@@ -330,7 +330,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 		for (int k = 0; k < cnt; ++k) {
 			float u = (float)k / (float)cnt;
 			float th = F(D(u * u) * DJB_PI * 0.5);
-			float c = F(cos(D(th))), r = F(tan(D(th)));
+			float c = cos_f(th), r = tan_f(th);
 			float pr = p22_radial<KIND_TABULAR>(self, r * r);
 			nint += (u * r * pr) / (c * c);
 			cdf[k] = F(D(nint * dth) * (2.0 * DJB_PI));
@@ -348,7 +348,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 			for (; j < qres; ++j) {
 				float u = (float)j / (float)qres;
 				float th = F(D(u) * DJB_PI * 0.5);
-				if (tab_cdf_radial(self, F(tan(D(th)))) >= c) { qf[nq++] = u; break; }
+				if (tab_cdf_radial(self, tan_f(th)) >= c) { qf[nq++] = u; break; }
 			}
 		}
 		qf[nq++] = 1.0f;
@@ -362,7 +362,7 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 		for (int k = 0; k < NTHETA_FIT; ++k) {
 			float u = (float)k / (float)NTHETA_FIT;
 			float th = F(D(u * u) * DJB_PI * 0.5);
-			float c = F(cos(D(th))), r = F(tan(D(th)));
+			float c = cos_f(th), r = tan_f(th);
 			float r2 = r * r;
 			float pr = p22_radial<KIND_TABULAR>(self, r2);
 			nb += (u * r2 * r * pr) / (c * c);
@@ -928,6 +928,29 @@ djb_status histogram_xy(djb_ctx *, int64_t n, const djb_vec3_view *v, int bins, 
 		++counts[by * bins + bx];
 	}
 	return DJB_OK;
+}
+
+unsigned long long trig_sweep_compare(int fn, uint32_t first_bits, int64_t count, const float *dev, int threads,
+                                      uint32_t *bad3, int cap)
+{
+	CpuCtx pool;
+	pool.threads = threads >= 1 ? threads : (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+	std::mutex mu;
+	unsigned long long n_bad = 0;
+	parallel_for(&pool, count, 1 << 16, [&](long long k0, long long k1) {
+		for (long long k = k0; k < k1; ++k) {
+			uint32_t xb = first_bits + (uint32_t)k, hb, db;
+			float x, h = 0.0f;
+			memcpy(&x, &xb, 4);
+			h = trig_site(fn, x);
+			memcpy(&hb, &h, 4); memcpy(&db, &dev[k], 4);
+			if (hb == db || (h != h && dev[k] != dev[k])) continue;
+			std::lock_guard<std::mutex> g(mu);
+			if (n_bad < (unsigned long long)cap && bad3) { bad3[3 * n_bad] = xb; bad3[3 * n_bad + 1] = db; bad3[3 * n_bad + 2] = hb; }
+			++n_bad;
+		}
+	});
+	return n_bad;
 }
 
 } // namespace djbcpu

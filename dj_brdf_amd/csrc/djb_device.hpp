@@ -85,6 +85,41 @@ DJB_DEV float fmin_(float a, float b) { return a < b ? a : b; }   // djb::min, d
 DJB_DEV float fmax_(float a, float b) { return a > b ? a : b; }   // djb::max, dj_brdf.h:575
 DJB_DEV float sat_(float x) { return fmin_(1.0f, fmax_(0.0f, x)); }
 
+// ------------------------------------------------------------------ float -> float sites of the fp64 trig family
+// Every place where the path rounds a double libm trig result of ONE float argument straight to float goes through
+// one of these, so that each is a float -> float map with 2^32 inputs: tools/exhaustive_trig.py sweeps all of them on
+// the device against the host's glibc (djb_selftest_trig_sweep).  The two-argument atan2 sites and the sites that keep
+// the double (cos(phi) * sin(theta) products, sgd/abc) are not of this shape and stay "observed" (DESIGN section 2).
+enum { TRIG_COS = 0, TRIG_SIN, TRIG_TAN, TRIG_ACOS, TRIG_ACOS_U, TRIG_ACOS_U32, TRIG_ATAN_SQU, TRIG_ATAN_U,
+       TRIG_ATAN_SQRT, TRIG_BECK_QF, TRIG_ACOS_DEG, TRIG_SITES };
+DJB_DEV float cos_f(float x) { return F(cos(D(x))); }
+DJB_DEV float sin_f(float x) { return F(sin(D(x))); }
+DJB_DEV float tan_f(float x) { return F(tan(D(x))); }
+DJB_DEV float acos_f(float x) { return F(acos(D(x))); }
+DJB_DEV float acos_u_f(float c) { return F(2.0 * acos(D(c)) / DJB_PI); }                    // dj_brdf.h:1341 (spline fresnel)
+DJB_DEV float acos_u32_f(float c) { return F(D(2.0f) * acos(D(c)) / D(F(DJB_PI))); }       // dj_brdf.h:2158 (tabular sigma)
+DJB_DEV float atan_squ_f(float r) { return F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI)))); }  // dj_brdf.h:2152 (tabular p22)
+DJB_DEV float atan_u_f(float r) { return F(atan(D(r)) * D(2.0f) / D(F(DJB_PI))); }          // dj_brdf.h:2165 (tabular cdf)
+DJB_DEV float atan_sqrt_f(float x) { return F(atan(sqrt(D(x)))); }                          // dj_brdf.h:2285 (aniso p22)
+DJB_DEV float beck_qf_f(float u) { return F(sqrt(-log(1.0 - D(u)))); }                      // dj_brdf.h:1887 (beckmann qf)
+DJB_DEV float acos_deg_f(float z) { return F(D(F(180.0 / DJB_PI)) * acos(D(z))); }          // dj_brdf.h:1633 (utia)
+DJB_DEV float trig_site(int fn, float x)
+{
+	switch (fn) {
+	case TRIG_COS: return cos_f(x);
+	case TRIG_SIN: return sin_f(x);
+	case TRIG_TAN: return tan_f(x);
+	case TRIG_ACOS: return acos_f(x);
+	case TRIG_ACOS_U: return acos_u_f(x);
+	case TRIG_ACOS_U32: return acos_u32_f(x);
+	case TRIG_ATAN_SQU: return atan_squ_f(x);
+	case TRIG_ATAN_U: return atan_u_f(x);
+	case TRIG_ATAN_SQRT: return atan_sqrt_f(x);
+	case TRIG_BECK_QF: return beck_qf_f(x);
+	default: return acos_deg_f(x);
+	}
+}
+
 DJB_DEV v3 mk(float x, float y, float z) { v3 v; v.x = x; v.y = y; v.z = z; return v; }
 DJB_DEV v3 add(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 DJB_DEV v3 sub(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -166,8 +201,8 @@ DJB_DEV float intensity(v3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f *
 // vec3(theta, phi), dj_brdf.h:589-595
 DJB_DEV v3 from_angles(float theta, float phi)
 {
-	float s = F(sin(D(theta)));
-	return mk(F(D(s) * cos(D(phi))), F(D(s) * sin(D(phi))), F(cos(D(theta))));
+	float s = sin_f(theta);
+	return mk(F(D(s) * cos(D(phi))), F(D(s) * sin(D(phi))), cos_f(theta));
 }
 
 // dj_brdf.h:650-661
@@ -175,7 +210,7 @@ DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 {
 	if (D(p.z) > 0.99999) { theta = 0.0f; phi = 0.0f; }
 	else if (D(p.z) < -0.99999) { theta = F(DJB_PI); phi = 0.0f; }
-	else { theta = F(acos(D(p.z))); phi = F(atan2(D(p.y), D(p.x))); }
+	else { theta = acos_f(p.z); phi = F(atan2(D(p.y), D(p.x))); }
 }
 
 typedef unsigned int LdsTab;   // where a device kernel staged a libm table (0 = the global copy); unused on the host
@@ -517,7 +552,7 @@ DJB_DEV void uniform_to_concentric(float u1, float u2, float &x, float &y)
 // (finite inputs), so only the surviving terms are evaluated.
 DJB_DEV v3 rotate_z(v3 x, float angle)
 {
-	float c = F(cos(D(angle))), s = F(sin(D(angle)));
+	float c = cos_f(angle), s = sin_f(angle);
 	float t2 = F(D(x.z) * (1.0 - D(c)));
 	// out = c*x; out += axis*t2 (adds 0 to x,y; t2 to z); out += s*cross
 	return mk((c * x.x + 0.0f * t2) + s * (0.0f * x.z - x.y),
@@ -526,7 +561,7 @@ DJB_DEV v3 rotate_z(v3 x, float angle)
 }
 DJB_DEV v3 rotate_y(v3 x, float angle)
 {
-	float c = F(cos(D(angle))), s = F(sin(D(angle)));
+	float c = cos_f(angle), s = sin_f(angle);
 	float t2 = F(D(x.y) * (1.0 - D(c)));
 	return mk((c * x.x + 0.0f * t2) + s * (x.z - 0.0f * x.y),
 	          (c * x.y + t2) + s * (0.0f * x.x - 0.0f * x.z),
@@ -608,7 +643,7 @@ DJB_DEV v3 fresnel_eval(const Fresnel &f, float c)
 		return add(sub(f0, scale(c, f1)), scale(pw, sub(mk(1, 1, 1), f0)));
 	}
 	case FR_SPLINE: {    // dj_brdf.h:1338-1344
-		float u = F(2.0 * acos(D(c)) / DJB_PI);
+		float u = acos_u_f(c);
 		return spline_v3(f.pts, f.npts, u);
 	}
 	default: return mk(1, 1, 1);
@@ -621,7 +656,7 @@ template <int KIND> DJB_DEV float p22_radial(const Brdf &b, float r_sqr)
 	if (KIND == KIND_BECKMANN) return F(glibc_exp(D(-r_sqr), b.exp_lds) / DJB_PI);                      // :1866
 	if (KIND == KIND_GGX) { float t = 1.0f + r_sqr; /* == float(1.0 + double(r_sqr)) */ return recip_to_f32(DJB_PI * D(t) * D(t)); } // :2056
 	float r = sqrtf(r_sqr);                                                             // :2151
-	float u = F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI))));
+	float u = atan_squ_f(r);
 	return spline_f(b.p22, b.n_p22, u);
 }
 
@@ -636,20 +671,20 @@ template <int KIND> DJB_DEV float sigma_std_radial(const Brdf &b, float c)
 		return F((D(c) * (1.0 + D(erf_given_exp(nu, e))) + D(s * tmp)) / 2.0);
 	}
 	if (KIND == KIND_GGX) return (1.0f + c) * 0.5f; /* == float((1.0 + double(c)) / 2.0) */                                // :2062
-	float u = F(D(2.0f) * acos(D(c)) / D(F(DJB_PI)));                                   // :2158
+	float u = acos_u32_f(c);                                   // :2158
 	return spline_f(b.sigma, b.n_sigma, u);
 }
 
 DJB_DEV float tab_cdf_radial(const Brdf &b, float r)                                   // :2164
 {
-	float u = F(atan(D(r)) * D(2.0f) / D(F(DJB_PI)));
+	float u = atan_u_f(r);
 	if (u < 0.0f) u = 0.0f;
 	return spline_f(b.cdf, b.n_cdf, sqrtf(u));
 }
 DJB_DEV float tab_qf_radial(const Brdf &b, float u)                                    // :2171
 {
 	float qf = spline_f(b.qf, b.n_qf, u);
-	return F(tan(D(qf * F(DJB_PI) / 2.0f)));
+	return tan_f(qf * F(DJB_PI) / 2.0f);
 }
 
 // ------------------------------------------------------------------ tabular_anisotropic fetches
@@ -682,11 +717,11 @@ DJB_DEV float aniso_grid(const Brdf &b, const float *tab, float theta, float phi
 DJB_DEV float aniso_p22_theta_phi(const Brdf &b, float theta, float phi) { return aniso_grid(b, b.p22, theta, phi); }
 DJB_DEV float aniso_p22_std(const Brdf &b, float x, float y)                           // :2178
 {
-	return aniso_p22_theta_phi(b, F(atan(sqrt(D(x * x + y * y)))), F(atan2(D(-y), D(-x))));
+	return aniso_p22_theta_phi(b, atan_sqrt_f(x * x + y * y), F(atan2(D(-y), D(-x))));
 }
 DJB_DEV float aniso_sigma_std(const Brdf &b, v3 k)                                     // :2198
 {
-	return aniso_grid(b, b.sigma, F(acos(D(k.z))), F(atan2(D(k.y), D(k.x))));
+	return aniso_grid(b, b.sigma, acos_f(k.z), F(atan2(D(k.y), D(k.x))));
 }
 DJB_DEV float aniso_pdf1(const Brdf &b, float phi) { return spline_rep(b.a_pdf1, b.azim, F(D(phi) * 0.5 / DJB_PI)); }       // :2768
 DJB_DEV float aniso_cdf1(const Brdf &b, float phi) { return spline_rep(b.a_cdf1, b.n_a_cdf1, F(D(phi) * 0.5 / DJB_PI)); }
@@ -715,7 +750,7 @@ template <int KIND> DJB_DEV float cdf_radial(const Brdf &b, float r)
 }
 template <int KIND> DJB_DEV float qf_radial(const Brdf &b, float u)
 {
-	if (KIND == KIND_BECKMANN) return F(sqrt(-log(1.0 - D(u))));
+	if (KIND == KIND_BECKMANN) return beck_qf_f(u);
 	if (KIND == KIND_GGX) return F(sqrt(D(u) / (1.0 - D(u))));
 	return tab_qf_radial(b, u);
 }
@@ -868,7 +903,7 @@ template <int FRK> DJB_DEV v3 fresnel_eval_k(const Fresnel &f, float c)
 	}
 	if (FRK == FR_UNPOLARIZED) return mk(unpolarized1(c, f.a[0]), unpolarized1(c, f.a[1]), unpolarized1(c, f.a[2]));
 	if (FRK == FR_SPLINE) {                              // dj_brdf.h:1338-1344: what every fitted (tabular) lobe carries
-		float u = F(2.0 * acos(D(c)) / DJB_PI);
+		float u = acos_u_f(c);
 		return spline_v3(f.pts, f.npts, u);
 	}
 	return fresnel_eval(f, c);
@@ -925,7 +960,7 @@ DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &
 	} else if (KIND == KIND_TABULAR_ANISO) {                                                    // :2828
 		float phi = aniso_qf1(b, u1);
 		float theta = aniso_qf2(b, u2, phi);
-		float tan_theta = F(tan(D(theta)));
+		float tan_theta = tan_f(theta);
 		xs = F(D(-tan_theta) * cos(D(phi)));
 		ys = F(D(-tan_theta) * sin(D(phi)));
 	} else {
@@ -1246,7 +1281,7 @@ DJB_DEV float srgb_decode(float v)
 DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 {
 	float r2d = F(180.0 / DJB_PI);
-	float theta_i = F(D(r2d) * acos(D(i.z))), theta_o = F(D(r2d) * acos(D(o.z)));
+	float theta_i = acos_deg_f(i.z), theta_o = acos_deg_f(o.z);
 	float phi_i = F(D(r2d) * atan2(D(i.y), D(i.x))), phi_o = F(D(r2d) * atan2(D(o.y), D(o.x)));
 	if (D(theta_i) >= 90.0 || D(theta_o) >= 90.0) return mk(0, 0, 0);
 	if (!(phi_i == phi_i) || !(phi_o == phi_o)) return mk(0, 0, 0);   // NaN guard: reference would spin

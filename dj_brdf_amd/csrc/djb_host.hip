@@ -1966,6 +1966,32 @@ try {
 }
 DJB_ABI_CATCH
 
+djb_status djb_selftest_trig_sweep(djb_ctx *ctx, int fn, uint32_t first_bits, int64_t count, int threads,
+                                   unsigned long long *n_bad, uint32_t *bad3, int cap)
+try {
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
+	djb_status st = check_call(ctx, nullptr, count, DJB_MEM_HOST);
+	if (st != DJB_OK) return st;
+	if (fn < 0 || fn >= DJB_TRIG_SITES || !n_bad || cap < 0 || (cap > 0 && !bad3) || count > ((int64_t)1 << 32) - (int64_t)first_bits)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid selftest arguments");
+	*n_bad = 0;
+	if (count == 0) return DJB_OK;
+	std::vector<float> host((size_t)count);
+	{
+		std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+		float *d = nullptr;
+		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * (size_t)count));
+		hipError_t e = djbk::launch_trig_sweep(ctx->stream, fn, first_bits, count, d);
+		if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		(void)hipFree(d);
+		if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));
+	}
+	*n_bad = djbcpu::trig_sweep_compare(fn, first_bits, count, host.data(), threads, bad3, cap);
+	return DJB_OK;
+}
+DJB_ABI_CATCH
+
 djb_status djb_histogram_xy(djb_ctx *ctx, int64_t n, const djb_vec3_view *v, int bins, unsigned long long *counts)
 try {
 	if (is_cpu(ctx)) return djbcpu::histogram_xy(ctx, n, v, bins, counts);

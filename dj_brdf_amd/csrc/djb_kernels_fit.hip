@@ -132,7 +132,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int k = tid; k < cnt; k += FIT_BLOCK) {
 		float th = fit_backscatter_theta(k, cnt);
 		float th2 = th * th;
-		float c = F(cos(D(th2))), t = F(tan(D(th2)));
+		float c = cos_f(th2), t = tan_f(th2);
 		theta[k] = th; cosv[k] = c; tanv[k] = t;
 		v3 w = from_angles(th2, 0.0f);
 		float fr_i = intensity(src_eval<SRC>(src, std_p, w, w, k));
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	}
 	__syncthreads();
 	const int nphi = s_nphi;
-	for (int k = tid; k < nphi; k += FIT_BLOCK) cphi[k] = F(cos(D(cphi[k])));
+	for (int k = tid; k < nphi; k += FIT_BLOCK) cphi[k] = cos_f(cphi[k]);
 	__syncthreads();
 	for (int e = tid; e < cnt * cnt; e += FIT_BLOCK) {
 		int io = e / cnt, jh = e - io * cnt;          // io: theta_o index, jh: theta_h index
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int k = tid; k < NTHETA_FIT; k += FIT_BLOCK) {
 		float u = (float)k / (float)NTHETA_FIT;
 		float th = F(D(u * u) * DJB_PI * 0.5);
-		float r = F(tan(D(th))), c = F(cos(D(th)));
+		float r = tan_f(th), c = cos_f(th);
 		float pr = p22_radial<KIND_TABULAR>(self, r * r);
 		terms[k] = (u * pr * r) / (c * c);
 	}
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int k = tid; k < NTHETA_SIGMA; k += FIT_BLOCK) {
 		float u = (float)k / (float)NTHETA_SIGMA;
 		float th = F(D(u * u) * DJB_PI * 0.5);
-		ui[k] = u; sh[k] = F(sin(D(th))); cthd[k] = cos(D(th));
+		ui[k] = u; sh[k] = sin_f(th); cthd[k] = cos(D(th));
 	}
 	for (int e = tid; e < NNODE_SIGMA; e += FIT_BLOCK) {   // ndf(vec3(theta_h, phi_h)): theta_k-independent
 		int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		for (int k = tid; k < cnt; k += FIT_BLOCK) {
 			float tmp = (float)k / (float)cnt;
 			float theta_k = F(D(tmp) * 0.5 * DJB_PI);
-			ckv[k] = F(cos(D(theta_k))); skv[k] = F(sin(D(theta_k)));
+			ckv[k] = cos_f(theta_k); skv[k] = sin_f(theta_k);
 		}
 		const int T = sig_tile(cnt), TS = T + 4;             // row stride: 16-byte aligned rows for the owners' float4 reads
 		const int n_sum = ((cnt + 63) / 64) * 64;            // threads [0, n_sum): row owners (whole waves)
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int k = tid; k < cnt; k += FIT_BLOCK) {
 		float u = (float)k / (float)cnt;
 		float th = F(D(u * u) * DJB_PI * 0.5);
-		float c = F(cos(D(th))), r = F(tan(D(th)));
+		float c = cos_f(th), r = tan_f(th);
 		float pr = p22_radial<KIND_TABULAR>(self, r * r);
 		qprobe[k] = (u * r * pr) / (c * c);       // staging (qprobe has 8*cnt slots)
 	}
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int j = tid; j < qres; j += FIT_BLOCK) {
 		float u = (float)j / (float)qres;
 		float th = F(D(u) * DJB_PI * 0.5);
-		qprobe[j] = tab_cdf_radial(self, F(tan(D(th))));
+		qprobe[j] = tab_cdf_radial(self, tan_f(th));
 	}
 	__syncthreads();
 	if (tid == 0) {   // forward scan; j persists across i (dj_brdf.h:2735)
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int k = tid; k < NTHETA_FIT; k += FIT_BLOCK) {
 		float u = (float)k / (float)NTHETA_FIT;
 		float th = F(D(u * u) * DJB_PI * 0.5);
-		float c = F(cos(D(th))), r = F(tan(D(th)));
+		float c = cos_f(th), r = tan_f(th);
 		float r2 = r * r;
 		float pr = p22_radial<KIND_TABULAR>(self, r2);
 		terms[k] = (u * r2 * r * pr) / (c * c);

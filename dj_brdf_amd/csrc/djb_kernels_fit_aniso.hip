@@ -61,13 +61,13 @@ __global__ __launch_bounds__(BLOCK) void ka_setup(Brdf src, Params std_p, AnisoS
 	int i2 = a / w, i1 = a - i2 * w;
 	const float dtheta = F(sqrt(DJB_PI * 0.5) / D((float)w)), dphi = F(2.0 * DJB_PI / D((float)h));
 	float theta = F(D((float)i1 / (float)w) * 0.5 * DJB_PI), phi = F(D((float)i2 / (float)h) * 2.0 * DJB_PI);
-	float st = F(sin(D(theta)));
-	float zo = F(cos(D(theta)));
+	float st = sin_f(theta);
+	float zo = cos_f(theta);
 	S.zo[a] = zo; S.xo[a] = F(D(st) * cos(D(phi))); S.yo[a] = F(D(st) * sin(D(phi)));
 	v3 wv = from_angles(theta, phi);
 	float fr_i = intensity(src_eval<SRC>(src, std_p, wv, wv));
 	S.k1[a] = F(D(dtheta * dphi) * (4.0 * D(fr_i) * glibc_pow(D(zo), D(5.0f))));
-	float tt = F(tan(D(theta)));
+	float tt = tan_f(theta);
 	S.tn[a] = tt; S.dn[a] = zo * zo;               // cos_theta * cos_theta (same float as zo)
 	S.s1[a] = F(D(-tt) * cos(D(phi))); S.s2[a] = F(D(-tt) * sin(D(phi)));
 	S.v0[a] = 1.0;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(BLOCK) void ka_norm_terms(AnisoScratch S, int shado
 	float phi = F(D((float)j / (float)NP_NORM) * 2.0 * DJB_PI);
 	float theta = F(D((float)i / (float)NT_NORM) * sqrt(DJB_PI * 0.5));
 	float ts = theta * theta;
-	float c = F(cos(D(ts)));
+	float c = cos_f(ts);
 	float weight = F(D(theta) * tan(D(ts)) / D(c * c));
 	S.terms[e] = weight * aniso_p22_theta_phi(self, ts, phi);
 }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void ka_sigma_tables(AnisoScratch S, Params 
 	if (e < NT_SIG) {
 		float theta = F(D((float)e / (float)NT_SIG) * sqrt(DJB_PI * 0.5));
 		float ts = theta * theta;
-		S.sig_theta[e] = theta; S.sig_sin[e] = F(sin(D(ts))); S.sig_cosd[e] = cos(D(ts));
+		S.sig_theta[e] = theta; S.sig_sin[e] = sin_f(ts); S.sig_cosd[e] = cos(D(ts));
 	}
 }
 __global__ __launch_bounds__(BLOCK) void ka_sigma_rows(AnisoScratch S)
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLOCK) void ka_sigma_rows(AnisoScratch S)
 	int i2 = a / w, i1 = a - i2 * w;
 	const float dtheta = F(sqrt(DJB_PI * 0.5) / D((float)NT_SIG)), dphi = F(2.0 * DJB_PI / D((float)NP_SIG));
 	float theta_k = F(D((float)i1 / (float)w) * 0.5 * DJB_PI);
-	float cos_k = F(cos(D(theta_k)));
+	float cos_k = cos_f(theta_k);
 	double sin_kd = sin(D(theta_k));
 	float nint = 0.0f;
 	for (int j2 = 0; j2 < NP_SIG; ++j2) {
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(BLOCK) void ka_pdf1(AnisoScratch S, int shadow)
 	{
 		int j = threadIdx.x;                          // ntheta = 256 == BLOCK
 		float theta = F(D((float)j / 256.0f) * 0.5 * DJB_PI);
-		float c = F(cos(D(theta)));
+		float c = cos_f(theta);
 		s_theta[j] = theta; s_tan[j] = tan(D(theta)); s_c2[j] = c * c;
 	}
 	__syncthreads();
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void ka_pdf2_norm(AnisoScratch S, int shadow
 	float phi = F(D((float)j / (float)S.azim) * 2.0 * DJB_PI), nint = 0.0f;
 	for (int i = 0; i < 256; ++i) {
 		float theta = F(D((float)i / 256.0f) * 0.5 * DJB_PI);
-		float c = F(cos(D(theta)));
+		float c = cos_f(theta);
 		nint = acc_tan_over_cos2(nint, aniso_pdf2(self, theta, phi), tan(D(theta)), c * c);
 	}
 	nint *= dtheta;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void ka_cdf2(AnisoScratch S, int shadow)
 	float phi = F(D((float)i / (float)S.azim) * 2.0 * DJB_PI), nint = 0.0f;
 	for (int j = 0; j < w; ++j) {
 		float theta = F(D((float)j / (float)w) * 0.5 * DJB_PI);
-		float c = F(cos(D(theta)));
+		float c = cos_f(theta);
 		nint = acc_tan_over_cos2(nint, aniso_pdf2(self, theta, phi), tan(D(theta)), c * c);
 		S.cdf2[j + E * i] = nint * dtheta;
 	}
@@ -507,11 +507,11 @@ __global__ __launch_bounds__(BLOCK) void ka_fit_terms(AnisoScratch S, int shadow
 	if (e >= NP_FIT * NT_FIT) return;
 	int j = e / NT_FIT, i = e - j * NT_FIT;
 	float phi = F(D((float)j / (float)NP_FIT) * 2.0 * DJB_PI);
-	float cp = F(cos(D(phi))), sp = F(sin(D(phi)));
+	float cp = cos_f(phi), sp = sin_f(phi);
 	float theta = F(D((float)i / (float)NT_FIT) * sqrt(DJB_PI * 0.5));
 	float ts = theta * theta;
 	float p22 = aniso_p22_theta_phi(self, ts, phi);
-	float tt = F(tan(D(ts))), ct = F(cos(D(ts)));
+	float tt = tan_f(ts), ct = cos_f(ts);
 	float tt2 = tt * tt;
 	float tmp2 = theta * p22 * tt / (ct * ct);
 	float e1 = -tt * cp, e2 = -tt * sp;

@@ -930,23 +930,34 @@ djb_status histogram_xy(djb_ctx *, int64_t n, const djb_vec3_view *v, int bins, 
 	return DJB_OK;
 }
 
-unsigned long long trig_sweep_compare(int fn, uint32_t first_bits, int64_t count, const float *dev, int threads,
+unsigned long long trig_sweep_compare(int host_fn, uint32_t first_bits, int64_t count, const void *dev, int threads,
                                       uint32_t *bad3, int cap)
 {
 	CpuCtx pool;
 	pool.threads = threads >= 1 ? threads : (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
 	std::mutex mu;
 	unsigned long long n_bad = 0;
+	const bool dbl = host_fn >= TRIG_DOUBLE;
 	parallel_for(&pool, count, 1 << 16, [&](long long k0, long long k1) {
 		for (long long k = k0; k < k1; ++k) {
-			uint32_t xb = first_bits + (uint32_t)k, hb, db;
-			float x, h = 0.0f;
+			uint32_t xb = first_bits + (uint32_t)k, r1, r2 = 0;
+			float x;
 			memcpy(&x, &xb, 4);
-			h = trig_site(fn, x);
-			memcpy(&hb, &h, 4); memcpy(&db, &dev[k], 4);
-			if (hb == db || (h != h && dev[k] != dev[k])) continue;
+			if (dbl) {
+				double h = trig_site_d(host_fn, x), d = ((const double *)dev)[k];
+				long long hb, db;
+				memcpy(&hb, &h, 8); memcpy(&db, &d, 8);
+				if (hb == db || (h != h && d != d)) continue;
+				// same-sign finite doubles order as their bit patterns
+				long long diff = ((hb ^ db) < 0) ? 0x7fffffffLL : (hb > db ? hb - db : db - hb);
+				r1 = (uint32_t)std::min(diff, 0x7fffffffLL);
+			} else {
+				float h = trig_site(host_fn, x), d = ((const float *)dev)[k];
+				memcpy(&r2, &h, 4); memcpy(&r1, &d, 4);
+				if (r1 == r2 || (h != h && d != d)) continue;
+			}
 			std::lock_guard<std::mutex> g(mu);
-			if (n_bad < (unsigned long long)cap && bad3) { bad3[3 * n_bad] = xb; bad3[3 * n_bad + 1] = db; bad3[3 * n_bad + 2] = hb; }
+			if (n_bad < (unsigned long long)cap && bad3) { bad3[3 * n_bad] = xb; bad3[3 * n_bad + 1] = r1; bad3[3 * n_bad + 2] = r2; }
 			++n_bad;
 		}
 	});

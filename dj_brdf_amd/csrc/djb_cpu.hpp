@@ -83,10 +83,11 @@ djb_status fit_merl_files(djb_ctx *, int n_files, const char *const *paths, int 
 djb_status gen_directions(djb_ctx *, int64_t n, uint32_t seed, uint64_t start, const djb_vec3_view *out);
 djb_status gen_uniforms(djb_ctx *, int64_t n, uint32_t seed, uint64_t start, float *out);
 djb_status histogram_xy(djb_ctx *, int64_t n, const djb_vec3_view *v, int bins, unsigned long long *counts);
-// host values of float -> float trig site `fn` (djb_device.hpp TRIG_*) for the inputs with bit patterns first_bits ..
-// first_bits + count - 1, compared with `dev` (the same sites evaluated on the GPU); NaN == NaN.  Returns the number of
-// differing inputs and stores the first `cap` of them (input bits, device bits, host bits).
-unsigned long long trig_sweep_compare(int fn, uint32_t first_bits, int64_t count, const float *dev, int threads,
+// host values of trig site `host_fn` (djb_device.hpp TRIG_*; float sites < TRIG_DOUBLE, double sites from TRIG_DOUBLE)
+// for the inputs with bit patterns first_bits .. first_bits + count - 1, compared with `dev` (a site evaluated on the
+// GPU: floats or doubles); NaN == NaN.  Returns the number of differing inputs and stores the first `cap` of them
+// (input bits, device bits, host bits; for a double site: input bits, |difference| in units of the last place, 0).
+unsigned long long trig_sweep_compare(int host_fn, uint32_t first_bits, int64_t count, const void *dev, int threads,
                                       uint32_t *bad3, int cap);
 
 } // namespace djbcpu

@@ -103,6 +103,18 @@ DJB_DEV float atan_u_f(float r) { return F(atan(D(r)) * D(2.0f) / D(F(DJB_PI)));
 DJB_DEV float atan_sqrt_f(float x) { return F(atan(sqrt(D(x)))); }                          // dj_brdf.h:2285 (aniso p22)
 DJB_DEV float beck_qf_f(float u) { return F(sqrt(-log(1.0 - D(u)))); }                      // dj_brdf.h:1887 (beckmann qf)
 DJB_DEV float acos_deg_f(float z) { return F(D(F(180.0 / DJB_PI)) * acos(D(z))); }          // dj_brdf.h:1633 (utia)
+// the sites that keep the double (products such as float(double(s) * cos(double(phi))), the sgd / abc models, the
+// sigma integrand): site TRIG_DOUBLE + {0 cos, 1 sin, 2 tan, 3 acos} of a float argument, as a double
+enum { TRIG_DOUBLE = 16, TRIG_DOUBLE_SITES = 4 };
+DJB_DEV double trig_site_d(int fn, float x)
+{
+	switch (fn - TRIG_DOUBLE) {
+	case 0: return cos(D(x));
+	case 1: return sin(D(x));
+	case 2: return tan(D(x));
+	default: return acos(D(x));
+	}
+}
 DJB_DEV float trig_site(int fn, float x)
 {
 	switch (fn) {

@@ -1966,28 +1966,35 @@ try {
 }
 DJB_ABI_CATCH
 
-djb_status djb_selftest_trig_sweep(djb_ctx *ctx, int fn, uint32_t first_bits, int64_t count, int threads,
+static_assert(djbdev::TRIG_SITES == DJB_TRIG_SITES && djbdev::TRIG_DOUBLE == DJB_TRIG_DOUBLE && djbdev::TRIG_DOUBLE_SITES == DJB_TRIG_DOUBLE_SITES, "djb_hip.h and djb_device.hpp number the trig sites differently");
+static bool trig_site_valid(int fn)
+{
+	return (fn >= 0 && fn < DJB_TRIG_SITES) || (fn >= DJB_TRIG_DOUBLE && fn < DJB_TRIG_DOUBLE + DJB_TRIG_DOUBLE_SITES);
+}
+djb_status djb_selftest_trig_sweep(djb_ctx *ctx, int fn, int host_fn, uint32_t first_bits, int64_t count, int threads,
                                    unsigned long long *n_bad, uint32_t *bad3, int cap)
 try {
 	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
 	djb_status st = check_call(ctx, nullptr, count, DJB_MEM_HOST);
 	if (st != DJB_OK) return st;
-	if (fn < 0 || fn >= DJB_TRIG_SITES || !n_bad || cap < 0 || (cap > 0 && !bad3) || count > ((int64_t)1 << 32) - (int64_t)first_bits)
+	if (!trig_site_valid(fn) || !trig_site_valid(host_fn) || (fn >= DJB_TRIG_DOUBLE) != (host_fn >= DJB_TRIG_DOUBLE) || !n_bad ||
+	    cap < 0 || (cap > 0 && !bad3) || count > ((int64_t)1 << 32) - (int64_t)first_bits)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid selftest arguments");
 	*n_bad = 0;
 	if (count == 0) return DJB_OK;
-	std::vector<float> host((size_t)count);
+	const size_t nb = (fn >= DJB_TRIG_DOUBLE ? sizeof(double) : sizeof(float)) * (size_t)count;
+	std::vector<char> host(nb);
 	{
 		std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
-		float *d = nullptr;
-		HIP_TRY(hipMalloc((void **)&d, sizeof(float) * (size_t)count));
+		void *d = nullptr;
+		HIP_TRY(hipMalloc(&d, nb));
 		hipError_t e = djbk::launch_trig_sweep(ctx->stream, fn, first_bits, count, d);
-		if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d, nb, hipMemcpyDeviceToHost, ctx->stream);
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 		(void)hipFree(d);
 		if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));
 	}
-	*n_bad = djbcpu::trig_sweep_compare(fn, first_bits, count, host.data(), threads, bad3, cap);
+	*n_bad = djbcpu::trig_sweep_compare(host_fn, first_bits, count, host.data(), threads, bad3, cap);
 	return DJB_OK;
 }
 DJB_ABI_CATCH

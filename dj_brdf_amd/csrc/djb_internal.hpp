@@ -56,7 +56,7 @@ hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsign
                                float *out);
 hipError_t launch_guard_selftest(hipStream_t s, long long n, uint32_t seed, unsigned long long *counters);
 hipError_t launch_libm_probe(hipStream_t s, int fn, long long n, const double *x, const double *y, double *out);
-hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n, float *out);
+hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n, void *out);
 hipError_t launch_histogram_xy(hipStream_t s, long long n, const View &v, int bins,
                                unsigned long long *counts);
 

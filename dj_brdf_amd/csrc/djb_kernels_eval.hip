@@ -545,14 +545,18 @@ hipError_t launch_libm_probe(hipStream_t s, int fn, long long n, const double *x
 	return hipGetLastError();
 }
 
-// float -> float trig site fn on the floats with bit patterns first .. first + n - 1 (djb_selftest_trig_sweep)
-__global__ __launch_bounds__(BLOCK) void k_trig_sweep(int fn, uint32_t first, long long n, float *out)
+// trig site fn on the floats with bit patterns first .. first + n - 1 (djb_selftest_trig_sweep): float sites write
+// floats, the double sites (fn >= TRIG_DOUBLE) doubles
+__global__ __launch_bounds__(BLOCK) void k_trig_sweep(int fn, uint32_t first, long long n, void *out)
 {
 	long long stride = (long long)gridDim.x * BLOCK;
-	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride)
-		out[k] = trig_site(fn, __uint_as_float(first + (uint32_t)k));
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		float x = __uint_as_float(first + (uint32_t)k);
+		if (fn >= TRIG_DOUBLE) ((double *)out)[k] = trig_site_d(fn, x);
+		else ((float *)out)[k] = trig_site(fn, x);
+	}
 }
-hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n, float *out)
+hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n, void *out)
 {
 	if (n <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k_trig_sweep, dim3(grid_for(n)), dim3(BLOCK), 0, s, fn, first, n, out);

@@ -1057,18 +1057,29 @@ def selftest_libm(fn: str, x, y=None, ctx: Optional[Context] = None):
 
 
 TRIG_SITES = ("cos", "sin", "tan", "acos", "acos_u", "acos_u32", "atan_squ", "atan_u", "atan_sqrt", "beck_qf", "acos_deg")
+TRIG_DOUBLE_SITES = ("cos_d", "sin_d", "tan_d", "acos_d")
 
 
-def selftest_trig_sweep(fn, first_bits: int, count: int, threads: int = 0, cap: int = 64, ctx: Optional[Context] = None):
-    """Float -> float trig site `fn` (name from TRIG_SITES or its index) on the GPU against the library's host
+def _trig_code(fn):
+    if isinstance(fn, str):
+        return 16 + TRIG_DOUBLE_SITES.index(fn) if fn in TRIG_DOUBLE_SITES else TRIG_SITES.index(fn)
+    return int(fn)
+
+
+def selftest_trig_sweep(fn, first_bits: int, count: int, threads: int = 0, cap: int = 64, host_fn=None,
+                        ctx: Optional[Context] = None):
+    """Trig site `fn` (a name from TRIG_SITES / TRIG_DOUBLE_SITES or its code) on the GPU against the library's host
     instantiation (glibc) for the floats with bit patterns first_bits .. first_bits + count - 1
-    (djb_selftest_trig_sweep).  Returns (number of differing inputs, [(input bits, device bits, host bits), ...])."""
+    (djb_selftest_trig_sweep).  Returns (number of differing inputs, rows): rows are (input bits, device bits, host
+    bits), or (input bits, difference in ulps, 0) for a double site.  host_fn: another site on the host side
+    (negative control)."""
     ctx = ctx or default_context()
-    code = TRIG_SITES.index(fn) if isinstance(fn, str) else int(fn)
+    code = _trig_code(fn)
     n_bad = C.c_ulonglong(0)
     bad = np.zeros((max(cap, 1), 3), np.uint32)
-    _lib.check(_lib.load().djb_selftest_trig_sweep(ctx._h, C.c_int(code), C.c_uint32(first_bits), C.c_int64(count),
-                                                   C.c_int(threads), C.byref(n_bad), bad.ctypes.data_as(C.c_void_p), C.c_int(cap)))
+    _lib.check(_lib.load().djb_selftest_trig_sweep(ctx._h, C.c_int(code), C.c_int(code if host_fn is None else _trig_code(host_fn)),
+                                                   C.c_uint32(first_bits), C.c_int64(count), C.c_int(threads), C.byref(n_bad),
+                                                   bad.ctypes.data_as(C.c_void_p), C.c_int(cap)))
     k = min(int(n_bad.value), cap)
     return int(n_bad.value), [tuple(int(v) for v in row) for row in bad[:k]]
 

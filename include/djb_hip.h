@@ -287,15 +287,20 @@ djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsign
  * to float).  The test-suite compares `out` with the libm of the host, bit for bit. */
 djb_status djb_selftest_libm(djb_ctx *, int fn, int64_t n, const double *x, const double *y, double *out);
 
-/* exhaustive check of the float -> float sites of the fp64 trig family (float(cos(double x)), float(2 acos(x) / pi),
- * ... : every place where the path rounds the double libm result of one float argument to float; `fn` numbers them as
- * the TRIG_* enum of csrc/djb_device.hpp, 0 .. DJB_TRIG_SITES - 1).  Evaluates site fn on the GPU for the `count`
- * floats whose bit patterns start at first_bits (count <= 2^32 - first_bits), evaluates the library's host
- * instantiation (the host's libm: glibc, what the reference links) on `threads` threads (0 = all cores) and returns
- * the number of inputs whose results differ (NaN == NaN); the first `cap` of them go to bad3 as
- * {input bits, device bits, host bits}.  tools/exhaustive_trig.py sweeps all 2^32 inputs of every site. */
+/* exhaustive check of the sites of the fp64 trig family.  Float sites (0 .. DJB_TRIG_SITES - 1, the TRIG_* enum of
+ * csrc/djb_device.hpp): every place where the path rounds the double libm result of ONE float argument to float
+ * (float(cos(double x)), float(2 acos(x) / pi), ...), i.e. a float -> float map with 2^32 inputs.  Double sites
+ * (DJB_TRIG_DOUBLE + 0 cos, 1 sin, 2 tan, 3 acos): the double result itself, for the places that keep it.
+ * Evaluates site fn on the GPU for the `count` floats whose bit patterns start at first_bits
+ * (count <= 2^32 - first_bits), evaluates site host_fn (= fn, except for the test-suite's negative control) with the
+ * library's host instantiation (the host's libm: glibc, what the reference links) on `threads` threads (0 = all
+ * cores), and returns the number of inputs whose results differ (NaN == NaN); the first `cap` of them go to bad3 as
+ * {input bits, device bits, host bits} (double sites: {input bits, |difference| in units of the last place, 0}).
+ * tools/exhaustive_trig.py sweeps all 2^32 inputs of every site. */
 #define DJB_TRIG_SITES 11
-djb_status djb_selftest_trig_sweep(djb_ctx *, int fn, uint32_t first_bits, int64_t count, int threads,
+#define DJB_TRIG_DOUBLE 16
+#define DJB_TRIG_DOUBLE_SITES 4
+djb_status djb_selftest_trig_sweep(djb_ctx *, int fn, int host_fn, uint32_t first_bits, int64_t count, int threads,
                                    unsigned long long *n_bad, uint32_t *bad3, int cap);
 
 /* microfacet::params -> private members (host side, no GPU work)       dj_brdf.h:1355-1506 */

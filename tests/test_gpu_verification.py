@@ -229,3 +229,31 @@ def test_context_follows_torch_current_stream(gpu_ctx):
     assert (lib.djb_ctx_stream(gpu_ctx._h) or 0) == (base or 0)
     torch.cuda.synchronize()
     assert torch.equal(again, want)
+
+
+# ---- fp64 trig family: every float -> float site, GPU (ocml) against the library's host instantiation (glibc)
+# tools/exhaustive_trig.py sweeps all 2^32 inputs per site (profiles/r02/exhaustive_trig.json: 0 differences); the
+# suite repeats 2^26 inputs per site over the ranges the path feeds them and proves the comparison can fail.
+_TRIG_RANGES = [
+    (0x3C000000, 1 << 24),   # 2^-7 .. : small angles / cosines
+    (0x3F000000, 1 << 24),   # 0.5 .. 2 (covers the acos pole at 1, theta up to pi/2 ...)
+    (0x40000000, 1 << 24),   # 2 .. 8 (phi up to 2 pi, tan poles)
+    (0xBF000000, 1 << 24),   # -0.5 .. -2
+]
+
+
+@pytest.mark.parametrize("site", djb.TRIG_SITES)
+def test_trig_float_sites_match_glibc(gpu_ctx, site):
+    for first, count in _TRIG_RANGES:
+        n_bad, rows = djb.selftest_trig_sweep(site, first, count, ctx=gpu_ctx)
+        assert n_bad == 0, (site, hex(first), rows[:4])
+
+
+def test_trig_sweep_negative_control(gpu_ctx):
+    # 2 acos(c) / pi with pi as a double against pi rounded to float: different float results on many inputs
+    n_bad, rows = djb.selftest_trig_sweep("acos_u", 0x3F000000, 1 << 20, host_fn="acos_u32", ctx=gpu_ctx)
+    assert n_bad > 1000 and len(rows) == 64
+    x, d, h = rows[0]
+    assert d != h and 0x3F000000 <= x < 0x3F000000 + (1 << 20)
+    with pytest.raises(djb.exc):
+        djb.selftest_trig_sweep("cos", 0x3F000000, 16, host_fn="cos_d", ctx=gpu_ctx)

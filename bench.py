@@ -430,11 +430,13 @@ def main():
             for other in ("ggx_eval_pdf", "beckmann_sample", "utia_eval"):
                 on, ob, ou, _ = WORKLOADS[other]
                 st, kp = make_step(other, on, djb, synth, ctx, torch)
-                st(); torch.cuda.synchronize()
-                ctx.timer_start()
-                for _ in range(3):
+                for _ in range(10):        # steady clocks: these launches are 1-20 ms, and the GPU idled during the CPU legs
                     st()
-                ms = ctx.timer_stop_ms() / 3
+                torch.cuda.synchronize()
+                ctx.timer_start()
+                for _ in range(10):
+                    st()
+                ms = ctx.timer_stop_ms() / 10
                 sec[other] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms,
                               "hbm_GBps": (on * ob / (ms * 1e-3) / 1e9) if ob else None}
                 del st, kp

@@ -91,7 +91,7 @@ DJB_DEV float sat_(float x) { return fmin_(1.0f, fmax_(0.0f, x)); }
 // the device against the host's glibc (djb_selftest_trig_sweep).  The two-argument atan2 sites and the sites that keep
 // the double (cos(phi) * sin(theta) products, sgd/abc) are not of this shape and stay "observed" (DESIGN section 2).
 enum { TRIG_COS = 0, TRIG_SIN, TRIG_TAN, TRIG_ACOS, TRIG_ACOS_U, TRIG_ACOS_U32, TRIG_ATAN_SQU, TRIG_ATAN_U,
-       TRIG_ATAN_SQRT, TRIG_BECK_QF, TRIG_ACOS_DEG, TRIG_SITES };
+       TRIG_ATAN_SQRT, TRIG_BECK_QF, TRIG_ACOS_DEG, TRIG_UTIA_BIN15, TRIG_UTIA_BIN7P5, TRIG_SITES };
 DJB_DEV float cos_f(float x) { return F(cos(D(x))); }
 DJB_DEV float sin_f(float x) { return F(sin(D(x))); }
 DJB_DEV float tan_f(float x) { return F(tan(D(x))); }
@@ -103,6 +103,23 @@ DJB_DEV float atan_u_f(float r) { return F(atan(D(r)) * D(2.0f) / D(F(DJB_PI)));
 DJB_DEV float atan_sqrt_f(float x) { return F(atan(sqrt(D(x)))); }                          // dj_brdf.h:2285 (aniso p22)
 DJB_DEV float beck_qf_f(float u) { return F(sqrt(-log(1.0 - D(u)))); }                      // dj_brdf.h:1887 (beckmann qf)
 DJB_DEV float acos_deg_f(float z) { return F(D(F(180.0 / DJB_PI)) * acos(D(z))); }          // dj_brdf.h:1633 (utia)
+// utia's grid cells (dj_brdf.h:1639-1646): (int)floor(double(theta) / 15.0) (clamped to 4) and (int)floor(double(phi) / 7.5)
+// are functions of one float too.  The device evaluates them without the fp64 division: RN(theta / 15) >= k  <=>
+// theta >= 15 k for a float theta, because a float below 15 k is at least 2^-20 below it while the quotient is rounded at
+// 2^-50, and 15 k (7.5 k) is a float; the sweep compares them with the host's division for every float in range.
+#if defined(DJB_HOST_MATH)
+DJB_DEV int utia_bin15(float theta) { int k = (int)floor(D(theta) / 15.0); return k > 4 ? 4 : k; }
+DJB_DEV int utia_bin7p5(float phi) { return (int)floor(D(phi) / 7.5); }
+#else
+DJB_DEV int utia_bin15(float theta) { return (theta >= 15.0f) + (theta >= 30.0f) + (theta >= 45.0f) + (theta >= 60.0f); }   // theta in [0, 90)
+DJB_DEV int utia_bin7p5(float phi)                                                                                          // phi in [0, 360)
+{
+	int k = (int)(phi * 0.13333334f);              // off by one at most
+	if (7.5f * (float)k > phi) --k;
+	if (7.5f * (float)(k + 1) <= phi) ++k;
+	return k;
+}
+#endif
 // the sites that keep the double (products such as float(double(s) * cos(double(phi))), the sgd / abc models, the
 // sigma integrand): site TRIG_DOUBLE + {0 cos, 1 sin, 2 tan, 3 acos} of a float argument, as a double
 enum { TRIG_DOUBLE = 16, TRIG_DOUBLE_SITES = 4 };
@@ -128,7 +145,9 @@ DJB_DEV float trig_site(int fn, float x)
 	case TRIG_ATAN_U: return atan_u_f(x);
 	case TRIG_ATAN_SQRT: return atan_sqrt_f(x);
 	case TRIG_BECK_QF: return beck_qf_f(x);
-	default: return acos_deg_f(x);
+	case TRIG_ACOS_DEG: return acos_deg_f(x);
+	case TRIG_UTIA_BIN15: return x >= 0.0f && x < 90.0f ? (float)utia_bin15(x) : 0.0f;      // 0 outside the range utia feeds
+	default: return x >= 0.0f && x < 360.0f ? (float)utia_bin7p5(x) : 0.0f;
 	}
 }
 
@@ -1301,12 +1320,10 @@ DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 	while (D(phi_o) < 0.0) phi_o = F(D(phi_o) + 360.0);
 	while (phi_i >= 360.0f) phi_i = F(D(phi_i) - 360.0);
 	while (phi_o >= 360.0f) phi_o = F(D(phi_o) - 360.0);
-	int iti0 = (int)floor(D(theta_i) / 15.0), iti1 = iti0 + 1;
-	if (iti0 > 4) { iti0 = 4; iti1 = 5; }
-	int itv0 = (int)floor(D(theta_o) / 15.0), itv1 = itv0 + 1;
-	if (itv0 > 4) { itv0 = 4; itv1 = 5; }
-	int ipi0 = (int)floor(D(phi_i) / 7.5), ipi1 = ipi0 + 1;
-	int ipv0 = (int)floor(D(phi_o) / 7.5), ipv1 = ipv0 + 1;
+	int iti0 = utia_bin15(theta_i), iti1 = iti0 + 1;          // (int)floor(theta / 15.0), > 4 -> 4 (then iti1 = 5)
+	int itv0 = utia_bin15(theta_o), itv1 = itv0 + 1;
+	int ipi0 = utia_bin7p5(phi_i), ipi1 = ipi0 + 1;            // (int)floor(phi / 7.5)
+	int ipv0 = utia_bin7p5(phi_o), ipv1 = ipv0 + 1;
 	float sum, wti[2], wtv[2], wpi[2], wpv[2];
 	wti[1] = theta_i - F(15.0 * iti0); wti[0] = F(15.0 * iti1) - theta_i;
 	sum = wti[0] + wti[1]; wti[0] /= sum; wti[1] /= sum;

@@ -1056,7 +1056,8 @@ def selftest_libm(fn: str, x, y=None, ctx: Optional[Context] = None):
     return out
 
 
-TRIG_SITES = ("cos", "sin", "tan", "acos", "acos_u", "acos_u32", "atan_squ", "atan_u", "atan_sqrt", "beck_qf", "acos_deg")
+TRIG_SITES = ("cos", "sin", "tan", "acos", "acos_u", "acos_u32", "atan_squ", "atan_u", "atan_sqrt", "beck_qf", "acos_deg",
+              "utia_bin15", "utia_bin7p5")
 TRIG_DOUBLE_SITES = ("cos_d", "sin_d", "tan_d", "acos_d")
 
 

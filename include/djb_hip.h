@@ -289,7 +289,8 @@ djb_status djb_selftest_libm(djb_ctx *, int fn, int64_t n, const double *x, cons
 
 /* exhaustive check of the sites of the fp64 trig family.  Float sites (0 .. DJB_TRIG_SITES - 1, the TRIG_* enum of
  * csrc/djb_device.hpp): every place where the path rounds the double libm result of ONE float argument to float
- * (float(cos(double x)), float(2 acos(x) / pi), ...), i.e. a float -> float map with 2^32 inputs.  Double sites
+ * (float(cos(double x)), float(2 acos(x) / pi), ..., utia's grid cells floor(x / 15.0)), i.e. a float -> float map
+ * with 2^32 inputs.  Double sites
  * (DJB_TRIG_DOUBLE + 0 cos, 1 sin, 2 tan, 3 acos): the double result itself, for the places that keep it.
  * Evaluates site fn on the GPU for the `count` floats whose bit patterns start at first_bits
  * (count <= 2^32 - first_bits), evaluates site host_fn (= fn, except for the test-suite's negative control) with the
@@ -297,7 +298,7 @@ djb_status djb_selftest_libm(djb_ctx *, int fn, int64_t n, const double *x, cons
  * cores), and returns the number of inputs whose results differ (NaN == NaN); the first `cap` of them go to bad3 as
  * {input bits, device bits, host bits} (double sites: {input bits, |difference| in units of the last place, 0}).
  * tools/exhaustive_trig.py sweeps all 2^32 inputs of every site. */
-#define DJB_TRIG_SITES 11
+#define DJB_TRIG_SITES 13
 #define DJB_TRIG_DOUBLE 16
 #define DJB_TRIG_DOUBLE_SITES 4
 djb_status djb_selftest_trig_sweep(djb_ctx *, int fn, int host_fn, uint32_t first_bits, int64_t count, int threads,

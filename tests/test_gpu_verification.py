@@ -239,6 +239,7 @@ _TRIG_RANGES = [
     (0x3F000000, 1 << 24),   # 0.5 .. 2 (covers the acos pole at 1, theta up to pi/2 ...)
     (0x40000000, 1 << 24),   # 2 .. 8 (phi up to 2 pi, tan poles)
     (0xBF000000, 1 << 24),   # -0.5 .. -2
+    (0x41000000, 3 << 24),   # 8 .. 512: utia's degrees (grid cells of 15 / 7.5 degrees)
 ]
 
 

@@ -236,19 +236,30 @@ DJB_DEV v3 from_angles(float theta, float phi)
 	return mk(F(D(s) * cos(D(phi))), F(D(s) * sin(D(phi))), cos_f(theta));
 }
 
+typedef unsigned int LdsTab;   // where a device kernel staged a libm table (0 = the global copy); unused on the host
+DJB_DEV double glibc_atan2(double y, double x);   // the host libm's atan2 (defined with the other glibc restatements below)
+// float(scale * atan2(double y, double x)) with the HOST libm's atan2 (dj_brdf.h:659, 1634).  On the device glibc's
+// routine (two IEEE fp64 divisions, a 13.5 KB table) costs twice the device libm's, so the device libm goes first:
+// it is within a few ulp64 of glibc's value (both are accurate to <= 2 ulp), and two doubles that close round to the
+// same float unless they sit next to a float rounding boundary.  near_f32_midpoint tests 1024 ulp64 either side
+// (probability 2^-18); there -- and for zeros, NaNs and results in the float subnormal range -- glibc's own
+// algorithm decides (glibc_atan2 below, bit-identical to the host libm: tests/test_gpu_parity.py).  So the value is
+// the reference's by construction, at the device libm's speed.
+DJB_DEV float atan2_to_f32(float y, float x, double scale);
 // dj_brdf.h:650-661
 DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 {
 	if (D(p.z) > 0.99999) { theta = 0.0f; phi = 0.0f; }
 	else if (D(p.z) < -0.99999) { theta = F(DJB_PI); phi = 0.0f; }
-	else { theta = acos_f(p.z); phi = F(atan2(D(p.y), D(p.x))); }
+	else { theta = acos_f(p.z); phi = atan2_to_f32(p.y, p.x, 1.0); }
 }
 
-typedef unsigned int LdsTab;   // where a device kernel staged a libm table (0 = the global copy); unused on the host
 #if defined(DJB_HOST_MATH)
 // host: the reference's unqualified exp() / pow() are these very glibc functions
 DJB_DEV double glibc_exp(double x, LdsTab = 0u) { return exp(x); }
 DJB_DEV double glibc_pow(double x, double y, LdsTab = 0u, LdsTab = 0u) { return pow(x, y); }
+DJB_DEV double glibc_atan2(double y, double x) { return atan2(y, x); }
+DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * atan2(D(y), D(x))); }
 #else
 // ---- glibc 2.35's double exp / pow, restated --------------------------------------------------------
 // The reference's unqualified exp() / pow() are glibc's double functions: ~0.51 ulp, not
@@ -387,6 +398,130 @@ DJB_DEV double glibc_pow(double x, double y, LdsTab PT = 0u, LdsTab ET = 0u)
 		else res = pow(x, y);
 	}
 	return res;
+}
+
+// ---- glibc 2.35's double atan2, restated ----------------------------------------------------------
+// __ieee754_atan2 of sysdeps/ieee754/dbl-64/e_atan2.c (IBM Accurate Mathematical Library; since glibc 2.34 without its
+// multi-precision fall-back) as the x86-64 FMA ifunc variant computes it: branch structure, operation order and the
+// placement of every fused multiply-add read off the disassembly of __ieee754_atan2_fma; the 241 x 7 table cij out of
+// libm.so.6 (tools/extract_glibc_dbl64_tables.py).  u = min / max of the magnitudes by an IEEE division and du its
+// residual; u < 1/16: odd polynomial d3 .. d13; else the Taylor expansion about the table point next to u; then the
+// quadrant identity with the two-term pi/2 or pi.  Complete: zeros, infinities, NaNs, the exponent-difference
+// shortcuts, the 2^+-500 rescaling.  Pinned against the host libm in oracle/ (0 mismatches over 5e7 argument pairs of
+// every class) and, as compiled here, in tests/test_gpu_parity.py::test_device_libm_restatements.  It is what
+// atan2_to_f32 (above) falls back on next to a float rounding boundary: with it the phi of xyz_to_theta_phi -- the last
+// libm call the MERL bin indices went through that was only observed to agree -- and utia's azimuths are the
+// reference's by construction.
+DJB_DEV double glibc_atan2(double y, double x)
+{
+	constexpr double d3 = -0x1.5555555555555p-2, d5 = 0x1.99999999997fdp-3, d7 = -0x1.24924923f7603p-3,
+	                 d9 = 0x1.c71c6e5129a3bp-4, d11 = -0x1.7458022b13c25p-4, d13 = 0x1.375f08b31cbcep-4,
+	                 hpi = 0x1.921fb54442d18p+0, hpi1 = 0x1.1a62633145c07p-54, opi = 0x1.921fb54442d18p+1,
+	                 opi1 = 0x1.1a62633145c07p-53, qpi = 0x1.921fb54442d18p-1, tqpi = 0x1.2d97c7f3321d2p+1,
+	                 twom500 = 0x1p-500, two500 = 0x1p+500, inv16 = 0x1p-4, TWO52 = 0x1p+52, TWO8 = 0x1p+8;
+	const int ux = __double2hiint(x), uy = __double2hiint(y);
+	const unsigned int dx = (unsigned int)__double2loint(x), dy = (unsigned int)__double2loint(y);
+	// x = NaN or y = NaN
+	if ((ux & 0x7ff00000) == 0x7ff00000 && (((ux & 0xfffff) | dx) != 0)) return x + y;
+	if ((uy & 0x7ff00000) == 0x7ff00000 && (((uy & 0xfffff) | dy) != 0)) return y + y;
+	// y = +-0
+	if (uy == 0 && dy == 0) return ux < 0 ? opi : 0.0;
+	if ((unsigned int)uy == 0x80000000u && dy == 0) return ux < 0 ? -opi : -0.0;
+	// x = +-0
+	if (x == 0.0) return uy < 0 ? -hpi : hpi;
+	// x = +-Inf
+	if (ux == 0x7ff00000 && dx == 0) {
+		if (uy == 0x7ff00000 && dy == 0) return qpi;
+		if ((unsigned int)uy == 0xfff00000u && dy == 0) return -qpi;
+		return uy < 0 ? -0.0 : 0.0;
+	}
+	if ((unsigned int)ux == 0xfff00000u && dx == 0) {
+		if (uy == 0x7ff00000 && dy == 0) return tqpi;
+		if ((unsigned int)uy == 0xfff00000u && dy == 0) return -tqpi;
+		return uy < 0 ? -opi : opi;
+	}
+	// y = +-Inf
+	if (uy == 0x7ff00000 && dy == 0) return hpi;
+	if ((unsigned int)uy == 0xfff00000u && dy == 0) return -hpi;
+	double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+	const int de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
+	// either x/y or y/x is very close to zero
+	if (de >= 0x3900000) return y > 0.0 ? hpi : -hpi;
+	if (de <= -0x3900000) {
+		if (x > 0.0) return __builtin_copysign(ay / ax, y);
+		return y > 0.0 ? opi : -opi;
+	}
+	if (ax < twom500 || ay < twom500) { ax *= two500; ay *= two500; }
+	if (ax > two500 || ay > two500) { ax *= twom500; ay *= twom500; }
+	const bool y_lt_x = ay < ax;
+	const double mx = y_lt_x ? ax : ay, mn = y_lt_x ? ay : ax;
+	const double u = mn / mx;
+	double v = mx * u;
+	const double vv = __builtin_fma(mx, u, -v);
+	const double du = ((mn - v) - vv) / mx;
+	// which of (i) x > 0, |y| < |x|: atan(u); (ii) x > 0, |x| <= |y|: pi/2 - atan(u); (iii) x < 0, |x| < |y|: pi/2 + atan(u);
+	// (iv) x < 0, |y| <= |x|: pi - atan(u)
+	const bool pos = x > 0.0, c3 = !pos && ay > ax;
+	double z;
+	if (u < inv16) {
+		v = u * u;
+		double p = __builtin_fma(d13, v, d11);
+		p = __builtin_fma(p, v, d9); p = __builtin_fma(p, v, d7); p = __builtin_fma(p, v, d5); p = __builtin_fma(p, v, d3);
+		if (pos && y_lt_x) z = u + __builtin_fma(u * v, p, du);
+		else {
+			const double zz = (u * v) * p, au = u < 0.0 ? -u : u;
+			if (pos) {
+				const double t2 = hpi - u, cor = hpi > au ? (hpi - t2) - u : hpi - (u + t2);
+				z = (((cor + hpi1) - du) - zz) + t2;
+			} else if (c3) {
+				const double t2 = u + hpi, cor = hpi > au ? (hpi - t2) + u : (u - t2) + hpi;
+				z = (((cor + hpi1) + du) + zz) + t2;
+			} else {
+				const double t2 = opi - u, cor = opi > au ? (opi - t2) - u : opi - (t2 + u);
+				z = (((cor + opi1) - du) - zz) + t2;
+			}
+		}
+		return __builtin_copysign(z, y);
+	}
+	const int i = (int)(__builtin_fma(u, TWO8, TWO52) - TWO52) - 16;
+	const double *c = DJB_GLIBC_ATAN_CIJ + 7 * i;
+	const double c0 = c[0], c1 = c[1], c2 = c[2], c3_ = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
+	const double t3 = u - c0;
+	if (pos && y_lt_x) {
+		const double w = du + t3, at3 = t3 < 0.0 ? -t3 : t3, adu = du < 0.0 ? -du : du;
+		const double dv = at3 > adu ? (t3 - w) + du : (du - w) + t3;
+		double p = __builtin_fma(c6, w, c5);
+		p = __builtin_fma(p, w, c4); p = __builtin_fma(p, w, c3_);
+		p = (w * w) * p;
+		p = __builtin_fma(dv, c2, p);
+		z = __builtin_fma(w, c2, p) + c1;
+		return __builtin_copysign(z, y);
+	}
+	const double w = t3 + du;
+	double p = __builtin_fma(c6, w, c5);
+	p = __builtin_fma(p, w, c4); p = __builtin_fma(p, w, c3_); p = __builtin_fma(p, w, c2);
+	if (pos) z = (hpi - c1) + __builtin_fma(-w, p, hpi1);
+	else if (c3) z = (hpi + c1) + __builtin_fma(w, p, hpi1);
+	else z = (opi - c1) + __builtin_fma(-w, p, opi1);
+	return __builtin_copysign(z, y);
+}
+// out of line: inlined into the rarely taken branch of atan2_to_f32 its divisions, constants and table reads cost
+// the hot loops more registers and scratch than the branch ever saves (utia eval: 2.8 -> 5.6 ms per 1e8)
+__device__ __attribute__((noinline)) double glibc_atan2_cold(double y, double x) { return glibc_atan2(y, x); }
+// the device-libm value and whether it is decided (tier 1 of a two-tier kernel: undecided units go to a second kernel)
+DJB_DEV float atan2_to_f32_t1(float y, float x, double scale, bool &ok)
+{
+	const double d = scale * atan2(D(y), D(x));
+	const double ad = d < 0.0 ? -d : d;
+	ok = !near_f32_midpoint(d, 1024) && ad >= 1e-37;
+	return F(d);
+}
+DJB_DEV float atan2_to_f32(float y, float x, double scale)
+{
+	bool ok;
+	const float r = atan2_to_f32_t1(y, x, scale, ok);
+	if (__builtin_expect(!ok, 0)) return F(scale * glibc_atan2_cold(D(y), D(x)));
+	return r;
 }
 
 #endif
@@ -748,11 +883,11 @@ DJB_DEV float aniso_grid(const Brdf &b, const float *tab, float theta, float phi
 DJB_DEV float aniso_p22_theta_phi(const Brdf &b, float theta, float phi) { return aniso_grid(b, b.p22, theta, phi); }
 DJB_DEV float aniso_p22_std(const Brdf &b, float x, float y)                           // :2178
 {
-	return aniso_p22_theta_phi(b, atan_sqrt_f(x * x + y * y), F(atan2(D(-y), D(-x))));
+	return aniso_p22_theta_phi(b, atan_sqrt_f(x * x + y * y), atan2_to_f32(-y, -x, 1.0));
 }
 DJB_DEV float aniso_sigma_std(const Brdf &b, v3 k)                                     // :2198
 {
-	return aniso_grid(b, b.sigma, acos_f(k.z), F(atan2(D(k.y), D(k.x))));
+	return aniso_grid(b, b.sigma, acos_f(k.z), atan2_to_f32(k.y, k.x, 1.0));
 }
 DJB_DEV float aniso_pdf1(const Brdf &b, float phi) { return spline_rep(b.a_pdf1, b.azim, F(D(phi) * 0.5 / DJB_PI)); }       // :2768
 DJB_DEV float aniso_cdf1(const Brdf &b, float phi) { return spline_rep(b.a_cdf1, b.n_a_cdf1, F(D(phi) * 0.5 / DJB_PI)); }
@@ -1309,11 +1444,23 @@ DJB_DEV float srgb_decode(float v)
 
 #endif
 
-DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
+// T1 (device only): tier 1 of the batch kernel -- the device-libm azimuths without glibc's atan2 behind them; ok = false
+// when one of the two was not decided away from a float rounding boundary (k_eval_utia_t1 then lists the pair for
+// k_eval_utia_fix, which runs utia_eval).  Everything else is the same code.
+template <bool T1> DJB_DEV v3 utia_eval_t(const Brdf &b, v3 i, v3 o, bool &ok)
 {
 	float r2d = F(180.0 / DJB_PI);
 	float theta_i = acos_deg_f(i.z), theta_o = acos_deg_f(o.z);
-	float phi_i = F(D(r2d) * atan2(D(i.y), D(i.x))), phi_o = F(D(r2d) * atan2(D(o.y), D(o.x)));
+	float phi_i, phi_o;
+	ok = true;
+#if !defined(DJB_HOST_MATH)
+	if (T1) {
+		bool ok_i, ok_o;
+		phi_i = atan2_to_f32_t1(i.y, i.x, D(r2d), ok_i); phi_o = atan2_to_f32_t1(o.y, o.x, D(r2d), ok_o);
+		ok = ok_i && ok_o;
+	} else
+#endif
+	{ phi_i = atan2_to_f32(i.y, i.x, D(r2d)); phi_o = atan2_to_f32(o.y, o.x, D(r2d)); }
 	if (D(theta_i) >= 90.0 || D(theta_o) >= 90.0) return mk(0, 0, 0);
 	if (!(phi_i == phi_i) || !(phi_o == phi_o)) return mk(0, 0, 0);   // NaN guard: reference would spin
 	while (D(phi_i) < 0.0) phi_i = F(D(phi_i) + 360.0);
@@ -1374,6 +1521,7 @@ DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o)
 	}
 	return mk(fmax_(0.f, RGB[0]), fmax_(0.f, RGB[1]), fmax_(0.f, RGB[2]));
 }
+DJB_DEV v3 utia_eval(const Brdf &b, v3 i, v3 o) { bool ok; return utia_eval_t<false>(b, i, o, ok); }
 
 // ------------------------------------------------------------------ per-pair params / beckmann::lrep
 // params::pdfparams(ax, ay, rho, tx, ty) -> the members eval needs (dj_brdf.h:1437-1474)

@@ -56,6 +56,7 @@ struct djb_ctx {
 	int merl_exact_only;      // DJB_OPT_MERL_EXACT_ONLY
 	int aniso_qf2_aligned = 0; // DJB_OPT_ANISO_QF2_ALIGNED
 	int fit_files_dense = 0;   // DJB_OPT_FIT_FILES_DENSE
+	int utia_exact_only = 0;   // DJB_OPT_UTIA_EXACT_ONLY: utia eval batches run k_eval<UTIA> (one kernel, exact fall-backs inline) instead of the two tiers
 	int scalar_on_device = 0;  // DJB_OPT_SCALAR_ON_DEVICE: scalar-size host calls go through the GPU too (A/B testing)
 	// HBM staging blocks of the DJB_MEM_HOST path, recycled across calls (hipMalloc costs more than
 	// a small batch); bounded by POOL_MAX_BYTES
@@ -745,6 +746,28 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 			auto off = [&](const View &v) { return View{ v.x + lo * v.stride, v.y + lo * v.stride, v.z + lo * v.stride, v.stride }; };
 			View oi = off(vi), oo = off(vo), ou = (want & 3) ? off(vout) : vout;
 			HIP_TRY(djbk::launch_merl_twotier(ctx->stream, b->dev, m, oi, oo, ou, dpdf ? dpdf + lo : nullptr, want,
+			                                  list, (unsigned int)cap, count));
+		}
+		return sg.finish();
+	}
+	if (b->dev.kind == DJB_KIND_UTIA && (want & 3) && !ctx->utia_exact_only) {
+		// two-tier (djb_kernels_eval.hip): pair indices travel as uint32, so very large batches are chunked; the
+		// worklist (16-byte header + 4 bytes per entry; ~2e-5 of the pairs need it) shares the context's scratch
+		const long long CH = 1LL << 31;
+		for (long long lo = 0; lo < n; lo += CH) {
+			long long m = n - lo < CH ? n - lo : CH;
+			size_t cap = (size_t)(m / 256 + 4096);
+			size_t need = 16 + 4 * cap;
+			if (ctx->scratch_bytes < need) {
+				HIP_TRY(hipStreamSynchronize(ctx->stream));
+				if (ctx->scratch) (void)hipFree(ctx->scratch);
+				ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+				HIP_TRY(hipMalloc(&ctx->scratch, need));
+				ctx->scratch_bytes = need;
+			}
+			unsigned int *count = (unsigned int *)ctx->scratch, *list = count + 4;
+			auto off = [&](const View &v) { return View{ v.x + lo * v.stride, v.y + lo * v.stride, v.z + lo * v.stride, v.stride }; };
+			HIP_TRY(djbk::launch_utia_twotier(ctx->stream, b->dev, m, off(vi), off(vo), off(vout), dpdf ? dpdf + lo : nullptr, want,
 			                                  list, (unsigned int)cap, count));
 		}
 		return sg.finish();
@@ -1864,6 +1887,7 @@ try {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	if (option == DJB_OPT_MERL_EXACT_ONLY) { ctx->merl_exact_only = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_ANISO_QF2_ALIGNED) { ctx->aniso_qf2_aligned = value != 0; return DJB_OK; }
+	if (option == DJB_OPT_UTIA_EXACT_ONLY) { ctx->utia_exact_only = value != 0; return DJB_OK; }
 	return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown option %d", option);
 }
 DJB_ABI_CATCH
@@ -1950,7 +1974,7 @@ try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_HOST);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
-	if (fn < 0 || fn > 4 || !x || !y || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid selftest arguments");
+	if (fn < 0 || fn > 7 || !x || !y || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid selftest arguments");
 	if (n == 0) return DJB_OK;
 	const size_t nb = sizeof(double) * (size_t)n;
 	double *d = nullptr;

@@ -54,6 +54,10 @@ hipError_t launch_gen_directions(hipStream_t s, long long n, uint32_t seed, unsi
                                  const View &out);
 hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsigned long long start,
                                float *out);
+// utia eval / evalp (want 1, 2, 5, 6), two-tier: k_eval_utia_t1 (no exact fall-backs; lists the undecided pairs) +
+// k_eval_utia_fix for the pairs of the worklist (count: 16 bytes, list: cap entries)
+hipError_t launch_utia_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o, const View &out,
+                               float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count);
 hipError_t launch_guard_selftest(hipStream_t s, long long n, uint32_t seed, unsigned long long *counters);
 hipError_t launch_libm_probe(hipStream_t s, int fn, long long n, const double *x, const double *y, double *out);
 hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n, void *out);

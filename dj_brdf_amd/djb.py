@@ -1027,6 +1027,12 @@ def set_scalar_on_device(ctx: Context, on: bool):
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(3), C.c_int(int(on))))
 
 
+def set_utia_exact_only(ctx: Context, on: bool):
+    """utia eval / evalp batches run the one-kernel form with the exact fall-backs inline (DJB_OPT_UTIA_EXACT_ONLY)
+    instead of the two-tier kernel; same bits."""
+    _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(5), C.c_int(int(on))))
+
+
 def set_aniso_qf2_aligned(ctx: Context, on: bool):
     """tabular_anisotropic objects built afterwards keep the rows of the conditional quantile table aligned
     (DJB_OPT_ANISO_QF2_ALIGNED) instead of reproducing the reference's shifted vector."""
@@ -1044,10 +1050,10 @@ def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):
 
 
 def selftest_libm(fn: str, x, y=None, ctx: Optional[Context] = None):
-    """The kernels' restatement of a host libm function (exp, pow, logf, expf, powf), evaluated on the GPU
+    """The kernels' restatement of a host libm function (exp, pow, logf, expf, powf, atan2(x, y)), evaluated on the GPU
     (djb_selftest_libm); float functions take and return values representable as float."""
     ctx = ctx or default_context()
-    code = {"exp": 0, "pow": 1, "logf": 2, "expf": 3, "powf": 4}[fn]
+    code = {"exp": 0, "pow": 1, "logf": 2, "expf": 3, "powf": 4, "atan2": 5, "atan2_f32": 6, "atan2_deg_f32": 7}[fn]
     x = np.ascontiguousarray(x, np.float64).reshape(-1)
     y = np.ascontiguousarray(x if y is None else y, np.float64).reshape(-1)
     out = np.empty_like(x)

@@ -2057,11 +2057,114 @@ static double glibc_pow(double x, double y)
 	}
 	return glibc_exp_core(ehi, elo, special);
 }
+/* ------------------------------------------------------------------ glibc 2.35 double atan2, restated
+ * __ieee754_atan2 of sysdeps/ieee754/dbl-64/e_atan2.c (IBM Accurate Mathematical Library; since glibc 2.34 without the
+ * multi-precision fall-back), as the x86-64 FMA ifunc variant of this image computes it: branch structure, operation
+ * order and the placement of every fused multiply-add read off the disassembly of __ieee754_atan2_fma; the 241 x 7
+ * table cij out of libm.so.6 (tools/extract_glibc_dbl64_tables.py).  u = min / max of the magnitudes by an IEEE division,
+ * du its residual; u < 1/16: odd polynomial d3 .. d13; else Taylor expansion about the table point next to u; then
+ * the quadrant identity with the two-term pi/2 or pi.  Complete (zeros, infinities, NaNs, the exponent-difference
+ * shortcuts, the 2^+-500 rescaling).  The default rounding mode is assumed (the original saves and restores it).
+ * o_libm_f64 / o_glibc_f64: fn 2 = atan2(x[k] = y-argument, y[k] = x-argument). */
+static double glibc_atan2(double y, double x)
+{
+	static const double d3 = -0x1.5555555555555p-2, d5 = 0x1.99999999997fdp-3, d7 = -0x1.24924923f7603p-3,
+	                    d9 = 0x1.c71c6e5129a3bp-4, d11 = -0x1.7458022b13c25p-4, d13 = 0x1.375f08b31cbcep-4,
+	                    hpi = 0x1.921fb54442d18p+0, hpi1 = 0x1.1a62633145c07p-54, opi = 0x1.921fb54442d18p+1,
+	                    opi1 = 0x1.1a62633145c07p-53, qpi = 0x1.921fb54442d18p-1, tqpi = 0x1.2d97c7f3321d2p+1,
+	                    twom500 = 0x1p-500, two500 = 0x1p+500, inv16 = 0x1p-4, TWO52 = 0x1p+52, TWO8 = 0x1p+8;
+	uint64_t bx, by;
+	memcpy(&bx, &x, 8); memcpy(&by, &y, 8);
+	const int32_t ux = (int32_t)(bx >> 32), uy = (int32_t)(by >> 32);
+	const uint32_t dx = (uint32_t)bx, dy = (uint32_t)by;
+	/* x = NaN or y = NaN */
+	if ((ux & 0x7ff00000) == 0x7ff00000 && (((ux & 0xfffff) | dx) != 0)) return x + y;
+	if ((uy & 0x7ff00000) == 0x7ff00000 && (((uy & 0xfffff) | dy) != 0)) return y + y;
+	/* y = +-0 */
+	if (uy == 0 && dy == 0) return ux < 0 ? opi : 0.0;
+	if ((uint32_t)uy == 0x80000000u && dy == 0) return ux < 0 ? -opi : -0.0;
+	/* x = +-0 */
+	if (x == 0.0) return uy < 0 ? -hpi : hpi;
+	/* x = +-Inf */
+	if (ux == 0x7ff00000 && dx == 0) {
+		if (uy == 0x7ff00000 && dy == 0) return qpi;
+		if ((uint32_t)uy == 0xfff00000u && dy == 0) return -qpi;
+		return uy < 0 ? -0.0 : 0.0;
+	}
+	if ((uint32_t)ux == 0xfff00000u && dx == 0) {
+		if (uy == 0x7ff00000 && dy == 0) return tqpi;
+		if ((uint32_t)uy == 0xfff00000u && dy == 0) return -tqpi;
+		return uy < 0 ? -opi : opi;
+	}
+	/* y = +-Inf */
+	if (uy == 0x7ff00000 && dy == 0) return hpi;
+	if ((uint32_t)uy == 0xfff00000u && dy == 0) return -hpi;
+	double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+	const int32_t de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
+	/* either x/y or y/x is very close to zero */
+	if (de >= 0x3900000) return y > 0.0 ? hpi : -hpi;
+	if (de <= -0x3900000) {
+		if (x > 0.0) return copysign(ay / ax, y);
+		return y > 0.0 ? opi : -opi;
+	}
+	if (ax < twom500 || ay < twom500) { ax *= two500; ay *= two500; }
+	if (ax > two500 || ay > two500) { ax *= twom500; ay *= twom500; }
+	double u, du, v, vv;
+	const int y_lt_x = ay < ax;
+	if (y_lt_x) { u = ay / ax; v = ax * u; vv = fma(ax, u, -v); du = ((ay - v) - vv) / ax; }
+	else { u = ax / ay; v = ay * u; vv = fma(ay, u, -v); du = ((ax - v) - vv) / ay; }
+	double z;
+	if (u < inv16) {
+		v = u * u;
+		double p = fma(d13, v, d11);
+		p = fma(p, v, d9); p = fma(p, v, d7); p = fma(p, v, d5); p = fma(p, v, d3);
+		if (x > 0.0) {
+			if (y_lt_x) z = u + fma(u * v, p, du);                                     /* (i)   atan(ay/ax) */
+			else {                                                                     /* (ii)  pi/2 - atan(ax/ay) */
+				const double zz = (u * v) * p, t2 = hpi - u;
+				const double cor = hpi > fabs(u) ? (hpi - t2) - u : hpi - (u + t2);
+				z = (((cor + hpi1) - du) - zz) + t2;
+			}
+		} else {
+			if (!y_lt_x && ay > ax) {                                                  /* (iii) pi/2 + atan(ax/ay) */
+				const double zz = (v * u) * p, t2 = u + hpi;
+				const double cor = hpi > fabs(u) ? (hpi - t2) + u : (u - t2) + hpi;
+				z = (((cor + hpi1) + du) + zz) + t2;
+			} else {                                                                   /* (iv)  pi - atan(ay/ax) */
+				const double zz = (v * u) * p, t2 = opi - u;
+				const double cor = opi > fabs(u) ? (opi - t2) - u : opi - (t2 + u);
+				z = (((cor + opi1) - du) - zz) + t2;
+			}
+		}
+		return copysign(z, y);
+	}
+	const int i = (int)(fma(u, TWO8, TWO52) - TWO52) - 16;
+	const double *c = DJB_GLIBC_ATAN_CIJ + 7 * i;
+	const double t3 = u - c[0];
+	if (x > 0.0 && y_lt_x) {                                                           /* (i) */
+		const double w = du + t3;
+		const double dv = fabs(t3) > fabs(du) ? (t3 - w) + du : (du - w) + t3;
+		double p = fma(c[6], w, c[5]);
+		p = fma(p, w, c[4]); p = fma(p, w, c[3]);
+		p = (w * w) * p;
+		p = fma(dv, c[2], p);
+		z = fma(w, c[2], p) + c[1];
+		return copysign(z, y);
+	}
+	const double w = t3 + du;
+	double p = fma(c[6], w, c[5]);
+	p = fma(p, w, c[4]); p = fma(p, w, c[3]); p = fma(p, w, c[2]);
+	if (x > 0.0) z = (hpi - c[1]) + fma(-w, p, hpi1);                                    /* (ii) */
+	else if (!y_lt_x && ay > ax) z = (hpi + c[1]) + fma(w, p, hpi1);                     /* (iii) */
+	else z = (opi - c[1]) + fma(-w, p, opi1);                                            /* (iv) */
+	return copysign(z, y);
+}
+
 void o_libm_f64(int fn, int64_t n, const double *x, const double *y, double *out)
 {
-	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? exp(x[k]) : pow(x[k], y[k]);
+	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? exp(x[k]) : fn == 1 ? pow(x[k], y[k]) : atan2(x[k], y[k]);
 }
 void o_glibc_f64(int fn, int64_t n, const double *x, const double *y, double *out)
 {
-	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? glibc_exp(x[k]) : glibc_pow(x[k], y[k]);
+	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? glibc_exp(x[k]) : fn == 1 ? glibc_pow(x[k], y[k]) : glibc_atan2(x[k], y[k]);
 }

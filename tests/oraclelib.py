@@ -341,11 +341,11 @@ class CheckerLib:
         return out
 
     def libm_f64(self, fn, x, y=None):
-        """host libm exp (0) / pow (1): what the reference's unqualified calls resolve to"""
+        """host libm exp (0) / pow (1) / atan2(x, y) (2): what the reference's unqualified calls resolve to"""
         return self._f64("libm_f64", fn, x, y)
 
     def glibc_f64(self, fn, x, y=None):
-        """restatement of glibc 2.35's exp / pow (the arithmetic the HIP kernels run)"""
+        """restatement of glibc 2.35's exp / pow / atan2 (the arithmetic the HIP kernels run)"""
         return self._f64("glibc_f64", fn, x, y)
 
     def erf(self, x):

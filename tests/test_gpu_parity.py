@@ -114,13 +114,13 @@ def test_microfacet_sample(gpu_ctx, oracle, dirs, ndf):
 
 
 def test_device_libm_restatements(gpu_ctx, oracle):
-    """The kernels' own copies of glibc's exp / pow (double) and logf / expf / powf (float), evaluated on the GPU
+    """The kernels' own copies of glibc's exp / pow / atan2 (double) and logf / expf / powf (float), evaluated on the GPU
     (djb_selftest_libm), against the libm of this host -- what the reference calls.  Every bit."""
     from test_oracle_golden import libm_f64_cases
     for fn, sets in libm_f64_cases(n=1 << 19).items():
         for x, y in sets:
             want = oracle.libm_f64(fn, x, y)
-            got = djb.selftest_libm(("exp", "pow")[fn], x, y, ctx=gpu_ctx)
+            got = djb.selftest_libm(("exp", "pow", "atan2")[fn], x, y, ctx=gpu_ctx)
             same = (want.view(np.uint64) == got.view(np.uint64)) | (np.isnan(want) & np.isnan(got))
             if fn == 1:      # pow: negative and subnormal bases are left to the device libm (never reached by the BRDF code): 1 ulp
                 other = ((np.abs(x) < 2.3e-308) & (x != 0)) | (x < 0)
@@ -128,6 +128,27 @@ def test_device_libm_restatements(gpu_ctx, oracle):
                     close = np.abs(got - want) <= 4 * np.spacing(np.abs(want))
                 same |= other & (close | (np.isinf(want) & (want == got)))
             assert same.all(), (fn, int((~same).sum()), x[~same][:3], y[~same][:3] if y is not None else None)
+    # the kernels' float(atan2(y, x)) and float(r2d * atan2(y, x)) of float arguments (device libm first, glibc's algorithm
+    # next to a float rounding boundary: djb_device.hpp atan2_to_f32) against the same expressions with the host libm
+    rng = np.random.default_rng(5)
+    n = 1 << 21
+    f32 = lambda a: np.asarray(a, np.float32)
+    anyf = lambda: rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    xx = f32(rng.uniform(-4, 4, n))
+    r2d = np.float64(np.float32(180.0 / np.pi))
+    with np.errstate(all="ignore"):
+        fams = [(f32(rng.uniform(-1, 1, n)), f32(rng.uniform(-1, 1, n))), (anyf(), anyf()),
+                (f32(rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-60, 60, n)), f32(rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-60, 60, n))),
+                (np.nextafter(xx, np.float32(np.inf)) * f32(np.where(rng.random(n) < 0.5, 1, -1)), xx),
+                (f32(xx * 2.0 ** rng.integers(-70, -20, n)), xx), (xx, f32(xx * 2.0 ** rng.integers(-70, -20, n))),
+                (f32([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3e38] * 12),
+                 f32(np.repeat([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3e38, 1e-30, -2.5], 12)))]
+        for y, x in fams:
+            a = oracle.libm_f64(2, y.astype(np.float64), x.astype(np.float64))
+            for name, want in (("atan2_f32", a.astype(np.float32)), ("atan2_deg_f32", (r2d * a).astype(np.float32))):
+                got = djb.selftest_libm(name, y, x, ctx=gpu_ctx).astype(np.float32)
+                same = (want.view(np.uint32) == got.view(np.uint32)) | (np.isnan(want) & np.isnan(got))
+                assert same.all(), (name, int((~same).sum()), y[~same][:3], x[~same][:3], want[~same][:3], got[~same][:3])
     rng = np.random.default_rng(3)
     n = 1 << 19
     anyf = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)

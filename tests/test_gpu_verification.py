@@ -258,3 +258,31 @@ def test_trig_sweep_negative_control(gpu_ctx):
     assert d != h and 0x3F000000 <= x < 0x3F000000 + (1 << 20)
     with pytest.raises(djb.exc):
         djb.selftest_trig_sweep("cos", 0x3F000000, 16, host_fn="cos_d", ctx=gpu_ctx)
+
+
+def test_utia_two_tier_equals_the_one_kernel_form(gpu_ctx):
+    """utia eval / evalp batches run two tiers (tier 1 without glibc's atan2 behind the azimuths, a worklist of the pairs
+    next to a float rounding boundary, tier 2 = the exact form); DJB_OPT_UTIA_EXACT_ONLY runs the one-kernel form.  Same
+    bits on 5e7 pairs, eval and evalp + pdf, dense and strided views."""
+    import torch
+    n = 50_000_000
+    i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
+    u = djb.utia.from_table(synth.utia_table_smooth(), ctx=gpu_ctx)
+    try:
+        for op in ("eval", "evalp"):
+            djb.set_utia_exact_only(gpu_ctx, False)
+            two = getattr(u, op)(i, o)
+            djb.set_utia_exact_only(gpu_ctx, True)
+            one = getattr(u, op)(i, o)
+            assert torch.equal(two.view(torch.int32), one.view(torch.int32)), op
+            assert float(two.abs().sum()) > 0
+        # strided (array-of-vec3) views take the non-dense instantiation
+        m = 1_000_000
+        ia = i[:, :m].t().contiguous(); oa = o[:, :m].t().contiguous()
+        djb.set_utia_exact_only(gpu_ctx, False)
+        two = u.eval(ia, oa)
+        djb.set_utia_exact_only(gpu_ctx, True)
+        one = u.eval(ia, oa)
+        assert torch.equal(two.view(torch.int32), one.view(torch.int32))
+    finally:
+        djb.set_utia_exact_only(gpu_ctx, False)

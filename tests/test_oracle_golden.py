@@ -95,7 +95,7 @@ def test_glibc_float_libm_restatement(oracle):
 
 
 def libm_f64_cases(n=1 << 20, seed=20240918):
-    """argument families for exp / pow: the ranges the BRDF code feeds them, random bit patterns, specials"""
+    """argument families for exp / pow / atan2: the ranges the BRDF code feeds them, random bit patterns, specials"""
     rng = np.random.default_rng(seed)
     bits64 = lambda: rng.integers(0, 1 << 64, n, dtype=np.uint64).view(np.float64)
     sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
@@ -112,12 +112,36 @@ def libm_f64_cases(n=1 << 20, seed=20240918):
                 (1 + rng.uniform(0, 3000, n) * rng.uniform(0, 1, n), rng.uniform(0.1, 3, n)),   # abc ndf, :3610
                 (rng.uniform(0, 1, n), np.full(n, 5.0)), (rng.uniform(0, 1, n), np.full(n, 6.0)),   # :1326, :2503
                 (rng.uniform(0, 100, n), rng.uniform(-400, 400, n))],
+            2: atan2_cases(rng, n, sp),
         }
 
 
+def atan2_cases(rng, n, sp):
+    """(y, x) families for atan2: every special pairing, random bit patterns, direction components as floats (what the
+    BRDF code feeds it) and doubles, wide exponent gaps (the +-57 binade shortcuts, the 2^+-500 rescaling), ratios next to
+    1/16 and to the 241 table nodes, the diagonals and the axes"""
+    bits64 = lambda: rng.integers(0, 1 << 64, n, dtype=np.uint64).view(np.float64)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    e = lambda lo, hi: 2.0 ** rng.integers(lo, hi, n)
+    sgn = lambda: np.where(rng.random(n) < 0.5, 1.0, -1.0)
+    sp2 = np.concatenate([sp, [0.0625, 0.06249999999999999, 0.0625000000000001, 1e-160, 1e160, 3.0, -3.0, 1.4e-45, -5e-324]])
+    xx = f32(rng.uniform(-4, 4, n))
+    return [(np.repeat(sp2, sp2.size), np.tile(sp2, sp2.size)), (bits64(), bits64()),
+            (f32(rng.uniform(-1, 1, n)), f32(rng.uniform(-1, 1, n))), (rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)),
+            (rng.uniform(-1, 1, n) * e(-600, 600), rng.uniform(-1, 1, n) * e(-600, 600)),
+            (f32(rng.uniform(-1, 1, n) * e(-60, 60)), f32(rng.uniform(-1, 1, n) * e(-60, 60))),
+            (f32(rng.uniform(0.9, 1.1, n) * (rng.integers(1, 260, n) / 256.0)), sgn()),
+            (np.nextafter(xx, np.inf) * sgn(), xx), (f32(xx * 2.0 ** rng.integers(-70, -20, n)), xx), (xx, f32(xx * 2.0 ** rng.integers(-70, -20, n))),
+            (rng.uniform(1, 2, n) * e(55, 60), rng.uniform(-2, 2, n)), (rng.uniform(-2, 2, n), rng.uniform(1, 2, n) * e(55, 60) * sgn()),
+            (rng.integers(1, 1 << 52, n).astype(np.uint64).view(np.float64), rng.integers(1, 1 << 52, n).astype(np.uint64).view(np.float64) * sgn()),
+            (rng.uniform(0.5, 2, n) * 2.0 ** rng.choice([-501, -500, -499, 499, 500, 501], n),
+             rng.uniform(-2, 2, n) * 2.0 ** rng.choice([-501, -500, -499, 499, 500, 501], n))]
+
+
 def test_glibc_double_libm_restatement(oracle):
-    """Same for the double exp / pow the reference's unqualified calls resolve to (oracle/djb_oracle.c
-    glibc_exp / glibc_pow; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma / __pow_fma)."""
+    """Same for the double exp / pow / atan2 the reference's unqualified calls resolve to (oracle/djb_oracle.c
+    glibc_exp / glibc_pow / glibc_atan2; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma /
+    __pow_fma / __ieee754_atan2_fma).  fn 2: x = the y argument of atan2, y = its x argument."""
     for fn, sets in libm_f64_cases().items():
         for x, y in sets:
             want, got = oracle.libm_f64(fn, x, y), oracle.glibc_f64(fn, x, y)

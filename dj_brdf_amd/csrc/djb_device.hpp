@@ -229,11 +229,13 @@ DJB_DEV float fdiv_r(float a, float b, double R)
 DJB_DEV v3 normalize(v3 v) { return scale(inversesqrt_(dot(v, v)), v); }              // dj_brdf.h:630
 DJB_DEV float intensity(v3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z; } // dj_brdf.h:69
 
+DJB_DEV double glibc_sin(double x);   // the host libm's sin / cos, for the places that keep the double (defined with the
+DJB_DEV double glibc_cos(double x);   // other glibc restatements below); the float -> float sites sin_f / cos_f are swept exhaustively instead
 // vec3(theta, phi), dj_brdf.h:589-595
 DJB_DEV v3 from_angles(float theta, float phi)
 {
 	float s = sin_f(theta);
-	return mk(F(D(s) * cos(D(phi))), F(D(s) * sin(D(phi))), cos_f(theta));
+	return mk(F(D(s) * glibc_cos(D(phi))), F(D(s) * glibc_sin(D(phi))), cos_f(theta));
 }
 
 typedef unsigned int LdsTab;   // where a device kernel staged a libm table (0 = the global copy); unused on the host
@@ -259,6 +261,8 @@ DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 DJB_DEV double glibc_exp(double x, LdsTab = 0u) { return exp(x); }
 DJB_DEV double glibc_pow(double x, double y, LdsTab = 0u, LdsTab = 0u) { return pow(x, y); }
 DJB_DEV double glibc_atan2(double y, double x) { return atan2(y, x); }
+DJB_DEV double glibc_sin(double x) { return sin(x); }
+DJB_DEV double glibc_cos(double x) { return cos(x); }
 DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * atan2(D(y), D(x))); }
 #else
 // ---- glibc 2.35's double exp / pow, restated --------------------------------------------------------
@@ -524,6 +528,95 @@ DJB_DEV float atan2_to_f32(float y, float x, double scale)
 	return r;
 }
 
+// ---- glibc 2.35's double sin / cos, restated -------------------------------------------------------
+// __sin / __cos of sysdeps/ieee754/dbl-64/s_sin.c (IBM Accurate Mathematical Library as cleaned up in glibc 2.28: no
+// slow paths) as the x86-64 FMA ifunc variants compute them -- operation order and fusion read off __sin_fma /
+// __cos_fma.  |x| < 0.126: odd Taylor polynomial; else x = x_k + r with x_k = k / 128 out of the 440-entry
+// __sincostab (sin and cos of x_k as double-doubles) and short polynomials in r; 0.855 < |x| < 2.43 through
+// pi/2 - |x|; up to 105414350 the three-constant reduction by pi/2.  Beyond that (__branred) the device libm answers:
+// the BRDF code's angles never get there.  Pinned against the host libm in oracle/ (0 mismatches over 7.5e7 arguments
+// of every class) and, as compiled here, in tests/test_gpu_parity.py::test_device_libm_restatements.  Used where the
+// reference keeps the double (float(double(s) * cos(double(phi))) in vec3(theta, phi) and the samplers, the sigma
+// integrands of the fitters): those values are the reference's by construction.
+DJB_DEV double glibc_do_sin(double x, double dx)                                      // sin(x + dx), |x| < 0.855
+{
+	constexpr double sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7, cs2 = 0.5, cs4 = -0x1.5555555555535p-5,
+	                 cs6 = 0x1.6c16bedd9e239p-10, s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ecep-7,
+	                 s3 = -0x1.a01a019db08b8p-13, s4 = 0x1.71de27b9a7ed9p-19, s5 = -0x1.addffc2fcdf59p-26, big = 0x1.8p+45;
+	const double ax = x < 0.0 ? -x : x;
+	if (ax < 0.126) {
+		const double xx = x * x;
+		double p = __builtin_fma(s5, xx, s4);
+		p = __builtin_fma(p, xx, s3); p = __builtin_fma(p, xx, s2); p = __builtin_fma(p, xx, s1);
+		return x + __builtin_fma(__builtin_fma(p, x, -(0.5 * dx)), xx, dx);
+	}
+	if (x <= 0.0) dx = -dx;
+	const double u = big + ax;
+	const double *T = DJB_GLIBC_SINCOS_TAB + 4 * __double2loint(u);
+	const double r = ax - (u - big), xx = r * r;
+	const double s = r + __builtin_fma(r * xx, __builtin_fma(sn5, xx, sn3), dx);
+	const double c = __builtin_fma(r, dx, xx * __builtin_fma(__builtin_fma(cs6, xx, cs4), xx, cs2));
+	const double sn = T[0], ssn = T[1], cs = T[2], ccs = T[3];
+	const double cor = __builtin_fma(s, cs, __builtin_fma(-c, sn, __builtin_fma(s, ccs, ssn)));
+	return __builtin_copysign(sn + cor, x);
+}
+DJB_DEV double glibc_do_cos(double x, double dx)                                      // cos(x + dx), |x| < 0.855
+{
+	constexpr double sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7, cs2 = 0.5, cs4 = -0x1.5555555555535p-5,
+	                 cs6 = 0x1.6c16bedd9e239p-10, big = 0x1.8p+45;
+	if (x < 0.0) dx = -dx;
+	const double ax = x < 0.0 ? -x : x, u = big + ax;
+	const double *T = DJB_GLIBC_SINCOS_TAB + 4 * __double2loint(u);
+	const double r = (ax - (u - big)) + dx, xx = r * r;
+	const double s = __builtin_fma(r * xx, __builtin_fma(sn5, xx, sn3), r);
+	const double c = xx * __builtin_fma(__builtin_fma(cs6, xx, cs4), xx, cs2);
+	const double sn = T[0], ssn = T[1], cs = T[2], ccs = T[3];
+	const double cor = __builtin_fma(-s, sn, __builtin_fma(-c, cs, __builtin_fma(-s, ssn, ccs)));
+	return cs + cor;
+}
+// reduce_sincos: x = n pi/2 + a + da, |a| <= pi/4, for 2.43 < |x| < 105414350
+DJB_DEV int glibc_reduce_sincos(double x, double &a, double &da)
+{
+	constexpr double toint = 0x1.8p+52, hpinv = 0x1.45f306dc9c883p-1, mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde973c000000p-27,
+	                 pp3 = -0x1.cb3b398000000p-55, pp4 = -0x1.d747f23e32ed7p-83;
+	const double t = __builtin_fma(x, hpinv, toint), xn = t - toint;
+	const double y = __builtin_fma(-xn, mp2, __builtin_fma(-xn, mp1, x));
+	const double t2 = __builtin_fma(-xn, pp3, y);
+	double db = __builtin_fma(-pp3, xn, y - t2);
+	const double b = __builtin_fma(-xn, pp4, t2);
+	db = db + __builtin_fma(-xn, pp4, t2 - b);
+	a = b; da = db;
+	return __double2loint(t) & 3;
+}
+DJB_DEV double glibc_do_sincos(double a, double da, int n)
+{
+	const double r = (n & 1) ? glibc_do_cos(a, da) : glibc_do_sin(a, da);
+	return (n & 2) ? -r : r;
+}
+DJB_DEV double glibc_sin(double x)
+{
+	constexpr double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+	const int k = __double2hiint(x) & 0x7fffffff;
+	if (k < 0x3e500000) return x;                                                       // |x| < 2^-26
+	if (k < 0x3feb6000) return glibc_do_sin(x, 0.0);                                    // |x| < 0.855469
+	if (k < 0x400368fd) return __builtin_copysign(glibc_do_cos(hp0 - (x < 0.0 ? -x : x), hp1), x);   // |x| < 2.426265
+	if (k < 0x419921fb) { double a, da; const int n = glibc_reduce_sincos(x, a, da); return glibc_do_sincos(a, da, n); }
+	return sin(x);                                                                      // __branred / Inf / NaN: device libm
+}
+DJB_DEV double glibc_cos(double x)
+{
+	constexpr double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+	const int k = __double2hiint(x) & 0x7fffffff;
+	if (k < 0x3e400000) return 1.0;                                                     // |x| < 2^-27
+	if (k < 0x3feb6000) return glibc_do_cos(x, 0.0);
+	if (k < 0x400368fd) {
+		const double y = hp0 - (x < 0.0 ? -x : x), a = y + hp1, da = (y - a) + hp1;
+		return glibc_do_sin(a, da);
+	}
+	if (k < 0x419921fb) { double a, da; const int n = glibc_reduce_sincos(x, a, da); return glibc_do_sincos(a, da, n + 1); }
+	return cos(x);
+}
+
 #endif
 
 // A&S 7.1.26 as the reference writes it, dj_brdf.h:667-688
@@ -708,8 +801,8 @@ DJB_DEV void uniform_to_concentric(float u1, float u2, float &x, float &y)
 	if (r1 == 0 && r2 == 0) { r = phi = 0; }
 	else if (r1 * r1 > r2 * r2) { r = r1; phi = F((DJB_PI / 4.0) * D(r2 / r1)); }
 	else { r = r2; phi = F((DJB_PI / 2.0) - D(r1 / r2) * (DJB_PI / 4.0)); }
-	x = F(D(r) * cos(D(phi)));
-	y = F(D(r) * sin(D(phi)));
+	x = F(D(r) * glibc_cos(D(phi)));
+	y = F(D(r) * glibc_sin(D(phi)));
 }
 
 // Rodrigues rotation about +z / +y with the reference's exact operation order (dj_brdf.h:754-765).
@@ -1127,13 +1220,13 @@ DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &
 		float phi = aniso_qf1(b, u1);
 		float theta = aniso_qf2(b, u2, phi);
 		float tan_theta = tan_f(theta);
-		xs = F(D(-tan_theta) * cos(D(phi)));
-		ys = F(D(-tan_theta) * sin(D(phi)));
+		xs = F(D(-tan_theta) * glibc_cos(D(phi)));
+		ys = F(D(-tan_theta) * glibc_sin(D(phi)));
 	} else {
 		float phi_h = F(D(u1) * DJB_PI * 2.0);
 		float r_h = tab_qf_radial(b, u2);
-		xs = F(D(r_h) * cos(D(phi_h)));
-		ys = F(D(r_h) * sin(D(phi_h)));
+		xs = F(D(r_h) * glibc_cos(D(phi_h)));
+		ys = F(D(r_h) * glibc_sin(D(phi_h)));
 	}
 }
 

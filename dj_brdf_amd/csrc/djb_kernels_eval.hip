@@ -606,7 +606,9 @@ __global__ __launch_bounds__(BLOCK) void k_libm_probe(int fn, long long n, const
 		case 4: r = D(glibc_powf(F(x[k]), F(y[k]), gt)); break;
 		case 5: r = glibc_atan2(x[k], y[k]); break;
 		case 6: r = D(atan2_to_f32(F(x[k]), F(y[k]), 1.0)); break;
-		default: r = D(atan2_to_f32(F(x[k]), F(y[k]), D(F(180.0 / DJB_PI)))); break;
+		case 7: r = D(atan2_to_f32(F(x[k]), F(y[k]), D(F(180.0 / DJB_PI)))); break;
+		case 8: r = glibc_sin(x[k]); break;
+		default: r = glibc_cos(x[k]); break;
 		}
 		out[k] = r;
 	}

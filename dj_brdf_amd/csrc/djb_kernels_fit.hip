@@ -188,11 +188,11 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 
 	// ================================================================ compute_sigma (dj_brdf.h:2348-2386)
 	for (int k = tid; k < NPHI_SIGMA; k += FIT_BLOCK)
-		cphid[k] = cos(D(F(D((float)k / (float)NPHI_SIGMA) * 2.0 * DJB_PI)));
+		cphid[k] = glibc_cos(D(F(D((float)k / (float)NPHI_SIGMA) * 2.0 * DJB_PI)));
 	for (int k = tid; k < NTHETA_SIGMA; k += FIT_BLOCK) {
 		float u = (float)k / (float)NTHETA_SIGMA;
 		float th = F(D(u * u) * DJB_PI * 0.5);
-		ui[k] = u; sh[k] = sin_f(th); cthd[k] = cos(D(th));
+		ui[k] = u; sh[k] = sin_f(th); cthd[k] = glibc_cos(D(th));
 	}
 	for (int e = tid; e < NNODE_SIGMA; e += FIT_BLOCK) {   // ndf(vec3(theta_h, phi_h)): theta_k-independent
 		int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;

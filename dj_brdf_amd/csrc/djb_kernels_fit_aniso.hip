@@ -63,13 +63,13 @@ __global__ __launch_bounds__(BLOCK) void ka_setup(Brdf src, Params std_p, AnisoS
 	float theta = F(D((float)i1 / (float)w) * 0.5 * DJB_PI), phi = F(D((float)i2 / (float)h) * 2.0 * DJB_PI);
 	float st = sin_f(theta);
 	float zo = cos_f(theta);
-	S.zo[a] = zo; S.xo[a] = F(D(st) * cos(D(phi))); S.yo[a] = F(D(st) * sin(D(phi)));
+	S.zo[a] = zo; S.xo[a] = F(D(st) * glibc_cos(D(phi))); S.yo[a] = F(D(st) * glibc_sin(D(phi)));
 	v3 wv = from_angles(theta, phi);
 	float fr_i = intensity(src_eval<SRC>(src, std_p, wv, wv));
 	S.k1[a] = F(D(dtheta * dphi) * (4.0 * D(fr_i) * glibc_pow(D(zo), D(5.0f))));
 	float tt = tan_f(theta);
 	S.tn[a] = tt; S.dn[a] = zo * zo;               // cos_theta * cos_theta (same float as zo)
-	S.s1[a] = F(D(-tt) * cos(D(phi))); S.s2[a] = F(D(-tt) * sin(D(phi)));
+	S.s1[a] = F(D(-tt) * glibc_cos(D(phi))); S.s2[a] = F(D(-tt) * glibc_sin(D(phi)));
 	S.v0[a] = 1.0;
 }
 
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(BLOCK) void ka_sigma_tables(AnisoScratch S, Params 
 		int i2 = e / NP_SIG, j2 = e - i2 * NP_SIG;
 		float phi_k = F(D((float)i2 / (float)S.azim) * 2.0 * DJB_PI);
 		float phi = F(D((float)j2 / (float)NP_SIG) * 2.0 * DJB_PI);
-		S.cosd[e] = cos(D(phi - phi_k));
+		S.cosd[e] = glibc_cos(D(phi - phi_k));
 	}
 	if (e < NT_SIG) {
 		float theta = F(D((float)e / (float)NT_SIG) * sqrt(DJB_PI * 0.5));
 		float ts = theta * theta;
-		S.sig_theta[e] = theta; S.sig_sin[e] = sin_f(ts); S.sig_cosd[e] = cos(D(ts));
+		S.sig_theta[e] = theta; S.sig_sin[e] = sin_f(ts); S.sig_cosd[e] = glibc_cos(D(ts));
 	}
 }
 __global__ __launch_bounds__(BLOCK) void ka_sigma_rows(AnisoScratch S)
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void ka_sigma_rows(AnisoScratch S)
 	const float dtheta = F(sqrt(DJB_PI * 0.5) / D((float)NT_SIG)), dphi = F(2.0 * DJB_PI / D((float)NP_SIG));
 	float theta_k = F(D((float)i1 / (float)w) * 0.5 * DJB_PI);
 	float cos_k = cos_f(theta_k);
-	double sin_kd = sin(D(theta_k));
+	double sin_kd = glibc_sin(D(theta_k));
 	float nint = 0.0f;
 	for (int j2 = 0; j2 < NP_SIG; ++j2) {
 		double cp = S.cosd[i2 * NP_SIG + j2];

@@ -2160,11 +2160,104 @@ static double glibc_atan2(double y, double x)
 	return copysign(z, y);
 }
 
+/* ------------------------------------------------------------------ glibc 2.35 double sin / cos, restated
+ * __sin / __cos of sysdeps/ieee754/dbl-64/s_sin.c (IBM Accurate Mathematical Library, as cleaned up in glibc 2.28:
+ * no slow paths), as the x86-64 FMA ifunc variants compute them (operation order and fusion read off __sin_fma /
+ * __cos_fma): |x| < 0.126: odd Taylor polynomial; else x = x_k + r with x_k = k/128 from the 440-entry __sincostab
+ * (sin and cos of x_k as double-doubles) and short polynomials in r; 0.855 < |x| < 2.43 through pi/2 - |x|;
+ * up to 105414350 a three-constant reduction by pi/2 (mp1, mp2, pp3, pp4); beyond that (__branred) the host libm is
+ * called -- the BRDF code never gets there.  fn 3 = sin(x[k]), 4 = cos(x[k]). */
+static const double SC_sn3 = -0x1.5555555555515p-3, SC_sn5 = 0x1.11110e829872fp-7, SC_cs2 = 0.5, SC_cs4 = -0x1.5555555555535p-5,
+                    SC_cs6 = 0x1.6c16bedd9e239p-10, SC_s1 = -0x1.5555555555555p-3, SC_s2 = 0x1.1111111110ecep-7,
+                    SC_s3 = -0x1.a01a019db08b8p-13, SC_s4 = 0x1.71de27b9a7ed9p-19, SC_s5 = -0x1.addffc2fcdf59p-26,
+                    SC_big = 0x1.8p+45, SC_hp0 = 0x1.921fb54442d18p+0, SC_hp1 = 0x1.1a62633145c07p-54;
+/* do_sin (s_sin.c): sin(x + dx), |x| < 0.855 */
+static double glibc_do_sin(double x, double dx)
+{
+	const double ax = fabs(x);
+	if (ax < 0.126) {                                   /* TAYLOR_SIN */
+		const double xx = x * x;
+		double p = fma(SC_s5, xx, SC_s4);
+		p = fma(p, xx, SC_s3); p = fma(p, xx, SC_s2); p = fma(p, xx, SC_s1);
+		return x + fma(fma(p, x, -(0.5 * dx)), xx, dx);
+	}
+	if (x <= 0.0) dx = -dx;
+	const double u = SC_big + ax;
+	uint64_t ub; memcpy(&ub, &u, 8);
+	const double *T = DJB_GLIBC_SINCOS_TAB + 4 * (int32_t)(uint32_t)ub;
+	const double r = ax - (u - SC_big), xx = r * r;
+	const double s = r + fma(r * xx, fma(SC_sn5, xx, SC_sn3), dx);
+	const double c = fma(r, dx, xx * fma(fma(SC_cs6, xx, SC_cs4), xx, SC_cs2));
+	const double sn = T[0], ssn = T[1], cs = T[2], ccs = T[3];
+	const double cor = fma(s, cs, fma(-c, sn, fma(s, ccs, ssn)));
+	return copysign(sn + cor, x);
+}
+/* do_cos: cos(x + dx), |x| < 0.855 */
+static double glibc_do_cos(double x, double dx)
+{
+	if (x < 0.0) dx = -dx;
+	const double ax = fabs(x), u = SC_big + ax;
+	uint64_t ub; memcpy(&ub, &u, 8);
+	const double *T = DJB_GLIBC_SINCOS_TAB + 4 * (int32_t)(uint32_t)ub;
+	const double r = (ax - (u - SC_big)) + dx, xx = r * r;
+	const double s = fma(r * xx, fma(SC_sn5, xx, SC_sn3), r);
+	const double c = xx * fma(fma(SC_cs6, xx, SC_cs4), xx, SC_cs2);
+	const double sn = T[0], ssn = T[1], cs = T[2], ccs = T[3];
+	const double cor = fma(-s, sn, fma(-c, cs, fma(-s, ssn, ccs)));
+	return cs + cor;
+}
+/* reduce_sincos: x = n pi/2 + a + da, |a| <= pi/4, 2.43 < |x| < 105414350 */
+static int glibc_reduce_sincos(double x, double *a, double *da)
+{
+	static const double toint = 0x1.8p+52, hpinv = 0x1.45f306dc9c883p-1, mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde973c000000p-27,
+	                    pp3 = -0x1.cb3b398000000p-55, pp4 = -0x1.d747f23e32ed7p-83;
+	const double t = fma(x, hpinv, toint), xn = t - toint;
+	uint64_t tb; memcpy(&tb, &t, 8);
+	const double y = fma(-xn, mp2, fma(-xn, mp1, x));
+	const double t2 = fma(-xn, pp3, y);
+	double db = fma(-pp3, xn, y - t2);
+	const double b = fma(-xn, pp4, t2);
+	db = db + fma(-xn, pp4, t2 - b);
+	*a = b; *da = db;
+	return (int)(tb & 3);
+}
+static double glibc_do_sincos(double a, double da, int n)
+{
+	const double r = (n & 1) ? glibc_do_cos(a, da) : glibc_do_sin(a, da);
+	return (n & 2) ? -r : r;
+}
+static double glibc_sin(double x)
+{
+	uint64_t b; memcpy(&b, &x, 8);
+	const int32_t k = (int32_t)(b >> 32) & 0x7fffffff;
+	if (k < 0x3e500000) return x;                                                   /* |x| < 2^-26 */
+	if (k < 0x3feb6000) return glibc_do_sin(x, 0.0);                                /* |x| < 0.855469 */
+	if (k < 0x400368fd) return copysign(glibc_do_cos(SC_hp0 - fabs(x), SC_hp1), x); /* |x| < 2.426265 */
+	if (k < 0x419921fb) { double a, da; const int n = glibc_reduce_sincos(x, &a, &da); return glibc_do_sincos(a, da, n); }
+	return sin(x);                                                                  /* __branred / Inf / NaN */
+}
+static double glibc_cos(double x)
+{
+	uint64_t b; memcpy(&b, &x, 8);
+	const int32_t k = (int32_t)(b >> 32) & 0x7fffffff;
+	if (k < 0x3e400000) return 1.0;                                                 /* |x| < 2^-27 */
+	if (k < 0x3feb6000) return glibc_do_cos(x, 0.0);
+	if (k < 0x400368fd) {
+		const double y = SC_hp0 - fabs(x), a = y + SC_hp1, da = (y - a) + SC_hp1;
+		return glibc_do_sin(a, da);
+	}
+	if (k < 0x419921fb) { double a, da; const int n = glibc_reduce_sincos(x, &a, &da); return glibc_do_sincos(a, da, n + 1); }
+	return cos(x);
+}
+
 void o_libm_f64(int fn, int64_t n, const double *x, const double *y, double *out)
 {
-	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? exp(x[k]) : fn == 1 ? pow(x[k], y[k]) : atan2(x[k], y[k]);
+	for (int64_t k = 0; k < n; ++k)
+		out[k] = fn == 0 ? exp(x[k]) : fn == 1 ? pow(x[k], y[k]) : fn == 2 ? atan2(x[k], y[k]) : fn == 3 ? sin(x[k]) : cos(x[k]);
 }
 void o_glibc_f64(int fn, int64_t n, const double *x, const double *y, double *out)
 {
-	for (int64_t k = 0; k < n; ++k) out[k] = fn == 0 ? glibc_exp(x[k]) : fn == 1 ? glibc_pow(x[k], y[k]) : glibc_atan2(x[k], y[k]);
+	for (int64_t k = 0; k < n; ++k)
+		out[k] = fn == 0 ? glibc_exp(x[k]) : fn == 1 ? glibc_pow(x[k], y[k]) : fn == 2 ? glibc_atan2(x[k], y[k])
+		       : fn == 3 ? glibc_sin(x[k]) : glibc_cos(x[k]);
 }

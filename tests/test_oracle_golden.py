@@ -113,7 +113,23 @@ def libm_f64_cases(n=1 << 20, seed=20240918):
                 (rng.uniform(0, 1, n), np.full(n, 5.0)), (rng.uniform(0, 1, n), np.full(n, 6.0)),   # :1326, :2503
                 (rng.uniform(0, 100, n), rng.uniform(-400, 400, n))],
             2: atan2_cases(rng, n, sp),
+            3: sincos_cases(rng, n), 4: sincos_cases(rng, n),
         }
+
+
+def sincos_cases(rng, n):
+    """arguments for sin / cos: the thresholds of s_sin.c (2^-26, 0.126, 0.855469, 2.426265, 105414350), random bit
+    patterns, angles as floats and doubles, small exponents, multiples of pi/2 +- ulps, the table nodes k/128, huge"""
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    sp = np.array([0.0, 1e-300, 5e-324, 2.0 ** -27, 2.0 ** -26, 1.4901161193847656e-08, 0.126, 0.12599999, 0.1260001, 0.855469, 0.8554687,
+                   0.85546875, 2.426265, 2.4262657, 2.4262656, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi, 105414350.0, 105414349.0,
+                   105414357.0, 1e9, 1e22, 1e300, np.inf, np.nan, 1.0, 0.5, 0.7853981633974483], np.float64)
+    return [(np.concatenate([sp, -sp]), None), (rng.integers(0, 1 << 64, n, dtype=np.uint64).view(np.float64), None),
+            (f32(rng.uniform(-7, 7, n)), None), (rng.uniform(-7, 7, n), None), (rng.uniform(-0.9, 0.9, n), None),
+            (rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-60, 0, n), None), (rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(0, 8.03, n), None),
+            (np.nextafter(rng.integers(-2000, 2000, n) * (np.pi / 2), rng.choice([-np.inf, np.inf], n)) + rng.integers(-3, 4, n) * 1e-15, None),
+            (rng.integers(-120, 120, n) / 128.0 + rng.uniform(-1e-9, 1e-9, n), None),
+            (rng.uniform(1e8, 1e300, n) * rng.choice([-1, 1], n), None)]
 
 
 def atan2_cases(rng, n, sp):
@@ -140,8 +156,9 @@ def atan2_cases(rng, n, sp):
 
 def test_glibc_double_libm_restatement(oracle):
     """Same for the double exp / pow / atan2 the reference's unqualified calls resolve to (oracle/djb_oracle.c
-    glibc_exp / glibc_pow / glibc_atan2; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma /
-    __pow_fma / __ieee754_atan2_fma).  fn 2: x = the y argument of atan2, y = its x argument."""
+    glibc_exp / glibc_pow / glibc_atan2 / glibc_sin / glibc_cos; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma /
+    __pow_fma / __ieee754_atan2_fma / __sin_fma / __cos_fma).  fn 2: x = the y argument of atan2, y = its x argument;
+    fn 3 / 4: sin / cos of x."""
     for fn, sets in libm_f64_cases().items():
         for x, y in sets:
             want, got = oracle.libm_f64(fn, x, y), oracle.glibc_f64(fn, x, y)

@@ -5,9 +5,10 @@ error ~0.51 ulp, not correctly rounded).  This script reads their two constant t
 (__exp_data, __pow_log_data: hidden symbols, located by their leading entries) and writes them, numeric data
 only, as dj_brdf_amd/csrc/djb_glibc_dbl64_tables.hpp (device) and oracle/glibc_dbl64_tables.h (checker).
 atan2 is the IBM Accurate Mathematical Library routine (sysdeps/ieee754/dbl-64/e_atan2.c; since 2.34 without its
-multi-precision fall-back): its 241 x 7 table cij (uatan.tbl) is read the same way, located by its first row.
+multi-precision fall-back): its 241 x 7 table cij (uatan.tbl) is read the same way, located by its first row; sin / cos
+(s_sin.c) read the 440-entry __sincostab.
 The operation order of the restatements (which multiply-adds are fused) was read off the disassembly of the
-x86-64 FMA ifunc variants (__exp_fma, __pow_fma, __ieee754_atan2_fma) of this image's glibc 2.35;
+x86-64 FMA ifunc variants (__exp_fma, __pow_fma, __ieee754_atan2_fma, __sin_fma, __cos_fma) of this image's glibc 2.35;
 tests/test_oracle_golden.py::test_glibc_double_libm_restatement pins them against the host libm bit for bit."""
 import os
 import struct
@@ -59,6 +60,20 @@ ATAN2_C = {"d3": "-0x1.5555555555555p-2", "d5": "0x1.99999999997fdp-3", "d7": "-
 for name, hx in ATAN2_C.items():
     assert find_all(struct.pack("<d", float.fromhex(hx))), name
 
+# __sincostab (sincostab.c, s_sin.c): 110 x {sin(x_k) hi, lo, cos(x_k) hi, lo}, x_k = k / 128
+sincos_off = None
+for off in find_all(struct.pack("<5d", 0.0, 0.0, 1.0, 0.0, float.fromhex("0x1.fffeaaaaeeeefp-8"))):
+    if abs(dbl(off + 8 * 436, 1)[0] - 0.7523107112959804) < 1e-15:
+        sincos_off = off
+assert sincos_off, "__sincostab not found"
+SINCOS_TAB = dbl(sincos_off, 440)
+SINCOS_C = {"sn3": "-0x1.5555555555515p-3", "sn5": "0x1.11110e829872fp-7", "cs2": "0x1.0000000000000p-1", "cs4": "-0x1.5555555555535p-5",
+            "cs6": "0x1.6c16bedd9e239p-10", "s1": "-0x1.5555555555555p-3", "s2": "0x1.1111111110ecep-7", "s3": "-0x1.a01a019db08b8p-13",
+            "s4": "0x1.71de27b9a7ed9p-19", "s5": "-0x1.addffc2fcdf59p-26", "hpinv": "0x1.45f306dc9c883p-1", "mp1": "0x1.921fb58000000p+0",
+            "mp2": "-0x1.dde973c000000p-27", "pp3": "-0x1.cb3b398000000p-55", "pp4": "-0x1.d747f23e32ed7p-83"}
+for name, hx in SINCOS_C.items():
+    assert find_all(struct.pack("<d", float.fromhex(hx))), name
+
 EXP_C = dbl(exp_off, 8)                       # invln2N, shift, negln2hiN, negln2loN, C2, C3, C4, C5
 EXP_TAB = u64(exp_off + 112, 256)             # {tail bits, scale bits} x 128
 POW_C = dbl(pow_off, 9)                       # ln2hi, ln2lo, A[0..6]
@@ -76,7 +91,7 @@ def emit(path, device):
     c0, c1 = ("// ", "") if device else ("/* ", " */")
     with open(path, "w") as f:
         for line in ("GENERATED by tools/extract_glibc_dbl64_tables.py from the host's libm.so.6 (GLIBC 2.35):",
-                     "the constant tables of glibc's double exp / pow / atan2 (sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c, e_atan2.c).",
+                     "the constant tables of glibc's double exp / pow / atan2 / sin / cos (sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c, e_atan2.c, s_sin.c).",
                      "Numeric data only; the algorithms are restated in djb_device.hpp / djb_oracle.c."):
             f.write(c0 + line + c1 + "\n")
         if device:
@@ -90,7 +105,9 @@ def emit(path, device):
         f.write("%sln2hi, ln2lo, A[0..6]%s\n%s DJB_GLIBC_POW_C[9] = { %s };\n\n"
                 % (c0, c1, cq, ", ".join(float.hex(v) for v in POW_C)))
         f.write("%scij[241][7] of e_atan2.c (uatan.tbl): x_i, atan(x_i), Taylor coefficients of atan about x_i%s\n%s double DJB_GLIBC_ATAN_CIJ[241 * 7] = {\n\t" % (c0, c1, q)
-                + arr(ATAN_CIJ, per=7) + "\n};\n")
+                + arr(ATAN_CIJ, per=7) + "\n};\n\n")
+        f.write("%s__sincostab of s_sin.c: 110 x {sin hi, sin lo, cos hi, cos lo} at k / 128%s\n%s double DJB_GLIBC_SINCOS_TAB[440] = {\n\t" % (c0, c1, q)
+                + arr(SINCOS_TAB, per=4) + "\n};\n")
 
 
 emit(os.path.join(ROOT, "dj_brdf_amd", "csrc", "djb_glibc_dbl64_tables.hpp"), True)

@@ -3,9 +3,10 @@
 microfacet parameters / Fresnel terms, and hashed MERL / UTIA tables.  Reports, per case, the
 fraction of bit-identical outputs and the largest relative difference.  Paths that are identical by
 construction (GGX, Beckmann, abc, MERL, all sampling: IEEE arithmetic plus glibc's own exp / pow / logf / expf /
-powf algorithms) must be 100 % bit-exact; paths that call an fp64 trigonometric function (ROCm's libm here,
-glibc's in the reference: UTIA's and sgd's acos / atan2, the spline Fresnel's acos, the fitters' cos / sin / tan)
-may differ in ~1e-9 of the outputs by a last-ulp effect -- those are counted, dumped with their inputs, and must
+powf algorithms) must be 100 % bit-exact.  Since round 2 that also holds for the fp64 trigonometric calls of UTIA,
+the spline Fresnel and the tabular fitter (atan2 / sin / cos restated from glibc, the float -> float sites verified
+over all 2^32 inputs); only tan / acos where the double is kept (sgd's g1, the anisotropic normalisation) still run
+ROCm's libm against glibc's and may differ in ~1e-10 of the outputs -- those are counted, dumped with their inputs, and must
 stay inside 1e-5.   PYTHONPATH=. python tests/fuzz_parity.py [rounds] [n] [seed]
 DJB_FUZZ_CTX=cpu runs the product's HOST path (Context("cpu")) instead: there every libm call is the host's glibc,
 i.e. the reference's own, so EVERY comparison must be bit-exact (no GPU needed)."""

@@ -54,7 +54,7 @@ WORKLOADS = {
     "merl_eval": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval> (two-tier exact)"),
     "ggx_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf>"),
     "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample<BECKMANN,rng>"),
-    "utia_eval": (100_000_000, 36, "evals", "k_eval<UTIA,eval>"),
+    "utia_eval": (100_000_000, 36, "evals", "k_eval_utia_t1<eval> + k_eval_utia_fix<eval> (two-tier exact)"),
     "merl_fit": (100, None, "materials", "k_fit<MERL>"),
     # end to end: 100 MERL files (34 992 012 B each) on local disk -> params: pread + PCIe + convert + fit
     "merl_fit_files": (100, None, "materials", "djb_fit_merl_files (reader threads -> pinned ring -> H2D -> k_merl_convert -> k_fit<MERL>)"),

@@ -231,6 +231,7 @@ DJB_DEV float intensity(v3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f *
 
 DJB_DEV double glibc_sin(double x);   // the host libm's sin / cos, for the places that keep the double (defined with the
 DJB_DEV double glibc_cos(double x);   // other glibc restatements below); the float -> float sites sin_f / cos_f are swept exhaustively instead
+DJB_DEV double glibc_tan(double x);
 // vec3(theta, phi), dj_brdf.h:589-595
 DJB_DEV v3 from_angles(float theta, float phi)
 {
@@ -263,6 +264,7 @@ DJB_DEV double glibc_pow(double x, double y, LdsTab = 0u, LdsTab = 0u) { return 
 DJB_DEV double glibc_atan2(double y, double x) { return atan2(y, x); }
 DJB_DEV double glibc_sin(double x) { return sin(x); }
 DJB_DEV double glibc_cos(double x) { return cos(x); }
+DJB_DEV double glibc_tan(double x) { return tan(x); }
 DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * atan2(D(y), D(x))); }
 #else
 // ---- glibc 2.35's double exp / pow, restated --------------------------------------------------------
@@ -615,6 +617,66 @@ DJB_DEV double glibc_cos(double x)
 	}
 	if (k < 0x419921fb) { double a, da; const int n = glibc_reduce_sincos(x, a, da); return glibc_do_sincos(a, da, n + 1); }
 	return cos(x);
+}
+
+// ---- glibc 2.35's double tan, restated (|x| <= 25) ----------------------------------------------------
+// __tan of sysdeps/ieee754/dbl-64/s_tan.c (no slow paths) as __tan_fma computes it.  |x| <= 0.0608: odd polynomial
+// d3 .. d11; <= 0.787: x = x_i + z with x_i out of the 186 x 4 table xfg (tan and cot of x_i):
+// tan = fi + pz (fi + gi) / (gi - pz); <= 25: x = n pi/2 + a + da (mp1, mp2, mp3), then the same two forms for a, or
+// -cot through a double-double division (polynomial) / gi - pz (fi + gi) / (fi + pz) (table) when n is odd.  Larger
+// arguments (a longer reduction, __branred) go to the device libm: the anisotropic fitter's angles stay below pi/2.
+// Pinned like the others (oracle: 4.6e7 arguments; test_device_libm_restatements on the GPU).
+DJB_DEV double glibc_tan(double x)
+{
+	constexpr double g1 = 0x1.b096c00000000p-27, g2 = 0x1.f212d00000000p-5, g3 = 0x1.92f1a00000000p-1, g4 = 25.0,
+	                 d3 = 0x1.5555555555555p-2, d5 = 0x1.11111111107c6p-3, d7 = 0x1.ba1ba1cdb8745p-5, d9 = 0x1.664ed49cfc666p-6,
+	                 d11 = 0x1.2385a3cf2e4eap-7, e0 = 0x1.5555555554dbdp-2, e1 = 0x1.11112e0a6b45fp-3, mfftnhf = -15.5, TWO8 = 256.0,
+	                 toint = 0x1.8p+52, hpinv = 0x1.45f306dc9c883p-1, mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde973c000000p-27,
+	                 mp3 = -0x1.cb3b399d747f2p-55;
+	if ((__double2hiint(x) & 0x7ff00000) == 0x7ff00000) return x - x;
+	const double w = x < 0.0 ? -x : x;
+	if (w <= g1) return x;
+	if (w <= g2) {
+		const double x2 = x * x;
+		double t = __builtin_fma(d11, x2, d9);
+		t = __builtin_fma(t, x2, d7); t = __builtin_fma(t, x2, d5); t = __builtin_fma(t, x2, d3);
+		return __builtin_fma(x * x2, t, x);
+	}
+	if (w <= g3) {
+		const int i = (int)__builtin_fma(TWO8, w, mfftnhf);
+		const double *r = DJB_GLIBC_TAN_XFG + 4 * i;
+		const double z = w - r[0], z2 = z * z;
+		const double pz = __builtin_fma(z * z2, __builtin_fma(z2, e1, e0), z), fi = r[1], gi = r[2];
+		return (((fi + gi) * pz) / (gi - pz) + fi) * (x < 0.0 ? -1.0 : 1.0);
+	}
+	if (!(w <= g4)) return tan(x);
+	const double t = __builtin_fma(x, hpinv, toint), xn = t - toint;
+	const int n = __double2loint(t) & 1;
+	const double t1 = __builtin_fma(-xn, mp2, __builtin_fma(-xn, mp1, x));
+	const double a = __builtin_fma(-xn, mp3, t1), da = __builtin_fma(-xn, mp3, t1 - a);
+	const bool neg = a < 0.0;
+	const double ya = neg ? -a : a, yya = neg ? -da : da, sy = neg ? -1.0 : 1.0;
+	if (ya <= g2) {
+		const double a2 = a * a;
+		double p = __builtin_fma(d11, a2, d9);
+		p = __builtin_fma(p, a2, d7); p = __builtin_fma(p, a2, d5); p = __builtin_fma(p, a2, d3);
+		const double t2 = __builtin_fma(a * a2, p, da), y = a + t2;
+		if (n == 0) return y;
+		// -cot(a + da): b + db = a + t2 exactly, then 1 / (b + db) as a double-double
+		const double at2 = t2 < 0.0 ? -t2 : t2;
+		const double db = ya > at2 ? (a - y) + t2 : (t2 - y) + a;
+		const double c = 1.0 / y, ch = c * y, cl = __builtin_fma(c, y, -ch);
+		const double cc = __builtin_fma(-db, c, ((1.0 - ch) - cl) + 0.0) / y;
+		const double z = c + cc, zz = (c - z) + cc;
+		return -(zz + z);
+	}
+	const int i = (int)__builtin_fma(TWO8, ya, mfftnhf);
+	const double *r = DJB_GLIBC_TAN_XFG + 4 * i;
+	const double z = (ya - r[0]) + yya, z2 = z * z;
+	const double pz = __builtin_fma(z * z2, __builtin_fma(z2, e1, e0), z), fi = r[1], gi = r[2];
+	const double num = (fi + gi) * pz;
+	if (n) return (gi - num / (pz + fi)) * -sy;
+	return (num / (gi - pz) + fi) * sy;
 }
 
 #endif

@@ -608,7 +608,8 @@ __global__ __launch_bounds__(BLOCK) void k_libm_probe(int fn, long long n, const
 		case 6: r = D(atan2_to_f32(F(x[k]), F(y[k]), 1.0)); break;
 		case 7: r = D(atan2_to_f32(F(x[k]), F(y[k]), D(F(180.0 / DJB_PI)))); break;
 		case 8: r = glibc_sin(x[k]); break;
-		default: r = glibc_cos(x[k]); break;
+		case 9: r = glibc_cos(x[k]); break;
+		default: r = glibc_tan(x[k]); break;
 		}
 		out[k] = r;
 	}

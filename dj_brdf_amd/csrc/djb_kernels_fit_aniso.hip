@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLOCK) void ka_norm_terms(AnisoScratch S, int shado
 	float theta = F(D((float)i / (float)NT_NORM) * sqrt(DJB_PI * 0.5));
 	float ts = theta * theta;
 	float c = cos_f(ts);
-	float weight = F(D(theta) * tan(D(ts)) / D(c * c));
+	float weight = F(D(theta) * glibc_tan(D(ts)) / D(c * c));
 	S.terms[e] = weight * aniso_p22_theta_phi(self, ts, phi);
 }
 // ---- ordered float sums of NACC arrays of M terms each (arrays are M apart, starting at `terms`).
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void ka_pdf1(AnisoScratch S, int shadow)
 		int j = threadIdx.x;                          // ntheta = 256 == BLOCK
 		float theta = F(D((float)j / 256.0f) * 0.5 * DJB_PI);
 		float c = cos_f(theta);
-		s_theta[j] = theta; s_tan[j] = tan(D(theta)); s_c2[j] = c * c;
+		s_theta[j] = theta; s_tan[j] = glibc_tan(D(theta)); s_c2[j] = c * c;
 	}
 	__syncthreads();
 	const float dtheta = F(0.5 * DJB_PI / D(256.0f));
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(BLOCK) void ka_pdf2_norm(AnisoScratch S, int shadow
 	for (int i = 0; i < 256; ++i) {
 		float theta = F(D((float)i / 256.0f) * 0.5 * DJB_PI);
 		float c = cos_f(theta);
-		nint = acc_tan_over_cos2(nint, aniso_pdf2(self, theta, phi), tan(D(theta)), c * c);
+		nint = acc_tan_over_cos2(nint, aniso_pdf2(self, theta, phi), glibc_tan(D(theta)), c * c);
 	}
 	nint *= dtheta;
 	S.rowk[j] = F(1.0 / D(nint));
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) void ka_cdf2(AnisoScratch S, int shadow)
 	for (int j = 0; j < w; ++j) {
 		float theta = F(D((float)j / (float)w) * 0.5 * DJB_PI);
 		float c = cos_f(theta);
-		nint = acc_tan_over_cos2(nint, aniso_pdf2(self, theta, phi), tan(D(theta)), c * c);
+		nint = acc_tan_over_cos2(nint, aniso_pdf2(self, theta, phi), glibc_tan(D(theta)), c * c);
 		S.cdf2[j + E * i] = nint * dtheta;
 	}
 	S.cdf2[w + E * i] = 1.0f;

@@ -2250,14 +2250,77 @@ static double glibc_cos(double x)
 	return cos(x);
 }
 
+/* ------------------------------------------------------------------ glibc 2.35 double tan, restated
+ * __tan of sysdeps/ieee754/dbl-64/s_tan.c (IBM Accurate Mathematical Library, without the slow paths) as the x86-64 FMA
+ * ifunc variant computes it (read off __tan_fma), for |x| <= 25 -- the anisotropic fitter's arguments stay below pi/2;
+ * larger arguments (a longer reduction, __branred) go to the host libm here and to the device libm in the kernels.
+ * |x| <= 0.0608: odd polynomial d3 .. d11; <= 0.787: x = x_i + z with x_i from the 186 x 4 table xfg (tan and cot of
+ * x_i): tan = fi + pz (fi + gi) / (gi - pz); <= 25: x = n pi/2 + a + da (mp1, mp2, mp3), then the same two forms for
+ * a, or -cot through a double-double division (polynomial) / gi - pz (fi + gi) / (fi + pz) (table) when n is odd.
+ * fn 5 = tan(x[k]). */
+static double glibc_tan(double x)
+{
+	static const double g1 = 0x1.b096c00000000p-27, g2 = 0x1.f212d00000000p-5, g3 = 0x1.92f1a00000000p-1, g4 = 25.0,
+	                    d3 = 0x1.5555555555555p-2, d5 = 0x1.11111111107c6p-3, d7 = 0x1.ba1ba1cdb8745p-5, d9 = 0x1.664ed49cfc666p-6,
+	                    d11 = 0x1.2385a3cf2e4eap-7, e0 = 0x1.5555555554dbdp-2, e1 = 0x1.11112e0a6b45fp-3, mfftnhf = -15.5, TWO8 = 256.0,
+	                    toint = 0x1.8p+52, hpinv = 0x1.45f306dc9c883p-1, mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde973c000000p-27,
+	                    mp3 = -0x1.cb3b399d747f2p-55;
+	uint64_t bx; memcpy(&bx, &x, 8);
+	if (((bx >> 32) & 0x7ff00000u) == 0x7ff00000u) return x - x;
+	const double w = x < 0.0 ? -x : x;
+	if (w <= g1) return x;
+	if (w <= g2) {                                                              /* (II) */
+		const double x2 = x * x;
+		double t = fma(d11, x2, d9);
+		t = fma(t, x2, d7); t = fma(t, x2, d5); t = fma(t, x2, d3);
+		return fma(x * x2, t, x);
+	}
+	if (w <= g3) {                                                              /* (III) */
+		const int i = (int)fma(TWO8, w, mfftnhf);
+		const double *r = DJB_GLIBC_TAN_XFG + 4 * i;
+		const double z = w - r[0], z2 = z * z;
+		const double pz = fma(z * z2, fma(z2, e1, e0), z), fi = r[1], gi = r[2];
+		return (((fi + gi) * pz) / (gi - pz) + fi) * (x < 0.0 ? -1.0 : 1.0);
+	}
+	if (!(w <= g4)) return tan(x);
+	/* (IV) 0.787 < |x| <= 25: range reduction */
+	const double t = fma(x, hpinv, toint), xn = t - toint;
+	uint64_t tb; memcpy(&tb, &t, 8);
+	const int n = (int)(tb & 1);
+	const double t1 = fma(-xn, mp2, fma(-xn, mp1, x));
+	const double a = fma(-xn, mp3, t1), da = fma(-xn, mp3, t1 - a);
+	double ya, yya, sy;
+	if (a < 0.0) { ya = -a; yya = -da; sy = -1.0; } else { ya = a; yya = da; sy = 1.0; }
+	if (ya <= g2) {
+		const double a2 = a * a;
+		double p = fma(d11, a2, d9);
+		p = fma(p, a2, d7); p = fma(p, a2, d5); p = fma(p, a2, d3);
+		const double t2 = fma(a * a2, p, da), y = a + t2;
+		if (n == 0) return y;
+		/* -cot(a + da): b + db = a + t2 exactly, then 1 / (b + db) as a double-double */
+		const double db = fabs(a) > fabs(t2) ? (a - y) + t2 : (t2 - y) + a;
+		const double c = 1.0 / y, ch = c * y, cl = fma(c, y, -ch);
+		const double cc = fma(-db, c, ((1.0 - ch) - cl) + 0.0) / y;
+		const double z = c + cc, zz = (c - z) + cc;
+		return -(zz + z);
+	}
+	const int i = (int)fma(TWO8, ya, mfftnhf);
+	const double *r = DJB_GLIBC_TAN_XFG + 4 * i;
+	const double z = (ya - r[0]) + yya, z2 = z * z;
+	const double pz = fma(z * z2, fma(z2, e1, e0), z), fi = r[1], gi = r[2];
+	const double num = (fi + gi) * pz;
+	if (n) return (gi - num / (pz + fi)) * -sy;
+	return (num / (gi - pz) + fi) * sy;
+}
+
 void o_libm_f64(int fn, int64_t n, const double *x, const double *y, double *out)
 {
 	for (int64_t k = 0; k < n; ++k)
-		out[k] = fn == 0 ? exp(x[k]) : fn == 1 ? pow(x[k], y[k]) : fn == 2 ? atan2(x[k], y[k]) : fn == 3 ? sin(x[k]) : cos(x[k]);
+		out[k] = fn == 0 ? exp(x[k]) : fn == 1 ? pow(x[k], y[k]) : fn == 2 ? atan2(x[k], y[k]) : fn == 3 ? sin(x[k]) : fn == 4 ? cos(x[k]) : tan(x[k]);
 }
 void o_glibc_f64(int fn, int64_t n, const double *x, const double *y, double *out)
 {
 	for (int64_t k = 0; k < n; ++k)
 		out[k] = fn == 0 ? glibc_exp(x[k]) : fn == 1 ? glibc_pow(x[k], y[k]) : fn == 2 ? glibc_atan2(x[k], y[k])
-		       : fn == 3 ? glibc_sin(x[k]) : glibc_cos(x[k]);
+		       : fn == 3 ? glibc_sin(x[k]) : fn == 4 ? glibc_cos(x[k]) : glibc_tan(x[k]);
 }

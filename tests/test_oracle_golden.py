@@ -113,8 +113,24 @@ def libm_f64_cases(n=1 << 20, seed=20240918):
                 (rng.uniform(0, 1, n), np.full(n, 5.0)), (rng.uniform(0, 1, n), np.full(n, 6.0)),   # :1326, :2503
                 (rng.uniform(0, 100, n), rng.uniform(-400, 400, n))],
             2: atan2_cases(rng, n, sp),
-            3: sincos_cases(rng, n), 4: sincos_cases(rng, n),
+            3: sincos_cases(rng, n), 4: sincos_cases(rng, n), 5: tan_cases(rng, n),
         }
+
+
+def tan_cases(rng, n):
+    """arguments for tan: the thresholds of s_tan.c (1.26e-8, 0.0608, 0.787, 25), random bit patterns, angles below pi/2 as
+    floats / doubles / squares of floats (the anisotropic fitter's), multiples of pi/2 +- ulps, the table nodes, beyond 25"""
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    sp = np.array([0.0, 1e-300, 5e-324, 1.2589993048095494e-08, 1.2589993048095496e-08, 1.25e-8, 0.060799986124038696, 0.0608, 0.06079,
+                   0.7869997024536133, 0.787, 0.7869, 25.0, 24.999, 25.0000001, np.pi / 2, np.pi / 4, np.pi, 3 * np.pi / 2, 1e8, 1e22,
+                   np.inf, np.nan, 1.0, 0.5, 1.5707963], np.float64)
+    return [(np.concatenate([sp, -sp]), None), (rng.integers(0, 1 << 64, n, dtype=np.uint64).view(np.float64), None),
+            (f32(rng.uniform(-1.6, 1.6, n)), None), (rng.uniform(-1.6, 1.6, n), None), (rng.uniform(-25, 25, n), None),
+            (rng.uniform(-0.8, 0.8, n), None), (rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-60, 0, n), None),
+            (np.nextafter(rng.integers(-15, 16, n) * (np.pi / 2), rng.choice([-np.inf, np.inf], n)) + rng.integers(-3, 4, n) * 1e-15, None),
+            (rng.integers(-15, 16, n) * (np.pi / 2) + rng.uniform(-1e-7, 1e-7, n), None),
+            (rng.integers(16, 202, n) / 256.0 * rng.choice([-1, 1], n) + rng.uniform(-1e-9, 1e-9, n), None),
+            (f32(rng.uniform(0, 1.2533, n)) ** 2, None), (rng.uniform(25, 1e9, n) * rng.choice([-1, 1], n), None)]
 
 
 def sincos_cases(rng, n):
@@ -156,9 +172,9 @@ def atan2_cases(rng, n, sp):
 
 def test_glibc_double_libm_restatement(oracle):
     """Same for the double exp / pow / atan2 the reference's unqualified calls resolve to (oracle/djb_oracle.c
-    glibc_exp / glibc_pow / glibc_atan2 / glibc_sin / glibc_cos; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma /
-    __pow_fma / __ieee754_atan2_fma / __sin_fma / __cos_fma).  fn 2: x = the y argument of atan2, y = its x argument;
-    fn 3 / 4: sin / cos of x."""
+    glibc_exp / glibc_pow / glibc_atan2 / glibc_sin / glibc_cos / glibc_tan; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma /
+    __pow_fma / __ieee754_atan2_fma / __sin_fma / __cos_fma / __tan_fma).  fn 2: x = the y argument of atan2, y = its x argument;
+    fn 3 / 4 / 5: sin / cos / tan of x."""
     for fn, sets in libm_f64_cases().items():
         for x, y in sets:
             want, got = oracle.libm_f64(fn, x, y), oracle.glibc_f64(fn, x, y)

@@ -6,9 +6,9 @@ error ~0.51 ulp, not correctly rounded).  This script reads their two constant t
 only, as dj_brdf_amd/csrc/djb_glibc_dbl64_tables.hpp (device) and oracle/glibc_dbl64_tables.h (checker).
 atan2 is the IBM Accurate Mathematical Library routine (sysdeps/ieee754/dbl-64/e_atan2.c; since 2.34 without its
 multi-precision fall-back): its 241 x 7 table cij (uatan.tbl) is read the same way, located by its first row; sin / cos
-(s_sin.c) read the 440-entry __sincostab.
+(s_sin.c) read the 440-entry __sincostab, tan (s_tan.c) the 186 x 4 xfg.
 The operation order of the restatements (which multiply-adds are fused) was read off the disassembly of the
-x86-64 FMA ifunc variants (__exp_fma, __pow_fma, __ieee754_atan2_fma, __sin_fma, __cos_fma) of this image's glibc 2.35;
+x86-64 FMA ifunc variants (__exp_fma, __pow_fma, __ieee754_atan2_fma, __sin_fma, __cos_fma, __tan_fma) of this image's glibc 2.35;
 tests/test_oracle_golden.py::test_glibc_double_libm_restatement pins them against the host libm bit for bit."""
 import os
 import struct
@@ -74,6 +74,19 @@ SINCOS_C = {"sn3": "-0x1.5555555555515p-3", "sn5": "0x1.11110e829872fp-7", "cs2"
 for name, hx in SINCOS_C.items():
     assert find_all(struct.pack("<d", float.fromhex(hx))), name
 
+# xfg[186][4] of s_tan.c (utan.tbl): {x_i, tan(x_i), cot(x_i), cot lo}, x_i ~ (i + 16) / 256
+tan_off = None
+for off in find_all(struct.pack("<2d", float.fromhex("0x1.000001e519d60p-4"), float.fromhex("0x1.0055796c4e240p-4"))):
+    if dbl(off + 32 * 186, 1)[0] == -15.5:
+        tan_off = off
+assert tan_off, "xfg not found"
+TAN_XFG = dbl(tan_off, 186 * 4)
+TAN_C = {"d3": "0x1.5555555555555p-2", "d5": "0x1.11111111107c6p-3", "d7": "0x1.ba1ba1cdb8745p-5", "d9": "0x1.664ed49cfc666p-6",
+         "d11": "0x1.2385a3cf2e4eap-7", "e0": "0x1.5555555554dbdp-2", "e1": "0x1.11112e0a6b45fp-3", "mp3": "-0x1.cb3b399d747f2p-55",
+         "g2": "0x1.f212d00000000p-5", "g3": "0x1.92f1a00000000p-1"}
+for name, hx in TAN_C.items():
+    assert find_all(struct.pack("<d", float.fromhex(hx))), name
+
 EXP_C = dbl(exp_off, 8)                       # invln2N, shift, negln2hiN, negln2loN, C2, C3, C4, C5
 EXP_TAB = u64(exp_off + 112, 256)             # {tail bits, scale bits} x 128
 POW_C = dbl(pow_off, 9)                       # ln2hi, ln2lo, A[0..6]
@@ -91,7 +104,7 @@ def emit(path, device):
     c0, c1 = ("// ", "") if device else ("/* ", " */")
     with open(path, "w") as f:
         for line in ("GENERATED by tools/extract_glibc_dbl64_tables.py from the host's libm.so.6 (GLIBC 2.35):",
-                     "the constant tables of glibc's double exp / pow / atan2 / sin / cos (sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c, e_atan2.c, s_sin.c).",
+                     "the constant tables of glibc's double exp / pow / atan2 / sin / cos / tan (sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c, e_atan2.c, s_sin.c, s_tan.c).",
                      "Numeric data only; the algorithms are restated in djb_device.hpp / djb_oracle.c."):
             f.write(c0 + line + c1 + "\n")
         if device:
@@ -107,7 +120,9 @@ def emit(path, device):
         f.write("%scij[241][7] of e_atan2.c (uatan.tbl): x_i, atan(x_i), Taylor coefficients of atan about x_i%s\n%s double DJB_GLIBC_ATAN_CIJ[241 * 7] = {\n\t" % (c0, c1, q)
                 + arr(ATAN_CIJ, per=7) + "\n};\n\n")
         f.write("%s__sincostab of s_sin.c: 110 x {sin hi, sin lo, cos hi, cos lo} at k / 128%s\n%s double DJB_GLIBC_SINCOS_TAB[440] = {\n\t" % (c0, c1, q)
-                + arr(SINCOS_TAB, per=4) + "\n};\n")
+                + arr(SINCOS_TAB, per=4) + "\n};\n\n")
+        f.write("%sxfg[186][4] of s_tan.c (utan.tbl): x_i, tan(x_i), cot(x_i) hi, lo%s\n%s double DJB_GLIBC_TAN_XFG[186 * 4] = {\n\t" % (c0, c1, q)
+                + arr(TAN_XFG, per=4) + "\n};\n")
 
 
 emit(os.path.join(ROOT, "dj_brdf_amd", "csrc", "djb_glibc_dbl64_tables.hpp"), True)

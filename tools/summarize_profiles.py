@@ -15,7 +15,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles", RND)
 os.makedirs(DST, exist_ok=True)
 DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf": ("k_eval<1, 5,",),
-            "beckmann_sample": ("k_sample<0",), "merl_fit": ("k_fit<3>",), "utia_eval": ("k_eval<4, 1,",)}
+            "beckmann_sample": ("k_sample<0",), "merl_fit": ("k_fit<3>",), "utia_eval": ("k_eval_utia_t1", "k_eval_utia_fix", "k_eval<4, 1,")}
 
 
 def counters(path):
@@ -50,7 +50,8 @@ for w in sorted(os.listdir(SRC)):
     write_kb = sum(v.get("WRITE_SIZE", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
     if fetch_kb or write_kb:
         out = {
-            "workload": w, "kernels": [k for k in per_kernel if any(t in k for t in DOMINANT.get(w, ()))],
+            "workload": w, "round": "round %d (profiles/%s)" % (int(RND.lstrip("r") or 0), RND),
+            "kernels": [k for k in per_kernel if any(t in k for t in DOMINANT.get(w, ()))],
             "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
             # MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-B streaming requests as 64 B on gfx950
             # (verified here on k_eval<GGX>: 1.2 GB reported for 2.4 GB read) -> x2; WRITE_SIZE is exact

@@ -20,16 +20,17 @@ for name, b in (("ggx", djb.ggx(ctx=ctx)), ("beckmann", djb.beckmann(ctx=ctx)), 
     def run():
         _lib.check(lib.djb_eval_pdf_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), C.byref(iso._p), C.c_int(0), C.byref(vout.view),
                                           C.c_void_p(pdf.data_ptr()), C.c_int(0)))
-    run(); torch.cuda.synchronize(); ctx.timer_start()
-    for _ in range(3): run()
-    ms = ctx.timer_stop_ms() / 3
+    for _ in range(10): run()      # steady clocks: these launches take 1-4 ms
+    torch.cuda.synchronize(); ctx.timer_start()
+    for _ in range(10): run()
+    ms = ctx.timer_stop_ms() / 10
     print(f"{name:16s} eval+pdf: {ms:8.3f} ms per 1e8 -> {n/ms/1e6:7.2f} G/s ({40*n/ms/1e6/8000*100:.1f} % of HBM at 40 B/pair)")
 for name, b in (("utia", u), ("sgd", djb.sgd("gold-metallic-paint", ctx=ctx)), ("abc", djb.abc("gold-metallic-paint", ctx=ctx)),
                 ("tabular(ggx)", djb.tabular(djb.ggx(ctx=ctx), 90, True, ctx=ctx))):
-    for _ in range(2):
+    for _ in range(10):
         _lib.check(lib.djb_eval_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), None, C.byref(vout.view), C.c_int(0)))
     torch.cuda.synchronize(); ctx.timer_start()
-    for _ in range(3):
+    for _ in range(10):
         _lib.check(lib.djb_eval_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), None, C.byref(vout.view), C.c_int(0)))
-    ms = ctx.timer_stop_ms() / 3
+    ms = ctx.timer_stop_ms() / 10
     print(f"{name:14s} eval: {ms:8.3f} ms per 1e8 -> {n/ms/1e6:7.2f} G eval/s ({36*n/ms/1e6/8000*100:.1f} % of HBM)")

@@ -22,7 +22,8 @@ for name, b in (("ggx", djb.ggx(ctx=ctx)), ("beckmann", djb.beckmann(ctx=ctx))):
                                           C.byref(vo.view), C.byref(p._p), C.byref(vw.view), C.byref(vi.view),
                                           C.c_void_p(pdf.data_ptr()), C.c_int(0)))
     for tag, f, bytes_ in (("sample", sample, 32), ("evalp_is", evalp_is, 48)):
-        f(); torch.cuda.synchronize(); ctx.timer_start()
-        for _ in range(3): f()
-        ms = ctx.timer_stop_ms() / 3
+        for _ in range(6): f()      # steady clocks
+        torch.cuda.synchronize(); ctx.timer_start()
+        for _ in range(6): f()
+        ms = ctx.timer_stop_ms() / 6
         print(f"{name:9s} {tag:9s}: {ms:7.3f} ms per 2e8 -> {n/ms/1e6:6.1f} G/s  ({bytes_*n/ms/1e6/8000*100:4.1f} % of HBM at {bytes_} B/unit)")

@@ -65,9 +65,9 @@ struct Brdf {
 	// two-level sampling tables below (dj_brdf.h:429-438)
 	const float *a_pdf1, *a_cdf1, *a_qf1, *a_pdf2, *a_cdf2, *a_qf2;
 	int elev, azim, n_a_cdf1, n_a_qf1;
-	// where glibc_exp() / glibc_pow() read their tables (LdsTab: 0 = the global copy, else 1 + the LDS byte offset
+	// where glibc_exp() / glibc_pow() / glibc_acos() read their tables (LdsTab: 0 = the global copy, else 1 + the LDS byte offset
 	// of a copy staged by the kernel, which sets these on its own copy of the struct; the host leaves them 0)
-	unsigned int exp_lds, pow_lds;
+	unsigned int exp_lds, pow_lds, acos_lds;
 };
 
 struct View { float *x, *y, *z; long long stride; };
@@ -229,9 +229,11 @@ DJB_DEV float fdiv_r(float a, float b, double R)
 DJB_DEV v3 normalize(v3 v) { return scale(inversesqrt_(dot(v, v)), v); }              // dj_brdf.h:630
 DJB_DEV float intensity(v3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z; } // dj_brdf.h:69
 
+typedef unsigned int LdsTab;   // where a device kernel staged a libm table (0 = the global copy); unused on the host
 DJB_DEV double glibc_sin(double x);   // the host libm's sin / cos, for the places that keep the double (defined with the
 DJB_DEV double glibc_cos(double x);   // other glibc restatements below); the float -> float sites sin_f / cos_f are swept exhaustively instead
 DJB_DEV double glibc_tan(double x);
+DJB_DEV double glibc_acos(double x, LdsTab AT);
 // vec3(theta, phi), dj_brdf.h:589-595
 DJB_DEV v3 from_angles(float theta, float phi)
 {
@@ -239,7 +241,6 @@ DJB_DEV v3 from_angles(float theta, float phi)
 	return mk(F(D(s) * glibc_cos(D(phi))), F(D(s) * glibc_sin(D(phi))), cos_f(theta));
 }
 
-typedef unsigned int LdsTab;   // where a device kernel staged a libm table (0 = the global copy); unused on the host
 DJB_DEV double glibc_atan2(double y, double x);   // the host libm's atan2 (defined with the other glibc restatements below)
 // float(scale * atan2(double y, double x)) with the HOST libm's atan2 (dj_brdf.h:659, 1634).  On the device glibc's
 // routine (two IEEE fp64 divisions, a 13.5 KB table) costs twice the device libm's, so the device libm goes first:
@@ -265,6 +266,7 @@ DJB_DEV double glibc_atan2(double y, double x) { return atan2(y, x); }
 DJB_DEV double glibc_sin(double x) { return sin(x); }
 DJB_DEV double glibc_cos(double x) { return cos(x); }
 DJB_DEV double glibc_tan(double x) { return tan(x); }
+DJB_DEV double glibc_acos(double x, LdsTab) { return acos(x); }
 DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * atan2(D(y), D(x))); }
 #else
 // ---- glibc 2.35's double exp / pow, restated --------------------------------------------------------
@@ -677,6 +679,78 @@ DJB_DEV double glibc_tan(double x)
 	const double num = (fi + gi) * pz;
 	if (n) return (gi - num / (pz + fi)) * -sy;
 	return (num / (gi - pz) + fi) * sy;
+}
+
+// ---- glibc 2.35's double acos, restated -------------------------------------------------------------
+// __ieee754_acos of sysdeps/ieee754/dbl-64/e_asin.c (no slow paths) as __ieee754_acos_fma computes it.  |x| < 1/8:
+// pi/2 - x - x^3 p(x^2) with a two-term pi/2; seven intervals up to 0.96875 with a Taylor expansion about the nearest
+// point of asincos.tbl (rows of 11 .. 15 entries: x_i, the coefficients, acos(x_i)); from 0.96875 to 1:
+// 2 asin(sqrt((1 - |x|) / 2)) with the square root seeded from root.tbl and refined as a double-double.  Complete.
+// Used by sgd's g1, the one place that keeps the double of an acos (dj_brdf.h:3431).  Pinned like the others
+// (oracle: 5.4e7 arguments; test_device_libm_restatements on the GPU).
+// AT: 0 = the global tables, else the handle of the LDS copy (asncs followed by inroot) of glibc_acos_tab_to_lds
+DJB_DEV LdsTab glibc_acos_tab_to_lds(double *lds, int tid, int nthreads)              // caller: __syncthreads() afterwards
+{
+	for (int k = tid; k < 2568; k += nthreads) lds[k] = DJB_GLIBC_ASNCS[k];
+	for (int k = tid; k < 128; k += nthreads) lds[2568 + k] = DJB_GLIBC_INROOT[k];
+	return 1u + (unsigned int)(uintptr_t)(lds_f64p)lds;
+}
+DJB_DEV double glibc_acos(double x, LdsTab AT)
+{
+	constexpr double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54, f1 = 0x1.55555555554f9p-3, f2 = 0x1.333333336127dp-4,
+	                 f3 = 0x1.6db6dae42c0e4p-5, f4 = 0x1.f1c7e04f4ad99p-6, f5 = 0x1.6e442c822d419p-6, f6 = 0x1.292d80f453c72p-6,
+	                 rt0 = 0x1.fffffffecc1ddp-1, rt1 = 0x1.fffffff757304p-2, rt2 = 0x1.800496769c91ap-2, rt3 = 0x1.4006318d1dab9p-2,
+	                 t27 = 0x1p+27;
+	const int m = __double2hiint(x), k = m & 0x7fffffff;
+	if (k < 0x3c880000) return hp0;
+	if (k < 0x3fc00000) {
+		const double x2 = x * x;
+		double p = __builtin_fma(f6, x2, f5);
+		p = __builtin_fma(p, x2, f4); p = __builtin_fma(p, x2, f3); p = __builtin_fma(p, x2, f2); p = __builtin_fma(p, x2, f1);
+		const double r = hp0 - x;
+		return r + __builtin_fma(-p, x * x2, ((hp0 - r) - x) + hp1);
+	}
+	if (k < 0x3fef0000) {
+		int S, n;
+		if (k < 0x3fd00000) { S = 11; n = 11 * ((k >> 15) & 0x1f); }
+		else if (k < 0x3fe00000) { S = 11; n = 352 + 11 * ((k >> 14) & 0x3f); }
+		else if (k < 0x3fe80000) { S = 12; n = 1056 + 12 * ((k >> 13) & 0x7f); }
+		else if (k < 0x3fed8000) { S = 13; n = 992 + 13 * ((k >> 13) & 0x7f); }
+		else if (k < 0x3fee8000) { S = 14; n = 884 + 14 * ((k >> 13) & 0x7f); }
+		else { S = 15; n = 768 + 15 * ((k >> 13) & 0x7f); }
+		const lds_f64p L = (lds_f64p)(uintptr_t)(AT - 1u) + n;
+		const double *G = DJB_GLIBC_ASNCS + n;
+		auto T = [&](int j) { return AT ? L[j] : G[j]; };
+		const double xx = (m > 0 ? x : -x) - T(0);
+		double p = T(S - 5);
+		for (int j = S - 6; j >= 2; --j) p = __builtin_fma(p, xx, T(j));
+		p = __builtin_fma(p, xx * xx, T(S - 4));
+		const double t = __builtin_fma(xx, T(1), p), y = T(S - 3);
+		return m > 0 ? (hp1 - t) + (hp0 - y) : (t + hp1) + (y + hp0);
+	}
+	if (k < 0x3ff00000) {
+		const double z = (m > 0 ? 1.0 - x : x + 1.0) * 0.5;
+		const int hz = __double2hiint(z);
+		const int ir = (hz >> 14) & 0x7f;
+		double t = (AT ? ((lds_f64p)(uintptr_t)(AT - 1u))[2568 + ir] : DJB_GLIBC_INROOT[ir]) * __hiloint2double((1023 + 511 - (hz >> 21)) << 20, 0);   // inroot * powtwo
+		const double r = __builtin_fma(-(t * t), z, 1.0);
+		double q = __builtin_fma(rt3, r, rt2);
+		q = __builtin_fma(q, r, rt1); q = __builtin_fma(q, r, rt0);
+		t = q * t;
+		const double c = z * t;
+		const double h = __builtin_fma(-c, t * 0.5, 1.5);
+		const double y = __builtin_fma(-t27, c, __builtin_fma(c, t27, c));
+		const double cc = __builtin_fma(-y, y, z) / __builtin_fma(h, c, y);
+		double p = __builtin_fma(f6, z, f5);
+		p = __builtin_fma(p, z, f4); p = __builtin_fma(p, z, f3); p = __builtin_fma(p, z, f2); p = __builtin_fma(p, z, f1);
+		p = (p * z) * (y + cc);
+		if (m < 0) return 2.0 * (((hp1 - cc) - p) + (hp0 - y));
+		return 2.0 * ((cc + p) + y);
+	}
+	const unsigned int lo = (unsigned int)__double2loint(x);
+	if (k == 0x3ff00000 && lo == 0) return m > 0 ? 0.0 : 2.0 * hp0;
+	if (k > 0x7ff00000 || (k == 0x7ff00000 && lo != 0)) return x + x;
+	return (x - x) / (x - x);
 }
 
 #endif
@@ -1711,9 +1785,10 @@ DJB_DEV void lrep_to_pdfparams(Lrep l, float &ax, float &ay, float &rho, float &
 }
 
 // ------------------------------------------------------------------ SGD (dj_brdf.h:3415-3500)
-DJB_DEV double sgd_g1(const Brdf &b, v3 k, double theta0, double c, double k_, double lambda)           // :3415
+// theta_k = acos(double(k.z)): the same for the three channels, evaluated once by the callers
+DJB_DEV double sgd_g1(const Brdf &b, double theta_k, double theta0, double c, double k_, double lambda)   // :3415
 {
-	double t1 = fmax(0.0, acos(D(k.z)) - theta0);
+	double t1 = fmax(0.0, theta_k - theta0);
 	double t2 = 1.0 - glibc_exp(c * glibc_pow(t1, k_, b.pow_lds, b.exp_lds), b.exp_lds);
 	double t3 = 1.0 + lambda * t2;
 	return fmin(1.0, fmax(0.0, t3));
@@ -1730,8 +1805,9 @@ DJB_DEV double sgd_ndf(const Brdf &b, double ch, double alpha, double p, double 
 DJB_DEV v3 sgd_g1_rgb(const Brdf &b, v3 k)                                                // sgd::g1, :3477
 {
 	const double *m = b.model;
-	return mk(F(sgd_g1(b, k, m[30], m[24], m[27], m[21])), F(sgd_g1(b, k, m[31], m[25], m[28], m[22])),
-	          F(sgd_g1(b, k, m[32], m[26], m[29], m[23])));
+	const double theta_k = glibc_acos(D(k.z), b.acos_lds);
+	return mk(F(sgd_g1(b, theta_k, m[30], m[24], m[27], m[21])), F(sgd_g1(b, theta_k, m[31], m[25], m[28], m[22])),
+	          F(sgd_g1(b, theta_k, m[32], m[26], m[29], m[23])));
 }
 DJB_DEV v3 sgd_ndf_rgb(const Brdf &b, v3 h)                                               // sgd::ndf, :3490
 {

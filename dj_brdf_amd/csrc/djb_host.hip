@@ -1974,7 +1974,7 @@ try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_HOST);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
-	if (fn < 0 || fn > 10 || !x || !y || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid selftest arguments");
+	if (fn < 0 || fn > 11 || !x || !y || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid selftest arguments");
 	if (n == 0) return DJB_OK;
 	const size_t nb = sizeof(double) * (size_t)n;
 	double *d = nullptr;

@@ -69,11 +69,15 @@ __global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Pa
 {
 	// Beckmann evaluates the fp64 exp of glibc (djb_device.hpp) three times per pair: its 2 KB table goes to LDS
 	// (sgd: 9 exp + 9 pow per pair, abc: one pow -- both tables)
-	constexpr bool EXPT = KIND == KIND_BECKMANN || KIND == KIND_SGD || KIND == KIND_ABC, POWT = KIND == KIND_SGD || KIND == KIND_ABC;
+	// (sgd also calls glibc's acos twice per pair: its 21 KB of tables)
+	constexpr bool EXPT = KIND == KIND_BECKMANN || KIND == KIND_SGD || KIND == KIND_ABC, POWT = KIND == KIND_SGD || KIND == KIND_ABC,
+	               ACOST = KIND == KIND_SGD;
 	__shared__ unsigned long long s_exp[EXPT ? 256 : 1];
 	__shared__ double s_pow[POWT ? 384 : 1];
+	__shared__ double s_acos[ACOST ? 2568 + 128 : 1];
 	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
 	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
+	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BLOCK);
 	if (EXPT || POWT) __syncthreads();
 	const long long stride = (long long)gridDim.x * BLOCK;
 	const unsigned int t = threadIdx.x;
@@ -609,7 +613,8 @@ __global__ __launch_bounds__(BLOCK) void k_libm_probe(int fn, long long n, const
 		case 7: r = D(atan2_to_f32(F(x[k]), F(y[k]), D(F(180.0 / DJB_PI)))); break;
 		case 8: r = glibc_sin(x[k]); break;
 		case 9: r = glibc_cos(x[k]); break;
-		default: r = glibc_tan(x[k]); break;
+		case 10: r = glibc_tan(x[k]); break;
+		default: r = glibc_acos(x[k], 0u); break;
 		}
 		out[k] = r;
 	}

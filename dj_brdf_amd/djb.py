@@ -1053,7 +1053,7 @@ def selftest_libm(fn: str, x, y=None, ctx: Optional[Context] = None):
     """The kernels' restatement of a host libm function (exp, pow, logf, expf, powf, atan2(x, y)), evaluated on the GPU
     (djb_selftest_libm); float functions take and return values representable as float."""
     ctx = ctx or default_context()
-    code = {"exp": 0, "pow": 1, "logf": 2, "expf": 3, "powf": 4, "atan2": 5, "atan2_f32": 6, "atan2_deg_f32": 7, "sin": 8, "cos": 9, "tan": 10}[fn]
+    code = {"exp": 0, "pow": 1, "logf": 2, "expf": 3, "powf": 4, "atan2": 5, "atan2_f32": 6, "atan2_deg_f32": 7, "sin": 8, "cos": 9, "tan": 10, "acos": 11}[fn]
     x = np.ascontiguousarray(x, np.float64).reshape(-1)
     y = np.ascontiguousarray(x if y is None else y, np.float64).reshape(-1)
     out = np.empty_like(x)

@@ -286,12 +286,12 @@ djb_status djb_merl_guard_stats(djb_ctx *, int64_t n, const djb_vec3_view *i, co
  * fallbacks, sRGB-decode mismatches, sRGB-decode fallbacks, mismatches of the exact division through a double
  * reciprocal (float(double(a) * R) vs a / b), its IEEE fallbacks}; every mismatch count must be 0. */
 djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters8);
-/* the kernels' restatements of the host libm functions the reference calls (glibc 2.35: double exp / pow / atan2 / sin / cos / tan,
+/* the kernels' restatements of the host libm functions the reference calls (glibc 2.35: double exp / pow / atan2 / sin / cos / tan / acos,
  * float logf / expf / powf -- dj_brdf.h:659, 685, 695, 1634, 1868, 1917, 1935, 3419, 3431, 3612), evaluated on the GPU for
  * host arrays: fn 0 exp(x), 1 pow(x, y), 2 logf(x), 3 expf(x), 4 powf(x, y) (float functions on the values cast
  * to float), 5 atan2(x, y) (x = the first, "y" argument of atan2), 6 / 7 the kernels' float(atan2(x, y)) and
  * float(float(180 / pi) * atan2(x, y)) of float arguments (device libm, glibc's algorithm next to a float rounding
- * boundary), 8 sin(x), 9 cos(x), 10 tan(x) (double).  The test-suite compares `out` with the libm of the host, bit for bit. */
+ * boundary), 8 sin(x), 9 cos(x), 10 tan(x), 11 acos(x) (double).  The test-suite compares `out` with the libm of the host, bit for bit. */
 djb_status djb_selftest_libm(djb_ctx *, int fn, int64_t n, const double *x, const double *y, double *out);
 
 /* exhaustive check of the sites of the fp64 trig family.  Float sites (0 .. DJB_TRIG_SITES - 1, the TRIG_* enum of

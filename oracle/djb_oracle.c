@@ -2313,14 +2313,78 @@ static double glibc_tan(double x)
 	return (num / (gi - pz) + fi) * sy;
 }
 
+/* ------------------------------------------------------------------ glibc 2.35 double acos, restated
+ * __ieee754_acos of sysdeps/ieee754/dbl-64/e_asin.c (IBM Accurate Mathematical Library, without the slow paths) as
+ * __ieee754_acos_fma computes it: |x| < 1/8: pi/2 - x - x^3 p(x^2) with a two-term pi/2; seven intervals up to
+ * 0.96875 with a Taylor expansion about the nearest point of asincos.tbl (rows of 11 .. 15 entries: x_i, the
+ * coefficients, acos(x_i) as hi + the expansion's constant term); from 0.96875 to 1: 2 asin(sqrt((1 - |x|) / 2)) with
+ * the square root built from root.tbl and refined as a double-double.  Complete.  fn 6 = acos(x[k]). */
+static double glibc_acos(double x)
+{
+	static const double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54, f1 = 0x1.55555555554f9p-3, f2 = 0x1.333333336127dp-4,
+	                    f3 = 0x1.6db6dae42c0e4p-5, f4 = 0x1.f1c7e04f4ad99p-6, f5 = 0x1.6e442c822d419p-6, f6 = 0x1.292d80f453c72p-6,
+	                    rt0 = 0x1.fffffffecc1ddp-1, rt1 = 0x1.fffffff757304p-2, rt2 = 0x1.800496769c91ap-2, rt3 = 0x1.4006318d1dab9p-2,
+	                    t27 = 0x1p+27;
+	uint64_t bx; memcpy(&bx, &x, 8);
+	const int32_t m = (int32_t)(bx >> 32), k = m & 0x7fffffff;
+	const uint32_t lo = (uint32_t)bx;
+	if (k < 0x3c880000) return hp0;                                                /* |x| < 2^-55 */
+	if (k < 0x3fc00000) {                                                          /* |x| < 1/8 */
+		const double x2 = x * x;
+		double p = fma(f6, x2, f5);
+		p = fma(p, x2, f4); p = fma(p, x2, f3); p = fma(p, x2, f2); p = fma(p, x2, f1);
+		const double r = hp0 - x;
+		return r + fma(-p, x * x2, ((hp0 - r) - x) + hp1);
+	}
+	if (k < 0x3fef0000) {                                                          /* 1/8 <= |x| < 0.96875: seven table intervals */
+		int S, n;
+		if (k < 0x3fd00000) { S = 11; n = 11 * ((k >> 15) & 0x1f); }
+		else if (k < 0x3fe00000) { S = 11; n = 352 + 11 * ((k >> 14) & 0x3f); }
+		else if (k < 0x3fe80000) { S = 12; n = 1056 + 12 * ((k >> 13) & 0x7f); }
+		else if (k < 0x3fed8000) { S = 13; n = 992 + 13 * ((k >> 13) & 0x7f); }
+		else if (k < 0x3fee8000) { S = 14; n = 884 + 14 * ((k >> 13) & 0x7f); }
+		else { S = 15; n = 768 + 15 * ((k >> 13) & 0x7f); }
+		const double *T = DJB_GLIBC_ASNCS + n;
+		const double xx = (m > 0 ? x : -x) - T[0];
+		double p = T[S - 5];
+		for (int j = S - 6; j >= 2; --j) p = fma(p, xx, T[j]);
+		p = fma(p, xx * xx, T[S - 4]);
+		const double t = fma(xx, T[1], p), y = T[S - 3];
+		return m > 0 ? (hp1 - t) + (hp0 - y) : (t + hp1) + (y + hp0);
+	}
+	if (k < 0x3ff00000) {                                                          /* 0.96875 <= |x| < 1 */
+		const double z = (m > 0 ? 1.0 - x : x + 1.0) * 0.5;
+		uint64_t bz; memcpy(&bz, &z, 8);
+		const int32_t hz = (int32_t)(bz >> 32);
+		double t = DJB_GLIBC_INROOT[(hz >> 14) & 0x7f] * ldexp(1.0, 511 - (hz >> 21));
+		const double r = fma(-(t * t), z, 1.0);
+		double q = fma(rt3, r, rt2);
+		q = fma(q, r, rt1); q = fma(q, r, rt0);
+		t = q * t;
+		const double c = z * t;
+		const double h = fma(-c, t * 0.5, 1.5);
+		const double y = fma(-t27, c, fma(c, t27, c));
+		const double den = fma(h, c, y);
+		const double cc = fma(-y, y, z) / den;
+		double p = fma(f6, z, f5);
+		p = fma(p, z, f4); p = fma(p, z, f3); p = fma(p, z, f2); p = fma(p, z, f1);
+		p = (p * z) * (y + cc);
+		if (m < 0) return 2.0 * (((hp1 - cc) - p) + (hp0 - y));
+		return 2.0 * ((cc + p) + y);
+	}
+	if (k == 0x3ff00000 && lo == 0) return m > 0 ? 0.0 : 2.0 * hp0;                /* |x| = 1 */
+	if (k > 0x7ff00000 || (k == 0x7ff00000 && lo != 0)) return x + x;              /* NaN */
+	return (x - x) / (x - x);                                                      /* |x| > 1 */
+}
+
 void o_libm_f64(int fn, int64_t n, const double *x, const double *y, double *out)
 {
 	for (int64_t k = 0; k < n; ++k)
-		out[k] = fn == 0 ? exp(x[k]) : fn == 1 ? pow(x[k], y[k]) : fn == 2 ? atan2(x[k], y[k]) : fn == 3 ? sin(x[k]) : fn == 4 ? cos(x[k]) : tan(x[k]);
+		out[k] = fn == 0 ? exp(x[k]) : fn == 1 ? pow(x[k], y[k]) : fn == 2 ? atan2(x[k], y[k]) : fn == 3 ? sin(x[k]) : fn == 4 ? cos(x[k]) : fn == 5 ? tan(x[k]) : acos(x[k]);
 }
 void o_glibc_f64(int fn, int64_t n, const double *x, const double *y, double *out)
 {
 	for (int64_t k = 0; k < n; ++k)
 		out[k] = fn == 0 ? glibc_exp(x[k]) : fn == 1 ? glibc_pow(x[k], y[k]) : fn == 2 ? glibc_atan2(x[k], y[k])
-		       : fn == 3 ? glibc_sin(x[k]) : fn == 4 ? glibc_cos(x[k]) : glibc_tan(x[k]);
+		       : fn == 3 ? glibc_sin(x[k]) : fn == 4 ? glibc_cos(x[k]) : fn == 5 ? glibc_tan(x[k]) : glibc_acos(x[k]);
 }

@@ -114,20 +114,20 @@ def test_microfacet_sample(gpu_ctx, oracle, dirs, ndf):
 
 
 def test_device_libm_restatements(gpu_ctx, oracle):
-    """The kernels' own copies of glibc's exp / pow / atan2 / sin / cos / tan (double) and logf / expf / powf (float), evaluated on the GPU
+    """The kernels' own copies of glibc's exp / pow / atan2 / sin / cos / tan / acos (double) and logf / expf / powf (float), evaluated on the GPU
     (djb_selftest_libm), against the libm of this host -- what the reference calls.  Every bit."""
     from test_oracle_golden import libm_f64_cases
     for fn, sets in libm_f64_cases(n=1 << 19).items():
         for x, y in sets:
             want = oracle.libm_f64(fn, x, y)
-            got = djb.selftest_libm(("exp", "pow", "atan2", "sin", "cos", "tan")[fn], x, y, ctx=gpu_ctx)
+            got = djb.selftest_libm(("exp", "pow", "atan2", "sin", "cos", "tan", "acos")[fn], x, y, ctx=gpu_ctx)
             same = (want.view(np.uint64) == got.view(np.uint64)) | (np.isnan(want) & np.isnan(got))
             if fn == 1:      # pow: negative and subnormal bases are left to the device libm (never reached by the BRDF code): 1 ulp
                 other = ((np.abs(x) < 2.3e-308) & (x != 0)) | (x < 0)
                 with np.errstate(all="ignore"):
                     close = np.abs(got - want) <= 4 * np.spacing(np.abs(want))
                 same |= other & (close | (np.isinf(want) & (want == got)))
-            if fn >= 3:      # sin / cos beyond 105414350 (__branred) and tan beyond 25 are left to the device libm (the BRDF code's angles stay below 7): 1 ulp
+            if 3 <= fn <= 5:      # sin / cos beyond 105414350 (__branred) and tan beyond 25 are left to the device libm (the BRDF code's angles stay below 7): 1 ulp
                 with np.errstate(all="ignore"):
                     same |= (np.abs(x) >= (25.0 if fn == 5 else 105414350.0)) & (np.abs(got - want) <= 2 * np.spacing(np.abs(want)))
             assert same.all(), (fn, int((~same).sum()), x[~same][:3], y[~same][:3] if y is not None else None)

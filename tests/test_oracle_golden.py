@@ -113,8 +113,24 @@ def libm_f64_cases(n=1 << 20, seed=20240918):
                 (rng.uniform(0, 1, n), np.full(n, 5.0)), (rng.uniform(0, 1, n), np.full(n, 6.0)),   # :1326, :2503
                 (rng.uniform(0, 100, n), rng.uniform(-400, 400, n))],
             2: atan2_cases(rng, n, sp),
-            3: sincos_cases(rng, n), 4: sincos_cases(rng, n), 5: tan_cases(rng, n),
+            3: sincos_cases(rng, n), 4: sincos_cases(rng, n), 5: tan_cases(rng, n), 6: acos_cases(rng, n),
         }
+
+
+def acos_cases(rng, n):
+    """arguments for acos: the nine interval boundaries of e_asin.c +- 1 ulp, random bit patterns, [-1, 1] as floats and
+    doubles, every interval separately, 1 - tiny, small exponents, |x| > 1"""
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    th = np.array([2.0 ** -55, 0.125, 0.25, 0.5, 0.75, 0.921875, 0.953125, 0.96875, 1.0])
+    sp = np.concatenate([[0.0, 1e-300, 5e-324, 2.0, np.inf, np.nan, 1.0000000000000002, 0.9999999999999999, 0.3, 0.6, 0.8, 0.93, 0.96, 0.99],
+                         th, np.nextafter(th, 0), np.nextafter(th, 2)])
+    sgn = lambda: rng.choice([-1.0, 1.0], n)
+    sets = [(np.concatenate([sp, -sp]), None), (rng.integers(0, 1 << 64, n, dtype=np.uint64).view(np.float64), None),
+            (f32(rng.uniform(-1, 1, n)), None), (rng.uniform(-1, 1, n), None),
+            ((1.0 - 2.0 ** rng.uniform(-53, -5, n)) * sgn(), None), (rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-70, 0, n), None)]
+    for lo, hi in ((0, 0.125), (0.125, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 0.921875), (0.921875, 0.953125), (0.953125, 0.96875), (0.96875, 1.0)):
+        sets.append((rng.uniform(lo, hi, n) * sgn(), None))
+    return sets
 
 
 def tan_cases(rng, n):
@@ -172,9 +188,9 @@ def atan2_cases(rng, n, sp):
 
 def test_glibc_double_libm_restatement(oracle):
     """Same for the double exp / pow / atan2 the reference's unqualified calls resolve to (oracle/djb_oracle.c
-    glibc_exp / glibc_pow / glibc_atan2 / glibc_sin / glibc_cos / glibc_tan; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma /
-    __pow_fma / __ieee754_atan2_fma / __sin_fma / __cos_fma / __tan_fma).  fn 2: x = the y argument of atan2, y = its x argument;
-    fn 3 / 4 / 5: sin / cos / tan of x."""
+    glibc_exp / glibc_pow / glibc_atan2 / glibc_sin / glibc_cos / glibc_tan / glibc_acos; tables by tools/extract_glibc_dbl64_tables.py; fusion read off __exp_fma /
+    __pow_fma / __ieee754_atan2_fma / __sin_fma / __cos_fma / __tan_fma / __ieee754_acos_fma).  fn 2: x = the y argument of atan2, y = its x argument;
+    fn 3 / 4 / 5 / 6: sin / cos / tan / acos of x."""
     for fn, sets in libm_f64_cases().items():
         for x, y in sets:
             want, got = oracle.libm_f64(fn, x, y), oracle.glibc_f64(fn, x, y)

@@ -6,9 +6,9 @@ error ~0.51 ulp, not correctly rounded).  This script reads their two constant t
 only, as dj_brdf_amd/csrc/djb_glibc_dbl64_tables.hpp (device) and oracle/glibc_dbl64_tables.h (checker).
 atan2 is the IBM Accurate Mathematical Library routine (sysdeps/ieee754/dbl-64/e_atan2.c; since 2.34 without its
 multi-precision fall-back): its 241 x 7 table cij (uatan.tbl) is read the same way, located by its first row; sin / cos
-(s_sin.c) read the 440-entry __sincostab, tan (s_tan.c) the 186 x 4 xfg.
+(s_sin.c) read the 440-entry __sincostab, tan (s_tan.c) the 186 x 4 xfg, acos (e_asin.c) asincos.tbl and root.tbl.
 The operation order of the restatements (which multiply-adds are fused) was read off the disassembly of the
-x86-64 FMA ifunc variants (__exp_fma, __pow_fma, __ieee754_atan2_fma, __sin_fma, __cos_fma, __tan_fma) of this image's glibc 2.35;
+x86-64 FMA ifunc variants (__exp_fma, __pow_fma, __ieee754_atan2_fma, __sin_fma, __cos_fma, __tan_fma, __ieee754_acos_fma) of this image's glibc 2.35;
 tests/test_oracle_golden.py::test_glibc_double_libm_restatement pins them against the host libm bit for bit."""
 import os
 import struct
@@ -87,6 +87,24 @@ TAN_C = {"d3": "0x1.5555555555555p-2", "d5": "0x1.11111111107c6p-3", "d7": "0x1.
 for name, hx in TAN_C.items():
     assert find_all(struct.pack("<d", float.fromhex(hx))), name
 
+# asncs[2568] (asincos.tbl) and inroot[128] (root.tbl) of e_asin.c; powtwo[k] = 2^k is generated, not read
+acos_off = None
+for off in find_all(struct.pack("<2d", float.fromhex("0x1.0400000000000p-3"), float.fromhex("0x1.0216988994424p+0"))):
+    if abs(dbl(off + 8 * 2567, 1)[0] - 0.006938468016094754) < 1e-17:
+        acos_off = off
+inroot_off = None
+for off in find_all(struct.pack("<2d", float.fromhex("0x1.68a1f80d71820p+0"), float.fromhex("0x1.65de82af9631fp+0"))):
+    if abs(dbl(off + 8 * 127, 1)[0] - 0.70849190843208) < 1e-13:
+        inroot_off = off
+assert acos_off and inroot_off, "asincos.tbl / root.tbl not found"
+ASNCS = dbl(acos_off, 2568)
+INROOT = dbl(inroot_off, 128)
+ACOS_C = {"f1": "0x1.55555555554f9p-3", "f2": "0x1.333333336127dp-4", "f3": "0x1.6db6dae42c0e4p-5", "f4": "0x1.f1c7e04f4ad99p-6",
+          "f5": "0x1.6e442c822d419p-6", "f6": "0x1.292d80f453c72p-6", "rt0": "0x1.fffffffecc1ddp-1", "rt1": "0x1.fffffff757304p-2",
+          "rt2": "0x1.800496769c91ap-2", "rt3": "0x1.4006318d1dab9p-2"}
+for name, hx in ACOS_C.items():
+    assert find_all(struct.pack("<d", float.fromhex(hx))), name
+
 EXP_C = dbl(exp_off, 8)                       # invln2N, shift, negln2hiN, negln2loN, C2, C3, C4, C5
 EXP_TAB = u64(exp_off + 112, 256)             # {tail bits, scale bits} x 128
 POW_C = dbl(pow_off, 9)                       # ln2hi, ln2lo, A[0..6]
@@ -104,7 +122,7 @@ def emit(path, device):
     c0, c1 = ("// ", "") if device else ("/* ", " */")
     with open(path, "w") as f:
         for line in ("GENERATED by tools/extract_glibc_dbl64_tables.py from the host's libm.so.6 (GLIBC 2.35):",
-                     "the constant tables of glibc's double exp / pow / atan2 / sin / cos / tan (sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c, e_atan2.c, s_sin.c, s_tan.c).",
+                     "the constant tables of glibc's double exp / pow / atan2 / sin / cos / tan / acos (sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c, e_atan2.c, s_sin.c, s_tan.c, e_asin.c).",
                      "Numeric data only; the algorithms are restated in djb_device.hpp / djb_oracle.c."):
             f.write(c0 + line + c1 + "\n")
         if device:
@@ -122,7 +140,11 @@ def emit(path, device):
         f.write("%s__sincostab of s_sin.c: 110 x {sin hi, sin lo, cos hi, cos lo} at k / 128%s\n%s double DJB_GLIBC_SINCOS_TAB[440] = {\n\t" % (c0, c1, q)
                 + arr(SINCOS_TAB, per=4) + "\n};\n\n")
         f.write("%sxfg[186][4] of s_tan.c (utan.tbl): x_i, tan(x_i), cot(x_i) hi, lo%s\n%s double DJB_GLIBC_TAN_XFG[186 * 4] = {\n\t" % (c0, c1, q)
-                + arr(TAN_XFG, per=4) + "\n};\n")
+                + arr(TAN_XFG, per=4) + "\n};\n\n")
+        f.write("%sasncs[2568] of e_asin.c (asincos.tbl): per interval rows {x_i, Taylor coefficients of asin / acos about x_i, values at x_i}%s\n%s double DJB_GLIBC_ASNCS[2568] = {\n\t" % (c0, c1, q)
+                + arr(ASNCS, per=6) + "\n};\n\n")
+        f.write("%sinroot[128] of e_asin.c (root.tbl): 1 / sqrt seeds%s\n%s double DJB_GLIBC_INROOT[128] = {\n\t" % (c0, c1, q)
+                + arr(INROOT, per=4) + "\n};\n")
 
 
 emit(os.path.join(ROOT, "dj_brdf_amd", "csrc", "djb_glibc_dbl64_tables.hpp"), True)

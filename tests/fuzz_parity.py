@@ -5,9 +5,8 @@ fraction of bit-identical outputs and the largest relative difference.  Paths th
 construction (GGX, Beckmann, abc, MERL, all sampling: IEEE arithmetic plus glibc's own exp / pow / logf / expf /
 powf algorithms) must be 100 % bit-exact.  Since round 2 that also holds for the fp64 trigonometric calls of UTIA,
 the spline Fresnel, sgd and the fitters (atan2 / sin / cos / tan / acos restated from glibc, the float -> float sites
-verified over all 2^32 inputs): no path is left on which ROCm's libm is merely observed to agree with glibc's; should
-one differ all the same the values are -- those are counted, dumped with their inputs, and must
-stay inside 1e-5.   PYTHONPATH=. python tests/fuzz_parity.py [rounds] [n] [seed]
+verified over all 2^32 inputs): no path is left on which ROCm's libm is merely observed to agree with glibc's; differing
+values, should one appear all the same, are counted, dumped with their inputs, and must stay inside 1e-5.   PYTHONPATH=. python tests/fuzz_parity.py [rounds] [n] [seed]
 DJB_FUZZ_CTX=cpu runs the product's HOST path (Context("cpu")) instead: there every libm call is the host's glibc,
 i.e. the reference's own, so EVERY comparison must be bit-exact (no GPU needed)."""
 import os, sys, time

@@ -89,7 +89,8 @@ DJB_DEV float sat_(float x) { return fmin_(1.0f, fmax_(0.0f, x)); }
 // Every place where the path rounds a double libm trig result of ONE float argument straight to float goes through
 // one of these, so that each is a float -> float map with 2^32 inputs: tools/exhaustive_trig.py sweeps all of them on
 // the device against the host's glibc (djb_selftest_trig_sweep).  The two-argument atan2 sites and the sites that keep
-// the double (cos(phi) * sin(theta) products, sgd/abc) are not of this shape and stay "observed" (DESIGN section 2).
+// the double (cos(phi) * sin(theta) products, the fitters' integrands, sgd's g1) are not of this shape: they run glibc's
+// own algorithms (glibc_atan2 / sin / cos / tan / acos below).
 enum { TRIG_COS = 0, TRIG_SIN, TRIG_TAN, TRIG_ACOS, TRIG_ACOS_U, TRIG_ACOS_U32, TRIG_ATAN_SQU, TRIG_ATAN_U,
        TRIG_ATAN_SQRT, TRIG_BECK_QF, TRIG_ACOS_DEG, TRIG_UTIA_BIN15, TRIG_UTIA_BIN7P5, TRIG_SITES };
 DJB_DEV float cos_f(float x) { return F(cos(D(x))); }

@@ -6,8 +6,8 @@ float inputs of every site (csrc/djb_device.hpp TRIG_*).  Needs a GPU:
     python tools/exhaustive_trig.py [--sites cos,acos] [--out gpurun_out/exhaustive_trig.json] [--chunk-log2 27]
 
 Prints one line per site and writes the list of differing inputs (input bits, device bits, host bits).  The *_d
-sites compare the double itself (the places that keep it); there the count is informational: it says how often
-ROCm's and glibc's double functions differ in the last place on float arguments.
+sites compare the double itself; there the count is informational: it says how often ROCm's and glibc's double
+functions differ in the last place on float arguments (the places that keep the double run glibc's own algorithms).
 """
 import argparse
 import json

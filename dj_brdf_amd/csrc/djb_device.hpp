@@ -179,10 +179,10 @@ DJB_DEV float recip_to_f32(double q) { return F(1.0 / q); }
 // tests that (256 ulp64 either side; probability 2^-20), and the caller then takes the exact path.
 // y comes from v_rsq_f64 / v_rcp_f64 refined by two Newton steps (error <= a few 2^-53 for any
 // seed accuracy >= 2^-14); e itself is within 2^-52 of the true value.
-DJB_DEV bool near_f32_midpoint(double y, long long width = 256)
+DJB_DEV bool near_f32_midpoint(double y, int width = 256)
 {
-	unsigned long long b = (unsigned long long)__double_as_longlong(y) & 0x1FFFFFFFull;
-	long long d = (long long)b - 0x10000000ll;
+	// the 29 mantissa bits a float does not keep sit in the low word: 32-bit arithmetic (4 VALU instead of ~10)
+	const int d = (int)((unsigned int)__double2loint(y) & 0x1FFFFFFFu) - 0x10000000;
 	return (d < 0 ? -d : d) <= width;
 }
 // inversesqrt = float(1.0 / sqrt(double(x))): two double roundings (dj_brdf.h:612)

@@ -757,7 +757,8 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 		for (long long lo = 0; lo < n; lo += CH) {
 			long long m = n - lo < CH ? n - lo : CH;
 			size_t cap = (size_t)(m / 256 + 4096);
-			size_t need = 16 + 4 * cap;
+			if (const char *e = getenv("DJB_UTIA_WORKLIST_CAP")) cap = (size_t)strtoull(e, nullptr, 10);   // test hook: force the overflow path
+			size_t need = 16 + 4 * (cap ? cap : 1);
 			if (ctx->scratch_bytes < need) {
 				HIP_TRY(hipStreamSynchronize(ctx->stream));
 				if (ctx->scratch) (void)hipFree(ctx->scratch);

@@ -134,7 +134,8 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
 /* DJB_OPT_UTIA_EXACT_ONLY = 1: utia eval / evalp batches run one kernel that carries the exact fall-backs of the azimuths
  * (glibc's atan2) and of the sRGB power inline, instead of the two-tier form (tier 1 without them + a worklist of the
  * pairs that sit next to a float rounding boundary, re-evaluated by a second kernel); both give the same bits, the
- * option exists to verify that */
+ * option exists to verify that.  (Environment DJB_UTIA_WORKLIST_CAP=<entries> overrides the worklist capacity: a test
+ * hook for the overflow path, in which the second kernel redoes the whole batch.) */
        DJB_OPT_UTIA_EXACT_ONLY = 5 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */

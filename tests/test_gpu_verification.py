@@ -286,3 +286,22 @@ def test_utia_two_tier_equals_the_one_kernel_form(gpu_ctx):
         assert torch.equal(two.view(torch.int32), one.view(torch.int32))
     finally:
         djb.set_utia_exact_only(gpu_ctx, False)
+
+
+def test_utia_worklist_overflow_redoes_the_batch(gpu_ctx, monkeypatch):
+    """A worklist too small for the undecided pairs (capacity forced to 0) makes tier 2 redo the whole batch: same bits."""
+    import torch
+    n = 20_000_000
+    i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
+    u = djb.utia.from_table(synth.utia_table_smooth(), ctx=gpu_ctx)
+    want = u.eval(i, o)
+    monkeypatch.setenv("DJB_UTIA_WORKLIST_CAP", "0")
+    got = u.eval(i, o)
+    monkeypatch.delenv("DJB_UTIA_WORKLIST_CAP")
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    try:
+        djb.set_utia_exact_only(gpu_ctx, True)
+        one = u.eval(i, o)
+    finally:
+        djb.set_utia_exact_only(gpu_ctx, False)
+    assert torch.equal(one.view(torch.int32), want.view(torch.int32))

@@ -14,6 +14,9 @@ Workloads (BASELINE.json configs):
   beckmann_sample  configs[3]: Beckmann elliptic(0.2,0.5,0.7) VNDF sample(), 1e9 samples, on-chip RNG
   merl_fit         configs[4]: power-iteration fit of 100 MERL materials resident in HBM
   utia_eval        (no BASELINE config; north_star names UTIA tables) utia::eval over 1e8 pairs
+  ggx_eval_pdf_contract   configs[1] with DJB_OPT_CONTRACT_1E5 (values within 1e-5 relative, not bit-identical)
+  merl_eval_uniform_bins  configs[2] with look-ups spread uniformly over all 1.458 M bins (worst case for the caches)
+  merl_eval_coherent      configs[2] on a renderer-like batch: neighbouring pixels of a bumpy plane, one light
 
 Multi-GPU (torchrun, one rank per GPU): units are independent, every rank runs the same per-GPU
 batch on its own device ("weak" scaling), there is NO data-path collective; the only
@@ -53,6 +56,11 @@ WORKLOADS = {
     # name: (default n per GPU, algorithmic HBM bytes per unit, unit, kernel family)
     "merl_eval": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval> (two-tier exact)"),
     "ggx_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf>"),
+    # the same configuration under DJB_OPT_CONTRACT_1E5: values within 1e-5 relative instead of bit-identical
+    "ggx_eval_pdf_contract": (100_000_000, 40, "evals", "k_ct_fast_v4<GGX,eval+pdf> + k_ct_fixup (two-tier, 1e-5 value contract)"),
+    # the headline kernel on two other look-up distributions (the 0.40 of merl_eval is distribution dependent):
+    "merl_eval_uniform_bins": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval>, (theta_h, theta_d, phi_d) bins uniform over the table"),
+    "merl_eval_coherent": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval>, renderer-like batch (neighbouring pixels of a bumpy plane)"),
     "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample<BECKMANN,rng>"),
     "utia_eval": (100_000_000, 36, "evals", "k_eval_utia_t1<eval> + k_eval_utia_fix<eval> (two-tier exact)"),
     "merl_fit": (100, None, "materials", "k_fit<MERL>"),
@@ -95,6 +103,57 @@ def parse():
 GGX_ALPHA, GGX_FRESNEL = 0.3, "ideal"       # overridden by --alpha / --fresnel
 
 
+def merl_pairs(name, n, djb, torch, ctx):
+    """(i, o) as [3, n] device tensors for the two extra MERL legs, generated on the device in chunks.
+    uniform_bins: a (theta_h, theta_d, phi_d) bin drawn uniformly from the 90 x 90 x 180 table, the pair at a jittered
+    position inside it (hd_to_io of the bin's angles) -- every table line equally likely, nothing for the caches to keep.
+    coherent: what a renderer hands over -- pixel k of a W-wide image of a gently bumpy plane, camera and one light
+    fixed, i / o = light / view direction in the pixel's shading frame: consecutive pairs land in the same or
+    neighbouring bins."""
+    dev = f"cuda:{ctx.device}"
+    i = torch.empty((3, n), dtype=torch.float32, device=dev)
+    o = torch.empty((3, n), dtype=torch.float32, device=dev)
+    CH = 1 << 26
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    for lo in range(0, n, CH):
+        m = min(CH, n - lo)
+        if name == "merl_eval_uniform_bins":
+            u = torch.rand((3, m), generator=g, device=dev, dtype=torch.float32)
+            ih = torch.randint(0, 90, (m,), generator=g, device=dev); idd = torch.randint(0, 90, (m,), generator=g, device=dev)
+            ip = torch.randint(0, 180, (m,), generator=g, device=dev)
+            j = 0.1 + 0.8 * u                                           # stay clear of the bin edges
+            th = ((ih + j[0]) ** 2 / 90.0) * (3.14159265 / 180.0)       # theta_h bins are quadratic (dj_brdf.h:906-920)
+            td = (idd + j[1]) * (3.14159265 / 180.0)
+            pd = (ip + j[2]) * (3.14159265 / 180.0)
+            h = torch.stack([torch.sin(th), torch.zeros_like(th), torch.cos(th)])
+            d = torch.stack([torch.sin(td) * torch.cos(pd), torch.sin(td) * torch.sin(pd), torch.cos(td)])
+            ii, oo = djb.brdf.hd_to_io(h.contiguous(), d.contiguous(), ctx=ctx)
+            i[:, lo:lo + m] = ii; o[:, lo:lo + m] = oo
+            del u, ih, idd, ip, j, th, td, pd, h, d, ii, oo
+        else:
+            W = 32768
+            k = torch.arange(lo, lo + m, device=dev, dtype=torch.int64)
+            x = (k % W).to(torch.float32) * (8.0 / W) - 4.0             # the plane spans [-4, 4] x [-4 H/W, ...]
+            y = (k // W).to(torch.float32) * (8.0 / W) - 4.0
+            # height field: three sinusoids, slopes <= ~0.45
+            sx = 0.20 * torch.cos(3.1 * x + 0.5 * y) * 3.1 * 0.05 + 0.15 * torch.cos(0.7 * x - 1.3 * y) * 0.7 + 0.1 * torch.sin(5.0 * x)
+            sy = 0.20 * torch.cos(3.1 * x + 0.5 * y) * 0.5 * 0.05 - 0.15 * torch.cos(0.7 * x - 1.3 * y) * 1.3 + 0.1 * torch.cos(4.0 * y)
+            nrm = torch.rsqrt(sx * sx + sy * sy + 1.0)
+            nx, ny, nz = -sx * nrm, -sy * nrm, nrm
+            # tangent frame: t = normalize(e_x - n (n.e_x)), b = n x t
+            tx, ty, tz = 1.0 - nx * nx, -ny * nx, -nz * nx
+            tn = torch.rsqrt(tx * tx + ty * ty + tz * tz); tx, ty, tz = tx * tn, ty * tn, tz * tn
+            bx, by, bz = ny * tz - nz * ty, nz * tx - nx * tz, nx * ty - ny * tx
+            def local(vx, vy, vz):
+                vn = torch.rsqrt(vx * vx + vy * vy + vz * vz); vx, vy, vz = vx * vn, vy * vn, vz * vn
+                return torch.stack([vx * tx + vy * ty + vz * tz, vx * bx + vy * by + vz * bz, vx * nx + vy * ny + vz * nz])
+            o[:, lo:lo + m] = local(0.0 - x, -6.0 - y, 5.0 + 0 * x)      # camera at (0, -6, 5)
+            i[:, lo:lo + m] = local(3.0 - x, 2.0 - y, 6.0 + 0 * x)       # point light at (3, 2, 6)
+            del k, x, y, sx, sy, nrm, nx, ny, nz, tx, ty, tz, tn, bx, by, bz
+    torch.cuda.synchronize()
+    return i, o
+
+
 def make_step(name, n, djb, synth, ctx, torch):
     """Returns (step_fn, keepalive).  Inputs are generated on-device before the timed region."""
     if name == "merl_eval":
@@ -109,7 +168,18 @@ def make_step(name, n, djb, synth, ctx, torch):
             djb._lib.check(lib.djb_eval_batch(ctx._h, m._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
                                               None, C.byref(vout.view), C.c_int(0)))
         return step, (i, o, m, out, vi, vo, vout)
-    if name == "ggx_eval_pdf":
+    if name in ("merl_eval_uniform_bins", "merl_eval_coherent"):
+        i, o = merl_pairs(name, n, djb, torch, ctx)
+        m = djb.merl.from_table(synth.merl_table(0.3), ctx=ctx)
+        out = torch.empty((3, n), dtype=torch.float32, device=i.device)
+        lib, C = djb._lib.load(), ctypes
+        vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
+
+        def step():
+            djb._lib.check(lib.djb_eval_batch(ctx._h, m._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                              None, C.byref(vout.view), C.c_int(0)))
+        return step, (i, o, m, out, vi, vo, vout)
+    if name in ("ggx_eval_pdf", "ggx_eval_pdf_contract"):
         i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
         o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
         fr = djb.fresnel.ideal() if GGX_FRESNEL == "ideal" else djb.fresnel.schlick((1.0, 0.71, 0.29))
@@ -120,10 +190,18 @@ def make_step(name, n, djb, synth, ctx, torch):
         lib, C = djb._lib.load(), ctypes
         vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
 
+        contract = name.endswith("_contract")
+
         def step():
-            djb._lib.check(lib.djb_eval_pdf_batch(ctx._h, g._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
-                                                  C.byref(p._p), C.c_int(0), C.byref(vout.view),
-                                                  C.c_void_p(pdf.data_ptr()), C.c_int(0)))
+            if contract:                      # the option is per context and off by default: on only around this launch
+                djb.set_contract_1e5(ctx, True)
+            try:
+                djb._lib.check(lib.djb_eval_pdf_batch(ctx._h, g._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                                      C.byref(p._p), C.c_int(0), C.byref(vout.view),
+                                                      C.c_void_p(pdf.data_ptr()), C.c_int(0)))
+            finally:
+                if contract:
+                    djb.set_contract_1e5(ctx, False)
         return step, (i, o, g, p, out, pdf, vi, vo, vout)
     if name == "beckmann_sample":
         o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
@@ -179,7 +257,7 @@ def cpu_baseline(name, synth, budget_s=12.0):
     L = oraclelib.CheckerLib(ref_path, "ref_") if kind == "reference" else oraclelib.oracle()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     par = None
-    if name == "merl_eval":
+    if name.startswith("merl_eval"):
         if kind == "reference":
             path = "/tmp/djb_bench_cpu.binary"
             synth.write_merl_binary(path, synth.merl_table(0.3))
@@ -187,7 +265,7 @@ def cpu_baseline(name, synth, budget_s=12.0):
         else:
             b = L.merl_from_table(synth.merl_table(0.3))
         op = "eval"
-    elif name == "ggx_eval_pdf":
+    elif name in ("ggx_eval_pdf", "ggx_eval_pdf_contract"):
         b, op, par = L.microfacet("ggx", ("ideal",) if GGX_FRESNEL == "ideal" else ("schlick", 1.0, 0.71, 0.29), True), "eval", ("elliptic", GGX_ALPHA, GGX_ALPHA, 0.0)
     elif name == "beckmann_sample":
         b, op, par = L.microfacet("beckmann", ("ideal",), True), "sample", ("elliptic", 0.2, 0.5, 0.7)
@@ -412,7 +490,11 @@ def main():
                                 "utia_eval": "UTIA 6x48x6x48x3 table, 16-tap interpolation + sRGB decode (synthetic payload)",
                                 "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material, tables resident in HBM",
                                 "merl_fit_files": "files on local disk -> pread -> PCIe -> k_merl_convert -> "
-                                                  "tabular(merl, 90) + both fits (end to end)"}[name],
+                                                  "tabular(merl, 90) + both fits (end to end)",
+                                "ggx_eval_pdf_contract": f"GGX isotropic alpha={args.alpha:g}, {args.fresnel} Fresnel, eval+pdf fused, "
+                                                         "DJB_OPT_CONTRACT_1E5 (values within 1e-5 relative of the reference, not bit-identical)",
+                                "merl_eval_uniform_bins": "MERL nearest-bin, look-ups uniform over all 90x90x180 bins",
+                                "merl_eval_coherent": "MERL nearest-bin, renderer-like coherent batch (bumpy plane, one light)"}[name],
                        "layout": "SoA float32 in HBM", "parallelism": f"independent x{world} (no collective)"
                        + (" -- SELF-TEST: all ranks share GPU 0 (DJB_BENCH_SHARE_GPU), not a scaling measurement" if share_gpu else "")},
             "roofline": roofline,
@@ -427,8 +509,10 @@ def main():
             if not args.no_cpu_baseline:
                 fitfiles["cpu_baseline"] = cpu_baseline("merl_fit_files", synth)
             sec = {"merl_fit_files_100": fitfiles, "merl_fit_100": fit100}
-            for other in ("ggx_eval_pdf", "beckmann_sample", "utia_eval"):
+            for other in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "beckmann_sample", "utia_eval", "merl_eval_uniform_bins", "merl_eval_coherent"):
                 on, ob, ou, _ = WORKLOADS[other]
+                if other.startswith("merl_eval_"):
+                    on //= 4          # 2.5e8 pairs (9 GB of streams, far beyond every cache): same rate as 1e9, a quarter of the set-up time
                 st, kp = make_step(other, on, djb, synth, ctx, torch)
                 for _ in range(10):        # steady clocks: these launches are 1-20 ms, and the GPU idled during the CPU legs
                     st()
@@ -437,8 +521,16 @@ def main():
                 for _ in range(10):
                     st()
                 ms = ctx.timer_stop_ms() / 10
-                sec[other] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms,
-                              "hbm_GBps": (on * ob / (ms * 1e-3) / 1e9) if ob else None}
+                sec[other] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms, "units_per_step": on,
+                              "hbm_GBps": (on * ob / (ms * 1e-3) / 1e9) if ob else None,
+                              "roofline_frac": (on * ob / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ob else None}
+                if other == "ggx_eval_pdf_contract":
+                    # measured accuracy of the fast path against the bit-exact per-pair code, same set-up, 2^28 generated pairs
+                    acc = djb.selftest_contract(kp[2], kp[3], n=1 << 28, seed=3, family=0, ctx=ctx)
+                    sec[other].update({"max_rel_err_eval": acc["max_rel_eval"], "max_rel_err_pdf": acc["max_rel_pdf"],
+                                       "values_outside_1e-5": acc["outside_1e5"], "zero_pattern_mismatches": acc["zero_mismatch"],
+                                       "exact_tier_share": acc["tier2"] / acc["pairs"], "contract": "1e-5 relative (north_star), "
+                                       "bit-exact tier for ill-conditioned pairs; DJB_OPT_CONTRACT_1E5, off by default"})
                 del st, kp
                 torch.cuda.empty_cache()
             rec["secondary"] = sec

@@ -57,6 +57,7 @@ struct djb_ctx {
 	int aniso_qf2_aligned = 0; // DJB_OPT_ANISO_QF2_ALIGNED
 	int fit_files_dense = 0;   // DJB_OPT_FIT_FILES_DENSE
 	int utia_exact_only = 0;   // DJB_OPT_UTIA_EXACT_ONLY: utia eval batches run k_eval<UTIA> (one kernel, exact fall-backs inline) instead of the two tiers
+	int contract_1e5 = 0;      // DJB_OPT_CONTRACT_1E5: dense GGX eval batches run the two-tier value-contract kernels
 	int scalar_on_device = 0;  // DJB_OPT_SCALAR_ON_DEVICE: scalar-size host calls go through the GPU too (A/B testing)
 	// HBM staging blocks of the DJB_MEM_HOST path, recycled across calls (hipMalloc costs more than
 	// a small batch); bounded by POOL_MAX_BYTES
@@ -772,6 +773,35 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 			                                  list, (unsigned int)cap, count));
 		}
 		return sg.finish();
+	}
+	if (ctx->contract_1e5 && b->dev.kind == DJB_KIND_GGX && djbk::contract_supported(b->dev, p)) {
+		auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+		const bool dense16 = vi.stride == 1 && vo.stride == 1 && al16(vi.x) && al16(vi.y) && al16(vi.z) && al16(vo.x) && al16(vo.y) && al16(vo.z) &&
+		                     (!(want & 3) || (vout.stride == 1 && al16(vout.x) && al16(vout.y) && al16(vout.z))) && (!(want & 4) || al16(dpdf));
+		if (dense16) {
+			// as for MERL: pair indices travel as uint32; worklist = 16-byte header + 32-byte records {k, i, o}
+			const long long CH = 1LL << 31;
+			for (long long lo = 0; lo < n; lo += CH) {
+				long long m = n - lo < CH ? n - lo : CH;
+				const size_t REC = 32;
+				size_t cap = (size_t)(m / 48 + 4096);
+				size_t need = 16 + REC * cap;
+				if (ctx->scratch_bytes < need) {
+					HIP_TRY(hipStreamSynchronize(ctx->stream));
+					if (ctx->scratch) (void)hipFree(ctx->scratch);
+					ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+					HIP_TRY(hipMalloc(&ctx->scratch, need));
+					ctx->scratch_bytes = need;
+				}
+				cap = (ctx->scratch_bytes - 16) / REC;
+				if (cap > 0xffffffffull) cap = 0xffffffffull;
+				unsigned int *count = (unsigned int *)ctx->scratch, *list = count + 4;
+				auto off = [&](const View &v) { return View{ v.x ? v.x + lo : nullptr, v.y ? v.y + lo : nullptr, v.z ? v.z + lo : nullptr, v.stride }; };
+				HIP_TRY(djbk::launch_eval_contract(ctx->stream, b->dev, p, m, off(vi), off(vo), off(vout), dpdf ? dpdf + lo : nullptr, want,
+				                                   list, (unsigned int)cap, count));
+			}
+			return sg.finish();
+		}
 	}
 	HIP_TRY(djbk::launch_eval(ctx->stream, b->dev, p, n, vi, vo, vout, dpdf, want));
 	return sg.finish();
@@ -1889,6 +1919,7 @@ try {
 	if (option == DJB_OPT_MERL_EXACT_ONLY) { ctx->merl_exact_only = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_ANISO_QF2_ALIGNED) { ctx->aniso_qf2_aligned = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_UTIA_EXACT_ONLY) { ctx->utia_exact_only = value != 0; return DJB_OK; }
+	if (option == DJB_OPT_CONTRACT_1E5) { ctx->contract_1e5 = value != 0; return DJB_OK; }
 	return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown option %d", option);
 }
 DJB_ABI_CATCH
@@ -1965,6 +1996,36 @@ try {
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	(void)hipFree(d);
 	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));
+	return DJB_OK;
+}
+DJB_ABI_CATCH
+
+djb_status djb_selftest_contract(djb_ctx *ctx, const djb_brdf *b, const djb_params *params, int64_t n, uint32_t seed, int family,
+                                 float *max_rel2, unsigned long long *counters4)
+try {
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
+	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
+	djb_status st = check_call(ctx, b, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	if (!max_rel2 || !counters4) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	Params p;
+	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
+	if (b->dev.kind != DJB_KIND_GGX || !djbk::contract_supported(b->dev, p))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf / params outside the domain of the contract-mode fast path");
+	unsigned char *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 64));
+	hipError_t e = hipMemsetAsync(d, 0, 64, ctx->stream);
+	if (e == hipSuccess)
+		e = djbk::launch_contract_selftest(ctx->stream, b->dev, p, n, seed, seed ^ 0x9e3779b9u, 0ull, family,
+		                                   (unsigned int *)d, (unsigned long long *)(d + 16));
+	unsigned char h[64];
+	if (e == hipSuccess) e = hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: contract selftest: %s", hipGetErrorString(e));
+	memcpy(max_rel2, h, 8);
+	memcpy(counters4, h + 16, 32);
 	return DJB_OK;
 }
 DJB_ABI_CATCH

@@ -58,6 +58,14 @@ hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsign
 // k_eval_utia_fix for the pairs of the worklist (count: 16 bytes, list: cap entries)
 hipError_t launch_utia_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o, const View &out,
                                float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count);
+// DJB_OPT_CONTRACT_1E5 (djb_kernels_contract.hip): GGX eval / evalp / pdf inside the 1e-5 value contract, two-tier like
+// the MERL lookup (list: cap records of 32 bytes, count: 1 uint32).  Views must be dense (stride 1) and 16-byte aligned.
+constexpr float CT_RHO_MAX = 0.9f;
+bool contract_supported(const Brdf &b, const Params &p);
+hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i, const View &o,
+                                const View &out, float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count);
+hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed_i, uint32_t seed_o,
+                                    unsigned long long start, int family, unsigned int *max_bits, unsigned long long *counters);
 hipError_t launch_guard_selftest(hipStream_t s, long long n, uint32_t seed, unsigned long long *counters);
 hipError_t launch_libm_probe(hipStream_t s, int fn, long long n, const double *x, const double *y, double *out);
 hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n, void *out);

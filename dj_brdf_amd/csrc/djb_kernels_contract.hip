@@ -1,0 +1,327 @@
+// djb_kernels_contract.hip -- DJB_OPT_CONTRACT_1E5: eval / evalp / pdf of the analytic lobes inside the
+// north star's VALUE contract (|result - reference| <= 1e-5 |reference|) instead of bit-identically.
+//
+// The default kernels (djb_kernels_eval.hip) spend ~350 VALU issue slots per GGX pair on reproducing the reference's
+// roundings: 15 correctly rounded divisions, 2 square roots, ~35 fp64 operations (microfacet::eval / pdf,
+// dj_brdf.h:1529-1555, 1713-1730 with ndf 1559, p22 1574, sigma 1619, g1 1633, gaf 1644).  This file evaluates the
+// same formulas with v_rsq_f32 / v_rcp_f32 (1 ulp each), algebraically merged denominators (6 transcendental-rate
+// instructions per eval+pdf pair instead of 15 divisions) and float4 non-temporal streams, which makes the GGX kernel
+// HBM-bound.  What keeps it inside the contract for EVERY input, not only for typical ones:
+//
+//  * every branch the reference takes on a computed value (g1 > 0, G > 0, h.z > 1e-4, dot(o, h) > 0) is decided from
+//    quantities that are bit-identical to the reference's (sums and products of the inputs in the reference's order),
+//    or the pair is handed to tier 2 when the approximate operand lies near the threshold;
+//  * the places where the reference's own float chain is ill-conditioned -- dot(o, h) and dot(i, h) of the pdf near
+//    theta_d = 90 deg, where one ulp of h moves the quotient by more than 1e-5 -- are detected (CT_DOT_MIN) and handed
+//    to tier 2 as well: an approximate evaluation cannot track the reference's rounding noise there;
+//  * tier 2 (k_ct_fixup) runs eval_one -- the bit-exact per-pair code of the default kernels -- on the listed pairs.
+//    Like the MERL tiers it streams {k, i, o} records, and on worklist overflow it redoes the whole batch exactly.
+//
+// Error budget of the fast path (u = 2^-24, all relative, tx = ty = 0, |rho| <= CT_RHO_MAX): D <= ~36 u (68 u at the
+// rho limit), shadowing-masking and the merged 1 / (4 o.z i.z) <= 15 u, the pdf's two dot products <= 18 u each with
+// CT_DOT_MIN = 0.25: worst case sum <= ~1e-5 * 0.5; measured maxima are reported by djb_selftest_contract
+// (tests/test_gpu_contract.py, bench.py secondary.ggx_eval_pdf_contract).
+// MERL / UTIA indices and cell decisions are never approximated: they do not go through this file.
+#include "djb_internal.hpp"
+#include "djb_worklist.hpp"
+
+using namespace djbdev;
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+inline int grid_for(long long n, long long cap = 256LL * 64)
+{
+	long long blocks = (n + BLOCK - 1) / BLOCK;
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	return (int)blocks;
+}
+
+constexpr float CT_DOT_MIN = 0.25f;      // pdf: dot(o, h), dot(i, h) below this -> tier 2 (conditioning, see header)
+constexpr float CT_HZ_MIN = 1.2e-4f;     // h.z below this -> tier 2 (the reference's h.z > 1e-4 cut, dj_brdf.h:1561)
+constexpr float CT_LO = 1e-12f, CT_HI = 1e12f;   // operand range of the rcp / rsq shortcuts (no denormals, no overflow)
+
+DJB_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+DJB_DEV float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
+DJB_DEV bool in_range(float x) { return (x > CT_LO) & (x < CT_HI); }          // false for NaN
+
+// launch-uniform constants of the fast path
+struct CtParams {
+	float ax, ay, rho, s, rho_ay;      // microfacet::params (tx = ty = 0, mean normal = +z)
+	float r_ax, r_t2;                  // float(1 / ax), float(1 / (ax ay s))
+	float k_d;                         // float(r_t2 / pi): the constant factor of D
+	float f0[3], f1[3];                // schlick: f0 and 1 - f0
+	int shadow;
+};
+
+// stretched-space norm and sigma of direction k (microfacet::sigma, dj_brdf.h:1619-1631, ggx::sigma_std_radial :2062)
+template <int KIND>
+DJB_DEV float ct_sigma(const CtParams &c, v3 k, bool &ok)
+{
+	float a = k.x * c.ax + k.y * c.ay * c.rho;
+	float bb = k.y * c.ay * c.s;
+	float n2 = a * a + bb * bb + k.z * k.z;                 // bit-identical to the reference's (tx = ty = 0)
+	ok &= (in_range(n2));
+	float rn = rsq_(n2), nrm = n2 * rn, kz = rn * k.z;
+	return nrm * ((1.0f + kz) * 0.5f);
+}
+
+// one pair; false = tier 2.  fr / pdf follow eval_one's WANT convention (1 eval, 2 evalp, 4 pdf)
+template <int KIND, int WANT, int FRK>
+DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
+{
+	static_assert(KIND == KIND_GGX, "contract mode: GGX");
+	// g1(k) > 0 <=> dot(k, m_n) = k.z > 0 (dj_brdf.h:1633-1642); gaf > 0 <=> both (shadow) / g1(o) (dj_brdf.h:1644-1665)
+	// -- decided on the inputs themselves, NaN included: the reference's comparisons are false for NaN and return zeros.
+	// Branch-free: dead pairs run the arithmetic on whatever they hold and select the zeros at the end.
+	const bool live = (o.z > 0.0f) & (!c.shadow | (i.z > 0.0f));
+	bool ok = (o.z > CT_LO) & (i.z > CT_LO);
+	v3 s = add(i, o);
+	float m = dot(s, s);
+	ok &= (in_range(m));
+	float r = rsq_(m), hz = r * s.z;
+	ok &= (hz > CT_HZ_MIN);
+	float sig_o = ct_sigma<KIND>(c, o, ok);
+	// 4 * o.z * i.z / G:  G = t / (g1i + g1o - t) with g1 = k.z / sigma  ->  4 (i.z sig_o + o.z sig_i - i.z o.z)
+	float den4;
+	if (c.shadow) {
+		float sig_i = ct_sigma<KIND>(c, i, ok);
+		den4 = 4.0f * ((i.z * sig_o + o.z * sig_i) - i.z * o.z);
+	} else den4 = 4.0f * (sig_o * i.z);
+	// slope of h and the stretched slope (microfacet::ndf / p22, dj_brdf.h:1559-1587)
+	float rz = rcp_(s.z), xs = -s.x * rz, ys = -s.y * rz;
+	float x_ = xs * c.r_ax;
+	float y_ = (c.ax * ys - c.rho_ay * xs) * c.r_t2;
+	float r2 = x_ * x_ + y_ * y_;
+	ok &= (r2 < 1e14f);
+	float t = 1.0f + r2, c2 = hz * hz;
+	float T = (t * t) * (c2 * c2);                            // D = k_d / T   (ggx::p22_radial, dj_brdf.h:2056)
+	float oh = r * dot(o, s);
+	fr = mk(0, 0, 0); pdf = 0.0f;
+	if (WANT & 3) {
+		float e = c.k_d * rcp_(T * den4);                      // D G / (4 o.z i.z)
+		if (WANT & 2) e *= i.z;                                // evalp
+		ok &= (e < 1e30f);
+		e = live ? e : 0.0f;
+		if (FRK == FR_SCHLICK) {                               // fresnel::schlick, dj_brdf.h:1322-1328
+			float cd = sat_(oh), c1 = 1.0f - cd, c2_ = c1 * c1, c5 = c2_ * c2_ * c1;
+			fr = mk(e * (c.f0[0] + c5 * c.f1[0]), e * (c.f0[1] + c5 * c.f1[1]), e * (c.f0[2] + c5 * c.f1[2]));
+		} else fr = mk(e, e, e);
+	}
+	if (WANT & 4) {
+		float ih = r * dot(i, s);
+		ok &= (oh > CT_DOT_MIN) & (ih > CT_DOT_MIN);
+		float q = (oh * c.k_d) * rcp_(T * (4.0f * ih * sig_o));  // (o.h) D / (sigma(o) 4 (i.h)), dj_brdf.h:1602-1615, 1724
+		ok &= (q < 1e30f);
+		pdf = live ? q : 0.0f;
+	}
+	return ok | !live;
+}
+
+template <int KIND, int WANT, int FRK>
+__global__ __launch_bounds__(BLOCK) void k_ct_fast_v4(CtParams c, long long n4, View vi, View vo, View vout, float *out_pdf,
+                                                      uint4 *list, unsigned int cap, unsigned int *count)
+{
+	__shared__ WaveBuf wbuf[BLOCK / 64];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	unsigned int wcount = 0;
+	const float4 *ix4 = (const float4 *)vi.x, *iy4 = (const float4 *)vi.y, *iz4 = (const float4 *)vi.z;
+	const float4 *ox4 = (const float4 *)vo.x, *oy4 = (const float4 *)vo.y, *oz4 = (const float4 *)vo.z;
+	const long long stride = (long long)gridDim.x * BLOCK;
+	for (long long q0 = (long long)blockIdx.x * BLOCK; q0 < n4; q0 += stride) {
+		const long long q = q0 + threadIdx.x;
+		bool amb[4] = { false, false, false, false };
+		float ixs[4], iys[4], izs[4], oxs[4], oys[4], ozs[4];
+		if (q < n4) {
+			float4 ax = nt_load4(ix4 + q), ay = nt_load4(iy4 + q), az = nt_load4(iz4 + q),
+			       bx = nt_load4(ox4 + q), by = nt_load4(oy4 + q), bz = nt_load4(oz4 + q);
+			ixs[0] = ax.x; ixs[1] = ax.y; ixs[2] = ax.z; ixs[3] = ax.w;
+			iys[0] = ay.x; iys[1] = ay.y; iys[2] = ay.z; iys[3] = ay.w;
+			izs[0] = az.x; izs[1] = az.y; izs[2] = az.z; izs[3] = az.w;
+			oxs[0] = bx.x; oxs[1] = bx.y; oxs[2] = bx.z; oxs[3] = bx.w;
+			oys[0] = by.x; oys[1] = by.y; oys[2] = by.z; oys[3] = by.w;
+			ozs[0] = bz.x; ozs[1] = bz.y; ozs[2] = bz.z; ozs[3] = bz.w;
+			float rr[4], gg[4], bb[4], pp[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				v3 fr; float pdf;
+				amb[j] = !ct_eval_one<KIND, WANT, FRK>(c, mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]), fr, pdf);
+				rr[j] = fr.x; gg[j] = fr.y; bb[j] = fr.z; pp[j] = pdf;
+			}
+			// tier-2 pairs get a placeholder here; k_ct_fixup runs after this kernel on the same stream and overwrites it
+			if (WANT & 3) {
+				nt_store4(rr[0], rr[1], rr[2], rr[3], (float4 *)vout.x + q);
+				nt_store4(gg[0], gg[1], gg[2], gg[3], (float4 *)vout.y + q);
+				nt_store4(bb[0], bb[1], bb[2], bb[3], (float4 *)vout.z + q);
+			}
+			if (WANT & 4) nt_store4(pp[0], pp[1], pp[2], pp[3], (float4 *)out_pdf + q);
+		}
+		if (__ballot(amb[0] | amb[1] | amb[2] | amb[3])) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+				wl_push(wbuf[wave], wcount, lane, list, cap, count, amb[j], (unsigned int)(4 * q + j),
+				        mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]));
+		}
+	}
+	if (wcount) wl_flush(wbuf[wave], wcount, lane, list, cap, count);
+}
+
+// tier 2: the bit-exact per-pair code on the listed pairs (or on the whole batch when the list overflowed)
+template <int KIND, int WANT, int FRK>
+__global__ __launch_bounds__(BLOCK) void k_ct_fixup(Brdf b, Params p, long long n, View vi, View vo, View vout, float *out_pdf,
+                                                    const uint4 *list, unsigned int cap, const unsigned int *count)
+{
+	const unsigned int m = *count;
+	if (m <= cap) {
+		const unsigned int stride = gridDim.x * BLOCK;
+		for (unsigned int j = blockIdx.x * BLOCK + threadIdx.x; j < m; j += stride) {
+			uint4 ra = list[2 * (size_t)j], rb = list[2 * (size_t)j + 1];
+			const long long k = (long long)ra.x;
+			v3 i = mk(__uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
+			v3 o = mk(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z));
+			v3 fr; float pdf;
+			eval_one<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
+			if (WANT & 3) store3(vout, k, fr);
+			if (WANT & 4) out_pdf[k] = pdf;
+		}
+	} else {
+		const long long stride = (long long)gridDim.x * BLOCK;
+		for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+			v3 fr; float pdf;
+			eval_one<KIND, WANT, FRK>(b, p, load3(vi, k), load3(vo, k), fr, pdf);
+			if (WANT & 3) store3(vout, k, fr);
+			if (WANT & 4) out_pdf[k] = pdf;
+		}
+	}
+}
+
+// ---- measurement: fast path vs the bit-exact path on generated directions.  stats[0..1]: max relative difference of
+// eval rgb / pdf among fast-path pairs (float bits, atomicMax); counters: [0] pairs, [1] tier-2 pairs, [2] fast-path
+// values where exactly one of the two results is zero, [3] fast-path values outside 1e-5
+template <int KIND, int FRK>
+__global__ __launch_bounds__(BLOCK) void k_ct_selftest(Brdf b, Params p, CtParams c, long long n, uint32_t seed_i, uint32_t seed_o,
+                                                       unsigned long long start, int family, unsigned int *max_bits,
+                                                       unsigned long long *counters)
+{
+	const long long stride = (long long)gridDim.x * BLOCK;
+	float me = 0, mp = 0;
+	unsigned long long n_t2 = 0, n_zero = 0, n_out = 0, n_all = 0;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		v3 i = gen_direction(seed_i, start + (unsigned long long)k), o = gen_direction(seed_o, start + (unsigned long long)k);
+		if (family == 1) {            // grazing, opposite azimuths: theta_d near 90 deg
+			float a = 0.02f + 0.3f * gen_uniform(seed_i ^ 0x51u, start + (unsigned long long)k);
+			o = mk(-i.x, -i.y, i.z); i.z = a * i.z; o.z = a * o.z;
+			i = normalize(i); o = normalize(o);
+		} else if (family == 2) {     // near-normal incidence
+			i = normalize(mk(0.01f * i.x, 0.01f * i.y, 1.0f)); o = normalize(mk(0.02f * o.x, 0.02f * o.y, 1.0f));
+		} else if (family == 3) {     // one direction at the horizon
+			o.z = 1e-3f * o.z; o = normalize(o);
+		} else if (family == 4) {     // un-normalised inputs
+			i = scale(0.5f + gen_uniform(seed_i ^ 0x77u, start + (unsigned long long)k), i); o = scale(3.0f, o);
+		}
+		v3 fa, fe; float pa, pe;
+		++n_all;
+		if (!ct_eval_one<KIND, 5, FRK>(c, i, o, fa, pa)) { ++n_t2; continue; }
+		eval_one<KIND, 5, FRK>(b, p, i, o, fe, pe);
+		const float va[4] = { fa.x, fa.y, fa.z, pa }, ve[4] = { fe.x, fe.y, fe.z, pe };
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if (va[j] == ve[j]) continue;
+			if (va[j] == 0.0f || ve[j] == 0.0f || !(fabsf(ve[j]) >= 1e-30f)) { ++n_zero; continue; }
+			float rel = fabsf(va[j] - ve[j]) / fabsf(ve[j]);
+			if (!(rel <= 1e-5f)) ++n_out;
+			if (j < 3) me = fmaxf(me, rel); else mp = fmaxf(mp, rel);
+		}
+	}
+	atomicMax(&max_bits[0], __float_as_uint(me));
+	atomicMax(&max_bits[1], __float_as_uint(mp));
+	atomicAdd(&counters[0], n_all); atomicAdd(&counters[1], n_t2);
+	atomicAdd(&counters[2], n_zero); atomicAdd(&counters[3], n_out);
+}
+
+bool ct_params(const Brdf &b, const Params &p, CtParams *c)
+{
+	if (p.tx != 0.0f || p.ty != 0.0f || !(p.nx == 0.0f && p.ny == 0.0f && p.nz == 1.0f)) return false;
+	if (!(fabsf(p.rho) <= djbk::CT_RHO_MAX) || !(p.ax >= 1e-4f && p.ax <= 1e4f) || !(p.ay >= 1e-4f && p.ay <= 1e4f)) return false;
+	const double t2 = (double)p.ax * (double)p.ay * (double)p.s;
+	if (!(t2 > 1e-9 && t2 < 1e9)) return false;
+	c->ax = p.ax; c->ay = p.ay; c->rho = p.rho; c->s = p.s; c->rho_ay = p.rho * p.ay;
+	c->r_ax = (float)(1.0 / (double)p.ax);
+	c->r_t2 = (float)(1.0 / (double)(p.ax * p.ay * p.s));
+	c->k_d = (float)((1.0 / (double)(p.ax * p.ay * p.s)) / DJB_PI);
+	c->shadow = b.shadow;
+	for (int k = 0; k < 3; ++k) { c->f0[k] = 1.0f; c->f1[k] = 0.0f; }
+	if (b.fr.kind == FR_SCHLICK) {
+		for (int k = 0; k < 3; ++k) {
+			// below f0 = 0.01 the term f0 + (1 - f0)(1 - c)^5 is ill-conditioned in c near 1 (header): exact kernels
+			if (!(b.fr.a[k] >= 0.01f && b.fr.a[k] <= 1.0f)) return false;
+			c->f0[k] = b.fr.a[k]; c->f1[k] = 1.0f - b.fr.a[k];
+		}
+	} else if (b.fr.kind != FR_IDEAL) return false;
+	return true;
+}
+
+template <int KIND, int FRK>
+hipError_t launch_ct(hipStream_t s, const Brdf &b, const Params &p, const CtParams &c, long long n, const View &i, const View &o,
+                     const View &out, float *out_pdf, int want, uint4 *list, unsigned int cap, unsigned int *count)
+{
+	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int), s);
+	if (e != hipSuccess) return e;
+	const long long n4 = n / 4;
+	const dim3 g(grid_for(n4)), t(BLOCK), gf(grid_for(n / 64 + 1, 2048));
+#define DJB_CT(W_) do { \
+		if (n4 > 0) hipLaunchKernelGGL((k_ct_fast_v4<KIND, W_, FRK>), g, t, 0, s, c, n4, i, o, out, out_pdf, list, cap, count); \
+		hipLaunchKernelGGL((k_ct_fixup<KIND, W_, FRK>), gf, t, 0, s, b, p, n, i, o, out, out_pdf, list, cap, count); } while (0)
+	switch (want) {
+	case 1: DJB_CT(1); break;
+	case 2: DJB_CT(2); break;
+	case 4: DJB_CT(4); break;
+	case 5: DJB_CT(5); break;
+	case 6: DJB_CT(6); break;
+	default: return hipErrorInvalidValue;
+	}
+#undef DJB_CT
+	return hipGetLastError();
+}
+
+} // namespace
+
+namespace djbk {
+
+bool contract_supported(const Brdf &b, const Params &p)
+{
+	CtParams c;
+	return b.kind == KIND_GGX && ct_params(b, p, &c);
+}
+
+hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i, const View &o,
+                                const View &out, float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count)
+{
+	CtParams c;
+	if (b.kind != KIND_GGX || !ct_params(b, p, &c)) return hipErrorInvalidValue;
+	if (n <= 0) return hipSuccess;
+	// the < 4-pair tail of the batch: the exact kernel (launched first: the fix-up kernel's overflow rescan covers it too)
+	const long long n4 = n / 4;
+	if (4 * n4 < n) {
+		auto off = [&](const View &v) { return View{ v.x ? v.x + 4 * n4 : nullptr, v.y ? v.y + 4 * n4 : nullptr, v.z ? v.z + 4 * n4 : nullptr, v.stride }; };
+		hipError_t e = launch_eval(s, b, p, n - 4 * n4, off(i), off(o), off(out), out_pdf ? out_pdf + 4 * n4 : nullptr, want);
+		if (e != hipSuccess) return e;
+	}
+	if (b.fr.kind == FR_SCHLICK) return launch_ct<KIND_GGX, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+	return launch_ct<KIND_GGX, FR_IDEAL>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+}
+
+hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed_i, uint32_t seed_o,
+                                    unsigned long long start, int family, unsigned int *max_bits, unsigned long long *counters)
+{
+	CtParams c;
+	if (b.kind != KIND_GGX || !ct_params(b, p, &c)) return hipErrorInvalidValue;
+	const dim3 g(grid_for(n, 256LL * 16)), t(BLOCK);
+	if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+	else hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_IDEAL>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+	return hipGetLastError();
+}
+
+} // namespace djbk

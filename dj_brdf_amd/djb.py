@@ -1033,6 +1033,24 @@ def set_utia_exact_only(ctx: Context, on: bool):
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(5), C.c_int(int(on))))
 
 
+def set_contract_1e5(ctx: Context, on: bool):
+    """DJB_OPT_CONTRACT_1E5: dense device-resident GGX eval / evalp / pdf batches are evaluated inside the 1e-5 relative
+    value contract (two-tier: fast reciprocal arithmetic + the bit-exact code for ill-conditioned pairs) instead of
+    bit-identically.  Off by default; everything else stays bit-identical."""
+    _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(6), C.c_int(int(on))))
+
+
+def selftest_contract(brdf, params=None, n: int = 1 << 24, seed: int = 1, family: int = 0, ctx: Optional[Context] = None):
+    """The contract-mode fast path against the bit-exact per-pair code on n generated pairs (djb_selftest_contract)."""
+    ctx = ctx or default_context()
+    mx = (C.c_float * 2)()
+    c = (C.c_ulonglong * 4)()
+    _lib.check(_lib.load().djb_selftest_contract(ctx._h, brdf._h, C.byref(params._p) if params is not None else None,
+                                                 C.c_int64(n), C.c_uint32(seed), C.c_int(family), mx, c))
+    return {"max_rel_eval": float(mx[0]), "max_rel_pdf": float(mx[1]), "pairs": int(c[0]), "tier2": int(c[1]),
+            "zero_mismatch": int(c[2]), "outside_1e5": int(c[3])}
+
+
 def set_aniso_qf2_aligned(ctx: Context, on: bool):
     """tabular_anisotropic objects built afterwards keep the rows of the conditional quantile table aligned
     (DJB_OPT_ANISO_QF2_ALIGNED) instead of reproducing the reference's shifted vector."""

@@ -136,7 +136,15 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * pairs that sit next to a float rounding boundary, re-evaluated by a second kernel); both give the same bits, the
  * option exists to verify that.  (Environment DJB_UTIA_WORKLIST_CAP=<entries> overrides the worklist capacity: a test
  * hook for the overflow path, in which the second kernel redoes the whole batch.) */
-       DJB_OPT_UTIA_EXACT_ONLY = 5 };
+       DJB_OPT_UTIA_EXACT_ONLY = 5,
+/* DJB_OPT_CONTRACT_1E5 = 1 (off by default): dense device-resident GGX eval / evalp / pdf batches (ideal or schlick Fresnel,
+ * f0 >= 0.01; params without mean-normal offset, |rho| <= 0.9) are evaluated inside the VALUE contract of the north star --
+ * every result within 1e-5 relative of the reference's, zeros exactly where the reference returns zeros -- instead of
+ * bit-identically: reciprocal / rsqrt instructions and merged denominators in place of the reference's 15 correctly
+ * rounded divisions, pairs whose reference value is ill-conditioned re-done by the bit-exact code (two tiers, as for
+ * MERL).  Everything else -- sampling, MERL / UTIA look-ups and their bin decisions, the fitters, other lobes and
+ * layouts -- is unaffected and stays bit-identical.  djb_selftest_contract measures the actual maximum difference. */
+       DJB_OPT_CONTRACT_1E5 = 6 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */
 djb_status  djb_timer_start(djb_ctx *ctx);
@@ -287,6 +295,13 @@ djb_status djb_merl_guard_stats(djb_ctx *, int64_t n, const djb_vec3_view *i, co
  * fallbacks, sRGB-decode mismatches, sRGB-decode fallbacks, mismatches of the exact division through a double
  * reciprocal (float(double(a) * R) vs a / b), its IEEE fallbacks}; every mismatch count must be 0. */
 djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters8);
+/* the DJB_OPT_CONTRACT_1E5 fast path against the bit-exact per-pair code on n generated pairs (family 0: the bench
+ * distribution; 1: grazing with opposite azimuths; 2: near-normal incidence; 3: o at the horizon; 4: un-normalised):
+ * max_rel2 = {max relative difference of the eval rgb, of the pdf} over the fast-path pairs, counters4 = {pairs, pairs
+ * handed to the exact tier, values where exactly one side is zero (must be 0), values outside 1e-5 (must be 0)}.
+ * DJB_ERR_INVALID_ARGUMENT when brdf / params are outside the fast path's domain. */
+djb_status djb_selftest_contract(djb_ctx *, const djb_brdf *, const djb_params *params, int64_t n, uint32_t seed, int family,
+                                 float *max_rel2, unsigned long long *counters4);
 /* the kernels' restatements of the host libm functions the reference calls (glibc 2.35: double exp / pow / atan2 / sin / cos / tan / acos,
  * float logf / expf / powf -- dj_brdf.h:659, 685, 695, 1634, 1868, 1917, 1935, 3419, 3431, 3612), evaluated on the GPU for
  * host arrays: fn 0 exp(x), 1 pow(x, y), 2 logf(x), 3 expf(x), 4 powf(x, y) (float functions on the values cast

@@ -272,11 +272,11 @@ void fit_tabular(const Brdf &src, const Params &std_p, int res, int shadow, FitR
 	{
 		std::vector<double> cphid(NPHI_SIGMA), cthd(NTHETA_SIGMA);
 		std::vector<float> sh(NTHETA_SIGMA), ui(NTHETA_SIGMA), ndf_tab(NNODE);
-		for (int k = 0; k < NPHI_SIGMA; ++k) cphid[k] = cos(D(F(D((float)k / (float)NPHI_SIGMA) * 2.0 * DJB_PI)));
+		for (int k = 0; k < NPHI_SIGMA; ++k) cphid[k] = glibc_cos(D(F(D((float)k / (float)NPHI_SIGMA) * 2.0 * DJB_PI)));
 		for (int k = 0; k < NTHETA_SIGMA; ++k) {
 			float u = (float)k / (float)NTHETA_SIGMA;
 			float th = F(D(u * u) * DJB_PI * 0.5);
-			ui[k] = u; sh[k] = sin_f(th); cthd[k] = cos(D(th));
+			ui[k] = u; sh[k] = sin_f(th); cthd[k] = glibc_cos(D(th));
 		}
 		for (int e = 0; e < NNODE; ++e) {
 			int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;

@@ -15,6 +15,13 @@
 
 #include "../../include/djb_hip.h"
 
+// the host path's libm check (djb_cpu_libm.cpp): init() runs once, by the first context of either kind
+namespace djbhostlibm {
+extern int use_restated;
+int init();
+int atan_log_kat();
+}
+
 namespace djbcpu {
 
 // handles: a CPU context / object starts with the same leading int as its GPU counterpart (djb_ctx: the device,

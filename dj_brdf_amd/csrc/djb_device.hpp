@@ -22,6 +22,34 @@
 #include <string.h>
 #define DJB_DEV static inline
 struct float4 { float x, y, z, w; };
+#if defined(DJB_HOST_RESTATED)
+// third instantiation (djb_cpu_libm.cpp only): the host code with the kernels' restatements of glibc 2.35's libm
+// functions compiled FOR THE HOST, so that the host path can run the very algorithms the kernels run on a machine
+// whose own libm is not glibc 2.35 / x86-64-FMA (see djbhostlibm below).  The device intrinsics the restatements use:
+#define __device__
+static inline int __double2loint(double x) { uint64_t u; memcpy(&u, &x, 8); return (int)(uint32_t)u; }
+static inline int __double2hiint(double x) { uint64_t u; memcpy(&u, &x, 8); return (int)(uint32_t)(u >> 32); }
+static inline double __hiloint2double(int hi, int lo) { uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double x; memcpy(&x, &u, 8); return x; }
+static inline long long __double_as_longlong(double x) { long long u; memcpy(&u, &x, 8); return u; }
+static inline double __longlong_as_double(long long u) { double x; memcpy(&x, &u, 8); return x; }
+static inline unsigned int __float_as_uint(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
+static inline float __uint_as_float(unsigned int u) { float x; memcpy(&x, &u, 4); return x; }
+#else
+// The host path's libm.  The kernels reproduce glibc 2.35's x86-64 (FMA ifunc) exp / pow / atan2 / sin / cos / tan /
+// acos / logf / expf / powf; the host path calls the HOST's libm, which is the same thing only on such a host.
+// djbhostlibm::init() (first context creation) compares the two on a few thousand arguments per function; when they
+// differ, `use_restated` sends every one of these calls of the host path to the kernels' restatements compiled for
+// the host (r_*), so scalar-size host calls and GPU batches keep returning the same bits (djb_cpu_libm.cpp).
+namespace djbhostlibm {
+extern int use_restated;
+double r_exp(double), r_pow(double, double), r_atan2(double, double), r_sin(double), r_cos(double), r_tan(double), r_acos(double);
+float r_logf(float), r_expf(float), r_powf(float, float);
+// 1: the host libm agrees with the restatements on the probe set; 0: it does not (restatements in use unless
+// DJB_HOST_LIBM=host); -1: not checked (CPU without FMA: the restatements cannot run on this host)
+int init();
+int atan_log_kat();    // 1: the host's atan / log (not restated: float -> float sites only) give glibc 2.35's values on the known-answer set
+}
+#endif
 #else
 #include <hip/hip_runtime.h>
 #define DJB_DEV __device__ __forceinline__
@@ -93,17 +121,31 @@ DJB_DEV float sat_(float x) { return fmin_(1.0f, fmax_(0.0f, x)); }
 // own algorithms (glibc_atan2 / sin / cos / tan / acos below).
 enum { TRIG_COS = 0, TRIG_SIN, TRIG_TAN, TRIG_ACOS, TRIG_ACOS_U, TRIG_ACOS_U32, TRIG_ATAN_SQU, TRIG_ATAN_U,
        TRIG_ATAN_SQRT, TRIG_BECK_QF, TRIG_ACOS_DEG, TRIG_UTIA_BIN15, TRIG_UTIA_BIN7P5, TRIG_SITES };
-DJB_DEV float cos_f(float x) { return F(cos(D(x))); }
-DJB_DEV float sin_f(float x) { return F(sin(D(x))); }
-DJB_DEV float tan_f(float x) { return F(tan(D(x))); }
-DJB_DEV float acos_f(float x) { return F(acos(D(x))); }
-DJB_DEV float acos_u_f(float c) { return F(2.0 * acos(D(c)) / DJB_PI); }                    // dj_brdf.h:1341 (spline fresnel)
-DJB_DEV float acos_u32_f(float c) { return F(D(2.0f) * acos(D(c)) / D(F(DJB_PI))); }       // dj_brdf.h:2158 (tabular sigma)
+// hl_*: the libm call of a site.  Device: ROCm's libm (each site is swept against glibc over all 2^32 inputs); host: the
+// host's libm, or the kernels' restatement of glibc's function when the host's libm is not glibc 2.35 (djbhostlibm).
+// atan and log have no restatement: their sites follow the host's libm (djbhostlibm::atan_log_kat reports on them).
+#if defined(DJB_HOST_MATH) && !defined(DJB_HOST_RESTATED)
+DJB_DEV double hl_cos(double x) { return djbhostlibm::use_restated ? djbhostlibm::r_cos(x) : cos(x); }
+DJB_DEV double hl_sin(double x) { return djbhostlibm::use_restated ? djbhostlibm::r_sin(x) : sin(x); }
+DJB_DEV double hl_tan(double x) { return djbhostlibm::use_restated ? djbhostlibm::r_tan(x) : tan(x); }
+DJB_DEV double hl_acos(double x) { return djbhostlibm::use_restated ? djbhostlibm::r_acos(x) : acos(x); }
+#else
+DJB_DEV double hl_cos(double x) { return cos(x); }
+DJB_DEV double hl_sin(double x) { return sin(x); }
+DJB_DEV double hl_tan(double x) { return tan(x); }
+DJB_DEV double hl_acos(double x) { return acos(x); }
+#endif
+DJB_DEV float cos_f(float x) { return F(hl_cos(D(x))); }
+DJB_DEV float sin_f(float x) { return F(hl_sin(D(x))); }
+DJB_DEV float tan_f(float x) { return F(hl_tan(D(x))); }
+DJB_DEV float acos_f(float x) { return F(hl_acos(D(x))); }
+DJB_DEV float acos_u_f(float c) { return F(2.0 * hl_acos(D(c)) / DJB_PI); }                    // dj_brdf.h:1341 (spline fresnel)
+DJB_DEV float acos_u32_f(float c) { return F(D(2.0f) * hl_acos(D(c)) / D(F(DJB_PI))); }       // dj_brdf.h:2158 (tabular sigma)
 DJB_DEV float atan_squ_f(float r) { return F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI)))); }  // dj_brdf.h:2152 (tabular p22)
 DJB_DEV float atan_u_f(float r) { return F(atan(D(r)) * D(2.0f) / D(F(DJB_PI))); }          // dj_brdf.h:2165 (tabular cdf)
 DJB_DEV float atan_sqrt_f(float x) { return F(atan(sqrt(D(x)))); }                          // dj_brdf.h:2285 (aniso p22)
 DJB_DEV float beck_qf_f(float u) { return F(sqrt(-log(1.0 - D(u)))); }                      // dj_brdf.h:1887 (beckmann qf)
-DJB_DEV float acos_deg_f(float z) { return F(D(F(180.0 / DJB_PI)) * acos(D(z))); }          // dj_brdf.h:1633 (utia)
+DJB_DEV float acos_deg_f(float z) { return F(D(F(180.0 / DJB_PI)) * hl_acos(D(z))); }          // dj_brdf.h:1633 (utia)
 // utia's grid cells (dj_brdf.h:1639-1646): (int)floor(double(theta) / 15.0) (clamped to 4) and (int)floor(double(phi) / 7.5)
 // are functions of one float too.  The device evaluates them without the fp64 division: RN(theta / 15) >= k  <=>
 // theta >= 15 k for a float theta, because a float below 15 k is at least 2^-20 below it while the quotient is rounded at
@@ -259,16 +301,17 @@ DJB_DEV void xyz_to_theta_phi(v3 p, float &theta, float &phi)
 	else { theta = acos_f(p.z); phi = atan2_to_f32(p.y, p.x, 1.0); }
 }
 
-#if defined(DJB_HOST_MATH)
-// host: the reference's unqualified exp() / pow() are these very glibc functions
-DJB_DEV double glibc_exp(double x, LdsTab = 0u) { return exp(x); }
-DJB_DEV double glibc_pow(double x, double y, LdsTab = 0u, LdsTab = 0u) { return pow(x, y); }
-DJB_DEV double glibc_atan2(double y, double x) { return atan2(y, x); }
-DJB_DEV double glibc_sin(double x) { return sin(x); }
-DJB_DEV double glibc_cos(double x) { return cos(x); }
-DJB_DEV double glibc_tan(double x) { return tan(x); }
-DJB_DEV double glibc_acos(double x, LdsTab) { return acos(x); }
-DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * atan2(D(y), D(x))); }
+#if defined(DJB_HOST_MATH) && !defined(DJB_HOST_RESTATED)
+// host: the reference's unqualified exp() / pow() ... are the host's glibc functions -- or, on a host whose
+// libm is not the glibc the kernels restate, the restatements themselves (djbhostlibm, top of this file)
+DJB_DEV double glibc_exp(double x, LdsTab = 0u) { return djbhostlibm::use_restated ? djbhostlibm::r_exp(x) : exp(x); }
+DJB_DEV double glibc_pow(double x, double y, LdsTab = 0u, LdsTab = 0u) { return djbhostlibm::use_restated ? djbhostlibm::r_pow(x, y) : pow(x, y); }
+DJB_DEV double glibc_atan2(double y, double x) { return djbhostlibm::use_restated ? djbhostlibm::r_atan2(y, x) : atan2(y, x); }
+DJB_DEV double glibc_sin(double x) { return hl_sin(x); }
+DJB_DEV double glibc_cos(double x) { return hl_cos(x); }
+DJB_DEV double glibc_tan(double x) { return hl_tan(x); }
+DJB_DEV double glibc_acos(double x, LdsTab) { return hl_acos(x); }
+DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * glibc_atan2(D(y), D(x))); }
 #else
 // ---- glibc 2.35's double exp / pow, restated --------------------------------------------------------
 // The reference's unqualified exp() / pow() are glibc's double functions: ~0.51 ulp, not
@@ -284,8 +327,13 @@ DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * at
 // LDS copies of the tables are addressed through address-space-3 pointers rebuilt from a 32-bit offset, so that
 // the look-ups compile to ds_read (a generic pointer that may be global or LDS compiles to flat_load); the
 // offset form also keeps `Brdf` the same size for the host and the device compilation.
+#if defined(DJB_HOST_MATH)
+typedef const unsigned long long *lds_u64p;   // host instantiation: the tables are only ever read from their global copies (T == 0)
+typedef const double *lds_f64p;
+#else
 typedef const __attribute__((address_space(3))) unsigned long long *lds_u64p;
 typedef const __attribute__((address_space(3))) double *lds_f64p;
+#endif
 DJB_DEV LdsTab glibc_exp_tab_to_lds(unsigned long long *lds, int tid, int nthreads)   // caller: __syncthreads() afterwards
 {
 	for (int k = tid; k < 256; k += nthreads) lds[k] = DJB_GLIBC_EXP_TAB[k];
@@ -516,6 +564,9 @@ DJB_DEV double glibc_atan2(double y, double x)
 }
 // out of line: inlined into the rarely taken branch of atan2_to_f32 its divisions, constants and table reads cost
 // the hot loops more registers and scratch than the branch ever saves (utia eval: 2.8 -> 5.6 ms per 1e8)
+#if defined(DJB_HOST_MATH)
+DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * glibc_atan2(D(y), D(x))); }
+#else
 __device__ __attribute__((noinline)) double glibc_atan2_cold(double y, double x) { return glibc_atan2(y, x); }
 // the device-libm value and whether it is decided (tier 1 of a two-tier kernel: undecided units go to a second kernel)
 DJB_DEV float atan2_to_f32_t1(float y, float x, double scale, bool &ok)
@@ -532,6 +583,7 @@ DJB_DEV float atan2_to_f32(float y, float x, double scale)
 	if (__builtin_expect(!ok, 0)) return F(scale * glibc_atan2_cold(D(y), D(x)));
 	return r;
 }
+#endif
 
 // ---- glibc 2.35's double sin / cos, restated -------------------------------------------------------
 // __sin / __cos of sysdeps/ieee754/dbl-64/s_sin.c (IBM Accurate Mathematical Library as cleaned up in glibc 2.28: no
@@ -772,13 +824,14 @@ DJB_DEV float erf_given_exp(float x, double e)
 }
 DJB_DEV float erf_(float x, LdsTab T = 0u) { return erf_given_exp(x, glibc_exp(D(-x * x), T)); }
 
-#if defined(DJB_HOST_MATH)
+#if defined(DJB_HOST_MATH) && !defined(DJB_HOST_RESTATED)
 // host: logf / std::exp(float) / std::pow(float, float) of the reference (dj_brdf.h:695, 1917, 1935) ARE glibc's
+// (or the restatements, djbhostlibm)
 struct GlibcTabs { LdsTab exp64; };
 DJB_DEV GlibcTabs glibc_tabs_global() { GlibcTabs t = { 0u }; return t; }
-DJB_DEV float glibc_logf(float x, const GlibcTabs &) { return logf(x); }
-DJB_DEV float glibc_expf(float x, const GlibcTabs &) { return expf(x); }
-DJB_DEV float glibc_powf(float x, float y, const GlibcTabs &) { return powf(x, y); }
+DJB_DEV float glibc_logf(float x, const GlibcTabs &) { return djbhostlibm::use_restated ? djbhostlibm::r_logf(x) : logf(x); }
+DJB_DEV float glibc_expf(float x, const GlibcTabs &) { return djbhostlibm::use_restated ? djbhostlibm::r_expf(x) : expf(x); }
+DJB_DEV float glibc_powf(float x, float y, const GlibcTabs &) { return djbhostlibm::use_restated ? djbhostlibm::r_powf(x, y) : powf(x, y); }
 #else
 // ---- glibc 2.35's float logf / expf / powf, restated -------------------------------------------
 // The reference calls the float libm in erfinv (logf) and in Beckmann's Newton inversion (powf, expf),
@@ -1184,7 +1237,11 @@ DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k, const Glibc
 		inv_erf = erfinv_(b, gt);
 		float value = normalization * (1 + b + sqrt_pi_inv * tan_k * glibc_expf(-inv_erf * inv_erf, gt)) - u;
 		float derivative = normalization * (1 - inv_erf * tan_k);
+#if defined(DJB_EXP_NEWTON_FIXED)      // timing experiment only (tools/exp): every lane runs exactly this many iterations
+		if (it == DJB_EXP_NEWTON_FIXED) { converged = true; break; }
+#else
 		if (fabsf(value) < 1e-5f) { converged = true; break; }
+#endif
 		if (value > 0) c = b; else a = b;
 		b -= value / derivative;
 	}

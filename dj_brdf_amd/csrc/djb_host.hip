@@ -952,15 +952,25 @@ static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **o
 
 djb_status djb_ctx_create(int device, djb_ctx **out)
 try {
+	djbhostlibm::init();      // once per process: is the host's libm the glibc the kernels restate?  (djb_cpu_libm.cpp)
 	if (device == DJB_DEVICE_CPU) return djbcpu::ctx_create(out);
 	return ctx_create(device, nullptr, true, out); }
 DJB_ABI_CATCH
 djb_status djb_ctx_create_on_stream(int device, void *hip_stream, djb_ctx **out)
 try {
+	djbhostlibm::init();
 	if (device == DJB_DEVICE_CPU) return djbcpu::ctx_create(out);
 	return ctx_create(device, hip_stream, false, out);
 }
 DJB_ABI_CATCH
+
+// 1: the host's libm returned glibc 2.35's bits on the probe set (the host path calls it); 0: it did not, and the host
+// path runs the kernels' restatements instead (unless DJB_HOST_LIBM=host); -1: not checked (CPU without FMA)
+int djb_ctx_libm_matches_host(const djb_ctx *) { return djbhostlibm::init(); }
+// 0: host-side libm calls go to the host's libm; 1: to the kernels' restatements of glibc 2.35's functions
+int djb_host_libm_mode(void) { djbhostlibm::init(); return djbhostlibm::use_restated; }
+// 1: the host's atan / log (not restated) gave glibc 2.35's values on the known-answer set; 0: they did not; -1: not checked
+int djb_host_atan_log_kat(void) { return djbhostlibm::atan_log_kat(); }
 
 djb_status djb_ctx_destroy(djb_ctx *ctx)
 try {

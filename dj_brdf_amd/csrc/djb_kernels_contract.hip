@@ -270,7 +270,10 @@ hipError_t launch_ct(hipStream_t s, const Brdf &b, const Params &p, const CtPara
 	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int), s);
 	if (e != hipSuccess) return e;
 	const long long n4 = n / 4;
-	const dim3 g(grid_for(n4)), t(BLOCK), gf(grid_for(n / 64 + 1, 2048));
+	// one workgroup per 1024 pairs, no grid-stride cap: measured (profiles/r03/contract_grid.txt, 1e8 pairs) 0.696 ms with
+	// the full grid against 0.77-0.82 ms with 2048 ... 32768 persistent workgroups -- the hardware dispatcher keeps more
+	// loads in flight across workgroup boundaries than a wave's in-order loop does
+	const dim3 g(grid_for(n4, 0x7fffffffLL)), t(BLOCK), gf(grid_for(n / 64 + 1, 2048));
 #define DJB_CT(W_) do { \
 		if (n4 > 0) hipLaunchKernelGGL((k_ct_fast_v4<KIND, W_, FRK>), g, t, 0, s, c, n4, i, o, out, out_pdf, list, cap, count); \
 		hipLaunchKernelGGL((k_ct_fixup<KIND, W_, FRK>), gf, t, 0, s, b, p, n, i, o, out, out_pdf, list, cap, count); } while (0)

@@ -1057,6 +1057,14 @@ def set_aniso_qf2_aligned(ctx: Context, on: bool):
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(2), C.c_int(int(on))))
 
 
+def host_libm_status():
+    """(matches, mode, atan_log_kat): does the host's libm return glibc 2.35's bits on the probe set (1 / 0 / -1 = not checked),
+    which libm the host path calls (0 = the host's, 1 = the kernels' restatements compiled for the host), and whether the
+    host's atan / log match their known answers (djb_ctx_libm_matches_host, djb_host_libm_mode, djb_host_atan_log_kat)."""
+    lib = _lib.load()
+    return int(lib.djb_ctx_libm_matches_host(None)), int(lib.djb_host_libm_mode()), int(lib.djb_host_atan_log_kat())
+
+
 def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):
     """Self-test of the kernels' guarded fp64 shortcuts against the exact double sequences on n
     hash-generated inputs (see djb_selftest_guarded_math).  Mismatch counters must be 0."""

@@ -117,6 +117,18 @@ void       *djb_ctx_stream(djb_ctx *ctx);
  * first waits for everything the context enqueued so far, so per-context scratch stays ordered.  Callers
  * that follow a framework's "current stream" (torch) call this before each batch call; cheap when unchanged. */
 djb_status  djb_ctx_set_stream(djb_ctx *ctx, void *hip_stream);
+/* The host's libm and the two execution paths.  The kernels reproduce what glibc 2.35 (x86-64, FMA ifunc variants)
+ * returns for the libm calls the reference makes (exp / pow / atan2 / sin / cos / tan / acos, logf / expf / powf); the host
+ * path (CPU contexts, scalar-size DJB_MEM_HOST calls) calls the host's libm.  The first context creation compares the two on
+ * a fixed probe set.  djb_ctx_libm_matches_host: 1 = identical (the host path keeps calling the host's libm), 0 = the host's
+ * libm differs -- the host path then runs the kernels' restatements compiled for the host, so scalar calls and GPU batches
+ * still agree bit for bit, and one line on stderr says so -- , -1 = not checked (CPU without FMA).  DJB_HOST_LIBM=restated|host
+ * (environment) forces the choice; djb_host_libm_mode returns it (1 = restatements).  atan and log, which occur only in
+ * float -> float sites, have no restatement: djb_host_atan_log_kat reports whether the host's match glibc 2.35's known answers. */
+int djb_ctx_libm_matches_host(const djb_ctx *);
+int djb_host_libm_mode(void);
+int djb_host_atan_log_kat(void);
+
 /* options.  DJB_OPT_MERL_EXACT_ONLY = 1 makes merl eval/evalp run the operation-by-operation fp64
  * kernel for every pair instead of the two-tier kernel (fp32 fast path + guard bands + fp64 path
  * for ambiguous pairs); both give the same bits, the option exists to verify that.           */

@@ -6,9 +6,9 @@
 // `djb::ggx`, `djb::tabular`, `djb::microfacet::params`, `djb::fresnel::*` recompiles against this
 // header (link with -ldjb_hip).  Two differences, both additive:
 //   * every operator also has a BATCH overload (n pairs per call) -- the form that makes sense
-//     on a GPU.  The scalar virtuals are batches of one: correct, and slow by construction
-//     (a kernel launch per call); renderers should gather a wavefront of intersections and call
-//     the batch form.
+//     on a GPU.  The scalar virtuals are batches of one, which the library answers on the calling
+//     thread from a host twin of the object (no launch, no lock: 60-200 ns per call);
+//     a renderer that can gather a wavefront of intersections should still call the batch form.
 //   * objects live on a djb::hip::context (one GPU + one stream); a process-wide default exists.
 // Errors: constructors and calls throw djb::exc carrying the library's djb_error message.
 // All arithmetic runs in the HIP kernels; this header contains no BRDF math.
@@ -25,6 +25,33 @@
 #include <vector>
 
 #include "djb_hip.h"
+
+/* Configuration macros of the reference header (dj_brdf.h:7-12, 43-48, 552-560), honoured here:
+ *   DJB_USE_DOUBLE_PRECISION  the kernels implement the reference's DEFAULT configuration -- float storage with the
+ *                             reference's double sub-expressions kept -- so a double float_t facade over them would
+ *                             silently return float-precision values: refused at compile time instead.
+ *   DJB_ASSERT(x)             user-overridable.  The reference asserts on invalid ARGUMENTS (radii, correlation, indices
+ *                             of refraction, resolutions, variates: dj_brdf.h:1257, 1453, 1466-1467, 2003, 2173, 2218, 2244,
+ *                             2780); a user macro is invoked at the same sites with the same conditions before the call
+ *                             reaches the library.  Without one the library's own validation throws djb::exc (the
+ *                             reference would abort in assert.h or, under NDEBUG, compute garbage).
+ *   DJB_LOG(fmt, ...)         user-overridable, default stdout like the reference.  Unless NVERBOSE is defined the
+ *                             constructors of tabular / tabular_anisotropic print the reference's progress lines
+ *                             (dj_brdf.h:2383-2384, 2429-2430, 2638-2639, 2698-2699, 2724-2725, 2759-2760).  The two lines that carry a value
+ *                             internal to the fit (the slope-pdf normalisation constants, :2301, :2335) and the
+ *                             per-sample chatter of merl::eval / utia::normalize (:1017, :1166) are not reproduced.   */
+#if defined(DJB_USE_DOUBLE_PRECISION) && DJB_USE_DOUBLE_PRECISION
+#error "dj_brdf_amd: DJB_USE_DOUBLE_PRECISION=1 is not supported -- the MI355X kernels implement the reference's default single-precision configuration (float_t = float); see include/djb_hip.hpp"
+#endif
+#ifdef DJB_ASSERT
+#	define DJB_USER_ASSERT(x) DJB_ASSERT(x)
+#else
+#	define DJB_USER_ASSERT(x) ((void)0)      /* the library validates the same conditions and the facade throws djb::exc */
+#	define DJB_ASSERT(x) ((void)0)
+#endif
+#ifndef DJB_LOG
+#	define DJB_LOG(format, ...) fprintf(stdout, format, ##__VA_ARGS__)
+#endif
 
 namespace djb {
 
@@ -304,7 +331,7 @@ namespace fresnel {
 	class unpolarized : public impl {
 		vec3 ior;
 	public:
-		explicit unpolarized(const vec3 &ior) : ior(ior) {}
+		explicit unpolarized(const vec3 &ior) : ior(ior) { DJB_USER_ASSERT(ior.x > 0.0 && ior.y > 0.0 && ior.z > 0.0 && "Invalid ior"); }   // dj_brdf.h:1257
 		impl *copy() const { return new unpolarized(*this); }
 		djb_fresnel_desc desc() const
 		{ djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_UNPOLARIZED; d.a[0] = ior.x; d.a[1] = ior.y; d.a[2] = ior.z; return d; }
@@ -384,9 +411,12 @@ public:
 		static params standard() { return params(); }
 		static params isotropic(float_t a) { return elliptic(a, a, 0); }
 		static params elliptic(float_t a1, float_t a2, float_t phi_a = 0.0)
-		{ params p; p.m_desc.kind = DJB_PARAMS_ELLIPTIC; p.m_desc.v[0] = a1; p.m_desc.v[1] = a2; p.m_desc.v[2] = phi_a; p.resolve(); return p; }
+		{ DJB_USER_ASSERT(a1 > 0.0 && a2 > 0.0 && "Invalid ellipse radii");                                   // dj_brdf.h:1453
+		  params p; p.m_desc.kind = DJB_PARAMS_ELLIPTIC; p.m_desc.v[0] = a1; p.m_desc.v[1] = a2; p.m_desc.v[2] = phi_a; p.resolve(); return p; }
 		static params pdfparams(float_t ax, float_t ay, float_t rho = 0.0, float_t tx_n = 0.0, float_t ty_n = 0.0)
 		{
+			DJB_USER_ASSERT(ax > 0.0 && ay > 0.0 && "Invalid scale parameters");                                  // dj_brdf.h:1466
+			DJB_USER_ASSERT(std::fabs(rho) < 1.0 && "Invalid correlation parameter");                            // dj_brdf.h:1467
 			params p; p.m_desc.kind = DJB_PARAMS_PDFPARAMS;
 			p.m_desc.v[0] = ax; p.m_desc.v[1] = ay; p.m_desc.v[2] = rho; p.m_desc.v[3] = tx_n; p.m_desc.v[4] = ty_n;
 			p.resolve(); return p;
@@ -474,7 +504,7 @@ public:
 	float_t p22_radial(float_t r_sqr) const { return rq(DJB_Q_P22_RADIAL, r_sqr); }
 	float_t sigma_std_radial(float_t cos_theta_k) const { return rq(DJB_Q_SIGMA_STD_RADIAL, cos_theta_k); }
 	float_t cdf_radial(float_t r) const { return rq(DJB_Q_CDF_RADIAL, r); }
-	float_t qf_radial(float_t u) const { return rq(DJB_Q_QF_RADIAL, u); }
+	float_t qf_radial(float_t u) const { return rq(DJB_Q_QF_RADIAL, u); }     // (tabular::qf_radial asserts 0 < u < 1, dj_brdf.h:2173: see tabular)
 	float_t qf2_radial(float_t u, float_t cos_theta_k, float_t sin_theta_k) const { return rq(DJB_Q_QF2_RADIAL, u, cos_theta_k, sin_theta_k); }
 	float_t qf3_radial(float_t u, float_t qf2) const { return rq(DJB_Q_QF3_RADIAL, u, qf2); }
 protected:
@@ -493,9 +523,9 @@ public:
 		lrep(float_t E1 = 0, float_t E2 = 0, float_t E3 = 1, float_t E4 = 1, float_t E5 = 0)
 		{ m_E[0] = E1; m_E[1] = E2; m_E[2] = E3; m_E[3] = E4; m_E[4] = E5; }
 		lrep operator+(const lrep &r) const { return op(DJB_LREP_ADD, &r, 0, 0); }
-		lrep operator*(float_t sc) const { return op(DJB_LREP_MUL, NULL, sc, 0); }
+		lrep operator*(float_t sc) const { DJB_USER_ASSERT(sc >= (float_t)0.0 && "Invalid scale"); return op(DJB_LREP_MUL, NULL, sc, 0); }   // dj_brdf.h:2003
 		lrep &operator+=(const lrep &r) { *this = op(DJB_LREP_IADD, &r, 0, 0); return *this; }
-		lrep &operator*=(float_t sc) { *this = op(DJB_LREP_IMUL, NULL, sc, 0); return *this; }
+		lrep &operator*=(float_t sc) { DJB_USER_ASSERT(sc >= (float_t)0.0 && "Invalid scale"); *this = op(DJB_LREP_IMUL, NULL, sc, 0); return *this; }   // dj_brdf.h:2024
 		void scale(float_t x, float_t y) { *this = op(DJB_LREP_SCALE, NULL, x, y); }
 		void shear(float_t x, float_t y) { *this = op(DJB_LREP_SHEAR, NULL, x, y); }
 		const float_t *moments() const { return m_E; }
@@ -538,7 +568,14 @@ class tabular : public radial {
 public:
 	tabular(const brdf &src, int resolution, bool shadow = true) : radial(&src.get_context(), fresnel::ideal())
 	{
+		DJB_USER_ASSERT(resolution > 2 && "Invalid Resolution");                                                // dj_brdf.h:2218
 		hip::check(djb_brdf_create_tabular(ctx(), src.handle(), resolution, shadow, &m_h));
+#ifndef NVERBOSE   // the reference's progress lines, in its order (the whole construction is one launch here)
+		DJB_LOG("djb_verbose: Projected area term ready\n");
+		DJB_LOG("djb_verbose: Fresnel function ready\n");
+		DJB_LOG("djb_verbose: Slope CDF ready\n");
+		DJB_LOG("djb_verbose: Slope QF ready\n");
+#endif
 		m_p22 = fetch(DJB_TAB_P22, 1); m_sigma = fetch(DJB_TAB_SIGMA, 1);
 		m_cdf = fetch(DJB_TAB_CDF, 1); m_qf = fetch(DJB_TAB_QF, 1);
 		std::vector<float_t> f = fetch(DJB_TAB_FRESNEL, 3);
@@ -573,7 +610,12 @@ public:
 	tabular_anisotropic(const brdf &src, int elevation_res, int azimuthal_res, bool shadow = true)
 		: microfacet(&src.get_context(), fresnel::ideal()), m_elev(elevation_res), m_azim(azimuthal_res)
 	{
+		DJB_USER_ASSERT(elevation_res > 1 && azimuthal_res > 1 && "Invalid Resolution");                       // dj_brdf.h:2244
 		hip::check(djb_brdf_create_tabular_anisotropic(ctx(), src.handle(), elevation_res, azimuthal_res, shadow, &m_h));
+#ifndef NVERBOSE
+		DJB_LOG("djb_verbose: Anisotropic projected area term ready\n");
+		DJB_LOG("djb_verbose: Fresnel function ready\n");
+#endif
 		m_p22 = fetch(DJB_ATAB_P22, 1); m_sigma = fetch(DJB_ATAB_SIGMA, 1);
 		std::vector<float_t> f = fetch(DJB_ATAB_FRESNEL, 3);
 		std::vector<vec3> pts;

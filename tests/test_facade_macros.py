@@ -1,0 +1,66 @@
+"""The reference header's configuration macros (dj_brdf.h:7-12, 43-48, 552-560) in the facade (include/djb_hip.hpp):
+DJB_USE_DOUBLE_PRECISION is refused at compile time, a user DJB_ASSERT fires at the reference's argument checks, a user
+DJB_LOG receives the constructors' progress lines unless NVERBOSE is defined.  CPU only (DJB_DEVICE=cpu)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "dj_brdf_amd", "lib")
+
+PROG = r"""
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <cstdarg>
+#include <cstdio>
+static std::vector<std::string> g_log;
+static void my_log(const char *fmt, ...) { char b[256]; va_list a; va_start(a, fmt); vsnprintf(b, sizeof b, fmt, a); va_end(a); g_log.push_back(b); }
+#define DJB_ASSERT(x) do { if (!(x)) throw std::runtime_error(std::string("user assert: ") + #x); } while (0)
+#define DJB_LOG(format, ...) my_log(format, ##__VA_ARGS__)
+#include "dj_brdf.h"
+int main()
+{
+	int fired = 0;
+	try { djb::microfacet::params::elliptic(-1.0f, 0.3f); } catch (const std::runtime_error &e) { ++fired; printf("%s\n", e.what()); }
+	try { djb::microfacet::params::pdfparams(0.3f, 0.3f, 1.5f); } catch (const std::runtime_error &e) { ++fired; printf("%s\n", e.what()); }
+	try { djb::ggx g; djb::tabular t(g, 2); } catch (const std::runtime_error &e) { ++fired; printf("%s\n", e.what()); }
+	djb::ggx g;
+	djb::tabular t(g, 16);
+	for (size_t k = 0; k < g_log.size(); ++k) printf("LOG %s", g_log[k].c_str());
+	printf("fired=%d logs=%d\n", fired, (int)g_log.size());
+	return 0;
+}
+"""
+
+
+def build(tmp_path, src, flags=()):
+    f = tmp_path / "prog.cpp"; f.write_text(src)
+    exe = tmp_path / "prog"
+    r = subprocess.run(["g++", "-O1", "-std=c++14", "-I" + os.path.join(ROOT, "include"), *flags, "-o", str(exe), str(f), "-L" + LIBDIR, "-ldjb_hip",
+                        "-Wl,-rpath," + LIBDIR, "-Wl,-rpath-link,/opt/rocm/lib", "-pthread"], capture_output=True, text=True)
+    return r, exe
+
+
+def test_double_precision_build_is_refused(tmp_path):
+    r, _ = build(tmp_path, '#include "dj_brdf.h"\nint main() { return 0; }\n', ["-DDJB_USE_DOUBLE_PRECISION=1"])
+    assert r.returncode != 0 and "DJB_USE_DOUBLE_PRECISION=1 is not supported" in r.stderr
+    r, _ = build(tmp_path, '#include "dj_brdf.h"\nint main() { return sizeof(djb::float_t) == 4 ? 0 : 1; }\n', ["-DDJB_USE_DOUBLE_PRECISION=0"])
+    assert r.returncode == 0, r.stderr
+
+
+def test_user_assert_and_log_macros(tmp_path):
+    r, exe = build(tmp_path, PROG)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, DJB_DEVICE="cpu", DJB_QUIET="1")
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "user assert: a1 > 0.0 && a2 > 0.0" in out.stdout and "Invalid correlation parameter" in out.stdout and "Invalid Resolution" in out.stdout
+    assert "fired=3 logs=4" in out.stdout
+    for line in ("Projected area term ready", "Fresnel function ready", "Slope CDF ready", "Slope QF ready"):
+        assert "LOG djb_verbose: " + line in out.stdout
+    # NVERBOSE silences the progress lines, as in the reference
+    r, exe = build(tmp_path, PROG, ["-DNVERBOSE"])
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert "fired=3 logs=0" in out.stdout

@@ -53,7 +53,7 @@ class exc(RuntimeError):
 # every symbol include/djb_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "djb_last_error", "djb_version", "djb_device_count", "djb_ctx_create", "djb_ctx_create_on_stream", "djb_ctx_destroy",
-    "djb_ctx_synchronize", "djb_ctx_set_stream", "djb_ctx_set_option", "djb_merl_guard_stats", "djb_ctx_stream", "djb_timer_start", "djb_timer_stop_ms",
+    "djb_ctx_synchronize", "djb_ctx_set_stream", "djb_ctx_set_option", "djb_merl_guard_stats", "djb_merl_guard_attack", "djb_ctx_stream", "djb_timer_start", "djb_timer_stop_ms",
     "djb_brdf_create_beckmann", "djb_brdf_create_ggx", "djb_brdf_create_merl_from_file",
     "djb_brdf_create_merl_from_memory", "djb_brdf_create_utia_from_file",
     "djb_brdf_create_utia_from_memory", "djb_brdf_create_lambert", "djb_brdf_create_tabular",

@@ -1578,20 +1578,21 @@ DJB_DEV int fit_merl_slot_index(int s, int res)
 // Tier 1 (this function): the three half/diff angles from closed-form geometry in fp32 --
 //     theta_h = angle(h, z),  theta_d = angle(i, h),  phi_d = azimuth of i around h
 // with h = (i+o)/|i+o| -- no rotations, no fp64, three polynomial atan2.  Each estimate carries a
-// guard band that bounds |estimate - the reference's own float value| (the reference's chain of
-// float roundings, amplified by 1/sin(theta_h) and 1/sin(theta_d), plus this path's error).
+// guard band that bounds |estimate - the reference's own float value|: the reference's chain of
+// float roundings (amplified by cot(theta_h) and 1/sin(theta_d)) plus this path's own error.
 // If an estimate lies inside the guard band of a bin boundary -- or in the regions where the
 // reference snaps angles (|z| > 0.99999, dj_brdf.h:652-656) -- the pair is AMBIGUOUS and is
 // handed to tier 2, the operation-by-operation fp64 path (merl_index).  Outside the bands both
-// paths land in the same bin AS LONG AS the band really bounds |estimate - reference|, so the composite is
-// bit-exact while ~99.7 % of the pairs never touch fp64.  That bound is an error model (first-order
-// propagation of the float roundings) with constants fixed by measurement, not a proof: k_merl_guard_stats
-// reports max |estimate - reference| / band, and tests/test_gpu_verification.py asserts it stays below 0.5
-// (observed <= 0.25: a 4x margin) with 0 index mismatches on the bench distribution and on eleven adversarial
-// input families (bin-edge hugging in all three coordinates, poles, grazing, full sphere, un-normalised),
-// 2.4e8 pairs per run; the composite is also compared with the exact kernel over 1e9 pairs -- DESIGN.md 4.2.
-struct MerlGuard { float a_h, b_h, a_d, b_d, c_d; };   // multiples of 2^-24
-#define MERL_GUARD_DEFAULT { 12.0f, 12.0f, 12.0f, 12.0f, 12.0f }
+// paths land in the same bin, so the composite is bit-exact while ~99.5 % of the pairs never touch fp64.
+// The band constants are DERIVED (a first-order worst-case bound of every rounding on both paths, u = 2^-24):
+//     |theta_h est - ref| <= u (5 cot(theta_h) + 13.1)                                   -> a_h = 12 (>= 5), b_h = 16
+//     |theta_d est - ref| <= u (25.5 + 5 cot(theta_h)) / sin(theta_d) + 32.4 u           -> a_d = 26, b_d = 12, c_d = 36
+//     |phi_d   est - ref| <= u (36.9 + 5 cot(theta_h)) / sin(theta_d) + 25.6 u           -> a_p = 40, b_d = 12, c_d = 36
+// and ATTACKED: tools/merl_guard_attack.py hill-climbs input bit patterns to maximise |estimate - reference| / band
+// (profiles/r03/merl_guard_attack.txt); k_merl_guard_stats samples the same ratio, and tests/test_gpu_verification.py
+// asserts it stays below 0.5 with 0 index mismatches on the bench distribution and on twelve adversarial families.
+struct MerlGuard { float a_h, b_h, a_d, b_d, c_d, a_p; };   // multiples of 2^-24
+#define MERL_GUARD_DEFAULT { 12.0f, 16.0f, 26.0f, 12.0f, 36.0f, 40.0f }
 
 DJB_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DJB_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -1645,6 +1646,7 @@ DJB_DEV MerlFast merl_fast_coords(v3 i, v3 o, const MerlGuard g)
 	float rsh = fast_rcp(sh), rsd = fast_rcp(sd);
 	float e_h = U * (g.a_h * rsh + g.b_h);
 	float e_d = U * (g.a_d + g.b_d * rsh) * rsd + U * g.c_d;
+	float e_p = U * (g.a_p + g.b_d * rsh) * rsd + U * g.c_d;
 	// bin coordinates (dj_brdf.h:906-957)
 	const float R2D = 57.29577951308232f;
 	float deg_h = th * R2D;
@@ -1654,7 +1656,7 @@ DJB_DEV MerlFast merl_fast_coords(v3 i, v3 o, const MerlGuard g)
 	f.m_d = e_d * R2D;
 	float pw = pd < 0.0f ? pd + 3.14159265359f : pd;
 	f.x_p = pw * R2D;
-	f.m_p = e_d * R2D;
+	f.m_p = e_p * R2D;
 	// The reference snaps (theta, phi) to (0, 0) / (pi, 0) when |z| > 0.99999, i.e. when the angle is
 	// within acos(0.99999) = 4.4721e-3 rad of a pole (dj_brdf.h:652-656).  A pair is "special"
 	// (always tier 2) unless both estimates, shrunk by their guard bands, clear that zone.

@@ -57,6 +57,13 @@ struct djb_ctx {
 	int aniso_qf2_aligned = 0; // DJB_OPT_ANISO_QF2_ALIGNED
 	int fit_files_dense = 0;   // DJB_OPT_FIT_FILES_DENSE
 	int utia_exact_only = 0;   // DJB_OPT_UTIA_EXACT_ONLY: utia eval batches run k_eval<UTIA> (one kernel, exact fall-backs inline) instead of the two tiers
+	// tier-2 worklist of the two-tier kernels: capacity as a share of the batch.  2 % covers the bench distribution 8x over;
+	// after a call whose list overflowed (hostile distributions: 6 % of uniformly drawn BINS sit in the reference's snap
+	// region) the share grows, so that only the first such call pays the full rescan (wl_note / wl_adapt)
+	double wl_frac = 1.0 / 48;
+	hipEvent_t wl_ev = nullptr;
+	unsigned int *wl_host = nullptr;      // pinned: the count of the last large call
+	size_t wl_last_cap = 0; long long wl_last_n = 0; bool wl_pending = false;
 	int contract_1e5 = 0;      // DJB_OPT_CONTRACT_1E5: dense GGX eval batches run the two-tier value-contract kernels
 	int scalar_on_device = 0;  // DJB_OPT_SCALAR_ON_DEVICE: scalar-size host calls go through the GPU too (A/B testing)
 	// HBM staging blocks of the DJB_MEM_HOST path, recycled across calls (hipMalloc costs more than
@@ -698,6 +705,28 @@ djb_status eval_host_pipelined(djb_ctx *ctx, const djb_brdf *b, long long n, con
 	}, taken);
 }
 
+// worklist capacity bookkeeping (ctx->call_mu held).  wl_adapt: if the previous large call has finished and its list
+// overflowed, grow the share (never blocks: an unfinished call is looked at next time).  wl_note: remember this call.
+void wl_adapt(djb_ctx *ctx)
+{
+	if (!ctx->wl_pending || hipEventQuery(ctx->wl_ev) != hipSuccess) return;
+	ctx->wl_pending = false;
+	const unsigned int count = *ctx->wl_host;
+	if ((size_t)count > ctx->wl_last_cap && ctx->wl_last_n > 0) {
+		const double need = 1.25 * (double)count / (double)ctx->wl_last_n;
+		ctx->wl_frac = std::min(0.25, std::max(need, 2.0 * ctx->wl_frac));
+	}
+}
+void wl_note(djb_ctx *ctx, const unsigned int *count, size_t cap, long long n)
+{
+	if (n < (1LL << 20) || ctx->wl_pending) return;
+	if (!ctx->wl_ev && hipEventCreateWithFlags(&ctx->wl_ev, hipEventDisableTiming) != hipSuccess) { ctx->wl_ev = nullptr; return; }
+	if (!ctx->wl_host && hipHostMalloc((void **)&ctx->wl_host, 16) != hipSuccess) { ctx->wl_host = nullptr; return; }
+	if (hipMemcpyAsync(ctx->wl_host, count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return;
+	if (hipEventRecord(ctx->wl_ev, ctx->stream) != hipSuccess) return;
+	ctx->wl_last_cap = cap; ctx->wl_last_n = n; ctx->wl_pending = true;
+}
+
 djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                        const djb_vec3_view *o, const djb_params *params, const djb_vec3_view *out_fr,
                        float *out_pdf, int mem, int want)
@@ -733,7 +762,8 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 			// worklist: 16-byte header (count) + cap records of 32 bytes {k, i, o}; ~1 % of uniformly
 			// distributed pairs are ambiguous, 2 % capacity; overflow falls back to a rescan
 			const size_t REC = 32;
-			size_t cap = (size_t)(m / 48 + 4096);
+			wl_adapt(ctx);
+			size_t cap = (size_t)((double)m * ctx->wl_frac) + 4096;
 			size_t need = 16 + REC * cap;
 			if (ctx->scratch_bytes < need) {
 				HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -742,12 +772,13 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 				HIP_TRY(hipMalloc(&ctx->scratch, need));
 				ctx->scratch_bytes = need;
 			}
-			cap = (ctx->scratch_bytes - 16) / REC;
+			if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
 			unsigned int *count = (unsigned int *)ctx->scratch, *list = count + 4;
 			auto off = [&](const View &v) { return View{ v.x + lo * v.stride, v.y + lo * v.stride, v.z + lo * v.stride, v.stride }; };
 			View oi = off(vi), oo = off(vo), ou = (want & 3) ? off(vout) : vout;
 			HIP_TRY(djbk::launch_merl_twotier(ctx->stream, b->dev, m, oi, oo, ou, dpdf ? dpdf + lo : nullptr, want,
 			                                  list, (unsigned int)cap, count));
+			wl_note(ctx, count, cap, m);
 		}
 		return sg.finish();
 	}
@@ -784,7 +815,8 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 			for (long long lo = 0; lo < n; lo += CH) {
 				long long m = n - lo < CH ? n - lo : CH;
 				const size_t REC = 32;
-				size_t cap = (size_t)(m / 48 + 4096);
+				wl_adapt(ctx);
+				size_t cap = (size_t)((double)m * ctx->wl_frac) + 4096;
 				size_t need = 16 + REC * cap;
 				if (ctx->scratch_bytes < need) {
 					HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -793,12 +825,12 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 					HIP_TRY(hipMalloc(&ctx->scratch, need));
 					ctx->scratch_bytes = need;
 				}
-				cap = (ctx->scratch_bytes - 16) / REC;
-				if (cap > 0xffffffffull) cap = 0xffffffffull;
+				if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
 				unsigned int *count = (unsigned int *)ctx->scratch, *list = count + 4;
 				auto off = [&](const View &v) { return View{ v.x ? v.x + lo : nullptr, v.y ? v.y + lo : nullptr, v.z ? v.z + lo : nullptr, v.stride }; };
 				HIP_TRY(djbk::launch_eval_contract(ctx->stream, b->dev, p, m, off(vi), off(vo), off(vout), dpdf ? dpdf + lo : nullptr, want,
 				                                   list, (unsigned int)cap, count));
+				wl_note(ctx, count, cap, m);
 			}
 			return sg.finish();
 		}
@@ -980,6 +1012,8 @@ try {
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
+	if (ctx->wl_ev) (void)hipEventDestroy(ctx->wl_ev);
+	if (ctx->wl_host) (void)hipHostFree(ctx->wl_host);
 	for (auto &p : ctx->pool) (void)hipFree(p.first);
 	if (ctx->pin) (void)hipHostFree(ctx->pin);
 	if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
@@ -1935,7 +1969,7 @@ try {
 DJB_ABI_CATCH
 
 djb_status djb_merl_guard_stats(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
-                                const float *guard5, float *max_ratio3, unsigned long long *counters4)
+                                const float *guard6, float *max_ratio3, unsigned long long *counters4)
 try {
 	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
@@ -1948,7 +1982,7 @@ try {
 	hipError_t e = hipMemsetAsync(d, 0, 64, ctx->stream);
 	if (e == hipSuccess)
 		e = djbk::launch_merl_guard_stats(ctx->stream, n, View{ i->x, i->y, i->z, (long long)i->stride },
-		                                  View{ o->x, o->y, o->z, (long long)o->stride }, guard5,
+		                                  View{ o->x, o->y, o->z, (long long)o->stride }, guard6,
 		                                  (unsigned int *)d, (unsigned long long *)(d + 16));
 	unsigned char h[64];
 	if (e == hipSuccess) e = hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, ctx->stream);
@@ -1957,6 +1991,29 @@ try {
 	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: guard stats: %s", hipGetErrorString(e));
 	memcpy(max_ratio3, h, 12);
 	memcpy(counters4, h + 16, 32);
+	return DJB_OK;
+}
+DJB_ABI_CATCH
+
+djb_status djb_merl_guard_attack(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o, const float *guard6,
+                                 int iters, uint32_t seed, float *best_ratio, unsigned long long *counters3)
+try {
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
+	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	if (!Staged::valid(i) || !Staged::valid(o) || !best_ratio || !counters3 || iters < 0)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
+	unsigned long long *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 32));
+	hipError_t e = hipMemsetAsync(d, 0, 32, ctx->stream);
+	if (e == hipSuccess)
+		e = djbk::launch_merl_guard_attack(ctx->stream, n, View{ i->x, i->y, i->z, (long long)i->stride },
+		                                   View{ o->x, o->y, o->z, (long long)o->stride }, guard6, iters, seed, best_ratio, d);
+	if (e == hipSuccess) e = hipMemcpyAsync(counters3, d, 24, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: guard attack: %s", hipGetErrorString(e));
 	return DJB_OK;
 }
 DJB_ABI_CATCH

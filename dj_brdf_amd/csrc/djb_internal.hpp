@@ -43,7 +43,12 @@ hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const 
                                const View &out, float *out_pdf, int want, unsigned int *list,
                                unsigned int cap, unsigned int *count);
 hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, const View &o,
-                                   const float *guard5, unsigned int *max_bits, unsigned long long *counters);
+                                   const float *guard6, unsigned int *max_bits, unsigned long long *counters);
+
+// directed search for the worst |estimate - reference| / guard band: i / o are candidates in device memory, updated in place;
+// best[n] receives each candidate's final ratio; counters = {evaluations, index mismatches among certain pairs, accepted moves}
+hipError_t launch_merl_guard_attack(hipStream_t s, long long n, const View &i, const View &o, const float *guard6, int iters, uint32_t seed,
+                                    float *best, unsigned long long *counters);
 
 // MERL payload (3*n doubles) -> packed RGB texel table (pre-scaled, below-horizon zeroed); n = 1458000
 hipError_t launch_merl_convert(hipStream_t s, const double *samples, long long n, djbdev::MerlTexel *table);

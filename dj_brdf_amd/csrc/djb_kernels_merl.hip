@@ -12,6 +12,7 @@
 // function, so the result never depends on the capacity.  Bit-exactness argument and calibration: DESIGN.md 4.2.
 #include "djb_internal.hpp"
 #include "djb_worklist.hpp"
+#include <stdlib.h>
 
 using namespace djbdev;
 
@@ -191,6 +192,61 @@ __global__ __launch_bounds__(BLOCK) void k_merl_guard_stats(long long n, View vi
 	atomicAdd(&counters[2], n_mismatch); atomicAdd(&counters[3], n_sure);
 }
 
+// ---- directed search: every lane hill-climbs ONE pair over the bit patterns of its six input floats, maximising
+// |fp32 estimate - the reference's own value| / guard band (the quantity k_merl_guard_stats samples).  A move adds
+// +-2^e units in the last place (e = 0..20, hash-drawn) to one coordinate; it is kept if the ratio grows.  Every
+// evaluated pair that tier 1 calls CERTAIN is also checked against the exact index: counters[1] must stay 0.
+DJB_DEV float merl_guard_ratio(v3 i, v3 o, const MerlGuard g, unsigned long long &n_mismatch)
+{
+	MerlFast f = merl_fast_coords(i, o, g);
+	int idx_fast;
+	const bool sure = merl_index_fast(i, o, g, idx_fast);
+	float th, td, pd;
+	merl_angles_exact(i, o, th, td, pd);
+	if (sure) {
+		const int idx_ref = phi_diff_index(pd) + theta_diff_index(td) * 180 + theta_half_index(th) * 16200;
+		if (idx_fast != idx_ref) ++n_mismatch;
+	}
+	if (f.special) return 0.0f;
+	float Th = D(th) <= 0.0 ? 0.0f : sqrtf(F((D(th) / (DJB_PI / 2.0)) * 90) * 90.0f);
+	float Xd = F(D(td) / (DJB_PI * 0.5) * 90);
+	float pw = D(pd) < 0.0 ? F(D(pd) + DJB_PI) : pd;
+	float Xp = F(D(pw) / DJB_PI * 360 / 2);
+	float dh = fabsf(f.t_h - Th), dd = fabsf(f.x_d - Xd), dp = fabsf(f.x_p - Xp);
+	dp = fminf(dp, 180.0f - dp);
+	float r = 0.0f;
+	if (f.m_h < 0.45f) r = fmaxf(r, dh / f.m_h);
+	if (f.m_d < 0.45f) { r = fmaxf(r, dd / f.m_d); r = fmaxf(r, dp / f.m_p); }
+	return r == r ? r : 0.0f;
+}
+__global__ __launch_bounds__(BLOCK) void k_merl_guard_attack(long long n, View vi, View vo, MerlGuard g, int iters, uint32_t seed,
+                                                             float *best, unsigned long long *counters)
+{
+	const long long stride = (long long)gridDim.x * BLOCK;
+	unsigned long long n_eval = 0, n_mis = 0, n_acc = 0;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		float c[6];
+		{ v3 i = load3(vi, k), o = load3(vo, k); c[0] = i.x; c[1] = i.y; c[2] = i.z; c[3] = o.x; c[4] = o.y; c[5] = o.z; }
+		float cur = merl_guard_ratio(mk(c[0], c[1], c[2]), mk(c[3], c[4], c[5]), g, n_mis);
+		++n_eval;
+		for (int it = 0; it < iters; ++it) {
+			const uint32_t h = hash_u32(seed, (uint64_t)k * 4096ull + (uint64_t)it, 7u);
+			const int w = (int)(h % 6u), e = (int)((h >> 3) % 21u);
+			const int delta = (h & 0x80000000u) ? (1 << e) : -(1 << e);
+			const float old = c[w];
+			const float cand = __uint_as_float(__float_as_uint(old) + (uint32_t)delta);       // +-2^e ulps (sign-magnitude walk)
+			if (!(fabsf(cand) < 16.0f)) continue;                                            // stay finite and near the family
+			c[w] = cand;
+			const float r = merl_guard_ratio(mk(c[0], c[1], c[2]), mk(c[3], c[4], c[5]), g, n_mis);
+			++n_eval;
+			if (r > cur) { cur = r; ++n_acc; } else c[w] = old;
+		}
+		store3(vi, k, mk(c[0], c[1], c[2])); store3(vo, k, mk(c[3], c[4], c[5]));
+		best[k] = cur;
+	}
+	atomicAdd(&counters[0], n_eval); atomicAdd(&counters[1], n_mis); atomicAdd(&counters[2], n_acc);
+}
+
 template <int WANT>
 hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
                      const View &out, float *out_pdf, const MerlGuard &g, unsigned int *list_words,
@@ -204,8 +260,12 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
 	             al16(i.x) && al16(i.y) && al16(i.z) && al16(o.x) && al16(o.y) && al16(o.z) &&
 	             (!(WANT & 3) || (al16(out.x) && al16(out.y) && al16(out.z))) && (!(WANT & 4) || al16(out_pdf));
 	long long n4 = dense ? n / 4 : 0;
+	long long gcap = DJB_MERL_GRID_CAP;
+#ifdef DJB_EXPERIMENT
+	if (const char *e = getenv("DJB_MERL_GRID_CAP_ENV")) gcap = atoll(e);
+#endif
 	if (n4 > 0)
-		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4, DJB_MERL_GRID_CAP)), dim3(BLOCK), 0, s, b, n4, i, o, out,
+		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4, gcap)), dim3(BLOCK), 0, s, b, n4, i, o, out,
 		                   out_pdf, g, list, cap, count);
 	if (4 * n4 < n)   // strided / unaligned input, or the < 4-pair tail of a dense batch
 		hipLaunchKernelGGL((k_merl_fast<WANT>), dim3(grid_for(n - 4 * n4)), dim3(BLOCK), 0, s, b, 4 * n4, n, i, o,
@@ -236,11 +296,20 @@ hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const 
 }
 
 hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, const View &o,
-                                   const float *guard5, unsigned int *max_bits, unsigned long long *counters)
+                                   const float *guard6, unsigned int *max_bits, unsigned long long *counters)
 {
 	MerlGuard g = MERL_GUARD_DEFAULT;
-	if (guard5) { g.a_h = guard5[0]; g.b_h = guard5[1]; g.a_d = guard5[2]; g.b_d = guard5[3]; g.c_d = guard5[4]; }
+	if (guard6) { g.a_h = guard6[0]; g.b_h = guard6[1]; g.a_d = guard6[2]; g.b_d = guard6[3]; g.c_d = guard6[4]; g.a_p = guard6[5]; }
 	hipLaunchKernelGGL(k_merl_guard_stats, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, i, o, g, max_bits, counters);
+	return hipGetLastError();
+}
+
+hipError_t launch_merl_guard_attack(hipStream_t s, long long n, const View &i, const View &o, const float *guard6, int iters, uint32_t seed,
+                                    float *best, unsigned long long *counters)
+{
+	MerlGuard g = MERL_GUARD_DEFAULT;
+	if (guard6) { g.a_h = guard6[0]; g.b_h = guard6[1]; g.a_d = guard6[2]; g.b_d = guard6[3]; g.c_d = guard6[4]; g.a_p = guard6[5]; }
+	hipLaunchKernelGGL(k_merl_guard_attack, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, i, o, g, iters, seed, best, counters);
 	return hipGetLastError();
 }
 

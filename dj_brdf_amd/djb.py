@@ -1117,6 +1117,14 @@ def selftest_trig_sweep(fn, first_bits: int, count: int, threads: int = 0, cap: 
     return int(n_bad.value), [tuple(int(v) for v in row) for row in bad[:k]]
 
 
+def _guard6(guard):
+    """{a_h, b_h, a_d, b_d, c_d, a_p} in units of 2^-24; a 5-tuple (the round-1/2 form) uses a_p = a_d"""
+    g = list(guard)
+    if len(g) == 5:
+        g.append(g[2])
+    return (C.c_float * 6)(*g)
+
+
 def merl_guard_stats(i, o, guard=None, ctx: Optional[Context] = None):
     """Calibration of the two-tier MERL kernel on device-resident pairs (see djb_merl_guard_stats)."""
     ctx = ctx or default_context()
@@ -1125,8 +1133,22 @@ def merl_guard_stats(i, o, guard=None, ctx: Optional[Context] = None):
     counters = (C.c_ulonglong * 4)()
     g = None
     if guard is not None:
-        g = (C.c_float * 5)(*guard)
+        g = _guard6(guard)
     _lib.check(_lib.load().djb_merl_guard_stats(ctx._h, C.c_int64(vi.n), C.byref(vi.view), C.byref(vo.view), g,
                                                 ratios, counters))
     return {"max_ratio": tuple(ratios), "special": counters[0], "ambiguous": counters[1],
             "mismatch": counters[2], "certain": counters[3]}
+
+
+def merl_guard_attack(i, o, iters: int = 256, seed: int = 1, guard=None, ctx: Optional[Context] = None):
+    """Directed search for the worst |tier-1 estimate - reference| / guard band (djb_merl_guard_attack): i, o are
+    [3, n] device tensors of candidate pairs, hill-climbed IN PLACE over their bit patterns.  Returns
+    (best ratio per candidate as a device tensor, {evaluations, mismatch, accepted})."""
+    ctx = ctx or default_context()
+    vi, vo = _Vec(i), _Vec(o)
+    best = torch.zeros((vi.n,), dtype=torch.float32, device=i.device)
+    counters = (C.c_ulonglong * 3)()
+    g = _guard6(guard) if guard is not None else None
+    _lib.check(_lib.load().djb_merl_guard_attack(ctx._h, C.c_int64(vi.n), C.byref(vi.view), C.byref(vo.view), g, C.c_int(iters),
+                                                 C.c_uint32(seed), C.c_void_p(best.data_ptr()), counters))
+    return best, {"evaluations": int(counters[0]), "mismatch": int(counters[1]), "accepted": int(counters[2])}

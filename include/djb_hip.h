@@ -297,9 +297,17 @@ djb_status djb_merl_index_batch(djb_ctx *, int64_t n, const djb_vec3_view *i,
 /* calibration of the two-tier MERL kernel on n device-resident pairs: max over the batch of
  * |fp32 estimate - reference value| / guard band for (theta_h, theta_d, phi_d), and the counters
  * {special-region pairs, ambiguous pairs, index mismatches among "certain" pairs (must be 0),
- * certain pairs}.  guard5 = NULL uses the shipped band constants.                           */
+ * certain pairs}.  guard6 = {a_h, b_h, a_d, b_d, c_d, a_p} in units of 2^-24; NULL = the shipped constants.                           */
 djb_status djb_merl_guard_stats(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
-                                const float *guard5, float *max_ratio3, unsigned long long *counters4);
+                                const float *guard6, float *max_ratio3, unsigned long long *counters4);
+
+/* directed search against the same guard bands: every one of the n device-resident candidate pairs (i, o: updated in
+ * place) hill-climbs over the bit patterns of its six floats for `iters` moves (+-2^e units in the last place of one
+ * coordinate, e = 0..20), keeping a move when |estimate - reference| / band grows.  best_ratio: device float[n], the
+ * final ratio of each candidate; counters3 (host) = {evaluations, index mismatches among pairs tier 1 called certain
+ * (must be 0), accepted moves}.  tools/merl_guard_attack.py restarts it from every adversarial family.            */
+djb_status djb_merl_guard_attack(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o, const float *guard6,
+                                 int iters, uint32_t seed, float *best_ratio, unsigned long long *counters3);
 
 /* self-test of the kernels' guarded fp64 shortcuts (float(1/sqrt(double x)), float(1/q), the sRGB
  * decode float(pow(t, 2.4f))) against the exact double sequences on n hash-generated inputs:

@@ -51,6 +51,23 @@ __global__ __launch_bounds__(256) void NAME(float *out, int iters, float seed)  
 	out[blockIdx.x * 256 + threadIdx.x] = (float)(d0 + d1 + d2 + d3) + f0 + f1 + f2 + f3;               \
 }
 
+// v_cndmask with its mask in an SGPR pair (%9) instead of vcc, and a cmp + cndmask pair as the compiler emits selects
+#define PROBE32S(NAME, ASM)                                                                             \
+__global__ __launch_bounds__(256) void NAME(float *out, int iters, float seed)                          \
+{                                                                                                       \
+	float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+	float c = 1.0000001f;                                                                               \
+	unsigned long long m = 0x5555555555555555ull + (unsigned long long)iters;                           \
+	for (int it = 0; it < iters; ++it) {                                                                \
+		R16(asm volatile(ASM(%0) "\n" ASM(%1) "\n" ASM(%2) "\n" ASM(%3) "\n" ASM(%4) "\n" ASM(%5) "\n" ASM(%6) "\n" ASM(%7)    \
+		                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(m) : "vcc");) \
+	}                                                                                                   \
+	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                         \
+}
+#define A_CNDMASK_S(r) "v_cndmask_b32_e64 " #r ", " #r ", %8, %9"
+#define A_CMP_CND(r) "v_cmp_lt_f32 vcc, " #r ", %8\n s_nop 1\n v_cndmask_b32 " #r ", " #r ", %8, vcc"
+#define A_CMP_S(r) "v_cmp_lt_f32_e64 %9, " #r ", %8"
+#define A_MAX_F32(r) "v_max_f32 " #r ", " #r ", %8"
 #define A_MUL_F32(r) "v_mul_f32 " #r ", " #r ", %8"
 #define A_ADD_F32(r) "v_add_f32 " #r ", " #r ", %8"
 #define A_FMA_F32(r) "v_fma_f32 " #r ", " #r ", %8, %8"
@@ -107,6 +124,7 @@ PROBE32(p_divscale_f32, A_DIVSCALE_F32) PROBE32(p_divfmas_f32, A_DIVFMAS_F32) PR
 PROBE32(p_ldexp_f32, A_LDEXP_F32) PROBE32(p_cvt_f32_u32, A_CVT_F32_U32) PROBE32(p_cndmask, A_CNDMASK) PROBE32(p_cmp, A_CMP)
 PROBE32(p_mul_lo_u32, A_MUL_LO_U32) PROBE32(p_mul_hi_u32, A_MUL_HI_U32) PROBE32(p_mul_u24, A_MUL_U24) PROBE32(p_mad_u24, A_MAD_U24)
 PROBE32(p_lshl, A_LSHL) PROBE32(p_add_u32, A_ADD_U32) PROBE32(p_xor, A_XOR) PROBE32(p_mov, A_MOV) PROBE32(p_bfe, A_BFE) PROBE32(p_mbcnt, A_MBCNT)
+PROBE32S(p_cndmask_sgpr, A_CNDMASK_S) PROBE32(p_cmp_cnd_pair, A_CMP_CND) PROBE32(p_max_f32, A_MAX_F32)
 PROBE64(p_mul_f64, A_MUL_F64) PROBE64(p_add_f64, A_ADD_F64) PROBE64(p_fma_f64, A_FMA_F64) PROBE64(p_rcp_f64, A_RCP_F64)
 PROBE64(p_rsq_f64, A_RSQ_F64) PROBE64(p_sqrt_f64, A_SQRT_F64) PROBE64(p_ldexp_f64, A_LDEXP_F64) PROBE64(p_divscale_f64, A_DIVSCALE_F64)
 PROBE64(p_divfmas_f64, A_DIVFMAS_F64) PROBE64(p_divfixup_f64, A_DIVFIXUP_F64) PROBE64(p_pk_mul_f32, A_PK_MUL_F32) PROBE64(p_pk_fma_f32, A_PK_FMA_F32)
@@ -121,7 +139,7 @@ int main()
 {
 	std::vector<Probe> P = {
 #define E(n) { #n, p_##n }
-		E(mul_f32), E(add_f32), E(fma_f32), E(mov), E(cndmask), E(cmp), E(add_u32), E(xor), E(lshl), E(bfe), E(mbcnt), E(ldexp_f32), E(cvt_f32_u32),
+		E(mul_f32), E(add_f32), E(fma_f32), E(mov), E(max_f32), E(cndmask), E(cndmask_sgpr), E(cmp_cnd_pair), E(cmp), E(add_u32), E(xor), E(lshl), E(bfe), E(mbcnt), E(ldexp_f32), E(cvt_f32_u32),
 		E(mul_u24), E(mad_u24), E(mul_lo_u32), E(mul_hi_u32),
 		E(rcp_f32), E(rsq_f32), E(sqrt_f32), E(exp_f32), E(log_f32), E(divscale_f32), E(divfmas_f32), E(divfixup_f32),
 		E(pk_mul_f32), E(pk_add_f32), E(pk_fma_f32),

@@ -97,6 +97,9 @@ def parse():
     ap.add_argument("--fresnel", default="ideal", choices=["ideal", "schlick"], help="ggx_eval_pdf: ideal (default) or schlick(1.0, 0.71, 0.29)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--selftest-n", type=int, default=None,
+                    help="harness self-test only (DJB_BENCH_SHARE_GPU runs of the N-rank path on one GPU): shrink the primary batch "
+                         "to this many units per rank but keep the secondary fit legs; the line is labelled")
     return ap.parse_args()
 
 
@@ -378,7 +381,7 @@ def main():
     GGX_ALPHA, GGX_FRESNEL = args.alpha, args.fresnel
     name = args.workload
     n_default, bytes_per_unit, unit, kernel = WORKLOADS[name]
-    n = args.n or n_default
+    n = args.n or args.selftest_n or n_default
     step, keep = make_step(name, n, djb, synth, ctx, torch)
 
     def barrier():
@@ -496,6 +499,7 @@ def main():
                                 "merl_eval_uniform_bins": "MERL nearest-bin, look-ups uniform over all 90x90x180 bins",
                                 "merl_eval_coherent": "MERL nearest-bin, renderer-like coherent batch (bumpy plane, one light)"}[name],
                        "layout": "SoA float32 in HBM", "parallelism": f"independent x{world} (no collective)"
+                       + (" -- SELF-TEST batch size (--selftest-n): not the BASELINE configuration" if args.selftest_n else "")
                        + (" -- SELF-TEST: all ranks share GPU 0 (DJB_BENCH_SHARE_GPU), not a scaling measurement" if share_gpu else "")},
             "roofline": roofline,
         }

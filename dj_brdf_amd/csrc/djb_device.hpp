@@ -213,6 +213,7 @@ DJB_DEV float fdiv4(float a, float b) { return a / (4.0f * b); }
 // host: the exact expressions themselves (dj_brdf.h:612; float(1.0 / q))
 DJB_DEV float inversesqrt_(float x) { return F(1.0 / sqrt(D(x))); }
 DJB_DEV float recip_to_f32(double q) { return F(1.0 / q); }
+DJB_DEV float sqrt_to_f32(double a) { return F(sqrt(a)); }
 #else
 // ---- guarded fast paths for float(<double expression>) -----------------------------------------
 // The reference rounds a correctly-rounded double result e to float.  A cheaper double y with
@@ -227,27 +228,54 @@ DJB_DEV bool near_f32_midpoint(double y, int width = 256)
 	const int d = (int)((unsigned int)__double2loint(y) & 0x1FFFFFFFu) - 0x10000000;
 	return (d < 0 ? -d : d) <= width;
 }
-// inversesqrt = float(1.0 / sqrt(double(x))): two double roundings (dj_brdf.h:612)
+// inversesqrt = float(1.0 / sqrt(double(x))): two double roundings (dj_brdf.h:612).
+// Seed: v_rsq_f32 (1 ulp, 3 issue slots; v_rsq_f64 costs 5.9 -- profiles/r03/valu_issue_cost.txt), then ONE step of the
+// cubically convergent iteration y (1 + e/2 + 3 e^2/8), e = 1 - x y^2, in fp64: x y0 is exact in a double (24 x 24 bits),
+// so e carries one rounding; |e| <= 2^-22 leaves (5/16) e^3 < 2^-67 plus three roundings -- within 2 ulp64 of the true value.
+DJB_DEV double inversesqrt_fast(float x)
+{
+	const double xd = D(x), yd = D(__builtin_amdgcn_rsqf(x));
+	const double e = __builtin_fma(-(xd * yd), yd, 1.0);
+	return __builtin_fma(yd * e, __builtin_fma(e, 0.375, 0.5), yd);
+}
 DJB_DEV float inversesqrt_(float x)
 {
-	double xd = D(x);
-	double y = __builtin_amdgcn_rsq(xd);
-	y = y * __builtin_fma(-0.5 * xd * y, y, 1.5);      // Newton: y (1.5 - 0.5 x y^2)
-	y = y * __builtin_fma(-0.5 * xd * y, y, 1.5);
+	const double y = inversesqrt_fast(x);
 	if (__builtin_expect(near_f32_midpoint(y) || !(x > 1e-30f && x < 1e30f), 0))
-		return F(1.0 / sqrt(xd));                      // exact path (also zero / inf / NaN / tiny)
+		return F(1.0 / sqrt(D(x)));                    // exact path (also zero / inf / NaN / tiny)
 	return F(y);
 }
-// float(1.0 / q) for a double q
+// float(1.0 / q) for a double q: v_rcp_f32 seed of float(q) (error < 2^-22 together), one step r (1 + e + e^2), e = 1 - q r
+DJB_DEV double recip_fast(double q)
+{
+	const double r = D(__builtin_amdgcn_rcpf(F(q)));
+	const double e = __builtin_fma(-q, r, 1.0);
+	return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
 DJB_DEV float recip_to_f32(double q)
 {
-	double r = __builtin_amdgcn_rcp(q);
-	r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r);   // Newton: r + r (1 - q r)
-	r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r);
+	const double r = recip_fast(q);
 	double aq = q < 0 ? -q : q;
 	if (__builtin_expect(near_f32_midpoint(r) || !(aq > 1e-30 && aq < 1e30), 0))
 		return F(1.0 / q);
 	return F(r);
+}
+// float(sqrt(a)) for a double a that is not a float (1 - c^2 and the like): v_rsq_f32 seed, two coupled Newton steps
+// (g -> sqrt(a), h -> 1 / (2 sqrt(a))): 7 fp64 operations instead of the ~17 + v_rsq_f64 of the IEEE expansion
+DJB_DEV double sqrt_fast(double a)
+{
+	const double y = D(__builtin_amdgcn_rsqf(F(a)));
+	double g = a * y, h = 0.5 * y;
+	const double r = __builtin_fma(-g, h, 0.5);
+	g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+	return __builtin_fma(__builtin_fma(-g, g, a), h, g);
+}
+DJB_DEV float sqrt_to_f32(double a)
+{
+	const double g = sqrt_fast(a);
+	if (__builtin_expect(near_f32_midpoint(g) || !(a > 1e-30 && a < 1e30), 0))
+		return F(sqrt(a));                             // exact path (also zero / negative / inf / NaN / tiny)
+	return F(g);
 }
 #endif
 // a / b for floats, given R = double(1 / b) to within 2^-52 (or 0: plain division).  float(double(a) * R) is the
@@ -1113,7 +1141,7 @@ template <int KIND> DJB_DEV float sigma_std_radial(const Brdf &b, float c)
 {
 	if (KIND == KIND_BECKMANN) {                                                        // :1871
 		if (D(c) == 1.0) return 1.0f;
-		float s = F(sqrt(1.0 - D(c * c)));
+		float s = sqrt_to_f32(1.0 - D(c * c));
 		float nu = c / s;
 		const double e = glibc_exp(D(-nu * nu), b.exp_lds);              // also the exponential inside erf(nu)
 		float tmp = F(e * D(inversesqrt_(F(DJB_PI))));
@@ -1254,7 +1282,7 @@ DJB_DEV float beckmann_qf2_radial(float u, float cos_k, float sin_k, const Glibc
 DJB_DEV float ggx_qf2_radial(float u, float cos_k, float sin_k)                        // :2089
 {
 	float sin_t = F(D(u) * (1.0 + D(cos_k)) - 1.0);
-	float cos_t = F(sqrt(1.0 - D(sin_t * sin_t)));
+	float cos_t = sqrt_to_f32(1.0 - D(sin_t * sin_t));
 	if (D(cos_t) > 0.707107) {
 		float tan_t = sin_t / cos_t;
 		if (D(sin_k) < 0.707107) {
@@ -1278,7 +1306,7 @@ DJB_DEV float ggx_qf2_radial(float u, float cos_k, float sin_k)                 
 
 DJB_DEV float ggx_qf3_radial(float u, float qf2)                                       // :2121
 {
-	float alpha = F(sqrt(1.0 + D(qf2 * qf2)));
+	float alpha = sqrt_to_f32(1.0 + D(qf2 * qf2));
 	float S;
 	if (D(u) < 0.5) { u = F(2.0 * (0.5 - D(u))); S = -1.0f; }
 	else { u = F(2.0 * (D(u) - 0.5)); S = 1.0f; }
@@ -1399,7 +1427,7 @@ DJB_DEV void mf_sample_vp22_std(const Brdf &b, float u1, float u2, v3 k, float &
 {
 	if (!DJB_NMAP(KIND)) {
 		float cos_k = k.z;
-		float sin_k = D(k.z) < 1.0 ? F(sqrt(1.0 - D(k.z * k.z))) : 0.0f;
+		float sin_k = D(k.z) < 1.0 ? sqrt_to_f32(1.0 - D(k.z * k.z)) : 0.0f;
 		float tx, ty;
 		if (KIND == KIND_BECKMANN) { tx = beckmann_qf2_radial(u1, cos_k, sin_k, gt); ty = beckmann_qf1(u2, gt); }
 		else { tx = ggx_qf2_radial(u1, cos_k, sin_k); ty = ggx_qf3_radial(u2, tx); }

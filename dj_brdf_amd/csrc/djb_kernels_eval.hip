@@ -394,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_uni(long long n, uint32_t seed, u
 //           [6] fdiv_r(a, b, 1/b) != a / b (must be 0), [7] its IEEE fallbacks (sub-normal quotients).
 __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t seed, unsigned long long *counters)
 {
-	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0, bad_p = 0, fb_p = 0, bad_q = 0, fb_q = 0;
+	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0, bad_p = 0, fb_p = 0, bad_q = 0, fb_q = 0, bad_s = 0, fb_s = 0;
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		uint32_t h0 = hash_u32(seed, (uint64_t)k, 0), h1 = hash_u32(seed, (uint64_t)k, 1), h2 = hash_u32(seed, (uint64_t)k, 2);
@@ -402,16 +402,19 @@ __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t 
 		int ex = (k & 7) ? (int)(h1 % 80u) - 40 : (int)(h1 % 3u) - 1;
 		float x = ldexpf(1.0f + (float)(h0 >> 9) * 1.1920928955078125e-07f, ex);
 		if (inversesqrt_(x) != F(1.0 / sqrt(D(x)))) ++bad_r;
-		double xd = D(x), y = __builtin_amdgcn_rsq(xd);
-		y = y * __builtin_fma(-0.5 * xd * y, y, 1.5); y = y * __builtin_fma(-0.5 * xd * y, y, 1.5);
-		if (near_f32_midpoint(y)) ++fb_r;
+		if (near_f32_midpoint(inversesqrt_fast(x))) ++fb_r;
 		// double q = pi * t * t (the GGX slope pdf denominator) or 1 + p*x (erf), random low bits
 		double q = (h2 & 1) ? DJB_PI * D(x) * D(x) : 1.0 + D(x) * 0.3275911;
 		q = __longlong_as_double(__double_as_longlong(q) ^ (long long)(h2 >> 3));
 		if (recip_to_f32(q) != F(1.0 / q)) ++bad_d;
-		double r = __builtin_amdgcn_rcp(q);
-		r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r); r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r);
-		if (near_f32_midpoint(r)) ++fb_d;
+		if (near_f32_midpoint(recip_fast(q))) ++fb_d;
+		// float(sqrt(a)) of a double that is not a float: 1 - c^2 with c in [0, 1] (three quarters of the draws) or the random q
+		{
+			const float cc = (float)(h0 >> 8) * 5.9604644775390625e-08f;
+			const double a = (k & 3) ? 1.0 - D(cc * cc) : (q < 0 ? -q : q);
+			if (sqrt_to_f32(a) != F(sqrt(a))) ++bad_s;
+			if (near_f32_midpoint(sqrt_fast(a))) ++fb_s;
+		}
 		// interpolated UTIA value above the sRGB knee: mostly (0.0375, 1.2], every 8th in [2^-4, 2^4)
 		float v = (k & 7) ? 0.0375f + (float)(h2 >> 8) * 5.9604644775390625e-08f * 1.1625f
 		                  : ldexpf(1.0f + (float)(h0 >> 9) * 1.1920928955078125e-07f, (int)(h1 % 8u) - 4);
@@ -438,6 +441,7 @@ __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t 
 	atomicAdd(&counters[2], fb_r); atomicAdd(&counters[3], fb_d);
 	atomicAdd(&counters[4], bad_p); atomicAdd(&counters[5], fb_p);
 	atomicAdd(&counters[6], bad_q); atomicAdd(&counters[7], fb_q);
+	atomicAdd(&counters[8], bad_s); atomicAdd(&counters[9], fb_s);
 }
 
 // bins x bins histogram over [-1,1]^2: LDS atomics, one global flush per workgroup

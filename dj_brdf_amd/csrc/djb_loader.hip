@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -108,6 +109,32 @@ djb_status read_part(const char *path, int part, char *dst, size_t *bytes, std::
 }
 
 
+// ---- releasing the file mappings of a gather, off the caller's critical path: a short-lived thread per call unmaps them
+// (~0.08 ms of kernel work per 35 MB mapping); the library's static destructor waits for the stragglers, so that neither
+// exit() nor dlclose() pulls the code out from under one.
+struct Reaper {
+	std::atomic<int> live{ 0 };
+	~Reaper() { while (live.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+};
+Reaper g_reaper;
+void reap_mappings(std::vector<std::vector<std::pair<void *, size_t>>> &&kept)
+{
+	size_t n = 0;
+	for (auto &v : kept) n += v.size();
+	if (!n) return;
+	auto maps = std::make_shared<std::vector<std::vector<std::pair<void *, size_t>>>>(std::move(kept));
+	g_reaper.live.fetch_add(1);
+	try {
+		std::thread([maps]() {
+			for (auto &v : *maps) for (auto &m : v) munmap(m.first, m.second);
+			g_reaper.live.fetch_sub(1);
+		}).detach();
+	} catch (...) {                     // no thread to be had: unmap here
+		g_reaper.live.fetch_sub(1);
+		for (auto &v : *maps) for (auto &m : v) munmap(m.first, m.second);
+	}
+}
+
 // ---- the sparse form: fetch only what the fit reads ----------------------------------------------------------
 // djb::tabular(merl, res) evaluates its source at a fixed set of directions (djb_device.hpp: fit_merl_slot_count):
 // cnt back-scattering configurations + the (theta_d, theta_h) Fresnel pairs, 5 545 of a MERL file's 4 374 000
@@ -148,28 +175,42 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 	memset(host, 0, bytes);
 	if (threads < 1) {
 		// measured on the GPU box, 100 files (profiles/r02/fit_files_rates.txt): 1 thread 30 ms, 4: 11.4, 8: 9.8, 16: 10.4
+		// round 3 (mappings released outside the loop; 100 files, profiles/r03/fit_files_rates.txt): 8 threads 6.3 ms, 16: 5.9, 32: 4.1, 64: 4.7
 		unsigned hc = std::thread::hardware_concurrency();
-		threads = hc > 8 ? 8 : hc > 1 ? (int)hc - 1 : 1;
+		threads = hc >= 128 ? 32 : hc > 8 ? (int)(hc / 4) : hc > 1 ? (int)hc - 1 : 1;
 		if (const char *ev = getenv("DJB_READER_THREADS")) { int v = atoi(ev); if (v >= 1 && v <= 256) threads = v; }
 	}
 	if (threads > n_files) threads = n_files;
 	std::atomic<int> next(0);
 	std::mutex mu;
 	djb_status status = DJB_OK; std::string status_msg; int status_file = n_files;
+	// Mappings are NOT unmapped inside the gather loop: munmap takes the process's mmap_lock for writing and broadcasts a
+	// TLB shootdown to every core that runs one of its threads, which serialised the readers (profiles/r03/fit_files_rates.txt:
+	// 8 -> 32 threads 9.4 -> 10.2 ms with munmap in the loop, 6.3 -> 4.1 ms without; MAP_POPULATE is worse still: 38 ms,
+	// it holds the lock while it fills the page tables).  They are released after the alphas are on their way, by a
+	// reaper thread (below).
+	std::vector<std::vector<std::pair<void *, size_t>>> kept((size_t)threads);
+	std::atomic<int> worker_id(0);
+	// no exception may leave a worker thread (std::terminate): allocation failures inside one become the call's status
 	auto worker = [&]() {
+		auto &keep = kept[(size_t)worker_id.fetch_add(1)];
 		for (;;) {
 			const int f = next.fetch_add(1);
 			if (f >= n_files) return;
+			djb_status st = DJB_OK;
 			std::string err;
-			djb_status st = djbfile::gather_file(paths[f], plan, (float *)(host + (size_t)f * n_slots), &err);
+			try { st = djbfile::gather_file(paths[f], plan, (float *)(host + (size_t)f * n_slots), &err, &keep); }
+			catch (const std::bad_alloc &) { st = DJB_ERR_OUT_OF_MEMORY; }
+			catch (...) { st = DJB_ERR_INTERNAL; }
 			if (st != DJB_OK) {
 				std::lock_guard<std::mutex> lk(mu);
-				if (f < status_file) { status_file = f; status = st; status_msg = err; }   // the reference stops at the first bad file
+				try { if (f < status_file) { status_file = f; status = st; status_msg = err.empty() ? "djb_error: out of host memory" : err; } }   // the reference stops at the first bad file
+				catch (...) { status = st; }
 			}
 		}
 	};
 	std::vector<std::thread> pool;
-	for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+	for (int t = 1; t < threads; ++t) { try { pool.emplace_back(worker); } catch (...) { break; } }    // fewer threads, same result
 	worker();
 	for (std::thread &t : pool) t.join();
 	const double t_loaded0 = now_s();
@@ -187,6 +228,7 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 	if (status == DJB_OK && status_msg.empty())
 		status = djb_fit_brdf_batch(ctx, n_files, mats.data(), res, shadow, alpha_beckmann, alpha_ggx, nullptr, nullptr, nullptr, nullptr, nullptr);
 	const double t_end = now_s();
+	reap_mappings(std::move(kept));
 	for (djb_brdf *b : mats) if (b) djb_brdf_destroy(b);
 	(void)hipHostFree(host); (void)hipFree(dev);
 	if (status != DJB_OK) return status_msg.empty() ? status : djbk::set_error(status, "%s", status_msg.c_str());

@@ -44,7 +44,10 @@ inline SlotPlan make_plan(const std::vector<int32_t> &idx)
 // out: 3 floats (r, g, b) per slot, slot-major.  Same checks and messages as djb::merl::merl (dj_brdf.h:963-983); the
 // header is untrusted (64-bit product of positive dims, MERL shape only); the reference reads the whole payload and
 // fails if the file is short (dj_brdf.h:979-982): same verdict here, from the file size.
-inline djb_status gather_file(const char *path, const SlotPlan &plan, float *out, std::string *err)
+// `keep` (optional): the mapping is handed back instead of unmapped -- see the caller (djb_loader.hip: unmapping inside
+// the gather loop is what stopped the gather from scaling with reader threads).
+inline djb_status gather_file(const char *path, const SlotPlan &plan, float *out, std::string *err,
+                              std::vector<std::pair<void *, size_t>> *keep = nullptr)
 {
 	char buf[256];
 	int fd = open(path, O_RDONLY);
@@ -81,7 +84,8 @@ inline djb_status gather_file(const char *path, const SlotPlan &plan, float *out
 		float *o = out + 3 * (size_t)plan.slot[k];
 		o[0] = r; o[1] = g; o[2] = b;
 	}
-	munmap(map, 12 + PAYLOAD);
+	if (keep) keep->emplace_back(map, 12 + PAYLOAD);
+	else munmap(map, 12 + PAYLOAD);
 	return DJB_OK;
 }
 

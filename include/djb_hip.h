@@ -62,8 +62,10 @@ enum { DJB_MEM_DEVICE = 0, DJB_MEM_HOST = 1 };
 /* DJB_MEM_HOST calls of at most this many units on a GPU context -- the scalar virtuals of the djb:: facade, a
  * renderer's per-hit calls -- are answered by that same host code on the calling thread, from a host copy of the
  * object's tables (no staging, no launch, no context lock): bit-identical to the batch path, ~100 ns instead of
- * ~15 us per pair.  DJB_OPT_SCALAR_ON_DEVICE = 1 routes them through the GPU as well.                          */
-#define DJB_SCALAR_HOST_MAX 64
+ * ~15 us per pair.  DJB_OPT_SCALAR_ON_DEVICE = 1 routes them through the GPU as well.  The threshold is the smallest
+ * measured break-even of the operators (profiles/r03/scalar_latency.txt, one host thread vs one GPU round trip of ~22 us:
+ * beckmann sample ~100 units, merl eval ~190, ggx eval ~320).                                                  */
+#define DJB_SCALAR_HOST_MAX 96
 
 typedef struct djb_ctx djb_ctx;     /* one GPU + one HIP stream */
 typedef struct djb_brdf djb_brdf;   /* an immutable BRDF object resident in HBM (djb::brdf subclass) */
@@ -311,10 +313,11 @@ djb_status djb_merl_guard_attack(djb_ctx *, int64_t n, const djb_vec3_view *i, c
 
 /* self-test of the kernels' guarded fp64 shortcuts (float(1/sqrt(double x)), float(1/q), the sRGB
  * decode float(pow(t, 2.4f))) against the exact double sequences on n hash-generated inputs:
- * counters[8] = {rsqrt mismatches, reciprocal mismatches, rsqrt exact-path fallbacks, reciprocal
+ * counters[10] = {rsqrt mismatches, reciprocal mismatches, rsqrt exact-path fallbacks, reciprocal
  * fallbacks, sRGB-decode mismatches, sRGB-decode fallbacks, mismatches of the exact division through a double
- * reciprocal (float(double(a) * R) vs a / b), its IEEE fallbacks}; every mismatch count must be 0. */
-djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters8);
+ * reciprocal (float(double(a) * R) vs a / b), its IEEE fallbacks, mismatches of float(sqrt(a)) for a double a, its fallbacks};
+ * every mismatch count must be 0. */
+djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters10);
 /* the DJB_OPT_CONTRACT_1E5 fast path against the bit-exact per-pair code on n generated pairs (family 0: the bench
  * distribution; 1: grazing with opposite azimuths; 2: near-normal incidence; 3: o at the horizon; 4: un-normalised):
  * max_rel2 = {max relative difference of the eval rgb, of the pdf} over the fast-path pairs, counters4 = {pairs, pairs

@@ -33,7 +33,7 @@ if mode == "cpu":
     m = np.load(os.path.join(G, "merl.npz"))
     out["merl_indices_differing"] = int(np.sum(djb.merl_index(m["i"], m["o"], ctx=ctx) != m["index"]))
 else:
-    # GPU box: the same object answers 64-unit host calls (host twin, on this thread) and one GPU batch
+    # GPU box: the same object answers scalar-size (64-unit) host calls (host twin, on this thread) and one GPU batch
     ctx = djb.default_context(0)
     out["status"] = djb.host_libm_status()
     n = 1 << 12

@@ -368,6 +368,8 @@ def test_guarded_fp64_shortcuts_are_exact(gpu_ctx):
     assert 0 < r["srgb_fallback"] < 2_000_000_000 * 1e-4
     assert 0 < r["rsqrt_fallback"] < 2_000_000_000 * 1e-4
     assert 0 < r["recip_fallback"] < 2_000_000_000 * 1e-4
+    # float(sqrt(a)) of a double (1 - c^2: the sin of the stretched view direction, Beckmann's sigma): round 3
+    assert r["sqrt_mismatch"] == 0 and 0 < r["sqrt_fallback"] < 2_000_000_000 * 1e-4
 
 
 def test_microfacet_mutators(gpu_ctx, oracle, dirs):

@@ -20,7 +20,7 @@ from dj_brdf_amd import djb, synth
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = 4096
-K = 64       # DJB_SCALAR_HOST_MAX
+K = 96       # DJB_SCALAR_HOST_MAX
 
 
 def bits(a):

@@ -3,7 +3,7 @@
 since 2.28 the table-driven algorithms of sysdeps/ieee754/dbl-64/e_exp.c and e_pow.c (ARM optimized-routines;
 error ~0.51 ulp, not correctly rounded).  This script reads their two constant tables out of libm.so.6
 (__exp_data, __pow_log_data: hidden symbols, located by their leading entries) and writes them, numeric data
-only, as dj_brdf_amd/csrc/djb_glibc_dbl64_tables.hpp (device) and oracle/glibc_dbl64_tables.h (checker).
+only, as dj_brdf_amd/csrc/djb_glibc_dbl64_tables.hpp (the one copy in the tree; oracle/Makefile derives the checker's C header from it).
 atan2 is the IBM Accurate Mathematical Library routine (sysdeps/ieee754/dbl-64/e_atan2.c; since 2.34 without its
 multi-precision fall-back): its 241 x 7 table cij (uatan.tbl) is read the same way, located by its first row; sin / cos
 (s_sin.c) read the 440-entry __sincostab, tan (s_tan.c) the 186 x 4 xfg, acos (e_asin.c) asincos.tbl and root.tbl.
@@ -148,5 +148,4 @@ def emit(path, device):
 
 
 emit(os.path.join(ROOT, "dj_brdf_amd", "csrc", "djb_glibc_dbl64_tables.hpp"), True)
-emit(os.path.join(ROOT, "oracle", "glibc_dbl64_tables.h"), False)
 print("wrote tables: __exp_data@%d __pow_log_data@%d cij@%d" % (exp_off, pow_off, atan_off))

@@ -16,6 +16,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -59,11 +61,26 @@ template <class F> void parallel_for(const CpuCtx *ctx, long long n, long long g
 	int t = ctx ? ctx->threads : 1;
 	if ((long long)t > n / grain) t = (int)(n / grain);
 	if (t <= 1) { f(0LL, n); return; }
+	// No exception may leave a worker thread (std::terminate) and none may leave this function before every thread has been
+	// joined: a worker's exception is carried to the caller's thread and rethrown there (the C ABI maps it to a status);
+	// if a thread cannot be created, its slice runs on the calling thread.
 	std::vector<std::thread> th;
 	th.reserve(t - 1);
-	for (int k = 1; k < t; ++k) th.emplace_back([=] { f(n * k / t, n * (k + 1) / t); });
-	f(0LL, n / t);
+	std::exception_ptr first;
+	std::mutex mu;
+	auto guarded = [&](long long k0, long long k1) {
+		try { f(k0, k1); }
+		catch (...) { std::lock_guard<std::mutex> lk(mu); if (!first) first = std::current_exception(); }
+	};
+	std::vector<int> inline_slices;
+	for (int k = 1; k < t; ++k) {
+		try { th.emplace_back([&guarded, n, k, t] { guarded(n * k / t, n * (k + 1) / t); }); }
+		catch (...) { inline_slices.push_back(k); }
+	}
+	guarded(0LL, n / t);
+	for (int k : inline_slices) guarded(n * k / t, n * (k + 1) / t);
 	for (auto &x : th) x.join();
+	if (first) std::rethrow_exception(first);
 }
 
 CpuBrdf *alloc_brdf(djb_ctx *ctx, int kind)

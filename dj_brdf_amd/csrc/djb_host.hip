@@ -137,7 +137,9 @@ djb_fresnel_desc current_fresnel_desc(const djb_brdf *b)
 	return d;
 }
 
-void build_twin(const djb_brdf *b)
+// `via`: the context of the CALL that needs the twin (validated by the caller: same device as the object).  The object's
+// creating context may be gone by now -- handles outlive their contexts -- so nothing here touches b->ctx.
+void build_twin(const djb_brdf *b, djb_ctx *via)
 {
 	djb_ctx *tc = djbcpu::twin_ctx();
 	djb_brdf *t = nullptr;
@@ -145,10 +147,10 @@ void build_twin(const djb_brdf *b)
 	const djb_fresnel_desc fd = current_fresnel_desc(b);
 	auto download = [&](std::vector<char> &host, const void *dev, size_t bytes) -> bool {
 		host.resize(bytes);
-		std::lock_guard<std::recursive_mutex> call_lock(b->ctx->call_mu);
-		if (hipSetDevice(b->ctx->device) != hipSuccess) return false;
-		if (hipMemcpyAsync(host.data(), dev, bytes, hipMemcpyDeviceToHost, b->ctx->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
-		return hipStreamSynchronize(b->ctx->stream) == hipSuccess;
+		std::lock_guard<std::recursive_mutex> call_lock(via->call_mu);
+		if (hipSetDevice(via->device) != hipSuccess) return false;
+		if (hipMemcpyAsync(host.data(), dev, bytes, hipMemcpyDeviceToHost, via->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+		return hipStreamSynchronize(via->stream) == hipSuccess;
 	};
 	switch (b->dev.kind) {
 	case DJB_KIND_BECKMANN: case DJB_KIND_GGX:
@@ -193,10 +195,16 @@ void build_twin(const djb_brdf *b)
 }
 
 // the host twin of a GPU object for a scalar-size host call, or NULL (then the call takes the GPU path)
+// (a brdf / ctx device mismatch is NOT answered here: the caller's check_call reports it, as for every other call.)
+// Concurrency: any number of threads may call the operators of one object at once -- they are const in the reference and
+// lock-free here -- but djb_brdf_set_fresnel / set_shadow replace tables of the twin that such readers may be walking: as
+// with the reference's microfacet::set_fresnel (delete + copy, dj_brdf.h:1521-1525) a setter must not run concurrently
+// with calls on the same object.
 const djb_brdf *scalar_twin(const djb_ctx *ctx, const djb_brdf *b, long long n, int mem)
 {
 	if (mem != DJB_MEM_HOST || n > SCALAR_HOST_MAX || n < 0 || !b || ctx->scalar_on_device) return nullptr;
-	std::call_once(b->twin_once, build_twin, b);
+	if (b->device != ctx->device) return nullptr;
+	std::call_once(b->twin_once, build_twin, b, const_cast<djb_ctx *>(ctx));
 	return b->twin;
 }
 
@@ -687,6 +695,7 @@ try {
 	if (option == DJB_OPT_ANISO_QF2_ALIGNED) { ctx->aniso_qf2_aligned = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_UTIA_EXACT_ONLY) { ctx->utia_exact_only = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_CONTRACT_1E5) { ctx->contract_1e5 = value != 0; return DJB_OK; }
+	if (option == DJB_OPT_TEST_WORKLIST_CAP) { ctx->test_worklist_cap = value; return DJB_OK; }
 	return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown option %d", option);
 }
 DJB_ABI_CATCH

@@ -249,7 +249,25 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
 	if ((want & 3) && (st = sg.out_vec(out_fr, &vout)) != DJB_OK) return st;
 	if ((want & 4) && (st = sg.out_arr(out_pdf, &dpdf)) != DJB_OK) return st;
-	if (b->dev.kind == DJB_KIND_MERL && (want & 3) && !ctx->merl_exact_only) {
+	// The two-tier kernels write placeholders in tier 1 and re-read their inputs in tier 2 (worklist overflow: the whole
+	// batch), so a device-resident caller whose OUTPUT arrays overlap its INPUT arrays (in-place evalp) must not use them:
+	// such calls take the one-kernel forms, which read a pair before they write it (index-aligned in-place views are
+	// the only supported kind of overlap, as for any elementwise kernel).
+	bool aliased = false;
+	if (mem == DJB_MEM_DEVICE) {
+		auto span = [&](const float *q, long long stride) { return std::make_pair((uintptr_t)q, (uintptr_t)(q + (n > 0 ? (n - 1) * stride + 1 : 0))); };
+		auto hit = [&](const float *a, long long sa, const float *bq, long long sb) {
+			if (!a || !bq || n <= 0) return false;
+			auto x = span(a, sa), y = span(bq, sb);
+			return x.first < y.second && y.first < x.second;
+		};
+		const float *ins[6] = { vi.x, vi.y, vi.z, vo.x, vo.y, vo.z };
+		const long long sin_[6] = { vi.stride, vi.stride, vi.stride, vo.stride, vo.stride, vo.stride };
+		const float *outs_[4] = { (want & 3) ? vout.x : nullptr, (want & 3) ? vout.y : nullptr, (want & 3) ? vout.z : nullptr, dpdf };
+		const long long sout[4] = { vout.stride, vout.stride, vout.stride, 1 };
+		for (int a = 0; a < 4 && !aliased; ++a) for (int c = 0; c < 6; ++c) if (hit(outs_[a], sout[a], ins[c], sin_[c])) { aliased = true; break; }
+	}
+	if (b->dev.kind == DJB_KIND_MERL && (want & 3) && !ctx->merl_exact_only && !aliased) {
 		// two-tier exact lookup; pair indices travel as uint32, so very large batches are chunked
 		const long long CH = 1LL << 31;
 		for (long long lo = 0; lo < n; lo += CH) {
@@ -259,6 +277,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 			const size_t REC = 32;
 			wl_adapt(ctx);
 			size_t cap = (size_t)((double)m * ctx->wl_frac) + 4096;
+			if (ctx->test_worklist_cap >= 0) cap = (size_t)ctx->test_worklist_cap + 1;      // (the record list needs one slot)
 			size_t need = 16 + REC * cap;
 			if (ctx->scratch_bytes < need) {
 				HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -277,14 +296,14 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 		}
 		return sg.finish();
 	}
-	if (b->dev.kind == DJB_KIND_UTIA && (want & 3) && !ctx->utia_exact_only) {
+	if (b->dev.kind == DJB_KIND_UTIA && (want & 3) && !ctx->utia_exact_only && !aliased) {
 		// two-tier (djb_kernels_eval.hip): pair indices travel as uint32, so very large batches are chunked; the
 		// worklist (16-byte header + 4 bytes per entry; ~2e-5 of the pairs need it) shares the context's scratch
 		const long long CH = 1LL << 31;
 		for (long long lo = 0; lo < n; lo += CH) {
 			long long m = n - lo < CH ? n - lo : CH;
 			size_t cap = (size_t)(m / 256 + 4096);
-			if (const char *e = getenv("DJB_UTIA_WORKLIST_CAP")) cap = (size_t)strtoull(e, nullptr, 10);   // test hook: force the overflow path
+			if (ctx->test_worklist_cap >= 0) cap = (size_t)ctx->test_worklist_cap;   // DJB_OPT_TEST_WORKLIST_CAP (tests): force the overflow path
 			size_t need = 16 + 4 * (cap ? cap : 1);
 			if (ctx->scratch_bytes < need) {
 				HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -300,7 +319,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 		}
 		return sg.finish();
 	}
-	if (ctx->contract_1e5 && b->dev.kind == DJB_KIND_GGX && djbk::contract_supported(b->dev, p)) {
+	if (ctx->contract_1e5 && !aliased && b->dev.kind == DJB_KIND_GGX && djbk::contract_supported(b->dev, p)) {
 		auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
 		const bool dense16 = vi.stride == 1 && vo.stride == 1 && al16(vi.x) && al16(vi.y) && al16(vi.z) && al16(vo.x) && al16(vo.y) && al16(vo.z) &&
 		                     (!(want & 3) || (vout.stride == 1 && al16(vout.x) && al16(vout.y) && al16(vout.z))) && (!(want & 4) || al16(dpdf));
@@ -312,6 +331,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 				const size_t REC = 32;
 				wl_adapt(ctx);
 				size_t cap = (size_t)((double)m * ctx->wl_frac) + 4096;
+				if (ctx->test_worklist_cap >= 0) cap = (size_t)ctx->test_worklist_cap + 1;
 				size_t need = 16 + REC * cap;
 				if (ctx->scratch_bytes < need) {
 					HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -335,16 +335,19 @@ static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *p
 				chunks[slot].state = 1; chunks[slot].file = (int)(item / CHUNKS_PER_FILE); chunks[slot].part = (int)(item % CHUNKS_PER_FILE);
 			}
 			std::string err; size_t bytes = 0;
-			djb_status st = read_part(paths[chunks[slot].file], chunks[slot].part, chunks[slot].host, &bytes, &err);
+			djb_status st;
+			try { st = read_part(paths[chunks[slot].file], chunks[slot].part, chunks[slot].host, &bytes, &err); }
+			catch (...) { st = DJB_ERR_OUT_OF_MEMORY; }              // nothing may leave a reader thread (std::terminate)
 			{
 				std::lock_guard<std::mutex> lk(mu);
-				chunks[slot].st = st; chunks[slot].err = err; chunks[slot].bytes = bytes; chunks[slot].state = 2;
+				chunks[slot].st = st; chunks[slot].bytes = bytes; chunks[slot].state = 2;
+				try { chunks[slot].err = err; } catch (...) { chunks[slot].st = DJB_ERR_OUT_OF_MEMORY; }
 			}
 			cv.notify_all();
 		}
 	};
 	std::vector<std::thread> readers;
-	for (int t = 0; t < reader_threads; ++t) readers.emplace_back(reader);
+	for (int t = 0; t < reader_threads; ++t) { try { readers.emplace_back(reader); } catch (...) { if (readers.empty()) throw; break; } }   // fewer readers, same result
 
 	// ---- consumer side (this thread): upload filled chunks, convert a file once its last chunk is on its way
 	long long uploaded = 0;

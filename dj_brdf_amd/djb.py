@@ -19,6 +19,7 @@ All arithmetic happens in the HIP kernels; nothing here evaluates a BRDF on the 
 """
 from __future__ import annotations
 
+import threading
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -95,7 +96,8 @@ class Context:
             pass
 
 
-_default_ctx = {}
+_default_cpu_ctx = {}
+_default_gpu_ctx = threading.local()
 
 
 def cpu_context() -> Context:
@@ -104,9 +106,20 @@ def cpu_context() -> Context:
 
 
 def default_context(device=0) -> Context:
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    """The default context of `device`: process-wide for "cpu", PER THREAD for a GPU.  A GPU context created without an
+    explicit stream follows torch's current stream, which is a per-thread notion: `set stream, then launch` on a context
+    shared by two threads that work under different torch streams could interleave (thread A's kernels on thread B's
+    stream).  Per-thread defaults rule that out; a Context object that is handed to several threads explicitly must either
+    pin its stream (Context(device, stream=...)) or be used under one torch stream.  Objects may be used with any context
+    of their device."""
+    if device in ("cpu", -1):
+        if "cpu" not in _default_cpu_ctx:
+            _default_cpu_ctx["cpu"] = Context("cpu")
+        return _default_cpu_ctx["cpu"]
+    d = _default_gpu_ctx.__dict__.setdefault("ctx", {})
+    if device not in d:
+        d[device] = Context(device)
+    return d[device]
 
 
 def device_count() -> int:
@@ -1049,6 +1062,11 @@ def selftest_contract(brdf, params=None, n: int = 1 << 24, seed: int = 1, family
                                                  C.c_int64(n), C.c_uint32(seed), C.c_int(family), mx, c))
     return {"max_rel_eval": float(mx[0]), "max_rel_pdf": float(mx[1]), "pairs": int(c[0]), "tier2": int(c[1]),
             "zero_mismatch": int(c[2]), "outside_1e5": int(c[3])}
+
+
+def set_test_worklist_cap(ctx: Context, entries: int):
+    """tests: override the tier-2 worklist capacity of the two-tier kernels (-1 = automatic); DJB_OPT_TEST_WORKLIST_CAP"""
+    _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(7), C.c_int(int(entries))))
 
 
 def set_aniso_qf2_aligned(ctx: Context, on: bool):

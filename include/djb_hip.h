@@ -14,6 +14,8 @@
  *  - Arrays are described by djb_vec3_view {x, y, z, stride}: element k is (x[k*stride],
  *    y[k*stride], z[k*stride]).  SoA = three arrays with stride 1 (fast path);
  *    an array of djb::vec3 (AoS) = {p, p+1, p+2, 3}.
+ *  - output arrays may coincide with input arrays only as index-aligned in-place views (out[k] shares storage with
+ *    in[k]); any other overlap of an output with an input is undefined, as for the reference's own loops.
  *  - `mem` says where the array pointers live: DJB_MEM_DEVICE (HBM of the ctx's GPU; the call is
  *    asynchronous on the ctx's stream) or DJB_MEM_HOST (the call stages through HBM and returns
  *    when the outputs are back in host memory).  Host batches of >= 2^20 units of the operator
@@ -148,8 +150,7 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
 /* DJB_OPT_UTIA_EXACT_ONLY = 1: utia eval / evalp batches run one kernel that carries the exact fall-backs of the azimuths
  * (glibc's atan2) and of the sRGB power inline, instead of the two-tier form (tier 1 without them + a worklist of the
  * pairs that sit next to a float rounding boundary, re-evaluated by a second kernel); both give the same bits, the
- * option exists to verify that.  (Environment DJB_UTIA_WORKLIST_CAP=<entries> overrides the worklist capacity: a test
- * hook for the overflow path, in which the second kernel redoes the whole batch.) */
+ * option exists to verify that. */
        DJB_OPT_UTIA_EXACT_ONLY = 5,
 /* DJB_OPT_CONTRACT_1E5 = 1 (off by default): dense device-resident GGX eval / evalp / pdf batches (ideal or schlick Fresnel,
  * f0 >= 0.01; params without mean-normal offset, |rho| <= 0.9) are evaluated inside the VALUE contract of the north star --
@@ -158,7 +159,11 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * rounded divisions, pairs whose reference value is ill-conditioned re-done by the bit-exact code (two tiers, as for
  * MERL).  Everything else -- sampling, MERL / UTIA look-ups and their bin decisions, the fitters, other lobes and
  * layouts -- is unaffected and stays bit-identical.  djb_selftest_contract measures the actual maximum difference. */
-       DJB_OPT_CONTRACT_1E5 = 6 };
+       DJB_OPT_CONTRACT_1E5 = 6,
+/* DJB_OPT_TEST_WORKLIST_CAP = <entries> (tests only; -1 = automatic, the default): overrides the capacity of the tier-2
+ * worklist of the two-tier kernels (merl, utia, contract mode), to exercise the overflow path in which the second kernel
+ * redoes the whole batch.  Results never depend on the capacity. */
+       DJB_OPT_TEST_WORKLIST_CAP = 7 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */
 djb_status  djb_timer_start(djb_ctx *ctx);
@@ -395,8 +400,12 @@ djb_status djb_fit_brdf_batch(djb_ctx *, int n_materials, const djb_brdf *const 
  * files, ~97 KB per material travel to HBM, then ONE fit launch for the whole batch.  With DJB_OPT_FIT_FILES_DENSE
  * the whole tables travel instead (reader threads -> pinned 4 MiB chunk ring -> async upload + conversion kernel).
  * Errors carry djb::merl's messages (dj_brdf.h:970-982), the lowest-indexed bad file wins.  reader_threads <= 0
- * picks a default.  timing (optional, 4 doubles): total seconds, seconds until every table was
- * resident in HBM, seconds of the fit, bytes read from the files.                            */
+ * picks a default (32 on a large host).  timing (optional, 4 doubles): total seconds, seconds until every table was
+ * resident in HBM, seconds of the fit, bytes read from the files.  The mapped files are released by a helper thread
+ * after the call has its alphas (unmapping inside the gather loop serialised the readers).  The default form reads
+ * through mmap: a file that is TRUNCATED by another process while the call runs raises SIGBUS like any mapped read
+ * (size and header are checked before mapping); callers that cannot rule that out -- network file systems with
+ * concurrent writers -- should set DJB_OPT_FIT_FILES_DENSE, whose pread() path returns "Reading <file> failed".  */
 djb_status djb_fit_merl_files(djb_ctx *, int n_files, const char *const *paths, int res, int shadow,
                               int reader_threads, float *alpha_beckmann, float *alpha_ggx,
                               double *timing);

@@ -295,9 +295,11 @@ def test_utia_worklist_overflow_redoes_the_batch(gpu_ctx, monkeypatch):
     i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
     u = djb.utia.from_table(synth.utia_table_smooth(), ctx=gpu_ctx)
     want = u.eval(i, o)
-    monkeypatch.setenv("DJB_UTIA_WORKLIST_CAP", "0")
-    got = u.eval(i, o)
-    monkeypatch.delenv("DJB_UTIA_WORKLIST_CAP")
+    djb.set_test_worklist_cap(gpu_ctx, 0)
+    try:
+        got = u.eval(i, o)
+    finally:
+        djb.set_test_worklist_cap(gpu_ctx, -1)
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
     try:
         djb.set_utia_exact_only(gpu_ctx, True)
@@ -305,3 +307,41 @@ def test_utia_worklist_overflow_redoes_the_batch(gpu_ctx, monkeypatch):
     finally:
         djb.set_utia_exact_only(gpu_ctx, False)
     assert torch.equal(one.view(torch.int32), want.view(torch.int32))
+
+
+def test_two_tier_overflow_and_in_place_calls(gpu_ctx):
+    """(1) MERL and contract-mode worklists forced to overflow: tier 2 redoes the batch, same results.  (2) In-place
+    evalp (the output arrays ARE the input arrays of i): the two-tier kernels must not be used -- their second tier
+    re-reads inputs the first has overwritten -- and the result must equal the out-of-place call bit for bit."""
+    import ctypes as C
+    import torch
+    n = 3_000_001
+    i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
+    m = djb.merl.from_table(synth.merl_table_hashed(), ctx=gpu_ctx)
+    u = djb.utia.from_table(synth.utia_table_smooth(), ctx=gpu_ctx)
+    g = djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    p = djb.microfacet.params.isotropic(0.3)
+    want_m, want_u = m.evalp(i, o), u.evalp(i, o)
+    djb.set_contract_1e5(gpu_ctx, True)
+    try:
+        want_g = g.evalp(i, o, p)
+        djb.set_test_worklist_cap(gpu_ctx, 3)
+        try:
+            assert torch.equal(m.evalp(i, o).view(torch.int32), want_m.view(torch.int32)), "merl: worklist overflow changed the result"
+            assert torch.equal(g.evalp(i, o, p).view(torch.int32), want_g.view(torch.int32)), "contract mode: worklist overflow changed the result"
+        finally:
+            djb.set_test_worklist_cap(gpu_ctx, -1)
+        lib = djb._lib.load()
+        for obj, want, par in ((m, want_m, None), (u, want_u, None), (g, None, p)):
+            ii = i.clone()
+            vi, vo = djb._Vec(ii), djb._Vec(o)
+            djb._lib.check(lib.djb_evalp_batch(gpu_ctx._h, obj._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                               C.byref(par._p) if par is not None else None, C.byref(vi.view), C.c_int(0)))
+            gpu_ctx.synchronize()
+            if want is None:          # contract mode must have stepped aside: the in-place call is the bit-exact kernel's
+                djb.set_contract_1e5(gpu_ctx, False)
+                want = g.evalp(i, o, p)
+                djb.set_contract_1e5(gpu_ctx, True)
+            assert torch.equal(ii.view(torch.int32), want.view(torch.int32)), f"in-place evalp differs ({obj.__class__.__name__})"
+    finally:
+        djb.set_contract_1e5(gpu_ctx, False)

@@ -45,7 +45,7 @@ struct djb_ctx {
 	double wl_frac = 1.0 / 48;
 	hipEvent_t wl_ev = nullptr;
 	unsigned int *wl_host = nullptr;      // pinned: the count of the last large call
-	size_t wl_last_cap = 0; long long wl_last_n = 0; bool wl_pending = false;
+	size_t wl_last_cap = 0; long long wl_last_n = 0; bool wl_pending = false; int wl_words = 1;
 	long long test_worklist_cap = -1;   // DJB_OPT_TEST_WORKLIST_CAP (tests): >= 0 overrides the tier-2 worklist capacity
 	int contract_1e5 = 0;      // DJB_OPT_CONTRACT_1E5: dense GGX eval batches run the two-tier value-contract kernels
 	int scalar_on_device = 0;  // DJB_OPT_SCALAR_ON_DEVICE: scalar-size host calls go through the GPU too (A/B testing)

@@ -206,20 +206,25 @@ void wl_adapt(djb_ctx *ctx)
 {
 	if (!ctx->wl_pending || hipEventQuery(ctx->wl_ev) != hipSuccess) return;
 	ctx->wl_pending = false;
-	const unsigned int count = *ctx->wl_host;
+	// sharded lists (contract mode): the fullest shard decides; scaled to the whole list
+	unsigned long long count = 0;
+	for (int k = 0; k < ctx->wl_words; ++k) count = std::max(count, (unsigned long long)ctx->wl_host[k]);
+	count *= (unsigned long long)ctx->wl_words;
 	if ((size_t)count > ctx->wl_last_cap && ctx->wl_last_n > 0) {
 		const double need = 1.25 * (double)count / (double)ctx->wl_last_n;
 		ctx->wl_frac = std::min(0.25, std::max(need, 2.0 * ctx->wl_frac));
 	}
 }
-void wl_note(djb_ctx *ctx, const unsigned int *count, size_t cap, long long n)
+void wl_note(djb_ctx *ctx, const unsigned int *count, size_t cap, long long n, int words = 1, int stride = 1)
 {
 	if (n < (1LL << 20) || ctx->wl_pending) return;
 	if (!ctx->wl_ev && hipEventCreateWithFlags(&ctx->wl_ev, hipEventDisableTiming) != hipSuccess) { ctx->wl_ev = nullptr; return; }
-	if (!ctx->wl_host && hipHostMalloc((void **)&ctx->wl_host, 16) != hipSuccess) { ctx->wl_host = nullptr; return; }
-	if (hipMemcpyAsync(ctx->wl_host, count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return;
+	if (!ctx->wl_host && hipHostMalloc((void **)&ctx->wl_host, sizeof(unsigned int) * djbk::CONTRACT_SHARDS) != hipSuccess) { ctx->wl_host = nullptr; return; }
+	// `words` counters, `stride` words apart -> packed into the pinned block (one strided 2-D copy)
+	if (hipMemcpy2DAsync(ctx->wl_host, sizeof(unsigned int), count, sizeof(unsigned int) * stride, sizeof(unsigned int), (size_t)words,
+	                     hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return;
 	if (hipEventRecord(ctx->wl_ev, ctx->stream) != hipSuccess) return;
-	ctx->wl_last_cap = cap; ctx->wl_last_n = n; ctx->wl_pending = true;
+	ctx->wl_last_cap = cap; ctx->wl_last_n = n; ctx->wl_words = words; ctx->wl_pending = true;
 }
 
 djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
@@ -319,20 +324,23 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 		}
 		return sg.finish();
 	}
-	if (ctx->contract_1e5 && !aliased && b->dev.kind == DJB_KIND_GGX && djbk::contract_supported(b->dev, p)) {
+	if (ctx->contract_1e5 && !aliased && (b->dev.kind == DJB_KIND_GGX || b->dev.kind == DJB_KIND_BECKMANN) && djbk::contract_supported(b->dev, p)) {
 		auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
 		const bool dense16 = vi.stride == 1 && vo.stride == 1 && al16(vi.x) && al16(vi.y) && al16(vi.z) && al16(vo.x) && al16(vo.y) && al16(vo.z) &&
 		                     (!(want & 3) || (vout.stride == 1 && al16(vout.x) && al16(vout.y) && al16(vout.z))) && (!(want & 4) || al16(dpdf));
 		if (dense16) {
-			// as for MERL: pair indices travel as uint32; worklist = 16-byte header + 32-byte records {k, i, o}
+			// as for MERL: pair indices travel as uint32; worklist = 512-byte header (CONTRACT_SHARDS counters) + 32-byte records {k, i, o}
 			const long long CH = 1LL << 31;
 			for (long long lo = 0; lo < n; lo += CH) {
 				long long m = n - lo < CH ? n - lo : CH;
 				const size_t REC = 32;
 				wl_adapt(ctx);
 				size_t cap = (size_t)((double)m * ctx->wl_frac) + 4096;
-				if (ctx->test_worklist_cap >= 0) cap = (size_t)ctx->test_worklist_cap + 1;
-				size_t need = 16 + REC * cap;
+				cap = (cap + djbk::CONTRACT_SHARDS - 1) / djbk::CONTRACT_SHARDS * djbk::CONTRACT_SHARDS;     // whole segments
+				if (ctx->test_worklist_cap >= 0) cap = ((size_t)ctx->test_worklist_cap / djbk::CONTRACT_SHARDS + 1) * djbk::CONTRACT_SHARDS;
+				if (cap > 0xfffffff0ull) cap = 0xfffffff0ull / djbk::CONTRACT_SHARDS * djbk::CONTRACT_SHARDS;
+				const size_t HDR = sizeof(unsigned int) * djbk::CONTRACT_SHARDS * djbk::CONTRACT_COUNTER_STRIDE;     // 8 KB of counters
+				size_t need = HDR + REC * cap;
 				if (ctx->scratch_bytes < need) {
 					HIP_TRY(hipStreamSynchronize(ctx->stream));
 					if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -340,12 +348,11 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 					HIP_TRY(hipMalloc(&ctx->scratch, need));
 					ctx->scratch_bytes = need;
 				}
-				if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
-				unsigned int *count = (unsigned int *)ctx->scratch, *list = count + 4;
+				unsigned int *count = (unsigned int *)ctx->scratch, *list = count + HDR / sizeof(unsigned int);
 				auto off = [&](const View &v) { return View{ v.x ? v.x + lo : nullptr, v.y ? v.y + lo : nullptr, v.z ? v.z + lo : nullptr, v.stride }; };
 				HIP_TRY(djbk::launch_eval_contract(ctx->stream, b->dev, p, m, off(vi), off(vo), off(vout), dpdf ? dpdf + lo : nullptr, want,
 				                                   list, (unsigned int)cap, count));
-				wl_note(ctx, count, cap, m);
+				wl_note(ctx, count, cap, m, (int)djbk::CONTRACT_SHARDS, (int)djbk::CONTRACT_COUNTER_STRIDE);
 			}
 			return sg.finish();
 		}
@@ -811,7 +818,7 @@ try {
 	if (!max_rel2 || !counters4) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	Params p;
 	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
-	if (b->dev.kind != DJB_KIND_GGX || !djbk::contract_supported(b->dev, p))
+	if ((b->dev.kind != DJB_KIND_GGX && b->dev.kind != DJB_KIND_BECKMANN) || !djbk::contract_supported(b->dev, p))
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf / params outside the domain of the contract-mode fast path");
 	unsigned char *d = nullptr;
 	HIP_TRY(hipMalloc((void **)&d, 64));

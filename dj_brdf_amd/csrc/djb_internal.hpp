@@ -64,7 +64,10 @@ hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsign
 hipError_t launch_utia_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o, const View &out,
                                float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count);
 // DJB_OPT_CONTRACT_1E5 (djb_kernels_contract.hip): GGX eval / evalp / pdf inside the 1e-5 value contract, two-tier like
-// the MERL lookup (list: cap records of 32 bytes, count: 1 uint32).  Views must be dense (stride 1) and 16-byte aligned.
+// the MERL lookup, with a sharded worklist (list: cap records of 32 bytes in total, count: CONTRACT_SHARDS uint32, CONTRACT_COUNTER_STRIDE words apart: the record
+// list is cut into that many equal segments).  Views must be dense (stride 1) and 16-byte aligned.
+constexpr unsigned int CONTRACT_SHARDS = 64;
+constexpr unsigned int CONTRACT_COUNTER_STRIDE = 32;   // words between two counters (one 128-byte line each)
 constexpr float CT_RHO_MAX = 0.9f;
 bool contract_supported(const Brdf &b, const Params &p);
 hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i, const View &o,

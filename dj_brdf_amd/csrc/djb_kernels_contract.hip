@@ -52,11 +52,25 @@ struct CtParams {
 	float ax, ay, rho, s, rho_ay;      // microfacet::params (tx = ty = 0, mean normal = +z)
 	float r_ax, r_t2;                  // float(1 / ax), float(1 / (ax ay s))
 	float k_d;                         // float(r_t2 / pi): the constant factor of D
+	float t2;                          // ax * ay * s as the reference rounds it (the divisor of mf_p22)
+	double R_ax, R_t2;                 // 1 / ax and 1 / t2 to within 2^-52: fdiv_r's exact divisions (Beckmann)
 	float f0[3], f1[3];                // schlick: f0 and 1 - f0
 	int shadow;
 };
 
-// stretched-space norm and sigma of direction k (microfacet::sigma, dj_brdf.h:1619-1631, ggx::sigma_std_radial :2062)
+// exp(y) for y <= 0 with the argument split y log2(e) = hi + lo, so that the result keeps ~2 ulp for |y| up to 80 (a plain
+// exp2(y * log2e) loses |y| * 2^-24)
+DJB_DEV float ct_exp_neg(float y)
+{
+	const float L = 1.44269502f, L_LO = 1.92596299e-8f;         // log2(e) = L + L_LO
+	const float hi = y * L;
+	const float lo = __builtin_fmaf(y, L, -hi) + y * L_LO;
+	const float e = __builtin_amdgcn_exp2f(hi);
+	return __builtin_fmaf(e, lo * 0.693147182f, e);
+}
+
+// stretched-space norm and sigma of direction k (microfacet::sigma, dj_brdf.h:1619-1631; ggx::sigma_std_radial :2062,
+// beckmann::sigma_std_radial :1871-1880 with the reference's A&S 7.1.26 erf, :667-688).  k.z > 0.
 template <int KIND>
 DJB_DEV float ct_sigma(const CtParams &c, v3 k, bool &ok)
 {
@@ -65,14 +79,75 @@ DJB_DEV float ct_sigma(const CtParams &c, v3 k, bool &ok)
 	float n2 = a * a + bb * bb + k.z * k.z;                 // bit-identical to the reference's (tx = ty = 0)
 	ok &= (in_range(n2));
 	float rn = rsq_(n2), nrm = n2 * rn, kz = rn * k.z;
-	return nrm * ((1.0f + kz) * 0.5f);
+	if (KIND == KIND_GGX) return nrm * ((1.0f + kz) * 0.5f);
+	// Beckmann: (c (1 + erf(nu)) + s exp(-nu^2) / sqrt(pi)) / 2,  s = sqrt(1 - c^2), nu = c / s
+	const float s2 = 1.0f - kz * kz;
+	const float rs = rsq_(fmaxf(s2, 1e-30f));
+	const float sn = s2 * rs, nu = kz * rs;
+	const float e = ct_exp_neg(-fminf(nu * nu, 100.0f));
+	const float t = rcp_(1.0f + 0.3275911f * nu);
+	const float poly = ((((1.061405429f * t - 1.453152027f) * t) + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f;
+	const float erf_nu = 1.0f - poly * t * e;
+	const float std_ = 0.5f * (kz * (1.0f + erf_nu) + sn * (e * 0.564189584f));
+	return nrm * (s2 > 1e-7f ? std_ : kz);                  // c -> 1: erf -> 1, the second term -> 0 (the reference returns 1 at c == 1)
+}
+
+// Beckmann.  exp(-r^2) makes D as sensitive as r^2 is large: an ulp of the half vector's slope moves D by r^2 2^-23, and
+// the reference's own float chain carries several -- so the slope of h is computed with the REFERENCE's operations
+// (h = normalize(i + o) through the guarded inverse square root, two IEEE divisions, the exact divisions by the
+// launch-uniform denominators: r^2 is the reference's, bit for bit), which also makes h.z > 1e-4, dot(o, h) and dot(i, h)
+// the reference's own values: no guard bands are needed for them.  Everything else -- both sigmas with their exp / erf,
+// the NDF's exp, shadowing-masking, the final quotients -- runs on the reciprocal / rsq / exp2 instructions.
+template <int WANT, int FRK>
+DJB_DEV bool ct_eval_beckmann(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
+{
+	const bool live = (o.z > 0.0f) & (!c.shadow | (i.z > 0.0f));
+	bool ok = (o.z > CT_LO) & (i.z > CT_LO);
+	const v3 h = normalize(add(i, o));                        // exact (dj_brdf.h:1536, 630-637)
+	const bool facing = h.z > 1e-4f;                          // microfacet::ndf's cut (dj_brdf.h:1561): the reference's decision
+	const float xs = -h.x / h.z, ys = -h.y / h.z;             // dj_brdf.h:1564
+	const float x_ = fdiv_r(xs, c.ax, c.R_ax);                 // microfacet::p22, dj_brdf.h:1574-1587
+	const float y_ = fdiv_r(c.ax * ys - c.rho_ay * xs, c.t2, c.R_t2);
+	const float r2 = x_ * x_ + y_ * y_;
+	ok &= (r2 < 60.0f) | !facing;                              // beyond: D heads for the denormals -> tier 2
+	const float c2 = h.z * h.z, c4 = c2 * c2;
+	const float en = ct_exp_neg(-fminf(r2, 100.0f));          // D = exp(-r^2) / (pi t2 c4)
+	const float sig_o = ct_sigma<KIND_BECKMANN>(c, o, ok);
+	float den4;
+	if (c.shadow) {
+		const float sig_i = ct_sigma<KIND_BECKMANN>(c, i, ok);
+		den4 = 4.0f * ((i.z * sig_o + o.z * sig_i) - i.z * o.z);
+	} else den4 = 4.0f * (sig_o * i.z);
+	const float oh = dot(o, h);
+	const bool on = live & facing;
+	fr = mk(0, 0, 0); pdf = 0.0f;
+	if (WANT & 3) {
+		float e = (c.k_d * en) * rcp_(c4 * den4);
+		if (WANT & 2) e *= i.z;
+		ok &= ((e < 1e30f) & (e > 1e-24f)) | !on;             // the exponential tail towards the denormals: tier 2 (the relative
+		                                                       // contract has no meaning there; zeros must match exactly)
+		e = on ? e : 0.0f;
+		if (FRK == FR_SCHLICK) {
+			float cd = sat_(oh), c1 = 1.0f - cd, c2_ = c1 * c1, c5 = c2_ * c2_ * c1;
+			fr = mk(e * (c.f0[0] + c5 * c.f1[0]), e * (c.f0[1] + c5 * c.f1[1]), e * (c.f0[2] + c5 * c.f1[2]));
+		} else fr = mk(e, e, e);
+	}
+	if (WANT & 4) {
+		const float ih = dot(i, h);
+		float q = (oh * (c.k_d * en)) * rcp_(c4 * (4.0f * ih * sig_o));
+		const bool pos = oh > 0.0f;                            // vndf is 0 unless dot(o, h) > 0 (dj_brdf.h:1605): the reference's decision
+		ok &= ((q < 1e30f) & (q > 1e-24f) & (ih > CT_LO)) | !(on & pos);
+		pdf = (on & pos) ? q : 0.0f;
+	}
+	return ok | !live;
 }
 
 // one pair; false = tier 2.  fr / pdf follow eval_one's WANT convention (1 eval, 2 evalp, 4 pdf)
 template <int KIND, int WANT, int FRK>
 DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 {
-	static_assert(KIND == KIND_GGX, "contract mode: GGX");
+	static_assert(KIND == KIND_GGX || KIND == KIND_BECKMANN, "contract mode: GGX and Beckmann");
+	if (KIND == KIND_BECKMANN) return ct_eval_beckmann<WANT, FRK>(c, i, o, fr, pdf);
 	// g1(k) > 0 <=> dot(k, m_n) = k.z > 0 (dj_brdf.h:1633-1642); gaf > 0 <=> both (shadow) / g1(o) (dj_brdf.h:1644-1665)
 	// -- decided on the inputs themselves, NaN included: the reference's comparisons are false for NaN and return zeros.
 	// Branch-free: dead pairs run the arithmetic on whatever they hold and select the zeros at the end.
@@ -120,13 +195,24 @@ DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 	return ok | !live;
 }
 
+// The tier-2 worklist is SHARDED: CT_SHARDS counters and list segments, workgroup b appends to shard b mod CT_SHARDS.
+// With one workgroup per 1024 pairs (the grid that streams fastest, launch_ct) nearly every wave has something to append
+// when ~1 % of the pairs are tier-2 (Beckmann's exp(-r^2) tail), i.e. one returning atomic per wave: 3.5e5 of them per 1e8
+// pairs on ONE address ran at the ~88 per microsecond a single word sustains -- 4.0 ms for a kernel whose streams take
+// 0.7 ms (profiles/r03/contract_beckmann_worklist.txt).  64 words take the same traffic in 0.06 ms.
+constexpr unsigned int CT_SHARDS = djbk::CONTRACT_SHARDS;
+constexpr unsigned int CT_STRIDE = djbk::CONTRACT_COUNTER_STRIDE;    // in words: atomics on words of one cache line still serialise
+
 template <int KIND, int WANT, int FRK>
 __global__ __launch_bounds__(BLOCK) void k_ct_fast_v4(CtParams c, long long n4, View vi, View vo, View vout, float *out_pdf,
-                                                      uint4 *list, unsigned int cap, unsigned int *count)
+                                                      uint4 *list_all, unsigned int cap, unsigned int *counts)
 {
 	__shared__ WaveBuf wbuf[BLOCK / 64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	unsigned int wcount = 0;
+	const unsigned int shard = blockIdx.x % CT_SHARDS;
+	uint4 *list = list_all + 2 * (size_t)shard * cap;            // cap = records per shard
+	unsigned int *count = counts + (size_t)shard * CT_STRIDE;    // one counter per 128-byte line
 	const float4 *ix4 = (const float4 *)vi.x, *iy4 = (const float4 *)vi.y, *iz4 = (const float4 *)vi.z;
 	const float4 *ox4 = (const float4 *)vo.x, *oy4 = (const float4 *)vo.y, *oz4 = (const float4 *)vo.z;
 	const long long stride = (long long)gridDim.x * BLOCK;
@@ -168,16 +254,23 @@ __global__ __launch_bounds__(BLOCK) void k_ct_fast_v4(CtParams c, long long n4, 
 	if (wcount) wl_flush(wbuf[wave], wcount, lane, list, cap, count);
 }
 
-// tier 2: the bit-exact per-pair code on the listed pairs (or on the whole batch when the list overflowed)
+// tier 2: the bit-exact per-pair code on the listed pairs (or on the whole batch when a shard of the list overflowed)
 template <int KIND, int WANT, int FRK>
 __global__ __launch_bounds__(BLOCK) void k_ct_fixup(Brdf b, Params p, long long n, View vi, View vo, View vout, float *out_pdf,
-                                                    const uint4 *list, unsigned int cap, const unsigned int *count)
+                                                    const uint4 *list, unsigned int cap, const unsigned int *counts)
 {
-	const unsigned int m = *count;
-	if (m <= cap) {
-		const unsigned int stride = gridDim.x * BLOCK;
-		for (unsigned int j = blockIdx.x * BLOCK + threadIdx.x; j < m; j += stride) {
-			uint4 ra = list[2 * (size_t)j], rb = list[2 * (size_t)j + 1];
+	__shared__ unsigned int s_counts[CT_SHARDS];
+	__shared__ int s_over;
+	if (threadIdx.x == 0) s_over = 0;
+	__syncthreads();
+	if (threadIdx.x < CT_SHARDS) { const unsigned int cnt = counts[(size_t)threadIdx.x * CT_STRIDE]; s_counts[threadIdx.x] = cnt; if (cnt > cap) s_over = 1; }
+	__syncthreads();
+	if (!s_over) {
+		const unsigned long long slots = (unsigned long long)CT_SHARDS * cap, stride = (unsigned long long)gridDim.x * BLOCK;
+		for (unsigned long long j = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; j < slots; j += stride) {
+			const unsigned int sh = (unsigned int)(j / cap), idx = (unsigned int)(j - (unsigned long long)sh * cap);
+			if (idx >= s_counts[sh]) continue;
+			uint4 ra = list[2 * j], rb = list[2 * j + 1];
 			const long long k = (long long)ra.x;
 			v3 i = mk(__uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
 			v3 o = mk(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z));
@@ -251,6 +344,8 @@ bool ct_params(const Brdf &b, const Params &p, CtParams *c)
 	c->r_ax = (float)(1.0 / (double)p.ax);
 	c->r_t2 = (float)(1.0 / (double)(p.ax * p.ay * p.s));
 	c->k_d = (float)((1.0 / (double)(p.ax * p.ay * p.s)) / DJB_PI);
+	c->t2 = p.ax * p.ay * p.s;
+	c->R_ax = p.r_ax; c->R_t2 = p.r_t2;
 	c->shadow = b.shadow;
 	for (int k = 0; k < 3; ++k) { c->f0[k] = 1.0f; c->f1[k] = 0.0f; }
 	if (b.fr.kind == FR_SCHLICK) {
@@ -265,15 +360,17 @@ bool ct_params(const Brdf &b, const Params &p, CtParams *c)
 
 template <int KIND, int FRK>
 hipError_t launch_ct(hipStream_t s, const Brdf &b, const Params &p, const CtParams &c, long long n, const View &i, const View &o,
-                     const View &out, float *out_pdf, int want, uint4 *list, unsigned int cap, unsigned int *count)
+                     const View &out, float *out_pdf, int want, uint4 *list, unsigned int cap /* records in total */, unsigned int *count /* CT_SHARDS words */)
 {
-	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int), s);
+	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int) * CT_SHARDS * CT_STRIDE, s);
 	if (e != hipSuccess) return e;
+	cap /= CT_SHARDS;                                          // records per shard
+	if (cap == 0) cap = 1;
 	const long long n4 = n / 4;
 	// one workgroup per 1024 pairs, no grid-stride cap: measured (profiles/r03/contract_grid.txt, 1e8 pairs) 0.696 ms with
 	// the full grid against 0.77-0.82 ms with 2048 ... 32768 persistent workgroups -- the hardware dispatcher keeps more
 	// loads in flight across workgroup boundaries than a wave's in-order loop does
-	const dim3 g(grid_for(n4, 0x7fffffffLL)), t(BLOCK), gf(grid_for(n / 64 + 1, 2048));
+	const dim3 g(grid_for(n4, 0x7fffffffLL)), t(BLOCK), gf(grid_for((long long)CT_SHARDS * cap, 2048));
 #define DJB_CT(W_) do { \
 		if (n4 > 0) hipLaunchKernelGGL((k_ct_fast_v4<KIND, W_, FRK>), g, t, 0, s, c, n4, i, o, out, out_pdf, list, cap, count); \
 		hipLaunchKernelGGL((k_ct_fixup<KIND, W_, FRK>), gf, t, 0, s, b, p, n, i, o, out, out_pdf, list, cap, count); } while (0)
@@ -296,14 +393,14 @@ namespace djbk {
 bool contract_supported(const Brdf &b, const Params &p)
 {
 	CtParams c;
-	return b.kind == KIND_GGX && ct_params(b, p, &c);
+	return (b.kind == KIND_GGX || b.kind == KIND_BECKMANN) && ct_params(b, p, &c);
 }
 
 hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i, const View &o,
                                 const View &out, float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count)
 {
 	CtParams c;
-	if (b.kind != KIND_GGX || !ct_params(b, p, &c)) return hipErrorInvalidValue;
+	if ((b.kind != KIND_GGX && b.kind != KIND_BECKMANN) || !ct_params(b, p, &c)) return hipErrorInvalidValue;
 	if (n <= 0) return hipSuccess;
 	// the < 4-pair tail of the batch: the exact kernel (launched first: the fix-up kernel's overflow rescan covers it too)
 	const long long n4 = n / 4;
@@ -311,6 +408,10 @@ hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, l
 		auto off = [&](const View &v) { return View{ v.x ? v.x + 4 * n4 : nullptr, v.y ? v.y + 4 * n4 : nullptr, v.z ? v.z + 4 * n4 : nullptr, v.stride }; };
 		hipError_t e = launch_eval(s, b, p, n - 4 * n4, off(i), off(o), off(out), out_pdf ? out_pdf + 4 * n4 : nullptr, want);
 		if (e != hipSuccess) return e;
+	}
+	if (b.kind == KIND_BECKMANN) {
+		if (b.fr.kind == FR_SCHLICK) return launch_ct<KIND_BECKMANN, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+		return launch_ct<KIND_BECKMANN, FR_IDEAL>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 	}
 	if (b.fr.kind == FR_SCHLICK) return launch_ct<KIND_GGX, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 	return launch_ct<KIND_GGX, FR_IDEAL>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
@@ -320,9 +421,12 @@ hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &
                                     unsigned long long start, int family, unsigned int *max_bits, unsigned long long *counters)
 {
 	CtParams c;
-	if (b.kind != KIND_GGX || !ct_params(b, p, &c)) return hipErrorInvalidValue;
+	if ((b.kind != KIND_GGX && b.kind != KIND_BECKMANN) || !ct_params(b, p, &c)) return hipErrorInvalidValue;
 	const dim3 g(grid_for(n, 256LL * 16)), t(BLOCK);
-	if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+	if (b.kind == KIND_BECKMANN) {
+		if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+		else hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_IDEAL>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+	} else if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 	else hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_IDEAL>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 	return hipGetLastError();
 }

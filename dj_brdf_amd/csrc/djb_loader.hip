@@ -126,7 +126,10 @@ void reap_mappings(std::vector<std::vector<std::pair<void *, size_t>>> &&kept)
 	g_reaper.live.fetch_add(1);
 	try {
 		std::thread([maps]() {
-			for (auto &v : *maps) for (auto &m : v) munmap(m.first, m.second);
+			// paced: every munmap holds the process's mmap_lock for writing for ~80 us (8.5 k page-table entries to tear down);
+			// back to back they starve the page faults of every other thread -- the caller's next 15 ms, measured -- so the
+			// reaper yields between two mappings
+			for (auto &v : *maps) for (auto &m : v) { munmap(m.first, m.second); std::this_thread::sleep_for(std::chrono::microseconds(200)); }
 			g_reaper.live.fetch_sub(1);
 		}).detach();
 	} catch (...) {                     // no thread to be had: unmap here

@@ -16,6 +16,7 @@ for dense, sweep in legs:
   for threads in sweep:
     best = None
     for rep in range(3):
+        time.sleep(0.08)      # let the previous call's reaper thread finish releasing its mappings
         t0 = time.perf_counter()
         ab, ag, tim = merl_params.fit_files_on(ctx, paths, reader_threads=threads)
         wall = time.perf_counter() - t0

@@ -226,6 +226,68 @@ static void run_sg(unsigned int entries, float **d, Texel *tab, long long n, int
 	       entries * 12.0 / 1048576.0, ms, n / ms / 1e6);
 }
 
+// ---- round 3, the last untested lever of DESIGN.md 4.2: serve the hottest table lines from LDS.  HOTPCT % of the look-ups
+// go to the first HOT_N texels of the table (128 KB: what one workgroup can hold next to nothing else), the rest
+// uniformly to the remainder; LDS = true answers the hot ones from a per-workgroup LDS copy, false from the table (where
+// they hit L2).  1024-thread workgroups, one per CU (the LDS copy allows no more), grid-stride.  The bench distribution
+// puts 11 % of its look-ups into its hottest 160 KB of lines (CPU histogram); 30 % is an optimistic case.
+constexpr unsigned int HOT_N = 10922;      // 128 KB of 12-byte texels
+template <bool LDS, int HOTPCT>
+__global__ __launch_bounds__(1024) void k_sg_hot(const Texel *tab, unsigned int entries, const v4f *a0, const v4f *a1,
+                                               const v4f *a2, const v4f *b0, const v4f *b1, const v4f *b2,
+                                               v4f *c0, v4f *c1, v4f *c2, long long n4)
+{
+	extern __shared__ float hot_lds[];
+	Texel *hot = (Texel *)hot_lds;
+	if (LDS) {
+		for (unsigned int t = threadIdx.x; t < HOT_N; t += 1024) hot[t] = tab[t];
+		__syncthreads();
+	}
+	const long long stride = (long long)gridDim.x * 1024;
+	for (long long q = (long long)blockIdx.x * 1024 + threadIdx.x; q < n4; q += stride) {
+		v4f x = ld<true>(a0 + q), y = ld<true>(a1 + q), z = ld<true>(a2 + q);
+		v4f u = ld<true>(b0 + q), v = ld<true>(b1 + q), w = ld<true>(b2 + q);
+		unsigned int h = pcg((unsigned int)q * 4u + (unsigned int)(x.x + u.x));
+		v4f yy = y + v, zz = z + w;
+		Texel t[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			h = pcg(h + j);
+			const unsigned int h2 = pcg(h ^ 0x9e3779b9u);
+			const bool is_hot = (h >> 7) % 100u < (unsigned int)HOTPCT;
+			const unsigned int ih = (unsigned int)(((unsigned long long)h2 * HOT_N) >> 32);
+			const unsigned int ic = HOT_N + (unsigned int)(((unsigned long long)h2 * (entries - HOT_N)) >> 32);
+			if (LDS) { if (is_hot) t[j] = hot[ih]; else t[j] = tab[ic]; }
+			else t[j] = tab[is_hot ? ih : ic];
+		}
+		v4f r = { t[0].x, t[1].x, t[2].x, t[3].x }, g = { t[0].y, t[1].y, t[2].y, t[3].y }, b = { t[0].z, t[1].z, t[2].z, t[3].z };
+		r += yy; g += zz;
+		st<true>(r, c0 + q); st<true>(g, c1 + q); st<true>(b, c2 + q);
+	}
+}
+template <bool LDS, int HOTPCT>
+static void run_sg_hot(unsigned int entries, float **d, Texel *tab, long long n, int blocks)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	const size_t lds = LDS ? sizeof(Texel) * HOT_N : 0;
+	if (LDS) (void)hipFuncSetAttribute((const void *)k_sg_hot<LDS, HOTPCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_sg_hot<LDS, HOTPCT>), dim3(blocks), dim3(1024), lds, 0, tab, entries, (const v4f *)d[0],
+		                   (const v4f *)d[1], (const v4f *)d[2], (const v4f *)d[3], (const v4f *)d[4],
+		                   (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n / 4);
+	};
+	launch(); launch();
+	if (hipDeviceSynchronize() != hipSuccess) { printf("hot: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return; }
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 3; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+	printf("streams+gather, %2d %% of the look-ups in the hottest 128 KB, served from %s, %4d workgroups x 1024: %7.3f ms  %7.1f G pairs/s\n",
+	       HOTPCT, LDS ? "LDS  " : "table", blocks, ms, n / ms / 1e6);
+}
+
 // ---- MODE 4 of the streams + gather experiment: the table look-ups go through the SCALAR memory
 // path (v_readlane -> s_load_dwordx4 -> v_writelane), leaving the vector memory pipeline to the streams
 template <int LANES_PER_BATCH>
@@ -539,6 +601,15 @@ int main(int argc, char **argv)
 				run_sg<3, 1>(e, d, tab, n, 16384); run_sg<0, 1>(e, d, tab, n, 2048); run_sg<0, 1>(e, d, tab, n, 1024);
 				run_sg<0, 1>(e, d, tab, n, 512); run_sg<2, 1>(e, d, tab, n, 2048); run_sg<2, 1>(e, d, tab, n, 1024);
 				run_sg<3, 1>(e, d, tab, n, 65536);
+			}
+			return 0;
+		}
+		if (argv[2][0] == 'h') {
+			const unsigned int e = 1458000u;
+			run_sg<0, 1>(e, d, tab, n, 16384);                      // the shipped shape, uniform look-ups, for scale
+			for (int blocks : { 256, 512 }) {
+				run_sg_hot<false, 11>(e, d, tab, n, blocks); run_sg_hot<true, 11>(e, d, tab, n, blocks);
+				run_sg_hot<false, 30>(e, d, tab, n, blocks); run_sg_hot<true, 30>(e, d, tab, n, blocks);
 			}
 			return 0;
 		}

@@ -14,7 +14,9 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles", RND)
 os.makedirs(DST, exist_ok=True)
-DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf": ("k_eval<1, 5,",),
+DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "merl_eval_uniform_bins": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"),
+            "merl_eval_coherent": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf_contract": ("k_ct_fast_v4<1, 5", "k_ct_fixup<1, 5"),
+            "ggx_eval_pdf": ("k_eval<1, 5,",),
             "beckmann_sample": ("k_sample<0",), "merl_fit": ("k_fit<3>",), "utia_eval": ("k_eval_utia_t1", "k_eval_utia_fix", "k_eval<4, 1,")}
 
 
@@ -37,7 +39,7 @@ for w in sorted(os.listdir(SRC)):
         if os.path.exists(os.path.join(d, name)):
             shutil.copy(os.path.join(d, name), os.path.join(DST, f"{w}_{name}"))
     rows, per_kernel = [], collections.defaultdict(dict)
-    for p in ("fetch", "write", "sq"):
+    for p in ("fetch", "write", "sq", "l2"):
         acc, meta = counters(os.path.join(d, p))
         for (k, c), v in sorted(acc.items()):
             rows.append([p, k, c, len(v), sum(v) / len(v)] + list(meta[k]))
@@ -60,6 +62,10 @@ for w in sorted(os.listdir(SRC)):
             "note": "FETCH_SIZE x2 (gfx950 streaming-read correction) + WRITE_SIZE; includes the table "
                     "gathers served by the Infinity Cache, also doubled: an upper bound on HBM traffic",
         }
+        hit = sum(v.get("TCC_HIT_sum", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
+        miss = sum(v.get("TCC_MISS_sum", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
+        if hit + miss > 0:
+            out["l2_hit_rate"] = hit / (hit + miss)          # TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), MI355X_MICROARCH.md section L2
         json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{w}.json"), "w"), indent=1)
         print(w, out["hbm_bytes_per_launch"] / 1e9, "GB per launch (corrected)")
 print(sorted(os.listdir(DST)))

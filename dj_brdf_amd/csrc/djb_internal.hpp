@@ -38,7 +38,9 @@ hipError_t launch_io_to_hd(hipStream_t s, long long n, const View &i, const View
                            const View &h, const View &d, bool inverse);
 hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const View &o, int32_t *idx);
 
-// two-tier exact MERL lookup (djb_kernels_merl.hip); list: worklist of `cap` uint32 slots, count: 1 uint32
+// two-tier exact MERL lookup (djb_kernels_merl.hip); list: `cap` 32-byte records in total, cut into WL_SHARDS equal segments;
+// count: WL_SHARDS counters, WL_COUNTER_STRIDE words apart (a returning atomic per flushing wave: one word sustains ~88 per
+// microsecond, words of one cache line serialise as well -- profiles/r03/contract_beckmann_worklist.txt)
 hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
                                const View &out, float *out_pdf, int want, unsigned int *list,
                                unsigned int cap, unsigned int *count);
@@ -66,8 +68,9 @@ hipError_t launch_utia_twotier(hipStream_t s, const Brdf &b, long long n, const 
 // DJB_OPT_CONTRACT_1E5 (djb_kernels_contract.hip): GGX eval / evalp / pdf inside the 1e-5 value contract, two-tier like
 // the MERL lookup, with a sharded worklist (list: cap records of 32 bytes in total, count: CONTRACT_SHARDS uint32, CONTRACT_COUNTER_STRIDE words apart: the record
 // list is cut into that many equal segments).  Views must be dense (stride 1) and 16-byte aligned.
-constexpr unsigned int CONTRACT_SHARDS = 64;
-constexpr unsigned int CONTRACT_COUNTER_STRIDE = 32;   // words between two counters (one 128-byte line each)
+constexpr unsigned int WL_SHARDS = 64;
+constexpr unsigned int WL_COUNTER_STRIDE = 32;         // words between two counters (one 128-byte line each)
+constexpr unsigned int CONTRACT_SHARDS = WL_SHARDS, CONTRACT_COUNTER_STRIDE = WL_COUNTER_STRIDE;
 constexpr float CT_RHO_MAX = 0.9f;
 bool contract_supported(const Brdf &b, const Params &p);
 hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i, const View &o,

@@ -45,11 +45,15 @@ DJB_DEV void merl_emit(const Brdf &b, int idx, v3 i, long long k, const View &vo
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_merl_fast(Brdf b, long long k_begin, long long n, View vi, View vo,
                                                      View vout, float *out_pdf, MerlGuard g,
-                                                     uint4 *list, unsigned int cap, unsigned int *count)
+                                                     uint4 *list_all, unsigned int cap, unsigned int *counts)
 {
 	__shared__ WaveBuf wbuf[BLOCK / 64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	unsigned int wcount = 0;                                     // wave-uniform
+	// sharded worklist (djb_internal.hpp WL_SHARDS: one counter per 128-byte line, one list segment per counter)
+	const unsigned int shard = blockIdx.x % djbk::WL_SHARDS;
+	uint4 *list = list_all + 2 * (size_t)shard * cap;
+	unsigned int *count = counts + (size_t)shard * djbk::WL_COUNTER_STRIDE;
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k0 = k_begin + (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {   // block-uniform trip count
 		long long k = k0 + threadIdx.x;
@@ -73,12 +77,15 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast(Brdf b, long long k_begin, 
 // kernel on the same stream and overwrites them.
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, View vi, View vo, View vout,
-                                                        float *out_pdf, MerlGuard g, uint4 *list,
-                                                        unsigned int cap, unsigned int *count)
+                                                        float *out_pdf, MerlGuard g, uint4 *list_all,
+                                                        unsigned int cap, unsigned int *counts)
 {
 	__shared__ WaveBuf wbuf[BLOCK / 64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	unsigned int wcount = 0;
+	const unsigned int shard = blockIdx.x % djbk::WL_SHARDS;
+	uint4 *list = list_all + 2 * (size_t)shard * cap;
+	unsigned int *count = counts + (size_t)shard * djbk::WL_COUNTER_STRIDE;
 	const float4 *ix4 = (const float4 *)vi.x, *iy4 = (const float4 *)vi.y, *iz4 = (const float4 *)vi.z;
 	const float4 *ox4 = (const float4 *)vo.x, *oy4 = (const float4 *)vo.y, *oz4 = (const float4 *)vo.z;
 	long long stride = (long long)gridDim.x * BLOCK;
@@ -134,19 +141,30 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, Vi
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_merl_fixup(Brdf b, long long n, View vi, View vo, View vout,
                                                       float *out_pdf, MerlGuard g, const uint4 *list,
-                                                      unsigned int cap, const unsigned int *count)
+                                                      unsigned int cap, const unsigned int *counts)
 {
-	const unsigned int m = *count;
-	if (m <= cap) {                      // normal case: the worklist holds every ambiguous pair
-		unsigned int stride = gridDim.x * BLOCK;
-		for (unsigned int j = blockIdx.x * BLOCK + threadIdx.x; j < m; j += stride) {
-			uint4 ra = list[2 * (size_t)j], rb = list[2 * (size_t)j + 1];
+	__shared__ unsigned int s_counts[djbk::WL_SHARDS];
+	__shared__ int s_over;
+	if (threadIdx.x == 0) s_over = 0;
+	__syncthreads();
+	if (threadIdx.x < djbk::WL_SHARDS) {
+		const unsigned int c = counts[(size_t)threadIdx.x * djbk::WL_COUNTER_STRIDE];
+		s_counts[threadIdx.x] = c;
+		if (c > cap) s_over = 1;
+	}
+	__syncthreads();
+	if (!s_over) {                       // normal case: the worklist holds every ambiguous pair (cap = records per shard)
+		const unsigned long long slots = (unsigned long long)djbk::WL_SHARDS * cap, stride = (unsigned long long)gridDim.x * BLOCK;
+		for (unsigned long long j = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; j < slots; j += stride) {
+			const unsigned int sh = (unsigned int)(j / cap), idx = (unsigned int)(j - (unsigned long long)sh * cap);
+			if (idx >= s_counts[sh]) continue;
+			uint4 ra = list[2 * j], rb = list[2 * j + 1];
 			long long k = (long long)ra.x;
 			v3 i = mk(__uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
 			v3 o = mk(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z));
 			merl_emit<WANT>(b, merl_index(i, o), i, k, vout, out_pdf);
 		}
-	} else {                             // overflow (adversarial input): rescan, same decision function
+	} else {                             // a shard overflowed (adversarial input): rescan, same decision function
 		long long stride = (long long)gridDim.x * BLOCK;
 		for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 			v3 i = load3(vi, k), o = load3(vo, k);
@@ -252,9 +270,11 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
                      const View &out, float *out_pdf, const MerlGuard &g, unsigned int *list_words,
                      unsigned int cap, unsigned int *count)
 {
-	uint4 *list = (uint4 *)list_words;       // cap records of 2 x uint4 (djbk::merl_worklist_bytes)
-	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int), s);
+	uint4 *list = (uint4 *)list_words;       // cap records of 2 x uint4 in total, cut into WL_SHARDS segments
+	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int) * djbk::WL_SHARDS * djbk::WL_COUNTER_STRIDE, s);
 	if (e != hipSuccess) return e;
+	cap /= djbk::WL_SHARDS;                  // records per shard
+	if (cap == 0) cap = 1;
 	auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
 	bool dense = i.stride == 1 && o.stride == 1 && (!(WANT & 3) || out.stride == 1) &&
 	             al16(i.x) && al16(i.y) && al16(i.z) && al16(o.x) && al16(o.y) && al16(o.z) &&
@@ -270,7 +290,7 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
 	if (4 * n4 < n)   // strided / unaligned input, or the < 4-pair tail of a dense batch
 		hipLaunchKernelGGL((k_merl_fast<WANT>), dim3(grid_for(n - 4 * n4)), dim3(BLOCK), 0, s, b, 4 * n4, n, i, o,
 		                   out, out_pdf, g, list, cap, count);
-	long long guess = n / 64 + 1;   // fix-up grid sized for a ~1.5 % worklist; grid-stride beyond
+	long long guess = (long long)djbk::WL_SHARDS * cap;   // one thread per list slot; grid-stride beyond 2048 workgroups
 	hipLaunchKernelGGL((k_merl_fixup<WANT>), dim3(grid_for(guess, 2048)), dim3(BLOCK), 0, s, b, n, i, o, out,
 	                   out_pdf, g, list, cap, count);
 	return hipGetLastError();

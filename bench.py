@@ -474,6 +474,9 @@ def main():
                     roofline["traffic"] = pj.get("hbm_bytes_per_launch")
                     roofline["traffic_source"] = ("static: read from profiles/pmc_%s.json (separate rocprofv3 --pmc passes of "
                                                   "tools/profile_bench.sh, %s), NOT measured in this run" % (name, pj.get("round", "round 1")))
+                    if pj.get("hbm_bytes_upper_bound"):
+                        roofline["traffic_upper_bound"] = pj["hbm_bytes_upper_bound"]
+                        roofline["traffic_note"] = pj.get("note")
                 except Exception:
                     pass
         else:

@@ -62,6 +62,23 @@ for w in sorted(os.listdir(SRC)):
             "note": "FETCH_SIZE x2 (gfx950 streaming-read correction) + WRITE_SIZE; includes the table "
                     "gathers served by the Infinity Cache, also doubled: an upper bound on HBM traffic",
         }
+        # Round 3 calibration (profiles/r03/gather_miss_calibration.txt): the x2 belongs to the STREAMS only.  An L2 miss of a
+        # 12-byte table gather is one 64-byte fabric request (FETCH_SIZE / TCC_MISS = 64.0 B on gather-only kernels, no
+        # 32-byte requests), which FETCH_SIZE counts exactly.  For the MERL legs, whose stream bytes are known (24 B per
+        # pair, read once): bytes = 24 n + (FETCH_SIZE - 12 n) + WRITE_SIZE; the doubled figure stays as the upper bound.
+        if w.startswith("merl_eval") and os.path.exists(os.path.join(d, "bench_plain.json")):
+            try:
+                n_units = json.loads(open(os.path.join(d, "bench_plain.json")).read().strip().splitlines()[-1])["config"]["units_per_gpu_per_step"]
+                gather = max(fetch_kb * 1024 - 12.0 * n_units, 0.0)
+                out["hbm_bytes_upper_bound"] = out["hbm_bytes_per_launch"]
+                out["hbm_bytes_per_launch"] = 24.0 * n_units + gather + write_kb * 1024
+                out["gather_miss_bytes_per_launch"] = gather
+                out["units_per_launch"] = n_units
+                out["note"] = ("streams 24 B/pair (FETCH_SIZE counts them at half: x2) + table-gather misses at 64 B each (FETCH_SIZE exact for them: "
+                               "profiles/r03/gather_miss_calibration.txt) + WRITE_SIZE; hbm_bytes_upper_bound = everything doubled, as reported until round 2; "
+                               "misses served by the Infinity Cache are included either way")
+            except Exception as e:  # pragma: no cover
+                print("calibration skipped:", e)
         hit = sum(v.get("TCC_HIT_sum", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
         miss = sum(v.get("TCC_MISS_sum", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
         if hit + miss > 0:

@@ -131,6 +131,60 @@ __global__ __launch_bounds__(256) void k_gather(const Texel *tab, unsigned int e
 	if (!STREAMS && accr.x == 123.456f) c0[0] = accr;
 }
 
+// ---- round 3: table layout vs the 64-byte sector a miss fetches (profiles/r03/gather_miss_calibration.txt).  LAYOUT 0: packed
+// 12-byte texels (shipped: 17 % of them straddle a 64-byte boundary and can miss twice); 1: five texels per 64-byte sector
+// (60 B + 4 B pad, +6.7 % footprint, none straddles); 2: padded to 16 bytes (+33 %).  Look-ups skewed like the bench
+// distribution: SKEW % of them into the first eighth of the table.
+template <int LAYOUT, int SKEW>
+__global__ __launch_bounds__(256) void k_gather_layout(const float *tab, unsigned int entries, const v4f *a0, const v4f *a1,
+                                                       const v4f *a2, const v4f *b0, const v4f *b1, const v4f *b2,
+                                                       v4f *c0, v4f *c1, v4f *c2, long long n4)
+{
+	long long stride = (long long)gridDim.x * 256;
+	for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+		v4f x = ld<true>(a0 + q), y = ld<true>(a1 + q), z = ld<true>(a2 + q);
+		v4f u = ld<true>(b0 + q), v = ld<true>(b1 + q), w = ld<true>(b2 + q);
+		unsigned int h = pcg((unsigned int)q * 4u + (unsigned int)(x.x + u.x));
+		float tx[4], ty[4], tz[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			h = pcg(h + j);
+			const unsigned int h2 = pcg(h ^ 0x85ebca6bu);
+			const bool hot = (h >> 7) % 100u < (unsigned int)SKEW;
+			const unsigned int range = hot ? entries / 8u : entries;
+			const unsigned int idx = (unsigned int)(((unsigned long long)h2 * range) >> 32);
+			unsigned int dw;                                             // dword offset of the texel
+			if (LAYOUT == 0) dw = 3u * idx;
+			else if (LAYOUT == 1) { const unsigned int s5 = idx / 5u; dw = 16u * s5 + 3u * (idx - 5u * s5); }
+			else dw = 4u * idx;
+			const float *t = tab + dw;
+			tx[j] = t[0]; ty[j] = t[1]; tz[j] = t[2];
+		}
+		v4f r = { tx[0], tx[1], tx[2], tx[3] }, g = { ty[0], ty[1], ty[2], ty[3] }, b = { tz[0], tz[1], tz[2], tz[3] };
+		r += y + v; g += z + w;
+		st<true>(r, c0 + q); st<true>(g, c1 + q); st<true>(b, c2 + q);
+	}
+}
+template <int LAYOUT, int SKEW>
+static void run_gather_layout(unsigned int entries, float **d, Texel *tab, long long n)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	auto launch = [&]() {
+		hipLaunchKernelGGL((k_gather_layout<LAYOUT, SKEW>), dim3(16384), dim3(256), 0, 0, (const float *)tab, entries, (const v4f *)d[0],
+		                   (const v4f *)d[1], (const v4f *)d[2], (const v4f *)d[3], (const v4f *)d[4],
+		                   (const v4f *)d[5], (v4f *)d[6], (v4f *)d[7], (v4f *)d[8], n / 4);
+	};
+	launch(); launch();
+	(void)hipEventRecord(e0);
+	for (int k = 0; k < 5; ++k) launch();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+	static const char *names[3] = { "packed 12 B        ", "5 per 64-B sector  ", "padded 16 B        " };
+	printf("streams+gather layout %s skew %2d %% into 1/8 of %u entries: %7.3f ms  %7.1f G pairs/s\n", names[LAYOUT], SKEW, entries, ms, n / ms / 1e6);
+}
+
 template <bool STREAMS>
 static void run_gather(unsigned int entries, float **d, Texel *tab, long long n)
 {
@@ -602,6 +656,13 @@ int main(int argc, char **argv)
 				run_sg<0, 1>(e, d, tab, n, 512); run_sg<2, 1>(e, d, tab, n, 2048); run_sg<2, 1>(e, d, tab, n, 1024);
 				run_sg<3, 1>(e, d, tab, n, 65536);
 			}
+			return 0;
+		}
+		if (argv[2][0] == 'l') {
+			const unsigned int e = 1458000u;
+			run_gather_layout<0, 0>(e, d, tab, n); run_gather_layout<1, 0>(e, d, tab, n); run_gather_layout<2, 0>(e, d, tab, n);
+			run_gather_layout<0, 60>(e, d, tab, n); run_gather_layout<1, 60>(e, d, tab, n); run_gather_layout<2, 60>(e, d, tab, n);
+			run_gather_layout<0, 85>(e, d, tab, n); run_gather_layout<1, 85>(e, d, tab, n); run_gather_layout<2, 85>(e, d, tab, n);
 			return 0;
 		}
 		if (argv[2][0] == 'h') {

@@ -61,7 +61,7 @@ WORKLOADS = {
     # the headline kernel on two other look-up distributions (the 0.40 of merl_eval is distribution dependent):
     "merl_eval_uniform_bins": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval>, (theta_h, theta_d, phi_d) bins uniform over the table"),
     "merl_eval_coherent": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval>, renderer-like batch (neighbouring pixels of a bumpy plane)"),
-    "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample<BECKMANN,rng>"),
+    "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample_bk<sample,rng>"),
     "utia_eval": (100_000_000, 36, "evals", "k_eval_utia_t1<eval> + k_eval_utia_fix<eval> (two-tier exact)"),
     "merl_fit": (100, None, "materials", "k_fit<MERL>"),
     # end to end: 100 MERL files (34 992 012 B each) on local disk -> params: pread + PCIe + convert + fit

@@ -24,6 +24,12 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
                          unsigned long long start, const View &o, const View &out_i,
                          const View *out_w, float *out_pdf);
 
+// the Beckmann lobe's sample / evalp_is (djb_kernels_sample.hip: common path + deferred full path); launch_sample forwards here
+hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p, long long n,
+                                  const float *u1, const float *u2, uint32_t seed_u1, uint32_t seed_u2,
+                                  unsigned long long start, const View &o, const View &out_i,
+                                  const View *out_w, float *out_pdf);
+
 // per-pair params: rec = n x 5 floats; mode 0 = pdfparams records, mode 1 = LEAN moments added to
 // base5 (params_to_lrep(base) * scale); out_pp (optional, mode 1) receives the resolved pdfparams
 hipError_t launch_eval_pp(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,

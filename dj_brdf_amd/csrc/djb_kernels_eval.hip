@@ -34,20 +34,7 @@ inline int grid_full(long long n)
 	return (int)blocks;
 }
 
-// Dense batches (every view SoA with stride 1: what device-resident callers and bench.py pass) address their arrays
-// as  uniform base pointer (SGPRs: array + first unit of the workgroup) + 32-bit lane offset,  which costs one
-// VALU shift for all ten arrays of a kernel; the generic strided form spends ~35 VALU instructions per pair on 64-bit
-// index arithmetic (k * stride per component), 10 % of the GGX eval+pdf kernel.  k0 is workgroup-uniform.
-DJB_DEV v3 load3_dense(const View &v, long long k0, unsigned int t)
-{
-	const float *x = v.x + k0, *y = v.y + k0, *z = v.z + k0;
-	return mk(x[t], y[t], z[t]);
-}
-DJB_DEV void store3_dense(const View &v, long long k0, unsigned int t, v3 a)
-{
-	float *x = v.x + k0, *y = v.y + k0, *z = v.z + k0;
-	x[t] = a.x; y[t] = a.y; z[t] = a.z;
-}
+// load3_dense / store3_dense (djb_device_units.inc): dense batches address their arrays as uniform base + lane offset
 inline bool dense(const View &v) { return v.stride == 1 || v.x == nullptr; }
 
 // min-waves hint per kind, measured (tools/kind_rates.py, ms per 1e8 pairs at 1 / 4 / 8 waves): the analytic /
@@ -505,7 +492,7 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 {
 	if (n <= 0) return hipSuccess;
 	switch (b.kind) {
-	case KIND_BECKMANN: return launch_sample_kind<KIND_BECKMANN>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_BECKMANN: return launch_sample_beckmann(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);   // djb_kernels_sample.hip
 	case KIND_GGX:      return launch_sample_kind<KIND_GGX>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_TABULAR:  return launch_sample_kind<KIND_TABULAR>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_TABULAR_ANISO: return launch_sample_kind<KIND_TABULAR_ANISO>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);

@@ -1,0 +1,371 @@
+// djb_kernels_sample.hip -- Beckmann VNDF sampling (sample / evalp_is, BASELINE configs[3]) as a two-path kernel.
+//
+// The reference's sampler (dj_brdf.h:1669-1700, 1806-1846, 1897-1952) is one long dependent chain per sample with a
+// data-dependent Newton loop (2.7 % of the samples take 2 trips, 72 % take 3, 25 % take 4, 0.5 % up to 9) and a dozen
+// rarely taken arms: Giles' tail polynomial of erfinv (an fp64 sqrt), the special cases of glibc's logf / expf / powf /
+// exp, the exact fall-backs of the guarded fp64 shortcuts.  Each arm is taken by well under 1 % of the lanes but, at
+// 64 lanes a wave, by 20-30 % of the waves, and one slow lane keeps its wave in the loop: the one-kernel form
+// (k_sample in djb_kernels_eval.hip) pays 4.85 trip-equivalents for a mean of 3.2.
+//
+// Here every lane runs the COMMON path only: the same operations in the same order as the reference on that path --
+// every result it produces is the reference's, bit for bit -- with exactly four Newton trips, no arm at all, and a
+// `rare` flag raised wherever the reference would have left the common path (any arm above, a fifth trip, a
+// degenerate direction).  Flagged samples are not stored; their inputs go to a per-wave queue in LDS, and whenever a
+// wave has collected 64 of them it runs the full per-sample code (sample_one, the one the one-kernel form runs) on
+// them as one dense wave.  ~1.3 % of the samples take that route on the bench distribution.  Nothing is approximated
+// anywhere: both paths are the reference's arithmetic, the split is by control flow only.
+#include "djb_internal.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+
+using namespace djbdev;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr unsigned int QCAP = 128;            // queue slots per wave: < 64 waiting + <= 64 new per iteration
+constexpr int TRIPS = 4;                      // Newton trips of the common path; a sample that needs more is deferred
+
+// why a sample leaves the common path (the site numbers only matter to the measurement build, DJB_EXP_RARE_COUNT)
+enum { R_LOGF = 0, R_EXPF, R_POWF, R_EXP64, R_GUARD, R_TAIL_LOOP, R_TAIL_QF1, R_TRIPS, R_CLAMP, R_DEGENERATE, R_SITES };
+struct Rare {
+	bool any = false;
+#ifdef DJB_EXP_RARE_COUNT
+	unsigned int bits = 0;
+	DJB_DEV void flag(int site, bool c) { any |= c; bits |= c ? 1u << site : 0u; }
+	DJB_DEV void merge(const Rare &r, bool act) { any |= act & r.any; bits |= act ? r.bits : 0u; }
+#else
+	DJB_DEV void flag(int, bool c) { any |= c; }
+	DJB_DEV void merge(const Rare &r, bool act) { any |= act & r.any; }
+#endif
+};
+#ifdef DJB_EXP_RARE_COUNT          // measurement builds only (tools/exp): samples on the common / deferred path, and per site
+__device__ unsigned long long g_rare[2 + R_SITES];
+#endif
+
+// Measured on 2.5e8 and 1e9 samples (profiles/r03/beckmann_sample_grid.txt): one workgroup per resident slot (256 CUs x 5)
+// is 19 % slower than ~48 tiles per workgroup -- the slots do not finish together -- and one tile per workgroup 60 % slower
+// (table staging and a nearly empty queue drain per tile).
+constexpr long long TILES_PER_WG = 48;
+inline int grid_persistent(long long n)
+{
+	const long long tiles = (n + BLOCK - 1) / BLOCK;
+	long long blocks = (tiles + TILES_PER_WG - 1) / TILES_PER_WG;
+	if (blocks < 5120) blocks = tiles < 5120 ? tiles : 5120;      // small batches: fill the chip first
+	if (blocks > 0x7fffffffLL) blocks = 0x7fffffffLL;
+	if (blocks < 1) blocks = 1;
+	return (int)blocks;
+}
+
+// ---- the common paths of the float libm restatements (djb_glibc_restated_f32.inc), special cases flagged instead of taken
+DJB_DEV float logf_main(float x, const GlibcTabs &gt, Rare &rare)
+{
+	const double *T = gt.logf;
+	constexpr double Ln2 = DJB_GLIBC_LOGF_C[0], A0 = DJB_GLIBC_LOGF_C[1], A1 = DJB_GLIBC_LOGF_C[2], A2 = DJB_GLIBC_LOGF_C[3];
+	const unsigned int ix = __float_as_uint(x);
+	// x == 1 needs no arm: table entry 9 is {1, 0}, so the polynomial below returns +0 like glibc's shortcut
+	rare.flag(R_LOGF, ix - 0x00800000u >= 0x7f800000u - 0x00800000u);
+	unsigned int tmp = ix - 0x3f330000u;
+	int i = (int)((tmp >> 19) % 16u), k = (int)tmp >> 23;
+	unsigned int iz = ix - (tmp & (0x1ffu << 23));
+	double invc = T[2 * i], logc = T[2 * i + 1], z = D(__uint_as_float(iz));
+	double r = __builtin_fma(z, invc, -1.0);
+	double y0 = __builtin_fma((double)k, Ln2, logc);
+	double r2 = r * r;
+	double y = __builtin_fma(A1, r, A2);
+	y = __builtin_fma(A0, r2, y);
+	y = __builtin_fma(y, r2, y0 + r);
+	return F(y);
+}
+DJB_DEV float expf_main(float x, const GlibcTabs &gt, Rare &rare)
+{
+	constexpr double Shift = DJB_GLIBC_EXP2F_C[4], InvLn2N = DJB_GLIBC_EXP2F_C[5];
+	rare.flag(R_EXPF, ((__float_as_uint(x) >> 20) & 0x7ffu) >= (0x42b00000u >> 20));
+	double xd = D(x), z = InvLn2N * xd;
+	double kd = z + Shift;
+	unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+	kd -= Shift;
+	double r = __builtin_fma(InvLn2N, xd, -kd);
+	return glibc_exp2_tail(ki, r, DJB_GLIBC_EXP2F_C[6], DJB_GLIBC_EXP2F_C[7], DJB_GLIBC_EXP2F_C[8], gt);
+}
+DJB_DEV float powf_main(float x, float y, const GlibcTabs &gt, Rare &rare)
+{
+	const double *T = gt.powlog;
+	constexpr double A0 = DJB_GLIBC_POWF_C[0], A1 = DJB_GLIBC_POWF_C[1], A2 = DJB_GLIBC_POWF_C[2], A3 = DJB_GLIBC_POWF_C[3],
+	                 A4 = DJB_GLIBC_POWF_C[4], ShiftScaled = DJB_GLIBC_EXP2F_C[0];
+	const unsigned int ix = __float_as_uint(x), iy = __float_as_uint(y);
+	rare.flag(R_POWF, (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) | (2u * iy - 1u >= 2u * 0x7f800000u - 1u));
+	unsigned int tmp = ix - 0x3f330000u;
+	int i = (int)((tmp >> 19) % 16u);
+	unsigned int top = tmp & 0xff800000u, iz = ix - top;
+	int k = (int)top >> 23;
+	double invc = T[2 * i], logc = T[2 * i + 1], z = D(__uint_as_float(iz));
+	double r = __builtin_fma(z, invc, -1.0), y0 = logc + (double)k;
+	double r2 = r * r;
+	double p0 = __builtin_fma(A0, r, A1), p = __builtin_fma(A2, r, A3), r4 = r2 * r2;
+	double q = __builtin_fma(A4, r, y0);
+	q = __builtin_fma(p, r2, q);
+	double logx = __builtin_fma(p0, r4, q);
+	double ylogx = D(y) * logx;
+	rare.flag(R_POWF, (((unsigned int)__double2hiint(ylogx) >> 15) & 0xffffu) >= (0x405f8000u >> 15));
+	double kd = ylogx + ShiftScaled;
+	unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+	kd -= ShiftScaled;
+	double rr = __builtin_fma(D(y), logx, -kd);
+	return glibc_exp2_tail(ki, rr, DJB_GLIBC_EXP2F_C[1], DJB_GLIBC_EXP2F_C[2], DJB_GLIBC_EXP2F_C[3], gt);
+}
+// glibc's fp64 exp of a non-positive argument, main path (glibc_exp_inline without its cold branch).  x <= -512 returns 0
+// instead of glibc's tiny value: the two places the sampler uses e = exp(-cot^2) -- 1 - poly t e in erf and 2 + k e in the
+// normalisation, both in double -- give the same result for every e below 2^-60, let alone below exp(-512)
+DJB_DEV double exp_main_neg(double x, LdsTab T, Rare &rare)
+{
+	const unsigned int hx = (unsigned int)__double2hiint(x), abstop = (hx >> 20) & 0x7ffu;
+	const bool big = abstop >= 0x408u;                                   // |x| >= 512, Inf, NaN
+	rare.flag(R_EXP64, (abstop < 0x3c9u) | (abstop >= 0x7ffu) | (big & !(hx >> 31)));
+	unsigned int klo, sh; int sl;
+	const double tmp = glibc_exp_tmp(x, 0.0, klo, sh, sl, T);
+	const double scale = __hiloint2double((int)sh, sl);
+	return big ? 0.0 : __builtin_fma(scale, tmp, scale);
+}
+// ---- the guarded fp64 shortcuts (djb_device.hpp) with the exact fall-back flagged instead of taken
+DJB_DEV float inversesqrt_g(float x, Rare &rare)
+{
+	const double y = inversesqrt_fast(x);
+	rare.flag(R_GUARD, near_f32_midpoint(y) | !((x > 1e-30f) & (x < 1e30f)));
+	return F(y);
+}
+DJB_DEV float recip_g(double q, Rare &rare)
+{
+	const double r = recip_fast(q);
+	const double aq = q < 0 ? -q : q;
+	rare.flag(R_GUARD, near_f32_midpoint(r) | !((aq > 1e-30) & (aq < 1e30)));
+	return F(r);
+}
+DJB_DEV float sqrt_g(double a, Rare &rare)
+{
+	const double g = sqrt_fast(a);
+	rare.flag(R_GUARD, near_f32_midpoint(g) | !((a > 1e-30) & (a < 1e30)));
+	return F(g);
+}
+DJB_DEV v3 normalize_g(v3 v, Rare &rare) { return scale(inversesqrt_g(dot(v, v), rare), v); }
+
+DJB_DEV float erf_given_exp_g(float x, double e, Rare &rare)               // erf_given_exp, djb_device.hpp
+{
+	const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f,
+	            a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+	float sign = x < 0 ? -1.0f : 1.0f;
+	x = fabsf(x);
+	float t = recip_g(1.0 + D(p * x), rare);
+	float poly = ((((a5 * t + a4) * t) + a3) * t + a2) * t + a1;
+	float y = F(1.0 - D(poly * t) * e);
+	return sign * y;
+}
+// Giles' erfinv, central arm (w < 5); the tail arm is flagged (dj_brdf.h:691-721)
+DJB_DEV float erfinv_central(float u, const GlibcTabs &gt, Rare &rare, int site)
+{
+	float w = -logf_main((1.0f - u) * (1.0f + u), gt, rare), p;
+	rare.flag(site, !(w < 5.0f));
+	w = w - 2.5f;
+	p = 2.81022636e-08f;
+	p = 3.43273939e-07f + p * w;
+	p = -3.5233877e-06f + p * w;
+	p = -4.39150654e-06f + p * w;
+	p = 0.00021858087f + p * w;
+	p = -0.00125372503f + p * w;
+	p = -0.00417768164f + p * w;
+	p = 0.246640727f + p * w;
+	p = 1.50140941f + p * w;
+	return p * u;
+}
+
+// beckmann_qf2_radial (djb_device_microfacet.inc, dj_brdf.h:1897-1952) for a sample that converges within TRIPS trips
+// UNROLL: four copies of the trip (sample: 15.7 vs 16.3 ms per 1e9) or a loop (evalp_is, whose tail needs the registers:
+// 107 VGPRs = 4 waves per SIMD instead of 160 = 3; 6.30 vs 6.80 ms per 2e8)
+template <bool UNROLL>
+DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &gt, Rare &rare)
+{
+	const float sqrt_pi_inv = F(1. / sqrt(DJB_PI));
+	float cot_k = cos_k / sin_k, tan_k = sin_k / cos_k;
+	const double e_cot = exp_main_neg(D(-cot_k * cot_k), gt.exp64, rare);
+	float a = -1, c = erf_given_exp_g(cot_k, e_cot, rare);
+	u = fmax_(u, 1e-6f);
+	float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
+	float b = c - (1 + c) * powf_main(1 - u, fit, gt, rare);
+	float normalization = recip_g(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot, rare);
+	float inv_erf = 0.0f, b_at = 0.0f;
+	bool done = false;
+	int trips = TRIPS;
+	if (!UNROLL) asm volatile("" : "+s"(trips));  // opaque bound: a loop, not four copies of the body
+#pragma unroll
+	for (int t = 0; t < trips; ++t) {
+		const float bt = !((b >= a) & (b <= c)) ? 0.5f * (a + c) : b;
+		Rare r;
+		const float ie = erfinv_central(bt, gt, r, R_TAIL_LOOP);
+		const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * expf_main(-ie * ie, gt, r)) - u;
+		const float derivative = normalization * (1 - ie * tan_k);
+		const bool act = !done;                       // a converged lane keeps its result; what it computes from here on is unused
+		rare.merge(r, act);
+		inv_erf = act ? ie : inv_erf;
+		b_at = act ? bt : b_at;
+		done |= fabsf(value) < 1e-5f;
+		const bool pos = value > 0;
+		c = pos ? bt : c; a = pos ? a : bt;
+		b = bt - value / derivative;
+	}
+	// not converged: more trips; b < -0.9999: the reference re-evaluates erfinv at the clamped argument
+	rare.flag(R_TRIPS, !done);
+	rare.flag(R_CLAMP, !(b_at >= -0.9999f));
+	return inv_erf;
+}
+
+// microfacet::sample for Beckmann (mf_sample, mf_sample_vp22_std; dj_brdf.h:1669-1700, 1806-1832), common path
+template <bool UNROLL>
+DJB_DEV v3 bk_sample_common(const Params &p, float u1, float u2, v3 o, const GlibcTabs &gt, Rare &rare)
+{
+	u1 = sat_(u1) * 0.99998f + 0.00001f;
+	u2 = sat_(u2) * 0.99998f + 0.00001f;
+	float a = o.x * p.ax + o.y * p.ay * p.rho;
+	float bb = o.y * p.ay * p.s;
+	float c = o.z - o.x * p.tx - o.y * p.ty;
+	v3 k = normalize_g(mk(a, bb, c), rare);
+	// k.z <= 0 returns (0, 0, 1) in the reference, k.z >= 1 skips the rotation: both to the full code
+	rare.flag(R_DEGENERATE, !(D(k.z) > 0.0) | !(D(k.z) < 1.0));
+	float cos_k = k.z;
+	float sin_k = sqrt_g(1.0 - D(k.z * k.z), rare);
+	rare.flag(R_DEGENERATE, !(sin_k > 0.0f));
+	float tx = bk_qf2_common<UNROLL>(u1, cos_k, sin_k, gt, rare);
+	float ty = erfinv_central(F(2.0 * D(u2) - 1.0), gt, rare, R_TAIL_QF1);                     // beckmann_qf1
+	float nrm = inversesqrt_g(k.x * k.x + k.y * k.y, rare);
+	float cp = k.x * nrm, sp = k.y * nrm;
+	float txm = cp * tx - sp * ty;
+	float tym = sp * tx + cp * ty;
+	float txh = p.ax * txm + p.tx;
+	float chol = p.rho * txm + p.s * tym;
+	float tyh = p.ay * chol + p.ty;
+	v3 h = normalize_g(mk(-txh, -tyh, 1), rare);
+	return sub(scale(F(2.0 * D(dot(o, h))), h), o);
+}
+
+template <bool IS, bool RNG, int FRK, bool DENSE>
+__global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long n, const float *u1a,
+                                                     const float *u2a, uint32_t seed1, uint32_t seed2,
+                                                     unsigned long long start, View vo, View vi_out,
+                                                     View vw_out, float *out_pdf)
+{
+	__shared__ double s_glibc[GLIBC_LDS_WORDS];
+	__shared__ unsigned long long s_exp[256];
+	__shared__ unsigned int s_q[WAVES][7][QCAP];       // deferred samples: {k lo, k hi, u1, u2, o.xyz}
+	GlibcTabs gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
+	gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	__syncthreads();
+	const unsigned int t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+	unsigned int (&q)[7][QCAP] = s_q[wave];
+	unsigned int qn = 0;                               // wave-uniform
+	// the full per-sample code on `cnt` queued samples starting at slot `first` (one per lane)
+	auto drain = [&](unsigned int first, unsigned int cnt) {
+		if (lane < cnt) {
+			const unsigned int j = first + lane;
+			const long long k = (long long)(((unsigned long long)q[1][j] << 32) | q[0][j]);
+			const float u1 = __uint_as_float(q[2][j]), u2 = __uint_as_float(q[3][j]);
+			const v3 o = mk(__uint_as_float(q[4][j]), __uint_as_float(q[5][j]), __uint_as_float(q[6][j]));
+			v3 i_out, w; float pdf;
+			sample_one<KIND_BECKMANN, IS, FRK>(b, p, u1, u2, o, gt, i_out, w, pdf);
+			store3(vi_out, k, i_out);
+			if (IS) { store3(vw_out, k, w); out_pdf[k] = pdf; }
+		}
+	};
+	const long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
+		const long long k = k0 + t;
+		const bool live = k < n;
+		float u1 = 0.5f, u2 = 0.5f; v3 o = mk(0, 0, 1);
+		if (live) {
+			u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : (DENSE ? (u1a + k0)[t] : u1a[k]);
+			u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : (DENSE ? (u2a + k0)[t] : u2a[k]);
+			o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
+		}
+		Rare why;
+		v3 i_ = bk_sample_common<!IS>(p, u1, u2, o, gt, why);
+		const bool rare = why.any & live;
+		v3 i_out = i_, w = mk(0, 0, 0); float pdf = 0.0f;
+		if (IS) { i_out = mk(0, 0, 0); w = mf_evalp_is_tail<KIND_BECKMANN, FRK>(b, p, i_, o, i_out, pdf); }
+		if (live && !rare) {
+			if (DENSE) store3_dense(vi_out, k0, t, i_out); else store3(vi_out, k, i_out);
+			if (IS) {
+				if (DENSE) { store3_dense(vw_out, k0, t, w); (out_pdf + k0)[t] = pdf; }
+				else { store3(vw_out, k, w); out_pdf[k] = pdf; }
+			}
+		}
+#ifdef DJB_EXP_RARE_COUNT
+		{
+			const unsigned int c0 = (unsigned int)__popcll(__ballot(live & !rare)), c1 = (unsigned int)__popcll(__ballot(rare));
+			if (lane == 0) { atomicAdd(&g_rare[0], (unsigned long long)c0); if (c1) atomicAdd(&g_rare[1], (unsigned long long)c1); }
+			for (int site = 0; site < R_SITES; ++site) {
+				const unsigned int c = (unsigned int)__popcll(__ballot(rare && ((why.bits >> site) & 1u)));
+				if (c && lane == 0) atomicAdd(&g_rare[2 + site], (unsigned long long)c);
+			}
+		}
+#endif
+		const unsigned long long mask = __ballot(rare);
+		if (mask) {
+			if (rare) {
+				const unsigned int j = qn + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+				q[0][j] = (unsigned int)(unsigned long long)k; q[1][j] = (unsigned int)((unsigned long long)k >> 32);
+				q[2][j] = __float_as_uint(u1); q[3][j] = __float_as_uint(u2);
+				q[4][j] = __float_as_uint(o.x); q[5][j] = __float_as_uint(o.y); q[6][j] = __float_as_uint(o.z);
+			}
+			qn += (unsigned int)__popcll(mask);
+			if (qn >= 64u) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				qn -= 64u;
+				drain(qn, 64u);
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	}
+	if (qn) {
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		drain(0u, qn);
+	}
+}
+
+} // namespace
+
+namespace djbk {
+
+// sample / evalp_is of a Beckmann lobe; same contract as launch_sample (djb_kernels_eval.hip), which forwards here
+hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p, long long n, const float *u1, const float *u2,
+                                  uint32_t s1, uint32_t s2, unsigned long long start, const View &o, const View &out_i,
+                                  const View *out_w, float *out_pdf)
+{
+	dim3 g(grid_persistent(n)), t(BLOCK);
+#ifdef DJB_EXPERIMENT
+	if (const char *e = getenv("DJB_SAMPLE_GRID_ENV")) g.x = (unsigned int)atoll(e);
+#endif
+	View w = out_w ? *out_w : View{ nullptr, nullptr, nullptr, 0 };
+	const bool is = out_w != nullptr, rng = u1 == nullptr;
+	auto dense1 = [](const View &v) { return !v.x || v.stride == 1; };
+	const bool dn = dense1(o) && dense1(out_i) && dense1(w);
+#ifdef DJB_EXP_RARE_COUNT
+	struct Report { hipStream_t s; ~Report() { unsigned long long h[2 + R_SITES]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rare), sizeof h);
+		fprintf(stderr, "djb_exp: sample_bk common %llu deferred %llu | logf %llu expf %llu powf %llu exp64 %llu guard %llu tail_loop %llu tail_qf1 %llu trips %llu clamp %llu degenerate %llu (cumulative)\n",
+		        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]); } } report{ s };
+#endif
+#define DJB_LAUNCH_S(IS_, RNG_, FRK_, DN_) hipLaunchKernelGGL((k_sample_bk<IS_, RNG_, FRK_, DN_>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf)
+#define DJB_LAUNCH_S2(IS_, FRK_) do { if (rng) { if (dn) DJB_LAUNCH_S(IS_, true, FRK_, true); else DJB_LAUNCH_S(IS_, true, FRK_, false); } \
+                                      else { if (dn) DJB_LAUNCH_S(IS_, false, FRK_, true); else DJB_LAUNCH_S(IS_, false, FRK_, false); } \
+                                      return hipGetLastError(); } while (0)
+	if (!is) DJB_LAUNCH_S2(false, -1);
+	if (b.fr.kind == FR_IDEAL) DJB_LAUNCH_S2(true, FR_IDEAL);
+	if (b.fr.kind == FR_SCHLICK) DJB_LAUNCH_S2(true, FR_SCHLICK);
+	if (b.fr.kind == FR_UNPOLARIZED) DJB_LAUNCH_S2(true, FR_UNPOLARIZED);
+	DJB_LAUNCH_S2(true, -1);
+#undef DJB_LAUNCH_S2
+#undef DJB_LAUNCH_S
+}
+
+} // namespace djbk

@@ -113,6 +113,79 @@ def test_microfacet_sample(gpu_ctx, oracle, dirs, ndf):
             assert same.all(), f"{ndf} evalp_is {name} {p}: {np.mean(~same):.2e} differ"
 
 
+def _beckmann_sampler_cases(n_bulk=150_001):
+    """Inputs that leave the common path of the Beckmann sampling kernel (djb_kernels_sample.hip) for every reason it
+    knows -- erfinv's tail arm at both call sites, more than four Newton trips, the clamp of the final argument,
+    exp(-cot^2) below glibc's main path, directions on / below / along the horizon and on the normal, NaNs -- mixed
+    into a random bulk so that dense waves, ragged tails and partly filled deferred queues all occur."""
+    rng = np.random.default_rng(77)
+    o = synth.directions_aos(n_bulk, synth.SEED_O).copy()
+    u1 = synth.uniforms(n_bulk, synth.SEED_U1).copy(); u2 = synth.uniforms(n_bulk, synth.SEED_U2).copy()
+    k = rng.permutation(n_bulk)
+    def take(m):
+        nonlocal k
+        sel, k = k[:m], k[m:]
+        return sel
+    edge = np.array([0.0, 1e-7, 1e-6, 1e-5, 1e-3, 0.5, 1 - 1e-3, 1 - 1e-5, 1 - 1e-6, 1 - 6e-8, 1.0], np.float32)
+    u2[take(4000)] = rng.choice(edge, 4000)                                   # qf1: tail arm, |2u - 1| -> 1
+    u2[take(4000)] = np.float32(1) - rng.random(4000, dtype=np.float32) * np.float32(4e-3)
+    u1[take(4000)] = rng.choice(edge, 4000)                                   # qf2: first guess at the ends of [-1, c]
+    u1[take(4000)] = rng.random(4000, dtype=np.float32) * np.float32(1e-4)    # many trips / bisection steps
+    u1[take(4000)] = np.float32(1) - rng.random(4000, dtype=np.float32) * np.float32(1e-4)
+    s = take(3000); o[s] = (0, 0, 1)                                          # on the normal: sin_k = 0
+    s = take(3000); t = rng.random(3000) * 1e-3; ph = rng.random(3000) * 6.2831853
+    o[s] = np.stack([np.sin(t) * np.cos(ph), np.sin(t) * np.sin(ph), np.cos(t)], 1).astype(np.float32)   # cot^2 >= 512 and beyond 745
+    s = take(3000); z = (rng.random(3000) * 2e-3).astype(np.float32); ph = rng.random(3000) * 6.2831853
+    o[s] = np.stack([np.sqrt(1 - z * z) * np.cos(ph), np.sqrt(1 - z * z) * np.sin(ph), z], 1).astype(np.float32)   # grazing
+    s = take(1000); o[s, 2] = -np.abs(o[s, 2])                                # below the horizon -> (0, 0, 1)
+    s = take(200); o[s, 0] = np.nan
+    s = take(200); u1[s] = np.nan
+    s = take(200); u2[s] = np.nan
+    s = take(200); o[s] = 0.0
+    return o, u1, u2
+
+
+def _same_bits(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+BK_SAMPLER_PARAMS = PARAMS + [("elliptic", 0.01, 0.01, 0.0), ("elliptic", 1.0, 1.0, 0.0), ("elliptic", 0.05, 0.8, 0.9)]
+
+
+@pytest.mark.parametrize("p", BK_SAMPLER_PARAMS, ids=lambda p: "default" if p is None else "-".join(str(x) for x in p))
+def test_beckmann_sampler_deferred_paths(gpu_ctx, oracle, p):
+    """sample / evalp_is of the Beckmann lobe on inputs chosen to leave the kernel's common path: every bit equals the oracle's,
+    for device-resident dense ([3, n]) and strided ([n, 3]) batches and for host batches, including batch sizes that end in
+    a partial wave."""
+    import torch
+    o, u1, u2 = _beckmann_sampler_cases()
+    g = djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    ob = oracle.microfacet("beckmann", ("schlick", 1.0, 0.71, 0.29), True)
+    up = mk_params(p)
+    want = oracle.sample(ob, u1, u2, o, p)
+    ww, wi, wpdf = oracle.evalp_is(ob, u1, u2, o, p)
+    dev = torch.device("cuda", 0)
+    tu1, tu2 = torch.as_tensor(u1, device=dev), torch.as_tensor(u2, device=dev)
+    for layout in ("host", "dense", "strided"):
+        oo = o if layout == "host" else torch.as_tensor(o, device=dev) if layout == "strided" else torch.as_tensor(np.ascontiguousarray(o.T), device=dev)
+        a1, a2 = (u1, u2) if layout == "host" else (tu1, tu2)
+        fix = (lambda x: x) if layout == "host" else (lambda x: x.cpu().numpy()) if layout == "strided" else (lambda x: x.cpu().numpy().T if x.dim() == 2 else x.cpu().numpy())
+        got = fix(g.sample(a1, a2, oo, up))
+        bad = ~_same_bits(got, want).all(axis=1)
+        assert not bad.any(), f"sample {layout} {p}: {int(bad.sum())} differ, first {np.flatnonzero(bad)[:5]} o={o[bad][:2]} u1={u1[bad][:2]} u2={u2[bad][:2]}"
+        w, gi, pdf = g.evalp_is(a1, a2, oo, up)
+        w, gi, pdf = fix(w), fix(gi), fix(pdf)
+        assert _same_bits(gi, wi).all(), f"evalp_is direction {layout} {p}"
+        assert _same_bits(w, ww).all(), f"evalp_is weight {layout} {p}"
+        assert _same_bits(pdf, wpdf).all(), f"evalp_is pdf {layout} {p}"
+    # short device batches: one partial wave, one wave + 1, a workgroup + 1
+    for m in (1, 63, 65, 97, 257, 1025):
+        oo = torch.as_tensor(np.ascontiguousarray(o[-m:].T), device=dev)
+        got = g.sample(tu1[-m:].contiguous(), tu2[-m:].contiguous(), oo, up).cpu().numpy().T
+        assert _same_bits(got, want[-m:]).all(), f"sample, {m} units, {p}"
+
+
 def test_device_libm_restatements(gpu_ctx, oracle):
     """The kernels' own copies of glibc's exp / pow / atan2 / sin / cos / tan / acos (double) and logf / expf / powf (float), evaluated on the GPU
     (djb_selftest_libm), against the libm of this host -- what the reference calls.  Every bit."""

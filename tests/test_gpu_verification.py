@@ -361,3 +361,15 @@ def test_two_tier_overflow_and_in_place_calls(gpu_ctx):
             assert torch.equal(ii.view(torch.int32), want.view(torch.int32)), f"in-place evalp differs ({obj.__class__.__name__})"
     finally:
         djb.set_contract_1e5(gpu_ctx, False)
+    # (3) in-place sample (the sampled directions overwrite o): the Beckmann kernel defers some samples to a later dense pass
+    # (djb_kernels_sample.hip) -- their inputs must come from its queue, not from the overwritten array
+    bk = djb.beckmann(djb.fresnel.ideal(), True, ctx=gpu_ctx)
+    pe = djb.microfacet.params.elliptic(0.2, 0.5, 0.7)
+    u1 = djb.gen_uniforms(n, synth.SEED_U1, ctx=gpu_ctx); u2 = djb.gen_uniforms(n, synth.SEED_U2, ctx=gpu_ctx)
+    want_s = bk.sample(u1, u2, o, pe)
+    oo = o.clone()
+    vo = djb._Vec(oo)
+    djb._lib.check(lib.djb_sample_batch(gpu_ctx._h, bk._h, C.c_int64(n), C.c_void_p(u1.data_ptr()), C.c_void_p(u2.data_ptr()),
+                                        C.byref(vo.view), C.byref(pe._p), C.byref(vo.view), C.c_int(0)))
+    gpu_ctx.synchronize()
+    assert torch.equal(oo.view(torch.int32), want_s.view(torch.int32)), "in-place Beckmann sample differs"

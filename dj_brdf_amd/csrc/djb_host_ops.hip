@@ -336,7 +336,8 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	{ unsigned int w[4]; float f4[4] = { p.ax, p.ay, p.rho, (float)b->dev.kind }; memcpy(w, f4, 16); ct_key = ((unsigned long long)(w[0] ^ (w[2] * 2654435761u)) << 32) | (w[1] ^ (w[3] * 40503u)); }
 	wl_adapt(ctx);
 	const bool ct_hopeless = ctx->ct_key == ct_key && ctx->ct_key_share > 0.30;
-	if (ctx->contract_1e5 && !aliased && !ct_hopeless && (b->dev.kind == DJB_KIND_GGX || b->dev.kind == DJB_KIND_BECKMANN) && djbk::contract_supported(b->dev, p)) {
+	const double *model_host = b->model_host.empty() ? nullptr : b->model_host.data();
+	if (ctx->contract_1e5 && !aliased && !ct_hopeless && djbk::contract_supported(b->dev, p, model_host)) {
 		auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
 		const bool dense16 = vi.stride == 1 && vo.stride == 1 && al16(vi.x) && al16(vi.y) && al16(vi.z) && al16(vo.x) && al16(vo.y) && al16(vo.z) &&
 		                     (!(want & 3) || (vout.stride == 1 && al16(vout.x) && al16(vout.y) && al16(vout.z))) && (!(want & 4) || al16(dpdf));
@@ -362,7 +363,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 				}
 				unsigned int *count = (unsigned int *)ctx->scratch, *list = count + HDR / sizeof(unsigned int);
 				auto off = [&](const View &v) { return View{ v.x ? v.x + lo : nullptr, v.y ? v.y + lo : nullptr, v.z ? v.z + lo : nullptr, v.stride }; };
-				HIP_TRY(djbk::launch_eval_contract(ctx->stream, b->dev, p, m, off(vi), off(vo), off(vout), dpdf ? dpdf + lo : nullptr, want,
+				HIP_TRY(djbk::launch_eval_contract(ctx->stream, b->dev, p, model_host, m, off(vi), off(vo), off(vout), dpdf ? dpdf + lo : nullptr, want,
 				                                   list, (unsigned int)cap, count));
 				wl_note(ctx, count, cap, m, (int)djbk::CONTRACT_SHARDS, (int)djbk::CONTRACT_COUNTER_STRIDE);
 				if (ctx->wl_pending) ctx->wl_note_key = ct_key;
@@ -831,13 +832,14 @@ try {
 	if (!max_rel2 || !counters4) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	Params p;
 	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
-	if ((b->dev.kind != DJB_KIND_GGX && b->dev.kind != DJB_KIND_BECKMANN) || !djbk::contract_supported(b->dev, p))
+	const double *model_host = b->model_host.empty() ? nullptr : b->model_host.data();
+	if (!djbk::contract_supported(b->dev, p, model_host))
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf / params outside the domain of the contract-mode fast path");
 	unsigned char *d = nullptr;
 	HIP_TRY(hipMalloc((void **)&d, 64));
 	hipError_t e = hipMemsetAsync(d, 0, 64, ctx->stream);
 	if (e == hipSuccess)
-		e = djbk::launch_contract_selftest(ctx->stream, b->dev, p, n, seed, seed ^ 0x9e3779b9u, 0ull, family,
+		e = djbk::launch_contract_selftest(ctx->stream, b->dev, p, model_host, n, seed, seed ^ 0x9e3779b9u, 0ull, family,
 		                                   (unsigned int *)d, (unsigned long long *)(d + 16));
 	unsigned char h[64];
 	if (e == hipSuccess) e = hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, ctx->stream);

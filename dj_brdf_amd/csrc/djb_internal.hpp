@@ -78,10 +78,11 @@ constexpr unsigned int WL_SHARDS = 64;
 constexpr unsigned int WL_COUNTER_STRIDE = 32;         // words between two counters (one 128-byte line each)
 constexpr unsigned int CONTRACT_SHARDS = WL_SHARDS, CONTRACT_COUNTER_STRIDE = WL_COUNTER_STRIDE;
 constexpr float CT_RHO_MAX = 0.9f;
-bool contract_supported(const Brdf &b, const Params &p);
-hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i, const View &o,
+// model_host: the host copy of b.model (sgd / abc rows), or NULL
+bool contract_supported(const Brdf &b, const Params &p, const double *model_host = nullptr);
+hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, const double *model_host, long long n, const View &i, const View &o,
                                 const View &out, float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count);
-hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed_i, uint32_t seed_o,
+hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, const double *model_host, long long n, uint32_t seed_i, uint32_t seed_o,
                                     unsigned long long start, int family, unsigned int *max_bits, unsigned long long *counters);
 hipError_t launch_guard_selftest(hipStream_t s, long long n, uint32_t seed, unsigned long long *counters);
 hipError_t launch_libm_probe(hipStream_t s, int fn, long long n, const double *x, const double *y, double *out);

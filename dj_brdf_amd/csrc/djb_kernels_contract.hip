@@ -56,6 +56,10 @@ struct CtParams {
 	double R_ax, R_t2;                 // 1 / ax and 1 / t2 to within 2^-52: fdiv_r's exact divisions (Beckmann)
 	float f0[3], f1[3];                // schlick: f0 and 1 - f0
 	int shadow;
+	// abc (model row kD[3] A[3] B C ior, dj_brdf.h:3608-3668)
+	float kd_pi[3];                    // kD / pi as the reference rounds it: float(kD) * (1.0f / float(pi))
+	float A[3], ior;
+	double B, C;
 };
 
 // exp(y) for y <= 0 with the argument split y log2(e) = hi + lo, so that the result keeps ~2 ulp for |y| up to 80 (a plain
@@ -142,11 +146,60 @@ DJB_DEV bool ct_eval_beckmann(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 	return ok | !live;
 }
 
+// ABC (abc::eval, dj_brdf.h:3633-3645: kD / pi + G F D / (pi i.z o.z), D = A / (1 + B (1 - h.z))^C, G = min of the two
+// min(1, 2 h.z k.z / dot(h, k)), F = unpolarized(ior)).  B reaches 8e6 in the published fits, so D moves by B C 2^-24 /
+// (1 + B (1 - h.z)) per ulp of h.z -- percent: like Beckmann's slope, h is computed with the REFERENCE's operations
+// (normalize through the guarded inverse square root), which also makes dot(i, h), dot(h, k) and the Fresnel term's
+// g = float(sqrt(n^2 + c^2 - 1)) (guarded fp64 square root) the reference's own floats: its ill-conditioned
+// differences g - c (ior -> 1) and 1 - h.z start from identical operands.  What is approximated: the power (frexp, v_log_f32
+// of the mantissa, the product with C in fp64, v_exp_f32 of the fraction: ~3e-7 relative for C <= 16), three divisions
+// by v_rcp_f32, the final products.  Sum of two non-negative terms: the relative error of the result is at most that of
+// the specular term, ~20 ulp.  pdf = i.z / pi (brdf::pdf, dj_brdf.h:842): one multiplication.
+template <int WANT>
+DJB_DEV bool ct_eval_abc(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
+{
+	const bool live = (i.z > 0.0f) & (o.z > 0.0f);            // dj_brdf.h:3636; false for NaN like the reference's test
+	fr = mk(0, 0, 0); pdf = 0.0f;
+	if (WANT & 4) pdf = i.z * 0.318309886f;                   // computed for every pair, live or not, as in eval_one
+	bool ok = true;
+	if (WANT & 3) {
+		const v3 h = normalize(add(i, o));                    // exact
+		const float cd = sat_(dot(i, h));
+		// fresnel::unpolarized, dj_brdf.h:1292-1303 (one ior for the three channels: abc's constructor, :3623)
+		const float g = sqrt_to_f32(D(c.ior * c.ior + cd * cd) - 1.0);
+		const float t1 = cd * (g + cd) - 1.0f, t2 = cd * (g - cd) + 1.0f;   // == float(double(c (g +- c)) -+ 1.0): one rounding of an exact difference
+		const float q3 = t1 * rcp_(t2), gm = g - cd, gp = g + cd, q4 = gm * rcp_(gp);
+		const float Fr = (0.5f * (q4 * q4)) * (1.0f + q3 * q3);
+		ok &= (gm > 0.0f) & in_range(gp) & in_range(t2);
+		// abc::gaf, dj_brdf.h:3647-3655
+		const float di = dot(h, i), dO = dot(h, o);
+		ok &= in_range(di) & in_range(dO);
+		const float g1i = fminf(1.0f, 2.0f * ((h.z * i.z) * rcp_(di))), g1o = fminf(1.0f, 2.0f * ((h.z * o.z) * rcp_(dO)));
+		const float G = fminf(g1i, g1o);
+		// (1 + B (1 - h.z))^C
+		const double td = __builtin_fma(c.B, 1.0 - D(h.z), 1.0);
+		const int e2 = __builtin_amdgcn_frexp_exp(td);
+		const float lm = __builtin_amdgcn_logf(F(__builtin_amdgcn_frexp_mant(td)));   // log2 of the mantissa in [0.5, 1)
+		const double y = c.C * (D(lm) + (double)e2);
+		const double yn = __builtin_rint(y);
+		const float den = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(F(y - yn)), (int)yn);
+		ok &= (td >= 1.0) & (td < 1e30) & (y < 100.0);
+		const float k = ((G * Fr) * rcp_(den)) * rcp_((3.14159274f * i.z) * o.z);
+		const float amin = fminf(c.A[0], fminf(c.A[1], c.A[2]));
+		ok &= ((k * amin > 1e-30f) | (k == 0.0f)) & (k < 1e30f) & (i.z > CT_LO) & (o.z > CT_LO);
+		v3 e = live ? mk(c.kd_pi[0] + c.A[0] * k, c.kd_pi[1] + c.A[1] * k, c.kd_pi[2] + c.A[2] * k) : mk(0, 0, 0);
+		if (WANT & 2) e = scale(i.z, e);                      // brdf::evalp = eval * i.z, dead pairs included (NaN i.z -> NaN, as in eval_one)
+		fr = e;
+	}
+	return ok | !live;
+}
+
 // one pair; false = tier 2.  fr / pdf follow eval_one's WANT convention (1 eval, 2 evalp, 4 pdf)
 template <int KIND, int WANT, int FRK>
 DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 {
-	static_assert(KIND == KIND_GGX || KIND == KIND_BECKMANN, "contract mode: GGX and Beckmann");
+	static_assert(KIND == KIND_GGX || KIND == KIND_BECKMANN || KIND == KIND_ABC, "contract mode: GGX, Beckmann and ABC");
+	if (KIND == KIND_ABC) return ct_eval_abc<WANT>(c, i, o, fr, pdf);
 	if (KIND == KIND_BECKMANN) return ct_eval_beckmann<WANT, FRK>(c, i, o, fr, pdf);
 	// g1(k) > 0 <=> dot(k, m_n) = k.z > 0 (dj_brdf.h:1633-1642); gaf > 0 <=> both (shadow) / g1(o) (dj_brdf.h:1644-1665)
 	// -- decided on the inputs themselves, NaN included: the reference's comparisons are false for NaN and return zeros.
@@ -334,6 +387,26 @@ __global__ __launch_bounds__(BLOCK) void k_ct_selftest(Brdf b, Params p, CtParam
 	atomicAdd(&counters[2], n_zero); atomicAdd(&counters[3], n_out);
 }
 
+// abc: the published rows and anything like them (one ior > 1 for the three channels, the constructor's Fresnel term)
+bool ct_params_abc(const Brdf &b, const double *m, CtParams *c)
+{
+	if (!m || b.fr.kind != FR_UNPOLARIZED) return false;
+	const float ior = (float)m[8];
+	if (!(b.fr.a[0] == ior && b.fr.a[1] == ior && b.fr.a[2] == ior) || !(ior > 1.0f && ior < 1e4f)) return false;
+	if (!(m[6] >= 0.0 && m[6] < 1e12) || !(m[7] >= 1e-3 && m[7] <= 16.0)) return false;
+	*c = CtParams{};
+	const float inv_pi = 1.0f / (float)DJB_PI;               // divs(kD, float(pi)) = (1.0f / float(pi)) * kD, dj_brdf.h:601, 3644
+	for (int k = 0; k < 3; ++k) {
+		const float kd = (float)m[k], a = (float)m[3 + k];
+		if (!(kd >= 0.0f && kd < 1e6f) || !(a > 1e-12f && a < 1e12f)) return false;
+		c->kd_pi[k] = inv_pi * kd; c->A[k] = a;
+	}
+	c->ior = ior; c->B = m[6]; c->C = m[7];
+	return true;
+}
+
+bool ct_params_any(const Brdf &b, const Params &p, const double *model_host, CtParams *c);
+
 bool ct_params(const Brdf &b, const Params &p, CtParams *c)
 {
 	if (p.tx != 0.0f || p.ty != 0.0f || !(p.nx == 0.0f && p.ny == 0.0f && p.nz == 1.0f)) return false;
@@ -356,6 +429,12 @@ bool ct_params(const Brdf &b, const Params &p, CtParams *c)
 		}
 	} else if (b.fr.kind != FR_IDEAL) return false;
 	return true;
+}
+
+bool ct_params_any(const Brdf &b, const Params &p, const double *model_host, CtParams *c)
+{
+	if (b.kind == KIND_ABC) return ct_params_abc(b, model_host, c);
+	return (b.kind == KIND_GGX || b.kind == KIND_BECKMANN) && ct_params(b, p, c);
 }
 
 template <int KIND, int FRK>
@@ -390,17 +469,17 @@ hipError_t launch_ct(hipStream_t s, const Brdf &b, const Params &p, const CtPara
 
 namespace djbk {
 
-bool contract_supported(const Brdf &b, const Params &p)
+bool contract_supported(const Brdf &b, const Params &p, const double *model_host)
 {
 	CtParams c;
-	return (b.kind == KIND_GGX || b.kind == KIND_BECKMANN) && ct_params(b, p, &c);
+	return ct_params_any(b, p, model_host, &c);
 }
 
-hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i, const View &o,
+hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, const double *model_host, long long n, const View &i, const View &o,
                                 const View &out, float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count)
 {
 	CtParams c;
-	if ((b.kind != KIND_GGX && b.kind != KIND_BECKMANN) || !ct_params(b, p, &c)) return hipErrorInvalidValue;
+	if (!ct_params_any(b, p, model_host, &c)) return hipErrorInvalidValue;
 	if (n <= 0) return hipSuccess;
 	// the < 4-pair tail of the batch: the exact kernel (launched first: the fix-up kernel's overflow rescan covers it too)
 	const long long n4 = n / 4;
@@ -409,6 +488,7 @@ hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, l
 		hipError_t e = launch_eval(s, b, p, n - 4 * n4, off(i), off(o), off(out), out_pdf ? out_pdf + 4 * n4 : nullptr, want);
 		if (e != hipSuccess) return e;
 	}
+	if (b.kind == KIND_ABC) return launch_ct<KIND_ABC, -1>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 	if (b.kind == KIND_BECKMANN) {
 		if (b.fr.kind == FR_SCHLICK) return launch_ct<KIND_BECKMANN, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 		return launch_ct<KIND_BECKMANN, FR_IDEAL>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
@@ -417,13 +497,14 @@ hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, l
 	return launch_ct<KIND_GGX, FR_IDEAL>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 }
 
-hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed_i, uint32_t seed_o,
+hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, const double *model_host, long long n, uint32_t seed_i, uint32_t seed_o,
                                     unsigned long long start, int family, unsigned int *max_bits, unsigned long long *counters)
 {
 	CtParams c;
-	if ((b.kind != KIND_GGX && b.kind != KIND_BECKMANN) || !ct_params(b, p, &c)) return hipErrorInvalidValue;
+	if (!ct_params_any(b, p, model_host, &c)) return hipErrorInvalidValue;
 	const dim3 g(grid_for(n, 256LL * 16)), t(BLOCK);
-	if (b.kind == KIND_BECKMANN) {
+	if (b.kind == KIND_ABC) hipLaunchKernelGGL((k_ct_selftest<KIND_ABC, -1>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+	else if (b.kind == KIND_BECKMANN) {
 		if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 		else hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_IDEAL>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 	} else if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);

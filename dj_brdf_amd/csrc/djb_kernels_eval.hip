@@ -492,7 +492,12 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 {
 	if (n <= 0) return hipSuccess;
 	switch (b.kind) {
-	case KIND_BECKMANN: return launch_sample_beckmann(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);   // djb_kernels_sample.hip
+	case KIND_BECKMANN:
+		// sample, and evalp_is with a Fresnel term fixed at compile time: the two-path kernel (djb_kernels_sample.hip).  evalp_is with
+		// a run-time Fresnel kind (spline, sgd) keeps the one-kernel form: both paths inlined would need 185 VGPRs (2 waves per SIMD)
+		if (!out_w || b.fr.kind == FR_IDEAL || b.fr.kind == FR_SCHLICK || b.fr.kind == FR_UNPOLARIZED)
+			return launch_sample_beckmann(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+		return launch_sample_kind<KIND_BECKMANN>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_GGX:      return launch_sample_kind<KIND_GGX>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_TABULAR:  return launch_sample_kind<KIND_TABULAR>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_TABULAR_ANISO: return launch_sample_kind<KIND_TABULAR_ANISO>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);

@@ -195,10 +195,7 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 	float normalization = recip_g(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot, rare);
 	float inv_erf = 0.0f, b_at = 0.0f;
 	bool done = false;
-	int trips = TRIPS;
-	if (!UNROLL) asm volatile("" : "+s"(trips));  // opaque bound: a loop, not four copies of the body
-#pragma unroll
-	for (int t = 0; t < trips; ++t) {
+	auto trip = [&]() {
 		const float bt = !((b >= a) & (b <= c)) ? 0.5f * (a + c) : b;
 		Rare r;
 		const float ie = erfinv_central(bt, gt, r, R_TAIL_LOOP);
@@ -212,6 +209,14 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 		const bool pos = value > 0;
 		c = pos ? bt : c; a = pos ? a : bt;
 		b = bt - value / derivative;
+	};
+	if (UNROLL) {
+#pragma unroll
+		for (int t = 0; t < TRIPS; ++t) trip();
+	} else {
+		int trips = TRIPS;
+		asm volatile("" : "+s"(trips));               // opaque bound: a loop, not four copies of the body
+		for (int t = 0; t < trips; ++t) trip();
 	}
 	// not converged: more trips; b < -0.9999: the reference re-evaluates erfinv at the clamped argument
 	rare.flag(R_TRIPS, !done);
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 
 namespace djbk {
 
-// sample / evalp_is of a Beckmann lobe; same contract as launch_sample (djb_kernels_eval.hip), which forwards here
+// sample / evalp_is (ideal, Schlick or unpolarized Fresnel) of a Beckmann lobe; same contract as launch_sample (djb_kernels_eval.hip), which forwards here
 hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p, long long n, const float *u1, const float *u2,
                                   uint32_t s1, uint32_t s2, unsigned long long start, const View &o, const View &out_i,
                                   const View *out_w, float *out_pdf)
@@ -363,7 +368,7 @@ hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p,
 	if (b.fr.kind == FR_IDEAL) DJB_LAUNCH_S2(true, FR_IDEAL);
 	if (b.fr.kind == FR_SCHLICK) DJB_LAUNCH_S2(true, FR_SCHLICK);
 	if (b.fr.kind == FR_UNPOLARIZED) DJB_LAUNCH_S2(true, FR_UNPOLARIZED);
-	DJB_LAUNCH_S2(true, -1);
+	return hipErrorInvalidValue;           // evalp_is with a run-time Fresnel kind: launch_sample keeps those on k_sample
 #undef DJB_LAUNCH_S2
 #undef DJB_LAUNCH_S
 }

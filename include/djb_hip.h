@@ -152,8 +152,9 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * pairs that sit next to a float rounding boundary, re-evaluated by a second kernel); both give the same bits, the
  * option exists to verify that. */
        DJB_OPT_UTIA_EXACT_ONLY = 5,
-/* DJB_OPT_CONTRACT_1E5 = 1 (off by default): dense device-resident GGX eval / evalp / pdf batches (ideal or schlick Fresnel,
- * f0 >= 0.01; params without mean-normal offset, |rho| <= 0.9) are evaluated inside the VALUE contract of the north star --
+/* DJB_OPT_CONTRACT_1E5 = 1 (off by default): dense device-resident eval / evalp / pdf batches of GGX and Beckmann (ideal or
+ * schlick Fresnel, f0 >= 0.01; params without mean-normal offset, |rho| <= 0.9) and of ABC (one ior > 1, 0 <= B < 1e12,
+ * 1e-3 <= C <= 16: every published row) are evaluated inside the VALUE contract of the north star --
  * every result within 1e-5 relative of the reference's, zeros exactly where the reference returns zeros -- instead of
  * bit-identically: reciprocal / rsqrt instructions and merged denominators in place of the reference's 15 correctly
  * rounded divisions, pairs whose reference value is ill-conditioned re-done by the bit-exact code (two tiers, as for

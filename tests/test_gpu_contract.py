@@ -174,3 +174,62 @@ def test_contract_random_setups(gpu_ctx):
         worst = max(worst, r["max_rel_eval"], r["max_rel_pdf"])
     print(f"\ncontract fuzz: worst relative difference over 60 random set-ups {worst:.3e}")
     assert worst <= RTOL
+
+
+# ---------------------------------------------------------------------------------------------- ABC (abc::eval)
+def test_contract_abc_all_materials_selftest(gpu_ctx):
+    """The ABC fast path (k_ct_fast_v4<ABC>) against the bit-exact per-pair code on the device: the 100 published rows x
+    the five input families, 2^22 generated pairs each (B reaches 8e6, C 2.7, ior 1.04 .. 100)."""
+    worst, t2 = 0.0, 0
+    for k, name in enumerate(synth.MERL_NAMES):
+        b = djb.abc(name, ctx=gpu_ctx)
+        for family in range(5):
+            r = djb.selftest_contract(b, None, n=1 << 22, seed=300 + 5 * k + family, family=family, ctx=gpu_ctx)
+            assert r["pairs"] == 1 << 22
+            assert r["zero_mismatch"] == 0 and r["outside_1e5"] == 0, (name, family, r)
+            worst, t2 = max(worst, r["max_rel_eval"], r["max_rel_pdf"]), max(t2, r["tier2"])
+    print(f"\ncontract abc: worst relative difference over 100 materials x 5 families {worst:.3e}, tier-2 share <= {t2 / (1 << 22):.2e}")
+    assert worst <= RTOL
+
+
+def test_contract_abc_vs_oracle_and_domain(ct_ctx, oracle):
+    """eval / evalp / pdf / fused through the batch API (dense device views -> the two-tier kernels) against the oracle,
+    hostile inputs included; rows outside the fast path's domain (ior <= 1, an exponent beyond 16) and sgd objects stay
+    on the bit-exact kernels."""
+    from dj_brdf_amd import param_tables
+    rng = np.random.default_rng(5)
+    n = N                                                         # rows of a [3, n] tensor stay 16-byte aligned: the two-tier kernels run
+    i, o = synth.directions_aos(n, synth.SEED_I), synth.directions_aos(n, synth.SEED_O)
+    i[:2000, 2] *= -1; o[2000:4000, 2] *= -1                      # below the horizon -> zeros
+    i[4000:4100] = np.nan; o[4100:4200, 0] = np.inf
+    i[4200:6200] = o[4200:6200] * np.float32([-1, -1, 1]) + rng.normal(0, 1e-4, (2000, 3)).astype(np.float32)   # theta_d -> 90 deg
+    o[6200:8200] = i[6200:8200]                                   # h = i = o
+    i[8200:9200] *= np.float32(3.0)                               # un-normalised
+    di, do = soa(i), soa(o)
+    worst = 0.0
+    for name in ("gold-metallic-paint", "alum-bronze", "black-fabric", "chrome", "white-marble", "yellow-plastic", "pearl-paint", "teflon"):
+        b, ob = djb.abc(name, ctx=ct_ctx), oracle.abc(name)
+        for mode in ("eval", "evalp", "pdf"):
+            got = getattr(b, mode)(di, do).cpu().numpy()
+            got = got.T if got.ndim == 2 else got
+            worst = max(worst, check_contract(f"abc/{name}/{mode}", got, oracle.eval(ob, i, o, None, mode)))
+    print(f"\ncontract abc vs oracle: worst relative difference {worst:.3e}")
+    assert worst > 0.0, "the value-contract kernels did not run (results are bit-identical to the oracle)"
+    # outside the domain: bit-exact
+    row = np.array(param_tables.abc_params("gold-metallic-paint"), np.float64)
+    djb.set_contract_1e5(ct_ctx, False)
+    for what in ("ior", "exponent", "sgd"):
+        if what == "sgd":
+            mk = lambda: djb.sgd("gold-metallic-paint", ctx=ct_ctx)
+        else:
+            r2 = row.copy()
+            if what == "ior": r2[8] = 0.9
+            else: r2[7] = 40.0
+            mk = lambda r2=r2: djb.abc.from_params(r2, ctx=ct_ctx)
+        want = mk().eval(di, do)
+        djb.set_contract_1e5(ct_ctx, True)
+        got = mk().eval(di, do)
+        djb.set_contract_1e5(ct_ctx, False)
+        same = (got.view(__import__("torch").int32) == want.view(__import__("torch").int32)) | (got.isnan() & want.isnan())
+        assert bool(same.all()), f"contract mode changed a result outside its domain ({what})"
+    djb.set_contract_1e5(ct_ctx, True)

@@ -8,7 +8,7 @@ from dj_brdf_amd import djb, synth, _lib
 ctx = djb.default_context(0); lib = _lib.load()
 if os.environ.get("DJB_KIND_RATES_CONTRACT"):      # DJB_OPT_CONTRACT_1E5: the ggx / beckmann ideal and schlick legs run the value-contract kernels
     djb.set_contract_1e5(ctx, True)
-    print("# DJB_OPT_CONTRACT_1E5 on (ggx / beckmann with ideal or schlick Fresnel take the two-tier value-contract kernels; the rest is unaffected)")
+    print("# DJB_OPT_CONTRACT_1E5 on (ggx / beckmann with ideal or schlick Fresnel and abc take the two-tier value-contract kernels; the rest is unaffected)")
 n = 100_000_000
 i = djb.gen_directions(n, synth.SEED_I, ctx=ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
 rng = np.random.default_rng(11)

@@ -12,7 +12,8 @@
 // `rare` flag raised wherever the reference would have left the common path (any arm above, a fifth trip, a
 // degenerate direction).  Flagged samples are not stored; their inputs go to a per-wave queue in LDS, and whenever a
 // wave has collected 64 of them it runs the full per-sample code (sample_one, the one the one-kernel form runs) on
-// them as one dense wave.  ~1.3 % of the samples take that route on the bench distribution.  Nothing is approximated
+// them as one dense wave.  1.35 % of the samples take that route on the bench distribution (by cause: profiles/r03/
+// beckmann_sample_two_path.txt, section 3; the DJB_EXP_RARE_COUNT build of this file counts them).  Nothing is approximated
 // anywhere: both paths are the reference's arithmetic, the split is by control flow only.
 #include "djb_internal.hpp"
 #include <stdio.h>
@@ -44,7 +45,7 @@ struct Rare {
 __device__ unsigned long long g_rare[2 + R_SITES];
 #endif
 
-// Measured on 2.5e8 and 1e9 samples (profiles/r03/beckmann_sample_grid.txt): one workgroup per resident slot (256 CUs x 5)
+// Measured on 2.5e8 and 1e9 samples (profiles/r03/beckmann_sample_two_path.txt, section 4): one workgroup per resident slot (256 CUs x 5)
 // is 19 % slower than ~48 tiles per workgroup -- the slots do not finish together -- and one tile per workgroup 60 % slower
 // (table staging and a nearly empty queue drain per tile).
 constexpr long long TILES_PER_WG = 48;

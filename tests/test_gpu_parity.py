@@ -179,6 +179,13 @@ def test_beckmann_sampler_deferred_paths(gpu_ctx, oracle, p):
         assert _same_bits(gi, wi).all(), f"evalp_is direction {layout} {p}"
         assert _same_bits(w, ww).all(), f"evalp_is weight {layout} {p}"
         assert _same_bits(pdf, wpdf).all(), f"evalp_is pdf {layout} {p}"
+    # on-chip uniforms (sample_rng), dense and strided device batches: the same bits as the array path fed with gen_uniforms
+    n = o.shape[0]
+    g1, g2 = djb.gen_uniforms(n, synth.SEED_U1, ctx=gpu_ctx), djb.gen_uniforms(n, synth.SEED_U2, ctx=gpu_ctx)
+    od, os_ = torch.as_tensor(np.ascontiguousarray(o.T), device=dev), torch.as_tensor(o, device=dev)
+    ref = g.sample(g1, g2, od, up)
+    assert torch.equal(g.sample_rng(synth.SEED_U1, synth.SEED_U2, od, up).view(torch.int32), ref.view(torch.int32)), f"sample_rng dense {p}"
+    assert torch.equal(g.sample_rng(synth.SEED_U1, synth.SEED_U2, os_, up).T.contiguous().view(torch.int32), ref.view(torch.int32)), f"sample_rng strided {p}"
     # short device batches: one partial wave, one wave + 1, a workgroup + 1
     for m in (1, 63, 65, 97, 257, 1025):
         oo = torch.as_tensor(np.ascontiguousarray(o[-m:].T), device=dev)

@@ -802,18 +802,18 @@ try {
 	return DJB_OK;
 }
 DJB_ABI_CATCH
-djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, unsigned long long *counters10)
+djb_status djb_selftest_guarded_math(djb_ctx *ctx, int64_t n, uint32_t seed, unsigned long long *counters12)
 try {
 	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
-	if (!counters10) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (!counters12) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	unsigned long long *d = nullptr;
-	HIP_TRY(hipMalloc((void **)&d, 80));
-	hipError_t e = hipMemsetAsync(d, 0, 80, ctx->stream);
+	HIP_TRY(hipMalloc((void **)&d, 96));
+	hipError_t e = hipMemsetAsync(d, 0, 96, ctx->stream);
 	if (e == hipSuccess) e = djbk::launch_guard_selftest(ctx->stream, n, seed, d);
-	if (e == hipSuccess) e = hipMemcpyAsync(counters10, d, 80, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(counters12, d, 96, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	(void)hipFree(d);
 	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));

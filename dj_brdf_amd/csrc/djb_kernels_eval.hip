@@ -378,10 +378,11 @@ __global__ __launch_bounds__(BLOCK) void k_gen_uni(long long n, uint32_t seed, u
 // counters: [0] inversesqrt mismatches, [1] reciprocal mismatches (both must be 0),
 //           [2] inversesqrt exact-path fallbacks, [3] reciprocal fallbacks,
 //           [4] sRGB-decode (pow 2.4) mismatches (must be 0), [5] sRGB-decode fallbacks,
-//           [6] fdiv_r(a, b, 1/b) != a / b (must be 0), [7] its IEEE fallbacks (sub-normal quotients).
+//           [6] fdiv_r(a, b, 1/b) != a / b (must be 0), [7] its IEEE fallbacks (sub-normal quotients),
+//           [8] float(sqrt(a)) mismatches, [9] its fallbacks, [10] div_to_f32(num, den) != float(num / den) (must be 0), [11] its fallbacks.
 __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t seed, unsigned long long *counters)
 {
-	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0, bad_p = 0, fb_p = 0, bad_q = 0, fb_q = 0, bad_s = 0, fb_s = 0;
+	unsigned long long bad_r = 0, bad_d = 0, fb_r = 0, fb_d = 0, bad_p = 0, fb_p = 0, bad_q = 0, fb_q = 0, bad_s = 0, fb_s = 0, bad_v = 0, fb_v = 0;
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		uint32_t h0 = hash_u32(seed, (uint64_t)k, 0), h1 = hash_u32(seed, (uint64_t)k, 1), h2 = hash_u32(seed, (uint64_t)k, 2);
@@ -423,12 +424,27 @@ __global__ __launch_bounds__(BLOCK) void k_guard_selftest(long long n, uint32_t 
 			float q0 = F(D(a_num) * (1.0 / D(bden)));
 			if (!(fabsf(q0) >= 1.17549435e-38f) && a_num != 0.0f) ++fb_q;
 		}
+		// float(num / den) of two doubles: the operands of ggx_qf2_radial's addition forms (quotients a, b in [0, 1.001]:
+		// -(a + b) / (1 - a b), (1 + a b) / (a - b)) three times out of four, else the random q above over a random double
+		{
+			const float qa = (float)(h0 >> 8) * 5.9664249e-08f, qb = (float)(h2 >> 8) * 5.9664249e-08f;
+			double num, den;
+			if ((k & 3) == 1) { num = D(-(qa + qb)); den = 1.0 - D(qa * qb); }
+			else if ((k & 3) == 2) { num = 1.0 + D(qa * qb); den = D(qa - qb); }
+			else if ((k & 3) == 3) { num = D(qa + qb); den = 1.0 - D(qa * qb); }
+			else { num = q; den = __longlong_as_double(__double_as_longlong(D(x)) ^ (long long)(h1 >> 2)); }
+			const float want = F(num / den), got = div_to_f32(num, den);
+			if (!(got == want || (got != got && want != want))) ++bad_v;
+			const double qq = num * recip_fast(den), aqq = qq < 0 ? -qq : qq;
+			if (near_f32_midpoint(qq) || !(aqq > 1e-30 && aqq < 1e30)) ++fb_v;
+		}
 	}
 	atomicAdd(&counters[0], bad_r); atomicAdd(&counters[1], bad_d);
 	atomicAdd(&counters[2], fb_r); atomicAdd(&counters[3], fb_d);
 	atomicAdd(&counters[4], bad_p); atomicAdd(&counters[5], fb_p);
 	atomicAdd(&counters[6], bad_q); atomicAdd(&counters[7], fb_q);
 	atomicAdd(&counters[8], bad_s); atomicAdd(&counters[9], fb_s);
+	atomicAdd(&counters[10], bad_v); atomicAdd(&counters[11], fb_v);
 }
 
 // bins x bins histogram over [-1,1]^2: LDS atomics, one global flush per workgroup

@@ -1087,11 +1087,11 @@ def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):
     """Self-test of the kernels' guarded fp64 shortcuts against the exact double sequences on n
     hash-generated inputs (see djb_selftest_guarded_math).  Mismatch counters must be 0."""
     ctx = ctx or default_context()
-    c = (C.c_ulonglong * 10)()
+    c = (C.c_ulonglong * 12)()
     _lib.check(_lib.load().djb_selftest_guarded_math(ctx._h, C.c_int64(n), C.c_uint32(seed), c))
     return {"rsqrt_mismatch": c[0], "recip_mismatch": c[1], "rsqrt_fallback": c[2], "recip_fallback": c[3],
             "srgb_mismatch": c[4], "srgb_fallback": c[5], "fdiv_mismatch": c[6], "fdiv_fallback": c[7],
-            "sqrt_mismatch": c[8], "sqrt_fallback": c[9]}
+            "sqrt_mismatch": c[8], "sqrt_fallback": c[9], "div_mismatch": c[10], "div_fallback": c[11]}
 
 
 def selftest_libm(fn: str, x, y=None, ctx: Optional[Context] = None):

@@ -319,11 +319,12 @@ djb_status djb_merl_guard_attack(djb_ctx *, int64_t n, const djb_vec3_view *i, c
 
 /* self-test of the kernels' guarded fp64 shortcuts (float(1/sqrt(double x)), float(1/q), the sRGB
  * decode float(pow(t, 2.4f))) against the exact double sequences on n hash-generated inputs:
- * counters[10] = {rsqrt mismatches, reciprocal mismatches, rsqrt exact-path fallbacks, reciprocal
+ * counters[12] = {rsqrt mismatches, reciprocal mismatches, rsqrt exact-path fallbacks, reciprocal
  * fallbacks, sRGB-decode mismatches, sRGB-decode fallbacks, mismatches of the exact division through a double
- * reciprocal (float(double(a) * R) vs a / b), its IEEE fallbacks, mismatches of float(sqrt(a)) for a double a, its fallbacks};
+ * reciprocal (float(double(a) * R) vs a / b), its IEEE fallbacks, mismatches of float(sqrt(a)) for a double a, its fallbacks,
+ * mismatches of float(num / den) for two doubles (the quotient of GGX's quantile function), its fallbacks};
  * every mismatch count must be 0. */
-djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters10);
+djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters12);
 /* the DJB_OPT_CONTRACT_1E5 fast path against the bit-exact per-pair code on n generated pairs (family 0: the bench
  * distribution; 1: grazing with opposite azimuths; 2: near-normal incidence; 3: o at the horizon; 4: un-normalised):
  * max_rel2 = {max relative difference of the eval rgb, of the pdf} over the fast-path pairs, counters4 = {pairs, pairs

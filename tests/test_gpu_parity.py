@@ -450,6 +450,8 @@ def test_guarded_fp64_shortcuts_are_exact(gpu_ctx):
     assert 0 < r["recip_fallback"] < 2_000_000_000 * 1e-4
     # float(sqrt(a)) of a double (1 - c^2: the sin of the stretched view direction, Beckmann's sigma): round 3
     assert r["sqrt_mismatch"] == 0 and 0 < r["sqrt_fallback"] < 2_000_000_000 * 1e-4
+    # float(num / den) of two doubles (the one quotient of GGX's quantile function, djb_device.hpp div_to_f32): round 3
+    assert r["div_mismatch"] == 0 and 0 < r["div_fallback"] < 2_000_000_000 * 1e-3
 
 
 def test_microfacet_mutators(gpu_ctx, oracle, dirs):

@@ -139,10 +139,36 @@ DJB_DEV float cos_f(float x) { return F(hl_cos(D(x))); }
 DJB_DEV float sin_f(float x) { return F(hl_sin(D(x))); }
 DJB_DEV float tan_f(float x) { return F(hl_tan(D(x))); }
 DJB_DEV float acos_f(float x) { return F(hl_acos(D(x))); }
+#if defined(DJB_HOST_MATH)
 DJB_DEV float acos_u_f(float c) { return F(2.0 * hl_acos(D(c)) / DJB_PI); }                    // dj_brdf.h:1341 (spline fresnel)
 DJB_DEV float acos_u32_f(float c) { return F(D(2.0f) * hl_acos(D(c)) / D(F(DJB_PI))); }       // dj_brdf.h:2158 (tabular sigma)
 DJB_DEV float atan_squ_f(float r) { return F(sqrt(D(2.0f) * atan(D(r)) / D(F(DJB_PI)))); }  // dj_brdf.h:2152 (tabular p22)
 DJB_DEV float atan_u_f(float r) { return F(atan(D(r)) * D(2.0f) / D(F(DJB_PI))); }          // dj_brdf.h:2165 (tabular cdf)
+#else
+// Device: the same four maps without their fp64 divisions by pi / float(pi).  num * RN(1 / c) is within 1.5 * 2^-52 of the
+// IEEE quotient num / c, so it (or, for atan_squ, its square root: another 2^-52) rounds to the same float unless it sits
+// next to a float rounding boundary (near_f32_midpoint, 256 ulp64 either side), where the reference's own expression
+// decides.  Like every site they are swept over all 2^32 inputs against the host's values (tools/exhaustive_trig.py).
+DJB_DEV bool near_f32_midpoint(double y, int width = 256);
+DJB_DEV double sqrt_fast(double a);
+DJB_DEV float div_c_to_f32(double num, double c, double rc)
+{
+	const double q = num * rc, aq = q < 0 ? -q : q;
+	if (__builtin_expect(near_f32_midpoint(q) || !(aq > 1e-30 && aq < 1e30), 0)) return F(num / c);
+	return F(q);
+}
+DJB_DEV float acos_u_f(float c) { return div_c_to_f32(2.0 * hl_acos(D(c)), DJB_PI, 0x1.45f306dc9c883p-2); }                    // dj_brdf.h:1341
+DJB_DEV float acos_u32_f(float c) { return div_c_to_f32(D(2.0f) * hl_acos(D(c)), D(F(DJB_PI)), 0x1.45f306446f9b4p-2); }        // dj_brdf.h:2158
+DJB_DEV float atan_u_f(float r) { return div_c_to_f32(atan(D(r)) * D(2.0f), D(F(DJB_PI)), 0x1.45f306446f9b4p-2); }             // dj_brdf.h:2165
+DJB_DEV float atan_squ_f(float r)                                                                                                 // dj_brdf.h:2152
+{
+	const double num = D(2.0f) * atan(D(r));
+	const double v = num * 0x1.45f306446f9b4p-2;
+	const double g = sqrt_fast(v);
+	if (__builtin_expect(near_f32_midpoint(g) || !(v > 1e-30 && v < 1e30), 0)) return F(sqrt(num / D(F(DJB_PI))));
+	return F(g);
+}
+#endif
 DJB_DEV float atan_sqrt_f(float x) { return F(atan(sqrt(D(x)))); }                          // dj_brdf.h:2285 (aniso p22)
 DJB_DEV float beck_qf_f(float u) { return F(sqrt(-log(1.0 - D(u)))); }                      // dj_brdf.h:1887 (beckmann qf)
 DJB_DEV float acos_deg_f(float z) { return F(D(F(180.0 / DJB_PI)) * hl_acos(D(z))); }          // dj_brdf.h:1633 (utia)
@@ -215,6 +241,8 @@ DJB_DEV float inversesqrt_(float x) { return F(1.0 / sqrt(D(x))); }
 DJB_DEV float recip_to_f32(double q) { return F(1.0 / q); }
 DJB_DEV float sqrt_to_f32(double a) { return F(sqrt(a)); }
 DJB_DEV float div_to_f32(double num, double den) { return F(num / den); }
+DJB_DEV float div_pi_to_f32(double num) { return F(num / DJB_PI); }
+DJB_DEV float inv_sqrt_pi_f() { return inversesqrt_(F(DJB_PI)); }
 #else
 // ---- guarded fast paths for float(<double expression>) -----------------------------------------
 // The reference rounds a correctly-rounded double result e to float.  A cheaper double y with
@@ -223,7 +251,7 @@ DJB_DEV float div_to_f32(double num, double den) { return F(num / den); }
 // tests that (256 ulp64 either side; probability 2^-20), and the caller then takes the exact path.
 // y comes from v_rsq_f64 / v_rcp_f64 refined by two Newton steps (error <= a few 2^-53 for any
 // seed accuracy >= 2^-14); e itself is within 2^-52 of the true value.
-DJB_DEV bool near_f32_midpoint(double y, int width = 256)
+DJB_DEV bool near_f32_midpoint(double y, int width)
 {
 	// the 29 mantissa bits a float does not keep sit in the low word: 32-bit arithmetic (4 VALU instead of ~10)
 	const int d = (int)((unsigned int)__double2loint(y) & 0x1FFFFFFFu) - 0x10000000;
@@ -273,6 +301,16 @@ DJB_DEV float div_to_f32(double num, double den)
 		return F(num / den);
 	return F(q);
 }
+// float(num / pi): num * RN(1 / pi) is within 1.5 * 2^-52 of the IEEE quotient -- same guard, no division at all
+DJB_DEV float div_pi_to_f32(double num)
+{
+	const double q = num * 0x1.45f306dc9c883p-2;
+	const double aq = q < 0 ? -q : q;
+	if (__builtin_expect(near_f32_midpoint(q) || !(aq > 1e-30 && aq < 1e30), 0)) return F(num / DJB_PI);
+	return F(q);
+}
+// inversesqrt(float(pi)) = float(1.0 / sqrt(double(3.14159274f))): a constant (the compiler does not fold v_rsq_f32 of a literal)
+DJB_DEV float inv_sqrt_pi_f() { return 0x1.20dd74p-1f; }
 // float(sqrt(a)) for a double a that is not a float (1 - c^2 and the like): v_rsq_f32 seed, two coupled Newton steps
 // (g -> sqrt(a), h -> 1 / (2 sqrt(a))): 7 fp64 operations instead of the ~17 + v_rsq_f64 of the IEEE expansion
 DJB_DEV double sqrt_fast(double a)

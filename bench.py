@@ -436,26 +436,34 @@ def main():
         def files_leg(dense):
             djb.set_fit_files_dense(ctx, dense)
             try:
-                merl_params.fit_files_on(ctx, all_mine[:2])        # warm-up: allocations, page cache of the first files
+                merl_params.fit_files_on(ctx, all_mine[:2])        # page cache of the first files, kernels loaded
+                barrier()
+                # first call of this shape on the context: also starts the reader threads and pins the staging buffer
+                t_files = time.perf_counter()
+                merl_params.fit_files_on(ctx, all_mine)
+                barrier()
+                first = time.perf_counter() - t_files
+                time.sleep(0.1)                                    # the previous call's mappings are released off the critical path
                 barrier()
                 t_files = time.perf_counter()
-                _, _, tim = merl_params.fit_files_on(ctx, all_mine)
+                _, _, tim = merl_params.fit_files_on(ctx, all_mine)   # the same job again: every file gathered, uploaded and fitted again
                 barrier()
                 wall = time.perf_counter() - t_files
             finally:
                 djb.set_fit_files_dense(ctx, False)
-            tt = torch.tensor([wall, tim["total_s"], tim["load_s"], tim["fit_s"]], dtype=torch.float64, device=red_dev)
+            tt = torch.tensor([wall, tim["total_s"], tim["load_s"], tim["fit_s"], first], dtype=torch.float64, device=red_dev)
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            wall, f_total, f_load, f_fit = (float(x) for x in tt)
-            return {"wall_ms": wall * 1e3, "value": 100 / wall, "unit": "materials/s",
+            wall, f_total, f_load, f_fit, first = (float(x) for x in tt)
+            return {"wall_ms": wall * 1e3, "first_call_wall_ms": first * 1e3, "value": 100 / wall, "unit": "materials/s",
                     "pipeline_ms": {"total": f_total * 1e3, "load": f_load * 1e3, "fit": f_fit * 1e3},
                     "bytes_read_this_rank": tim["bytes"]}
         sparse, dense = files_leg(False), files_leg(True)
         fitfiles = {"materials": 100, "n_gpus": world, "scaling": "strong", **sparse,
                     "what": "end to end, files -> alphas, max over ranks: table indices a tabular(merl, 90) fit reads computed on the GPU, "
                             "worker threads gather those 5 545 x 3 doubles per file from the mapped files (page cache warm), "
-                            "97 KB per material -> HBM, one k_fit launch per rank",
+                            "97 KB per material -> HBM, one k_fit launch per rank; wall_ms is the second call of this shape on the context "
+                            "(reader threads parked, staging buffer pinned, slot plan cached), first_call_wall_ms the one that set those up",
                     "dense_upload": {**dense, "what": "same job with every 35 MB table uploaded and converted in full (pread -> 4 MiB pinned "
                                                       "chunk ring -> H2D -> k_merl_convert), as in round 1: same alphas"}}
 

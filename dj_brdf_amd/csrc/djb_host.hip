@@ -384,6 +384,7 @@ try {
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+	if (ctx->loader_state && ctx->loader_state_free) ctx->loader_state_free(ctx->loader_state);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->wl_ev) (void)hipEventDestroy(ctx->wl_ev);
 	if (ctx->wl_host) (void)hipHostFree(ctx->wl_host);
@@ -736,6 +737,7 @@ djb_status set_error(djb_status st, const char *fmt, ...)
 }
 
 int ctx_option_fit_files_dense(djb_ctx *ctx) { return ctx->fit_files_dense; }
+void **ctx_loader_state(djb_ctx *ctx, void (*free_fn)(void *)) { ctx->loader_state_free = free_fn; return &ctx->loader_state; }
 
 // per-slot texels of the file-fit pipeline (see djb_loader.hip): a source for djb_fit_brdf_batch only
 djb_status wrap_merl_slots(djb_ctx *ctx, djbdev::MerlTexel *slots, djb_brdf **out)

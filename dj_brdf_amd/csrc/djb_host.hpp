@@ -38,6 +38,10 @@ struct djb_ctx {
 	int merl_exact_only;      // DJB_OPT_MERL_EXACT_ONLY
 	int aniso_qf2_aligned = 0; // DJB_OPT_ANISO_QF2_ALIGNED
 	int fit_files_dense = 0;   // DJB_OPT_FIT_FILES_DENSE
+	// what djb_fit_merl_files keeps between calls (djb_loader.hip: slot plans, a pinned / device buffer pair, its worker threads);
+	// created on first use under call_mu, released by djb_ctx_destroy through loader_state_free
+	void *loader_state = nullptr;
+	void (*loader_state_free)(void *) = nullptr;
 	int utia_exact_only = 0;   // DJB_OPT_UTIA_EXACT_ONLY: utia eval batches run k_eval<UTIA> (one kernel, exact fall-backs inline) instead of the two tiers
 	// tier-2 worklist of the two-tier kernels: capacity as a share of the batch.  2 % covers the bench distribution 8x over;
 	// after a call whose list overflowed (hostile distributions: 6 % of uniformly drawn BINS sit in the reference's snap

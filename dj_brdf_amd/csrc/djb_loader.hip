@@ -21,6 +21,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -46,6 +48,8 @@ djb_status wrap_merl_table(djb_ctx *ctx, djbdev::MerlTexel *table, djb_brdf **ou
 // the same for a per-slot (sparse) texel array of the file-fit pipeline (djbdev::Brdf::merl_sparse)
 djb_status wrap_merl_slots(djb_ctx *ctx, djbdev::MerlTexel *slots, djb_brdf **out);
 int ctx_option_fit_files_dense(djb_ctx *ctx);
+// the slot of the context that holds this file's LoaderState (freed by djb_ctx_destroy through free_fn)
+void **ctx_loader_state(djb_ctx *ctx, void (*free_fn)(void *));
 hipStream_t ctx_stream(djb_ctx *ctx);
 int ctx_device(djb_ctx *ctx);
 // every entry point that enqueues on the ctx stream holds the context's call mutex (see djb_ctx)
@@ -138,6 +142,85 @@ void reap_mappings(std::vector<std::vector<std::pair<void *, size_t>>> &&kept)
 	}
 }
 
+// ---- what the sparse form keeps between calls, per context (all of it used under the context's call mutex) -----
+// A call on 100 files spends ~2.2 ms gathering; creating 31 threads (0.6-1.2 ms before the last one starts), pinning a
+// 6.6 MB buffer (0.4-0.9 ms), computing the slot plan on the GPU (0.27 ms) and releasing all of it again used to cost as
+// much once more: the threads now park between calls, the buffers grow and stay, the plan is cached per resolution.
+class WorkerPool {
+	std::vector<std::thread> th;
+	std::mutex mu;
+	std::condition_variable cv, done_cv;
+	const std::function<void()> *job = nullptr;
+	unsigned long long gen = 0;
+	int want = 0, pending = 0;
+	bool stop = false;
+	void loop(int id)
+	{
+		unsigned long long seen = 0;
+		for (;;) {
+			const std::function<void()> *fn = nullptr;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return stop || gen != seen; });
+				if (stop) return;
+				seen = gen;
+				if (id < want) fn = job;
+			}
+			if (fn) {
+				(*fn)();                                  // never throws (the job catches)
+				std::lock_guard<std::mutex> lk(mu);
+				if (--pending == 0) done_cv.notify_all();
+			}
+		}
+	}
+public:
+	// runs fn on `n` threads (the caller is one of them) and returns when all have returned
+	void run(int n, const std::function<void()> &fn)
+	{
+		int helpers = n - 1;
+		while ((int)th.size() < helpers) {
+			try { th.emplace_back(&WorkerPool::loop, this, (int)th.size()); } catch (...) { helpers = (int)th.size(); break; }   // fewer threads, same result
+		}
+		if (helpers > 0) {
+			std::lock_guard<std::mutex> lk(mu);
+			job = &fn; want = helpers; pending = helpers; ++gen;
+		}
+		if (helpers > 0) cv.notify_all();
+		fn();
+		if (helpers > 0) {
+			std::unique_lock<std::mutex> lk(mu);
+			done_cv.wait(lk, [&] { return pending == 0; });
+			job = nullptr;
+		}
+	}
+	~WorkerPool()
+	{
+		{ std::lock_guard<std::mutex> lk(mu); stop = true; }
+		cv.notify_all();
+		for (std::thread &t : th) t.join();
+	}
+};
+struct LoaderState {
+	std::map<int, djbfile::SlotPlan> plans;              // by fit resolution
+	djbdev::MerlTexel *host = nullptr, *dev = nullptr;   // [file][slot] texels: pinned staging and its HBM copy, grow-only
+	size_t bytes = 0;
+	int device = 0;
+	WorkerPool pool;
+	~LoaderState()
+	{
+		(void)hipSetDevice(device);
+		if (host) (void)hipHostFree(host);
+		if (dev) (void)hipFree(dev);
+	}
+};
+void free_loader_state(void *p) { delete (LoaderState *)p; }
+LoaderState *loader_state(djb_ctx *ctx)
+{
+	void **slot = djbk::ctx_loader_state(ctx, free_loader_state);
+	if (!*slot) { LoaderState *ls = new LoaderState(); ls->device = djbk::ctx_device(ctx); *slot = ls; }
+	return (LoaderState *)*slot;
+}
+
 // ---- the sparse form: fetch only what the fit reads ----------------------------------------------------------
 // djb::tabular(merl, res) evaluates its source at a fixed set of directions (djb_device.hpp: fit_merl_slot_count):
 // cnt back-scattering configurations + the (theta_d, theta_h) Fresnel pairs, 5 545 of a MERL file's 4 374 000
@@ -153,9 +236,9 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 	hipStream_t stream = djbk::ctx_stream(ctx);
 	const double t_begin = now_s();
 	const int n_slots = djbk::fit_merl_slots(res);
-	// ---- which table entries does a fit at this resolution read?  (device code, once per call: 8 k indices)
-	djbfile::SlotPlan plan;
-	{
+	LoaderState *ls = loader_state(ctx);
+	// ---- which table entries does a fit at this resolution read?  (device code, once per context and resolution: 8 k indices)
+	if (!ls->plans.count(res)) {
 		int32_t *d_idx = nullptr;
 		std::vector<int32_t> idx(n_slots);
 		hipError_t e = hipMalloc((void **)&d_idx, sizeof(int32_t) * n_slots);
@@ -165,17 +248,29 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 		if (e == hipSuccess) e = se;
 		if (d_idx) (void)hipFree(d_idx);
 		if (e != hipSuccess) { (void)hipGetLastError(); return djbk::set_error(DJB_ERR_HIP, "djb_error: fit slot indices: %s", hipGetErrorString(e)); }
-		plan = djbfile::make_plan(idx);
+		ls->plans[res] = djbfile::make_plan(idx);
 	}
+	const djbfile::SlotPlan &plan = ls->plans[res];
+	const double t_plan = now_s();
 	// ---- gather: files are independent -> worker threads; results land in one pinned block [file][slot]
-	djbdev::MerlTexel *host = nullptr, *dev = nullptr;
 	const size_t bytes = sizeof(djbdev::MerlTexel) * (size_t)n_slots * n_files;
-	if (hipHostMalloc((void **)&host, bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&dev, bytes) != hipSuccess) {
-		(void)hipGetLastError();
-		if (host) (void)hipHostFree(host);
-		return djbk::set_error(DJB_ERR_HIP, "djb_error: cannot allocate the per-slot tables of %d files", n_files);
+	if (ls->bytes < bytes) {
+		(void)hipStreamSynchronize(stream);
+		if (ls->host) (void)hipHostFree(ls->host);
+		if (ls->dev) (void)hipFree(ls->dev);
+		ls->host = ls->dev = nullptr; ls->bytes = 0;
+		if (hipHostMalloc((void **)&ls->host, bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&ls->dev, bytes) != hipSuccess) {
+			(void)hipGetLastError();
+			if (ls->host) (void)hipHostFree(ls->host);
+			if (ls->dev) (void)hipFree(ls->dev);
+			ls->host = ls->dev = nullptr;
+			return djbk::set_error(DJB_ERR_HIP, "djb_error: cannot allocate the per-slot tables of %d files", n_files);
+		}
+		ls->bytes = bytes;
+		memset(ls->host, 0, bytes);          // slots the fit never evaluates are never written either: they stay zero
 	}
-	memset(host, 0, bytes);
+	djbdev::MerlTexel *host = ls->host, *dev = ls->dev;
+	const double t_alloc = now_s();
 	if (threads < 1) {
 		// measured on the GPU box, 100 files (profiles/r02/fit_files_rates.txt): 1 thread 30 ms, 4: 11.4, 8: 9.8, 16: 10.4
 		// round 3 (mappings released outside the loop; 100 files, profiles/r03/fit_files_rates.txt): 8 threads 6.3 ms, 16: 5.9, 32: 4.1, 64: 4.7
@@ -212,10 +307,7 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 			}
 		}
 	};
-	std::vector<std::thread> pool;
-	for (int t = 1; t < threads; ++t) { try { pool.emplace_back(worker); } catch (...) { break; } }    // fewer threads, same result
-	worker();
-	for (std::thread &t : pool) t.join();
+	ls->pool.run(threads, worker);
 	const double t_loaded0 = now_s();
 	hipError_t e = hipSuccess;
 	if (status == DJB_OK) {
@@ -225,15 +317,16 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 		if (e != hipSuccess) { (void)hipGetLastError(); status = DJB_ERR_HIP; status_msg = std::string("djb_error: upload failed: ") + hipGetErrorString(e); }
 	}
 	const double t_loaded = now_s();
-	(void)t_loaded0;
 	std::vector<djb_brdf *> mats(n_files, nullptr);
 	for (int k = 0; k < n_files && status == DJB_OK; ++k) status = djbk::wrap_merl_slots(ctx, dev + (size_t)k * n_slots, &mats[k]);
 	if (status == DJB_OK && status_msg.empty())
 		status = djb_fit_brdf_batch(ctx, n_files, mats.data(), res, shadow, alpha_beckmann, alpha_ggx, nullptr, nullptr, nullptr, nullptr, nullptr);
 	const double t_end = now_s();
+	if (getenv("DJB_LOADER_TRACE"))
+		fprintf(stderr, "djb_loader: plan %.3f ms, alloc %.3f, gather (%d threads) %.3f, upload %.3f, fit %.3f\n", 1e3 * (t_plan - t_begin),
+		        1e3 * (t_alloc - t_plan), threads, 1e3 * (t_loaded0 - t_alloc), 1e3 * (t_loaded - t_loaded0), 1e3 * (t_end - t_loaded));
 	reap_mappings(std::move(kept));
 	for (djb_brdf *b : mats) if (b) djb_brdf_destroy(b);
-	(void)hipHostFree(host); (void)hipFree(dev);
 	if (status != DJB_OK) return status_msg.empty() ? status : djbk::set_error(status, "%s", status_msg.c_str());
 	if (timing) {
 		timing[0] = t_end - t_begin; timing[1] = t_loaded - t_begin; timing[2] = t_end - t_loaded;

@@ -15,6 +15,7 @@
 // four times (dj_brdf.h:2467-2480), whose summation order is likewise kept.
 #include <cstdlib>
 #include "djb_internal.hpp"
+#include <stdio.h>
 
 using namespace djbdev;
 
@@ -80,6 +81,12 @@ DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o, int slot)
 	return fr;
 }
 
+#ifdef DJB_EXP_FIT_TS            // measurement builds only: wall-clock stamps (100 MHz) of the phase boundaries, last workgroup's thread 0
+__device__ unsigned long long g_fit_ts[16];
+#define DJB_FIT_TS(k_) do { if (tid == 0 && blockIdx.x == gridDim.x - 1) g_fit_ts[k_] = wall_clock64(); } while (0)
+#else
+#define DJB_FIT_TS(k_) do { } while (0)
+#endif
 template <int SRC>
 __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_p, int n_mat, int res, int shadow,
                                                    double *km_scratch, float *ratio_scratch,
@@ -121,6 +128,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	self.n_p22 = res; self.n_sigma = res; self.n_cdf = res; self.n_qf = res;
 	self.merl = nullptr; self.merl_sparse = 0; self.utia = nullptr; self.exp_lds = 0u; self.pow_lds = 0u;
 
+	DJB_FIT_TS(0);
 	// ================================================================ compute_p22_smith (dj_brdf.h:2482-2522)
 	const float dtheta_k = F(sqrt(DJB_PI * 0.5) / D((float)cnt));
 	const float dphi_h = F(DJB_PI / 180.0);
@@ -167,6 +175,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int k = tid; k < res; k += FIT_BLOCK) p22[k] = k < cnt ? F(1e-2 * v0[k]) : 0.0f;
 	__syncthreads();
 
+	DJB_FIT_TS(1);
 	// ================================================================ normalize_p22 (dj_brdf.h:2277-2304)
 	for (int k = tid; k < NTHETA_FIT; k += FIT_BLOCK) {
 		float u = (float)k / (float)NTHETA_FIT;
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int k = tid; k < res; k += FIT_BLOCK) p22[k] *= s_scale;
 	__syncthreads();
 
+	DJB_FIT_TS(2);
 	// ================================================================ compute_sigma (dj_brdf.h:2348-2386)
 	for (int k = tid; k < NPHI_SIGMA; k += FIT_BLOCK)
 		cphid[k] = glibc_cos(D(F(D((float)k / (float)NPHI_SIGMA) * 2.0 * DJB_PI)));
@@ -298,6 +308,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	if (tid == 0) sigma[cnt] = sigma[cnt - 1];
 	__syncthreads();
 
+	DJB_FIT_TS(3);
 	// ================================================================ compute_fresnel (dj_brdf.h:2583-2641)
 	// pair (i, j) runs iff theta_h(j-1) < pi/2 - theta_d(i)   (theta_h(-1) := 0)
 	const int n_pairs = cnt * (cnt + 1);
@@ -360,6 +371,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	if (tid < 3) fres[3 * cnt + tid] = fres[3 * (cnt - 1) + tid];
 	__syncthreads();
 
+	DJB_FIT_TS(4);
 	// ================================================================ compute_cdf (dj_brdf.h:2705-2727)
 	for (int k = tid; k < cnt; k += FIT_BLOCK) {
 		float u = (float)k / (float)cnt;
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	}
 	__syncthreads();
 
+	DJB_FIT_TS(5);
 	// ================================================================ compute_qf (dj_brdf.h:2731-2762)
 	const int qres = cnt * 8;
 	for (int j = tid; j < qres; j += FIT_BLOCK) {
@@ -399,6 +412,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	}
 	__syncthreads();
 
+	DJB_FIT_TS(6);
 	// ================================================================ fits (dj_brdf.h:3133-3184)
 	for (int k = tid; k < NTHETA_FIT; k += FIT_BLOCK) {
 		float u = (float)k / (float)NTHETA_FIT;
@@ -426,6 +440,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		out.fresnel[3 * o] = fres[3 * k]; out.fresnel[3 * o + 1] = fres[3 * k + 1];
 		out.fresnel[3 * o + 2] = fres[3 * k + 2];
 	}
+	DJB_FIT_TS(7);
 }
 
 // the MERL table index each query slot reads (the file pipeline gathers exactly these entries on the host)
@@ -446,6 +461,15 @@ hipError_t launch_fit_kind(hipStream_t s, const Brdf *srcs, const Params &std_p,
 	if (split.parts > 1 && (e = hipMemsetAsync(split.sig_done, 0, sizeof(unsigned int) * 2 * n_mat, s)) != hipSuccess) return e;
 	hipLaunchKernelGGL((k_fit<SRC>), dim3(n_mat * split.parts), dim3(FIT_BLOCK), lds, s, srcs, std_p, n_mat, res, shadow,
 	                   km, ratio, out, split);
+#ifdef DJB_EXP_FIT_TS
+	{
+		unsigned long long h[16];
+		(void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fit_ts), sizeof h);
+		fprintf(stderr, "djb_exp: k_fit phases (us, last workgroup of %d x %d): p22_smith %.1f normalize %.1f sigma %.1f fresnel %.1f cdf %.1f qf %.1f fits %.1f\n",
+		        n_mat, split.parts, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01,
+		        (h[6] - h[5]) * 0.01, (h[7] - h[6]) * 0.01);
+	}
+#endif
 	return hipGetLastError();
 }
 

@@ -13,7 +13,10 @@ out_i = torch.empty((3, n), dtype=torch.float32, device=o.device); out_w = torch
 pdf = torch.empty((n,), dtype=torch.float32, device=o.device)
 vo, vi, vw = djb._Vec(o), djb._Vec(out_i), djb._Vec(out_w)
 p = djb.microfacet.params.elliptic(0.2, 0.5, 0.7)
-for name, b in (("ggx", djb.ggx(ctx=ctx)), ("beckmann", djb.beckmann(ctx=ctx))):
+lobes = [("ggx", djb.ggx(ctx=ctx)), ("beckmann", djb.beckmann(ctx=ctx))]
+if os.environ.get("DJB_SAMPLE_RATES_TABULAR"):      # the fitted lobe the dj_merl / dj_utia plugins sample at render time (nmap scheme)
+    lobes.append(("tabular", djb.tabular(djb.ggx(ctx=ctx), 90, True, ctx=ctx)))
+for name, b in lobes:
     def sample():
         _lib.check(lib.djb_sample_batch(ctx._h, b._h, C.c_int64(n), C.c_void_p(u1.data_ptr()), C.c_void_p(u2.data_ptr()),
                                         C.byref(vo.view), C.byref(p._p), C.byref(vi.view), C.c_int(0)))

@@ -28,6 +28,9 @@ constexpr int NTHETA_FIT = 128;                          // dj_brdf.h:2279, 3135
 constexpr int MAX_PHI_STEPS = 512;
 // columns of the sigma quadrature staged per step (two LDS buffers of cnt x (tile + 1) floats)
 __host__ __device__ inline int sig_tile(int cnt) { return cnt <= 100 ? 64 : 32; }
+#ifndef DJB_FIT_WIDE_TILES
+#define DJB_FIT_WIDE_TILES 1      // 0: measurement builds (the tile width of a sliced sigma pass stays sig_tile)
+#endif
 
 struct LdsPlan {   // byte offsets into dynamic LDS (doubles first: 8-byte aligned)
 	int v0, v1, cphid, cthd;                 // doubles
@@ -229,17 +232,38 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			float theta_k = F(D(tmp) * 0.5 * DJB_PI);
 			ckv[k] = cos_f(theta_k); skv[k] = sin_f(theta_k);
 		}
-		const int T = sig_tile(cnt), TS = T + 4;             // row stride: 16-byte aligned rows for the owners' float4 reads
+		// A workgroup that owns a slice of the rows (parts > 1) needs the tile buffers for that many rows only: the same LDS holds
+		// tiles of two or four times the nodes, i.e. a half or a quarter of the producer / consumer hand-overs (barriers) per row.  Rows are stored relative to
+		// the slice; the bounded-wait fallback below (partners late) walks the other rows in chunks of at most `rcap`.
+		const int rcap = parts > 1 ? (cnt + parts - 1) / parts : cnt;
+		const int T0 = sig_tile(cnt);
+		const int fit4 = rcap * (4 * T0 + 4) <= cnt * (T0 + 4), fit2 = rcap * (2 * T0 + 4) <= cnt * (T0 + 4);
+		const int T = (DJB_FIT_WIDE_TILES && parts > 1) ? (fit4 ? 4 * T0 : fit2 ? 2 * T0 : T0) : T0;
+		const int TS = T + 4;                                // row stride: 16-byte aligned rows for the owners' float4 reads
+		const int BUF = rcap * TS;                           // floats per tile buffer (two of them fit LdsPlan::stile by construction)
 		const int n_sum = ((cnt + 63) / 64) * 64;            // threads [0, n_sum): row owners (whole waves)
 		const int n_prod = FIT_BLOCK - n_sum;                // threads [n_sum, FIT_BLOCK): producers
 		const int a = tid - n_sum, col = a % T, grp = a / T, ngrp = n_prod / T;
 		const int ntiles = (NNODE_SIGMA + T - 1) / T;
 		// rows [r0, r1) of the quadrature; every workgroup of the material runs the same code on its slice
 		auto sigma_rows = [&](int r0, int r1) {
+			// a producer lane serves the same rows k = r0 + grp + j ngrp in every tile: their sin / cos(theta_k) are read once
+			// (registers) instead of twice per row and tile from LDS, and the rows' chains are independent of each other
+			constexpr int RMAX = 8;
+			const int nrows = (r1 - r0 + ngrp - 1) / (ngrp > 0 ? ngrp : 1);              // rows per producer lane, workgroup-uniform
+			const bool held = nrows <= RMAX;
+			float skr[RMAX]; double ckr[RMAX];
+			__syncthreads();                                     // skv / ckv (and, on a re-run, the previous rows' tiles) are complete
+#pragma unroll
+			for (int j = 0; j < RMAX; ++j) {
+				const int k = r0 + grp + j * ngrp;
+				const bool on = held && a >= 0 && grp < ngrp && k < r1;
+				skr[j] = on ? skv[k] : 0.0f; ckr[j] = on ? D(ckv[k]) : 0.0;
+			}
 			auto produce = [&](int t) {
 				const int e = t * T + col;
 				if (a < 0 || grp >= ngrp) return;
-				float *buf = stile + (t & 1) * cnt * TS;
+				float *buf = stile + (t & 1) * BUF - r0 * TS;         // row k of the slice at (k - r0) * TS
 				if (e >= NNODE_SIGMA) {                              // pad the last tile: x + 0.0f == x
 					for (int k = r0 + grp; k < r1; k += ngrp) buf[k * TS + col] = 0.0f;
 					return;
@@ -247,9 +271,21 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 				const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
 				const double cp = cphid[j2], ct = cthd[j1];
 				const float s1 = sh[j1], nd = ndf_tab[e], w = ui[j1];
-				for (int k = r0 + grp; k < r1; k += ngrp) {
-					float kh = F(D(skv[k] * s1) * cp + D(ckv[k]) * ct);
-					buf[k * TS + col] = fmax_(0.0f, kh) * nd * w * s1;
+				if (held) {
+#pragma unroll
+					for (int j = 0; j < RMAX; ++j) {
+						if (j >= nrows) break;                       // uniform
+						const int k = r0 + grp + j * ngrp;
+						if (k < r1) {
+							float kh = F(D(skr[j] * s1) * cp + ckr[j] * ct);
+							buf[k * TS + col] = fmax_(0.0f, kh) * nd * w * s1;
+						}
+					}
+				} else {
+					for (int k = r0 + grp; k < r1; k += ngrp) {
+						float kh = F(D(skv[k] * s1) * cp + D(ckv[k]) * ct);
+						buf[k * TS + col] = fmax_(0.0f, kh) * nd * w * s1;
+					}
 				}
 			};
 			__syncthreads();
@@ -261,7 +297,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 				else if (tid >= r0 && tid < r1) {
 					// the tile's T terms of this row: all loads first (8 x 16 bytes in flight), then the adds in
 					// the reference's order -- a load-add-load-add chain exposes the LDS latency 64 times per tile
-					const float4 *row = (const float4 *)(stile + (t & 1) * cnt * TS + tid * TS);
+					const float4 *row = (const float4 *)(stile + (t & 1) * BUF + (tid - r0) * TS);
 					for (int c = 0; c < T / 4; c += 8) {
 						float4 v[8];
 #pragma unroll
@@ -301,7 +337,10 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 				__threadfence();
 				if (tid < cnt && !(tid >= r0 && tid < r1))
 					sigma[tid] = __uint_as_float(__hip_atomic_load((const unsigned int *)sx + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-			} else { sigma_rows(0, r0); sigma_rows(r1, cnt); }
+			} else {
+				for (int q = 0; q < r0; q += rcap) sigma_rows(q, q + rcap < r0 ? q + rcap : r0);
+				for (int q = r1; q < cnt; q += rcap) sigma_rows(q, q + rcap < cnt ? q + rcap : cnt);
+			}
 		}
 	}
 	__syncthreads();

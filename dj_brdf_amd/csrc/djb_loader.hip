@@ -322,6 +322,16 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 	if (status == DJB_OK && status_msg.empty())
 		status = djb_fit_brdf_batch(ctx, n_files, mats.data(), res, shadow, alpha_beckmann, alpha_ggx, nullptr, nullptr, nullptr, nullptr, nullptr);
 	const double t_end = now_s();
+	if (getenv("DJB_LOADER_TRACE")) {
+		// how scattered is the plan?  distinct 4 KB pages / 64 KB fault-around windows one file's gather touches (3 channel planes)
+		size_t pages = 0, windows = 0; long long lp = -1, lw = -1;
+		for (int ch = 0; ch < 3; ++ch) for (int32_t i : plan.idx) {
+			const long long byte = 12 + 8 * ((long long)i + (long long)ch * MERL_N), pg = byte >> 12, w = byte >> 16;
+			if (pg != lp) { ++pages; lp = pg; }
+			if (w != lw) { ++windows; lw = w; }
+		}
+		fprintf(stderr, "djb_loader: %zu entries per channel on %zu pages / %zu 64-KB windows per file\n", plan.idx.size(), pages, windows);
+	}
 	if (getenv("DJB_LOADER_TRACE"))
 		fprintf(stderr, "djb_loader: plan %.3f ms, alloc %.3f, gather (%d threads) %.3f, upload %.3f, fit %.3f\n", 1e3 * (t_plan - t_begin),
 		        1e3 * (t_alloc - t_plan), threads, 1e3 * (t_loaded0 - t_alloc), 1e3 * (t_loaded - t_loaded0), 1e3 * (t_end - t_loaded));

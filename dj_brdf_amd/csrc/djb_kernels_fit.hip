@@ -120,7 +120,11 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	__shared__ float s_scale;
 
 	const Brdf src = srcs[m];
-	double *kmT = km_scratch + (size_t)blockIdx.x * cnt * cnt;   // kmT[theta_h][theta_o], private to the workgroup
+	// kmT[theta_h][theta_o], private to the workgroup.  It is dead before the sigma pass fills ndf_tab, so when it fits there
+	// (res 90: 63 368 of 64 800 bytes) it lives in LDS: the four matvecs of the power iteration -- 89 lanes, 89 dependent
+	// fp64 multiply-adds each -- read it at LDS latency instead of the L2's.
+	const bool km_lds = (size_t)cnt * cnt * sizeof(double) <= (size_t)NNODE_SIGMA * sizeof(float) && (P.ndf & 7) == 0;
+	double *kmT = km_lds ? (double *)(lds + P.ndf) : km_scratch + (size_t)blockIdx.x * cnt * cnt;
 	float *ratio = ratio_scratch + (size_t)m * cnt * (cnt + 1) * 3;
 
 	// the object under construction: tabular NDF, ideal Fresnel until compute_fresnel finishes
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		float ch = cosv[jh];
 		kmT[(size_t)jh * cnt + io] = D(theta[jh] * kji[io] * nint * tanv[jh] / (ch * ch));
 	}
-	__threadfence_block();
+	if (!km_lds) __threadfence_block();
 	__syncthreads();
 	// matrix::eigenvector(4): 4 un-normalised matvecs from ones, row sums in index order
 	for (int it = 0; it < 4; ++it) {

@@ -158,14 +158,39 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	const int nphi = s_nphi;
 	for (int k = tid; k < nphi; k += FIT_BLOCK) cphi[k] = cos_f(cphi[k]);
 	__syncthreads();
-	for (int e = tid; e < cnt * cnt; e += FIT_BLOCK) {
-		int io = e / cnt, jh = e - io * cnt;          // io: theta_o index, jh: theta_h index
-		float tan_product = tanv[jh] * tanv[io];
-		float nint = 0.0f;
-		for (int q = 0; q < nphi; ++q) nint += fmax_(1.0f, tan_product * cphi[q]);
-		nint *= dphi_h;
-		float ch = cosv[jh];
-		kmT[(size_t)jh * cnt + io] = D(theta[jh] * kji[io] * nint * tanv[jh] / (ch * ch));
+	{
+		// Entry (io, jh) integrates max(1, tan(theta_h) tan(theta_o) cos(phi)) over the phi steps.  Where the product of the
+		// tangents is <= 1 every term is exactly 1.0f and the sum exactly nphi (an integer below 2^24): no loop.  tanv grows
+		// with the index, so for a given io the entries that need the loop are a suffix jh >= jmin(io); they are enumerated
+		// (prefix sums over io, a 7-step search per work item) so that every lane of the loop has one.
+		int *hoff = (int *)stile, *hmin = hoff + cnt + 1;        // the sigma tiles are not in use yet
+		auto store = [&](int io, int jh, float nint) {
+			nint *= dphi_h;
+			const float ch = cosv[jh];
+			kmT[(size_t)jh * cnt + io] = D(theta[jh] * kji[io] * nint * tanv[jh] / (ch * ch));
+		};
+		for (int io = tid; io < cnt; io += FIT_BLOCK) {
+			int jm = 0;
+			while (jm < cnt && !(tanv[jm] * tanv[io] > 1.0f)) ++jm;
+			hmin[io] = jm; hoff[io + 1] = cnt - jm;
+		}
+		__syncthreads();
+		if (tid == 0) { hoff[0] = 0; for (int io = 0; io < cnt; ++io) hoff[io + 1] += hoff[io]; }
+		for (int e = tid; e < cnt * cnt; e += FIT_BLOCK) {       // the entries without a loop
+			const int io = e / cnt, jh = e - io * cnt;
+			if (jh < hmin[io]) store(io, jh, (float)nphi);
+		}
+		__syncthreads();
+		const int n_heavy = hoff[cnt];
+		for (int w = tid; w < n_heavy; w += FIT_BLOCK) {
+			int lo = 0, hi = cnt - 1;                            // the io with hoff[io] <= w < hoff[io + 1]
+			while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (hoff[mid] <= w) lo = mid; else hi = mid - 1; }
+			const int io = lo, jh = hmin[io] + (w - hoff[io]);
+			const float tan_product = tanv[jh] * tanv[io];
+			float nint = 0.0f;
+			for (int q = 0; q < nphi; ++q) nint += fmax_(1.0f, tan_product * cphi[q]);
+			store(io, jh, nint);
+		}
 	}
 	if (!km_lds) __threadfence_block();
 	__syncthreads();
@@ -465,18 +490,30 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		float th = F(D(u) * DJB_PI * 0.5);
 		qprobe[j] = tab_cdf_radial(self, tan_f(th));
 	}
+	if (tid == 0) s_nqf = 0;
 	__syncthreads();
-	if (tid == 0) {   // forward scan; j persists across i (dj_brdf.h:2735)
-		int nq = 0, j = 0;
-		qf[nq++] = 0.0f;
-		for (int i = 1; i < cnt; ++i) {
-			float c = (float)i / (float)cnt;
-			for (; j < qres; ++j)
-				if (qprobe[j] >= c) { qf[nq++] = (float)j / (float)qres; break; }
+	// The reference scans forward with a j that persists across i (dj_brdf.h:2735): entry i is the first j >= j(i-1) with
+	// probe[j] >= i / cnt.  The thresholds grow with i, so the sets {j : probe[j] >= c_i} shrink and that first j is simply the
+	// first j of set i -- no dependence on i - 1 -- and the i that find one are a prefix 1 .. I (an i without one leaves j at
+	// the end for all later i).  One lane per i scans the 8 cnt probes (independent LDS reads) instead of one lane doing all.
+	if (tid >= 1 && tid < cnt) {
+		const float c = (float)tid / (float)cnt;
+		int j = 0;
+		for (; j + 16 <= qres; j += 16) {                        // 16 probes per step: the reads do not wait for each other
+			bool any = false;
+#pragma unroll
+			for (int t = 0; t < 16; ++t) any |= qprobe[j + t] >= c;
+			if (any) break;
 		}
-		qf[nq++] = 1.0f;
-		s_nqf = nq;
-		for (int k = nq; k < res; ++k) qf[k] = 0.0f;
+		while (j < qres && !(qprobe[j] >= c)) ++j;
+		if (j < qres) { qf[tid] = (float)j / (float)qres; atomicAdd(&s_nqf, 1); }
+	}
+	__syncthreads();
+	if (tid == 0) {
+		const int found = s_nqf;                                 // entries 1 .. found are set
+		qf[0] = 0.0f; qf[found + 1] = 1.0f;
+		s_nqf = found + 2;
+		for (int k = found + 2; k < res; ++k) qf[k] = 0.0f;
 	}
 	__syncthreads();
 

@@ -28,17 +28,20 @@ constexpr int NTHETA_FIT = 128;                          // dj_brdf.h:2279, 3135
 constexpr int MAX_PHI_STEPS = 512;
 // columns of the sigma quadrature staged per step (two LDS buffers of cnt x (tile + 1) floats)
 __host__ __device__ inline int sig_tile(int cnt) { return cnt <= 100 ? 64 : 32; }
+#ifndef DJB_FIT_FRESNEL_SPLIT_MIN
+#define DJB_FIT_FRESNEL_SPLIT_MIN 4     // slices per material from which the Fresnel-ratio pass is sliced as well (measured: profiles/r03/fit_phases.txt)
+#endif
 #ifndef DJB_FIT_WIDE_TILES
 #define DJB_FIT_WIDE_TILES 1      // 0: measurement builds (the tile width of a sliced sigma pass stays sig_tile)
 #endif
 
 struct LdsPlan {   // byte offsets into dynamic LDS (doubles first: 8-byte aligned)
-	int v0, v1, cphid, cthd;                 // doubles
+	int v0, v1, cphid, cthd, sphid;          // doubles
 	int p22, sigma, cdf, qf, fres;           // floats (fres: 3 per entry)
 	int theta, cosv, tanv, kji;              // floats [cnt]
 	int cphi;                                // floats [MAX_PHI_STEPS]
 	int ndf;                                 // floats [16200]
-	int sh, ui;                              // floats [90]
+	int sh, ui, cthf;                        // floats [90]
 	int terms;                               // floats [2*128]
 	int qprobe;                              // floats [8*cnt]
 	int skv, ckv;                            // floats [cnt]: sin / cos of theta_k (sigma rows)
@@ -51,13 +54,13 @@ __host__ __device__ inline LdsPlan make_plan(int res)
 	LdsPlan p; int cnt = res - 1, off = 0;
 	auto take = [&](int bytes) { int o = off; off += (bytes + 15) & ~15; return o; };
 	p.v0 = take(8 * cnt); p.v1 = take(8 * cnt);
-	p.cphid = take(8 * NPHI_SIGMA); p.cthd = take(8 * NTHETA_SIGMA);
+	p.cphid = take(8 * NPHI_SIGMA); p.cthd = take(8 * NTHETA_SIGMA); p.sphid = take(8 * NPHI_SIGMA);
 	p.p22 = take(4 * res); p.sigma = take(4 * res); p.cdf = take(4 * res); p.qf = take(4 * res);
 	p.fres = take(12 * res);
 	p.theta = take(4 * cnt); p.cosv = take(4 * cnt); p.tanv = take(4 * cnt); p.kji = take(4 * cnt);
 	p.cphi = take(4 * MAX_PHI_STEPS);
 	p.ndf = take(4 * NNODE_SIGMA);
-	p.sh = take(4 * NTHETA_SIGMA); p.ui = take(4 * NTHETA_SIGMA);
+	p.sh = take(4 * NTHETA_SIGMA); p.ui = take(4 * NTHETA_SIGMA); p.cthf = take(4 * NTHETA_SIGMA);
 	p.terms = take(4 * 2 * NTHETA_FIT);
 	p.qprobe = take(4 * 8 * cnt);
 	p.skv = take(4 * cnt); p.ckv = take(4 * cnt);
@@ -104,16 +107,16 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	const int tid = threadIdx.x, cnt = res - 1;
 	// Slicing the Fresnel-ratio pass as well pays when few materials run (4+ slices each): with ~200 workgroups in
 	// flight the extra release / acquire pairs (L2 write-backs of everybody's scratch) cost what the slicing gains.
-	const bool fresnel_split = parts >= 4;
+	const bool fresnel_split = parts >= DJB_FIT_FRESNEL_SPLIT_MIN;
 	const LdsPlan P = make_plan(res);
 	double *v0 = (double *)(lds + P.v0), *v1 = (double *)(lds + P.v1);
-	double *cphid = (double *)(lds + P.cphid), *cthd = (double *)(lds + P.cthd);
+	double *cphid = (double *)(lds + P.cphid), *cthd = (double *)(lds + P.cthd), *sphid = (double *)(lds + P.sphid);
 	float *p22 = (float *)(lds + P.p22), *sigma = (float *)(lds + P.sigma);
 	float *cdf = (float *)(lds + P.cdf), *qf = (float *)(lds + P.qf), *fres = (float *)(lds + P.fres);
 	float *theta = (float *)(lds + P.theta), *cosv = (float *)(lds + P.cosv);
 	float *tanv = (float *)(lds + P.tanv), *kji = (float *)(lds + P.kji);
 	float *cphi = (float *)(lds + P.cphi), *ndf_tab = (float *)(lds + P.ndf);
-	float *sh = (float *)(lds + P.sh), *ui = (float *)(lds + P.ui);
+	float *sh = (float *)(lds + P.sh), *ui = (float *)(lds + P.ui), *cthf = (float *)(lds + P.cthf);
 	float *terms = (float *)(lds + P.terms), *qprobe = (float *)(lds + P.qprobe);
 	float *skv = (float *)(lds + P.skv), *ckv = (float *)(lds + P.ckv), *stile = (float *)(lds + P.stile);
 	__shared__ int s_nphi, s_nqf, s_have;
@@ -229,19 +232,23 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 
 	DJB_FIT_TS(2);
 	// ================================================================ compute_sigma (dj_brdf.h:2348-2386)
-	for (int k = tid; k < NPHI_SIGMA; k += FIT_BLOCK)
-		cphid[k] = glibc_cos(D(F(D((float)k / (float)NPHI_SIGMA) * 2.0 * DJB_PI)));
+	for (int k = tid; k < NPHI_SIGMA; k += FIT_BLOCK) {
+		const double phi_h = D(F(D((float)k / (float)NPHI_SIGMA) * 2.0 * DJB_PI));
+		cphid[k] = glibc_cos(phi_h); sphid[k] = glibc_sin(phi_h);
+	}
 	for (int k = tid; k < NTHETA_SIGMA; k += FIT_BLOCK) {
 		float u = (float)k / (float)NTHETA_SIGMA;
 		float th = F(D(u * u) * DJB_PI * 0.5);
-		ui[k] = u; sh[k] = sin_f(th); cthd[k] = glibc_cos(D(th));
+		ui[k] = u; sh[k] = sin_f(th); cthd[k] = glibc_cos(D(th)); cthf[k] = cos_f(th);
 	}
-	for (int e = tid; e < NNODE_SIGMA; e += FIT_BLOCK) {   // ndf(vec3(theta_h, phi_h)): theta_k-independent
-		int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
-		float phi_h = F(D((float)j2 / (float)NPHI_SIGMA) * 2.0 * DJB_PI);
-		float u = (float)j1 / (float)NTHETA_SIGMA;
-		float th = F(D(u * u) * DJB_PI * 0.5);
-		ndf_tab[e] = mf_ndf<KIND_TABULAR>(self, from_angles(th, phi_h), std_p);
+	__syncthreads();
+	// ndf(vec3(theta_h, phi_h)) of the 180 x 90 quadrature nodes (theta_k-independent).  vec3(theta, phi) is
+	// (float(s cos phi), float(s sin phi), cos_f(theta)) with s = sin_f(theta) (dj_brdf.h:589-595): the four trigonometric values
+	// of a node come from the 90 + 180 entries above instead of four fp64 libm calls per node
+	for (int e = tid; e < NNODE_SIGMA; e += FIT_BLOCK) {
+		const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
+		const float s1 = sh[j1];
+		ndf_tab[e] = mf_ndf<KIND_TABULAR>(self, mk(F(D(s1) * cphid[j2]), F(D(s1) * sphid[j2]), cthf[j1]), std_p);
 	}
 	__syncthreads();
 	{

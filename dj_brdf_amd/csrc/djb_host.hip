@@ -385,6 +385,7 @@ try {
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
 	if (ctx->loader_state && ctx->loader_state_free) ctx->loader_state_free(ctx->loader_state);
+	for (auto &kv : ctx->fit_fresnel_dirs) (void)hipFree(kv.second);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->wl_ev) (void)hipEventDestroy(ctx->wl_ev);
 	if (ctx->wl_host) (void)hipHostFree(ctx->wl_host);

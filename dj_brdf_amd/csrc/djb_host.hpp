@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <thread>
 #include <unistd.h>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -40,6 +41,7 @@ struct djb_ctx {
 	int fit_files_dense = 0;   // DJB_OPT_FIT_FILES_DENSE
 	// what djb_fit_merl_files keeps between calls (djb_loader.hip: slot plans, a pinned / device buffer pair, its worker threads);
 	// created on first use under call_mu, released by djb_ctx_destroy through loader_state_free
+	std::map<int, float *> fit_fresnel_dirs;   // by resolution: djbk::FitSplit::fres_dirs (device memory, freed by djb_ctx_destroy)
 	void *loader_state = nullptr;
 	void (*loader_state_free)(void *) = nullptr;
 	int utia_exact_only = 0;   // DJB_OPT_UTIA_EXACT_ONLY: utia eval batches run k_eval<UTIA> (one kernel, exact fall-backs inline) instead of the two tiers

@@ -48,6 +48,19 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 		if (ce != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); return fail(DJB_ERR_HIP, "djb_error: fit upload failed: %s", hipGetErrorString(ce)); }
 	}
 	split.sig_x = (float *)(base + o_sigx); split.sig_done = (unsigned int *)(base + o_done);
+	// the directions of the Fresnel-ratio pass depend on the resolution only: once per context (the launch below is stream-ordered before the fit)
+	split.fres_dirs = nullptr;
+	{
+		auto it = ctx->fit_fresnel_dirs.find(res);
+		if (it == ctx->fit_fresnel_dirs.end()) {
+			float *d = nullptr;
+			if (hipMalloc((void **)&d, sizeof(float) * 3 * (size_t)cnt * (cnt + 1)) == hipSuccess) {
+				if (djbk::launch_fit_fresnel_dirs(ctx->stream, res, d) == hipSuccess) it = ctx->fit_fresnel_dirs.emplace(res, d).first;
+				else { (void)hipGetLastError(); (void)hipFree(d); }
+			} else (void)hipGetLastError();
+		}
+		if (it != ctx->fit_fresnel_dirs.end()) split.fres_dirs = it->second;
+	}
 	// from here on the kernel may be running on `base`: every exit synchronises the stream before `pool`
 	// hands the block back to the context (and before `staging` goes out of scope)
 	hipError_t e = djbk::launch_fit(ctx->stream, d_srcs, src_kind, std_p, n_mat, res, shadow != 0, km, ratio, o, split);

@@ -100,7 +100,11 @@ struct FitOut {           // device pointers, [n_mat][res] (fresnel [n_mat][res]
 // (theta_d, theta_h) pairs) -- can be sliced over `parts` workgroups (fit_parts(n_mat)): parts - 1 helper
 // workgroups per material redo the cheap phases before them and exchange their slices through sig_x [n_mat][res],
 // the ratio scratch and the arrival counters sig_done [n_mat][2] (zeroed by launch_fit).
-struct FitSplit { int parts; float *sig_x; unsigned int *sig_done; };
+// fres_dirs (optional): the outgoing direction of every (theta_d, theta_h) pair of the Fresnel-ratio pass, 3 floats per pair, x = NaN
+// for the pairs the reference skips (launch_fit_fresnel_dirs).  They depend on the resolution only, so the host computes them once per
+// context and resolution instead of every workgroup of every fit recomputing 5 456 rotations; NULL: computed in place.
+struct FitSplit { int parts; float *sig_x; unsigned int *sig_done; const float *fres_dirs; };
+hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, float *dirs /* 3 * (res - 1) * res floats */);
 int fit_parts(int n_mat, int n_cus);
 // srcs: device array of n_mat Brdf views (all of kind `src_kind`); std_p: params::standard().
 // km_scratch: n_mat*parts*(res-1)^2 doubles; ratio_scratch: n_mat*(res-1)*res*3 floats.

@@ -392,7 +392,13 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		const float qnan = __builtin_nanf("");
 		float rx = qnan, ry = qnan, rz = qnan;
 		v3 dir_i, dir_o;
-		if (fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) {
+		bool valid;
+		if (split.fres_dirs) {                                   // tabulated once per context and resolution (k_fit_fresnel_dirs)
+			const float *d = split.fres_dirs + 3 * (size_t)e;
+			dir_o = mk(d[0], d[1], d[2]); dir_i = mk(0, 0, 1);
+			valid = dir_o.x == dir_o.x;
+		} else valid = fit_fresnel_dirs(i, j, cnt, dir_i, dir_o);
+		if (valid) {
 			v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o, cnt + e);
 			v3 fr2; float pdf;
 			mf_eval_pdf<KIND_TABULAR, 1>(self, std_p, dir_i, dir_o, fr2, pdf);
@@ -555,6 +561,17 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	DJB_FIT_TS(7);
 }
 
+// dir_o of every pair of the Fresnel-ratio pass (dir_i is (0, 0, 1) for all of them, dj_brdf.h:2609); x = NaN: the reference skips the pair
+__global__ __launch_bounds__(256) void k_fit_fresnel_dirs(int res, float *dirs)
+{
+	const int cnt = res - 1, e = blockIdx.x * 256 + threadIdx.x;
+	if (e >= cnt * (cnt + 1)) return;
+	const int i = e / (cnt + 1), j = e - i * (cnt + 1);
+	v3 dir_i, dir_o;
+	if (!fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) dir_o = mk(__builtin_nanf(""), 0.0f, 0.0f);
+	dirs[3 * (size_t)e] = dir_o.x; dirs[3 * (size_t)e + 1] = dir_o.y; dirs[3 * (size_t)e + 2] = dir_o.z;
+}
+
 // the MERL table index each query slot reads (the file pipeline gathers exactly these entries on the host)
 __global__ __launch_bounds__(256) void k_fit_merl_slots(int res, int n_slots, int32_t *idx)
 {
@@ -592,6 +609,12 @@ namespace djbk {
 size_t fit_lds_bytes(int res) { return (size_t)make_plan(res).total; }
 
 int fit_merl_slots(int res) { return fit_merl_slot_count(res); }
+hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, float *dirs)
+{
+	const int n = (res - 1) * res;
+	hipLaunchKernelGGL(k_fit_fresnel_dirs, dim3((n + 255) / 256), dim3(256), 0, s, res, dirs);
+	return hipGetLastError();
+}
 hipError_t launch_fit_merl_slots(hipStream_t s, int res, int32_t *idx)
 {
 	const int n = fit_merl_slot_count(res);

@@ -54,8 +54,8 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 		auto it = ctx->fit_fresnel_dirs.find(res);
 		if (it == ctx->fit_fresnel_dirs.end()) {
 			float *d = nullptr;
-			if (hipMalloc((void **)&d, sizeof(float) * 3 * (size_t)cnt * (cnt + 1)) == hipSuccess) {
-				if (djbk::launch_fit_fresnel_dirs(ctx->stream, res, d) == hipSuccess) it = ctx->fit_fresnel_dirs.emplace(res, d).first;
+			if (hipMalloc((void **)&d, sizeof(float) * djbk::fit_fresnel_dirs_floats(res)) == hipSuccess) {
+				if (djbk::launch_fit_fresnel_dirs(ctx->stream, res, std_p, d) == hipSuccess) it = ctx->fit_fresnel_dirs.emplace(res, d).first;
 				else { (void)hipGetLastError(); (void)hipFree(d); }
 			} else (void)hipGetLastError();
 		}

@@ -100,11 +100,14 @@ struct FitOut {           // device pointers, [n_mat][res] (fresnel [n_mat][res]
 // (theta_d, theta_h) pairs) -- can be sliced over `parts` workgroups (fit_parts(n_mat)): parts - 1 helper
 // workgroups per material redo the cheap phases before them and exchange their slices through sig_x [n_mat][res],
 // the ratio scratch and the arrival counters sig_done [n_mat][2] (zeroed by launch_fit).
-// fres_dirs (optional): the outgoing direction of every (theta_d, theta_h) pair of the Fresnel-ratio pass, 3 floats per pair, x = NaN
-// for the pairs the reference skips (launch_fit_fresnel_dirs).  They depend on the resolution only, so the host computes them once per
-// context and resolution instead of every workgroup of every fit recomputing 5 456 rotations; NULL: computed in place.
+// fres_dirs (optional): one record of 5 floats per (theta_d, theta_h) pair of the Fresnel-ratio pass -- the outgoing direction (x = NaN
+// for the pairs the reference skips) and the fitted lobe's two table coordinates that the pair's geometry fixes -- plus one trailing float
+// (launch_fit_fresnel_dirs; fit_fresnel_dirs_floats(res) floats).  They depend on the resolution only, so the host computes them once per
+// context and resolution instead of every workgroup of every fit recomputing 5 456 double rotations and 11 k fp64 libm calls; NULL:
+// computed in place.
 struct FitSplit { int parts; float *sig_x; unsigned int *sig_done; const float *fres_dirs; };
-hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, float *dirs /* 3 * (res - 1) * res floats */);
+size_t fit_fresnel_dirs_floats(int res);
+hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, const Params &std_p, float *recs);
 int fit_parts(int n_mat, int n_cus);
 // srcs: device array of n_mat Brdf views (all of kind `src_kind`); std_p: params::standard().
 // km_scratch: n_mat*parts*(res-1)^2 doubles; ratio_scratch: n_mat*(res-1)*res*3 floats.

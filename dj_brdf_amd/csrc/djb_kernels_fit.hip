@@ -28,6 +28,7 @@ constexpr int NTHETA_FIT = 128;                          // dj_brdf.h:2279, 3135
 constexpr int MAX_PHI_STEPS = 512;
 // columns of the sigma quadrature staged per step (two LDS buffers of cnt x (tile + 1) floats)
 __host__ __device__ inline int sig_tile(int cnt) { return cnt <= 100 ? 64 : 32; }
+constexpr int FRES_REC = 5;             // floats per record of FitSplit::fres_dirs
 #ifndef DJB_FIT_FRESNEL_SPLIT_MIN
 #define DJB_FIT_FRESNEL_SPLIT_MIN 4     // slices per material from which the Fresnel-ratio pass is sliced as well (measured: profiles/r03/fit_phases.txt)
 #endif
@@ -393,15 +394,18 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		float rx = qnan, ry = qnan, rz = qnan;
 		v3 dir_i, dir_o;
 		bool valid;
+		EvalHints hints; const EvalHints *hp = nullptr;
 		if (split.fres_dirs) {                                   // tabulated once per context and resolution (k_fit_fresnel_dirs)
-			const float *d = split.fres_dirs + 3 * (size_t)e;
+			const float *d = split.fres_dirs + FRES_REC * (size_t)e;
 			dir_o = mk(d[0], d[1], d[2]); dir_i = mk(0, 0, 1);
 			valid = dir_o.x == dir_o.x;
+			hints.u_sigma_o = d[3]; hints.u_ndf_h = d[4]; hints.u_sigma_i = split.fres_dirs[FRES_REC * (size_t)n_pairs];
+			hp = &hints;
 		} else valid = fit_fresnel_dirs(i, j, cnt, dir_i, dir_o);
 		if (valid) {
 			v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o, cnt + e);
 			v3 fr2; float pdf;
-			mf_eval_pdf<KIND_TABULAR, 1>(self, std_p, dir_i, dir_o, fr2, pdf);
+			mf_eval_pdf<KIND_TABULAR, 1>(self, std_p, dir_i, dir_o, fr2, pdf, hp);
 			if (D(fr2.x) > 1e-4) rx = fr1.x / fr2.x;
 			if (D(fr2.y) > 1e-4) ry = fr1.y / fr2.y;
 			if (D(fr2.z) > 1e-4) rz = fr1.z / fr2.z;
@@ -413,15 +417,21 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		// i, a 7-step search per work item -- so that every lane evaluates one; a third of the lanes used to idle through
 		// skipped pairs (100 materials: 161 -> 135 us).  The skipped pairs read as "no sample" (NaN) in the row sums below.
 		int *foff = (int *)stile;                                // [cnt + 1]; the sigma tiles are done with
-		for (int i = tid; i < cnt; i += FIT_BLOCK) {
-			int nj = 0; float td, th;
-			while (nj <= cnt && fit_fresnel_valid(i, nj, cnt, td, th)) ++nj;
-			foff[i + 1] = nj;
+		if (split.fres_dirs) {                                   // tabulated with the directions
+			const int *g = (const int *)(split.fres_dirs + FRES_REC * (size_t)n_pairs + 1);
+			for (int i = tid; i <= cnt; i += FIT_BLOCK) foff[i] = g[i];
+		} else {
+			for (int i = tid; i < cnt; i += FIT_BLOCK) {
+				int nj = 0; float td, th;
+				while (nj <= cnt && fit_fresnel_valid(i, nj, cnt, td, th)) ++nj;
+				foff[i + 1] = nj;
+			}
+			__syncthreads();
+			if (tid == 0) { foff[0] = 0; for (int i = 0; i < cnt; ++i) foff[i + 1] += foff[i]; }
 		}
 		__syncthreads();
-		if (tid == 0) { foff[0] = 0; for (int i = 0; i < cnt; ++i) foff[i + 1] += foff[i]; }
-		__syncthreads();
 		const int n_valid = foff[cnt];
+		DJB_FIT_TS(8);
 		const float qnan = __builtin_nanf("");
 		for (int e = tid; e < n_pairs; e += FIT_BLOCK) {
 			const int i = e / (cnt + 1), j = e - i * (cnt + 1);
@@ -435,6 +445,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		}
 		__threadfence_block();
 		__syncthreads();
+		DJB_FIT_TS(9);
 	} else {
 		// this workgroup's slice of the (theta_d, theta_h) pairs (one pair per lane); helpers hand theirs over and leave
 		auto fresnel_pairs = [&](int e0, int e1) {
@@ -561,15 +572,32 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	DJB_FIT_TS(7);
 }
 
-// dir_o of every pair of the Fresnel-ratio pass (dir_i is (0, 0, 1) for all of them, dj_brdf.h:2609); x = NaN: the reference skips the pair
-__global__ __launch_bounds__(256) void k_fit_fresnel_dirs(int res, float *dirs)
+// One record per pair of the Fresnel-ratio pass: dir_o (dir_i is (0, 0, 1) for all of them, dj_brdf.h:2609; x = NaN: the reference
+// skips the pair) and the two table coordinates of the fitted lobe that the pair's geometry fixes -- sigma's for dir_o, the NDF's for
+// the half vector -- plus, after the last record, sigma's coordinate for dir_i and the res prefix sums that enumerate the valid pairs.
+// Everything in them is independent of the material.
+__global__ __launch_bounds__(256) void k_fit_fresnel_dirs(int res, Params std_p, float *recs)
 {
-	const int cnt = res - 1, e = blockIdx.x * 256 + threadIdx.x;
-	if (e >= cnt * (cnt + 1)) return;
+	const int cnt = res - 1, n_pairs = cnt * (cnt + 1), e = blockIdx.x * 256 + threadIdx.x;
+	if (e == 0) {
+		recs[FRES_REC * (size_t)n_pairs] = mf_sigma_table_u(mk(0, 0, 1), std_p);
+		// prefix sums of the number of valid theta_h per theta_d (for a given theta_d they are a prefix): the enumeration of the valid pairs
+		int *foff = (int *)(recs + FRES_REC * (size_t)n_pairs + 1);
+		foff[0] = 0;
+		for (int i2 = 0; i2 < cnt; ++i2) {
+			int nj = 0; float td, th;
+			while (nj <= cnt && fit_fresnel_valid(i2, nj, cnt, td, th)) ++nj;
+			foff[i2 + 1] = foff[i2] + nj;
+		}
+	}
+	if (e >= n_pairs) return;
 	const int i = e / (cnt + 1), j = e - i * (cnt + 1);
 	v3 dir_i, dir_o;
-	if (!fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) dir_o = mk(__builtin_nanf(""), 0.0f, 0.0f);
-	dirs[3 * (size_t)e] = dir_o.x; dirs[3 * (size_t)e + 1] = dir_o.y; dirs[3 * (size_t)e + 2] = dir_o.z;
+	float *r = recs + FRES_REC * (size_t)e;
+	if (!fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) { r[0] = __builtin_nanf(""); r[1] = r[2] = r[3] = r[4] = 0.0f; return; }
+	r[0] = dir_o.x; r[1] = dir_o.y; r[2] = dir_o.z;
+	r[3] = mf_sigma_table_u(dir_o, std_p);
+	r[4] = mf_ndf_table_u(normalize(add(dir_i, dir_o)), std_p);
 }
 
 // the MERL table index each query slot reads (the file pipeline gathers exactly these entries on the host)
@@ -597,6 +625,7 @@ hipError_t launch_fit_kind(hipStream_t s, const Brdf *srcs, const Params &std_p,
 		fprintf(stderr, "djb_exp: k_fit phases (us, last workgroup of %d x %d): p22_smith %.1f normalize %.1f sigma %.1f fresnel %.1f cdf %.1f qf %.1f fits %.1f\n",
 		        n_mat, split.parts, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01,
 		        (h[6] - h[5]) * 0.01, (h[7] - h[6]) * 0.01);
+		fprintf(stderr, "djb_exp:   fresnel (unsplit): prefix %.1f pairs %.1f row sums %.1f\n", (h[8] - h[3]) * 0.01, (h[9] - h[8]) * 0.01, (h[4] - h[9]) * 0.01);
 	}
 #endif
 	return hipGetLastError();
@@ -609,10 +638,11 @@ namespace djbk {
 size_t fit_lds_bytes(int res) { return (size_t)make_plan(res).total; }
 
 int fit_merl_slots(int res) { return fit_merl_slot_count(res); }
-hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, float *dirs)
+size_t fit_fresnel_dirs_floats(int res) { return (size_t)FRES_REC * (res - 1) * res + 1 + (size_t)res; }
+hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, const Params &std_p, float *recs)
 {
 	const int n = (res - 1) * res;
-	hipLaunchKernelGGL(k_fit_fresnel_dirs, dim3((n + 255) / 256), dim3(256), 0, s, res, dirs);
+	hipLaunchKernelGGL(k_fit_fresnel_dirs, dim3((n + 255) / 256), dim3(256), 0, s, res, std_p, recs);
 	return hipGetLastError();
 }
 hipError_t launch_fit_merl_slots(hipStream_t s, int res, int32_t *idx)

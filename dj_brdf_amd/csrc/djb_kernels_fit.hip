@@ -249,7 +249,8 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	for (int e = tid; e < NNODE_SIGMA; e += FIT_BLOCK) {
 		const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
 		const float s1 = sh[j1];
-		ndf_tab[e] = mf_ndf<KIND_TABULAR>(self, mk(F(D(s1) * cphid[j2]), F(D(s1) * sphid[j2]), cthf[j1]), std_p);
+		const float *u_node = split.fres_dirs ? split.fres_dirs + FRES_REC * (size_t)cnt * (cnt + 1) + 1 + res + e : nullptr;   // tabulated once per context
+		ndf_tab[e] = mf_ndf<KIND_TABULAR>(self, mk(F(D(s1) * cphid[j2]), F(D(s1) * sphid[j2]), cthf[j1]), std_p, u_node);
 	}
 	__syncthreads();
 	{
@@ -585,7 +586,8 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 
 // One record per pair of the Fresnel-ratio pass: dir_o (dir_i is (0, 0, 1) for all of them, dj_brdf.h:2609; x = NaN: the reference
 // skips the pair) and the two table coordinates of the fitted lobe that the pair's geometry fixes -- sigma's for dir_o, the NDF's for
-// the half vector -- plus, after the last record, sigma's coordinate for dir_i and the res prefix sums that enumerate the valid pairs.
+// the half vector -- plus, after the last record, sigma's coordinate for dir_i, the res prefix sums that enumerate the valid pairs and
+// the NDF's coordinate at the 16 200 nodes of the sigma quadrature.
 // Everything in them is independent of the material.
 __global__ __launch_bounds__(256) void k_fit_fresnel_dirs(int res, Params std_p, float *recs)
 {
@@ -600,6 +602,11 @@ __global__ __launch_bounds__(256) void k_fit_fresnel_dirs(int res, Params std_p,
 			while (nj <= cnt && fit_fresnel_valid(i2, nj, cnt, td, th)) ++nj;
 			foff[i2 + 1] = foff[i2] + nj;
 		}
+	}
+	if (e < NNODE_SIGMA) {           // the NDF's table coordinate at each node of the sigma quadrature (the nodes do not depend on res)
+		const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
+		const float phi_h = F(D((float)j2 / (float)NPHI_SIGMA) * 2.0 * DJB_PI), u = (float)j1 / (float)NTHETA_SIGMA;
+		recs[FRES_REC * (size_t)n_pairs + 1 + res + e] = mf_ndf_table_u(from_angles(F(D(u * u) * DJB_PI * 0.5), phi_h), std_p);
 	}
 	if (e >= n_pairs) return;
 	const int i = e / (cnt + 1), j = e - i * (cnt + 1);
@@ -649,10 +656,10 @@ namespace djbk {
 size_t fit_lds_bytes(int res) { return (size_t)make_plan(res).total; }
 
 int fit_merl_slots(int res) { return fit_merl_slot_count(res); }
-size_t fit_fresnel_dirs_floats(int res) { return (size_t)FRES_REC * (res - 1) * res + 1 + (size_t)res; }
+size_t fit_fresnel_dirs_floats(int res) { return (size_t)FRES_REC * (res - 1) * res + 1 + (size_t)res + NNODE_SIGMA; }
 hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, const Params &std_p, float *recs)
 {
-	const int n = (res - 1) * res;
+	const int n = (res - 1) * res > NNODE_SIGMA ? (res - 1) * res : NNODE_SIGMA;
 	hipLaunchKernelGGL(k_fit_fresnel_dirs, dim3((n + 255) / 256), dim3(256), 0, s, res, std_p, recs);
 	return hipGetLastError();
 }

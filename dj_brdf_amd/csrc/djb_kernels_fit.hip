@@ -143,7 +143,10 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	// ================================================================ compute_p22_smith (dj_brdf.h:2482-2522)
 	const float dtheta_k = F(sqrt(DJB_PI * 0.5) / D((float)cnt));
 	const float dphi_h = F(DJB_PI / 180.0);
-	if (tid == 0) {   // the float-stepped phi loop (361 steps for dphi = pi/180): same phi values
+	// the phi integral of every (theta_o, theta_h) entry of the K matrix depends on the resolution only: tabulated once per context
+	// (k_fit_smith_nint, the same loops as below), so that building K is one multiplication chain per entry
+	const float *nint_tab = split.fres_dirs ? split.fres_dirs + FRES_REC * (size_t)cnt * (cnt + 1) + 1 + res + NNODE_SIGMA : nullptr;
+	if (tid == 0 && !nint_tab) {   // the float-stepped phi loop (361 steps for dphi = pi/180): same phi values
 		int c = 0;
 		for (float phi = 0.0f; D(phi) < 2.0 * DJB_PI && c < MAX_PHI_STEPS; phi += dphi_h) cphi[c++] = phi;
 		s_nphi = c;
@@ -159,6 +162,13 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		v0[k] = 1.0;
 	}
 	__syncthreads();
+	if (nint_tab) {
+		for (int e = tid; e < cnt * cnt; e += FIT_BLOCK) {
+			const int io = e / cnt, jh = e - io * cnt;
+			const float ch = cosv[jh];
+			kmT[(size_t)jh * cnt + io] = D(theta[jh] * kji[io] * nint_tab[e] * tanv[jh] / (ch * ch));
+		}
+	} else {
 	const int nphi = s_nphi;
 	for (int k = tid; k < nphi; k += FIT_BLOCK) cphi[k] = cos_f(cphi[k]);
 	__syncthreads();
@@ -195,6 +205,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			for (int q = 0; q < nphi; ++q) nint += fmax_(1.0f, tan_product * cphi[q]);
 			store(io, jh, nint);
 		}
+	}
 	}
 	if (!km_lds) __threadfence_block();
 	__syncthreads();
@@ -584,10 +595,37 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	DJB_FIT_TS(7);
 }
 
+// nint[io * cnt + jh] = dphi * sum over the float-stepped phi of max(1, tan(theta_h) tan(theta_o) cos(phi)) (compute_p22_smith,
+// dj_brdf.h:2482-2522): the same operations in the same order as k_fit's own loops, one workgroup
+__global__ __launch_bounds__(1024) void k_fit_smith_nint(int res, float *nint)
+{
+	__shared__ float s_tan[256], s_cphi[MAX_PHI_STEPS];
+	__shared__ int s_n;
+	const int cnt = res - 1, tid = threadIdx.x;
+	const float dphi_h = F(DJB_PI / 180.0);
+	if (tid == 0) {
+		int c = 0;
+		for (float phi = 0.0f; D(phi) < 2.0 * DJB_PI && c < MAX_PHI_STEPS; phi += dphi_h) s_cphi[c++] = phi;
+		s_n = c;
+	}
+	for (int k = tid; k < cnt && k < 256; k += 1024) { const float th = fit_backscatter_theta(k, cnt); s_tan[k] = tan_f(th * th); }
+	__syncthreads();
+	const int nphi = s_n;
+	for (int k = tid; k < nphi; k += 1024) s_cphi[k] = cos_f(s_cphi[k]);
+	__syncthreads();
+	for (int e = tid; e < cnt * cnt; e += 1024) {
+		const int io = e / cnt, jh = e - io * cnt;
+		const float tan_product = s_tan[jh] * s_tan[io];
+		float acc = 0.0f;
+		for (int q = 0; q < nphi; ++q) acc += fmax_(1.0f, tan_product * s_cphi[q]);
+		nint[e] = acc * dphi_h;
+	}
+}
+
 // One record per pair of the Fresnel-ratio pass: dir_o (dir_i is (0, 0, 1) for all of them, dj_brdf.h:2609; x = NaN: the reference
 // skips the pair) and the two table coordinates of the fitted lobe that the pair's geometry fixes -- sigma's for dir_o, the NDF's for
 // the half vector -- plus, after the last record, sigma's coordinate for dir_i, the res prefix sums that enumerate the valid pairs and
-// the NDF's coordinate at the 16 200 nodes of the sigma quadrature.
+// the NDF's coordinate at the 16 200 nodes of the sigma quadrature; then the (res - 1)^2 phi integrals of the K matrix (k_fit_smith_nint).
 // Everything in them is independent of the material.
 __global__ __launch_bounds__(256) void k_fit_fresnel_dirs(int res, Params std_p, float *recs)
 {
@@ -656,11 +694,13 @@ namespace djbk {
 size_t fit_lds_bytes(int res) { return (size_t)make_plan(res).total; }
 
 int fit_merl_slots(int res) { return fit_merl_slot_count(res); }
-size_t fit_fresnel_dirs_floats(int res) { return (size_t)FRES_REC * (res - 1) * res + 1 + (size_t)res + NNODE_SIGMA; }
+size_t fit_fresnel_dirs_floats(int res) { return (size_t)FRES_REC * (res - 1) * res + 1 + (size_t)res + NNODE_SIGMA + (size_t)(res - 1) * (res - 1); }
 hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, const Params &std_p, float *recs)
 {
 	const int n = (res - 1) * res > NNODE_SIGMA ? (res - 1) * res : NNODE_SIGMA;
 	hipLaunchKernelGGL(k_fit_fresnel_dirs, dim3((n + 255) / 256), dim3(256), 0, s, res, std_p, recs);
+	if (res - 1 > 256) return hipErrorInvalidValue;        // k_fit_smith_nint's tangent table (the fit itself is built for res <= ~100)
+	hipLaunchKernelGGL(k_fit_smith_nint, dim3(1), dim3(1024), 0, s, res, recs + FRES_REC * (size_t)(res - 1) * res + 1 + res + NNODE_SIGMA);
 	return hipGetLastError();
 }
 hipError_t launch_fit_merl_slots(hipStream_t s, int res, int32_t *idx)

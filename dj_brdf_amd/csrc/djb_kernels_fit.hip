@@ -70,14 +70,18 @@ __host__ __device__ inline LdsPlan make_plan(int res)
 	return p;
 }
 
-// slot: the query slot of this look-up (djb_device.hpp: fit_merl_slot_count); a sparse MERL source holds one texel per slot
+// slot: the query slot of this look-up (djb_device.hpp: fit_merl_slot_count); a sparse MERL source holds one texel per slot.
+// slot_bin (optional): the MERL bin of every slot (fit_merl_slot_index: the fit's directions depend on the resolution only, so their
+// half / difference angle transforms -- fp64 atan2 / acos, the most expensive thing a dense MERL source does here -- are tabulated
+// once per context with the rest of FitSplit::fres_dirs)
 template <int SRC>
-DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o, int slot)
+DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o, int slot, const int *slot_bin = nullptr)
 {
 	v3 fr = mk(0, 0, 0); float pdf;
 	if (SRC <= KIND_TABULAR || SRC == KIND_TABULAR_ANISO) mf_eval_pdf<SRC, 1>(src, std_p, i, o, fr, pdf);
 	else if (SRC == KIND_MERL) {
 		if (src.merl_sparse) { MerlTexel t = src.merl[slot]; fr = mk(t.x, t.y, t.z); }
+		else if (slot_bin) { MerlTexel t = src.merl[slot_bin[slot]]; fr = mk(t.x, t.y, t.z); }
 		else fr = merl_eval(src, i, o);
 	}
 	else if (SRC == KIND_UTIA) fr = utia_eval(src, i, o);
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	// the phi integral of every (theta_o, theta_h) entry of the K matrix depends on the resolution only: tabulated once per context
 	// (k_fit_smith_nint, the same loops as below), so that building K is one multiplication chain per entry
 	const float *nint_tab = split.fres_dirs ? split.fres_dirs + FRES_REC * (size_t)cnt * (cnt + 1) + 1 + res + NNODE_SIGMA : nullptr;
+	const int *slot_bin = nint_tab ? (const int *)(nint_tab + (size_t)cnt * cnt) : nullptr;      // [cnt + cnt (cnt + 1)]
 	if (tid == 0 && !nint_tab) {   // the float-stepped phi loop (361 steps for dphi = pi/180): same phi values
 		int c = 0;
 		for (float phi = 0.0f; D(phi) < 2.0 * DJB_PI && c < MAX_PHI_STEPS; phi += dphi_h) cphi[c++] = phi;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		float c = cos_f(th2), t = tan_f(th2);
 		theta[k] = th; cosv[k] = c; tanv[k] = t;
 		v3 w = from_angles(th2, 0.0f);
-		float fr_i = intensity(src_eval<SRC>(src, std_p, w, w, k));
+		float fr_i = intensity(src_eval<SRC>(src, std_p, w, w, k, slot_bin));
 		kji[k] = F((D(dtheta_k) * glibc_pow(D(c), D(6.0f))) * (8.0 * D(fr_i)));
 		v0[k] = 1.0;
 	}
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			hp = &hints;
 		} else valid = fit_fresnel_dirs(i, j, cnt, dir_i, dir_o);
 		if (valid) {
-			v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o, cnt + e);
+			v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o, cnt + e, slot_bin);
 			v3 fr2; float pdf;
 			mf_eval_pdf<KIND_TABULAR, 1>(self, std_p, dir_i, dir_o, fr2, pdf, hp);
 			if (D(fr2.x) > 1e-4) rx = fr1.x / fr2.x;
@@ -625,7 +630,8 @@ __global__ __launch_bounds__(1024) void k_fit_smith_nint(int res, float *nint)
 // One record per pair of the Fresnel-ratio pass: dir_o (dir_i is (0, 0, 1) for all of them, dj_brdf.h:2609; x = NaN: the reference
 // skips the pair) and the two table coordinates of the fitted lobe that the pair's geometry fixes -- sigma's for dir_o, the NDF's for
 // the half vector -- plus, after the last record, sigma's coordinate for dir_i, the res prefix sums that enumerate the valid pairs and
-// the NDF's coordinate at the 16 200 nodes of the sigma quadrature; then the (res - 1)^2 phi integrals of the K matrix (k_fit_smith_nint).
+// the NDF's coordinate at the 16 200 nodes of the sigma quadrature; then the (res - 1)^2 phi integrals of the K matrix (k_fit_smith_nint)
+// and the MERL bin of each of the (res - 1) (res + 1) query slots.
 // Everything in them is independent of the material.
 __global__ __launch_bounds__(256) void k_fit_fresnel_dirs(int res, Params std_p, float *recs)
 {
@@ -645,6 +651,11 @@ __global__ __launch_bounds__(256) void k_fit_fresnel_dirs(int res, Params std_p,
 		const int j2 = e / NTHETA_SIGMA, j1 = e - j2 * NTHETA_SIGMA;
 		const float phi_h = F(D((float)j2 / (float)NPHI_SIGMA) * 2.0 * DJB_PI), u = (float)j1 / (float)NTHETA_SIGMA;
 		recs[FRES_REC * (size_t)n_pairs + 1 + res + e] = mf_ndf_table_u(from_angles(F(D(u * u) * DJB_PI * 0.5), phi_h), std_p);
+	}
+	if (e < cnt + n_pairs) {         // the MERL bin of every query slot of a fit at this resolution (-1: a pair the reference skips)
+		int *bins = (int *)(recs + FRES_REC * (size_t)n_pairs + 1 + res + NNODE_SIGMA + (size_t)cnt * cnt);
+		const int b = fit_merl_slot_index(e, res);
+		bins[e] = b < 0 ? 0 : b;
 	}
 	if (e >= n_pairs) return;
 	const int i = e / (cnt + 1), j = e - i * (cnt + 1);
@@ -694,10 +705,10 @@ namespace djbk {
 size_t fit_lds_bytes(int res) { return (size_t)make_plan(res).total; }
 
 int fit_merl_slots(int res) { return fit_merl_slot_count(res); }
-size_t fit_fresnel_dirs_floats(int res) { return (size_t)FRES_REC * (res - 1) * res + 1 + (size_t)res + NNODE_SIGMA + (size_t)(res - 1) * (res - 1); }
+size_t fit_fresnel_dirs_floats(int res) { return (size_t)FRES_REC * (res - 1) * res + 1 + (size_t)res + NNODE_SIGMA + (size_t)(res - 1) * (res - 1) + (size_t)(res - 1) * (res + 1); }
 hipError_t launch_fit_fresnel_dirs(hipStream_t s, int res, const Params &std_p, float *recs)
 {
-	const int n = (res - 1) * res > NNODE_SIGMA ? (res - 1) * res : NNODE_SIGMA;
+	const int n = (res - 1) * (res + 1) > NNODE_SIGMA ? (res - 1) * (res + 1) : NNODE_SIGMA;
 	hipLaunchKernelGGL(k_fit_fresnel_dirs, dim3((n + 255) / 256), dim3(256), 0, s, res, std_p, recs);
 	if (res - 1 > 256) return hipErrorInvalidValue;        // k_fit_smith_nint's tangent table (the fit itself is built for res <= ~100)
 	hipLaunchKernelGGL(k_fit_smith_nint, dim3(1), dim3(1024), 0, s, res, recs + FRES_REC * (size_t)(res - 1) * res + 1 + res + NNODE_SIGMA);

@@ -426,7 +426,8 @@ def main():
             fit_ms = float(t[0])
         fit100 = {"materials": 100, "n_gpus": world, "wall_ms": fit_ms, "scaling": "strong",
                   "value": 100 / (fit_ms * 1e-3), "unit": "materials/s",
-                  "what": "compute only: tables resident in HBM, one k_fit launch per rank"}
+                  "what": "compute only: tables resident in HBM, one k_fit launch per rank (after one untimed call: the context keeps the fit's "
+                          "material-independent geometry tables per resolution -- directions, K-matrix integrals, MERL bins of the query slots)"}
         del st, kp
         torch.cuda.empty_cache()
         # ... and end to end, files -> alphas (the reference driver's loop is file to file): rank r takes files r, r+N, ...

@@ -41,6 +41,7 @@ struct djb_ctx {
 	int fit_files_dense = 0;   // DJB_OPT_FIT_FILES_DENSE
 	// what djb_fit_merl_files keeps between calls (djb_loader.hip: slot plans, a pinned / device buffer pair, its worker threads);
 	// created on first use under call_mu, released by djb_ctx_destroy through loader_state_free
+	std::map<int, int> fit_seen;               // by resolution: single-material fits so far (the tables below are built from the second on)
 	std::map<int, float *> fit_fresnel_dirs;   // by resolution: djbk::FitSplit::fres_dirs (device memory, freed by djb_ctx_destroy)
 	void *loader_state = nullptr;
 	void (*loader_state_free)(void *) = nullptr;

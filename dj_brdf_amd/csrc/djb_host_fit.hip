@@ -52,7 +52,8 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 	split.fres_dirs = nullptr;
 	{
 		auto it = ctx->fit_fresnel_dirs.find(res);
-		if (it == ctx->fit_fresnel_dirs.end()) {
+		// built from the second material on: a context that fits one material once would only pay for them
+		if (it == ctx->fit_fresnel_dirs.end() && (n_mat >= 2 || ++ctx->fit_seen[res] >= 2)) {
 			float *d = nullptr;
 			if (hipMalloc((void **)&d, sizeof(float) * djbk::fit_fresnel_dirs_floats(res)) == hipSuccess) {
 				if (djbk::launch_fit_fresnel_dirs(ctx->stream, res, std_p, d) == hipSuccess) it = ctx->fit_fresnel_dirs.emplace(res, d).first;

@@ -308,11 +308,13 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			const bool held = nrows <= RMAX;
 			float skr[RMAX]; double ckr[RMAX];
 			__syncthreads();                                     // skv / ckv (and, on a re-run, the previous rows' tiles) are complete
+			// (a lane whose j-th row would lie past the slice repeats the slice's last row: it stores the same value to the same slot
+			// as the lane that owns that row, and the row loop needs no per-row predicate -- seven straight-line chains)
 #pragma unroll
 			for (int j = 0; j < RMAX; ++j) {
-				const int k = r0 + grp + j * ngrp;
-				const bool on = held && a >= 0 && grp < ngrp && k < r1;
-				skr[j] = on ? skv[k] : 0.0f; ckr[j] = on ? D(ckv[k]) : 0.0;
+				int k = r0 + (grp > 0 ? grp : 0) + j * ngrp;
+				k = k < r1 ? k : r1 - 1;
+				skr[j] = held ? skv[k] : 0.0f; ckr[j] = held ? D(ckv[k]) : 0.0;
 			}
 			auto produce = [&](int t) {
 				const int e = t * T + col;
@@ -329,11 +331,10 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 #pragma unroll
 					for (int j = 0; j < RMAX; ++j) {
 						if (j >= nrows) break;                       // uniform
-						const int k = r0 + grp + j * ngrp;
-						if (k < r1) {
-							float kh = F(D(skr[j] * s1) * cp + ckr[j] * ct);
-							buf[k * TS + col] = fmax_(0.0f, kh) * nd * w * s1;
-						}
+						int k = r0 + grp + j * ngrp;
+						k = k < r1 ? k : r1 - 1;
+						float kh = F(D(skr[j] * s1) * cp + ckr[j] * ct);
+						buf[k * TS + col] = fmax_(0.0f, kh) * nd * w * s1;
 					}
 				} else {
 					for (int k = r0 + grp; k < r1; k += ngrp) {
@@ -346,7 +347,13 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			produce(0);
 			__syncthreads();
 			float nint = 0.0f;                                   // row accumulator of thread tid (r0 <= tid < r1)
+#ifdef DJB_EXP_FIT_TS
+			unsigned long long acc_work = 0, t_loop0 = wall_clock64();
+#endif
 			for (int t = 0; t < ntiles; ++t) {
+#ifdef DJB_EXP_FIT_TS
+				const unsigned long long t_w0 = wall_clock64();
+#endif
 				if (tid >= n_sum) { if (t + 1 < ntiles) produce(t + 1); }
 				else if (tid >= r0 && tid < r1) {
 					// the tile's T terms of this row: all loads first (8 x 16 bytes in flight), then the adds in
@@ -360,12 +367,23 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 						for (int j = 0; j < 8; ++j) { nint += v[j].x; nint += v[j].y; nint += v[j].z; nint += v[j].w; }   // zero-padded last tile: x + 0.0f == x
 					}
 				}
+#ifdef DJB_EXP_FIT_TS
+				acc_work += wall_clock64() - t_w0;
+#endif
 				__syncthreads();
 			}
+#ifdef DJB_EXP_FIT_TS
+			if (blockIdx.x == gridDim.x - 1) {
+				if (tid == n_sum) { g_fit_ts[10] = acc_work; g_fit_ts[12] = wall_clock64() - t_loop0; }      // first producer lane
+				if (tid == r0) g_fit_ts[11] = acc_work;                                                     // first row owner
+			}
+#endif
 			if (tid >= r0 && tid < r1) { nint *= dth * dph; sigma[tid] = fmax_(ckv[tid], nint); }
 		};
 		const int r0 = (cnt * part) / parts, r1 = (cnt * (part + 1)) / parts;
+		DJB_FIT_TS(13);
 		sigma_rows(r0, r1);
+		DJB_FIT_TS(14);
 		if (parts > 1) {
 			// every workgroup of the material publishes its rows; with few materials (fresnel_split) all of them
 			// pick the others' up and go on to take a slice of the Fresnel-ratio pass, which needs the whole
@@ -375,8 +393,10 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			// depends on scheduling.
 			float *sx = split.sig_x + (size_t)m * res;
 			unsigned int *done = split.sig_done + 2 * m;
+			// One release per workgroup, not one fence per thread: the barrier orders the row owners' stores before thread 0's
+			// release (release is cumulative), and an agent-scope release writes the XCD's dirty L2 lines back -- with 200
+			// workgroups' register spills in there, 1 024 of them per workgroup cost the material's main workgroup a 78 us wait
 			if (tid >= r0 && tid < r1) sx[tid] = sigma[tid];
-			__threadfence();
 			__syncthreads();
 			if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			if (!fresnel_split && part > 0) return;          // sigma-only slicing: the helper is done
@@ -385,10 +405,10 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 				while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)parts && ++spins < (1 << 14))
 					__builtin_amdgcn_s_sleep(8);
 				s_have = spins < (1 << 14);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one acquire; the barrier extends it to the workgroup
 			}
 			__syncthreads();
 			if (s_have) {
-				__threadfence();
 				if (tid < cnt && !(tid >= r0 && tid < r1))
 					sigma[tid] = __uint_as_float(__hip_atomic_load((const unsigned int *)sx + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 			} else {
@@ -470,8 +490,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 		};
 		const int e0 = (int)(((long long)n_pairs * part) / parts), e1 = (int)(((long long)n_pairs * (part + 1)) / parts);
 		fresnel_pairs(e0, e1);
-		__threadfence();
-		__syncthreads();
+		__syncthreads();                                         // (as above: thread 0's release below covers the workgroup's stores)
 		unsigned int *done = split.sig_done + 2 * m + 1;
 		if (part > 0) {
 			if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -482,10 +501,10 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(parts - 1) && ++spins < (1 << 14))
 				__builtin_amdgcn_s_sleep(8);
 			s_have = spins < (1 << 14);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 		}
 		__syncthreads();
 		if (!s_have) { fresnel_pairs(e1, n_pairs); __threadfence_block(); }
-		__threadfence();
 		__syncthreads();
 	}
 	for (int i = tid; i < cnt; i += FIT_BLOCK) {
@@ -692,6 +711,9 @@ hipError_t launch_fit_kind(hipStream_t s, const Brdf *srcs, const Params &std_p,
 		fprintf(stderr, "djb_exp: k_fit phases (us, last workgroup of %d x %d): p22_smith %.1f normalize %.1f sigma %.1f fresnel %.1f cdf %.1f qf %.1f fits %.1f\n",
 		        n_mat, split.parts, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01,
 		        (h[6] - h[5]) * 0.01, (h[7] - h[6]) * 0.01);
+		fprintf(stderr, "djb_exp:   [%d x %d] sigma: tables + NDF fill %.1f us, own rows %.1f, exchange with the other slices %.1f\n", n_mat, split.parts, (h[13] - h[2]) * 0.01, (h[14] - h[13]) * 0.01, (h[3] - h[14]) * 0.01);
+		fprintf(stderr, "djb_exp:   [%d x %d] sigma tile loop %.1f us: a producer wave busy %.1f, a row owner busy %.1f (the rest of each: waiting at the barrier)\n",
+		        n_mat, split.parts, h[12] * 0.01, h[10] * 0.01, h[11] * 0.01);
 		fprintf(stderr, "djb_exp:   fresnel (unsplit): prefix %.1f pairs %.1f row sums %.1f\n", (h[8] - h[3]) * 0.01, (h[9] - h[8]) * 0.01, (h[4] - h[9]) * 0.01);
 	}
 #endif

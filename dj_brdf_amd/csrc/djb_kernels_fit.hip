@@ -405,7 +405,9 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 				while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)parts && ++spins < (1 << 14))
 					__builtin_amdgcn_s_sleep(8);
 				s_have = spins < (1 << 14);
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one acquire; the barrier extends it to the workgroup
+				// one fence; the barrier extends it to the workgroup.  A full one (write-back, then invalidate): this workgroup's own
+				// rows share cache lines with the rows it is about to read, and its L2 holds them dirty
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
 			}
 			__syncthreads();
 			if (s_have) {
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 			while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(parts - 1) && ++spins < (1 << 14))
 				__builtin_amdgcn_s_sleep(8);
 			s_have = spins < (1 << 14);
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");     // as above: the slices' ratios meet inside cache lines
 		}
 		__syncthreads();
 		if (!s_have) { fresnel_pairs(e1, n_pairs); __threadfence_block(); }

@@ -177,15 +177,17 @@ public:
 	// runs fn on `n` threads (the caller is one of them) and returns when all have returned
 	void run(int n, const std::function<void()> &fn)
 	{
-		int helpers = n - 1;
-		while ((int)th.size() < helpers) {
-			try { th.emplace_back(&WorkerPool::loop, this, (int)th.size()); } catch (...) { helpers = (int)th.size(); break; }   // fewer threads, same result
-		}
+		const int helpers = n - 1;
 		if (helpers > 0) {
-			std::lock_guard<std::mutex> lk(mu);
-			job = &fn; want = helpers; pending = helpers; ++gen;
+			{ std::lock_guard<std::mutex> lk(mu); job = &fn; want = helpers; pending = helpers; ++gen; }
+			cv.notify_all();
 		}
-		if (helpers > 0) cv.notify_all();
+		// threads the pool does not have yet join the job as they come up (creating 31 of them takes ~1 ms: the first call's
+		// gather is under way meanwhile)
+		while ((int)th.size() < helpers) {
+			try { th.emplace_back(&WorkerPool::loop, this, (int)th.size()); }
+			catch (...) { std::lock_guard<std::mutex> lk(mu); pending -= helpers - (int)th.size(); break; }   // fewer threads, same result
+		}
 		fn();
 		if (helpers > 0) {
 			std::unique_lock<std::mutex> lk(mu);

@@ -253,9 +253,12 @@ DJB_DEV float inv_sqrt_pi_f() { return inversesqrt_(F(DJB_PI)); }
 // seed accuracy >= 2^-14); e itself is within 2^-52 of the true value.
 DJB_DEV bool near_f32_midpoint(double y, int width)
 {
-	// the 29 mantissa bits a float does not keep sit in the low word: 32-bit arithmetic (4 VALU instead of ~10)
-	const int d = (int)((unsigned int)__double2loint(y) & 0x1FFFFFFFu) - 0x10000000;
-	return (d < 0 ? -d : d) <= width;
+	// the 29 mantissa bits a float does not keep sit in the low word.  With x = lo & 0x1FFFFFFF the test is
+	// |x - 2^28| <= width, i.e. x - (2^28 - width) in [0, 2 width]; lo << 3 = 8 x (mod 2^32) drops the three bits the
+	// float keeps, so one shift-add and one unsigned compare do it: 8 (x - (2^28 - width)) <= 16 width, negatives wrap to
+	// >= 2^31 (checked over all 2^32 low words, tools/near_midpoint_check.c).  2 VALU (v_lshl_add_u32, v_cmp) instead of 5.
+	const unsigned int d = ((unsigned int)__double2loint(y) << 3) + (0u - (((unsigned int)0x10000000 - (unsigned int)width) << 3));
+	return d <= ((unsigned int)width << 4);
 }
 // inversesqrt = float(1.0 / sqrt(double(x))): two double roundings (dj_brdf.h:612).
 // Seed: v_rsq_f32 (1 ulp, 3 issue slots; v_rsq_f64 costs 5.9 -- profiles/r03/valu_issue_cost.txt), then ONE step of the

@@ -60,13 +60,17 @@ inline int grid_persistent(long long n)
 }
 
 // ---- the common paths of the float libm restatements (djb_glibc_restated_f32.inc), special cases flagged instead of taken
+// RANGE_FLAG = false: the caller knows x is a float in [0, 2) -- never negative, Inf or NaN -- and flags the sample itself
+// whenever this returns <= -5.  That covers glibc's other special case, x zero or sub-normal: for ix < 0x00800000 the code
+// below has k = -127 or -126, z in [0.699, 1.399) and |r| <= 1/32, i.e. it returns k ln2 + logc + log1p(r) <= -86.9.
+template <bool RANGE_FLAG>
 DJB_DEV float logf_main(float x, const GlibcTabs &gt, Rare &rare)
 {
 	const double *T = gt.logf;
 	constexpr double Ln2 = DJB_GLIBC_LOGF_C[0], A0 = DJB_GLIBC_LOGF_C[1], A1 = DJB_GLIBC_LOGF_C[2], A2 = DJB_GLIBC_LOGF_C[3];
 	const unsigned int ix = __float_as_uint(x);
 	// x == 1 needs no arm: table entry 9 is {1, 0}, so the polynomial below returns +0 like glibc's shortcut
-	rare.flag(R_LOGF, ix - 0x00800000u >= 0x7f800000u - 0x00800000u);
+	if (RANGE_FLAG) rare.flag(R_LOGF, ix - 0x00800000u >= 0x7f800000u - 0x00800000u);
 	unsigned int tmp = ix - 0x3f330000u;
 	int i = (int)((tmp >> 19) % 16u), k = (int)tmp >> 23;
 	unsigned int iz = ix - (tmp & (0x1ffu << 23));
@@ -79,10 +83,10 @@ DJB_DEV float logf_main(float x, const GlibcTabs &gt, Rare &rare)
 	y = __builtin_fma(y, r2, y0 + r);
 	return F(y);
 }
-DJB_DEV float expf_main(float x, const GlibcTabs &gt, Rare &rare)
+// |x| < 88 or NaN only (glibc's overflow / underflow arms start at 88): the one caller passes -ie^2 with |ie| <= 2.2, see there
+DJB_DEV float expf_main(float x, const GlibcTabs &gt)
 {
 	constexpr double Shift = DJB_GLIBC_EXP2F_C[4], InvLn2N = DJB_GLIBC_EXP2F_C[5];
-	rare.flag(R_EXPF, ((__float_as_uint(x) >> 20) & 0x7ffu) >= (0x42b00000u >> 20));
 	double xd = D(x), z = InvLn2N * xd;
 	double kd = z + Shift;
 	unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
@@ -90,13 +94,14 @@ DJB_DEV float expf_main(float x, const GlibcTabs &gt, Rare &rare)
 	double r = __builtin_fma(InvLn2N, xd, -kd);
 	return glibc_exp2_tail(ki, r, DJB_GLIBC_EXP2F_C[6], DJB_GLIBC_EXP2F_C[7], DJB_GLIBC_EXP2F_C[8], gt);
 }
-DJB_DEV float powf_main(float x, float y, const GlibcTabs &gt, Rare &rare)
+// x a normal positive float, y finite and non-zero, |y log2 x| < 126 (glibc's special cases are exactly the complement): the one
+// caller passes x = 1 - u in [1e-5, 1 - 1e-6] and y = fit in [0.49, 1], see there
+DJB_DEV float powf_main(float x, float y, const GlibcTabs &gt)
 {
 	const double *T = gt.powlog;
 	constexpr double A0 = DJB_GLIBC_POWF_C[0], A1 = DJB_GLIBC_POWF_C[1], A2 = DJB_GLIBC_POWF_C[2], A3 = DJB_GLIBC_POWF_C[3],
 	                 A4 = DJB_GLIBC_POWF_C[4], ShiftScaled = DJB_GLIBC_EXP2F_C[0];
-	const unsigned int ix = __float_as_uint(x), iy = __float_as_uint(y);
-	rare.flag(R_POWF, (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) | (2u * iy - 1u >= 2u * 0x7f800000u - 1u));
+	const unsigned int ix = __float_as_uint(x);
 	unsigned int tmp = ix - 0x3f330000u;
 	int i = (int)((tmp >> 19) % 16u);
 	unsigned int top = tmp & 0xff800000u, iz = ix - top;
@@ -109,7 +114,6 @@ DJB_DEV float powf_main(float x, float y, const GlibcTabs &gt, Rare &rare)
 	q = __builtin_fma(p, r2, q);
 	double logx = __builtin_fma(p0, r4, q);
 	double ylogx = D(y) * logx;
-	rare.flag(R_POWF, (((unsigned int)__double2hiint(ylogx) >> 15) & 0xffffu) >= (0x405f8000u >> 15));
 	double kd = ylogx + ShiftScaled;
 	unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
 	kd -= ShiftScaled;
@@ -162,10 +166,13 @@ DJB_DEV float erf_given_exp_g(float x, double e, Rare &rare)               // er
 	float y = F(1.0 - D(poly * t) * e);
 	return sign * y;
 }
-// Giles' erfinv, central arm (w < 5); the tail arm is flagged (dj_brdf.h:691-721)
+// Giles' erfinv, central arm (w < 5); the tail arm is flagged (dj_brdf.h:691-721).  IN_UNIT: the caller guarantees u in [-1, 1]
+// and not NaN; then (1 - u)(1 + u) is a float in [0, 1 + 2^-23] and logf's own range flag is covered by `w < 5` (logf_main).
+// Either way a sample that is not flagged here has w in [-2e-7, 5), so |p| <= sum |c_k| 2.5^k < 2.18 and |result| <= 2.18 |u|.
+template <bool IN_UNIT>
 DJB_DEV float erfinv_central(float u, const GlibcTabs &gt, Rare &rare, int site)
 {
-	float w = -logf_main((1.0f - u) * (1.0f + u), gt, rare), p;
+	float w = -logf_main<!IN_UNIT>((1.0f - u) * (1.0f + u), gt, rare), p;
 	rare.flag(site, !(w < 5.0f));
 	w = w - 2.5f;
 	p = 2.81022636e-08f;
@@ -192,15 +199,19 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 	float a = -1, c = erf_given_exp_g(cot_k, e_cot, rare);
 	u = fmax_(u, 1e-6f);
 	float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
-	float b = c - (1 + c) * powf_main(1 - u, fit, gt, rare);
+	// u = max(u, 1e-6) is never NaN (djb::max returns its second argument then) and at most 0.99999; fit = 1 + c (-0.876 + c (0.4265
+	// - 0.0594 c)) lies in [0.49, 1] for the cos_k in (0, 1) that are not flagged: powf's special cases cannot occur
+	float b = c - (1 + c) * powf_main(1 - u, fit, gt);
 	float normalization = recip_g(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot, rare);
 	float inv_erf = 0.0f, b_at = 0.0f;
 	bool done = false;
 	auto trip = [&]() {
 		const float bt = !((b >= a) & (b <= c)) ? 0.5f * (a + c) : b;
 		Rare r;
-		const float ie = erfinv_central(bt, gt, r, R_TAIL_LOOP);
-		const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * expf_main(-ie * ie, gt, r)) - u;
+		// bt lies in [a, c], a sub-interval of [-1, erf(cot_k)] with finite ends (c = erf_given_exp_g of a finite positive cot_k is in
+		// [0, 1]; a NaN b takes the midpoint): IN_UNIT holds, and |ie| <= 2.18 keeps -ie^2 inside expf's main path
+		const float ie = erfinv_central<true>(bt, gt, r, R_TAIL_LOOP);
+		const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * expf_main(-ie * ie, gt)) - u;
 		const float derivative = normalization * (1 - ie * tan_k);
 		const bool act = !done;                       // a converged lane keeps its result; what it computes from here on is unused
 		rare.merge(r, act);
@@ -241,7 +252,7 @@ DJB_DEV v3 bk_sample_common(const Params &p, float u1, float u2, v3 o, const Gli
 	float sin_k = sqrt_g(1.0 - D(k.z * k.z), rare);
 	rare.flag(R_DEGENERATE, !(sin_k > 0.0f));
 	float tx = bk_qf2_common<UNROLL>(u1, cos_k, sin_k, gt, rare);
-	float ty = erfinv_central(F(2.0 * D(u2) - 1.0), gt, rare, R_TAIL_QF1);                     // beckmann_qf1
+	float ty = erfinv_central<false>(F(2.0 * D(u2) - 1.0), gt, rare, R_TAIL_QF1);                     // beckmann_qf1
 	float nrm = inversesqrt_g(k.x * k.x + k.y * k.y, rare);
 	float cp = k.x * nrm, sp = k.y * nrm;
 	float txm = cp * tx - sp * ty;

@@ -123,37 +123,46 @@ DJB_DEV float powf_main(float x, float y, const GlibcTabs &gt)
 // glibc's fp64 exp of a non-positive argument, main path (glibc_exp_inline without its cold branch).  x <= -512 returns 0
 // instead of glibc's tiny value: the two places the sampler uses e = exp(-cot^2) -- 1 - poly t e in erf and 2 + k e in the
 // normalisation, both in double -- give the same result for every e below 2^-60, let alone below exp(-512)
+// The one caller passes x = -cot_k^2 with the sign bit set and |x| <= 8.5e6 (see bk_qf2_common): of glibc's special cases only
+// the tiny argument (|x| < 2^-54, where it returns 1 + x) can occur.
 DJB_DEV double exp_main_neg(double x, LdsTab T, Rare &rare)
 {
 	const unsigned int hx = (unsigned int)__double2hiint(x), abstop = (hx >> 20) & 0x7ffu;
-	const bool big = abstop >= 0x408u;                                   // |x| >= 512, Inf, NaN
-	rare.flag(R_EXP64, (abstop < 0x3c9u) | (abstop >= 0x7ffu) | (big & !(hx >> 31)));
+	const bool big = abstop >= 0x408u;                                   // |x| >= 512
+	rare.flag(R_EXP64, abstop < 0x3c9u);
 	unsigned int klo, sh; int sl;
 	const double tmp = glibc_exp_tmp(x, 0.0, klo, sh, sl, T);
 	const double scale = __hiloint2double((int)sh, sl);
 	return big ? 0.0 : __builtin_fma(scale, tmp, scale);
 }
 // ---- the guarded fp64 shortcuts (djb_device.hpp) with the exact fall-back flagged instead of taken
+// RANGE: what the caller does NOT know about the operand -- R_BOTH: nothing (the shortcut's domain is (1e-30, 1e30), anything else
+// is flagged); R_UPPER: it is >= 1 or Inf / NaN; R_NONE: it is inside the domain for every sample no other flag has caught
+enum { R_NONE = 0, R_UPPER, R_BOTH };
+template <int RANGE>
 DJB_DEV float inversesqrt_g(float x, Rare &rare)
 {
 	const double y = inversesqrt_fast(x);
-	rare.flag(R_GUARD, near_f32_midpoint(y) | !((x > 1e-30f) & (x < 1e30f)));
+	rare.flag(R_GUARD, near_f32_midpoint(y) | (RANGE == R_BOTH ? !((x > 1e-30f) & (x < 1e30f)) : RANGE == R_UPPER ? !(x < 1e30f) : false));
 	return F(y);
 }
+template <int RANGE>
 DJB_DEV float recip_g(double q, Rare &rare)
 {
 	const double r = recip_fast(q);
 	const double aq = q < 0 ? -q : q;
-	rare.flag(R_GUARD, near_f32_midpoint(r) | !((aq > 1e-30) & (aq < 1e30)));
+	rare.flag(R_GUARD, near_f32_midpoint(r) | (RANGE == R_BOTH ? !((aq > 1e-30) & (aq < 1e30)) : false));
 	return F(r);
 }
+template <int RANGE>
 DJB_DEV float sqrt_g(double a, Rare &rare)
 {
 	const double g = sqrt_fast(a);
-	rare.flag(R_GUARD, near_f32_midpoint(g) | !((a > 1e-30) & (a < 1e30)));
+	rare.flag(R_GUARD, near_f32_midpoint(g) | (RANGE == R_BOTH ? !((a > 1e-30) & (a < 1e30)) : false));
 	return F(g);
 }
-DJB_DEV v3 normalize_g(v3 v, Rare &rare) { return scale(inversesqrt_g(dot(v, v), rare), v); }
+template <int RANGE>
+DJB_DEV v3 normalize_g(v3 v, Rare &rare) { return scale(inversesqrt_g<RANGE>(dot(v, v), rare), v); }
 
 DJB_DEV float erf_given_exp_g(float x, double e, Rare &rare)               // erf_given_exp, djb_device.hpp
 {
@@ -161,7 +170,7 @@ DJB_DEV float erf_given_exp_g(float x, double e, Rare &rare)               // er
 	            a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
 	float sign = x < 0 ? -1.0f : 1.0f;
 	x = fabsf(x);
-	float t = recip_g(1.0 + D(p * x), rare);
+	float t = recip_g<R_NONE>(1.0 + D(p * x), rare);                        // x = cot_k in (0, 2900]: the operand is in [1, 952]
 	float poly = ((((a5 * t + a4) * t) + a3) * t + a2) * t + a1;
 	float y = F(1.0 - D(poly * t) * e);
 	return sign * y;
@@ -202,7 +211,9 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 	// u = max(u, 1e-6) is never NaN (djb::max returns its second argument then) and at most 0.99999; fit = 1 + c (-0.876 + c (0.4265
 	// - 0.0594 c)) lies in [0.49, 1] for the cos_k in (0, 1) that are not flagged: powf's special cases cannot occur
 	float b = c - (1 + c) * powf_main(1 - u, fit, gt);
-	float normalization = recip_g(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot, rare);
+	// c >= -2.4e-7 (erf's poly t is at most 1.0000002 and e_cot at most 1) and the second term lies in [0, 7.6e7]: an argument
+	// tiny enough for tan_k > 2^27 (1 + 2^-22) has cot_k^2 < 2^-54, which exp_main_neg flags
+	float normalization = recip_g<R_NONE>(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot, rare);
 	float inv_erf = 0.0f, b_at = 0.0f;
 	bool done = false;
 	auto trip = [&]() {
@@ -245,22 +256,23 @@ DJB_DEV v3 bk_sample_common(const Params &p, float u1, float u2, v3 o, const Gli
 	float a = o.x * p.ax + o.y * p.ay * p.rho;
 	float bb = o.y * p.ay * p.s;
 	float c = o.z - o.x * p.tx - o.y * p.ty;
-	v3 k = normalize_g(mk(a, bb, c), rare);
+	v3 k = normalize_g<R_BOTH>(mk(a, bb, c), rare);
 	// k.z <= 0 returns (0, 0, 1) in the reference, k.z >= 1 skips the rotation: both to the full code
 	rare.flag(R_DEGENERATE, !(D(k.z) > 0.0) | !(D(k.z) < 1.0));
 	float cos_k = k.z;
-	float sin_k = sqrt_g(1.0 - D(k.z * k.z), rare);
-	rare.flag(R_DEGENERATE, !(sin_k > 0.0f));
+	// a float k.z in (0, 1) is at most 1 - 2^-24, its float square at most 1 - 2^-23: the operand lies in [2^-23, 1], sin_k in
+	// [3.4e-4, 1] (the reference's `sin_k > 0` test cannot fail), cot_k in (0, 2900] and tan_k in [3.4e-4, Inf)
+	float sin_k = sqrt_g<R_NONE>(1.0 - D(k.z * k.z), rare);
 	float tx = bk_qf2_common<UNROLL>(u1, cos_k, sin_k, gt, rare);
 	float ty = erfinv_central<false>(F(2.0 * D(u2) - 1.0), gt, rare, R_TAIL_QF1);                     // beckmann_qf1
-	float nrm = inversesqrt_g(k.x * k.x + k.y * k.y, rare);
+	float nrm = inversesqrt_g<R_BOTH>(k.x * k.x + k.y * k.y, rare);
 	float cp = k.x * nrm, sp = k.y * nrm;
 	float txm = cp * tx - sp * ty;
 	float tym = sp * tx + cp * ty;
 	float txh = p.ax * txm + p.tx;
 	float chol = p.rho * txm + p.s * tym;
 	float tyh = p.ay * chol + p.ty;
-	v3 h = normalize_g(mk(-txh, -tyh, 1), rare);
+	v3 h = normalize_g<R_UPPER>(mk(-txh, -tyh, 1), rare);                              // (txh^2 + tyh^2) + 1 >= 1, or Inf / NaN
 	return sub(scale(F(2.0 * D(dot(o, h))), h), o);
 }
 

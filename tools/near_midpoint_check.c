@@ -1,13 +1,15 @@
 /* Exhaustive check that the two-instruction form of near_f32_midpoint (dj_brdf_amd/csrc/djb_device.hpp) equals its
  * definition |(lo & 0x1FFFFFFF) - 2^28| <= width for every low word, for the widths the kernels use.
- * gcc -O2 -o /tmp/nmc tools/near_midpoint_check.c && /tmp/nmc */
+ * gcc -O3 -o /tmp/nmc tools/near_midpoint_check.c && /tmp/nmc [width ...]   (default: 256 1024 1 0 4096) */
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
-int main(void)
+int main(int argc, char **argv)
 {
-	const int widths[] = { 256, 1024, 1, 0, 4096 };
-	for (unsigned w = 0; w < sizeof widths / sizeof widths[0]; ++w) {
-		const int width = widths[w];
+	const int defaults[] = { 256, 1024, 1, 0, 4096 };
+	const int nw = argc > 1 ? argc - 1 : (int)(sizeof defaults / sizeof defaults[0]);
+	for (int w = 0; w < nw; ++w) {
+		const int width = argc > 1 ? atoi(argv[w + 1]) : defaults[w];
 		unsigned long long bad = 0, hits = 0;
 		uint32_t lo = 0;
 		do {

@@ -216,30 +216,33 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 	float normalization = recip_g<R_NONE>(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot, rare);
 	float inv_erf = 0.0f, b_at = 0.0f;
 	bool done = false;
-	auto trip = [&]() {
+	auto trip = [&](bool last) {
 		const float bt = !((b >= a) & (b <= c)) ? 0.5f * (a + c) : b;
-		Rare r;
 		// bt lies in [a, c], a sub-interval of [-1, erf(cot_k)] with finite ends (c = erf_given_exp_g of a finite positive cot_k is in
 		// [0, 1]; a NaN b takes the midpoint): IN_UNIT holds, and |ie| <= 2.18 keeps -ie^2 inside expf's main path
-		const float ie = erfinv_central<true>(bt, gt, r, R_TAIL_LOOP);
+		const float ie = erfinv_central<true>(bt, gt, rare, R_TAIL_LOOP);
 		const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * expf_main(-ie * ie, gt)) - u;
 		const float derivative = normalization * (1 - ie * tan_k);
-		const bool act = !done;                       // a converged lane keeps its result; what it computes from here on is unused
-		rare.merge(r, act);
-		inv_erf = act ? ie : inv_erf;
-		b_at = act ? bt : b_at;
-		done |= fabsf(value) < 1e-5f;
+		inv_erf = ie; b_at = bt;
+		done = fabsf(value) < 1e-5f;
 		const bool pos = value > 0;
 		c = pos ? bt : c; a = pos ? a : bt;
-		b = bt - value / derivative;
+		// a converged lane is frozen instead of masked: with b = bt -- now an end of [a, c] -- the next trip takes the same bt and so
+		// repeats this one exactly (same ie, value, flags; the updates of a, c and done are idempotent): the last trip's ie and
+		// bt are the converged ones, and no per-trip select of the results is needed
+		if (!last) {
+			float next = bt - value / derivative;
+			asm volatile("" : "+v"(next));          // computed by all lanes: no branch around the division for the converged ones
+			b = done ? bt : next;
+		}
 	};
 	if (UNROLL) {
 #pragma unroll
-		for (int t = 0; t < TRIPS; ++t) trip();
+		for (int t = 0; t < TRIPS; ++t) trip(t == TRIPS - 1);
 	} else {
 		int trips = TRIPS;
 		asm volatile("" : "+s"(trips));               // opaque bound: a loop, not four copies of the body
-		for (int t = 0; t < trips; ++t) trip();
+		for (int t = 0; t < trips; ++t) trip(false);
 	}
 	// not converged: more trips; b < -0.9999: the reference re-evaluates erfinv at the clamped argument
 	rare.flag(R_TRIPS, !done);

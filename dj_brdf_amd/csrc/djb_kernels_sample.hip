@@ -12,8 +12,9 @@
 // `rare` flag raised wherever the reference would have left the common path (any arm above, a fifth trip, a
 // degenerate direction).  Flagged samples are not stored; their inputs go to a per-wave queue in LDS, and whenever a
 // wave has collected 64 of them it runs the full per-sample code (sample_one, the one the one-kernel form runs) on
-// them as one dense wave.  1.35 % of the samples take that route on the bench distribution (by cause: profiles/r03/
-// beckmann_sample_two_path.txt, section 3; the DJB_EXP_RARE_COUNT build of this file counts them).  Nothing is approximated
+// them as one dense wave.  1.3 % of the samples take that route on the bench distribution (by cause: profiles/r03/
+// beckmann_sample_two_path.txt, section 3; the DJB_EXP_RARE_COUNT build of this file counts them).  A flag is only raised where
+// the operands at that call site can actually meet the special case (the range arguments stand next to each site).  Nothing is approximated
 // anywhere: both paths are the reference's arithmetic, the split is by control flow only.
 #include "djb_internal.hpp"
 #include <stdio.h>

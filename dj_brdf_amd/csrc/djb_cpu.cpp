@@ -186,7 +186,7 @@ void sample_loop(const Brdf &b, const Params &p, long long k0, long long k1, con
 }
 
 template <int KIND, int WANT, int MODE>
-void pp_loop(const Brdf &b, long long k0, long long k1, const View &vi, const View &vo, const float *rec, const Lrep &base,
+void pp_loop(const Brdf &b, long long k0, long long k1, const View &vi, const View &vo, const float *rec, const LeanCfg &base,
              const View &vout, float *out_pdf, float *out_pp)
 {
 	for (long long k = k0; k < k1; ++k) {
@@ -197,7 +197,7 @@ void pp_loop(const Brdf &b, long long k0, long long k1, const View &vi, const Vi
 	}
 }
 template <int KIND, int MODE>
-void pp_kind(const Brdf &b, long long k0, long long k1, const View &vi, const View &vo, const float *rec, const Lrep &base,
+void pp_kind(const Brdf &b, long long k0, long long k1, const View &vi, const View &vo, const float *rec, const LeanCfg &base,
              const View &vout, float *out_pdf, float *out_pp, int want)
 {
 	switch (want) {
@@ -748,15 +748,15 @@ djb_status sample(djb_ctx *ctx, const djb_brdf *b_, int64_t n, const float *u1, 
 }
 
 djb_status eval_pp(djb_ctx *ctx, const djb_brdf *b_, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o, const float *rec,
-                   int mode, const float *base5, int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pp)
+                   int mode, const float *base5, float scale, int lean_flags, int want, const djb_vec3_view *out_fr, float *out_pdf,
+                   float *out_pp)
 {
 	if (!b_ || !rec) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	const Brdf &b = B(b_)->dev;
 	if (!is_microfacet_kind(b.kind)) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need a microfacet BRDF");
 	if (!valid(i) || !valid(o) || ((want & 3) && !valid(out_fr)) || ((want & 4) && !out_pdf))
 		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
-	Lrep base = { 0, 0, 1, 1, 0 };
-	if (base5) { base.E1 = base5[0]; base.E2 = base5[1]; base.E3 = base5[2]; base.E4 = base5[3]; base.E5 = base5[4]; }
+	const LeanCfg base = lean_cfg(base5, scale, lean_flags);
 	const View vi = view_of(i), vo = view_of(o), vout = (want & 3) ? view_of(out_fr) : View{ nullptr, nullptr, nullptr, 0 };
 	parallel_for(C(ctx), n, 4096, [&](long long k0, long long k1) {
 #define DJB_PP_(K_) (mode == 0 ? pp_kind<K_, 0>(b, k0, k1, vi, vo, rec, base, vout, out_pdf, out_pp, want) \

@@ -655,7 +655,7 @@ DJB_ABI_CATCH
 
 static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
                                  const djb_vec3_view *o, const float *rec, int mode, const float *base5,
-                                 int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pp, int mem)
+                                 float scale, int lean_flags, int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pp, int mem)
 {
 	if (!b || !rec || !ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	const int bkind = djb_brdf_kind(b);
@@ -665,8 +665,8 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: want must be eval(1)|evalp(2) and/or pdf(4)");
 	djb_status st = cpu_pair_check(ctx, b);
 	if (st != DJB_OK) return st;
-	if (is_cpu(ctx)) return n <= 0 ? DJB_OK : djbcpu::eval_pp(ctx, b, n, i, o, rec, mode, base5, want, out_fr, out_pdf, out_pp);
-	if (const djb_brdf *tw = scalar_twin(ctx, b, n, mem)) return n <= 0 ? DJB_OK : djbcpu::eval_pp(djbcpu::twin_ctx(), tw, n, i, o, rec, mode, base5, want, out_fr, out_pdf, out_pp);
+	if (is_cpu(ctx)) return n <= 0 ? DJB_OK : djbcpu::eval_pp(ctx, b, n, i, o, rec, mode, base5, scale, lean_flags, want, out_fr, out_pdf, out_pp);
+	if (const djb_brdf *tw = scalar_twin(ctx, b, n, mem)) return n <= 0 ? DJB_OK : djbcpu::eval_pp(djbcpu::twin_ctx(), tw, n, i, o, rec, mode, base5, scale, lean_flags, want, out_fr, out_pdf, out_pp);
 	st = check_call(ctx, b, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -680,7 +680,7 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
 		if (out_pp) { kq = (int)outs.size(); outs.push_back(PipeArr::arr(out_pp, 5)); }
 		st = host_pipeline(ctx, n, ins, outs, [&](long long m, int s) {
 			djb_vec3_view dvi = ins[0].view(s), dvo = ins[1].view(s), dvf = wfr ? outs[kf].view(s) : djb_vec3_view{ nullptr, nullptr, nullptr, 0 };
-			return eval_pp_common(ctx, b, m, &dvi, &dvo, ins[2].dev[s], mode, base5, want, wfr ? &dvf : nullptr,
+			return eval_pp_common(ctx, b, m, &dvi, &dvo, ins[2].dev[s], mode, base5, scale, lean_flags, want, wfr ? &dvf : nullptr,
 			                      wpdf ? outs[kp].dev[s] : nullptr, out_pp ? outs[kq].dev[s] : nullptr, DJB_MEM_DEVICE);
 		}, &taken);
 		if (taken || st != DJB_OK) return st;
@@ -705,7 +705,7 @@ static djb_status eval_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, con
 			sg.out_raw.push_back({ dpp, { out_pp, sizeof(float) * 5 * (size_t)n } });
 		}
 	}
-	HIP_TRY(djbk::launch_eval_pp(ctx->stream, b->dev, n, vi, vo, drec, mode, base5, vout, dpdf, dpp, want));
+	HIP_TRY(djbk::launch_eval_pp(ctx->stream, b->dev, n, vi, vo, drec, mode, base5, scale, lean_flags, vout, dpdf, dpp, want));
 	return sg.finish();
 }
 
@@ -713,19 +713,22 @@ djb_status djb_eval_pp_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const d
                              const djb_vec3_view *o, const float *pdfparams, int want,
                              const djb_vec3_view *out_fr, float *out_pdf, int mem)
 try {
-	return eval_pp_common(ctx, b, n, i, o, pdfparams, 0, nullptr, want, out_fr, out_pdf, nullptr, mem);
+	return eval_pp_common(ctx, b, n, i, o, pdfparams, 0, nullptr, 1.0f, 0, want, out_fr, out_pdf, nullptr, mem);
 }
 DJB_ABI_CATCH
 
 djb_status djb_eval_lean_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
-                               const djb_vec3_view *o, const djb_params *base, float scale, const float *lean,
-                               int want, const djb_vec3_view *out_fr, float *out_pdf, float *out_pdfparams, int mem)
+                               const djb_vec3_view *o, const djb_params *base, float scale, int lean_flags,
+                               const float *lean, int want, const djb_vec3_view *out_fr, float *out_pdf,
+                               float *out_pdfparams, int mem)
 try {
-	float l1[5], base5[5];
-	djb_status st = djb_params_to_lrep(base, l1);
+	if (lean_flags & ~(DJB_LEAN_NAIVE_MIP | DJB_LEAN_BIASED))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown LEAN flag");
+	if (!(scale >= 0.0f)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid scale");   // lrep::operator*= asserts sc >= 0, dj_brdf.h:2024
+	float base5[5];
+	djb_status st = djb_params_to_lrep(base, base5);                                           // lrep2, dj_beckmannconductor.cpp:312
 	if (st != DJB_OK) return st;
-	if ((st = djb_lrep_op(DJB_LREP_IMUL, l1, nullptr, scale, 0.0f, base5)) != DJB_OK) return st;
-	return eval_pp_common(ctx, b, n, i, o, lean, 1, base5, want, out_fr, out_pdf, out_pdfparams, mem);
+	return eval_pp_common(ctx, b, n, i, o, lean, 1, base5, scale, lean_flags, want, out_fr, out_pdf, out_pdfparams, mem);
 }
 DJB_ABI_CATCH
 

@@ -30,11 +30,12 @@ hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p,
                                   unsigned long long start, const View &o, const View &out_i,
                                   const View *out_w, float *out_pdf);
 
-// per-pair params: rec = n x 5 floats; mode 0 = pdfparams records, mode 1 = LEAN moments added to
-// base5 (params_to_lrep(base) * scale); out_pp (optional, mode 1) receives the resolved pdfparams
+// per-pair params: rec = n x 5 floats; mode 0 = pdfparams records, mode 1 = LEAN texel moments composed with
+// base5 = params_to_lrep(base) (unscaled), scale = dmapscale, lean_flags = DJB_LEAN_* as dj_beckmannconductor does;
+// out_pp (optional, mode 1) receives the resolved pdfparams
 hipError_t launch_eval_pp(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
-                          const float *rec, int mode, const float *base5, const View &out, float *out_pdf,
-                          float *out_pp, int want);
+                          const float *rec, int mode, const float *base5, float scale, int lean_flags, const View &out,
+                          float *out_pdf, float *out_pp, int want);
 
 // microfacet / radial queries; out.x holds scalar results (out.xyz for the Fresnel query)
 hipError_t launch_query(hipStream_t s, const Brdf &b, const Params &p, int which, long long n,

@@ -183,11 +183,11 @@ hipError_t launch_eval_kind(hipStream_t s, const Brdf &b, const Params &p, long 
 // ------------------------------------------------------------------ per-pair parameters (LEAN / LEADR)
 // The batch form of "build microfacet::params per hit, then evalp(i, o, &params)"
 // (mitsuba/dj_beckmannconductor.cpp:291-319).  MODE 0: pdfparams records (ax, ay, rho, tx, ty) are
-// read per pair.  MODE 1: per-pair LEAN moments (E1..E5) are combined on the fly with the scaled
-// base lobe: params = lrep_to_params(base_lrep + lean_k), and optionally written back.
+// read per pair.  MODE 1: per-pair LEAN texel moments (E1..E5) are composed on the fly with the base
+// lobe, params = lrep_to_params(lrep(lean_k) * dmapscale + params_to_lrep(base)), and optionally written back.
 template <int KIND, int WANT, int MODE, int FRK = -1>
 __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi, View vo, const float *rec,
-                                                   Lrep base, View vout, float *out_pdf, float *out_pp)
+                                                   LeanCfg base, View vout, float *out_pdf, float *out_pp)
 {
 	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];     // as in k_eval
 	if (KIND == KIND_BECKMANN) { b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK); __syncthreads(); }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi,
 
 template <int KIND, int MODE, int FRK>
 hipError_t launch_eval_pp_kind_fr(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
-                                  const float *rec, const Lrep &base, const View &out, float *out_pdf,
+                                  const float *rec, const LeanCfg &base, const View &out, float *out_pdf,
                                   float *out_pp, int want)
 {
 	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
@@ -219,7 +219,7 @@ hipError_t launch_eval_pp_kind_fr(hipStream_t s, const Brdf &b, long long n, con
 
 template <int KIND, int MODE>
 hipError_t launch_eval_pp_kind(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
-                               const float *rec, const Lrep &base, const View &out, float *out_pdf,
+                               const float *rec, const LeanCfg &base, const View &out, float *out_pdf,
                                float *out_pp, int want)
 {
 	// as launch_eval_kind: the analytic lobes get kernels specialised for the ideal / schlick Fresnel terms
@@ -527,12 +527,11 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 }
 
 hipError_t launch_eval_pp(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
-                          const float *rec, int mode, const float *base5, const View &out, float *out_pdf,
-                          float *out_pp, int want)
+                          const float *rec, int mode, const float *base5, float scale, int lean_flags, const View &out,
+                          float *out_pdf, float *out_pp, int want)
 {
 	if (n <= 0) return hipSuccess;
-	Lrep base = { 0, 0, 1, 1, 0 };
-	if (base5) { base.E1 = base5[0]; base.E2 = base5[1]; base.E3 = base5[2]; base.E4 = base5[3]; base.E5 = base5[4]; }
+	const LeanCfg base = lean_cfg(base5, scale, lean_flags);
 #define DJB_PP(K) (mode == 0 ? launch_eval_pp_kind<K, 0>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want) \
                              : launch_eval_pp_kind<K, 1>(s, b, n, i, o, rec, base, out, out_pdf, out_pp, want))
 	switch (b.kind) {

@@ -624,11 +624,17 @@ def _eval_pp(self, i, o, pdfparams, want="evalp"):
     return _eval_records(self, "djb_eval_pp_batch", i, o, pdfparams, want, lambda p: [C.c_void_p(p)])
 
 
-def _eval_lean(self, i, o, base, scale, lean, want="evalp", return_params=False):
-    """dj_beckmannconductor's per-hit path, batched: params_k = lrep_to_params(lrep(base)*scale + lean_k)
-    with lean [n,5] = LEAN/LEADR slope moments (E1..E5)."""
+LEAN_NAIVE_MIP, LEAN_BIASED = 1, 2      # include/djb_hip.h DJB_LEAN_*
+
+
+def _eval_lean(self, i, o, base, scale, lean, want="evalp", return_params=False, filtering=True, biased=False):
+    """dj_beckmannconductor's per-hit path, batched (mitsuba/dj_beckmannconductor.cpp:296-314):
+    params_k = lrep_to_params(lrep(lean_k) * scale + params_to_lrep(base)), lean [n,5] = LEAN/LEADR texel moments
+    (E1..E5), scale = the plugin's dmapscale.  filtering=False: the plugin's leanFiltering=false branch,
+    lrep(E1, E2, E1*E1, E2*E2, E1*E2).  biased=True: records are raw texels (E1, E2 carry +25, E5 +625)."""
+    flags = (0 if filtering else LEAN_NAIVE_MIP) | (LEAN_BIASED if biased else 0)
     return _eval_records(self, "djb_eval_lean_batch", i, o, lean, want,
-                         lambda p: [_params_ptr(base), C.c_float(scale), C.c_void_p(p)], want_pp=return_params)
+                         lambda p: [_params_ptr(base), C.c_float(scale), C.c_int(flags), C.c_void_p(p)], want_pp=return_params)
 
 
 microfacet.eval_pp = _eval_pp

@@ -273,15 +273,20 @@ djb_status djb_query_batch(djb_ctx *, const djb_brdf *, int which, int64_t n, co
 /* ---- per-pair microfacet parameters (what dj_beckmannconductor builds per hit,
  * mitsuba/dj_beckmannconductor.cpp:291-319).  want = 1 eval | 2 evalp, optionally | 4 pdf.
  * djb_eval_pp_batch:   pdfparams = n records (ax, ay, rho, tx_n, ty_n), i.e. evalp(i, o, &params_k).
- * djb_eval_lean_batch: lean = n records of LEAN/LEADR slope moments (E1..E5); per pair
- *   params_k = lrep_to_params(params_to_lrep(base) * scale + lean_k)   (dj_brdf.h:1965-1999)
- *   and, if out_pdfparams != NULL, the resolved (ax, ay, rho, tx, ty) are written back.
+ * djb_eval_lean_batch: lean = n records of LEAN/LEADR texel moments (E1..E5); per pair, in the plugin's order
+ *   (mitsuba/dj_beckmannconductor.cpp:296-314, repeated at 344-362 and 384-402):
+ *     lrep1 = lrep(E1, E2, E3, E4, E5)               [DJB_LEAN_NAIVE_MIP: lrep(E1, E2, E1*E1, E2*E2, E1*E2), leanFiltering=false]
+ *     lrep1 *= scale                                  [m_dmapScale]
+ *     params_k = lrep_to_params(lrep1 + params_to_lrep(base))          (dj_brdf.h:1965-2033; operator+ is not commutative in float)
+ *   DJB_LEAN_BIASED: the records are raw texels, E1 -= 25, E2 -= 25, E5 -= 625 first (l.300-303).
+ *   If out_pdfparams != NULL, the resolved (ax, ay, rho, tx, ty) are written back.
  * Records live in the same memory space as the directions.                                 */
+enum { DJB_LEAN_NAIVE_MIP = 1, DJB_LEAN_BIASED = 2 };
 djb_status djb_eval_pp_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i,
                              const djb_vec3_view *o, const float *pdfparams, int want,
                              const djb_vec3_view *out_fr, float *out_pdf, int mem);
 djb_status djb_eval_lean_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i,
-                               const djb_vec3_view *o, const djb_params *base, float scale,
+                               const djb_vec3_view *o, const djb_params *base, float scale, int lean_flags,
                                const float *lean, int want, const djb_vec3_view *out_fr,
                                float *out_pdf, float *out_pdfparams, int mem);
 /* beckmann::lrep algebra on {E1..E5} (host scalars; dj_brdf.h:330-356, 1959-2051).  b may be NULL

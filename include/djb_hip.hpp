@@ -542,12 +542,14 @@ public:
 		hip::check(djb_lrep_to_params(l.m_E, &d));
 		*params = microfacet::params::pdfparams(d.v[0], d.v[1], d.v[2], d.v[3], d.v[4]);
 	}
-	/* batch form of dj_beckmannconductor's per-hit evaluation: lean[n][5] slope moments */
-	void evalp_lean(size_t n, const vec3 *i, const vec3 *o, const microfacet::params &base, float_t scale,
-	                const float_t *lean, vec3 *out_fr_cos, float_t *out_pdf = NULL) const
+	/* batch form of dj_beckmannconductor's per-hit evaluation (mitsuba/dj_beckmannconductor.cpp:296-319):
+	 * lean[n][5] texel moments; params_k = lrep_to_params(lrep(lean_k) * dmapscale + params_to_lrep(base));
+	 * lean_flags = DJB_LEAN_NAIVE_MIP (leanFiltering = false) | DJB_LEAN_BIASED (raw texels, bias 25 / 625) */
+	void evalp_lean(size_t n, const vec3 *i, const vec3 *o, const microfacet::params &base, float_t dmapscale,
+	                const float_t *lean, vec3 *out_fr_cos, float_t *out_pdf = NULL, int lean_flags = 0) const
 	{
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out_fr_cos);
-		hip::check(djb_eval_lean_batch(ctx(), m_h, (int64_t)n, &vi, &vo, base.desc(), scale, lean,
+		hip::check(djb_eval_lean_batch(ctx(), m_h, (int64_t)n, &vi, &vo, base.desc(), dmapscale, lean_flags, lean,
 		                               out_pdf ? 6 : 2, &vr, out_pdf, NULL, DJB_MEM_HOST));
 	}
 	beckmann(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)

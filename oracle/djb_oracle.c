@@ -1544,14 +1544,32 @@ void o_params_lrep_roundtrip(const o_param_desc *pd, float *out_pdfparams)
 	o_params p = params_from_desc(pd);
 	lrep_to_pdfparams(params_to_lrep(&p), out_pdfparams);
 }
-/* mitsuba/dj_beckmannconductor.cpp:291-319 per hit: lrep_to_params(params_to_lrep(base)*scale + lean_k) */
+/* one hit of the plugin (mitsuba/dj_beckmannconductor.cpp:296-314; again at 344-362, 384-402):
+ *   flags & 2: the record is a raw texel, E1 -= BIAS, E2 -= BIAS, E5 -= BIAS*BIAS (BIAS = 25.f, l.300-303)
+ *   lrep1 = lrep(E1..E5), or with flags & 1 (leanFiltering = false) lrep(E1, E2, E1*E1, E2*E2, E1*E2)   (l.306-309)
+ *   lrep1 *= dmapscale (l.311, hdr:2022-2033); lrep2 = params_to_lrep(base) (l.312); lrep_to_params(lrep1 + lrep2) (l.314) */
+static void lean_hit_pdfparams(const float *rec, const o_params *base, float scale, int flags, float *pp)
+{
+	float E1 = rec[0], E2 = rec[1], E3 = rec[2], E4 = rec[3], E5 = rec[4];
+	const float BIAS = 25.f;
+	if (flags & 2) { E1 -= BIAS; E2 -= BIAS; E5 -= BIAS * BIAS; }
+	o_lrep l1 = { E1, E2, E3, E4, E5 };
+	if (flags & 1) { o_lrep naive = { E1, E2, E1 * E1, E2 * E2, E1 * E2 }; l1 = naive; }
+	l1 = lrep_mul(l1, scale);          /* operator*= computes the same values as operator* (hdr:2001-2009 vs 2022-2033) */
+	lrep_to_pdfparams(lrep_add(l1, params_to_lrep(base)), pp);
+}
+void o_lean_params(int64_t n, const o_param_desc *base, float scale, int flags, const float *lean, float *out_pdfparams)
+{
+	o_params p0 = params_from_desc(base);
+	for (int64_t k = 0; k < n; ++k) lean_hit_pdfparams(lean + 5 * k, &p0, scale, flags, out_pdfparams + 5 * k);
+}
 void o_eval_lean(const o_brdf *b, int op, int64_t n, const float *i, const float *o, const o_param_desc *base,
-                 float scale, const float *lean, float *out, float *out_pdfparams)
+                 float scale, int flags, const float *lean, float *out, float *out_pdfparams)
 {
 	o_params p0 = params_from_desc(base);
 	for (int64_t k = 0; k < n; ++k) {
 		float pp[5];
-		lrep_to_pdfparams(lrep_add(lrep_mul(params_to_lrep(&p0), scale), lrep_from(lean + 5 * k)), pp);
+		lean_hit_pdfparams(lean + 5 * k, &p0, scale, flags, pp);
 		if (out_pdfparams) memcpy(out_pdfparams + 5 * k, pp, sizeof pp);
 		o_params p;
 		params_set_pdfparams(&p, pp[0], pp[1], pp[2], pp[3], pp[4]);

@@ -317,29 +317,48 @@ void ref_params_lrep_roundtrip(const shim_params *sp, float *out_pdfparams)
 	q.get_pdfparams(&out_pdfparams[0], &out_pdfparams[1], &out_pdfparams[2], &out_pdfparams[3], &out_pdfparams[4]);
 }
 
-// what dj_beckmannconductor does per hit (mitsuba/dj_beckmannconductor.cpp:291-319, without the
-// texture fetch): base params -> lrep1; lrep1 *= scale; params = lrep_to_params(lrep1 + lrep2);
-// then evalp / pdf with those per-pair params.  lean: n x 5 raw moments (E1..E5) of lrep2.
-// op: 0 eval, 1 evalp (n x 3), 2 pdf (n)
+// One hit of dj_beckmann_conductor::eval / pdf / sample, statement by statement as the plugin has it
+// (/root/reference/mitsuba/dj_beckmannconductor.cpp:296-314; the same block again at 344-362 and 384-402),
+// minus the texture fetches: `lean` holds the five texel values per hit, `base` the elliptic params the
+// plugin builds from its alpha textures (l.291-295), `scale` = m_dmapScale.
+// flags: 1 = leanFiltering false (naive MIP branch), 2 = texels carry the +25 / +625 bias (subtract it as l.300-303 do).
+// op: 0 eval, 1 evalp (n x 3), 2 pdf (n), 3 = parameters only
 void ref_eval_lean(void *b_, int op, long n, const float *i, const float *o, const shim_params *base,
-                   float scale, const float *lean, float *out, float *out_pdfparams)
+                   float scale, int flags, const float *lean, float *out, float *out_pdfparams)
 {
 	const djb::brdf *b = (const djb::brdf *)b_;
 	param_holder ph(base);
-	djb::microfacet::params p0 = ph.ptr ? ph.p : djb::microfacet::params::standard();
+	const bool m_leanFiltering = !(flags & 1);
+	const float m_dmapScale = scale;
 	for (long k = 0; k < n; ++k) {
-		djb::beckmann::lrep l1, l2(lean[5*k], lean[5*k+1], lean[5*k+2], lean[5*k+3], lean[5*k+4]);
-		djb::beckmann::params_to_lrep(p0, &l1);
-		l1 *= scale;
-		djb::microfacet::params p;
-		djb::beckmann::lrep_to_params(l1 + l2, &p);
+		djb::microfacet::params params = ph.ptr ? ph.p : djb::microfacet::params::standard();
+		float E1 = lean[5*k], E2 = lean[5*k+1], E3 = lean[5*k+2], E4 = lean[5*k+3], E5 = lean[5*k+4];
+		const float BIAS = 25.f;
+		if (flags & 2) {
+			E1-= BIAS;
+			E2-= BIAS;
+			E5-= BIAS*BIAS;
+		}
+		djb::beckmann::lrep lrep1, lrep2;
+
+		if (m_leanFiltering) { // LEAN filtering
+			lrep1 = djb::beckmann::lrep(E1, E2, E3, E4, E5);
+		} else { // Naive MIP mapping
+			lrep1 = djb::beckmann::lrep(E1, E2, E1*E1, E2*E2, E1*E2);
+		}
+		lrep1*= m_dmapScale;
+		djb::beckmann::params_to_lrep(params, &lrep2);
+		/* Get final microfacet Parameters */
+		djb::beckmann::lrep_to_params(lrep1 + lrep2, &params);
+
 		if (out_pdfparams)
-			p.get_pdfparams(&out_pdfparams[5*k], &out_pdfparams[5*k+1], &out_pdfparams[5*k+2],
-			                &out_pdfparams[5*k+3], &out_pdfparams[5*k+4]);
+			params.get_pdfparams(&out_pdfparams[5*k], &out_pdfparams[5*k+1], &out_pdfparams[5*k+2],
+			                     &out_pdfparams[5*k+3], &out_pdfparams[5*k+4]);
+		if (op == 3) continue;
 		djb::vec3 vi = ld(i, k), vo = ld(o, k);
-		if (op == 0)      st(out, k, b->eval(vi, vo, &p));
-		else if (op == 1) st(out, k, b->evalp(vi, vo, &p));
-		else              out[k] = b->pdf(vi, vo, &p);
+		if (op == 0)      st(out, k, b->eval(vi, vo, (const void *)&params));
+		else if (op == 1) st(out, k, b->evalp(vi, vo, (const void *)&params));
+		else              out[k] = b->pdf(vi, vo, (const void *)&params);
 	}
 }
 

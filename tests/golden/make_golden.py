@@ -30,6 +30,14 @@ from golden_cases import (FIT_CASES, MICROFACET_CASES, N_FIT_EVAL, N_HD, N_MERL,
                           PARAM_CASES, PARAMS_TXT_MATERIALS)
 
 
+ONLY = set(sys.argv[1:])      # e.g. `make_golden.py lean.npz`: rewrite just that fixture (the others stay byte-identical in git)
+
+
+def save(name, **arrays):
+    if not ONLY or name in ONLY:
+        np.savez_compressed(os.path.join(HERE, name), **arrays)
+
+
 def main():
     R = oraclelib.reference()
     assert R is not None, "needs /root/reference (build container)"
@@ -47,7 +55,7 @@ def main():
         out[f"c{k}_sample"] = R.sample(b, u1, u2, o, par)
         w, si, pdf = R.evalp_is(b, u1, u2, o, par)
         out[f"c{k}_is_w"], out[f"c{k}_is_i"], out[f"c{k}_is_pdf"] = w, si, pdf
-    np.savez_compressed(os.path.join(HERE, "microfacet.npz"), **out)
+    save("microfacet.npz", **out)
 
     # ---- params, special functions, half/diff transforms
     out = {}
@@ -68,7 +76,7 @@ def main():
     h, d = R.io_to_hd(i, o)
     bi, bo = R.hd_to_io(h, d)
     out.update(hd_i=i, hd_o=o, hd_h=h, hd_d=d, hd_back_i=bi, hd_back_o=bo)
-    np.savez_compressed(os.path.join(HERE, "math.npz"), **out)
+    save("math.npz", **out)
 
     # ---- sgd / abc analytic models (published parameter tables) and the fit the dj_abc / dj_sgd
     #      plugins run at load time: tabular(model, 90)  (mitsuba/dj_abc.cpp:31, dj_sgd.cpp:31)
@@ -91,10 +99,10 @@ def main():
         t = R.tabular(getattr(R, kind)(MODEL_MATERIALS[0]), 90, True)
         for k, v in R.tabular_tables(t).items():
             out[f"{kind}_fit_{k}"] = np.atleast_1d(v)
-    np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
+    save("models.npz", **out)
 
     # ---- beckmann::lrep algebra and the per-hit LEAN path of dj_beckmannconductor
-    from golden_cases import LEAN_BASE, LEAN_SCALE, N_LEAN, lean_moments, lrep_cases
+    from golden_cases import LEAN_BASE, LEAN_CASES, N_LEAN, lean_moments, lean_texels, lrep_cases
     out = {}
     for k, (op, a, b, x, y) in enumerate(lrep_cases()):
         out[f"lrep{k}"] = R.lrep_op(op, a, b, x, y)
@@ -104,13 +112,15 @@ def main():
     o = synth.directions_aos(N_LEAN, synth.SEED_O, start=30000)
     lean = lean_moments(N_LEAN)
     out.update(i=i, o=o, lean=lean)
-    for ndf in ("beckmann", "ggx"):
-        b = R.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
-        for op in ("eval", "evalp", "pdf"):
-            val, pp = R.eval_lean(b, i, o, LEAN_BASE, LEAN_SCALE, lean, op)
-            out[f"{ndf}_{op}"] = val
-        out["pdfparams"] = pp
-    np.savez_compressed(os.path.join(HERE, "lean.npz"), **out)
+    for c, (scale, filtering, biased) in enumerate(LEAN_CASES):
+        tex = lean_texels(lean, biased)
+        for ndf in ("beckmann", "ggx"):
+            b = R.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
+            for op in ("eval", "evalp", "pdf"):
+                val, pp = R.eval_lean(b, i, o, LEAN_BASE, scale, tex, op, filtering=filtering, biased=biased)
+                out[f"c{c}_{ndf}_{op}"] = val
+            out[f"c{c}_pdfparams"] = pp
+    save("lean.npz", **out)
 
     # ---- tabular_anisotropic: fit tables, moment fits, sampling queries, operators
     from golden_cases import ANISO_CASES, N_ANISO, aniso_source
@@ -133,7 +143,7 @@ def main():
         out[f"{name}_eval_ell"] = R.eval(t, i, o, ("elliptic", 0.2, 0.5, 0.7), "eval")
         out[f"{name}_sample"] = R.sample(t, u1, u2, o)
     shutil.rmtree(tmpa, ignore_errors=True)
-    np.savez_compressed(os.path.join(HERE, "aniso.npz"), **out)
+    save("aniso.npz", **out)
 
     # ---- MERL lookup (hash-filled table: exact on any machine)
     tmp = tempfile.mkdtemp(prefix="djb_golden_")
@@ -143,9 +153,10 @@ def main():
         path = os.path.join(tmp, "hashed.binary")
         synth.write_merl_binary(path, synth.merl_table_hashed())
         m = R.merl(path)
-        np.savez_compressed(os.path.join(HERE, "merl.npz"), i=i, o=o, index=R.merl_index(i, o),
-                            eval=R.eval(m, i, o), evalp=R.eval(m, i, o, None, "evalp"),
-                            pdf=R.eval(m, i, o, None, "pdf"))
+        save("merl.npz", i=i, o=o, index=R.merl_index(i, o), eval=R.eval(m, i, o),
+             evalp=R.eval(m, i, o, None, "evalp"), pdf=R.eval(m, i, o, None, "pdf"))
+        if ONLY and not ({"fit.npz", "params_expected.txt"} & ONLY):
+            return
 
         # ---- the fitter
         i = synth.directions_aos(N_FIT_EVAL, synth.SEED_I, start=9000)
@@ -168,7 +179,7 @@ def main():
             out[f"{name}_eval"] = R.eval(t, i, o, None, "eval")
             out[f"{name}_pdf"] = R.eval(t, i, o, None, "pdf")
             out[f"{name}_sample"] = R.sample(t, u1, u2, o)
-        np.savez_compressed(os.path.join(HERE, "fit.npz"), **out)
+        save("fit.npz", **out)
 
         # ---- params.txt of the reference's own example driver (examples/merl_params.cpp)
         exe = oraclelib.ref_merl_params_binary()
@@ -178,7 +189,8 @@ def main():
             synth.write_merl_binary(path, synth.merl_table(*recipe))
             files.append(path)
         subprocess.run([exe] + files, cwd=tmp, check=True, stdout=subprocess.DEVNULL)
-        shutil.copy(os.path.join(tmp, "params.txt"), os.path.join(HERE, "params_expected.txt"))
+        if not ONLY or "params_expected.txt" in ONLY:
+            shutil.copy(os.path.join(tmp, "params.txt"), os.path.join(HERE, "params_expected.txt"))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     for f in sorted(os.listdir(HERE)):

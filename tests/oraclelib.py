@@ -179,16 +179,19 @@ class CheckerLib:
         self._fn("params_lrep_roundtrip")(C.byref(pd), _ptr(out))
         return out
 
-    def eval_lean(self, b, i, o, base, scale, lean, op="eval"):
-        """dj_beckmannconductor's per-hit path: params = lrep_to_params(lrep(base)*scale + lean_k)."""
+    def eval_lean(self, b, i, o, base, scale, lean, op="eval", filtering=True, biased=False):
+        """dj_beckmannconductor's per-hit path (mitsuba/dj_beckmannconductor.cpp:296-314):
+        params = lrep_to_params(lrep(lean_k) * scale + params_to_lrep(base)); filtering=False is the plugin's
+        naive-MIP branch, biased=True subtracts the texel bias (25, 25, 625) first."""
         i, o, lean = _f32(i), _f32(o), _f32(lean)
         n = i.shape[0]
         opc = {"eval": 0, "evalp": 1, "pdf": 2}[op]
         out = np.empty((n,) if opc == 2 else (n, 3), dtype=np.float32)
         pp = np.empty((n, 5), dtype=np.float32)
         pd = param_desc(base)
+        flags = (0 if filtering else 1) | (2 if biased else 0)
         self._fn("eval_lean")(b, C.c_int(opc), C.c_int64(n), _ptr(i), _ptr(o), C.byref(pd), C.c_float(scale),
-                              _ptr(lean), _ptr(out), _ptr(pp))
+                              C.c_int(flags), _ptr(lean), _ptr(out), _ptr(pp))
         return out, pp
 
     def eval_pp(self, b, i, o, pp, op="eval"):

@@ -176,14 +176,17 @@ def test_params_txt_on_the_cpu(cpu, tmp_path):
 
 
 def test_lean_and_queries(cpu, oracle, dirs):
-    from golden_cases import LEAN_BASE, LEAN_SCALE, lean_moments
+    from golden_cases import LEAN_BASE, LEAN_CASES, lean_moments, lean_texels
     i, o, u1, u2 = dirs
     lean = lean_moments(N)
     b = djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=cpu)
     ob = oracle.microfacet("beckmann", ("schlick", 1.0, 0.71, 0.29), True)
-    got = djb._eval_lean(b, i, o, mk_params(LEAN_BASE), LEAN_SCALE, lean, want="evalp")
-    want, _ = oracle.eval_lean(ob, i, o, LEAN_BASE, LEAN_SCALE, lean, "evalp")
-    assert same(got, want)
+    for scale, filtering, biased in LEAN_CASES:
+        tex = lean_texels(lean, biased)
+        got, gpp = djb._eval_lean(b, i, o, mk_params(LEAN_BASE), scale, tex, want="evalp", return_params=True,
+                                  filtering=filtering, biased=biased)
+        want, wpp = oracle.eval_lean(ob, i, o, LEAN_BASE, scale, tex, "evalp", filtering=filtering, biased=biased)
+        assert same(gpp, wpp) and same(got, want), (scale, filtering, biased)
     h = oracle.io_to_hd(i, o)[0]
     up, p = mk_params(PARAMS[2]), PARAMS[2]
     assert same(b.ndf(h, up), oracle.microfacet_query(ob, "ndf", h, params=p))

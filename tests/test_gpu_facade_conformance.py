@@ -145,15 +145,17 @@ def test_tabular_and_lrep(facade, oracle, inputs):
 
 def test_anisotropic_and_lean(facade, oracle, inputs):
     i, o, u1, u2 = inputs
-    from golden_cases import LEAN_BASE, LEAN_SCALE, lean_moments
+    from golden_cases import LEAN_BASE, LEAN_SCALE, lean_moments, lean_texels
     # dj_beckmannconductor's per-hit path through beckmann::lrep and per-call microfacet::params
     lean = lean_moments(N)
     for ndf in ("beckmann", "ggx"):
         f, b = facade.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True), oracle.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
-        for op in ("evalp", "pdf"):
-            got, gpp = facade.eval_lean(f, i, o, LEAN_BASE, LEAN_SCALE, lean, op)
-            want, wpp = oracle.eval_lean(b, i, o, LEAN_BASE, LEAN_SCALE, lean, op)
-            close(f"{ndf} lean params", gpp, wpp); close(f"{ndf} lean {op}", got, want)
+        for scale, filtering, biased in ((LEAN_SCALE, True, False), (2.0, False, False), (0.5, True, True)):
+            tex = lean_texels(lean, biased)
+            for op in ("evalp", "pdf"):
+                got, gpp = facade.eval_lean(f, i, o, LEAN_BASE, scale, tex, op, filtering=filtering, biased=biased)
+                want, wpp = oracle.eval_lean(b, i, o, LEAN_BASE, scale, tex, op, filtering=filtering, biased=biased)
+                close(f"{ndf} lean params", gpp, wpp); close(f"{ndf} lean {op}", got, want)
     # tabular_anisotropic on a small grid: tables, fits, two-level sampling queries, eval
     ft = facade.tabular_anisotropic(facade.microfacet("ggx"), 12, 16, True)
     ot = oracle.tabular_anisotropic(oracle.microfacet("ggx"), 12, 16, True)

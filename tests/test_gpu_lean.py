@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from dj_brdf_amd import djb
-from golden_cases import LEAN_BASE, LEAN_SCALE, PARAM_CASES, lrep_cases
+from golden_cases import (LEAN_ANCHOR, LEAN_ANCHOR_E, LEAN_BASE, LEAN_CASES, LEAN_SCALE, PARAM_CASES, lean_texels,
+                          lrep_cases)
 from test_gpu_parity import assert_close, mk_params
 
 pytestmark = pytest.mark.gpu
@@ -43,14 +44,40 @@ def test_lean_eval_golden(gpu_ctx, ndf):
     g = np.load(os.path.join(G, "lean.npz"))
     b = getattr(djb, ndf)(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
     base = mk_params(LEAN_BASE)
-    for op in ("eval", "evalp", "pdf"):
-        val, pp = b.eval_lean(g["i"], g["o"], base, LEAN_SCALE, g["lean"], want=op, return_params=True)
-        assert np.array_equal(pp.view(np.uint32), g["pdfparams"].view(np.uint32)), "resolved per-pair params differ"
-        ex = assert_close(f"{ndf}/lean/{op}", val, g[f"{ndf}_{op}"])
-        assert ex > 0.9999
-        assert_close(f"{ndf}/pp/{op}", b.eval_pp(g["i"], g["o"], g["pdfparams"], want=op), g[f"{ndf}_{op}"])
-    fr, pdf = b.eval_lean(g["i"], g["o"], base, LEAN_SCALE, g["lean"], want="evalp+pdf")
-    assert_close("fused evalp", fr, g[f"{ndf}_evalp"]); assert_close("fused pdf", pdf, g[f"{ndf}_pdf"])
+    # tile the 512 golden hits past the scalar-twin threshold so the kernels (not the host twin) answer
+    reps = 4
+    i, o = np.tile(g["i"], (reps, 1)), np.tile(g["o"], (reps, 1))
+    for c, (scale, filtering, biased) in enumerate(LEAN_CASES):
+        tex = np.tile(lean_texels(g["lean"], biased), (reps, 1))
+        kw = dict(filtering=filtering, biased=biased)
+        wpp = np.tile(g[f"c{c}_pdfparams"], (reps, 1))
+        for op in ("eval", "evalp", "pdf"):
+            want = np.tile(g[f"c{c}_{ndf}_{op}"], (reps, 1) if op != "pdf" else reps)
+            val, pp = b.eval_lean(i, o, base, scale, tex, want=op, return_params=True, **kw)
+            assert np.array_equal(pp.view(np.uint32), wpp.view(np.uint32)), f"case {c}: resolved per-pair params differ"
+            ex = assert_close(f"{ndf}/lean{c}/{op}", val, want)
+            assert ex > 0.9999
+            assert_close(f"{ndf}/pp{c}/{op}", b.eval_pp(i, o, wpp, want=op), want)
+        fr, pdf = b.eval_lean(i, o, base, scale, tex, want="evalp+pdf", **kw)
+        assert_close("fused evalp", fr, np.tile(g[f"c{c}_{ndf}_evalp"], (reps, 1)))
+        assert_close("fused pdf", pdf, np.tile(g[f"c{c}_{ndf}_pdf"], reps))
+
+
+def test_lean_composition_anchor(gpu_ctx):
+    """lrep(lean) * dmapscale + params_to_lrep(base), the plugin's order (mitsuba/dj_beckmannconductor.cpp:296-314):
+    the per-pair params the real header gives for one texel at dmapscale 0.7 and 2."""
+    b = djb.beckmann(ctx=gpu_ctx)
+    n = 4096                                              # device kernel, not the scalar twin
+    d = np.tile(np.array([[0.3, 0.2, 0.9327379]], np.float32), (n, 1))
+    E = np.tile(np.array([LEAN_ANCHOR_E], np.float32), (n, 1))
+    for scale, want in LEAN_ANCHOR.items():
+        _, pp = b.eval_lean(d, d, mk_params(LEAN_BASE), scale, E, want="pdf", return_params=True)
+        assert np.allclose(pp[0], want, rtol=0, atol=6e-4 if scale == 2.0 else 1e-6), (scale, pp[0])
+        assert np.array_equal(pp, np.tile(pp[:1], (n, 1)))
+        one = b.eval_lean(d[:1], d[:1], mk_params(LEAN_BASE), scale, E[:1], want="pdf", return_params=True)[1]
+        assert np.array_equal(one.view(np.uint32), pp[:1].view(np.uint32)), "scalar twin and kernel disagree"
+    with pytest.raises(djb.exc):
+        b.eval_lean(d, d, mk_params(LEAN_BASE), -1.0, E, want="pdf")     # DJB_ASSERT(sc >= 0), dj_brdf.h:2024
 
 
 def test_lean_device_tensors(gpu_ctx):

@@ -288,18 +288,27 @@ def test_parameter_tables_complete():
 
 
 def test_lrep_and_lean_path(oracle):
-    from golden_cases import LEAN_BASE, LEAN_SCALE, lrep_cases
+    from golden_cases import LEAN_ANCHOR, LEAN_ANCHOR_E, LEAN_BASE, LEAN_CASES, lean_texels, lrep_cases
     g = np.load(os.path.join(G, "lean.npz"))
     for k, (op, a, b, x, y) in enumerate(lrep_cases()):
         assert same(oracle.lrep_op(op, a, b, x, y), g[f"lrep{k}"]), (k, op)
     for k, p in enumerate(PARAM_CASES):
         assert same(oracle.params_lrep_roundtrip(p), g[f"roundtrip{k}"]), p
-    for ndf in ("beckmann", "ggx"):
-        b = oracle.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
-        for op in ("eval", "evalp", "pdf"):
-            val, pp = oracle.eval_lean(b, g["i"], g["o"], LEAN_BASE, LEAN_SCALE, g["lean"], op)
-            assert same(val, g[f"{ndf}_{op}"]) and same(pp, g["pdfparams"]), (ndf, op)
-            assert same(oracle.eval_pp(b, g["i"], g["o"], g["pdfparams"], op), g[f"{ndf}_{op}"])
+    for c, (scale, filtering, biased) in enumerate(LEAN_CASES):
+        tex = lean_texels(g["lean"], biased)
+        for ndf in ("beckmann", "ggx"):
+            b = oracle.microfacet(ndf, ("schlick", 1.0, 0.71, 0.29), True)
+            for op in ("eval", "evalp", "pdf"):
+                val, pp = oracle.eval_lean(b, g["i"], g["o"], LEAN_BASE, scale, tex, op, filtering=filtering, biased=biased)
+                assert same(val, g[f"c{c}_{ndf}_{op}"]) and same(pp, g[f"c{c}_pdfparams"]), (c, ndf, op)
+                assert same(oracle.eval_pp(b, g["i"], g["o"], g[f"c{c}_pdfparams"], op), g[f"c{c}_{ndf}_{op}"])
+    # the composition is lrep(lean) * dmapscale + params_to_lrep(base) (mitsuba/dj_beckmannconductor.cpp:296-314):
+    # values the real header gives for one texel, which no other operand order reproduces at scale != 1
+    b = oracle.microfacet("beckmann")
+    d = np.array([[0.3, 0.2, 0.9327379]], np.float32)
+    for scale, want in LEAN_ANCHOR.items():
+        _, pp = oracle.eval_lean(b, d, d, LEAN_BASE, scale, np.array([LEAN_ANCHOR_E], np.float32), "pdf")
+        assert np.allclose(pp[0], want, rtol=0, atol=6e-4 if scale == 2.0 else 1e-6), (scale, pp[0], want)
 
 
 @pytest.mark.parametrize("name", ["a_ggx", "a_beckmann", "a_abc", "a_merl"])

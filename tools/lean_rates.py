@@ -20,7 +20,7 @@ base = djb.microfacet.params.isotropic(0.1)
 for name, b in (("beckmann ideal", djb.beckmann(ctx=ctx)), ("beckmann schlick", djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), ctx=ctx)),
                 ("ggx ideal", djb.ggx(ctx=ctx))):
     def run():
-        _lib.check(lib.djb_eval_lean_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), C.byref(base._p), C.c_float(1.0),
+        _lib.check(lib.djb_eval_lean_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), C.byref(base._p), C.c_float(1.0), C.c_int(0),
                                            C.c_void_p(lean.data_ptr()), C.c_int(6), C.byref(vout.view), C.c_void_p(pdf.data_ptr()), C.c_void_p(0), C.c_int(0)))
     run(); torch.cuda.synchronize(); ctx.timer_start()
     for _ in range(3): run()

@@ -772,6 +772,46 @@ djb_status eval_pp(djb_ctx *ctx, const djb_brdf *b_, int64_t n, const djb_vec3_v
 	return DJB_OK;
 }
 
+template <int KIND, int MODE>
+static void pp_sample_loop(const Brdf &b, long long k0, long long k1, const float *u1, const float *u2, const View &vo, const float *rec,
+                           const LeanCfg &base, bool is, const View &vi_out, const View &vw_out, float *out_pdf, float *out_pp)
+{
+	const GlibcTabs gt = glibc_tabs_global();
+	for (long long k = k0; k < k1; ++k) {
+		v3 i_out, w; float pdf;
+		if (is) pp_sample_one<KIND, true, MODE>(b, u1[k], u2[k], load3(vo, k), rec + 5 * k, base, out_pp ? out_pp + 5 * k : nullptr, gt, i_out, w, pdf);
+		else pp_sample_one<KIND, false, MODE>(b, u1[k], u2[k], load3(vo, k), rec + 5 * k, base, out_pp ? out_pp + 5 * k : nullptr, gt, i_out, w, pdf);
+		store3(vi_out, k, i_out);
+		if (is) { store3(vw_out, k, w); out_pdf[k] = pdf; }
+	}
+}
+
+djb_status sample_pp(djb_ctx *ctx, const djb_brdf *b_, int64_t n, const float *u1, const float *u2, const djb_vec3_view *o,
+                     const float *rec, int mode, const float *base5, float scale, int lean_flags, const djb_vec3_view *out_w,
+                     const djb_vec3_view *out_i, float *out_pdf, float *out_pp)
+{
+	if (!b_ || !rec || !u1 || !u2) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	const Brdf &b = B(b_)->dev;
+	if (!is_microfacet_kind(b.kind)) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need a microfacet BRDF");
+	const bool is = out_w != nullptr;
+	if (!valid(o) || !valid(out_i) || (is && (!valid(out_w) || !out_pdf)))
+		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	const LeanCfg base = lean_cfg(base5, scale, lean_flags);
+	const View vo = view_of(o), vi = view_of(out_i), vw = is ? view_of(out_w) : View{ nullptr, nullptr, nullptr, 0 };
+	parallel_for(C(ctx), n, 2048, [&](long long k0, long long k1) {
+#define DJB_SPP_(K_) (mode == 0 ? pp_sample_loop<K_, 0>(b, k0, k1, u1, u2, vo, rec, base, is, vi, vw, out_pdf, out_pp) \
+                                : pp_sample_loop<K_, 1>(b, k0, k1, u1, u2, vo, rec, base, is, vi, vw, out_pdf, out_pp))
+		switch (b.kind) {
+		case KIND_BECKMANN: DJB_SPP_(KIND_BECKMANN); break;
+		case KIND_GGX: DJB_SPP_(KIND_GGX); break;
+		case KIND_TABULAR: DJB_SPP_(KIND_TABULAR); break;
+		case KIND_TABULAR_ANISO: DJB_SPP_(KIND_TABULAR_ANISO); break;
+		}
+#undef DJB_SPP_
+	});
+	return DJB_OK;
+}
+
 djb_status query(djb_ctx *ctx, const djb_brdf *b_, int which, int64_t n, const djb_vec3_view *a, const djb_vec3_view *bb,
                  const djb_vec3_view *c, const djb_params *params, const djb_vec3_view *out)
 {

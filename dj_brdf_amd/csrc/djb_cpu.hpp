@@ -77,6 +77,9 @@ djb_status sample(djb_ctx *, const djb_brdf *, int64_t n, const float *u1, const
 djb_status eval_pp(djb_ctx *, const djb_brdf *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o, const float *rec,
                    int mode, const float *base5, float scale, int lean_flags, int want, const djb_vec3_view *out_fr, float *out_pdf,
                    float *out_pp);
+djb_status sample_pp(djb_ctx *, const djb_brdf *, int64_t n, const float *u1, const float *u2, const djb_vec3_view *o, const float *rec,
+                     int mode, const float *base5, float scale, int lean_flags, const djb_vec3_view *out_w, const djb_vec3_view *out_i,
+                     float *out_pdf, float *out_pp);
 djb_status query(djb_ctx *, const djb_brdf *, int which, int64_t n, const djb_vec3_view *a, const djb_vec3_view *b,
                  const djb_vec3_view *c, const djb_params *, const djb_vec3_view *out);
 djb_status io_hd(djb_ctx *, int64_t n, const djb_vec3_view *a, const djb_vec3_view *b, const djb_vec3_view *c,

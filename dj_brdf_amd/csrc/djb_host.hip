@@ -351,6 +351,9 @@ static djb_status ctx_create(int device, void *hip_stream, bool own, djb_ctx **o
 	// pinned, device-visible arena for small host-memory calls; without it they use the HBM staging path
 	if (hipHostMalloc((void **)&c->pin, PIN_BYTES, hipHostMallocDefault) == hipSuccess) c->pin_bytes = PIN_BYTES;
 	else { c->pin = nullptr; (void)hipGetLastError(); }
+	// DJB_SCALAR_ON_DEVICE=1: the initial value of DJB_OPT_SCALAR_ON_DEVICE for every GPU context of the process, so that
+	// programs written against the C++ facade (which never call djb_ctx_set_option) can be A/B-tested on the kernel path
+	if (const char *e = getenv("DJB_SCALAR_ON_DEVICE")) c->scalar_on_device = atoi(e) != 0;
 	*out = c;
 	return DJB_OK;
 }

@@ -732,6 +732,89 @@ try {
 }
 DJB_ABI_CATCH
 
+// sample (out_w == NULL) / evalp_is with per-pair parameter records: mode 0 pdfparams, mode 1 LEAN texels
+static djb_status sample_pp_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
+                                   const djb_vec3_view *o, const float *rec, int mode, const float *base5, float scale,
+                                   int lean_flags, const djb_vec3_view *out_w, const djb_vec3_view *out_i, float *out_pdf,
+                                   float *out_pp, int mem)
+{
+	if (!b || !rec || !ctx || !u1 || !u2) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	const int bkind = djb_brdf_kind(b);
+	if (bkind > DJB_KIND_TABULAR && bkind != DJB_KIND_TABULAR_ANISO)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need a microfacet brdf");
+	const bool is = out_w != nullptr;
+	if (is && !out_pdf) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	djb_status st = cpu_pair_check(ctx, b);
+	if (st != DJB_OK) return st;
+	if (is_cpu(ctx)) return n <= 0 ? DJB_OK : djbcpu::sample_pp(ctx, b, n, u1, u2, o, rec, mode, base5, scale, lean_flags, out_w, out_i, out_pdf, out_pp);
+	if (const djb_brdf *tw = scalar_twin(ctx, b, n, mem))
+		return n <= 0 ? DJB_OK : djbcpu::sample_pp(djbcpu::twin_ctx(), tw, n, u1, u2, o, rec, mode, base5, scale, lean_flags, out_w, out_i, out_pdf, out_pp);
+	st = check_call(ctx, b, n, mem);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	if (mem == DJB_MEM_HOST && n > SMALL_N && o && out_i) {          // large host batch: chunked, both PCIe directions busy
+		bool taken = false;
+		std::vector<PipeArr> ins{ PipeArr::arr(u1), PipeArr::arr(u2), PipeArr::vec(o), PipeArr::arr(rec, 5) }, outs{ PipeArr::vec(out_i) };
+		int kq = -1;
+		if (is) { outs.push_back(PipeArr::vec(out_w)); outs.push_back(PipeArr::arr(out_pdf)); }
+		if (out_pp) { kq = (int)outs.size(); outs.push_back(PipeArr::arr(out_pp, 5)); }
+		st = host_pipeline(ctx, n, ins, outs, [&](long long m, int s) {
+			djb_vec3_view dvo = ins[2].view(s), dvi = outs[0].view(s), dvw = is ? outs[1].view(s) : djb_vec3_view{ nullptr, nullptr, nullptr, 0 };
+			return sample_pp_common(ctx, b, m, ins[0].dev[s], ins[1].dev[s], &dvo, ins[3].dev[s], mode, base5, scale, lean_flags,
+			                        is ? &dvw : nullptr, &dvi, is ? outs[2].dev[s] : nullptr, out_pp ? outs[kq].dev[s] : nullptr, DJB_MEM_DEVICE);
+		}, &taken);
+		if (taken || st != DJB_OK) return st;
+	}
+	Staged sg(ctx, n, mem);
+	View vo, vi, vw; const float *d1, *d2, *drec = rec; float *dpdf = nullptr, *dpp = nullptr;
+	if ((st = sg.in_f(u1, &d1)) != DJB_OK) return st;
+	if ((st = sg.in_f(u2, &d2)) != DJB_OK) return st;
+	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
+	if (mem == DJB_MEM_HOST) {
+		float *d = nullptr;
+		if ((st = sg.alloc(sizeof(float) * 5 * (size_t)n, (void **)&d)) != DJB_OK) return st;
+		if (n && (st = sg.copy(d, rec, sizeof(float) * 5 * (size_t)n, hipMemcpyHostToDevice)) != DJB_OK) return st;
+		drec = d;
+	}
+	if ((st = sg.out_vec(out_i, &vi)) != DJB_OK) return st;
+	if (is) {
+		if ((st = sg.out_vec(out_w, &vw)) != DJB_OK) return st;
+		if ((st = sg.out_arr(out_pdf, &dpdf)) != DJB_OK) return st;
+	}
+	if (out_pp) {
+		if (mem == DJB_MEM_DEVICE) dpp = out_pp;
+		else {
+			if ((st = sg.alloc(sizeof(float) * 5 * (size_t)n, (void **)&dpp)) != DJB_OK) return st;
+			sg.out_raw.push_back({ dpp, { out_pp, sizeof(float) * 5 * (size_t)n } });
+		}
+	}
+	HIP_TRY(djbk::launch_sample_pp(ctx->stream, b->dev, n, d1, d2, vo, drec, mode, base5, scale, lean_flags, vi, is ? &vw : nullptr, dpdf, dpp));
+	return sg.finish();
+}
+
+djb_status djb_sample_pp_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
+                               const djb_vec3_view *o, const float *pdfparams, const djb_vec3_view *out_w,
+                               const djb_vec3_view *out_i, float *out_pdf, int mem)
+try {
+	return sample_pp_common(ctx, b, n, u1, u2, o, pdfparams, 0, nullptr, 1.0f, 0, out_w, out_i, out_pdf, nullptr, mem);
+}
+DJB_ABI_CATCH
+
+djb_status djb_sample_lean_batch(djb_ctx *ctx, const djb_brdf *b, int64_t n, const float *u1, const float *u2,
+                                 const djb_vec3_view *o, const djb_params *base, float scale, int lean_flags,
+                                 const float *lean, const djb_vec3_view *out_w, const djb_vec3_view *out_i,
+                                 float *out_pdf, float *out_pdfparams, int mem)
+try {
+	if (lean_flags & ~(DJB_LEAN_NAIVE_MIP | DJB_LEAN_BIASED))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown LEAN flag");
+	if (!(scale >= 0.0f)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid scale");
+	float base5[5];
+	djb_status st = djb_params_to_lrep(base, base5);
+	if (st != DJB_OK) return st;
+	return sample_pp_common(ctx, b, n, u1, u2, o, lean, 1, base5, scale, lean_flags, out_w, out_i, out_pdf, out_pdfparams, mem);
+}
+DJB_ABI_CATCH
+
 djb_status djb_merl_guard_stats(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
                                 const float *guard6, float *max_ratio3, unsigned long long *counters4)
 try {

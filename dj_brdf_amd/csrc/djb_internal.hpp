@@ -37,6 +37,11 @@ hipError_t launch_eval_pp(hipStream_t s, const Brdf &b, long long n, const View 
                           const float *rec, int mode, const float *base5, float scale, int lean_flags, const View &out,
                           float *out_pdf, float *out_pp, int want);
 
+// sample (out_w == NULL) / evalp_is with the same per-pair records
+hipError_t launch_sample_pp(hipStream_t s, const Brdf &b, long long n, const float *u1, const float *u2, const View &o,
+                            const float *rec, int mode, const float *base5, float scale, int lean_flags, const View &out_i,
+                            const View *out_w, float *out_pdf, float *out_pp);
+
 // microfacet / radial queries; out.x holds scalar results (out.xyz for the Fresnel query)
 hipError_t launch_query(hipStream_t s, const Brdf &b, const Params &p, int which, long long n,
                         const View &a, const View &bb, const View &c, const View &out);

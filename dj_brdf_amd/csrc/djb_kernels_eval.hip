@@ -303,6 +303,53 @@ hipError_t launch_sample_kind(hipStream_t s, const Brdf &b, const Params &p, lon
 #undef DJB_LAUNCH_S
 }
 
+// sample / evalp_is with per-pair parameters (records as in k_eval_pp): one Newton inversion per lane on the general path --
+// the two-path Beckmann sampler of djb_kernels_sample.hip needs wave-uniform parameters
+template <int KIND, bool IS, int MODE, int FRK = -1>
+__global__ __launch_bounds__(BLOCK) void k_sample_pp(Brdf b, long long n, const float *u1a, const float *u2a, View vo,
+                                                     const float *rec, LeanCfg base, View vi_out, View vw_out,
+                                                     float *out_pdf, float *out_pp)
+{
+	__shared__ double s_glibc[KIND == KIND_BECKMANN ? GLIBC_LDS_WORDS : 1];
+	GlibcTabs gt = glibc_tabs_global();
+	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];
+	if (KIND == KIND_BECKMANN) {
+		gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
+		gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+		__syncthreads();
+	}
+	const long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		v3 i_out, w; float pdf;
+		pp_sample_one<KIND, IS, MODE, FRK>(b, u1a[k], u2a[k], load3(vo, k), rec + 5 * k, base, out_pp ? out_pp + 5 * k : nullptr,
+		                                   gt, i_out, w, pdf);
+		store3(vi_out, k, i_out);
+		if (IS) { store3(vw_out, k, w); out_pdf[k] = pdf; }
+	}
+}
+
+template <int KIND>
+hipError_t launch_sample_pp_kind(hipStream_t s, const Brdf &b, long long n, const float *u1, const float *u2, const View &o,
+                                 const float *rec, int mode, const LeanCfg &base, const View &out_i, const View *out_w,
+                                 float *out_pdf, float *out_pp)
+{
+	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
+	View w = out_w ? *out_w : View{ nullptr, nullptr, nullptr, 0 };
+#define DJB_SPP(IS_, FRK_) do { if (mode == 0) hipLaunchKernelGGL((k_sample_pp<KIND, IS_, 0, FRK_>), g, t, 0, s, b, n, u1, u2, o, rec, base, out_i, w, out_pdf, out_pp); \
+                                else hipLaunchKernelGGL((k_sample_pp<KIND, IS_, 1, FRK_>), g, t, 0, s, b, n, u1, u2, o, rec, base, out_i, w, out_pdf, out_pp); \
+                                return hipGetLastError(); } while (0)
+	if (!out_w) DJB_SPP(false, -1);
+	if constexpr (KIND == KIND_BECKMANN || KIND == KIND_GGX) {
+		if (b.fr.kind == FR_IDEAL) DJB_SPP(true, FR_IDEAL);
+		if (b.fr.kind == FR_SCHLICK) DJB_SPP(true, FR_SCHLICK);
+	}
+	if constexpr (KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO) {
+		if (b.fr.kind == FR_SPLINE) DJB_SPP(true, FR_SPLINE);
+	}
+	DJB_SPP(true, -1);
+#undef DJB_SPP
+}
+
 // ------------------------------------------------------------------ microfacet / radial queries
 template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_query(Brdf b, Params p, int which, long long n, View va, View vb,
@@ -541,6 +588,21 @@ hipError_t launch_eval_pp(hipStream_t s, const Brdf &b, long long n, const View 
 	case KIND_TABULAR_ANISO: return DJB_PP(KIND_TABULAR_ANISO);
 	}
 #undef DJB_PP
+	return hipErrorInvalidValue;
+}
+
+hipError_t launch_sample_pp(hipStream_t s, const Brdf &b, long long n, const float *u1, const float *u2, const View &o,
+                            const float *rec, int mode, const float *base5, float scale, int lean_flags, const View &out_i,
+                            const View *out_w, float *out_pdf, float *out_pp)
+{
+	if (n <= 0) return hipSuccess;
+	const LeanCfg base = lean_cfg(base5, scale, lean_flags);
+	switch (b.kind) {
+	case KIND_BECKMANN: return launch_sample_pp_kind<KIND_BECKMANN>(s, b, n, u1, u2, o, rec, mode, base, out_i, out_w, out_pdf, out_pp);
+	case KIND_GGX:      return launch_sample_pp_kind<KIND_GGX>(s, b, n, u1, u2, o, rec, mode, base, out_i, out_w, out_pdf, out_pp);
+	case KIND_TABULAR:  return launch_sample_pp_kind<KIND_TABULAR>(s, b, n, u1, u2, o, rec, mode, base, out_i, out_w, out_pdf, out_pp);
+	case KIND_TABULAR_ANISO: return launch_sample_pp_kind<KIND_TABULAR_ANISO>(s, b, n, u1, u2, o, rec, mode, base, out_i, out_w, out_pdf, out_pp);
+	}
 	return hipErrorInvalidValue;
 }
 

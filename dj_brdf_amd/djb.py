@@ -637,8 +637,57 @@ def _eval_lean(self, i, o, base, scale, lean, want="evalp", return_params=False,
                          lambda p: [_params_ptr(base), C.c_float(scale), C.c_int(flags), C.c_void_p(p)], want_pp=return_params)
 
 
+def _sample_records(self, fn, u1, u2, o, records, evalp_is, extra_args, want_pp=False):
+    """shared driver of sample_pp / sample_lean: sample() or evalp_is() with per-pair 5-float records."""
+    lib = _lib.load()
+    vo = _Vec(o)
+    k1, p1 = _scalar_in(u1, vo)
+    k2, p2 = _scalar_in(u2, vo)
+    if vo.is_torch:
+        rec = records.float().contiguous() if isinstance(records, torch.Tensor) else \
+            torch.as_tensor(np.asarray(records, np.float32), device=vo.device)
+        rec_ptr = rec.data_ptr()
+    else:
+        rec = np.ascontiguousarray(records, dtype=np.float32)
+        rec_ptr = rec.ctypes.data
+    assert tuple(rec.shape) == (vo.n, 5), "records must be [n, 5]"
+    i = vo.like()
+    w = vo.like() if evalp_is else None
+    pdf, pdf_ptr = vo.scalars() if evalp_is else (None, None)
+    pp = pp_ptr = None
+    if want_pp:
+        pp = torch.empty((vo.n, 5), dtype=torch.float32, device=vo.device) if vo.is_torch else np.empty((vo.n, 5), np.float32)
+        pp_ptr = pp.data_ptr() if vo.is_torch else pp.ctypes.data
+    args = [self.ctx._h, self._h, C.c_int64(vo.n), C.c_void_p(p1), C.c_void_p(p2), C.byref(vo.view)] + extra_args(rec_ptr) + \
+           [C.byref(w.view) if w else None, C.byref(i.view), C.c_void_p(pdf_ptr)]
+    if fn == "djb_sample_lean_batch":
+        args.append(C.c_void_p(pp_ptr))
+    args.append(C.c_int(vo.mem))
+    _lib.check(getattr(lib, fn)(*args))
+    del k1, k2
+    res = (w.keep, i.keep, pdf) if evalp_is else (i.keep,)
+    if want_pp:
+        res = res + (pp,)
+    return res[0] if len(res) == 1 else res
+
+
+def _sample_pp(self, u1, u2, o, pdfparams, evalp_is=False):
+    """sample() -- or with evalp_is=True (weight, i, pdf) -- with per-pair pdfparams records [n,5]."""
+    return _sample_records(self, "djb_sample_pp_batch", u1, u2, o, pdfparams, evalp_is, lambda p: [C.c_void_p(p)])
+
+
+def _sample_lean(self, u1, u2, o, base, scale, lean, evalp_is=True, return_params=False, filtering=True, biased=False):
+    """dj_beckmann_conductor::sample, batched (mitsuba/dj_beckmannconductor.cpp:373-413): per-pair params as eval_lean,
+    then evalp_is (or sample) with them."""
+    flags = (0 if filtering else LEAN_NAIVE_MIP) | (LEAN_BIASED if biased else 0)
+    return _sample_records(self, "djb_sample_lean_batch", u1, u2, o, lean, evalp_is,
+                           lambda p: [_params_ptr(base), C.c_float(scale), C.c_int(flags), C.c_void_p(p)], want_pp=return_params)
+
+
 microfacet.eval_pp = _eval_pp
 microfacet.eval_lean = _eval_lean
+microfacet.sample_pp = _sample_pp
+microfacet.sample_lean = _sample_lean
 
 
 class beckmann(microfacet):

@@ -142,7 +142,8 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * in which a row whose conditional CDF cannot be inverted for every quantile comes up short and shifts
  * all later rows (dj_brdf.h:3005-3034) -- the two differ only for such (grazing-heavy) data.          */
        DJB_OPT_ANISO_QF2_ALIGNED = 2,
-/* DJB_OPT_SCALAR_ON_DEVICE = 1: scalar-size DJB_MEM_HOST calls (<= DJB_SCALAR_HOST_MAX units) run on the GPU too */
+/* DJB_OPT_SCALAR_ON_DEVICE = 1: scalar-size DJB_MEM_HOST calls (<= DJB_SCALAR_HOST_MAX units) run on the GPU too
+ * (initial value: the environment variable DJB_SCALAR_ON_DEVICE, default 0) */
        DJB_OPT_SCALAR_ON_DEVICE = 3,
 /* DJB_OPT_FIT_FILES_DENSE = 1: djb_fit_merl_files uploads and converts every 35 MB table in full before the fit (the
  * round-1 pipeline) instead of fetching only the ~5.5 k entries per file that tabular(merl, res) reads; same alphas */
@@ -289,6 +290,16 @@ djb_status djb_eval_lean_batch(djb_ctx *, const djb_brdf *, int64_t n, const djb
                                const djb_vec3_view *o, const djb_params *base, float scale, int lean_flags,
                                const float *lean, int want, const djb_vec3_view *out_fr,
                                float *out_pdf, float *out_pdfparams, int mem);
+/* sample() (out_w == out_pdf == NULL) / evalp_is() with the same per-pair records: the batch form of
+ * dj_beckmann_conductor::sample (mitsuba/dj_beckmannconductor.cpp:373-413): params_k as above, then
+ * evalp_is(u1_k, u2_k, o_k, &i_k, &pdf_k, &params_k) (dj_brdf.h:1734-1765). */
+djb_status djb_sample_pp_batch(djb_ctx *, const djb_brdf *, int64_t n, const float *u1, const float *u2,
+                               const djb_vec3_view *o, const float *pdfparams, const djb_vec3_view *out_w,
+                               const djb_vec3_view *out_i, float *out_pdf, int mem);
+djb_status djb_sample_lean_batch(djb_ctx *, const djb_brdf *, int64_t n, const float *u1, const float *u2,
+                                 const djb_vec3_view *o, const djb_params *base, float scale, int lean_flags,
+                                 const float *lean, const djb_vec3_view *out_w, const djb_vec3_view *out_i,
+                                 float *out_pdf, float *out_pdfparams, int mem);
 /* beckmann::lrep algebra on {E1..E5} (host scalars; dj_brdf.h:330-356, 1959-2051).  b may be NULL
  * (= the default lrep(0,0,1,1,0)); x (and y) are the scalar arguments of mul / shear / scale.
  * IADD keeps the reference's operator+= ordering (dj_brdf.h:2013-2017), which differs from ADD.   */

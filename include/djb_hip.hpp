@@ -47,7 +47,8 @@
 #	define DJB_USER_ASSERT(x) DJB_ASSERT(x)
 #else
 #	define DJB_USER_ASSERT(x) ((void)0)      /* the library validates the same conditions and the facade throws djb::exc */
-#	define DJB_ASSERT(x) ((void)0)
+#	include <cassert>
+#	define DJB_ASSERT(x) assert(x)          /* dj_brdf.h:552-554: user code that uses DJB_ASSERT itself keeps its assertions */
 #endif
 #ifndef DJB_LOG
 #	define DJB_LOG(format, ...) fprintf(stdout, format, ##__VA_ARGS__)
@@ -551,6 +552,16 @@ public:
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out_fr_cos);
 		hip::check(djb_eval_lean_batch(ctx(), m_h, (int64_t)n, &vi, &vo, base.desc(), dmapscale, lean_flags, lean,
 		                               out_pdf ? 6 : 2, &vr, out_pdf, NULL, DJB_MEM_HOST));
+	}
+	/* batch form of dj_beckmann_conductor::sample (mitsuba/dj_beckmannconductor.cpp:373-413): per-hit params as above,
+	 * then evalp_is; returns through out_fr_cos (weights), out_i, out_pdf */
+	void evalp_is_lean(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, const microfacet::params &base,
+	                   float_t dmapscale, const float_t *lean, vec3 *out_fr_cos, vec3 *out_i, float_t *out_pdf,
+	                   int lean_flags = 0) const
+	{
+		djb_vec3_view vo = hip::view(o), vr = hip::view(out_fr_cos), vi = hip::view(out_i);
+		hip::check(djb_sample_lean_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, base.desc(), dmapscale, lean_flags, lean,
+		                                 &vr, &vi, out_pdf, NULL, DJB_MEM_HOST));
 	}
 	beckmann(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)
 	{ djb_fresnel_desc d = f.desc(); hip::check(djb_brdf_create_beckmann(ctx(), &d, shadow, &m_h)); }

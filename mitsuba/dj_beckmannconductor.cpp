@@ -1,152 +1,321 @@
-// mitsuba/dj_beckmannconductor.cpp -- Mitsuba 0.5 BSDF plugin "dj_beckmannconductor" on top of
-// the MI355X engine.
+// mitsuba/dj_beckmannconductor.cpp -- Mitsuba 0.5 BSDF plugin "dj_beckmannconductor" (class dj_beckmann_conductor) on top of
+// the MI355X engine: drop-in for jdupuy/dj_brdf mitsuba/dj_beckmannconductor.cpp:151-582 (see mitsuba/djb_mitsuba.hpp).
 //
-// Same plugin name, XML properties (alpha / alpha1 / alpha2 / alphaAngle, material | eta + k,
-// leanmap1 / leanmap2, leanFiltering, dmapscale, merl) and BSDF signatures as the reference's
-// shell (jdupuy/dj_brdf mitsuba/dj_beckmannconductor.cpp:151-491).  Per hit the reference builds
-//     params  = elliptic(alpha1, alpha2, phi)            -> lrep1 (params_to_lrep), lrep1 *= scale
-//     lrep2   = LEAN-map texel moments (E1, E2 biased by 25, E5 by 625: l.300-303)
-//     params' = lrep_to_params(lrep1 + lrep2)
-//     value   = evalp(i, o, &params') * fresnelConductorExact(...)
-// Everything up to `value` is one call here (beckmann::evalp_lean / djb_eval_lean_batch); the exact
-// conductor Fresnel stays Mitsuba's (its arithmetic lives in the renderer).
-// NOT COMPILED HERE (no Mitsuba SDK in the image); see mitsuba/dj_merl.cpp and INTEGRATION.md.
-#include <mitsuba/core/fresolver.h>
-#include <mitsuba/render/bsdf.h>
-#include <mitsuba/render/texture.h>
-#include <mitsuba/hw/basicshader.h>
+// A Beckmann conductor whose lobe is rebuilt per hit from LEAN / LEADR maps.  Per hit the reference does (l.291-314, again at
+// 339-362 and 379-402):
+//     params = elliptic(alpha1(its), alpha2(its), alphaAngle(its))            alpha* are TEXTURES evaluated at the hit
+//     E1..E5 = texels of leanmap1 (E1, E2) and leanmap2 (E3, E4, E5);  E1 -= 25, E2 -= 25, E5 -= 625      (always, l.300-303)
+//     lrep1  = leanFiltering ? lrep(E1, E2, E3, E4, E5) : lrep(E1, E2, E1*E1, E2*E2, E1*E2)
+//     lrep1 *= dmapscale;  params = lrep_to_params(lrep1 + params_to_lrep(params))
+// and then evalp / pdf / evalp_is with those params.  Here that whole block plus the operator is ONE library call per hit:
+// beckmann::evalp_lean / evalp_is_lean (djb_eval_lean_batch / djb_sample_lean_batch with n = 1 and
+// DJB_LEAN_BIASED [| DJB_LEAN_NAIVE_MIP]); a wavefront renderer passes n hits to the same calls.
+// The exact conductor Fresnel factor stays Mitsuba's (fresnelConductorExact: its arithmetic lives in the renderer).
+//
+// Reference behaviour kept, quirks included:
+//   * material defaults to "none" (ideal mirror) unless mitsubaFresnel is set, then "Cu" (l.160-162);
+//   * with a "merl" property the Beckmann lobe carries the MERL-fitted Fresnel spline, beckmann(tab->get_fresnel()), and every
+//     alpha is MULTIPLIED by the fitted base roughness (l.179-213); the default alpha is the base roughness itself (1 without merl);
+//   * eval and pdf do not reject directions below the horizon (the cosTheta tests are commented out, l.282-283, 333-334);
+//     sample does not either (l.374);
+//   * the +25 / +625 texel bias is subtracted even when no LEAN map is given (constant-0 default textures, l.216-221);
+//   * ESpatiallyVarying looks at alpha1 / alpha2 / specularReflectance only, not at the LEAN maps (l.259-261);
+//   * the unserializing constructor restores the six textures and eta / k but none of the scalar options.
+#include "djb_mitsuba.hpp"
 #include "microfacet.h"
 #include "ior.h"
 
-#include "djb_hip.hpp"
-
 MTS_NAMESPACE_BEGIN
+using namespace djb_mts;
 
 class dj_beckmann_conductor : public BSDF {
 public:
-	static const int BIAS = 25;   // the LEAN maps store E1, E2 with a +25 bias (and E5 + 625)
-
 	dj_beckmann_conductor(const Properties &props) : BSDF(props), m_brdf(NULL) {
 		ref<FileResolver> fResolver = Thread::getThread()->getFileResolver();
 		m_specularReflectance = new ConstantSpectrumTexture(props.getSpectrum("specularReflectance", Spectrum(1.0f)));
-		std::string materialName = props.getString("material", "Cu");
-		Spectrum intEta, intK;
-		if (boost::to_lower_copy(materialName) == "none") {
-			intEta = Spectrum(0.0f); intK = Spectrum(1.0f);
-		} else {
+
+		// Fresnel: optical constants for Mitsuba's exact conductor term
+		m_mitsubaFresnel = props.getBoolean("mitsubaFresnel", false);
+		const std::string materialName = props.getString("material", m_mitsubaFresnel ? "Cu" : "none");
+		Spectrum intEta(0.0f), intK(1.0f);
+		if (boost::to_lower_copy(materialName) != "none") {
 			intEta.fromContinuousSpectrum(InterpolatedSpectrum(fResolver->resolve("data/ior/" + materialName + ".eta.spd")));
 			intK.fromContinuousSpectrum(InterpolatedSpectrum(fResolver->resolve("data/ior/" + materialName + ".k.spd")));
 		}
-		Float extEta = lookupIOR(props, "extEta", "air");
+		const Float extEta = lookupIOR(props, "extEta", "air");
 		m_eta = props.getSpectrum("eta", intEta) / extEta;
 		m_k = props.getSpectrum("k", intK) / extEta;
 
-		Float alpha = props.getFloat("alpha", 0.1f);
-		m_alpha1 = props.getFloat("alpha1", alpha);
-		m_alpha2 = props.getFloat("alpha2", alpha);
-		m_alphaAngle = degToRad(props.getFloat("alphaAngle", 0.0f));
-		m_scale = props.getFloat("dmapscale", 1.0f);
-		m_brdf = new djb::beckmann(djb::fresnel::ideal(), true);
-		if (props.hasProperty("merl")) {   // base roughness fitted from a MERL file (l.179-190), on the GPU
-			djb::merl merl(fResolver->resolve(props.getString("merl")).string().c_str());
-			djb::tabular tab(merl, 90, true);
-			float a, dummy;
-			djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&a, &dummy);
-			m_alpha1 = m_alpha2 = a;
+		// the lobe; with "merl": base roughness and Fresnel spline fitted from the measured material (one fit launch)
+		float baseRoughness = 1.f;
+		if (props.hasProperty("merl")) {
+			const std::string file = fResolver->resolve(props.getString("merl")).string();
+			djb::merl merl(file.c_str());
+			djb::tabular tab(merl, 90);
+			djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&baseRoughness, &baseRoughness);
+			m_brdf = new djb::beckmann(tab.get_fresnel());
+		} else {
+			m_brdf = new djb::beckmann();
 		}
-		m_leanmap1 = new ConstantFloatTexture(0.0f);
-		m_leanmap2 = new ConstantFloatTexture(0.0f);
+
+		// roughness: "alpha", or "alpha1" + "alpha2", each scaled by the base roughness
+		if (props.hasProperty("alpha")) {
+			m_alpha1 = m_alpha2 = new ConstantFloatTexture(baseRoughness * props.getFloat("alpha", 1.0f));
+			if (props.hasProperty("alpha1") || props.hasProperty("alpha2") || props.hasProperty("alphaAngle"))
+				SLog(EError, "Microfacet model: please specify either 'alpha' or 'alpha1'/'alpha2'/'alphaAngle'.");
+		} else if (props.hasProperty("alpha1") || props.hasProperty("alpha2")) {
+			if (!props.hasProperty("alpha1") || !props.hasProperty("alpha2"))
+				SLog(EError, "Microfacet model: both 'alpha1' and 'alpha2' must be specified.");
+			m_alpha1 = new ConstantFloatTexture(baseRoughness * props.getFloat("alpha1", 1.0f));
+			m_alpha2 = new ConstantFloatTexture(baseRoughness * props.getFloat("alpha2", 1.0f));
+		} else {
+			m_alpha1 = m_alpha2 = new ConstantFloatTexture(baseRoughness);
+		}
+		m_alphaAngle = new ConstantFloatTexture(M_PI / 180.0 * props.getFloat("alphaAngle", 0.0f));
+
+		// LEAN maps
+		m_leanFiltering = props.getBoolean("leanFiltering", true);
+		m_leanmap1 = new ConstantSpectrumTexture(props.getSpectrum("leanmap1", Spectrum(0.0f)));
+		m_leanmap2 = new ConstantSpectrumTexture(props.getSpectrum("leanmap2", Spectrum(0.0f)));
+		m_dmapScale = props.getFloat("dmapscale", 1.0f);
 	}
-	dj_beckmann_conductor(Stream *stream, InstanceManager *manager) : BSDF(stream, manager), m_brdf(NULL) { configure(); }
+
+	dj_beckmann_conductor(Stream *stream, InstanceManager *manager) : BSDF(stream, manager), m_brdf(NULL) {
+		m_alpha1 = static_cast<Texture *>(manager->getInstance(stream));
+		m_alpha2 = static_cast<Texture *>(manager->getInstance(stream));
+		m_alphaAngle = static_cast<Texture *>(manager->getInstance(stream));
+		m_leanmap1 = static_cast<Texture *>(manager->getInstance(stream));
+		m_leanmap2 = static_cast<Texture *>(manager->getInstance(stream));
+		m_specularReflectance = static_cast<Texture *>(manager->getInstance(stream));
+		m_eta = Spectrum(stream);
+		m_k = Spectrum(stream);
+		configure();
+	}
 	~dj_beckmann_conductor() { delete m_brdf; }
 
-	void addChild(const std::string &name, ConfigurableObject *child) {
-		if (child->getClass()->derivesFrom(MTS_CLASS(Texture))) {
-			if (name == "leanmap1") m_leanmap1 = static_cast<Texture *>(child);
-			else if (name == "leanmap2") m_leanmap2 = static_cast<Texture *>(child);
-			else if (name == "specularReflectance") m_specularReflectance = static_cast<Texture *>(child);
-			else BSDF::addChild(name, child);
-		} else BSDF::addChild(name, child);
+	void serialize(Stream *stream, InstanceManager *manager) const {
+		BSDF::serialize(stream, manager);
+		const Texture *textures[6] = { m_alpha1.get(), m_alpha2.get(), m_alphaAngle.get(), m_leanmap1.get(), m_leanmap2.get(),
+		                               m_specularReflectance.get() };
+		for (int k = 0; k < 6; ++k)
+			manager->serialize(stream, textures[k]);
+		m_eta.serialize(stream);
+		m_k.serialize(stream);
 	}
 
 	void configure() {
+		unsigned int extraFlags = 0;
+		if (m_alpha1 != m_alpha2)
+			extraFlags |= EAnisotropic;
+		if (!m_alpha1->isConstant() || !m_alpha2->isConstant() || !m_specularReflectance->isConstant())
+			extraFlags |= ESpatiallyVarying;
 		m_components.clear();
-		m_components.push_back(EGlossyReflection | EFrontSide | ESpatiallyVarying | EAnisotropic);
-		m_usesRayDifferentials = true;
+		m_components.push_back(EGlossyReflection | EFrontSide | extraFlags);
+		m_specularReflectance = ensureEnergyConservation(m_specularReflectance, "specularReflectance", 1.0f);
+		m_usesRayDifferentials = m_alpha1->usesRayDifferentials() || m_alpha2->usesRayDifferentials()
+			|| m_specularReflectance->usesRayDifferentials();
 		BSDF::configure();
 	}
 
-	// texel -> slope moments of the LEAN map (E1, E2 from map 1; E3, E4, E5 from map 2)
-	void leanMoments(const Intersection &its, float lean[5]) const {
-		Spectrum m1 = m_leanmap1->eval(its, true), m2 = m_leanmap2->eval(its, true);
-		Float r1, g1, b1, r2, g2, b2;
-		m1.toLinearRGB(r1, g1, b1); m2.toLinearRGB(r2, g2, b2);
-		lean[0] = r1 - BIAS; lean[1] = g1 - BIAS;
-		lean[2] = r2; lean[3] = g2; lean[4] = b2 - BIAS * BIAS;
-	}
-
 	Spectrum eval(const BSDFSamplingRecord &bRec, EMeasure measure) const {
-		if (!(bRec.typeMask & EGlossyReflection) || measure != ESolidAngle
-			|| Frame::cosTheta(bRec.wi) <= 0 || Frame::cosTheta(bRec.wo) <= 0)
+		if (measure != ESolidAngle || other_component(bRec) || lobe_masked(bRec, EGlossyReflection))
 			return Spectrum(0.0f);
-		djb::vec3 o(bRec.wi.x, bRec.wi.y, bRec.wi.z), i(bRec.wo.x, bRec.wo.y, bRec.wo.z), fr_cos;
-		float lean[5];
-		leanMoments(bRec.its, lean);
-		m_brdf->evalp_lean(1, &i, &o, djb::microfacet::params::elliptic(m_alpha1, m_alpha2, m_alphaAngle),
-		                   m_scale, lean, &fr_cos);
-		Vector H = normalize(bRec.wo + bRec.wi);
-		const Spectrum F = fresnelConductorExact(dot(bRec.wi, H), m_eta, m_k) * m_specularReflectance->eval(bRec.its);
-		return F * fr_cos.x;
+		hit h(*this, bRec.its);
+		const djb::vec3 o = dir(bRec.wi), i = dir(bRec.wo);
+		djb::vec3 fr_cos;
+		m_brdf->evalp_lean(1, &i, &o, h.base, m_dmapScale, h.texel, &fr_cos, NULL, h.flags);
+		return conductor(bRec) * rgb(fr_cos);
 	}
 
 	Float pdf(const BSDFSamplingRecord &bRec, EMeasure measure) const {
-		if (!(bRec.typeMask & EGlossyReflection) || measure != ESolidAngle
-			|| Frame::cosTheta(bRec.wi) <= 0 || Frame::cosTheta(bRec.wo) <= 0)
+		if (measure != ESolidAngle || other_component(bRec) || lobe_masked(bRec, EGlossyReflection))
 			return 0.0f;
-		djb::vec3 o(bRec.wi.x, bRec.wi.y, bRec.wi.z), i(bRec.wo.x, bRec.wo.y, bRec.wo.z), fr_cos;
-		float lean[5], pdf_;
-		leanMoments(bRec.its, lean);
-		m_brdf->evalp_lean(1, &i, &o, djb::microfacet::params::elliptic(m_alpha1, m_alpha2, m_alphaAngle),
-		                   m_scale, lean, &fr_cos, &pdf_);
-		return pdf_;
+		hit h(*this, bRec.its);
+		const djb::vec3 o = dir(bRec.wi), i = dir(bRec.wo);
+		djb::vec3 fr_cos;
+		float pdf;
+		m_brdf->evalp_lean(1, &i, &o, h.base, m_dmapScale, h.texel, &fr_cos, &pdf, h.flags);
+		return pdf;
 	}
 
-	Spectrum sample(BSDFSamplingRecord &bRec, Float &pdf_, const Point2 &sample) const {
-		if (!(bRec.typeMask & EGlossyReflection) || Frame::cosTheta(bRec.wi) <= 0)
+	Spectrum sample(BSDFSamplingRecord &bRec, Float &pdf, const Point2 &sample) const {
+		if (other_component(bRec) || lobe_masked(bRec, EGlossyReflection))
 			return Spectrum(0.0f);
-		float lean[5];
-		leanMoments(bRec.its, lean);
-		djb::beckmann::lrep l1, l2(lean[0], lean[1], lean[2], lean[3], lean[4]);
-		djb::beckmann::params_to_lrep(djb::microfacet::params::elliptic(m_alpha1, m_alpha2, m_alphaAngle), &l1);
-		l1 *= m_scale;
-		djb::microfacet::params params;
-		djb::beckmann::lrep_to_params(l1 + l2, &params);
-		djb::vec3 o(bRec.wi.x, bRec.wi.y, bRec.wi.z), i;
-		djb::vec3 w = m_brdf->evalp_is(sample.x, sample.y, o, &i, &pdf_, &params);
-		if (pdf_ <= 0 || i.z <= 0) return Spectrum(0.0f);
-		bRec.wo = Vector(i.x, i.y, i.z);
+		hit h(*this, bRec.its);
+		const djb::vec3 o = dir(bRec.wi);
+		djb::vec3 i, fr_cos;
+		m_brdf->evalp_is_lean(1, &sample.x, &sample.y, &o, h.base, m_dmapScale, h.texel, &fr_cos, &i, &pdf, h.flags);
+		bRec.wo = Normal(i.x, i.y, i.z);
 		bRec.eta = 1.0f;
 		bRec.sampledComponent = 0;
 		bRec.sampledType = EGlossyReflection;
-		Vector H = normalize(bRec.wo + bRec.wi);
-		return fresnelConductorExact(dot(bRec.wi, H), m_eta, m_k) * m_specularReflectance->eval(bRec.its) * w.x;
+		return conductor(bRec) * rgb(fr_cos);
 	}
 	Spectrum sample(BSDFSamplingRecord &bRec, const Point2 &sample) const {
-		Float pdf_;
-		return dj_beckmann_conductor::sample(bRec, pdf_, sample);
+		Float pdf_ = 0.f;
+		return this->sample(bRec, pdf_, sample);
 	}
 
-	void serialize(Stream *stream, InstanceManager *manager) const { BSDF::serialize(stream, manager); }
-	Float getRoughness(const Intersection &its, int component) const { return 0.5f * (m_alpha1 + m_alpha2); }
-	std::string toString() const { return "dj_beckmannconductor[engine = libdjb_hip (MI355X)]"; }
+	void addChild(const std::string &name, ConfigurableObject *child) {
+		if (!child->getClass()->derivesFrom(MTS_CLASS(Texture))) {
+			BSDF::addChild(name, child);
+			return;
+		}
+		Texture *texture = static_cast<Texture *>(child);
+		if (name == "alpha") m_alpha1 = m_alpha2 = texture;
+		else if (name == "alpha1") m_alpha1 = texture;
+		else if (name == "alpha2") m_alpha2 = texture;
+		else if (name == "alphaAngle") m_alphaAngle = texture;
+		else if (name == "leanmap1") m_leanmap1 = texture;
+		else if (name == "leanmap2") m_leanmap2 = texture;
+		else if (name == "specularReflectance") m_specularReflectance = texture;
+		else BSDF::addChild(name, child);
+	}
+
+	Float getRoughness(const Intersection &its, int component) const {
+		return 0.5f * (m_alpha1->eval(its).average() + m_alpha2->eval(its).average());
+	}
+
+	std::string toString() const {
+		std::ostringstream oss;
+		oss << "dj_beckmann_conductor[" << endl
+			<< "  id = \"" << getID() << "\"," << endl;
+		const char *names[6] = { "alpha1", "alpha2", "alphaAngle", "leanmap1", "leanmap2", "specularReflectance" };
+		const Texture *textures[6] = { m_alpha1.get(), m_alpha2.get(), m_alphaAngle.get(), m_leanmap1.get(), m_leanmap2.get(),
+		                               m_specularReflectance.get() };
+		for (int k = 0; k < 6; ++k)
+			oss << "  " << names[k] << " = " << indent(textures[k]->toString()) << "," << endl;
+		oss << "  eta = " << m_eta.toString() << "," << endl
+			<< "  k = " << m_k.toString() << endl
+			<< "]";
+		return oss.str();
+	}
+
+	Shader *createShader(Renderer *renderer) const;
 	MTS_DECLARE_CLASS()
 private:
+	// what one intersection contributes: the base lobe from the alpha textures and the raw LEAN texel (bias still on)
+	struct hit {
+		hit(const dj_beckmann_conductor &s, const Intersection &its)
+			: base(djb::microfacet::params::elliptic(s.m_alpha1->eval(its).average(), s.m_alpha2->eval(its).average(),
+			                                         s.m_alphaAngle->eval(its).average())),
+			  flags(DJB_LEAN_BIASED | (s.m_leanFiltering ? 0 : DJB_LEAN_NAIVE_MIP))
+		{
+			Float dummy;
+			s.m_leanmap1->eval(its).toLinearRGB(texel[0], texel[1], dummy);
+			s.m_leanmap2->eval(its).toLinearRGB(texel[2], texel[3], texel[4]);
+		}
+		djb::microfacet::params base;
+		Float texel[5];
+		int flags;
+	};
+	// l.321-324 / 421-424: exact conductor Fresnel at the half vector times the specular reflectance texture
+	Spectrum conductor(const BSDFSamplingRecord &bRec) const {
+		Vector H = normalize(bRec.wo + bRec.wi);
+		return fresnelConductorExact(dot(bRec.wi, H), m_eta, m_k) * m_specularReflectance->eval(bRec.its);
+	}
+
+	ref<Texture> m_specularReflectance;
+	ref<Texture> m_alpha1, m_alpha2, m_alphaAngle;
+	ref<Texture> m_leanmap1, m_leanmap2;
 	djb::beckmann *m_brdf;
-	ref<Texture> m_specularReflectance, m_leanmap1, m_leanmap2;
 	Spectrum m_eta, m_k;
-	Float m_alpha1, m_alpha2, m_alphaAngle, m_scale;
+	Float m_dmapScale;
+	bool m_leanFiltering;
+	bool m_mitsubaFresnel;
 };
 
+// GLSL preview of the rough conductor (VPL renderer): Ashikhmin-Shirley lobe with Schlick's Fresnel from the reflectance at
+// normal incidence, roughness clamped to 0.2 -- the program text is the reference's (l.456-520); renderer UI, no djb math
+class dj_beckmann_conductor_shader : public Shader {
+public:
+	dj_beckmann_conductor_shader(Renderer *renderer, const Texture *specularReflectance, const Texture *alpha1,
+			const Texture *alpha2, const Spectrum &eta, const Spectrum &k)
+		: Shader(renderer, EBSDFShader), m_specularReflectance(specularReflectance), m_alpha1(alpha1), m_alpha2(alpha2) {
+		m_specularReflectanceShader = renderer->registerShaderForResource(m_specularReflectance.get());
+		m_alpha1Shader = renderer->registerShaderForResource(m_alpha1.get());
+		m_alpha2Shader = renderer->registerShaderForResource(m_alpha2.get());
+		m_R0 = fresnelConductorExact(1.0f, eta, k);
+	}
+	bool isComplete() const {
+		return m_specularReflectanceShader.get() != NULL && m_alpha1Shader.get() != NULL && m_alpha2Shader.get() != NULL;
+	}
+	void putDependencies(std::vector<Shader *> &deps) {
+		deps.push_back(m_specularReflectanceShader.get());
+		deps.push_back(m_alpha1Shader.get());
+		deps.push_back(m_alpha2Shader.get());
+	}
+	void cleanup(Renderer *renderer) {
+		renderer->unregisterShaderForResource(m_specularReflectance.get());
+		renderer->unregisterShaderForResource(m_alpha1.get());
+		renderer->unregisterShaderForResource(m_alpha2.get());
+	}
+	void resolve(const GPUProgram *program, const std::string &evalName, std::vector<int> &parameterIDs) const {
+		parameterIDs.push_back(program->getParameterID(evalName + "_R0", false));
+	}
+	void bind(GPUProgram *program, const std::vector<int> &parameterIDs, int &textureUnitOffset) const {
+		program->setParameter(parameterIDs[0], m_R0);
+	}
+	void generateCode(std::ostringstream &oss, const std::string &evalName, const std::vector<std::string> &depNames) const {
+		const std::string &e = evalName;
+		oss << "uniform vec3 " << e << "_R0;" << endl
+			<< endl
+			<< "float " << e << "_D(vec3 m, float alpha1, float alpha2) {" << endl
+			<< "    float ct = cosTheta(m), ds = 1-ct*ct;" << endl
+			<< "    if (ds <= 0.0)" << endl
+			<< "        return 0.0f;" << endl
+			<< "    alpha1 = 2 / (alpha1 * alpha1) - 2;" << endl
+			<< "    alpha2 = 2 / (alpha2 * alpha2) - 2;" << endl
+			<< "    float exponent = (alpha1*m.x*m.x + alpha2*m.y*m.y)/ds;" << endl
+			<< "    return sqrt((alpha1+2) * (alpha2+2)) * 0.15915 * pow(ct, exponent);" << endl
+			<< "}" << endl
+			<< endl
+			<< "float " << e << "_G(vec3 m, vec3 wi, vec3 wo) {" << endl
+			<< "    if ((dot(wi, m) * cosTheta(wi)) <= 0 || " << endl
+			<< "        (dot(wo, m) * cosTheta(wo)) <= 0)" << endl
+			<< "        return 0.0;" << endl
+			<< "    float nDotM = cosTheta(m);" << endl
+			<< "    return min(1.0, min(" << endl
+			<< "        abs(2 * nDotM * cosTheta(wo) / dot(wo, m))," << endl
+			<< "        abs(2 * nDotM * cosTheta(wi) / dot(wi, m))));" << endl
+			<< "}" << endl
+			<< endl
+			<< "vec3 " << e << "_schlick(float ct) {" << endl
+			<< "    float ctSqr = ct*ct, ct5 = ctSqr*ctSqr*ct;" << endl
+			<< "    return " << e << "_R0 + (vec3(1.0) - " << e << "_R0) * ct5;" << endl
+			<< "}" << endl
+			<< endl
+			<< "vec3 " << e << "(vec2 uv, vec3 wi, vec3 wo) {" << endl
+			<< "   if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0)" << endl
+			<< "    	return vec3(0.0);" << endl
+			<< "   vec3 H = normalize(wi + wo);" << endl
+			<< "   vec3 reflectance = " << depNames[0] << "(uv);" << endl
+			<< "   float alpha1 = max(0.2, " << depNames[1] << "(uv).r);" << endl
+			<< "   float alpha2 = max(0.2, " << depNames[2] << "(uv).r);" << endl
+			<< "   float D = " << e << "_D(H, alpha1, alpha2)" << ";" << endl
+			<< "   float G = " << e << "_G(H, wi, wo);" << endl
+			<< "   vec3 F = " << e << "_schlick(1-dot(wi, H));" << endl
+			<< "   return reflectance * F * (D * G / (4*cosTheta(wi)));" << endl
+			<< "}" << endl
+			<< endl
+			<< "vec3 " << e << "_diffuse(vec2 uv, vec3 wi, vec3 wo) {" << endl
+			<< "    if (cosTheta(wi) < 0.0 || cosTheta(wo) < 0.0)" << endl
+			<< "    	return vec3(0.0);" << endl
+			<< "    return " << e << "_R0 * inv_pi * inv_pi * cosTheta(wo);"<< endl
+			<< "}" << endl;
+	}
+	MTS_DECLARE_CLASS()
+private:
+	ref<const Texture> m_specularReflectance, m_alpha1, m_alpha2;
+	ref<Shader> m_specularReflectanceShader, m_alpha1Shader, m_alpha2Shader;
+	Spectrum m_R0;
+};
+
+Shader *dj_beckmann_conductor::createShader(Renderer *renderer) const {
+	return new dj_beckmann_conductor_shader(renderer, m_specularReflectance.get(), m_alpha1.get(), m_alpha2.get(), m_eta, m_k);
+}
+
+MTS_IMPLEMENT_CLASS(dj_beckmann_conductor_shader, false, Shader)
 MTS_IMPLEMENT_CLASS_S(dj_beckmann_conductor, false, BSDF)
-MTS_EXPORT_PLUGIN(dj_beckmann_conductor, "dj_beckmannconductor BRDF (MI355X engine)")
+MTS_EXPORT_PLUGIN(dj_beckmann_conductor, "Rough conductor BRDF");
 MTS_NAMESPACE_END

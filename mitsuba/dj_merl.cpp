@@ -1,114 +1,78 @@
-// mitsuba/dj_merl.cpp -- Mitsuba 0.5 BSDF plugin "dj_merl" on top of the MI355X engine.
+// mitsuba/dj_merl.cpp -- Mitsuba 0.5 BSDF plugin "dj_merl" on top of the MI355X engine (drop-in for jdupuy/dj_brdf
+// mitsuba/dj_merl.cpp:17-189; see mitsuba/djb_mitsuba.hpp for what "drop-in" covers and how it is tested).
 //
-// Same plugin name, XML properties ("filename") and BSDF method signatures as the reference's
-// shell (jdupuy/dj_brdf mitsuba/dj_merl.cpp:18-140): eval = merl evalp, sample/pdf = GGX lobe whose
-// roughness is fitted at load time with tabular(merl, 90, /*shadow*/false).  What changes is where
-// the arithmetic runs: the MERL table and the fitted lobe live in HBM behind libdjb_hip.so, and
-// the fit is one launch of the power-iteration kernel.
-//
-// NOT COMPILED IN THIS REPOSITORY: it needs the Mitsuba 0.5 SDK (<mitsuba/render/bsdf.h> ...),
-// which is absent from the build image.  Copy into mitsuba/src/bsdfs/, add
-//   plugins += env.SharedLibrary('dj_merl', ['dj_merl.cpp'], LIBS=['djb_hip'], CPPPATH=[...include])
-// to src/bsdfs/SConscript, and see INTEGRATION.md for the wavefront (batched) integration, which
-// is the form that actually uses the GPU; the per-intersection calls below are batches of one.
-#include <mitsuba/core/fresolver.h>
-#include <mitsuba/render/bsdf.h>
-#include <mitsuba/hw/basicshader.h>
-
-#include "djb_hip.hpp"
+// eval = merl::evalp; sample / pdf = a GGX lobe whose roughness is fitted at load time with tabular(merl, 90, shadow=false)
+// (l.32: the plugin, unlike examples/merl_params.cpp, fits without shadowing).  The table and the fit live in HBM; the fit
+// is one launch of the power-iteration kernel.
+// Reference quirks kept: the single component is registered as EDiffuseReflection (l.51) and that is what eval / pdf /
+// sample test (l.57, 69, 81) although sample reports EGlossyReflection (l.92); no getRoughness override.
+#include "djb_mitsuba.hpp"
 
 MTS_NAMESPACE_BEGIN
+using namespace djb_mts;
 
 class dj_merl : public BSDF {
 public:
 	dj_merl(const Properties &props) : BSDF(props), m_brdf(NULL), m_ggx(NULL) {
-		ref<FileResolver> fResolver = Thread::getThread()->getFileResolver();
-		fs::path path = fResolver->resolve(props.getString("filename"));
-		m_brdf = new djb::merl(path.string().c_str());            // throws djb::exc like the reference
-		djb::tabular tab(*m_brdf, 90, false);                      // GPU fit
-		m_params = djb::tabular::fit_ggx_parameters(tab);
+		m_reflectance = reflectance_property(props);
+		const std::string file = resolved(props.getString("filename")).string();
+		m_brdf = new djb::merl(file.c_str());                                   // throws djb::exc like the reference
+		m_params = djb::tabular::fit_ggx_parameters(djb::tabular(*m_brdf, 90, false));
 		m_ggx = new djb::ggx();
 	}
-	dj_merl(Stream *stream, InstanceManager *manager) : BSDF(stream, manager), m_brdf(NULL), m_ggx(NULL) {
-		configure();
-	}
+	dj_merl(Stream *stream, InstanceManager *manager) : BSDF(stream, manager), m_brdf(NULL), m_ggx(NULL) { configure(); }
 	~dj_merl() { delete m_brdf; delete m_ggx; }
 
 	void configure() {
 		m_components.clear();
-		m_components.push_back(EGlossyReflection | EFrontSide | 0);
+		m_components.push_back(EDiffuseReflection | EFrontSide | 0);
 		m_usesRayDifferentials = false;
 		BSDF::configure();
 	}
 
-	// djb's i is the light direction and o the viewer: Mitsuba's wi/wo are swapped (dj_brdf.h:23-26)
 	Spectrum eval(const BSDFSamplingRecord &bRec, EMeasure measure) const {
-		if (!(bRec.typeMask & EGlossyReflection) || measure != ESolidAngle
-			|| Frame::cosTheta(bRec.wi) <= 0 || Frame::cosTheta(bRec.wo) <= 0)
+		if (unwanted(bRec, measure))
 			return Spectrum(0.0f);
-		djb::vec3 o(bRec.wi.x, bRec.wi.y, bRec.wi.z), i(bRec.wo.x, bRec.wo.y, bRec.wo.z);
-		djb::vec3 fr_p = m_brdf->evalp(i, o);
-		Spectrum s; s.fromLinearRGB(fr_p.x, fr_p.y, fr_p.z);
-		return s;
+		return rgb(m_brdf->evalp(dir(bRec.wo), dir(bRec.wi)));
 	}
-
 	Float pdf(const BSDFSamplingRecord &bRec, EMeasure measure) const {
-		if (!(bRec.typeMask & EGlossyReflection) || measure != ESolidAngle
-			|| Frame::cosTheta(bRec.wi) <= 0 || Frame::cosTheta(bRec.wo) <= 0)
+		if (unwanted(bRec, measure))
 			return 0.0f;
-		djb::vec3 o(bRec.wi.x, bRec.wi.y, bRec.wi.z), i(bRec.wo.x, bRec.wo.y, bRec.wo.z);
-		return m_ggx->pdf(i, o, &m_params);
-	}
-
-	Spectrum sample(BSDFSamplingRecord &bRec, Float &pdf_, const Point2 &sample) const {
-		if (!(bRec.typeMask & EGlossyReflection) || Frame::cosTheta(bRec.wi) <= 0)
-			return Spectrum(0.0f);
-		djb::vec3 o(bRec.wi.x, bRec.wi.y, bRec.wi.z);
-		djb::vec3 i = m_ggx->sample(sample.x, sample.y, o, &m_params);
-		if (i.z <= 0) return Spectrum(0.0f);
-		bRec.wo = Vector(i.x, i.y, i.z);
-		bRec.eta = 1.0f;
-		bRec.sampledComponent = 0;
-		bRec.sampledType = EGlossyReflection;
-		pdf_ = m_ggx->pdf(i, o, &m_params);
-		if (pdf_ <= 0) return Spectrum(0.0f);
-		return eval(bRec, ESolidAngle) / pdf_;
+		return m_ggx->pdf(dir(bRec.wo), dir(bRec.wi), &m_params);
 	}
 	Spectrum sample(BSDFSamplingRecord &bRec, const Point2 &sample) const {
-		Float pdf_;
-		return dj_merl::sample(bRec, pdf_, sample);
+		if (lobe_masked(bRec, EDiffuseReflection) || at_or_below(bRec.wi))
+			return Spectrum(0.0f);
+		const djb::vec3 o = dir(bRec.wi);
+		return finish_lobe_sample(*this, *m_brdf, bRec, m_ggx->sample(sample.x, sample.y, o, &m_params), o);
+	}
+	Spectrum sample(BSDFSamplingRecord &bRec, Float &pdf_, const Point2 &sample_) const {
+		Spectrum res = sample(bRec, sample_);
+		pdf_ = pdf(bRec, ESolidAngle);        // l.101-102: evaluated even when the sample was rejected
+		return res;
 	}
 
-	void serialize(Stream *stream, InstanceManager *manager) const { BSDF::serialize(stream, manager); }
-	Float getRoughness(const Intersection &its, int component) const {
-		float a1, a2; m_params.get_ellipse(&a1, &a2); return 0.5f * (a1 + a2);
+	void addChild(const std::string &name, ConfigurableObject *child) {
+		if (!is_reflectance_child(name, child))      // l.106-113: the texture child is accepted and dropped
+			BSDF::addChild(name, child);
 	}
-	std::string toString() const { return "dj_merl[engine = libdjb_hip (MI355X)]"; }
+	void serialize(Stream *stream, InstanceManager *manager) const { BSDF::serialize(stream, manager); }
+	std::string toString() const { return id_only("dj_merl", getID()); }
 	Shader *createShader(Renderer *renderer) const;
 	MTS_DECLARE_CLASS()
 private:
+	bool unwanted(const BSDFSamplingRecord &bRec, EMeasure measure) const
+	{ return lobe_masked(bRec, EDiffuseReflection) || measure != ESolidAngle || at_or_below(bRec.wi) || at_or_below(bRec.wo); }
+	ref<const Texture> m_reflectance;
 	djb::brdf *m_brdf;
 	djb::ggx *m_ggx;
 	djb::microfacet::params m_params;
 };
 
-// the VPL preview shader is renderer UI, not djb math: a constant diffuse stand-in
-class dj_merl_shader : public Shader {
-public:
-	dj_merl_shader(Renderer *renderer) : Shader(renderer, EBSDFShader) {}
-	void generateCode(std::ostringstream &oss, const std::string &evalName,
-			const std::vector<std::string> &depNames) const {
-		oss << "vec3 " << evalName << "(vec2 uv, vec3 wi, vec3 wo) {\n"
-			<< "    if (cosTheta(wi) < 0.0 || cosTheta(wo) < 0.0) return vec3(0.0);\n"
-			<< "    return vec3(0.5 * inv_pi * cosTheta(wo));\n}\n\n"
-			<< "vec3 " << evalName << "_diffuse(vec2 uv, vec3 wi, vec3 wo) {\n"
-			<< "    return " << evalName << "(uv, wi, wo);\n}\n";
-	}
-	MTS_DECLARE_CLASS()
-};
-Shader *dj_merl::createShader(Renderer *renderer) const { return new dj_merl_shader(renderer); }
+DJB_MTS_PREVIEW_SHADER(dj_merl_shader)
+Shader *dj_merl::createShader(Renderer *renderer) const { return new dj_merl_shader(renderer, m_reflectance.get()); }
 
 MTS_IMPLEMENT_CLASS(dj_merl_shader, false, Shader)
 MTS_IMPLEMENT_CLASS_S(dj_merl, false, BSDF)
-MTS_EXPORT_PLUGIN(dj_merl, "dj_merl BRDF (MI355X engine)")
+MTS_EXPORT_PLUGIN(dj_merl, "dj_merl BRDF")
 MTS_NAMESPACE_END

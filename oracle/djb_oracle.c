@@ -1579,6 +1579,26 @@ void o_eval_lean(const o_brdf *b, int op, int64_t n, const float *i, const float
 		else out[k] = brdf_pdf(b, vi, vo, &p);
 	}
 }
+/* dj_beckmann_conductor::sample per hit (mitsuba/dj_beckmannconductor.cpp:373-413): params as above, then
+ * evalp_is(u1, u2, o, &i, &pdf, &params) (hdr:1734-1765); is == 0: sample() only (hdr:1669-1709) */
+void o_sample_lean(const o_brdf *b, int is, int64_t n, const float *u1, const float *u2, const float *o,
+                   const o_param_desc *base, float scale, int flags, const float *lean, float *out_w, float *out_i,
+                   float *out_pdf, float *out_pdfparams)
+{
+	o_params p0 = params_from_desc(base);
+	for (int64_t k = 0; k < n; ++k) {
+		float pp[5];
+		lean_hit_pdfparams(lean + 5 * k, &p0, scale, flags, pp);
+		if (out_pdfparams) memcpy(out_pdfparams + 5 * k, pp, sizeof pp);
+		o_params p;
+		params_set_pdfparams(&p, pp[0], pp[1], pp[2], pp[3], pp[4]);
+		o_vec3 vo = ld3(o, k);
+		if (!is) { st3(out_i, k, mf_sample(b, u1[k], u2[k], vo, &p)); continue; }
+		o_vec3 vi = v3(0, 0, 0); float pdf = 0;
+		o_vec3 w = mf_evalp_is(b, u1[k], u2[k], vo, &p, &vi, &pdf);
+		st3(out_w, k, w); st3(out_i, k, vi); out_pdf[k] = pdf;
+	}
+}
 /* per-pair pdfparams (n x 5: ax, ay, rho, tx, ty) */
 void o_eval_pp(const o_brdf *b, int op, int64_t n, const float *i, const float *o, const float *pp, float *out)
 {

@@ -305,6 +305,57 @@ void ref_lrep_op(int op, const float *a, const float *b, float x, float y, float
 	p.get_pdfparams(&out_pdfparams[0], &out_pdfparams[1], &out_pdfparams[2], &out_pdfparams[3], &out_pdfparams[4]);
 }
 
+// dj_beckmann_conductor::sample per hit (/root/reference/mitsuba/dj_beckmannconductor.cpp:373-413), the parameter block as
+// in ref_eval_lean, then the plugin's evalp_is call (l.404-413).  is == 0: sample() with the same params instead.
+void ref_sample_lean(void *b_, int is, long n, const float *u1, const float *u2, const float *o, const shim_params *base,
+                     float scale, int flags, const float *lean, float *out_w, float *out_i, float *out_pdf,
+                     float *out_pdfparams)
+{
+	const djb::brdf *m_brdf = (const djb::brdf *)b_;
+	param_holder ph(base);
+	const bool m_leanFiltering = !(flags & 1);
+	const float m_dmapScale = scale;
+	for (long k = 0; k < n; ++k) {
+		djb::microfacet::params params = ph.ptr ? ph.p : djb::microfacet::params::standard();
+		float E1 = lean[5*k], E2 = lean[5*k+1], E3 = lean[5*k+2], E4 = lean[5*k+3], E5 = lean[5*k+4];
+		const float BIAS = 25.f;
+		if (flags & 2) {
+			E1-= BIAS;
+			E2-= BIAS;
+			E5-= BIAS*BIAS;
+		}
+		djb::beckmann::lrep lrep1, lrep2;
+
+		if (m_leanFiltering) { // LEAN filtering
+			lrep1 = djb::beckmann::lrep(E1, E2, E3, E4, E5);
+		} else { // Naive MIP mapping
+			lrep1 = djb::beckmann::lrep(E1, E2, E1*E1, E2*E2, E1*E2);
+		}
+		lrep1*= m_dmapScale;
+		djb::beckmann::params_to_lrep(params, &lrep2);
+		/* Get final microfacet Parameters */
+		djb::beckmann::lrep_to_params(lrep1 + lrep2, &params);
+		if (out_pdfparams)
+			params.get_pdfparams(&out_pdfparams[5*k], &out_pdfparams[5*k+1], &out_pdfparams[5*k+2],
+			                     &out_pdfparams[5*k+3], &out_pdfparams[5*k+4]);
+
+		/* Importance Sample the BRDF */
+		djb::vec3 vo = ld(o, k);
+		if (!is) { st(out_i, k, m_brdf->sample(u1[k], u2[k], vo, (const void *)&params)); continue; }
+		djb::vec3 i(0);
+		float pdf = 0;
+		djb::vec3 fr_cos = m_brdf->evalp_is(
+			u1[k],
+			u2[k],
+			vo,
+			&i,
+			&pdf,
+			(const void *)&params
+		);
+		st(out_w, k, fr_cos); st(out_i, k, i); out_pdf[k] = pdf;
+	}
+}
+
 // params -> lrep -> params (hdr:1965-1990): out = pdfparams of lrep_to_params(params_to_lrep(p))
 void ref_params_lrep_roundtrip(const shim_params *sp, float *out_pdfparams)
 {

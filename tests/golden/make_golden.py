@@ -111,7 +111,9 @@ def main():
     i = synth.directions_aos(N_LEAN, synth.SEED_I, start=30000)
     o = synth.directions_aos(N_LEAN, synth.SEED_O, start=30000)
     lean = lean_moments(N_LEAN)
-    out.update(i=i, o=o, lean=lean)
+    u1 = synth.uniforms(N_LEAN, synth.SEED_U1, start=30000)
+    u2 = synth.uniforms(N_LEAN, synth.SEED_U2, start=30000)
+    out.update(i=i, o=o, lean=lean, u1=u1, u2=u2)
     for c, (scale, filtering, biased) in enumerate(LEAN_CASES):
         tex = lean_texels(lean, biased)
         for ndf in ("beckmann", "ggx"):
@@ -120,6 +122,11 @@ def main():
                 val, pp = R.eval_lean(b, i, o, LEAN_BASE, scale, tex, op, filtering=filtering, biased=biased)
                 out[f"c{c}_{ndf}_{op}"] = val
             out[f"c{c}_pdfparams"] = pp
+            # dj_beckmann_conductor::sample per hit: evalp_is (and sample) with the per-hit params
+            w, si, pdf, pp2 = R.sample_lean(b, u1, u2, o, LEAN_BASE, scale, tex, True, filtering=filtering, biased=biased)
+            assert np.array_equal(pp2.view(np.uint32), pp.view(np.uint32))
+            out[f"c{c}_{ndf}_is_w"], out[f"c{c}_{ndf}_is_i"], out[f"c{c}_{ndf}_is_pdf"] = w, si, pdf
+            out[f"c{c}_{ndf}_sample"] = R.sample_lean(b, u1, u2, o, LEAN_BASE, scale, tex, False, filtering=filtering, biased=biased)[0]
     save("lean.npz", **out)
 
     # ---- tabular_anisotropic: fit tables, moment fits, sampling queries, operators

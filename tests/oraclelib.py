@@ -194,6 +194,19 @@ class CheckerLib:
                               C.c_int(flags), _ptr(lean), _ptr(out), _ptr(pp))
         return out, pp
 
+    def sample_lean(self, b, u1, u2, o, base, scale, lean, evalp_is=True, filtering=True, biased=False):
+        """dj_beckmann_conductor::sample per hit (mitsuba/dj_beckmannconductor.cpp:373-413): (w, i, pdf, pdfparams),
+        or with evalp_is=False (i, pdfparams) from sample() with the same per-hit params."""
+        u1, u2, o, lean = _f32(u1), _f32(u2), _f32(o), _f32(lean)
+        n = o.shape[0]
+        w = np.zeros((n, 3), np.float32); i = np.zeros((n, 3), np.float32)
+        pdf = np.zeros((n,), np.float32); pp = np.empty((n, 5), np.float32)
+        pd = param_desc(base)
+        flags = (0 if filtering else 1) | (2 if biased else 0)
+        self._fn("sample_lean")(b, C.c_int(1 if evalp_is else 0), C.c_int64(n), _ptr(u1), _ptr(u2), _ptr(o), C.byref(pd),
+                                C.c_float(scale), C.c_int(flags), _ptr(lean), _ptr(w), _ptr(i), _ptr(pdf), _ptr(pp))
+        return (w, i, pdf, pp) if evalp_is else (i, pp)
+
     def eval_pp(self, b, i, o, pp, op="eval"):
         assert self.prefix == "o_"
         i, o, pp = _f32(i), _f32(o), _f32(pp)

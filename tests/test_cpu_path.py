@@ -187,6 +187,12 @@ def test_lean_and_queries(cpu, oracle, dirs):
                                   filtering=filtering, biased=biased)
         want, wpp = oracle.eval_lean(ob, i, o, LEAN_BASE, scale, tex, "evalp", filtering=filtering, biased=biased)
         assert same(gpp, wpp) and same(got, want), (scale, filtering, biased)
+        gw, gi, gpdf, gpp = b.sample_lean(u1, u2, o, mk_params(LEAN_BASE), scale, tex, True, return_params=True,
+                                          filtering=filtering, biased=biased)
+        ww, wi, wpdf, wpp = oracle.sample_lean(ob, u1, u2, o, LEAN_BASE, scale, tex, True, filtering=filtering, biased=biased)
+        assert same(gpp, wpp) and same(gi, wi) and same(gw, ww) and same(gpdf, wpdf), (scale, filtering, biased)
+    pp = oracle.eval_lean(ob, i, o, LEAN_BASE, 0.7, lean, "pdf")[1]
+    assert same(b.sample_pp(u1, u2, o, pp), oracle.sample_lean(ob, u1, u2, o, LEAN_BASE, 0.7, lean, False)[0])
     h = oracle.io_to_hd(i, o)[0]
     up, p = mk_params(PARAMS[2]), PARAMS[2]
     assert same(b.ndf(h, up), oracle.microfacet_query(ob, "ndf", h, params=p))

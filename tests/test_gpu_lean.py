@@ -63,6 +63,32 @@ def test_lean_eval_golden(gpu_ctx, ndf):
         assert_close("fused pdf", pdf, np.tile(g[f"c{c}_{ndf}_pdf"], reps))
 
 
+@pytest.mark.parametrize("ndf", ["beckmann", "ggx"])
+def test_lean_sample_golden(gpu_ctx, ndf):
+    """dj_beckmann_conductor::sample per hit (mitsuba/dj_beckmannconductor.cpp:373-413), batched: per-hit params, then
+    evalp_is -- against the real reference's outputs for the same hits."""
+    g = np.load(os.path.join(G, "lean.npz"))
+    b = getattr(djb, ndf)(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=gpu_ctx)
+    base = mk_params(LEAN_BASE)
+    reps = 4
+    o, u1, u2 = np.tile(g["o"], (reps, 1)), np.tile(g["u1"], reps), np.tile(g["u2"], reps)
+    for c, (scale, filtering, biased) in enumerate(LEAN_CASES):
+        tex = np.tile(lean_texels(g["lean"], biased), (reps, 1))
+        kw = dict(filtering=filtering, biased=biased)
+        w, si, pdf, pp = b.sample_lean(u1, u2, o, base, scale, tex, True, return_params=True, **kw)
+        assert np.array_equal(pp.view(np.uint32), np.tile(g[f"c{c}_pdfparams"], (reps, 1)).view(np.uint32))
+        assert assert_close(f"{ndf}/lean{c}/is_i", si, np.tile(g[f"c{c}_{ndf}_is_i"], (reps, 1))) > 0.999
+        assert_close(f"{ndf}/lean{c}/is_w", w, np.tile(g[f"c{c}_{ndf}_is_w"], (reps, 1)))
+        assert_close(f"{ndf}/lean{c}/is_pdf", pdf, np.tile(g[f"c{c}_{ndf}_is_pdf"], reps))
+        si2 = b.sample_lean(u1, u2, o, base, scale, tex, False, **kw)
+        assert_close(f"{ndf}/lean{c}/sample", si2, np.tile(g[f"c{c}_{ndf}_sample"], (reps, 1)))
+        assert np.array_equal(b.sample_pp(u1, u2, o, pp).view(np.uint32), si2.view(np.uint32))
+        # scalar-size call (host twin) == kernel
+        one = b.sample_lean(u1[:1], u2[:1], o[:1], base, scale, tex[:1], True, **kw)
+        for a, k in zip(one, (w, si, pdf)):
+            assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(k[:1]).view(np.uint32))
+
+
 def test_lean_composition_anchor(gpu_ctx):
     """lrep(lean) * dmapscale + params_to_lrep(base), the plugin's order (mitsuba/dj_beckmannconductor.cpp:296-314):
     the per-pair params the real header gives for one texel at dmapscale 0.7 and 2."""

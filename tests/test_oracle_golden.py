@@ -302,6 +302,11 @@ def test_lrep_and_lean_path(oracle):
                 val, pp = oracle.eval_lean(b, g["i"], g["o"], LEAN_BASE, scale, tex, op, filtering=filtering, biased=biased)
                 assert same(val, g[f"c{c}_{ndf}_{op}"]) and same(pp, g[f"c{c}_pdfparams"]), (c, ndf, op)
                 assert same(oracle.eval_pp(b, g["i"], g["o"], g[f"c{c}_pdfparams"], op), g[f"c{c}_{ndf}_{op}"])
+            kw = dict(filtering=filtering, biased=biased)
+            w, si, pdf, pp = oracle.sample_lean(b, g["u1"], g["u2"], g["o"], LEAN_BASE, scale, tex, True, **kw)
+            assert same(pp, g[f"c{c}_pdfparams"]) and same(w, g[f"c{c}_{ndf}_is_w"]) and same(si, g[f"c{c}_{ndf}_is_i"]) \
+                and same(pdf, g[f"c{c}_{ndf}_is_pdf"]), (c, ndf)
+            assert same(oracle.sample_lean(b, g["u1"], g["u2"], g["o"], LEAN_BASE, scale, tex, False, **kw)[0], g[f"c{c}_{ndf}_sample"])
     # the composition is lrep(lean) * dmapscale + params_to_lrep(base) (mitsuba/dj_beckmannconductor.cpp:296-314):
     # values the real header gives for one texel, which no other operand order reproduces at scale != 1
     b = oracle.microfacet("beckmann")

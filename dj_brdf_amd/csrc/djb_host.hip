@@ -644,10 +644,11 @@ try {
 	*count = b->raw_count;
 	if (!out) return DJB_OK;
 	if (capacity < b->raw_count) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: get_samples needs room for %lld doubles", b->raw_count);
-	HIP_TRY(hipSetDevice(b->ctx->device));
-	std::lock_guard<std::recursive_mutex> call_lock(b->ctx->call_mu);
-	HIP_TRY(hipMemcpyAsync(out, b->raw_samples, sizeof(double) * (size_t)b->raw_count, hipMemcpyDeviceToHost, b->ctx->stream));
-	HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+	// The payload was complete (stream synchronised) when the constructor returned and is immutable since: a blocking copy
+	// on the object's device needs neither a stream nor a lock -- and must not touch b->ctx, which may have been destroyed
+	// (handles outlive their creating context, :141)
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipMemcpy(out, b->raw_samples, sizeof(double) * (size_t)b->raw_count, hipMemcpyDeviceToHost));
 	if (b->dev.kind == DJB_KIND_UTIA) {      // utia::normalize, dj_brdf.h:1162-1177: clamp to zero, then *= (float_t)(1.f / 140.f)
 		const float k = 1.f / 140.f;
 		for (long long j = 0; j < b->raw_count; ++j) { double v = out[j] > 0.0 ? out[j] : 0.0; out[j] = v * k; }
@@ -678,7 +679,7 @@ try {
 	if (is_cpu(b)) return djbcpu::set_fresnel(b, f);
 	if (!b || !is_microfacet_kind(b->dev.kind))
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: set_fresnel needs a microfacet BRDF");
-	HIP_TRY(hipSetDevice(b->ctx->device));
+	HIP_TRY(hipSetDevice(b->device));          // not b->ctx->device: the creating context may be gone (:141)
 	// kernels receive the descriptor by value at launch; a replaced spline table stays allocated
 	// until the handle is destroyed, so launches in flight are unaffected
 	djbdev::Fresnel saved = b->dev.fr;

@@ -10,9 +10,13 @@
 #pragma once
 
 #include <algorithm>
+#include <csetjmp>
+#include <csignal>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,6 +43,38 @@ inline SlotPlan make_plan(const std::vector<int32_t> &idx)
 	SlotPlan plan;
 	for (int32_t s : order) { plan.slot.push_back(s); plan.idx.push_back(idx[s]); }
 	return plan;
+}
+
+// ---- a file that shrinks under its mapping ---------------------------------------------------------------------------
+// The size is checked before the file is mapped, but another process can truncate it afterwards; touching a page that lies
+// beyond the new end of file raises SIGBUS, where the reference -- which fread()s -- reports "Reading %s failed"
+// (dj_brdf.h:979-982).  pread per entry would give that verdict for free but costs a system call per double (measured:
+// 24 files 6 ms mapped vs 190 ms with pread on one thread; process_vm_readv on the own mapping: 8 ms per FILE), so the
+// gather keeps the mapping and runs under a guard: a process-wide SIGBUS handler, installed on first use, that jumps back
+// into gather_file when -- and only when -- the faulting address lies inside the mapping the current thread is gathering
+// from; any other SIGBUS goes to the handler that was installed before (or to the default action).
+struct BusGuard { sigjmp_buf env; const char *lo, *hi; };
+inline thread_local BusGuard *t_bus_guard = nullptr;
+inline struct sigaction g_prev_sigbus;
+inline std::once_flag g_sigbus_once;
+inline void on_sigbus(int sig, siginfo_t *si, void *uc)
+{
+	BusGuard *g = t_bus_guard;
+	const char *addr = (const char *)si->si_addr;
+	if (g && addr >= g->lo && addr < g->hi) siglongjmp(g->env, 1);
+	if ((g_prev_sigbus.sa_flags & SA_SIGINFO) && g_prev_sigbus.sa_sigaction) { g_prev_sigbus.sa_sigaction(sig, si, uc); return; }
+	if (!(g_prev_sigbus.sa_flags & SA_SIGINFO) && g_prev_sigbus.sa_handler == SIG_IGN) return;
+	if (!(g_prev_sigbus.sa_flags & SA_SIGINFO) && g_prev_sigbus.sa_handler != SIG_DFL) { g_prev_sigbus.sa_handler(sig); return; }
+	struct sigaction dfl; memset(&dfl, 0, sizeof dfl); dfl.sa_handler = SIG_DFL; sigemptyset(&dfl.sa_mask);
+	sigaction(SIGBUS, &dfl, nullptr);          // not ours and nobody else's: the faulting access re-executes under the default action
+}
+inline void install_sigbus_guard()
+{
+	std::call_once(g_sigbus_once, []() {
+		struct sigaction sa; memset(&sa, 0, sizeof sa);
+		sa.sa_sigaction = on_sigbus; sa.sa_flags = SA_SIGINFO; sigemptyset(&sa.sa_mask);
+		sigaction(SIGBUS, &sa, &g_prev_sigbus);
+	});
 }
 
 // out: 3 floats (r, g, b) per slot, slot-major.  Same checks and messages as djb::merl::merl (dj_brdf.h:963-983); the
@@ -70,8 +106,19 @@ inline djb_status gather_file(const char *path, const SlotPlan &plan, float *out
 	void *map = mmap(nullptr, 12 + PAYLOAD, PROT_READ, MAP_PRIVATE, fd, 0);
 	close(fd);
 	if (map == MAP_FAILED) { snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED; }
+	// test seam (tests/test_gpu_golden.py, tests/test_cpu_path.py): shrink the file now, i.e. after the size check and the mapping
+	if (const char *shrink = getenv("DJB_TEST_SHRINK_AFTER_MAP")) { if (truncate(path, atoll(shrink)) != 0) { /* the test notices */ } }
 	const char *base = (const char *)map + 12;                   // the payload is 4 bytes off 8-byte alignment: memcpy each double
 	const size_t m = plan.slot.size();
+	install_sigbus_guard();
+	BusGuard guard;
+	guard.lo = (const char *)map; guard.hi = guard.lo + 12 + PAYLOAD;
+	if (sigsetjmp(guard.env, 1) != 0) {                         // a page of the mapping is gone: the file shrank under us
+		t_bus_guard = nullptr;
+		munmap(map, 12 + PAYLOAD);
+		snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED;
+	}
+	t_bus_guard = &guard;
 	for (size_t k = 0; k < m; ++k) {
 		const long long i = plan.idx[k];
 		double s[3];
@@ -84,6 +131,7 @@ inline djb_status gather_file(const char *path, const SlotPlan &plan, float *out
 		float *o = out + 3 * (size_t)plan.slot[k];
 		o[0] = r; o[1] = g; o[2] = b;
 	}
+	t_bus_guard = nullptr;
 	if (keep) keep->emplace_back(map, 12 + PAYLOAD);
 	else munmap(map, 12 + PAYLOAD);
 	return DJB_OK;

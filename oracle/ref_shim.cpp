@@ -356,6 +356,14 @@ void ref_sample_lean(void *b_, int is, long n, const float *u1, const float *u2,
 	}
 }
 
+#ifdef DJB_FACADE_SHIM
+// conformance harness only: route the facade's one-pair calls through the GPU kernels (1) or the host twin (0)
+int ref_facade_scalar_on_device(int on)
+{
+	return (int)djb_ctx_set_option(djb::hip::context::standard().get(), DJB_OPT_SCALAR_ON_DEVICE, on);
+}
+#endif
+
 // params -> lrep -> params (hdr:1965-1990): out = pdfparams of lrep_to_params(params_to_lrep(p))
 void ref_params_lrep_roundtrip(const shim_params *sp, float *out_pdfparams)
 {

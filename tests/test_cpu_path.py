@@ -175,6 +175,26 @@ def test_params_txt_on_the_cpu(cpu, tmp_path):
     assert e.value.status_name == "DJB_ERR_OPEN_FAILED"
 
 
+def test_file_that_shrinks_under_the_gather(cpu, tmp_path, monkeypatch):
+    """The file passes the size check, is mapped, and is then truncated by someone else: the reference, which fread()s,
+    reports "Reading <file> failed" (dj_brdf.h:979-982); so does the gather, instead of dying on SIGBUS -- and the process
+    goes on to fit the next file."""
+    p = str(tmp_path / "shrinks.binary")
+    synth.write_merl_binary(p, synth.merl_table(*PARAMS_TXT_MATERIALS[0][1]))
+    monkeypatch.setenv("DJB_TEST_SHRINK_AFTER_MAP", "9000000")          # the test seam of csrc/djb_merl_file.hpp
+    with pytest.raises(djb.exc) as e:
+        merl_params.fit_files_on(cpu, [p])
+    assert e.value.status_name == "DJB_ERR_READ_FAILED" and str(e.value).strip() == f"djb_error: Reading {p} failed"
+    assert os.path.getsize(p) == 9000000
+    monkeypatch.delenv("DJB_TEST_SHRINK_AFTER_MAP")
+    with pytest.raises(djb.exc) as e:                                    # now short before the mapping: same verdict
+        merl_params.fit_files_on(cpu, [p])
+    assert e.value.status_name == "DJB_ERR_READ_FAILED"
+    synth.write_merl_binary(p, synth.merl_table(*PARAMS_TXT_MATERIALS[0][1]))
+    ab, ag, _ = merl_params.fit_files_on(cpu, [p])
+    assert np.isfinite(ab).all() and np.isfinite(ag).all()
+
+
 def test_lean_and_queries(cpu, oracle, dirs):
     from golden_cases import LEAN_BASE, LEAN_CASES, lean_moments, lean_texels
     i, o, u1, u2 = dirs

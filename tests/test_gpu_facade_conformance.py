@@ -3,8 +3,12 @@
 oracle/ref_shim.cpp -- the extern "C" wrapper that exposes every public class of the REAL reference to the
 test-suite -- is compiled a second time, unchanged apart from -DDJB_FACADE_SHIM, against this
 repository's dj_brdf.h (oracle/Makefile `facade`).  The resulting library has the same ref_* entry
-points, but every call constructs the facade's djb:: objects and runs on the GPU (one scalar call per
-element).  Here it is driven exactly like the real reference in tests/test_oracle_vs_ref.py and compared
+points, but every call constructs the facade's djb:: objects on the GPU context; constructors and fits
+run on the GPU, and each element is one scalar facade call.  Scalar calls have two execution paths and the
+whole module runs once on each:
+  * "twin"   (default): answered on the calling thread from the host twin of the GPU object (csrc/djb_host.hip);
+  * "device" (DJB_OPT_SCALAR_ON_DEVICE): a launch + a PCIe round trip per call -- the kernels' operator path.
+Here the library is driven exactly like the real reference in tests/test_oracle_vs_ref.py and compared
 with the CPU oracle (which is itself pinned bit-exact to the reference)."""
 import os
 
@@ -19,14 +23,17 @@ FRESNEL_CASES = [("ideal",)] + list(_FRESNELS)
 
 pytestmark = pytest.mark.gpu
 SHIM = os.path.join(oraclelib.ORACLE_DIR, "_facade", "libdjb_facade_shim.so")
-N = 192   # every element is one scalar facade call (a launch + a PCIe round trip)
+N = 192   # every element is one scalar facade call
 
 
-@pytest.fixture(scope="module")
-def facade(gpu_ctx):
+@pytest.fixture(scope="module", params=["twin", "device"])
+def facade(gpu_ctx, request):
     if not os.path.exists(SHIM):
         pytest.skip("oracle/_facade/libdjb_facade_shim.so not built (make -C oracle facade)")
-    return oraclelib.CheckerLib(SHIM, "ref_")
+    lib = oraclelib.CheckerLib(SHIM, "ref_")
+    assert lib._fn("facade_scalar_on_device")(1 if request.param == "device" else 0) == 0
+    yield lib
+    lib._fn("facade_scalar_on_device")(0)
 
 
 @pytest.fixture(scope="module")

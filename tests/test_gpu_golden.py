@@ -288,12 +288,17 @@ def test_cpp_facade_programs(gpu_ctx, tmp_path):
     assert r.returncode != 0 and "Failed to open" in r.stderr
 
 
-def test_reference_programs_unchanged(gpu_ctx, tmp_path):
+@pytest.mark.parametrize("scalar_on_device", ["0", "1"])
+def test_reference_programs_unchanged(gpu_ctx, tmp_path, monkeypatch, scalar_on_device):
     """The reference's OWN programs -- tests/plot_cdf.cpp, tests/plot_qf.cpp, tests/nrm_utia.cpp and
     examples/merl_params.cpp -- compiled UNCHANGED against include/dj_brdf.h (examples/Makefile
-    `reftests`, sources left in place under /root/reference) and run on the GPU must write, byte for
-    byte, what the real reference binaries write on the CPU (tests/golden/reftests/, make_reftests.sh)."""
+    `reftests`, sources left in place under /root/reference) and run on a GPU context must write, byte for
+    byte, what the real reference binaries write on the CPU (tests/golden/reftests/, make_reftests.sh).
+    Their constructors and fits run on the GPU; their one-pair operator calls are answered by the host twin of the
+    GPU object (scalar_on_device = 0, the default) or go through the kernels (DJB_SCALAR_ON_DEVICE=1)."""
     import subprocess
+    monkeypatch.setenv("DJB_SCALAR_ON_DEVICE", scalar_on_device)
+    monkeypatch.delenv("DJB_DEVICE", raising=False)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rt = os.path.join(root, "examples", "_reftests")
     if not os.path.exists(os.path.join(rt, "plot_cdf")):
@@ -358,3 +363,23 @@ def test_native_file_pipeline(gpu_ctx, tmp_path):
     with pytest.raises(djb.exc) as e:
         merl_params.fit_files_on(gpu_ctx, [str(bad)])
     assert e.value.status_name == "DJB_ERR_READ_FAILED"
+
+
+def test_file_that_shrinks_under_the_gather_gpu(gpu_ctx, tmp_path, monkeypatch):
+    """as tests/test_cpu_path.py::test_file_that_shrinks_under_the_gather, through the GPU file pipeline's reader threads:
+    a file truncated after the size check and the mapping gives "Reading <file> failed" (dj_brdf.h:979-982), not SIGBUS,
+    the other files of the batch are unaffected afterwards"""
+    paths = []
+    for k in range(3):
+        p = str(tmp_path / f"s{k}.binary")
+        synth.write_merl_binary(p, synth.merl_table(*synth.material_recipe(k))); paths.append(p)
+    want = merl_params.fit_files_on(gpu_ctx, paths)
+    monkeypatch.setenv("DJB_TEST_SHRINK_AFTER_MAP", "12000000")
+    with pytest.raises(djb.exc) as e:
+        merl_params.fit_files_on(gpu_ctx, paths)
+    assert e.value.status_name == "DJB_ERR_READ_FAILED" and "Reading" in str(e.value) and "failed" in str(e.value)
+    monkeypatch.delenv("DJB_TEST_SHRINK_AFTER_MAP")
+    for k in range(3):
+        synth.write_merl_binary(paths[k], synth.merl_table(*synth.material_recipe(k)))
+    got = merl_params.fit_files_on(gpu_ctx, paths)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

@@ -24,6 +24,7 @@
 // hardware FMA each would be a libm call) and -ffp-contract=off; nothing here runs unless the CPU has FMA.
 #define DJB_HOST_MATH 1
 #define DJB_HOST_RESTATED 1
+#include <gnu/libc-version.h>
 #include "djb_device.hpp"
 
 #include <stdio.h>
@@ -131,6 +132,17 @@ void do_init()
 	}
 	g_kat = kat_bad == 0 ? 1 : 0;
 	use_restated = g_status == 0;
+	// The probe set is a SAMPLE (4096 arguments per function): a libm that differs from glibc 2.35 on one argument in 1e4 ...
+	// 1e6 -- e.g. a later glibc with correctly rounded float functions -- would pass it.  So the host libm is trusted only if
+	// it also SAYS it is glibc 2.35; any other version runs the restatements (validated against 2.35 on every bit), which
+	// keeps "scalar path == batch path" true by construction there as well.
+	const char *ver = gnu_get_libc_version();
+	const bool known_good = ver && !strcmp(ver, "2.35");
+	if (g_status == 1 && !known_good) {
+		use_restated = 1;
+		fprintf(stderr, "dj_brdf_amd: host libc is glibc %s, not 2.35: the probe set found no difference, but it is a sample -- host-side calls "
+		                "run the kernels' restatements of glibc 2.35's functions (DJB_HOST_LIBM=host keeps the host's)\n", ver ? ver : "?");
+	}
 	if (env && !strcmp(env, "restated")) use_restated = 1;
 	if (env && !strcmp(env, "host")) use_restated = 0;
 	if (g_status == 0) {

@@ -700,7 +700,11 @@ try {
 	if (option == DJB_OPT_MERL_EXACT_ONLY) { ctx->merl_exact_only = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_ANISO_QF2_ALIGNED) { ctx->aniso_qf2_aligned = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_UTIA_EXACT_ONLY) { ctx->utia_exact_only = value != 0; return DJB_OK; }
-	if (option == DJB_OPT_CONTRACT_1E5) { ctx->contract_1e5 = value != 0; return DJB_OK; }
+	if (option == DJB_OPT_CONTRACT_1E5) {
+		ctx->contract_1e5 = value != 0;
+		ctx->ct_key = 0; ctx->ct_key_share = 0.0; ctx->ct_hopeless_calls = 0;     // the "hopeless lobe" verdict does not outlive a toggle
+		return DJB_OK;
+	}
 	if (option == DJB_OPT_TEST_WORKLIST_CAP) { ctx->test_worklist_cap = value; return DJB_OK; }
 	return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown option %d", option);
 }

@@ -55,6 +55,7 @@ struct djb_ctx {
 	size_t wl_last_cap = 0; long long wl_last_n = 0; bool wl_pending = false; int wl_words = 1;
 	double wl_last_share = 0.0;            // tier-2 pairs / pairs of the last large two-tier call
 	unsigned long long wl_note_key = 0, ct_key = 0; double ct_key_share = 0.0;   // contract mode: (lobe, params) of that call and its share
+	unsigned int ct_hopeless_calls = 0;        // calls answered by the exact kernel because of ct_key_share: every 16th re-probes
 	long long test_worklist_cap = -1;   // DJB_OPT_TEST_WORKLIST_CAP (tests): >= 0 overrides the tier-2 worklist capacity
 	int contract_1e5 = 0;      // DJB_OPT_CONTRACT_1E5: dense GGX eval batches run the two-tier value-contract kernels
 	int scalar_on_device = 0;  // DJB_OPT_SCALAR_ON_DEVICE: scalar-size host calls go through the GPU too (A/B testing)

@@ -217,16 +217,19 @@ void wl_adapt(djb_ctx *ctx)
 		ctx->wl_frac = std::min(0.25, std::max(need, 2.0 * ctx->wl_frac));
 	}
 }
-void wl_note(djb_ctx *ctx, const unsigned int *count, size_t cap, long long n, int words = 1, int stride = 1)
+// true iff THIS call's counters are the ones in flight (a small call, or a note still pending from another call, is not recorded)
+bool wl_note(djb_ctx *ctx, const unsigned int *count, size_t cap, long long n, int words = 1, int stride = 1)
 {
-	if (n < (1LL << 20) || ctx->wl_pending) return;
-	if (!ctx->wl_ev && hipEventCreateWithFlags(&ctx->wl_ev, hipEventDisableTiming) != hipSuccess) { ctx->wl_ev = nullptr; return; }
-	if (!ctx->wl_host && hipHostMalloc((void **)&ctx->wl_host, sizeof(unsigned int) * djbk::CONTRACT_SHARDS) != hipSuccess) { ctx->wl_host = nullptr; return; }
+	if (n < (1LL << 20) || ctx->wl_pending) return false;
+	if (!ctx->wl_ev && hipEventCreateWithFlags(&ctx->wl_ev, hipEventDisableTiming) != hipSuccess) { ctx->wl_ev = nullptr; return false; }
+	if (!ctx->wl_host && hipHostMalloc((void **)&ctx->wl_host, sizeof(unsigned int) * djbk::CONTRACT_SHARDS) != hipSuccess) { ctx->wl_host = nullptr; return false; }
 	// `words` counters, `stride` words apart -> packed into the pinned block (one strided 2-D copy)
 	if (hipMemcpy2DAsync(ctx->wl_host, sizeof(unsigned int), count, sizeof(unsigned int) * stride, sizeof(unsigned int), (size_t)words,
-	                     hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return;
-	if (hipEventRecord(ctx->wl_ev, ctx->stream) != hipSuccess) return;
+	                     hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+	if (hipEventRecord(ctx->wl_ev, ctx->stream) != hipSuccess) return false;
 	ctx->wl_last_cap = cap; ctx->wl_last_n = n; ctx->wl_words = words; ctx->wl_pending = true;
+	ctx->wl_note_key = 0;            // a key is attached by the contract path only, and only to its own note
+	return true;
 }
 
 djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec3_view *i,
@@ -335,7 +338,12 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	unsigned long long ct_key = 0;
 	{ unsigned int w[4]; float f4[4] = { p.ax, p.ay, p.rho, (float)b->dev.kind }; memcpy(w, f4, 16); ct_key = ((unsigned long long)(w[0] ^ (w[2] * 2654435761u)) << 32) | (w[1] ^ (w[3] * 40503u)); }
 	wl_adapt(ctx);
-	const bool ct_hopeless = ctx->ct_key == ct_key && ctx->ct_key_share > 0.30;
+	// The verdict is re-examined: every CT_REPROBE-th call with the hopeless key runs the contract kernels again (the direction
+	// distribution may have changed), and toggling DJB_OPT_CONTRACT_1E5 forgets it (djb_ctx_set_option).  Under the option the
+	// returned BITS may therefore depend on the call history; the values stay within the contract either way.
+	constexpr unsigned int CT_REPROBE = 16;
+	bool ct_hopeless = ctx->ct_key == ct_key && ctx->ct_key_share > 0.30;
+	if (ct_hopeless && ctx->contract_1e5 && ++ctx->ct_hopeless_calls % CT_REPROBE == 0) ct_hopeless = false;
 	const double *model_host = b->model_host.empty() ? nullptr : b->model_host.data();
 	if (ctx->contract_1e5 && !aliased && !ct_hopeless && djbk::contract_supported(b->dev, p, model_host)) {
 		auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
@@ -365,8 +373,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 				auto off = [&](const View &v) { return View{ v.x ? v.x + lo : nullptr, v.y ? v.y + lo : nullptr, v.z ? v.z + lo : nullptr, v.stride }; };
 				HIP_TRY(djbk::launch_eval_contract(ctx->stream, b->dev, p, model_host, m, off(vi), off(vo), off(vout), dpdf ? dpdf + lo : nullptr, want,
 				                                   list, (unsigned int)cap, count));
-				wl_note(ctx, count, cap, m, (int)djbk::CONTRACT_SHARDS, (int)djbk::CONTRACT_COUNTER_STRIDE);
-				if (ctx->wl_pending) ctx->wl_note_key = ct_key;
+				if (wl_note(ctx, count, cap, m, (int)djbk::CONTRACT_SHARDS, (int)djbk::CONTRACT_COUNTER_STRIDE)) ctx->wl_note_key = ct_key;
 			}
 			return sg.finish();
 		}

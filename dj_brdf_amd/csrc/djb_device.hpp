@@ -112,6 +112,10 @@ DJB_DEV double D(float x) { return (double)x; }
 DJB_DEV float fmin_(float a, float b) { return a < b ? a : b; }   // djb::min, dj_brdf.h:574
 DJB_DEV float fmax_(float a, float b) { return a > b ? a : b; }   // djb::max, dj_brdf.h:575
 DJB_DEV float sat_(float x) { return fmin_(1.0f, fmax_(0.0f, x)); }
+// the same templates on doubles: NOT IEEE fmin / fmax -- djb::max(a, NaN) is NaN (the comparison is false and b is returned), which is
+// how a NaN acos (an un-normalised direction with z > 1 in sgd::g1) or a NaN LEAN record reaches the reference's result
+DJB_DEV double dmin_(double a, double b) { return a < b ? a : b; }
+DJB_DEV double dmax_(double a, double b) { return a > b ? a : b; }
 
 // ------------------------------------------------------------------ float -> float sites of the fp64 trig family
 // Every place where the path rounds a double libm trig result of ONE float argument straight to float goes through

@@ -333,16 +333,22 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	}
 	// contract mode pays while tier 2 is a small share of the batch.  A narrow Beckmann lobe sends most pairs there (the
 	// denormal tail of exp(-r^2): 73 % at alpha = 0.05 on the bench distribution) and would cost tier 1 ON TOP of the exact
-	// evaluation: if the last large contract call with the same lobe and parameters listed more than 30 % of its pairs, the
+	// evaluation: if the last large contract call with the same lobe and parameters listed more than 15-20 % of its pairs, the
 	// call goes to the bit-exact kernel directly (which satisfies the contract trivially)
 	unsigned long long ct_key = 0;
-	{ unsigned int w[4]; float f4[4] = { p.ax, p.ay, p.rho, (float)b->dev.kind }; memcpy(w, f4, 16); ct_key = ((unsigned long long)(w[0] ^ (w[2] * 2654435761u)) << 32) | (w[1] ^ (w[3] * 40503u)); }
+	{ unsigned int w[4]; float f4[4] = { p.ax, p.ay, p.rho, (float)b->dev.kind }; memcpy(w, f4, 16); ct_key = ((unsigned long long)(w[0] ^ (w[2] * 2654435761u)) << 32) | (w[1] ^ (w[3] * 40503u));
+	  // model lobes (sgd / abc) take no params: the object is the key (each material has its own wall)
+	  if (b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_ABC) ct_key ^= (unsigned long long)(uintptr_t)b * 0x9E3779B97F4A7C15ull;
+	  if (!ct_key) ct_key = 1; }
 	wl_adapt(ctx);
 	// The verdict is re-examined: every CT_REPROBE-th call with the hopeless key runs the contract kernels again (the direction
 	// distribution may have changed), and toggling DJB_OPT_CONTRACT_1E5 forgets it (djb_ctx_set_option).  Under the option the
 	// returned BITS may therefore depend on the call history; the values stay within the contract either way.
 	constexpr unsigned int CT_REPROBE = 16;
-	bool ct_hopeless = ctx->ct_key == ct_key && ctx->ct_key_share > 0.30;
+	// thresholds: below the worklist's 25 % capacity limit (a list that overflows makes tier 2 redo the whole batch ON TOP of
+	// tier 1); sgd's tier 1 is the most expensive of the set (0.9 ms against 5 ms per 1e8), its break-even is lower
+	const double ct_give_up = b->dev.kind == DJB_KIND_SGD ? 0.15 : 0.20;
+	bool ct_hopeless = ctx->ct_key == ct_key && ctx->ct_key_share > ct_give_up;
 	if (ct_hopeless && ctx->contract_1e5 && ++ctx->ct_hopeless_calls % CT_REPROBE == 0) ct_hopeless = false;
 	const double *model_host = b->model_host.empty() ? nullptr : b->model_host.data();
 	if (ctx->contract_1e5 && !aliased && !ct_hopeless && djbk::contract_supported(b->dev, p, model_host)) {
@@ -648,12 +654,13 @@ DJB_ABI_CATCH
 djb_status djb_lrep_to_params(const float *l, djb_params *out)                           // :1976-1990
 try {
 	if (!l || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	// djb::max(a, b) = a > b ? a : b and djb::min(a, b) = a < b ? a : b with the reference's operand order: a NaN moment stays NaN
 	float t1 = l[2] - l[0] * l[0], t2 = l[3] - l[1] * l[1];
-	t1 = t1 > 0.0f ? t1 : 0.0f; t2 = t2 > 0.0f ? t2 : 0.0f;
+	t1 = 0.0f > t1 ? 0.0f : t1; t2 = 0.0f > t2 ? 0.0f : t2;
 	double sx = std::sqrt(2.0 * (double)t1), sy = std::sqrt(2.0 * (double)t2);
-	float ax = (float)(sx > 1e-5 ? sx : 1e-5), ay = (float)(sy > 1e-5 ? sy : 1e-5);
+	float ax = (float)(1e-5 > sx ? 1e-5 : sx), ay = (float)(1e-5 > sy ? 1e-5 : sy);
 	float rho = 2.0f * (l[4] - l[0] * l[1]) / (ax * ay);
-	rho = rho > -0.99f ? rho : -0.99f; rho = rho < 0.99f ? rho : 0.99f;
+	rho = -0.99f > rho ? -0.99f : rho; rho = 0.99f < rho ? 0.99f : rho;
 	out->kind = DJB_PARAMS_PDFPARAMS;
 	out->v[0] = ax; out->v[1] = ay; out->v[2] = rho; out->v[3] = l[0]; out->v[4] = l[1];
 	return DJB_OK;

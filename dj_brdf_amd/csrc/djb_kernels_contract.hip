@@ -55,11 +55,18 @@ struct CtParams {
 	float t2;                          // ax * ay * s as the reference rounds it (the divisor of mf_p22)
 	double R_ax, R_t2;                 // 1 / ax and 1 / t2 to within 2^-52: fdiv_r's exact divisions (Beckmann)
 	float f0[3], f1[3];                // schlick: f0 and 1 - f0
+	float n2m1[3];                     // unpolarized: ior^2 - 1 per channel (ior >= CT_IOR_MIN)
 	int shadow;
 	// abc (model row kD[3] A[3] B C ior, dj_brdf.h:3608-3668)
 	float kd_pi[3];                    // kD / pi as the reference rounds it: float(kD) * (1.0f / float(pi))
 	float A[3], ior;
 	double B, C;
+	// sgd (model row rhoD rhoS alpha p f0 f1 kap lambda c k theta0, 3 doubles each; dj_brdf.h:3415-3500)
+	float kd[3], ks[3], sf0[3], sf1[3], s1mf0[3];      // rhoD, rhoS, Fresnel f0, f1, 1 - f0 as floats (the reference's vec3::from_raw)
+	double alpha[3], inv_alpha[3];
+	float p_[3], lkap[3];                              // NDF exponent; log2(kap / pi)
+	float lam[3], l2c[3], kk[3], th0_hi[3], th0_lo[3]; // g1: lambda, log2(c), k, theta0 = hi + lo
+	float x_max[3], x_zero[3];                         // g1: tier-1 range of x = c t1^k (ct_params_sgd)
 };
 
 // exp(y) for y <= 0 with the argument split y log2(e) = hi + lo, so that the result keeps ~2 ulp for |y| up to 80 (a plain
@@ -71,6 +78,38 @@ DJB_DEV float ct_exp_neg(float y)
 	const float lo = __builtin_fmaf(y, L, -hi) + y * L_LO;
 	const float e = __builtin_amdgcn_exp2f(hi);
 	return __builtin_fmaf(e, lo * 0.693147182f, e);
+}
+
+// fresnel::unpolarized (dj_brdf.h:1292-1303) for one channel, c = cos(theta_d) in [0, 1], n2m1 = ior^2 - 1 > 0:
+//   g = sqrt(n^2 + c^2 - 1);  F = 1/2 ((g - c) / (g + c))^2 (1 + ((c (g + c) - 1) / (c (g - c) + 1))^2).
+// The reference forms g - c as a float difference; here g - c = (n^2 - 1) / (g + c), the same number without the
+// cancellation.  The reference's own rounding noise in g - c is u g / (g - c) relative -- 21 u at ior = 1.05 (c = 1), doubled by
+// the square: 3e-6 -- which is why CT_IOR_MIN = 1.05: below it the reference's float chain is itself noisier than the
+// contract and only the bit-exact kernel can follow it.  c (g + c) - 1 changes sign near Brewster's angle, but it enters
+// through 1 + (.)^2, which is insensitive there.  Cost: one rsq and two rcp per channel.
+constexpr float CT_IOR_MIN = 1.05f, CT_IOR_MAX = 1e3f;
+DJB_DEV float ct_unpolarized(float c, float n2m1)
+{
+	const float g2 = n2m1 + c * c;
+	const float g = g2 * rsq_(g2);
+	const float gp = g + c, gm = n2m1 * rcp_(gp);
+	const float t1 = c * gp - 1.0f, t2 = c * gm + 1.0f;
+	const float q3 = t1 * rcp_(t2), q4 = gm * rcp_(gp);
+	return (0.5f * (q4 * q4)) * (1.0f + q3 * q3);
+}
+// F(cos theta_d) * e for the Fresnel kinds of the contract set; cd is clamped to [0, 1] as microfacet::eval does (dj_brdf.h:1545)
+template <int FRK>
+DJB_DEV v3 ct_fresnel_times(const CtParams &c, float oh, float e)
+{
+	if (FRK == FR_SCHLICK) {                                   // fresnel::schlick, dj_brdf.h:1322-1328
+		const float cd = sat_(oh), c1 = 1.0f - cd, c2_ = c1 * c1, c5 = c2_ * c2_ * c1;
+		return mk(e * (c.f0[0] + c5 * c.f1[0]), e * (c.f0[1] + c5 * c.f1[1]), e * (c.f0[2] + c5 * c.f1[2]));
+	}
+	if (FRK == FR_UNPOLARIZED) {
+		const float cd = sat_(oh);
+		return mk(e * ct_unpolarized(cd, c.n2m1[0]), e * ct_unpolarized(cd, c.n2m1[1]), e * ct_unpolarized(cd, c.n2m1[2]));
+	}
+	return mk(e, e, e);
 }
 
 // stretched-space norm and sigma of direction k (microfacet::sigma, dj_brdf.h:1619-1631; ggx::sigma_std_radial :2062,
@@ -131,10 +170,7 @@ DJB_DEV bool ct_eval_beckmann(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 		ok &= ((e < 1e30f) & (e > 1e-24f)) | !on;             // the exponential tail towards the denormals: tier 2 (the relative
 		                                                       // contract has no meaning there; zeros must match exactly)
 		e = on ? e : 0.0f;
-		if (FRK == FR_SCHLICK) {
-			float cd = sat_(oh), c1 = 1.0f - cd, c2_ = c1 * c1, c5 = c2_ * c2_ * c1;
-			fr = mk(e * (c.f0[0] + c5 * c.f1[0]), e * (c.f0[1] + c5 * c.f1[1]), e * (c.f0[2] + c5 * c.f1[2]));
-		} else fr = mk(e, e, e);
+		fr = ct_fresnel_times<FRK>(c, oh, e);
 	}
 	if (WANT & 4) {
 		const float ih = dot(i, h);
@@ -194,12 +230,103 @@ DJB_DEV bool ct_eval_abc(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 	return ok | !live;
 }
 
+// ---- SGD (sgd::eval, dj_brdf.h:3454-3468: (Kd + Ks F D G / (i.z o.z)) / pi per channel; 9 pow + 9 exp + 2 acos in fp64 per pair
+// in the bit-exact kernel, every one of them glibc's algorithm).  Tier 1:
+//   h            the reference's own float (exact normalize, as for ABC): c = sat(dot(i, h)) and h.z are its operands.
+//   F            f0 - c f1 + (1 - c)^5 (1 - f0) in float (the power by three products, 4 u); the sum can cancel when f1 is
+//                large: |F| < 0.05 (|f0| + |c f1| + |...|) -> tier 2.
+//   D            kap e^-ax / (pi ax^p hz^4), ax = alpha + (1 - hz^2) / (hz^2 alpha): alpha goes down to 1.6e-5, so ax reaches the
+//                hundreds before e^-ax underflows and an ulp32 of ax would move D by ax 2^-24.  ax is therefore formed in fp64
+//                (one division), and e^-ax / ax^p is ONE v_exp_f32 of the fp64 exponent -ax log2(e) - p log2(ax) split into
+//                integer + fraction (log2 of the mantissa by v_log_f32: |p| <= 4 keeps its 6e-8 below 2.4e-7).  Where e^-ax has
+//                underflowed the specular term vanishes against Kd > 0 and the pair stays in tier 1.
+//   G = g1 g1    g1 = clamp(1 - w), w = lambda expm1(x), x = c t1^k, t1 = max(0, acos(k.z) - theta0): a WALL -- k reaches 856, c
+//                1e38, lambda 1.5e7 in the published rows.  Tier 1 evaluates it with a float acos (A&S 4.4.46, |err| <= SGD_DT
+//                with the float roundings) and v_log / v_exp; the error this makes in g1 is
+//                    dg1 = lambda e^x x (dx / x),     dx / x <= R = k (SGD_DT / t1 + 1.2e-7 |ln t1|) + 4e-7
+//                with R bounded per channel over the t1 that matter (ct_params_sgd), so "dg1 <= 1.5e-6 g1" is a threshold on x
+//                alone: x <= x_max (the plateau and the foot of the wall) -> tier 1; x >= x_zero (beyond the wall, g1 = 0 with
+//                certainty) -> tier 1; in between -- ON the wall -- the fp64 acos / pow / exp of tier 2 answer.  Which share of
+//                the pairs that is depends on the material (profiles/r04/contract_sgd_materials.txt: 22 of the 100 published
+//                rows below 5 %, 40 below 10 % on the bench distribution); the host routes a material whose last large
+//                batch listed more than 15 % straight to the bit-exact kernel.
+constexpr double SGD_DT = 4e-7;        // |float acos - acos| bound, radians (A&S eps 2e-8 + Horner / sqrt roundings)
+
+DJB_DEV float ct_acos01(float x)      // Abramowitz & Stegun 4.4.46 on [0, 1]: sqrt(1 - x) P7(x)
+{
+	float p = -0.0012624911f;
+	p = p * x + 0.0066700901f; p = p * x - 0.0170881256f; p = p * x + 0.0308918810f;
+	p = p * x - 0.0501743046f; p = p * x + 0.0889789874f; p = p * x - 0.2145988016f; p = p * x + 1.5707963050f;
+	const float s = 1.0f - x;
+	return (s * rsq_(fmaxf(s, 1e-30f))) * p;
+}
+// g1 of one direction / channel.  x <= x_max <= 0.5: expm1 by its series (six terms: 3e-7 relative at 0.5); x >= x_zero: 0.
+DJB_DEV float ct_sgd_g1(float theta_k, float th0_hi, float th0_lo, float lam, float l2c, float kk, float x_max, float x_zero, bool &ok)
+{
+	const float d = (theta_k - th0_hi) - th0_lo;
+	const float t1 = fmaxf(d, 1e-30f);                          // d <= 0: the plateau (x underflows to 0, g1 = 1)
+	const float lx = l2c + kk * __builtin_amdgcn_logf(t1);
+	const float x = __builtin_amdgcn_exp2f(fminf(lx, 7.0f));
+	const float xs = fminf(x, 0.5f);
+	const float em1 = xs * (1.0f + xs * (0.5f + xs * (0.166666672f + xs * (0.0416666679f + xs * (0.00833333377f + xs * 0.00138888892f)))));
+	const float g1 = fmaxf(1.0f - lam * em1, 0.0f);
+	const bool beyond = x >= x_zero;
+	ok &= (x <= x_max) | beyond;
+	return beyond ? 0.0f : g1;
+}
+template <int WANT>
+DJB_DEV bool ct_eval_sgd(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
+{
+	const bool live = (i.z > 0.0f) & (o.z > 0.0f);            // dj_brdf.h:3456
+	fr = mk(0, 0, 0); pdf = 0.0f;
+	if (WANT & 4) pdf = i.z * 0.318309886f;                   // brdf::pdf = i.z / pi
+	bool ok = true;
+	if (WANT & 3) {
+		const v3 h = normalize(add(i, o));                    // exact
+		const float cd = sat_(dot(i, h));
+		ok &= (h.z > 1e-3f) & (i.z > 1e-6f) & (o.z > 1e-6f) & (i.z <= 1.0f) & (o.z <= 1.0f);
+		// Fresnel (fresnel::sgd, dj_brdf.h:1330-1336)
+		const float c1 = 1.0f - cd, c2_ = c1 * c1, c5 = c2_ * c2_ * c1;
+		// NDF: shared fp64 part
+		const double c2d = D(h.z) * D(h.z);
+		const double t2 = (1.0 - c2d) / c2d;
+		const float hz2 = h.z * h.z, rc4 = rcp_(hz2 * hz2);
+		const float th_i = ct_acos01(fminf(i.z, 1.0f)), th_o = ct_acos01(fminf(o.z, 1.0f));
+		const float riz = rcp_(i.z * o.z);
+		float e[3];
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch) {
+			const float t_f1 = cd * c.sf1[ch], t_p = c5 * c.s1mf0[ch];
+			const float Fr = (c.sf0[ch] - t_f1) + t_p;
+			ok &= fabsf(Fr) >= 0.05f * (fabsf(c.sf0[ch]) + fabsf(t_f1) + fabsf(t_p));
+			const double ax = __builtin_fma(t2, c.inv_alpha[ch], c.alpha[ch]);
+			const int ea = __builtin_amdgcn_frexp_exp(ax);
+			const float lm = __builtin_amdgcn_logf(F(__builtin_amdgcn_frexp_mant(ax)));
+			double y = __builtin_fma(-1.4426950408889634, ax, D(c.lkap[ch])) - D(c.p_[ch]) * (D(lm) + (double)ea);
+			ok &= (ax > 0.0) & (y < 100.0);                      // overflow side: tier 2; a NaN h.z fails the comparison too
+			y = __builtin_fmax(y, -200.0);                       // e^-ax underflowed: D = 0 against Kd >= SGD_KD_MIN (ct_params_sgd)
+			const double yn = __builtin_rint(y);
+			const float Dn = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(F(y - yn)), (int)yn) * rc4;
+			const float G = ct_sgd_g1(th_i, c.th0_hi[ch], c.th0_lo[ch], c.lam[ch], c.l2c[ch], c.kk[ch], c.x_max[ch], c.x_zero[ch], ok) *
+			                ct_sgd_g1(th_o, c.th0_hi[ch], c.th0_lo[ch], c.lam[ch], c.l2c[ch], c.kk[ch], c.x_max[ch], c.x_zero[ch], ok);
+			const float spec = (c.ks[ch] * ((Fr * Dn) * G)) * riz;
+			ok &= (spec >= 0.0f) & (spec < 1e30f);
+			e[ch] = (c.kd[ch] + spec) * 0.318309886f;
+		}
+		v3 v = live ? mk(e[0], e[1], e[2]) : mk(0, 0, 0);
+		if (WANT & 2) v = scale(i.z, v);
+		fr = v;
+	}
+	return ok | !live;
+}
+
 // one pair; false = tier 2.  fr / pdf follow eval_one's WANT convention (1 eval, 2 evalp, 4 pdf)
 template <int KIND, int WANT, int FRK>
 DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 {
-	static_assert(KIND == KIND_GGX || KIND == KIND_BECKMANN || KIND == KIND_ABC, "contract mode: GGX, Beckmann and ABC");
+	static_assert(KIND == KIND_GGX || KIND == KIND_BECKMANN || KIND == KIND_ABC || KIND == KIND_SGD, "contract mode: GGX, Beckmann, ABC and SGD");
 	if (KIND == KIND_ABC) return ct_eval_abc<WANT>(c, i, o, fr, pdf);
+	if (KIND == KIND_SGD) return ct_eval_sgd<WANT>(c, i, o, fr, pdf);
 	if (KIND == KIND_BECKMANN) return ct_eval_beckmann<WANT, FRK>(c, i, o, fr, pdf);
 	// g1(k) > 0 <=> dot(k, m_n) = k.z > 0 (dj_brdf.h:1633-1642); gaf > 0 <=> both (shadow) / g1(o) (dj_brdf.h:1644-1665)
 	// -- decided on the inputs themselves, NaN included: the reference's comparisons are false for NaN and return zeros.
@@ -233,10 +360,7 @@ DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 		if (WANT & 2) e *= i.z;                                // evalp
 		ok &= (e < 1e30f);
 		e = live ? e : 0.0f;
-		if (FRK == FR_SCHLICK) {                               // fresnel::schlick, dj_brdf.h:1322-1328
-			float cd = sat_(oh), c1 = 1.0f - cd, c2_ = c1 * c1, c5 = c2_ * c2_ * c1;
-			fr = mk(e * (c.f0[0] + c5 * c.f1[0]), e * (c.f0[1] + c5 * c.f1[1]), e * (c.f0[2] + c5 * c.f1[2]));
-		} else fr = mk(e, e, e);
+		fr = ct_fresnel_times<FRK>(c, oh, e);
 	}
 	if (WANT & 4) {
 		float ih = r * dot(i, s);
@@ -314,6 +438,16 @@ __global__ __launch_bounds__(BLOCK) void k_ct_fixup(Brdf b, Params p, long long 
 {
 	__shared__ unsigned int s_counts[CT_SHARDS];
 	__shared__ int s_over;
+	// the fp64 exp / pow / acos of glibc that eval_one<SGD | ABC | BECKMANN> calls: tables to LDS, as in k_eval (sgd's tier 2 can
+	// be a large share of the batch: the wall of its shadowing term)
+	constexpr bool EXPT = KIND == KIND_BECKMANN || KIND == KIND_SGD || KIND == KIND_ABC, POWT = KIND == KIND_SGD || KIND == KIND_ABC,
+	               ACOST = KIND == KIND_SGD;
+	__shared__ unsigned long long s_exp[EXPT ? 256 : 1];
+	__shared__ double s_pow[POWT ? 384 : 1];
+	__shared__ double s_acos[ACOST ? 2568 + 128 : 1];
+	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
+	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BLOCK);
 	if (threadIdx.x == 0) s_over = 0;
 	__syncthreads();
 	if (threadIdx.x < CT_SHARDS) { const unsigned int cnt = counts[(size_t)threadIdx.x * CT_STRIDE]; s_counts[threadIdx.x] = cnt; if (cnt > cap) s_over = 1; }
@@ -405,6 +539,55 @@ bool ct_params_abc(const Brdf &b, const double *m, CtParams *c)
 	return true;
 }
 
+// sgd: the published rows and anything like them (constructor's fresnel::sgd(f0, f1), positive alpha / kap / lambda / c, k >= 1,
+// a diffuse term that is not negligible: where e^-ax underflows tier 1 returns Kd / pi, which needs Kd to dominate).
+// Per channel the error bound of g1 (header of ct_eval_sgd) is turned into two thresholds on x = c t1^k:
+//   t_neg  the t1 below which w = lambda expm1(x) < 1e-8 whatever the relative error of x (as long as it is below 1);
+//   R      the bound of dx / x for t1 in [t_neg, pi/2 - theta0];
+//   x_max  the largest x <= 0.5 with lambda e^x x R <= 1.5e-6 (1 - w);   x_zero: the smallest x with w - 1 >= 4 lambda e^x x R + 1e-6.
+constexpr double SGD_KD_MIN = 1e-4;
+bool ct_params_sgd(const Brdf &b, const double *m, CtParams *c)
+{
+	if (!m || b.fr.kind != FR_SGD) return false;
+	*c = CtParams{};
+	for (int k = 0; k < 3; ++k) {
+		const double rd = m[k], rs = m[3 + k], al = m[6 + k], pp = m[9 + k], f0 = m[12 + k], f1 = m[15 + k], kap = m[18 + k],
+		             lam = m[21 + k], cc = m[24 + k], kk = m[27 + k], th0 = m[30 + k];
+		if ((float)f0 != b.fr.a[k] || (float)f1 != b.fr.b[k]) return false;          // a replaced Fresnel term: exact kernels
+		if (!(rd >= SGD_KD_MIN && rd < 1e6) || !(rs >= 0.0 && rs < 1e6)) return false;
+		if (!(al >= 1e-6 && al <= 10.0) || !(pp >= 0.0 && pp <= 4.0) || !(kap > 1e-6 && kap < 1e8)) return false;
+		if (!(lam > 1e-12 && lam < 1e9) || !(cc > 1e-30 && cc < 1e39) || !(kk >= 2.0 && kk <= 2000.0) || !(th0 > -1.5 && th0 < 1.5)) return false;
+		if (!(std::fabs(f0) < 1e3) || !(std::fabs(f1) < 1e3)) return false;
+		c->kd[k] = (float)rd; c->ks[k] = (float)rs;
+		c->sf0[k] = (float)f0; c->sf1[k] = (float)f1; c->s1mf0[k] = 1.0f - (float)f0;
+		c->alpha[k] = al; c->inv_alpha[k] = 1.0 / al;
+		c->p_[k] = (float)pp; c->lkap[k] = (float)std::log2(kap / DJB_PI);
+		c->lam[k] = (float)lam; c->l2c[k] = (float)std::log2(cc); c->kk[k] = (float)kk;
+		c->th0_hi[k] = (float)th0; c->th0_lo[k] = (float)(th0 - (double)c->th0_hi[k]);
+		// the corner t1 = 0 sits inside the acos error: up to t1 = 2 SGD_DT the reference may be on either side; nothing may happen there
+		const double l2lam = std::log2(lam), l2c = std::log2(cc);
+		if (!(l2lam + l2c + kk * std::log2(2.0 * SGD_DT) + std::log2(1.0 + kk) < std::log2(3e-8))) return false;
+		const double t_hi = DJB_PI * 0.5 - th0 + 1e-3;
+		c->x_max[k] = 0.5f; c->x_zero[k] = 3.0e38f;
+		if (t_hi <= 4.0 * SGD_DT) continue;                                           // theta_k never exceeds theta0: all plateau
+		double t_neg = std::exp2((std::log2(1e-8) - l2lam - l2c) / kk);               // lambda c t^k = 1e-8
+		t_neg = std::min(std::max(t_neg, 4.0 * SGD_DT), t_hi);
+		const double Lmax = std::max(std::fabs(std::log(t_neg)), std::fabs(std::log(t_hi)));
+		const double R = kk * (SGD_DT / t_neg + 1.2e-7 * Lmax) + 4e-7;
+		if (!(R < 0.25)) return false;
+		auto w_of = [&](double x) { return lam * std::expm1(x); };
+		auto good = [&](double x) { const double w = w_of(x); return w < 1.0 && (w + lam) * x * R <= 1.5e-6 * (1.0 - w); };
+		double lo = 0.0, hi = 0.5;
+		if (good(hi)) lo = hi;
+		else for (int it = 0; it < 60; ++it) { const double mid = 0.5 * (lo + hi); if (good(mid)) lo = mid; else hi = mid; }
+		c->x_max[k] = (float)(lo * (1.0 - 1e-6));
+		auto dead = [&](double x) { const double w = w_of(x); return w - 1.0 >= 4.0 * (w + lam) * x * R + 1e-6; };
+		lo = 0.0; hi = 100.0;
+		if (dead(hi)) { for (int it = 0; it < 80; ++it) { const double mid = 0.5 * (lo + hi); if (dead(mid)) hi = mid; else lo = mid; } c->x_zero[k] = (float)(hi * (1.0 + 1e-6)); }
+	}
+	return true;
+}
+
 bool ct_params_any(const Brdf &b, const Params &p, const double *model_host, CtParams *c);
 
 bool ct_params(const Brdf &b, const Params &p, CtParams *c)
@@ -420,8 +603,13 @@ bool ct_params(const Brdf &b, const Params &p, CtParams *c)
 	c->t2 = p.ax * p.ay * p.s;
 	c->R_ax = p.r_ax; c->R_t2 = p.r_t2;
 	c->shadow = b.shadow;
-	for (int k = 0; k < 3; ++k) { c->f0[k] = 1.0f; c->f1[k] = 0.0f; }
-	if (b.fr.kind == FR_SCHLICK) {
+	for (int k = 0; k < 3; ++k) { c->f0[k] = 1.0f; c->f1[k] = 0.0f; c->n2m1[k] = 1.25f; }
+	if (b.fr.kind == FR_UNPOLARIZED) {
+		for (int k = 0; k < 3; ++k) {
+			if (!(b.fr.a[k] >= CT_IOR_MIN && b.fr.a[k] <= CT_IOR_MAX)) return false;      // ct_unpolarized: the reference's own noise below 1.05
+			c->n2m1[k] = (float)((double)b.fr.a[k] * (double)b.fr.a[k] - 1.0);
+		}
+	} else if (b.fr.kind == FR_SCHLICK) {
 		for (int k = 0; k < 3; ++k) {
 			// below f0 = 0.01 the term f0 + (1 - f0)(1 - c)^5 is ill-conditioned in c near 1 (header): exact kernels
 			if (!(b.fr.a[k] >= 0.01f && b.fr.a[k] <= 1.0f)) return false;
@@ -434,6 +622,7 @@ bool ct_params(const Brdf &b, const Params &p, CtParams *c)
 bool ct_params_any(const Brdf &b, const Params &p, const double *model_host, CtParams *c)
 {
 	if (b.kind == KIND_ABC) return ct_params_abc(b, model_host, c);
+	if (b.kind == KIND_SGD) return ct_params_sgd(b, model_host, c);
 	return (b.kind == KIND_GGX || b.kind == KIND_BECKMANN) && ct_params(b, p, c);
 }
 
@@ -489,11 +678,16 @@ hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, c
 		if (e != hipSuccess) return e;
 	}
 	if (b.kind == KIND_ABC) return launch_ct<KIND_ABC, -1>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+	if (b.kind == KIND_SGD) return launch_ct<KIND_SGD, -1>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+	// the pdf has no Fresnel term: one instantiation serves every kind
+	const int frk = want == 4 ? FR_IDEAL : b.fr.kind;
 	if (b.kind == KIND_BECKMANN) {
-		if (b.fr.kind == FR_SCHLICK) return launch_ct<KIND_BECKMANN, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+		if (frk == FR_SCHLICK) return launch_ct<KIND_BECKMANN, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+		if (frk == FR_UNPOLARIZED) return launch_ct<KIND_BECKMANN, FR_UNPOLARIZED>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 		return launch_ct<KIND_BECKMANN, FR_IDEAL>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 	}
-	if (b.fr.kind == FR_SCHLICK) return launch_ct<KIND_GGX, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+	if (frk == FR_SCHLICK) return launch_ct<KIND_GGX, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
+	if (frk == FR_UNPOLARIZED) return launch_ct<KIND_GGX, FR_UNPOLARIZED>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 	return launch_ct<KIND_GGX, FR_IDEAL>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 }
 
@@ -504,10 +698,13 @@ hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &
 	if (!ct_params_any(b, p, model_host, &c)) return hipErrorInvalidValue;
 	const dim3 g(grid_for(n, 256LL * 16)), t(BLOCK);
 	if (b.kind == KIND_ABC) hipLaunchKernelGGL((k_ct_selftest<KIND_ABC, -1>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+	else if (b.kind == KIND_SGD) hipLaunchKernelGGL((k_ct_selftest<KIND_SGD, -1>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 	else if (b.kind == KIND_BECKMANN) {
 		if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+		else if (b.fr.kind == FR_UNPOLARIZED) hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_UNPOLARIZED>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 		else hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_IDEAL>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
-	} else if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+	} else if (b.fr.kind == FR_UNPOLARIZED) hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_UNPOLARIZED>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
+	else if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 	else hipLaunchKernelGGL((k_ct_selftest<KIND_GGX, FR_IDEAL>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 	return hipGetLastError();
 }

@@ -109,9 +109,12 @@ def default_context(device=0) -> Context:
     """The default context of `device`: process-wide for "cpu", PER THREAD for a GPU.  A GPU context created without an
     explicit stream follows torch's current stream, which is a per-thread notion: `set stream, then launch` on a context
     shared by two threads that work under different torch streams could interleave (thread A's kernels on thread B's
-    stream).  Per-thread defaults rule that out; a Context object that is handed to several threads explicitly must either
-    pin its stream (Context(device, stream=...)) or be used under one torch stream.  Objects may be used with any context
-    of their device."""
+    stream).  Per-thread defaults keep threads that each BUILD their own objects apart.  What they do not do: a BRDF object
+    remembers the context it was built with (`obj.ctx`) and its methods launch on that one, so an object created on
+    thread A and called from thread B still drives A's default context and follows whatever torch stream the CALLING
+    thread has current.  Sharing objects across threads that use different torch streams therefore needs either a pinned
+    stream (Context(device, stream=...), passed as ctx= at construction) or rebinding (`obj.ctx = default_context(dev)` on
+    the calling thread -- handles may be used with any context of their device, tests/test_gpu_scalar_path.py)."""
     if device in ("cpu", -1):
         if "cpu" not in _default_cpu_ctx:
             _default_cpu_ctx["cpu"] = Context("cpu")

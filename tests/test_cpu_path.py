@@ -95,6 +95,14 @@ def test_merl_utia_lambert_models(cpu, oracle, dirs, tmp_path):
     for kind in ("sgd", "abc"):
         b, ob = getattr(djb, kind)("gold-metallic-paint", ctx=cpu), getattr(oracle, kind)("gold-metallic-paint")
         assert same(b.eval(i, o), oracle.eval(ob, i, o)), kind
+        # un-normalised directions: z > 1 makes sgd::g1's acos NaN, and djb::max(0.0, NaN) is NaN (not IEEE fmax's 0), so the
+        # reference returns NaN; below-horizon and NaN inputs for completeness
+        i3, o3 = (i * np.float32(3.0)).astype(np.float32), o.copy()
+        o3[::7, 2] *= -1; i3[::11] = np.nan
+        got, want = b.eval(i3, o3), oracle.eval(ob, i3, o3)
+        assert same(got, want), kind
+        if kind == "sgd":
+            assert np.isnan(want).any() and not np.isnan(want).all()
     h, d = djb.brdf.io_to_hd(i, o, ctx=cpu)
     wh, wd = oracle.io_to_hd(i, o)
     assert same(h, wh) and same(d, wd)
@@ -211,6 +219,11 @@ def test_lean_and_queries(cpu, oracle, dirs):
                                           filtering=filtering, biased=biased)
         ww, wi, wpdf, wpp = oracle.sample_lean(ob, u1, u2, o, LEAN_BASE, scale, tex, True, filtering=filtering, biased=biased)
         assert same(gpp, wpp) and same(gi, wi) and same(gw, ww) and same(gpdf, wpdf), (scale, filtering, biased)
+    # NaN moments stay NaN through lrep_to_params: djb::max(1e-5, NaN) = NaN and min(0.99, max(-0.99, NaN)) = NaN (dj_brdf.h:574-575)
+    bad = lean.copy(); bad[0::5, 2] = np.nan; bad[1::5, 4] = np.nan; bad[2::5, 0] = np.inf
+    got, gpp = djb._eval_lean(b, i, o, mk_params(LEAN_BASE), 0.7, bad, want="evalp", return_params=True)
+    want, wpp = oracle.eval_lean(ob, i, o, LEAN_BASE, 0.7, bad, "evalp")
+    assert same(gpp, wpp) and same(got, want) and np.isnan(wpp).any()
     pp = oracle.eval_lean(ob, i, o, LEAN_BASE, 0.7, lean, "pdf")[1]
     assert same(b.sample_pp(u1, u2, o, pp), oracle.sample_lean(ob, u1, u2, o, LEAN_BASE, 0.7, lean, False)[0])
     h = oracle.io_to_hd(i, o)[0]

@@ -61,6 +61,11 @@ WORKLOADS = {
     # the headline kernel on two other look-up distributions (the 0.40 of merl_eval is distribution dependent):
     "merl_eval_uniform_bins": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval>, (theta_h, theta_d, phi_d) bins uniform over the table"),
     "merl_eval_coherent": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval>, renderer-like batch (neighbouring pixels of a bumpy plane)"),
+    # kinds the round-4 contract mode reaches (no BASELINE config of their own): exact kernel and DJB_OPT_CONTRACT_1E5
+    "ggx_unpolarized_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf,unpolarized>"),
+    "ggx_unpolarized_eval_pdf_contract": (100_000_000, 40, "evals", "k_ct_fast_v4<GGX,eval+pdf,unpolarized> + k_ct_fixup (1e-5 value contract)"),
+    "sgd_eval": (100_000_000, 36, "evals", "k_eval<SGD,eval> (gold-metallic-paint)"),
+    "sgd_eval_contract": (100_000_000, 36, "evals", "k_ct_fast_v4<SGD,eval> + k_ct_fixup (gold-metallic-paint, 1e-5 value contract)"),
     "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample_bk<sample,rng>"),
     "utia_eval": (100_000_000, 36, "evals", "k_eval_utia_t1<eval> + k_eval_utia_fix<eval> (two-tier exact)"),
     "merl_fit": (100, None, "materials", "k_fit<MERL>"),
@@ -182,10 +187,30 @@ def make_step(name, n, djb, synth, ctx, torch):
             djb._lib.check(lib.djb_eval_batch(ctx._h, m._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
                                               None, C.byref(vout.view), C.c_int(0)))
         return step, (i, o, m, out, vi, vo, vout)
-    if name in ("ggx_eval_pdf", "ggx_eval_pdf_contract"):
+    if name in ("sgd_eval", "sgd_eval_contract"):
         i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
         o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
-        fr = djb.fresnel.ideal() if GGX_FRESNEL == "ideal" else djb.fresnel.schlick((1.0, 0.71, 0.29))
+        m = djb.sgd("gold-metallic-paint", ctx=ctx)
+        out = torch.empty((3, n), dtype=torch.float32, device=i.device)
+        lib, C = djb._lib.load(), ctypes
+        vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
+        contract = name.endswith("_contract")
+
+        def step():
+            if contract:
+                djb.set_contract_1e5(ctx, True)
+            try:
+                djb._lib.check(lib.djb_eval_batch(ctx._h, m._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                                  None, C.byref(vout.view), C.c_int(0)))
+            finally:
+                if contract:
+                    djb.set_contract_1e5(ctx, False)
+        return step, (i, o, m, None, out, vi, vo, vout)
+    if name in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "ggx_unpolarized_eval_pdf", "ggx_unpolarized_eval_pdf_contract"):
+        i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
+        o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
+        fr = djb.fresnel.unpolarized((1.5, 1.8, 2.4)) if "unpolarized" in name else \
+            djb.fresnel.ideal() if GGX_FRESNEL == "ideal" else djb.fresnel.schlick((1.0, 0.71, 0.29))
         g = djb.ggx(fr, True, ctx=ctx)
         p = djb.microfacet.params.isotropic(GGX_ALPHA)
         out = torch.empty((3, n), dtype=torch.float32, device=i.device)
@@ -268,8 +293,11 @@ def cpu_baseline(name, synth, budget_s=12.0):
         else:
             b = L.merl_from_table(synth.merl_table(0.3))
         op = "eval"
-    elif name in ("ggx_eval_pdf", "ggx_eval_pdf_contract"):
-        b, op, par = L.microfacet("ggx", ("ideal",) if GGX_FRESNEL == "ideal" else ("schlick", 1.0, 0.71, 0.29), True), "eval", ("elliptic", GGX_ALPHA, GGX_ALPHA, 0.0)
+    elif name in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "ggx_unpolarized_eval_pdf", "ggx_unpolarized_eval_pdf_contract"):
+        fres = ("unpolarized", 1.5, 1.8, 2.4) if "unpolarized" in name else ("ideal",) if GGX_FRESNEL == "ideal" else ("schlick", 1.0, 0.71, 0.29)
+        b, op, par = L.microfacet("ggx", fres, True), "eval", ("elliptic", GGX_ALPHA, GGX_ALPHA, 0.0)
+    elif name in ("sgd_eval", "sgd_eval_contract"):
+        b, op = L.sgd("gold-metallic-paint"), "eval"
     elif name == "beckmann_sample":
         b, op, par = L.microfacet("beckmann", ("ideal",), True), "sample", ("elliptic", 0.2, 0.5, 0.7)
     elif name == "utia_eval":
@@ -323,7 +351,7 @@ def cpu_baseline(name, synth, budget_s=12.0):
                 L.sample(b, u1[idx], u2[idx], o[idx], par)
             else:
                 L.eval(b, i[idx], o[idx], par, "eval")
-                if name == "ggx_eval_pdf":
+                if name.startswith("ggx_"):
                     L.eval(b, i[idx], o[idx], par, "pdf")
         ths = [threading.Thread(target=work, args=(c,)) for c in chunks]
         t0 = time.perf_counter()
@@ -506,6 +534,10 @@ def main():
                                 "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material, tables resident in HBM",
                                 "merl_fit_files": "files on local disk -> pread -> PCIe -> k_merl_convert -> "
                                                   "tabular(merl, 90) + both fits (end to end)",
+                                "ggx_unpolarized_eval_pdf": f"GGX isotropic alpha={args.alpha:g}, unpolarized Fresnel ior (1.5, 1.8, 2.4), eval+pdf fused",
+                                "ggx_unpolarized_eval_pdf_contract": f"GGX isotropic alpha={args.alpha:g}, unpolarized Fresnel ior (1.5, 1.8, 2.4), eval+pdf fused, DJB_OPT_CONTRACT_1E5",
+                                "sgd_eval": "sgd::eval, gold-metallic-paint (published row)",
+                                "sgd_eval_contract": "sgd::eval, gold-metallic-paint, DJB_OPT_CONTRACT_1E5",
                                 "ggx_eval_pdf_contract": f"GGX isotropic alpha={args.alpha:g}, {args.fresnel} Fresnel, eval+pdf fused, "
                                                          "DJB_OPT_CONTRACT_1E5 (values within 1e-5 relative of the reference, not bit-identical)",
                                 "merl_eval_uniform_bins": "MERL nearest-bin, look-ups uniform over all 90x90x180 bins",
@@ -525,7 +557,8 @@ def main():
             if not args.no_cpu_baseline:
                 fitfiles["cpu_baseline"] = cpu_baseline("merl_fit_files", synth)
             sec = {"merl_fit_files_100": fitfiles, "merl_fit_100": fit100}
-            for other in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "beckmann_sample", "utia_eval", "merl_eval_uniform_bins", "merl_eval_coherent"):
+            for other in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "ggx_unpolarized_eval_pdf", "ggx_unpolarized_eval_pdf_contract",
+                          "sgd_eval", "sgd_eval_contract", "beckmann_sample", "utia_eval", "merl_eval_uniform_bins", "merl_eval_coherent"):
                 on, ob, ou, _ = WORKLOADS[other]
                 if other.startswith("merl_eval_"):
                     on //= 4          # 2.5e8 pairs (9 GB of streams, far beyond every cache): same rate as 1e9, a quarter of the set-up time
@@ -540,7 +573,7 @@ def main():
                 sec[other] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms, "units_per_step": on,
                               "hbm_GBps": (on * ob / (ms * 1e-3) / 1e9) if ob else None,
                               "roofline_frac": (on * ob / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ob else None}
-                if other == "ggx_eval_pdf_contract":
+                if other.endswith("_contract"):
                     # measured accuracy of the fast path against the bit-exact per-pair code, same set-up, 2^28 generated pairs
                     acc = djb.selftest_contract(kp[2], kp[3], n=1 << 28, seed=3, family=0, ctx=ctx)
                     sec[other].update({"max_rel_err_eval": acc["max_rel_eval"], "max_rel_err_pdf": acc["max_rel_pdf"],

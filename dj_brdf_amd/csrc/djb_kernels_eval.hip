@@ -85,6 +85,11 @@ __global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Pa
 // appends the index of every pair with an azimuth that was not decided away from a float rounding boundary (8e-6 of
 // them) to a worklist; tier 2 re-evaluates those with utia_eval and overwrites the result.  If the list overflows,
 // tier 2 redoes the whole batch, so the result never depends on the capacity.
+//
+// Tried and dropped (round 4, profiles/r04/NOTES.md): a wave-cooperative record fetch -- eight neighbouring lanes load the
+// eight 16-byte chunks of one record, 8 lines per load instruction instead of 64, data to their owner lanes through LDS.
+// Bit-identical, but 4.0-4.2 ms per 1e8 against 2.83: the 16 bpermutes, 16 LDS writes and 12 LDS reads per pair-set cost
+// more than the line look-ups they save.
 template <int WANT, bool DENSE>
 __global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_eval_utia_t1(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
                                                                         unsigned int *list, unsigned int cap, unsigned int *count)

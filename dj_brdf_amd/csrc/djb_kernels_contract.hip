@@ -400,6 +400,7 @@ __global__ __launch_bounds__(BLOCK) void k_ct_fast_v4(CtParams c, long long n4, 
 		if (q < n4) {
 			float4 ax = nt_load4(ix4 + q), ay = nt_load4(iy4 + q), az = nt_load4(iz4 + q),
 			       bx = nt_load4(ox4 + q), by = nt_load4(oy4 + q), bz = nt_load4(oz4 + q);
+			nt_load_wait6(ax, ay, az, bx, by, bz);
 			ixs[0] = ax.x; ixs[1] = ax.y; ixs[2] = ax.z; ixs[3] = ax.w;
 			iys[0] = ay.x; iys[1] = ay.y; iys[2] = ay.z; iys[3] = ay.w;
 			izs[0] = az.x; izs[1] = az.y; izs[2] = az.z; izs[3] = az.w;

@@ -7,17 +7,62 @@ namespace djbdev {
 
 constexpr unsigned int WBUF = 128;   // per-wave LDS staging slots for worklist records (7 dwords each)
 
-// 16-byte non-temporal accesses for the streams that are touched exactly once
+// 16-byte accesses for the streams that are touched exactly once.  DJB_STREAM_LOAD_POLICY / DJB_STREAM_STORE_POLICY pick
+// the cache-policy bits (0 = nt through the compiler's builtin; 1 = sc1, 2 = sc0 sc1, 3 = sc0 sc1 nt, 4 = plain: inline asm):
+// what the streams leave behind in the XCD's L2 decides how much of it the table gathers keep (profiles/r04/merl_stream_policy.txt)
+#ifndef DJB_STREAM_LOAD_POLICY
+#define DJB_STREAM_LOAD_POLICY 0
+#endif
+#ifndef DJB_STREAM_STORE_POLICY
+#define DJB_STREAM_STORE_POLICY 0
+#endif
 typedef float nt_v4f __attribute__((ext_vector_type(4)));
+#if DJB_STREAM_LOAD_POLICY == 0
 DJB_DEV float4 nt_load4(const float4 *p)
 {
 	nt_v4f v = __builtin_nontemporal_load((const nt_v4f *)p);
 	return make_float4(v.x, v.y, v.z, v.w);
 }
+DJB_DEV void nt_load_wait6(float4 &, float4 &, float4 &, float4 &, float4 &, float4 &) {}
+#else
+DJB_DEV float4 nt_load4(const float4 *p)
+{
+	nt_v4f v;
+#if DJB_STREAM_LOAD_POLICY == 1
+	asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+#elif DJB_STREAM_LOAD_POLICY == 2
+	asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+#elif DJB_STREAM_LOAD_POLICY == 3
+	asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+#else
+	asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+#endif
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+// the compiler does not count loads issued from inline asm: wait for them here, with the six results as operands so
+// that no use can be scheduled ahead of the wait
+DJB_DEV void nt_load_wait6(float4 &a, float4 &b, float4 &c, float4 &d, float4 &e, float4 &f)
+{
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w),
+	             "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w) :: "memory");
+	asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w), "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w),
+	             "+v"(f.x), "+v"(f.y), "+v"(f.z), "+v"(f.w) :: "memory");
+}
+#endif
 DJB_DEV void nt_store4(float a, float b, float c, float d, float4 *p)
 {
 	nt_v4f v = { a, b, c, d };
+#if DJB_STREAM_STORE_POLICY == 0
 	__builtin_nontemporal_store(v, (nt_v4f *)p);
+#elif DJB_STREAM_STORE_POLICY == 1
+	asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#elif DJB_STREAM_STORE_POLICY == 2
+	asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#elif DJB_STREAM_STORE_POLICY == 3
+	asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#else
+	asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#endif
 }
 
 // ---- per-wave worklist staging.  Ambiguous pairs are staged per wave in LDS (no barrier needed: one

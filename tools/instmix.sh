@@ -2,7 +2,8 @@
 # instruction mix of the dominant kernel of a workload (run on the GPU box): tools/instmix.sh <workload>
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
-w=$1; O=$R/gpurun_out/mix/$w; rm -rf $O; mkdir -p $O
+# optional second argument: a tag for the output directory (a DJB_LIB_PATH variant of the library measured next to the shipped one)
+w=$1; O=$R/gpurun_out/mix/$w$2; rm -rf $O; mkdir -p $O
 A="--workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/a -- python bench.py $A >/dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $O/b -- python bench.py $A >/dev/null 2>&1

@@ -377,6 +377,70 @@ def cpu_baseline(name, synth, budget_s=12.0):
             "single_thread": r1, "scaling_probe": {str(k): v for k, v in probe.items()}}
 
 
+def rank_placement(torch, dist, rank, local, world, pin):
+    """Where this rank runs: device id, PCI bus id, the GPU's NUMA node and the CPUs the rank's host threads (the file
+    pipeline's reader pool above all) may use.  With more than one rank per node (pin=True) each rank is confined to its
+    share of the CPUs of its GPU's NUMA node -- ranks whose GPUs hang off the same node split that node's CPUs between
+    them -- and DJB_READER_THREADS defaults to that share (at most 32: profiles/r03/fit_files_rates.txt), so that eight
+    ranks do not each start a 32-thread pool on the same cores.  Returns the list of every rank's record (rank order)."""
+    info = {"rank": rank, "local_rank": local, "device": local, "pci_bus_id": None, "numa_node": None}
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        info["name"] = pr.name
+        info["pci_bus_id"] = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open(f"/sys/bus/pci/devices/{info['pci_bus_id']}/numa_node") as f:
+            info["numa_node"] = int(f.read().strip())
+    except Exception:
+        pass
+    allowed = sorted(os.sched_getaffinity(0))
+    node_cpus = allowed
+    if info["numa_node"] is not None and info["numa_node"] >= 0:
+        try:
+            cl = open(f"/sys/devices/system/node/node{info['numa_node']}/cpulist").read().strip()
+            cpus = set()
+            for part in cl.split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+            node_cpus = [c for c in allowed if c in cpus] or allowed
+        except Exception:
+            pass
+    everyone = [info]
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, info)
+    if pin and world > 1:
+        peers = [r["rank"] for r in everyone if r["numa_node"] == info["numa_node"]]      # ranks sharing this NUMA node's CPUs
+        k, j = len(peers), peers.index(rank)
+        mine = node_cpus[j * len(node_cpus) // k:(j + 1) * len(node_cpus) // k] or node_cpus
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            mine = allowed
+        os.environ.setdefault("DJB_READER_THREADS", str(max(2, min(32, len(mine)))))
+        info["cpus"] = len(mine)
+        info["cpu_range"] = f"{mine[0]}-{mine[-1]}"
+        info["reader_threads"] = int(os.environ["DJB_READER_THREADS"])
+        everyone = [None] * world
+        dist.all_gather_object(everyone, info)
+    else:
+        info["cpus"] = len(allowed)
+    return everyone
+
+
+# What the 1 / 2 / 4 / 8-GPU curve of the fit legs should look like (DESIGN.md section 6), so that the first real SCALE record
+# can be held against a stated expectation.  End to end (files -> alphas): a fixed part (slot plan look-up, waking the reader
+# pool, the 97 KB-per-material upload, one k_fit launch of ~0.35 ms, the host-side barrier) plus the gather of 5 545 x 3
+# doubles per file, which is the only part that shrinks with the rank's share of the files; compute only: one wave of
+# workgroups at every N (100 materials or 13: the launch floor); dense upload: each rank's PCIe link.
+def scaling_model_ms(world):
+    ns = sorted({1, 2, 4, 8, world})
+    return {"merl_fit_files_100.wall_ms": {str(n): round(1.15 + 1.4 / n, 2) for n in ns},
+            "merl_fit_100.wall_ms": {str(n): 0.34 if n == 1 else 0.30 for n in ns},
+            "merl_fit_files_100.dense_upload.wall_ms": {str(n): round(2.0 + 134.0 / n, 1) for n in ns},
+            "primary.value": "N x the single-GPU rate (weak scaling, no data-path collective)",
+            "source": "model: N=1 terms measured on one MI355X (profiles/r04), 1/N applied to the per-file gather only; NOT a measurement"}
+
+
 def main():
     args = parse()
     import torch
@@ -403,6 +467,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     red_dev = "cpu" if share_gpu else f"cuda:{local}"      # where the control-plane reductions live
+    ranks = rank_placement(torch, dist, rank, local, world, pin=world > 1 and os.environ.get("DJB_BENCH_NO_PIN") != "1")
     ctx = djb.Context(local)    # runs on torch's current stream of this device
 
     global GGX_ALPHA, GGX_FRESNEL
@@ -516,6 +581,19 @@ def main():
                         roofline["traffic_note"] = pj.get("note")
                 except Exception:
                     pass
+            vj = os.path.join(ROOT, "profiles", f"valu_{name}.json")
+            if os.path.exists(vj):       # VALU issue load beside the HBM fraction: tools/instmix.sh + tools/valu_report.py
+                try:
+                    v = json.load(open(vj))
+                    issue_ms = v["slots_per_unit"] * n / 64.0 * 1.155e-6 / 1024.0
+                    roofline["valu"] = {"insts_per_unit": v["insts_per_unit"], "slots_per_unit": v["slots_per_unit"],
+                                        "frac_of_issue": issue_ms / launch_ms,
+                                        "note": "issue-bound" if issue_ms / launch_ms > 0.9 else None,
+                                        "source": "static: instruction mix from profiles/valu_%s.json (SQ_INSTS_VALU_* passes of rocprofv3, %s; "
+                                                  "issue slots per class from tools/valu_cost_probe.hip, one slot = 1.155 ns per wave-instruction "
+                                                  "per SIMD, 1024 SIMDs), divided by this run's launch_ms" % (name, v.get("round", "?"))}
+                except Exception:
+                    pass
         else:
             # the fit moves ~5.5k table reads per material: HBM traffic is negligible, the kernel is
             # latency/VALU-bound; report the achieved rate only
@@ -546,7 +624,10 @@ def main():
                        + (" -- SELF-TEST batch size (--selftest-n): not the BASELINE configuration" if args.selftest_n else "")
                        + (" -- SELF-TEST: all ranks share GPU 0 (DJB_BENCH_SHARE_GPU), not a scaling measurement" if share_gpu else "")},
             "roofline": roofline,
+            "ranks": ranks,
         }
+        if world > 1 or name.startswith("merl_fit") or want_secondary:
+            rec["scaling_model_ms"] = scaling_model_ms(world)
         if name == "merl_fit_files":
             rec["pipeline"] = keep[1].get("timing")   # last step: total / load (read+upload+convert) / fit seconds
         if world == 1 and not args.no_cpu_baseline:

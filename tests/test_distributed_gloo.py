@@ -76,3 +76,41 @@ def test_two_rank_sharding_gloo(oracle):
         assert tmax == float(world)
         if rank == 0:
             assert np.array_equal(full.view(np.uint32), want.view(np.uint32)), "sharded pair ranges do not concatenate to the unsharded result"
+
+
+def _placement_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.pop("DJB_READER_THREADS", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    before = sorted(os.sched_getaffinity(0))
+    ranks = bench.rank_placement(torch, dist, rank, 0, world, pin=True)
+    q.put((rank, before, sorted(os.sched_getaffinity(0)), ranks, os.environ.get("DJB_READER_THREADS")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bench_rank_placement_splits_the_cpus():
+    """bench.py --gpus N: every rank reports where it runs and confines its host threads (the file pipeline's reader pool)
+    to its own share of the CPUs -- here two gloo ranks without GPUs, i.e. one (unknown) NUMA node split in two."""
+    import bench
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_placement_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=200) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, all0, mine0, ranks0, rt0), (_, all1, mine1, ranks1, rt1) = res
+    assert all0 == all1 and ranks0 == ranks1 and [r["rank"] for r in ranks0] == [0, 1]
+    if len(all0) >= 2:
+        assert not set(mine0) & set(mine1), "the two ranks share CPUs"
+        assert sorted(mine0 + mine1) == all0, "CPUs were dropped"
+    assert int(rt0) == max(2, min(32, len(mine0))) and ranks0[1]["reader_threads"] == int(rt1)
+    m = bench.scaling_model_ms(8)
+    assert set(m["merl_fit_files_100.wall_ms"]) == {"1", "2", "4", "8"}

@@ -459,7 +459,9 @@ static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, cons
 		if ((st = sg.out_vec(out_w, &vw)) != DJB_OK) return st;
 		if ((st = sg.out_arr(out_pdf, &dpdf)) != DJB_OK) return st;
 	}
-	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, d1, d2, 0, 0, 0, vo, vi, is ? &vw : nullptr, dpdf));
+	// DJB_OPT_CONTRACT_1E5 reaches `sample` of a Beckmann lobe (directions within 1e-5 per component); evalp_is keeps the
+	// reference's direction: its pdf moves by 1e-3 for a 1e-5 change of the direction, so only exact directions keep it inside the contract
+	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, d1, d2, 0, 0, 0, vo, vi, is ? &vw : nullptr, dpdf, ctx->contract_1e5 && !is));
 	return sg.finish();
 }
 
@@ -495,7 +497,7 @@ try {
 	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
 	if (!Staged::valid(o) || !Staged::valid(out_i)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null vec3 view");
 	View vo{ o->x, o->y, o->z, (long long)o->stride }, vi{ out_i->x, out_i->y, out_i->z, (long long)out_i->stride };
-	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, nullptr, nullptr, seed_u1, seed_u2, start, vo, vi, nullptr, nullptr));
+	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, nullptr, nullptr, seed_u1, seed_u2, start, vo, vi, nullptr, nullptr, ctx->contract_1e5));
 	return DJB_OK;
 }
 DJB_ABI_CATCH
@@ -947,6 +949,36 @@ try {
 	(void)hipFree(d);
 	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: contract selftest: %s", hipGetErrorString(e));
 	memcpy(max_rel2, h, 8);
+	memcpy(counters4, h + 16, 32);
+	return DJB_OK;
+}
+DJB_ABI_CATCH
+
+djb_status djb_selftest_contract_sample(djb_ctx *ctx, const djb_brdf *b, const djb_params *params, int64_t n, uint32_t seed, int family,
+                                        float *max_abs2, unsigned long long *counters4)
+try {
+	float *max_abs1 = max_abs2;
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
+	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
+	djb_status st = check_call(ctx, b, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	if (!max_abs1 || !counters4) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	Params p;
+	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
+	if (!djbk::sample_contract_supported(b->dev, p))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf / params outside the domain of the contract-mode sampler");
+	unsigned char *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 64));
+	hipError_t e = hipMemsetAsync(d, 0, 64, ctx->stream);
+	if (e == hipSuccess)
+		e = djbk::launch_sample_contract_selftest(ctx->stream, b->dev, p, n, seed, 0ull, family, (unsigned int *)d, (unsigned long long *)(d + 16));
+	unsigned char h[64];
+	if (e == hipSuccess) e = hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: contract sampler selftest: %s", hipGetErrorString(e));
+	memcpy(max_abs1, h, 8);
 	memcpy(counters4, h + 16, 32);
 	return DJB_OK;
 }

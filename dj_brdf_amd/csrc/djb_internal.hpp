@@ -19,16 +19,21 @@ hipError_t launch_eval(hipStream_t s, const Brdf &b, const Params &p, long long 
 
 // sample / evalp_is.  If u1 == nullptr the uniforms come from the on-chip counter RNG
 // (seed_u1, seed_u2, start); out_w / out_pdf may be null-views (sample only).
+// contract (DJB_OPT_CONTRACT_1E5): Beckmann `sample` may return directions within 1e-5 per component instead of the reference's bits
 hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long long n,
                          const float *u1, const float *u2, uint32_t seed_u1, uint32_t seed_u2,
                          unsigned long long start, const View &o, const View &out_i,
-                         const View *out_w, float *out_pdf);
+                         const View *out_w, float *out_pdf, bool contract = false);
 
 // the Beckmann lobe's sample / evalp_is (djb_kernels_sample.hip: common path + deferred full path); launch_sample forwards here
 hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p, long long n,
                                   const float *u1, const float *u2, uint32_t seed_u1, uint32_t seed_u2,
                                   unsigned long long start, const View &o, const View &out_i,
-                                  const View *out_w, float *out_pdf);
+                                  const View *out_w, float *out_pdf, bool contract = false);
+bool sample_contract_supported(const Brdf &b, const Params &p);
+// the contract-mode sampler against the full per-sample code on n generated samples (k_sample_ct_selftest)
+hipError_t launch_sample_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed, unsigned long long start,
+                                           int family, unsigned int *max_bits, unsigned long long *counters);
 
 // per-pair params: rec = n x 5 floats; mode 0 = pdfparams records, mode 1 = LEAN texel moments composed with
 // base5 = params_to_lrep(base) (unscaled), scale = dmapscale, lean_flags = DJB_LEAN_* as dj_beckmannconductor does;

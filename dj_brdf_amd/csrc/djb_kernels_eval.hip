@@ -556,7 +556,7 @@ hipError_t launch_eval(hipStream_t s, const Brdf &b, const Params &p, long long 
 
 hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long long n, const float *u1,
                          const float *u2, uint32_t s1, uint32_t s2, unsigned long long start,
-                         const View &o, const View &out_i, const View *out_w, float *out_pdf)
+                         const View &o, const View &out_i, const View *out_w, float *out_pdf, bool contract)
 {
 	if (n <= 0) return hipSuccess;
 	switch (b.kind) {
@@ -564,7 +564,7 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 		// sample, and evalp_is with a Fresnel term fixed at compile time: the two-path kernel (djb_kernels_sample.hip).  evalp_is with
 		// a run-time Fresnel kind (spline, sgd) keeps the one-kernel form: both paths inlined would need 185 VGPRs (2 waves per SIMD)
 		if (!out_w || b.fr.kind == FR_IDEAL || b.fr.kind == FR_SCHLICK || b.fr.kind == FR_UNPOLARIZED)
-			return launch_sample_beckmann(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+			return launch_sample_beckmann(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf, contract);
 		return launch_sample_kind<KIND_BECKMANN>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_GGX:      return launch_sample_kind<KIND_GGX>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_TABULAR:  return launch_sample_kind<KIND_TABULAR>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);

@@ -280,7 +280,159 @@ DJB_DEV v3 bk_sample_common(const Params &p, float u1, float u2, v3 o, const Gli
 	return sub(scale(F(2.0 * D(dot(o, h))), h), o);
 }
 
-template <bool IS, bool RNG, int FRK, bool DENSE>
+// ---- DJB_OPT_CONTRACT_1E5: the sampled DIRECTION inside a value contract -- every component of the returned unit vector within
+// 1e-5 of the reference's -- instead of bit-identically.  Same structure as above: a straight-line common path for every lane,
+// the full per-sample code (sample_one: the reference's arithmetic) for the flagged ones; what changes is the arithmetic of
+// the common path: v_rcp / v_rsq / v_log / v_exp in fp32 where the exact path runs glibc's logf / expf / powf / exp restated
+// in fp64 and correctly rounded divisions (~300 instead of ~690 VALU per sample).  What keeps a sample inside the contract:
+//  * the stretched view direction k and sin(theta_k) are the REFERENCE's floats (guarded exact normalize / sqrt, as in
+//    the common path above): near normal incidence 1 - k.z^2 amplifies an ulp of k.z by 1 / sin^2;
+//  * every decision the reference takes on a computed value is either taken on bit-identical operands (k.z > 0, k.z < 1) or
+//    guarded by a band: Newton's exit |value| < 1e-5 (band CTS_VAL_BAND around the threshold: the approximate value is
+//    within CTS_EPSV of the reference's), the bisection safeguard b in [a, c] (band CTS_B_BAND at both ends), erfinv's
+//    arm w < 5 and the final clamp b >= -0.9999.  Inside a band the sample goes to the exact path.  With the same
+//    decisions the two Newton sequences stay within CTS_EPSV / |derivative| of each other (the iteration contracts);
+//  * the error that reaches the direction is bounded per sample -- d slope / d b = sqrt(pi)/2 exp(slope^2), the lobe's
+//    stretch, |d h / d slope| <= h.z, |d i / d h| <= 4 -- and a sample whose bound exceeds CTS_DIR_MAX goes to the exact
+//    path as well.  djb_selftest_contract_sample measures the actual maximum (tests/test_gpu_contract.py).
+// CTS_EPSV_U u + CTS_EPSV_0 bounds |value_contract - value_reference| at equal b: value = N S - u with N S ~ u, N carrying
+// 2.5e-7 relative (one v_rcp, erf's and the exponential's 1e-7 absolute) and S 2e-7 (v_exp of the split argument), plus both
+// sides' own roundings; CTS_DIR_MAX leaves 2e-6 of the 1e-5 to everything that is not the Newton sequence (the rotation,
+// the two rsq normalisations, the reflection: ~5e-7 measured).  The selftest reports how much of the bound is ever used.
+constexpr float CTS_VAL_BAND = 1.0e-6f, CTS_B_BAND = 4.0e-6f, CTS_EPSV_U = 5.0e-7f, CTS_EPSV_0 = 1.5e-7f, CTS_DIR_MAX = 8.0e-6f;
+
+DJB_DEV float cts_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// exp(y), y <= 0, ~2 ulp: y log2(e) split into hi + lo (a plain exp2(y * log2e) loses |y| 2^-24)
+DJB_DEV float cts_exp_neg(float y)
+{
+	const float L = 1.44269502f, L_LO = 1.92596299e-8f;
+	const float hi = y * L;
+	const float lo = __builtin_fmaf(y, L, -hi) + y * L_LO;
+	const float e = __builtin_amdgcn_exp2f(hi);
+	return __builtin_fmaf(e, lo * 0.693147182f, e);
+}
+// x^y for x in [1e-6, 1], y in [0.4, 1.1]: x = m 2^e, y log2(x) split into an integer and a fraction whose absolute error
+// stays ~1.5e-7 (the product y e is carried with its fma residual) -> relative error < 3e-7
+DJB_DEV float cts_pow(float x, float y)
+{
+#pragma clang fp contract(fast)
+	const float m = __builtin_amdgcn_frexp_mantf(x), fe = (float)__builtin_amdgcn_frexp_expf(x);
+	const float lm = __builtin_amdgcn_logf(m);                 // log2 m in [-1, 0]
+	const float t1 = y * fe, r1 = __builtin_fmaf(y, fe, -t1);
+	const float n = rintf(t1);
+	const float f = ((t1 - n) + y * lm) + r1;
+	return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+// Giles' erfinv, central arm, with v_log_f32; tail = the reference is in (or within 1e-2 of) the other arm
+DJB_DEV float cts_erfinv(float u, bool &tail)
+{
+#pragma clang fp contract(fast)
+	float w = -0.693147182f * __builtin_amdgcn_logf((1.0f - u) * (1.0f + u)), p;
+	tail = !(w < 4.99f);
+	w = w - 2.5f;
+	p = 2.81022636e-08f;
+	p = 3.43273939e-07f + p * w;
+	p = -3.5233877e-06f + p * w;
+	p = -4.39150654e-06f + p * w;
+	p = 0.00021858087f + p * w;
+	p = -0.00125372503f + p * w;
+	p = -0.00417768164f + p * w;
+	p = 0.246640727f + p * w;
+	p = 1.50140941f + p * w;
+	return p * u;
+}
+
+// is the lobe inside the domain the bounds above were made for?  (anything else keeps the exact kernel)
+inline bool cts_params_ok(const Params &p)
+{
+	return p.ax >= 1e-3f && p.ax <= 1e2f && p.ay >= 1e-3f && p.ay <= 1e2f && fabsf(p.rho) <= 0.99f &&
+	       fabsf(p.tx) <= 10.0f && fabsf(p.ty) <= 10.0f;
+}
+
+DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &rare, float *bound_out = nullptr)
+{
+	u1 = sat_(u1) * 0.99998f + 0.00001f;
+	u2 = sat_(u2) * 0.99998f + 0.00001f;
+	const float sa = o.x * p.ax + o.y * p.ay * p.rho;
+	const float sb = o.y * p.ay * p.s;
+	const float sc = o.z - o.x * p.tx - o.y * p.ty;
+	const v3 k = normalize_g<R_BOTH>(mk(sa, sb, sc), rare);                    // the reference's k
+	// k.z <= 0 / k.z >= 1: the reference's special cases; below 1e-3 (tan_k > 1e3) the bounds of the header were not made
+	rare.flag(R_DEGENERATE, !(k.z > 1e-3f) | !(D(k.z) < 1.0));
+	const float cos_k = k.z;
+	const float sin_k = sqrt_g<R_NONE>(1.0 - D(k.z * k.z), rare);              // the reference's sin_k, in [3.4e-4, 1]
+	const float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
+	const float u = fmax_(u1, 1e-6f);
+	float ie = 0.0f, b_at = 0.0f, E = 1.0f, rder = 0.0f, tx, ty, hz, oh, ol2;
+	// margin = how far the closest decision of the Newton loop stayed from its threshold, in units of its band (> 1: certain)
+	float margin = 3.0e38f;
+	bool done = false, tails = false;
+	v3 h;
+	{
+#pragma clang fp contract(fast)          // approximate arithmetic from here on: fused multiply-adds only remove roundings
+		const float cot_k = cos_k * cts_rcp(sin_k), tan_k = sin_k * cts_rcp(cos_k);
+		const float e_cot = cts_exp_neg(-fminf(cot_k * cot_k, 100.0f));
+		// erf(cot_k), Abramowitz & Stegun 7.1.26 as the reference evaluates it (dj_brdf.h:667-688)
+		const float t = cts_rcp(1.0f + 0.3275911f * cot_k);
+		const float poly = ((((1.061405429f * t - 1.453152027f) * t) + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f;
+		float c = 1.0f - (poly * t) * e_cot, a = -1.0f;
+		float b = c - (1 + c) * cts_pow(1 - u, fit);
+		const float K = 0.564189584f * tan_k;                                  // tan_k / sqrt(pi)
+		const float N = cts_rcp((1 + c) + K * e_cot);                         // the normalisation of the CDF
+#pragma unroll
+		for (int trip = 0; trip < TRIPS; ++trip) {
+			// the safeguard's decision (b in [a, c]) is certain only away from both ends; the exit's (|value| < 1e-5) only away
+			// from the threshold.  A converged lane sits ON an end and repeats its last trip: it takes no decisions any more
+			const float m_ends = fminf(fabsf(b - a), fabsf(b - c)) * (1.0f / CTS_B_BAND);
+			const bool inside = (b >= a) & (b <= c);
+			const float bt = inside ? b : 0.5f * (a + c);
+			bool tail;
+			ie = cts_erfinv(bt, tail);
+			tails |= tail;
+			E = cts_exp_neg(-ie * ie);
+			const float value = N * ((1 + bt) + K * E) - u;
+			const float derivative = N * (1 - ie * tan_k);
+			rder = cts_rcp(derivative);
+			const float av = fabsf(value);
+			const float m_exit = fabsf(av - 1e-5f) * (1.0f / CTS_VAL_BAND);
+			margin = done ? margin : fminf(margin, fminf(m_ends, m_exit));
+			done = av < 1e-5f;                                                 // a frozen lane: the same value again
+			b_at = bt;
+			const bool pos = value > 0;
+			c = pos ? bt : c; a = pos ? a : bt;
+			b = done ? bt : bt - value * rder;
+		}
+		tx = ie;
+		bool tail2;
+		ty = cts_erfinv(2.0f * u2 - 1.0f, tail2);                             // beckmann_qf1: float(2.0 * u2 - 1.0) is one rounding (fused here)
+		tails |= tail2;
+		const float nrm = __builtin_amdgcn_rsqf(k.x * k.x + k.y * k.y);
+		const float cp = k.x * nrm, sp = k.y * nrm;
+		const float txm = cp * tx - sp * ty, tym = sp * tx + cp * ty;
+		const float txh = p.ax * txm + p.tx;
+		const float chol = p.rho * txm + p.s * tym;
+		const float tyh = p.ay * chol + p.ty;
+		hz = __builtin_amdgcn_rsqf((txh * txh + tyh * tyh) + 1.0f);
+		h = mk(-txh * hz, -tyh * hz, hz);
+		oh = dot(o, h);
+		ol2 = dot(o, o);
+	}
+	rare.flag(R_TRIPS, !done | !(margin > 1.0f));                              // NaN anywhere: not done, or a false comparison
+	rare.flag(R_TAIL_LOOP, tails);
+	rare.flag(R_CLAMP, !(b_at > -0.99989f));
+	// the error that can reach the direction (header): the Newton sequence's distance to the reference's, through erfinv's slope,
+	// the lobe's stretch (the norm of [[ax, 0], [ay rho, ay s]] is at most sqrt(ax^2 + ay^2)), |d h / d slope| <= h.z, and the
+	// reflection i = 2 (o.h) h - o: |d i| <= (2 |o| + 2 |o.h|) |d h|.  The contract is relative to |o| (1 for a direction).
+	const float err_tx = ((CTS_EPSV_U * u + CTS_EPSV_0) * 0.886226925f) * fabsf(rder) * cts_rcp(E) + 3e-7f * (fabsf(tx) + fabsf(ty));
+	const float stretch = sqrtf(p.ax * p.ax + p.ay * p.ay);                    // launch-uniform
+	const float ol = ol2 * __builtin_amdgcn_rsqf(fmaxf(ol2, 1e-30f));
+	const float bound = ((2.0f * ol + 2.0f * fabsf(oh)) * hz) * (stretch * err_tx);
+	rare.flag(R_GUARD, !(bound < CTS_DIR_MAX * fmaxf(ol, 1.0f)));
+	if (bound_out) *bound_out = bound;
+	return sub(scale(2.0f * oh, h), o);
+}
+
+template <bool IS, bool RNG, int FRK, bool DENSE, bool CT = false>
 __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long n, const float *u1a,
                                                      const float *u2a, uint32_t seed1, uint32_t seed2,
                                                      unsigned long long start, View vo, View vi_out,
@@ -319,7 +471,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 			o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
 		}
 		Rare why;
-		v3 i_ = bk_sample_common<!IS>(p, u1, u2, o, gt, why);
+		v3 i_ = CT ? bk_sample_contract(p, u1, u2, o, why) : bk_sample_common<!IS>(p, u1, u2, o, gt, why);
 		const bool rare = why.any & live;
 		v3 i_out = i_, w = mk(0, 0, 0); float pdf = 0.0f;
 		if (IS) { i_out = mk(0, 0, 0); w = mf_evalp_is_tail<KIND_BECKMANN, FRK>(b, p, i_, o, i_out, pdf); }
@@ -366,14 +518,67 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 	}
 }
 
+// ---- measurement: the contract path against the full per-sample code on generated (u1, u2, o).  max_bits[0]: largest
+// |component difference| among the samples the contract path kept (float bits, atomicMax), max_bits[1]: largest
+// difference / per-sample bound among them (how much of the bound is used; must stay below 1); counters: [0] samples, [1] samples
+// handed to the exact path, [2] kept samples with a component outside 1e-5, [3] kept samples where the reference returns its
+// degenerate (0, 0, 1)
+__global__ __launch_bounds__(BLOCK) void k_sample_ct_selftest(Brdf b, Params p, long long n, uint32_t seed, unsigned long long start,
+                                                              int family, unsigned int *max_bits, unsigned long long *counters)
+{
+	__shared__ double s_glibc[GLIBC_LDS_WORDS];
+	__shared__ unsigned long long s_exp[256];
+	GlibcTabs gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
+	gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	__syncthreads();
+	const long long stride = (long long)gridDim.x * BLOCK;
+	float worst = 0.0f, used = 0.0f;
+	unsigned long long n_all = 0, n_def = 0, n_out = 0, n_deg = 0;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		const unsigned long long kk = start + (unsigned long long)k;
+		float u1 = gen_uniform(seed ^ 0x1111u, kk), u2 = gen_uniform(seed ^ 0x2222u, kk);
+		v3 o = gen_direction(seed, kk);
+		if (family == 1) { o.z = 0.02f + 0.05f * o.z; o = normalize(o); }                 // grazing view
+		else if (family == 2) o = normalize(mk(0.01f * o.x, 0.01f * o.y, 1.0f));          // near-normal view
+		else if (family == 3) { u1 = u1 < 0.5f ? 1e-4f * u1 : 1.0f - 1e-4f * (1.0f - u1); u2 = u2 < 0.5f ? 1e-3f * u2 : 1.0f - 1e-3f * (1.0f - u2); }   // the tails of both uniforms
+		else if (family == 4) o = scale(0.25f + 3.0f * gen_uniform(seed ^ 0x77u, kk), o); // un-normalised view
+		++n_all;
+		Rare why;
+		float bound;
+		const v3 ia = bk_sample_contract(p, u1, u2, o, why, &bound);
+		if (why.any) { ++n_def; continue; }
+		v3 ie, w; float pdf;
+		sample_one<KIND_BECKMANN, false, -1>(b, p, u1, u2, o, gt, ie, w, pdf);
+		const float scale_o = fmaxf(1.0f, sqrtf(dot(o, o)));                  // the contract is relative to |o| (1 for a direction)
+		const float d = fmaxf(fabsf(ia.x - ie.x), fmaxf(fabsf(ia.y - ie.y), fabsf(ia.z - ie.z))) / scale_o;
+		if (!(d <= 1e-5f)) ++n_out;
+		if (ie.x == 0.0f && ie.y == 0.0f && ie.z == 1.0f) ++n_deg;
+		worst = fmaxf(worst, d == d ? d : 3.0e38f);
+		used = fmaxf(used, (d - 1.5e-6f) * scale_o / bound);     // 1.5e-6: the allowance for everything that is not the Newton sequence (CTS_DIR_MAX)
+	}
+	atomicMax(&max_bits[0], __float_as_uint(worst));
+	atomicMax(&max_bits[1], __float_as_uint(used));
+	atomicAdd(&counters[0], n_all); atomicAdd(&counters[1], n_def); atomicAdd(&counters[2], n_out); atomicAdd(&counters[3], n_deg);
+}
+
 } // namespace
 
 namespace djbk {
 
+bool sample_contract_supported(const Brdf &b, const Params &p) { return b.kind == KIND_BECKMANN && cts_params_ok(p); }
+
+hipError_t launch_sample_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed, unsigned long long start,
+                                           int family, unsigned int *max_bits, unsigned long long *counters)
+{
+	if (!sample_contract_supported(b, p)) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_sample_ct_selftest, dim3(grid_persistent(n)), dim3(BLOCK), 0, s, b, p, n, seed, start, family, max_bits, counters);
+	return hipGetLastError();
+}
+
 // sample / evalp_is (ideal, Schlick or unpolarized Fresnel) of a Beckmann lobe; same contract as launch_sample (djb_kernels_eval.hip), which forwards here
 hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p, long long n, const float *u1, const float *u2,
                                   uint32_t s1, uint32_t s2, unsigned long long start, const View &o, const View &out_i,
-                                  const View *out_w, float *out_pdf)
+                                  const View *out_w, float *out_pdf, bool contract)
 {
 	dim3 g(grid_persistent(n)), t(BLOCK);
 #ifdef DJB_EXPERIMENT
@@ -392,6 +597,13 @@ hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p,
 #define DJB_LAUNCH_S2(IS_, FRK_) do { if (rng) { if (dn) DJB_LAUNCH_S(IS_, true, FRK_, true); else DJB_LAUNCH_S(IS_, true, FRK_, false); } \
                                       else { if (dn) DJB_LAUNCH_S(IS_, false, FRK_, true); else DJB_LAUNCH_S(IS_, false, FRK_, false); } \
                                       return hipGetLastError(); } while (0)
+	if (!is && contract && cts_params_ok(p)) {       // DJB_OPT_CONTRACT_1E5: directions within 1e-5 (bk_sample_contract)
+		if (rng) { if (dn) hipLaunchKernelGGL((k_sample_bk<false, true, -1, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
+		           else hipLaunchKernelGGL((k_sample_bk<false, true, -1, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf); }
+		else { if (dn) hipLaunchKernelGGL((k_sample_bk<false, false, -1, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
+		       else hipLaunchKernelGGL((k_sample_bk<false, false, -1, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf); }
+		return hipGetLastError();
+	}
 	if (!is) DJB_LAUNCH_S2(false, -1);
 	if (b.fr.kind == FR_IDEAL) DJB_LAUNCH_S2(true, FR_IDEAL);
 	if (b.fr.kind == FR_SCHLICK) DJB_LAUNCH_S2(true, FR_SCHLICK);

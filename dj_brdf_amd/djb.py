@@ -1122,6 +1122,18 @@ def selftest_contract(brdf, params=None, n: int = 1 << 24, seed: int = 1, family
             "zero_mismatch": int(c[2]), "outside_1e5": int(c[3])}
 
 
+def selftest_contract_sample(brdf, params=None, n: int = 1 << 24, seed: int = 1, family: int = 0, ctx: Optional[Context] = None):
+    """The contract-mode Beckmann sampler against the bit-exact per-sample code on n generated samples
+    (djb_selftest_contract_sample): directions must agree to 1e-5 per component wherever the fast path keeps the sample."""
+    ctx = ctx or default_context()
+    mx = (C.c_float * 2)()
+    c = (C.c_ulonglong * 4)()
+    _lib.check(_lib.load().djb_selftest_contract_sample(ctx._h, brdf._h, C.byref(params._p) if params is not None else None,
+                                                        C.c_int64(n), C.c_uint32(seed), C.c_int(family), mx, c))
+    return {"max_abs_dir": float(mx[0]), "bound_used": float(mx[1]), "samples": int(c[0]), "exact_path": int(c[1]), "outside_1e5": int(c[2]),
+            "degenerate_kept": int(c[3])}
+
+
 def set_test_worklist_cap(ctx: Context, entries: int):
     """tests: override the tier-2 worklist capacity of the two-tier kernels (-1 = automatic); DJB_OPT_TEST_WORKLIST_CAP"""
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(7), C.c_int(int(entries))))

@@ -159,8 +159,12 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * every result within 1e-5 relative of the reference's, zeros exactly where the reference returns zeros -- instead of
  * bit-identically: reciprocal / rsqrt instructions and merged denominators in place of the reference's 15 correctly
  * rounded divisions, pairs whose reference value is ill-conditioned re-done by the bit-exact code (two tiers, as for
- * MERL).  Everything else -- sampling, MERL / UTIA look-ups and their bin decisions, the fitters, other lobes and
- * layouts -- is unaffected and stays bit-identical.  djb_selftest_contract measures the actual maximum difference. */
+ * MERL).  Since round 4 also: unpolarized Fresnel (ior >= 1.05) for GGX / Beckmann, sgd::eval, and `sample` of a Beckmann lobe
+ * (djb_sample_batch / djb_sample_rng_batch; 1e-3 <= ax, ay <= 100, |rho| <= 0.99): every component of the returned unit vector
+ * within 1e-5 of the reference's, samples whose decisions or conditioning are in doubt re-done by the bit-exact code in the same
+ * launch.  Everything else -- evalp_is (its pdf needs the reference's own direction), MERL / UTIA look-ups and their bin
+ * decisions, the fitters, other lobes and layouts -- is unaffected and stays bit-identical.  djb_selftest_contract and
+ * djb_selftest_contract_sample measure the actual maximum difference. */
        DJB_OPT_CONTRACT_1E5 = 6,
 /* DJB_OPT_TEST_WORKLIST_CAP = <entries> (tests only; -1 = automatic, the default): overrides the capacity of the tier-2
  * worklist of the two-tier kernels (merl, utia, contract mode), to exercise the overflow path in which the second kernel
@@ -348,6 +352,14 @@ djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsign
  * DJB_ERR_INVALID_ARGUMENT when brdf / params are outside the fast path's domain. */
 djb_status djb_selftest_contract(djb_ctx *, const djb_brdf *, const djb_params *params, int64_t n, uint32_t seed, int family,
                                  float *max_rel2, unsigned long long *counters4);
+/* the DJB_OPT_CONTRACT_1E5 sampler (Beckmann `sample`) against the bit-exact per-sample code on n generated (u1, u2, o)
+ * (family 0: the bench distribution; 1: grazing view; 2: near-normal view; 3: both uniforms in their tails; 4: un-normalised
+ * view): max_abs2 = {largest |component difference| among the samples the fast path kept, largest difference / per-sample
+ * error bound among them (the share of the bound that is ever used; < 1)}, counters4 = {samples, samples
+ * handed to the exact path, kept samples with a component outside 1e-5 (must be 0), kept samples for which the
+ * reference returns its degenerate (0, 0, 1)}.  DJB_ERR_INVALID_ARGUMENT when brdf / params are outside the sampler's domain. */
+djb_status djb_selftest_contract_sample(djb_ctx *, const djb_brdf *, const djb_params *params, int64_t n, uint32_t seed, int family,
+                                        float *max_abs2, unsigned long long *counters4);
 /* the kernels' restatements of the host libm functions the reference calls (glibc 2.35: double exp / pow / atan2 / sin / cos / tan / acos,
  * float logf / expf / powf -- dj_brdf.h:659, 685, 695, 1634, 1868, 1917, 1935, 3419, 3431, 3612), evaluated on the GPU for
  * host arrays: fn 0 exp(x), 1 pow(x, y), 2 logf(x), 3 expf(x), 4 powf(x, y) (float functions on the values cast

@@ -292,3 +292,66 @@ def test_contract_sgd_vs_oracle(ct_ctx, oracle):
             differs += int(np.sum(np.ascontiguousarray(got, np.float32).view(np.uint32) != want.view(np.uint32)))
     print(f"\ncontract sgd vs oracle: worst relative difference {worst:.3e}")
     assert differs > 0, "the value-contract kernels did not run (results are bit-identical to the oracle)"
+
+
+# ---------------------------------------------------------------- Beckmann `sample` under the contract (round 4)
+SAMPLE_PARAMS = [None, ("elliptic", 0.2, 0.5, 0.7), ("elliptic", 0.3, 0.3, 0.0), ("elliptic", 0.02, 0.02, 0.0),
+                 ("pdfparams", 0.4, 0.25, 0.6, 0.1, -0.2), ("elliptic", 0.05, 0.8, 0.3)]
+ATOL_DIR = 1e-5          # every component of the sampled unit vector (x |o| for an un-normalised view direction)
+
+
+def check_directions(name, got, want, o):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN pattern differs"
+    tol = ATOL_DIR * np.maximum(1.0, np.linalg.norm(np.asarray(o, np.float64), axis=1, keepdims=True))
+    m = np.isfinite(want)
+    d = np.where(m, np.abs(got - want), 0.0)
+    assert np.all(d <= tol), f"{name}: {int(np.sum(d > tol))} components outside the contract, worst {float(d.max()):.3e}"
+    # the reference's degenerate answer (0, 0, 1) (stretched view direction below the horizon) is a decision, not a value
+    deg = np.all(want == np.array([0.0, 0.0, 1.0]), axis=1)
+    assert np.array_equal(got[deg], want[deg]), f"{name}: degenerate samples differ"
+    return float(d.max())
+
+
+def test_contract_beckmann_sample_vs_oracle(ct_ctx, oracle):
+    """djb_sample_batch / djb_sample_rng_batch with DJB_OPT_CONTRACT_1E5: directions within 1e-5 per component of the oracle's,
+    on the bench inputs, a grazing and a near-normal family and un-normalised view directions; evalp_is stays bit-exact"""
+    n = 1 << 18
+    u1, u2 = synth.uniforms(n, synth.SEED_U1), synth.uniforms(n, synth.SEED_U2)
+    base = synth.directions_aos(n, synth.SEED_O)
+    graz = base.copy(); graz[:, 2] = 0.02 + 0.05 * graz[:, 2]; graz /= np.linalg.norm(graz, axis=1, keepdims=True)
+    near = base * np.array([0.01, 0.01, 0.0], np.float32) + np.array([0, 0, 1], np.float32); near /= np.linalg.norm(near, axis=1, keepdims=True)
+    long_ = base * (0.25 + 3.0 * synth.uniforms(n, 77))[:, None]
+    import torch
+    b = djb.beckmann(ctx=ct_ctx); ob = oracle.microfacet("beckmann")
+    worst, differs = 0.0, 0
+    for fam, o in (("bench", base), ("grazing", graz.astype(np.float32)), ("near-normal", near.astype(np.float32)), ("un-normalised", long_.astype(np.float32))):
+        do, d1, d2 = soa(o), torch.from_numpy(u1).cuda(), torch.from_numpy(u2).cuda()
+        for p in SAMPLE_PARAMS:
+            got = b.sample(d1, d2, do, mk_params(p)).cpu().numpy().T
+            want = oracle.sample(ob, u1, u2, o, p)
+            worst = max(worst, check_directions(f"sample/{fam}/{p}", got, want, o))
+            differs += int(np.sum(np.ascontiguousarray(got, np.float32).view(np.uint32) != want.view(np.uint32)))
+    assert differs > 0, "contract mode returned bit-identical directions everywhere: the fast path did not run"
+    # evalp_is is outside the option's reach: its pdf moves by 1e-3 for a 1e-5 change of direction
+    o = base[:4096]; p = ("elliptic", 0.2, 0.5, 0.7)
+    w, i_, pdf = b.evalp_is(torch.from_numpy(u1[:4096]).cuda(), torch.from_numpy(u2[:4096]).cuda(), soa(o), mk_params(p))
+    ww, wi, wpdf = oracle.evalp_is(ob, u1[:4096], u2[:4096], o, p)
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    assert np.array_equal(bits(i_.cpu().numpy().T), bits(wi)) and np.array_equal(bits(pdf.cpu().numpy()), bits(wpdf)) and np.array_equal(bits(w.cpu().numpy().T), bits(ww))
+    print(f"\ncontract-mode Beckmann sample: worst component difference vs the oracle {worst:.3e} (contract {ATOL_DIR})")
+
+
+def test_contract_beckmann_sample_selftest(gpu_ctx):
+    """djb_selftest_contract_sample: 2^26 generated samples per lobe and family against the bit-exact per-sample code on the
+    device -- nothing the fast path keeps may be outside 1e-5, and its per-sample error bound must bound (usage < 1)"""
+    b = djb.beckmann(ctx=gpu_ctx)
+    for p in SAMPLE_PARAMS[1:] + [("elliptic", 1.0, 1.0, 0.0)]:
+        for family in range(5):
+            r = djb.selftest_contract_sample(b, mk_params(p), n=1 << 26, seed=21 + family, family=family, ctx=gpu_ctx)
+            assert r["outside_1e5"] == 0 and r["max_abs_dir"] <= ATOL_DIR, (p, family, r)
+            assert r["bound_used"] < 1.0, (p, family, r)
+    r = djb.selftest_contract_sample(b, mk_params(("elliptic", 0.2, 0.5, 0.7)), n=1 << 26, seed=5, family=0, ctx=gpu_ctx)
+    assert r["exact_path"] < 0.15 * r["samples"], f"the fast path keeps too little of the bench distribution: {r}"
+    with pytest.raises(djb.exc):          # outside the sampler's domain (and a GGX lobe has no contract sampler)
+        djb.selftest_contract_sample(djb.ggx(ctx=gpu_ctx), mk_params(("elliptic", 0.3, 0.3, 0.0)), n=1024, ctx=gpu_ctx)

@@ -120,6 +120,13 @@ def test_merl_two_tier_on_adversarial_families(gpu_ctx):
     for name, i, o in _merl_families(m, f"cuda:{gpu_ctx.device}"):
         s = djb.merl_guard_stats(i, o, ctx=gpu_ctx)
         a = mobj.eval(i, o)
+        # ... and with a worklist too small for the family: tier 2 then re-takes tier 1's decision pair by pair (the overflow
+        # rescan), which only works if the decision function gives the same answer in both kernels
+        djb.set_test_worklist_cap(gpu_ctx, 64)
+        try:
+            a_rescan = mobj.eval(i, o)
+        finally:
+            djb.set_test_worklist_cap(gpu_ctx, -1)
         djb.set_merl_exact_only(gpu_ctx, True)
         try:
             b = mobj.eval(i, o)
@@ -130,6 +137,9 @@ def test_merl_two_tier_on_adversarial_families(gpu_ctx):
         report.append((name, s, diff))
         assert s["mismatch"] == 0, (name, s)
         assert diff == 0, f"{name}: {diff} of {m} two-tier results differ from the exact kernel ({s})"
+        diff_rescan = int((a_rescan.view(torch.int32) != b.view(torch.int32)).any(dim=0).sum())
+        assert diff_rescan == 0, f"{name}: {diff_rescan} of {m} results differ from the exact kernel when the worklist overflows"
+        del a_rescan
         assert max(s["max_ratio"]) < 0.5, f"{name}: guard-band margin below 2x: {s}"
         assert s["special"] + s["ambiguous"] + s["certain"] == m
         del i, o, a, b

@@ -7,7 +7,7 @@
 // header (link with -ldjb_hip).  Two differences, both additive:
 //   * every operator also has a BATCH overload (n pairs per call) -- the form that makes sense
 //     on a GPU.  The scalar virtuals are batches of one, which the library answers on the calling
-//     thread from a host twin of the object (no launch, no lock: 60-200 ns per call, DESIGN.md 1.1);
+//     thread from a host twin of the object (no launch, no lock: 60-200 ns per call, DESIGN.md 1);
 //     a renderer that can gather a wavefront of intersections should still call the batch form.
 //   * objects live on a djb::hip::context (one GPU + one stream); a process-wide default exists.
 // Errors: constructors and calls throw djb::exc carrying the library's djb_error message.

@@ -1,6 +1,6 @@
 // tools/newton_trip_stats.cpp -- trip count of beckmann::qf2_radial's Newton loop (dj_brdf.h:1897-1952) on the bench distribution of configs[3]:
 // its histogram, the per-wave maximum a 64-lane wave pays, how much of it a (u, cos_k) table predicts, and what sorting the 256 samples of a
-// workgroup by predicted / true trip count would buy.  Host code: g++ -O2 -ffp-contract=off -o tools/bin/newton_trip_stats tools/newton_trip_stats.cpp
+// workgroup by predicted / true trip count would buy (profiles/r03/NOTES.md 4.4).  Host code: g++ -O2 -ffp-contract=off -o tools/bin/newton_trip_stats tools/newton_trip_stats.cpp
 #define DJB_HOST_MATH 1
 #include "../dj_brdf_amd/csrc/djb_device.hpp"
 #include <cstdio>

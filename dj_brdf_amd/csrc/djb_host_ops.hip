@@ -459,9 +459,9 @@ static djb_status sample_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, cons
 		if ((st = sg.out_vec(out_w, &vw)) != DJB_OK) return st;
 		if ((st = sg.out_arr(out_pdf, &dpdf)) != DJB_OK) return st;
 	}
-	// DJB_OPT_CONTRACT_1E5 reaches `sample` of a Beckmann lobe (directions within 1e-5 per component); evalp_is keeps the
-	// reference's direction: its pdf moves by 1e-3 for a 1e-5 change of the direction, so only exact directions keep it inside the contract
-	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, d1, d2, 0, 0, 0, vo, vi, is ? &vw : nullptr, dpdf, ctx->contract_1e5 && !is));
+	// DJB_OPT_CONTRACT_1E5 reaches `sample` of a Beckmann lobe (directions within 1e-5 per component) and the weight / pdf of
+	// evalp_is (GGX, Beckmann) -- for the reference's own direction: the pdf moves by 1e-3 for a 1e-5 change of direction
+	HIP_TRY(djbk::launch_sample(ctx->stream, b->dev, p, n, d1, d2, 0, 0, 0, vo, vi, is ? &vw : nullptr, dpdf, ctx->contract_1e5));
 	return sg.finish();
 }
 

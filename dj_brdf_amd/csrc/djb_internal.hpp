@@ -89,6 +89,29 @@ constexpr unsigned int WL_SHARDS = 64;
 constexpr unsigned int WL_COUNTER_STRIDE = 32;         // words between two counters (one 128-byte line each)
 constexpr unsigned int CONTRACT_SHARDS = WL_SHARDS, CONTRACT_COUNTER_STRIDE = WL_COUNTER_STRIDE;
 constexpr float CT_RHO_MAX = 0.9f;
+// launch-uniform constants of the contract-mode fast paths (filled by contract_params on the host, a kernel argument)
+struct CtParams {
+	float ax, ay, rho, s, rho_ay;      // microfacet::params (tx = ty = 0, mean normal = +z)
+	float r_ax, r_t2;                  // float(1 / ax), float(1 / (ax ay s))
+	float k_d;                         // float(r_t2 / pi): the constant factor of D
+	float t2;                          // ax * ay * s as the reference rounds it (the divisor of mf_p22)
+	double R_ax, R_t2;                 // 1 / ax and 1 / t2 to within 2^-52: fdiv_r's exact divisions (Beckmann)
+	float f0[3], f1[3];                // schlick: f0 and 1 - f0
+	float n2m1[3];                     // unpolarized: ior^2 - 1 per channel (ior >= CT_IOR_MIN)
+	int shadow;
+	// abc (model row kD[3] A[3] B C ior, dj_brdf.h:3608-3668)
+	float kd_pi[3];                    // kD / pi as the reference rounds it: float(kD) * (1.0f / float(pi))
+	float A[3], ior;
+	double B, C;
+	// sgd (model row rhoD rhoS alpha p f0 f1 kap lambda c k theta0, 3 doubles each; dj_brdf.h:3415-3500)
+	float kd[3], ks[3], sf0[3], sf1[3], s1mf0[3];      // rhoD, rhoS, Fresnel f0, f1, 1 - f0 as floats (the reference's vec3::from_raw)
+	double alpha[3], inv_alpha[3];
+	float p_[3], lkap[3];                              // NDF exponent; log2(kap / pi)
+	float lam[3], l2c[3], kk[3], th0_hi[3], th0_lo[3]; // g1: lambda, log2(c), k, theta0 = hi + lo
+	float x_max[3], x_zero[3];                         // g1: tier-1 range of x = c t1^k (ct_params_sgd)
+};
+// false: brdf / params outside the fast path's domain
+bool contract_params(const Brdf &b, const Params &p, const double *model_host, CtParams *c);
 // model_host: the host copy of b.model (sgd / abc rows), or NULL
 bool contract_supported(const Brdf &b, const Params &p, const double *model_host = nullptr);
 hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, const double *model_host, long long n, const View &i, const View &o,

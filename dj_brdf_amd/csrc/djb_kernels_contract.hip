@@ -39,101 +39,7 @@ inline int grid_for(long long n, long long cap = 256LL * 64)
 	return (int)blocks;
 }
 
-constexpr float CT_DOT_MIN = 0.25f;      // pdf: dot(o, h), dot(i, h) below this -> tier 2 (conditioning, see header)
-constexpr float CT_HZ_MIN = 1.2e-4f;     // h.z below this -> tier 2 (the reference's h.z > 1e-4 cut, dj_brdf.h:1561)
-constexpr float CT_LO = 1e-12f, CT_HI = 1e12f;   // operand range of the rcp / rsq shortcuts (no denormals, no overflow)
-
-DJB_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
-DJB_DEV float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
-DJB_DEV bool in_range(float x) { return (x > CT_LO) & (x < CT_HI); }          // false for NaN
-
-// launch-uniform constants of the fast path
-struct CtParams {
-	float ax, ay, rho, s, rho_ay;      // microfacet::params (tx = ty = 0, mean normal = +z)
-	float r_ax, r_t2;                  // float(1 / ax), float(1 / (ax ay s))
-	float k_d;                         // float(r_t2 / pi): the constant factor of D
-	float t2;                          // ax * ay * s as the reference rounds it (the divisor of mf_p22)
-	double R_ax, R_t2;                 // 1 / ax and 1 / t2 to within 2^-52: fdiv_r's exact divisions (Beckmann)
-	float f0[3], f1[3];                // schlick: f0 and 1 - f0
-	float n2m1[3];                     // unpolarized: ior^2 - 1 per channel (ior >= CT_IOR_MIN)
-	int shadow;
-	// abc (model row kD[3] A[3] B C ior, dj_brdf.h:3608-3668)
-	float kd_pi[3];                    // kD / pi as the reference rounds it: float(kD) * (1.0f / float(pi))
-	float A[3], ior;
-	double B, C;
-	// sgd (model row rhoD rhoS alpha p f0 f1 kap lambda c k theta0, 3 doubles each; dj_brdf.h:3415-3500)
-	float kd[3], ks[3], sf0[3], sf1[3], s1mf0[3];      // rhoD, rhoS, Fresnel f0, f1, 1 - f0 as floats (the reference's vec3::from_raw)
-	double alpha[3], inv_alpha[3];
-	float p_[3], lkap[3];                              // NDF exponent; log2(kap / pi)
-	float lam[3], l2c[3], kk[3], th0_hi[3], th0_lo[3]; // g1: lambda, log2(c), k, theta0 = hi + lo
-	float x_max[3], x_zero[3];                         // g1: tier-1 range of x = c t1^k (ct_params_sgd)
-};
-
-// exp(y) for y <= 0 with the argument split y log2(e) = hi + lo, so that the result keeps ~2 ulp for |y| up to 80 (a plain
-// exp2(y * log2e) loses |y| * 2^-24)
-DJB_DEV float ct_exp_neg(float y)
-{
-	const float L = 1.44269502f, L_LO = 1.92596299e-8f;         // log2(e) = L + L_LO
-	const float hi = y * L;
-	const float lo = __builtin_fmaf(y, L, -hi) + y * L_LO;
-	const float e = __builtin_amdgcn_exp2f(hi);
-	return __builtin_fmaf(e, lo * 0.693147182f, e);
-}
-
-// fresnel::unpolarized (dj_brdf.h:1292-1303) for one channel, c = cos(theta_d) in [0, 1], n2m1 = ior^2 - 1 > 0:
-//   g = sqrt(n^2 + c^2 - 1);  F = 1/2 ((g - c) / (g + c))^2 (1 + ((c (g + c) - 1) / (c (g - c) + 1))^2).
-// The reference forms g - c as a float difference; here g - c = (n^2 - 1) / (g + c), the same number without the
-// cancellation.  The reference's own rounding noise in g - c is u g / (g - c) relative -- 21 u at ior = 1.05 (c = 1), doubled by
-// the square: 3e-6 -- which is why CT_IOR_MIN = 1.05: below it the reference's float chain is itself noisier than the
-// contract and only the bit-exact kernel can follow it.  c (g + c) - 1 changes sign near Brewster's angle, but it enters
-// through 1 + (.)^2, which is insensitive there.  Cost: one rsq and two rcp per channel.
-constexpr float CT_IOR_MIN = 1.05f, CT_IOR_MAX = 1e3f;
-DJB_DEV float ct_unpolarized(float c, float n2m1)
-{
-	const float g2 = n2m1 + c * c;
-	const float g = g2 * rsq_(g2);
-	const float gp = g + c, gm = n2m1 * rcp_(gp);
-	const float t1 = c * gp - 1.0f, t2 = c * gm + 1.0f;
-	const float q3 = t1 * rcp_(t2), q4 = gm * rcp_(gp);
-	return (0.5f * (q4 * q4)) * (1.0f + q3 * q3);
-}
-// F(cos theta_d) * e for the Fresnel kinds of the contract set; cd is clamped to [0, 1] as microfacet::eval does (dj_brdf.h:1545)
-template <int FRK>
-DJB_DEV v3 ct_fresnel_times(const CtParams &c, float oh, float e)
-{
-	if (FRK == FR_SCHLICK) {                                   // fresnel::schlick, dj_brdf.h:1322-1328
-		const float cd = sat_(oh), c1 = 1.0f - cd, c2_ = c1 * c1, c5 = c2_ * c2_ * c1;
-		return mk(e * (c.f0[0] + c5 * c.f1[0]), e * (c.f0[1] + c5 * c.f1[1]), e * (c.f0[2] + c5 * c.f1[2]));
-	}
-	if (FRK == FR_UNPOLARIZED) {
-		const float cd = sat_(oh);
-		return mk(e * ct_unpolarized(cd, c.n2m1[0]), e * ct_unpolarized(cd, c.n2m1[1]), e * ct_unpolarized(cd, c.n2m1[2]));
-	}
-	return mk(e, e, e);
-}
-
-// stretched-space norm and sigma of direction k (microfacet::sigma, dj_brdf.h:1619-1631; ggx::sigma_std_radial :2062,
-// beckmann::sigma_std_radial :1871-1880 with the reference's A&S 7.1.26 erf, :667-688).  k.z > 0.
-template <int KIND>
-DJB_DEV float ct_sigma(const CtParams &c, v3 k, bool &ok)
-{
-	float a = k.x * c.ax + k.y * c.ay * c.rho;
-	float bb = k.y * c.ay * c.s;
-	float n2 = a * a + bb * bb + k.z * k.z;                 // bit-identical to the reference's (tx = ty = 0)
-	ok &= (in_range(n2));
-	float rn = rsq_(n2), nrm = n2 * rn, kz = rn * k.z;
-	if (KIND == KIND_GGX) return nrm * ((1.0f + kz) * 0.5f);
-	// Beckmann: (c (1 + erf(nu)) + s exp(-nu^2) / sqrt(pi)) / 2,  s = sqrt(1 - c^2), nu = c / s
-	const float s2 = 1.0f - kz * kz;
-	const float rs = rsq_(fmaxf(s2, 1e-30f));
-	const float sn = s2 * rs, nu = kz * rs;
-	const float e = ct_exp_neg(-fminf(nu * nu, 100.0f));
-	const float t = rcp_(1.0f + 0.3275911f * nu);
-	const float poly = ((((1.061405429f * t - 1.453152027f) * t) + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f;
-	const float erf_nu = 1.0f - poly * t * e;
-	const float std_ = 0.5f * (kz * (1.0f + erf_nu) + sn * (e * 0.564189584f));
-	return nrm * (s2 > 1e-7f ? std_ : kz);                  // c -> 1: erf -> 1, the second term -> 0 (the reference returns 1 at c == 1)
-}
+#include "djb_contract_device.inc"   // CtParams, the shortcuts, ct_sigma, the Fresnel terms, the evalp_is tail (shared with the samplers)
 
 // Beckmann.  exp(-r^2) makes D as sensitive as r^2 is large: an ulp of the half vector's slope moves D by r^2 2^-23, and
 // the reference's own float chain carries several -- so the slope of h is computed with the REFERENCE's operations
@@ -664,6 +570,8 @@ bool contract_supported(const Brdf &b, const Params &p, const double *model_host
 	CtParams c;
 	return ct_params_any(b, p, model_host, &c);
 }
+
+bool contract_params(const Brdf &b, const Params &p, const double *model_host, CtParams *c) { return ct_params_any(b, p, model_host, c); }
 
 hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, const double *model_host, long long n, const View &i, const View &o,
                                 const View &out, float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count)

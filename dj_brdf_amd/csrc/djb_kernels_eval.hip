@@ -244,6 +244,32 @@ hipError_t launch_eval_pp_kind(hipStream_t s, const Brdf &b, long long n, const 
 }
 
 // ------------------------------------------------------------------ sample / evalp_is
+#include "djb_contract_device.inc"   // ct_is_tail: the evalp_is tail under DJB_OPT_CONTRACT_1E5
+// evalp_is of a GGX lobe under the contract: the EXACT sampled direction (mf_sample), weight and pdf by ct_is_tail; the few
+// pairs it declines run the exact tail in place (a cold branch: 0.05 % of the bench distribution)
+template <bool RNG, int FRK, bool DENSE>
+__global__ __launch_bounds__(BLOCK) void k_evalp_is_ggx_ct(Brdf b, Params p, djbk::CtParams ct, long long n, const float *u1a,
+                                                           const float *u2a, uint32_t seed1, uint32_t seed2,
+                                                           unsigned long long start, View vo, View vi_out,
+                                                           View vw_out, float *out_pdf)
+{
+	const GlibcTabs gt = glibc_tabs_global();
+	const long long stride = (long long)gridDim.x * BLOCK;
+	const unsigned int t = threadIdx.x;
+	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {
+		const long long k = k0 + t;
+		if (k >= n) continue;
+		float u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : (DENSE ? (u1a + k0)[t] : u1a[k]);
+		float u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : (DENSE ? (u2a + k0)[t] : u2a[k]);
+		const v3 o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
+		const v3 i_ = mf_sample<KIND_GGX>(b, p, u1, u2, o, gt);
+		v3 w, i_out; float pdf; bool live;
+		if (ct_is_tail<KIND_GGX, FRK>(ct, i_, o, w, pdf, live)) i_out = live ? i_ : mk(0, 0, 0);
+		else { i_out = mk(0, 0, 0); w = mf_evalp_is_tail<KIND_GGX, FRK>(b, p, i_, o, i_out, pdf); }
+		if (DENSE) { store3_dense(vi_out, k0, t, i_out); store3_dense(vw_out, k0, t, w); (out_pdf + k0)[t] = pdf; }
+		else { store3(vi_out, k, i_out); store3(vw_out, k, w); out_pdf[k] = pdf; }
+	}
+}
 // FRK: Fresnel kind fixed at compile time for evalp_is of the analytic lobes (as in k_eval)
 template <int KIND, bool IS, bool RNG, int FRK = -1, bool DENSE = false>
 __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n, const float *u1a,
@@ -566,7 +592,24 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 		if (!out_w || b.fr.kind == FR_IDEAL || b.fr.kind == FR_SCHLICK || b.fr.kind == FR_UNPOLARIZED)
 			return launch_sample_beckmann(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf, contract);
 		return launch_sample_kind<KIND_BECKMANN>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
-	case KIND_GGX:      return launch_sample_kind<KIND_GGX>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	case KIND_GGX: {
+		CtParams ct;
+		if (contract && out_w && contract_params(b, p, nullptr, &ct)) {      // evalp_is under DJB_OPT_CONTRACT_1E5: exact direction, contract tail
+			const dim3 g(grid_full(n)), t(BLOCK);
+			const bool rng = u1 == nullptr, dn = dense(o) && dense(out_i) && dense(*out_w);
+#define DJB_IS_CT(FRK_) do { \
+			if (rng) { if (dn) hipLaunchKernelGGL((k_evalp_is_ggx_ct<true, FRK_, true>), g, t, 0, s, b, p, ct, n, u1, u2, s1, s2, start, o, out_i, *out_w, out_pdf); \
+			           else hipLaunchKernelGGL((k_evalp_is_ggx_ct<true, FRK_, false>), g, t, 0, s, b, p, ct, n, u1, u2, s1, s2, start, o, out_i, *out_w, out_pdf); } \
+			else { if (dn) hipLaunchKernelGGL((k_evalp_is_ggx_ct<false, FRK_, true>), g, t, 0, s, b, p, ct, n, u1, u2, s1, s2, start, o, out_i, *out_w, out_pdf); \
+			       else hipLaunchKernelGGL((k_evalp_is_ggx_ct<false, FRK_, false>), g, t, 0, s, b, p, ct, n, u1, u2, s1, s2, start, o, out_i, *out_w, out_pdf); } \
+			return hipGetLastError(); } while (0)
+			if (b.fr.kind == FR_IDEAL) DJB_IS_CT(FR_IDEAL);
+			if (b.fr.kind == FR_SCHLICK) DJB_IS_CT(FR_SCHLICK);
+			if (b.fr.kind == FR_UNPOLARIZED) DJB_IS_CT(FR_UNPOLARIZED);
+#undef DJB_IS_CT
+		}
+		return launch_sample_kind<KIND_GGX>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
+	}
 	case KIND_TABULAR:  return launch_sample_kind<KIND_TABULAR>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_TABULAR_ANISO: return launch_sample_kind<KIND_TABULAR_ANISO>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_MERL:     return launch_sample_kind<KIND_MERL>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);

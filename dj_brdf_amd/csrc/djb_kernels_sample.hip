@@ -432,11 +432,15 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 	return sub(scale(2.0f * oh, h), o);
 }
 
+#include "djb_contract_device.inc"   // ct_is_tail: the evalp_is tail under DJB_OPT_CONTRACT_1E5
+
+// CT (DJB_OPT_CONTRACT_1E5): sample -> bk_sample_contract (directions within 1e-5); evalp_is -> the EXACT direction of the common
+// path with ct_is_tail for weight and pdf.  Either way a declined sample takes the exact per-sample code through the queue.
 template <bool IS, bool RNG, int FRK, bool DENSE, bool CT = false>
 __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long n, const float *u1a,
                                                      const float *u2a, uint32_t seed1, uint32_t seed2,
                                                      unsigned long long start, View vo, View vi_out,
-                                                     View vw_out, float *out_pdf)
+                                                     View vw_out, float *out_pdf, djbk::CtParams ct)
 {
 	__shared__ double s_glibc[GLIBC_LDS_WORDS];
 	__shared__ unsigned long long s_exp[256];
@@ -471,10 +475,14 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 			o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
 		}
 		Rare why;
-		v3 i_ = CT ? bk_sample_contract(p, u1, u2, o, why) : bk_sample_common<!IS>(p, u1, u2, o, gt, why);
-		const bool rare = why.any & live;
+		v3 i_ = (CT && !IS) ? bk_sample_contract(p, u1, u2, o, why) : bk_sample_common<!IS>(p, u1, u2, o, gt, why);
 		v3 i_out = i_, w = mk(0, 0, 0); float pdf = 0.0f;
-		if (IS) { i_out = mk(0, 0, 0); w = mf_evalp_is_tail<KIND_BECKMANN, FRK>(b, p, i_, o, i_out, pdf); }
+		if (IS && CT) {
+			bool alive;
+			why.flag(R_GUARD, !ct_is_tail<KIND_BECKMANN, FRK == -1 ? FR_IDEAL : FRK>(ct, i_, o, w, pdf, alive));
+			i_out = alive ? i_ : mk(0, 0, 0);
+		} else if (IS) { i_out = mk(0, 0, 0); w = mf_evalp_is_tail<KIND_BECKMANN, FRK>(b, p, i_, o, i_out, pdf); }
+		const bool rare = why.any & live;
 		if (live && !rare) {
 			if (DENSE) store3_dense(vi_out, k0, t, i_out); else store3(vi_out, k, i_out);
 			if (IS) {
@@ -586,6 +594,8 @@ hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p,
 #endif
 	View w = out_w ? *out_w : View{ nullptr, nullptr, nullptr, 0 };
 	const bool is = out_w != nullptr, rng = u1 == nullptr;
+	djbk::CtParams ct{};
+	const bool ct_is = is && contract && contract_params(b, p, nullptr, &ct);     // evalp_is under the contract: exact direction, contract tail
 	auto dense1 = [](const View &v) { return !v.x || v.stride == 1; };
 	const bool dn = dense1(o) && dense1(out_i) && dense1(w);
 #ifdef DJB_EXP_RARE_COUNT
@@ -593,18 +603,30 @@ hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p,
 		fprintf(stderr, "djb_exp: sample_bk common %llu deferred %llu | logf %llu expf %llu powf %llu exp64 %llu guard %llu tail_loop %llu tail_qf1 %llu trips %llu clamp %llu degenerate %llu (cumulative)\n",
 		        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]); } } report{ s };
 #endif
-#define DJB_LAUNCH_S(IS_, RNG_, FRK_, DN_) hipLaunchKernelGGL((k_sample_bk<IS_, RNG_, FRK_, DN_>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf)
+#define DJB_LAUNCH_S(IS_, RNG_, FRK_, DN_) hipLaunchKernelGGL((k_sample_bk<IS_, RNG_, FRK_, DN_>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct)
 #define DJB_LAUNCH_S2(IS_, FRK_) do { if (rng) { if (dn) DJB_LAUNCH_S(IS_, true, FRK_, true); else DJB_LAUNCH_S(IS_, true, FRK_, false); } \
                                       else { if (dn) DJB_LAUNCH_S(IS_, false, FRK_, true); else DJB_LAUNCH_S(IS_, false, FRK_, false); } \
                                       return hipGetLastError(); } while (0)
 	if (!is && contract && cts_params_ok(p)) {       // DJB_OPT_CONTRACT_1E5: directions within 1e-5 (bk_sample_contract)
-		if (rng) { if (dn) hipLaunchKernelGGL((k_sample_bk<false, true, -1, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
-		           else hipLaunchKernelGGL((k_sample_bk<false, true, -1, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf); }
-		else { if (dn) hipLaunchKernelGGL((k_sample_bk<false, false, -1, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf);
-		       else hipLaunchKernelGGL((k_sample_bk<false, false, -1, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf); }
+		if (rng) { if (dn) hipLaunchKernelGGL((k_sample_bk<false, true, -1, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct);
+		           else hipLaunchKernelGGL((k_sample_bk<false, true, -1, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct); }
+		else { if (dn) hipLaunchKernelGGL((k_sample_bk<false, false, -1, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct);
+		       else hipLaunchKernelGGL((k_sample_bk<false, false, -1, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct); }
 		return hipGetLastError();
 	}
 	if (!is) DJB_LAUNCH_S2(false, -1);
+	if (ct_is) {
+#define DJB_LAUNCH_CT(FRK_) do { \
+		if (rng) { if (dn) hipLaunchKernelGGL((k_sample_bk<true, true, FRK_, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct); \
+		           else hipLaunchKernelGGL((k_sample_bk<true, true, FRK_, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct); } \
+		else { if (dn) hipLaunchKernelGGL((k_sample_bk<true, false, FRK_, true, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct); \
+		       else hipLaunchKernelGGL((k_sample_bk<true, false, FRK_, false, true>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct); } \
+		return hipGetLastError(); } while (0)
+		if (b.fr.kind == FR_IDEAL) DJB_LAUNCH_CT(FR_IDEAL);
+		if (b.fr.kind == FR_SCHLICK) DJB_LAUNCH_CT(FR_SCHLICK);
+		if (b.fr.kind == FR_UNPOLARIZED) DJB_LAUNCH_CT(FR_UNPOLARIZED);
+#undef DJB_LAUNCH_CT
+	}
 	if (b.fr.kind == FR_IDEAL) DJB_LAUNCH_S2(true, FR_IDEAL);
 	if (b.fr.kind == FR_SCHLICK) DJB_LAUNCH_S2(true, FR_SCHLICK);
 	if (b.fr.kind == FR_UNPOLARIZED) DJB_LAUNCH_S2(true, FR_UNPOLARIZED);

@@ -333,12 +333,12 @@ def test_contract_beckmann_sample_vs_oracle(ct_ctx, oracle):
             worst = max(worst, check_directions(f"sample/{fam}/{p}", got, want, o))
             differs += int(np.sum(np.ascontiguousarray(got, np.float32).view(np.uint32) != want.view(np.uint32)))
     assert differs > 0, "contract mode returned bit-identical directions everywhere: the fast path did not run"
-    # evalp_is is outside the option's reach: its pdf moves by 1e-3 for a 1e-5 change of direction
+    # evalp_is keeps the reference's DIRECTION under the option (its pdf moves by 1e-3 for a 1e-5 change of direction)
     o = base[:4096]; p = ("elliptic", 0.2, 0.5, 0.7)
     w, i_, pdf = b.evalp_is(torch.from_numpy(u1[:4096]).cuda(), torch.from_numpy(u2[:4096]).cuda(), soa(o), mk_params(p))
     ww, wi, wpdf = oracle.evalp_is(ob, u1[:4096], u2[:4096], o, p)
     bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
-    assert np.array_equal(bits(i_.cpu().numpy().T), bits(wi)) and np.array_equal(bits(pdf.cpu().numpy()), bits(wpdf)) and np.array_equal(bits(w.cpu().numpy().T), bits(ww))
+    assert np.array_equal(bits(i_.cpu().numpy().T), bits(wi))
     print(f"\ncontract-mode Beckmann sample: worst component difference vs the oracle {worst:.3e} (contract {ATOL_DIR})")
 
 
@@ -355,3 +355,42 @@ def test_contract_beckmann_sample_selftest(gpu_ctx):
     assert r["exact_path"] < 0.15 * r["samples"], f"the fast path keeps too little of the bench distribution: {r}"
     with pytest.raises(djb.exc):          # outside the sampler's domain (and a GGX lobe has no contract sampler)
         djb.selftest_contract_sample(djb.ggx(ctx=gpu_ctx), mk_params(("elliptic", 0.3, 0.3, 0.0)), n=1024, ctx=gpu_ctx)
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+def test_contract_evalp_is_vs_oracle(ct_ctx, oracle, ndf):
+    """evalp_is under DJB_OPT_CONTRACT_1E5: the sampled direction is the reference's, bit for bit; weight and pdf are within
+    1e-5 relative with the reference's zero pattern (ct_is_tail) -- bench inputs, grazing and near-normal views, three
+    Fresnel terms, shadowing on / off, dense device batches (the fast path) and a host batch"""
+    import torch
+    n = 1 << 17
+    u1, u2 = synth.uniforms(n, synth.SEED_U1), synth.uniforms(n, synth.SEED_U2)
+    base = synth.directions_aos(n, synth.SEED_O)
+    graz = base.copy(); graz[:, 2] = 0.02 + 0.05 * graz[:, 2]; graz /= np.linalg.norm(graz, axis=1, keepdims=True)
+    near = base * np.array([0.01, 0.01, 0.0], np.float32) + np.array([0, 0, 1], np.float32); near /= np.linalg.norm(near, axis=1, keepdims=True)
+    below = base.copy(); below[::7, 2] *= -1                       # some views below the horizon: weight, pdf and direction all zero
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    worst, differs = 0.0, 0
+    d1, d2 = torch.from_numpy(u1).cuda(), torch.from_numpy(u2).cuda()
+    for fres in (("ideal",), ("schlick", 1.0, 0.71, 0.29), ("unpolarized", 1.5, 1.8, 2.4)):
+        for shadow in (True, False):
+            g = getattr(djb, ndf)(mk_fresnel(fres), shadow, ctx=ct_ctx)
+            ob = oracle.microfacet(ndf, fres, shadow)
+            for fam, o in (("bench", base), ("grazing", graz.astype(np.float32)), ("near-normal", near.astype(np.float32)), ("below", below)):
+                for p in PARAMS[:4] if fam == "bench" else PARAMS[2:3]:
+                    w, i_, pdf = g.evalp_is(d1, d2, soa(o), mk_params(p))
+                    ww, wi, wpdf = oracle.evalp_is(ob, u1, u2, o, p)
+                    name = f"{ndf}/{fres[0]}/{shadow}/{fam}/{p}"
+                    assert np.array_equal(bits(i_.cpu().numpy().T), bits(wi)), f"{name}: sampled directions are not the reference's"
+                    worst = max(worst, check_contract(name + "/weight", w.cpu().numpy().T, ww))
+                    worst = max(worst, check_contract(name + "/pdf", pdf.cpu().numpy(), wpdf))
+                    differs += int(np.sum(bits(pdf.cpu().numpy()) != bits(wpdf)))
+    assert differs > 0, "contract mode returned bit-identical pdfs everywhere: the fast tail did not run"
+    # a host batch through the same option
+    g = getattr(djb, ndf)(ctx=ct_ctx); ob = oracle.microfacet(ndf)
+    p = ("elliptic", 0.2, 0.5, 0.7)
+    w, i_, pdf = g.evalp_is(u1[:5000], u2[:5000], base[:5000], mk_params(p))
+    ww, wi, wpdf = oracle.evalp_is(ob, u1[:5000], u2[:5000], base[:5000], p)
+    assert np.array_equal(bits(i_), bits(wi))
+    check_contract("host/weight", w, ww); check_contract("host/pdf", pdf, wpdf)
+    print(f"\ncontract-mode {ndf} evalp_is: max relative error of weight / pdf vs the oracle {worst:.3e} (contract {RTOL})")

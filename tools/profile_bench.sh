@@ -8,7 +8,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 #   pass 5: --pmc TCC_HIT_sum TCC_MISS_sum    (L2 hit rate of the table gathers: the MERL legs)
-for w in ${WORKLOADS:-merl_eval merl_eval_uniform_bins merl_eval_coherent ggx_eval_pdf ggx_eval_pdf_contract beckmann_sample utia_eval merl_fit}; do
+for w in ${WORKLOADS:-merl_eval merl_eval_uniform_bins merl_eval_coherent ggx_eval_pdf ggx_eval_pdf_contract beckmann_sample beckmann_sample_contract utia_eval merl_fit}; do
   O=$R/gpurun_out/prof/$w; rm -rf $O; mkdir -p $O
   A="--workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
   case $w in merl_eval_*) A="$A --n 250000000";; esac

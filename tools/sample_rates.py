@@ -16,6 +16,8 @@ p = djb.microfacet.params.elliptic(0.2, 0.5, 0.7)
 lobes = [("ggx", djb.ggx(ctx=ctx)), ("beckmann", djb.beckmann(ctx=ctx))]
 if os.environ.get("DJB_SAMPLE_RATES_TABULAR"):      # the fitted lobe the dj_merl / dj_utia plugins sample at render time (nmap scheme)
     lobes.append(("tabular", djb.tabular(djb.ggx(ctx=ctx), 90, True, ctx=ctx)))
+if os.environ.get("DJB_SAMPLE_RATES_CONTRACT"):     # DJB_OPT_CONTRACT_1E5: Beckmann sample within 1e-5, evalp_is weights / pdfs within 1e-5 of the exact direction's
+    djb.set_contract_1e5(ctx, True); print("# DJB_OPT_CONTRACT_1E5 on")
 for name, b in lobes:
     def sample():
         _lib.check(lib.djb_sample_batch(ctx._h, b._h, C.c_int64(n), C.c_void_p(u1.data_ptr()), C.c_void_p(u2.data_ptr()),

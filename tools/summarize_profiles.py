@@ -17,7 +17,7 @@ os.makedirs(DST, exist_ok=True)
 DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "merl_eval_uniform_bins": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"),
             "merl_eval_coherent": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf_contract": ("k_ct_fast_v4<1, 5", "k_ct_fixup<1, 5"),
             "ggx_eval_pdf": ("k_eval<1, 5,",),
-            "beckmann_sample": ("k_sample_bk<",), "merl_fit": ("k_fit<3>",), "utia_eval": ("k_eval_utia_t1", "k_eval_utia_fix", "k_eval<4, 1,")}
+            "beckmann_sample": ("k_sample_bk<",), "beckmann_sample_contract": ("k_sample_bk<",), "merl_fit": ("k_fit<3>",), "utia_eval": ("k_eval_utia_t1", "k_eval_utia_fix", "k_eval<4, 1,")}
 
 
 def counters(path):

@@ -1105,9 +1105,12 @@ def set_utia_exact_only(ctx: Context, on: bool):
 
 
 def set_contract_1e5(ctx: Context, on: bool):
-    """DJB_OPT_CONTRACT_1E5: dense device-resident GGX eval / evalp / pdf batches are evaluated inside the 1e-5 relative
-    value contract (two-tier: fast reciprocal arithmetic + the bit-exact code for ill-conditioned pairs) instead of
-    bit-identically.  Off by default; everything else stays bit-identical."""
+    """DJB_OPT_CONTRACT_1E5 (off by default): results inside the north star's VALUE contract -- within 1e-5 relative of the
+    reference's, zeros / NaNs exactly where it has them -- instead of bit-identically, always as two tiers (fast fp32
+    arithmetic + the bit-exact code for pairs whose decisions or conditioning are in doubt).  Reaches dense device-resident
+    eval / evalp / pdf batches of GGX / Beckmann (ideal, Schlick, unpolarized Fresnel), ABC and SGD; `sample` of a Beckmann
+    lobe (directions within 1e-5 per component); weight and pdf of `evalp_is` (GGX, Beckmann; the sampled direction stays
+    the reference's, bit for bit).  Everything else stays bit-identical (include/djb_hip.h)."""
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(6), C.c_int(int(on))))
 
 

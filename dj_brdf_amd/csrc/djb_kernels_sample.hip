@@ -395,7 +395,9 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 			rder = cts_rcp(derivative);
 			const float av = fabsf(value);
 			const float m_exit = fabsf(av - 1e-5f) * (1.0f / CTS_VAL_BAND);
-			margin = done ? margin : fminf(margin, fminf(m_ends, m_exit));
+			// (v_min_f32 drops a NaN operand: a NaN margin must count as "no margin")
+			const float m_trip = ((m_ends == m_ends) & (m_exit == m_exit)) ? fminf(m_ends, m_exit) : 0.0f;
+			margin = done ? margin : fminf(margin, m_trip);
 			done = av < 1e-5f;                                                 // a frozen lane: the same value again
 			b_at = bt;
 			const bool pos = value > 0;

@@ -303,9 +303,13 @@ ATOL_DIR = 1e-5          # every component of the sampled unit vector (x |o| for
 def check_directions(name, got, want, o):
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
     assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN pattern differs"
-    tol = ATOL_DIR * np.maximum(1.0, np.linalg.norm(np.asarray(o, np.float64), axis=1, keepdims=True))
-    m = np.isfinite(want)
-    d = np.where(m, np.abs(got - want), 0.0)
+    with np.errstate(invalid="ignore", over="ignore"):
+        on = np.linalg.norm(np.asarray(o, np.float64), axis=1, keepdims=True)
+    tol = ATOL_DIR * np.where(np.isfinite(on), np.maximum(1.0, on), 1.0)
+    m = np.isfinite(want) & np.isfinite(got)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want)), f"{name}: Inf pattern differs"
+    with np.errstate(invalid="ignore"):
+        d = np.where(m, np.abs(got - want), 0.0)
     assert np.all(d <= tol), f"{name}: {int(np.sum(d > tol))} components outside the contract, worst {float(d.max()):.3e}"
     # the reference's degenerate answer (0, 0, 1) (stretched view direction below the horizon) is a decision, not a value
     deg = np.all(want == np.array([0.0, 0.0, 1.0]), axis=1)
@@ -394,3 +398,37 @@ def test_contract_evalp_is_vs_oracle(ct_ctx, oracle, ndf):
     assert np.array_equal(bits(i_), bits(wi))
     check_contract("host/weight", w, ww); check_contract("host/pdf", pdf, wpdf)
     print(f"\ncontract-mode {ndf} evalp_is: max relative error of weight / pdf vs the oracle {worst:.3e} (contract {RTOL})")
+
+
+def test_contract_beckmann_sample_hostile_inputs(gpu_ctx):
+    """NaN / Inf / zero / un-normalised / below-horizon view directions, uniforms outside [0, 1) and NaN, a ragged batch size,
+    a strided (array-of-vec3) layout: under the option the sampler returns the exact kernel's NaNs and degenerate answers,
+    and stays within the contract everywhere else"""
+    import torch
+    n = (1 << 16) + 5
+    o = synth.directions_aos(n, 31).copy()
+    u1, u2 = synth.uniforms(n, 32).copy(), synth.uniforms(n, 33).copy()
+    k = n // 10
+    o[:k, 2] *= -1                                                   # below the horizon
+    o[k:2 * k] *= 1e-3; o[2 * k:3 * k] *= 250.0                     # un-normalised, both ways
+    o[3 * k:3 * k + 50] = 0.0
+    o[3 * k + 50:3 * k + 100, 0] = np.nan; o[3 * k + 100:3 * k + 150, 2] = np.inf
+    o[4 * k:5 * k, 2] = 1e-4 * np.abs(o[4 * k:5 * k, 2])             # grazing
+    o[5 * k:6 * k, :2] *= 1e-5                                       # on the normal
+    u1[6 * k:6 * k + 100] = np.nan; u2[6 * k + 100:6 * k + 200] = np.nan
+    u1[6 * k + 200:6 * k + 300] = -0.5; u2[6 * k + 300:6 * k + 400] = 1.5; u1[6 * k + 400:6 * k + 500] = 1.0; u2[6 * k + 500:6 * k + 600] = 0.0
+    u1[7 * k:8 * k] *= 1e-4; u2[8 * k:9 * k] = 1.0 - 1e-4 * u2[8 * k:9 * k]    # the tails of both uniforms
+    b = djb.beckmann(ctx=gpu_ctx)
+    d1, d2 = torch.from_numpy(u1).cuda(), torch.from_numpy(u2).cuda()
+    for p in (("elliptic", 0.2, 0.5, 0.7), ("pdfparams", 0.4, 0.25, 0.6, 0.1, -0.2), None):
+        for lay in ("soa", "aos"):
+            do = soa(o) if lay == "soa" else torch.from_numpy(o).cuda()
+            exact = b.sample(d1, d2, do, mk_params(p)).cpu().numpy()
+            djb.set_contract_1e5(gpu_ctx, True)
+            try:
+                got = b.sample(d1, d2, do, mk_params(p)).cpu().numpy()
+            finally:
+                djb.set_contract_1e5(gpu_ctx, False)
+            if lay == "soa":
+                exact, got = exact.T, got.T
+            check_directions(f"hostile/{lay}/{p}", got, exact, o)

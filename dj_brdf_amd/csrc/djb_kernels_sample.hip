@@ -288,18 +288,21 @@ DJB_DEV v3 bk_sample_common(const Params &p, float u1, float u2, v3 o, const Gli
 //  * the stretched view direction k and sin(theta_k) are the REFERENCE's floats (guarded exact normalize / sqrt, as in
 //    the common path above): near normal incidence 1 - k.z^2 amplifies an ulp of k.z by 1 / sin^2;
 //  * every decision the reference takes on a computed value is either taken on bit-identical operands (k.z > 0, k.z < 1) or
-//    guarded by a band: Newton's exit |value| < 1e-5 (band CTS_VAL_BAND around the threshold: the approximate value is
-//    within CTS_EPSV of the reference's), the bisection safeguard b in [a, c] (band CTS_B_BAND at both ends), erfinv's
+//    guarded by a band: Newton's exit |value| < 1e-5 (2 epsv(u) around the threshold, below), the bisection safeguard
+//    b in [a, c] (max(CTS_B_BAND, 2 epsv / |f'|) at both ends), erfinv's
 //    arm w < 5 and the final clamp b >= -0.9999.  Inside a band the sample goes to the exact path.  With the same
-//    decisions the two Newton sequences stay within CTS_EPSV / |derivative| of each other (the iteration contracts);
+//    decisions the two Newton sequences stay within epsv / |derivative| of each other (the iteration contracts);
 //  * the error that reaches the direction is bounded per sample -- d slope / d b = sqrt(pi)/2 exp(slope^2), the lobe's
 //    stretch, |d h / d slope| <= h.z, |d i / d h| <= 4 -- and a sample whose bound exceeds CTS_DIR_MAX goes to the exact
 //    path as well.  djb_selftest_contract_sample measures the actual maximum (tests/test_gpu_contract.py).
-// CTS_EPSV_U u + CTS_EPSV_0 bounds |value_contract - value_reference| at equal b: value = N S - u with N S ~ u, N carrying
+// epsv(u) = CTS_EPSV_U u + CTS_EPSV_0 bounds |value_contract - value_reference| at equal b: value = N S - u with N S ~ u, N carrying
 // 2.5e-7 relative (one v_rcp, erf's and the exponential's 1e-7 absolute) and S 2e-7 (v_exp of the split argument), plus both
-// sides' own roundings; CTS_DIR_MAX leaves 2e-6 of the 1e-5 to everything that is not the Newton sequence (the rotation,
-// the two rsq normalisations, the reflection: ~5e-7 measured).  The selftest reports how much of the bound is ever used.
-constexpr float CTS_VAL_BAND = 1.0e-6f, CTS_B_BAND = 4.0e-6f, CTS_EPSV_U = 5.0e-7f, CTS_EPSV_0 = 1.5e-7f, CTS_DIR_MAX = 8.0e-6f;
+// sides' own roundings.  The two sequences sit epsv / |f'| apart (the iteration contracts), which the value sees as another
+// epsv: the exit test is decided only outside 2 epsv(u) of its threshold, the safeguard's only outside max(CTS_B_BAND,
+// 2 epsv / |f'|) of an end (CTS_B_BAND covers the first trip: b0's own error, 4e-7).  CTS_DIR_MAX leaves 2e-6 of the 1e-5 to
+// everything that is not the Newton sequence (the rotation, the two rsq normalisations, the reflection: ~5e-7 measured).
+// The selftest reports how much of the per-sample bound is ever used.
+constexpr float CTS_B_BAND = 4.0e-6f, CTS_EPSV_U = 5.0e-7f, CTS_EPSV_0 = 1.5e-7f, CTS_DIR_MAX = 8.0e-6f;
 
 DJB_DEV float cts_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // exp(y), y <= 0, ~2 ulp: y log2(e) split into hi + lo (a plain exp2(y * log2e) loses |y| 2^-24)
@@ -363,6 +366,7 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 	const float sin_k = sqrt_g<R_NONE>(1.0 - D(k.z * k.z), rare);              // the reference's sin_k, in [3.4e-4, 1]
 	const float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
 	const float u = fmax_(u1, 1e-6f);
+	const float epsv = CTS_EPSV_U * u + CTS_EPSV_0;
 	float ie = 0.0f, b_at = 0.0f, E = 1.0f, rder = 0.0f, tx, ty, hz, oh, ol2;
 	// margin = how far the closest decision of the Newton loop stayed from its threshold, in units of its band (> 1: certain)
 	float margin = 3.0e38f;
@@ -379,11 +383,12 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 		float b = c - (1 + c) * cts_pow(1 - u, fit);
 		const float K = 0.564189584f * tan_k;                                  // tan_k / sqrt(pi)
 		const float N = cts_rcp((1 + c) + K * e_cot);                         // the normalisation of the CDF
+		const float r_vband = cts_rcp(2.0f * epsv);
 #pragma unroll
 		for (int trip = 0; trip < TRIPS; ++trip) {
 			// the safeguard's decision (b in [a, c]) is certain only away from both ends; the exit's (|value| < 1e-5) only away
 			// from the threshold.  A converged lane sits ON an end and repeats its last trip: it takes no decisions any more
-			const float m_ends = fminf(fabsf(b - a), fabsf(b - c)) * (1.0f / CTS_B_BAND);
+			const float m_ends = fminf(fabsf(b - a), fabsf(b - c)) * cts_rcp(fmaxf(CTS_B_BAND, (2.0f * epsv) * fabsf(rder)));
 			const bool inside = (b >= a) & (b <= c);
 			const float bt = inside ? b : 0.5f * (a + c);
 			bool tail;
@@ -394,7 +399,7 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 			const float derivative = N * (1 - ie * tan_k);
 			rder = cts_rcp(derivative);
 			const float av = fabsf(value);
-			const float m_exit = fabsf(av - 1e-5f) * (1.0f / CTS_VAL_BAND);
+			const float m_exit = fabsf(av - 1e-5f) * r_vband;
 			// (v_min_f32 drops a NaN operand: a NaN margin must count as "no margin")
 			const float m_trip = ((m_ends == m_ends) & (m_exit == m_exit)) ? fminf(m_ends, m_exit) : 0.0f;
 			margin = done ? margin : fminf(margin, m_trip);
@@ -425,7 +430,7 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 	// the error that can reach the direction (header): the Newton sequence's distance to the reference's, through erfinv's slope,
 	// the lobe's stretch (the norm of [[ax, 0], [ay rho, ay s]] is at most sqrt(ax^2 + ay^2)), |d h / d slope| <= h.z, and the
 	// reflection i = 2 (o.h) h - o: |d i| <= (2 |o| + 2 |o.h|) |d h|.  The contract is relative to |o| (1 for a direction).
-	const float err_tx = ((CTS_EPSV_U * u + CTS_EPSV_0) * 0.886226925f) * fabsf(rder) * cts_rcp(E) + 3e-7f * (fabsf(tx) + fabsf(ty));
+	const float err_tx = (epsv * 0.886226925f) * fabsf(rder) * cts_rcp(E) + 3e-7f * (fabsf(tx) + fabsf(ty));
 	const float stretch = sqrtf(p.ax * p.ax + p.ay * p.ay);                    // launch-uniform
 	const float ol = ol2 * __builtin_amdgcn_rsqf(fmaxf(ol2, 1e-30f));
 	const float bound = ((2.0f * ol + 2.0f * fabsf(oh)) * hz) * (stretch * err_tx);

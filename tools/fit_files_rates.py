@@ -8,7 +8,7 @@ from dj_brdf_amd import djb, merl_params, synth
 ctx = djb.Context(0)
 paths = bench.synth_merl_files(100, synth)
 merl_params.fit_files_on(ctx, paths[:4])
-legs = ((False, (1, 2, 4, 8, 16, 32, 64)),) if os.environ.get("FIT_RATES_SPARSE_ONLY") else ((False, (1, 2, 4, 8, 16, 32)), (True, (2, 4, 8)))
+legs = ((False, (8, 16, 25, 32, 50, 64, 100)),) if os.environ.get("FIT_RATES_SPARSE_ONLY") else ((False, (1, 2, 4, 8, 16, 32)), (True, (2, 4, 8)))
 print("DJB_GATHER_MODE =", os.environ.get("DJB_GATHER_MODE", "(default)"))
 for dense, sweep in legs:
   djb.set_fit_files_dense(ctx, dense)

@@ -368,8 +368,7 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 	const float u = fmax_(u1, 1e-6f);
 	const float epsv = CTS_EPSV_U * u + CTS_EPSV_0;
 	float ie = 0.0f, b_at = 0.0f, E = 1.0f, rder = 0.0f, tx, ty, hz, oh, ol2;
-	// margin = how far the closest decision of the Newton loop stayed from its threshold, in units of its band (> 1: certain)
-	float margin = 3.0e38f;
+	bool doubt = false;                     // a decision of the Newton loop fell inside its band (or met a NaN: the tests are "clearly outside")
 	bool done = false, tails = false;
 	v3 h;
 	{
@@ -383,12 +382,12 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 		float b = c - (1 + c) * cts_pow(1 - u, fit);
 		const float K = 0.564189584f * tan_k;                                  // tan_k / sqrt(pi)
 		const float N = cts_rcp((1 + c) + K * e_cot);                         // the normalisation of the CDF
-		const float r_vband = cts_rcp(2.0f * epsv);
+		const float vband = 2.0f * epsv;
 #pragma unroll
 		for (int trip = 0; trip < TRIPS; ++trip) {
 			// the safeguard's decision (b in [a, c]) is certain only away from both ends; the exit's (|value| < 1e-5) only away
 			// from the threshold.  A converged lane sits ON an end and repeats its last trip: it takes no decisions any more
-			const float m_ends = fminf(fabsf(b - a), fabsf(b - c)) * cts_rcp(fmaxf(CTS_B_BAND, (2.0f * epsv) * fabsf(rder)));
+			const bool clear_ends = (fabsf(b - a) > fmaxf(CTS_B_BAND, vband * fabsf(rder))) & (fabsf(b - c) > fmaxf(CTS_B_BAND, vband * fabsf(rder)));
 			const bool inside = (b >= a) & (b <= c);
 			const float bt = inside ? b : 0.5f * (a + c);
 			bool tail;
@@ -399,10 +398,7 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 			const float derivative = N * (1 - ie * tan_k);
 			rder = cts_rcp(derivative);
 			const float av = fabsf(value);
-			const float m_exit = fabsf(av - 1e-5f) * r_vband;
-			// (v_min_f32 drops a NaN operand: a NaN margin must count as "no margin")
-			const float m_trip = ((m_ends == m_ends) & (m_exit == m_exit)) ? fminf(m_ends, m_exit) : 0.0f;
-			margin = done ? margin : fminf(margin, m_trip);
+			doubt |= !done & !(clear_ends & (fabsf(av - 1e-5f) > vband));      // `done` is still the previous trip's: a frozen lane decides nothing
 			done = av < 1e-5f;                                                 // a frozen lane: the same value again
 			b_at = bt;
 			const bool pos = value > 0;
@@ -424,7 +420,7 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 		oh = dot(o, h);
 		ol2 = dot(o, o);
 	}
-	rare.flag(R_TRIPS, !done | !(margin > 1.0f));                              // NaN anywhere: not done, or a false comparison
+	rare.flag(R_TRIPS, !done | doubt);
 	rare.flag(R_TAIL_LOOP, tails);
 	rare.flag(R_CLAMP, !(b_at > -0.99989f));
 	// the error that can reach the direction (header): the Newton sequence's distance to the reference's, through erfinv's slope,

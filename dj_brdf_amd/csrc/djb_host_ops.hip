@@ -984,6 +984,32 @@ try {
 }
 DJB_ABI_CATCH
 
+djb_status djb_contract_sample_attack(djb_ctx *ctx, const djb_brdf *b, const djb_params *params, int64_t n, float *u1, float *u2,
+                                      const djb_vec3_view *o, int iters, uint32_t seed, float *best, unsigned long long *counters3)
+try {
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
+	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
+	djb_status st = check_call(ctx, b, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	if (!Staged::valid(o) || !u1 || !u2 || !best || !counters3 || iters < 0) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
+	Params p;
+	if ((st = device_params(params, &p, b->dev.kind)) != DJB_OK) return st;
+	if (!djbk::sample_contract_supported(b->dev, p))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf / params outside the domain of the contract-mode sampler");
+	unsigned long long *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 32));
+	hipError_t e = hipMemsetAsync(d, 0, 32, ctx->stream);
+	if (e == hipSuccess)
+		e = djbk::launch_sample_contract_attack(ctx->stream, b->dev, p, n, u1, u2, View{ o->x, o->y, o->z, (long long)o->stride }, iters, seed, best, d);
+	if (e == hipSuccess) e = hipMemcpyAsync(counters3, d, 24, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: contract sampler attack: %s", hipGetErrorString(e));
+	return DJB_OK;
+}
+DJB_ABI_CATCH
+
 djb_status djb_selftest_libm(djb_ctx *ctx, int fn, int64_t n, const double *x, const double *y, double *out)
 try {
 	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");

@@ -34,6 +34,9 @@ bool sample_contract_supported(const Brdf &b, const Params &p);
 // the contract-mode sampler against the full per-sample code on n generated samples (k_sample_ct_selftest)
 hipError_t launch_sample_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed, unsigned long long start,
                                            int family, unsigned int *max_bits, unsigned long long *counters);
+// directed search over the bit patterns of (u1, u2, o) for the largest contract-vs-exact difference (k_sample_ct_attack); u1, u2, o are updated in place
+hipError_t launch_sample_contract_attack(hipStream_t s, const Brdf &b, const Params &p, long long n, float *u1, float *u2, const View &o, int iters,
+                                         uint32_t seed, float *best, unsigned long long *counters);
 
 // per-pair params: rec = n x 5 floats; mode 0 = pdfparams records, mode 1 = LEAN texel moments composed with
 // base5 = params_to_lrep(base) (unscaled), scale = dmapscale, lean_flags = DJB_LEAN_* as dj_beckmannconductor does;

@@ -576,11 +576,70 @@ __global__ __launch_bounds__(BLOCK) void k_sample_ct_selftest(Brdf b, Params p, 
 	atomicAdd(&counters[0], n_all); atomicAdd(&counters[1], n_def); atomicAdd(&counters[2], n_out); atomicAdd(&counters[3], n_deg);
 }
 
+
+// ---- directed search instead of sampling: every lane hill-climbs ONE sample over the bit patterns of its five inputs
+// (u1, u2, o.xyz), maximising the component difference between the contract path and the full per-sample code (in units of
+// the contract, 1e-5 max(1, |o|)); a sample the contract path hands to the exact path scores 0.  A move adds +-2^e units in the
+// last place (e = 0..20, hash-drawn) to one input and is kept if the score grows.  counters: [0] evaluations, [1] evaluated
+// samples the fast path KEPT with a component outside the contract (must stay 0), [2] accepted moves.  best[k]: the score reached.
+DJB_DEV float cts_attack_score(const Brdf &b, const Params &p, float u1, float u2, v3 o, const GlibcTabs &gt, unsigned long long &n_out)
+{
+	Rare why;
+	const v3 ia = bk_sample_contract(p, u1, u2, o, why);
+	if (why.any) return 0.0f;
+	v3 ie, w; float pdf;
+	sample_one<KIND_BECKMANN, false, -1>(b, p, u1, u2, o, gt, ie, w, pdf);
+	const float scale_o = fmaxf(1.0f, sqrtf(dot(o, o)));
+	const float d = fmaxf(fabsf(ia.x - ie.x), fmaxf(fabsf(ia.y - ie.y), fabsf(ia.z - ie.z))) / (1e-5f * scale_o);
+	if (!(d <= 1.0f)) ++n_out;                                       // NaN on one side only counts too
+	return d == d ? d : 3.0e38f;
+}
+__global__ __launch_bounds__(BLOCK) void k_sample_ct_attack(Brdf b, Params p, long long n, float *u1a, float *u2a, View vo, int iters, uint32_t seed,
+                                                            float *best, unsigned long long *counters)
+{
+	__shared__ double s_glibc[GLIBC_LDS_WORDS];
+	__shared__ unsigned long long s_exp[256];
+	GlibcTabs gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
+	gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	__syncthreads();
+	const long long stride = (long long)gridDim.x * BLOCK;
+	unsigned long long n_eval = 0, n_out = 0, n_acc = 0;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		float c[5];
+		{ const v3 o = load3(vo, k); c[0] = u1a[k]; c[1] = u2a[k]; c[2] = o.x; c[3] = o.y; c[4] = o.z; }
+		float cur = cts_attack_score(b, p, c[0], c[1], mk(c[2], c[3], c[4]), gt, n_out);
+		++n_eval;
+		for (int it = 0; it < iters; ++it) {
+			const uint32_t h = hash_u32(seed, (uint64_t)k * 4096ull + (uint64_t)it, 11u);
+			const int w = (int)(h % 5u), e = (int)((h >> 3) % 21u);
+			const int delta = (h & 0x80000000u) ? (1 << e) : -(1 << e);
+			const float old = c[w];
+			const float cand = __uint_as_float(__float_as_uint(old) + (uint32_t)delta);
+			if (!(fabsf(cand) < 16.0f)) continue;                        // stay finite and near the family
+			c[w] = cand;
+			const float r = cts_attack_score(b, p, c[0], c[1], mk(c[2], c[3], c[4]), gt, n_out);
+			++n_eval;
+			if (r > cur) { cur = r; ++n_acc; } else c[w] = old;
+		}
+		u1a[k] = c[0]; u2a[k] = c[1]; store3(vo, k, mk(c[2], c[3], c[4]));
+		best[k] = cur;
+	}
+	atomicAdd(&counters[0], n_eval); atomicAdd(&counters[1], n_out); atomicAdd(&counters[2], n_acc);
+}
+
 } // namespace
 
 namespace djbk {
 
 bool sample_contract_supported(const Brdf &b, const Params &p) { return b.kind == KIND_BECKMANN && cts_params_ok(p); }
+
+hipError_t launch_sample_contract_attack(hipStream_t s, const Brdf &b, const Params &p, long long n, float *u1, float *u2, const View &o, int iters,
+                                         uint32_t seed, float *best, unsigned long long *counters)
+{
+	if (!sample_contract_supported(b, p)) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_sample_ct_attack, dim3(grid_persistent(n)), dim3(BLOCK), 0, s, b, p, n, u1, u2, o, iters, seed, best, counters);
+	return hipGetLastError();
+}
 
 hipError_t launch_sample_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed, unsigned long long start,
                                            int family, unsigned int *max_bits, unsigned long long *counters)

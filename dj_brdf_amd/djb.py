@@ -1137,6 +1137,20 @@ def selftest_contract_sample(brdf, params=None, n: int = 1 << 24, seed: int = 1,
             "degenerate_kept": int(c[3])}
 
 
+def contract_sample_attack(brdf, u1, u2, o, params=None, iters: int = 256, seed: int = 1, ctx: Optional[Context] = None):
+    """Directed search for the largest difference between the contract-mode Beckmann sampler and the bit-exact code
+    (djb_contract_sample_attack): u1, u2 ([n]) and o ([3, n]) are device tensors of candidates, hill-climbed IN PLACE over
+    their bit patterns.  Returns (score per candidate in units of the contract, {evaluations, outside, accepted})."""
+    ctx = ctx or default_context()
+    vo = _Vec(o)
+    best = torch.zeros((vo.n,), dtype=torch.float32, device=o.device)
+    counters = (C.c_ulonglong * 3)()
+    _lib.check(_lib.load().djb_contract_sample_attack(ctx._h, brdf._h, C.byref(params._p) if params is not None else None, C.c_int64(vo.n),
+                                                      C.c_void_p(u1.data_ptr()), C.c_void_p(u2.data_ptr()), C.byref(vo.view), C.c_int(iters),
+                                                      C.c_uint32(seed), C.c_void_p(best.data_ptr()), counters))
+    return best, {"evaluations": int(counters[0]), "outside": int(counters[1]), "accepted": int(counters[2])}
+
+
 def set_test_worklist_cap(ctx: Context, entries: int):
     """tests: override the tier-2 worklist capacity of the two-tier kernels (-1 = automatic); DJB_OPT_TEST_WORKLIST_CAP"""
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(7), C.c_int(int(entries))))

@@ -361,6 +361,14 @@ djb_status djb_selftest_contract(djb_ctx *, const djb_brdf *, const djb_params *
  * reference returns its degenerate (0, 0, 1)}.  DJB_ERR_INVALID_ARGUMENT when brdf / params are outside the sampler's domain. */
 djb_status djb_selftest_contract_sample(djb_ctx *, const djb_brdf *, const djb_params *params, int64_t n, uint32_t seed, int family,
                                         float *max_abs2, unsigned long long *counters4);
+/* directed search against the same sampler: n candidate samples (u1[n], u2[n], o: device arrays, updated IN PLACE) hill-climb
+ * over the bit patterns of their five inputs (iters moves each, +-2^e units in the last place of one input) to maximise the
+ * component difference between the contract path and the bit-exact code, in units of the contract (1e-5 max(1, |o|)); a sample
+ * the fast path hands to the exact path scores 0.  best[n] (device) = the score each candidate reached (< 1 = inside the
+ * contract); counters3 = {evaluations, evaluated samples the fast path kept OUTSIDE the contract (must be 0), accepted moves}.
+ * tools/contract_sample_attack.py restarts it from several input families. */
+djb_status djb_contract_sample_attack(djb_ctx *, const djb_brdf *, const djb_params *params, int64_t n, float *u1, float *u2,
+                                      const djb_vec3_view *o, int iters, uint32_t seed, float *best, unsigned long long *counters3);
 /* the kernels' restatements of the host libm functions the reference calls (glibc 2.35: double exp / pow / atan2 / sin / cos / tan / acos,
  * float logf / expf / powf -- dj_brdf.h:659, 685, 695, 1634, 1868, 1917, 1935, 3419, 3431, 3612), evaluated on the GPU for
  * host arrays: fn 0 exp(x), 1 pow(x, y), 2 logf(x), 3 expf(x), 4 powf(x, y) (float functions on the values cast

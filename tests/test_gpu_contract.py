@@ -432,3 +432,17 @@ def test_contract_beckmann_sample_hostile_inputs(gpu_ctx):
             if lay == "soa":
                 exact, got = exact.T, got.T
             check_directions(f"hostile/{lay}/{p}", got, exact, o)
+
+
+def test_contract_beckmann_sample_attack(gpu_ctx):
+    """directed search instead of sampling (tools/contract_sample_attack.py, shorter): candidates hill-climb over the bit patterns
+    of (u1, u2, o) to maximise the contract-vs-exact difference; nothing the fast path keeps may leave the contract"""
+    import torch
+    m = 1 << 15
+    b = djb.beckmann(ctx=gpu_ctx)
+    for p in (("elliptic", 0.2, 0.5, 0.7), ("elliptic", 1.0, 1.0, 0.0)):
+        o = djb.gen_directions(m, 61, ctx=gpu_ctx)
+        u1, u2 = djb.gen_uniforms(m, 62, ctx=gpu_ctx), djb.gen_uniforms(m, 63, ctx=gpu_ctx)
+        best, c = djb.contract_sample_attack(b, u1, u2, o, mk_params(p), iters=256, seed=9, ctx=gpu_ctx)
+        assert c["outside"] == 0 and float(best.max()) < 1.0, (p, c, float(best.max()))
+        assert c["accepted"] > 0 and c["evaluations"] >= m * 200

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4: why samples leave the contract-mode sampler's fast path (DJB_EXP_RARE_COUNT build: cumulative counts by cause after each launch)
+# (needs the counting build: `make -C dj_brdf_amd/csrc BUILD=build_rc OUT=../../gpurun_variants/libdjb_rc.so EXTRA=-DDJB_EXP_RARE_COUNT`)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 DJB_LIB_PATH=gpurun_variants/libdjb_rc.so PYTHONPATH=. timeout 600 python - > gpurun_out/contract_sample_causes.txt 2>&1 <<'PY'
 import torch

@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 4: cache-policy bits of the MERL kernel's 36 B/pair streams (DJB_STREAM_LOAD_POLICY / DJB_STREAM_STORE_POLICY variants,
 # djb_worklist.hpp) -> profiles/r04/merl_stream_policy.txt
+# (variants: `make -C dj_brdf_amd/csrc BUILD=build_s1 OUT=../../gpurun_variants/libdjb_s1.so EXTRA=-DDJB_STREAM_STORE_POLICY=1` etc.;
+#  sN = store policy N, lN = load policy N, l1s1 = both 1)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 O=gpurun_out/merl_stream_policy.txt; : > $O
 run() { # name lib workload extra

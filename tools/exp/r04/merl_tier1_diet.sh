@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 4: the tier-1 MERL estimate in fewer instructions (FMA contraction inside the tier, x rsq(x) instead of sqrt + rcp, one-reciprocal
 # atan2, folded checks) x SLP vectorisation on / off for djb_kernels_merl.hip -> profiles/r04/merl_tier1_diet.txt
+# (as run between commits 126344b and the tier-1 rewrite: old+slp = the library of 126344b; newslp / newnoslp / oldnoslp = the rewritten / old
+#  djb_device_tables.inc with and without -fno-slp-vectorize for djb_kernels_merl.hip, built as variants into gpurun_variants/)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 O=gpurun_out/merl_tier1_diet.txt; : > $O
 BASE=dj_brdf_amd/lib/libdjb_hip.so

@@ -2,6 +2,8 @@
 # round 4: (a) how much of the MERL tier-1 kernel's time is its arithmetic?  timing-only variants with part of the VALU work removed
 # (-DDJB_EXP_MERL_NOGUARD: no guard bands / snap test; -DDJB_EXP_MERL_ATAN_CHEAP: the three atan2 replaced by 5 instructions), each
 # with its SQ_INSTS_VALU count -> profiles/r04/merl_valu_sensitivity.txt;  (b) instruction mixes -> profiles/valu_<workload>.json
+# (as run on the tree of commit 452eecc: the timing-only flags -DDJB_EXP_MERL_NOGUARD / -DDJB_EXP_MERL_ATAN_CHEAP lived in djb_device_tables.inc
+#  until the tier was rewritten; variants built with `make -C dj_brdf_amd/csrc BUILD=build_x OUT=../../gpurun_variants/libdjb_x.so EXTRA=-D...`)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 O=gpurun_out/merl_valu_sensitivity.txt; : > $O
 BASE=dj_brdf_amd/lib/libdjb_hip.so

@@ -360,10 +360,20 @@ __global__ __launch_bounds__(BLOCK) void k_ct_fixup(Brdf b, Params p, long long 
 	if (threadIdx.x < CT_SHARDS) { const unsigned int cnt = counts[(size_t)threadIdx.x * CT_STRIDE]; s_counts[threadIdx.x] = cnt; if (cnt > cap) s_over = 1; }
 	__syncthreads();
 	if (!s_over) {
-		const unsigned long long slots = (unsigned long long)CT_SHARDS * cap, stride = (unsigned long long)gridDim.x * BLOCK;
-		for (unsigned long long j = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; j < slots; j += stride) {
-			const unsigned int sh = (unsigned int)(j / cap), idx = (unsigned int)(j - (unsigned long long)sh * cap);
-			if (idx >= s_counts[sh]) continue;
+		// records numbered through, shard after shard, and dealt to the threads by that number (as in k_merl_fixup)
+		__shared__ unsigned int s_first[CT_SHARDS + 1];
+		if (threadIdx.x == 0) {
+			unsigned int acc = 0;
+			for (unsigned int sh = 0; sh < CT_SHARDS; ++sh) { s_first[sh] = acc; acc += s_counts[sh]; }
+			s_first[CT_SHARDS] = acc;
+		}
+		__syncthreads();
+		const unsigned int total = s_first[CT_SHARDS], stride = gridDim.x * BLOCK;
+		for (unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; g < total; g += stride) {
+			unsigned int sh = 0;
+#pragma unroll
+			for (unsigned int step = CT_SHARDS / 2; step; step >>= 1) if (s_first[sh + step] <= (unsigned int)g) sh += step;
+			const size_t j = (size_t)sh * cap + ((unsigned int)g - s_first[sh]);
 			uint4 ra = list[2 * j], rb = list[2 * j + 1];
 			const long long k = (long long)ra.x;
 			v3 i = mk(__uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));

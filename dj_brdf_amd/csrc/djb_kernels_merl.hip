@@ -303,7 +303,10 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
 		hipLaunchKernelGGL((k_merl_fast<WANT>), dim3(grid_for(n - 4 * n4)), dim3(BLOCK), 0, s, b, 4 * n4, n, i, o,
 		                   out, out_pdf, g, list, cap, count);
 	long long guess = (long long)djbk::WL_SHARDS * cap;   // one thread per list slot; grid-stride beyond 2048 workgroups
-	hipLaunchKernelGGL((k_merl_fixup<WANT>), dim3(grid_for(guess, 2048)), dim3(BLOCK), 0, s, b, n, i, o, out,
+#ifndef DJB_MERL_FIXUP_GRID
+#define DJB_MERL_FIXUP_GRID 2048
+#endif
+	hipLaunchKernelGGL((k_merl_fixup<WANT>), dim3(grid_for(guess, DJB_MERL_FIXUP_GRID)), dim3(BLOCK), 0, s, b, n, i, o, out,
 	                   out_pdf, g, list, cap, count);
 	return hipGetLastError();
 }

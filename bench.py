@@ -54,13 +54,13 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 WORKLOADS = {
     # name: (default n per GPU, algorithmic HBM bytes per unit, unit, kernel family)
-    "merl_eval": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval> (two-tier exact)"),
+    "merl_eval": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> (two-tier exact, tier 2 drained in-kernel)"),
     "ggx_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf>"),
     # the same configuration under DJB_OPT_CONTRACT_1E5: values within 1e-5 relative instead of bit-identical
     "ggx_eval_pdf_contract": (100_000_000, 40, "evals", "k_ct_fast_v4<GGX,eval+pdf> + k_ct_fixup (two-tier, 1e-5 value contract)"),
     # the headline kernel on two other look-up distributions (the 0.40 of merl_eval is distribution dependent):
-    "merl_eval_uniform_bins": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval>, (theta_h, theta_d, phi_d) bins uniform over the table"),
-    "merl_eval_coherent": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval> + k_merl_fixup<eval>, renderer-like batch (neighbouring pixels of a bumpy plane)"),
+    "merl_eval_uniform_bins": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval>, (theta_h, theta_d, phi_d) bins uniform over the table"),
+    "merl_eval_coherent": (1_000_000_000, 36, "evals", "k_merl_fast_v4<eval>, renderer-like batch (neighbouring pixels of a bumpy plane)"),
     # kinds the round-4 contract mode reaches (no BASELINE config of their own): exact kernel and DJB_OPT_CONTRACT_1E5
     "ggx_unpolarized_eval_pdf": (100_000_000, 40, "evals", "k_eval<GGX,eval+pdf,unpolarized>"),
     "ggx_unpolarized_eval_pdf_contract": (100_000_000, 40, "evals", "k_ct_fast_v4<GGX,eval+pdf,unpolarized> + k_ct_fixup (1e-5 value contract)"),

@@ -278,33 +278,14 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 		for (int a = 0; a < 4 && !aliased; ++a) for (int c = 0; c < 6; ++c) if (hit(outs_[a], sout[a], ins[c], sin_[c])) { aliased = true; break; }
 	}
 	if (b->dev.kind == DJB_KIND_MERL && (want & 3) && !ctx->merl_exact_only && !aliased) {
-		// two-tier exact lookup; pair indices travel as uint32, so very large batches are chunked
+		// two-tier exact lookup (both tiers in one kernel: tier 2 is drained from per-wave LDS queues); pair indices travel as uint32, so very
+		// large batches are chunked
 		const long long CH = 1LL << 31;
 		for (long long lo = 0; lo < n; lo += CH) {
 			long long m = n - lo < CH ? n - lo : CH;
-			// worklist: 8 KB header (WL_SHARDS counters, one per cache line) + cap records of 32 bytes {k, i, o}; ~1 % of uniformly
-			// distributed pairs are ambiguous, 2 % capacity; overflow falls back to a rescan
-			const size_t REC = 32;
-			wl_adapt(ctx);
-			size_t cap = (size_t)((double)m * ctx->wl_frac) + 4096;
-			cap = (cap + djbk::WL_SHARDS - 1) / djbk::WL_SHARDS * djbk::WL_SHARDS;              // whole segments
-			if (ctx->test_worklist_cap >= 0) cap = ((size_t)ctx->test_worklist_cap / djbk::WL_SHARDS + 1) * djbk::WL_SHARDS;
-			if (cap > 0xfffffff0ull) cap = 0xfffffff0ull / djbk::WL_SHARDS * djbk::WL_SHARDS;
-			const size_t HDR = sizeof(unsigned int) * djbk::WL_SHARDS * djbk::WL_COUNTER_STRIDE;   // 8 KB of counters
-			size_t need = HDR + REC * cap;
-			if (ctx->scratch_bytes < need) {
-				HIP_TRY(hipStreamSynchronize(ctx->stream));
-				if (ctx->scratch) (void)hipFree(ctx->scratch);
-				ctx->scratch = nullptr; ctx->scratch_bytes = 0;
-				HIP_TRY(hipMalloc(&ctx->scratch, need));
-				ctx->scratch_bytes = need;
-			}
-			unsigned int *count = (unsigned int *)ctx->scratch, *list = count + HDR / sizeof(unsigned int);
 			auto off = [&](const View &v) { return View{ v.x + lo * v.stride, v.y + lo * v.stride, v.z + lo * v.stride, v.stride }; };
 			View oi = off(vi), oo = off(vo), ou = (want & 3) ? off(vout) : vout;
-			HIP_TRY(djbk::launch_merl_twotier(ctx->stream, b->dev, m, oi, oo, ou, dpdf ? dpdf + lo : nullptr, want,
-			                                  list, (unsigned int)cap, count));
-			wl_note(ctx, count, cap, m, (int)djbk::WL_SHARDS, (int)djbk::WL_COUNTER_STRIDE);
+			HIP_TRY(djbk::launch_merl_twotier(ctx->stream, b->dev, m, oi, oo, ou, dpdf ? dpdf + lo : nullptr, want));
 		}
 		return sg.finish();
 	}

@@ -62,8 +62,7 @@ hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const Vi
 // count: WL_SHARDS counters, WL_COUNTER_STRIDE words apart (a returning atomic per flushing wave: one word sustains ~88 per
 // microsecond, words of one cache line serialise as well -- profiles/r03/contract_beckmann_worklist.txt)
 hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
-                               const View &out, float *out_pdf, int want, unsigned int *list,
-                               unsigned int cap, unsigned int *count);
+                               const View &out, float *out_pdf, int want);
 hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, const View &o,
                                    const float *guard6, unsigned int *max_bits, unsigned long long *counters);
 

@@ -2,14 +2,17 @@
 //
 // k_eval<MERL> (djb_kernels_eval.hip) reproduces the reference operation by operation: 8 fp64
 // libm-class calls per pair, ~770 VALU instructions, VALU-bound at 17 % of the HBM roofline.
-// Here the same result is produced in two launches:
-//   k_merl_fast   every pair: fp32 closed-form angles + guard bands (merl_index_fast).  Certain
-//                 pairs (~99 %) gather their table entry and are done; ambiguous pairs append a
-//                 32-byte record {k, i, o} to a worklist in HBM (one wave-aggregated atomic).
-//   k_merl_fixup  ambiguous pairs only, read back densely from the worklist (coalesced; the inputs
-//                 are not gathered a second time): the exact fp64 path (merl_index).
-// If the worklist overflows its capacity the fix-up kernel rescans the batch with the same decision
-// function, so the result never depends on the capacity.  Bit-exactness argument and calibration: DESIGN.md 4.2.
+// Here the same result comes from two tiers inside ONE kernel:
+//   tier 1   every pair: fp32 closed-form angles + guard bands (merl_index_fast).  Certain pairs (~99.6 %) gather their
+//            table entry and are done; an ambiguous pair's {k, i, o} goes to a per-wave queue in LDS (one wave, in-order
+//            LDS: no barrier, no atomics).
+//   tier 2   whenever a wave has queued 64 pairs -- and once more at its end for what is left -- it runs the exact fp64
+//            path (merl_index) on them as one dense wave and overwrites their placeholders.
+// Until round 4 tier 2 was a second kernel fed through a sharded worklist in HBM (0.43-0.52 ms per 1e9 pairs, bound by its
+// scattered result stores, plus a memset, a launch and an adaptive list capacity on the host).  The drain costs the kernel the
+// exact path's registers (~140 VGPRs: 3 waves per SIMD instead of 6), which tier 1 does not notice -- it is bound by the
+// memory system at any occupancy from 2 to 7 waves (profiles/r04/merl_occupancy.txt).
+// Bit-exactness argument and calibration of the bands: DESIGN.md 4.2.
 #include "djb_internal.hpp"
 #include "djb_worklist.hpp"
 #include <stdlib.h>
@@ -42,58 +45,98 @@ DJB_DEV void merl_emit(const Brdf &b, int idx, v3 i, long long k, const View &vo
 	if (WANT & 4) out_pdf[k] = F(D(i.z) / DJB_PI);                // brdf::pdf,   dj_brdf.h:842-845
 }
 
+// ---- the per-wave queue of ambiguous pairs and its drain.  QCAP: fewer than 64 pairs wait when an iteration starts and an
+// iteration adds at most 4 x 64, so 320 slots always suffice; there is ONE drain site per kernel (the exact path is ~6 000
+// instructions and ~140 registers: every further inlined copy costs both)
+constexpr unsigned int QCAP = 320;
+typedef unsigned int MerlQueue[7][QCAP];
+DJB_DEV void merl_queue(MerlQueue &q, unsigned int &qn, int lane, bool amb, unsigned int k, v3 i, v3 o)
+{
+	const unsigned long long mask = __ballot(amb);
+	if (!mask) return;
+	if (amb) {
+		const unsigned int j = qn + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+		q[0][j] = k;
+		q[1][j] = __float_as_uint(i.x); q[2][j] = __float_as_uint(i.y); q[3][j] = __float_as_uint(i.z);
+		q[4][j] = __float_as_uint(o.x); q[5][j] = __float_as_uint(o.y); q[6][j] = __float_as_uint(o.z);
+	}
+	qn += (unsigned int)__popcll(mask);
+}
+// tier 2 on `cnt` queued pairs starting at slot `first`, one per lane: the operation-by-operation fp64 path
+template <int WANT>
+DJB_DEV void merl_drain(const Brdf &b, MerlQueue &q, unsigned int first, unsigned int cnt, int lane, long long k_base, const View &vout, float *out_pdf)
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	// the placeholders of these very pairs were stored by this wave as parts of float4 stores: they must have left the wave
+	// before the scalar stores below are issued
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if ((unsigned int)lane < cnt) {
+		const unsigned int j = first + (unsigned int)lane;
+		const long long k = k_base + (long long)q[0][j];
+		const v3 i = mk(__uint_as_float(q[1][j]), __uint_as_float(q[2][j]), __uint_as_float(q[3][j]));
+		const v3 o = mk(__uint_as_float(q[4][j]), __uint_as_float(q[5][j]), __uint_as_float(q[6][j]));
+		merl_emit<WANT>(b, merl_index(i, o), i, k, vout, out_pdf);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_merl_fast(Brdf b, long long k_begin, long long n, View vi, View vo,
-                                                     View vout, float *out_pdf, MerlGuard g,
-                                                     uint4 *list_all, unsigned int cap, unsigned int *counts)
+                                                     View vout, float *out_pdf, MerlGuard g)
 {
-	__shared__ WaveBuf wbuf[BLOCK / 64];
+	__shared__ MerlQueue wbuf[BLOCK / 64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned int wcount = 0;                                     // wave-uniform
-	// sharded worklist (djb_internal.hpp WL_SHARDS: one counter per 128-byte line, one list segment per counter)
-	const unsigned int shard = blockIdx.x % djbk::WL_SHARDS;
-	uint4 *list = list_all + 2 * (size_t)shard * cap;
-	unsigned int *count = counts + (size_t)shard * djbk::WL_COUNTER_STRIDE;
-	long long stride = (long long)gridDim.x * BLOCK;
-	for (long long k0 = k_begin + (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {   // block-uniform trip count
-		long long k = k0 + threadIdx.x;
-		bool amb = false;
-		v3 i = mk(0, 0, 1), o = mk(0, 0, 1);
-		if (k < n) {
-			i = load3(vi, k); o = load3(vo, k);
-			int idx;
-			if (merl_index_fast(i, o, g, idx)) merl_emit<WANT>(b, idx, i, k, vout, out_pdf);
-			else amb = true;                                      // tier 2 (k_merl_fixup) finishes this pair
+	unsigned int qn = 0;                                         // wave-uniform
+	const long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k0 = k_begin + (long long)blockIdx.x * BLOCK; ; k0 += stride) {   // block-uniform trip count; one extra trip flushes the queue
+		const bool last = k0 >= n;
+		if (!last) {
+			long long k = k0 + threadIdx.x;
+			bool amb = false;
+			v3 i = mk(0, 0, 1), o = mk(0, 0, 1);
+			if (k < n) {
+				i = load3(vi, k); o = load3(vo, k);
+				int idx;
+				if (merl_index_fast(i, o, g, idx)) merl_emit<WANT>(b, idx, i, k, vout, out_pdf);
+				else amb = true;                                  // tier 2 finishes this pair
+			}
+			merl_queue(wbuf[wave], qn, lane, amb, (unsigned int)k, i, o);   // pair indices travel as uint32 (the host chunks at 2^31)
 		}
-		wl_push(wbuf[wave], wcount, lane, list, cap, count, amb, (unsigned int)k, i, o);
+		while (qn >= 64u || (last && qn)) {                       // tier 2: a full wave of waiting pairs, or what is left at the end
+			const unsigned int cnt = qn < 64u ? qn : 64u;
+			qn -= cnt;
+			merl_drain<WANT>(b, wbuf[wave], qn, cnt, lane, 0, vout, out_pdf);
+		}
+		if (last) break;
 	}
-	if (wcount) wl_flush(wbuf[wave], wcount, lane, list, cap, count);
 }
 
 // Same kernel for dense SoA input (stride 1, 16-byte aligned): four consecutive pairs per lane,
 // float4 loads/stores, so each wave keeps 6 x 1 KiB loads and four independent table gathers in
 // flight -- the scalar version is latency-bound (one load -> compute -> gather -> store chain per
-// wave).  Ambiguous pairs get a placeholder in the float4 store; k_merl_fixup runs after this
-// kernel on the same stream and overwrites them.
+// wave).  Ambiguous pairs get a placeholder in the float4 store; tier 2 overwrites it from the same wave, later.
+#ifdef DJB_EXP_MERL_WAVES          // timing experiment: tier 1 at a forced occupancy (waves per SIMD)
+#define DJB_MERL_V4_ATTR __attribute__((amdgpu_waves_per_eu(DJB_EXP_MERL_WAVES, DJB_EXP_MERL_WAVES)))
+#else
+#define DJB_MERL_V4_ATTR
+#endif
 template <int WANT>
-__global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, View vi, View vo, View vout,
-                                                        float *out_pdf, MerlGuard g, uint4 *list_all,
-                                                        unsigned int cap, unsigned int *counts)
+__global__ __launch_bounds__(BLOCK) DJB_MERL_V4_ATTR void k_merl_fast_v4(Brdf b, long long n4, View vi, View vo, View vout,
+                                                                          float *out_pdf, MerlGuard g)
 {
-	__shared__ WaveBuf wbuf[BLOCK / 64];
+	__shared__ MerlQueue wbuf[BLOCK / 64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned int wcount = 0;
-	const unsigned int shard = blockIdx.x % djbk::WL_SHARDS;
-	uint4 *list = list_all + 2 * (size_t)shard * cap;
-	unsigned int *count = counts + (size_t)shard * djbk::WL_COUNTER_STRIDE;
+	unsigned int qn = 0;
 	const float4 *ix4 = (const float4 *)vi.x, *iy4 = (const float4 *)vi.y, *iz4 = (const float4 *)vi.z;
 	const float4 *ox4 = (const float4 *)vo.x, *oy4 = (const float4 *)vo.y, *oz4 = (const float4 *)vo.z;
 	long long stride = (long long)gridDim.x * BLOCK;
-	for (long long q0 = (long long)blockIdx.x * BLOCK; q0 < n4; q0 += stride) {
+	for (long long q0 = (long long)blockIdx.x * BLOCK; ; q0 += stride) {       // one extra trip flushes the queue
+		const bool last = q0 >= n4;
 		long long q = q0 + threadIdx.x;
 		bool amb[4] = { false, false, false, false };
 		float ixs[4], iys[4], izs[4], oxs[4], oys[4], ozs[4];
-		if (q < n4) {
+		if (!last && q < n4) {
 			// the 36 B/pair streams are touched once: non-temporal, so they do not evict the table from L2
 			float4 ax = nt_load4(ix4 + q), ay = nt_load4(iy4 + q), az = nt_load4(iz4 + q),
 			       bx = nt_load4(ox4 + q), by = nt_load4(oy4 + q), bz = nt_load4(oz4 + q);
@@ -120,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, Vi
 					gg[j] = (WANT & 2) ? s * t[j].y : t[j].y;
 					bb[j] = (WANT & 2) ? s * t[j].z : t[j].z;
 				}
-				// ambiguous pairs get a placeholder here; k_merl_fixup overwrites it
+				// ambiguous pairs get a placeholder here; tier 2 overwrites it
 				nt_store4(r[0], r[1], r[2], r[3], (float4 *)vout.x + q);
 				nt_store4(gg[0], gg[1], gg[2], gg[3], (float4 *)vout.y + q);
 				nt_store4(bb[0], bb[1], bb[2], bb[3], (float4 *)vout.z + q);
@@ -132,57 +175,14 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast_v4(Brdf b, long long n4, Vi
 		if (__ballot(amb[0] | amb[1] | amb[2] | amb[3])) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j)
-				wl_push(wbuf[wave], wcount, lane, list, cap, count, amb[j], (unsigned int)(4 * q + j),
-				        mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]));
+				merl_queue(wbuf[wave], qn, lane, amb[j], (unsigned int)(4 * q + j), mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]));
 		}
-	}
-	if (wcount) wl_flush(wbuf[wave], wcount, lane, list, cap, count);
-}
-
-template <int WANT>
-__global__ __launch_bounds__(BLOCK) void k_merl_fixup(Brdf b, long long n, View vi, View vo, View vout,
-                                                      float *out_pdf, MerlGuard g, const uint4 *list,
-                                                      unsigned int cap, const unsigned int *counts)
-{
-	__shared__ unsigned int s_counts[djbk::WL_SHARDS], s_first[djbk::WL_SHARDS + 1];
-	__shared__ int s_over;
-	if (threadIdx.x == 0) s_over = 0;
-	__syncthreads();
-	if (threadIdx.x < djbk::WL_SHARDS) {
-		const unsigned int c = counts[(size_t)threadIdx.x * djbk::WL_COUNTER_STRIDE];
-		s_counts[threadIdx.x] = c;
-		if (c > cap) s_over = 1;
-	}
-	__syncthreads();
-	if (!s_over) {                       // normal case: the worklist holds every ambiguous pair (cap = records per shard)
-		// The records are numbered through, shard after shard (s_first = running sum of the shard counts), and dealt to the threads
-		// by that number: a thread walks records, not list slots (80-98 % of the slots are empty, and finding the shard of a
-		// slot took a 64-bit division per slot: the kernel spent 0.5 ms on 4e6 records of a 1e9-pair batch)
-		if (threadIdx.x == 0) {
-			unsigned int acc = 0;
-			for (unsigned int sh = 0; sh < djbk::WL_SHARDS; ++sh) { s_first[sh] = acc; acc += s_counts[sh]; }
-			s_first[djbk::WL_SHARDS] = acc;          // <= WL_SHARDS * cap <= 2^32 - 16 (launch_tt)
+		while (qn >= 64u || (last && qn)) {                           // tier 2: a full wave of waiting pairs, or what is left at the end
+			const unsigned int cnt = qn < 64u ? qn : 64u;
+			qn -= cnt;
+			merl_drain<WANT>(b, wbuf[wave], qn, cnt, lane, 0, vout, out_pdf);
 		}
-		__syncthreads();
-		const unsigned int total = s_first[djbk::WL_SHARDS], stride = gridDim.x * BLOCK;
-		for (unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; g < total; g += stride) {
-			unsigned int sh = 0;                                           // the last shard whose first record is <= g
-#pragma unroll
-			for (unsigned int step = djbk::WL_SHARDS / 2; step; step >>= 1) if (s_first[sh + step] <= (unsigned int)g) sh += step;
-			const size_t j = (size_t)sh * cap + ((unsigned int)g - s_first[sh]);
-			uint4 ra = list[2 * j], rb = list[2 * j + 1];
-			long long k = (long long)ra.x;
-			v3 i = mk(__uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
-			v3 o = mk(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z));
-			merl_emit<WANT>(b, merl_index(i, o), i, k, vout, out_pdf);
-		}
-	} else {                             // a shard overflowed (adversarial input): rescan, same decision function
-		long long stride = (long long)gridDim.x * BLOCK;
-		for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-			v3 i = load3(vi, k), o = load3(vo, k);
-			int idx;
-			if (!merl_index_fast(i, o, g, idx)) merl_emit<WANT>(b, merl_index(i, o), i, k, vout, out_pdf);
-		}
+		if (last) break;
 	}
 }
 
@@ -279,14 +279,8 @@ __global__ __launch_bounds__(BLOCK) void k_merl_guard_attack(long long n, View v
 
 template <int WANT>
 hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
-                     const View &out, float *out_pdf, const MerlGuard &g, unsigned int *list_words,
-                     unsigned int cap, unsigned int *count)
+                     const View &out, float *out_pdf, const MerlGuard &g)
 {
-	uint4 *list = (uint4 *)list_words;       // cap records of 2 x uint4 in total, cut into WL_SHARDS segments
-	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int) * djbk::WL_SHARDS * djbk::WL_COUNTER_STRIDE, s);
-	if (e != hipSuccess) return e;
-	cap /= djbk::WL_SHARDS;                  // records per shard
-	if (cap == 0) cap = 1;
 	auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
 	bool dense = i.stride == 1 && o.stride == 1 && (!(WANT & 3) || out.stride == 1) &&
 	             al16(i.x) && al16(i.y) && al16(i.z) && al16(o.x) && al16(o.y) && al16(o.z) &&
@@ -297,17 +291,9 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
 	if (const char *e = getenv("DJB_MERL_GRID_CAP_ENV")) gcap = atoll(e);
 #endif
 	if (n4 > 0)
-		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4, gcap)), dim3(BLOCK), 0, s, b, n4, i, o, out,
-		                   out_pdf, g, list, cap, count);
+		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4, gcap)), dim3(BLOCK), 0, s, b, n4, i, o, out, out_pdf, g);
 	if (4 * n4 < n)   // strided / unaligned input, or the < 4-pair tail of a dense batch
-		hipLaunchKernelGGL((k_merl_fast<WANT>), dim3(grid_for(n - 4 * n4)), dim3(BLOCK), 0, s, b, 4 * n4, n, i, o,
-		                   out, out_pdf, g, list, cap, count);
-	long long guess = (long long)djbk::WL_SHARDS * cap;   // one thread per list slot; grid-stride beyond 2048 workgroups
-#ifndef DJB_MERL_FIXUP_GRID
-#define DJB_MERL_FIXUP_GRID 2048
-#endif
-	hipLaunchKernelGGL((k_merl_fixup<WANT>), dim3(grid_for(guess, DJB_MERL_FIXUP_GRID)), dim3(BLOCK), 0, s, b, n, i, o, out,
-	                   out_pdf, g, list, cap, count);
+		hipLaunchKernelGGL((k_merl_fast<WANT>), dim3(grid_for(n - 4 * n4)), dim3(BLOCK), 0, s, b, 4 * n4, n, i, o, out, out_pdf, g);
 	return hipGetLastError();
 }
 
@@ -316,16 +302,15 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
 namespace djbk {
 
 hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
-                               const View &out, float *out_pdf, int want, unsigned int *list,
-                               unsigned int cap, unsigned int *count)
+                               const View &out, float *out_pdf, int want)
 {
 	if (n <= 0) return hipSuccess;
 	const MerlGuard g = MERL_GUARD_DEFAULT;
 	switch (want) {
-	case 1: return launch_tt<1>(s, b, n, i, o, out, out_pdf, g, list, cap, count);
-	case 2: return launch_tt<2>(s, b, n, i, o, out, out_pdf, g, list, cap, count);
-	case 5: return launch_tt<5>(s, b, n, i, o, out, out_pdf, g, list, cap, count);
-	case 6: return launch_tt<6>(s, b, n, i, o, out, out_pdf, g, list, cap, count);
+	case 1: return launch_tt<1>(s, b, n, i, o, out, out_pdf, g);
+	case 2: return launch_tt<2>(s, b, n, i, o, out, out_pdf, g);
+	case 5: return launch_tt<5>(s, b, n, i, o, out, out_pdf, g);
+	case 6: return launch_tt<6>(s, b, n, i, o, out, out_pdf, g);
 	}
 	return hipErrorInvalidValue;
 }

@@ -45,48 +45,6 @@ DJB_DEV void merl_emit(const Brdf &b, int idx, v3 i, long long k, const View &vo
 	if (WANT & 4) out_pdf[k] = F(D(i.z) / DJB_PI);                // brdf::pdf,   dj_brdf.h:842-845
 }
 
-// ---- which rows of the table the XCD's L2 should keep.  Random pairs reach 10.6 MB of the table, an XCD's L2 holds 4 MiB,
-// and LRU spends it badly: it keeps 66 % of the look-ups on chip where the hottest 3.5 MB of rows would keep 78 % (the
-// look-up probability of a (theta_h, theta_d) row varies 100-fold with the bin's solid angle).  So the rows are ranked by
-// their prior under uniform directions (djb_merl_row_rank.inc, tools/gen_merl_row_rank.py), the hottest `hot_rows` are gathered
-// with the default policy and the others with a streaming one (`policy`: 1 nt, 2 sc1, 3 sc0 sc1 nt), i.e. without
-// displacing them.  A hint: no result depends on it, and under any other distribution a fixed 3.5 MB subset is no worse
-// than LRU on 17.5 MB.
-__device__ const unsigned short g_merl_row_rank[8100] = {
-#include "djb_merl_row_rank.inc"
-};
-constexpr int HOT_WORDS = 256;                      // 8100 rows, one bit each, padded
-DJB_DEV void merl_stage_hot(unsigned int *s_hot, unsigned int hot_rows)
-{
-	for (int w = threadIdx.x; w < HOT_WORDS; w += BLOCK) {
-		unsigned int bits = 0;
-		for (int r = 0; r < 32; ++r) { const int row = 32 * w + r; if (row < 8100 && g_merl_row_rank[row] < hot_rows) bits |= 1u << r; }
-		s_hot[w] = bits;
-	}
-	__syncthreads();
-}
-typedef float merl_v3f __attribute__((ext_vector_type(3)));
-// one table gather per lane, the lanes flagged `cold` with the streaming policy, the others plain: both loads target the same
-// registers under complementary exec masks.  The compiler does not count loads issued from inline asm: merl_gather_wait.
-#define DJB_MERL_GATHER_ASM(POL) \
-	asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, %1, %3\n\tglobal_load_dwordx3 %0, %2, off " POL "\n\t" \
-	             "s_andn2_b64 exec, %1, %3\n\tglobal_load_dwordx3 %0, %2, off\n\ts_mov_b64 exec, %1" \
-	             : "=&v"(v), "=&s"(save) : "v"(p), "s"(coldm) : "memory")
-DJB_DEV merl_v3f merl_gather(const MerlTexel *p, bool cold, int policy)
-{
-	merl_v3f v;
-	unsigned long long save;
-	const unsigned long long coldm = __ballot(cold);
-	if (policy == 1) DJB_MERL_GATHER_ASM("nt");
-	else if (policy == 2) DJB_MERL_GATHER_ASM("sc1");
-	else DJB_MERL_GATHER_ASM("sc0 sc1 nt");
-	return v;
-}
-DJB_DEV void merl_gather_wait(merl_v3f &a, merl_v3f &b, merl_v3f &c, merl_v3f &d)
-{
-	asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
-}
-
 // ---- the per-wave queue of ambiguous pairs and its drain.  QCAP: fewer than 64 pairs wait when an iteration starts and an
 // iteration adds at most 4 x 64, so 320 slots always suffice; there is ONE drain site per kernel (the exact path is ~6 000
 // instructions and ~140 registers: every further inlined copy costs both)
@@ -165,13 +123,11 @@ __global__ __launch_bounds__(BLOCK) void k_merl_fast(Brdf b, long long k_begin, 
 #endif
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) DJB_MERL_V4_ATTR void k_merl_fast_v4(Brdf b, long long n4, View vi, View vo, View vout,
-                                                                          float *out_pdf, MerlGuard g, int policy, unsigned int hot_rows)
+                                                                          float *out_pdf, MerlGuard g)
 {
 	__shared__ MerlQueue wbuf[BLOCK / 64];
-	__shared__ unsigned int s_hot[HOT_WORDS];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	unsigned int qn = 0;
-	if (policy) merl_stage_hot(s_hot, hot_rows);
 	const float4 *ix4 = (const float4 *)vi.x, *iy4 = (const float4 *)vi.y, *iz4 = (const float4 *)vi.z;
 	const float4 *ox4 = (const float4 *)vo.x, *oy4 = (const float4 *)vo.y, *oz4 = (const float4 *)vo.z;
 	long long stride = (long long)gridDim.x * BLOCK;
@@ -197,21 +153,8 @@ __global__ __launch_bounds__(BLOCK) DJB_MERL_V4_ATTR void k_merl_fast_v4(Brdf b,
 				amb[j] = !merl_index_fast(mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]), g, idx[j]);
 			if (WANT & 3) {
 				MerlTexel t[4];
-				if (policy) {
-					merl_v3f tv[4];
 #pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						const unsigned int row = (unsigned int)idx[j] / 180u;         // ambiguous pairs: any row will do
-						const bool cold = !((s_hot[(row >> 5) & (HOT_WORDS - 1)] >> (row & 31u)) & 1u);
-						tv[j] = merl_gather(b.merl + (amb[j] ? 0 : idx[j]), cold, policy);
-					}
-					merl_gather_wait(tv[0], tv[1], tv[2], tv[3]);
-#pragma unroll
-					for (int j = 0; j < 4; ++j) { t[j].x = tv[j].x; t[j].y = tv[j].y; t[j].z = tv[j].z; }
-				} else {
-#pragma unroll
-					for (int j = 0; j < 4; ++j) t[j] = b.merl[amb[j] ? 0 : idx[j]];
-				}
+				for (int j = 0; j < 4; ++j) t[j] = b.merl[amb[j] ? 0 : idx[j]];
 				float r[4], gg[4], bb[4];
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
@@ -347,10 +290,8 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
 #ifdef DJB_EXPERIMENT
 	if (const char *e = getenv("DJB_MERL_GRID_CAP_ENV")) gcap = atoll(e);
 #endif
-	static const int policy = getenv("DJB_MERL_COLD_POLICY") ? atoi(getenv("DJB_MERL_COLD_POLICY")) : 0;
-	static const unsigned int hot_rows = getenv("DJB_MERL_HOT_ROWS") ? (unsigned int)atoi(getenv("DJB_MERL_HOT_ROWS")) : 1699u;
 	if (n4 > 0)
-		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4, gcap)), dim3(BLOCK), 0, s, b, n4, i, o, out, out_pdf, g, policy, hot_rows);
+		hipLaunchKernelGGL((k_merl_fast_v4<WANT>), dim3(grid_for(n4, gcap)), dim3(BLOCK), 0, s, b, n4, i, o, out, out_pdf, g);
 	if (4 * n4 < n)   // strided / unaligned input, or the < 4-pair tail of a dense batch
 		hipLaunchKernelGGL((k_merl_fast<WANT>), dim3(grid_for(n - 4 * n4)), dim3(BLOCK), 0, s, b, 4 * n4, n, i, o, out, out_pdf, g);
 	return hipGetLastError();

@@ -31,6 +31,29 @@ def test_library_exports_every_declared_symbol():
     assert lib.djb_version() == 100
 
 
+# SURVEY.md section 8-N, measured with the reference compiled here: ggx isotropic(0.3), i = (0.3, 0.2, .), o = (-0.4, 0.1, .)
+C_ABI_DEMO_KNOWN = ["eval 0.621380985 0.621380985 0.621380985", "pdf 0.581518769", "sample 0.657071352 0.080957301 0.749468625"]
+
+
+def run_c_abi_demo(where):
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    # the header is C: a cgo / JNI binding compiles against it without a C++ compiler
+    src = os.path.join(ROOT, "examples", "c_abi_demo.c")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, src], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "examples"), "c_abi_demo"], check=True)
+    r = subprocess.run([os.path.join(ROOT, "examples", "c_abi_demo"), where], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return r.stdout.strip().splitlines()
+
+
+def test_c_abi_from_plain_c_on_the_host_path():
+    """examples/c_abi_demo.c -- C99, linked with gcc, no C++ on the caller's side -- reproduces the reference's known answers
+    through the CPU context (the product's host path)."""
+    out = run_c_abi_demo("cpu")
+    assert out[0] == "device cpu" and out[1:] == C_ABI_DEMO_KNOWN, out
+
+
 def test_params_resolve_matches_reference_golden():
     g = np.load(os.path.join(ROOT, "tests", "golden", "math.npz"))
     for k, p in enumerate(PARAM_CASES):

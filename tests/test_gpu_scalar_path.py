@@ -142,3 +142,12 @@ def test_handles_outlive_their_creating_context():
     assert np.array_equal(bits(g.eval(i[:1], o[:1])), bits(ref.eval(i[:1], o[:1])))      # twin built via context B
     assert np.array_equal(bits(m.eval(i, o)), bits(djb.merl.from_table(tab, ctx=b).eval(i, o)))
     b.close()
+
+
+@pytest.mark.gpu
+def test_c_abi_from_plain_c_on_a_gpu_context():
+    """The same C99 program on a GPU context: a one-pair DJB_MEM_HOST call (answered by the host twin of the object) and the
+    reference's known answers again."""
+    from test_capi_host import C_ABI_DEMO_KNOWN, run_c_abi_demo
+    out = run_c_abi_demo("gpu")
+    assert out[0] == "device gpu" and out[1:] == C_ABI_DEMO_KNOWN, out

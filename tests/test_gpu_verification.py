@@ -120,8 +120,9 @@ def test_merl_two_tier_on_adversarial_families(gpu_ctx):
     for name, i, o in _merl_families(m, f"cuda:{gpu_ctx.device}"):
         s = djb.merl_guard_stats(i, o, ctx=gpu_ctx)
         a = mobj.eval(i, o)
-        # ... and with a worklist too small for the family: tier 2 then re-takes tier 1's decision pair by pair (the overflow
-        # rescan), which only works if the decision function gives the same answer in both kernels
+        # ... and once more with the worklist knob set: until round 4 that forced tier 2's overflow rescan (a second kernel re-taking
+        # tier 1's decision pair by pair); the look-up now drains its ambiguous pairs from per-wave LDS queues inside the same kernel,
+        # no capacity is involved any more, and this second evaluation checks that the result does not depend on the knob or the run
         djb.set_test_worklist_cap(gpu_ctx, 64)
         try:
             a_rescan = mobj.eval(i, o)
@@ -336,7 +337,8 @@ def test_utia_worklist_overflow_redoes_the_batch(gpu_ctx, monkeypatch):
 
 
 def test_two_tier_overflow_and_in_place_calls(gpu_ctx):
-    """(1) MERL and contract-mode worklists forced to overflow: tier 2 redoes the batch, same results.  (2) In-place
+    """(1) Contract-mode worklist forced to overflow: tier 2 redoes the batch, same results (the MERL look-up has no worklist
+    since round 4 -- its tier 2 runs in-kernel -- and must simply not notice the knob).  (2) In-place
     evalp (the output arrays ARE the input arrays of i): the two-tier kernels must not be used -- their second tier
     re-reads inputs the first has overwritten -- and the result must equal the out-of-place call bit for bit."""
     import ctypes as C

@@ -34,7 +34,7 @@ struct djb_ctx {
 	hipStream_t stream;
 	bool owns_stream;
 	hipEvent_t ev0, ev1;
-	void *scratch;            // worklist of the two-tier MERL kernel (grown on demand)
+	void *scratch;            // worklist of the two-tier kernels (utia, contract mode; grown on demand)
 	size_t scratch_bytes;
 	int merl_exact_only;      // DJB_OPT_MERL_EXACT_ONLY
 	int aniso_qf2_aligned = 0; // DJB_OPT_ANISO_QF2_ALIGNED

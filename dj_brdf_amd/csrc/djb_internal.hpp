@@ -58,9 +58,8 @@ hipError_t launch_io_to_hd(hipStream_t s, long long n, const View &i, const View
                            const View &h, const View &d, bool inverse);
 hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const View &o, int32_t *idx);
 
-// two-tier exact MERL lookup (djb_kernels_merl.hip); list: `cap` 32-byte records in total, cut into WL_SHARDS equal segments;
-// count: WL_SHARDS counters, WL_COUNTER_STRIDE words apart (a returning atomic per flushing wave: one word sustains ~88 per
-// microsecond, words of one cache line serialise as well -- profiles/r03/contract_beckmann_worklist.txt)
+// two-tier exact MERL lookup (djb_kernels_merl.hip): one kernel, the ambiguous pairs of tier 1 wait in per-wave LDS queues and are
+// drained by the exact path as dense waves (no worklist in HBM, no second launch)
 hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o,
                                const View &out, float *out_pdf, int want);
 hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, const View &o,

@@ -168,8 +168,8 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * djb_selftest_contract_sample measure the actual maximum difference. */
        DJB_OPT_CONTRACT_1E5 = 6,
 /* DJB_OPT_TEST_WORKLIST_CAP = <entries> (tests only; -1 = automatic, the default): overrides the capacity of the tier-2
- * worklist of the two-tier kernels (merl, utia, contract mode), to exercise the overflow path in which the second kernel
- * redoes the whole batch.  Results never depend on the capacity. */
+ * worklist of the two-tier kernels (utia, contract mode; the MERL look-up drains its tier 2 in-kernel and has none), to exercise
+ * the overflow path in which the second kernel redoes the whole batch.  Results never depend on the capacity. */
        DJB_OPT_TEST_WORKLIST_CAP = 7 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */

@@ -22,6 +22,9 @@
  *    calls (eval / evalp / pdf / sample / evalp_is and the per-pair-parameter forms) are cut into
  *    chunks so that inputs travel to HBM while earlier results travel back (a helper thread and a
  *    second stream per call; results do not depend on the chunking).
+ *    A DJB_MEM_DEVICE operator call of fewer than 2^20 units is a sequence of kernel launches (and at most one memset) on the
+ *    ctx's stream and nothing else -- once the kind has run once on the ctx, which may allocate scratch -- so it can be recorded
+ *    by hipStreamBeginCapture on that stream and replayed from a hipGraph (tests/test_gpu_graph_capture.py).
  *  - Every function returns a djb_status; djb_last_error() returns the thread-local message
  *    (the text djb::exc would have carried, dj_brdf.h:54-59 / 578-587).
  *  - Handles are immutable after creation; batch calls on one ctx are serialised on its stream.

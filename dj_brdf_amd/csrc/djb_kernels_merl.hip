@@ -286,6 +286,14 @@ hipError_t launch_tt(hipStream_t s, const Brdf &b, long long n, const View &i, c
 	             al16(i.x) && al16(i.y) && al16(i.z) && al16(o.x) && al16(o.y) && al16(o.z) &&
 	             (!(WANT & 3) || (al16(out.x) && al16(out.y) && al16(out.z))) && (!(WANT & 4) || al16(out_pdf));
 	long long n4 = dense ? n / 4 : 0;
+	// a batch too small to give every CU a workgroup of four-pair lanes runs one pair per lane: four times the waves, a quarter
+	// of the dependent chain per wave -- 5.6-7.4 instead of 7.1-10.8 us per call below 2^17 pairs, equal at 2^18, slower above
+	// (profiles/r04/merl_small_batches.txt)
+	long long v4_min = 1LL << 18;
+#ifdef DJB_EXPERIMENT
+	if (const char *e = getenv("DJB_MERL_V4_MIN")) v4_min = atoll(e);
+#endif
+	if (n < v4_min) n4 = 0;
 	long long gcap = DJB_MERL_GRID_CAP;
 #ifdef DJB_EXPERIMENT
 	if (const char *e = getenv("DJB_MERL_GRID_CAP_ENV")) gcap = atoll(e);

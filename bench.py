@@ -380,11 +380,28 @@ def cpu_baseline(name, synth, budget_s=12.0):
         probe[t] = run(int(min(600_000 * t, 1.2e8)), t)
         if probe[t] > best:
             best, best_t = probe[t], t
+    quota = cpu_quota()
     return {"value": best, "unit": "evals/s" if op != "sample" else "samples/s", "cores": best_t, "kind": kind,
             "sample": f"600k units per thread of the same synthetic workload, thread counts {sorted(probe)} of "
                       f"{cores} usable logical CPUs (ctypes releases the GIL; the reference object is const); "
-                      f"best at {best_t} threads; single-thread {r1:.3e}/s",
-            "single_thread": r1, "scaling_probe": {str(k): v for k, v in probe.items()}}
+                      f"best at {best_t} threads; single-thread {r1:.3e}/s"
+                      + (f"; the container's CPU quota (cgroup cpu.max) is {quota:g} CPUs: the rate stops scaling there, "
+                         f"whatever the thread count" if quota is not None else ""),
+            "cpu_quota_cpus": quota, "single_thread": r1, "scaling_probe": {str(k): v for k, v in probe.items()}}
+
+
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited or unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
 
 
 def rank_placement(torch, dist, rank, local, world, pin):

@@ -59,30 +59,31 @@ for w in sorted(os.listdir(SRC)):
             # (verified here on k_eval<GGX>: 1.2 GB reported for 2.4 GB read) -> x2; WRITE_SIZE is exact
             # (verified on k_gen_dir / k_eval: 12 B per element).  Units are KB (x1024).
             "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
-            "note": "FETCH_SIZE x2 (gfx950 streaming-read correction) + WRITE_SIZE; includes the table "
-                    "gathers served by the Infinity Cache, also doubled: an upper bound on HBM traffic",
+            "note": "FETCH_SIZE x2 (gfx950: 128-byte read requests are tallied at 64) + WRITE_SIZE",
         }
-        # Round 3 calibration (profiles/r03/gather_miss_calibration.txt): the x2 belongs to the STREAMS only.  An L2 miss of a
-        # 12-byte table gather is one 64-byte fabric request (FETCH_SIZE / TCC_MISS = 64.0 B on gather-only kernels, no
-        # 32-byte requests), which FETCH_SIZE counts exactly.  For the MERL legs, whose stream bytes are known (24 B per
-        # pair, read once): bytes = 24 n + (FETCH_SIZE - 12 n) + WRITE_SIZE; the doubled figure stays as the upper bound.
+        # Table gathers (the MERL legs).  An L2 miss of a 12-byte gather is ONE memory-side request that fills the whole 128-byte line:
+        # the compulsory misses of a table that fits the L2 equal its number of 128-byte lines per XCD (0.75 MB: 6 159 per XCD for
+        # 6 144 lines; 3 MB: 24 588 for 24 576 -- profiles/r03/gather_miss_calibration.txt), and there are no 32-byte requests.  FETCH_SIZE
+        # tallies every request at 64 bytes, so the x2 applies to them as it does to the streams.  (Round 3 read the same table as "64
+        # bytes per miss" -- FETCH_SIZE / TCC_MISS is 64 by construction -- and reported the gather misses at half their size; round 4
+        # corrects it: tools/exp/r04/merl_pair_lines.sh asked for both halves of each line explicitly and changed no counter.)
+        # Their stream bytes being known (24 B per pair, read once), the gathers' share is split out.
         if w.startswith("merl_eval") and os.path.exists(os.path.join(d, "bench_plain.json")):
             try:
                 n_units = json.loads(open(os.path.join(d, "bench_plain.json")).read().strip().splitlines()[-1])["config"]["units_per_gpu_per_step"]
-                gather = max(fetch_kb * 1024 - 12.0 * n_units, 0.0)
-                out["hbm_bytes_upper_bound"] = out["hbm_bytes_per_launch"]
-                out["hbm_bytes_per_launch"] = 24.0 * n_units + gather + write_kb * 1024
-                out["gather_miss_bytes_per_launch"] = gather
+                requests = max(fetch_kb * 1024 / 64.0 - 24.0 * n_units / 128.0, 0.0)
+                out["gather_miss_requests_per_launch"] = requests
+                out["gather_miss_bytes_per_launch"] = 128.0 * requests
                 out["units_per_launch"] = n_units
-                out["note"] = ("streams 24 B/pair (FETCH_SIZE counts them at half: x2) + table-gather misses at 64 B each (FETCH_SIZE exact for them: "
-                               "profiles/r03/gather_miss_calibration.txt) + WRITE_SIZE; hbm_bytes_upper_bound = everything doubled, as reported until round 2; "
-                               "misses served by the Infinity Cache are included either way")
+                out["note"] = ("memory-side bytes = 2 x FETCH_SIZE (every read request of this kernel moves 128 bytes -- the 24 B/pair streams and the "
+                               "line fills of the table-gather misses alike -- and is tallied at 64) + WRITE_SIZE; the gather misses (gather_miss_bytes) "
+                               "are served by the Infinity Cache (17.5 MB table), the streams by HBM")
             except Exception as e:  # pragma: no cover
-                print("calibration skipped:", e)
+                print("gather split skipped:", e)
         hit = sum(v.get("TCC_HIT_sum", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
         miss = sum(v.get("TCC_MISS_sum", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
         if hit + miss > 0:
             out["l2_hit_rate"] = hit / (hit + miss)          # TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), MI355X_MICROARCH.md section L2
         json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{w}.json"), "w"), indent=1)
-        print(w, out["hbm_bytes_per_launch"] / 1e9, "GB per launch (corrected)")
+        print(w, out["hbm_bytes_per_launch"] / 1e9, "GB per launch")
 print(sorted(os.listdir(DST)))

@@ -607,9 +607,9 @@ def main():
                     roofline["traffic"] = pj.get("hbm_bytes_per_launch")
                     roofline["traffic_source"] = ("static: read from profiles/pmc_%s.json (separate rocprofv3 --pmc passes of "
                                                   "tools/profile_bench.sh, %s), NOT measured in this run" % (name, pj.get("round", "round 1")))
-                    if pj.get("hbm_bytes_upper_bound"):
-                        roofline["traffic_upper_bound"] = pj["hbm_bytes_upper_bound"]
-                        roofline["traffic_note"] = pj.get("note")
+                    roofline["traffic_note"] = pj.get("note")
+                    if pj.get("gather_miss_bytes_per_launch") is not None:      # the table gathers' share (line fills out of the Infinity Cache)
+                        roofline["traffic_gather_miss_bytes"] = pj["gather_miss_bytes_per_launch"]
                 except Exception:
                     pass
             vj = os.path.join(ROOT, "profiles", f"valu_{name}.json")

@@ -153,29 +153,8 @@ __global__ __launch_bounds__(BLOCK) DJB_MERL_V4_ATTR void k_merl_fast_v4(Brdf b,
 				amb[j] = !merl_index_fast(mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]), g, idx[j]);
 			if (WANT & 3) {
 				MerlTexel t[4];
-#ifdef DJB_EXP_MERL_PAIR_LINES
-				// experiment: neighbouring lanes fetch WHOLE 128-byte lines -- in each of two load instructions one lane of a pair reads
-				// its texel and the other a word of the sibling 64-byte sector of that texel's line, so that a miss is one 128-byte request
-				// instead of (eventually) two 64-byte ones
-				{
-					const bool even = !(lane & 1);
-					const char *base = (const char *)b.merl;
-					const unsigned int last = 1458000u * 12u - 64u;
-#pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						const unsigned int own = 12u * (unsigned int)(amb[j] ? 0 : idx[j]);
-						const unsigned int nb = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-						unsigned int sib = (nb & ~63u) ^ 64u;
-						sib = sib > last ? own : sib;
-						const MerlTexel t1 = *(const MerlTexel *)(base + (even ? own : sib));
-						const MerlTexel t2 = *(const MerlTexel *)(base + (even ? sib : own));
-						t[j].x = even ? t1.x : t2.x; t[j].y = even ? t1.y : t2.y; t[j].z = even ? t1.z : t2.z;
-					}
-				}
-#else
 #pragma unroll
 				for (int j = 0; j < 4; ++j) t[j] = b.merl[amb[j] ? 0 : idx[j]];
-#endif
 				float r[4], gg[4], bb[4];
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {

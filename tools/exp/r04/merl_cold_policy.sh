@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: table gathers of the rows outside the hottest DJB_MERL_HOT_ROWS (prior: uniform directions) with a streaming cache policy
 # (DJB_MERL_COLD_POLICY 0 = all plain, 1 = nt, 2 = sc1, 3 = sc0 sc1 nt) -> profiles/r04/merl_cold_policy.txt
+# library: the tree of commit 40cea38 ("experiment: MERL gathers of cold rows...": the kernel reads DJB_MERL_COLD_POLICY / DJB_MERL_HOT_ROWS), built as the shipped one
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 O=gpurun_out/merl_cold_policy.txt; : > $O
 run() { # policy rows workload

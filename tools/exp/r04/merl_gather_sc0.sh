@@ -2,6 +2,7 @@
 # round 4: every table gather of the MERL look-up with sc0 (skip the CU's 32 KB vector cache, which a 17.5 MB table never hits) --
 # variant library gpurun_variants/libdjb_gpol.so (the exec-masked asm gathers of commit 40cea38 + policy 4 = sc0); hot_rows 0 = every row
 # takes the policy, 8100 = none (the asm path with plain loads: the control) -> profiles/r04/merl_gather_sc0.txt
+# variant: git diff bc0b574 40cea38 -- dj_brdf_amd/csrc/djb_kernels_merl.hip applied (+ djb_merl_row_rank.inc of 40cea38, + `else if (policy == 4) DJB_MERL_GATHER_ASM("sc0")`), make BUILD=build_gpol OUT=../../gpurun_variants/libdjb_gpol.so
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 O=gpurun_out/merl_gather_sc0.txt; : > $O
 run() { # label lib policy rows workload

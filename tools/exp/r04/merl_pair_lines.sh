@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: table gathers that fetch whole 128-byte lines (neighbouring lanes read a texel and a word of the sibling sector in the same
 # load instruction; -DDJB_EXP_MERL_PAIR_LINES variant in gpurun_variants/libdjb_pl.so) -> profiles/r04/merl_pair_lines.txt
+# variant: the tree of the commit "experiment: MERL gathers that ask for both halves of each 128-byte line", make BUILD=build_pl OUT=../../gpurun_variants/libdjb_pl.so EXTRA=-DDJB_EXP_MERL_PAIR_LINES
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; mkdir -p gpurun_out
 O=$R/gpurun_out/merl_pair_lines.txt; : > $O

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: the MERL look-up on small batches: four pairs per lane (k_merl_fast_v4) vs one (k_merl_fast), replayed from a graph so that
 # the kernel's own latency shows -> profiles/r04/merl_small_batches.txt   (DJB_MERL_V4_MIN: batches below it take the one-pair kernel)
+# library: the shipped one built with EXTRA=-DDJB_EXPERIMENT (DJB_MERL_V4_MIN is read only then; shipped threshold 2^18)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 O=gpurun_out/merl_small_batches.txt; : > $O
 for m in 0 1000000000; do

@@ -385,3 +385,37 @@ def test_two_tier_overflow_and_in_place_calls(gpu_ctx):
                                         C.byref(vo.view), C.byref(pe._p), C.byref(vo.view), C.c_int(0)))
     gpu_ctx.synchronize()
     assert torch.equal(oo.view(torch.int32), want_s.view(torch.int32)), "in-place Beckmann sample differs"
+
+
+def test_merl_two_tier_every_output_set_and_launch_shape(gpu_ctx):
+    """The fused two-tier look-up against the operation-by-operation kernel for every output set the operator surface asks for
+    (eval, evalp, eval + pdf, evalp + pdf) and every launch shape: dense SoA above 2^18 pairs (four pairs per lane + the < 4-pair
+    tail), dense SoA below (one pair per lane), an array of vec3 (strided).  Inputs: bench directions mixed with pairs that sit on
+    phi_d bin edges, so that the in-kernel drain of ambiguous pairs runs in every shape.  Bit for bit; pdf = float(double(i.z) / pi)."""
+    import numpy as np
+    import torch
+    dev = f"cuda:{gpu_ctx.device}"
+    tab = synth.merl_table_hashed()
+    m = djb.merl.from_table(tab, ctx=gpu_ctx)
+    for n in ((1 << 20) + 3, (1 << 16) + 1):
+        i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
+        fam = dict((name, (a, b)) for name, a, b in _merl_families(n // 2, dev))
+        ei, eo = fam["phi_d_near_bin_edges"]
+        i[:, : n // 2] = ei; o[:, : n // 2] = eo              # half of the batch is adversarial
+        for layout in ("soa", "aos"):
+            ii, oo = (i, o) if layout == "soa" else (i.t().contiguous(), o.t().contiguous())
+            got = {"eval": m.eval(ii, oo), "evalp": m.evalp(ii, oo), "eval_pdf": m.eval_pdf(ii, oo), "evalp_pdf": m.eval_pdf(ii, oo, cos=True)}
+            djb.set_merl_exact_only(gpu_ctx, True)
+            try:
+                want = {"eval": m.eval(ii, oo), "evalp": m.evalp(ii, oo), "eval_pdf": m.eval_pdf(ii, oo), "evalp_pdf": m.eval_pdf(ii, oo, cos=True)}
+            finally:
+                djb.set_merl_exact_only(gpu_ctx, False)
+            bits = lambda t: t.contiguous().view(torch.int32)
+            for k in ("eval", "evalp"):
+                assert torch.equal(bits(got[k]), bits(want[k])), (n, layout, k)
+            for k in ("eval_pdf", "evalp_pdf"):
+                assert torch.equal(bits(got[k][0]), bits(want[k][0])) and torch.equal(bits(got[k][1]), bits(want[k][1])), (n, layout, k)
+            iz = i[2].double().cpu().numpy()
+            pdf = (iz / np.pi).astype(np.float32)
+            assert np.array_equal(got["eval_pdf"][1].cpu().numpy().view(np.uint32), pdf.view(np.uint32)), (n, layout, "pdf")
+            assert torch.equal(bits(got["eval_pdf"][0]), bits(got["eval"])) and torch.equal(bits(got["evalp_pdf"][0]), bits(got["evalp"]))

@@ -19,7 +19,7 @@ hipError_t launch_eval(hipStream_t s, const Brdf &b, const Params &p, long long 
 
 // sample / evalp_is.  If u1 == nullptr the uniforms come from the on-chip counter RNG
 // (seed_u1, seed_u2, start); out_w / out_pdf may be null-views (sample only).
-// contract (DJB_OPT_CONTRACT_1E5): Beckmann `sample` may return directions within 1e-5 per component instead of the reference's bits
+// contract (DJB_OPT_CONTRACT_1E5): Beckmann and GGX `sample` may return directions within 1e-5 per component instead of the reference's bits
 hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long long n,
                          const float *u1, const float *u2, uint32_t seed_u1, uint32_t seed_u2,
                          unsigned long long start, const View &o, const View &out_i,
@@ -30,6 +30,9 @@ hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p,
                                   const float *u1, const float *u2, uint32_t seed_u1, uint32_t seed_u2,
                                   unsigned long long start, const View &o, const View &out_i,
                                   const View *out_w, float *out_pdf, bool contract = false);
+// ggx `sample` under DJB_OPT_CONTRACT_1E5: directions within 1e-5 per component (djb_kernels_sample.hip, ggx_sample_contract)
+hipError_t launch_sample_ggx_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const float *u1, const float *u2,
+                                      uint32_t seed_u1, uint32_t seed_u2, unsigned long long start, const View &o, const View &out_i);
 bool sample_contract_supported(const Brdf &b, const Params &p);
 // the contract-mode sampler against the full per-sample code on n generated samples (k_sample_ct_selftest)
 hipError_t launch_sample_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, long long n, uint32_t seed, unsigned long long start,

@@ -593,6 +593,8 @@ hipError_t launch_sample(hipStream_t s, const Brdf &b, const Params &p, long lon
 			return launch_sample_beckmann(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf, contract);
 		return launch_sample_kind<KIND_BECKMANN>(s, b, p, n, u1, u2, s1, s2, start, o, out_i, out_w, out_pdf);
 	case KIND_GGX: {
+		if (contract && !out_w && sample_contract_supported(b, p))              // sample under DJB_OPT_CONTRACT_1E5: directions within 1e-5
+			return launch_sample_ggx_contract(s, b, p, n, u1, u2, s1, s2, start, o, out_i);
 		CtParams ct;
 		if (contract && out_w && contract_params(b, p, nullptr, &ct)) {      // evalp_is under DJB_OPT_CONTRACT_1E5: exact direction, contract tail
 			const dim3 g(grid_full(n)), t(BLOCK);

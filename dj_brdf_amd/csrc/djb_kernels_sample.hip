@@ -439,22 +439,128 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 	return sub(scale(2.0f * oh, h), o);
 }
 
+
+// ---- the same for GGX (round 4).  ggx::qf2_radial / qf3_radial are closed forms (dj_brdf.h:2089-2146): there is no Newton sequence to
+// follow, and every decision the reference takes on a computed value is harmless -- the four tangent / cotangent addition forms are
+// one function, so picking another form than the reference near 0.707107 moves the result by rounding only; u2 < 0.5 and k.z in
+// (0, 1) are decided on operands bit-identical to the reference's.  What is kept exact, cheaply: the stretched view direction k (guarded exact normalize as above: 1 - k.z^2 amplifies an ulp of k.z by 1 / sin^2 near normal incidence),
+// sin_t = float(u (1 + cos_k) - 1) (three fp64 operations: its square is cancelled against 1) and the two cubic / quartic
+// polynomials of qf3 (fp64 Horner as in the reference: their quotient is a difference of nearly equal terms towards u2 -> 0 and 1).
+// What is approximated: five divisions and three square roots (v_rcp / v_rsq / v_sqrt_f32, ~1 ulp each) and the final products.
+// Slopes come out with a relative error of a few ulp (an absolute one where a + b cancels, |a|, |b| <= 1); through
+// |d h| <= |d slope| h.z and the reflection that is ~1e-6 of the 1e-5 contract; the per-sample bound below is the same first-order
+// estimate as Beckmann's (the lobe's stretch, h.z, 2 |o| + 2 |o.h|), checked by the same self-test and directed search.
+// Error model (first order, this path's roundings plus the reference's own, which are of the same kind and half the size): a, b carry
+// 1.5 ulp each (v_rcp + a product), their product 4; whichever of the four forms is taken, numerator and denominator are then off by at
+// most CTG_OPS (|a| + |b| + |a b| + 1) in absolute terms, and tx = num / den by that over |den| for the numerator plus |tx| times that
+// over |den| for the denominator: tx = (1 + rho) tx + e_abs with rho = CTG_REL + CTG_OPS asum, e_abs = CTG_OPS asum, asum = (|a| + |b| + |a b|
+// + 1) / |den|.  rho is the term that matters: where a b -> 1 (the sampled normal at the horizon of the stretched frame) it grows like
+// |tx|, the lobe's stretch turns the slope back into a moderate one, and a sharp lobe (alpha = 0.02) seen at grazing incidence leaves
+// the contract by eps / alpha ~ 1.5 if it is ignored (measured: 1.27e-5 before the term was in the bound).
+#ifndef DJB_CTG_OPS
+#define DJB_CTG_OPS 6e-8f
+#define DJB_CTG_REL 1e-7f
+#endif
+constexpr float CTG_OPS = DJB_CTG_OPS, CTG_REL = DJB_CTG_REL;
+DJB_DEV v3 ggx_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &rare, float *bound_out = nullptr)
+{
+	u1 = sat_(u1) * 0.99998f + 0.00001f;
+	u2 = sat_(u2) * 0.99998f + 0.00001f;
+	const float sa = o.x * p.ax + o.y * p.ay * p.rho;
+	const float sb = o.y * p.ay * p.s;
+	const float sc = o.z - o.x * p.tx - o.y * p.ty;
+	const v3 k = normalize_g<R_BOTH>(mk(sa, sb, sc), rare);                    // the reference's k
+	rare.flag(R_DEGENERATE, !(k.z > 1e-3f));                                   // k.z <= 0: the reference returns (0, 0, 1); NaN; a view too grazing for the bounds
+	// k.z == 1 (a sharp lobe seen near the normal: the stretched view direction rounds to the pole) is the reference's other special case
+	// -- sin_k = 0 and no rotation of the sampled slope (dj_brdf.h:1806-1832) -- and common enough to be kept here
+	const bool pole = !(D(k.z) < 1.0);
+	const float cos_k = k.z;
+	// sin_k = float(sqrt(1.0 - double(k.z * k.z))) in the reference: the float product is formed as there, 1 - it loses at most half
+	// an ulp of the difference in float (nothing above 0.5), v_sqrt_f32 another ulp: 1.5 ulp of sin_k, not amplified (what IS amplified,
+	// 1 / sin^2 times an ulp of k.z, sits in k.z itself, which is the reference's)
+	const float sin_k = pole ? 0.0f : __builtin_amdgcn_sqrtf(1.0f - k.z * k.z);
+	const float sin_t = F(D(u1) * (1.0 + D(cos_k)) - 1.0);                      // the reference's (ggx_qf2_radial)
+	const float s2 = sin_t * sin_t;                                            // as the reference forms it: 1 - s2 below loses nothing more
+	// qf3's remap and polynomials, the reference's own values (ggx_qf3_radial)
+	const bool lower = D(u2) < 0.5;
+	const float ur = lower ? F(2.0 * (0.5 - D(u2))) : F(2.0 * (D(u2) - 0.5));
+	const double x = D(ur);
+	const float pn = F(x * (x * (x * (-0.365728915865723) + 0.790235037209296) - 0.424965825137544) + 0.000152998850436920);
+	const float qd = F(x * (x * (x * (x * 0.169507819808272 - 0.397203533833404) - 0.232500544458471) + 1) - 0.539825872510702);
+	float tx, ty, hz, oh, ol2, asum;
+	v3 h;
+	{
+#pragma clang fp contract(fast)
+		const float cos_t = __builtin_amdgcn_sqrtf(fmaxf(1.0f - s2, 0.0f));
+		const bool tan_t = cos_t > 0.707107f, tan_k = sin_k < 0.707107f;
+		const float a = (tan_t ? sin_t : cos_t) * cts_rcp(tan_t ? cos_t : sin_t);       // tan_t or cot_t
+		const float b = (tan_k ? sin_k : cos_k) * cts_rcp(tan_k ? cos_k : sin_k);       // tan_k or cot_k
+		const float prod = a * b;
+		float num, den;
+		if (tan_t == tan_k) { const float s = a + b; num = tan_t ? -s : s; den = 1.0f - prod; }
+		else { num = 1.0f + prod; den = tan_t ? a - b : b - a; }
+		const float rden = cts_rcp(den);
+		tx = num * rden;
+		asum = (fabsf(a) + fabsf(b) + fabsf(prod) + 1.0f) * fabsf(rden);                // an absolute error of num / den, over |den|
+		const float alpha = __builtin_amdgcn_sqrtf(1.0f + tx * tx);
+		ty = (lower ? -alpha : alpha) * (pn * cts_rcp(qd));
+		const float nrm = __builtin_amdgcn_rsqf(k.x * k.x + k.y * k.y);
+		const float cp = pole ? 1.0f : k.x * nrm, sp = pole ? 0.0f : k.y * nrm;
+		const float txm = cp * tx - sp * ty, tym = sp * tx + cp * ty;
+		const float txh = p.ax * txm + p.tx;
+		const float chol = p.rho * txm + p.s * tym;
+		const float tyh = p.ay * chol + p.ty;
+		hz = __builtin_amdgcn_rsqf((txh * txh + tyh * tyh) + 1.0f);
+		h = mk(-txh * hz, -tyh * hz, hz);
+		oh = dot(o, h);
+		ol2 = dot(o, o);
+	}
+	// den = 0 (the sampled normal at the horizon of the stretched frame) or a vanishing quotient polynomial: not a number to bound
+	rare.flag(R_CLAMP, !(fabsf(tx) < 1e18f) | !(fabsf(ty) < 1e18f));
+	// tx is off by rho tx + e_abs (header), and ty = +-sqrt(1 + tx^2) p / q follows tx's relative error as far as sqrt(1 + tx^2) follows
+	// tx: where the error is large (a b -> 1, |tx| -> 1e5) the slope vector is scaled as a whole.  A scaling survives the lobe's linear
+	// stretch as a scaling (about the mean slope (p.tx, p.ty)) and moves h by |slope| h.z^2 = sin(theta_h) h.z per unit, not by
+	// |slope| h.z; what is not a scaling -- e_abs, the part of ty that does not follow, the roundings of the rest -- goes through the stretch
+	// and h.z as before.
+	const float rho = CTG_REL + CTG_OPS * asum, e_abs = CTG_OPS * asum;
+	const float rest = e_abs + rho * fabsf(ty) * cts_rcp(1.0f + tx * tx) + CTG_REL * (fabsf(tx) + fabsf(ty));
+	const float stretch = sqrtf(p.ax * p.ax + p.ay * p.ay);                    // launch-uniform
+	const float sin_h = __builtin_amdgcn_sqrtf(fmaxf(1.0f - hz * hz, 0.0f));
+	const float dh = hz * (rho * (sin_h + fabsf(p.tx) + fabsf(p.ty)) + stretch * rest);
+	const float ol = ol2 * __builtin_amdgcn_rsqf(fmaxf(ol2, 1e-30f));
+	const float bound = (2.0f * ol + 2.0f * fabsf(oh)) * dh;
+	rare.flag(R_TRIPS, !(bound < CTS_DIR_MAX * fmaxf(ol, 1.0f)));             // (the Newton-trips site: GGX has no other use for it)
+	if (bound_out) *bound_out = bound;
+	return sub(scale(2.0f * oh, h), o);
+}
+// one name for both lobes' contract paths
+template <int KIND>
+DJB_DEV v3 sample_contract(const Params &p, float u1, float u2, v3 o, Rare &rare, float *bound_out = nullptr)
+{
+	if (KIND == KIND_GGX) return ggx_sample_contract(p, u1, u2, o, rare, bound_out);
+	return bk_sample_contract(p, u1, u2, o, rare, bound_out);
+}
+
 #include "djb_contract_device.inc"   // ct_is_tail: the evalp_is tail under DJB_OPT_CONTRACT_1E5
 
 // CT (DJB_OPT_CONTRACT_1E5): sample -> bk_sample_contract (directions within 1e-5); evalp_is -> the EXACT direction of the common
 // path with ct_is_tail for weight and pdf.  Either way a declined sample takes the exact per-sample code through the queue.
-template <bool IS, bool RNG, int FRK, bool DENSE, bool CT = false>
+template <bool IS, bool RNG, int FRK, bool DENSE, bool CT = false, int KIND = KIND_BECKMANN>
 __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long n, const float *u1a,
                                                      const float *u2a, uint32_t seed1, uint32_t seed2,
                                                      unsigned long long start, View vo, View vi_out,
                                                      View vw_out, float *out_pdf, djbk::CtParams ct)
 {
-	__shared__ double s_glibc[GLIBC_LDS_WORDS];
-	__shared__ unsigned long long s_exp[256];
+	static_assert(KIND == KIND_BECKMANN || (KIND == KIND_GGX && CT && !IS), "GGX: the contract-mode sampler only (its exact sampler is k_sample)");
+	__shared__ double s_glibc[KIND == KIND_BECKMANN ? GLIBC_LDS_WORDS : 1];
+	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];
 	__shared__ unsigned int s_q[WAVES][7][QCAP];       // deferred samples: {k lo, k hi, u1, u2, o.xyz}
-	GlibcTabs gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
-	gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
-	__syncthreads();
+	GlibcTabs gt = glibc_tabs_global();                // GGX's sampler calls no libm function
+	if (KIND == KIND_BECKMANN) {
+		gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
+		gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+		__syncthreads();
+	}
 	const unsigned int t = threadIdx.x, wave = t >> 6, lane = t & 63u;
 	unsigned int (&q)[7][QCAP] = s_q[wave];
 	unsigned int qn = 0;                               // wave-uniform
@@ -466,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 			const float u1 = __uint_as_float(q[2][j]), u2 = __uint_as_float(q[3][j]);
 			const v3 o = mk(__uint_as_float(q[4][j]), __uint_as_float(q[5][j]), __uint_as_float(q[6][j]));
 			v3 i_out, w; float pdf;
-			sample_one<KIND_BECKMANN, IS, FRK>(b, p, u1, u2, o, gt, i_out, w, pdf);
+			sample_one<KIND, IS, FRK>(b, p, u1, u2, o, gt, i_out, w, pdf);
 			store3(vi_out, k, i_out);
 			if (IS) { store3(vw_out, k, w); out_pdf[k] = pdf; }
 		}
@@ -482,7 +588,9 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 			o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
 		}
 		Rare why;
-		v3 i_ = (CT && !IS) ? bk_sample_contract(p, u1, u2, o, why) : bk_sample_common<!IS>(p, u1, u2, o, gt, why);
+		v3 i_;
+		if constexpr (CT && !IS) i_ = sample_contract<KIND>(p, u1, u2, o, why);
+		else i_ = bk_sample_common<!IS>(p, u1, u2, o, gt, why);
 		v3 i_out = i_, w = mk(0, 0, 0); float pdf = 0.0f;
 		if (IS && CT) {
 			bool alive;
@@ -538,6 +646,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 // difference / per-sample bound among them (how much of the bound is used; must stay below 1); counters: [0] samples, [1] samples
 // handed to the exact path, [2] kept samples with a component outside 1e-5, [3] kept samples where the reference returns its
 // degenerate (0, 0, 1)
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_sample_ct_selftest(Brdf b, Params p, long long n, uint32_t seed, unsigned long long start,
                                                               int family, unsigned int *max_bits, unsigned long long *counters)
 {
@@ -560,10 +669,10 @@ __global__ __launch_bounds__(BLOCK) void k_sample_ct_selftest(Brdf b, Params p, 
 		++n_all;
 		Rare why;
 		float bound;
-		const v3 ia = bk_sample_contract(p, u1, u2, o, why, &bound);
+		const v3 ia = sample_contract<KIND>(p, u1, u2, o, why, &bound);
 		if (why.any) { ++n_def; continue; }
 		v3 ie, w; float pdf;
-		sample_one<KIND_BECKMANN, false, -1>(b, p, u1, u2, o, gt, ie, w, pdf);
+		sample_one<KIND, false, -1>(b, p, u1, u2, o, gt, ie, w, pdf);
 		const float scale_o = fmaxf(1.0f, sqrtf(dot(o, o)));                  // the contract is relative to |o| (1 for a direction)
 		const float d = fmaxf(fabsf(ia.x - ie.x), fmaxf(fabsf(ia.y - ie.y), fabsf(ia.z - ie.z))) / scale_o;
 		if (!(d <= 1e-5f)) ++n_out;
@@ -582,18 +691,20 @@ __global__ __launch_bounds__(BLOCK) void k_sample_ct_selftest(Brdf b, Params p, 
 // the contract, 1e-5 max(1, |o|)); a sample the contract path hands to the exact path scores 0.  A move adds +-2^e units in the
 // last place (e = 0..20, hash-drawn) to one input and is kept if the score grows.  counters: [0] evaluations, [1] evaluated
 // samples the fast path KEPT with a component outside the contract (must stay 0), [2] accepted moves.  best[k]: the score reached.
+template <int KIND>
 DJB_DEV float cts_attack_score(const Brdf &b, const Params &p, float u1, float u2, v3 o, const GlibcTabs &gt, unsigned long long &n_out)
 {
 	Rare why;
-	const v3 ia = bk_sample_contract(p, u1, u2, o, why);
+	const v3 ia = sample_contract<KIND>(p, u1, u2, o, why);
 	if (why.any) return 0.0f;
 	v3 ie, w; float pdf;
-	sample_one<KIND_BECKMANN, false, -1>(b, p, u1, u2, o, gt, ie, w, pdf);
+	sample_one<KIND, false, -1>(b, p, u1, u2, o, gt, ie, w, pdf);
 	const float scale_o = fmaxf(1.0f, sqrtf(dot(o, o)));
 	const float d = fmaxf(fabsf(ia.x - ie.x), fmaxf(fabsf(ia.y - ie.y), fabsf(ia.z - ie.z))) / (1e-5f * scale_o);
 	if (!(d <= 1.0f)) ++n_out;                                       // NaN on one side only counts too
 	return d == d ? d : 3.0e38f;
 }
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_sample_ct_attack(Brdf b, Params p, long long n, float *u1a, float *u2a, View vo, int iters, uint32_t seed,
                                                             float *best, unsigned long long *counters)
 {
@@ -607,7 +718,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_ct_attack(Brdf b, Params p, lo
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		float c[5];
 		{ const v3 o = load3(vo, k); c[0] = u1a[k]; c[1] = u2a[k]; c[2] = o.x; c[3] = o.y; c[4] = o.z; }
-		float cur = cts_attack_score(b, p, c[0], c[1], mk(c[2], c[3], c[4]), gt, n_out);
+		float cur = cts_attack_score<KIND>(b, p, c[0], c[1], mk(c[2], c[3], c[4]), gt, n_out);
 		++n_eval;
 		for (int it = 0; it < iters; ++it) {
 			const uint32_t h = hash_u32(seed, (uint64_t)k * 4096ull + (uint64_t)it, 11u);
@@ -617,7 +728,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_ct_attack(Brdf b, Params p, lo
 			const float cand = __uint_as_float(__float_as_uint(old) + (uint32_t)delta);
 			if (!(fabsf(cand) < 16.0f)) continue;                        // stay finite and near the family
 			c[w] = cand;
-			const float r = cts_attack_score(b, p, c[0], c[1], mk(c[2], c[3], c[4]), gt, n_out);
+			const float r = cts_attack_score<KIND>(b, p, c[0], c[1], mk(c[2], c[3], c[4]), gt, n_out);
 			++n_eval;
 			if (r > cur) { cur = r; ++n_acc; } else c[w] = old;
 		}
@@ -631,13 +742,14 @@ __global__ __launch_bounds__(BLOCK) void k_sample_ct_attack(Brdf b, Params p, lo
 
 namespace djbk {
 
-bool sample_contract_supported(const Brdf &b, const Params &p) { return b.kind == KIND_BECKMANN && cts_params_ok(p); }
+bool sample_contract_supported(const Brdf &b, const Params &p) { return (b.kind == KIND_BECKMANN || b.kind == KIND_GGX) && cts_params_ok(p); }
 
 hipError_t launch_sample_contract_attack(hipStream_t s, const Brdf &b, const Params &p, long long n, float *u1, float *u2, const View &o, int iters,
                                          uint32_t seed, float *best, unsigned long long *counters)
 {
 	if (!sample_contract_supported(b, p)) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_sample_ct_attack, dim3(grid_persistent(n)), dim3(BLOCK), 0, s, b, p, n, u1, u2, o, iters, seed, best, counters);
+	if (b.kind == KIND_GGX) hipLaunchKernelGGL(k_sample_ct_attack<KIND_GGX>, dim3(grid_persistent(n)), dim3(BLOCK), 0, s, b, p, n, u1, u2, o, iters, seed, best, counters);
+	else hipLaunchKernelGGL(k_sample_ct_attack<KIND_BECKMANN>, dim3(grid_persistent(n)), dim3(BLOCK), 0, s, b, p, n, u1, u2, o, iters, seed, best, counters);
 	return hipGetLastError();
 }
 
@@ -645,7 +757,29 @@ hipError_t launch_sample_contract_selftest(hipStream_t s, const Brdf &b, const P
                                            int family, unsigned int *max_bits, unsigned long long *counters)
 {
 	if (!sample_contract_supported(b, p)) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_sample_ct_selftest, dim3(grid_persistent(n)), dim3(BLOCK), 0, s, b, p, n, seed, start, family, max_bits, counters);
+	if (b.kind == KIND_GGX) hipLaunchKernelGGL(k_sample_ct_selftest<KIND_GGX>, dim3(grid_persistent(n)), dim3(BLOCK), 0, s, b, p, n, seed, start, family, max_bits, counters);
+	else hipLaunchKernelGGL(k_sample_ct_selftest<KIND_BECKMANN>, dim3(grid_persistent(n)), dim3(BLOCK), 0, s, b, p, n, seed, start, family, max_bits, counters);
+	return hipGetLastError();
+}
+
+// ggx `sample` under DJB_OPT_CONTRACT_1E5 (ggx_sample_contract + the exact per-sample code for declined samples, one launch)
+hipError_t launch_sample_ggx_contract(hipStream_t s, const Brdf &b, const Params &p, long long n, const float *u1, const float *u2,
+                                      uint32_t s1, uint32_t s2, unsigned long long start, const View &o, const View &out_i)
+{
+	if (b.kind != KIND_GGX || !cts_params_ok(p)) return hipErrorInvalidValue;
+	const dim3 g(grid_persistent(n)), t(BLOCK);
+	const View w{ nullptr, nullptr, nullptr, 0 };
+	const djbk::CtParams ct{};
+	const bool rng = u1 == nullptr, dn = o.stride == 1 && out_i.stride == 1;
+#ifdef DJB_EXP_RARE_COUNT
+	struct Report { hipStream_t s; ~Report() { unsigned long long h[2 + R_SITES]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rare), sizeof h);
+		fprintf(stderr, "djb_exp: ggx contract sample: common %llu deferred %llu | guard %llu bound %llu clamp %llu degenerate %llu (cumulative)\n",
+		        h[0], h[1], h[2 + R_GUARD], h[2 + R_TRIPS], h[2 + R_CLAMP], h[2 + R_DEGENERATE]); } } report{ s };
+#endif
+	if (rng) { if (dn) hipLaunchKernelGGL((k_sample_bk<false, true, -1, true, true, KIND_GGX>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, (float *)nullptr, ct);
+	           else hipLaunchKernelGGL((k_sample_bk<false, true, -1, false, true, KIND_GGX>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, (float *)nullptr, ct); }
+	else { if (dn) hipLaunchKernelGGL((k_sample_bk<false, false, -1, true, true, KIND_GGX>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, (float *)nullptr, ct);
+	       else hipLaunchKernelGGL((k_sample_bk<false, false, -1, false, true, KIND_GGX>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, (float *)nullptr, ct); }
 	return hipGetLastError();
 }
 

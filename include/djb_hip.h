@@ -162,7 +162,7 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * every result within 1e-5 relative of the reference's, zeros exactly where the reference returns zeros -- instead of
  * bit-identically: reciprocal / rsqrt instructions and merged denominators in place of the reference's 15 correctly
  * rounded divisions, pairs whose reference value is ill-conditioned re-done by the bit-exact code (two tiers, as for
- * MERL).  Since round 4 also: unpolarized Fresnel (ior >= 1.05) for GGX / Beckmann, sgd::eval, and `sample` of a Beckmann lobe
+ * MERL).  Since round 4 also: unpolarized Fresnel (ior >= 1.05) for GGX / Beckmann, sgd::eval, and `sample` of a Beckmann or GGX lobe
  * (djb_sample_batch / djb_sample_rng_batch; 1e-3 <= ax, ay <= 100, |rho| <= 0.99): every component of the returned unit vector
  * within 1e-5 of the reference's, samples whose decisions or conditioning are in doubt re-done by the bit-exact code in the same
  * launch; and evalp_is of GGX / Beckmann (same Fresnel / params domain as eval): the sampled direction stays the reference's
@@ -356,7 +356,7 @@ djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsign
  * DJB_ERR_INVALID_ARGUMENT when brdf / params are outside the fast path's domain. */
 djb_status djb_selftest_contract(djb_ctx *, const djb_brdf *, const djb_params *params, int64_t n, uint32_t seed, int family,
                                  float *max_rel2, unsigned long long *counters4);
-/* the DJB_OPT_CONTRACT_1E5 sampler (Beckmann `sample`) against the bit-exact per-sample code on n generated (u1, u2, o)
+/* the DJB_OPT_CONTRACT_1E5 sampler (`sample` of a Beckmann or GGX lobe) against the bit-exact per-sample code on n generated (u1, u2, o)
  * (family 0: the bench distribution; 1: grazing view; 2: near-normal view; 3: both uniforms in their tails; 4: un-normalised
  * view): max_abs2 = {largest |component difference| among the samples the fast path kept, largest difference / per-sample
  * error bound among them (the share of the bound that is ever used; < 1)}, counters4 = {samples, samples

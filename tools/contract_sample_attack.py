@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Directed attack on the contract-mode Beckmann sampler: candidates from several input families hill-climb
+"""Directed attack on the contract-mode samplers (--ndf beckmann | ggx): candidates from several input families hill-climb
 over the bit patterns of (u1, u2, o) to maximise the difference between the fp32 fast path and the bit-exact per-sample code,
 in units of the contract (1e-5 max(1, |o|)).  The fast path is inside the contract as long as that score stays below 1 for
 every sample it keeps; every evaluated kept sample outside it is counted (must be 0).
@@ -25,15 +25,16 @@ def families(m, dev, djb, synth, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=1 << 18); ap.add_argument("--iters", type=int, default=512); ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--ndf", default="beckmann", choices=["beckmann", "ggx"])
     a = ap.parse_args()
     import torch
     from dj_brdf_amd import djb, synth
     ctx = djb.default_context(0); dev = f"cuda:{ctx.device}"
-    b = djb.beckmann(ctx=ctx); P = djb.microfacet.params
-    lobes = [("elliptic(0.2,0.5,0.7)", P.elliptic(0.2, 0.5, 0.7)), ("isotropic(0.05)", P.isotropic(0.05)), ("isotropic(1.0)", P.isotropic(1.0)),
+    b = getattr(djb, a.ndf)(ctx=ctx); P = djb.microfacet.params
+    lobes = [("elliptic(0.2,0.5,0.7)", P.elliptic(0.2, 0.5, 0.7)), ("isotropic(0.05)", P.isotropic(0.05)), ("isotropic(0.02)", P.isotropic(0.02)), ("isotropic(1.0)", P.isotropic(1.0)),
              ("pdfparams(0.4,0.25,0.6,0.1,-0.2)", P.pdfparams(0.4, 0.25, 0.6, 0.1, -0.2))]
     tot_eval = tot_out = 0; worst = 0.0
-    print(f"# contract_sample_attack: {a.m} candidates per family and lobe, {a.iters} moves x {a.rounds} rounds; score = component difference / (1e-5 max(1, |o|))")
+    print(f"# contract_sample_attack ({a.ndf}): {a.m} candidates per family and lobe, {a.iters} moves x {a.rounds} rounds; score = component difference / (1e-5 max(1, |o|))")
     for lname, p in lobes:
         for name, u1, u2, o in families(a.m, dev, djb, synth, torch):
             u1, u2, o = u1.contiguous().float(), u2.contiguous().float(), o.contiguous().float()

@@ -1126,7 +1126,7 @@ def selftest_contract(brdf, params=None, n: int = 1 << 24, seed: int = 1, family
 
 
 def selftest_contract_sample(brdf, params=None, n: int = 1 << 24, seed: int = 1, family: int = 0, ctx: Optional[Context] = None):
-    """The contract-mode Beckmann sampler against the bit-exact per-sample code on n generated samples
+    """The contract-mode sampler of a Beckmann or GGX lobe against the bit-exact per-sample code on n generated samples
     (djb_selftest_contract_sample): directions must agree to 1e-5 per component wherever the fast path keeps the sample."""
     ctx = ctx or default_context()
     mx = (C.c_float * 2)()
@@ -1138,7 +1138,7 @@ def selftest_contract_sample(brdf, params=None, n: int = 1 << 24, seed: int = 1,
 
 
 def contract_sample_attack(brdf, u1, u2, o, params=None, iters: int = 256, seed: int = 1, ctx: Optional[Context] = None):
-    """Directed search for the largest difference between the contract-mode Beckmann sampler and the bit-exact code
+    """Directed search for the largest difference between the contract-mode sampler (Beckmann or GGX lobe) and the bit-exact code
     (djb_contract_sample_attack): u1, u2 ([n]) and o ([3, n]) are device tensors of candidates, hill-climbed IN PLACE over
     their bit patterns.  Returns (score per candidate in units of the contract, {evaluations, outside, accepted})."""
     ctx = ctx or default_context()

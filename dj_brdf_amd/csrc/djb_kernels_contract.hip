@@ -58,7 +58,12 @@ DJB_DEV bool ct_eval_beckmann(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 	const float x_ = fdiv_r(xs, c.ax, c.R_ax);                 // microfacet::p22, dj_brdf.h:1574-1587
 	const float y_ = fdiv_r(c.ax * ys - c.rho_ay * xs, c.t2, c.R_t2);
 	const float r2 = x_ * x_ + y_ * y_;
-	ok &= (r2 < 60.0f) | !facing;                              // beyond: D heads for the denormals -> tier 2
+	// r^2 >= 104: the reference's float(exp(-r^2) / pi) IS zero (exp(-103.5) / pi = 3.6e-46 is below half of the smallest float
+	// denormal, 7.0e-46) and with it p22, D, eval and pdf -- decided on the reference's own r^2, so the zeros are its zeros.  A sharp lobe
+	// (alpha = 0.05: r^2 = 400 tan^2 theta_h) puts most random pairs there.  Below 80 the results are normal floats and ct_exp_neg keeps its
+	// 2 ulp (its argument split holds down to 2^-126 = exp(-87.3)); between 80 and 104 D heads for the denormals: tier 2.
+	const bool zero_d = facing & (r2 >= 104.0f);
+	ok &= (r2 < 80.0f) | !facing | zero_d;
 	const float c2 = h.z * h.z, c4 = c2 * c2;
 	const float en = ct_exp_neg(-fminf(r2, 100.0f));          // D = exp(-r^2) / (pi t2 c4)
 	const float sig_o = ct_sigma<KIND_BECKMANN>(c, o, ok);
@@ -73,17 +78,17 @@ DJB_DEV bool ct_eval_beckmann(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 	if (WANT & 3) {
 		float e = (c.k_d * en) * rcp_(c4 * den4);
 		if (WANT & 2) e *= i.z;
-		ok &= ((e < 1e30f) & (e > 1e-24f)) | !on;             // the exponential tail towards the denormals: tier 2 (the relative
+		ok &= ((e < 1e30f) & (e > 1e-33f)) | !on | zero_d;    // the exponential tail towards the denormals: tier 2 (the relative
 		                                                       // contract has no meaning there; zeros must match exactly)
-		e = on ? e : 0.0f;
+		e = (on & !zero_d) ? e : 0.0f;
 		fr = ct_fresnel_times<FRK>(c, oh, e);
 	}
 	if (WANT & 4) {
 		const float ih = dot(i, h);
 		float q = (oh * (c.k_d * en)) * rcp_(c4 * (4.0f * ih * sig_o));
 		const bool pos = oh > 0.0f;                            // vndf is 0 unless dot(o, h) > 0 (dj_brdf.h:1605): the reference's decision
-		ok &= ((q < 1e30f) & (q > 1e-24f) & (ih > CT_LO)) | !(on & pos);
-		pdf = (on & pos) ? q : 0.0f;
+		ok &= ((((q < 1e30f) & (q > 1e-33f)) | zero_d) & (ih > CT_LO)) | !(on & pos);   // zero_d: +0 / (4 dot(i, h)) with dot(i, h) > 0
+		pdf = (on & pos & !zero_d) ? q : 0.0f;
 	}
 	return ok | !live;
 }
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void k_ct_selftest(Brdf b, Params p, CtParam
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			if (va[j] == ve[j]) continue;
-			if (va[j] == 0.0f || ve[j] == 0.0f || !(fabsf(ve[j]) >= 1e-30f)) { ++n_zero; continue; }
+			if (va[j] == 0.0f || ve[j] == 0.0f || !(fabsf(ve[j]) >= 1.2e-38f)) { ++n_zero; continue; }   // a zero on one side only, or a sub-normal reference value: must be equal
 			float rel = fabsf(va[j] - ve[j]) / fabsf(ve[j]);
 			if (!(rel <= 1e-5f)) ++n_out;
 			if (j < 3) me = fmaxf(me, rel); else mp = fmaxf(mp, rel);

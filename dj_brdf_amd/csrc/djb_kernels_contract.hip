@@ -82,6 +82,8 @@ DJB_DEV bool ct_eval_beckmann(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 		                                                       // contract has no meaning there; zeros must match exactly)
 		e = (on & !zero_d) ? e : 0.0f;
 		fr = ct_fresnel_times<FRK>(c, oh, e);
+		// eval = evalp / i.z even where evalp is vec3(0) (dj_brdf.h:1551-1555): NaN for a dead pair with i.z = 0 (or NaN)
+		if ((WANT & 1) && !live && ((i.z == 0.0f) | (i.z != i.z))) fr = mk(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
 	}
 	if (WANT & 4) {
 		const float ih = dot(i, h);
@@ -272,6 +274,8 @@ DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 		ok &= (e < 1e30f);
 		e = live ? e : 0.0f;
 		fr = ct_fresnel_times<FRK>(c, oh, e);
+		// eval = evalp / i.z even where evalp is vec3(0) (dj_brdf.h:1551-1555): NaN for a dead pair with i.z = 0 (or NaN)
+		if ((WANT & 1) && !live && ((i.z == 0.0f) | (i.z != i.z))) fr = mk(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
 	}
 	if (WANT & 4) {
 		float ih = r * dot(i, s);

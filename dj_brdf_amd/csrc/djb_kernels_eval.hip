@@ -79,6 +79,105 @@ __global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Pa
 	}
 }
 
+// ---- Beckmann eval / evalp / pdf of a SHARP lobe, bit-identical, two paths.  exp(-r^2) makes most pairs of a sharp lobe exact
+// zeros -- float(exp(-r^2) / pi) IS zero from r^2 = 102.83 on (half of the smallest denormal), and r^2 = tan^2(theta_h) / alpha^2 passes 104
+// at theta_h = 27 deg for alpha = 0.05 -- but k_eval pays the whole evaluation for them: both sigmas (an fp64 exp and an erf each), the
+// shadowing term, the Fresnel term, ~430 VALU.  Here every lane computes only what decides that: h and the stretched slope radius, with
+// the reference's own operations (the same functions eval_one calls, so r^2 is its r^2 bit for bit).  A pair is TRIVIAL when the
+// reference's result is a zero that can be written down:
+//   (a) o below the horizon (or i, with shadowing): g1 = 0, G = 0, eval and pdf keep their initial +0 (dj_brdf.h:1529-1555, 1633-1665,
+//       1713-1730) whatever else the pair holds, NaNs included (0 * NaN is NaN, and `G > 0` is false for it); eval divides that
+//       vec3(0) by i.z all the same (-0 for i below the horizon, NaN on it);
+//   (b) both directions finite, |component| < 8, z > 1e-4, and h.z <= 1e-4 (ndf returns 0) or r^2 >= 104 (p22 is +0): then D = +0; G
+//       is finite -- sigma >= k.z / 2 > 0, so g1 <= ~1, and g1i + g1o - g1i g1o > 0 -- or not positive, F is finite and not negative
+//       (ideal; schlick with f0 in [0, 1]; unpolarized with ior > 1: beckmann_sharp_supported), so eval = evalp = (+0, +0, +0);
+//       pdf = (+0) / (4 dot(i, h)) = +0 for dot(i, h) > 0 -- pairs with dot(i, h) <= 0 are not taken.
+// Everything else is queued per wave in LDS and evaluated by eval_one in dense waves of 64, as the deferred samples of k_sample_bk are.
+// Only launched for lobes sharp enough to make that pay (beckmann_sharp_supported): the prefix alone takes 0.76 ms per 1e8 pairs, a full
+// pair about two thirds of what it takes in k_eval; eval + pdf of 1e8 bench pairs 1.87 -> 1.01 ms at alpha = 0.02 (91 % zeros), 1.89 -> 1.27 at
+// 0.05 (59 %), 1.82 -> 1.57 at 0.08, even at 0.1, slower above (profiles/r04/beckmann_sharp.txt).
+constexpr unsigned int SHQ = 128;       // queue slots per wave: < 64 waiting + <= 64 new per iteration
+template <int WANT, int FRK, bool DENSE>
+__global__ __launch_bounds__(BLOCK) void k_eval_bk_sharp(Brdf b, Params p, long long n, View vi, View vo, View vout, float *out_pdf)
+{
+	__shared__ unsigned long long s_exp[256];
+	__shared__ unsigned int s_q[BLOCK / 64][8][SHQ];      // {k lo, k hi, i.xyz, o.xyz}
+	b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	__syncthreads();
+	const unsigned int t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+	unsigned int (&q)[8][SHQ] = s_q[wave];
+	unsigned int qn = 0;                                   // wave-uniform
+	auto drain = [&](unsigned int first, unsigned int cnt) {
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the placeholders of these pairs were stored by other lanes of this wave: they leave first
+		if (lane < cnt) {
+			const unsigned int j = first + lane;
+			const long long k = (long long)(((unsigned long long)q[1][j] << 32) | q[0][j]);
+			const v3 i = mk(__uint_as_float(q[2][j]), __uint_as_float(q[3][j]), __uint_as_float(q[4][j]));
+			const v3 o = mk(__uint_as_float(q[5][j]), __uint_as_float(q[6][j]), __uint_as_float(q[7][j]));
+			v3 fr = mk(0, 0, 0); float pdf = 0.0f;
+			eval_one<KIND_BECKMANN, WANT, FRK>(b, p, i, o, fr, pdf);
+			if (WANT & 3) store3(vout, k, fr);
+			if (WANT & 4) out_pdf[k] = pdf;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	};
+	const long long stride = (long long)gridDim.x * BLOCK;
+	// the next tile's directions are requested before this tile's are looked at: a persistent loop has no other workgroup's loads to hide behind
+	v3 i_next = mk(0, 0, 1), o_next = mk(0, 0, 1);
+	{
+		const long long k0 = (long long)blockIdx.x * BLOCK, k = k0 + t;
+		if (k < n) { i_next = DENSE ? load3_dense(vi, k0, t) : load3(vi, k); o_next = DENSE ? load3_dense(vo, k0, t) : load3(vo, k); }
+	}
+	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
+		const long long k = k0 + t;
+		const bool live = k < n;
+		const v3 i = i_next, o = o_next;
+		{
+			const long long k0n = k0 + stride, kn = k0n + t;
+			i_next = mk(0, 0, 1); o_next = mk(0, 0, 1);
+			if (kn < n) { i_next = DENSE ? load3_dense(vi, k0n, t) : load3(vi, kn); o_next = DENSE ? load3_dense(vo, k0n, t) : load3(vo, kn); }
+		}
+		// (a): dot(k, m_n) = k.x 0 + k.y 0 + k.z for the mean normal (0, 0, 1) of a lobe without offset: not positive, or NaN
+		const bool fin_o = (fabsf(o.x) < 3e38f) & (fabsf(o.y) < 3e38f), fin_i = (fabsf(i.x) < 3e38f) & (fabsf(i.y) < 3e38f);
+		const bool below = (fin_o & !(o.z > 0.0f)) | ((b.shadow != 0) & fin_i & !(i.z > 0.0f));
+		// (b)
+		const float big = fmaxf(fmaxf(fmaxf(fabsf(i.x), fabsf(i.y)), fabsf(i.z)), fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)));
+		const bool sane = (big < 8.0f) & (i.z > 1e-4f) & (o.z > 1e-4f);
+		const v3 h = normalize(add(i, o));                                          // as mf_eval_pdf
+		const bool facing = h.z > 1e-4f;                                            // mf_ndf's cut
+		const float r2 = mf_p22_rsqr(-h.x / h.z, -h.y / h.z, p);                    // mf_ndf / mf_p22's slope radius
+		const float ih = dot(i, h);
+		bool trivial = below | (sane & (!facing | (r2 >= 104.0f)));
+		// (b)'s pdf is (+0) / (4 dot(i, h)) when G > 0 and the initial +0 when it is not (a sigma can be NaN for a direction that the
+		// stretch rounds onto the pole): the same +0 as long as dot(i, h) > 0, which is all that is taken here
+		if (WANT & 4) trivial &= below | (ih > 0.0f);
+		if (live) {
+			// every lane stores -- whole lines leave the wave; a queued pair's value is a placeholder that the drain overwrites (after
+			// waiting for these stores: drain).  eval = evalp / i.z = (1 / i.z) * vec3(0): +0 in (b); in (a) -0 for i below the horizon,
+			// NaN on it (dj_brdf.h:1551-1555)
+			const v3 z = (WANT & 1) ? divs(mk(0, 0, 0), i.z) : mk(0, 0, 0);
+			if (WANT & 3) { if (DENSE) store3_dense(vout, k0, t, z); else store3(vout, k, z); }
+			if (WANT & 4) { if (DENSE) (out_pdf + k0)[t] = 0.0f; else out_pdf[k] = 0.0f; }
+		}
+		const bool full = live & !trivial;
+		const unsigned long long mask = __ballot(full);
+		if (mask) {
+			if (full) {
+				const unsigned int j = qn + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+				q[0][j] = (unsigned int)(unsigned long long)k; q[1][j] = (unsigned int)((unsigned long long)k >> 32);
+				q[2][j] = __float_as_uint(i.x); q[3][j] = __float_as_uint(i.y); q[4][j] = __float_as_uint(i.z);
+				q[5][j] = __float_as_uint(o.x); q[6][j] = __float_as_uint(o.y); q[7][j] = __float_as_uint(o.z);
+			}
+			qn += (unsigned int)__popcll(mask);
+			if (qn >= 64u) { qn -= 64u; drain(qn, 64u); }
+		}
+	}
+	if (qn) drain(0u, qn);
+}
+
 // utia::eval, two-tier.  The exact fall-back of the azimuths (glibc's atan2, djb_device.hpp atan2_to_f32) kept inside
 // k_eval<UTIA> as a rarely taken branch doubles the kernel's time (2.8 -> 5.3 ms per 1e8; inline or as a call: its
 // registers and constants land in the loop).  Tier 1 runs the same per-pair code without it (utia_eval_t<true>) and
@@ -142,12 +241,49 @@ hipError_t launch_utia_tt(hipStream_t s, const Brdf &b, long long n, const View 
 	return hipGetLastError();
 }
 
+// k_eval_bk_sharp's domain: no mean-normal offset (the (a) / (b) arguments use m_n = +z), a Fresnel term that cannot be negative or NaN,
+// and a lobe sharp enough for the trivial pairs to pay for the prefix (DJB_BK_SHARP_ALPHA: profiles/r04/beckmann_sharp.txt)
+#ifndef DJB_BK_SHARP_ALPHA
+#define DJB_BK_SHARP_ALPHA 0.10f
+#endif
+inline bool beckmann_sharp_supported(const Brdf &b, const Params &p)
+{
+	static const float alpha_max = getenv("DJB_BK_SHARP_ALPHA") ? (float)atof(getenv("DJB_BK_SHARP_ALPHA")) : DJB_BK_SHARP_ALPHA;
+	if (b.kind != KIND_BECKMANN) return false;
+	if (!(p.tx == 0.0f && p.ty == 0.0f && p.nx == 0.0f && p.ny == 0.0f && p.nz == 1.0f)) return false;
+	if (!(p.ax >= 1e-3f && p.ay >= 1e-3f && p.ax <= alpha_max && p.ay <= alpha_max && fabsf(p.rho) <= 0.99f)) return false;
+	if (b.fr.kind == FR_SCHLICK) { for (int c = 0; c < 3; ++c) if (!(b.fr.a[c] >= 0.0f && b.fr.a[c] <= 1.0f)) return false; }
+	else if (b.fr.kind == FR_UNPOLARIZED) { for (int c = 0; c < 3; ++c) if (!(b.fr.a[c] > 1.0f && b.fr.a[c] < 1e6f)) return false; }
+	else if (b.fr.kind != FR_IDEAL) return false;
+	return true;
+}
+
 template <int KIND, int FRK>
 hipError_t launch_eval_kind_fr(hipStream_t s, const Brdf &b, const Params &p, long long n,
                                const View &i, const View &o, const View &out, float *out_pdf, int want)
 {
 	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
 	const bool dn = dense(i) && dense(o) && dense(out);
+	if constexpr (KIND == KIND_BECKMANN && (FRK == FR_IDEAL || FRK == FR_SCHLICK || FRK == FR_UNPOLARIZED)) {
+		if (beckmann_sharp_supported(b, p) && n >= (1LL << 16)) {
+			// persistent grid, ~32 tiles per workgroup: the queue needs iterations to fill
+			long long tiles = (n + BLOCK - 1) / BLOCK, blocks = (tiles + 31) / 32;
+			if (blocks < 4096) blocks = tiles < 4096 ? tiles : 4096;
+			const dim3 gs((unsigned int)(blocks > 0x7fffffffLL ? 0x7fffffffLL : blocks));
+#define DJB_LAUNCH_SHARP(W_) do { if (dn) hipLaunchKernelGGL((k_eval_bk_sharp<W_, FRK, true>), gs, t, 0, s, b, p, n, i, o, out, out_pdf); \
+                                  else hipLaunchKernelGGL((k_eval_bk_sharp<W_, FRK, false>), gs, t, 0, s, b, p, n, i, o, out, out_pdf); } while (0)
+			switch (want) {
+			case 1: DJB_LAUNCH_SHARP(1); break;
+			case 2: DJB_LAUNCH_SHARP(2); break;
+			case 4: DJB_LAUNCH_SHARP(4); break;
+			case 5: DJB_LAUNCH_SHARP(5); break;
+			case 6: DJB_LAUNCH_SHARP(6); break;
+			default: return hipErrorInvalidValue;
+			}
+#undef DJB_LAUNCH_SHARP
+			return hipGetLastError();
+		}
+	}
 #define DJB_LAUNCH_EVAL(W_) do { if (dn) hipLaunchKernelGGL((k_eval<KIND, W_, FRK, true>), g, t, 0, s, b, p, n, i, o, out, out_pdf); \
                                  else hipLaunchKernelGGL((k_eval<KIND, W_, FRK, false>), g, t, 0, s, b, p, n, i, o, out, out_pdf); } while (0)
 	switch (want) {

@@ -273,3 +273,26 @@ def test_cpp_programs_run_without_a_gpu(tmp_path):
             assert (tmp_path / f).read_bytes() == open(os.path.join(G, "reftests", f), "rb").read(), f
         r = subprocess.run([os.path.join(rt, "merl_params")] + files, cwd=str(tmp_path), capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and (tmp_path / "params.txt").read_bytes() == want
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+def test_eval_divides_the_zero_vector_by_cos_i(cpu, oracle, dirs, ndf):
+    """microfacet::eval = evalp / i.z (dj_brdf.h:1551-1555) even where evalp returned vec3(0): -0 for i below the horizon, NaN on it.
+    The host path against the oracle on pairs with either direction below / on the horizon, signs of zeros included."""
+    i, o, _, _ = dirs
+    i, o = i[:4096].copy(), o[:4096].copy()
+    i[:1024, 2] *= -1; o[1024:2048, 2] *= -1
+    i[2048:2112, 2] = 0.0; i[2112:2176, 2] = -0.0; o[2176:2240, 2] = 0.0; i[2240:2304, 2] = np.nan
+    def vb(a):
+        a = np.ascontiguousarray(a, np.float32)
+        return np.where(np.isnan(a), np.uint32(0x7fc00000), a.view(np.uint32))
+    for shadow in (True, False):
+        g = getattr(djb, ndf)(djb.fresnel.ideal(), shadow, ctx=cpu)
+        ob = oracle.microfacet(ndf, ("ideal",), shadow)
+        for p in (None, ("elliptic", 0.3, 0.3, 0.0), ("elliptic", 0.05, 0.05, 0.0)):
+            for op in ("eval", "evalp", "pdf"):
+                want = oracle.eval(ob, i, o, p, op)
+                assert np.array_equal(vb(getattr(g, op)(i, o, mk_params(p))), vb(want)), (ndf, shadow, p, op)
+            if shadow:
+                w = oracle.eval(ob, i, o, p, "eval")
+                assert np.all(np.signbit(w[:1024])) and np.all(np.isnan(w[2048:2176])), "the reference's own zeros are not what this test believes"

@@ -662,3 +662,88 @@ def test_get_samples(gpu_ctx, tmp_path):
         n = C.c_int64(0)
         g = djb.ggx(ctx=gpu_ctx)          # kept alive across the call: `djb.ggx(...)._h` alone hands a freed handle to the library
         _lib.check(_lib.load().djb_brdf_get_samples(g._h, None, C.c_int64(0), C.byref(n)))
+
+
+SHARP_PARAMS = [("elliptic", 0.05, 0.05, 0.0), ("elliptic", 0.02, 0.1, 0.3), ("pdfparams", 0.05, 0.08, 0.5, 0.0, 0.0), ("elliptic", 0.001, 0.1, 1.0)]
+
+
+def hostile_pairs(dirs):
+    """the bench directions with families a renderer can produce mixed in: either direction below the horizon, un-normalised, pointing away
+    from each other, grazing, on the normal, equal, NaN / Inf / zero vectors, h on the normal"""
+    i, o, _, _ = dirs
+    i, o = i.copy(), o.copy()
+    n = i.shape[0]; k = n // 16
+    o[:k, 2] *= -1                                                   # o below the horizon
+    i[k:2 * k, 2] *= -1                                              # i below the horizon
+    i[2 * k:3 * k] *= 0.01; o[2 * k:3 * k] *= 6.0                   # un-normalised, very different lengths (dot(i, h) may turn negative)
+    i[3 * k:3 * k + k // 2, 0] *= -5.0                               # i pointing away from o: dot(i, h) < 0
+    o[4 * k:5 * k, 2] = 2e-4 * np.abs(o[4 * k:5 * k, 2])             # grazing o (around the z > 1e-4 cut)
+    i[5 * k:6 * k] = np.array([0, 0, 1], np.float32) + 1e-4 * i[5 * k:6 * k]     # on the normal: sigma's pole
+    o[6 * k:7 * k] = i[6 * k:7 * k]                                  # i == o
+    o[7 * k:7 * k + 64, 0] = np.nan; i[7 * k + 64:7 * k + 128, 2] = np.inf; o[7 * k + 128:7 * k + 192] = 0.0; i[7 * k + 192:7 * k + 256, 1] = -np.inf
+    i[7 * k + 256:7 * k + 320, 2] = 0.0; o[7 * k + 320:7 * k + 384, 2] = 0.0; i[7 * k + 384:7 * k + 448, 2] = -0.0      # exactly on the horizon
+    o[8 * k:9 * k, :2] *= 1e-3                                       # h nearly on the normal: r^2 small even for a sharp lobe
+    i[9 * k:10 * k] = -o[9 * k:10 * k] * np.array([1, 1, -1], np.float32) * 3.0      # mirror pairs of different lengths: h on the normal
+    return i, o
+
+
+def value_bits(a):
+    """the bits of every value, signs of zeros included; NaNs (whose payload is the processor's business) as one pattern"""
+    a = np.ascontiguousarray(a, np.float32)
+    return np.where(np.isnan(a), np.uint32(0x7fc00000), a.view(np.uint32))
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+def test_microfacet_eval_on_hostile_pairs(gpu_ctx, oracle, dirs, ndf):
+    """eval = evalp / i.z divides evalp's vec3(0) all the same (dj_brdf.h:1551-1555): -0 for i below the horizon, NaN on it -- and everything
+    else a renderer's stray pairs produce: the kernels return the reference's bits (NaN payloads aside), every output set, on the device
+    and on the product's host path"""
+    import torch
+    i, o = hostile_pairs(dirs)
+    di, do = torch.from_numpy(np.ascontiguousarray(i.T)).cuda(), torch.from_numpy(np.ascontiguousarray(o.T)).cuda()
+    cpu = djb.cpu_context()
+    m = 1 << 13                                                       # the host path on a slice (every family is 2^13 long)
+    sl = np.r_[0:64, 8192:8192 + 64, 7 * 8192:7 * 8192 + 448, 3 * 8192:3 * 8192 + 64]
+    for fres in (("ideal",), ("schlick", 1.0, 0.71, 0.29)):
+        for shadow in (True, False):
+            g = getattr(djb, ndf)(mk_fresnel(fres), shadow, ctx=gpu_ctx); gc = getattr(djb, ndf)(mk_fresnel(fres), shadow, ctx=cpu)
+            ob = oracle.microfacet(ndf, fres, shadow)
+            for p in (None, ("elliptic", 0.3, 0.3, 0.0), ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)):
+                up = mk_params(p)
+                for op in ("eval", "evalp", "pdf"):
+                    want = oracle.eval(ob, i, o, p, op)
+                    got = getattr(g, op)(di, do, up).cpu().numpy()
+                    got = got.T if got.ndim == 2 else got
+                    assert np.array_equal(value_bits(got), value_bits(want)), (ndf, fres, shadow, p, op, int(np.sum(value_bits(got) != value_bits(want))))
+                    hc = np.asarray(getattr(gc, op)(i[sl], o[sl], up))
+                    assert np.array_equal(value_bits(hc), value_bits(want[sl])), (ndf, fres, shadow, p, op, "host path")
+    del m
+
+
+@pytest.mark.parametrize("fres", [("ideal",), ("schlick", 1.0, 0.71, 0.29), ("unpolarized", 1.5, 1.8, 2.4), ("schlick", 0.0, 1.0, 0.5)], ids=lambda f: "-".join(str(x) for x in f))
+def test_beckmann_sharp_lobe_two_path_kernel(gpu_ctx, oracle, dirs, fres):
+    """k_eval_bk_sharp (lobes with alpha <= 0.1: pairs whose result is a known zero are written at once, the others evaluated in dense
+    waves) must return the reference's BITS -- zeros with their signs, NaNs, everything: against the oracle on the bench directions
+    mixed with below-horizon, un-normalised, grazing, on-the-normal, i == o, NaN and Inf pairs; every output set, both layouts."""
+    import torch
+    i, o = hostile_pairs(dirs)
+    bits = value_bits
+    di, do = torch.from_numpy(np.ascontiguousarray(i.T)).cuda(), torch.from_numpy(np.ascontiguousarray(o.T)).cuda()      # dense SoA
+    ai, ao = torch.from_numpy(i).cuda(), torch.from_numpy(o).cuda()                                                      # array of vec3
+    trivial_share = []
+    for shadow in (True, False):
+        g = djb.beckmann(mk_fresnel(fres), shadow, ctx=gpu_ctx)
+        ob = oracle.microfacet("beckmann", fres, shadow)
+        for p in SHARP_PARAMS:
+            up = mk_params(p)
+            want = {op: oracle.eval(ob, i, o, p, op) for op in ("eval", "evalp", "pdf")}
+            trivial_share.append(float(np.mean(np.all(want["eval"] == 0, axis=1))))
+            for op in ("eval", "evalp", "pdf"):
+                got_s = getattr(g, op)(di, do, up).cpu().numpy(); got_a = getattr(g, op)(ai, ao, up).cpu().numpy()
+                got_s = got_s.T if got_s.ndim == 2 else got_s
+                assert np.array_equal(bits(got_s), bits(want[op])), (fres, shadow, p, op, "soa", int(np.sum(bits(got_s) != bits(want[op]))))
+                assert np.array_equal(bits(got_a), bits(want[op])), (fres, shadow, p, op, "aos")
+            for cos in (False, True):
+                fr, pdf = g.eval_pdf(di, do, up, cos=cos)
+                assert np.array_equal(bits(fr.cpu().numpy().T), bits(want["evalp" if cos else "eval"])) and np.array_equal(bits(pdf.cpu().numpy()), bits(want["pdf"])), (fres, shadow, p, cos)
+    assert max(trivial_share) > 0.5, "the test lobes are not sharp enough to exercise the trivial path"

@@ -45,6 +45,27 @@ def test_microfacet_bit_exact(oracle, reference, inputs, ndf, fres, par):
                                   bits(reference.microfacet_query(br, q, *args, params=par))), q
 
 
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+def test_microfacet_on_and_below_the_horizon(oracle, reference, inputs, ndf):
+    """either direction below or exactly on the horizon, un-normalised: eval = evalp / i.z divides evalp's vec3(0) all the same
+    (-0, NaN): the restatement against the real reference, signs of zeros included (NaN payloads aside)"""
+    i, o, _, _ = inputs
+    i, o = i[:8192].copy(), o[:8192].copy()
+    i[:1024, 2] *= -1; o[1024:2048, 2] *= -1
+    i[2048:2112, 2] = 0.0; i[2112:2176, 2] = -0.0; o[2176:2240, 2] = 0.0      # (NaN / Inf directions trip the reference's own asserts)
+    i[3072:4096] *= 0.01; o[3072:4096] *= 6.0; i[4096:4608, 0] *= -5.0
+    vb = lambda a: np.where(np.isnan(a), np.uint32(0x7fc00000), np.ascontiguousarray(a, np.float32).view(np.uint32))
+    for shadow in (True, False):
+        bo, br = oracle.microfacet(ndf, ("schlick", 0.9, 0.5, 0.1), shadow), reference.microfacet(ndf, ("schlick", 0.9, 0.5, 0.1), shadow)
+        for par in (None, ("elliptic", 0.05, 0.05, 0.0), ("pdfparams", 0.8, 0.1, -0.6, 0.2, 0.2)):
+            for op in ("eval", "evalp", "pdf"):
+                a, b = oracle.eval(bo, i, o, par, op), reference.eval(br, i, o, par, op)
+                assert np.array_equal(vb(a), vb(b)), (ndf, shadow, par, op)
+        if shadow:
+            w = reference.eval(br, i, o, None, "eval")
+            assert np.all(np.signbit(w[:1024])) and np.all(np.isnan(w[2048:2176]))
+
+
 def test_radial_queries(oracle, reference):
     u = np.linspace(0.001, 0.999, 5000).astype(np.float32)
     c = np.linspace(0.01, 1.0, 5000).astype(np.float32)

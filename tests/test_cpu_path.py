@@ -296,3 +296,13 @@ def test_eval_divides_the_zero_vector_by_cos_i(cpu, oracle, dirs, ndf):
             if shadow:
                 w = oracle.eval(ob, i, o, p, "eval")
                 assert np.all(np.signbit(w[:1024])) and np.all(np.isnan(w[2048:2176])), "the reference's own zeros are not what this test believes"
+
+
+def test_every_kind_and_operator_on_hostile_pairs_host_path():
+    """tools/hostile_parity_sweep.py --cpu: the same sweep through the product's host path"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "hostile_parity_sweep.py"), "--cpu"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines[-1] == "cases with a mismatch: 0" and sum(l.endswith(" ok") for l in lines) >= 70, "\n".join(l for l in lines if not l.endswith(" ok"))

@@ -747,3 +747,14 @@ def test_beckmann_sharp_lobe_two_path_kernel(gpu_ctx, oracle, dirs, fres):
                 fr, pdf = g.eval_pdf(di, do, up, cos=cos)
                 assert np.array_equal(bits(fr.cpu().numpy().T), bits(want["evalp" if cos else "eval"])) and np.array_equal(bits(pdf.cpu().numpy()), bits(want["pdf"])), (fres, shadow, p, cos)
     assert max(trivial_share) > 0.5, "the test lobes are not sharp enough to exercise the trivial path"
+
+
+def test_every_kind_and_operator_on_hostile_pairs(gpu_ctx):
+    """tools/hostile_parity_sweep.py: ten BRDF kinds x (eval, evalp, pdf, sample, evalp_is) on the hostile pairs and uniforms outside [0, 1) /
+    NaN, device kernels against the oracle, value bits with the signs of zeros"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "hostile_parity_sweep.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines[-1] == "cases with a mismatch: 0" and sum(l.endswith(" ok") for l in lines) >= 70, "\n".join(l for l in lines if not l.endswith(" ok"))

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Every BRDF kind x every operator on pairs a renderer's stray rays produce (either direction below / on the horizon, un-normalised,
+opposed, grazing, on the normal, equal, NaN / Inf / zero vectors; uniforms outside [0, 1), NaN): the device kernels against the oracle,
+value bits with the signs of zeros (NaN payloads aside).  python tools/hostile_parity_sweep.py   (GPU box; prints one line per case)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import oraclelib  # noqa: E402
+from dj_brdf_amd import djb, synth  # noqa: E402
+from test_gpu_parity import hostile_pairs, value_bits, mk_params  # noqa: E402
+
+ctx = djb.default_context(0) if "--cpu" not in sys.argv else djb.cpu_context()
+O = oraclelib.oracle()
+n = 1 << 17
+dirs = (synth.directions_aos(n, synth.SEED_I), synth.directions_aos(n, synth.SEED_O), synth.uniforms(n, synth.SEED_U1), synth.uniforms(n, synth.SEED_U2))
+i, o = hostile_pairs(dirs)
+u1, u2 = dirs[2].copy(), dirs[3].copy()
+u1[:64] = np.nan; u2[64:128] = np.nan; u1[128:192] = -0.5; u2[192:256] = 1.5; u1[256:320] = 1.0; u2[320:384] = 0.0; u1[384:448] = 0.0; u2[448:512] = 1.0
+if ctx.is_cpu:
+    n = 1 << 13
+    sel = np.r_[0:512, 8192:8192 + 512, 2 * 8192:2 * 8192 + 512, 3 * 8192:3 * 8192 + 512, 4 * 8192:4 * 8192 + 512, 5 * 8192:5 * 8192 + 512, 6 * 8192:6 * 8192 + 512, 7 * 8192:7 * 8192 + 512,
+                8 * 8192:8 * 8192 + 512, 9 * 8192:9 * 8192 + 512, 10 * 8192:10 * 8192 + 512]
+    i, o, u1, u2 = i[sel], o[sel], u1[sel], u2[sel]
+    dev = lambda a: a
+else:
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T if a.ndim == 2 else a)).cuda()
+di, do, d1, d2 = dev(i), dev(o), dev(u1), dev(u2)
+host = lambda t: (t.cpu().numpy().T if t.ndim == 2 else t.cpu().numpy()) if not ctx.is_cpu else np.asarray(t)
+
+tab = synth.merl_table_hashed()
+kinds = [
+    ("ggx", djb.ggx(ctx=ctx), O.microfacet("ggx"), [None, ("elliptic", 0.2, 0.5, 0.7), ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)]),
+    ("ggx schlick noshadow", djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), False, ctx=ctx), O.microfacet("ggx", ("schlick", 1.0, 0.71, 0.29), False), [("elliptic", 0.3, 0.3, 0.0)]),
+    ("beckmann", djb.beckmann(ctx=ctx), O.microfacet("beckmann"), [None, ("elliptic", 0.2, 0.5, 0.7), ("elliptic", 0.05, 0.05, 0.0), ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)]),
+    ("beckmann unpol", djb.beckmann(djb.fresnel.unpolarized((1.5, 1.8, 2.4)), True, ctx=ctx), O.microfacet("beckmann", ("unpolarized", 1.5, 1.8, 2.4), True), [("elliptic", 0.3, 0.3, 0.0)]),
+    ("merl", djb.merl.from_table(tab, ctx=ctx), O.merl_from_table(tab), [None]),
+    ("utia", djb.utia.from_table(synth.utia_table_smooth(), ctx=ctx), None, [None]),
+    ("lambert", djb.lambert(ctx=ctx), O.lambert(), [None]),
+    ("sgd", djb.sgd("gold-metallic-paint", ctx=ctx), O.sgd("gold-metallic-paint"), [None]),
+    ("abc", djb.abc("gold-metallic-paint", ctx=ctx), O.abc("gold-metallic-paint"), [None]),
+]
+tg = djb.tabular(djb.ggx(ctx=ctx), 90, True, ctx=ctx)
+kinds.append(("tabular(ggx)", tg, O.tabular(O.microfacet("ggx"), 90, True), [None, ("elliptic", 0.3, 0.3, 0.0)]))
+bad = 0
+for name, g, ob, plist in kinds:
+    if ob is None:
+        continue
+    for p in plist:
+        up = mk_params(p)
+        for op in ("eval", "evalp", "pdf"):
+            got = host(getattr(g, op)(di, do, up)); want = O.eval(ob, i, o, p, op)
+            m = value_bits(got) != value_bits(want)
+            fam = np.unique(np.where(m.reshape(len(i), -1).any(axis=1))[0] // (len(i) // 16 if not ctx.is_cpu else 512))
+            print("%-22s %-40s %-8s %s" % (name, p, op, "ok" if not m.any() else "MISMATCH %d values, families %s" % (int(m.sum()), fam.tolist()))); bad += int(m.any())
+        got = host(g.sample(d1, d2, do, up)); want = O.sample(ob, u1, u2, o, p)
+        m = value_bits(got) != value_bits(want)
+        print("%-22s %-40s %-8s %s" % (name, p, "sample", "ok" if not m.any() else "MISMATCH %d values, rows %s" % (int(m.sum()), np.where(m.any(axis=1))[0][:6].tolist()))); bad += int(m.any())
+        w, si, pdf = g.evalp_is(d1, d2, do, up); ww, wi, wp = O.evalp_is(ob, u1, u2, o, p)
+        m = (value_bits(host(w)) != value_bits(ww)).any(axis=1) | (value_bits(host(si)) != value_bits(wi)).any(axis=1) | (value_bits(host(pdf)) != value_bits(wp))
+        print("%-22s %-40s %-8s %s" % (name, p, "evalp_is", "ok" if not m.any() else "MISMATCH %d samples, rows %s" % (int(m.sum()), np.where(m)[0][:6].tolist()))); bad += int(m.any())
+print("cases with a mismatch:", bad)

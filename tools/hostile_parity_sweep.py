@@ -63,4 +63,14 @@ for name, g, ob, plist in kinds:
         w, si, pdf = g.evalp_is(d1, d2, do, up); ww, wi, wp = O.evalp_is(ob, u1, u2, o, p)
         m = (value_bits(host(w)) != value_bits(ww)).any(axis=1) | (value_bits(host(si)) != value_bits(wi)).any(axis=1) | (value_bits(host(pdf)) != value_bits(wp))
         print("%-22s %-40s %-8s %s" % (name, p, "evalp_is", "ok" if not m.any() else "MISMATCH %d samples, rows %s" % (int(m.sum()), np.where(m)[0][:6].tolist()))); bad += int(m.any())
+# the microfacet queries (ndf, gaf, g1, sigma, vndf, p22, vp22) on the same directions used as h / k / slopes
+xy = np.stack([np.tan(3.0 * (u1 - 0.5)), 40.0 * (u2 - 0.5), np.zeros_like(u1)], 1).astype(np.float32)
+for name, g, ob, plist in kinds[:4]:
+    for p in plist:
+        up = mk_params(p)
+        for q, dargs, oargs in (("ndf", (di,), (i,)), ("gaf", (di, do, di), (i, o, i)), ("g1", (di, do), (i, o)), ("sigma", (do,), (o,)), ("vndf", (di, do), (i, o)),
+                                ("p22", (dev(xy[:, 0]), dev(xy[:, 1])), (xy,)), ("vp22", (dev(xy[:, 0]), dev(xy[:, 1]), do), (xy, o))):
+            got = host(getattr(g, q)(*dargs, up)); want = O.microfacet_query(ob, q, *oargs, params=p)
+            m = value_bits(got) != value_bits(want)
+            print("%-22s %-40s %-8s %s" % (name, p, q, "ok" if not m.any() else "MISMATCH %d values, rows %s" % (int(m.sum()), np.where(m)[0][:6].tolist()))); bad += int(m.any())
 print("cases with a mismatch:", bad)

@@ -73,4 +73,20 @@ for name, g, ob, plist in kinds[:4]:
             got = host(getattr(g, q)(*dargs, up)); want = O.microfacet_query(ob, q, *oargs, params=p)
             m = value_bits(got) != value_bits(want)
             print("%-22s %-40s %-8s %s" % (name, p, q, "ok" if not m.any() else "MISMATCH %d values, rows %s" % (int(m.sum()), np.where(m)[0][:6].tolist()))); bad += int(m.any())
+# the analytic lobes at the corners of the parameter space (very sharp, very rough, strongly correlated, large mean-normal offsets)
+extreme = [("elliptic", 1e-4, 1e-4, 0.0), ("elliptic", 1e-3, 30.0, 1.3), ("elliptic", 50.0, 50.0, 0.0), ("pdfparams", 0.3, 0.3, 0.999, 0.0, 0.0), ("pdfparams", 0.3, 2.0, -0.999, 0.0, 0.0),
+           ("pdfparams", 0.5, 0.5, 0.0, 8.0, -8.0), ("pdfparams", 1e-3, 1e-3, 0.0, 0.3, 0.3), ("pdfparams", 20.0, 0.01, 0.9, -2.0, 0.5)]
+for name, g, ob, _ in (kinds[0], kinds[2]):
+    for p in extreme:
+        up = mk_params(p)
+        for op in ("eval", "evalp", "pdf"):
+            got = host(getattr(g, op)(di, do, up)); want = O.eval(ob, i, o, p, op)
+            m = value_bits(got) != value_bits(want)
+            print("%-22s %-40s %-8s %s" % (name, p, op, "ok" if not m.any() else "MISMATCH %d values, rows %s" % (int(m.sum()), np.where(m.reshape(len(i), -1).any(axis=1))[0][:6].tolist()))); bad += int(m.any())
+        got = host(g.sample(d1, d2, do, up)); want = O.sample(ob, u1, u2, o, p)
+        m = value_bits(got) != value_bits(want)
+        print("%-22s %-40s %-8s %s" % (name, p, "sample", "ok" if not m.any() else "MISMATCH %d values, rows %s" % (int(m.sum()), np.where(m.any(axis=1))[0][:6].tolist()))); bad += int(m.any())
+        w, si, pdf = g.evalp_is(d1, d2, do, up); ww, wi, wp = O.evalp_is(ob, u1, u2, o, p)
+        m = (value_bits(host(w)) != value_bits(ww)).any(axis=1) | (value_bits(host(si)) != value_bits(wi)).any(axis=1) | (value_bits(host(pdf)) != value_bits(wp))
+        print("%-22s %-40s %-8s %s" % (name, p, "evalp_is", "ok" if not m.any() else "MISMATCH %d samples, rows %s" % (int(m.sum()), np.where(m)[0][:6].tolist()))); bad += int(m.any())
 print("cases with a mismatch:", bad)

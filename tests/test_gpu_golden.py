@@ -383,3 +383,15 @@ def test_file_that_shrinks_under_the_gather_gpu(gpu_ctx, tmp_path, monkeypatch):
         synth.write_merl_binary(paths[k], synth.merl_table(*synth.material_recipe(k)))
     got = merl_params.fit_files_on(gpu_ctx, paths)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.gpu
+def test_fitter_on_degenerate_tables():
+    """tools/degenerate_fit_sweep.py: the tabular fitter on all-zero / below-the-horizon / constant / tiny / huge tables, a NaN and an Inf
+    texel, one hot texel, at resolutions 90, 17 and 3: tables, Fresnel spline and both fits equal the oracle's bits"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "degenerate_fit_sweep.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines[-1] == "cases with a mismatch: 0" and sum(l.endswith(" ok") for l in lines) >= 27, "\n".join(l for l in lines if not l.endswith(" ok"))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """The tabular fitter on degenerate MERL tables (all zero, all below the horizon, constant, tiny, huge, a NaN texel, an Inf texel, one hot
-texel) and odd resolutions against the oracle: tables, the Fresnel spline and both fits, value bits (NaN payloads aside).
+texel) and odd resolutions against the oracle: tables, the Fresnel spline and both fits, value bits (NaN payloads aside).  The real
+reference, built with its asserts on, stops in normalize_p22 (`nint > 0.0`, hdr:2296) on the zero / huge / NaN tables; the oracle -- and the
+product -- compute what an NDEBUG build of it goes on to compute, and equal it bit for bit where it does not assert (constant, hot texel).
     python tools/degenerate_fit_sweep.py [--cpu]"""
 import os
 import sys

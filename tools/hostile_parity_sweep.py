@@ -89,4 +89,33 @@ for name, g, ob, _ in (kinds[0], kinds[2]):
         w, si, pdf = g.evalp_is(d1, d2, do, up); ww, wi, wp = O.evalp_is(ob, u1, u2, o, p)
         m = (value_bits(host(w)) != value_bits(ww)).any(axis=1) | (value_bits(host(si)) != value_bits(wi)).any(axis=1) | (value_bits(host(pdf)) != value_bits(wp))
         print("%-22s %-40s %-8s %s" % (name, p, "evalp_is", "ok" if not m.any() else "MISMATCH %d samples, rows %s" % (int(m.sum()), np.where(m)[0][:6].tolist()))); bad += int(m.any())
+# the per-hit path of dj_beckmannconductor on the same hostile directions: LEAN moments from a bumpy map (plus degenerate records: zero
+# variance, negative variance, NaN, huge), every flag combination; per-pair pdfparams records
+rg = np.random.default_rng(5)
+m = len(i)
+lean = np.stack([0.3 * rg.standard_normal(m), 0.3 * rg.standard_normal(m), np.zeros(m), np.zeros(m), 0.02 * rg.standard_normal(m)], 1).astype(np.float32)
+lean[:, 2] = lean[:, 0] ** 2 + rg.uniform(1e-4, 0.2, m); lean[:, 3] = lean[:, 1] ** 2 + rg.uniform(1e-4, 0.2, m)
+lean[:64, 2] = lean[:64, 0] ** 2; lean[64:128, 3] = 0.5 * lean[64:128, 1] ** 2; lean[128:192, 4] = np.nan; lean[192:256] *= 1e6; lean[256:320] = 0.0
+pp = np.stack([rg.uniform(0.02, 1.2, m), rg.uniform(0.02, 1.2, m), rg.uniform(-0.95, 0.95, m), rg.uniform(-0.5, 0.5, m), rg.uniform(-0.5, 0.5, m)], 1).astype(np.float32)
+pp[:64, 0] = 0.0; pp[64:128, 2] = 1.0; pp[128:192, 1] = np.nan; pp[192:256, 3] = 50.0
+dlean, dpp = (lean, pp) if ctx.is_cpu else (torch.from_numpy(lean).cuda(), torch.from_numpy(pp).cuda())
+gb, ogb = djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=ctx), O.microfacet("beckmann", ("schlick", 1.0, 0.71, 0.29), True)
+base = ("elliptic", 0.1, 0.3, 0.4)
+for scale_, filt, biased in ((1.0, True, False), (0.5, False, False), (2.0, True, True)):
+    rec = lean.copy()
+    if biased: rec[:, :2] += 25.0; rec[:, 4] += 625.0
+    drec = rec if ctx.is_cpu else torch.from_numpy(rec).cuda()
+    for op in ("eval", "evalp", "pdf"):
+        got = host(gb.eval_lean(di, do, mk_params(base), scale_, drec, want=op, filtering=filt, biased=biased)); want = O.eval_lean(ogb, i, o, base, scale_, rec, op, filt, biased)[0]
+        mm = value_bits(got) != value_bits(want)
+        print("%-22s %-40s %-8s %s" % ("beckmann lean", "scale %g filtering %d biased %d" % (scale_, filt, biased), op, "ok" if not mm.any() else "MISMATCH %d values, rows %s" % (int(mm.sum()), np.where(mm.reshape(m, -1).any(axis=1))[0][:6].tolist()))); bad += int(mm.any())
+    w, si, pdf = gb.sample_lean(d1, d2, do, mk_params(base), scale_, drec, evalp_is=True, filtering=filt, biased=biased)
+    ww, wi, wp, _ = O.sample_lean(ogb, u1, u2, o, base, scale_, rec, True, filt, biased)
+    mm = (value_bits(host(w)) != value_bits(ww)).any(axis=1) | (value_bits(host(si)) != value_bits(wi)).any(axis=1) | (value_bits(host(pdf)) != value_bits(wp))
+    print("%-22s %-40s %-8s %s" % ("beckmann lean", "scale %g filtering %d biased %d" % (scale_, filt, biased), "evalp_is", "ok" if not mm.any() else "MISMATCH %d samples, rows %s" % (int(mm.sum()), np.where(mm)[0][:6].tolist()))); bad += int(mm.any())
+for name, g, ob in (("ggx pp", kinds[0][1], kinds[0][2]), ("beckmann pp", kinds[2][1], kinds[2][2])):
+    for op in ("eval", "evalp", "pdf"):
+        got = host(g.eval_pp(di, do, dpp, want=op)); want = O.eval_pp(ob, i, o, pp, op)
+        mm = value_bits(got) != value_bits(want)
+        print("%-22s %-40s %-8s %s" % (name, "pdfparams records", op, "ok" if not mm.any() else "MISMATCH %d values, rows %s" % (int(mm.sum()), np.where(mm.reshape(m, -1).any(axis=1))[0][:6].tolist()))); bad += int(mm.any())
 print("cases with a mismatch:", bad)

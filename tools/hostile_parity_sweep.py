@@ -33,22 +33,41 @@ di, do, d1, d2 = dev(i), dev(o), dev(u1), dev(u2)
 host = lambda t: (t.cpu().numpy().T if t.ndim == 2 else t.cpu().numpy()) if not ctx.is_cpu else np.asarray(t)
 
 tab = synth.merl_table_hashed()
+np.random.default_rng(3).uniform(-5.0, 130.0, size=3 * 288 * 288).tofile("/tmp/hostile_sweep_utia.bin")      # raw doubles: the UTIA file format
 kinds = [
     ("ggx", djb.ggx(ctx=ctx), O.microfacet("ggx"), [None, ("elliptic", 0.2, 0.5, 0.7), ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)]),
     ("ggx schlick noshadow", djb.ggx(djb.fresnel.schlick((1.0, 0.71, 0.29)), False, ctx=ctx), O.microfacet("ggx", ("schlick", 1.0, 0.71, 0.29), False), [("elliptic", 0.3, 0.3, 0.0)]),
     ("beckmann", djb.beckmann(ctx=ctx), O.microfacet("beckmann"), [None, ("elliptic", 0.2, 0.5, 0.7), ("elliptic", 0.05, 0.05, 0.0), ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)]),
     ("beckmann unpol", djb.beckmann(djb.fresnel.unpolarized((1.5, 1.8, 2.4)), True, ctx=ctx), O.microfacet("beckmann", ("unpolarized", 1.5, 1.8, 2.4), True), [("elliptic", 0.3, 0.3, 0.0)]),
     ("merl", djb.merl.from_table(tab, ctx=ctx), O.merl_from_table(tab), [None]),
-    ("utia", djb.utia.from_table(synth.utia_table_smooth(), ctx=ctx), None, [None]),
+    ("utia", djb.utia("/tmp/hostile_sweep_utia.bin", ctx=ctx), O.utia("/tmp/hostile_sweep_utia.bin"), [None]),
     ("lambert", djb.lambert(ctx=ctx), O.lambert(), [None]),
     ("sgd", djb.sgd("gold-metallic-paint", ctx=ctx), O.sgd("gold-metallic-paint"), [None]),
     ("abc", djb.abc("gold-metallic-paint", ctx=ctx), O.abc("gold-metallic-paint"), [None]),
 ]
 tg = djb.tabular(djb.ggx(ctx=ctx), 90, True, ctx=ctx)
 kinds.append(("tabular(ggx)", tg, O.tabular(O.microfacet("ggx"), 90, True), [None, ("elliptic", 0.3, 0.3, 0.0)]))
+kinds.append(("tabular_aniso(beckmann)", djb.tabular_anisotropic(djb.beckmann(ctx=ctx), 12, 16, True, ctx=ctx), O.tabular_anisotropic(O.microfacet("beckmann"), 12, 16, True), [None]))
 bad = 0
+# utia::eval indexes its table with (int)floor(angle / step) of acos / atan2 results: a NaN, infinite or un-normalised direction (|z| > 1) is
+# undefined behaviour in the reference (and a crash in the oracle); its hostile set is the same pairs normalised, the unusable ones dropped
+def unit_or_up(v):
+    with np.errstate(all="ignore"):
+        l = np.linalg.norm(v.astype(np.float64), axis=1, keepdims=True)
+        w = (v / l).astype(np.float32)
+    good = np.isfinite(w).all(axis=1) & (np.abs(w) <= 1.0).all(axis=1)
+    w[~good] = np.array([0, 0, 1], np.float32)
+    return w
+iu, ou = unit_or_up(i), unit_or_up(o)
+diu, dou = dev(iu), dev(ou)
 for name, g, ob, plist in kinds:
     if ob is None:
+        continue
+    if name == "utia":
+        for op in ("eval", "evalp", "pdf"):
+            got = host(getattr(g, op)(diu, dou)); want = O.eval(ob, iu, ou, None, op)
+            m = value_bits(got) != value_bits(want)
+            print("%-22s %-40s %-8s %s" % (name, "normalised hostile pairs", op, "ok" if not m.any() else "MISMATCH %d values" % int(m.sum()))); bad += int(m.any())
         continue
     for p in plist:
         up = mk_params(p)

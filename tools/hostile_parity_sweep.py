@@ -137,4 +137,13 @@ for name, g, ob in (("ggx pp", kinds[0][1], kinds[0][2]), ("beckmann pp", kinds[
         got = host(g.eval_pp(di, do, dpp, want=op)); want = O.eval_pp(ob, i, o, pp, op)
         mm = value_bits(got) != value_bits(want)
         print("%-22s %-40s %-8s %s" % (name, "pdfparams records", op, "ok" if not mm.any() else "MISMATCH %d values, rows %s" % (int(mm.sum()), np.where(mm.reshape(m, -1).any(axis=1))[0][:6].tolist()))); bad += int(mm.any())
+# brdf::io_to_hd / hd_to_io and the MERL bin index on the same directions
+for fn, ofn in (("io_to_hd", O.io_to_hd), ("hd_to_io", O.hd_to_io)):
+    ga, gb_ = getattr(djb.brdf, fn)(di, do, ctx=ctx); wa, wb = ofn(i, o)
+    mm = (value_bits(host(ga)) != value_bits(wa)) | (value_bits(host(gb_)) != value_bits(wb))
+    print("%-22s %-40s %-8s %s" % ("brdf", fn, "", "ok" if not mm.any() else "MISMATCH %d values, rows %s" % (int(mm.sum()), np.where(mm.any(axis=1))[0][:6].tolist()))); bad += int(mm.any())
+fin = np.isfinite(i).all(axis=1) & np.isfinite(o).all(axis=1)       # (int) of a NaN angle is undefined in the reference
+gi = np.asarray(host(djb.merl_index(di, do, ctx=ctx))) if not ctx.is_cpu else np.asarray(djb.merl_index(i, o, ctx=ctx)); wi_ = O.merl_index(i, o)
+mm = (gi.reshape(-1) != wi_.reshape(-1)) & fin
+print("%-22s %-40s %-8s %s" % ("merl", "bin index (finite directions)", "", "ok" if not mm.any() else "MISMATCH %d, rows %s" % (int(mm.sum()), np.where(mm)[0][:6].tolist()))); bad += int(mm.any())
 print("cases with a mismatch:", bad)

@@ -385,6 +385,17 @@ def test_two_tier_overflow_and_in_place_calls(gpu_ctx):
                                         C.byref(vo.view), C.byref(pe._p), C.byref(vo.view), C.c_int(0)))
     gpu_ctx.synchronize()
     assert torch.equal(oo.view(torch.int32), want_s.view(torch.int32)), "in-place Beckmann sample differs"
+    # (4) in-place evalp of a SHARP Beckmann lobe, over i and over o: k_eval_bk_sharp stores placeholders for the pairs it queues and
+    # evaluates them later -- from its queue, not from the arrays it has already written
+    ps = djb.microfacet.params.isotropic(0.05)
+    want_e = bk.evalp(i, o, ps)
+    for over_i in (True, False):
+        ii, oo = i.clone(), o.clone()
+        vi, vo = djb._Vec(ii), djb._Vec(oo)
+        dst = vi if over_i else vo
+        djb._lib.check(lib.djb_evalp_batch(gpu_ctx._h, bk._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), C.byref(ps._p), C.byref(dst.view), C.c_int(0)))
+        gpu_ctx.synchronize()
+        assert torch.equal((ii if over_i else oo).view(torch.int32), want_e.view(torch.int32)), f"in-place sharp-lobe evalp differs (over {'i' if over_i else 'o'})"
 
 
 def test_merl_two_tier_every_output_set_and_launch_shape(gpu_ctx):

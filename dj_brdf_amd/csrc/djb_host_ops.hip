@@ -343,7 +343,11 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 				long long m = n - lo < CH ? n - lo : CH;
 				const size_t REC = 32;
 				wl_adapt(ctx);
-				size_t cap = (size_t)((double)m * ctx->wl_frac) + 4096;
+				// a first call has nothing to adapt to, and an overflow costs a full exact pass ON TOP of tier 1 (sgd: 8 ms instead of 1.4 per 1e8
+				// on each of the first two calls -- tools/exp/r04/contract_fixup_share.sh): the kinds whose tier 2 is a few per cent by
+				// nature (sgd's wall, Beckmann's exp(-r^2) tail) start at 12 % (3.8 B of scratch per pair) instead of 2 %
+				const double floor_frac = (b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_BECKMANN) ? 0.12 : 0.0;
+				size_t cap = (size_t)((double)m * std::max(ctx->wl_frac, floor_frac)) + 4096;
 				cap = (cap + djbk::CONTRACT_SHARDS - 1) / djbk::CONTRACT_SHARDS * djbk::CONTRACT_SHARDS;     // whole segments
 				if (ctx->test_worklist_cap >= 0) cap = ((size_t)ctx->test_worklist_cap / djbk::CONTRACT_SHARDS + 1) * djbk::CONTRACT_SHARDS;
 				if (cap > 0xfffffff0ull) cap = 0xfffffff0ull / djbk::CONTRACT_SHARDS * djbk::CONTRACT_SHARDS;

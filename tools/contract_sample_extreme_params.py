@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The contract-mode samplers (djb_selftest_contract_sample) at the corners of their parameter domain (1e-3 <= ax, ay <= 100, |rho| <= 0.99,
 |tx|, |ty| <= 10): nothing kept may be outside 1e-5, the bound must bound.  python tools/contract_sample_extreme_params.py  (GPU box)"""
-import sys; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from dj_brdf_amd import djb
 from test_gpu_contract import mk_params
 ctx = djb.default_context(0)

@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Why samples leave the GGX contract sampler's fast path, by input family (needs a -DDJB_EXP_RARE_COUNT build: DJB_LIB_PATH=...)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from dj_brdf_amd import djb, synth
 ctx = djb.default_context(0)

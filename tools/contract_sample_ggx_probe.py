@@ -1,4 +1,8 @@
-import sys; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+#!/usr/bin/env python3
+"""djb_selftest_contract_sample on the GGX lobe over lobes x families (profiles/r04/contract_sample_ggx.txt)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from dj_brdf_amd import djb
 from test_gpu_contract import SAMPLE_PARAMS, mk_params
 ctx = djb.default_context(0)

@@ -347,98 +347,6 @@ __global__ __launch_bounds__(BLOCK) void k_ct_fast_v4(CtParams c, long long n4, 
 	if (wcount) wl_flush(wbuf[wave], wcount, lane, list, cap, count);
 }
 
-// The same tier 1 with tier 2 drained IN the kernel, as the MERL look-up does (djb_kernels_merl.hip): a declined pair leaves a placeholder
-// in the wave's float4 store and its {k, i, o} in a per-wave LDS queue; whenever 64 wait -- and once at the wave's end -- the wave runs
-// eval_one on them as one dense wave.  For the kinds whose tier 2 is a few per cent by nature (sgd's wall, Beckmann's exp(-r^2) tail): no
-// worklist in HBM, no capacity to overflow on a first call, no second launch.  Persistent grid (the queue needs iterations to fill).
-// counts: the workgroup adds its number of tier-2 pairs to its shard's counter (the host's tier-2 share bookkeeping, wl_note).
-constexpr unsigned int CTQ = 320;            // < 64 waiting + at most 4 x 64 new per iteration
-template <int KIND, int WANT, int FRK>
-__global__ __launch_bounds__(BLOCK) void k_ct_drain_v4(CtParams c, Brdf b, Params p, long long n4, View vi, View vo, View vout, float *out_pdf,
-                                                       unsigned int *counts)
-{
-	constexpr bool EXPT = KIND == KIND_BECKMANN || KIND == KIND_SGD || KIND == KIND_ABC, POWT = KIND == KIND_SGD || KIND == KIND_ABC, ACOST = KIND == KIND_SGD;
-	__shared__ unsigned long long s_exp[EXPT ? 256 : 1];
-	__shared__ double s_pow[POWT ? 384 : 1];
-	__shared__ double s_acos[ACOST ? 2568 + 128 : 1];
-	__shared__ unsigned int s_q[BLOCK / 64][7][CTQ];
-	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
-	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
-	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BLOCK);
-	__syncthreads();
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned int (&q_)[7][CTQ] = s_q[wave];
-	unsigned int qn = 0, total = 0;                              // wave-uniform
-	const float4 *ix4 = (const float4 *)vi.x, *iy4 = (const float4 *)vi.y, *iz4 = (const float4 *)vi.z;
-	const float4 *ox4 = (const float4 *)vo.x, *oy4 = (const float4 *)vo.y, *oz4 = (const float4 *)vo.z;
-	const long long stride = (long long)gridDim.x * BLOCK;
-	for (long long q0 = (long long)blockIdx.x * BLOCK; ; q0 += stride) {          // one extra trip drains what is left
-		const bool last = q0 >= n4;
-		const long long q = q0 + threadIdx.x;
-		bool amb[4] = { false, false, false, false };
-		float ixs[4], iys[4], izs[4], oxs[4], oys[4], ozs[4];
-		if (!last && q < n4) {
-			float4 ax = nt_load4(ix4 + q), ay = nt_load4(iy4 + q), az = nt_load4(iz4 + q),
-			       bx = nt_load4(ox4 + q), by = nt_load4(oy4 + q), bz = nt_load4(oz4 + q);
-			nt_load_wait6(ax, ay, az, bx, by, bz);
-			ixs[0] = ax.x; ixs[1] = ax.y; ixs[2] = ax.z; ixs[3] = ax.w;
-			iys[0] = ay.x; iys[1] = ay.y; iys[2] = ay.z; iys[3] = ay.w;
-			izs[0] = az.x; izs[1] = az.y; izs[2] = az.z; izs[3] = az.w;
-			oxs[0] = bx.x; oxs[1] = bx.y; oxs[2] = bx.z; oxs[3] = bx.w;
-			oys[0] = by.x; oys[1] = by.y; oys[2] = by.z; oys[3] = by.w;
-			ozs[0] = bz.x; ozs[1] = bz.y; ozs[2] = bz.z; ozs[3] = bz.w;
-			float rr[4], gg[4], bb[4], pp[4];
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				v3 fr; float pdf;
-				amb[j] = !ct_eval_one<KIND, WANT, FRK>(c, mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]), fr, pdf);
-				rr[j] = fr.x; gg[j] = fr.y; bb[j] = fr.z; pp[j] = pdf;
-			}
-			if (WANT & 3) {
-				nt_store4(rr[0], rr[1], rr[2], rr[3], (float4 *)vout.x + q);
-				nt_store4(gg[0], gg[1], gg[2], gg[3], (float4 *)vout.y + q);
-				nt_store4(bb[0], bb[1], bb[2], bb[3], (float4 *)vout.z + q);
-			}
-			if (WANT & 4) nt_store4(pp[0], pp[1], pp[2], pp[3], (float4 *)out_pdf + q);
-		}
-		if (__ballot(amb[0] | amb[1] | amb[2] | amb[3])) {
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const unsigned long long mask = __ballot(amb[j]);
-				if (!mask) continue;
-				if (amb[j]) {
-					const unsigned int s_ = qn + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
-					q_[0][s_] = (unsigned int)(4 * q + j);
-					q_[1][s_] = __float_as_uint(ixs[j]); q_[2][s_] = __float_as_uint(iys[j]); q_[3][s_] = __float_as_uint(izs[j]);
-					q_[4][s_] = __float_as_uint(oxs[j]); q_[5][s_] = __float_as_uint(oys[j]); q_[6][s_] = __float_as_uint(ozs[j]);
-				}
-				qn += (unsigned int)__popcll(mask); total += (unsigned int)__popcll(mask);
-			}
-		}
-		while (qn >= 64u || (last && qn)) {                                       // ONE drain site: the exact path is large
-			const unsigned int cnt = qn < 64u ? qn : 64u;
-			qn -= cnt;
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the placeholders of these pairs leave the wave first
-			if ((unsigned int)lane < cnt) {
-				const unsigned int s_ = qn + (unsigned int)lane;
-				const long long k = (long long)q_[0][s_];
-				const v3 i = mk(__uint_as_float(q_[1][s_]), __uint_as_float(q_[2][s_]), __uint_as_float(q_[3][s_]));
-				const v3 o = mk(__uint_as_float(q_[4][s_]), __uint_as_float(q_[5][s_]), __uint_as_float(q_[6][s_]));
-				v3 fr; float pdf;
-				eval_one<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
-				if (WANT & 3) store3(vout, k, fr);
-				if (WANT & 4) out_pdf[k] = pdf;
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-		}
-		if (last) break;
-	}
-	if (lane == 0 && total) atomicAdd(counts + (size_t)(blockIdx.x % CT_SHARDS) * CT_STRIDE, total);
-}
-
 // tier 2: the bit-exact per-pair code on the listed pairs (or on the whole batch when a shard of the list overflowed)
 template <int KIND, int WANT, int FRK>
 __global__ __launch_bounds__(BLOCK) void k_ct_fixup(Brdf b, Params p, long long n, View vi, View vo, View vout, float *out_pdf,
@@ -653,26 +561,6 @@ hipError_t launch_ct(hipStream_t s, const Brdf &b, const Params &p, const CtPara
 	cap /= CT_SHARDS;                                          // records per shard
 	if (cap == 0) cap = 1;
 	const long long n4 = n / 4;
-	if constexpr (KIND == KIND_SGD || KIND == KIND_BECKMANN) {
-		static const bool drain = !(getenv("DJB_CT_DRAIN") && atoi(getenv("DJB_CT_DRAIN")) == 0);
-		if (drain) {
-			// persistent grid, ~16 tiles per workgroup
-			long long tiles = (n4 + BLOCK - 1) / BLOCK, blocks = (tiles + 15) / 16;
-			if (blocks < 2048) blocks = tiles < 2048 ? tiles : 2048;
-			const dim3 gd((unsigned int)(blocks < 1 ? 1 : blocks)), td(BLOCK);
-#define DJB_CTD(W_) do { if (n4 > 0) hipLaunchKernelGGL((k_ct_drain_v4<KIND, W_, FRK>), gd, td, 0, s, c, b, p, n4, i, o, out, out_pdf, count); } while (0)
-			switch (want) {
-			case 1: DJB_CTD(1); break;
-			case 2: DJB_CTD(2); break;
-			case 4: DJB_CTD(4); break;
-			case 5: DJB_CTD(5); break;
-			case 6: DJB_CTD(6); break;
-			default: return hipErrorInvalidValue;
-			}
-#undef DJB_CTD
-			return hipGetLastError();
-		}
-	}
 	// one workgroup per 1024 pairs, no grid-stride cap: measured (profiles/r03/contract_grid.txt, 1e8 pairs) 0.696 ms with
 	// the full grid against 0.77-0.82 ms with 2048 ... 32768 persistent workgroups -- the hardware dispatcher keeps more
 	// loads in flight across workgroup boundaries than a wave's in-order loop does

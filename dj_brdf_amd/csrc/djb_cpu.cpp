@@ -573,6 +573,66 @@ djb_status create_tabular_from_tables(djb_ctx *ctx, int shadow, int res, const f
 	return DJB_OK;
 }
 
+// ---- user-defined sources (dj_brdf.h:74-109: any class deriving from djb::brdf can be fitted).  The (i, o) pairs at which
+// tabular::tabular(const brdf &, res, shadow) calls brdf.eval, in the reference's call order: the res - 1 back-scatter
+// directions of compute_p22_smith (dj_brdf.h:2488-2494), then the pairs of compute_fresnel (dj_brdf.h:2589-2611; dir_i is
+// forced to (0, 0, 1) there).  A pair the reference's loop never reaches reads NaN.  Slot numbering = fit_merl_slot_count.
+int fit_query_count(int res) { return res > 2 ? fit_merl_slot_count(res) : 0; }
+int fit_aniso_query_count(int elev, int azim) { return elev > 1 && azim > 1 ? aniso_query_count(elev, azim) : 0; }
+djb_status fit_query_dirs(int res, float *i3, float *o3)
+{
+	if (res <= 2) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");   // dj_brdf.h:2218
+	const int cnt = res - 1;
+	auto put = [](float *p, int s, v3 v) { p[3 * (size_t)s] = v.x; p[3 * (size_t)s + 1] = v.y; p[3 * (size_t)s + 2] = v.z; };
+	for (int k = 0; k < cnt; ++k) {
+		float th = fit_backscatter_theta(k, cnt);
+		v3 w = from_angles(th * th, 0.0f);
+		put(i3, k, w); put(o3, k, w);
+	}
+	const float qnan = __builtin_nanf("");
+	for (int i = 0; i < cnt; ++i)
+		for (int j = 0; j <= cnt; ++j) {
+			const int s = cnt + i * (cnt + 1) + j;
+			v3 dir_i, dir_o;
+			if (!fit_fresnel_dirs(i, j, cnt, dir_i, dir_o)) dir_i = dir_o = mk(qnan, qnan, qnan);
+			put(i3, s, dir_i); put(o3, s, dir_o);
+		}
+	return DJB_OK;
+}
+djb_status fit_aniso_query_dirs(int elev, int azim, float *i3, float *o3)
+{
+	if (elev <= 1 || azim <= 1 || elev > 1024 || azim > 1024)
+		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");           // dj_brdf.h:2244
+	aniso_query_dirs(elev, azim, i3, o3);
+	return DJB_OK;
+}
+
+// the source of a fit from per-slot samples: what brdf.eval returned at each query slot (rgb, 3 floats per slot)
+static Brdf sampled_source(const float *rgb)
+{
+	Brdf src;
+	memset(&src, 0, sizeof src);
+	src.kind = KIND_MERL; src.shadow = 1; src.fr.kind = FR_IDEAL;
+	src.merl = (const MerlTexel *)rgb; src.merl_sparse = 1;
+	return src;
+}
+djb_status create_tabular_from_samples(djb_ctx *ctx, int res, int shadow, const float *rgb, djb_brdf **out)
+{
+	if (res <= 2) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");   // dj_brdf.h:2218
+	Params std_p;
+	djb_status st = params_for(nullptr, -1, &std_p);
+	if (st != DJB_OK) return st;
+	FitResult R;
+	fit_tabular(sampled_source(rgb), std_p, res, shadow != 0, R);
+	CpuBrdf *t = alloc_brdf(ctx, KIND_TABULAR);
+	t->p22.swap(R.p22); t->sigma.swap(R.sigma); t->cdf.swap(R.cdf); t->qf.swap(R.qf); t->fresnel.swap(R.fresnel);
+	t->qf.resize(R.n_qf);
+	t->alpha_beckmann = R.alpha_beckmann; t->alpha_ggx = R.alpha_ggx;
+	finish_tabular(t, res, shadow);
+	*out = (djb_brdf *)t;
+	return DJB_OK;
+}
+
 static void finish_aniso(CpuBrdf *t, int shadow)
 {
 	Brdf &d = t->dev;
@@ -606,6 +666,25 @@ djb_status create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src, int ele
 	if (st != DJB_OK) return st;
 	AnisoFit A;
 	fit_aniso(C(ctx), B(src)->dev, std_p, elev, azim, shadow != 0, A);
+	CpuBrdf *t = alloc_brdf(ctx, KIND_TABULAR_ANISO);
+	t->elev = elev; t->azim = azim; t->aniso_qf2_entries = A.qf2_entries;
+	for (int k = 0; k < 8; ++k) t->aniso[k].swap(A.tab[k]);
+	t->fresnel.swap(A.fresnel);
+	memcpy(t->aniso_fit, A.fit, sizeof t->aniso_fit);
+	finish_aniso(t, shadow);
+	*out = (djb_brdf *)t;
+	return DJB_OK;
+}
+
+djb_status create_tabular_anisotropic_from_samples(djb_ctx *ctx, int elev, int azim, int shadow, const float *rgb, djb_brdf **out)
+{
+	if (elev <= 1 || azim <= 1 || elev > 1024 || azim > 1024)
+		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");           // dj_brdf.h:2244
+	Params std_p;
+	djb_status st = params_for(nullptr, -1, &std_p);
+	if (st != DJB_OK) return st;
+	AnisoFit A;
+	fit_aniso(C(ctx), sampled_source(rgb), std_p, elev, azim, shadow != 0, A);
 	CpuBrdf *t = alloc_brdf(ctx, KIND_TABULAR_ANISO);
 	t->elev = elev; t->azim = azim; t->aniso_qf2_entries = A.qf2_entries;
 	for (int k = 0; k < 8; ++k) t->aniso[k].swap(A.tab[k]);

@@ -56,6 +56,13 @@ djb_status create_tabular_from_tables(djb_ctx *, int shadow, int res, const floa
 djb_status create_aniso_from_tables(djb_ctx *, int shadow, int elev, int azim, const float *const tabs[8], const int counts[8],
                                     const float *fresnel3, const float fit10[10], int qf2_entries, djb_brdf **);
 djb_status create_tabular_anisotropic(djb_ctx *, const djb_brdf *src, int elev, int azim, int shadow, djb_brdf **);
+// fits of user-defined sources: the query slots of a fit (host code, any context) and the fit from per-slot samples
+int fit_query_count(int res);
+int fit_aniso_query_count(int elev, int azim);
+djb_status fit_query_dirs(int res, float *i3, float *o3);
+djb_status fit_aniso_query_dirs(int elev, int azim, float *i3, float *o3);
+djb_status create_tabular_from_samples(djb_ctx *, int res, int shadow, const float *rgb, djb_brdf **);
+djb_status create_tabular_anisotropic_from_samples(djb_ctx *, int elev, int azim, int shadow, const float *rgb, djb_brdf **);
 djb_status destroy(djb_brdf *);
 int kind(const djb_brdf *);
 int get_shadow(const djb_brdf *);

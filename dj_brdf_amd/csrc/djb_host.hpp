@@ -338,6 +338,12 @@ djb_status alloc_brdf(djb_ctx *ctx, int kind, djb_brdf **out);
 djb_status upload_floats(djb_brdf *b, const float *host, size_t count, const float **dev_out);
 djb_status set_fresnel(djb_brdf *b, const djb_fresnel_desc *f);
 djb_status create_microfacet(djb_ctx *ctx, int kind, const djb_fresnel_desc *f, int shadow, djb_brdf **out);
+} // namespace djbh
+namespace djbk {
+// per-slot rgb samples in HBM as a fit source (djbdev::Brdf::merl_sparse; djb_host.hip): never handed to the eval kernels
+djb_status wrap_merl_slots(djb_ctx *ctx, djbdev::MerlTexel *slots, djb_brdf **out);
+}
+namespace djbh {
 
 } // namespace djbh
 

@@ -87,26 +87,18 @@ static djb_status run_fit(djb_ctx *ctx, const std::vector<Brdf> &srcs, int src_k
 	return DJB_OK;
 }
 
-djb_status djb_brdf_create_tabular(djb_ctx *ctx, const djb_brdf *src, int res, int shadow, djb_brdf **out)
-try {
-	if (is_cpu(ctx) && src && out) {
-		if (!is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a CPU context fits BRDFs of a CPU context");
-		return djbcpu::create_tabular(ctx, src, res, shadow, out);
-	}
-	if (src && is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf belongs to a CPU context");
-	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
-	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
-	if (st != DJB_OK) return st;
-	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+// the tabular object of a fit of `src` (a device view: a resident BRDF, or the per-slot samples of a user-defined one)
+static djb_status gpu_tabular(djb_ctx *ctx, const Brdf &src, int res, int shadow, djb_brdf **out)
+{
 	if (res <= 2) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");
 	djb_brdf *t;
 	alloc_brdf(ctx, DJB_KIND_TABULAR, &t);
 	t->dev.shadow = shadow != 0;
 	t->p22.resize(res); t->sigma.resize(res); t->cdf.resize(res); t->qf.resize(res); t->fresnel.resize(3 * (size_t)res);
 	int n_qf = 0;
-	std::vector<Brdf> srcs(1, src->dev);
-	st = run_fit(ctx, srcs, src->dev.kind, res, shadow, &t->alpha_beckmann, &t->alpha_ggx, t->p22.data(),
-	             t->sigma.data(), t->cdf.data(), t->qf.data(), t->fresnel.data(), &n_qf);
+	std::vector<Brdf> srcs(1, src);
+	djb_status st = run_fit(ctx, srcs, src.kind, res, shadow, &t->alpha_beckmann, &t->alpha_ggx, t->p22.data(),
+	                        t->sigma.data(), t->cdf.data(), t->qf.data(), t->fresnel.data(), &n_qf);
 	if (st != DJB_OK) { djb_brdf_destroy(t); return st; }
 	t->qf.resize(n_qf);
 	t->dev.n_p22 = res; t->dev.n_sigma = res; t->dev.n_cdf = res; t->dev.n_qf = n_qf;
@@ -121,21 +113,104 @@ try {
 	*out = t;
 	return DJB_OK;
 }
-DJB_ABI_CATCH
 
-// djb::tabular_anisotropic(brdf, elevation_res, azimuthal_res, shadow), dj_brdf.h:2238-2273
-djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src, int elev, int azim,
-                                               int shadow, djb_brdf **out)
+djb_status djb_brdf_create_tabular(djb_ctx *ctx, const djb_brdf *src, int res, int shadow, djb_brdf **out)
 try {
 	if (is_cpu(ctx) && src && out) {
 		if (!is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a CPU context fits BRDFs of a CPU context");
-		return djbcpu::create_tabular_anisotropic(ctx, src, elev, azim, shadow, out);
+		return djbcpu::create_tabular(ctx, src, res, shadow, out);
 	}
 	if (src && is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf belongs to a CPU context");
 	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	return gpu_tabular(ctx, src->dev, res, shadow, out);
+}
+DJB_ABI_CATCH
+
+// ---- fits of user-defined sources (dj_brdf.h:74-109: `eval` is the one pure virtual; tabular's constructor only ever calls
+// brdf.eval, at directions that depend on the resolution alone).  The caller evaluates its BRDF on the host at the query slots
+// (djb_fit_query_dirs) and hands the rgb samples over; the fit itself is the same k_fit launch, reading one rgb per slot.
+static djb_status store_dirs(const std::vector<float> &v3s, int64_t n, const djb_vec3_view *out)
+{
+	if (!out) return DJB_OK;
+	if (!out->x || !out->y || !out->z) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null view");
+	for (int64_t k = 0; k < n; ++k) {
+		out->x[k * out->stride] = v3s[3 * (size_t)k]; out->y[k * out->stride] = v3s[3 * (size_t)k + 1]; out->z[k * out->stride] = v3s[3 * (size_t)k + 2];
+	}
+	return DJB_OK;
+}
+djb_status djb_fit_query_dirs(int res, int64_t capacity, const djb_vec3_view *out_i, const djb_vec3_view *out_o, int64_t *count)
+try {
+	if (res <= 2) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");            // dj_brdf.h:2218
+	const int64_t n = djbcpu::fit_query_count(res);
+	if (count) *count = n;
+	if (!out_i && !out_o) return DJB_OK;
+	if (capacity < n) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a fit at resolution %d has %lld query slots, capacity %lld", res, (long long)n, (long long)capacity);
+	djbhostlibm::init();
+	std::vector<float> vi(3 * (size_t)n), vo(3 * (size_t)n);
+	djb_status st = djbcpu::fit_query_dirs(res, vi.data(), vo.data());
+	if (st == DJB_OK) st = store_dirs(vi, n, out_i);
+	if (st == DJB_OK) st = store_dirs(vo, n, out_o);
+	return st;
+}
+DJB_ABI_CATCH
+
+djb_status djb_fit_aniso_query_dirs(int elev, int azim, int64_t capacity, const djb_vec3_view *out_i, const djb_vec3_view *out_o, int64_t *count)
+try {
+	if (elev <= 1 || azim <= 1 || elev > 1024 || azim > 1024)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");                       // dj_brdf.h:2244
+	const int64_t n = djbcpu::fit_aniso_query_count(elev, azim);
+	if (count) *count = n;
+	if (!out_i && !out_o) return DJB_OK;
+	if (capacity < n) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a %d x %d fit has %lld query slots, capacity %lld", elev, azim, (long long)n, (long long)capacity);
+	djbhostlibm::init();
+	std::vector<float> vi(3 * (size_t)n), vo(3 * (size_t)n);
+	djb_status st = djbcpu::fit_aniso_query_dirs(elev, azim, vi.data(), vo.data());
+	if (st == DJB_OK) st = store_dirs(vi, n, out_i);
+	if (st == DJB_OK) st = store_dirs(vo, n, out_o);
+	return st;
+}
+DJB_ABI_CATCH
+
+// the samples in HBM as a per-slot source (djbdev::Brdf::merl_sparse); `holder` owns the block
+static djb_status upload_samples(djb_ctx *ctx, const float *rgb, int64_t n, djb_brdf **holder)
+{
+	djbdev::MerlTexel *d = nullptr;
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipMalloc((void **)&d, sizeof(djbdev::MerlTexel) * (size_t)n));
+	hipError_t e = hipMemcpyAsync(d, rgb, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // pageable source: the caller may free `rgb` on return
+	if (e != hipSuccess) { (void)hipFree(d); (void)hipGetLastError(); return fail(DJB_ERR_HIP, "djb_error: sample upload failed: %s", hipGetErrorString(e)); }
+	djb_status st = djbk::wrap_merl_slots(ctx, d, holder);
+	if (st != DJB_OK) { (void)hipFree(d); return st; }
+	(*holder)->allocs.push_back(d);
+	return DJB_OK;
+}
+
+djb_status djb_brdf_create_tabular_from_samples(djb_ctx *ctx, int res, int shadow, const float *rgb, int64_t count, djb_brdf **out)
+try {
+	if (!ctx || !rgb || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (res <= 2) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");            // dj_brdf.h:2218
+	if (count != djbcpu::fit_query_count(res))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a fit at resolution %d takes %d samples, got %lld", res, djbcpu::fit_query_count(res), (long long)count);
+	if (is_cpu(ctx)) return djbcpu::create_tabular_from_samples(ctx, res, shadow, rgb, out);
+	djb_status st = check_call(ctx, nullptr, 0, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	djb_brdf *holder = nullptr;
+	if ((st = upload_samples(ctx, rgb, count, &holder)) != DJB_OK) return st;
+	st = gpu_tabular(ctx, holder->dev, res, shadow, out);
+	djb_brdf_destroy(holder);
+	return st;
+}
+DJB_ABI_CATCH
+
+// djb::tabular_anisotropic(brdf, elevation_res, azimuthal_res, shadow), dj_brdf.h:2238-2273
+static djb_status gpu_tabular_aniso(djb_ctx *ctx, const Brdf &src_dev, int elev, int azim, int shadow, djb_brdf **out)
+{
+	djb_status st;
 	if (elev <= 1 || azim <= 1 || elev > 1024 || azim > 1024)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");           // dj_brdf.h:2244
 	Params std_p;
@@ -168,7 +243,7 @@ try {
 	S.sig_theta = F4(o_st); S.sig_sin = F4(o_ss); S.sig_cosd = (double *)(blk + o_sc);
 	S.ratio = F4(o_ratio); S.probes = F4(o_probes); S.rowk = F4(o_rowk);
 	S.qf2_rows = F4(o_qrows); S.qf2_len = (int *)(blk + o_qlen); S.qf2_aligned = ctx->aniso_qf2_aligned;
-	if (e == hipSuccess) e = djbk::launch_fit_aniso(ctx->stream, src->dev, std_p, S, shadow != 0);
+	if (e == hipSuccess) e = djbk::launch_fit_aniso(ctx->stream, src_dev, std_p, S, shadow != 0);
 	djb_brdf *t;
 	alloc_brdf(ctx, DJB_KIND_TABULAR_ANISO, &t);
 	t->allocs.push_back(blk);
@@ -202,7 +277,43 @@ try {
 	*out = t;
 	return DJB_OK;
 }
+djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *ctx, const djb_brdf *src, int elev, int azim,
+                                               int shadow, djb_brdf **out)
+try {
+	if (is_cpu(ctx) && src && out) {
+		if (!is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a CPU context fits BRDFs of a CPU context");
+		return djbcpu::create_tabular_anisotropic(ctx, src, elev, azim, shadow, out);
+	}
+	if (src && is_cpu(src)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: brdf belongs to a CPU context");
+	if (!ctx || !src || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	djb_status st = check_call(ctx, src, 0, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	return gpu_tabular_aniso(ctx, src->dev, elev, azim, shadow, out);
+}
 DJB_ABI_CATCH
+
+// tabular_anisotropic of a user-defined source, dj_brdf.h:2238-2273 with brdf.eval sampled by the caller at djb_fit_aniso_query_dirs
+djb_status djb_brdf_create_tabular_anisotropic_from_samples(djb_ctx *ctx, int elev, int azim, int shadow, const float *rgb,
+                                                            int64_t count, djb_brdf **out)
+try {
+	if (!ctx || !rgb || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (elev <= 1 || azim <= 1 || elev > 1024 || azim > 1024)
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: Invalid Resolution");           // dj_brdf.h:2244
+	if (count != djbcpu::fit_aniso_query_count(elev, azim))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a %d x %d fit takes %d samples, got %lld", elev, azim, djbcpu::fit_aniso_query_count(elev, azim), (long long)count);
+	if (is_cpu(ctx)) return djbcpu::create_tabular_anisotropic_from_samples(ctx, elev, azim, shadow, rgb, out);
+	djb_status st = check_call(ctx, nullptr, 0, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	djb_brdf *holder = nullptr;
+	if ((st = upload_samples(ctx, rgb, count, &holder)) != DJB_OK) return st;
+	st = gpu_tabular_aniso(ctx, holder->dev, elev, azim, shadow, out);
+	djb_brdf_destroy(holder);
+	return st;
+}
+DJB_ABI_CATCH
+
 
 djb_status djb_tabular_anisotropic_get(const djb_brdf *tab, int which, float *outp, int *count, int *elev, int *azim)
 try {

@@ -37,12 +37,17 @@ DJB_DEV Brdf self_view(const AnisoScratch &S, int shadow)
 	return b;
 }
 
+// slot: the query slot of this look-up (djb_cpu_aniso.inc: aniso_query_dirs); a per-slot source (Brdf::merl_sparse: the samples of a
+// user-defined brdf, djb_brdf_create_tabular_anisotropic_from_samples) holds one rgb per slot
 template <int SRC>
-DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o)
+DJB_DEV v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o, int slot)
 {
 	v3 fr = mk(0, 0, 0); float pdf;
 	if (SRC <= KIND_TABULAR || SRC == KIND_TABULAR_ANISO) mf_eval_pdf<SRC, 1>(src, std_p, i, o, fr, pdf);
-	else if (SRC == KIND_MERL) fr = merl_eval(src, i, o);
+	else if (SRC == KIND_MERL) {
+		if (src.merl_sparse) { MerlTexel t = src.merl[slot]; fr = mk(t.x, t.y, t.z); }
+		else fr = merl_eval(src, i, o);
+	}
 	else if (SRC == KIND_UTIA) fr = utia_eval(src, i, o);
 	else if (SRC == KIND_SGD) fr = sgd_eval(src, i, o);
 	else if (SRC == KIND_ABC) fr = abc_eval(src, i, o);
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(BLOCK) void ka_setup(Brdf src, Params std_p, AnisoS
 	float zo = cos_f(theta);
 	S.zo[a] = zo; S.xo[a] = F(D(st) * glibc_cos(D(phi))); S.yo[a] = F(D(st) * glibc_sin(D(phi)));
 	v3 wv = from_angles(theta, phi);
-	float fr_i = intensity(src_eval<SRC>(src, std_p, wv, wv));
+	float fr_i = intensity(src_eval<SRC>(src, std_p, wv, wv, a));
 	S.k1[a] = F(D(dtheta * dphi) * (4.0 * D(fr_i) * glibc_pow(D(zo), D(5.0f))));
 	float tt = tan_f(theta);
 	S.tn[a] = tt; S.dn[a] = zo * zo;               // cos_theta * cos_theta (same float as zo)
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void ka_fres_pairs(Brdf src, Params std_p, A
 		v3 dir_i, dir_o;
 		hd_to_io(dir_h, dir_d, dir_i, dir_o);
 		dir_i = mk(0, 0, 1);
-		v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o);
+		v3 fr1 = src_eval<SRC>(src, std_p, dir_i, dir_o, cnt * S.azim + e);
 		v3 fr2; float pdf;
 		mf_eval_pdf<KIND_TABULAR_ANISO, 1>(self, std_p, dir_i, dir_o, fr2, pdf);
 		if (D(fr2.x) > 1e-4) rx = fr1.x / fr2.x;

@@ -878,15 +878,115 @@ class utia(brdf):
         return _get_samples(self)
 
 
+# --------------------------------------------------------------------------- user-defined BRDFs (dj_brdf.h:74-109)
+def fit_query_dirs(resolution: int):
+    """The (i, o) pairs at which ``tabular(src, resolution)`` evaluates its source, in the reference's call order
+    (dj_brdf.h:2494, 2610): two [n,3] float32 arrays; a pair the reference's loop never reaches is NaN."""
+    return _query_dirs("djb_fit_query_dirs", (C.c_int(resolution),))
+
+
+def fit_aniso_query_dirs(elevation_res: int, azimuthal_res: int):
+    """the same for ``tabular_anisotropic(src, elevation_res, azimuthal_res)`` (dj_brdf.h:2545, 2671)"""
+    return _query_dirs("djb_fit_aniso_query_dirs", (C.c_int(elevation_res), C.c_int(azimuthal_res)))
+
+
+def _query_dirs(fn, head):
+    f = getattr(_lib.load(), fn)
+    n = C.c_int64()
+    _lib.check(f(*head, C.c_int64(0), None, None, C.byref(n)))
+    qi, qo = _Vec(np.empty((n.value, 3), np.float32)), _Vec(np.empty((n.value, 3), np.float32))
+    _lib.check(f(*head, n, C.byref(qi.view), C.byref(qo.view), None))
+    return qi.keep, qo.keep
+
+
+def _sample_source(src, qi, qo) -> np.ndarray:
+    """src.eval at the valid query slots (one vectorised call, slot order kept) -> [n,3] float32, zeros elsewhere"""
+    ok = ~np.isnan(qo[:, 0])
+    rgb = np.zeros((qi.shape[0], 3), np.float32)
+    rgb[ok] = np.asarray(src.eval(qi[ok], qo[ok]), np.float32).reshape(-1, 3)
+    return rgb
+
+
+class user_brdf(brdf):
+    """A BRDF defined by the CALLER: the reference's extension point -- ``class brdf`` with its public constructor and
+    ``eval`` as the one pure virtual (dj_brdf.h:74-109).  Derive and override ``eval(i, o, user_param=None)`` (host
+    [n,3] float32 arrays in, [n,3] out; vectorised numpy is the natural form).  The other operators are the
+    reference's base-class defaults (dj_brdf.h:795-845); ``tabular`` / ``tabular_anisotropic`` fit such an object by
+    calling its eval() on the host at the fit's query directions and running the fit kernels on the samples."""
+
+    def __init__(self, ctx=None):
+        super().__init__(ctx)
+        self._base = lambert(ctx=self.ctx)      # brdf::sample / brdf::pdf are what lambert inherits unchanged
+
+    def eval(self, i, o, user_param=None):      # pure virtual
+        raise NotImplementedError("djb_error: a user_brdf must override eval(i, o, user_param=None)")
+
+    @staticmethod
+    def _host(a):
+        return np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+
+    def evalp(self, i, o, user_param=None):     # dj_brdf.h:803-806: eval * i.z
+        i = self._host(i)
+        return np.asarray(self.eval(i, self._host(o), user_param), np.float32).reshape(-1, 3) * i[:, 2:3]
+
+    def eval_hd(self, h, d, user_param=None):   # dj_brdf.h:795-801
+        i, o = brdf.hd_to_io(self._host(h), self._host(d), ctx=self.ctx)
+        return np.asarray(self.eval(i, o, user_param), np.float32).reshape(-1, 3)
+
+    def evalp_hd(self, h, d, user_param=None):  # dj_brdf.h:808-814
+        i, o = brdf.hd_to_io(self._host(h), self._host(d), ctx=self.ctx)
+        return np.asarray(self.eval(i, o, user_param), np.float32).reshape(-1, 3) * i[:, 2:3]
+
+    def pdf(self, i, o, user_param=None):       # dj_brdf.h:842-845
+        return self._base.pdf(self._host(i), self._host(o))
+
+    def eval_pdf(self, i, o, user_param=None, cos=False):
+        return (self.evalp if cos else self.eval)(i, o, user_param), self.pdf(i, o)
+
+    def sample(self, u1, u2, o, user_param=None):   # dj_brdf.h:830-840
+        return self._base.sample(u1, u2, self._host(o))
+
+    def sample_rng(self, seed_u1, seed_u2, o, user_param=None, start=0):
+        raise exc(1, "djb_error: sample_rng needs a BRDF resident on the GPU")
+
+    def evalp_is(self, u1, u2, o, user_param=None):   # dj_brdf.h:816-828: evalp(i_, o) / pdf(i_, o), vec3 / float = (1.0 / b) * a
+        o = self._host(o)
+        i_ = self.sample(u1, u2, o, user_param)
+        pdf_ = self.pdf(i_, o)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = (1.0 / pdf_.astype(np.float64)).astype(np.float32)
+            w = inv[:, None] * self.evalp(i_, o, user_param)
+        return w, i_, pdf_
+
+
 class tabular(microfacet):
     """djb::tabular(brdf, res, shadow): the power-iteration fit, executed by the HIP fit kernel
     (dj_brdf.h:394-425, 2215-2236)."""
 
     def __init__(self, src: brdf, resolution: int, shadow: bool = True, ctx=None):
         brdf.__init__(self, ctx or src.ctx)
-        _lib.check(_lib.load().djb_brdf_create_tabular(self.ctx._h, src._h, C.c_int(resolution),
-                                                       C.c_int(int(shadow)), C.byref(self._h)))
+        if isinstance(src, user_brdf):      # host code: eval() sampled where the reference calls it (dj_brdf.h:2494, 2610)
+            qi, qo = fit_query_dirs(resolution)
+            self._from_samples(resolution, shadow, _sample_source(src, qi, qo))
+        else:
+            _lib.check(_lib.load().djb_brdf_create_tabular(self.ctx._h, src._h, C.c_int(resolution),
+                                                           C.c_int(int(shadow)), C.byref(self._h)))
         self._fresnel = None
+
+    def _from_samples(self, resolution, shadow, rgb):
+        rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+        _lib.check(_lib.load().djb_brdf_create_tabular_from_samples(
+            self.ctx._h, C.c_int(resolution), C.c_int(int(shadow)), C.c_void_p(rgb.ctypes.data), C.c_int64(rgb.shape[0]),
+            C.byref(self._h)))
+
+    @classmethod
+    def from_samples(cls, resolution: int, rgb, shadow: bool = True, ctx=None):
+        """the fit of a source known only through its values at ``fit_query_dirs(resolution)`` ([n,3] rgb; NaN slots ignored)"""
+        t = cls.__new__(cls)
+        brdf.__init__(t, ctx)
+        t._from_samples(resolution, shadow, rgb)
+        t._fresnel = None
+        return t
 
     def supports_smith_vndf_sampling(self):
         return False
@@ -936,10 +1036,29 @@ class tabular_anisotropic(microfacet):
 
     def __init__(self, src: brdf, elevation_res: int, azimuthal_res: int, shadow: bool = True, ctx=None):
         brdf.__init__(self, ctx or src.ctx)
-        _lib.check(_lib.load().djb_brdf_create_tabular_anisotropic(
-            self.ctx._h, src._h, C.c_int(elevation_res), C.c_int(azimuthal_res), C.c_int(int(shadow)),
-            C.byref(self._h)))
+        if isinstance(src, user_brdf):      # dj_brdf.h:2545, 2671
+            qi, qo = fit_aniso_query_dirs(elevation_res, azimuthal_res)
+            self._from_samples(elevation_res, azimuthal_res, shadow, _sample_source(src, qi, qo))
+        else:
+            _lib.check(_lib.load().djb_brdf_create_tabular_anisotropic(
+                self.ctx._h, src._h, C.c_int(elevation_res), C.c_int(azimuthal_res), C.c_int(int(shadow)),
+                C.byref(self._h)))
         self._fresnel = None
+
+    def _from_samples(self, elevation_res, azimuthal_res, shadow, rgb):
+        rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+        _lib.check(_lib.load().djb_brdf_create_tabular_anisotropic_from_samples(
+            self.ctx._h, C.c_int(elevation_res), C.c_int(azimuthal_res), C.c_int(int(shadow)), C.c_void_p(rgb.ctypes.data),
+            C.c_int64(rgb.shape[0]), C.byref(self._h)))
+
+    @classmethod
+    def from_samples(cls, elevation_res: int, azimuthal_res: int, rgb, shadow: bool = True, ctx=None):
+        """the fit of a source known only through its values at ``fit_aniso_query_dirs(elevation_res, azimuthal_res)``"""
+        t = cls.__new__(cls)
+        brdf.__init__(t, ctx)
+        t._from_samples(elevation_res, azimuthal_res, shadow, rgb)
+        t._fresnel = None
+        return t
 
     def supports_smith_vndf_sampling(self):
         return False

@@ -92,9 +92,15 @@ typedef struct {
 	float tx_n, ty_n;
 } djb_params_resolved;
 
-/* djb::fresnel::{ideal,unpolarized,schlick,sgd,spline} (dj_brdf.h:149-207) */
+/* djb::fresnel::{ideal,unpolarized,schlick,sgd,spline} (dj_brdf.h:149-207).
+ * DJB_FRESNEL_HOST marks a term only the CALLER can evaluate -- a class a user derived from fresnel::impl
+ * (dj_brdf.h:157-162).  It never reaches a kernel: the constructors and djb_brdf_set_fresnel refuse it
+ * (DJB_ERR_INVALID_ARGUMENT).  The caller creates the object with DJB_FRESNEL_IDEAL instead -- that term is exactly
+ * (1, 1, 1), so evalp returns the bare D G / (4 o.z) and evalp_is G / G1 -- and multiplies by its own F(cos theta_d) on
+ * the host, which is the reference's expression `F * scalar` (dj_brdf.h:1545, 1762) operation for operation;
+ * include/djb_hip.hpp's microfacet::evalp / evalp_is do exactly that.                                               */
 enum { DJB_FRESNEL_IDEAL = 0, DJB_FRESNEL_UNPOLARIZED = 1, DJB_FRESNEL_SCHLICK = 2,
-       DJB_FRESNEL_SGD = 3, DJB_FRESNEL_SPLINE = 4 };
+       DJB_FRESNEL_SGD = 3, DJB_FRESNEL_SPLINE = 4, DJB_FRESNEL_HOST = 5 };
 typedef struct {
 	int kind;
 	float a[3];           /* unpolarized: ior; schlick: f0; sgd: f0 */
@@ -210,6 +216,25 @@ djb_status djb_brdf_create_tabular(djb_ctx *, const djb_brdf *src, int res, int 
  * 90 x 90 in the reference) is recomputed on the fly, never stored.           dj_brdf.h:441-444 */
 djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *, const djb_brdf *src, int elevation_res,
                                                int azimuthal_res, int shadow, djb_brdf **);
+/* ---- fits of USER-DEFINED sources.  The reference's extension point is `class brdf` with `eval` as its one pure virtual
+ * (dj_brdf.h:74-109); tabular's and tabular_anisotropic's constructors only ever call brdf.eval, at directions fixed by
+ * the resolution: the res-1 back-scatter pairs eval(w, w) of compute_p22_smith (dj_brdf.h:2482-2522; (elev-1)*azim of
+ * them for the anisotropic grid, dj_brdf.h:2525-2579) and the pairs of compute_fresnel with dir_i = (0,0,1)
+ * (dj_brdf.h:2583-2641, 2643-2701).  djb_fit_query_dirs / djb_fit_aniso_query_dirs return those (i, o) pairs (host arrays,
+ * any view layout) in the reference's CALL ORDER; a pair its loop never reaches has NaN components and must be skipped.
+ * The caller evaluates its BRDF there (host code: a C++ virtual, a Python callable, a cgo callback ...), writes rgb[3*s]
+ * for slot s (skipped slots: any value) and the *_from_samples constructors run the same fit kernels on them.  Pure host
+ * functions; out_i / out_o may be NULL to query *count only.                                                        */
+djb_status djb_fit_query_dirs(int res, int64_t capacity, const djb_vec3_view *out_i, const djb_vec3_view *out_o,
+                              int64_t *count);
+djb_status djb_fit_aniso_query_dirs(int elevation_res, int azimuthal_res, int64_t capacity, const djb_vec3_view *out_i,
+                                    const djb_vec3_view *out_o, int64_t *count);
+/* djb::tabular(const brdf &user_defined, res, shadow)                 dj_brdf.h:2215-2236 */
+djb_status djb_brdf_create_tabular_from_samples(djb_ctx *, int res, int shadow, const float *rgb, int64_t count,
+                                                djb_brdf **);
+/* djb::tabular_anisotropic(const brdf &user_defined, elev, azim, shadow)   dj_brdf.h:2238-2273 */
+djb_status djb_brdf_create_tabular_anisotropic_from_samples(djb_ctx *, int elevation_res, int azimuthal_res, int shadow,
+                                                            const float *rgb, int64_t count, djb_brdf **);
 djb_status djb_brdf_destroy(djb_brdf *);
 int        djb_brdf_kind(const djb_brdf *);
 /* merl::get_samples() / utia::get_samples(): the table as the reference holds it -- the file's

@@ -10,8 +10,16 @@
 //     thread from a host twin of the object (no launch, no lock: 60-200 ns per call);
 //     a renderer that can gather a wavefront of intersections should still call the batch form.
 //   * objects live on a djb::hip::context (one GPU + one stream); a process-wide default exists.
+//   * the reference's EXTENSION POINTS are kept: `class brdf` has a public default constructor and `eval` as its one pure
+//     virtual (dj_brdf.h:74-109), `fresnel::impl` has `eval` and `copy` (dj_brdf.h:157-162).  A class a user derives from
+//     either is host code; the library never sees it.  Such an object works wherever the reference accepts it: its other
+//     operators are the base-class defaults of dj_brdf.h:795-845, tabular / tabular_anisotropic fit it by sampling its
+//     eval() on the host at the fit's query directions (djb_fit_query_dirs) and running the fit kernels on the samples,
+//     and a microfacet BRDF holding a user-defined Fresnel term evaluates D G on the GPU and multiplies by the user's
+//     F(cos theta_d) on the host ("user-defined classes").
 // Errors: constructors and calls throw djb::exc carrying the library's djb_error message.
-// All arithmetic runs in the HIP kernels; this header contains no BRDF math.
+// All arithmetic of the library's own classes runs in the HIP kernels; this header only holds the reference's vec3
+// helpers and the one-line base-class compositions a user-derived object needs.
 #ifndef DJB_HIP_HPP
 #define DJB_HIP_HPP
 
@@ -100,6 +108,12 @@ inline vec3 &operator*=(vec3 &a, float_t b) { a.x *= b; a.y *= b; a.z *= b; retu
 inline float_t dot(const vec3 &a, const vec3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline vec3 cross(const vec3 &a, const vec3 &b) { return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 inline vec3 normalize(const vec3 &v) { return (float_t)(1.0 / std::sqrt((double)dot(v, v))) * v; }
+/* utility API, dj_brdf.h:574-576, 612-616, 639-645 (user-derived classes written against the reference use them) */
+template <typename T> static T min(const T &a, const T &b) { return a < b ? a : b; }
+template <typename T> static T max(const T &a, const T &b) { return a > b ? a : b; }
+template <typename T> static T sat(const T &x) { return min(T(1), max(T(0), x)); }
+template <typename T> static T max3(const T &x, const T &y, const T &z) { T m = x; if (m < y) m = y; if (m < z) m = z; return m; }
+inline float_t inversesqrt(float_t x) { return (float_t)(1.0 / std::sqrt((double)x)); }
 
 namespace hip {
 
@@ -160,31 +174,53 @@ inline djb_vec3_view view(const vec3 *p)
 
 } // namespace hip
 
-/* BRDF interface, dj_brdf.h:74-109 */
+/* BRDF interface, dj_brdf.h:74-109.
+ * Two kinds of object implement it:
+ *   * the library's classes below: RESIDENT in HBM behind a djb_brdf handle, every operator a call into libdjb_hip.so;
+ *   * classes a user derives from djb::brdf (public default constructor, `eval` overridden): host code with no handle.
+ *     Their other operators are the reference's base-class defaults (dj_brdf.h:795-845), their batch overloads loop over
+ *     the scalar virtuals, and tabular / tabular_anisotropic fit them from host-side samples of eval().               */
 class brdf {
 public:
-	// ---- the reference's scalar virtuals (batches of one)
-	virtual vec3 eval(const vec3 &i, const vec3 &o, const void *user_param = NULL) const
-	{ vec3 r; eval(1, &i, &o, &r, user_param); return r; }
-	virtual vec3 evalp(const vec3 &i, const vec3 &o, const void *user_param = NULL) const
-	{ vec3 r; evalp(1, &i, &o, &r, user_param); return r; }
-	virtual vec3 eval_hd(const vec3 &h, const vec3 &d, const void *user_param = NULL) const
+	// ---- the reference's virtuals.  evaluate f_r: the one pure virtual (dj_brdf.h:77-78)
+	virtual vec3 eval(const vec3 &i, const vec3 &o, const void *user_param = NULL) const = 0;
+	virtual vec3 eval_hd(const vec3 &h, const vec3 &d, const void *user_param = NULL) const            // dj_brdf.h:795-801
 	{ vec3 i, o; hd_to_io(h, d, &i, &o); return eval(i, o, user_param); }
-	virtual vec3 evalp_hd(const vec3 &h, const vec3 &d, const void *user_param = NULL) const
-	{ vec3 i, o; hd_to_io(h, d, &i, &o); return evalp(i, o, user_param); }
+	virtual vec3 evalp(const vec3 &i, const vec3 &o, const void *user_param = NULL) const               // dj_brdf.h:803-806
+	{
+		if (!resident()) return eval(i, o, user_param) * i.z;
+		vec3 r; evalp(1, &i, &o, &r, user_param); return r;
+	}
+	virtual vec3 evalp_hd(const vec3 &h, const vec3 &d, const void *user_param = NULL) const           // dj_brdf.h:808-814: eval * cos,
+	{ vec3 i, o; hd_to_io(h, d, &i, &o); return eval(i, o, user_param) * i.z; }                        // also where evalp is overridden
 	virtual vec3 evalp_is(float_t u1, float_t u2, const vec3 &o, vec3 *i, float_t *pdf,
 	                      const void *user_param = NULL) const
 	{
+		if (!resident()) {                                                                               // dj_brdf.h:816-828
+			const vec3 i_ = sample(u1, u2, o, user_param);
+			float_t pdf_ = this->pdf(i_, o);
+			if (i) *i = i_;
+			if (pdf) *pdf = pdf_;
+			return evalp(i_, o, user_param) / pdf_;
+		}
 		vec3 w, i_; float_t pdf_ = 0;
 		evalp_is(1, &u1, &u2, &o, &w, &i_, &pdf_, user_param);
 		if (i) *i = i_;
 		if (pdf) *pdf = pdf_;
 		return w;
 	}
-	virtual vec3 sample(float_t u1, float_t u2, const vec3 &o, const void *user_param = NULL) const
-	{ vec3 r; sample(1, &u1, &u2, &o, &r, user_param); return r; }
-	virtual float_t pdf(const vec3 &i, const vec3 &o, const void *user_param = NULL) const
-	{ float_t r = 0; pdf(1, &i, &o, &r, user_param); return r; }
+	virtual vec3 sample(float_t u1, float_t u2, const vec3 &o, const void *user_param = NULL) const    // dj_brdf.h:830-840
+	{
+		vec3 r; djb_vec3_view vo = hip::view(&o), vi = hip::view(&r);
+		hip::check(djb_sample_batch(op_ctx(), op_handle(), 1, &u1, &u2, &vo, m_h ? params_of(user_param) : NULL, &vi, DJB_MEM_HOST));
+		return r;
+	}
+	virtual float_t pdf(const vec3 &i, const vec3 &o, const void *user_param = NULL) const              // dj_brdf.h:842-845
+	{
+		float_t r = 0; djb_vec3_view vi = hip::view(&i), vo = hip::view(&o);
+		hip::check(djb_pdf_batch(op_ctx(), op_handle(), 1, &vi, &vo, m_h ? params_of(user_param) : NULL, &r, DJB_MEM_HOST));
+		return r;
+	}
 	static void io_to_hd(const vec3 &i, const vec3 &o, vec3 *h, vec3 *d)
 	{
 		djb_vec3_view vi = hip::view(&i), vo = hip::view(&o), vh = hip::view(h), vd = hip::view(d);
@@ -196,56 +232,125 @@ public:
 		hip::check(djb_hd_to_io_batch(hip::context::standard().get(), 1, &vh, &vd, &vi, &vo, DJB_MEM_HOST));
 	}
 
-	// ---- batch overloads: n pairs, host arrays of djb::vec3
+	// ---- batch overloads: n pairs, host arrays of djb::vec3.  A resident object runs them as one launch; a user-derived
+	// object (host code) is called once per pair.
 	void eval(size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param = NULL) const
 	{
+		if (!resident()) { for (size_t k = 0; k < n; ++k) out[k] = eval(i[k], o[k], user_param); return; }
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out);
 		hip::check(djb_eval_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 	}
 	void evalp(size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param = NULL) const
 	{
+		if (!resident()) { for (size_t k = 0; k < n; ++k) out[k] = evalp(i[k], o[k], user_param); return; }
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out);
 		hip::check(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 	}
 	void pdf(size_t n, const vec3 *i, const vec3 *o, float_t *out, const void *user_param = NULL) const
 	{
+		if (!overrides_resident_ops()) { for (size_t k = 0; k < n; ++k) out[k] = pdf(i[k], o[k], user_param); return; }
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o);
 		hip::check(djb_pdf_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), out, DJB_MEM_HOST));
 	}
 	void sample(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_i,
 	            const void *user_param = NULL) const
 	{
+		if (!overrides_resident_ops()) { for (size_t k = 0; k < n; ++k) out_i[k] = sample(u1[k], u2[k], o[k], user_param); return; }
 		djb_vec3_view vo = hip::view(o), vi = hip::view(out_i);
 		hip::check(djb_sample_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vi, DJB_MEM_HOST));
 	}
 	void evalp_is(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_weight,
 	              vec3 *out_i, float_t *out_pdf, const void *user_param = NULL) const
 	{
+		if (!resident()) {
+			for (size_t k = 0; k < n; ++k) out_weight[k] = evalp_is(u1[k], u2[k], o[k], &out_i[k], &out_pdf[k], user_param);
+			return;
+		}
 		djb_vec3_view vo = hip::view(o), vw = hip::view(out_weight), vi = hip::view(out_i);
 		hip::check(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi,
 		                              out_pdf, DJB_MEM_HOST));
 	}
-	// ---- batch, device-resident (SoA or strided views in HBM; asynchronous on the context stream)
+	// ---- batch, device-resident (SoA or strided views in HBM; asynchronous on the context stream): resident objects only
 	void eval_device(int64_t n, const djb_vec3_view &i, const djb_vec3_view &o, const djb_vec3_view &out,
 	                 const void *user_param = NULL) const
-	{ hip::check(djb_eval_batch(ctx(), m_h, n, &i, &o, params_of(user_param), &out, DJB_MEM_DEVICE)); }
+	{ need_resident("eval_device"); hip::check(djb_eval_batch(ctx(), m_h, n, &i, &o, params_of(user_param), &out, DJB_MEM_DEVICE)); }
 	void eval_pdf_device(int64_t n, const djb_vec3_view &i, const djb_vec3_view &o, const djb_vec3_view &out,
 	                     float_t *out_pdf, bool cos = false, const void *user_param = NULL) const
-	{ hip::check(djb_eval_pdf_batch(ctx(), m_h, n, &i, &o, params_of(user_param), cos, &out, out_pdf, DJB_MEM_DEVICE)); }
+	{ need_resident("eval_pdf_device"); hip::check(djb_eval_pdf_batch(ctx(), m_h, n, &i, &o, params_of(user_param), cos, &out, out_pdf, DJB_MEM_DEVICE)); }
 
+	// NULL for a user-derived object; for a microfacet BRDF with a user-defined Fresnel term the handle of its D G part
 	const djb_brdf *handle() const { return m_h; }
-	hip::context &get_context() const { return *m_ctx; }
+	// true: every operator of this object is answered by the library from the handle (kernels / host twin);
+	// false: host code is involved (a user-derived class, a user-defined fresnel::impl) and fits sample eval() on the host
+	bool resident() const { return m_h != NULL && !m_host_eval; }
+	hip::context &get_context() const { return m_ctx ? *m_ctx : hip::context::standard(); }
+	brdf() : m_h(NULL), m_ctx(NULL), m_host_eval(true) {}                                                // dj_brdf.h:102
 	virtual ~brdf() { djb_brdf_destroy(m_h); }
 protected:
-	explicit brdf(hip::context *c) : m_h(NULL), m_ctx(c ? c : &hip::context::standard()) {}
-	djb_ctx *ctx() const { return m_ctx->get(); }
+	explicit brdf(hip::context *c) : m_h(NULL), m_ctx(c ? c : &hip::context::standard()), m_host_eval(false) {}
+	djb_ctx *ctx() const { return get_context().get(); }
 	virtual const djb_params *params_of(const void *) const { return NULL; }   // ignored by merl/utia/...
+	// eval of a resident object: what the library's classes override `eval` with
+	vec3 eval_resident(const vec3 &i, const vec3 &o, const void *user_param) const
+	{
+		vec3 r; djb_vec3_view vi = hip::view(&i), vo = hip::view(&o), vr = hip::view(&r);
+		hip::check(djb_eval_batch(ctx(), m_h, 1, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+		return r;
+	}
+	// one-pair calls on the handle whatever resident() says (the D G part of a microfacet BRDF with a user-defined Fresnel term)
+	vec3 handle_evalp(const vec3 &i, const vec3 &o, const void *user_param) const
+	{
+		vec3 r; djb_vec3_view vi = hip::view(&i), vo = hip::view(&o), vr = hip::view(&r);
+		hip::check(djb_evalp_batch(ctx(), m_h, 1, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+		return r;
+	}
+	vec3 handle_evalp_is(float_t u1, float_t u2, const vec3 &o, vec3 *i, float_t *pdf, const void *user_param) const
+	{
+		vec3 w; djb_vec3_view vo = hip::view(&o), vw = hip::view(&w), vi = hip::view(i);
+		hip::check(djb_evalp_is_batch(ctx(), m_h, 1, &u1, &u2, &vo, params_of(user_param), &vw, &vi, pdf, DJB_MEM_HOST));
+		return w;
+	}
+	// sample / pdf never involve the Fresnel term: a handle answers them even when eval is composed on the host
+	bool overrides_resident_ops() const { return m_h != NULL; }
+	void need_resident(const char *what) const
+	{ if (!resident()) throw exc(std::string("djb_error: ") + what + " needs a BRDF resident on the GPU (this object is evaluated by host code)", DJB_ERR_INVALID_ARGUMENT); }
 	djb_brdf *m_h;
 	hip::context *m_ctx;
-private: // noncopyable, dj_brdf.h:104-108
+	bool m_host_eval;
+private:
+	// the base-class sample / pdf (dj_brdf.h:830-845) are what djb::lambert inherits unchanged: a user-derived object
+	// borrows them from a Lambertian on the default context
+	static const djb_brdf *base_ops()
+	{
+		struct holder { djb_brdf *h; holder() : h(NULL) { hip::check(djb_brdf_create_lambert(hip::context::standard().get(), &h)); } ~holder() { djb_brdf_destroy(h); } };
+		static holder b;
+		return b.h;
+	}
+	const djb_brdf *op_handle() const { return m_h ? m_h : base_ops(); }
+	djb_ctx *op_ctx() const { return m_h ? ctx() : hip::context::standard().get(); }
+	// noncopyable, dj_brdf.h:104-108
 	brdf(const brdf &);
 	brdf &operator=(const brdf &);
 };
+/* what each of the library's classes declares: eval answered from the handle; the batch overloads stay visible */
+#define DJB_HIP_RESIDENT_EVAL \
+	using brdf::eval; \
+	vec3 eval(const vec3 &i, const vec3 &o, const void *user_param = NULL) const { return eval_resident(i, o, user_param); }
+
+namespace hip {
+/* brdf.eval(i, o) of a host-evaluated source at the query slots of a fit, in the reference's call order
+ * (dj_brdf.h:2494, 2610; 2545, 2671).  A slot its loops never reach (NaN direction) is not evaluated. */
+inline std::vector<float_t> sample_source(const brdf &src, const std::vector<vec3> &qi, const std::vector<vec3> &qo)
+{
+	std::vector<float_t> rgb(3 * qi.size(), (float_t)0);
+	for (size_t s = 0; s < qi.size(); ++s) {
+		if (qo[s].x != qo[s].x) continue;
+		const vec3 fr = src.eval(qi[s], qo[s]);
+		rgb[3 * s] = fr.x; rgb[3 * s + 1] = fr.y; rgb[3 * s + 2] = fr.z;
+	}
+	return rgb;
+}
+} // namespace hip
 
 /* Lambertian BRDF, dj_brdf.h:112-123 */
 class lambert : public brdf {
@@ -257,6 +362,7 @@ public:
 		vec3 m_reflectance;
 	};
 	explicit lambert(hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_lambert(ctx(), &m_h)); }
+	DJB_HIP_RESIDENT_EVAL
 protected:
 	const djb_params *params_of(const void *user_param) const   // dj_brdf.h:863-865
 	{
@@ -276,6 +382,7 @@ public:
 	merl(const double *samples, int64_t n_per_channel, hip::context *c = NULL) : brdf(c)
 	{ hip::check(djb_brdf_create_merl_from_memory(ctx(), samples, n_per_channel, &m_h)); }
 	const std::vector<double> &get_samples() const { return hip::fetch_samples(m_h, m_samples); }   // dj_brdf.h:132
+	DJB_HIP_RESIDENT_EVAL
 private:
 	mutable std::vector<double> m_samples;
 };
@@ -286,6 +393,7 @@ public:
 	explicit utia(const char *filename, hip::context *c = NULL) : brdf(c)
 	{ hip::check(djb_brdf_create_utia_from_file(ctx(), filename, &m_h)); }
 	const std::vector<double> &get_samples() const { return hip::fetch_samples(m_h, m_samples); }   // dj_brdf.h:143
+	DJB_HIP_RESIDENT_EVAL
 private:
 	mutable std::vector<double> m_samples;
 };
@@ -303,12 +411,20 @@ namespace fresnel {
 	}
 	inline void ior_to_f0(const vec3 &ior, vec3 *f0) { ior_to_f0(ior.x, &f0->x); ior_to_f0(ior.y, &f0->y); ior_to_f0(ior.z, &f0->z); }
 	inline void f0_to_ior(const vec3 &f0, vec3 *ior) { f0_to_ior(f0.x, &ior->x); f0_to_ior(f0.y, &ior->y); f0_to_ior(f0.z, &ior->z); }
+	/* dj_brdf.h:157-162.  The five terms below are fused into the eval kernels (desc() names them to the library).  A class
+	 * a user derives from impl -- eval() and copy() overridden, as in the reference -- is host code: a microfacet BRDF that
+	 * holds one keeps D and G on the GPU and calls the user's eval() on the host per pair (microfacet::evalp below). */
 	class impl {
 	public:
 		virtual ~impl() {}
-		/* dj_brdf.h:160.  Stand-alone evaluation goes through a temporary microfacet object on the
-		 * default context (one launch); inside a BRDF the term is fused into the eval kernels. */
-		vec3 eval(float_t cos_theta_d) const
+		virtual vec3 eval(float_t cos_theta_d) const = 0;
+		virtual impl *copy() const = 0;
+		// how the library runs this term; the default marks a term only the caller can evaluate
+		virtual djb_fresnel_desc desc() const { djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_HOST; return d; }
+	protected:
+		/* stand-alone evaluation of a term the library knows: through a temporary microfacet object on the default
+		 * context (answered by its host twin) */
+		vec3 eval_desc(float_t cos_theta_d) const
 		{
 			djb_fresnel_desc d = desc();
 			djb_ctx *c = hip::context::standard().get();
@@ -321,11 +437,10 @@ namespace fresnel {
 			hip::check(st);
 			return r;
 		}
-		virtual impl *copy() const = 0;
-		virtual djb_fresnel_desc desc() const = 0;
 	};
 	class ideal : public impl {
 	public:
+		vec3 eval(float_t cos_theta_d) const { return eval_desc(cos_theta_d); }
 		impl *copy() const { return new ideal(); }
 		djb_fresnel_desc desc() const { djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_IDEAL; return d; }
 	};
@@ -333,6 +448,7 @@ namespace fresnel {
 		vec3 ior;
 	public:
 		explicit unpolarized(const vec3 &ior) : ior(ior) { DJB_USER_ASSERT(ior.x > 0.0 && ior.y > 0.0 && ior.z > 0.0 && "Invalid ior"); }   // dj_brdf.h:1257
+		vec3 eval(float_t cos_theta_d) const { return eval_desc(cos_theta_d); }
 		impl *copy() const { return new unpolarized(*this); }
 		djb_fresnel_desc desc() const
 		{ djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_UNPOLARIZED; d.a[0] = ior.x; d.a[1] = ior.y; d.a[2] = ior.z; return d; }
@@ -341,6 +457,7 @@ namespace fresnel {
 		vec3 f0;
 	public:
 		explicit schlick(const vec3 &f0) : f0(f0) {}
+		vec3 eval(float_t cos_theta_d) const { return eval_desc(cos_theta_d); }
 		impl *copy() const { return new schlick(*this); }
 		djb_fresnel_desc desc() const
 		{ djb_fresnel_desc d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_SCHLICK; d.a[0] = f0.x; d.a[1] = f0.y; d.a[2] = f0.z; return d; }
@@ -349,6 +466,7 @@ namespace fresnel {
 		vec3 f0, f1;
 	public:
 		sgd(const vec3 &f0, const vec3 &f1) : f0(f0), f1(f1) {}
+		vec3 eval(float_t cos_theta_d) const { return eval_desc(cos_theta_d); }
 		impl *copy() const { return new sgd(*this); }
 		djb_fresnel_desc desc() const
 		{
@@ -361,6 +479,7 @@ namespace fresnel {
 	public:
 		explicit spline(const std::vector<vec3> &points) : m_points(points) {}
 		const std::vector<vec3> &get_points() const { return m_points; }
+		vec3 eval(float_t cos_theta_d) const { return eval_desc(cos_theta_d); }
 		impl *copy() const { return new spline(*this); }
 		djb_fresnel_desc desc() const
 		{
@@ -374,6 +493,7 @@ namespace fresnel {
 class sgd : public brdf {
 public:
 	explicit sgd(const char *name, hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_sgd(ctx(), name, &m_h)); }
+	DJB_HIP_RESIDENT_EVAL
 	vec3 ndf(const vec3 &h) const { return mq(DJB_Q_MODEL_NDF, h, NULL, NULL); }
 	vec3 gaf(const vec3 &h, const vec3 &i, const vec3 &o) const { return mq(DJB_Q_MODEL_GAF, h, &i, &o); }
 	vec3 g1(const vec3 &k) const { return mq(DJB_Q_MODEL_G1, k, NULL, NULL); }
@@ -391,6 +511,7 @@ protected:
 class abc : public brdf {
 public:
 	explicit abc(const char *name, hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_abc(ctx(), name, &m_h)); }
+	DJB_HIP_RESIDENT_EVAL
 	vec3 ndf(const vec3 &h) const { return mq(DJB_Q_MODEL_NDF, h, NULL, NULL); }
 	float_t gaf(const vec3 &h, const vec3 &i, const vec3 &o) const { return mq(DJB_Q_MODEL_GAF, h, &i, &o).x; }
 	vec3 fresnel(float_t cos_theta_d) const { return mq(DJB_Q_FRESNEL, vec3(cos_theta_d, 0, 0), NULL, NULL); }
@@ -457,17 +578,20 @@ public:
 	void set_fresnel(const fresnel::impl &f)                                                         // dj_brdf.h:1521-1525
 	{
 		const fresnel::impl *copy = f.copy();
-		djb_fresnel_desc d = copy->desc();
+		bool host = false;
+		djb_fresnel_desc d = resident_desc(*copy, &host);
 		djb_status st = djb_brdf_set_fresnel(m_h, &d);
 		if (st != DJB_OK) { delete copy; hip::check(st); }
 		delete m_fresnel;
 		m_fresnel = copy;
+		m_host_eval = host;
 	}
 	const fresnel::impl &get_fresnel() const { return *m_fresnel; }
 	virtual ~microfacet() { delete m_fresnel; }
 
 	// eval / sampling queries (dj_brdf.h:258-276), scalar form = batch of one
-	vec3 fresnel(float_t cos_theta_d) const { return q3(DJB_Q_FRESNEL, vec3(cos_theta_d, 0, 0)); }
+	vec3 fresnel(float_t cos_theta_d) const                                                           // dj_brdf.h:258
+	{ return m_host_eval ? m_fresnel->eval(cos_theta_d) : q3(DJB_Q_FRESNEL, vec3(cos_theta_d, 0, 0)); }
 	float_t ndf(const vec3 &h, const params &p = params::standard()) const { return q(DJB_Q_NDF, &h, NULL, NULL, p); }
 	float_t gaf(const vec3 &h, const vec3 &i, const vec3 &o, const params &p = params::standard()) const { return q(DJB_Q_GAF, &h, &i, &o, p); }
 	float_t g1(const vec3 &h, const vec3 &k, const params &p = params::standard()) const { return q(DJB_Q_G1, &h, &k, NULL, p); }
@@ -478,8 +602,50 @@ public:
 	// the base-class quantile functions are stubs in the reference too (dj_brdf.h:1783-1791)
 	virtual float_t qf2(float_t, const vec3 &) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
 	virtual float_t qf3(float_t, const vec3 &, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
+	// ---- the operators that involve the Fresnel term.  With one of the library's terms everything runs behind the handle.
+	// With a USER-DEFINED fresnel::impl (m_host_eval) the handle holds the same lobe with fresnel::ideal -- F = (1, 1, 1)
+	// exactly -- and the reference's expressions are finished here with the user's eval(), operation for operation.
+	using brdf::eval; using brdf::evalp; using brdf::evalp_is;
+	vec3 evalp(const vec3 &i, const vec3 &o, const void *user_param = NULL) const                    // dj_brdf.h:1524-1546
+	{
+		if (!m_host_eval) return brdf::evalp(i, o, user_param);
+		const params p = user_param ? *reinterpret_cast<const params *>(user_param) : params::standard();
+		vec3 h = normalize(i + o);
+		if (gaf(h, i, o, p) > (float_t)0.0) {
+			float_t cos_theta_d = sat(dot(o, h));
+			vec3 F = m_fresnel->eval(cos_theta_d);
+			return F * handle_evalp(i, o, user_param).x;           // F * ((D * G) / (4.0 * o.z))
+		}
+		return vec3(0);
+	}
+	vec3 eval(const vec3 &i, const vec3 &o, const void *user_param = NULL) const                     // dj_brdf.h:1550-1554
+	{ return m_host_eval ? evalp(i, o, user_param) / i.z : eval_resident(i, o, user_param); }
+	vec3 evalp_is(float_t u1, float_t u2, const vec3 &o, vec3 *i, float_t *pdf, const void *user_param = NULL) const   // dj_brdf.h:1731-1765
+	{
+		if (!m_host_eval) return brdf::evalp_is(u1, u2, o, i, pdf, user_param);
+		const params p = user_param ? *reinterpret_cast<const params *>(user_param) : params::standard();
+		vec3 i_; float_t pdf_ = 0;
+		vec3 w = handle_evalp_is(u1, u2, o, &i_, &pdf_, user_param);    // G / G1 (Smith VNDF kinds), the direction, its pdf
+		vec3 h = normalize(i_ + o);
+		if (pdf) *pdf = (float_t)0;
+		if (gaf(h, i_, o, p) > (float_t)0.0) {
+			if (i) *i = i_;
+			if (pdf) *pdf = pdf_;
+			if (!supports_smith_vndf_sampling()) return evalp(i_, o, user_param) / pdf_;
+			return m_fresnel->eval(sat(dot(o, h))) * w.x;
+		}
+		return vec3(0);
+	}
 protected:
 	microfacet(hip::context *c, const fresnel::impl &f) : brdf(c), m_fresnel(f.copy()) {}
+	// the term the handle is created with: the library's own, or ideal under a user-defined one (*host = true)
+	static djb_fresnel_desc resident_desc(const fresnel::impl &f, bool *host)
+	{
+		djb_fresnel_desc d = f.desc();
+		*host = d.kind == DJB_FRESNEL_HOST;
+		if (*host) { d = djb_fresnel_desc(); d.kind = DJB_FRESNEL_IDEAL; }
+		return d;
+	}
 	const djb_params *params_of(const void *user_param) const
 	{ return user_param ? reinterpret_cast<const params *>(user_param)->desc() : NULL; }   // dj_brdf.h:1532-1534
 	float_t q(int which, const vec3 *a, const vec3 *b, const vec3 *c, const params &p) const
@@ -564,7 +730,7 @@ public:
 		                                 &vr, &vi, out_pdf, NULL, DJB_MEM_HOST));
 	}
 	beckmann(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)
-	{ djb_fresnel_desc d = f.desc(); hip::check(djb_brdf_create_beckmann(ctx(), &d, shadow, &m_h)); }
+	{ djb_fresnel_desc d = resident_desc(f, &m_host_eval); hip::check(djb_brdf_create_beckmann(ctx(), &d, shadow, &m_h)); }
 	float_t qf1(float_t u) const { return rq(DJB_Q_QF1, u); }
 };
 
@@ -572,7 +738,7 @@ public:
 class ggx : public radial {
 public:
 	ggx(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)
-	{ djb_fresnel_desc d = f.desc(); hip::check(djb_brdf_create_ggx(ctx(), &d, shadow, &m_h)); }
+	{ djb_fresnel_desc d = resident_desc(f, &m_host_eval); hip::check(djb_brdf_create_ggx(ctx(), &d, shadow, &m_h)); }
 	float_t qf1(float_t u) const { return rq(DJB_Q_QF1, u); }
 };
 
@@ -582,7 +748,16 @@ public:
 	tabular(const brdf &src, int resolution, bool shadow = true) : radial(&src.get_context(), fresnel::ideal())
 	{
 		DJB_USER_ASSERT(resolution > 2 && "Invalid Resolution");                                                // dj_brdf.h:2218
-		hip::check(djb_brdf_create_tabular(ctx(), src.handle(), resolution, shadow, &m_h));
+		if (src.resident()) hip::check(djb_brdf_create_tabular(ctx(), src.handle(), resolution, shadow, &m_h));
+		else {   // host code (a user-derived brdf, a user-defined Fresnel term): its eval() sampled where the reference calls it
+			int64_t n = 0;
+			hip::check(djb_fit_query_dirs(resolution, 0, NULL, NULL, &n));
+			std::vector<vec3> qi((size_t)n), qo((size_t)n);
+			djb_vec3_view vi = hip::view(&qi[0]), vo = hip::view(&qo[0]);
+			hip::check(djb_fit_query_dirs(resolution, n, &vi, &vo, NULL));
+			std::vector<float_t> rgb = hip::sample_source(src, qi, qo);
+			hip::check(djb_brdf_create_tabular_from_samples(ctx(), resolution, shadow, &rgb[0], n, &m_h));
+		}
 #ifndef NVERBOSE   // the reference's progress lines, in its order (the whole construction is one launch here)
 		DJB_LOG("djb_verbose: Projected area term ready\n");
 		DJB_LOG("djb_verbose: Fresnel function ready\n");
@@ -624,7 +799,16 @@ public:
 		: microfacet(&src.get_context(), fresnel::ideal()), m_elev(elevation_res), m_azim(azimuthal_res)
 	{
 		DJB_USER_ASSERT(elevation_res > 1 && azimuthal_res > 1 && "Invalid Resolution");                       // dj_brdf.h:2244
-		hip::check(djb_brdf_create_tabular_anisotropic(ctx(), src.handle(), elevation_res, azimuthal_res, shadow, &m_h));
+		if (src.resident()) hip::check(djb_brdf_create_tabular_anisotropic(ctx(), src.handle(), elevation_res, azimuthal_res, shadow, &m_h));
+		else {   // as in tabular: eval() of the host-evaluated source at the (elev - 1) * azim + (elev - 1) * elev query slots
+			int64_t n = 0;
+			hip::check(djb_fit_aniso_query_dirs(elevation_res, azimuthal_res, 0, NULL, NULL, &n));
+			std::vector<vec3> qi((size_t)n), qo((size_t)n);
+			djb_vec3_view vi = hip::view(&qi[0]), vo = hip::view(&qo[0]);
+			hip::check(djb_fit_aniso_query_dirs(elevation_res, azimuthal_res, n, &vi, &vo, NULL));
+			std::vector<float_t> rgb = hip::sample_source(src, qi, qo);
+			hip::check(djb_brdf_create_tabular_anisotropic_from_samples(ctx(), elevation_res, azimuthal_res, shadow, &rgb[0], n, &m_h));
+		}
 #ifndef NVERBOSE
 		DJB_LOG("djb_verbose: Anisotropic projected area term ready\n");
 		DJB_LOG("djb_verbose: Fresnel function ready\n");

@@ -225,6 +225,13 @@ static o_vec3 fresnel_eval(const o_fresnel *f, float c)
 		float u = F(2.0 * acos(D(c)) / O_PI);
 		return spline_eval_v3(f->pts, f->npts, u);
 	}
+	case O_FRESNEL_CUSTOM: { /* ref_shim.cpp user_lazanyi::eval: a = f0, b.x = the correction's weight */
+		double m = 1.0 - D(c);
+		float p5 = F(m * m * m * m * m);
+		float p7 = F(D(p5) * m * m);
+		float t = f->b.x * c * p7;
+		return v3_sub(v3_add(f->a, v3_scale(p5, v3_sub(v3(1, 1, 1), f->a))), v3(t, t, t));
+	}
 	default: return v3(1, 1, 1);
 	}
 }
@@ -864,9 +871,33 @@ void o_model_query(const o_brdf *b, int which, int64_t n, const float *a, const 
 /* ------------------------------------------------------------------ generic dispatch */
 static int is_microfacet(const o_brdf *b) { return b->kind <= O_BRDF_TABULAR || b->kind == O_BRDF_TABULAR_ANISO; }
 
+/* the user-defined lobes of ref_shim.cpp (user_phong::eval, user_ward::eval); model = {which, kd[3], ks[3], p0, p1} */
+static o_vec3 custom_eval(const o_brdf *b, o_vec3 i, o_vec3 o)
+{
+	const double *m = b->model;
+	o_vec3 kd = v3(F(m[1]), F(m[2]), F(m[3])), ks = v3(F(m[4]), F(m[5]), F(m[6]));
+	if ((int)m[0] == 0) {
+		float n = F(m[7]);
+		o_vec3 r = v3(-o.x, -o.y, o.z);
+		float c = v3_dot(r, i);
+		if (!(c > 0.0f)) c = 0.0f;
+		float s = F((D(n) + 2.0) / (2.0 * O_PI) * pow(D(c), D(n)));
+		return v3_add(v3_div(kd, F(O_PI)), v3_scale(s, ks));
+	}
+	float ax = F(m[7]), ay = F(m[8]);
+	if (!(i.z > 0.0f && o.z > 0.0f)) return v3(0, 0, 0);
+	o_vec3 h = v3_normalize(v3_add(i, o));
+	float tx = h.x / ax, ty = h.y / ay;
+	float q = (tx * tx + ty * ty) / (h.z * h.z);
+	float e = F(exp(-D(q)));
+	float den = F(4.0 * O_PI * D(ax * ay) * sqrt(D(i.z * o.z)));
+	return v3_add(v3_div(kd, F(O_PI)), v3_scale(e / den, ks));
+}
+
 static o_vec3 brdf_eval(const o_brdf *b, o_vec3 i, o_vec3 o, const o_params *p)
 {
 	switch (b->kind) {
+	case O_BRDF_CUSTOM: return custom_eval(b, i, o);
 	case O_BRDF_MERL: return merl_eval(b, i, o);
 	case O_BRDF_UTIA: return utia_eval(b, i, o);
 	case O_BRDF_LAMBERT: return v3_div(p && p->a1 == -1.0f ? p->n : v3(1, 1, 1), F(O_PI)); /* hdr:861-868: reflectance / M_PI */
@@ -1622,6 +1653,7 @@ o_brdf *o_create_microfacet(int ndf, int fkind, const float *fd, int nf, int sha
 	if (fkind == O_FRESNEL_UNPOLARIZED || fkind == O_FRESNEL_SCHLICK || fkind == O_FRESNEL_SGD)
 		b->fresnel.a = v3(fd[0], fd[1], fd[2]);
 	if (fkind == O_FRESNEL_SGD) b->fresnel.b = v3(fd[3], fd[4], fd[5]);
+	if (fkind == O_FRESNEL_CUSTOM) { b->fresnel.a = v3(fd[0], fd[1], fd[2]); b->fresnel.b = v3(fd[3], 0, 0); }
 	if (fkind == O_FRESNEL_SPLINE) {
 		b->fresnel.npts = nf;
 		b->fresnel.pts = (o_vec3 *)malloc(sizeof(o_vec3) * nf);
@@ -1714,6 +1746,16 @@ o_brdf *o_create_abc(const double *p) /* hdr:3617-3629: fresnel::unpolarized(vec
 	return b;
 }
 
+o_brdf *o_create_custom(int which, const float *params, int n)
+{
+	if (which < 0 || which > 1 || n != (which == 0 ? 7 : 8)) { set_err("o_create_custom: bad arguments"); return NULL; }
+	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
+	b->kind = O_BRDF_CUSTOM;
+	b->model[0] = which;
+	for (int k = 0; k < n; ++k) b->model[1 + k] = params[k];
+	return b;
+}
+
 o_brdf *o_create_lambert(void)
 {
 	o_brdf *b = (o_brdf *)calloc(1, sizeof *b);
@@ -1742,6 +1784,12 @@ void o_eval(const o_brdf *b, int op, int64_t n, const float *i, const float *o,
 		o_vec3 vi = ld3(i, k), vo = ld3(o, k);
 		if (op == 0) st3(out, k, brdf_eval(b, vi, vo, &p));
 		else if (op == 1) st3(out, k, brdf_evalp(b, vi, vo, &p));
+		else if (op == 3 || op == 4) { /* eval_hd / evalp_hd (hdr:795-801, 808-814): vi, vo hold h, d; both go through EVAL */
+			o_vec3 wi, wo;
+			hd_to_io(vi, vo, &wi, &wo);
+			o_vec3 fr = brdf_eval(b, wi, wo, &p);
+			st3(out, k, op == 3 ? fr : v3_scale(wi.z, fr));
+		}
 		else out[k] = brdf_pdf(b, vi, vo, &p);
 	}
 }

@@ -47,11 +47,18 @@ typedef struct {
 	float v[5];
 } o_param_desc;
 
+/* O_FRESNEL_CUSTOM / O_BRDF_CUSTOM: the test-suite's USER-DEFINED classes -- the lobes and the Fresnel term that
+ * oracle/ref_shim.cpp derives from djb::brdf (hdr:74-109) and djb::fresnel::impl (hdr:157-162), restated here so that the
+ * reference's handling of user classes (base-class operators hdr:795-845, fits of arbitrary sources hdr:2482-2701) has an
+ * oracle too.  They are fixtures of this repository, not reference code. */
 enum { O_FRESNEL_IDEAL = 0, O_FRESNEL_UNPOLARIZED = 1, O_FRESNEL_SCHLICK = 2,
-       O_FRESNEL_SGD = 3, O_FRESNEL_SPLINE = 4 };
+       O_FRESNEL_SGD = 3, O_FRESNEL_SPLINE = 4, O_FRESNEL_CUSTOM = 5 };
 
 enum { O_BRDF_BECKMANN = 0, O_BRDF_GGX = 1, O_BRDF_TABULAR = 2, O_BRDF_MERL = 3,
-       O_BRDF_UTIA = 4, O_BRDF_LAMBERT = 5, O_BRDF_SGD = 6, O_BRDF_ABC = 7, O_BRDF_TABULAR_ANISO = 8 };
+       O_BRDF_UTIA = 4, O_BRDF_LAMBERT = 5, O_BRDF_SGD = 6, O_BRDF_ABC = 7, O_BRDF_TABULAR_ANISO = 8,
+       O_BRDF_CUSTOM = 9 };
+/* which = 0: Phong lobe {kd[3], ks[3], exponent}; 1: Ward lobe {kd[3], ks[3], ax, ay} (ref_shim.cpp: user_phong, user_ward) */
+struct o_brdf *o_create_custom(int which, const float *params, int n);
 
 /* djb::tabular_anisotropic(brdf, elevation_res, azimuthal_res, shadow) (hdr:428-478, 2238-2273) */
 struct o_brdf *o_create_tabular_anisotropic(const struct o_brdf *src, int elev, int azim, int shadow);

@@ -55,9 +55,63 @@ struct param_holder {
 djb::vec3 ld(const float *p, long k) { return djb::vec3(p[3*k], p[3*k+1], p[3*k+2]); }
 void st(float *p, long k, const djb::vec3 &v) { p[3*k] = v.x; p[3*k+1] = v.y; p[3*k+2] = v.z; }
 
+// ---- USER-DEFINED classes: what a user of the reference derives from its two extension points -- djb::brdf (public
+// constructor, `eval` the one pure virtual, hdr:74-109) and djb::fresnel::impl (`eval`, `copy`, hdr:157-162).  Written
+// against the reference's interface only, so the same text compiles against include/dj_brdf.h (-DDJB_FACADE_SHIM).
+// oracle/djb_oracle.c restates them (custom_eval, O_FRESNEL_CUSTOM); examples/custom_brdf.cpp holds the same lobes.
+class user_phong : public djb::brdf {
+public:
+	user_phong(const float *p) : m_kd(p[0], p[1], p[2]), m_ks(p[3], p[4], p[5]), m_n(p[6]) {}
+	djb::vec3 eval(const djb::vec3 &i, const djb::vec3 &o, const void *user_param = NULL) const
+	{
+		const djb::vec3 r(-o.x, -o.y, o.z);
+		float c = djb::dot(r, i);
+		if (!(c > 0.0f)) c = 0.0f;
+		const float s = (float)(((double)m_n + 2.0) / (2.0 * M_PI) * std::pow((double)c, (double)m_n));
+		return m_kd / (float)M_PI + m_ks * s;
+	}
+private:
+	djb::vec3 m_kd, m_ks;
+	float m_n;
+};
+class user_ward : public djb::brdf {
+public:
+	user_ward(const float *p) : m_kd(p[0], p[1], p[2]), m_ks(p[3], p[4], p[5]), m_ax(p[6]), m_ay(p[7]) {}
+	djb::vec3 eval(const djb::vec3 &i, const djb::vec3 &o, const void *user_param = NULL) const
+	{
+		if (!(i.z > 0.0f && o.z > 0.0f)) return djb::vec3(0);
+		const djb::vec3 h = djb::normalize(i + o);
+		const float tx = h.x / m_ax, ty = h.y / m_ay;
+		const float q = (tx * tx + ty * ty) / (h.z * h.z);
+		const float e = (float)std::exp(-(double)q);
+		const float den = (float)(4.0 * M_PI * (double)(m_ax * m_ay) * std::sqrt((double)(i.z * o.z)));
+		return m_kd / (float)M_PI + m_ks * (e / den);
+	}
+private:
+	djb::vec3 m_kd, m_ks;
+	float m_ax, m_ay;
+};
+class user_lazanyi : public djb::fresnel::impl {
+public:
+	user_lazanyi(const float *p) : m_f0(p[0], p[1], p[2]), m_a(p[3]) {}
+	djb::vec3 eval(float cos_theta_d) const
+	{
+		const double m = 1.0 - (double)cos_theta_d;
+		const float p5 = (float)(m * m * m * m * m);
+		const float p7 = (float)((double)p5 * m * m);
+		const float t = m_a * cos_theta_d * p7;
+		return m_f0 + (djb::vec3(1) - m_f0) * p5 - djb::vec3(t);
+	}
+	djb::fresnel::impl *copy() const { return new user_lazanyi(*this); }
+private:
+	djb::vec3 m_f0;
+	float m_a;
+};
+
 djb::fresnel::impl *make_fresnel(int kind, const float *d, int n)
 {
 	switch (kind) {
+	case 5: return new user_lazanyi(d);
 	case 1: return new djb::fresnel::unpolarized(djb::vec3(d[0], d[1], d[2]));
 	case 2: return new djb::fresnel::schlick(djb::vec3(d[0], d[1], d[2]));
 	case 3: return new djb::fresnel::sgd(djb::vec3(d[0], d[1], d[2]),
@@ -98,6 +152,13 @@ void *ref_create_utia(const char *path) { SHIM_TRY(new djb::utia(path)) }
 void *ref_create_sgd(const char *name)  { SHIM_TRY(new djb::sgd(name)) }
 void *ref_create_abc(const char *name)  { SHIM_TRY(new djb::abc(name)) }
 void *ref_create_lambert()              { return new djb::lambert(); }
+void *ref_create_custom(int which, const float *params, int n)
+{
+	if (which == 0 && n == 7) return new user_phong(params);
+	if (which == 1 && n == 8) return new user_ward(params);
+	snprintf(g_err, sizeof g_err, "ref_create_custom: bad arguments");
+	return NULL;
+}
 void *ref_create_tabular(void *src, int res, int shadow)
 {
 	SHIM_TRY(new djb::tabular(*(const djb::brdf *)src, res, shadow != 0))
@@ -105,7 +166,7 @@ void *ref_create_tabular(void *src, int res, int shadow)
 void ref_destroy(void *b) { delete (djb::brdf *)b; }
 
 // ---- operator surface (hdr:74-109) -----------------------------------------
-// op: 0 eval, 1 evalp (out n x 3); 2 pdf (out n)
+// op: 0 eval, 1 evalp (out n x 3); 2 pdf (out n); 3 eval_hd, 4 evalp_hd (i, o hold h, d; out n x 3)
 void ref_eval(void *b_, int op, long n, const float *i, const float *o,
               const shim_params *sp, float *out)
 {
@@ -115,6 +176,8 @@ void ref_eval(void *b_, int op, long n, const float *i, const float *o,
 		djb::vec3 vi = ld(i, k), vo = ld(o, k);
 		if (op == 0)      st(out, k, b->eval(vi, vo, ph.ptr));
 		else if (op == 1) st(out, k, b->evalp(vi, vo, ph.ptr));
+		else if (op == 3) st(out, k, b->eval_hd(vi, vo, ph.ptr));      // vi, vo hold h, d
+		else if (op == 4) st(out, k, b->evalp_hd(vi, vo, ph.ptr));
 		else              out[k] = b->pdf(vi, vo, ph.ptr);
 	}
 }

@@ -152,6 +152,48 @@ def main():
     shutil.rmtree(tmpa, ignore_errors=True)
     save("aniso.npz", **out)
 
+    # ---- user-defined classes: a BRDF derived from djb::brdf, a Fresnel term derived from djb::fresnel::impl
+    from golden_cases import (CUSTOM_ANISO, CUSTOM_FITS, CUSTOM_FRESNEL, CUSTOM_FRESNEL_FIT, CUSTOM_LOBES, CUSTOM_PARAMS,
+                              N_CUSTOM)
+    i = synth.directions_aos(N_CUSTOM, synth.SEED_I, start=50000)
+    o = synth.directions_aos(N_CUSTOM, synth.SEED_O, start=50000)
+    u1 = synth.uniforms(N_CUSTOM, synth.SEED_U1, start=50000)
+    u2 = synth.uniforms(N_CUSTOM, synth.SEED_U2, start=50000)
+    h, d = R.io_to_hd(i, o)
+    out = {"i": i, "o": o, "u1": u1, "u2": u2, "h": h, "d": d}
+    for name, lobe in CUSTOM_LOBES.items():
+        b = R.custom(*lobe)
+        for op in ("eval", "evalp", "pdf"):
+            out[f"{name}_{op}"] = R.eval(b, i, o, None, op)
+        for op in ("eval_hd", "evalp_hd"):
+            out[f"{name}_{op}"] = R.eval(b, h, d, None, op)
+        out[f"{name}_sample"] = R.sample(b, u1, u2, o)
+        out[f"{name}_is_w"], out[f"{name}_is_i"], out[f"{name}_is_pdf"] = R.evalp_is(b, u1, u2, o)
+        for res, shadow in CUSTOM_FITS:
+            for k, v in R.tabular_tables(R.tabular(b, res, shadow)).items():
+                out[f"{name}_fit{res}_{k}"] = np.atleast_1d(v)
+        t = R.tabular_anisotropic(b, *CUSTOM_ANISO)
+        for k, v in R.aniso_tables(t).items():
+            out[f"{name}_aniso_{k}"] = v
+    for ndf in ("ggx", "beckmann"):
+        for shadow in (True, False):
+            b = R.microfacet(ndf, CUSTOM_FRESNEL, shadow)
+            tag = f"{ndf}{int(shadow)}"
+            for op in ("eval", "evalp"):
+                out[f"{tag}_{op}"] = R.eval(b, i, o, CUSTOM_PARAMS, op)
+            for op in ("eval_hd", "evalp_hd"):
+                out[f"{tag}_{op}"] = R.eval(b, h, d, CUSTOM_PARAMS, op)
+            out[f"{tag}_is_w"], out[f"{tag}_is_i"], out[f"{tag}_is_pdf"] = R.evalp_is(b, u1, u2, o, CUSTOM_PARAMS)
+            out[f"{tag}_fresnel"] = R.fresnel_eval(b, np.clip(o[:, 2], 0, 1))
+        # eval_hd / evalp_hd of the library's own classes too (evalp_hd is eval * cos, hdr:808-814, also where evalp is overridden)
+        b = R.microfacet(ndf, ("schlick", 0.9, 0.5, 0.1), True)
+        for op in ("eval_hd", "evalp_hd"):
+            out[f"{ndf}_schlick_{op}"] = R.eval(b, h, d, CUSTOM_PARAMS, op)
+        t = R.tabular(R.microfacet(ndf, CUSTOM_FRESNEL, True), CUSTOM_FRESNEL_FIT, True)
+        for k, v in R.tabular_tables(t).items():
+            out[f"{ndf}_fit_{k}"] = np.atleast_1d(v)
+    save("custom.npz", **out)
+
     # ---- MERL lookup (hash-filled table: exact on any machine)
     tmp = tempfile.mkdtemp(prefix="djb_golden_")
     try:

@@ -20,5 +20,9 @@ import sys, numpy as np
 np.full(3 * 288 * 288, 140.0 * 0.9).tofile(sys.argv[1])
 PY
 (cd "$W" && { ./nrm_utia furnace_fail.bin > out.txt && echo "exit=0" >> out.txt || echo "exit=$?" >> out.txt; } && cp out.txt "$OUT/nrm_utia_fail.txt")
+# a user program with classes DERIVED from djb::brdf and djb::fresnel::impl (examples/custom_brdf.cpp, written against the
+# reference's interface only): what the real reference prints for it
+g++ -O2 -ffp-contract=off -DNVERBOSE -w -I"$REF" -o "$W/custom_brdf" "$HERE/../../examples/custom_brdf.cpp" -lm
+"$W/custom_brdf" > "$OUT/custom_brdf.txt"
 rm -rf "$W"
 ls -la "$OUT"

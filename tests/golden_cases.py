@@ -148,3 +148,20 @@ def aniso_big_source(L, src, tmpdir=None):
         return L.utia(path)
     tab = synth.merl_table(*src[1:]) if src[0] == "merl" else synth.merl_table_grazing(src[1])
     return L.merl_from_table(tab) if is_oracle else L.merl.from_table(tab)
+
+
+# ---- user-defined classes (the reference's extension points: a class derived from djb::brdf, hdr:74-109, and one derived
+# from djb::fresnel::impl, hdr:157-162).  The classes themselves are fixtures of this repository (oracle/ref_shim.cpp:
+# user_phong, user_ward, user_lazanyi; restated in oracle/djb_oracle.c); the golden values are what the REAL reference
+# computes with them: base-class operators, eval_hd / evalp_hd, fits of arbitrary sources.
+N_CUSTOM = 512
+CUSTOM_LOBES = {
+    "phong50": ("phong", 0.05, 0.04, 0.03, 0.9, 0.8, 0.7, 50.0),
+    "phong3": ("phong", 0.3, 0.2, 0.1, 0.2, 0.3, 0.4, 3.5),
+    "ward": ("ward", 0.02, 0.02, 0.02, 0.8, 0.7, 0.6, 0.15, 0.4),
+}
+CUSTOM_FRESNEL = ("custom", 0.95, 0.64, 0.54, 1.5)
+CUSTOM_FITS = [(90, True), (17, False)]          # tabular(lobe, res, shadow)
+CUSTOM_ANISO = (9, 16)                           # tabular_anisotropic(lobe, elev, azim)
+CUSTOM_PARAMS = ("elliptic", 0.3, 0.1, 0.4)      # user_param of the microfacet BRDFs that hold the user's Fresnel term
+CUSTOM_FRESNEL_FIT = 40                          # tabular(ggx(user fresnel), res)

@@ -18,7 +18,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-FRESNEL = {"ideal": 0, "unpolarized": 1, "schlick": 2, "sgd": 3, "spline": 4}
+# "custom": the user-defined fresnel::impl of oracle/ref_shim.cpp (user_lazanyi: f0[3], a)
+FRESNEL = {"ideal": 0, "unpolarized": 1, "schlick": 2, "sgd": 3, "spline": 4, "custom": 5}
+# user-defined BRDF classes of oracle/ref_shim.cpp: ("phong", kd[3], ks[3], exponent), ("ward", kd[3], ks[3], ax, ay)
+CUSTOM = {"phong": (0, 7), "ward": (1, 8)}
+EVAL_OPS = {"eval": 0, "evalp": 1, "pdf": 2, "eval_hd": 3, "evalp_hd": 4}
 
 
 class ParamDesc(C.Structure):
@@ -99,6 +103,17 @@ class CheckerLib:
 
     def lambert(self):
         return C.c_void_p(self._fn("create_lambert")())
+
+    def custom(self, which: str, *params):
+        """a BRDF class DERIVED FROM djb::brdf by the user (ref_shim.cpp user_phong / user_ward; the oracle restates them)"""
+        code, n = CUSTOM[which]
+        p = _f32(np.array(params, dtype=np.float32).reshape(-1))
+        assert p.size == n, (which, p.size)
+        fn = self._fn("create_custom"); fn.restype = C.c_void_p
+        h = fn(C.c_int(code), _ptr(p), C.c_int(n))
+        if not h:
+            raise RuntimeError(self._fn("last_error")().decode())
+        return C.c_void_p(h)
 
     def sgd(self, name: str):
         """djb::sgd(name): the reference looks the name up in its own table; the oracle gets the
@@ -229,7 +244,7 @@ class CheckerLib:
     def eval(self, b, i, o, params=None, op="eval"):
         i, o = _f32(i), _f32(o)
         n = i.shape[0]
-        opc = {"eval": 0, "evalp": 1, "pdf": 2}[op]
+        opc = EVAL_OPS[op]     # eval_hd / evalp_hd: i, o hold h, d
         out = np.empty((n,) if opc == 2 else (n, 3), dtype=np.float32)
         pd = param_desc(params)
         self._fn("eval")(b, C.c_int(opc), C.c_int64(n), _ptr(i), _ptr(o), C.byref(pd), _ptr(out))

@@ -160,6 +160,14 @@ def test_anisotropic_short_rows_and_utia_source(cpu, oracle, tmp_path):
             assert same(t.qf2(g[f"{name}_qf2_u"], g[f"{name}_qf2_phi"]), g[f"{name}_qf2"])
 
 
+@pytest.mark.parametrize("name", ["phong50", "phong3", "ward"])
+def test_user_defined_brdf_is_fitted_from_host_samples(cpu, oracle, name):
+    """the reference's extension point (dj_brdf.h:74-109) on the host path: tests/user_defined_cases.py"""
+    import user_defined_cases
+    user_defined_cases.check_user_defined_fits(cpu, oracle, name)
+    user_defined_cases.check_sample_count_errors(cpu)
+
+
 def test_params_txt_on_the_cpu(cpu, tmp_path):
     """BASELINE configs[0]: the merl_params driver on a machine without a GPU -- byte-identical params.txt"""
     files = []
@@ -264,6 +272,11 @@ def test_cpp_programs_run_without_a_gpu(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         assert (tmp_path / "params.txt").read_bytes() == want, mode
         (tmp_path / "params.txt").unlink()
+    # user-defined classes (examples/custom_brdf.cpp: BRDFs derived from djb::brdf, a Fresnel term derived from fresnel::impl,
+    # written against the reference's interface): the bytes the REAL reference prints for the same source (make_reftests.sh)
+    r = subprocess.run([os.path.join(ROOT, "examples", "custom_brdf")], capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(os.path.join(G, "reftests", "custom_brdf.txt"), "rb").read()
     rt = os.path.join(ROOT, "examples", "_reftests")
     if os.path.exists(os.path.join(rt, "plot_cdf")):
         for prog in ("plot_cdf", "plot_qf"):

@@ -76,6 +76,58 @@ def test_microfacet_classes(facade, oracle, inputs, ndf):
             facade.destroy(f)
 
 
+def test_user_defined_classes(facade, oracle, inputs):
+    """Classes DERIVED BY THE USER from djb::brdf and djb::fresnel::impl (ref_shim.cpp: user_phong, user_ward, user_lazanyi),
+    compiled against include/dj_brdf.h: base-class operators (dj_brdf.h:795-845), eval_hd / evalp_hd, fits of the user's lobes
+    (their eval() sampled on the host, the fit on the GPU), and the library's microfacet BRDFs holding the user's Fresnel term
+    (D G on the GPU / host twin, F on the host)."""
+    from golden_cases import CUSTOM_ANISO, CUSTOM_FITS, CUSTOM_FRESNEL, CUSTOM_FRESNEL_FIT, CUSTOM_LOBES, CUSTOM_PARAMS
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "custom.npz"))
+    i, o, u1, u2 = inputs
+    h, d = oracle.io_to_hd(i, o)
+    for name, lobe in CUSTOM_LOBES.items():
+        f, b = facade.custom(*lobe), oracle.custom(*lobe)
+        for op in ("eval", "evalp", "pdf"):
+            close(f"{name}/{op}", facade.eval(f, i, o, None, op), oracle.eval(b, i, o, None, op))
+        for op in ("eval_hd", "evalp_hd"):
+            close(f"{name}/{op}", facade.eval(f, h, d, None, op), oracle.eval(b, h, d, None, op))
+        close(f"{name}/sample", facade.sample(f, u1, u2, o), oracle.sample(b, u1, u2, o))
+        for tag, x, y in zip(("w", "i", "pdf"), facade.evalp_is(f, u1, u2, o), oracle.evalp_is(b, u1, u2, o)):
+            close(f"{name}/evalp_is {tag}", x, y)
+        for res, shadow in CUSTOM_FITS:
+            got = facade.tabular_tables(facade.tabular(f, res, shadow))
+            for k, v in got.items():
+                close(f"{name}/fit{res}/{k}", np.atleast_1d(v), g[f"{name}_fit{res}_{k}"])
+        got = facade.aniso_tables(facade.tabular_anisotropic(f, *CUSTOM_ANISO))
+        for k, v in got.items():
+            close(f"{name}/aniso/{k}", v, g[f"{name}_aniso_{k}"])
+        facade.destroy(f)
+    for ndf in ("ggx", "beckmann"):
+        for shadow in (True, False):
+            f, b = facade.microfacet(ndf, CUSTOM_FRESNEL, shadow), oracle.microfacet(ndf, CUSTOM_FRESNEL, shadow)
+            for p in (CUSTOM_PARAMS, None):
+                for op in ("eval", "evalp", "pdf"):
+                    close(f"{ndf}/user fresnel/{op}", facade.eval(f, i, o, p, op), oracle.eval(b, i, o, p, op))
+                for op in ("eval_hd", "evalp_hd"):
+                    close(f"{ndf}/user fresnel/{op}", facade.eval(f, h, d, p, op), oracle.eval(b, h, d, p, op))
+                for tag, x, y in zip(("w", "i", "pdf"), facade.evalp_is(f, u1, u2, o, p), oracle.evalp_is(b, u1, u2, o, p)):
+                    close(f"{ndf}/user fresnel/evalp_is {tag}", x, y)
+            c = np.clip(o[:, 2], 0, 1)
+            close("user fresnel()", facade.fresnel_eval(f, c), oracle.fresnel_eval(b, c))
+            facade.destroy(f)
+        # eval_hd / evalp_hd of the library's own classes: evalp_hd is eval * cos (dj_brdf.h:808-814), not evalp
+        f, b = facade.microfacet(ndf, ("schlick", 0.9, 0.5, 0.1), True), oracle.microfacet(ndf, ("schlick", 0.9, 0.5, 0.1), True)
+        for op in ("eval_hd", "evalp_hd"):
+            close(f"{ndf}/schlick/{op}", facade.eval(f, h, d, CUSTOM_PARAMS, op), oracle.eval(b, h, d, CUSTOM_PARAMS, op))
+        facade.destroy(f)
+        f = facade.microfacet(ndf, CUSTOM_FRESNEL, True)
+        got = facade.tabular_tables(facade.tabular(f, CUSTOM_FRESNEL_FIT, True))
+        for k, v in got.items():
+            close(f"{ndf}/user fresnel/fit/{k}", np.atleast_1d(v), g[f"{ndf}_fit_{k}"])
+        facade.destroy(f)
+
+
 def test_params_vec3_and_helpers(facade, oracle, inputs):
     i, o, _, _ = inputs
     for p in PARAM_CASES:

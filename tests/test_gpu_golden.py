@@ -319,6 +319,11 @@ def test_reference_programs_unchanged(gpu_ctx, tmp_path, monkeypatch, scalar_on_
     r = subprocess.run([os.path.join(rt, "merl_params")] + files, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "params.txt").read_bytes() == open(os.path.join(G, "params_expected.txt"), "rb").read()
+    # a fifth program: classes the USER derives from djb::brdf / djb::fresnel::impl (examples/custom_brdf.cpp, written against
+    # the reference's interface only).  Their eval() runs on the host at the fits' query directions, the fits on the GPU.
+    r = subprocess.run([os.path.join(root, "examples", "custom_brdf")], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(os.path.join(want_dir, "custom_brdf.txt"), "rb").read()
     # the white-furnace test on a table that violates it at the first outgoing direction
     np.full(3 * 288 * 288, 140.0 * 0.9).tofile(str(tmp_path / "furnace_fail.bin"))
     r = subprocess.run([os.path.join(rt, "nrm_utia"), "furnace_fail.bin"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)

@@ -249,6 +249,47 @@ def test_fitter(oracle, name):
     assert same(oracle.sample(t, g["u1"], g["u2"], g["o"]), g[f"{name}_sample"])
 
 
+def test_user_defined_classes(oracle):
+    """tests/golden/custom.npz: the REAL reference running ref_shim.cpp's user-derived classes (a Phong and a Ward lobe derived
+    from djb::brdf, a Fresnel term derived from fresnel::impl) -- base-class operators, eval_hd / evalp_hd, isotropic and
+    anisotropic fits.  The oracle restates the classes and must reproduce every value."""
+    from golden_cases import CUSTOM_ANISO, CUSTOM_FITS, CUSTOM_FRESNEL, CUSTOM_FRESNEL_FIT, CUSTOM_LOBES, CUSTOM_PARAMS
+    g = np.load(os.path.join(G, "custom.npz"))
+    i, o, u1, u2, h, d = (g[k] for k in ("i", "o", "u1", "u2", "h", "d"))
+    oh, od = oracle.io_to_hd(i, o)
+    assert same(oh, h) and same(od, d)
+    for name, lobe in CUSTOM_LOBES.items():
+        b = oracle.custom(*lobe)
+        for op in ("eval", "evalp", "pdf"):
+            assert same(oracle.eval(b, i, o, None, op), g[f"{name}_{op}"]), (name, op)
+        for op in ("eval_hd", "evalp_hd"):
+            assert same(oracle.eval(b, h, d, None, op), g[f"{name}_{op}"]), (name, op)
+        assert same(oracle.sample(b, u1, u2, o), g[f"{name}_sample"])
+        for a, k in zip(oracle.evalp_is(b, u1, u2, o), ("is_w", "is_i", "is_pdf")):
+            assert same(a, g[f"{name}_{k}"]), (name, k)
+        for res, shadow in CUSTOM_FITS:
+            for k, v in oracle.tabular_tables(oracle.tabular(b, res, shadow)).items():
+                assert same(np.atleast_1d(v), g[f"{name}_fit{res}_{k}"]), (name, res, k)
+        for k, v in oracle.aniso_tables(oracle.tabular_anisotropic(b, *CUSTOM_ANISO)).items():
+            assert same(v, g[f"{name}_aniso_{k}"]), (name, k)
+    for ndf in ("ggx", "beckmann"):
+        for shadow in (True, False):
+            b, tag = oracle.microfacet(ndf, CUSTOM_FRESNEL, shadow), f"{ndf}{int(shadow)}"
+            for op in ("eval", "evalp"):
+                assert same(oracle.eval(b, i, o, CUSTOM_PARAMS, op), g[f"{tag}_{op}"]), (tag, op)
+            for op in ("eval_hd", "evalp_hd"):
+                assert same(oracle.eval(b, h, d, CUSTOM_PARAMS, op), g[f"{tag}_{op}"]), (tag, op)
+            for a, k in zip(oracle.evalp_is(b, u1, u2, o, CUSTOM_PARAMS), ("is_w", "is_i", "is_pdf")):
+                assert same(a, g[f"{tag}_{k}"]), (tag, k)
+            assert same(oracle.fresnel_eval(b, np.clip(o[:, 2], 0, 1)), g[f"{tag}_fresnel"])
+        b = oracle.microfacet(ndf, ("schlick", 0.9, 0.5, 0.1), True)
+        for op in ("eval_hd", "evalp_hd"):
+            assert same(oracle.eval(b, h, d, CUSTOM_PARAMS, op), g[f"{ndf}_schlick_{op}"]), (ndf, op)
+        t = oracle.tabular(oracle.microfacet(ndf, CUSTOM_FRESNEL, True), CUSTOM_FRESNEL_FIT, True)
+        for k, v in oracle.tabular_tables(t).items():
+            assert same(np.atleast_1d(v), g[f"{ndf}_fit_{k}"]), (ndf, k)
+
+
 def test_params_txt_of_reference_driver(oracle):
     """examples/merl_params.cpp run on three synthetic files; the oracle's fit prints the same bytes."""
     want = open(os.path.join(G, "params_expected.txt")).read()

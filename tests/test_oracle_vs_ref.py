@@ -45,6 +45,60 @@ def test_microfacet_bit_exact(oracle, reference, inputs, ndf, fres, par):
                                   bits(reference.microfacet_query(br, q, *args, params=par))), q
 
 
+CUSTOM_LOBES = [("phong", 0.05, 0.04, 0.03, 0.9, 0.8, 0.7, 50.0), ("phong", 0.3, 0.2, 0.1, 0.2, 0.3, 0.4, 3.5),
+                ("ward", 0.02, 0.02, 0.02, 0.8, 0.7, 0.6, 0.15, 0.4)]
+CUSTOM_FRESNEL = ("custom", 0.95, 0.64, 0.54, 1.5)
+
+
+@pytest.mark.parametrize("lobe", CUSTOM_LOBES, ids=lambda l: f"{l[0]}{l[-1]}")
+def test_user_defined_brdf_classes(oracle, reference, inputs, lobe):
+    """The reference's extension point (hdr:74-109): a class derived from djb::brdf that overrides eval.  The real reference
+    runs ref_shim.cpp's user classes; the oracle restates the lobes and the base-class operators (hdr:795-845) and the
+    fits of an arbitrary source (hdr:2482-2522, 2583-2641; 2525-2579, 2643-2701)."""
+    i, o, u1, u2 = inputs
+    bo, br = oracle.custom(*lobe), reference.custom(*lobe)
+    for op in ("eval", "evalp", "pdf"):
+        assert np.array_equal(bits(oracle.eval(bo, i, o, None, op)), bits(reference.eval(br, i, o, None, op))), op
+    h, d = reference.io_to_hd(i, o)
+    for op in ("eval_hd", "evalp_hd"):
+        assert np.array_equal(bits(oracle.eval(bo, h, d, None, op)), bits(reference.eval(br, h, d, None, op))), op
+    assert np.array_equal(bits(oracle.sample(bo, u1, u2, o)), bits(reference.sample(br, u1, u2, o)))
+    for a, b in zip(oracle.evalp_is(bo, u1, u2, o), reference.evalp_is(br, u1, u2, o)):
+        assert np.array_equal(bits(a), bits(b))
+    for res, shadow in ((90, True), (17, False)):
+        A, B = oracle.tabular_tables(oracle.tabular(bo, res, shadow)), reference.tabular_tables(reference.tabular(br, res, shadow))
+        for k in A:
+            assert np.array_equal(bits(np.atleast_1d(A[k])), bits(np.atleast_1d(B[k]))), (res, k)
+    to, tr = oracle.tabular_anisotropic(bo, 9, 16), reference.tabular_anisotropic(br, 9, 16)
+    A, B = oracle.aniso_tables(to), reference.aniso_tables(tr)
+    for k in A:
+        assert np.array_equal(bits(np.atleast_1d(A[k])), bits(np.atleast_1d(B[k]))), k
+
+
+@pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
+def test_user_defined_fresnel_and_hd_operators(oracle, reference, inputs, ndf):
+    """hdr:157-162: a user's fresnel::impl inside the reference's microfacet BRDFs; and eval_hd / evalp_hd (hdr:795-814), which
+    no other test exercises: evalp_hd is eval * cos even for the classes that override evalp."""
+    i, o, u1, u2 = inputs
+    par = ("elliptic", 0.3, 0.1, 0.4)
+    h, d = reference.io_to_hd(i, o)
+    for fres in (CUSTOM_FRESNEL, ("schlick", 0.9, 0.5, 0.1)):
+        for shadow in (True, False):
+            bo, br = oracle.microfacet(ndf, fres, shadow), reference.microfacet(ndf, fres, shadow)
+            for op in ("eval", "evalp"):
+                assert np.array_equal(bits(oracle.eval(bo, i, o, par, op)), bits(reference.eval(br, i, o, par, op))), op
+            for op in ("eval_hd", "evalp_hd"):
+                assert np.array_equal(bits(oracle.eval(bo, h, d, par, op)), bits(reference.eval(br, h, d, par, op))), op
+            for a, b in zip(oracle.evalp_is(bo, u1, u2, o, par), reference.evalp_is(br, u1, u2, o, par)):
+                assert np.array_equal(bits(a), bits(b))
+            c = np.clip(o[:, 2], 0, 1)
+            assert np.array_equal(bits(oracle.fresnel_eval(bo, c)), bits(reference.fresnel_eval(br, c)))
+    bo, br = oracle.microfacet(ndf, CUSTOM_FRESNEL), reference.microfacet(ndf, CUSTOM_FRESNEL)
+    A, B = oracle.tabular_tables(oracle.tabular(bo, 40, True)), reference.tabular_tables(reference.tabular(br, 40, True))
+    for k in A:
+        assert np.array_equal(bits(np.atleast_1d(A[k])), bits(np.atleast_1d(B[k]))), k
+
+
 @pytest.mark.parametrize("ndf", ["ggx", "beckmann"])
 def test_microfacet_on_and_below_the_horizon(oracle, reference, inputs, ndf):
     """either direction below or exactly on the horizon, un-normalised: eval = evalp / i.z divides evalp's vec3(0) all the same

@@ -66,7 +66,7 @@ EXPORTS = [
     "djb_evalp_is_batch", "djb_io_to_hd_batch", "djb_hd_to_io_batch", "djb_merl_index_batch", "djb_query_batch",
     "djb_params_resolve", "djb_tabular_get", "djb_tabular_fit", "djb_fit_merl_batch", "djb_fit_brdf_batch",
     "djb_gen_directions", "djb_gen_uniforms", "djb_histogram_xy",
-    "djb_fit_query_dirs", "djb_fit_aniso_query_dirs", "djb_brdf_create_tabular_from_samples",
+    "djb_set_file_map_observer", "djb_fit_query_dirs", "djb_fit_aniso_query_dirs", "djb_brdf_create_tabular_from_samples",
     "djb_brdf_create_tabular_anisotropic_from_samples",
 ]
 

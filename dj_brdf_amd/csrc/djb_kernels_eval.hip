@@ -144,8 +144,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_bk_sharp(Brdf b, Params p, long 
 		const bool fin_o = (fabsf(o.x) < 3e38f) & (fabsf(o.y) < 3e38f), fin_i = (fabsf(i.x) < 3e38f) & (fabsf(i.y) < 3e38f);
 		const bool below = (fin_o & !(o.z > 0.0f)) | ((b.shadow != 0) & fin_i & !(i.z > 0.0f));
 		// (b)
-		const float big = fmaxf(fmaxf(fmaxf(fabsf(i.x), fabsf(i.y)), fabsf(i.z)), fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)));
-		const bool sane = (big < 8.0f) & (i.z > 1e-4f) & (o.z > 1e-4f);
+		// each component on its own: fmaxf drops a NaN operand, and a NaN in i.x / i.y (with fine z's) must reach the exact path --
+		// without shadowing G = g1(o) > 0 there and F(sat(NaN)) = NaN for the Schlick / unpolarized terms, so the reference returns NaN * 0
+		const bool sane = (fabsf(i.x) < 8.0f) & (fabsf(i.y) < 8.0f) & (fabsf(i.z) < 8.0f) & (fabsf(o.x) < 8.0f) & (fabsf(o.y) < 8.0f) &
+		                  (fabsf(o.z) < 8.0f) & (i.z > 1e-4f) & (o.z > 1e-4f);
 		const v3 h = normalize(add(i, o));                                          // as mf_eval_pdf
 		const bool facing = h.z > 1e-4f;                                            // mf_ndf's cut
 		const float r2 = mf_p22_rsqr(-h.x / h.z, -h.y / h.z, p);                    // mf_ndf / mf_p22's slope radius

@@ -352,6 +352,13 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow,
                                  int reader_threads, float *alpha_beckmann, float *alpha_ggx, double *timing);
 
+extern "C" djb_status djb_set_file_map_observer(void (*fn)(const char *path, void *user), void *user)
+{
+	djbfile::g_map_observer_user.store(user, std::memory_order_release);
+	djbfile::g_map_observer.store(fn, std::memory_order_release);
+	return DJB_OK;
+}
+
 extern "C" djb_status djb_fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow,
                                          int reader_threads, float *alpha_beckmann, float *alpha_ggx,
                                          double *timing /* optional [4]: total, read+upload, fit, bytes */)

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <csetjmp>
 #include <csignal>
 #include <cstdint>
@@ -53,10 +54,18 @@ inline SlotPlan make_plan(const std::vector<int32_t> &idx)
 // gather keeps the mapping and runs under a guard: a process-wide SIGBUS handler, installed on first use, that jumps back
 // into gather_file when -- and only when -- the faulting address lies inside the mapping the current thread is gathering
 // from; any other SIGBUS goes to the handler that was installed before (or to the default action).
+// Ownership rules of the handler (a host such as Mitsuba or Python's faulthandler may install its own later):
+//   * every gather_file entry queries the current disposition (one sigaction call per file) and re-installs the guard if it is
+//     no longer ours, chaining to whatever it found -- so a handler installed after ours does not disable the guard, it becomes
+//     the one foreign faults are forwarded to;
+//   * a fault that is not ours and has no previous handler resets the disposition to the default and returns, so that the
+//     faulting access re-executes under it; the next gather_file re-arms the guard;
+//   * the per-thread guard pointer lives in initial-exec TLS: reading it from the handler never enters __tls_get_addr / malloc,
+//     also for a foreign SIGBUS on a thread that has never run gather_file.
 struct BusGuard { sigjmp_buf env; const char *lo, *hi; };
-inline thread_local BusGuard *t_bus_guard = nullptr;
+inline thread_local BusGuard *t_bus_guard __attribute__((tls_model("initial-exec"))) = nullptr;
 inline struct sigaction g_prev_sigbus;
-inline std::once_flag g_sigbus_once;
+inline std::mutex g_sigbus_mu;
 inline void on_sigbus(int sig, siginfo_t *si, void *uc)
 {
 	BusGuard *g = t_bus_guard;
@@ -70,12 +79,22 @@ inline void on_sigbus(int sig, siginfo_t *si, void *uc)
 }
 inline void install_sigbus_guard()
 {
-	std::call_once(g_sigbus_once, []() {
-		struct sigaction sa; memset(&sa, 0, sizeof sa);
-		sa.sa_sigaction = on_sigbus; sa.sa_flags = SA_SIGINFO; sigemptyset(&sa.sa_mask);
-		sigaction(SIGBUS, &sa, &g_prev_sigbus);
-	});
+	struct sigaction cur;
+	if (sigaction(SIGBUS, nullptr, &cur) == 0 && (cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == on_sigbus) return;
+	std::lock_guard<std::mutex> lk(g_sigbus_mu);
+	if (sigaction(SIGBUS, nullptr, &cur) == 0 && (cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == on_sigbus) return;
+	struct sigaction sa; memset(&sa, 0, sizeof sa);
+	sa.sa_sigaction = on_sigbus; sa.sa_flags = SA_SIGINFO; sigemptyset(&sa.sa_mask);
+	g_prev_sigbus = cur;                       // published before the handler that reads it is installed
+	sigaction(SIGBUS, &sa, nullptr);
 }
+
+// Observer of the file pipeline (djb_set_file_map_observer, include/djb_hip.h): called with the path after a file has passed its
+// size check and has been mapped, before the gather.  The library itself never writes to an input file; the tests of the guard
+// above register a callback that truncates the file at exactly this point.
+typedef void (*map_observer_fn)(const char *path, void *user);
+inline std::atomic<map_observer_fn> g_map_observer{nullptr};
+inline std::atomic<void *> g_map_observer_user{nullptr};
 
 // out: 3 floats (r, g, b) per slot, slot-major.  Same checks and messages as djb::merl::merl (dj_brdf.h:963-983); the
 // header is untrusted (64-bit product of positive dims, MERL shape only); the reference reads the whole payload and
@@ -106,8 +125,7 @@ inline djb_status gather_file(const char *path, const SlotPlan &plan, float *out
 	void *map = mmap(nullptr, 12 + PAYLOAD, PROT_READ, MAP_PRIVATE, fd, 0);
 	close(fd);
 	if (map == MAP_FAILED) { snprintf(buf, sizeof buf, "djb_error: Reading %s failed\n", path); *err = buf; return DJB_ERR_READ_FAILED; }
-	// test seam (tests/test_gpu_golden.py, tests/test_cpu_path.py): shrink the file now, i.e. after the size check and the mapping
-	if (const char *shrink = getenv("DJB_TEST_SHRINK_AFTER_MAP")) { if (truncate(path, atoll(shrink)) != 0) { /* the test notices */ } }
+	if (map_observer_fn obs = g_map_observer.load(std::memory_order_acquire)) obs(path, g_map_observer_user.load(std::memory_order_acquire));
 	const char *base = (const char *)map + 12;                   // the payload is 4 bytes off 8-byte alignment: memcpy each double
 	const size_t m = plan.slot.size();
 	install_sigbus_guard();

@@ -125,6 +125,21 @@ def default_context(device=0) -> Context:
     return d[device]
 
 
+_MAP_OBSERVER = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+
+
+def set_file_map_observer(fn):
+    """djb_set_file_map_observer: ``fn(path)`` is called by the MERL file pipeline after a file has been size-checked and mapped,
+    before its entries are gathered (None removes it).  Returns the ctypes callback: the caller keeps it alive."""
+    lib = _lib.load()
+    if fn is None:
+        _lib.check(lib.djb_set_file_map_observer(None, None))
+        return None
+    cb = _MAP_OBSERVER(lambda path, _user: fn(path.decode()))
+    _lib.check(lib.djb_set_file_map_observer(cb, None))
+    return cb
+
+
 def device_count() -> int:
     n = C.c_int()
     st = _lib.load().djb_device_count(C.byref(n))

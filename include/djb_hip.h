@@ -181,6 +181,11 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * the overflow path in which the second kernel redoes the whole batch.  Results never depend on the capacity. */
        DJB_OPT_TEST_WORKLIST_CAP = 7 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
+/* Observer of the MERL file pipeline (djb_fit_merl_files, both context kinds): `fn(path, user)` is called from the reader thread
+ * after a file has passed its size check and has been mapped, before its entries are gathered; NULL removes it.  Diagnostics /
+ * tests (a callback that truncates the file there exercises the "file shrinks under the mapping" guard: the verdict is the
+ * reference's "Reading %s failed", dj_brdf.h:979-982, not SIGBUS).  The library itself never writes to an input file.  */
+djb_status  djb_set_file_map_observer(void (*fn)(const char *path, void *user), void *user);
 /* HIP-event timing on the ctx stream (what bench.py's roofline leg uses) */
 djb_status  djb_timer_start(djb_ctx *ctx);
 djb_status  djb_timer_stop_ms(djb_ctx *ctx, float *ms);

@@ -225,94 +225,14 @@ private:
 	bool m_mitsubaFresnel;
 };
 
-// GLSL preview of the rough conductor (VPL renderer): Ashikhmin-Shirley lobe with Schlick's Fresnel from the reflectance at
-// normal incidence, roughness clamped to 0.2 -- the program text is the reference's (l.456-520); renderer UI, no djb math
-class dj_beckmann_conductor_shader : public Shader {
-public:
-	dj_beckmann_conductor_shader(Renderer *renderer, const Texture *specularReflectance, const Texture *alpha1,
-			const Texture *alpha2, const Spectrum &eta, const Spectrum &k)
-		: Shader(renderer, EBSDFShader), m_specularReflectance(specularReflectance), m_alpha1(alpha1), m_alpha2(alpha2) {
-		m_specularReflectanceShader = renderer->registerShaderForResource(m_specularReflectance.get());
-		m_alpha1Shader = renderer->registerShaderForResource(m_alpha1.get());
-		m_alpha2Shader = renderer->registerShaderForResource(m_alpha2.get());
-		m_R0 = fresnelConductorExact(1.0f, eta, k);
-	}
-	bool isComplete() const {
-		return m_specularReflectanceShader.get() != NULL && m_alpha1Shader.get() != NULL && m_alpha2Shader.get() != NULL;
-	}
-	void putDependencies(std::vector<Shader *> &deps) {
-		deps.push_back(m_specularReflectanceShader.get());
-		deps.push_back(m_alpha1Shader.get());
-		deps.push_back(m_alpha2Shader.get());
-	}
-	void cleanup(Renderer *renderer) {
-		renderer->unregisterShaderForResource(m_specularReflectance.get());
-		renderer->unregisterShaderForResource(m_alpha1.get());
-		renderer->unregisterShaderForResource(m_alpha2.get());
-	}
-	void resolve(const GPUProgram *program, const std::string &evalName, std::vector<int> &parameterIDs) const {
-		parameterIDs.push_back(program->getParameterID(evalName + "_R0", false));
-	}
-	void bind(GPUProgram *program, const std::vector<int> &parameterIDs, int &textureUnitOffset) const {
-		program->setParameter(parameterIDs[0], m_R0);
-	}
-	void generateCode(std::ostringstream &oss, const std::string &evalName, const std::vector<std::string> &depNames) const {
-		const std::string &e = evalName;
-		oss << "uniform vec3 " << e << "_R0;" << endl
-			<< endl
-			<< "float " << e << "_D(vec3 m, float alpha1, float alpha2) {" << endl
-			<< "    float ct = cosTheta(m), ds = 1-ct*ct;" << endl
-			<< "    if (ds <= 0.0)" << endl
-			<< "        return 0.0f;" << endl
-			<< "    alpha1 = 2 / (alpha1 * alpha1) - 2;" << endl
-			<< "    alpha2 = 2 / (alpha2 * alpha2) - 2;" << endl
-			<< "    float exponent = (alpha1*m.x*m.x + alpha2*m.y*m.y)/ds;" << endl
-			<< "    return sqrt((alpha1+2) * (alpha2+2)) * 0.15915 * pow(ct, exponent);" << endl
-			<< "}" << endl
-			<< endl
-			<< "float " << e << "_G(vec3 m, vec3 wi, vec3 wo) {" << endl
-			<< "    if ((dot(wi, m) * cosTheta(wi)) <= 0 || " << endl
-			<< "        (dot(wo, m) * cosTheta(wo)) <= 0)" << endl
-			<< "        return 0.0;" << endl
-			<< "    float nDotM = cosTheta(m);" << endl
-			<< "    return min(1.0, min(" << endl
-			<< "        abs(2 * nDotM * cosTheta(wo) / dot(wo, m))," << endl
-			<< "        abs(2 * nDotM * cosTheta(wi) / dot(wi, m))));" << endl
-			<< "}" << endl
-			<< endl
-			<< "vec3 " << e << "_schlick(float ct) {" << endl
-			<< "    float ctSqr = ct*ct, ct5 = ctSqr*ctSqr*ct;" << endl
-			<< "    return " << e << "_R0 + (vec3(1.0) - " << e << "_R0) * ct5;" << endl
-			<< "}" << endl
-			<< endl
-			<< "vec3 " << e << "(vec2 uv, vec3 wi, vec3 wo) {" << endl
-			<< "   if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0)" << endl
-			<< "    	return vec3(0.0);" << endl
-			<< "   vec3 H = normalize(wi + wo);" << endl
-			<< "   vec3 reflectance = " << depNames[0] << "(uv);" << endl
-			<< "   float alpha1 = max(0.2, " << depNames[1] << "(uv).r);" << endl
-			<< "   float alpha2 = max(0.2, " << depNames[2] << "(uv).r);" << endl
-			<< "   float D = " << e << "_D(H, alpha1, alpha2)" << ";" << endl
-			<< "   float G = " << e << "_G(H, wi, wo);" << endl
-			<< "   vec3 F = " << e << "_schlick(1-dot(wi, H));" << endl
-			<< "   return reflectance * F * (D * G / (4*cosTheta(wi)));" << endl
-			<< "}" << endl
-			<< endl
-			<< "vec3 " << e << "_diffuse(vec2 uv, vec3 wi, vec3 wo) {" << endl
-			<< "    if (cosTheta(wi) < 0.0 || cosTheta(wo) < 0.0)" << endl
-			<< "    	return vec3(0.0);" << endl
-			<< "    return " << e << "_R0 * inv_pi * inv_pi * cosTheta(wo);"<< endl
-			<< "}" << endl;
-	}
-	MTS_DECLARE_CLASS()
-private:
-	ref<const Texture> m_specularReflectance, m_alpha1, m_alpha2;
-	ref<Shader> m_specularReflectanceShader, m_alpha1Shader, m_alpha2Shader;
-	Spectrum m_R0;
-};
+// GLSL preview (VPL renderer): the reference ships an Ashikhmin-Shirley stand-in with its own GLSL program here
+// (mitsuba/dj_beckmannconductor.cpp:456-520).  Preview shaders are renderer UI with no djb math and are out of scope
+// (SURVEY.md 2 #21): like the four measured-material shells this one registers the neutral diffuse preview of
+// djb_mitsuba.hpp, driven by the specular reflectance texture.
+DJB_MTS_PREVIEW_SHADER(dj_beckmann_conductor_shader)
 
 Shader *dj_beckmann_conductor::createShader(Renderer *renderer) const {
-	return new dj_beckmann_conductor_shader(renderer, m_specularReflectance.get(), m_alpha1.get(), m_alpha2.get(), m_eta, m_k);
+	return new dj_beckmann_conductor_shader(renderer, m_specularReflectance.get());
 }
 
 MTS_IMPLEMENT_CLASS(dj_beckmann_conductor_shader, false, Shader)

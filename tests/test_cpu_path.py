@@ -197,12 +197,14 @@ def test_file_that_shrinks_under_the_gather(cpu, tmp_path, monkeypatch):
     goes on to fit the next file."""
     p = str(tmp_path / "shrinks.binary")
     synth.write_merl_binary(p, synth.merl_table(*PARAMS_TXT_MATERIALS[0][1]))
-    monkeypatch.setenv("DJB_TEST_SHRINK_AFTER_MAP", "9000000")          # the test seam of csrc/djb_merl_file.hpp
-    with pytest.raises(djb.exc) as e:
-        merl_params.fit_files_on(cpu, [p])
-    assert e.value.status_name == "DJB_ERR_READ_FAILED" and str(e.value).strip() == f"djb_error: Reading {p} failed"
-    assert os.path.getsize(p) == 9000000
-    monkeypatch.delenv("DJB_TEST_SHRINK_AFTER_MAP")
+    observer = djb.set_file_map_observer(lambda path: os.truncate(path, 9000000))   # after the size check and the mapping
+    try:
+        with pytest.raises(djb.exc) as e:
+            merl_params.fit_files_on(cpu, [p])
+        assert e.value.status_name == "DJB_ERR_READ_FAILED" and str(e.value).strip() == f"djb_error: Reading {p} failed"
+        assert os.path.getsize(p) == 9000000
+    finally:
+        djb.set_file_map_observer(None); del observer
     with pytest.raises(djb.exc) as e:                                    # now short before the mapping: same verdict
         merl_params.fit_files_on(cpu, [p])
     assert e.value.status_name == "DJB_ERR_READ_FAILED"

@@ -379,11 +379,13 @@ def test_file_that_shrinks_under_the_gather_gpu(gpu_ctx, tmp_path, monkeypatch):
         p = str(tmp_path / f"s{k}.binary")
         synth.write_merl_binary(p, synth.merl_table(*synth.material_recipe(k))); paths.append(p)
     want = merl_params.fit_files_on(gpu_ctx, paths)
-    monkeypatch.setenv("DJB_TEST_SHRINK_AFTER_MAP", "12000000")
-    with pytest.raises(djb.exc) as e:
-        merl_params.fit_files_on(gpu_ctx, paths)
-    assert e.value.status_name == "DJB_ERR_READ_FAILED" and "Reading" in str(e.value) and "failed" in str(e.value)
-    monkeypatch.delenv("DJB_TEST_SHRINK_AFTER_MAP")
+    observer = djb.set_file_map_observer(lambda path: os.truncate(path, 12000000))   # after the size check and the mapping
+    try:
+        with pytest.raises(djb.exc) as e:
+            merl_params.fit_files_on(gpu_ctx, paths)
+        assert e.value.status_name == "DJB_ERR_READ_FAILED" and "Reading" in str(e.value) and "failed" in str(e.value)
+    finally:
+        djb.set_file_map_observer(None); del observer
     for k in range(3):
         synth.write_merl_binary(paths[k], synth.merl_table(*synth.material_recipe(k)))
     got = merl_params.fit_files_on(gpu_ctx, paths)

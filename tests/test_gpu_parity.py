@@ -682,6 +682,9 @@ def hostile_pairs(dirs):
     o[6 * k:7 * k] = i[6 * k:7 * k]                                  # i == o
     o[7 * k:7 * k + 64, 0] = np.nan; i[7 * k + 64:7 * k + 128, 2] = np.inf; o[7 * k + 128:7 * k + 192] = 0.0; i[7 * k + 192:7 * k + 256, 1] = -np.inf
     i[7 * k + 256:7 * k + 320, 2] = 0.0; o[7 * k + 320:7 * k + 384, 2] = 0.0; i[7 * k + 384:7 * k + 448, 2] = -0.0      # exactly on the horizon
+    # a NaN in x or y of ONE direction with both z's fine: no shadowing -> G = g1(o) > 0, F(sat(NaN)) = NaN for Schlick / unpolarized,
+    # and the reference returns NaN * 0 = NaN (a max() over the components would hide the NaN: ADVICE r04)
+    i[7 * k + 448:7 * k + 512, 0] = np.nan; i[7 * k + 512:7 * k + 576, 1] = np.nan; o[7 * k + 576:7 * k + 640, 1] = np.nan
     o[8 * k:9 * k, :2] *= 1e-3                                       # h nearly on the normal: r^2 small even for a sharp lobe
     i[9 * k:10 * k] = -o[9 * k:10 * k] * np.array([1, 1, -1], np.float32) * 3.0      # mirror pairs of different lengths: h on the normal
     return i, o

@@ -164,6 +164,21 @@ def merl_pairs(name, n, djb, torch, ctx):
     return i, o
 
 
+def contract_mode(step, name, djb, ctx):
+    """A `*_contract` workload runs under DJB_OPT_CONTRACT_1E5.  The option is per context and off by default; it is switched ON
+    ONCE here, outside every timed region, and OFF by step.cleanup() (finish()) when the leg is over -- toggling it around every
+    launch would reset the context's per-lobe tier-2 statistics each time, so the timed loop would never run the code path a
+    caller who simply leaves the option on gets."""
+    if name.endswith("_contract"):
+        djb.set_contract_1e5(ctx, True)
+        step.cleanup = lambda: djb.set_contract_1e5(ctx, False)
+    return step
+
+
+def finish(step):
+    getattr(step, "cleanup", lambda: None)()
+
+
 def make_step(name, n, djb, synth, ctx, torch):
     """Returns (step_fn, keepalive).  Inputs are generated on-device before the timed region."""
     if name == "merl_eval":
@@ -196,18 +211,10 @@ def make_step(name, n, djb, synth, ctx, torch):
         out = torch.empty((3, n), dtype=torch.float32, device=i.device)
         lib, C = djb._lib.load(), ctypes
         vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
-        contract = name.endswith("_contract")
-
         def step():
-            if contract:
-                djb.set_contract_1e5(ctx, True)
-            try:
-                djb._lib.check(lib.djb_eval_batch(ctx._h, m._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
-                                                  None, C.byref(vout.view), C.c_int(0)))
-            finally:
-                if contract:
-                    djb.set_contract_1e5(ctx, False)
-        return step, (i, o, m, None, out, vi, vo, vout)
+            djb._lib.check(lib.djb_eval_batch(ctx._h, m._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                              None, C.byref(vout.view), C.c_int(0)))
+        return contract_mode(step, name, djb, ctx), (i, o, m, None, out, vi, vo, vout)
     if name in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "ggx_unpolarized_eval_pdf", "ggx_unpolarized_eval_pdf_contract"):
         i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
         o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
@@ -220,19 +227,11 @@ def make_step(name, n, djb, synth, ctx, torch):
         lib, C = djb._lib.load(), ctypes
         vi, vo, vout = djb._Vec(i), djb._Vec(o), djb._Vec(out)
 
-        contract = name.endswith("_contract")
-
         def step():
-            if contract:                      # the option is per context and off by default: on only around this launch
-                djb.set_contract_1e5(ctx, True)
-            try:
-                djb._lib.check(lib.djb_eval_pdf_batch(ctx._h, g._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
-                                                      C.byref(p._p), C.c_int(0), C.byref(vout.view),
-                                                      C.c_void_p(pdf.data_ptr()), C.c_int(0)))
-            finally:
-                if contract:
-                    djb.set_contract_1e5(ctx, False)
-        return step, (i, o, g, p, out, pdf, vi, vo, vout)
+            djb._lib.check(lib.djb_eval_pdf_batch(ctx._h, g._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
+                                                  C.byref(p._p), C.c_int(0), C.byref(vout.view),
+                                                  C.c_void_p(pdf.data_ptr()), C.c_int(0)))
+        return contract_mode(step, name, djb, ctx), (i, o, g, p, out, pdf, vi, vo, vout)
     if name in ("beckmann_sample", "beckmann_sample_contract"):
         o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
         b = djb.beckmann(djb.fresnel.ideal(), True, ctx=ctx)
@@ -241,19 +240,11 @@ def make_step(name, n, djb, synth, ctx, torch):
         lib, C = djb._lib.load(), ctypes
         vo, vout = djb._Vec(o), djb._Vec(out)
 
-        contract = name.endswith("_contract")
-
         def step():
-            if contract:
-                djb.set_contract_1e5(ctx, True)
-            try:
-                djb._lib.check(lib.djb_sample_rng_batch(ctx._h, b._h, C.c_int64(n), C.c_uint32(synth.SEED_U1),
-                                                        C.c_uint32(synth.SEED_U2), C.c_uint64(0), C.byref(vo.view),
-                                                        C.byref(p._p), C.byref(vout.view)))
-            finally:
-                if contract:
-                    djb.set_contract_1e5(ctx, False)
-        return step, (o, out, b, p, vo, vout)
+            djb._lib.check(lib.djb_sample_rng_batch(ctx._h, b._h, C.c_int64(n), C.c_uint32(synth.SEED_U1),
+                                                    C.c_uint32(synth.SEED_U2), C.c_uint64(0), C.byref(vo.view),
+                                                    C.byref(p._p), C.byref(vout.view)))
+        return contract_mode(step, name, djb, ctx), (o, out, b, p, vo, vout)
     if name == "utia_eval":
         i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
         o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
@@ -529,6 +520,7 @@ def main():
     # material m -> rank m mod N, no exchange; tables resident in HBM).  Every rank takes part.
     fit100 = fitfiles = None
     want_secondary = not args.no_secondary and name == "merl_eval" and args.n is None
+    finish(step)
     if want_secondary:
         del step, keep
         torch.cuda.empty_cache()
@@ -684,6 +676,7 @@ def main():
                 for _ in range(10):
                     st()
                 ms = ctx.timer_stop_ms() / 10
+                finish(st)
                 sec[other] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms, "units_per_step": on,
                               "hbm_GBps": (on * ob / (ms * 1e-3) / 1e9) if ob else None,
                               "roofline_frac": (on * ob / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ob else None}

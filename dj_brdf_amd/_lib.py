@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DJB_LIB_PATH") or os.path.join(_HERE, "lib", "libdjb_hip.so")
 
 DJB_OK = 0
+ABI_VERSION = 210          # include/djb_hip.h: DJB_HIP_VERSION (the major digit must match the loaded library)
 STATUS_NAMES = {
     0: "DJB_OK", 1: "DJB_ERR_INVALID_ARGUMENT", 2: "DJB_ERR_OPEN_FAILED", 3: "DJB_ERR_BAD_HEADER",
     4: "DJB_ERR_READ_FAILED", 5: "DJB_ERR_NOT_IMPLEMENTED", 6: "DJB_ERR_HIP", 7: "DJB_ERR_NO_DEVICE",
@@ -95,6 +96,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("djb_last_error", "djb_ctx_stream"):
             fn.restype = C.c_int
+    if lib.djb_version() // 100 != ABI_VERSION // 100:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.djb_version()}, this binding was written against {ABI_VERSION} "
+                          "(include/djb_hip.h: DJB_HIP_VERSION) -- rebuild the library")
     _lib = lib
     return lib
 

@@ -702,7 +702,8 @@ try {
 	if (option == DJB_OPT_UTIA_EXACT_ONLY) { ctx->utia_exact_only = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_CONTRACT_1E5) {
 		ctx->contract_1e5 = value != 0;
-		ctx->ct_key = 0; ctx->ct_key_share = 0.0; ctx->ct_hopeless_calls = 0;     // the "hopeless lobe" verdict does not outlive a toggle
+		// the "hopeless lobe" verdict does not outlive a toggle -- nor does the key of a note still in flight, which would re-arm it
+		ctx->ct_key = 0; ctx->ct_key_share = 0.0; ctx->ct_hopeless_calls = 0; ctx->wl_note_key = 0;
 		return DJB_OK;
 	}
 	if (option == DJB_OPT_TEST_WORKLIST_CAP) { ctx->test_worklist_cap = value; return DJB_OK; }

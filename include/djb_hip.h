@@ -39,7 +39,18 @@
 extern "C" {
 #endif
 
-#define DJB_HIP_VERSION 100
+/* ABI version = 100 * major + 10 * minor (+ patch).  A change of an existing signature or of the meaning of an argument bumps the
+ * MAJOR digit, additions bump the minor one; djb_version() returns the value the loaded library was built with, and the C++
+ * facade / the Python mirror refuse a library whose major differs from the header they were written against.
+ *   100  rounds 1-3
+ *   200  round 4: djb_eval_lean_batch / djb_sample_lean_batch gained `int lean_flags` (after `dmapscale`) and compose the per-hit
+ *        lobe as the plugin does, lrep(lean) * dmapscale + params_to_lrep(base) (mitsuba/dj_beckmannconductor.cpp:296-314) --
+ *        before: lrep(base) * scale + lean.  Callers built against 100 must be recompiled.
+ *   210  round 5: + djb_fit_query_dirs, djb_fit_aniso_query_dirs, djb_brdf_create_tabular_from_samples,
+ *        djb_brdf_create_tabular_anisotropic_from_samples (fits of user-defined sources), djb_set_file_map_observer,
+ *        DJB_FRESNEL_HOST.  No existing entry changed.                                                                  */
+#define DJB_HIP_VERSION 210
+#define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
 typedef enum {
 	DJB_OK = 0,

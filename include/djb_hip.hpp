@@ -125,8 +125,17 @@ inline void check(djb_status st)
 /* one GPU + one HIP stream -- or, with device == DJB_DEVICE_CPU, the library's host execution path */
 class context {
 public:
-	explicit context(int device = 0) : m_ctx(NULL) { check(djb_ctx_create(device, &m_ctx)); }
-	context(int device, void *hip_stream) : m_ctx(NULL) { check(djb_ctx_create_on_stream(device, hip_stream, &m_ctx)); }
+	explicit context(int device = 0) : m_ctx(NULL) { abi_check(); check(djb_ctx_create(device, &m_ctx)); }
+	context(int device, void *hip_stream) : m_ctx(NULL) { abi_check(); check(djb_ctx_create_on_stream(device, hip_stream, &m_ctx)); }
+	// the loaded libdjb_hip.so must have the ABI major this header was written against (djb_hip.h: DJB_HIP_VERSION)
+	static void abi_check()
+	{
+		if (DJB_HIP_VERSION_MAJOR(djb_version()) != DJB_HIP_VERSION_MAJOR(DJB_HIP_VERSION)) {
+			char msg[160];
+			snprintf(msg, sizeof msg, "djb_error: libdjb_hip.so has ABI version %d, this program was compiled against %d", djb_version(), (int)DJB_HIP_VERSION);
+			throw exc(msg, DJB_ERR_INVALID_ARGUMENT);
+		}
+	}
 	~context() { djb_ctx_destroy(m_ctx); }
 	djb_ctx *get() const { return m_ctx; }
 	void synchronize() const { check(djb_ctx_synchronize(m_ctx)); }

@@ -45,6 +45,10 @@ struct Rare {
 #ifdef DJB_EXP_RARE_COUNT          // measurement builds only (tools/exp): samples on the common / deferred path, and per site
 __device__ unsigned long long g_rare[2 + R_SITES];
 #endif
+#ifdef DJB_EXP_TRIP4_CHECK         // measurement builds only: {samples that need trip 4, shown to converge there, shown but NOT converged (must be 0),
+__device__ unsigned int g_trip4_printed;
+__device__ unsigned long long g_trip4[4];   //                not shown although they converge (the price: they take the exact path)}
+#endif
 
 // Measured on 2.5e8 and 1e9 samples (profiles/r03/beckmann_sample_two_path.txt, section 4): one workgroup per resident slot (256 CUs x 5)
 // is 19 % slower than ~48 tiles per workgroup -- the slots do not finish together -- and one tile per workgroup 60 % slower
@@ -217,14 +221,56 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 	float normalization = recip_g<R_NONE>(D(1 + c) + D(sqrt_pi_inv * tan_k) * e_cot, rare);
 	float inv_erf = 0.0f, b_at = 0.0f;
 	bool done = false;
+#ifdef DJB_BK_TRIP4_FULL           // A/B and measurement builds: the last trip evaluates its value like the others (the round-4 form)
+	constexpr bool SHORT_LAST = false;
+#else
+	constexpr bool SHORT_LAST = true;
+#endif
+	// The LAST trip (round 5).  What a sample needs from trip 4 is erfinv(b3) -- and the knowledge that the reference leaves its loop
+	// there, |value(b3)| < 1e-5.  That value is not computed any more (glibc's expf, the CDF, its derivative: a quarter of a trip):
+	// b3 = b2 - q, q = value(b2) / derivative(b2), is a Newton step on a smooth function, so
+	//     |value(b3)| <= 1/2 max|f''| q^2 + rounding,   f'' = -N tan_k sqrt(pi)/2 exp(erfinv(b)^2)   (f' = N (1 - erfinv(b) tan_k)),
+	// and the sample is KNOWN to converge there when 0.4431 N tan_k q^2 / E(b2) < 4e-6 with |q| < 2e-3: exp(erfinv^2) = 1 / E moves by
+	// at most e^(125 |q|) = 1.28 over the step inside the central arm (E >= 0.027, |erfinv| <= 1.9: both ends are flagged otherwise),
+	// the float evaluation of value adds < 1e-6 at either end (terms of magnitude <= 1, a few ulps each), the error of the float
+	// derivative enters as q * |d derivative| < 2e-7: 1.28 * 4e-6 + 2.2e-6 = 7.3e-6 < 1e-5.  A sample that needs trip 4 and cannot show
+	// this, or whose b3 leaves [a, c] (the reference bisects), is flagged: the exact per-sample code decides.  Nothing is approximated --
+	// a sample that is kept has taken the reference's decisions and carries the reference's erfinv(b3).  Measured (DJB_EXP_RARE_COUNT
+	// build with DJB_EXP_TRIP4_CHECK): profiles/r05/beckmann_trip4.txt.
+	float q_step = 0.0f, e_last = 1.0f;
 	auto trip = [&](bool last) {
-		const float bt = !((b >= a) & (b <= c)) ? 0.5f * (a + c) : b;
+		const bool inside = (b >= a) & (b <= c);
+		const float bt = !inside ? 0.5f * (a + c) : b;
 		// bt lies in [a, c], a sub-interval of [-1, erf(cot_k)] with finite ends (c = erf_given_exp_g of a finite positive cot_k is in
 		// [0, 1]; a NaN b takes the midpoint): IN_UNIT holds, and |ie| <= 2.18 keeps -ie^2 inside expf's main path
 		const float ie = erfinv_central<true>(bt, gt, rare, R_TAIL_LOOP);
-		const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * expf_main(-ie * ie, gt)) - u;
-		const float derivative = normalization * (1 - ie * tan_k);
 		inv_erf = ie; b_at = bt;
+		if (last && SHORT_LAST) {
+			const float nt = 0.4431f * (normalization * tan_k);
+			const bool sure = inside & (fabsf(q_step) < 2e-3f) & (nt * (q_step * q_step) < 4e-6f * e_last);
+#ifdef DJB_EXP_TRIP4_CHECK           // measurement: the decision above against the value it stands in for
+			{
+				const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * expf_main(-ie * ie, gt)) - u;
+				const bool truly = fabsf(value) < 1e-5f;
+				const unsigned int n4 = (unsigned int)__popcll(__ballot(!done)), ns = (unsigned int)__popcll(__ballot(!done & sure)),
+				                   nw = (unsigned int)__popcll(__ballot(!done & sure & !truly)), nl = (unsigned int)__popcll(__ballot(!done & !sure & truly));
+				if (!done & sure & !truly) {
+					if (atomicAdd(&g_trip4_printed, 1u) < 12u)
+						printf("djb_exp trip4 miss: u %.9g cos_k %.9g sin_k %.9g tan_k %.9g N %.9g a %.9g c %.9g b3 %.9g q %.9g E2 %.9g ie3 %.9g value3 %.9g nt*q*q %.9g\n",
+						       u, cos_k, sin_k, tan_k, normalization, a, c, bt, q_step, e_last, ie, value, nt * (q_step * q_step));
+				}
+				if ((threadIdx.x & 63u) == 0) {
+					atomicAdd(&g_trip4[0], (unsigned long long)n4); atomicAdd(&g_trip4[1], (unsigned long long)ns);
+					atomicAdd(&g_trip4[2], (unsigned long long)nw); atomicAdd(&g_trip4[3], (unsigned long long)nl);
+				}
+			}
+#endif
+			done |= sure;                                    // a lane frozen since an earlier trip stays done (and repeats its erfinv)
+			return;
+		}
+		const float e_ie = expf_main(-ie * ie, gt);
+		const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * e_ie) - u;
+		const float derivative = normalization * (1 - ie * tan_k);
 		done = fabsf(value) < 1e-5f;
 		const bool pos = value > 0;
 		c = pos ? bt : c; a = pos ? a : bt;
@@ -232,18 +278,20 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 		// repeats this one exactly (same ie, value, flags; the updates of a, c and done are idempotent): the last trip's ie and
 		// bt are the converged ones, and no per-trip select of the results is needed
 		if (!last) {
-			float next = bt - value / derivative;
-			asm volatile("" : "+v"(next));          // computed by all lanes: no branch around the division for the converged ones
-			b = done ? bt : next;
+			float qv = value / derivative;
+			asm volatile("" : "+v"(qv));            // computed by all lanes: no branch around the division for the converged ones
+			b = done ? bt : bt - qv;
+			q_step = qv; e_last = e_ie;
 		}
 	};
 	if (UNROLL) {
 #pragma unroll
 		for (int t = 0; t < TRIPS; ++t) trip(t == TRIPS - 1);
 	} else {
-		int trips = TRIPS;
-		asm volatile("" : "+s"(trips));               // opaque bound: a loop, not four copies of the body
+		int trips = SHORT_LAST ? TRIPS - 1 : TRIPS;
+		asm volatile("" : "+s"(trips));               // opaque bound: a loop, not copies of the body
 		for (int t = 0; t < trips; ++t) trip(false);
+		if (SHORT_LAST) trip(true);
 	}
 	// not converged: more trips; b < -0.9999: the reference re-evaluates erfinv at the clamped argument
 	rare.flag(R_TRIPS, !done);
@@ -371,7 +419,7 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 	const float fit = 1 + cos_k * (-0.876f + cos_k * (0.4265f - 0.0594f * cos_k));
 	const float u = fmax_(u1, 1e-6f);
 	const float epsv = CTS_EPSV_U * u + CTS_EPSV_0;
-	float ie = 0.0f, b_at = 0.0f, E = 1.0f, rder = 0.0f, tx, ty, hz, oh, ol2;
+	float ie = 0.0f, b_at = 0.0f, E = 1.0f, rder = 0.0f, q_step = 0.0f, tx, ty, hz, oh, ol2;
 	bool doubt = false;                     // a decision of the Newton loop fell inside its band (or met a NaN: the tests are "clearly outside")
 	bool done = false, tails = false;
 	v3 h;
@@ -397,6 +445,19 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 			bool tail;
 			ie = cts_erfinv(bt, tail);
 			tails |= tail;
+#ifndef DJB_BK_TRIP4_FULL
+			if (trip == TRIPS - 1) {
+				// the last trip (round 5, as in bk_qf2_common): only erfinv(b3) is needed; that the reference leaves its loop there is shown
+				// from the Newton step that led here instead of being computed -- 1/2 |f''| q^2 with room for both sequences' rounding --
+				// and a sample that cannot show it is in doubt (exact path).  E and rder stay those of b2: the error estimate below reads
+				// them within the factor e^(125 |q|) <= 1.28 the step can move them by (it has a factor of five in hand)
+				const bool sure = inside & clear_ends & (fabsf(q_step) < 2e-3f) & ((0.4431f * (N * tan_k)) * (q_step * q_step) < 3e-6f * E);
+				doubt |= !done & !sure;
+				done |= sure;
+				b_at = bt;
+				break;
+			}
+#endif
 			E = cts_exp_neg(-ie * ie);
 			const float value = N * ((1 + bt) + K * E) - u;
 			const float derivative = N * (1 - ie * tan_k);
@@ -407,7 +468,8 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 			b_at = bt;
 			const bool pos = value > 0;
 			c = pos ? bt : c; a = pos ? a : bt;
-			b = done ? bt : bt - value * rder;
+			q_step = value * rder;
+			b = done ? bt : bt - q_step;
 		}
 		tx = ie;
 		bool tail2;
@@ -801,7 +863,12 @@ hipError_t launch_sample_beckmann(hipStream_t s, const Brdf &b, const Params &p,
 #ifdef DJB_EXP_RARE_COUNT
 	struct Report { hipStream_t s; ~Report() { unsigned long long h[2 + R_SITES]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rare), sizeof h);
 		fprintf(stderr, "djb_exp: sample_bk common %llu deferred %llu | logf %llu expf %llu powf %llu exp64 %llu guard %llu tail_loop %llu tail_qf1 %llu trips %llu clamp %llu degenerate %llu (cumulative)\n",
-		        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]); } } report{ s };
+		        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+#ifdef DJB_EXP_TRIP4_CHECK
+		unsigned long long t4[4]; (void)hipMemcpyFromSymbol(t4, HIP_SYMBOL(g_trip4), sizeof t4);
+		fprintf(stderr, "djb_exp: trip 4: needed by %llu, shown to converge %llu, SHOWN BUT NOT CONVERGED %llu (must be 0), converge but not shown %llu (cumulative)\n", t4[0], t4[1], t4[2], t4[3]);
+#endif
+		} } report{ s };
 #endif
 #define DJB_LAUNCH_S(IS_, RNG_, FRK_, DN_) hipLaunchKernelGGL((k_sample_bk<IS_, RNG_, FRK_, DN_>), g, t, 0, s, b, p, n, u1, u2, s1, s2, start, o, out_i, w, out_pdf, ct)
 #define DJB_LAUNCH_S2(IS_, FRK_) do { if (rng) { if (dn) DJB_LAUNCH_S(IS_, true, FRK_, true); else DJB_LAUNCH_S(IS_, true, FRK_, false); } \

@@ -93,6 +93,61 @@ def synth_merl_files(n, synth, rank=0, distinct=10, only=None):
     return paths
 
 
+# the kernel function(s) a workload launches in its timed region: a tracked profile summary (profiles/pmc_*.json, valu_*.json) is
+# attached to the bench line only if it was taken on exactly these -- a summary that lists anything else describes a kernel
+# that no longer exists (round 4 shipped a valu_merl_eval.json of the pre-fusion kernel pair) and is reported as stale instead
+LAUNCHES = {
+    "merl_eval": ["k_merl_fast_v4"], "merl_eval_uniform_bins": ["k_merl_fast_v4"], "merl_eval_coherent": ["k_merl_fast_v4"],
+    "ggx_eval_pdf": ["k_eval"], "ggx_unpolarized_eval_pdf": ["k_eval"], "sgd_eval": ["k_eval"],
+    "ggx_eval_pdf_contract": ["k_ct_fast_v4", "k_ct_fixup"], "ggx_unpolarized_eval_pdf_contract": ["k_ct_fast_v4", "k_ct_fixup"],
+    "sgd_eval_contract": ["k_ct_fast_v4", "k_ct_fixup"],
+    "beckmann_sample": ["k_sample_bk"], "beckmann_sample_contract": ["k_sample_bk"],
+    "utia_eval": ["k_eval_utia_t1", "k_eval_utia_fix"], "merl_fit": ["k_fit"],
+}
+
+
+def profile_matches(name, kernel_names):
+    """(ok, listed): do the kernels a profile summary lists equal the set this workload launches?"""
+    import re
+    listed = sorted({m.group(1) for k in kernel_names for m in [re.search(r"(k_[A-Za-z0-9_]+)", k.replace("(anonymous namespace)::", ""))] if m})
+    want = sorted(LAUNCHES.get(name, []))
+    return bool(want) and listed == want, listed
+
+
+def drop_page_cache(paths):
+    """Ask the kernel to drop the page cache of these files (fsync + posix_fadvise(DONTNEED): works for clean pages without root;
+    a tmpfs keeps its pages, which is reported).  Returns the resident fraction afterwards, from mincore() on a sample of the files."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6", use_errno=True)
+    libc.mmap.restype = ctypes.c_void_p
+    libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+    libc.munmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    libc.mincore.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    for p in paths:
+        fd = os.open(p, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+        except OSError:
+            pass
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        os.close(fd)
+    resident = total = 0
+    page = os.sysconf("SC_PAGE_SIZE")
+    for p in paths[:: max(1, len(paths) // 8)]:
+        size = os.path.getsize(p)
+        fd = os.open(p, os.O_RDONLY)
+        addr = libc.mmap(None, size, 1, 1, fd, 0)                 # PROT_READ, MAP_SHARED
+        os.close(fd)
+        if addr in (None, ctypes.c_void_p(-1).value):
+            continue
+        pages = (size + page - 1) // page
+        vec = (ctypes.c_ubyte * pages)()
+        if libc.mincore(addr, size, vec) == 0:
+            resident += sum(b & 1 for b in vec); total += pages
+        libc.munmap(addr, size)
+    return (resident / total) if total else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +159,9 @@ def parse():
     ap.add_argument("--fresnel", default="ideal", choices=["ideal", "schlick"], help="ggx_eval_pdf: ideal (default) or schlick(1.0, 0.71, 0.29)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--merl-dir", default=None,
+                    help="a directory of real MERL files (*.binary): the end-to-end files -> alphas leg also runs on them "
+                         "(secondary.merl_fit_dir; examples/merl_params.cpp:53-69 is the loop it stands for).  The offline image has none.")
     ap.add_argument("--selftest-n", type=int, default=None,
                     help="harness self-test only (DJB_BENCH_SHARE_GPU runs of the N-rank path on one GPU): shrink the primary batch "
                          "to this many units per rank but keep the secondary fit legs; the line is labelled")
@@ -372,7 +430,10 @@ def cpu_baseline(name, synth, budget_s=12.0):
         if probe[t] > best:
             best, best_t = probe[t], t
     quota = cpu_quota()
-    return {"value": best, "unit": "evals/s" if op != "sample" else "samples/s", "cores": best_t, "kind": kind,
+    # cores: the CPUs that actually did the work -- the thread count of the best run, capped by the container's CPU quota (128
+    # threads under a 16-CPU quota get 16 CPUs' worth of time); the thread count itself is kept as `threads`
+    eff = best_t if quota is None else max(1, min(best_t, int(round(quota))))
+    return {"value": best, "unit": "evals/s" if op != "sample" else "samples/s", "cores": eff, "threads": best_t, "kind": kind,
             "sample": f"600k units per thread of the same synthetic workload, thread counts {sorted(probe)} of "
                       f"{cores} usable logical CPUs (ctypes releases the GIL; the reference object is const); "
                       f"best at {best_t} threads; single-thread {r1:.3e}/s"
@@ -566,16 +627,48 @@ def main():
                 _, _, tim = merl_params.fit_files_on(ctx, all_mine)   # the same job again: every file gathered, uploaded and fitted again
                 barrier()
                 wall = time.perf_counter() - t_files
+                # ... and once with the files' page cache dropped first: what 100 files cost the first time they are read
+                time.sleep(0.1)
+                still_resident = drop_page_cache(all_mine)
+                barrier()
+                t_files = time.perf_counter()
+                merl_params.fit_files_on(ctx, all_mine)
+                barrier()
+                cold = time.perf_counter() - t_files
             finally:
                 djb.set_fit_files_dense(ctx, False)
-            tt = torch.tensor([wall, tim["total_s"], tim["load_s"], tim["fit_s"], first], dtype=torch.float64, device=red_dev)
+            tt = torch.tensor([wall, tim["total_s"], tim["load_s"], tim["fit_s"], first, cold], dtype=torch.float64, device=red_dev)
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            wall, f_total, f_load, f_fit, first = (float(x) for x in tt)
+            wall, f_total, f_load, f_fit, first, cold = (float(x) for x in tt)
             return {"wall_ms": wall * 1e3, "first_call_wall_ms": first * 1e3, "value": 100 / wall, "unit": "materials/s",
+                    "cold_cache_wall_ms": cold * 1e3,
+                    "cold_cache_note": ("page cache of this rank's files dropped before the call (fsync + posix_fadvise(DONTNEED)); resident "
+                                        "fraction afterwards by mincore: %s%s" % ("n/a" if still_resident is None else "%.3f" % still_resident,
+                                        " -- the files sit on a file system that keeps its pages (tmpfs): this is NOT a cold read"
+                                        if still_resident is not None and still_resident > 0.5 else "")),
                     "pipeline_ms": {"total": f_total * 1e3, "load": f_load * 1e3, "fit": f_fit * 1e3},
                     "bytes_read_this_rank": tim["bytes"]}
         sparse, dense = files_leg(False), files_leg(True)
+        fitdir = None
+        if args.merl_dir:          # the same leg on real MERL files (rank r takes files r, r + N, ...), warm then cold
+            import glob
+            real = sorted(glob.glob(os.path.join(args.merl_dir, "*.binary")))
+            mine_real = real[rank::world]
+            if mine_real:
+                merl_params.fit_files_on(ctx, mine_real[:1])
+                barrier(); t0f = time.perf_counter()
+                ab_r, ag_r, _ = merl_params.fit_files_on(ctx, mine_real)
+                barrier(); warm_r = time.perf_counter() - t0f
+                res_r = drop_page_cache(mine_real)
+                barrier(); t0f = time.perf_counter()
+                merl_params.fit_files_on(ctx, mine_real)
+                barrier(); cold_r = time.perf_counter() - t0f
+                fitdir = {"dir": args.merl_dir, "files": len(real), "files_this_rank": len(mine_real), "wall_ms": warm_r * 1e3,
+                          "cold_cache_wall_ms": cold_r * 1e3, "resident_after_drop": res_r,
+                          "first_materials": [[os.path.basename(pth).split(".")[0], "%.3f" % a, "%.3f" % g] for pth, a, g in zip(mine_real[:5], ab_r[:5], ag_r[:5])]}
+            else:
+                fitdir = {"dir": args.merl_dir, "files": 0, "note": "no *.binary files found"}
         fitfiles = {"materials": 100, "n_gpus": world, "scaling": "strong", **sparse,
                     "what": "end to end, files -> alphas, max over ranks: table indices a tabular(merl, 90) fit reads computed on the GPU, "
                             "worker threads gather those 5 545 x 3 doubles per file from the mapped files (page cache warm), "
@@ -596,25 +689,36 @@ def main():
             if os.path.exists(pmc):      # HBM bytes per launch from rocprofv3 PMC passes (profiles/README.md)
                 try:
                     pj = json.load(open(pmc))
-                    roofline["traffic"] = pj.get("hbm_bytes_per_launch")
-                    roofline["traffic_source"] = ("static: read from profiles/pmc_%s.json (separate rocprofv3 --pmc passes of "
-                                                  "tools/profile_bench.sh, %s), NOT measured in this run" % (name, pj.get("round", "round 1")))
-                    roofline["traffic_note"] = pj.get("note")
-                    if pj.get("gather_miss_bytes_per_launch") is not None:      # the table gathers' share (line fills out of the Infinity Cache)
-                        roofline["traffic_gather_miss_bytes"] = pj["gather_miss_bytes_per_launch"]
+                    ok, listed = profile_matches(name, pj.get("kernels", []))
+                    if ok:
+                        roofline["traffic"] = pj.get("hbm_bytes_per_launch")
+                        roofline["traffic_source"] = ("static: read from profiles/pmc_%s.json (separate rocprofv3 --pmc passes of "
+                                                      "tools/profile_bench.sh, %s, tree %s; kernels %s = the ones this run launched), NOT measured in this run"
+                                                      % (name, pj.get("round", "round 1"), pj.get("tree", "not recorded"), listed))
+                        roofline["traffic_note"] = pj.get("note")
+                        if pj.get("gather_miss_bytes_per_launch") is not None:      # the table gathers' share (line fills out of the Infinity Cache)
+                            roofline["traffic_gather_miss_bytes"] = pj["gather_miss_bytes_per_launch"]
+                    else:
+                        roofline["traffic_source"] = ("STALE: profiles/pmc_%s.json lists kernels %s, this workload launches %s -- not attached"
+                                                      % (name, listed, sorted(LAUNCHES.get(name, []))))
                 except Exception:
                     pass
             vj = os.path.join(ROOT, "profiles", f"valu_{name}.json")
             if os.path.exists(vj):       # VALU issue load beside the HBM fraction: tools/instmix.sh + tools/valu_report.py
                 try:
                     v = json.load(open(vj))
+                    ok, listed = profile_matches(name, [k.get("kernel", "") for k in v.get("kernels", [])])
                     issue_ms = v["slots_per_unit"] * n / 64.0 * 1.155e-6 / 1024.0
-                    roofline["valu"] = {"insts_per_unit": v["insts_per_unit"], "slots_per_unit": v["slots_per_unit"],
-                                        "frac_of_issue": issue_ms / launch_ms,
-                                        "note": "issue-bound" if issue_ms / launch_ms > 0.9 else None,
-                                        "source": "static: instruction mix from profiles/valu_%s.json (SQ_INSTS_VALU_* passes of rocprofv3, %s; "
-                                                  "issue slots per class from tools/valu_cost_probe.hip, one slot = 1.155 ns per wave-instruction "
-                                                  "per SIMD, 1024 SIMDs), divided by this run's launch_ms" % (name, v.get("round", "?"))}
+                    if ok:
+                        roofline["valu"] = {"insts_per_unit": v["insts_per_unit"], "slots_per_unit": v["slots_per_unit"],
+                                            "frac_of_issue": issue_ms / launch_ms, "kernels": listed,
+                                            "note": "issue-bound" if issue_ms / launch_ms > 0.9 else None,
+                                            "source": "static: instruction mix from profiles/valu_%s.json (SQ_INSTS_VALU_* passes of rocprofv3, %s, tree %s; "
+                                                      "issue slots per class from tools/valu_cost_probe.hip, one slot = 1.155 ns per wave-instruction "
+                                                      "per SIMD, 1024 SIMDs), divided by this run's launch_ms" % (name, v.get("round", "?"), v.get("tree", "not recorded"))}
+                    else:
+                        roofline["valu"] = {"stale": True, "note": "profiles/valu_%s.json lists kernels %s, this workload launches %s -- not attached"
+                                                                   % (name, listed, sorted(LAUNCHES.get(name, [])))}
                 except Exception:
                     pass
         else:
@@ -662,6 +766,8 @@ def main():
             if not args.no_cpu_baseline:
                 fitfiles["cpu_baseline"] = cpu_baseline("merl_fit_files", synth)
             sec = {"merl_fit_files_100": fitfiles, "merl_fit_100": fit100}
+            if fitdir is not None:
+                sec["merl_fit_dir"] = fitdir
             for other in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "ggx_unpolarized_eval_pdf", "ggx_unpolarized_eval_pdf_contract",
                           "sgd_eval", "sgd_eval_contract", "beckmann_sample", "beckmann_sample_contract", "utia_eval", "merl_eval_uniform_bins",
                           "merl_eval_coherent"):

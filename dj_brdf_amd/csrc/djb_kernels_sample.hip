@@ -252,9 +252,11 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 			{
 				const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * expf_main(-ie * ie, gt)) - u;
 				const bool truly = fabsf(value) < 1e-5f;
-				const unsigned int n4 = (unsigned int)__popcll(__ballot(!done)), ns = (unsigned int)__popcll(__ballot(!done & sure)),
-				                   nw = (unsigned int)__popcll(__ballot(!done & sure & !truly)), nl = (unsigned int)__popcll(__ballot(!done & !sure & truly));
-				if (!done & sure & !truly) {
+				// (samples that are flagged anyway -- k.z <= 0 runs this code on a negative tan_k, the tail arm of erfinv -- are not counted)
+				const bool counted = !done & !rare.any;
+				const unsigned int n4 = (unsigned int)__popcll(__ballot(counted)), ns = (unsigned int)__popcll(__ballot(counted & sure)),
+				                   nw = (unsigned int)__popcll(__ballot(counted & sure & !truly)), nl = (unsigned int)__popcll(__ballot(counted & !sure & truly));
+				if (counted & sure & !truly) {
 					if (atomicAdd(&g_trip4_printed, 1u) < 12u)
 						printf("djb_exp trip4 miss: u %.9g cos_k %.9g sin_k %.9g tan_k %.9g N %.9g a %.9g c %.9g b3 %.9g q %.9g E2 %.9g ie3 %.9g value3 %.9g nt*q*q %.9g\n",
 						       u, cos_k, sin_k, tan_k, normalization, a, c, bt, q_step, e_last, ie, value, nt * (q_step * q_step));

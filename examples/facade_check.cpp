@@ -4,6 +4,9 @@
 #include <cmath>
 #include <cstdio>
 
+#include <cmath>
+#include <vector>
+
 #include "djb_hip.hpp"
 
 static int g_fail = 0;
@@ -72,6 +75,29 @@ int main()
 		djb::beckmann::lrep l1, l2(0.1f, -0.05f, 0.02f, 0.03f, 0.001f);          // mitsuba/dj_beckmannconductor.cpp:304-314
 		djb::beckmann::params_to_lrep(ell, &l1); l1 *= 0.7f; djb::microfacet::params lp; djb::beckmann::lrep_to_params(l1 + l2, &lp);
 		float lax, lay; lp.get_pdfparams(&lax, &lay); expect("lrep path ax > 0", lax > 0 ? 1.0 : 0.0, 1.0);
+		// the numerical contract is a property of the context (hip::context::set_contract_1e5): a batch of a context in 1e-5 mode stays
+		// within 1e-5 relative of the bit-exact one; one-pair calls never change
+		{
+			djb::hip::context &c0 = djb::hip::context::standard();
+			const size_t nb = 1u << 16;                       // a batch well above the scalar threshold
+			std::vector<djb::vec3> bi(nb), bo(nb), exact(nb), fast(nb);
+			for (size_t k = 0; k < nb; ++k) {
+				const float t = 0.05f + 1.4f * (float)k / (float)nb, ph = 0.37f * (float)k;
+				bi[k] = djb::vec3(t, ph); bo[k] = djb::vec3(1.45f - t, 1.3f * ph + 0.5f);
+			}
+			ggs.eval(nb, &bi[0], &bo[0], &exact[0], &iso);
+			c0.set_contract_1e5(true);
+			ggs.eval(nb, &bi[0], &bo[0], &fast[0], &iso);
+			const float one_pair = ggs.eval(i, o, &iso).y;
+			c0.set_contract_1e5(false);
+			double worst = 0;
+			for (size_t k = 0; k < nb; ++k) {
+				const double e = exact[k].y, f = fast[k].y;
+				if (e != f) worst = std::fmax(worst, std::fabs(f - e) / std::fmax(std::fabs(e), 1e-30));
+			}
+			expect("contract mode: worst rel. diff < 1e-5", worst < 1e-5 ? 1.0 : 0.0, 1.0);
+			expect("contract mode: one-pair call unchanged", one_pair, 0.441180676);
+		}
 		try { djb::merl bad("/nonexistent/file.binary"); g_fail = 1; }
 		catch (const djb::exc &e) { printf("djb::exc as expected: %s", e.what()); }
 	} catch (const djb::exc &e) {

@@ -8,6 +8,8 @@
 // context/stream per GPU, no exchange between GPUs); each GPU runs the native pipeline
 // djb_fit_merl_files (reader threads -> pinned ring -> async upload -> conversion -> ONE fit launch).
 // `-s` runs the reference's own loop shape instead (load, fit, next file) on the djb:: classes.
+// DJB_EXAMPLE_SHARE_GPU=1 (self-test on a box with fewer GPUs than `-g N` asks for): the N host threads still run, each with
+// its own context and stream, but context g lives on device g mod (number of GPUs) -- the multi-GPU code path on one device.
 // Build: make -C examples      Run: ./merl_params [-s] [-g N] a.binary b.binary ...
 #include <cstdio>
 #include <cstdlib>
@@ -73,7 +75,9 @@ int main(int argc, char **argv)
 		int n_dev = djb::hip::context::device_count();
 		const bool on_cpu = djb::hip::context::standard_device() == DJB_DEVICE_CPU;   // DJB_DEVICE=cpu, or no HIP device at all
 		if (on_cpu) n_dev = 1;                       // one host context; djb_fit_merl_files spreads the files over its threads
-		if (gpus <= 0 || gpus > n_dev) gpus = n_dev;
+		const char *share_env = getenv("DJB_EXAMPLE_SHARE_GPU");
+		const bool share = !on_cpu && share_env && !strcmp(share_env, "1") && n_dev > 0;
+		if (gpus <= 0 || (gpus > n_dev && !share)) gpus = n_dev;
 		if (gpus > n && n > 0) gpus = n;
 		std::vector<std::string> errors(gpus);
 		std::vector<std::thread> workers;
@@ -85,7 +89,7 @@ int main(int argc, char **argv)
 				if (mine.empty()) return;
 				std::vector<float> ab(mine.size()), ag(mine.size());
 				djb_ctx *ctx = NULL;
-				djb_status st = djb_ctx_create(on_cpu ? DJB_DEVICE_CPU : g, &ctx);
+				djb_status st = djb_ctx_create(on_cpu ? DJB_DEVICE_CPU : share ? g % n_dev : g, &ctx);
 				if (st == DJB_OK)
 					st = djb_fit_merl_files(ctx, (int)mine.size(), &mine[0], 90, 1, 0, &ab[0], &ag[0], NULL);
 				if (st != DJB_OK) errors[g] = djb_last_error();

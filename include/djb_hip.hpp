@@ -139,6 +139,16 @@ public:
 	~context() { djb_ctx_destroy(m_ctx); }
 	djb_ctx *get() const { return m_ctx; }
 	void synchronize() const { check(djb_ctx_synchronize(m_ctx)); }
+	// The numerical contract of this context's BATCH calls.  Default (false): every value is the reference's, bit
+	// for bit.  true = DJB_OPT_CONTRACT_1E5: values within 1e-5 relative of the reference's (sampled directions: every component
+	// within 1e-5), zeros and NaNs exactly where the reference has them -- the north star's tolerance, spent on speed (GGX eval+pdf
+	// 0.53 -> 0.76 of the HBM roofline).  What changes bits under it: eval / evalp / pdf / eval_pdf batches of ggx and beckmann
+	// (ideal, Schlick f0 >= 0.01, unpolarized ior >= 1.05; no mean-normal offset, |rho| <= 0.9), sgd and abc eval, sample and the
+	// weights / pdfs of evalp_is of ggx and beckmann (evalp_is directions stay bit-identical).  What never changes: MERL / UTIA
+	// look-ups and their bin indices, tabular and tabular_anisotropic (fits, eval, sampling), lambert, the queries, LEAN / per-pair
+	// parameter calls, every scalar (one-pair) call, and everything on a CPU context.
+	void set_contract_1e5(bool on) { set_option(DJB_OPT_CONTRACT_1E5, on ? 1 : 0); }
+	void set_option(int option, int value) { check(djb_ctx_set_option(m_ctx, option, value)); }
 	// The process-wide default context, used by every djb:: object that is not given one.  DJB_DEVICE=<n> selects GPU n,
 	// DJB_DEVICE=cpu the host path.  Without the variable it is GPU 0 -- and, ONLY on a machine that has no HIP device at
 	// all, the host path (announced once on stderr): the reference is a CPU library and its programs, compiled against

@@ -276,11 +276,14 @@ def test_cpp_facade_programs(gpu_ctx, tmp_path):
         synth.write_merl_binary(p, synth.merl_table(*recipe)); files.append(p)
     want = open(os.path.join(G, "params_expected.txt"), "rb").read()
     # default: native pipeline, files dealt to every visible GPU; -s: the reference's own loop on the djb:: classes
-    for mode in ([], ["-s"], ["-g", "1"]):
+    # -g 2 / -g 3 with DJB_EXAMPLE_SHARE_GPU=1: the in-process multi-GPU path (one host thread + context + stream per "GPU",
+    # materials dealt round-robin, no exchange) with every context on device 0 -- what an 8-GPU node runs, on the one GPU here
+    env = dict(os.environ, DJB_EXAMPLE_SHARE_GPU="1")
+    for mode in ([], ["-s"], ["-g", "1"], ["-g", "2"], ["-g", "3"]):
         if (tmp_path / "params.txt").exists():
             (tmp_path / "params.txt").unlink()
         r = subprocess.run([os.path.join(root, "examples", "merl_params")] + mode + files, cwd=str(tmp_path),
-                           capture_output=True, text=True, timeout=300)
+                           capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         assert open(tmp_path / "params.txt", "rb").read() == want, mode
     r = subprocess.run([os.path.join(root, "examples", "merl_params"), str(tmp_path / "missing.binary")],

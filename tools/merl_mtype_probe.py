@@ -22,8 +22,11 @@ def view(base):
     v = _lib.Vec3View(); v.x, v.y, v.z, v.stride = base, base + 4 * n, base + 8 * n, 1
     return v
 m = djb.merl.from_table(synth.merl_table(0.3), ctx=ctx)
-for kin, kout in (("hipMalloc", "hipMalloc"), ("uncached", "hipMalloc"), ("hipMalloc", "uncached"), ("uncached", "uncached"),
-                  ("finegrained", "finegrained"), ("hipMalloc", "hipMalloc")):
+CONFIGS = (("hipMalloc", "hipMalloc"), ("uncached", "hipMalloc"), ("hipMalloc", "uncached"), ("uncached", "uncached"),
+           ("finegrained", "finegrained"), ("hipMalloc", "hipMalloc"))
+if os.environ.get("DJB_MTYPE_ONLY"):      # one configuration only, e.g. "uncached,uncached": a run under rocprofv3 --pmc (round 5)
+    CONFIGS = (tuple(os.environ["DJB_MTYPE_ONLY"].split(",")),)
+for kin, kout in CONFIGS:
     pi, po, pr = alloc(kin), alloc(kin), alloc(kout)
     vi, vo, vr = view(pi), view(po), view(pr)
     _lib.check(lib.djb_gen_directions(ctx._h, C.c_int64(n), C.c_uint32(synth.SEED_I), C.c_uint64(0), C.byref(vi)))

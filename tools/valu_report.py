@@ -30,6 +30,14 @@ COST = {"ADD_F32": 0.94, "MUL_F32": 1.00, "FMA_F32": 1.36, "TRANS_F32": 2.96,
         "CVT": 1.50, "INT32": 1.20, "INT64": 1.60, "OTHER": 1.45}
 
 
+def kernel_id(full):
+    """'void (anonymous namespace)::k_merl_fast_v4<1>(djbdev::Brdf, ...)' -> 'k_merl_fast_v4<1>' (round 4 cut at the first '(',
+    which is the one of '(anonymous namespace)': every name came out as 'void ')"""
+    import re
+    m = re.search(r"(k_\w+(?:<[^()]*>)?)\s*\(", full.replace("(anonymous namespace)::", ""))
+    return m.group(1) if m else full
+
+
 def main():
     w = sys.argv[1]
     units = float(sys.argv[2])
@@ -61,7 +69,7 @@ def main():
         d = dur.get(k) or dur_pmc.get(k)
         ms = sorted(d)[len(d) // 2] if d else None
         issue_ms = slots * SLOT_NS * 1e-6 / N_SIMD
-        kernels.append({"kernel": k.split("(")[0], "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"],
+        kernels.append({"kernel": kernel_id(k), "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"],
                         "salu_wave_insts_per_launch": c.get("SQ_INSTS_SALU"),
                         "insts_per_unit": c["SQ_INSTS_VALU"] / (units / 64.0), "slots_per_unit": slots / (units / 64.0),
                         "issue_ms_per_launch": issue_ms, "kernel_ms_under_counters": ms,

@@ -212,70 +212,6 @@ __global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_eval_utia_t1(Brdf
 		}
 	}
 }
-// Tier 1 with a WAVE-COOPERATIVE record fetch (round 5; DJB_UTIA_COOP=1 selects it, A/B against the lane-private form above).
-// The lane-private fetch asks the texture path for 12 x 64 (lane, line) look-ups per wave -- 6 x 16 bytes of each of a lane's two
-// 128-byte records.  Here eight neighbouring lanes fetch the eight 16-byte chunks of ONE record, so a wave-instruction touches 8
-// lines instead of 64 (16 instructions x 8 = 128 look-ups per wave), straight into LDS (global_load_lds_dwordx4: no staging
-// registers, no ds_write); each lane then reads its own record back (6 x ds_read_b128).  The LDS image of a load instruction is
-// lane-linear, so the bank-conflict-free placement is made on the SOURCE side: position c of record slot R holds chunk
-// (c + (R >> 1)) & 7, and the reader of chunk j looks at position (j - (R >> 1)) & 7 -- 64 lanes x 16 bytes then spread over all
-// sixteen 16-byte columns of the 256-byte bank span, four lanes each.  One 8 KB tile per wave, the two records of a pair one after
-// the other (the second fetch is in flight while the first record is accumulated).  Same per-pair code (utia_prepare /
-// utia_accumulate / utia_decode), same sums in the same order: bit-identical.
-template <int WANT, bool DENSE>
-__global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_eval_utia_coop(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
-                                                                          unsigned int *list, unsigned int cap, unsigned int *count)
-{
-	__shared__ float4 s_tile[BLOCK / 64][64 * 8];
-	const long long stride = (long long)gridDim.x * BLOCK;
-	const unsigned int t = threadIdx.x, wave = t >> 6, lane = t & 63u;
-	float4 *tile = s_tile[wave];
-	typedef __attribute__((address_space(3))) void lds_void;
-	typedef __attribute__((address_space(1))) const void glb_void;
-	const unsigned int rot_own = (lane >> 1) & 7u;
-	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
-		const long long k = k0 + t;
-		const bool live = k < n;
-		v3 i = mk(0, 0, 1), o = mk(0, 0, 1);
-		if (live) { i = DENSE ? load3_dense(vi, k0, t) : load3(vi, k); o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k); }
-		bool ok;
-		const UtiaTaps u = utia_prepare<true>(i, o, ok);
-		float acc[3] = { 0.0f, 0.0f, 0.0f };
-		auto fetch = [&](int a) {
-#pragma unroll
-			for (unsigned int r = 0; r < 8u; ++r) {
-				const unsigned int sl = r * 8u + (lane >> 3);                       // the lane whose record this lane helps to fetch
-				const int e_src = __shfl(u.e[a], (int)sl);
-				const unsigned int chunk = ((lane & 7u) + ((sl >> 1) & 7u)) & 7u;
-				const float4 *src = b.utia + 8 * (size_t)e_src + chunk;
-				__builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(tile + r * 64u), 16, 0, 0);
-			}
-		};
-		auto take = [&](float4 (&q)[6]) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's eight LDS-direct loads have landed
-#pragma unroll
-			for (unsigned int j = 0; j < 6u; ++j) q[j] = tile[lane * 8u + ((j - rot_own) & 7u)];
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // read before the tile is overwritten
-		};
-		float4 q[6];
-		fetch(0);
-		take(q);
-		fetch(1);                                                                   // in flight while record 0 is accumulated
-		utia_accumulate(u, 0, q, acc);
-		take(q);
-		utia_accumulate(u, 1, q, acc);
-		const v3 e = utia_decode(u, acc);
-		if (live) {
-			v3 fr = (WANT & 2) ? scale(i.z, e) : e;                                     // brdf::evalp, dj_brdf.h:803-806
-			if (DENSE) store3_dense(vout, k0, t, fr); else store3(vout, k, fr);
-			if (WANT & 4) { float pdf = F(D(i.z) / DJB_PI); if (DENSE) (out_pdf + k0)[t] = pdf; else out_pdf[k] = pdf; }   // dj_brdf.h:842-845
-			if (__builtin_expect(!ok, 0)) {
-				const unsigned int slot = atomicAdd(count, 1u);
-				if (slot < cap) list[slot] = (unsigned int)k;
-			}
-		}
-	}
-}
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_eval_utia_fix(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
                                                          const unsigned int *list, unsigned int cap, const unsigned int *count)
@@ -300,12 +236,7 @@ hipError_t launch_utia_tt(hipStream_t s, const Brdf &b, long long n, const View 
 	hipError_t e = hipMemsetAsync(count, 0, 16, s);
 	if (e != hipSuccess) return e;
 	dim3 g(grid_for(n)), t(BLOCK);
-	static const bool coop = getenv("DJB_UTIA_COOP") && atoi(getenv("DJB_UTIA_COOP")) != 0;       // round-5 A/B switch (profiles/r05/utia_coop.txt)
-	if (coop) {
-		if (dense(i) && dense(o) && dense(out)) hipLaunchKernelGGL((k_eval_utia_coop<WANT, true>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-		else hipLaunchKernelGGL((k_eval_utia_coop<WANT, false>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-	}
-	else if (dense(i) && dense(o) && dense(out)) hipLaunchKernelGGL((k_eval_utia_t1<WANT, true>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
+	if (dense(i) && dense(o) && dense(out)) hipLaunchKernelGGL((k_eval_utia_t1<WANT, true>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
 	else hipLaunchKernelGGL((k_eval_utia_t1<WANT, false>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL((k_eval_utia_fix<WANT>), dim3(64), t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);

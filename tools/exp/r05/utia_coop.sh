@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: utia::eval tier 1 with a wave-cooperative record fetch (k_eval_utia_coop, DJB_UTIA_COOP=1) against the lane-private form
+# (the kernel lives in the commit "experiment: utia::eval tier 1 with a wave-cooperative record fetch"; it was removed again: slower)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 O=gpurun_out/utia_coop.txt; : > $O
 echo "== parity with DJB_UTIA_COOP=1 (bit-identical to the oracle)" >> $O

@@ -9,8 +9,18 @@ import os
 import shutil
 import sys
 
+import subprocess
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+# the tree the passes were taken on: this script runs in the build container right after the gpurun call that profiled the working tree
+# (the GPU box has no .git); bench.py prints it next to the figures it reads from these summaries
+try:
+    TREE = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+    if subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "dj_brdf_amd/csrc", "bench.py"], capture_output=True, text=True).stdout.strip():
+        TREE += "+uncommitted"
+except Exception:
+    TREE = "unknown"
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles", RND)
 os.makedirs(DST, exist_ok=True)
@@ -52,7 +62,7 @@ for w in sorted(os.listdir(SRC)):
     write_kb = sum(v.get("WRITE_SIZE", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
     if fetch_kb or write_kb:
         out = {
-            "workload": w, "round": "round %d (profiles/%s)" % (int(RND.lstrip("r") or 0), RND),
+            "workload": w, "round": "round %d (profiles/%s)" % (int(RND.lstrip("r") or 0), RND), "tree": TREE,
             "kernels": [k for k in per_kernel if any(t in k for t in DOMINANT.get(w, ()))],
             "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
             # MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-B streaming requests as 64 B on gfx950
@@ -86,4 +96,13 @@ for w in sorted(os.listdir(SRC)):
             out["l2_hit_rate"] = hit / (hit + miss)          # TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), MI355X_MICROARCH.md section L2
         json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{w}.json"), "w"), indent=1)
         print(w, out["hbm_bytes_per_launch"] / 1e9, "GB per launch")
+# the instruction-mix summaries of tools/valu_report.py (written on the GPU box into gpurun_out/): tracked copies, stamped with the tree
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "valu_*.json"))):
+    if os.path.getmtime(f) < os.path.getmtime(SRC):          # older than this round's profile passes: a leftover
+        continue
+    v = json.load(open(f))
+    v["tree"] = TREE
+    v["round"] = "round %d (profiles/%s)" % (int(RND.lstrip("r") or 0), RND)
+    json.dump(v, open(os.path.join(ROOT, "profiles", os.path.basename(f)), "w"), indent=1)
+    print(os.path.basename(f), "%.1f instr / %.1f slots per unit" % (v["insts_per_unit"], v["slots_per_unit"]), [k["kernel"] for k in v["kernels"]])
 print(sorted(os.listdir(DST)))

@@ -213,6 +213,10 @@ void pp_kind(const Brdf &b, long long k0, long long k1, const View &vi, const Vi
 v3 src_eval(const Brdf &src, const Params &std_p, v3 i, v3 o, int slot = -1)
 {
 	if (src.kind == KIND_MERL && src.merl_sparse) { MerlTexel t = src.merl[slot]; return mk(t.x, t.y, t.z); }
+	// the fitters call brdf.eval(i, o) with user_param == NULL: a Lambertian source has the default reflectance (1, 1, 1)
+	// (dj_brdf.h:863-865) -- std_p are MICROFACET params, whose n = (0, 0, 1) eval_one would read as a reflectance (found in
+	// round 5 by examples/c_abi_demo.c: tabular(lambert) on a CPU context fitted a blue-only source; the GPU kernels were right)
+	if (src.kind == KIND_LAMBERT) return divs(mk(1, 1, 1), F(DJB_PI));
 	v3 fr = mk(0, 0, 0); float pdf = 0.0f;
 	DJB_KIND_SWITCH(src.kind, (eval_one<K, 1>(src, std_p, i, o, fr, pdf)))
 	return fr;

@@ -6,8 +6,21 @@
  * 0.749468625)) and prints the results with %.9g, as a caller of djb::ggx::eval / pdf / sample would (dj_brdf.h:77-97). */
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "djb_hip.h"
+
+/* a BRDF the CALLER defines (the reference's extension point: a class derived from djb::brdf, dj_brdf.h:74-109 -- here a C
+ * function, what a cgo / JNI callback would be).  It restates djb::lambert::eval (dj_brdf.h:861-868: reflectance / M_PI with
+ * vec3 / float_t = (1.0 / b) * a, b = float(M_PI)) so that the fit of the callback can be held against the fit of the library's
+ * own Lambertian, table by table */
+static void my_brdf(const float *i, const float *o, float *rgb)
+{
+	const float pi_f = (float)3.14159265358979323846;
+	const float inv_pi = (float)(1.0 / (double)pi_f);
+	(void)i; (void)o;
+	rgb[0] = inv_pi * 1.0f; rgb[1] = inv_pi * 1.0f; rgb[2] = inv_pi * 1.0f;
+}
 
 #define CHECK(call) do { djb_status s_ = (call); if (s_ != DJB_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, (int)s_, djb_last_error()); return 1; } } while (0)
 
@@ -37,6 +50,38 @@ int main(int argc, char **argv)
 	CHECK(djb_sample_batch(ctx, ggx, 1, &u1, &u2, &vo, &p, &vin, DJB_MEM_HOST));
 	printf("device %s\n", device == DJB_DEVICE_CPU ? "cpu" : "gpu");
 	printf("eval %.9g %.9g %.9g\npdf %.9g\nsample %.9g %.9g %.9g\n", fr[0], fr[1], fr[2], pdf, in[0], in[1], in[2]);
+	/* fit a caller-defined BRDF: the library says where tabular's constructor evaluates its source (dj_brdf.h:2494, 2610), the caller
+	 * evaluates there, the fit runs on the samples; held against tabular(lambert) on the same context: every table identical */
+	{
+		const int res = 32;
+		int64_t nq = 0, k, evaluated = 0;
+		CHECK(djb_fit_query_dirs(res, 0, NULL, NULL, &nq));
+		float *qi = (float *)malloc(sizeof(float) * 3 * (size_t)nq), *qo = (float *)malloc(sizeof(float) * 3 * (size_t)nq);
+		float *rgb = (float *)calloc(3 * (size_t)nq, sizeof(float));
+		djb_vec3_view vqi = { qi, qi + 1, qi + 2, 3 }, vqo = { qo, qo + 1, qo + 2, 3 };
+		CHECK(djb_fit_query_dirs(res, nq, &vqi, &vqo, NULL));
+		for (k = 0; k < nq; ++k)
+			if (qo[3 * k] == qo[3 * k]) { my_brdf(qi + 3 * k, qo + 3 * k, rgb + 3 * k); ++evaluated; }     /* NaN: a pair the reference skips */
+		djb_brdf *tab = NULL, *lam = NULL, *tab_lam = NULL;
+		CHECK(djb_brdf_create_tabular_from_samples(ctx, res, 1, rgb, nq, &tab));
+		CHECK(djb_brdf_create_lambert(ctx, &lam));
+		CHECK(djb_brdf_create_tabular(ctx, lam, res, 1, &tab_lam));
+		float a_user = 0, a_lam = 0, t_user[3 * 32], t_lam[3 * 32];
+		int which, same = 1;
+		CHECK(djb_tabular_fit(tab, NULL, &a_user));
+		CHECK(djb_tabular_fit(tab_lam, NULL, &a_lam));
+		for (which = DJB_TAB_P22; which <= DJB_TAB_FRESNEL; ++which) {
+			int n_user = 0, n_lam = 0;
+			memset(t_user, 0, sizeof t_user); memset(t_lam, 0, sizeof t_lam);
+			CHECK(djb_tabular_get(tab, which, NULL, &n_user)); CHECK(djb_tabular_get(tab_lam, which, NULL, &n_lam));
+			CHECK(djb_tabular_get(tab, which, t_user, NULL)); CHECK(djb_tabular_get(tab_lam, which, t_lam, NULL));
+			same = same && n_user == n_lam && memcmp(t_user, t_lam, sizeof t_user) == 0;
+		}
+		printf("user-defined fit: %lld of %lld query slots evaluated, alpha_ggx %.3f (tabular(lambert): %.3f), tables %s\n", (long long)evaluated,
+		       (long long)nq, a_user, a_lam, same ? "identical" : "DIFFERENT");
+		CHECK(djb_brdf_destroy(tab)); CHECK(djb_brdf_destroy(tab_lam)); CHECK(djb_brdf_destroy(lam));
+		free(qi); free(qo); free(rgb);
+	}
 	CHECK(djb_brdf_destroy(ggx));
 	CHECK(djb_ctx_destroy(ctx));
 	return 0;

@@ -32,7 +32,9 @@ def test_library_exports_every_declared_symbol():
 
 
 # SURVEY.md section 8-N, measured with the reference compiled here: ggx isotropic(0.3), i = (0.3, 0.2, .), o = (-0.4, 0.1, .)
-C_ABI_DEMO_KNOWN = ["eval 0.621380985 0.621380985 0.621380985", "pdf 0.581518769", "sample 0.657071352 0.080957301 0.749468625"]
+C_ABI_DEMO_KNOWN = ["eval 0.621380985 0.621380985 0.621380985", "pdf 0.581518769", "sample 0.657071352 0.080957301 0.749468625",
+                    # a caller-defined BRDF (a C callback) fitted from samples at djb_fit_query_dirs == tabular(lambert) on the same context
+                    "user-defined fit: 728 of 1023 query slots evaluated, alpha_ggx 0.693 (tabular(lambert): 0.693), tables identical"]
 
 
 def run_c_abi_demo(where):

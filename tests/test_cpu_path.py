@@ -166,6 +166,8 @@ def test_user_defined_brdf_is_fitted_from_host_samples(cpu, oracle, name):
     import user_defined_cases
     user_defined_cases.check_user_defined_fits(cpu, oracle, name)
     user_defined_cases.check_sample_count_errors(cpu)
+    if name == "ward":
+        user_defined_cases.check_lambert_source(cpu, oracle)
 
 
 def test_params_txt_on_the_cpu(cpu, tmp_path):

@@ -23,6 +23,10 @@ def test_sample_count_errors(gpu_ctx):
     user_defined_cases.check_sample_count_errors(gpu_ctx)
 
 
+def test_lambert_source(gpu_ctx, oracle):
+    user_defined_cases.check_lambert_source(gpu_ctx, oracle)
+
+
 def test_sampled_fit_equals_resident_fit(gpu_ctx):
     """a resident BRDF sampled at the query slots and fitted from the samples gives the tables of the resident fit: the slot
     numbering of djb_fit_query_dirs is the one k_fit reads (every slot, both resolutions' skipped pairs included)"""

@@ -82,6 +82,27 @@ def check_user_defined_fits(ctx, oracle, name):
     assert same(fb, g[f"{name}_aniso_fit_beckmann"]) and same(fg, g[f"{name}_aniso_fit_ggx"])
 
 
+def check_lambert_source(ctx, oracle):
+    """tabular / tabular_anisotropic of the library's own Lambertian (eval with user_param == NULL: reflectance 1) against the oracle --
+    and the same fit from samples of its eval(): three ways to the same tables.  (Round 5: the host path read the microfacet
+    standard params' normal (0, 0, 1) as the reflectance and fitted a blue-only source; no test had a Lambertian source.)"""
+    lam, olam = djb.lambert(ctx=ctx), oracle.lambert()
+    for res in (32, 90):
+        t = djb.tabular(lam, res, True, ctx=ctx)
+        want = oracle.tabular_tables(oracle.tabular(olam, res, True))
+        qi, qo = djb.fit_query_dirs(res)
+        ok = ~np.isnan(qo[:, 0])
+        rgb = np.zeros((qi.shape[0], 3), np.float32)
+        rgb[ok] = lam.eval(qi[ok], qo[ok])
+        t2 = djb.tabular.from_samples(res, rgb, True, ctx=ctx)
+        for k, v, v2 in (("p22", t.get_p22v(), t2.get_p22v()), ("sigma", t.get_sigmav(), t2.get_sigmav()), ("cdf", t.get_cdfv(), t2.get_cdfv()),
+                         ("qf", t.get_qfv(), t2.get_qfv()), ("fresnel", t.get_fresnel().get_points(), t2.get_fresnel().get_points())):
+            assert same(v, want[k]) and same(v2, want[k]), (res, k)
+    ta = djb.tabular_anisotropic(lam, 9, 16, True, ctx=ctx)
+    wa = oracle.aniso_tables(oracle.tabular_anisotropic(olam, 9, 16, True))
+    assert same(ta.get_p22v()[0], wa["p22"]) and same(ta.get_sigmav()[0], wa["sigma"]) and same(ta.get_fresnel().get_points(), wa["fresnel"])
+
+
 def check_sample_count_errors(ctx):
     import pytest
     qi, qo = djb.fit_query_dirs(20)

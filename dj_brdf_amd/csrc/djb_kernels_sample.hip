@@ -619,14 +619,6 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 	__shared__ double s_glibc[KIND == KIND_BECKMANN ? GLIBC_LDS_WORDS : 1];
 	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];
 	__shared__ unsigned int s_q[WAVES][7][QCAP];       // deferred samples: {k lo, k hi, u1, u2, o.xyz}
-	// Contract mode (Beckmann sample): TWO levels of deferral (round 5).  A sample the fp32 path declines (8.5 % of the bench
-	// distribution: its error bound, a decision inside a band) is an ORDINARY sample -- it needs the reference's arithmetic, not the
-	// rare arms -- yet the full per-sample code costs a dense wave of declined samples what its worst lane costs (up to nine trips, both
-	// erfinv arms: ~5x a common-path sample; profiles/r05/beckmann_defer_cost.txt: 3.75 of the 11.8 ms per 1e9).  So the declined samples
-	// first run the exact kernel's straight-line common path (bk_sample_common: four trips, no arm, bit-identical wherever it raises no
-	// flag) as dense waves, and only what THAT flags (1.6 % of all samples) goes on to sample_one through a second queue.
-	constexpr bool TWO_LEVEL = CT && !IS && KIND == KIND_BECKMANN;
-	__shared__ unsigned int s_q2[TWO_LEVEL ? WAVES : 1][7][TWO_LEVEL ? QCAP : 1];
 	GlibcTabs gt = glibc_tabs_global();                // GGX's sampler calls no libm function
 	if (KIND == KIND_BECKMANN) {
 		gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
@@ -635,61 +627,22 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 	}
 	const unsigned int t = threadIdx.x, wave = t >> 6, lane = t & 63u;
 	unsigned int (&q)[7][QCAP] = s_q[wave];
-	unsigned int qn = 0, q2n = 0;                      // wave-uniform
+	unsigned int qn = 0;                               // wave-uniform
 	// the full per-sample code on `cnt` queued samples starting at slot `first` (one per lane)
-	auto drain_full = [&](unsigned int (&qq)[7][TWO_LEVEL ? QCAP : 1], unsigned int first, unsigned int cnt) {
+	auto drain = [&](unsigned int first, unsigned int cnt) {
 		if (lane < cnt) {
 			const unsigned int j = first + lane;
-			const long long k = (long long)(((unsigned long long)qq[1][j] << 32) | qq[0][j]);
-			const float u1 = __uint_as_float(qq[2][j]), u2 = __uint_as_float(qq[3][j]);
-			const v3 o = mk(__uint_as_float(qq[4][j]), __uint_as_float(qq[5][j]), __uint_as_float(qq[6][j]));
+			const long long k = (long long)(((unsigned long long)q[1][j] << 32) | q[0][j]);
+			const float u1 = __uint_as_float(q[2][j]), u2 = __uint_as_float(q[3][j]);
+			const v3 o = mk(__uint_as_float(q[4][j]), __uint_as_float(q[5][j]), __uint_as_float(q[6][j]));
 			v3 i_out, w; float pdf;
 			sample_one<KIND, IS, FRK>(b, p, u1, u2, o, gt, i_out, w, pdf);
 			store3(vi_out, k, i_out);
-		}
-	};
-	auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-	auto drain = [&](unsigned int first, unsigned int cnt) {
-		if constexpr (TWO_LEVEL) {
-			// level 1: the exact common path; its flagged samples move to the second queue
-			const bool act = lane < cnt;
-			const unsigned int j = first + (act ? lane : 0u);
-			const unsigned int klo = q[0][j], khi = q[1][j];
-			const float u1 = __uint_as_float(q[2][j]), u2 = __uint_as_float(q[3][j]);
-			const v3 o = mk(__uint_as_float(q[4][j]), __uint_as_float(q[5][j]), __uint_as_float(q[6][j]));
-			Rare why2;
-			const v3 i2 = bk_sample_common<true>(p, u1, u2, o, gt, why2);
-			const bool again = act & why2.any;
-			if (act & !again) store3(vi_out, (long long)(((unsigned long long)khi << 32) | klo), i2);
-			const unsigned long long m2 = __ballot(again);
-			if (m2) {
-				unsigned int (&q2)[7][QCAP] = s_q2[wave];
-				if (again) {
-					const unsigned int j2 = q2n + (unsigned int)__popcll(m2 & ((1ull << lane) - 1ull));
-					q2[0][j2] = klo; q2[1][j2] = khi; q2[2][j2] = __float_as_uint(u1); q2[3][j2] = __float_as_uint(u2);
-					q2[4][j2] = __float_as_uint(o.x); q2[5][j2] = __float_as_uint(o.y); q2[6][j2] = __float_as_uint(o.z);
-				}
-				q2n += (unsigned int)__popcll(m2);               // < 128: emptied below, in the loop body (the one place sample_one is inlined)
-			}
-		} else {
-			if (lane < cnt) {
-				const unsigned int j = first + lane;
-				const long long k = (long long)(((unsigned long long)q[1][j] << 32) | q[0][j]);
-				const float u1 = __uint_as_float(q[2][j]), u2 = __uint_as_float(q[3][j]);
-				const v3 o = mk(__uint_as_float(q[4][j]), __uint_as_float(q[5][j]), __uint_as_float(q[6][j]));
-				v3 i_out, w; float pdf;
-				sample_one<KIND, IS, FRK>(b, p, u1, u2, o, gt, i_out, w, pdf);
-				store3(vi_out, k, i_out);
-				if (IS) { store3(vw_out, k, w); out_pdf[k] = pdf; }
-			}
+			if (IS) { store3(vw_out, k, w); out_pdf[k] = pdf; }
 		}
 	};
 	const long long stride = (long long)gridDim.x * BLOCK;
-	// One drain site per level: the loop makes one extra pass (`flush`, workgroup-uniform) after its last tile that computes nothing and
-	// empties what is left in the queues -- the per-sample code is inlined once instead of once in the loop and once behind it
-	for (long long k0 = (long long)blockIdx.x * BLOCK; ; k0 += stride) {            // k0: workgroup-uniform
-		const bool flush = k0 >= n;
-		if (!flush) {
+	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
 		const long long k = k0 + t;
 		const bool live = k < n;
 		float u1 = 0.5f, u2 = 0.5f; v3 o = mk(0, 0, 1);
@@ -708,9 +661,9 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 			why.flag(R_GUARD, !ct_is_tail<KIND_BECKMANN, FRK == -1 ? FR_IDEAL : FRK>(ct, i_, o, w, pdf, alive));
 			i_out = alive ? i_ : mk(0, 0, 0);
 		} else if (IS) { i_out = mk(0, 0, 0); w = mf_evalp_is_tail<KIND_BECKMANN, FRK>(b, p, i_, o, i_out, pdf); }
-#if defined(DJB_EXP_NO_DEFER) && DJB_EXP_NO_DEFER == 2   // timing-only: the flags are computed, nobody is deferred (n < 0 never holds, the compiler cannot know)
-		const bool rare = why.any & live & (n < 0);
-#elif defined(DJB_EXP_NO_DEFER)      // timing-only: nobody is deferred AND the flag computations are dead code: the bare arithmetic of the common path
+#if defined(DJB_EXP_NO_DEFER) && DJB_EXP_NO_DEFER == 2   // timing-only builds (tools/exp/r05/beckmann_defer_cost.sh): the flags are computed, nobody is deferred
+		const bool rare = why.any & live & (n < 0);          //   (n < 0 never holds, the compiler cannot know)
+#elif defined(DJB_EXP_NO_DEFER)      // ... nobody is deferred AND the flag computations are dead code: the bare arithmetic of the common path
 		const bool rare = false;
 #else
 		const bool rare = why.any & live;
@@ -741,18 +694,20 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 				q[4][j] = __float_as_uint(o.x); q[5][j] = __float_as_uint(o.y); q[6][j] = __float_as_uint(o.z);
 			}
 			qn += (unsigned int)__popcll(mask);
-		}
-		}   // !flush
-		const unsigned int cnt = qn >= 64u ? 64u : (flush ? qn : 0u);
-		if (cnt) { wave_sync(); qn -= cnt; drain(qn, cnt); wave_sync(); }
-		if constexpr (TWO_LEVEL) {
-			for (;;) {
-				const unsigned int cnt2 = q2n >= 64u ? 64u : (flush ? q2n : 0u);
-				if (!cnt2) break;
-				wave_sync(); q2n -= cnt2; drain_full(s_q2[wave], q2n, cnt2); wave_sync();
+			if (qn >= 64u) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				qn -= 64u;
+				drain(qn, 64u);
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
 			}
 		}
-		if (flush) break;
+	}
+	if (qn) {
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		drain(0u, qn);
 	}
 }
 

@@ -4,7 +4,7 @@
 #include <cmath>
 #include <cstdio>
 
-#include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "djb_hip.hpp"
@@ -12,7 +12,7 @@
 static int g_fail = 0;
 static void expect(const char *what, double got, double want)
 {
-	double rel = std::fabs(got - want) / std::fmax(std::fabs(want), 1e-30);
+	double rel = want == 0.0 ? std::fabs(got) : std::fabs(got - want) / std::fmax(std::fabs(want), 1e-30);
 	printf("%-34s %.9g (want %.9g) %s\n", what, got, want, rel <= 1e-5 ? "ok" : "MISMATCH");
 	if (!(rel <= 1e-5)) g_fail = 1;
 }
@@ -97,6 +97,38 @@ int main()
 			}
 			expect("contract mode: worst rel. diff < 1e-5", worst < 1e-5 ? 1.0 : 0.0, 1.0);
 			expect("contract mode: one-pair call unchanged", one_pair, 0.441180676);
+		}
+		// a user-defined Fresnel term (dj_brdf.h:157-162) in batches: D G of all pairs in one library call + the user's F per pair
+		// on the host must give the bits of n one-pair calls (which ask for G and compose the reference's expressions one by one)
+		{
+			struct tint : public djb::fresnel::impl {
+				djb::vec3 eval(float c) const { const float m = 1.0f - c; return djb::vec3(0.9f, 0.6f, 0.3f) + djb::vec3(0.1f, 0.4f, 0.7f) * (m * m * m); }
+				djb::fresnel::impl *copy() const { return new tint(*this); }
+			};
+			tint user_f; djb::ggx gu(user_f); djb::beckmann bu(user_f, false);
+			const size_t nb = 4096;
+			std::vector<djb::vec3> bi(nb), bo(nb), a(nb), b1(nb), wi(nb), wi1(nb);
+			std::vector<float> u1(nb), u2(nb), pd(nb), pd1(nb);
+			for (size_t k = 0; k < nb; ++k) {
+				const float t = 0.02f + 1.7f * (float)k / (float)nb, ph = 0.37f * (float)k;      // some pairs below the horizon
+				bi[k] = djb::vec3(t, ph); bo[k] = djb::vec3(1.75f - t, 1.3f * ph + 0.5f);
+				u1[k] = (float)((k * 2654435761u) >> 8 & 0xffffff) / 16777216.0f; u2[k] = (float)((k * 40503u + 77u) & 0xffff) / 65536.0f;
+			}
+			int diff = 0;
+			const djb::microfacet *objs[2] = { &gu, &bu };
+			for (int w = 0; w < 2; ++w) {
+				const djb::microfacet &m = *objs[w];
+				m.eval(nb, &bi[0], &bo[0], &a[0], &ell);
+				for (size_t k = 0; k < nb; ++k) { djb::vec3 r = m.eval(bi[k], bo[k], &ell); diff += std::memcmp(&r, &a[k], sizeof r) != 0; }
+				m.evalp(nb, &bi[0], &bo[0], &a[0]);
+				for (size_t k = 0; k < nb; ++k) { djb::vec3 r = m.evalp(bi[k], bo[k]); diff += std::memcmp(&r, &a[k], sizeof r) != 0; }
+				m.evalp_is(nb, &u1[0], &u2[0], &bo[0], &a[0], &wi[0], &pd[0], &ell);
+				for (size_t k = 0; k < nb; ++k) {
+					djb::vec3 ii(0); float pp = 0; djb::vec3 r = m.evalp_is(u1[k], u2[k], bo[k], &ii, &pp, &ell);
+					diff += std::memcmp(&r, &a[k], sizeof r) != 0 || std::memcmp(&pp, &pd[k], sizeof pp) != 0;
+				}
+			}
+			expect("user Fresnel: batch == one-pair calls (bits differing)", (double)diff, 0.0);
 		}
 		try { djb::merl bad("/nonexistent/file.binary"); g_fail = 1; }
 		catch (const djb::exc &e) { printf("djb::exc as expected: %s", e.what()); }

@@ -255,13 +255,13 @@ public:
 	// object (host code) is called once per pair.
 	void eval(size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param = NULL) const
 	{
-		if (!resident()) { for (size_t k = 0; k < n; ++k) out[k] = eval(i[k], o[k], user_param); return; }
+		if (!resident()) { host_eval_batch(false, n, i, o, out, user_param); return; }
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out);
 		hip::check(djb_eval_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 	}
 	void evalp(size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param = NULL) const
 	{
-		if (!resident()) { for (size_t k = 0; k < n; ++k) out[k] = evalp(i[k], o[k], user_param); return; }
+		if (!resident()) { host_eval_batch(true, n, i, o, out, user_param); return; }
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out);
 		hip::check(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 	}
@@ -281,10 +281,7 @@ public:
 	void evalp_is(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_weight,
 	              vec3 *out_i, float_t *out_pdf, const void *user_param = NULL) const
 	{
-		if (!resident()) {
-			for (size_t k = 0; k < n; ++k) out_weight[k] = evalp_is(u1[k], u2[k], o[k], &out_i[k], &out_pdf[k], user_param);
-			return;
-		}
+		if (!resident()) { host_evalp_is_batch(n, u1, u2, o, out_weight, out_i, out_pdf, user_param); return; }
 		djb_vec3_view vo = hip::view(o), vw = hip::view(out_weight), vi = hip::view(out_i);
 		hip::check(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi,
 		                              out_pdf, DJB_MEM_HOST));
@@ -331,6 +328,13 @@ protected:
 	}
 	// sample / pdf never involve the Fresnel term: a handle answers them even when eval is composed on the host
 	bool overrides_resident_ops() const { return m_h != NULL; }
+	// batches of an object evaluated by host code: one scalar virtual call per pair (microfacet overrides these: D G of the whole
+	// batch in one library call, the user's Fresnel term per pair)
+	virtual void host_eval_batch(bool cosine, size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param) const
+	{ for (size_t k = 0; k < n; ++k) out[k] = cosine ? evalp(i[k], o[k], user_param) : eval(i[k], o[k], user_param); }
+	virtual void host_evalp_is_batch(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_weight, vec3 *out_i,
+	                                 float_t *out_pdf, const void *user_param) const
+	{ for (size_t k = 0; k < n; ++k) out_weight[k] = evalp_is(u1[k], u2[k], o[k], &out_i[k], &out_pdf[k], user_param); }
 	void need_resident(const char *what) const
 	{ if (!resident()) throw exc(std::string("djb_error: ") + what + " needs a BRDF resident on the GPU (this object is evaluated by host code)", DJB_ERR_INVALID_ARGUMENT); }
 	djb_brdf *m_h;
@@ -656,6 +660,40 @@ public:
 		return vec3(0);
 	}
 protected:
+	// Batches under a user-defined Fresnel term: the D G part of EVERY pair in one call on the handle (a kernel launch on a GPU
+	// context), then the user's F(cos theta_d) per pair on the host.  A non-zero, non-NaN D G value can only come from the reference's
+	// G > 0 branch, where the result is F * that value (dj_brdf.h:1545, 1762); every other pair (zeros, NaNs: a handful) takes the
+	// one-pair path, which asks for G itself.  Same bits as n scalar calls.
+	void host_eval_batch(bool cosine, size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param) const
+	{
+		if (!n) return;
+		std::vector<vec3> dg(n);
+		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(&dg[0]);
+		hip::check(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+		for (size_t k = 0; k < n; ++k) {
+			const float_t s = dg[k].x;
+			if (s == s && s != (float_t)0) {
+				const vec3 h = normalize(i[k] + o[k]);
+				const vec3 fr_cos = m_fresnel->eval(sat(dot(o[k], h))) * s;
+				out[k] = cosine ? fr_cos : fr_cos / i[k].z;
+			} else out[k] = cosine ? evalp(i[k], o[k], user_param) : eval(i[k], o[k], user_param);
+		}
+	}
+	void host_evalp_is_batch(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_weight, vec3 *out_i,
+	                         float_t *out_pdf, const void *user_param) const
+	{
+		if (!n) return;
+		if (!supports_smith_vndf_sampling()) { brdf::host_evalp_is_batch(n, u1, u2, o, out_weight, out_i, out_pdf, user_param); return; }
+		djb_vec3_view vo = hip::view(o), vw = hip::view(out_weight), vi = hip::view(out_i);
+		hip::check(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi, out_pdf, DJB_MEM_HOST));
+		for (size_t k = 0; k < n; ++k) {
+			const float_t s = out_weight[k].x;                     // G / G1 under fresnel::ideal
+			if (s == s && s != (float_t)0) {
+				const vec3 h = normalize(out_i[k] + o[k]);
+				out_weight[k] = m_fresnel->eval(sat(dot(o[k], h))) * s;
+			} else out_weight[k] = evalp_is(u1[k], u2[k], o[k], &out_i[k], &out_pdf[k], user_param);
+		}
+	}
 	microfacet(hip::context *c, const fresnel::impl &f) : brdf(c), m_fresnel(f.copy()) {}
 	// the term the handle is created with: the library's own, or ideal under a user-defined one (*host = true)
 	static djb_fresnel_desc resident_desc(const fresnel::impl &f, bool *host)

@@ -46,6 +46,7 @@ struct CpuBrdf {
 	std::vector<MerlTexel> merl;
 	std::vector<float4> utia;
 	std::vector<double> model, raw;
+	UserNdf ndf = {};         // KIND_USER: the caller's callbacks (dev.user_ndf points here)
 };
 
 CpuCtx *C(djb_ctx *c) { return (CpuCtx *)c; }
@@ -116,7 +117,7 @@ djb_status params_for(const djb_params *in, int brdf_kind, Params *p)
 {
 	// a scalar call costs ~100 ns: do not re-derive params::standard() (cos / sin / sqrt chain, what the reference does
 	// on every call with user_param == NULL, dj_brdf.h:1532-1534) each time, and not at all for the kinds that ignore it
-	const bool uses_params = brdf_kind <= KIND_TABULAR || brdf_kind == KIND_TABULAR_ANISO || brdf_kind == KIND_LAMBERT;
+	const bool uses_params = DJB_IS_MICROFACET(brdf_kind) || brdf_kind == KIND_LAMBERT;
 	if (!uses_params && (!in || in->kind != DJB_PARAMS_LAMBERT)) { memset(p, 0, sizeof *p); return DJB_OK; }
 	if (!in && brdf_kind != KIND_LAMBERT) {
 		static const Params std_p = [] {
@@ -168,6 +169,7 @@ void eval_kind(const Brdf &b, const Params &p, long long k0, long long k1, const
 	case KIND_LAMBERT: { constexpr int K = KIND_LAMBERT; CALL; } break; \
 	case KIND_SGD: { constexpr int K = KIND_SGD; CALL; } break; \
 	case KIND_ABC: { constexpr int K = KIND_ABC; CALL; } break; \
+	case KIND_USER: { constexpr int K = KIND_USER; CALL; } break; \
 	}
 
 template <int KIND, bool IS>
@@ -699,10 +701,29 @@ djb_status create_tabular_anisotropic_from_samples(djb_ctx *ctx, int elev, int a
 	return DJB_OK;
 }
 
+// a microfacet BRDF around a user-defined NDF (host code): dj_brdf.h:283-295 / 307-314
+djb_status create_user_microfacet(djb_ctx *ctx, const djb_user_ndf *ndf, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
+{
+	static_assert(sizeof(UserNdf) == sizeof(djb_user_ndf), "UserNdf mirrors djb_user_ndf");
+	if (!ndf || !ndf->supports_smith_vndf_sampling) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: user NDF without supports_smith_vndf_sampling");
+	const bool radial = ndf->p22_radial != nullptr;
+	if (radial ? !(ndf->sigma_std_radial && ndf->qf_radial) : !(ndf->p22_std && ndf->sigma_std && ndf->sample_vp22_std))
+		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: user NDF lacks a required callback (radial: p22_radial, sigma_std_radial, qf_radial; "
+		                                                 "microfacet: p22_std, sigma_std, sample_vp22_std)");
+	CpuBrdf *b = alloc_brdf(ctx, KIND_USER);
+	memcpy(&b->ndf, ndf, sizeof b->ndf);
+	b->dev.user_ndf = &b->ndf;
+	b->dev.shadow = shadow != 0;
+	djb_status st = apply_fresnel(b, f);
+	if (st != DJB_OK) { delete b; return st; }
+	*out = (djb_brdf *)b;
+	return DJB_OK;
+}
+
 djb_status destroy(djb_brdf *b) { delete B(b); return DJB_OK; }
 int kind(const djb_brdf *b) { return B(b)->dev.kind; }
 int get_shadow(const djb_brdf *b) { return B(b)->dev.shadow; }
-static bool is_microfacet_kind(int k) { return k == KIND_BECKMANN || k == KIND_GGX || k == KIND_TABULAR || k == KIND_TABULAR_ANISO; }
+static bool is_microfacet_kind(int k) { return DJB_IS_MICROFACET(k); }
 djb_status set_shadow(djb_brdf *b, int shadow)
 {
 	if (!is_microfacet_kind(B(b)->dev.kind)) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: set_shadow needs a microfacet BRDF");
@@ -836,7 +857,7 @@ djb_status eval_pp(djb_ctx *ctx, const djb_brdf *b_, int64_t n, const djb_vec3_v
 {
 	if (!b_ || !rec) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	const Brdf &b = B(b_)->dev;
-	if (!is_microfacet_kind(b.kind)) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need a microfacet BRDF");
+	if (!is_microfacet_kind(b.kind) || b.kind == KIND_USER) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need one of the library's microfacet BRDFs");
 	if (!valid(i) || !valid(o) || ((want & 3) && !valid(out_fr)) || ((want & 4) && !out_pdf))
 		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	const LeanCfg base = lean_cfg(base5, scale, lean_flags);
@@ -875,7 +896,7 @@ djb_status sample_pp(djb_ctx *ctx, const djb_brdf *b_, int64_t n, const float *u
 {
 	if (!b_ || !rec || !u1 || !u2) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
 	const Brdf &b = B(b_)->dev;
-	if (!is_microfacet_kind(b.kind)) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need a microfacet BRDF");
+	if (!is_microfacet_kind(b.kind) || b.kind == KIND_USER) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: per-pair params need one of the library's microfacet BRDFs");
 	const bool is = out_w != nullptr;
 	if (!valid(o) || !valid(out_i) || (is && (!valid(out_w) || !out_pdf)))
 		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
@@ -899,6 +920,13 @@ djb_status query(djb_ctx *ctx, const djb_brdf *b_, int which, int64_t n, const d
                  const djb_vec3_view *c, const djb_params *params, const djb_vec3_view *out)
 {
 	const Brdf &b = B(b_)->dev;
+	if (b.kind == KIND_USER && which >= Q_P22_RADIAL && which <= Q_QF1) {   // the radial queries of a user NDF: only what the user's class has
+		const UserNdf &u = B(b_)->ndf;
+		const bool have = which == Q_P22_RADIAL ? u.p22_radial != nullptr : which == Q_SIGMA_STD_RADIAL ? u.sigma_std_radial != nullptr
+		                : which == Q_CDF_RADIAL ? u.cdf_radial != nullptr : which == Q_QF_RADIAL ? u.qf_radial != nullptr
+		                : which == Q_QF2_RADIAL ? u.qf2_radial != nullptr : which == Q_QF3_RADIAL ? u.qf3_radial != nullptr : false;
+		if (!have) return djbk::set_error(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented");
+	}
 	Params p;
 	djb_status st = params_for(params, b.kind, &p);
 	if (st != DJB_OK) return st;
@@ -912,6 +940,7 @@ djb_status query(djb_ctx *ctx, const djb_brdf *b_, int which, int64_t n, const d
 			case KIND_GGX: r = query_one<KIND_GGX>(b, p, which, k, va, vb, vc); break;
 			case KIND_TABULAR: r = query_one<KIND_TABULAR>(b, p, which, k, va, vb, vc); break;
 			case KIND_TABULAR_ANISO: r = query_one<KIND_TABULAR_ANISO>(b, p, which, k, va, vb, vc); break;
+			case KIND_USER: r = query_one<KIND_USER>(b, p, which, k, va, vb, vc); break;
 			case KIND_SGD: r = model_query_one<KIND_SGD>(b, which, k, va, vb, vc); break;
 			case KIND_ABC: r = model_query_one<KIND_ABC>(b, which, k, va, vb, vc); break;
 			}

@@ -49,6 +49,7 @@ djb_status create_utia_from_records(djb_ctx *, const float *records, djb_brdf **
 djb_status create_utia_from_file(djb_ctx *, const char *path, djb_brdf **);
 djb_status create_lambert(djb_ctx *, djb_brdf **);
 djb_status create_model(djb_ctx *, int kind, const double *row, int count, djb_brdf **);
+djb_status create_user_microfacet(djb_ctx *, const djb_user_ndf *, const djb_fresnel_desc *, int shadow, djb_brdf **);
 djb_status create_tabular(djb_ctx *, const djb_brdf *src, int res, int shadow, djb_brdf **);
 // a tabular / tabular_anisotropic object from tables fitted elsewhere (the host twin of a GPU-fitted object)
 djb_status create_tabular_from_tables(djb_ctx *, int shadow, int res, const float *p22, const float *sigma, const float *cdf,

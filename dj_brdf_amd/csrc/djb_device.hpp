@@ -96,12 +96,33 @@ struct Brdf {
 	// where glibc_exp() / glibc_pow() / glibc_acos() read their tables (LdsTab: 0 = the global copy, else 1 + the LDS byte offset
 	// of a copy staged by the kernel, which sets these on its own copy of the struct; the host leaves them 0)
 	unsigned int exp_lds, pow_lds, acos_lds;
+	// KIND_USER (host path only): the callbacks of a user-defined NDF (UserNdf below); never set on an object a kernel sees
+	const void *user_ndf;
 };
 
 struct View { float *x, *y, *z; long long stride; };
 
+// KIND_USER: a microfacet BRDF whose NDF is HOST CODE of the caller -- a class derived from djb::radial (its public virtuals
+// p22_radial / sigma_std_radial / cdf_radial / qf_radial / qf2_radial / qf3_radial, dj_brdf.h:307-314) or from djb::microfacet
+// (the protected virtuals p22_std / sigma_std / sample_vp22_std_*, dj_brdf.h:283-295).  Host instantiation only: everything
+// around the NDF (params, sigma's stretch, G1 / G2, eval / pdf / sample / evalp_is, the queries) is the same per-unit code.
 enum { KIND_BECKMANN = 0, KIND_GGX = 1, KIND_TABULAR = 2, KIND_MERL = 3, KIND_UTIA = 4, KIND_LAMBERT = 5,
-       KIND_SGD = 6, KIND_ABC = 7, KIND_TABULAR_ANISO = 8 };
+       KIND_SGD = 6, KIND_ABC = 7, KIND_TABULAR_ANISO = 8, KIND_USER = 9 };
+// same layout as djb_user_ndf (include/djb_hip.h)
+struct UserNdf {
+	void *user;
+	int (*supports_smith_vndf_sampling)(void *);
+	float (*p22_radial)(void *, float);                 // != NULL: a radial NDF
+	float (*sigma_std_radial)(void *, float);
+	float (*cdf_radial)(void *, float);
+	float (*qf_radial)(void *, float);
+	float (*qf2_radial)(void *, float, float, float);
+	float (*qf3_radial)(void *, float, float);
+	float (*p22_std)(void *, float, float);             // used when p22_radial == NULL
+	float (*sigma_std)(void *, const float *);
+	void (*sample_vp22_std)(void *, float, float, const float *, float *, float *);
+};
+#define DJB_IS_MICROFACET(K) ((K) <= KIND_TABULAR || (K) == KIND_TABULAR_ANISO || (K) == KIND_USER)
 // the two tabulated microfacet classes sample with the non-VNDF "nmap" scheme (supports_smith_vndf_sampling() == false)
 #define DJB_NMAP(K) ((K) == KIND_TABULAR || (K) == KIND_TABULAR_ANISO)
 enum { FR_IDEAL = 0, FR_UNPOLARIZED = 1, FR_SCHLICK = 2, FR_SGD = 3, FR_SPLINE = 4 };

@@ -558,6 +558,15 @@ try {
 }
 DJB_ABI_CATCH
 
+// a microfacet BRDF around a user-defined NDF: host code of the caller, so a CPU-context object (include/djb_hip.h)
+djb_status djb_brdf_create_user_microfacet(djb_ctx *ctx, const djb_user_ndf *ndf, const djb_fresnel_desc *f, int shadow, djb_brdf **out)
+try {
+	if (!ctx || !ndf || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (!is_cpu(ctx)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a user-defined NDF is host code: create the object on a CPU context (DJB_DEVICE_CPU)");
+	return djbcpu::create_user_microfacet(ctx, ndf, f, shadow, out);
+}
+DJB_ABI_CATCH
+
 // ---- sgd / abc: one row of the published parameter tables + the model's own Fresnel
 struct SgdRow { const char *name, *other_name; double v[33]; };
 struct AbcRow { const char *name; double v[9]; };
@@ -660,7 +669,7 @@ int djb_brdf_get_shadow(const djb_brdf *b) { return !b ? -1 : is_cpu(b) ? djbcpu
 
 static bool is_microfacet_kind(int k)
 {
-	return k == DJB_KIND_BECKMANN || k == DJB_KIND_GGX || k == DJB_KIND_TABULAR || k == DJB_KIND_TABULAR_ANISO;
+	return k == DJB_KIND_BECKMANN || k == DJB_KIND_GGX || k == DJB_KIND_TABULAR || k == DJB_KIND_TABULAR_ANISO || k == DJB_KIND_USER;
 }
 
 djb_status djb_brdf_set_shadow(djb_brdf *b, int shadow)

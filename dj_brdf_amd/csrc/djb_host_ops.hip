@@ -533,7 +533,8 @@ try {
 			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: sgd / abc answer ndf, gaf, fresnel (and g1 for sgd) only");
 	} else if (model_q)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: DJB_Q_MODEL_* need an sgd or abc brdf");
-	if (bkind > DJB_KIND_TABULAR && !aniso && !model)
+	const bool user_ndf = bkind == DJB_KIND_USER;          // a user-defined NDF on the host path: the CPU side knows which radial queries it has
+	if (bkind > DJB_KIND_TABULAR && !aniso && !model && !user_ndf)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: queries need a microfacet brdf");
 	if ((which >= DJB_Q_QF2_RADIAL && which <= DJB_Q_QF1) && (bkind == DJB_KIND_TABULAR || aniso))
 		return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented");          // dj_brdf.h:1854, 1859

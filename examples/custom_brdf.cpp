@@ -75,6 +75,49 @@ private:
 	float m_a;
 };
 
+// a radial NDF defined by the user (dj_brdf.h:301-324: the public virtuals of class radial): a Student-t-like slope distribution
+// p22(r^2) = (g - 1) / (pi (1 + r^2)^g) with g = 3, sampled with the "nmap" scheme through its quantile function
+class student : public djb::radial {
+public:
+	student() : djb::radial() {}
+	explicit student(const djb::fresnel::impl &f, bool shadow = true) : djb::radial(f, shadow) {}
+	bool supports_smith_vndf_sampling() const { return false; }
+	float p22_radial(float r_sqr) const
+	{ const double t = 1.0 + (double)r_sqr; return (float)(2.0 / (M_PI * t * t * t)); }
+	float sigma_std_radial(float cos_theta_k) const                   // a smooth stand-in for the projected area: (1 + c (1 + c) / 2) / 2
+	{ const float c = cos_theta_k; return (float)((1.0 + (double)(c * (1.0f + c)) * 0.5) * 0.5); }
+	float cdf_radial(float r) const
+	{ const double t = 1.0 + (double)(r * r); return (float)(1.0 - 1.0 / (t * t)); }
+	float qf_radial(float u) const
+	{ return (float)std::sqrt(1.0 / std::sqrt(1.0 - (double)u) - 1.0); }
+};
+
+// an NDF defined at the microfacet level (dj_brdf.h:283-295: the protected virtuals of class microfacet): not radial --
+// a slope distribution that is a product of two different 1D laws
+class separable : public djb::microfacet {
+public:
+	separable() : djb::microfacet() {}
+	bool supports_smith_vndf_sampling() const { return false; }
+protected:
+	float sigma_std(const djb::vec3 &k) const
+	{ return (float)(0.5 * ((double)k.z + std::sqrt((double)(k.z * k.z) + 0.5 * (double)(k.x * k.x) + 0.25 * (double)(k.y * k.y)))); }
+	float p22_std(float x, float y) const
+	{
+		const float gx = (float)(std::exp(-(double)(x * x)) / std::sqrt(M_PI));         // Gaussian in x
+		const double ty = 1.0 + (double)(y * y);
+		const float cy = (float)(1.0 / (2.0 * ty * std::sqrt(ty)));                     // 1 / (2 (1 + y^2)^(3/2)) in y
+		return gx * cy;
+	}
+	void sample_vp22_std_nmap(float u1, float u2, const djb::vec3 &k, float *xslope, float *yslope) const
+	{
+		(void)k;
+		const double a = 2.0 * (double)u1 - 1.0;                       // a crude but deterministic sampler: what matters here is that it is called
+		*xslope = (float)(a * std::sqrt(-std::log(1.0 - std::fabs(a) * 0.999)));
+		const double b = 2.0 * (double)u2 - 1.0;
+		*yslope = (float)(b / std::sqrt(1.0 - b * b * 0.999));
+	}
+};
+
 void show(const char *tag, const djb::vec3 &v) { printf("%s %a %a %a\n", tag, v.x, v.y, v.z); }
 void show_table(const char *tag, const std::vector<djb::float_t> &v)
 {
@@ -171,6 +214,46 @@ int main()
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
 		printf("ggx(lazanyi) res 64: beckmann %.3f ggx %.3f  (%a %a)\n", ab, ag, ab, ag);
 		show("  fresnel(0.1)", tab.fresnel(0.1f)); show("  fresnel(0.9)", tab.fresnel(0.9f));
+	}
+
+	// ---- 5. user-defined NDFs: a class derived from djb::radial, one derived from djb::microfacet
+	{
+		student st;
+		lazanyi f(djb::vec3(0.9f, 0.7f, 0.5f), 0.5f);
+		student st_f(f, false);
+		separable sp;
+		const djb::microfacet::params pr = djb::microfacet::params::elliptic(0.35f, 0.2f, 1.1f);
+		const djb::microfacet::params pp = djb::microfacet::params::pdfparams(0.4f, 0.25f, 0.3f, 0.1f, -0.05f);
+		const djb::vec3 i(0.5f, 0.2f), o(0.7f, 2.9f), h = djb::normalize(i + o);
+		const djb::microfacet *objs[3] = { &st, &st_f, &sp };
+		const char *names[3] = { "student", "student+lazanyi", "separable" };
+		for (int w = 0; w < 3; ++w) {
+			const djb::microfacet &m = *objs[w];
+			printf("%s\n", names[w]);
+			show("  eval", m.eval(i, o)); show("  eval(pr)", m.eval(i, o, &pr)); show("  evalp(pp)", m.evalp(i, o, &pp));
+			printf("  pdf %a %a\n", m.pdf(i, o), m.pdf(i, o, &pr));
+			show("  sample", m.sample(0.31f, 0.77f, o, &pr));
+			djb::vec3 wi; float pdf = 0;
+			show("  evalp_is", m.evalp_is(0.62f, 0.18f, o, &wi, &pdf, &pp)); show("    i", wi); printf("    pdf %a\n", pdf);
+			printf("  ndf %a gaf %a g1 %a sigma %a p22 %a vp22 %a vndf %a\n", m.ndf(h, pr), m.gaf(h, i, o, pr), m.g1(h, o, pp), m.sigma(o, pr),
+			       m.p22(0.3f, -0.2f, pp), m.vp22(0.3f, -0.2f, o, pr), m.vndf(h, o));
+			show("  fresnel(0.4)", m.fresnel(0.4f));
+			djb::vec3 hh, dd;
+			djb::brdf::io_to_hd(i, o, &hh, &dd);
+			show("  evalp_hd", m.evalp_hd(hh, dd, &pr));
+		}
+		printf("student radial queries %a %a %a %a\n", st.p22_radial(0.7f), st.sigma_std_radial(0.6f), st.cdf_radial(0.9f), st.qf_radial(0.35f));
+		// fit them: the sources' eval runs the user's NDF on the host, the fit itself where the library likes
+		djb::tabular t1(st, 48);
+		float ab, ag;
+		djb::tabular::fit_beckmann_parameters(t1).get_ellipse(&ab, NULL);
+		djb::tabular::fit_ggx_parameters(t1).get_ellipse(&ag, NULL);
+		printf("tabular(student, 48): %a %a\n", ab, ag);
+		show_table("  p22", t1.get_p22v());
+		djb::tabular_anisotropic t2(sp, 10, 12);
+		float v[5];
+		djb::tabular_anisotropic::fit_ggx_parameters(t2).get_pdfparams(&v[0], &v[1], &v[2], &v[3], &v[4]);
+		printf("tabular_anisotropic(separable, 10, 12) ggx %a %a %a %a %a\n", v[0], v[1], v[2], v[3], v[4]);
 	}
 	return 0;
 }

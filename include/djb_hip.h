@@ -48,8 +48,9 @@ extern "C" {
  *        before: lrep(base) * scale + lean.  Callers built against 100 must be recompiled.
  *   210  round 5: + djb_fit_query_dirs, djb_fit_aniso_query_dirs, djb_brdf_create_tabular_from_samples,
  *        djb_brdf_create_tabular_anisotropic_from_samples (fits of user-defined sources), djb_set_file_map_observer,
- *        DJB_FRESNEL_HOST.  No existing entry changed.                                                                  */
-#define DJB_HIP_VERSION 210
+ *        DJB_FRESNEL_HOST.  No existing entry changed.
+ *   220  round 5: + djb_brdf_create_user_microfacet / djb_user_ndf (user-defined NDFs on the host path), DJB_KIND_USER.      */
+#define DJB_HIP_VERSION 220
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
 typedef enum {
@@ -122,7 +123,7 @@ typedef struct {
 
 enum { DJB_KIND_BECKMANN = 0, DJB_KIND_GGX = 1, DJB_KIND_TABULAR = 2, DJB_KIND_MERL = 3,
        DJB_KIND_UTIA = 4, DJB_KIND_LAMBERT = 5, DJB_KIND_SGD = 6, DJB_KIND_ABC = 7,
-       DJB_KIND_TABULAR_ANISO = 8 };
+       DJB_KIND_TABULAR_ANISO = 8, DJB_KIND_USER = 9 };
 
 /* ---------------------------------------------------------------- library / context */
 const char *djb_last_error(void);
@@ -232,6 +233,30 @@ djb_status djb_brdf_create_tabular(djb_ctx *, const djb_brdf *src, int res, int 
  * 90 x 90 in the reference) is recomputed on the fly, never stored.           dj_brdf.h:441-444 */
 djb_status djb_brdf_create_tabular_anisotropic(djb_ctx *, const djb_brdf *src, int elevation_res,
                                                int azimuthal_res, int shadow, djb_brdf **);
+/* ---- USER-DEFINED microfacet NDFs.  The reference's third extension point: a class derived from djb::radial overrides its public
+ * virtuals p22_radial / sigma_std_radial / cdf_radial / qf_radial (+ qf2_radial / qf3_radial for Smith VNDF sampling,
+ * dj_brdf.h:307-314), one derived from djb::microfacet the protected p22_std / sigma_std / sample_vp22_std_* (dj_brdf.h:283-295);
+ * everything else -- params, the stretch of sigma, G1 / G2, eval / evalp / pdf / sample / evalp_is, the queries -- is base-class code.
+ * Here the base-class code is the library's per-unit code on its HOST path and the user's functions are callbacks: the object lives
+ * on a CPU context (a GPU cannot call host code; batches are spread over the context's threads), fits of it run wherever the
+ * caller likes through the *_from_samples constructors above.  p22_radial != NULL makes it a radial NDF (required then:
+ * sigma_std_radial, qf_radial; qf2_radial / qf3_radial when supports_smith_vndf_sampling returns non-zero); otherwise p22_std,
+ * sigma_std and sample_vp22_std (= the virtual sample_vp22_std_smith, whose default forwards to _nmap) are required.       */
+typedef struct {
+	void  *user;
+	int   (*supports_smith_vndf_sampling)(void *user);
+	float (*p22_radial)(void *user, float r_sqr);
+	float (*sigma_std_radial)(void *user, float cos_theta_k);
+	float (*cdf_radial)(void *user, float r);
+	float (*qf_radial)(void *user, float u);
+	float (*qf2_radial)(void *user, float u, float cos_theta_k, float sin_theta_k);
+	float (*qf3_radial)(void *user, float u, float qf2);
+	float (*p22_std)(void *user, float x, float y);
+	float (*sigma_std)(void *user, const float k[3]);
+	void  (*sample_vp22_std)(void *user, float u1, float u2, const float k[3], float *xslope, float *yslope);
+} djb_user_ndf;
+djb_status djb_brdf_create_user_microfacet(djb_ctx *cpu_ctx, const djb_user_ndf *ndf, const djb_fresnel_desc *, int shadow,
+                                           djb_brdf **);
 /* ---- fits of USER-DEFINED sources.  The reference's extension point is `class brdf` with `eval` as its one pure virtual
  * (dj_brdf.h:74-109); tabular's and tabular_anisotropic's constructors only ever call brdf.eval, at directions fixed by
  * the resolution: the res-1 back-scatter pairs eval(w, w) of compute_p22_smith (dj_brdf.h:2482-2522; (elev-1)*azim of

@@ -164,6 +164,8 @@ public:
 		return DJB_DEVICE_CPU;
 	}
 	static context &standard() { static context c(standard_device()); return c; }
+	// the process-wide HOST-path context: where objects whose NDF is user code live (a GPU cannot call host code)
+	static context &host() { static context c(DJB_DEVICE_CPU); return c; }
 	static int device_count() { int n = 0; return djb_device_count(&n) == DJB_OK ? n : 0; }
 private:
 	context(const context &);
@@ -298,12 +300,15 @@ public:
 	const djb_brdf *handle() const { return m_h; }
 	// true: every operator of this object is answered by the library from the handle (kernels / host twin);
 	// false: host code is involved (a user-derived class, a user-defined fresnel::impl) and fits sample eval() on the host
-	bool resident() const { return m_h != NULL && !m_host_eval; }
+	bool resident() const { return m_h != NULL && !m_host_eval && !m_host_only; }
+	// the context a fit of this object should run on: its own, unless it lives on the host path because its NDF is user code --
+	// then its eval() is sampled there and the fit itself runs on the default context (the GPU, where there is one)
+	hip::context &fit_context() const { return m_host_only ? hip::context::standard() : get_context(); }
 	hip::context &get_context() const { return m_ctx ? *m_ctx : hip::context::standard(); }
-	brdf() : m_h(NULL), m_ctx(NULL), m_host_eval(true) {}                                                // dj_brdf.h:102
+	brdf() : m_h(NULL), m_ctx(NULL), m_host_eval(true), m_host_only(false) {}                            // dj_brdf.h:102
 	virtual ~brdf() { djb_brdf_destroy(m_h); }
 protected:
-	explicit brdf(hip::context *c) : m_h(NULL), m_ctx(c ? c : &hip::context::standard()), m_host_eval(false) {}
+	explicit brdf(hip::context *c) : m_h(NULL), m_ctx(c ? c : &hip::context::standard()), m_host_eval(false), m_host_only(false) {}
 	djb_ctx *ctx() const { return get_context().get(); }
 	virtual const djb_params *params_of(const void *) const { return NULL; }   // ignored by merl/utia/...
 	// eval of a resident object: what the library's classes override `eval` with
@@ -339,7 +344,8 @@ protected:
 	{ if (!resident()) throw exc(std::string("djb_error: ") + what + " needs a BRDF resident on the GPU (this object is evaluated by host code)", DJB_ERR_INVALID_ARGUMENT); }
 	djb_brdf *m_h;
 	hip::context *m_ctx;
-	bool m_host_eval;
+	bool m_host_eval;        // eval involves host code beyond the handle (a user-derived brdf; a user-defined Fresnel term)
+	bool m_host_only;        // the handle itself lives on the host path (a user-defined NDF: callbacks)
 private:
 	// the base-class sample / pdf (dj_brdf.h:830-845) are what djb::lambert inherits unchanged: a user-derived object
 	// borrows them from a Lambertian on the default context
@@ -590,8 +596,9 @@ public:
 		djb_params_resolved m_r;
 	};
 
-	// false for the two tabulated classes, which sample with the "nmap" scheme (dj_brdf.h:412, 439)
-	bool supports_smith_vndf_sampling() const
+	// false for the two tabulated classes, which sample with the "nmap" scheme (dj_brdf.h:412, 439); a user-defined NDF class
+	// overrides it (pure virtual in the reference, dj_brdf.h:274)
+	virtual bool supports_smith_vndf_sampling() const
 	{
 		const int k = djb_brdf_kind(m_h);
 		return k != DJB_KIND_TABULAR && k != DJB_KIND_TABULAR_ANISO;
@@ -631,7 +638,7 @@ public:
 	using brdf::eval; using brdf::evalp; using brdf::evalp_is;
 	vec3 evalp(const vec3 &i, const vec3 &o, const void *user_param = NULL) const                    // dj_brdf.h:1524-1546
 	{
-		if (!m_host_eval) return brdf::evalp(i, o, user_param);
+		if (!m_host_eval) return handle_evalp(i, o, user_param);
 		const params p = user_param ? *reinterpret_cast<const params *>(user_param) : params::standard();
 		vec3 h = normalize(i + o);
 		if (gaf(h, i, o, p) > (float_t)0.0) {
@@ -645,7 +652,13 @@ public:
 	{ return m_host_eval ? evalp(i, o, user_param) / i.z : eval_resident(i, o, user_param); }
 	vec3 evalp_is(float_t u1, float_t u2, const vec3 &o, vec3 *i, float_t *pdf, const void *user_param = NULL) const   // dj_brdf.h:1731-1765
 	{
-		if (!m_host_eval) return brdf::evalp_is(u1, u2, o, i, pdf, user_param);
+		if (!m_host_eval) {
+			vec3 i0; float_t pdf0 = 0;
+			const vec3 w0 = handle_evalp_is(u1, u2, o, &i0, &pdf0, user_param);
+			if (i) *i = i0;
+			if (pdf) *pdf = pdf0;
+			return w0;
+		}
 		const params p = user_param ? *reinterpret_cast<const params *>(user_param) : params::standard();
 		vec3 i_; float_t pdf_ = 0;
 		vec3 w = handle_evalp_is(u1, u2, o, &i_, &pdf_, user_param);    // G / G1 (Smith VNDF kinds), the direction, its pdf
@@ -667,6 +680,11 @@ protected:
 	void host_eval_batch(bool cosine, size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param) const
 	{
 		if (!n) return;
+		if (!m_host_eval) {      // a user-defined NDF with one of the library's Fresnel terms: the handle answers the whole batch
+			djb_vec3_view vi0 = hip::view(i), vo0 = hip::view(o), vr0 = hip::view(out);
+			hip::check((cosine ? djb_evalp_batch : djb_eval_batch)(ctx(), m_h, (int64_t)n, &vi0, &vo0, params_of(user_param), &vr0, DJB_MEM_HOST));
+			return;
+		}
 		std::vector<vec3> dg(n);
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(&dg[0]);
 		hip::check(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
@@ -683,9 +701,10 @@ protected:
 	                         float_t *out_pdf, const void *user_param) const
 	{
 		if (!n) return;
-		if (!supports_smith_vndf_sampling()) { brdf::host_evalp_is_batch(n, u1, u2, o, out_weight, out_i, out_pdf, user_param); return; }
+		if (m_host_eval && !supports_smith_vndf_sampling()) { brdf::host_evalp_is_batch(n, u1, u2, o, out_weight, out_i, out_pdf, user_param); return; }
 		djb_vec3_view vo = hip::view(o), vw = hip::view(out_weight), vi = hip::view(out_i);
 		hip::check(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi, out_pdf, DJB_MEM_HOST));
+		if (!m_host_eval) return;
 		for (size_t k = 0; k < n; ++k) {
 			const float_t s = out_weight[k].x;                     // G / G1 under fresnel::ideal
 			if (s == s && s != (float_t)0) {
@@ -695,6 +714,39 @@ protected:
 		}
 	}
 	microfacet(hip::context *c, const fresnel::impl &f) : brdf(c), m_fresnel(f.copy()) {}
+	/* ---- a USER-DEFINED NDF (the reference's protected constructor and pure virtuals, dj_brdf.h:283-295): a class derived from
+	 * microfacet implements sigma_std, p22_std, sample_vp22_std_nmap and supports_smith_vndf_sampling (and may override
+	 * sample_vp22_std_smith, qf2, qf3).  The object is a handle on the library's HOST path (hip::context::host()) whose NDF calls
+	 * back into these virtuals; params, sigma's stretch, G1 / G2, eval / evalp / pdf / sample / evalp_is and the queries are the
+	 * library's own per-unit code, the same the kernels run. */
+	microfacet(const fresnel::impl &f = fresnel::ideal(), bool shadow = true) : brdf(&hip::context::host()), m_fresnel(f.copy())
+	{ m_host_only = true; create_user_handle(false, shadow); }
+	virtual float_t sigma_std(const vec3 &) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
+	virtual float_t p22_std(float_t, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
+	virtual void sample_vp22_std_smith(float_t u1, float_t u2, const vec3 &k, float_t *xslope, float_t *yslope) const   // dj_brdf.h:1769-1781
+	{
+		if (supports_smith_vndf_sampling()) { *xslope = qf2(u1, k); *yslope = qf3(u2, k, *xslope); }
+		else sample_vp22_std_nmap(u1, u2, k, xslope, yslope);
+	}
+	virtual void sample_vp22_std_nmap(float_t, float_t, const vec3 &, float_t *, float_t *) const
+	{ throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
+	struct user_tag {};
+	microfacet(user_tag, const fresnel::impl &f) : brdf(&hip::context::host()), m_fresnel(f.copy()) { m_host_only = true; }   // radial's user constructor
+	// the callbacks only forward to the virtuals above.  They are called from the library's host path -- for batches from several of
+	// its worker threads at once (the operators are const, as in the reference) -- and must not throw
+	static int cb_smith(void *u) { return static_cast<const microfacet *>(u)->supports_smith_vndf_sampling() ? 1 : 0; }
+	static float cb_p22_std(void *u, float x, float y) { return static_cast<const microfacet *>(u)->p22_std(x, y); }
+	static float cb_sigma_std(void *u, const float *k) { return static_cast<const microfacet *>(u)->sigma_std(vec3(k[0], k[1], k[2])); }
+	static void cb_sample_std(void *u, float u1, float u2, const float *k, float *x, float *y)
+	{ static_cast<const microfacet *>(u)->sample_vp22_std_smith(u1, u2, vec3(k[0], k[1], k[2]), x, y); }
+	void create_user_handle(bool, bool shadow)
+	{
+		djb_user_ndf n = djb_user_ndf();
+		n.user = const_cast<microfacet *>(this);
+		n.supports_smith_vndf_sampling = cb_smith; n.p22_std = cb_p22_std; n.sigma_std = cb_sigma_std; n.sample_vp22_std = cb_sample_std;
+		djb_fresnel_desc d = resident_desc(*m_fresnel, &m_host_eval);
+		hip::check(djb_brdf_create_user_microfacet(ctx(), &n, &d, shadow ? 1 : 0, &m_h));
+	}
 	// the term the handle is created with: the library's own, or ideal under a user-defined one (*host = true)
 	static djb_fresnel_desc resident_desc(const fresnel::impl &f, bool *host)
 	{
@@ -722,20 +774,49 @@ protected:
 	const fresnel::impl *m_fresnel;
 };
 
-/* Radial microfacets, dj_brdf.h:301-324 */
+/* Radial microfacets, dj_brdf.h:301-324.  The six queries are the reference's public virtuals: the library's lobes answer them
+ * from the handle; a class a USER derives from radial (public constructor, as in the reference) overrides p22_radial,
+ * sigma_std_radial, cdf_radial, qf_radial (+ qf2_radial / qf3_radial for Smith VNDF sampling) and supports_smith_vndf_sampling,
+ * and is evaluated on the library's host path with those as callbacks (see microfacet). */
 class radial : public microfacet {
 public:
-	float_t p22_radial(float_t r_sqr) const { return rq(DJB_Q_P22_RADIAL, r_sqr); }
-	float_t sigma_std_radial(float_t cos_theta_k) const { return rq(DJB_Q_SIGMA_STD_RADIAL, cos_theta_k); }
-	float_t cdf_radial(float_t r) const { return rq(DJB_Q_CDF_RADIAL, r); }
-	float_t qf_radial(float_t u) const { return rq(DJB_Q_QF_RADIAL, u); }     // (tabular::qf_radial asserts 0 < u < 1, dj_brdf.h:2173: see tabular)
-	float_t qf2_radial(float_t u, float_t cos_theta_k, float_t sin_theta_k) const { return rq(DJB_Q_QF2_RADIAL, u, cos_theta_k, sin_theta_k); }
-	float_t qf3_radial(float_t u, float_t qf2) const { return rq(DJB_Q_QF3_RADIAL, u, qf2); }
+	radial(const fresnel::impl &f = fresnel::ideal(), bool shadow = true) : microfacet(user_tag(), f)
+	{
+		djb_user_ndf n = djb_user_ndf();
+		n.user = this;
+		n.supports_smith_vndf_sampling = cb_smith_r; n.p22_radial = cb_p22_radial; n.sigma_std_radial = cb_sigma_std_radial;
+		n.cdf_radial = cb_cdf_radial; n.qf_radial = cb_qf_radial; n.qf2_radial = cb_qf2_radial; n.qf3_radial = cb_qf3_radial;
+		djb_fresnel_desc d = resident_desc(*m_fresnel, &m_host_eval);
+		hip::check(djb_brdf_create_user_microfacet(ctx(), &n, &d, shadow ? 1 : 0, &m_h));
+	}
+	virtual float_t p22_radial(float_t r_sqr) const = 0;
+	virtual float_t sigma_std_radial(float_t cos_theta_k) const = 0;
+	virtual float_t cdf_radial(float_t r) const = 0;
+	virtual float_t qf_radial(float_t u) const = 0;
+	virtual float_t qf2_radial(float_t, float_t, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }   // dj_brdf.h:1848-1855
+	virtual float_t qf3_radial(float_t, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }             // dj_brdf.h:1857-1860
 protected:
 	radial(hip::context *c, const fresnel::impl &f) : microfacet(c, f) {}
 	float_t rq(int which, float_t a, float_t b = 0, float_t c = 0) const
 	{ vec3 v(a, b, c); return q(which, &v, NULL, NULL, params::standard()); }
+private:
+	static int cb_smith_r(void *u) { return static_cast<const radial *>(u)->supports_smith_vndf_sampling() ? 1 : 0; }
+	static float cb_p22_radial(void *u, float r) { return static_cast<const radial *>(u)->p22_radial(r); }
+	static float cb_sigma_std_radial(void *u, float c) { return static_cast<const radial *>(u)->sigma_std_radial(c); }
+	static float cb_cdf_radial(void *u, float r) { return static_cast<const radial *>(u)->cdf_radial(r); }
+	static float cb_qf_radial(void *u, float x) { return static_cast<const radial *>(u)->qf_radial(x); }
+	static float cb_qf2_radial(void *u, float x, float c, float sn) { return static_cast<const radial *>(u)->qf2_radial(x, c, sn); }
+	static float cb_qf3_radial(void *u, float x, float q2) { return static_cast<const radial *>(u)->qf3_radial(x, q2); }
 };
+/* what the library's radial lobes declare: the radial queries answered from the handle */
+#define DJB_HIP_RESIDENT_RADIAL \
+	float_t p22_radial(float_t r_sqr) const { return rq(DJB_Q_P22_RADIAL, r_sqr); } \
+	float_t sigma_std_radial(float_t cos_theta_k) const { return rq(DJB_Q_SIGMA_STD_RADIAL, cos_theta_k); } \
+	float_t cdf_radial(float_t r) const { return rq(DJB_Q_CDF_RADIAL, r); } \
+	float_t qf_radial(float_t u) const { return rq(DJB_Q_QF_RADIAL, u); }
+#define DJB_HIP_RESIDENT_RADIAL_SMITH \
+	float_t qf2_radial(float_t u, float_t cos_theta_k, float_t sin_theta_k) const { return rq(DJB_Q_QF2_RADIAL, u, cos_theta_k, sin_theta_k); } \
+	float_t qf3_radial(float_t u, float_t qf2) const { return rq(DJB_Q_QF3_RADIAL, u, qf2); }
 
 /* Beckmann Microfacet NDF, dj_brdf.h:327-371 */
 class beckmann : public radial {
@@ -788,6 +869,8 @@ public:
 	}
 	beckmann(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)
 	{ djb_fresnel_desc d = resident_desc(f, &m_host_eval); hip::check(djb_brdf_create_beckmann(ctx(), &d, shadow, &m_h)); }
+	DJB_HIP_RESIDENT_RADIAL
+	DJB_HIP_RESIDENT_RADIAL_SMITH
 	float_t qf1(float_t u) const { return rq(DJB_Q_QF1, u); }
 };
 
@@ -796,13 +879,15 @@ class ggx : public radial {
 public:
 	ggx(const fresnel::impl &f = fresnel::ideal(), bool shadow = true, hip::context *c = NULL) : radial(c, f)
 	{ djb_fresnel_desc d = resident_desc(f, &m_host_eval); hip::check(djb_brdf_create_ggx(ctx(), &d, shadow, &m_h)); }
+	DJB_HIP_RESIDENT_RADIAL
+	DJB_HIP_RESIDENT_RADIAL_SMITH
 	float_t qf1(float_t u) const { return rq(DJB_Q_QF1, u); }
 };
 
 /* Tabulated Microfacet NDF -- the power-iteration fit, dj_brdf.h:394-425 */
 class tabular : public radial {
 public:
-	tabular(const brdf &src, int resolution, bool shadow = true) : radial(&src.get_context(), fresnel::ideal())
+	tabular(const brdf &src, int resolution, bool shadow = true) : radial(&src.fit_context(), fresnel::ideal())
 	{
 		DJB_USER_ASSERT(resolution > 2 && "Invalid Resolution");                                                // dj_brdf.h:2218
 		if (src.resident()) hip::check(djb_brdf_create_tabular(ctx(), src.handle(), resolution, shadow, &m_h));
@@ -833,6 +918,7 @@ public:
 	{ float_t a = 0; hip::check(djb_tabular_fit(t.m_h, &a, NULL)); return microfacet::params::isotropic(a); }
 	static microfacet::params fit_ggx_parameters(const tabular &t)
 	{ float_t a = 0; hip::check(djb_tabular_fit(t.m_h, NULL, &a)); return microfacet::params::isotropic(a); }
+	DJB_HIP_RESIDENT_RADIAL
 	const std::vector<float_t> &get_p22v() const { return m_p22; }
 	const std::vector<float_t> &get_sigmav() const { return m_sigma; }
 	const std::vector<float_t> &get_cdfv() const { return m_cdf; }
@@ -853,7 +939,7 @@ private:
 class tabular_anisotropic : public microfacet {
 public:
 	tabular_anisotropic(const brdf &src, int elevation_res, int azimuthal_res, bool shadow = true)
-		: microfacet(&src.get_context(), fresnel::ideal()), m_elev(elevation_res), m_azim(azimuthal_res)
+		: microfacet(&src.fit_context(), fresnel::ideal()), m_elev(elevation_res), m_azim(azimuthal_res)
 	{
 		DJB_USER_ASSERT(elevation_res > 1 && azimuthal_res > 1 && "Invalid Resolution");                       // dj_brdf.h:2244
 		if (src.resident()) hip::check(djb_brdf_create_tabular_anisotropic(ctx(), src.handle(), elevation_res, azimuthal_res, shadow, &m_h));

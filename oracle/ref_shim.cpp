@@ -108,6 +108,41 @@ private:
 	float m_a;
 };
 
+// user-defined NDFs (hdr:301-324: the public virtuals of class radial; hdr:283-295: the protected virtuals of class microfacet) --
+// the classes of examples/custom_brdf.cpp.  No oracle restatement: what the real reference computes with them is stored in
+// tests/golden/custom.npz and the facade (the same classes compiled against include/dj_brdf.h) is held against that.
+class user_student : public djb::radial {
+public:
+	user_student(const djb::fresnel::impl &f, bool shadow) : djb::radial(f, shadow) {}
+	bool supports_smith_vndf_sampling() const { return false; }
+	float p22_radial(float r_sqr) const { const double t = 1.0 + (double)r_sqr; return (float)(2.0 / (M_PI * t * t * t)); }
+	float sigma_std_radial(float c) const { return (float)((1.0 + (double)(c * (1.0f + c)) * 0.5) * 0.5); }
+	float cdf_radial(float r) const { const double t = 1.0 + (double)(r * r); return (float)(1.0 - 1.0 / (t * t)); }
+	float qf_radial(float u) const { return (float)std::sqrt(1.0 / std::sqrt(1.0 - (double)u) - 1.0); }
+};
+class user_separable : public djb::microfacet {
+public:
+	user_separable(const djb::fresnel::impl &f, bool shadow) : djb::microfacet(f, shadow) {}
+	bool supports_smith_vndf_sampling() const { return false; }
+protected:
+	float sigma_std(const djb::vec3 &k) const
+	{ return (float)(0.5 * ((double)k.z + std::sqrt((double)(k.z * k.z) + 0.5 * (double)(k.x * k.x) + 0.25 * (double)(k.y * k.y)))); }
+	float p22_std(float x, float y) const
+	{
+		const float gx = (float)(std::exp(-(double)(x * x)) / std::sqrt(M_PI));
+		const double ty = 1.0 + (double)(y * y);
+		const float cy = (float)(1.0 / (2.0 * ty * std::sqrt(ty)));
+		return gx * cy;
+	}
+	void sample_vp22_std_nmap(float u1, float u2, const djb::vec3 &k, float *xslope, float *yslope) const
+	{
+		const double a = 2.0 * (double)u1 - 1.0;
+		*xslope = (float)(a * std::sqrt(-std::log(1.0 - std::fabs(a) * 0.999)));
+		const double b = 2.0 * (double)u2 - 1.0;
+		*yslope = (float)(b / std::sqrt(1.0 - b * b * 0.999));
+	}
+};
+
 djb::fresnel::impl *make_fresnel(int kind, const float *d, int n)
 {
 	switch (kind) {
@@ -138,6 +173,8 @@ void *ref_create_microfacet(int ndf, int fkind, const float *fdata, int nf, int 
 {
 	djb::fresnel::impl *f = make_fresnel(fkind, fdata, nf);
 	djb::brdf *b = ndf == 0 ? (djb::brdf *)new djb::beckmann(*f, shadow != 0)
+	             : ndf == 2 ? (djb::brdf *)new user_student(*f, shadow != 0)          // user-defined NDFs
+	             : ndf == 3 ? (djb::brdf *)new user_separable(*f, shadow != 0)
 	                        : (djb::brdf *)new djb::ggx(*f, shadow != 0);
 	delete f;
 	return b;

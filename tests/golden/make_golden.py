@@ -192,6 +192,30 @@ def main():
         t = R.tabular(R.microfacet(ndf, CUSTOM_FRESNEL, True), CUSTOM_FRESNEL_FIT, True)
         for k, v in R.tabular_tables(t).items():
             out[f"{ndf}_fit_{k}"] = np.atleast_1d(v)
+    # user-defined NDFs: classes derived from djb::radial / djb::microfacet, with a library Fresnel term and with the user's
+    from golden_cases import CUSTOM_NDFS, CUSTOM_NDF_PARAMS, CUSTOM_NDF_QUERIES
+    M = 128      # the first M pairs: every element is one scalar call of a user virtual on the other side
+    i, o, u1, u2, h, d = i[:M], o[:M], u1[:M], u2[:M], h[:M], d[:M]
+    for ndf in CUSTOM_NDFS:
+        for fk, fres in (("ideal", ("ideal",)), ("schlick", ("schlick", 0.9, 0.5, 0.1)), ("user", CUSTOM_FRESNEL)):
+            for shadow in (True, False):
+                b = R.microfacet(ndf, fres, shadow)
+                for pk, par in enumerate(CUSTOM_NDF_PARAMS):
+                    tag = f"{ndf}_{fk}{int(shadow)}_p{pk}"
+                    for op in ("eval", "evalp", "pdf"):
+                        out[f"{tag}_{op}"] = R.eval(b, i, o, par, op)
+                    out[f"{tag}_evalp_hd"] = R.eval(b, h, d, par, "evalp_hd")
+                    out[f"{tag}_sample"] = R.sample(b, u1, u2, o, par)
+                    out[f"{tag}_is_w"], out[f"{tag}_is_i"], out[f"{tag}_is_pdf"] = R.evalp_is(b, u1, u2, o, par)
+                    if fk == "ideal" and shadow:
+                        args = {"h": i, "i": i, "o": o}
+                        for q, sig in CUSTOM_NDF_QUERIES:
+                            out[f"{tag}_{q}"] = R.microfacet_query(b, q, *[args[c] for c in sig], params=par)
+        b = R.microfacet(ndf, ("ideal",), True)
+        for k, v in R.tabular_tables(R.tabular(b, 40, True)).items():
+            out[f"{ndf}_fit_{k}"] = np.atleast_1d(v)
+        for k, v in R.aniso_tables(R.tabular_anisotropic(b, *CUSTOM_ANISO)).items():
+            out[f"{ndf}_aniso_{k}"] = v
     save("custom.npz", **out)
 
     # ---- MERL lookup (hash-filled table: exact on any machine)

@@ -165,3 +165,7 @@ CUSTOM_FITS = [(90, True), (17, False)]          # tabular(lobe, res, shadow)
 CUSTOM_ANISO = (9, 16)                           # tabular_anisotropic(lobe, elev, azim)
 CUSTOM_PARAMS = ("elliptic", 0.3, 0.1, 0.4)      # user_param of the microfacet BRDFs that hold the user's Fresnel term
 CUSTOM_FRESNEL_FIT = 40                          # tabular(ggx(user fresnel), res)
+# user-defined NDFs (classes derived from djb::radial / djb::microfacet: ref_shim.cpp user_student, user_separable)
+CUSTOM_NDFS = ["student", "separable"]
+CUSTOM_NDF_PARAMS = [None, ("elliptic", 0.35, 0.2, 1.1), ("pdfparams", 0.4, 0.25, 0.3, 0.1, -0.05)]
+CUSTOM_NDF_QUERIES = [("ndf", "h"), ("gaf", "hio"), ("g1", "ho"), ("sigma", "o"), ("vndf", "ho")]

@@ -79,7 +79,10 @@ class CheckerLib:
         kind = FRESNEL[fresnel[0]]
         data = _f32(np.array(fresnel[1:], dtype=np.float32).reshape(-1)) if len(fresnel) > 1 else _f32([0])
         nf = data.size // 3
-        h = self._fn("create_microfacet")(C.c_int(0 if ndf == "beckmann" else 1), C.c_int(kind),
+        # "student" / "separable": NDF classes DERIVED BY THE USER from djb::radial / djb::microfacet (ref_shim.cpp; no oracle restatement)
+        code = {"beckmann": 0, "ggx": 1, "student": 2, "separable": 3}[ndf]
+        assert code < 2 or self.prefix == "ref_", "user-defined NDFs exist in the reference / facade shims only"
+        h = self._fn("create_microfacet")(C.c_int(code), C.c_int(kind),
                                           _ptr(data), C.c_int(nf), C.c_int(int(shadow)))
         return C.c_void_p(h)
 

@@ -28,13 +28,15 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libdjb_hip.so does not export {s}"
     assert sorted(_lib.EXPORTS) == syms, "dj_brdf_amd/_lib.py EXPORTS out of sync with include/djb_hip.h"
-    assert lib.djb_version() == _lib.ABI_VERSION == 210      # include/djb_hip.h: the changelog of the ABI
+    assert lib.djb_version() == _lib.ABI_VERSION == 220      # include/djb_hip.h: the changelog of the ABI
 
 
 # SURVEY.md section 8-N, measured with the reference compiled here: ggx isotropic(0.3), i = (0.3, 0.2, .), o = (-0.4, 0.1, .)
 C_ABI_DEMO_KNOWN = ["eval 0.621380985 0.621380985 0.621380985", "pdf 0.581518769", "sample 0.657071352 0.080957301 0.749468625",
                     # a caller-defined BRDF (a C callback) fitted from samples at djb_fit_query_dirs == tabular(lambert) on the same context
-                    "user-defined fit: 728 of 1023 query slots evaluated, alpha_ggx 0.693 (tabular(lambert): 0.693), tables identical"]
+                    "user-defined fit: 728 of 1023 query slots evaluated, alpha_ggx 0.693 (tabular(lambert): 0.693), tables identical",
+                    # a caller-defined NDF (C callbacks restating GGX's radial functions) on the host path == the library's ggx
+                    "user-defined NDF (GGX restated as callbacks): eval 0.621380985, identical to the library's ggx"]
 
 
 def run_c_abi_demo(where):

@@ -170,6 +170,29 @@ def test_user_defined_brdf_is_fitted_from_host_samples(cpu, oracle, name):
         user_defined_cases.check_lambert_source(cpu, oracle)
 
 
+def test_facade_user_classes_on_the_host_path():
+    """The C++ facade's extension points without a GPU: oracle/ref_shim.cpp compiled against include/dj_brdf.h (oracle/_facade, the
+    conformance harness of tests/test_gpu_facade_conformance.py) driven with DJB_DEVICE=cpu -- user-derived brdf / fresnel::impl
+    classes against the oracle and the reference's golden, user-derived radial / microfacet NDF classes against the golden."""
+    import sys
+    shim = os.path.join(ROOT, "oracle", "_facade", "libdjb_facade_shim.so")
+    if not os.path.exists(shim):
+        pytest.skip("oracle/_facade/libdjb_facade_shim.so not built (make -C oracle facade)")
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oraclelib, test_gpu_facade_conformance as T\n"
+        "from dj_brdf_amd import synth\n"
+        "lib = oraclelib.CheckerLib(T.SHIM, 'ref_')\n"
+        "inputs = (synth.directions_aos(T.N, synth.SEED_I, start=777), synth.directions_aos(T.N, synth.SEED_O, start=777),\n"
+        "          synth.uniforms(T.N, synth.SEED_U1, start=777), synth.uniforms(T.N, synth.SEED_U2, start=777))\n"
+        "T.test_user_defined_classes.__wrapped__(lib, oraclelib.oracle(), inputs) if hasattr(T.test_user_defined_classes, '__wrapped__') "
+        "else T.test_user_defined_classes(lib, oraclelib.oracle(), inputs)\n"
+        "T.test_user_defined_ndf_classes(lib)\n"
+        "print('ok')\n" % (os.path.join(ROOT, "tests"), ROOT))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, DJB_DEVICE="cpu", DJB_QUIET="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_params_txt_on_the_cpu(cpu, tmp_path):
     """BASELINE configs[0]: the merl_params driver on a machine without a GPU -- byte-identical params.txt"""
     files = []

@@ -128,6 +128,42 @@ def test_user_defined_classes(facade, oracle, inputs):
         facade.destroy(f)
 
 
+def test_user_defined_ndf_classes(facade):
+    """NDF classes DERIVED BY THE USER from djb::radial (public virtuals p22_radial / sigma_std_radial / cdf_radial / qf_radial,
+    dj_brdf.h:301-324) and from djb::microfacet (protected p22_std / sigma_std / sample_vp22_std_nmap, dj_brdf.h:283-295), compiled
+    against include/dj_brdf.h: the objects live on the library's host path with the user's functions as callbacks, everything around
+    the NDF is the library's per-unit code.  Against tests/golden/custom.npz = the REAL reference running the same classes
+    (ref_shim.cpp: user_student, user_separable), with a library Fresnel term and with the user's; fits of them run on the GPU."""
+    from golden_cases import CUSTOM_ANISO, CUSTOM_FRESNEL, CUSTOM_NDFS, CUSTOM_NDF_PARAMS, CUSTOM_NDF_QUERIES
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "custom.npz"))
+    M = 128
+    i, o, u1, u2, h, d = (g[k][:M] for k in ("i", "o", "u1", "u2", "h", "d"))
+    for ndf in CUSTOM_NDFS:
+        for fk, fres in (("ideal", ("ideal",)), ("schlick", ("schlick", 0.9, 0.5, 0.1)), ("user", CUSTOM_FRESNEL)):
+            for shadow in (True, False):
+                f = facade.microfacet(ndf, fres, shadow)
+                for pk, par in enumerate(CUSTOM_NDF_PARAMS):
+                    tag = f"{ndf}_{fk}{int(shadow)}_p{pk}"
+                    for op in ("eval", "evalp", "pdf"):
+                        close(f"{tag}/{op}", facade.eval(f, i, o, par, op), g[f"{tag}_{op}"])
+                    close(f"{tag}/evalp_hd", facade.eval(f, h, d, par, "evalp_hd"), g[f"{tag}_evalp_hd"])
+                    close(f"{tag}/sample", facade.sample(f, u1, u2, o, par), g[f"{tag}_sample"])
+                    for t, x in zip(("is_w", "is_i", "is_pdf"), facade.evalp_is(f, u1, u2, o, par)):
+                        close(f"{tag}/{t}", x, g[f"{tag}_{t}"])
+                    if fk == "ideal" and shadow:
+                        args = {"h": i, "i": i, "o": o}
+                        for q, sig in CUSTOM_NDF_QUERIES:
+                            close(f"{tag}/{q}", facade.microfacet_query(f, q, *[args[c] for c in sig], params=par), g[f"{tag}_{q}"])
+                facade.destroy(f)
+        f = facade.microfacet(ndf, ("ideal",), True)
+        for k, v in facade.tabular_tables(facade.tabular(f, 40, True)).items():
+            close(f"{ndf}/fit/{k}", np.atleast_1d(v), g[f"{ndf}_fit_{k}"])
+        for k, v in facade.aniso_tables(facade.tabular_anisotropic(f, *CUSTOM_ANISO)).items():
+            close(f"{ndf}/aniso/{k}", v, g[f"{ndf}_aniso_{k}"])
+        facade.destroy(f)
+
+
 def test_params_vec3_and_helpers(facade, oracle, inputs):
     i, o, _, _ = inputs
     for p in PARAM_CASES:

@@ -62,7 +62,7 @@ EXPORTS = [
     "djb_eval_pp_batch", "djb_eval_lean_batch", "djb_sample_pp_batch", "djb_sample_lean_batch", "djb_lrep_op", "djb_params_to_lrep", "djb_lrep_to_params",
     "djb_brdf_create_sgd", "djb_brdf_create_abc", "djb_brdf_create_sgd_from_params",
     "djb_brdf_create_abc_from_params",
-    "djb_brdf_destroy", "djb_brdf_kind", "djb_brdf_get_samples", "djb_brdf_get_shadow", "djb_brdf_set_shadow", "djb_brdf_set_fresnel", "djb_eval_batch", "djb_evalp_batch",
+    "djb_brdf_destroy", "djb_brdf_kind", "djb_brdf_get_samples", "djb_brdf_get_shadow", "djb_brdf_set_shadow", "djb_brdf_set_fresnel", "djb_brdf_get_fresnel", "djb_eval_batch", "djb_evalp_batch",
     "djb_pdf_batch", "djb_eval_pdf_batch", "djb_sample_batch", "djb_sample_rng_batch",
     "djb_evalp_is_batch", "djb_io_to_hd_batch", "djb_hd_to_io_batch", "djb_merl_index_batch", "djb_query_batch",
     "djb_params_resolve", "djb_tabular_get", "djb_tabular_fit", "djb_fit_merl_batch", "djb_fit_brdf_batch",

@@ -741,6 +741,19 @@ djb_status set_fresnel(djb_brdf *b_, const djb_fresnel_desc *f)
 	return st;
 }
 
+djb_status get_fresnel(const djb_brdf *b_, djb_fresnel_desc *out)
+{
+	const CpuBrdf *b = B(b_);
+	const int k = b->dev.kind;
+	if (!is_microfacet_kind(k) && k != KIND_SGD && k != KIND_ABC) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: this brdf has no Fresnel term");
+	const Fresnel &fr = b->dev.fr;
+	memset(out, 0, sizeof *out);
+	out->kind = fr.kind;
+	for (int c = 0; c < 3; ++c) { out->a[c] = fr.a[c]; out->b[c] = fr.b[c]; }
+	if (fr.kind == FR_SPLINE) { out->points = b->fresnel.data(); out->npoints = fr.npts; }
+	return DJB_OK;
+}
+
 djb_status get_samples(const djb_brdf *b_, double *out, int64_t capacity, int64_t *count)
 {
 	const CpuBrdf *b = B(b_);

@@ -69,6 +69,7 @@ int kind(const djb_brdf *);
 int get_shadow(const djb_brdf *);
 djb_status set_shadow(djb_brdf *, int shadow);
 djb_status set_fresnel(djb_brdf *, const djb_fresnel_desc *);
+djb_status get_fresnel(const djb_brdf *, djb_fresnel_desc *out);
 djb_status get_samples(const djb_brdf *, double *out, int64_t capacity, int64_t *count);
 djb_status tabular_get(const djb_brdf *, int which, float *out, int *count);
 djb_status tabular_fit(const djb_brdf *, float *alpha_beckmann, float *alpha_ggx);

@@ -700,6 +700,21 @@ try {
 }
 DJB_ABI_CATCH
 
+djb_status djb_brdf_get_fresnel(const djb_brdf *b, djb_fresnel_desc *out)
+try {
+	if (!b || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (is_cpu(b)) return djbcpu::get_fresnel(b, out);
+	const int k = b->dev.kind;
+	if (!is_microfacet_kind(k) && k != DJB_KIND_SGD && k != DJB_KIND_ABC) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: this brdf has no Fresnel term");
+	const djbdev::Fresnel &fr = b->dev.fr;
+	memset(out, 0, sizeof *out);
+	out->kind = fr.kind;
+	for (int c = 0; c < 3; ++c) { out->a[c] = fr.a[c]; out->b[c] = fr.b[c]; }
+	if (fr.kind == djbdev::FR_SPLINE) { out->points = b->fresnel.data(); out->npoints = fr.npts; }      // the host copy of the table
+	return DJB_OK;
+}
+DJB_ABI_CATCH
+
 djb_status djb_ctx_set_option(djb_ctx *ctx, int option, int value)
 try {
 	if (is_cpu(ctx)) return DJB_OK;           // the options select GPU code paths

@@ -49,7 +49,8 @@ extern "C" {
  *   210  round 5: + djb_fit_query_dirs, djb_fit_aniso_query_dirs, djb_brdf_create_tabular_from_samples,
  *        djb_brdf_create_tabular_anisotropic_from_samples (fits of user-defined sources), djb_set_file_map_observer,
  *        DJB_FRESNEL_HOST.  No existing entry changed.
- *   220  round 5: + djb_brdf_create_user_microfacet / djb_user_ndf (user-defined NDFs on the host path), DJB_KIND_USER.      */
+ *   220  round 5: + djb_brdf_create_user_microfacet / djb_user_ndf (user-defined NDFs on the host path), DJB_KIND_USER,
+ *        djb_brdf_get_fresnel.                                                                                           */
 #define DJB_HIP_VERSION 220
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
@@ -292,6 +293,10 @@ djb_status djb_brdf_set_shadow(djb_brdf *, int shadow);
 /* microfacet::set_fresnel(const fresnel::impl &) -- e.g. tab->set_fresnel(fresnel::ideal()) after a
  * fit (mitsuba/dj_brdf.cpp:214).  NULL = fresnel::ideal.               dj_brdf.h:279, 1521-1525 */
 djb_status djb_brdf_set_fresnel(djb_brdf *, const djb_fresnel_desc *fresnel);
+/* microfacet::get_fresnel / sgd::get_fresnel / abc::get_fresnel: the term the object evaluates (sgd: fresnel::sgd(f0, f1) of its
+ * table row, abc: fresnel::unpolarized(vec3(ior))); for a spline `points` stays valid as long as the object and its Fresnel term
+ * do.                                                                              dj_brdf.h:282, 510, 534, 3443, 3623 */
+djb_status djb_brdf_get_fresnel(const djb_brdf *, djb_fresnel_desc *out);
 
 /* ---------------------------------------------------------------- the operator surface */
 /* brdf::eval(i, o, user_param) -> vec3                                dj_brdf.h:77-78   */

@@ -516,12 +516,32 @@ namespace fresnel {
 			d.points = m_points.empty() ? NULL : &m_points[0].x; d.npoints = (int)m_points.size(); return d;
 		}
 	};
+	/* the library's term behind a handle as one of the classes above (sgd::get_fresnel, abc::get_fresnel) */
+	inline impl *from_handle(const djb_brdf *h)
+	{
+		djb_fresnel_desc d;
+		hip::check(djb_brdf_get_fresnel(h, &d));
+		switch (d.kind) {
+		case DJB_FRESNEL_UNPOLARIZED: return new unpolarized(vec3(d.a[0], d.a[1], d.a[2]));
+		case DJB_FRESNEL_SCHLICK: return new schlick(vec3(d.a[0], d.a[1], d.a[2]));
+		case DJB_FRESNEL_SGD: return new sgd(vec3(d.a[0], d.a[1], d.a[2]), vec3(d.b[0], d.b[1], d.b[2]));
+		case DJB_FRESNEL_SPLINE: {
+			std::vector<vec3> pts;
+			for (int k = 0; k < d.npoints; ++k) pts.push_back(vec3(d.points[3 * k], d.points[3 * k + 1], d.points[3 * k + 2]));
+			return new spline(pts);
+		}
+		default: return new ideal();
+		}
+	}
 } // namespace fresnel
 
 /* Shifted Gamma Distribution BRDF, dj_brdf.h:481-511 (published per-material parameters) */
 class sgd : public brdf {
 public:
-	explicit sgd(const char *name, hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_sgd(ctx(), name, &m_h)); }
+	explicit sgd(const char *name, hip::context *c = NULL) : brdf(c), m_fresnel(NULL)
+	{ hip::check(djb_brdf_create_sgd(ctx(), name, &m_h)); m_fresnel = fresnel::from_handle(m_h); }     // fresnel::sgd(f0, f1), dj_brdf.h:3443
+	~sgd() { delete m_fresnel; }
+	const fresnel::impl &get_fresnel() const { return *m_fresnel; }                                   // dj_brdf.h:510
 	DJB_HIP_RESIDENT_EVAL
 	vec3 ndf(const vec3 &h) const { return mq(DJB_Q_MODEL_NDF, h, NULL, NULL); }
 	vec3 gaf(const vec3 &h, const vec3 &i, const vec3 &o) const { return mq(DJB_Q_MODEL_GAF, h, &i, &o); }
@@ -534,12 +554,17 @@ protected:
 		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, &vb, &vc, NULL, &vr, DJB_MEM_HOST));
 		return r;
 	}
+private:
+	const fresnel::impl *m_fresnel;
 };
 
 /* ABC Distribution BRDF, dj_brdf.h:514-535 */
 class abc : public brdf {
 public:
-	explicit abc(const char *name, hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_abc(ctx(), name, &m_h)); }
+	explicit abc(const char *name, hip::context *c = NULL) : brdf(c), m_fresnel(NULL)
+	{ hip::check(djb_brdf_create_abc(ctx(), name, &m_h)); m_fresnel = fresnel::from_handle(m_h); }     // fresnel::unpolarized(vec3(ior)), dj_brdf.h:3623
+	~abc() { delete m_fresnel; }
+	const fresnel::impl &get_fresnel() const { return *m_fresnel; }                                   // dj_brdf.h:534
 	DJB_HIP_RESIDENT_EVAL
 	vec3 ndf(const vec3 &h) const { return mq(DJB_Q_MODEL_NDF, h, NULL, NULL); }
 	float_t gaf(const vec3 &h, const vec3 &i, const vec3 &o) const { return mq(DJB_Q_MODEL_GAF, h, &i, &o).x; }
@@ -551,6 +576,8 @@ protected:
 		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, &vb, &vc, NULL, &vr, DJB_MEM_HOST));
 		return r;
 	}
+private:
+	const fresnel::impl *m_fresnel;
 };
 
 /* Microfacet API, dj_brdf.h:210-298 */

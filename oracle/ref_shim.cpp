@@ -348,6 +348,7 @@ void ref_model_query(void *b_, int which, long n, const float *a, const float *b
 	for (long k = 0; k < n; ++k) {
 		djb::vec3 A = ld(a, k), r(0);
 		if (which == 3) r = s ? s->fresnel(A.x) : c->fresnel(A.x);
+		else if (which == 4) r = s ? s->get_fresnel().eval(A.x) : c->get_fresnel().eval(A.x);      // hdr:510, 534
 		else if (s) {
 			if (which == 0) r = s->ndf(A);
 			else if (which == 1) r = s->gaf(A, ld(bi, k), ld(co, k));

@@ -337,7 +337,9 @@ class CheckerLib:
 
     def model_query(self, b, which, a, i=None, o=None):
         """sgd / abc members: which = 'ndf' | 'gaf' | 'g1' | 'fresnel' (a = h, k, or cos_theta_d in column 0)"""
-        code = {"ndf": 0, "gaf": 1, "g1": 2, "fresnel": 3}[which]
+        code = {"ndf": 0, "gaf": 1, "g1": 2, "fresnel": 3, "get_fresnel": 4}[which]      # get_fresnel: the reference / facade shims only
+        if code == 4 and self.prefix == "o_":
+            code = 3
         a = _f32(a); i = _f32(i) if i is not None else a; o = _f32(o) if o is not None else a
         out = np.empty((a.shape[0], 3), dtype=np.float32)
         self._fn("model_query")(b, C.c_int(code), C.c_int64(a.shape[0]), _ptr(a), _ptr(i), _ptr(o), _ptr(out))

@@ -220,6 +220,8 @@ def test_lambert_merl_utia_models(facade, oracle, inputs, tmp_path):
         close(f"{kind} eval", facade.eval(f, i, o), oracle.eval(b, i, o), 1e-5)
         close(f"{kind} ndf", facade.model_query(f, "ndf", i), oracle.model_query(b, "ndf", i), 1e-5)
         close(f"{kind} gaf", facade.model_query(f, "gaf", i, o, i), oracle.model_query(b, "gaf", i, o, i), 1e-5)
+        cc = np.zeros_like(i); cc[:, 0] = np.clip(i[:, 2], 0, 1)
+        close(f"{kind} get_fresnel().eval", facade.model_query(f, "get_fresnel", cc), oracle.model_query(b, "fresnel", cc))
         if kind == "sgd":
             close("sgd g1", facade.model_query(f, "g1", o), oracle.model_query(b, "g1", o), 1e-5)
         with pytest.raises(RuntimeError):

@@ -187,6 +187,10 @@ def test_merl_params_driver_bytes(oracle, reference, tmp_path):
 def test_sgd_abc_all_materials(oracle, reference, inputs):
     from dj_brdf_amd import param_tables
     i, o, _, _ = inputs
+    cc = np.zeros((256, 3), np.float32); cc[:, 0] = np.linspace(0, 1, 256, dtype=np.float32)
+    for kind in ("sgd", "abc"):      # get_fresnel() is the object fresnel() evaluates (hdr:509-510, 533-534)
+        b = getattr(reference, kind)("gold-metallic-paint")
+        assert np.array_equal(bits(reference.model_query(b, "get_fresnel", cc)), bits(reference.model_query(b, "fresnel", cc)))
     i, o = i[:20000], o[:20000]
     for name in param_tables.abc_names():
         for kind in ("sgd", "abc"):

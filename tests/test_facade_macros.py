@@ -64,3 +64,15 @@ def test_user_assert_and_log_macros(tmp_path):
     r, exe = build(tmp_path, PROG, ["-DNVERBOSE"])
     out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
     assert "fired=3 logs=0" in out.stdout
+
+
+def test_facade_has_the_reference_public_surface():
+    """tests/api/api_surface_probe.cpp uses every public name of dj_brdf.h:41-537 once with the reference's signatures -- the classes a
+    user may DERIVE from (brdf, fresnel::impl, radial, microfacet) included.  It must pass -fsyntax-only against include/dj_brdf.h; where
+    the reference is mounted it is compiled against the reference header as well, which proves the probe itself."""
+    src = os.path.join(ROOT, "tests", "api", "api_surface_probe.cpp")
+    r = subprocess.run(["g++", "-fsyntax-only", "-DNVERBOSE", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    if os.path.exists("/root/reference/dj_brdf.h"):
+        r = subprocess.run(["g++", "-fsyntax-only", "-DNVERBOSE", "-w", "-I", "/root/reference", src], capture_output=True, text=True)
+        assert r.returncode == 0, "the probe does not compile against the reference itself:\n" + r.stderr[-4000:]

@@ -356,7 +356,10 @@ DJB_DEV v3 bk_sample_common(const Params &p, float u1, float u2, v3 o, const Gli
 // decided only outside 2 epsv(u) of its threshold, the safeguard's only outside max(CTS_B_BAND, 2 epsv / |f'|) of an end
 // (CTS_B_BAND covers the first trip: b0's own error, 4e-7).  CTS_DIR_MAX leaves 2e-6 of the 1e-5 to everything that is not the
 // Newton sequence (the rotation, the two rsq normalisations, the reflection: ~5e-7 measured).
-constexpr float CTS_B_BAND = 4.0e-6f, CTS_EPSV_U = 5.0e-7f, CTS_EPSV_0 = 1.5e-7f, CTS_DIR_MAX = 8.0e-6f;
+#ifndef DJB_EXP_CTS_SCALE            // sensitivity builds only (tools/exp/r05/beckmann_share_sensitivity.sh): the error model's constants scaled
+#define DJB_EXP_CTS_SCALE 1.0f
+#endif
+constexpr float CTS_B_BAND = 4.0e-6f, CTS_EPSV_U = 5.0e-7f * DJB_EXP_CTS_SCALE, CTS_EPSV_0 = 1.5e-7f * DJB_EXP_CTS_SCALE, CTS_DIR_MAX = 8.0e-6f;
 
 DJB_DEV float cts_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // exp(y), y <= 0, ~2 ulp: y log2(e) split into hi + lo (a plain exp2(y * log2e) loses |y| 2^-24)

@@ -29,10 +29,16 @@ MTS_NAMESPACE_BEGIN
 using namespace djb_mts;
 
 class dj_beckmann_conductor : public BSDF {
+	// the six texture slots, in the order the reference serializes and prints them (l.224-229, 244-249, 436-441)
+	enum slot { ALPHA1, ALPHA2, ALPHA_ANGLE, LEANMAP1, LEANMAP2, SPECULAR, SLOTS };
+	static const char *slot_name(int k) {
+		static const char *const names[SLOTS] = { "alpha1", "alpha2", "alphaAngle", "leanmap1", "leanmap2", "specularReflectance" };
+		return names[k];
+	}
 public:
 	dj_beckmann_conductor(const Properties &props) : BSDF(props), m_brdf(NULL) {
 		ref<FileResolver> fResolver = Thread::getThread()->getFileResolver();
-		m_specularReflectance = new ConstantSpectrumTexture(props.getSpectrum("specularReflectance", Spectrum(1.0f)));
+		m_tex[SPECULAR] = new ConstantSpectrumTexture(props.getSpectrum(slot_name(SPECULAR), Spectrum(1.0f)));
 
 		// Fresnel: optical constants for Mitsuba's exact conductor term
 		m_mitsubaFresnel = props.getBoolean("mitsubaFresnel", false);
@@ -47,46 +53,45 @@ public:
 		m_k = props.getSpectrum("k", intK) / extEta;
 
 		// the lobe; with "merl": base roughness and Fresnel spline fitted from the measured material (one fit launch)
-		float baseRoughness = 1.f;
+		float base = 1.f;
 		if (props.hasProperty("merl")) {
 			const std::string file = fResolver->resolve(props.getString("merl")).string();
 			djb::merl merl(file.c_str());
 			djb::tabular tab(merl, 90);
-			djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&baseRoughness, &baseRoughness);
+			djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&base, &base);
 			m_brdf = new djb::beckmann(tab.get_fresnel());
 		} else {
 			m_brdf = new djb::beckmann();
 		}
 
-		// roughness: "alpha", or "alpha1" + "alpha2", each scaled by the base roughness
-		if (props.hasProperty("alpha")) {
-			m_alpha1 = m_alpha2 = new ConstantFloatTexture(baseRoughness * props.getFloat("alpha", 1.0f));
+		// roughness, each value scaled by the base roughness: "alpha" alone, or "alpha1" together with "alpha2" (l.193-213)
+		const bool both = props.hasProperty("alpha");
+		const bool split = !both && (props.hasProperty("alpha1") || props.hasProperty("alpha2"));
+		if (both) {
+			m_tex[ALPHA1] = m_tex[ALPHA2] = new ConstantFloatTexture(base * props.getFloat("alpha", 1.0f));
 			if (props.hasProperty("alpha1") || props.hasProperty("alpha2") || props.hasProperty("alphaAngle"))
 				SLog(EError, "Microfacet model: please specify either 'alpha' or 'alpha1'/'alpha2'/'alphaAngle'.");
-		} else if (props.hasProperty("alpha1") || props.hasProperty("alpha2")) {
+		} else if (split) {
 			if (!props.hasProperty("alpha1") || !props.hasProperty("alpha2"))
 				SLog(EError, "Microfacet model: both 'alpha1' and 'alpha2' must be specified.");
-			m_alpha1 = new ConstantFloatTexture(baseRoughness * props.getFloat("alpha1", 1.0f));
-			m_alpha2 = new ConstantFloatTexture(baseRoughness * props.getFloat("alpha2", 1.0f));
+			for (int k = ALPHA1; k <= ALPHA2; ++k)
+				m_tex[k] = new ConstantFloatTexture(base * props.getFloat(slot_name(k), 1.0f));
 		} else {
-			m_alpha1 = m_alpha2 = new ConstantFloatTexture(baseRoughness);
+			m_tex[ALPHA1] = m_tex[ALPHA2] = new ConstantFloatTexture(base);
 		}
-		m_alphaAngle = new ConstantFloatTexture(M_PI / 180.0 * props.getFloat("alphaAngle", 0.0f));
+		m_tex[ALPHA_ANGLE] = new ConstantFloatTexture(M_PI / 180.0 * props.getFloat(slot_name(ALPHA_ANGLE), 0.0f));
 
 		// LEAN maps
 		m_leanFiltering = props.getBoolean("leanFiltering", true);
-		m_leanmap1 = new ConstantSpectrumTexture(props.getSpectrum("leanmap1", Spectrum(0.0f)));
-		m_leanmap2 = new ConstantSpectrumTexture(props.getSpectrum("leanmap2", Spectrum(0.0f)));
+		for (int k = LEANMAP1; k <= LEANMAP2; ++k)
+			m_tex[k] = new ConstantSpectrumTexture(props.getSpectrum(slot_name(k), Spectrum(0.0f)));
 		m_dmapScale = props.getFloat("dmapscale", 1.0f);
 	}
 
+	// restores the textures and eta / k, none of the scalar options (as the reference, l.223-234)
 	dj_beckmann_conductor(Stream *stream, InstanceManager *manager) : BSDF(stream, manager), m_brdf(NULL) {
-		m_alpha1 = static_cast<Texture *>(manager->getInstance(stream));
-		m_alpha2 = static_cast<Texture *>(manager->getInstance(stream));
-		m_alphaAngle = static_cast<Texture *>(manager->getInstance(stream));
-		m_leanmap1 = static_cast<Texture *>(manager->getInstance(stream));
-		m_leanmap2 = static_cast<Texture *>(manager->getInstance(stream));
-		m_specularReflectance = static_cast<Texture *>(manager->getInstance(stream));
+		for (int k = 0; k < SLOTS; ++k)
+			m_tex[k] = static_cast<Texture *>(manager->getInstance(stream));
 		m_eta = Spectrum(stream);
 		m_k = Spectrum(stream);
 		configure();
@@ -95,25 +100,30 @@ public:
 
 	void serialize(Stream *stream, InstanceManager *manager) const {
 		BSDF::serialize(stream, manager);
-		const Texture *textures[6] = { m_alpha1.get(), m_alpha2.get(), m_alphaAngle.get(), m_leanmap1.get(), m_leanmap2.get(),
-		                               m_specularReflectance.get() };
-		for (int k = 0; k < 6; ++k)
-			manager->serialize(stream, textures[k]);
+		for (int k = 0; k < SLOTS; ++k)
+			manager->serialize(stream, m_tex[k].get());
 		m_eta.serialize(stream);
 		m_k.serialize(stream);
 	}
 
 	void configure() {
-		unsigned int extraFlags = 0;
-		if (m_alpha1 != m_alpha2)
-			extraFlags |= EAnisotropic;
-		if (!m_alpha1->isConstant() || !m_alpha2->isConstant() || !m_specularReflectance->isConstant())
-			extraFlags |= ESpatiallyVarying;
+		// the LEAN maps and the angle count for neither flag (l.256-268)
+		const Texture *seen[3] = { m_tex[ALPHA1].get(), m_tex[ALPHA2].get(), m_tex[SPECULAR].get() };
+		bool varying = false, differentials = false;
+		unsigned int flags = EGlossyReflection | EFrontSide;
+		if (seen[0] != seen[1])
+			flags |= EAnisotropic;
+		for (int k = 0; k < 3; ++k)
+			varying |= !seen[k]->isConstant();
+		if (varying)
+			flags |= ESpatiallyVarying;
 		m_components.clear();
-		m_components.push_back(EGlossyReflection | EFrontSide | extraFlags);
-		m_specularReflectance = ensureEnergyConservation(m_specularReflectance, "specularReflectance", 1.0f);
-		m_usesRayDifferentials = m_alpha1->usesRayDifferentials() || m_alpha2->usesRayDifferentials()
-			|| m_specularReflectance->usesRayDifferentials();
+		m_components.push_back(flags);
+		m_tex[SPECULAR] = ensureEnergyConservation(m_tex[SPECULAR], slot_name(SPECULAR), 1.0f);
+		seen[2] = m_tex[SPECULAR].get();
+		for (int k = 0; k < 3; ++k)
+			differentials |= seen[k]->usesRayDifferentials();
+		m_usesRayDifferentials = differentials;
 		BSDF::configure();
 	}
 
@@ -133,9 +143,9 @@ public:
 		hit h(*this, bRec.its);
 		const djb::vec3 o = dir(bRec.wi), i = dir(bRec.wo);
 		djb::vec3 fr_cos;
-		float pdf;
-		m_brdf->evalp_lean(1, &i, &o, h.base, m_dmapScale, h.texel, &fr_cos, &pdf, h.flags);
-		return pdf;
+		float density;
+		m_brdf->evalp_lean(1, &i, &o, h.base, m_dmapScale, h.texel, &fr_cos, &density, h.flags);
+		return density;
 	}
 
 	Spectrum sample(BSDFSamplingRecord &bRec, Float &pdf, const Point2 &sample) const {
@@ -145,46 +155,40 @@ public:
 		const djb::vec3 o = dir(bRec.wi);
 		djb::vec3 i, fr_cos;
 		m_brdf->evalp_is_lean(1, &sample.x, &sample.y, &o, h.base, m_dmapScale, h.texel, &fr_cos, &i, &pdf, h.flags);
-		bRec.wo = Normal(i.x, i.y, i.z);
-		bRec.eta = 1.0f;
-		bRec.sampledComponent = 0;
-		bRec.sampledType = EGlossyReflection;
+		glossy_sample(bRec, Normal(i.x, i.y, i.z));
 		return conductor(bRec) * rgb(fr_cos);
 	}
 	Spectrum sample(BSDFSamplingRecord &bRec, const Point2 &sample) const {
-		Float pdf_ = 0.f;
-		return this->sample(bRec, pdf_, sample);
+		Float unused = 0.f;
+		return this->sample(bRec, unused, sample);
 	}
 
 	void addChild(const std::string &name, ConfigurableObject *child) {
-		if (!child->getClass()->derivesFrom(MTS_CLASS(Texture))) {
-			BSDF::addChild(name, child);
-			return;
+		if (child->getClass()->derivesFrom(MTS_CLASS(Texture))) {
+			Texture *texture = static_cast<Texture *>(child);
+			if (name == "alpha") {
+				m_tex[ALPHA1] = m_tex[ALPHA2] = texture;
+				return;
+			}
+			for (int k = 0; k < SLOTS; ++k)
+				if (name == slot_name(k)) {
+					m_tex[k] = texture;
+					return;
+				}
 		}
-		Texture *texture = static_cast<Texture *>(child);
-		if (name == "alpha") m_alpha1 = m_alpha2 = texture;
-		else if (name == "alpha1") m_alpha1 = texture;
-		else if (name == "alpha2") m_alpha2 = texture;
-		else if (name == "alphaAngle") m_alphaAngle = texture;
-		else if (name == "leanmap1") m_leanmap1 = texture;
-		else if (name == "leanmap2") m_leanmap2 = texture;
-		else if (name == "specularReflectance") m_specularReflectance = texture;
-		else BSDF::addChild(name, child);
+		BSDF::addChild(name, child);
 	}
 
 	Float getRoughness(const Intersection &its, int component) const {
-		return 0.5f * (m_alpha1->eval(its).average() + m_alpha2->eval(its).average());
+		return 0.5f * (m_tex[ALPHA1]->eval(its).average() + m_tex[ALPHA2]->eval(its).average());
 	}
 
 	std::string toString() const {
 		std::ostringstream oss;
 		oss << "dj_beckmann_conductor[" << endl
 			<< "  id = \"" << getID() << "\"," << endl;
-		const char *names[6] = { "alpha1", "alpha2", "alphaAngle", "leanmap1", "leanmap2", "specularReflectance" };
-		const Texture *textures[6] = { m_alpha1.get(), m_alpha2.get(), m_alphaAngle.get(), m_leanmap1.get(), m_leanmap2.get(),
-		                               m_specularReflectance.get() };
-		for (int k = 0; k < 6; ++k)
-			oss << "  " << names[k] << " = " << indent(textures[k]->toString()) << "," << endl;
+		for (int k = 0; k < SLOTS; ++k)
+			oss << "  " << slot_name(k) << " = " << indent(m_tex[k]->toString()) << "," << endl;
 		oss << "  eta = " << m_eta.toString() << "," << endl
 			<< "  k = " << m_k.toString() << endl
 			<< "]";
@@ -197,13 +201,13 @@ private:
 	// what one intersection contributes: the base lobe from the alpha textures and the raw LEAN texel (bias still on)
 	struct hit {
 		hit(const dj_beckmann_conductor &s, const Intersection &its)
-			: base(djb::microfacet::params::elliptic(s.m_alpha1->eval(its).average(), s.m_alpha2->eval(its).average(),
-			                                         s.m_alphaAngle->eval(its).average())),
+			: base(djb::microfacet::params::elliptic(s.m_tex[ALPHA1]->eval(its).average(), s.m_tex[ALPHA2]->eval(its).average(),
+			                                         s.m_tex[ALPHA_ANGLE]->eval(its).average())),
 			  flags(DJB_LEAN_BIASED | (s.m_leanFiltering ? 0 : DJB_LEAN_NAIVE_MIP))
 		{
 			Float dummy;
-			s.m_leanmap1->eval(its).toLinearRGB(texel[0], texel[1], dummy);
-			s.m_leanmap2->eval(its).toLinearRGB(texel[2], texel[3], texel[4]);
+			s.m_tex[LEANMAP1]->eval(its).toLinearRGB(texel[0], texel[1], dummy);
+			s.m_tex[LEANMAP2]->eval(its).toLinearRGB(texel[2], texel[3], texel[4]);
 		}
 		djb::microfacet::params base;
 		Float texel[5];
@@ -211,18 +215,15 @@ private:
 	};
 	// l.321-324 / 421-424: exact conductor Fresnel at the half vector times the specular reflectance texture
 	Spectrum conductor(const BSDFSamplingRecord &bRec) const {
-		Vector H = normalize(bRec.wo + bRec.wi);
-		return fresnelConductorExact(dot(bRec.wi, H), m_eta, m_k) * m_specularReflectance->eval(bRec.its);
+		const Vector half = normalize(bRec.wo + bRec.wi);
+		return fresnelConductorExact(dot(bRec.wi, half), m_eta, m_k) * m_tex[SPECULAR]->eval(bRec.its);
 	}
 
-	ref<Texture> m_specularReflectance;
-	ref<Texture> m_alpha1, m_alpha2, m_alphaAngle;
-	ref<Texture> m_leanmap1, m_leanmap2;
+	ref<Texture> m_tex[SLOTS];
 	djb::beckmann *m_brdf;
 	Spectrum m_eta, m_k;
 	Float m_dmapScale;
-	bool m_leanFiltering;
-	bool m_mitsubaFresnel;
+	bool m_leanFiltering, m_mitsubaFresnel;
 };
 
 // GLSL preview (VPL renderer): the reference ships an Ashikhmin-Shirley stand-in with its own GLSL program here
@@ -232,7 +233,7 @@ private:
 DJB_MTS_PREVIEW_SHADER(dj_beckmann_conductor_shader)
 
 Shader *dj_beckmann_conductor::createShader(Renderer *renderer) const {
-	return new dj_beckmann_conductor_shader(renderer, m_specularReflectance.get());
+	return new dj_beckmann_conductor_shader(renderer, m_tex[SPECULAR].get());
 }
 
 MTS_IMPLEMENT_CLASS(dj_beckmann_conductor_shader, false, Shader)

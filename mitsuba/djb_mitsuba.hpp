@@ -45,16 +45,21 @@ inline bool is_reflectance_child(const std::string &name, ConfigurableObject *ch
 }
 inline fs::path resolved(const std::string &name) { return Thread::getThread()->getFileResolver()->resolve(name); }
 
+// what every glossy shell writes into the record next to the sampled direction
+inline void glossy_sample(BSDFSamplingRecord &bRec, const Vector &wo)
+{
+	bRec.wo = wo;
+	bRec.eta = 1.0f;
+	bRec.sampledComponent = 0;
+	bRec.sampledType = BSDF::EGlossyReflection;
+}
 // direction sampled on a fitted lobe, value = measured evalp / lobe pdf: the tail shared by dj_merl / dj_abc / dj_sgd
 // (mitsuba/dj_merl.cpp:83-97, dj_abc.cpp:87-103).  `pdf_of` is the shell's own BSDF::pdf, guards included, as there.
 template <class Shell>
 inline Spectrum finish_lobe_sample(const Shell &shell, const djb::brdf &measured, BSDFSamplingRecord &bRec,
                                    const djb::vec3 &i, const djb::vec3 &o)
 {
-	bRec.wo = Vector(i.x, i.y, i.z);
-	bRec.eta = 1.0f;
-	bRec.sampledComponent = 0;
-	bRec.sampledType = BSDF::EGlossyReflection;
+	glossy_sample(bRec, Vector(i.x, i.y, i.z));
 	if (at_or_below(bRec.wo))
 		return Spectrum(0.0f);
 	return rgb(measured.evalp(i, o) / shell.pdf(bRec, ESolidAngle));

@@ -319,8 +319,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 	unsigned long long ct_key = 0;
 	{ unsigned int w[4]; float f4[4] = { p.ax, p.ay, p.rho, (float)b->dev.kind }; memcpy(w, f4, 16); ct_key = ((unsigned long long)(w[0] ^ (w[2] * 2654435761u)) << 32) | (w[1] ^ (w[3] * 40503u));
 	  // model lobes (sgd / abc) take no params: the object is the key (each material has its own wall)
-	  // (a tabular lobe takes params, but its tier-2 share is its table's: the object is part of the key as well)
-	  if (b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_ABC || b->dev.kind == DJB_KIND_TABULAR) ct_key ^= (unsigned long long)(uintptr_t)b * 0x9E3779B97F4A7C15ull;
+	  if (b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_ABC) ct_key ^= (unsigned long long)(uintptr_t)b * 0x9E3779B97F4A7C15ull;
 	  if (!ct_key) ct_key = 1; }
 	wl_adapt(ctx);
 	// The verdict is re-examined: every CT_REPROBE-th call with the hopeless key runs the contract kernels again (the direction
@@ -347,7 +346,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 				// a first call has nothing to adapt to, and an overflow costs a full exact pass ON TOP of tier 1 (sgd: 8 ms instead of 1.4 per 1e8
 				// on each of the first two calls -- tools/exp/r04/contract_fixup_share.sh): the kinds whose tier 2 is a few per cent by
 				// nature (sgd's wall, Beckmann's exp(-r^2) tail) start at 12 % (3.8 B of scratch per pair) instead of 2 %
-				const double floor_frac = (b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_BECKMANN || b->dev.kind == DJB_KIND_TABULAR) ? 0.12 : 0.0;
+				const double floor_frac = (b->dev.kind == DJB_KIND_SGD || b->dev.kind == DJB_KIND_BECKMANN) ? 0.12 : 0.0;
 				size_t cap = (size_t)((double)m * std::max(ctx->wl_frac, floor_frac)) + 4096;
 				cap = (cap + djbk::CONTRACT_SHARDS - 1) / djbk::CONTRACT_SHARDS * djbk::CONTRACT_SHARDS;     // whole segments
 				if (ctx->test_worklist_cap >= 0) cap = ((size_t)ctx->test_worklist_cap / djbk::CONTRACT_SHARDS + 1) * djbk::CONTRACT_SHARDS;

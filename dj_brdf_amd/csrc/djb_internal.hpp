@@ -113,9 +113,6 @@ struct CtParams {
 	float p_[3], lkap[3];                              // NDF exponent; log2(kap / pi)
 	float lam[3], l2c[3], kk[3], th0_hi[3], th0_lo[3]; // g1: lambda, log2(c), k, theta0 = hi + lo
 	float x_max[3], x_zero[3];                         // g1: tier-1 range of x = c t1^k (ct_params_sgd)
-	// tabular (dj_brdf.h:2151-2162): the object's tables in HBM (the tier-1 kernel stages them in LDS); fr = the spline Fresnel's points
-	const float *tab_p22, *tab_sigma, *tab_fr;
-	int n_p22, n_sigma, n_fr;
 };
 // false: brdf / params outside the fast path's domain
 bool contract_params(const Brdf &b, const Params &p, const double *model_host, CtParams *c);

@@ -233,112 +233,11 @@ DJB_DEV bool ct_eval_sgd(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 	return ok | !live;
 }
 
-// Tabular lobes (djb::tabular: microfacet::eval / pdf with p22_radial, sigma_std_radial and -- as fitted -- a spline Fresnel term read
-// from tables; dj_brdf.h:2151-2162, 1338-1344).  As for Beckmann the half vector, its slopes and r^2 are computed with the REFERENCE's
-// operations (a steep p22 table is as sensitive to r as exp(-r^2)), which also makes h.z > 1e-4, dot(o, h) and dot(i, h) the reference's
-// own floats.  The four look-ups -- p22 at u = sqrt(2 atan(r) / pi), sigma at u = 2 acos(cos theta_k) / pi for o and for i, the Fresnel
-// points at u = 2 acos(cos theta_d) / pi -- go through ct_tab (djb_contract_device.inc): the reference's float arithmetic from an fp32 u,
-// with an estimate of what the difference of the two u can do to the value.  The pair stays on the fast path while the sum of the
-// relative estimates is below CT_TAB_BUDGET, which leaves 3e-6 of the 1e-5 to the arithmetic around the look-ups (a dozen roundings, four
-// v_rcp / v_rsq); everything else is tier 2.  Which share that is depends on the material: profiles/r05/contract_tabular.txt.
-struct CtTabs { const float *p22, *sigma, *fr; int n_p22, n_sigma, n_fr; };
-constexpr float CT_TAB_BUDGET = 7.0e-6f;
-// sigma(k) = nrm * sigma_std_radial(k.z / nrm) (dj_brdf.h:1619-1631, 2158-2162) with the norm by v_rsq_f32; adds its relative estimate to esum
-DJB_DEV float ct_sigma_tab(const CtParams &c, const CtTabs &T, v3 k, bool &ok, float &esum)
-{
-	const float a = k.x * c.ax + k.y * c.ay * c.rho;
-	const float bb = k.y * c.ay * c.s;
-	const float m2 = a * a + bb * bb, n2 = m2 + k.z * k.z;
-	ok &= in_range(n2);
-	const float rn = rsq_(n2), nrm = n2 * rn, kz = fminf(rn * k.z, 1.0f);
-	const float s2 = m2 * (rn * rn);                             // sin^2 of the stretched direction, without the cancellation of 1 - kz^2
-	const float u = ct_acos_unit(kz) * 0.636619747f;
-	// the cosine is approximate here and rounded in the reference: both move the angle by (their error) / sin(theta)
-	const CtTab t = ct_tab(T.sigma, T.n_sigma, u, CT_TAB_REL_ACOS, fminf(CT_TAB_COS_ABS * rsq_(fmaxf(s2, 1e-20f)), 1.0f));
-	ok &= !t.near_node & (t.val > 1e-30f);
-	esum += t.err * rcp_(fmaxf(t.val, 1e-30f));
-	return nrm * t.val;
-}
-template <int WANT, int FRK>
-DJB_DEV bool ct_eval_tabular(const CtParams &c, const CtTabs &T, v3 i, v3 o, v3 &fr, float &pdf)
-{
-	const bool live = (o.z > 0.0f) & (!c.shadow | (i.z > 0.0f));
-	bool ok = (o.z > CT_LO) & (i.z > CT_LO);
-	const v3 h = normalize(add(i, o));                        // exact (dj_brdf.h:1536, 630-637)
-	const bool facing = h.z > 1e-4f;                          // microfacet::ndf's cut (dj_brdf.h:1561): the reference's decision
-	const float xs = -h.x / h.z, ys = -h.y / h.z;             // dj_brdf.h:1564
-	const float x_ = fdiv_r(xs, c.ax, c.R_ax);                 // microfacet::p22, dj_brdf.h:1574-1587
-	const float y_ = fdiv_r(c.ax * ys - c.rho_ay * xs, c.t2, c.R_t2);
-	const float r2 = x_ * x_ + y_ * y_;                       // the reference's float
-	ok &= (r2 < 1e30f) | !facing;
-	float esum = 0.0f;
-	// D = p22_radial(r^2) / (t2 cos^4)
-	const float ud = __builtin_amdgcn_sqrtf(ct_atan_pos(__builtin_amdgcn_sqrtf(fminf(r2, 1e30f))) * 0.636619747f);
-	const CtTab d = ct_tab(T.p22, T.n_p22, ud, CT_TAB_REL_ATAN, 0.0f);
-	const bool zero_d = facing & d.flat_zero;                 // p22 is exactly zero here: so are D, eval and pdf, in the reference too
-	ok &= !d.near_node | !facing;
-	ok &= (d.val > 1e-30f) | zero_d | !facing;                // a negative or vanishing interpolant: tier 2
-	esum += d.err * rcp_(fmaxf(d.val, 1e-30f));
-	const float c2 = h.z * h.z, c4 = c2 * c2;
-	const float sig_o = ct_sigma_tab(c, T, o, ok, esum);
-	const float e_pdf = esum;                                  // the pdf involves D and sigma(o) only
-	float den4;
-	if (c.shadow) {
-		const float sig_i = ct_sigma_tab(c, T, i, ok, esum);
-		den4 = 4.0f * ((i.z * sig_o + o.z * sig_i) - i.z * o.z);
-		// a fitted sigma table may dip below k.z (g1 > 1): the quotient's denominator can then cancel -- the reference's `G > 0` decides: tier 2
-		ok &= den4 > 0.25f * (i.z * sig_o + o.z * sig_i);
-	} else den4 = 4.0f * (sig_o * i.z);
-	const float oh = dot(o, h);
-	const bool on = live & facing;
-	const float Dn = c.r_t2 * d.val;
-	fr = mk(0, 0, 0); pdf = 0.0f;
-	if (WANT & 3) {
-		float e = Dn * rcp_(c4 * den4);
-		if (WANT & 2) e *= i.z;
-		ok &= ((e < 1e30f) & (e > 1e-33f)) | !on | zero_d;
-		e = (on & !zero_d) ? e : 0.0f;
-		float ef = 0.0f;
-		if (FRK == FR_SPLINE) {                                // fresnel::spline::eval, dj_brdf.h:1338-1344
-			const float cd = sat_(oh);
-			const float uf = ct_acos_unit(cd) * 0.636619747f;
-			const float t = uf * (float)T.n_fr - uf;
-			const float ip = truncf(t), frac = t - ip;
-			const int k = (int)ip, n = T.n_fr;
-			const int i1 = k >= n ? n - 1 : (k < 0 ? 0 : k), k2 = k + 1, i2 = k2 >= n ? n - 1 : (k2 < 0 ? 0 : k2);
-			const float dt = CT_TAB_REL_ACOS * t;
-			ok &= ((frac > dt) & (frac < 1.0f - dt)) | !on | zero_d;
-			float f[3];
-#pragma unroll
-			for (int ch = 0; ch < 3; ++ch) {
-				const float p1 = T.fr[3 * i1 + ch], p2 = T.fr[3 * i2 + ch];
-				f[ch] = p1 + frac * (p2 - p1);
-				const bool flat = (p1 == p2);                 // no slope: the value does not depend on the fraction (a zero channel included)
-				const float rel = (dt * fabsf(p2 - p1)) * rcp_(fmaxf(fabsf(f[ch]), 1e-30f));
-				ef = fmaxf(ef, flat ? 0.0f : rel);
-			}
-			fr = mk(f[0] * e, f[1] * e, f[2] * e);
-		} else fr = mk(e, e, e);
-		ok &= (esum + ef <= CT_TAB_BUDGET) | !on | zero_d;
-		// eval = evalp / i.z even where evalp is vec3(0) (dj_brdf.h:1551-1555): NaN for a dead pair with i.z = 0 (or NaN)
-		if ((WANT & 1) && !live && ((i.z == 0.0f) | (i.z != i.z))) fr = mk(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-	}
-	if (WANT & 4) {
-		const float ih = dot(i, h);
-		const float q = (oh * Dn) * rcp_(c4 * (4.0f * ih * sig_o));
-		const bool pos = oh > 0.0f;                            // vndf is 0 unless dot(o, h) > 0 (dj_brdf.h:1605): the reference's decision
-		ok &= ((((q < 1e30f) & (q > 1e-33f)) | zero_d) & (ih > CT_LO) & ((e_pdf <= CT_TAB_BUDGET) | zero_d)) | !(on & pos);
-		pdf = (on & pos & !zero_d) ? q : 0.0f;
-	}
-	return ok | !live;
-}
-
 // one pair; false = tier 2.  fr / pdf follow eval_one's WANT convention (1 eval, 2 evalp, 4 pdf)
 template <int KIND, int WANT, int FRK>
-DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf, const CtTabs *tabs = nullptr)
+DJB_DEV bool ct_eval_one(const CtParams &c, v3 i, v3 o, v3 &fr, float &pdf)
 {
-	static_assert(KIND == KIND_GGX || KIND == KIND_BECKMANN || KIND == KIND_ABC || KIND == KIND_SGD || KIND == KIND_TABULAR, "contract mode: GGX, Beckmann, tabular, ABC and SGD");
-	if (KIND == KIND_TABULAR) return ct_eval_tabular<WANT, FRK>(c, *tabs, i, o, fr, pdf);
+	static_assert(KIND == KIND_GGX || KIND == KIND_BECKMANN || KIND == KIND_ABC || KIND == KIND_SGD, "contract mode: GGX, Beckmann, ABC and SGD");
 	if (KIND == KIND_ABC) return ct_eval_abc<WANT>(c, i, o, fr, pdf);
 	if (KIND == KIND_SGD) return ct_eval_sgd<WANT>(c, i, o, fr, pdf);
 	if (KIND == KIND_BECKMANN) return ct_eval_beckmann<WANT, FRK>(c, i, o, fr, pdf);
@@ -401,16 +300,6 @@ __global__ __launch_bounds__(BLOCK) void k_ct_fast_v4(CtParams c, long long n4, 
                                                       uint4 *list_all, unsigned int cap, unsigned int *counts)
 {
 	__shared__ WaveBuf wbuf[BLOCK / 64];
-	// tabular: the object's three tables, staged once per workgroup (<= 10 KB; the look-ups are lane-divergent LDS reads)
-	__shared__ float s_tab[KIND == KIND_TABULAR ? 5 * CT_TAB_MAX : 1];
-	CtTabs tabs = { nullptr, nullptr, nullptr, 0, 0, 0 };
-	if (KIND == KIND_TABULAR) {
-		for (int k = threadIdx.x; k < c.n_p22; k += BLOCK) s_tab[k] = c.tab_p22[k];
-		for (int k = threadIdx.x; k < c.n_sigma; k += BLOCK) s_tab[CT_TAB_MAX + k] = c.tab_sigma[k];
-		for (int k = threadIdx.x; k < 3 * c.n_fr; k += BLOCK) s_tab[2 * CT_TAB_MAX + k] = c.tab_fr[k];
-		tabs = CtTabs{ s_tab, s_tab + CT_TAB_MAX, s_tab + 2 * CT_TAB_MAX, c.n_p22, c.n_sigma, c.n_fr };
-		__syncthreads();
-	}
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	unsigned int wcount = 0;
 	const unsigned int shard = blockIdx.x % CT_SHARDS;
@@ -437,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void k_ct_fast_v4(CtParams c, long long n4, 
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				v3 fr; float pdf;
-				amb[j] = !ct_eval_one<KIND, WANT, FRK>(c, mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]), fr, pdf, &tabs);
+				amb[j] = !ct_eval_one<KIND, WANT, FRK>(c, mk(ixs[j], iys[j], izs[j]), mk(oxs[j], oys[j], ozs[j]), fr, pdf);
 				rr[j] = fr.x; gg[j] = fr.y; bb[j] = fr.z; pp[j] = pdf;
 			}
 			// tier-2 pairs get a placeholder here; k_ct_fixup runs after this kernel on the same stream and overwrites it
@@ -540,8 +429,7 @@ __global__ __launch_bounds__(BLOCK) void k_ct_selftest(Brdf b, Params p, CtParam
 		}
 		v3 fa, fe; float pa, pe;
 		++n_all;
-		const CtTabs tabs = { c.tab_p22, c.tab_sigma, c.tab_fr, c.n_p22, c.n_sigma, c.n_fr };      // tabular: straight from HBM here
-		if (!ct_eval_one<KIND, 5, FRK>(c, i, o, fa, pa, &tabs)) { ++n_t2; continue; }
+		if (!ct_eval_one<KIND, 5, FRK>(c, i, o, fa, pa)) { ++n_t2; continue; }
 		eval_one<KIND, 5, FRK>(b, p, i, o, fe, pe);
 		const float va[4] = { fa.x, fa.y, fa.z, pa }, ve[4] = { fe.x, fe.y, fe.z, pe };
 #pragma unroll
@@ -634,7 +522,6 @@ bool ct_params(const Brdf &b, const Params &p, CtParams *c)
 	if (!(fabsf(p.rho) <= djbk::CT_RHO_MAX) || !(p.ax >= 1e-4f && p.ax <= 1e4f) || !(p.ay >= 1e-4f && p.ay <= 1e4f)) return false;
 	const double t2 = (double)p.ax * (double)p.ay * (double)p.s;
 	if (!(t2 > 1e-9 && t2 < 1e9)) return false;
-	c->tab_p22 = c->tab_sigma = c->tab_fr = nullptr; c->n_p22 = c->n_sigma = c->n_fr = 0;
 	c->ax = p.ax; c->ay = p.ay; c->rho = p.rho; c->s = p.s; c->rho_ay = p.rho * p.ay;
 	c->r_ax = (float)(1.0 / (double)p.ax);
 	c->r_t2 = (float)(1.0 / (double)(p.ax * p.ay * p.s));
@@ -643,18 +530,6 @@ bool ct_params(const Brdf &b, const Params &p, CtParams *c)
 	c->R_ax = p.r_ax; c->R_t2 = p.r_t2;
 	c->shadow = b.shadow;
 	for (int k = 0; k < 3; ++k) { c->f0[k] = 1.0f; c->f1[k] = 0.0f; c->n2m1[k] = 1.25f; }
-	if (b.kind == KIND_TABULAR) {
-		// the object's tables (tabular(brdf, res): res nodes each; the fitted spline Fresnel term has res points too), or the ideal term
-		// the plugins install with mitsubaFresnel (mitsuba/dj_brdf.cpp:90); any other Fresnel term on a tabular lobe keeps the exact kernels
-		if (!b.p22 || !b.sigma || b.n_p22 < 2 || b.n_p22 > CT_TAB_MAX || b.n_sigma < 2 || b.n_sigma > CT_TAB_MAX) return false;
-		c->tab_p22 = b.p22; c->tab_sigma = b.sigma; c->n_p22 = b.n_p22; c->n_sigma = b.n_sigma;
-		c->tab_fr = nullptr; c->n_fr = 0;
-		if (b.fr.kind == FR_SPLINE) {
-			if (!b.fr.pts || b.fr.npts < 2 || b.fr.npts > CT_TAB_MAX) return false;
-			c->tab_fr = b.fr.pts; c->n_fr = b.fr.npts;
-		} else if (b.fr.kind != FR_IDEAL) return false;
-		return true;
-	}
 	if (b.fr.kind == FR_UNPOLARIZED) {
 		for (int k = 0; k < 3; ++k) {
 			if (!(b.fr.a[k] >= CT_IOR_MIN && b.fr.a[k] <= CT_IOR_MAX)) return false;      // ct_unpolarized: the reference's own noise below 1.05
@@ -674,7 +549,7 @@ bool ct_params_any(const Brdf &b, const Params &p, const double *model_host, CtP
 {
 	if (b.kind == KIND_ABC) return ct_params_abc(b, model_host, c);
 	if (b.kind == KIND_SGD) return ct_params_sgd(b, model_host, c);
-	return (b.kind == KIND_GGX || b.kind == KIND_BECKMANN || b.kind == KIND_TABULAR) && ct_params(b, p, c);
+	return (b.kind == KIND_GGX || b.kind == KIND_BECKMANN) && ct_params(b, p, c);
 }
 
 template <int KIND, int FRK>
@@ -734,10 +609,6 @@ hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, c
 	if (b.kind == KIND_SGD) return launch_ct<KIND_SGD, -1>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 	// the pdf has no Fresnel term: one instantiation serves every kind
 	const int frk = want == 4 ? FR_IDEAL : b.fr.kind;
-	if (b.kind == KIND_TABULAR) {
-		if (frk == FR_SPLINE) return launch_ct<KIND_TABULAR, FR_SPLINE>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
-		return launch_ct<KIND_TABULAR, FR_IDEAL>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
-	}
 	if (b.kind == KIND_BECKMANN) {
 		if (frk == FR_SCHLICK) return launch_ct<KIND_BECKMANN, FR_SCHLICK>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
 		if (frk == FR_UNPOLARIZED) return launch_ct<KIND_BECKMANN, FR_UNPOLARIZED>(s, b, p, c, n, i, o, out, out_pdf, want, (uint4 *)list, cap, count);
@@ -756,10 +627,7 @@ hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &
 	const dim3 g(grid_for(n, 256LL * 16)), t(BLOCK);
 	if (b.kind == KIND_ABC) hipLaunchKernelGGL((k_ct_selftest<KIND_ABC, -1>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 	else if (b.kind == KIND_SGD) hipLaunchKernelGGL((k_ct_selftest<KIND_SGD, -1>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
-	else if (b.kind == KIND_TABULAR) {
-		if (b.fr.kind == FR_SPLINE) hipLaunchKernelGGL((k_ct_selftest<KIND_TABULAR, FR_SPLINE>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
-		else hipLaunchKernelGGL((k_ct_selftest<KIND_TABULAR, FR_IDEAL>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
-	} else if (b.kind == KIND_BECKMANN) {
+	else if (b.kind == KIND_BECKMANN) {
 		if (b.fr.kind == FR_SCHLICK) hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_SCHLICK>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 		else if (b.fr.kind == FR_UNPOLARIZED) hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_UNPOLARIZED>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);
 		else hipLaunchKernelGGL((k_ct_selftest<KIND_BECKMANN, FR_IDEAL>), g, t, 0, s, b, p, c, n, seed_i, seed_o, start, family, max_bits, counters);

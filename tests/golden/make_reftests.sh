@@ -24,5 +24,8 @@ PY
 # reference's interface only): what the real reference prints for it
 g++ -O2 -ffp-contract=off -DNVERBOSE -w -I"$REF" -o "$W/custom_brdf" "$HERE/../../examples/custom_brdf.cpp" -lm
 "$W/custom_brdf" > "$OUT/custom_brdf.txt"
+# its randomised companion (random user lobes / Fresnel terms / NDFs, random resolutions and directions): seeds 1..6
+g++ -O2 -ffp-contract=off -DNVERBOSE -w -I"$REF" -o "$W/custom_brdf_fuzz" "$HERE/../../examples/custom_brdf_fuzz.cpp" -lm
+"$W/custom_brdf_fuzz" 1 6 > "$OUT/custom_brdf_fuzz.txt"
 rm -rf "$W"
 ls -la "$OUT"

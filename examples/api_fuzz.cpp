@@ -1,0 +1,269 @@
+// examples/api_fuzz.cpp -- the library's OWN classes driven through the reference's public interface with random arguments: lobes,
+// parameterisations, the five Fresnel terms, every operator and query, the LEAN representation, the two published models, a UTIA file
+// written by the program itself, isotropic and anisotropic fits.  Every result is printed bit for bit.
+//
+// Written against the REFERENCE's interface only; compiles unchanged against either header and must print the same bytes per seed:
+//   api_fuzz <first seed> <number of seeds> [scratch directory]
+//   g++ -I/root/reference -> the reference (oracle/Makefile: oracle/_ref/api_fuzz; seeds 1..4 kept as tests/golden/reftests/api_fuzz.txt)
+//   g++ -I include -ldjb_hip -> this repository (host path or GPU)
+// (MERL files are 35 MB each and have their own programs: examples/merl_params.cpp, tests/test_gpu_golden.py.)
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#define DJ_BRDF_IMPLEMENTATION 1
+#include "dj_brdf.h"
+
+namespace {
+
+struct rng {                                     // splitmix64: the same stream on every machine
+	uint64_t s;
+	explicit rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 777u) {}
+	uint64_t bits() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+	float u() { return (float)(bits() >> 40) * (1.0f / 16777216.0f); }
+	float in(float a, float b) { return a + (b - a) * u(); }
+	float log_in(float a, float b) { return (float)std::exp((double)in((float)std::log((double)a), (float)std::log((double)b))); }
+	int below(int n) { return (int)(bits() % (uint64_t)n); }
+	djb::vec3 dir(float zmin = 0.02f)
+	{
+		const float z = in(zmin, 1.0f), phi = in(0.0f, 6.2831853f), r = (float)std::sqrt(1.0 - (double)z * z);
+		return djb::vec3(r * (float)std::cos((double)phi), r * (float)std::sin((double)phi), z);
+	}
+	// what a renderer's stray rays look like: now and then below the horizon, on it, on the normal, un-normalised
+	djb::vec3 any_dir()
+	{
+		djb::vec3 d = dir();
+		switch (below(12)) {
+		case 0: d.z = -d.z; break;
+		case 1: d = djb::vec3(d.x, d.y, 0.0f); break;
+		case 2: d = djb::vec3(0, 0, 1); break;
+		case 3: d = d * in(0.3f, 3.0f); break;
+		default: break;
+		}
+		return d;
+	}
+};
+
+void put(float v) { if (v != v) printf(" nan"); else printf(" %a", v); }
+void show(const char *tag, const djb::vec3 &v) { printf("%s", tag); put(v.x); put(v.y); put(v.z); printf("\n"); }
+void show1(const char *tag, float v) { printf("%s", tag); put(v); printf("\n"); }
+void show_table(const char *tag, const std::vector<djb::float_t> &v)
+{
+	uint64_t h = 0xcbf29ce484222325ull;
+	for (size_t k = 0; k < v.size(); ++k) {
+		uint32_t w; float f = v[k]; memcpy(&w, &f, 4);
+		if (f != f) w = 0x7fc00000u;
+		for (int b = 0; b < 4; ++b) { h ^= (w >> (8 * b)) & 0xffu; h *= 0x100000001b3ull; }
+	}
+	printf("%s n=%d fnv=%016llx", tag, (int)v.size(), (unsigned long long)h);
+	if (!v.empty()) { put(v[0]); put(v[v.size() / 2]); put(v.back()); }
+	printf("\n");
+}
+
+djb::microfacet::params random_params(rng &g)
+{
+	switch (g.below(4)) {
+	case 0: return djb::microfacet::params::standard();
+	case 1: return djb::microfacet::params::isotropic(g.log_in(0.02f, 2.0f));
+	case 2: return djb::microfacet::params::elliptic(g.log_in(0.02f, 2.0f), g.log_in(0.02f, 2.0f), g.in(-3.2f, 3.2f));
+	default: return djb::microfacet::params::pdfparams(g.log_in(0.02f, 2.0f), g.log_in(0.02f, 2.0f), g.in(-0.95f, 0.95f),
+	                                                   g.below(2) ? g.in(-0.5f, 0.5f) : 0.0f, g.below(2) ? g.in(-0.5f, 0.5f) : 0.0f);
+	}
+}
+
+djb::fresnel::impl *random_fresnel(rng &g)
+{
+	switch (g.below(5)) {
+	case 0: return new djb::fresnel::ideal();
+	case 1: return new djb::fresnel::unpolarized(djb::vec3(g.in(1.02f, 3.0f), g.in(1.02f, 3.0f), g.log_in(1.02f, 60.0f)));
+	case 2: return new djb::fresnel::schlick(djb::vec3(g.u(), g.u(), g.u()));
+	case 3: return new djb::fresnel::sgd(djb::vec3(g.u(), g.u(), g.u()), djb::vec3(g.in(-0.3f, 0.3f), g.in(-0.3f, 0.3f), g.in(-0.3f, 0.3f)));
+	default: {
+		std::vector<djb::vec3> pts;
+		const int n = 2 + g.below(40);
+		for (int k = 0; k < n; ++k) pts.push_back(djb::vec3(g.in(0.0f, 1.5f), g.in(0.0f, 1.5f), g.in(0.0f, 1.5f)));
+		return new djb::fresnel::spline(pts);
+	}
+	}
+}
+
+void params_round_trip(rng &g)
+{
+	djb::microfacet::params p = random_params(g);
+	float a1, a2, phi, ax, ay, rho, tx, ty;
+	p.get_ellipse(&a1, &a2, &phi); p.get_pdfparams(&ax, &ay, &rho, &tx, &ty);
+	printf("params ellipse"); put(a1); put(a2); put(phi); printf(" pdf"); put(ax); put(ay); put(rho); put(tx); put(ty); printf("\n");
+	djb::vec3 n; p.get_location(&n); show("  location", n);
+	p.set_ellipse(g.log_in(0.05f, 1.0f), g.log_in(0.05f, 1.0f), g.in(-3.0f, 3.0f));
+	p.set_location(djb::normalize(djb::vec3(g.in(-0.3f, 0.3f), g.in(-0.3f, 0.3f), 1.0f)));
+	p.get_pdfparams(&ax, &ay, &rho, &tx, &ty);
+	printf("  after set_ellipse / set_location"); put(ax); put(ay); put(rho); put(tx); put(ty); printf("\n");
+	p.set_pdfparams(g.log_in(0.05f, 1.0f), g.log_in(0.05f, 1.0f), g.in(-0.9f, 0.9f), g.in(-0.2f, 0.2f), g.in(-0.2f, 0.2f));
+	p.get_ellipse(&a1, &a2, &phi); p.get_location(&tx, &ty);
+	printf("  after set_pdfparams"); put(a1); put(a2); put(phi); put(tx); put(ty); printf("\n");
+	// LEAN / LEADR representation
+	djb::beckmann::lrep l1, l2(g.in(-0.3f, 0.3f), g.in(-0.3f, 0.3f), g.in(0.1f, 1.0f), g.in(0.1f, 1.0f), g.in(-0.05f, 0.05f));
+	djb::beckmann::params_to_lrep(p, &l1);
+	djb::beckmann::lrep l3 = (l1 + l2) * g.in(0.2f, 2.0f);
+	l3 *= g.in(0.5f, 1.5f);
+	l3.shear(g.in(-0.2f, 0.2f), g.in(-0.2f, 0.2f));
+	l3.scale(g.in(0.5f, 2.0f), g.in(0.5f, 2.0f));
+	djb::beckmann::lrep l4 = l2; l4 += l1;
+	djb::microfacet::params q, q2;
+	djb::beckmann::lrep_to_params(l3, &q); djb::beckmann::lrep_to_params(l4, &q2);
+	q.get_pdfparams(&ax, &ay, &rho, &tx, &ty);
+	printf("  lrep"); put(ax); put(ay); put(rho); put(tx); put(ty);
+	q2.get_pdfparams(&ax, &ay, &rho, &tx, &ty);
+	printf(" +="); put(ax); put(ay); put(rho); put(tx); put(ty); printf("\n");
+}
+
+template <class Lobe>
+void lobe_calls(const char *name, rng &g, const Lobe &b)
+{
+	for (int k = 0; k < 3; ++k) {
+		const djb::microfacet::params p = random_params(g);
+		const bool hostile = k == 2;
+		const djb::vec3 i = hostile ? g.any_dir() : g.dir(), o = hostile ? g.any_dir() : g.dir();
+		printf("%s call %d%s\n", name, k, hostile ? " (stray)" : "");
+		show("  eval", b.eval(i, o, &p)); show("  evalp", b.evalp(i, o, &p)); show1("  pdf", b.pdf(i, o, &p));
+		const float u1 = g.u(), u2 = g.u();
+		show("  sample", b.sample(u1, u2, o, &p));
+		djb::vec3 wi; float pdf;
+		show("  evalp_is", b.evalp_is(u1, u2, o, &wi, &pdf, &p)); show("    i", wi); show1("    pdf", pdf);
+		if (!hostile) {
+			djb::vec3 h, d; djb::brdf::io_to_hd(i, o, &h, &d);
+			show("  io_to_hd h", h); show("    d", d);
+			djb::vec3 i2, o2; djb::brdf::hd_to_io(h, d, &i2, &o2);
+			show("  hd_to_io i", i2); show("    o", o2);
+			show("  eval_hd", b.eval_hd(h, d, &p)); show("  evalp_hd", b.evalp_hd(h, d, &p));
+			show1("  ndf", b.ndf(h, p)); show1("  gaf", b.gaf(h, i, o, p)); show1("  g1", b.g1(h, o, p)); show1("  sigma", b.sigma(o, p));
+			const float x = g.in(-2.0f, 2.0f), y = g.in(-2.0f, 2.0f);
+			show1("  p22", b.p22(x, y, p)); show1("  vp22", b.vp22(x, y, o, p)); show1("  vndf", b.vndf(h, o, p));
+		}
+	}
+	const float c = g.u(), r = g.log_in(0.01f, 20.0f), u = g.in(0.001f, 0.999f);
+	show("  fresnel", b.fresnel(c));
+	show1("  p22_radial", b.p22_radial(r * r)); show1("  sigma_std_radial", b.sigma_std_radial(c));
+	show1("  cdf_radial", b.cdf_radial(r)); show1("  qf_radial", b.qf_radial(u));
+}
+
+template <class Lobe>
+void smith_queries(rng &g, const Lobe &b)
+{
+	const float u = g.in(0.001f, 0.999f), c = g.in(0.05f, 0.999f), s = (float)std::sqrt(1.0 - (double)c * c);
+	const float q2 = b.qf2_radial(u, c, s);
+	show1("  qf1", b.qf1(u)); show1("  qf2_radial", q2); show1("  qf3_radial", b.qf3_radial(g.in(0.001f, 0.999f), q2));
+	// microfacet::qf2 / qf3 are not overridden by the radial lobes: the base class throws (dj_brdf.h:1782-1791)
+	const djb::vec3 k = g.dir(0.1f);
+	try { show1("  qf2", b.qf2(u, k)); } catch (const djb::exc &e) { printf("  qf2: %s\n", e.what()); }
+	try { show1("  qf3", b.qf3(u, k, q2)); } catch (const djb::exc &e) { printf("  qf3: %s\n", e.what()); }
+}
+
+void one_seed(unsigned seed, const std::string &scratch)
+{
+	rng g(seed);
+	printf("== seed %u\n", seed);
+	params_round_trip(g);
+	// the two analytic lobes with a random Fresnel term
+	{
+		djb::fresnel::impl *f = random_fresnel(g);
+		const bool shadow = g.below(4) != 0;
+		djb::ggx gx(*f, shadow);
+		djb::beckmann bk(*f, shadow);
+		printf("fresnel(0.37) of the term:"); { const djb::vec3 v = f->eval(0.37f); put(v.x); put(v.y); put(v.z); } printf(" shadow %d\n", (int)gx.get_shadow());
+		lobe_calls("ggx", g, gx); smith_queries(g, gx);
+		lobe_calls("beckmann", g, bk); smith_queries(g, bk);
+		// mutators
+		djb::fresnel::impl *f2 = random_fresnel(g);
+		gx.set_fresnel(*f2); gx.set_shadow(!shadow);
+		show("  after set_fresnel / set_shadow", gx.eval(g.dir(), g.dir()));
+		show("  get_fresnel().eval", gx.get_fresnel().eval(g.u()));
+		// a fit of the lobe as it stands
+		const int res = 8 + g.below(56);
+		djb::tabular tab(bk, res, g.below(2) != 0);
+		float ab, ag;
+		djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&ab, NULL);
+		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
+		printf("tabular(beckmann, %d)", res); put(ab); put(ag); printf("\n");
+		show_table("  p22", tab.get_p22v()); show_table("  sigma", tab.get_sigmav()); show_table("  cdf", tab.get_cdfv()); show_table("  qf", tab.get_qfv());
+		lobe_calls("tabular", g, tab);
+		delete f; delete f2;
+	}
+	// the published models
+	{
+		static const char *const names[6] = { "gold-metallic-paint", "chrome", "blue-fabric", "alum-bronze", "white-marble", "teflon" };
+		const char *name = names[g.below(6)];
+		djb::sgd s(name); djb::abc a(name);
+		const djb::vec3 i = g.dir(), o = g.dir(), h = djb::normalize(i + o);
+		printf("models %s\n", name);
+		show("  sgd.eval", s.eval(i, o)); show("  sgd.ndf", s.ndf(h)); show("  sgd.gaf", s.gaf(h, i, o)); show("  sgd.g1", s.g1(o)); show("  sgd.fresnel", s.fresnel(g.u()));
+		show("  abc.eval", a.eval(i, o)); show("  abc.ndf", a.ndf(h)); show1("  abc.gaf", a.gaf(h, i, o)); show("  abc.fresnel", a.fresnel(g.u()));
+		show("  sgd.eval stray", s.eval(g.any_dir(), g.any_dir())); show("  abc.eval stray", a.eval(g.any_dir(), g.any_dir()));
+		show1("  sgd.pdf", s.pdf(i, o)); show("  abc.sample", a.sample(g.u(), g.u(), o));
+		djb::tabular tab(a, 12 + g.below(30));
+		float ag;
+		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
+		printf("  tabular(abc) ggx"); put(ag); printf("\n");
+		show1("  tab.pdf", tab.pdf(i, o)); show("  tab.sample", tab.sample(g.u(), g.u(), o));
+	}
+	// lambert
+	{
+		djb::lambert l;
+		djb::lambert::params lp(djb::vec3(g.u(), g.u(), g.u()));
+		const djb::vec3 i = g.any_dir(), o = g.any_dir();
+		show("lambert.eval", l.eval(i, o, &lp)); show("  evalp", l.evalp(i, o)); show1("  pdf", l.pdf(i, o)); show("  sample", l.sample(g.u(), g.u(), o));
+	}
+	// a UTIA file written here: look-ups, and an anisotropic fit of it
+	{
+		const std::string path = scratch + "/api_fuzz_utia.bin";
+		std::vector<double> tab(3 * 288 * 288);
+		const double base = g.in(5.0f, 60.0f), gloss = g.in(10.0f, 120.0f), width = g.in(0.5f, 6.0f);
+		for (int c = 0; c < 3; ++c)
+		for (int ti = 0; ti < 6; ++ti) for (int pi = 0; pi < 48; ++pi) for (int tv = 0; tv < 6; ++tv) for (int pv = 0; pv < 48; ++pv) {
+			const int dp = (pi - pv + 72) % 48 - 24, dt = ti - tv;                     // 0 = mirror azimuth, same elevation
+			const double spec = gloss / (1.0 + width * (double)(dp * dp) / 16.0 + 2.0 * (double)(dt * dt));
+			tab[(size_t)c * 288 * 288 + 288 * (48 * ti + pi) + 48 * tv + pv] = base * (1.0 + 0.2 * c) + spec + ((ti * 7 + pi * 3 + tv * 5 + pv) % 11) * 0.25;
+		}
+		if (g.below(3) == 0) tab[(size_t)g.below(3 * 288 * 288)] = -4.0;             // utia::normalize clamps negative samples
+		FILE *f = fopen(path.c_str(), "wb");
+		if (!f || fwrite(&tab[0], sizeof(double), tab.size(), f) != tab.size()) { printf("cannot write %s\n", path.c_str()); exit(2); }
+		fclose(f);
+		djb::utia u(path.c_str());
+		for (int k = 0; k < 4; ++k) { const djb::vec3 i = k == 3 ? g.any_dir() : g.dir(), o = k == 3 ? g.any_dir() : g.dir(); show("utia.eval", u.eval(i, o)); show("  evalp", u.evalp(i, o)); }
+		const int elev = 6 + g.below(6), azim = 8 + g.below(10);
+		djb::tabular_anisotropic ta(u, elev, azim);
+		float v[5];
+		djb::tabular_anisotropic::fit_beckmann_parameters(ta).get_pdfparams(&v[0], &v[1], &v[2], &v[3], &v[4]);
+		printf("tabular_anisotropic(utia, %d, %d) beckmann", elev, azim); for (int k = 0; k < 5; ++k) put(v[k]);
+		djb::tabular_anisotropic::fit_ggx_parameters(ta).get_pdfparams(&v[0], &v[1], &v[2], &v[3], &v[4]);
+		printf(" ggx"); for (int k = 0; k < 5; ++k) put(v[k]); printf("\n");
+		int ec, ac;
+		show_table("  p22", ta.get_p22v(&ec, &ac)); printf("  grid %d %d\n", ec, ac); show_table("  sigma", ta.get_sigmav(&ec, &ac));
+		const float phi = g.in(0.0f, 6.28f), th = g.in(0.0f, 1.5f), w = g.in(0.01f, 0.99f);
+		show1("  pdf1", ta.pdf1(phi)); show1("  cdf1", ta.cdf1(phi)); show1("  qf1", ta.qf1(w));
+		show1("  pdf2", ta.pdf2(th, phi)); show1("  cdf2", ta.cdf2(th, phi)); show1("  qf2", ta.qf2(w, phi));
+		const djb::vec3 i = g.dir(), o = g.dir();
+		const djb::microfacet::params p = random_params(g);
+		show("  eval", ta.eval(i, o, &p)); show1("  pdf", ta.pdf(i, o, &p));
+		djb::vec3 wi; float pdf;
+		show("  evalp_is", ta.evalp_is(g.u(), g.u(), o, &wi, &pdf, &p)); show("    i", wi); show1("    pdf", pdf);
+		remove(path.c_str());
+	}
+	// errors are the reference's
+	try { djb::sgd nope("no-such-material"); printf("no exception\n"); } catch (const djb::exc &e) { printf("exc: %s", e.what()); }
+	try { djb::utia nope((scratch + "/does-not-exist.bin").c_str()); printf("no exception\n"); } catch (const djb::exc &e) { printf("exc raised for a missing file\n"); }
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+	const unsigned first = argc > 1 ? (unsigned)atoi(argv[1]) : 1u, count = argc > 2 ? (unsigned)atoi(argv[2]) : 2u;
+	const std::string scratch = argc > 3 ? argv[3] : "/tmp";
+	for (unsigned s = first; s < first + count; ++s) one_seed(s, scratch);
+	return 0;
+}

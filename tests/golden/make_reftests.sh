@@ -27,5 +27,8 @@ g++ -O2 -ffp-contract=off -DNVERBOSE -w -I"$REF" -o "$W/custom_brdf" "$HERE/../.
 # its randomised companion (random user lobes / Fresnel terms / NDFs, random resolutions and directions): seeds 1..6
 g++ -O2 -ffp-contract=off -DNVERBOSE -w -I"$REF" -o "$W/custom_brdf_fuzz" "$HERE/../../examples/custom_brdf_fuzz.cpp" -lm
 "$W/custom_brdf_fuzz" 1 6 > "$OUT/custom_brdf_fuzz.txt"
+# the library's own classes through the reference's public interface with random arguments (examples/api_fuzz.cpp): seeds 1..4
+g++ -O2 -ffp-contract=off -DNVERBOSE -w -I"$REF" -o "$W/api_fuzz" "$HERE/../../examples/api_fuzz.cpp" -lm
+"$W/api_fuzz" 1 4 "$W" > "$OUT/api_fuzz.txt"
 rm -rf "$W"
 ls -la "$OUT"

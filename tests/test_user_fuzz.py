@@ -1,9 +1,14 @@
-"""Randomised check of the reference's extension points (examples/custom_brdf_fuzz.cpp): user-defined BRDFs of five shapes, a
+"""Randomised whole-program checks against the REAL reference.
+examples/api_fuzz.cpp: the library's own classes through the reference's public interface with random arguments -- both analytic lobes
+with the five Fresnel terms and every parameterisation, every operator and query (stray directions included), mutators, the LEAN
+representation, sgd / abc, lambert, a UTIA file written by the program, isotropic and anisotropic fits, the error messages.
+examples/custom_brdf_fuzz.cpp: the reference's extension points: user-defined BRDFs of five shapes, a
 user-defined Fresnel term and a user-defined radial NDF with random coefficients, fitted (tabular, tabular_anisotropic) at random
 resolutions and evaluated / sampled at random directions; every printed float must equal the REAL reference's, bit for bit.
-  * golden: seeds 1..6 against tests/golden/reftests/custom_brdf_fuzz.txt (written by tests/golden/make_reftests.sh from the reference);
-  * live: further seeds against oracle/_ref/custom_brdf_fuzz -- the same source compiled against /root/reference/dj_brdf.h by
-    oracle/Makefile (test infrastructure; the binary travels to the GPU box, the reference's sources do not)."""
+  * golden: the first seeds against tests/golden/reftests/{custom_brdf_fuzz,api_fuzz}.txt (written by tests/golden/make_reftests.sh from
+    the reference);
+  * live: further seeds against oracle/_ref/{custom_brdf_fuzz,api_fuzz} -- the same sources compiled against /root/reference/dj_brdf.h
+    by oracle/Makefile (test infrastructure; the binaries travel to the GPU box, the reference's sources do not)."""
 import os
 import subprocess
 
@@ -15,10 +20,10 @@ REF = os.path.join(ROOT, "oracle", "_ref", "custom_brdf_fuzz")
 GOLDEN = os.path.join(ROOT, "tests", "golden", "reftests", "custom_brdf_fuzz.txt")
 
 
-def run(exe, first, count, env_extra=None, drop=()):
+def run(exe, first, count, env_extra=None, drop=(), scratch=None):
     env = {k: v for k, v in os.environ.items() if k not in drop}
     env.update(env_extra or {}, DJB_QUIET="1")
-    r = subprocess.run([exe, str(first), str(count)], capture_output=True, timeout=1500, env=env)
+    r = subprocess.run([exe, str(first), str(count)] + ([str(scratch)] if scratch else []), capture_output=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     return r.stdout
 
@@ -61,4 +66,40 @@ def test_user_fuzz_golden_on_gpu():
 def test_user_fuzz_live_on_gpu():
     need(EXE); need(REF)
     want, got = run(REF, 2000, 40), run(EXE, 2000, 40, drop=("DJB_DEVICE",))
+    assert got == want, first_difference(got, want)
+
+
+# ---------------------------------------------------------------------------------------------- the shipped classes (examples/api_fuzz.cpp)
+API_EXE = os.path.join(ROOT, "examples", "api_fuzz")
+API_REF = os.path.join(ROOT, "oracle", "_ref", "api_fuzz")
+API_GOLDEN = os.path.join(ROOT, "tests", "golden", "reftests", "api_fuzz.txt")
+
+
+def test_api_fuzz_golden_on_host_path(tmp_path):
+    need(API_EXE)
+    got = run(API_EXE, 1, 4, {"DJB_DEVICE": "cpu"}, scratch=tmp_path)
+    assert got == open(API_GOLDEN, "rb").read(), first_difference(got, open(API_GOLDEN, "rb").read())
+
+
+def test_api_fuzz_live_on_host_path(tmp_path):
+    need(API_EXE); need(API_REF)
+    want, got = run(API_REF, 5000, 30, scratch=tmp_path), run(API_EXE, 5000, 30, {"DJB_DEVICE": "cpu"}, scratch=tmp_path)
+    assert want.count(b"== seed") == 30
+    assert got == want, first_difference(got, want)
+
+
+@pytest.mark.gpu
+def test_api_fuzz_golden_on_gpu(tmp_path):
+    need(API_EXE)
+    got = run(API_EXE, 1, 4, drop=("DJB_DEVICE",), scratch=tmp_path)
+    assert got == open(API_GOLDEN, "rb").read(), first_difference(got, open(API_GOLDEN, "rb").read())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scalar_on_device", ["0", "1"])
+def test_api_fuzz_live_on_gpu(tmp_path, scalar_on_device):
+    """one-pair calls answered by the host twin of the GPU objects (default) and sent through the kernels (DJB_SCALAR_ON_DEVICE=1)"""
+    need(API_EXE); need(API_REF)
+    want = run(API_REF, 6000, 30, scratch=tmp_path)
+    got = run(API_EXE, 6000, 30, {"DJB_SCALAR_ON_DEVICE": scalar_on_device}, drop=("DJB_DEVICE",), scratch=tmp_path)
     assert got == want, first_difference(got, want)

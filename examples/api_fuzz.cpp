@@ -3,10 +3,9 @@
 // written by the program itself, isotropic and anisotropic fits.  Every result is printed bit for bit.
 //
 // Written against the REFERENCE's interface only; compiles unchanged against either header and must print the same bytes per seed:
-//   api_fuzz <first seed> <number of seeds> [scratch directory]
+//   api_fuzz <first seed> <number of seeds> [scratch directory [merl]]      (merl: each seed also writes and fits a 35 MB MERL file)
 //   g++ -I/root/reference -> the reference (oracle/Makefile: oracle/_ref/api_fuzz; seeds 1..4 kept as tests/golden/reftests/api_fuzz.txt)
 //   g++ -I include -ldjb_hip -> this repository (host path or GPU)
-// (MERL files are 35 MB each and have their own programs: examples/merl_params.cpp, tests/test_gpu_golden.py.)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -163,7 +162,7 @@ void smith_queries(rng &g, const Lobe &b)
 	try { show1("  qf3", b.qf3(u, k, q2)); } catch (const djb::exc &e) { printf("  qf3: %s\n", e.what()); }
 }
 
-void one_seed(unsigned seed, const std::string &scratch)
+void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 {
 	rng g(seed);
 	printf("== seed %u\n", seed);
@@ -253,6 +252,47 @@ void one_seed(unsigned seed, const std::string &scratch)
 		show("  evalp_is", ta.evalp_is(g.u(), g.u(), o, &wi, &pdf, &p)); show("    i", wi); show1("    pdf", pdf);
 		remove(path.c_str());
 	}
+	// optional (35 MB per seed): a MERL file written here -- nearest-bin look-ups, the samples, a fit at a random resolution
+	if (with_merl) {
+		const std::string path = scratch + "/api_fuzz_merl.binary";
+		const int dims[3] = { 90, 90, 180 };
+		const size_t n = 90u * 90u * 180u;
+		std::vector<double> tab(3 * n);
+		const double alpha = g.log_in(0.03f, 0.6f), kd = g.in(0.0f, 0.4f), a2 = alpha * alpha;
+		const uint64_t salt = g.bits();
+		for (int th = 0; th < 90; ++th) for (int td = 0; td < 90; ++td) for (int pd = 0; pd < 180; ++pd) {
+			const size_t k = (size_t)pd + 180u * ((size_t)td + 90u * (size_t)th);
+			const double theta_h = (double)(th * th) / 8100.0 * 1.5707963267948966;             // MERL's non-linear theta_h bins
+			const double t = std::tan(theta_h), c = std::cos(theta_h);
+			const double d = a2 / (3.141592653589793 * c * c * c * c * (a2 + t * t) * (a2 + t * t) + 1e-300);
+			const double fr = 0.04 + 0.96 * std::pow(1.0 - std::cos((double)td * 0.017453292519943295), 5.0);
+			uint64_t hsh = (k + 1) * 0x9E3779B97F4A7C15ull ^ salt; hsh ^= hsh >> 29; hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 32;
+			const double noise = 1.0 + 0.1 * ((double)(hsh & 0xffff) / 65536.0 - 0.5);
+			const bool hole = (hsh >> 20) % 257 == 0;                                               // MERL marks invalid bins with negative samples
+			for (int ch = 0; ch < 3; ++ch) {
+				const double scale = ch == 0 ? 1500.0 : (ch == 1 ? 1500.0 / 1.15 : 1500.0 / 1.66);
+				tab[ch * n + k] = hole ? -1.0 : (kd * (1.0 - 0.2 * ch) / 3.141592653589793 + fr * d * 0.25 * (1.0 + 0.001 * pd)) * noise * scale;
+			}
+		}
+		FILE *f = fopen(path.c_str(), "wb");
+		if (!f || fwrite(dims, sizeof(int), 3, f) != 3 || fwrite(&tab[0], sizeof(double), tab.size(), f) != tab.size()) { printf("cannot write %s\n", path.c_str()); exit(2); }
+		fclose(f);
+		djb::merl m(path.c_str());
+		printf("merl alpha %a samples %d", (float)alpha, (int)m.get_samples().size());
+		{ const std::vector<double> &sm = m.get_samples(); double acc = 0; for (size_t k = 0; k < sm.size(); k += 9973) acc += sm[k]; printf(" sum %a\n", acc); }
+		for (int k = 0; k < 6; ++k) { const djb::vec3 i = k == 5 ? g.any_dir() : g.dir(), o = k == 5 ? g.any_dir() : g.dir(); show("  eval", m.eval(i, o)); show("  evalp", m.evalp(i, o)); }
+		const int res = 16 + g.below(90);
+		djb::tabular tab_m(m, res, g.below(2) != 0);
+		float ab, ag;
+		djb::tabular::fit_beckmann_parameters(tab_m).get_ellipse(&ab, NULL);
+		djb::tabular::fit_ggx_parameters(tab_m).get_ellipse(&ag, NULL);
+		printf("  tabular(merl, %d)", res); put(ab); put(ag); printf("\n");
+		show_table("  p22", tab_m.get_p22v()); show_table("  sigma", tab_m.get_sigmav()); show_table("  cdf", tab_m.get_cdfv()); show_table("  qf", tab_m.get_qfv());
+		show("  fitted fresnel", tab_m.fresnel(g.u()));
+		const djb::vec3 i = g.dir(), o = g.dir();
+		show("  tab.eval", tab_m.eval(i, o)); show1("  tab.pdf", tab_m.pdf(i, o)); show("  tab.sample", tab_m.sample(g.u(), g.u(), o));
+		remove(path.c_str());
+	}
 	// errors are the reference's
 	try { djb::sgd nope("no-such-material"); printf("no exception\n"); } catch (const djb::exc &e) { printf("exc: %s", e.what()); }
 	try { djb::utia nope((scratch + "/does-not-exist.bin").c_str()); printf("no exception\n"); } catch (const djb::exc &e) { printf("exc raised for a missing file\n"); }
@@ -264,6 +304,7 @@ int main(int argc, char **argv)
 {
 	const unsigned first = argc > 1 ? (unsigned)atoi(argv[1]) : 1u, count = argc > 2 ? (unsigned)atoi(argv[2]) : 2u;
 	const std::string scratch = argc > 3 ? argv[3] : "/tmp";
-	for (unsigned s = first; s < first + count; ++s) one_seed(s, scratch);
+	const bool with_merl = argc > 4 && !strcmp(argv[4], "merl");
+	for (unsigned s = first; s < first + count; ++s) one_seed(s, scratch, with_merl);
 	return 0;
 }

@@ -20,10 +20,10 @@ REF = os.path.join(ROOT, "oracle", "_ref", "custom_brdf_fuzz")
 GOLDEN = os.path.join(ROOT, "tests", "golden", "reftests", "custom_brdf_fuzz.txt")
 
 
-def run(exe, first, count, env_extra=None, drop=(), scratch=None):
+def run(exe, first, count, env_extra=None, drop=(), scratch=None, merl=False):
     env = {k: v for k, v in os.environ.items() if k not in drop}
     env.update(env_extra or {}, DJB_QUIET="1")
-    r = subprocess.run([exe, str(first), str(count)] + ([str(scratch)] if scratch else []), capture_output=True, timeout=1500, env=env)
+    r = subprocess.run([exe, str(first), str(count)] + ([str(scratch)] if scratch else []) + (["merl"] if merl else []), capture_output=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     return r.stdout
 
@@ -102,4 +102,21 @@ def test_api_fuzz_live_on_gpu(tmp_path, scalar_on_device):
     need(API_EXE); need(API_REF)
     want = run(API_REF, 6000, 30, scratch=tmp_path)
     got = run(API_EXE, 6000, 30, {"DJB_SCALAR_ON_DEVICE": scalar_on_device}, drop=("DJB_DEVICE",), scratch=tmp_path)
+    assert got == want, first_difference(got, want)
+
+
+def test_api_fuzz_with_merl_files_on_host_path(tmp_path):
+    """each seed also writes a 35 MB MERL file (a noisy GGX-like table with invalid bins), looks it up and fits it at a random resolution"""
+    need(API_EXE); need(API_REF)
+    want, got = run(API_REF, 8000, 4, scratch=tmp_path, merl=True), run(API_EXE, 8000, 4, {"DJB_DEVICE": "cpu"}, scratch=tmp_path, merl=True)
+    assert want.count(b"tabular(merl") == 4
+    assert got == want, first_difference(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scalar_on_device", ["0", "1"])
+def test_api_fuzz_with_merl_files_on_gpu(tmp_path, scalar_on_device):
+    need(API_EXE); need(API_REF)
+    want = run(API_REF, 9000, 6, scratch=tmp_path, merl=True)
+    got = run(API_EXE, 9000, 6, {"DJB_SCALAR_ON_DEVICE": scalar_on_device}, drop=("DJB_DEVICE",), scratch=tmp_path, merl=True)
     assert got == want, first_difference(got, want)

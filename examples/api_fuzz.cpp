@@ -3,7 +3,8 @@
 // written by the program itself, isotropic and anisotropic fits.  Every result is printed bit for bit.
 //
 // Written against the REFERENCE's interface only; compiles unchanged against either header and must print the same bytes per seed:
-//   api_fuzz <first seed> <number of seeds> [scratch directory [merl]]      (merl: each seed also writes and fits a 35 MB MERL file)
+//   api_fuzz <first seed> <number of seeds> [scratch directory [merl] [threads=N]]
+//     merl: each seed also writes and fits a 35 MB MERL file;  threads=N: the seeds run concurrently on N host threads (same output)
 //   g++ -I/root/reference -> the reference (oracle/Makefile: oracle/_ref/api_fuzz; seeds 1..4 kept as tests/golden/reftests/api_fuzz.txt)
 //   g++ -I include -ldjb_hip -> this repository (host path or GPU)
 #include <cmath>
@@ -13,11 +14,17 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <thread>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #define DJ_BRDF_IMPLEMENTATION 1
 #include "dj_brdf.h"
 
 namespace {
+
+// every line goes through `out`: stdout, or (threads mode) a buffer of the seed's own, printed in seed order afterwards
+thread_local FILE *out = stdout;
 
 struct rng {                                     // splitmix64: the same stream on every machine
 	uint64_t s;
@@ -47,9 +54,9 @@ struct rng {                                     // splitmix64: the same stream 
 	}
 };
 
-void put(float v) { if (v != v) printf(" nan"); else printf(" %a", v); }
-void show(const char *tag, const djb::vec3 &v) { printf("%s", tag); put(v.x); put(v.y); put(v.z); printf("\n"); }
-void show1(const char *tag, float v) { printf("%s", tag); put(v); printf("\n"); }
+void put(float v) { if (v != v) fprintf(out, " nan"); else fprintf(out, " %a", v); }
+void show(const char *tag, const djb::vec3 &v) { fprintf(out, "%s", tag); put(v.x); put(v.y); put(v.z); fprintf(out, "\n"); }
+void show1(const char *tag, float v) { fprintf(out, "%s", tag); put(v); fprintf(out, "\n"); }
 void show_table(const char *tag, const std::vector<djb::float_t> &v)
 {
 	uint64_t h = 0xcbf29ce484222325ull;
@@ -58,9 +65,9 @@ void show_table(const char *tag, const std::vector<djb::float_t> &v)
 		if (f != f) w = 0x7fc00000u;
 		for (int b = 0; b < 4; ++b) { h ^= (w >> (8 * b)) & 0xffu; h *= 0x100000001b3ull; }
 	}
-	printf("%s n=%d fnv=%016llx", tag, (int)v.size(), (unsigned long long)h);
+	fprintf(out, "%s n=%d fnv=%016llx", tag, (int)v.size(), (unsigned long long)h);
 	if (!v.empty()) { put(v[0]); put(v[v.size() / 2]); put(v.back()); }
-	printf("\n");
+	fprintf(out, "\n");
 }
 
 djb::microfacet::params random_params(rng &g)
@@ -95,15 +102,15 @@ void params_round_trip(rng &g)
 	djb::microfacet::params p = random_params(g);
 	float a1, a2, phi, ax, ay, rho, tx, ty;
 	p.get_ellipse(&a1, &a2, &phi); p.get_pdfparams(&ax, &ay, &rho, &tx, &ty);
-	printf("params ellipse"); put(a1); put(a2); put(phi); printf(" pdf"); put(ax); put(ay); put(rho); put(tx); put(ty); printf("\n");
+	fprintf(out, "params ellipse"); put(a1); put(a2); put(phi); fprintf(out, " pdf"); put(ax); put(ay); put(rho); put(tx); put(ty); fprintf(out, "\n");
 	djb::vec3 n; p.get_location(&n); show("  location", n);
 	p.set_ellipse(g.log_in(0.05f, 1.0f), g.log_in(0.05f, 1.0f), g.in(-3.0f, 3.0f));
 	p.set_location(djb::normalize(djb::vec3(g.in(-0.3f, 0.3f), g.in(-0.3f, 0.3f), 1.0f)));
 	p.get_pdfparams(&ax, &ay, &rho, &tx, &ty);
-	printf("  after set_ellipse / set_location"); put(ax); put(ay); put(rho); put(tx); put(ty); printf("\n");
+	fprintf(out, "  after set_ellipse / set_location"); put(ax); put(ay); put(rho); put(tx); put(ty); fprintf(out, "\n");
 	p.set_pdfparams(g.log_in(0.05f, 1.0f), g.log_in(0.05f, 1.0f), g.in(-0.9f, 0.9f), g.in(-0.2f, 0.2f), g.in(-0.2f, 0.2f));
 	p.get_ellipse(&a1, &a2, &phi); p.get_location(&tx, &ty);
-	printf("  after set_pdfparams"); put(a1); put(a2); put(phi); put(tx); put(ty); printf("\n");
+	fprintf(out, "  after set_pdfparams"); put(a1); put(a2); put(phi); put(tx); put(ty); fprintf(out, "\n");
 	// LEAN / LEADR representation
 	djb::beckmann::lrep l1, l2(g.in(-0.3f, 0.3f), g.in(-0.3f, 0.3f), g.in(0.1f, 1.0f), g.in(0.1f, 1.0f), g.in(-0.05f, 0.05f));
 	djb::beckmann::params_to_lrep(p, &l1);
@@ -115,9 +122,9 @@ void params_round_trip(rng &g)
 	djb::microfacet::params q, q2;
 	djb::beckmann::lrep_to_params(l3, &q); djb::beckmann::lrep_to_params(l4, &q2);
 	q.get_pdfparams(&ax, &ay, &rho, &tx, &ty);
-	printf("  lrep"); put(ax); put(ay); put(rho); put(tx); put(ty);
+	fprintf(out, "  lrep"); put(ax); put(ay); put(rho); put(tx); put(ty);
 	q2.get_pdfparams(&ax, &ay, &rho, &tx, &ty);
-	printf(" +="); put(ax); put(ay); put(rho); put(tx); put(ty); printf("\n");
+	fprintf(out, " +="); put(ax); put(ay); put(rho); put(tx); put(ty); fprintf(out, "\n");
 }
 
 template <class Lobe>
@@ -127,7 +134,7 @@ void lobe_calls(const char *name, rng &g, const Lobe &b)
 		const djb::microfacet::params p = random_params(g);
 		const bool hostile = k == 2;
 		const djb::vec3 i = hostile ? g.any_dir() : g.dir(), o = hostile ? g.any_dir() : g.dir();
-		printf("%s call %d%s\n", name, k, hostile ? " (stray)" : "");
+		fprintf(out, "%s call %d%s\n", name, k, hostile ? " (stray)" : "");
 		show("  eval", b.eval(i, o, &p)); show("  evalp", b.evalp(i, o, &p)); show1("  pdf", b.pdf(i, o, &p));
 		const float u1 = g.u(), u2 = g.u();
 		show("  sample", b.sample(u1, u2, o, &p));
@@ -158,14 +165,14 @@ void smith_queries(rng &g, const Lobe &b)
 	show1("  qf1", b.qf1(u)); show1("  qf2_radial", q2); show1("  qf3_radial", b.qf3_radial(g.in(0.001f, 0.999f), q2));
 	// microfacet::qf2 / qf3 are not overridden by the radial lobes: the base class throws (dj_brdf.h:1782-1791)
 	const djb::vec3 k = g.dir(0.1f);
-	try { show1("  qf2", b.qf2(u, k)); } catch (const djb::exc &e) { printf("  qf2: %s\n", e.what()); }
-	try { show1("  qf3", b.qf3(u, k, q2)); } catch (const djb::exc &e) { printf("  qf3: %s\n", e.what()); }
+	try { show1("  qf2", b.qf2(u, k)); } catch (const djb::exc &e) { fprintf(out, "  qf2: %s\n", e.what()); }
+	try { show1("  qf3", b.qf3(u, k, q2)); } catch (const djb::exc &e) { fprintf(out, "  qf3: %s\n", e.what()); }
 }
 
 void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 {
 	rng g(seed);
-	printf("== seed %u\n", seed);
+	fprintf(out, "== seed %u\n", seed);
 	params_round_trip(g);
 	// the two analytic lobes with a random Fresnel term
 	{
@@ -173,7 +180,7 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		const bool shadow = g.below(4) != 0;
 		djb::ggx gx(*f, shadow);
 		djb::beckmann bk(*f, shadow);
-		printf("fresnel(0.37) of the term:"); { const djb::vec3 v = f->eval(0.37f); put(v.x); put(v.y); put(v.z); } printf(" shadow %d\n", (int)gx.get_shadow());
+		fprintf(out, "fresnel(0.37) of the term:"); { const djb::vec3 v = f->eval(0.37f); put(v.x); put(v.y); put(v.z); } fprintf(out, " shadow %d\n", (int)gx.get_shadow());
 		lobe_calls("ggx", g, gx); smith_queries(g, gx);
 		lobe_calls("beckmann", g, bk); smith_queries(g, bk);
 		// mutators
@@ -187,7 +194,7 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		float ab, ag;
 		djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&ab, NULL);
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
-		printf("tabular(beckmann, %d)", res); put(ab); put(ag); printf("\n");
+		fprintf(out, "tabular(beckmann, %d)", res); put(ab); put(ag); fprintf(out, "\n");
 		show_table("  p22", tab.get_p22v()); show_table("  sigma", tab.get_sigmav()); show_table("  cdf", tab.get_cdfv()); show_table("  qf", tab.get_qfv());
 		lobe_calls("tabular", g, tab);
 		delete f; delete f2;
@@ -198,7 +205,7 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		const char *name = names[g.below(6)];
 		djb::sgd s(name); djb::abc a(name);
 		const djb::vec3 i = g.dir(), o = g.dir(), h = djb::normalize(i + o);
-		printf("models %s\n", name);
+		fprintf(out, "models %s\n", name);
 		show("  sgd.eval", s.eval(i, o)); show("  sgd.ndf", s.ndf(h)); show("  sgd.gaf", s.gaf(h, i, o)); show("  sgd.g1", s.g1(o)); show("  sgd.fresnel", s.fresnel(g.u()));
 		show("  abc.eval", a.eval(i, o)); show("  abc.ndf", a.ndf(h)); show1("  abc.gaf", a.gaf(h, i, o)); show("  abc.fresnel", a.fresnel(g.u()));
 		show("  sgd.eval stray", s.eval(g.any_dir(), g.any_dir())); show("  abc.eval stray", a.eval(g.any_dir(), g.any_dir()));
@@ -206,7 +213,7 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		djb::tabular tab(a, 12 + g.below(30));
 		float ag;
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
-		printf("  tabular(abc) ggx"); put(ag); printf("\n");
+		fprintf(out, "  tabular(abc) ggx"); put(ag); fprintf(out, "\n");
 		show1("  tab.pdf", tab.pdf(i, o)); show("  tab.sample", tab.sample(g.u(), g.u(), o));
 	}
 	// lambert
@@ -229,7 +236,7 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		}
 		if (g.below(3) == 0) tab[(size_t)g.below(3 * 288 * 288)] = -4.0;             // utia::normalize clamps negative samples
 		FILE *f = fopen(path.c_str(), "wb");
-		if (!f || fwrite(&tab[0], sizeof(double), tab.size(), f) != tab.size()) { printf("cannot write %s\n", path.c_str()); exit(2); }
+		if (!f || fwrite(&tab[0], sizeof(double), tab.size(), f) != tab.size()) { fprintf(out, "cannot write %s\n", path.c_str()); exit(2); }
 		fclose(f);
 		djb::utia u(path.c_str());
 		for (int k = 0; k < 4; ++k) { const djb::vec3 i = k == 3 ? g.any_dir() : g.dir(), o = k == 3 ? g.any_dir() : g.dir(); show("utia.eval", u.eval(i, o)); show("  evalp", u.evalp(i, o)); }
@@ -237,11 +244,11 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		djb::tabular_anisotropic ta(u, elev, azim);
 		float v[5];
 		djb::tabular_anisotropic::fit_beckmann_parameters(ta).get_pdfparams(&v[0], &v[1], &v[2], &v[3], &v[4]);
-		printf("tabular_anisotropic(utia, %d, %d) beckmann", elev, azim); for (int k = 0; k < 5; ++k) put(v[k]);
+		fprintf(out, "tabular_anisotropic(utia, %d, %d) beckmann", elev, azim); for (int k = 0; k < 5; ++k) put(v[k]);
 		djb::tabular_anisotropic::fit_ggx_parameters(ta).get_pdfparams(&v[0], &v[1], &v[2], &v[3], &v[4]);
-		printf(" ggx"); for (int k = 0; k < 5; ++k) put(v[k]); printf("\n");
+		fprintf(out, " ggx"); for (int k = 0; k < 5; ++k) put(v[k]); fprintf(out, "\n");
 		int ec, ac;
-		show_table("  p22", ta.get_p22v(&ec, &ac)); printf("  grid %d %d\n", ec, ac); show_table("  sigma", ta.get_sigmav(&ec, &ac));
+		show_table("  p22", ta.get_p22v(&ec, &ac)); fprintf(out, "  grid %d %d\n", ec, ac); show_table("  sigma", ta.get_sigmav(&ec, &ac));
 		const float phi = g.in(0.0f, 6.28f), th = g.in(0.0f, 1.5f), w = g.in(0.01f, 0.99f);
 		show1("  pdf1", ta.pdf1(phi)); show1("  cdf1", ta.cdf1(phi)); show1("  qf1", ta.qf1(w));
 		show1("  pdf2", ta.pdf2(th, phi)); show1("  cdf2", ta.cdf2(th, phi)); show1("  qf2", ta.qf2(w, phi));
@@ -275,18 +282,18 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 			}
 		}
 		FILE *f = fopen(path.c_str(), "wb");
-		if (!f || fwrite(dims, sizeof(int), 3, f) != 3 || fwrite(&tab[0], sizeof(double), tab.size(), f) != tab.size()) { printf("cannot write %s\n", path.c_str()); exit(2); }
+		if (!f || fwrite(dims, sizeof(int), 3, f) != 3 || fwrite(&tab[0], sizeof(double), tab.size(), f) != tab.size()) { fprintf(out, "cannot write %s\n", path.c_str()); exit(2); }
 		fclose(f);
 		djb::merl m(path.c_str());
-		printf("merl alpha %a samples %d", (float)alpha, (int)m.get_samples().size());
-		{ const std::vector<double> &sm = m.get_samples(); double acc = 0; for (size_t k = 0; k < sm.size(); k += 9973) acc += sm[k]; printf(" sum %a\n", acc); }
+		fprintf(out, "merl alpha %a samples %d", (float)alpha, (int)m.get_samples().size());
+		{ const std::vector<double> &sm = m.get_samples(); double acc = 0; for (size_t k = 0; k < sm.size(); k += 9973) acc += sm[k]; fprintf(out, " sum %a\n", acc); }
 		for (int k = 0; k < 6; ++k) { const djb::vec3 i = k == 5 ? g.any_dir() : g.dir(), o = k == 5 ? g.any_dir() : g.dir(); show("  eval", m.eval(i, o)); show("  evalp", m.evalp(i, o)); }
 		const int res = 16 + g.below(90);
 		djb::tabular tab_m(m, res, g.below(2) != 0);
 		float ab, ag;
 		djb::tabular::fit_beckmann_parameters(tab_m).get_ellipse(&ab, NULL);
 		djb::tabular::fit_ggx_parameters(tab_m).get_ellipse(&ag, NULL);
-		printf("  tabular(merl, %d)", res); put(ab); put(ag); printf("\n");
+		fprintf(out, "  tabular(merl, %d)", res); put(ab); put(ag); fprintf(out, "\n");
 		show_table("  p22", tab_m.get_p22v()); show_table("  sigma", tab_m.get_sigmav()); show_table("  cdf", tab_m.get_cdfv()); show_table("  qf", tab_m.get_qfv());
 		show("  fitted fresnel", tab_m.fresnel(g.u()));
 		const djb::vec3 i = g.dir(), o = g.dir();
@@ -294,17 +301,44 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		remove(path.c_str());
 	}
 	// errors are the reference's
-	try { djb::sgd nope("no-such-material"); printf("no exception\n"); } catch (const djb::exc &e) { printf("exc: %s", e.what()); }
-	try { djb::utia nope((scratch + "/does-not-exist.bin").c_str()); printf("no exception\n"); } catch (const djb::exc &e) { printf("exc raised for a missing file\n"); }
+	try { djb::sgd nope("no-such-material"); fprintf(out, "no exception\n"); } catch (const djb::exc &e) { fprintf(out, "exc: %s", e.what()); }
+	try { djb::utia nope((scratch + "/does-not-exist.bin").c_str()); fprintf(out, "no exception\n"); } catch (const djb::exc &e) { fprintf(out, "exc raised for a missing file\n"); }
 }
 
 } // namespace
+
+// one seed into a buffer of its own
+std::string seed_to_string(unsigned seed, const std::string &scratch, bool with_merl)
+{
+	char *buf = NULL; size_t len = 0;
+	FILE *f = open_memstream(&buf, &len);
+	out = f;
+	char sub[32]; snprintf(sub, sizeof sub, "/s%u", seed);                 // the files the seed writes: a name of its own
+	mkdir((scratch + sub).c_str(), 0777);
+	one_seed(seed, scratch + sub, with_merl);
+	rmdir((scratch + sub).c_str());
+	fclose(f); out = stdout;
+	std::string r(buf, len); free(buf);
+	return r;
+}
 
 int main(int argc, char **argv)
 {
 	const unsigned first = argc > 1 ? (unsigned)atoi(argv[1]) : 1u, count = argc > 2 ? (unsigned)atoi(argv[2]) : 2u;
 	const std::string scratch = argc > 3 ? argv[3] : "/tmp";
-	const bool with_merl = argc > 4 && !strcmp(argv[4], "merl");
-	for (unsigned s = first; s < first + count; ++s) one_seed(s, scratch, with_merl);
+	bool with_merl = false; int threads = 0;
+	for (int a = 4; a < argc; ++a) { if (!strcmp(argv[a], "merl")) with_merl = true; else if (!strncmp(argv[a], "threads=", 8)) threads = atoi(argv[a] + 8); }
+	if (threads <= 0) {
+		for (unsigned s = first; s < first + count; ++s) one_seed(s, scratch, with_merl);
+		return 0;
+	}
+	// threads=N: the seeds are dealt to N host threads that share the process's default context and run CONCURRENTLY; the output is
+	// printed in seed order and must be the sequential run's
+	std::vector<std::string> text(count);
+	std::vector<std::thread> pool;
+	for (int t = 0; t < threads; ++t)
+		pool.push_back(std::thread([&, t]() { for (unsigned k = (unsigned)t; k < count; k += (unsigned)threads) text[k] = seed_to_string(first + k, scratch, with_merl); }));
+	for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
+	for (unsigned k = 0; k < count; ++k) fputs(text[k].c_str(), stdout);
 	return 0;
 }

@@ -2,7 +2,7 @@
 // parameters, fitted at random resolutions and evaluated at random directions, every result printed bit for bit.
 //
 // Written against the REFERENCE's interface only; it compiles unchanged against either header and must print the same bytes for the
-// same seeds:   custom_brdf_fuzz <first seed> <number of seeds>
+// same seeds:   custom_brdf_fuzz <first seed> <number of seeds> [threads=N]      (threads=N: the seeds run concurrently, same output)
 //   g++ -I/root/reference -> the reference (tests/golden/make_reftests.sh keeps the output of seeds 1..6 as a fixture;
 //                            tests/test_user_fuzz.py compares more seeds live where the reference is present)
 //   g++ -I include -ldjb_hip -> this repository (host path or GPU)
@@ -12,12 +12,17 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdint.h>
+#include <string>
 #include <vector>
+#include <thread>
 
 #define DJ_BRDF_IMPLEMENTATION 1
 #include "dj_brdf.h"
 
 namespace {
+
+// every line goes through `out`: stdout, or (threads mode) a buffer of the seed's own, printed in seed order afterwards
+thread_local FILE *out = stdout;
 
 struct rng {                                     // splitmix64: the same stream on every machine
 	uint64_t s;
@@ -104,8 +109,8 @@ private:
 	float m_g;
 };
 
-void put(float v) { if (v != v) printf(" nan"); else printf(" %a", v); }          // the sign of a NaN is not part of the contract
-void show(const char *tag, const djb::vec3 &v) { printf("%s", tag); put(v.x); put(v.y); put(v.z); printf("\n"); }
+void put(float v) { if (v != v) fprintf(out, " nan"); else fprintf(out, " %a", v); }          // the sign of a NaN is not part of the contract
+void show(const char *tag, const djb::vec3 &v) { fprintf(out, "%s", tag); put(v.x); put(v.y); put(v.z); fprintf(out, "\n"); }
 void show_table(const char *tag, const std::vector<djb::float_t> &v)
 {
 	uint64_t h = 0xcbf29ce484222325ull;
@@ -114,15 +119,15 @@ void show_table(const char *tag, const std::vector<djb::float_t> &v)
 		if (f != f) w = 0x7fc00000u;
 		for (int b = 0; b < 4; ++b) { h ^= (w >> (8 * b)) & 0xffu; h *= 0x100000001b3ull; }
 	}
-	printf("%s n=%d fnv=%016llx", tag, (int)v.size(), (unsigned long long)h);
+	fprintf(out, "%s n=%d fnv=%016llx", tag, (int)v.size(), (unsigned long long)h);
 	if (!v.empty()) { put(v[0]); put(v[v.size() / 2]); put(v.back()); }
-	printf("\n");
+	fprintf(out, "\n");
 }
 
 void one_seed(unsigned seed)
 {
 	rng g(seed);
-	printf("== seed %u\n", seed);
+	fprintf(out, "== seed %u\n", seed);
 	// 1. an isotropic fit of a random lobe at a random resolution
 	{
 		lobe l(g);
@@ -132,20 +137,20 @@ void one_seed(unsigned seed)
 		float ab, ag;
 		djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&ab, NULL);
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
-		printf("tabular(shape %d, %d, %d):", l.shape(), res, (int)shadow); put(ab); put(ag); printf("\n");
+		fprintf(out, "tabular(shape %d, %d, %d):", l.shape(), res, (int)shadow); put(ab); put(ag); fprintf(out, "\n");
 		show_table("  p22", tab.get_p22v()); show_table("  sigma", tab.get_sigmav());
 		show_table("  cdf", tab.get_cdfv()); show_table("  qf", tab.get_qfv());
 		for (int k = 0; k < 3; ++k) {
 			const djb::vec3 i = g.dir(), o = g.dir();
 			djb::microfacet::params pr = djb::microfacet::params::elliptic(g.log_in(0.05f, 1.5f), g.log_in(0.05f, 1.5f), g.in(0.0f, 3.0f));
-			show("  eval", tab.eval(i, o, k ? &pr : NULL)); printf("  pdf"); put(tab.pdf(i, o, k ? &pr : NULL)); printf("\n");
+			show("  eval", tab.eval(i, o, k ? &pr : NULL)); fprintf(out, "  pdf"); put(tab.pdf(i, o, k ? &pr : NULL)); fprintf(out, "\n");
 			djb::vec3 wi; float pdf;
-			show("  evalp_is", tab.evalp_is(g.u(), g.u(), o, &wi, &pdf, k ? &pr : NULL)); show("    i", wi); printf("    pdf"); put(pdf); printf("\n");
+			show("  evalp_is", tab.evalp_is(g.u(), g.u(), o, &wi, &pdf, k ? &pr : NULL)); show("    i", wi); fprintf(out, "    pdf"); put(pdf); fprintf(out, "\n");
 			show("  fresnel", tab.fresnel(g.u()));
 		}
 		// the base-class operators of the user's own object
 		const djb::vec3 i = g.dir(), o = g.dir();
-		show("  lobe.evalp", l.evalp(i, o)); printf("  lobe.pdf"); put(l.pdf(i, o)); printf("\n");
+		show("  lobe.evalp", l.evalp(i, o)); fprintf(out, "  lobe.pdf"); put(l.pdf(i, o)); fprintf(out, "\n");
 		djb::vec3 wi; float pdf;
 		show("  lobe.evalp_is", l.evalp_is(g.u(), g.u(), o, &wi, &pdf)); show("    i", wi);
 	}
@@ -156,11 +161,11 @@ void one_seed(unsigned seed)
 		djb::tabular_anisotropic tab(l, elev, azim);
 		float v[5];
 		djb::tabular_anisotropic::fit_beckmann_parameters(tab).get_pdfparams(&v[0], &v[1], &v[2], &v[3], &v[4]);
-		printf("tabular_anisotropic(shape %d, %d, %d) beckmann", l.shape(), elev, azim); for (int k = 0; k < 5; ++k) put(v[k]); printf("\n");
+		fprintf(out, "tabular_anisotropic(shape %d, %d, %d) beckmann", l.shape(), elev, azim); for (int k = 0; k < 5; ++k) put(v[k]); fprintf(out, "\n");
 		djb::tabular_anisotropic::fit_ggx_parameters(tab).get_pdfparams(&v[0], &v[1], &v[2], &v[3], &v[4]);
-		printf("  ggx"); for (int k = 0; k < 5; ++k) put(v[k]); printf("\n");
+		fprintf(out, "  ggx"); for (int k = 0; k < 5; ++k) put(v[k]); fprintf(out, "\n");
 		const djb::vec3 i = g.dir(), o = g.dir();
-		show("  eval", tab.eval(i, o)); printf("  pdf"); put(tab.pdf(i, o)); printf("\n");
+		show("  eval", tab.eval(i, o)); fprintf(out, "  pdf"); put(tab.pdf(i, o)); fprintf(out, "\n");
 		djb::vec3 wi; float pdf;
 		show("  evalp_is", tab.evalp_is(g.u(), g.u(), o, &wi, &pdf)); show("    i", wi);
 	}
@@ -174,12 +179,12 @@ void one_seed(unsigned seed)
 			const djb::vec3 i = g.dir(), o = g.dir();
 			show("ggx(user F).eval", gx.eval(i, o, &pr)); show("  beckmann.evalp", bk.evalp(i, o, &pr));
 			djb::vec3 wi; float pdf;
-			show("  ggx.evalp_is", gx.evalp_is(g.u(), g.u(), o, &wi, &pdf, &pr)); show("    i", wi); printf("    pdf"); put(pdf); printf("\n");
+			show("  ggx.evalp_is", gx.evalp_is(g.u(), g.u(), o, &wi, &pdf, &pr)); show("    i", wi); fprintf(out, "    pdf"); put(pdf); fprintf(out, "\n");
 		}
 		djb::tabular tab(gx, 16 + g.below(40));
 		float ag;
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
-		printf("  tabular(ggx(user F)) ggx"); put(ag); printf("\n");
+		fprintf(out, "  tabular(ggx(user F)) ggx"); put(ag); fprintf(out, "\n");
 		show_table("  p22", tab.get_p22v());
 		show("  fitted fresnel", tab.fresnel(g.u()));
 	}
@@ -189,16 +194,16 @@ void one_seed(unsigned seed)
 		student st(g.in(1.6f, 5.0f), f, g.below(2) != 0);
 		djb::microfacet::params pr = djb::microfacet::params::elliptic(g.log_in(0.1f, 1.0f), g.log_in(0.1f, 1.0f), g.in(0.0f, 3.0f));
 		const djb::vec3 i = g.dir(), o = g.dir();
-		show("student.eval", st.eval(i, o, &pr)); printf("  pdf"); put(st.pdf(i, o, &pr)); printf("\n");
+		show("student.eval", st.eval(i, o, &pr)); fprintf(out, "  pdf"); put(st.pdf(i, o, &pr)); fprintf(out, "\n");
 		show("  sample", st.sample(g.u(), g.u(), o, &pr));
 		djb::vec3 wi; float pdf;
-		show("  evalp_is", st.evalp_is(g.u(), g.u(), o, &wi, &pdf, &pr)); show("    i", wi); printf("    pdf"); put(pdf); printf("\n");
-		printf("  ndf"); put(st.ndf(djb::normalize(i + o), pr)); printf(" sigma"); put(st.sigma(o, pr)); printf(" g1"); put(st.g1(djb::normalize(i + o), o, pr)); printf("\n");
+		show("  evalp_is", st.evalp_is(g.u(), g.u(), o, &wi, &pdf, &pr)); show("    i", wi); fprintf(out, "    pdf"); put(pdf); fprintf(out, "\n");
+		fprintf(out, "  ndf"); put(st.ndf(djb::normalize(i + o), pr)); fprintf(out, " sigma"); put(st.sigma(o, pr)); fprintf(out, " g1"); put(st.g1(djb::normalize(i + o), o, pr)); fprintf(out, "\n");
 		djb::tabular tab(st, 12 + g.below(50));
 		float ab, ag;
 		djb::tabular::fit_beckmann_parameters(tab).get_ellipse(&ab, NULL);
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
-		printf("  tabular(student)"); put(ab); put(ag); printf("\n");
+		fprintf(out, "  tabular(student)"); put(ab); put(ag); fprintf(out, "\n");
 		show_table("  qf", tab.get_qfv());
 	}
 }
@@ -208,6 +213,25 @@ void one_seed(unsigned seed)
 int main(int argc, char **argv)
 {
 	const unsigned first = argc > 1 ? (unsigned)atoi(argv[1]) : 1u, count = argc > 2 ? (unsigned)atoi(argv[2]) : 4u;
-	for (unsigned s = first; s < first + count; ++s) one_seed(s);
+	const int threads = argc > 3 && !strncmp(argv[3], "threads=", 8) ? atoi(argv[3] + 8) : 0;
+	if (threads <= 0) {
+		for (unsigned s = first; s < first + count; ++s) one_seed(s);
+		return 0;
+	}
+	// threads=N: the seeds are dealt to N host threads that share the process's default context and run CONCURRENTLY (user-defined
+	// objects being fitted from several threads at once); the output is printed in seed order and must be the sequential run's
+	std::vector<std::string> text(count);
+	std::vector<std::thread> pool;
+	for (int t = 0; t < threads; ++t)
+		pool.push_back(std::thread([&, t]() {
+			for (unsigned k = (unsigned)t; k < count; k += (unsigned)threads) {
+				char *buf = NULL; size_t len = 0;
+				FILE *f = open_memstream(&buf, &len);
+				out = f; one_seed(first + k); fclose(f); out = stdout;
+				text[k].assign(buf, len); free(buf);
+			}
+		}));
+	for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
+	for (unsigned k = 0; k < count; ++k) fputs(text[k].c_str(), stdout);
 	return 0;
 }

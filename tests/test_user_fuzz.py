@@ -20,10 +20,11 @@ REF = os.path.join(ROOT, "oracle", "_ref", "custom_brdf_fuzz")
 GOLDEN = os.path.join(ROOT, "tests", "golden", "reftests", "custom_brdf_fuzz.txt")
 
 
-def run(exe, first, count, env_extra=None, drop=(), scratch=None, merl=False):
+def run(exe, first, count, env_extra=None, drop=(), scratch=None, merl=False, threads=0):
     env = {k: v for k, v in os.environ.items() if k not in drop}
     env.update(env_extra or {}, DJB_QUIET="1")
-    r = subprocess.run([exe, str(first), str(count)] + ([str(scratch)] if scratch else []) + (["merl"] if merl else []), capture_output=True, timeout=1500, env=env)
+    r = subprocess.run([exe, str(first), str(count)] + ([str(scratch)] if scratch else []) + (["merl"] if merl else []) + ([f"threads={threads}"] if threads else []),
+                       capture_output=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     return r.stdout
 
@@ -119,4 +120,29 @@ def test_api_fuzz_with_merl_files_on_gpu(tmp_path, scalar_on_device):
     need(API_EXE); need(API_REF)
     want = run(API_REF, 9000, 6, scratch=tmp_path, merl=True)
     got = run(API_EXE, 9000, 6, {"DJB_SCALAR_ON_DEVICE": scalar_on_device}, drop=("DJB_DEVICE",), scratch=tmp_path, merl=True)
+    assert got == want, first_difference(got, want)
+
+
+# ---------------------------------------------------------------------------------------------- concurrency: threads=N
+# The reference is a header of const methods: any number of threads may use it.  The facade promises the same on ONE shared
+# default context (INTEGRATION.md "Ownership and threading"): the seeds dealt to 8 host threads -- objects created, fitted, queried
+# and destroyed concurrently -- must print what the sequential reference prints.
+def test_fuzz_programs_from_eight_threads_on_host_path(tmp_path):
+    need(API_EXE); need(API_REF); need(EXE); need(REF)
+    want = run(API_REF, 12000, 32, scratch=tmp_path)
+    got = run(API_EXE, 12000, 32, {"DJB_DEVICE": "cpu"}, scratch=tmp_path, threads=8)
+    assert got == want, first_difference(got, want)
+    want, got = run(REF, 12000, 32), run(EXE, 12000, 32, {"DJB_DEVICE": "cpu"}, threads=8)
+    assert got == want, first_difference(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scalar_on_device", ["0", "1"])
+def test_fuzz_programs_from_eight_threads_on_gpu(tmp_path, scalar_on_device):
+    need(API_EXE); need(API_REF); need(EXE); need(REF)
+    env = {"DJB_SCALAR_ON_DEVICE": scalar_on_device}
+    want = run(API_REF, 13000, 48, scratch=tmp_path, merl=True)
+    got = run(API_EXE, 13000, 48, env, drop=("DJB_DEVICE",), scratch=tmp_path, merl=True, threads=8)
+    assert got == want, first_difference(got, want)
+    want, got = run(REF, 13000, 64), run(EXE, 13000, 64, env, drop=("DJB_DEVICE",), threads=8)
     assert got == want, first_difference(got, want)

@@ -21,3 +21,11 @@ from dj_brdf_amd import synth
 for k, a in enumerate((0.3, 0.1, 0.05)): synth.write_merl_binary('$W/s/m%d.binary' % k, synth.merl_table(alpha=a))"
 (cd $W/s && for mode in "" "-s"; do ../merl_params $mode m0.binary m1.binary m2.binary > /dev/null 2>> $W/e7 && cp params.txt p$mode.txt; done && $ROOT/examples/merl_params m0.binary m1.binary m2.binary > /dev/null && cmp params.txt p.txt && cmp params.txt p-s.txt && echo "merl_params (file pipeline, both modes): the unsanitized build's params.txt")
 echo "sanitizer reports: $(cat $W/e1 $W/e2 $W/e3 $W/e4 $W/e5 $W/e6 $W/e7 | wc -c) bytes"
+# ThreadSanitizer: the same host path, the two fuzzers from 8 threads on the shared CPU context
+make -s -C dj_brdf_amd/csrc BUILD=build_tsan OUT=../../gpurun_variants/libdjb_tsan.so CXX="g++ -fsanitize=thread -fno-omit-frame-pointer -g" -j16
+TSAN="-O1 -g -fsanitize=thread -std=c++14 -DNVERBOSE -I$ROOT/include -L$ROOT/gpurun_variants -l:libdjb_tsan.so -Wl,-rpath,$ROOT/gpurun_variants -pthread"
+g++ -o $W/api_fuzz_t examples/api_fuzz.cpp $TSAN; g++ -o $W/custom_brdf_fuzz_t examples/custom_brdf_fuzz.cpp $TSAN
+$W/api_fuzz_t 100 32 $W/s threads=8 2> $W/t1 | cmp - <($R/api_fuzz 100 32 $W/r) && echo "TSan: api_fuzz 32 seeds from 8 threads: reference's bytes"
+$W/custom_brdf_fuzz_t 200 32 threads=8 2> $W/t2 | cmp - <($R/custom_brdf_fuzz 200 32) && echo "TSan: custom_brdf_fuzz 32 seeds from 8 threads: reference's bytes"
+echo "ThreadSanitizer reports: $(cat $W/t1 $W/t2 | wc -c) bytes"
+rm -rf dj_brdf_amd/csrc/build_asan dj_brdf_amd/csrc/build_tsan gpurun_variants/libdjb_asan.so gpurun_variants/libdjb_tsan.so

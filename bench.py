@@ -698,6 +698,22 @@ def main():
                         roofline["traffic_note"] = pj.get("note")
                         if pj.get("gather_miss_bytes_per_launch") is not None:      # the table gathers' share (line fills out of the Infinity Cache)
                             roofline["traffic_gather_miss_bytes"] = pj["gather_miss_bytes_per_launch"]
+                        # the same counters as memory-side REQUESTS: a read request moves 128 bytes (FETCH_SIZE tallies it at 64), the L2 writes
+                        # back in 64-byte requests; every memory-bound kernel of this library sustains 60-63 G requests/s (= 8 TB/s in 128-byte
+                        # reads; profiles/r04/fabric_request_rate.txt), so requests / 62e9 is the time the memory system needs for this
+                        # access pattern -- for the MERL launch the line fills of the gather misses are 45 % of the requests
+                        if pj.get("FETCH_SIZE_KB_per_launch") and pj.get("WRITE_SIZE_KB_per_launch") and pj.get("units_per_launch"):
+                            rd = pj["FETCH_SIZE_KB_per_launch"] * 1024.0 / 64.0
+                            wr = pj["WRITE_SIZE_KB_per_launch"] * 1024.0 / 64.0
+                            upl = float(pj["units_per_launch"])
+                            floor_ms = (rd + wr) / 62e9 * 1e3 * (n / upl)
+                            roofline["request_model"] = {
+                                "read_requests_per_unit": rd / upl, "write_requests_per_unit": wr / upl, "sustained_G_requests_per_s": 62.0,
+                                "memory_system_floor_ms": floor_ms, "launch_ms_over_floor": launch_ms / floor_ms,
+                                "note": "static (same PMC passes as `traffic`): 128-byte read requests + 64-byte write requests per unit, and the time "
+                                        "they take at the 62 G requests/s this memory system sustains; `frac` above prices the ALGORITHMIC bytes "
+                                        "against 8 TB/s as the contract asks, this object says how far the launch is from what its access "
+                                        "pattern allows"}
                     else:
                         roofline["traffic_source"] = ("STALE: profiles/pmc_%s.json lists kernels %s, this workload launches %s -- not attached"
                                                       % (name, listed, sorted(LAUNCHES.get(name, []))))

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DJB_LIB_PATH") or os.path.join(_HERE, "lib", "libdjb_hip.so")
 
 DJB_OK = 0
-ABI_VERSION = 220          # include/djb_hip.h: DJB_HIP_VERSION (the major digit must match the loaded library)
+ABI_VERSION = 230          # include/djb_hip.h: DJB_HIP_VERSION (the major digit must match the loaded library)
 STATUS_NAMES = {
     0: "DJB_OK", 1: "DJB_ERR_INVALID_ARGUMENT", 2: "DJB_ERR_OPEN_FAILED", 3: "DJB_ERR_BAD_HEADER",
     4: "DJB_ERR_READ_FAILED", 5: "DJB_ERR_NOT_IMPLEMENTED", 6: "DJB_ERR_HIP", 7: "DJB_ERR_NO_DEVICE",
@@ -66,7 +66,7 @@ EXPORTS = [
     "djb_pdf_batch", "djb_eval_pdf_batch", "djb_sample_batch", "djb_sample_rng_batch",
     "djb_evalp_is_batch", "djb_io_to_hd_batch", "djb_hd_to_io_batch", "djb_merl_index_batch", "djb_query_batch",
     "djb_params_resolve", "djb_tabular_get", "djb_tabular_fit", "djb_fit_merl_batch", "djb_fit_brdf_batch",
-    "djb_gen_directions", "djb_gen_uniforms", "djb_histogram_xy",
+    "djb_gen_directions", "djb_gen_uniforms", "djb_histogram_xy", "djb_helper",
     "djb_set_file_map_observer", "djb_brdf_create_user_microfacet", "djb_fit_query_dirs", "djb_fit_aniso_query_dirs", "djb_brdf_create_tabular_from_samples",
     "djb_brdf_create_tabular_anisotropic_from_samples",
 ]

@@ -1093,6 +1093,21 @@ djb_status gen_directions(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t start
 	parallel_for(C(ctx), n, 1 << 14, [&](long long k0, long long k1) { for (long long k = k0; k < k1; ++k) store3(v, k, gen_direction(seed, start + (unsigned long long)k)); });
 	return DJB_OK;
 }
+// the helpers the reference defines as file-static functions of its implementation section (dj_brdf.h:650-765), for callers that
+// compiled against them: evaluated here by the per-unit code every operator uses
+djb_status helper(int which, const float *in, float *out)
+{
+	const GlibcTabs gt{};
+	switch (which) {
+	case DJB_HELPER_ERF: out[0] = erf_(in[0]); return DJB_OK;
+	case DJB_HELPER_ERFINV: out[0] = erfinv_(in[0], gt); return DJB_OK;
+	case DJB_HELPER_XYZ_TO_THETA_PHI: xyz_to_theta_phi(mk(in[0], in[1], in[2]), out[0], out[1]); return DJB_OK;
+	case DJB_HELPER_UNIFORM_TO_CONCENTRIC: uniform_to_concentric(in[0], in[1], out[0], out[1]); return DJB_OK;
+	case DJB_HELPER_ROTATE_VECTOR: { const v3 r = rotate_axis(mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]), in[6]); out[0] = r.x; out[1] = r.y; out[2] = r.z; return DJB_OK; }
+	default: return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: unknown helper");
+	}
+}
+
 djb_status gen_uniforms(djb_ctx *ctx, int64_t n, uint32_t seed, uint64_t start, float *out)
 {
 	if (!out) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");

@@ -102,6 +102,7 @@ djb_status fit_merl_files(djb_ctx *, int n_files, const char *const *paths, int 
                           float *ag, double *timing);
 djb_status gen_directions(djb_ctx *, int64_t n, uint32_t seed, uint64_t start, const djb_vec3_view *out);
 djb_status gen_uniforms(djb_ctx *, int64_t n, uint32_t seed, uint64_t start, float *out);
+djb_status helper(int which, const float *in, float *out);    // djb_helper: the reference's file-static helpers, host arithmetic
 djb_status histogram_xy(djb_ctx *, int64_t n, const djb_vec3_view *v, int bins, unsigned long long *counts);
 // host values of trig site `host_fn` (djb_device.hpp TRIG_*; float sites < TRIG_DOUBLE, double sites from TRIG_DOUBLE)
 // for the inputs with bit patterns first_bits .. first_bits + count - 1, compared with `dev` (a site evaluated on the

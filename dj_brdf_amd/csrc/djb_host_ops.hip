@@ -583,6 +583,14 @@ try {
 }
 DJB_ABI_CATCH
 
+// ---------------------------------------------------------------- the reference's file-static helpers (host scalars)
+djb_status djb_helper(int which, const float *in, float *out)
+try {
+	if (!in || !out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	return djbcpu::helper(which, in, out);
+}
+DJB_ABI_CATCH
+
 // ---------------------------------------------------------------- beckmann::lrep (host scalars)
 // dj_brdf.h:1959-2051, float arithmetic in the reference's order (this TU is built with
 // -ffp-contract=off).  lrep = {E1, E2, E3, E4, E5}.

@@ -300,6 +300,26 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		show("  tab.eval", tab_m.eval(i, o)); show1("  tab.pdf", tab_m.pdf(i, o)); show("  tab.sample", tab_m.sample(g.u(), g.u(), o));
 		remove(path.c_str());
 	}
+	// the file-static helpers of the implementation section (dj_brdf.h:650-765, 1181-1249): visible to any program that defines
+	// DJ_BRDF_IMPLEMENTATION, e.g. to a user-defined lobe's own sample()
+	{
+		const float x = g.in(-3.0f, 3.0f), u = g.in(-0.9999f, 0.9999f);
+		fprintf(out, "helpers erf"); put(djb::erf(x)); put(djb::erf(g.log_in(1e-4f, 6.0f))); fprintf(out, " erfinv"); put(djb::erfinv(u)); put(djb::erfinv(1.0f - g.log_in(1e-7f, 1e-2f))); fprintf(out, "\n");
+		float th, ph; const djb::vec3 d = g.below(6) ? g.any_dir() : djb::vec3(0, 0, g.below(2) ? 1.0f : -1.0f);
+		djb::xyz_to_theta_phi(d, &th, &ph); fprintf(out, "  theta phi"); put(th); put(ph);
+		float cx, cy; djb::uniform_to_concentric(g.below(8) ? g.u() : 0.5f, g.below(8) ? g.u() : 0.5f, &cx, &cy); fprintf(out, " concentric"); put(cx); put(cy); fprintf(out, "\n");
+		show("  rotate_vector", djb::rotate_vector(g.dir(), djb::normalize(djb::vec3(g.in(-1.0f, 1.0f), g.in(-1.0f, 1.0f), g.in(-1.0f, 1.0f))), g.in(-4.0f, 4.0f)));
+		show("  cross", djb::cross(g.dir(), g.dir())); fprintf(out, "  max3 %d inversesqrt", djb::max3(g.below(9), g.below(9), g.below(9))); put(djb::inversesqrt(g.log_in(1e-3f, 1e3f))); fprintf(out, "\n");
+		std::vector<float> tab; std::vector<djb::vec3> tab3;
+		const int n = 2 + g.below(30), w = 2 + g.below(6), h = 2 + g.below(6);
+		for (int k = 0; k < n; ++k) { tab.push_back(g.in(-1.0f, 2.0f)); tab3.push_back(djb::vec3(g.u(), g.u(), g.u())); }
+		std::vector<float> grid; for (int k = 0; k < w * h; ++k) grid.push_back(g.in(0.0f, 5.0f));
+		const float s = g.in(-0.2f, 1.2f);
+		fprintf(out, "  spline"); put(djb::spline::eval(tab, djb::spline::uwrap_edge, s)); put(djb::spline::eval(tab, djb::spline::uwrap_repeat, g.u()));
+		show(" vec3", djb::spline::eval(tab3, djb::spline::uwrap_edge, g.u()));
+		fprintf(out, "  eval2d"); put(djb::spline::eval2d(grid, w, h, djb::spline::uwrap_edge, g.u(), djb::spline::uwrap_repeat, g.u()));
+		fprintf(out, " lerp"); put(djb::spline::lerp(g.u(), g.u(), g.u())); fprintf(out, " wrap %d %d\n", djb::spline::uwrap_repeat(g.below(40) - 20, 7), djb::spline::uwrap_edge(g.below(40) - 20, 7));
+	}
 	// errors are the reference's
 	try { djb::sgd nope("no-such-material"); fprintf(out, "no exception\n"); } catch (const djb::exc &e) { fprintf(out, "exc: %s", e.what()); }
 	try { djb::utia nope((scratch + "/does-not-exist.bin").c_str()); fprintf(out, "no exception\n"); } catch (const djb::exc &e) { fprintf(out, "exc raised for a missing file\n"); }

@@ -50,8 +50,9 @@ extern "C" {
  *        djb_brdf_create_tabular_anisotropic_from_samples (fits of user-defined sources), djb_set_file_map_observer,
  *        DJB_FRESNEL_HOST.  No existing entry changed.
  *   220  round 5: + djb_brdf_create_user_microfacet / djb_user_ndf (user-defined NDFs on the host path), DJB_KIND_USER,
- *        djb_brdf_get_fresnel.                                                                                           */
-#define DJB_HIP_VERSION 220
+ *        djb_brdf_get_fresnel.
+ *   230  round 5: + djb_helper (the reference's file-static erf / erfinv / xyz_to_theta_phi / uniform_to_concentric / rotate_vector).  */
+#define DJB_HIP_VERSION 230
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
 typedef enum {
@@ -387,6 +388,14 @@ enum { DJB_LREP_ADD = 0, DJB_LREP_MUL = 1, DJB_LREP_IADD = 2, DJB_LREP_IMUL = 3,
 djb_status djb_lrep_op(int op, const float *a, const float *b, float x, float y, float *out);
 djb_status djb_params_to_lrep(const djb_params *params, float *out_lrep);      /* beckmann::params_to_lrep */
 djb_status djb_lrep_to_params(const float *lrep, djb_params *out_pdfparams);   /* beckmann::lrep_to_params */
+
+/* The file-static helpers of the reference's implementation section (dj_brdf.h:650-765) -- erf (A&S 7.1.26), erfinv (Giles),
+ * xyz_to_theta_phi, uniform_to_concentric (Cline), rotate_vector (Rodrigues) -- for callers that were compiled against them (a user-defined
+ * lobe's own sample() or NDF): one call, host scalars, the arithmetic of the library's operators.  in / out:
+ *   ERF, ERFINV: in[0] -> out[0];  XYZ_TO_THETA_PHI: in[0..2] -> out[0] theta, out[1] phi;  UNIFORM_TO_CONCENTRIC: in[0..1] -> out[0..1];
+ *   ROTATE_VECTOR: in[0..2] x, in[3..5] axis, in[6] angle -> out[0..2].                                                          (ABI 230) */
+enum { DJB_HELPER_ERF = 0, DJB_HELPER_ERFINV = 1, DJB_HELPER_XYZ_TO_THETA_PHI = 2, DJB_HELPER_UNIFORM_TO_CONCENTRIC = 3, DJB_HELPER_ROTATE_VECTOR = 4 };
+djb_status djb_helper(int which, const float *in, float *out);
 
 /* brdf::io_to_hd / brdf::hd_to_io (static)                            dj_brdf.h:99-100  */
 djb_status djb_io_to_hd_batch(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,

@@ -114,6 +114,41 @@ template <typename T> static T max(const T &a, const T &b) { return a > b ? a : 
 template <typename T> static T sat(const T &x) { return min(T(1), max(T(0), x)); }
 template <typename T> static T max3(const T &x, const T &y, const T &z) { T m = x; if (m < y) m = y; if (m < z) m = z; return m; }
 inline float_t inversesqrt(float_t x) { return (float_t)(1.0 / std::sqrt((double)x)); }
+/* The other file-static helpers of the reference's implementation section (dj_brdf.h:650-765), visible to every program that defines
+ * DJ_BRDF_IMPLEMENTATION: a user-defined lobe's own sample() or NDF may call them.  Answered by the library (djb_helper: the
+ * arithmetic its operators use); the ABI status is checked further down (hip::check is not declared yet here). */
+namespace hip { inline void helper(int which, const float *in, float *out); }
+inline float_t erf(float_t x) { float_t r; hip::helper(DJB_HELPER_ERF, &x, &r); return r; }
+inline float_t erfinv(float_t u) { float_t r; hip::helper(DJB_HELPER_ERFINV, &u, &r); return r; }
+inline void xyz_to_theta_phi(const vec3 &p, float_t *theta, float_t *phi)
+{ const float_t in[3] = { p.x, p.y, p.z }; float_t out[2]; hip::helper(DJB_HELPER_XYZ_TO_THETA_PHI, in, out); *theta = out[0]; *phi = out[1]; }
+inline void uniform_to_concentric(float_t u1, float_t u2, float_t *x, float_t *y)
+{ const float_t in[2] = { u1, u2 }; float_t out[2]; hip::helper(DJB_HELPER_UNIFORM_TO_CONCENTRIC, in, out); *x = out[0]; *y = out[1]; }
+inline vec3 rotate_vector(const vec3 &x, const vec3 &axis, float_t angle)
+{ const float_t in[7] = { x.x, x.y, x.z, axis.x, axis.y, axis.z, angle }; float_t out[3]; hip::helper(DJB_HELPER_ROTATE_VECTOR, in, out); return vec3(out[0], out[1], out[2]); }
+/* the private linear-table helpers, dj_brdf.h:1181-1249: plain host templates (they work on the caller's own std::vector) */
+namespace spline {
+typedef int (*uwrap_callback)(int, int);
+inline int uwrap_repeat(int i, int edge) { i %= edge; return i < 0 ? i + edge : i; }
+inline int uwrap_edge(int i, int edge) { return i >= edge ? edge - 1 : (i < 0 ? 0 : i); }
+template <typename T> T lerp(const T &x1, const T &x2, float_t u) { return x1 + u * (x2 - x1); }
+// node and fraction of u * n - u, both formed in float as the reference does
+inline float_t locate(float_t u, int n, int *whole) { double w; const float_t f = (float_t)modf((double)(u * n - u), &w); *whole = (int)w; return f; }
+template <typename T> static T eval(const std::vector<T> &points, uwrap_callback wrap, float_t u)
+{
+	const int n = (int)points.size();
+	int k; const float_t f = locate(u, n, &k);
+	return lerp(points[wrap(k, n)], points[wrap(k + 1, n)], f);
+}
+template <typename T> static T eval2d(const std::vector<T> &points, int w, int h, uwrap_callback wrap1, float_t u1, uwrap_callback wrap2, float_t u2)
+{
+	int k1, k2;
+	const float_t f1 = locate(u1, w, &k1), f2 = locate(u2, h, &k2);
+	const int i1 = wrap1(k1, w), i2 = wrap1(k1 + 1, w), j1 = wrap2(k2, h), j2 = wrap2(k2 + 1, h);
+	const float_t lo = lerp(points[i1 + w * j1], points[i2 + w * j1], f1), hi = lerp(points[i1 + w * j2], points[i2 + w * j2], f1);
+	return lerp(lo, hi, f2);
+}
+} // namespace spline
 
 namespace hip {
 
@@ -121,6 +156,7 @@ inline void check(djb_status st)
 {
 	if (st != DJB_OK) throw exc(djb_last_error(), (int)st);
 }
+inline void helper(int which, const float *in, float *out) { check(djb_helper(which, in, out)); }
 
 /* one GPU + one HIP stream -- or, with device == DJB_DEVICE_CPU, the library's host execution path */
 class context {

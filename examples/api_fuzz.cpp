@@ -310,6 +310,17 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		float cx, cy; djb::uniform_to_concentric(g.below(8) ? g.u() : 0.5f, g.below(8) ? g.u() : 0.5f, &cx, &cy); fprintf(out, " concentric"); put(cx); put(cy); fprintf(out, "\n");
 		show("  rotate_vector", djb::rotate_vector(g.dir(), djb::normalize(djb::vec3(g.in(-1.0f, 1.0f), g.in(-1.0f, 1.0f), g.in(-1.0f, 1.0f))), g.in(-4.0f, 4.0f)));
 		show("  cross", djb::cross(g.dir(), g.dir())); fprintf(out, "  max3 %d inversesqrt", djb::max3(g.below(9), g.below(9), g.below(9))); put(djb::inversesqrt(g.log_in(1e-3f, 1e3f))); fprintf(out, "\n");
+		{	// vec3 and the Fresnel utilities
+			djb::vec3 a = g.dir(), b = g.dir(), c(g.in(0.0f, 3.1f), g.in(0.0f, 6.2f));
+			const double raw[3] = { (double)g.u() * 1.000000123, (double)g.u() / 3.0, 1e-40 };
+			show("  vec3(theta, phi)", c); show("  from_raw", djb::vec3::from_raw(raw));
+			show("  a*b a/b", a * b + a / (b + djb::vec3(0.5f))); show("  a/s s*a", a / g.in(0.1f, 3.0f) + g.u() * b);
+			a += b; a *= b; a *= g.u(); show("  += *= *=", a); show("  vec3(s)", djb::vec3(g.u()) - b);
+			float f0, ior; djb::vec3 v0, v1;
+			djb::fresnel::ior_to_f0(g.in(1.0f, 4.0f), &f0); djb::fresnel::f0_to_ior(g.in(0.0f, 0.99f), &ior);
+			djb::fresnel::ior_to_f0(djb::vec3(g.in(1.0f, 3.0f), g.in(1.0f, 3.0f), g.in(1.0f, 3.0f)), &v0); djb::fresnel::f0_to_ior(djb::vec3(g.u(), g.u(), g.u()) * 0.98f, &v1);
+			fprintf(out, "  ior_to_f0"); put(f0); put(ior); show(" v", v0 + v1);
+		}
 		std::vector<float> tab; std::vector<djb::vec3> tab3;
 		const int n = 2 + g.below(30), w = 2 + g.below(6), h = 2 + g.below(6);
 		for (int k = 0; k < n; ++k) { tab.push_back(g.in(-1.0f, 2.0f)); tab3.push_back(djb::vec3(g.u(), g.u(), g.u())); }

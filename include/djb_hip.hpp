@@ -43,6 +43,7 @@
  *                             2780); a user macro is invoked at the same sites with the same conditions before the call
  *                             reaches the library.  Without one the library's own validation throws djb::exc (the
  *                             reference would abort in assert.h or, under NDEBUG, compute garbage).
+ *   DJB_EPSILON               see below: only the reference's default value is supported.
  *   DJB_LOG(fmt, ...)         user-overridable, default stdout like the reference.  Unless NVERBOSE is defined the
  *                             constructors of tabular / tabular_anisotropic print the reference's progress lines
  *                             (dj_brdf.h:2383-2384, 2429-2430, 2638-2639, 2698-2699, 2724-2725, 2759-2760).  The two lines that carry a value
@@ -60,6 +61,15 @@
 #endif
 #ifndef DJB_LOG
 #	define DJB_LOG(format, ...) fprintf(stdout, format, ##__VA_ARGS__)
+#endif
+/* DJB_EPSILON (dj_brdf.h:49-51, used once: microfacet::ndf is zero unless h.z > DJB_EPSILON, :1561).  The kernels are built for the
+ * reference's default, 1e-4; a program that defines another value before including the header is refused when it creates its first
+ * context (a float cannot be compared by the preprocessor), instead of silently getting the default's results.  M_PI: dj_brdf.h:562. */
+#ifndef DJB_EPSILON
+#	define DJB_EPSILON (float_t)1e-4
+#endif
+#ifndef M_PI
+#	define M_PI 3.1415926535897932384626433832795
 #endif
 
 namespace djb {
@@ -166,6 +176,8 @@ public:
 	// the loaded libdjb_hip.so must have the ABI major this header was written against (djb_hip.h: DJB_HIP_VERSION)
 	static void abi_check()
 	{
+		if (!((float_t)(DJB_EPSILON) == (float_t)1e-4))
+			throw exc("djb_error: DJB_EPSILON was redefined; libdjb_hip.so is built for the reference's default (1e-4)", DJB_ERR_INVALID_ARGUMENT);
 		if (DJB_HIP_VERSION_MAJOR(djb_version()) != DJB_HIP_VERSION_MAJOR(DJB_HIP_VERSION)) {
 			char msg[160];
 			snprintf(msg, sizeof msg, "djb_error: libdjb_hip.so has ABI version %d, this program was compiled against %d", djb_version(), (int)DJB_HIP_VERSION);

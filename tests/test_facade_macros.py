@@ -76,3 +76,20 @@ def test_facade_has_the_reference_public_surface():
     if os.path.exists("/root/reference/dj_brdf.h"):
         r = subprocess.run(["g++", "-fsyntax-only", "-DNVERBOSE", "-w", "-I", "/root/reference", src], capture_output=True, text=True)
         assert r.returncode == 0, "the probe does not compile against the reference itself:\n" + r.stderr[-4000:]
+
+
+def test_epsilon_macro(tmp_path):
+    """DJB_EPSILON (dj_brdf.h:49-51): defined by the header with the reference's default; a program that redefines it is refused when
+    it creates its first object (the kernels implement h.z > 1e-4), not silently given the default's results"""
+    prog = '#include <cstdio>\n#include "dj_brdf.h"\nint main() { try { djb::ggx g; printf("eps %g pi %.3f\\n", (double)(djb::float_t)DJB_EPSILON * 1.0, M_PI); }' \
+           ' catch (const djb::exc &e) { printf("%s\\n", e.what()); return 3; } return 0; }\n'
+    prog = prog.replace("(djb::float_t)DJB_EPSILON", "[]{ using djb::float_t; return DJB_EPSILON; }()")
+    env = dict(os.environ, DJB_DEVICE="cpu", DJB_QUIET="1")
+    r, exe = build(tmp_path, prog)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "eps 0.0001 pi 3.142" in out.stdout, out.stdout + out.stderr
+    r, exe = build(tmp_path, prog, ["-DDJB_EPSILON=(float_t)1e-3"])
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3 and "DJB_EPSILON was redefined" in out.stdout, out.stdout + out.stderr

@@ -93,3 +93,20 @@ def test_epsilon_macro(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 3 and "DJB_EPSILON was redefined" in out.stdout, out.stdout + out.stderr
+
+
+def test_header_in_several_translation_units(tmp_path):
+    """the reference is included everywhere and implemented in ONE translation unit (`#define DJ_BRDF_IMPLEMENTATION 1`, dj_brdf.h:4-6);
+    the facade is header-only: the same two files must compile, link without duplicate symbols, and run"""
+    (tmp_path / "a.cpp").write_text('#define DJ_BRDF_IMPLEMENTATION 1\n#include "dj_brdf.h"\nfloat other(const djb::vec3 &i, const djb::vec3 &o);\n'
+                                    'int main() { djb::ggx g; djb::vec3 i(0.3f, 0.1f, 0.9f), o(0.1f, 0.2f, 0.95f); printf("%a %a\\n", g.eval(i, o).x, other(i, o)); return 0; }\n')
+    (tmp_path / "b.cpp").write_text('#include "dj_brdf.h"\nfloat other(const djb::vec3 &i, const djb::vec3 &o) { djb::beckmann b; djb::tabular t(b, 16); return t.pdf(i, o); }\n')
+    for f in ("a", "b"):
+        r = subprocess.run(["g++", "-O1", "-std=c++14", "-DNVERBOSE", "-I" + os.path.join(ROOT, "include"), "-c", str(tmp_path / (f + ".cpp")), "-o", str(tmp_path / (f + ".o"))],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run(["g++", str(tmp_path / "a.o"), str(tmp_path / "b.o"), "-o", str(tmp_path / "prog"), "-L" + LIBDIR, "-ldjb_hip", "-Wl,-rpath," + LIBDIR,
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-pthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(tmp_path / "prog")], env=dict(os.environ, DJB_DEVICE="cpu", DJB_QUIET="1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "0x1.6d4a2ap-4 0x1.5af378p-4", out.stdout + out.stderr      # what the reference prints for it

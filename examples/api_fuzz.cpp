@@ -300,6 +300,29 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		show("  tab.eval", tab_m.eval(i, o)); show1("  tab.pdf", tab_m.pdf(i, o)); show("  tab.sample", tab_m.sample(g.u(), g.u(), o));
 		remove(path.c_str());
 	}
+	// the same objects behind base-class pointers, as a renderer holds them (mitsuba/dj_brdf.cpp keeps a djb::microfacet *)
+	{
+		djb::fresnel::impl *f = random_fresnel(g);
+		std::vector<djb::brdf *> all;
+		djb::radial *rad[2] = { new djb::ggx(*f), new djb::beckmann(*f, false) };
+		djb::microfacet *mf = new djb::tabular(*rad[1], 10 + g.below(20));
+		all.push_back(rad[0]); all.push_back(rad[1]); all.push_back(mf); all.push_back(new djb::lambert); all.push_back(new djb::sgd("chrome")); all.push_back(new djb::abc("teflon"));
+		const djb::microfacet::params p = random_params(g);
+		const djb::vec3 i = g.dir(), o = g.dir();
+		for (size_t k = 0; k < all.size(); ++k) {
+			const djb::brdf *b = all[k];
+			const void *up = k < 3 ? (const void *)&p : NULL;
+			fprintf(out, "brdf* %d", (int)k); { const djb::vec3 v = b->eval(i, o, up); put(v.x); put(v.y); put(v.z); } put(b->pdf(i, o, up));
+			djb::vec3 wi; float pdf; const djb::vec3 w = b->evalp_is(g.u(), g.u(), o, &wi, &pdf, up); put(w.x); put(wi.z); put(pdf); fprintf(out, "\n");
+		}
+		for (int k = 0; k < 2; ++k) { fprintf(out, "radial* %d", k); put(rad[k]->p22_radial(g.log_in(1e-3f, 30.0f))); put(rad[k]->qf_radial(g.in(0.01f, 0.99f))); put(rad[k]->qf2_radial(g.in(0.01f, 0.99f), 0.6f, 0.8f)); fprintf(out, " vndf %d\n", (int)rad[k]->supports_smith_vndf_sampling()); }
+		djb::fresnel::impl *f2 = random_fresnel(g);
+		mf->set_fresnel(*f2); mf->set_shadow(false);
+		fprintf(out, "microfacet* shadow %d vndf %d", (int)mf->get_shadow(), (int)mf->supports_smith_vndf_sampling()); { const djb::vec3 v = mf->fresnel(g.u()); put(v.x); put(v.y); put(v.z); }
+		put(mf->ndf(djb::normalize(i + o), p)); put(mf->sigma(i, p)); fprintf(out, " tabular? %d\n", dynamic_cast<djb::tabular *>(mf) != NULL && dynamic_cast<djb::ggx *>(mf) == NULL);
+		for (size_t k = 0; k < all.size(); ++k) delete all[k];            // virtual destructors, through the base
+		delete f; delete f2;
+	}
 	// the file-static helpers of the implementation section (dj_brdf.h:650-765, 1181-1249): visible to any program that defines
 	// DJ_BRDF_IMPLEMENTATION, e.g. to a user-defined lobe's own sample()
 	{

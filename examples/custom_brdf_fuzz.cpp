@@ -109,6 +109,26 @@ private:
 	float m_g;
 };
 
+// ---- a user-defined BRDF that brings its own importance sampling, built from the helpers the reference's implementation section
+// offers (uniform_to_concentric, rotate_vector, erf): sample / pdf overridden, evalp_is inherited (dj_brdf.h:816-828 calls the overrides)
+class sampled_lobe : public djb::brdf {
+public:
+	sampled_lobe(rng &g) : m_w(g.in(0.2f, 2.0f)), m_tilt(g.in(-0.4f, 0.4f)) {}
+	djb::vec3 eval(const djb::vec3 &i, const djb::vec3 &o, const void *user_param = NULL) const
+	{ (void)user_param; if (!(i.z > 0.0f && o.z > 0.0f)) return djb::vec3(0); return djb::vec3(0.3f + 0.5f * djb::erf(m_w * djb::dot(i, o)), 0.2f, 0.1f * i.z); }
+	djb::vec3 sample(float u1, float u2, const djb::vec3 &o, const void *user_param = NULL) const
+	{
+		(void)user_param; (void)o;
+		float x, y; djb::uniform_to_concentric(u1, u2, &x, &y);
+		const djb::vec3 d(x, y, (float)std::sqrt(djb::max(0.0, 1.0 - (double)x * x - (double)y * y)));
+		return djb::rotate_vector(d, djb::vec3(0, 1, 0), m_tilt);        // a tilted cosine lobe
+	}
+	float pdf(const djb::vec3 &i, const djb::vec3 &o, const void *user_param = NULL) const
+	{ (void)user_param; (void)o; const djb::vec3 d = djb::rotate_vector(i, djb::vec3(0, 1, 0), -m_tilt); return djb::max(d.z, 0.0f) / (float)M_PI; }
+private:
+	float m_w, m_tilt;
+};
+
 void put(float v) { if (v != v) fprintf(out, " nan"); else fprintf(out, " %a", v); }          // the sign of a NaN is not part of the contract
 void show(const char *tag, const djb::vec3 &v) { fprintf(out, "%s", tag); put(v.x); put(v.y); put(v.z); fprintf(out, "\n"); }
 void show_table(const char *tag, const std::vector<djb::float_t> &v)
@@ -205,6 +225,21 @@ void one_seed(unsigned seed)
 		djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
 		fprintf(out, "  tabular(student)"); put(ab); put(ag); fprintf(out, "\n");
 		show_table("  qf", tab.get_qfv());
+	}
+	// 5. a user-defined lobe with its own sample() / pdf(): the inherited evalp_is and the batch overloads must go through them
+	{
+		sampled_lobe sl(g);
+		const djb::vec3 o = g.dir();
+		for (int k = 0; k < 3; ++k) {
+			const float u1 = g.u(), u2 = g.u();
+			djb::vec3 wi; float pdf;
+			show("sampled_lobe.evalp_is", sl.evalp_is(u1, u2, o, &wi, &pdf)); show("  i", wi); fprintf(out, "  pdf"); put(pdf); put(sl.pdf(wi, o)); fprintf(out, "\n");
+		}
+		const djb::brdf &base = sl;
+		show("  via brdf&", base.sample(g.u(), g.u(), o)); show("  evalp_hd", base.evalp_hd(djb::normalize(g.dir() + o), o));
+		djb::tabular tab(sl, 10 + g.below(20));
+		float ag; djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
+		fprintf(out, "  tabular(sampled_lobe)"); put(ag); fprintf(out, "\n");
 	}
 }
 

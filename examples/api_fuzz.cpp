@@ -354,6 +354,9 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		fprintf(out, "  eval2d"); put(djb::spline::eval2d(grid, w, h, djb::spline::uwrap_edge, g.u(), djb::spline::uwrap_repeat, g.u()));
 		fprintf(out, " lerp"); put(djb::spline::lerp(g.u(), g.u(), g.u())); fprintf(out, " wrap %d %d\n", djb::spline::uwrap_repeat(g.below(40) - 20, 7), djb::spline::uwrap_edge(g.below(40) - 20, 7));
 	}
+	// the exception type is the caller's to throw as well: a printf-style message, 255 characters kept (dj_brdf.h:54-59, 578-587)
+	try { throw djb::exc("user error %d: %s / %.3f\n", g.below(100), "lobe", (double)g.u()); } catch (const std::exception &e) { fprintf(out, "caught %s", e.what()); }
+	try { throw djb::exc("%s", std::string(300 + g.below(50), 'x').c_str()); } catch (const djb::exc &e) { fprintf(out, "long message kept %d\n", (int)e.m_str.size()); }
 	// errors are the reference's
 	try { djb::sgd nope("no-such-material"); fprintf(out, "no exception\n"); } catch (const djb::exc &e) { fprintf(out, "exc: %s", e.what()); }
 	try { djb::utia nope((scratch + "/does-not-exist.bin").c_str()); fprintf(out, "no exception\n"); } catch (const djb::exc &e) { fprintf(out, "exc raised for a missing file\n"); }

@@ -24,6 +24,7 @@
 #define DJB_HIP_HPP
 
 #include <cmath>
+#include <cstdarg>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -78,7 +79,18 @@ typedef float float_t;                      // dj_brdf.h:44-48 (single precision
 
 /* Exception API, dj_brdf.h:54-59 */
 struct exc : public std::exception {
-	explicit exc(const std::string &msg, int status = 0) : m_str(msg), m_status(status) {}
+	// the reference's constructor: a printf-style message, 255 characters kept (dj_brdf.h:55, 578-587)
+	exc(const char *fmt, ...) __attribute__((format(printf, 2, 3))) : m_status(0)
+	{
+		char buf[256];
+		va_list args;
+		va_start(args, fmt);
+		vsnprintf(buf, sizeof buf, fmt, args);
+		va_end(args);
+		m_str = buf;
+	}
+	// what the facade throws when the library reports an error: its message as it is, and the djb_status (an extension)
+	exc(djb_status status, const std::string &msg) : m_str(msg), m_status((int)status) {}
 	virtual ~exc() throw() {}
 	const char *what() const throw() { return m_str.c_str(); }
 	std::string m_str;
@@ -164,7 +176,7 @@ namespace hip {
 
 inline void check(djb_status st)
 {
-	if (st != DJB_OK) throw exc(djb_last_error(), (int)st);
+	if (st != DJB_OK) throw exc(st, djb_last_error());
 }
 inline void helper(int which, const float *in, float *out) { check(djb_helper(which, in, out)); }
 
@@ -177,11 +189,11 @@ public:
 	static void abi_check()
 	{
 		if (!((float_t)(DJB_EPSILON) == (float_t)1e-4))
-			throw exc("djb_error: DJB_EPSILON was redefined; libdjb_hip.so is built for the reference's default (1e-4)", DJB_ERR_INVALID_ARGUMENT);
+			throw exc(DJB_ERR_INVALID_ARGUMENT, "djb_error: DJB_EPSILON was redefined; libdjb_hip.so is built for the reference's default (1e-4)");
 		if (DJB_HIP_VERSION_MAJOR(djb_version()) != DJB_HIP_VERSION_MAJOR(DJB_HIP_VERSION)) {
 			char msg[160];
 			snprintf(msg, sizeof msg, "djb_error: libdjb_hip.so has ABI version %d, this program was compiled against %d", djb_version(), (int)DJB_HIP_VERSION);
-			throw exc(msg, DJB_ERR_INVALID_ARGUMENT);
+			throw exc(DJB_ERR_INVALID_ARGUMENT, msg);
 		}
 	}
 	~context() { djb_ctx_destroy(m_ctx); }
@@ -389,7 +401,7 @@ protected:
 	                                 float_t *out_pdf, const void *user_param) const
 	{ for (size_t k = 0; k < n; ++k) out_weight[k] = evalp_is(u1[k], u2[k], o[k], &out_i[k], &out_pdf[k], user_param); }
 	void need_resident(const char *what) const
-	{ if (!resident()) throw exc(std::string("djb_error: ") + what + " needs a BRDF resident on the GPU (this object is evaluated by host code)", DJB_ERR_INVALID_ARGUMENT); }
+	{ if (!resident()) throw exc(DJB_ERR_INVALID_ARGUMENT, std::string("djb_error: ") + what + " needs a BRDF resident on the GPU (this object is evaluated by host code)"); }
 	djb_brdf *m_h;
 	hip::context *m_ctx;
 	bool m_host_eval;        // eval involves host code beyond the handle (a user-derived brdf; a user-defined Fresnel term)
@@ -705,8 +717,8 @@ public:
 	float_t vp22(float_t x, float_t y, const vec3 &k, const params &p = params::standard()) const { vec3 a(x, y, 0); return q(DJB_Q_VP22, &a, &k, NULL, p); }
 	float_t vndf(const vec3 &h, const vec3 &k, const params &p = params::standard()) const { return q(DJB_Q_VNDF, &h, &k, NULL, p); }
 	// the base-class quantile functions are stubs in the reference too (dj_brdf.h:1783-1791)
-	virtual float_t qf2(float_t, const vec3 &) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
-	virtual float_t qf3(float_t, const vec3 &, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
+	virtual float_t qf2(float_t, const vec3 &) const { throw exc(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented"); }
+	virtual float_t qf3(float_t, const vec3 &, float_t) const { throw exc(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented"); }
 	// ---- the operators that involve the Fresnel term.  With one of the library's terms everything runs behind the handle.
 	// With a USER-DEFINED fresnel::impl (m_host_eval) the handle holds the same lobe with fresnel::ideal -- F = (1, 1, 1)
 	// exactly -- and the reference's expressions are finished here with the user's eval(), operation for operation.
@@ -796,15 +808,15 @@ protected:
 	 * library's own per-unit code, the same the kernels run. */
 	microfacet(const fresnel::impl &f = fresnel::ideal(), bool shadow = true) : brdf(&hip::context::host()), m_fresnel(f.copy())
 	{ m_host_only = true; create_user_handle(false, shadow); }
-	virtual float_t sigma_std(const vec3 &) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
-	virtual float_t p22_std(float_t, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
+	virtual float_t sigma_std(const vec3 &) const { throw exc(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented"); }
+	virtual float_t p22_std(float_t, float_t) const { throw exc(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented"); }
 	virtual void sample_vp22_std_smith(float_t u1, float_t u2, const vec3 &k, float_t *xslope, float_t *yslope) const   // dj_brdf.h:1769-1781
 	{
 		if (supports_smith_vndf_sampling()) { *xslope = qf2(u1, k); *yslope = qf3(u2, k, *xslope); }
 		else sample_vp22_std_nmap(u1, u2, k, xslope, yslope);
 	}
 	virtual void sample_vp22_std_nmap(float_t, float_t, const vec3 &, float_t *, float_t *) const
-	{ throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }
+	{ throw exc(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented"); }
 	struct user_tag {};
 	microfacet(user_tag, const fresnel::impl &f) : brdf(&hip::context::host()), m_fresnel(f.copy()) { m_host_only = true; }   // radial's user constructor
 	// the callbacks only forward to the virtuals above.  They are called from the library's host path -- for batches from several of
@@ -868,8 +880,8 @@ public:
 	virtual float_t sigma_std_radial(float_t cos_theta_k) const = 0;
 	virtual float_t cdf_radial(float_t r) const = 0;
 	virtual float_t qf_radial(float_t u) const = 0;
-	virtual float_t qf2_radial(float_t, float_t, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }   // dj_brdf.h:1848-1855
-	virtual float_t qf3_radial(float_t, float_t) const { throw exc("djb_error: Not Implemented", DJB_ERR_NOT_IMPLEMENTED); }             // dj_brdf.h:1857-1860
+	virtual float_t qf2_radial(float_t, float_t, float_t) const { throw exc(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented"); }   // dj_brdf.h:1848-1855
+	virtual float_t qf3_radial(float_t, float_t) const { throw exc(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented"); }             // dj_brdf.h:1857-1860
 protected:
 	radial(hip::context *c, const fresnel::impl &f) : microfacet(c, f) {}
 	float_t rq(int which, float_t a, float_t b = 0, float_t c = 0) const

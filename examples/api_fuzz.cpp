@@ -111,6 +111,15 @@ void params_round_trip(rng &g)
 	p.set_pdfparams(g.log_in(0.05f, 1.0f), g.log_in(0.05f, 1.0f), g.in(-0.9f, 0.9f), g.in(-0.2f, 0.2f), g.in(-0.2f, 0.2f));
 	p.get_ellipse(&a1, &a2, &phi); p.get_location(&tx, &ty);
 	fprintf(out, "  after set_pdfparams"); put(a1); put(a2); put(phi); put(tx); put(ty); fprintf(out, "\n");
+	// the constructors ("prefer factories", dj_brdf.h:236-238) and a default-constructed object
+	{
+		djb::microfacet::params c0, c1(g.log_in(0.05f, 1.0f), g.log_in(0.05f, 1.0f), g.in(-3.0f, 3.0f)), c2(g.log_in(0.05f, 1.0f), g.log_in(0.05f, 1.0f), g.in(-0.9f, 0.9f), g.in(-0.3f, 0.3f), g.in(-0.3f, 0.3f));
+		float v[5];
+		c0.get_pdfparams(&v[0], &v[1], &v[2], &v[3], &v[4]); fprintf(out, "  ctor()"); for (int k = 0; k < 5; ++k) put(v[k]);
+		c1.get_pdfparams(&v[0], &v[1], &v[2]); fprintf(out, " ctor(3)"); for (int k = 0; k < 3; ++k) put(v[k]);
+		c2.get_ellipse(&v[0], &v[1], &v[2]); c2.get_location(&v[3], &v[4]); fprintf(out, " ctor(5)"); for (int k = 0; k < 5; ++k) put(v[k]);
+		c2.set_location(g.in(-0.2f, 0.2f), g.in(-0.2f, 0.2f)); djb::vec3 nn; c2.get_location(&nn); show(" n", nn);
+	}
 	// LEAN / LEADR representation
 	djb::beckmann::lrep l1, l2(g.in(-0.3f, 0.3f), g.in(-0.3f, 0.3f), g.in(0.1f, 1.0f), g.in(0.1f, 1.0f), g.in(-0.05f, 0.05f));
 	djb::beckmann::params_to_lrep(p, &l1);
@@ -219,9 +228,10 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 	// lambert
 	{
 		djb::lambert l;
-		djb::lambert::params lp(djb::vec3(g.u(), g.u(), g.u()));
+		djb::lambert::params lp(djb::vec3(g.u(), g.u(), g.u())), lp0;
+		lp0.m_reflectance = lp.m_reflectance * 0.5f + lp0.m_reflectance * 0.25f;
 		const djb::vec3 i = g.any_dir(), o = g.any_dir();
-		show("lambert.eval", l.eval(i, o, &lp)); show("  evalp", l.evalp(i, o)); show1("  pdf", l.pdf(i, o)); show("  sample", l.sample(g.u(), g.u(), o));
+		show("lambert.eval", l.eval(i, o, &lp)); show("  eval(lp0)", l.eval(i, o, &lp0)); show("  eval()", l.eval(i, o)); show("  evalp", l.evalp(i, o)); show1("  pdf", l.pdf(i, o)); show("  sample", l.sample(g.u(), g.u(), o));
 	}
 	// a UTIA file written here: look-ups, and an anisotropic fit of it
 	{

@@ -5,6 +5,9 @@ Two sides share this file, the mock and the harness:
   * `--side ref`  : the REFERENCE's shells (/root/reference/mitsuba/*.cpp, unchanged) on /root/reference/dj_brdf.h,
                     built into oracle/_ref/shells/ -- build container only.  `--golden` stores the outputs as
                     tests/golden/shells.npz (data: inputs, outputs, queried property names, strings).
+  * `--side refsrc`: the REFERENCE's shell sources, unchanged, compiled against THIS repository's facade (include/dj_brdf.h + libdjb_hip.so)
+                    into oracle/_ref/shells_on_facade/ (built here, travels to the GPU box): the facade as a drop-in for the reference's own
+                    callers, the sixth plugin dj_brdf.cpp included (`--which dj_brdf`, golden tests/golden/shells_dj_brdf.npz).
   * `--side repo` : this repository's shells (mitsuba/*.cpp) on include/djb_hip.hpp + libdjb_hip.so, built into
                     tests/mitsuba_mock/_build/.  DJB_DEVICE=cpu selects the library's host path, otherwise GPU 0;
                     DJB_SCALAR_ON_DEVICE=1 sends the one-hit calls through the kernels instead of the host twin.
@@ -31,6 +34,7 @@ from dj_brdf_amd import synth  # noqa: E402
 SHELLS = ["dj_merl", "dj_utia", "dj_abc", "dj_sgd", "dj_beckmannconductor"]
 REF_DIR = os.path.join(ROOT, "oracle", "_ref", "shells")
 REPO_DIR = os.path.join(HERE, "_build")
+REFSRC_DIR = os.path.join(ROOT, "oracle", "_ref", "shells_on_facade")     # built from the reference's sources: lives with the other reference-built files
 
 # BSDF::EBSDFType of the mock (mitsuba/mock.h)
 DIFFUSE, GLOSSY, ALL = 0x2, 0x8, 0xFFFFFFFF
@@ -41,11 +45,19 @@ N = 192
 def build(side, shells=SHELLS, quiet=True):
     """compile one shared object per shell; returns the directory"""
     cxx = shutil.which("g++") or shutil.which("c++")
-    out = REF_DIR if side == "ref" else REPO_DIR
+    out = {"ref": REF_DIR, "refsrc": REFSRC_DIR}.get(side, REPO_DIR)
     os.makedirs(out, exist_ok=True)
     for s in shells:
         so = os.path.join(out, f"libshell_{s}.so")
-        if side == "ref":
+        if side == "refsrc":
+            # the REFERENCE's shell sources, unchanged, on this repository's facade: their `#include "dj_brdf.h"` finds include/dj_brdf.h
+            src = f"/root/reference/mitsuba/{s}.cpp"
+            inc = ["-I", os.path.join(ROOT, "include")]
+            lib = os.path.join(ROOT, "dj_brdf_amd", "lib")
+            link = ["-L", lib, "-ldjb_hip", f"-Wl,-rpath,{lib}"]
+            deps = [src] + [os.path.join(ROOT, "include", f) for f in ("djb_hip.h", "djb_hip.hpp", "dj_brdf.h")]
+            flags = ["-w"]
+        elif side == "ref":
             src = f"/root/reference/mitsuba/{s}.cpp"
             inc = ["-I", "/root/reference"]
             link, deps = [], [src, "/root/reference/dj_brdf.h"]
@@ -244,6 +256,39 @@ def cases(files):
     return c
 
 
+def cases_dj_brdf(files):
+    """the sixth plugin, mitsuba/dj_brdf.cpp (not one of the five named ones; this repository ships no shell of its
+    own for it).  Its REFERENCE source is compiled unchanged against the facade (side "refsrc") and must behave as on the reference's
+    header: distribution beckmann / ggx / tabular, lobes fitted from a MERL or a UTIA file, both Fresnel modes."""
+    merl, utia = files["merl"], files["utia"]
+    D = "dj_brdf"
+    c = [("db_default", D, dict(), [])]
+    for dist in ("beckmann", "ggx", "GGX"):
+        c += [(f"db_{dist}_alpha", D, dict(distribution=dist, alpha=0.3), []),
+              (f"db_{dist}_aniso", D, dict(distribution=dist, alpha1=0.15, alpha2=0.4, alphaAngle=35.0), []),
+              (f"db_{dist}_merl", D, dict(distribution=dist, merl=merl), []),
+              (f"db_{dist}_merl_alpha", D, dict(distribution=dist, merl=merl, alpha=0.7, mitsubaFresnel=True), []),
+              (f"db_{dist}_utia", D, dict(distribution=dist, utia=utia, alpha1=0.8, alpha2=1.2, alphaAngle=15.0), [])]
+    c += [
+        ("db_tabular_merl", D, dict(distribution="tabular", merl=merl), []),
+        ("db_tabular_merl_mf", D, dict(distribution="tabular", merl=merl, mitsubaFresnel=True, material="Au", alpha=0.9), []),
+        ("db_tabular_utia", D, dict(distribution="tabular", utia=utia), []),
+        ("db_tabular_nofile", D, dict(distribution="tabular"), []),
+        ("db_eta_k", D, dict(alpha=0.25, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.2), specularReflectance=(0.9, 0.8, 0.7)), []),
+        ("db_material_au", D, dict(alpha=0.25, material="Au", extEta=1.33), []),
+        ("db_textures", D, dict(alpha=0.3), [("alpha1", affine((0.15, 0.15, 0.15), (0.3, 0.3, 0.3))), ("alpha2", affine((0.4, 0.4, 0.4), (0, 0, 0), (-0.2, -0.2, -0.2))),
+                                             ("alphaAngle", affine((0.1, 0.2, 0.3), (1.0, 1.0, 1.0))), ("specularReflectance", affine((0.9, 0.8, 0.7), (0.05, 0.05, 0.05)))]),
+        ("db_alpha_child", D, dict(), [("alpha", affine((0.35, 0.35, 0.35), (0.1, 0.1, 0.1)))]),
+        ("db_err_distribution", D, dict(distribution="phong"), []),
+        ("db_err_alpha_and_alpha1", D, dict(alpha=0.3, alpha1=0.2), []),
+        ("db_err_alpha1_only", D, dict(alpha1=0.3), []),
+        ("db_err_missing_merl", D, dict(merl=os.path.join(files["dir"], "absent.binary")), []),
+        ("db_badchild", D, dict(), [("reflectance", affine((1, 1, 1)))]),
+        ("db_nontexture", D, dict(), [("alpha", None)]),
+    ]
+    return c
+
+
 def write_inputs(d):
     merl = os.path.join(d, "shells-material.binary")
     synth.write_merl_binary(merl, synth.merl_table(0.25, (0.10, 0.08, 0.05), (0.9, 0.7, 0.4)))
@@ -252,8 +297,9 @@ def write_inputs(d):
     return dict(dir=d, merl=merl, utia=utia)
 
 
-def run(side, libdir=None):
-    libdir = libdir or build(side)
+def run(side, libdir=None, which="five"):
+    """which: "five" = the five named plugins (cases), "dj_brdf" = the sixth (cases_dj_brdf)"""
+    libdir = libdir or build(side, SHELLS if which == "five" else ["dj_brdf"])
     out = {}
     tmp = tempfile.mkdtemp(prefix="djb_shells_")
     try:
@@ -262,7 +308,7 @@ def run(side, libdir=None):
         for k, v in rec.items():
             out[f"in_{k}"] = v
         loaded = {}
-        for name, shell, props_kv, children in cases(files):
+        for name, shell, props_kv, children in (cases(files) if which == "five" else cases_dj_brdf(files)):
             S = loaded.get(shell) or loaded.setdefault(shell, Shell(libdir, shell))
             S.resolver_log()
             props = S.props(name, **props_kv)
@@ -303,12 +349,14 @@ def run(side, libdir=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--side", choices=["ref", "repo"], required=True)
+    ap.add_argument("--side", choices=["ref", "repo", "refsrc"], required=True)
     ap.add_argument("--out")
     ap.add_argument("--golden", action="store_true")
+    ap.add_argument("--which", choices=["five", "dj_brdf"], default="five")
+    ap.add_argument("--prebuilt", action="store_true", help="use the libraries already in the side's directory (the GPU box has no /root/reference to build refsrc from)")
     a = ap.parse_args()
-    res = run(a.side)
-    path = os.path.join(ROOT, "tests", "golden", "shells.npz") if a.golden else a.out
+    res = run(a.side, libdir={"ref": REF_DIR, "refsrc": REFSRC_DIR, "repo": REPO_DIR}[a.side] if a.prebuilt else None, which=a.which)
+    path = os.path.join(ROOT, "tests", "golden", "shells.npz" if a.which == "five" else "shells_dj_brdf.npz") if a.golden else a.out
     if a.golden:
         assert a.side == "ref", "the golden file comes from the reference's shells"
     np.savez_compressed(path, **res)

@@ -206,6 +206,16 @@ void one_seed(unsigned seed, const std::string &scratch, bool with_merl)
 		fprintf(out, "tabular(beckmann, %d)", res); put(ab); put(ag); fprintf(out, "\n");
 		show_table("  p22", tab.get_p22v()); show_table("  sigma", tab.get_sigmav()); show_table("  cdf", tab.get_cdfv()); show_table("  qf", tab.get_qfv());
 		lobe_calls("tabular", g, tab);
+		// fits of fits: a table as the source of another table, isotropic and anisotropic
+		{
+			djb::tabular tt(tab, 8 + g.below(24), g.below(2) != 0);
+			djb::tabular_anisotropic ta(tab, 6 + g.below(5), 8 + g.below(8));
+			djb::tabular tat(ta, 8 + g.below(16));
+			int ec, ac;
+			show_table("  tabular(tabular) p22", tt.get_p22v()); show_table("  aniso(tabular) sigma", ta.get_sigmav(&ec, &ac)); show_table("  tabular(aniso(tabular)) qf", tat.get_qfv());
+			float a1, a2; djb::tabular::fit_ggx_parameters(tt).get_ellipse(&a1, NULL); djb::tabular::fit_beckmann_parameters(tat).get_ellipse(&a2, NULL);
+			fprintf(out, "  alphas"); put(a1); put(a2); fprintf(out, "\n");
+		}
 		delete f; delete f2;
 	}
 	// the published models

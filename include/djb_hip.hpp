@@ -102,8 +102,8 @@ struct vec3 {
 	static vec3 from_raw(const double *v) { return vec3((float_t)v[0], (float_t)v[1], (float_t)v[2]); }
 	static vec3 from_raw(const float *v) { return vec3(v[0], v[1], v[2]); }
 	static const float_t *to_raw(const vec3 &v) { return &v.x; }
-	explicit vec3(float_t x = 0) : x(x), y(x), z(x) {}
-	vec3(float_t x, float_t y, float_t z) : x(x), y(y), z(z) {}
+	explicit vec3(float_t s = 0) : x(s), y(s), z(s) {}
+	vec3(float_t x_, float_t y_, float_t z_) : x(x_), y(y_), z(z_) {}
 	explicit vec3(float_t theta, float_t phi)   // dj_brdf.h:589-595 (double libm, rounded where the reference rounds)
 	{
 		float_t s = (float_t)std::sin((double)theta);
@@ -466,7 +466,7 @@ protected:
 /* MERL BRDF, dj_brdf.h:126-133 */
 class merl : public brdf {
 public:
-	explicit merl(const char *filename, hip::context *c = NULL) : brdf(c)
+	merl(const char *filename, hip::context *c = NULL) : brdf(c)
 	{ hip::check(djb_brdf_create_merl_from_file(ctx(), filename, &m_h)); }
 	merl(const double *samples, int64_t n_per_channel, hip::context *c = NULL) : brdf(c)
 	{ hip::check(djb_brdf_create_merl_from_memory(ctx(), samples, n_per_channel, &m_h)); }
@@ -479,7 +479,7 @@ private:
 /* UTIA BRDF, dj_brdf.h:136-146 */
 class utia : public brdf {
 public:
-	explicit utia(const char *filename, hip::context *c = NULL) : brdf(c)
+	utia(const char *filename, hip::context *c = NULL) : brdf(c)
 	{ hip::check(djb_brdf_create_utia_from_file(ctx(), filename, &m_h)); }
 	const std::vector<double> &get_samples() const { return hip::fetch_samples(m_h, m_samples); }   // dj_brdf.h:143
 	DJB_HIP_RESIDENT_EVAL
@@ -536,7 +536,7 @@ namespace fresnel {
 	class unpolarized : public impl {
 		vec3 ior;
 	public:
-		explicit unpolarized(const vec3 &ior) : ior(ior) { DJB_USER_ASSERT(ior.x > 0.0 && ior.y > 0.0 && ior.z > 0.0 && "Invalid ior"); }   // dj_brdf.h:1257
+		unpolarized(const vec3 &ior_) : ior(ior_) { DJB_USER_ASSERT(ior.x > 0.0 && ior.y > 0.0 && ior.z > 0.0 && "Invalid ior"); }   // dj_brdf.h:1257
 		vec3 eval(float_t cos_theta_d) const { return eval_desc(cos_theta_d); }
 		impl *copy() const { return new unpolarized(*this); }
 		djb_fresnel_desc desc() const
@@ -545,7 +545,7 @@ namespace fresnel {
 	class schlick : public impl {
 		vec3 f0;
 	public:
-		explicit schlick(const vec3 &f0) : f0(f0) {}
+		schlick(const vec3 &f0_) : f0(f0_) {}
 		vec3 eval(float_t cos_theta_d) const { return eval_desc(cos_theta_d); }
 		impl *copy() const { return new schlick(*this); }
 		djb_fresnel_desc desc() const
@@ -554,7 +554,7 @@ namespace fresnel {
 	class sgd : public impl {
 		vec3 f0, f1;
 	public:
-		sgd(const vec3 &f0, const vec3 &f1) : f0(f0), f1(f1) {}
+		sgd(const vec3 &f0_, const vec3 &f1_) : f0(f0_), f1(f1_) {}
 		vec3 eval(float_t cos_theta_d) const { return eval_desc(cos_theta_d); }
 		impl *copy() const { return new sgd(*this); }
 		djb_fresnel_desc desc() const
@@ -598,7 +598,7 @@ namespace fresnel {
 /* Shifted Gamma Distribution BRDF, dj_brdf.h:481-511 (published per-material parameters) */
 class sgd : public brdf {
 public:
-	explicit sgd(const char *name, hip::context *c = NULL) : brdf(c), m_fresnel(NULL)
+	sgd(const char *name, hip::context *c = NULL) : brdf(c), m_fresnel(NULL)
 	{ hip::check(djb_brdf_create_sgd(ctx(), name, &m_h)); m_fresnel = fresnel::from_handle(m_h); }     // fresnel::sgd(f0, f1), dj_brdf.h:3443
 	~sgd() { delete m_fresnel; }
 	const fresnel::impl &get_fresnel() const { return *m_fresnel; }                                   // dj_brdf.h:510
@@ -621,7 +621,7 @@ private:
 /* ABC Distribution BRDF, dj_brdf.h:514-535 */
 class abc : public brdf {
 public:
-	explicit abc(const char *name, hip::context *c = NULL) : brdf(c), m_fresnel(NULL)
+	abc(const char *name, hip::context *c = NULL) : brdf(c), m_fresnel(NULL)
 	{ hip::check(djb_brdf_create_abc(ctx(), name, &m_h)); m_fresnel = fresnel::from_handle(m_h); }     // fresnel::unpolarized(vec3(ior)), dj_brdf.h:3623
 	~abc() { delete m_fresnel; }
 	const fresnel::impl &get_fresnel() const { return *m_fresnel; }                                   // dj_brdf.h:534

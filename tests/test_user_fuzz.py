@@ -38,6 +38,38 @@ def first_difference(a, b):
     return f"{len(la)} vs {len(lb)} lines"
 
 
+def seed_blocks(text):
+    out, cur, key = {}, [], None
+    for line in text.decode().splitlines():
+        if line.startswith("== seed "):
+            if key is not None:
+                out[key] = cur
+            key, cur = int(line.split()[2]), []
+        cur.append(line)
+    if key is not None:
+        out[key] = cur
+    return out
+
+
+def assert_same_as_reference(got, want, ref_exe, extra=()):
+    """got == want, except where the REFERENCE has no defined answer: tabular_anisotropic::qf2 (dj_brdf.h:2812-2822) reads past the end of an
+    m_qf2 that compute_qf2 (:3005-3037) left shorter than elev x azim, so what it prints for such a seed depends on the heap, i.e. on the
+    seeds run before it (5 of 3200 seeds in profiles/r05/fuzz_soak.txt).  A differing seed is accepted only if the reference, run ALONE,
+    disagrees with its own in-sequence output, and we differ from it on those lines only."""
+    if got == want:
+        return
+    G, W = seed_blocks(got), seed_blocks(want)
+    assert sorted(G) == sorted(W), first_difference(got, want)
+    for k in sorted(W):
+        if G[k] == W[k]:
+            continue
+        alone = seed_blocks(subprocess.run([ref_exe, str(k), "1"] + [str(x) for x in extra], capture_output=True, timeout=600).stdout)[k]
+        assert len(alone) == len(W[k]) == len(G[k]), f"seed {k}: {first_difference(got, want)}"
+        unstable = {n for n, (a, b) in enumerate(zip(alone, W[k])) if a != b}
+        ours_off = {n for n, (a, b) in enumerate(zip(G[k], W[k])) if a != b} | {n for n, (a, b) in enumerate(zip(G[k], alone)) if a != b}
+        assert unstable and ours_off <= unstable, f"seed {k}: lines {sorted(ours_off)[:6]} differ from a reproducible reference: {first_difference(got, want)}"
+
+
 def need(path):
     if not os.path.exists(path):
         pytest.skip(f"{os.path.relpath(path, ROOT)} not built")
@@ -53,7 +85,7 @@ def test_user_fuzz_live_on_host_path():
     need(EXE); need(REF)
     want, got = run(REF, 1000, 40), run(EXE, 1000, 40, {"DJB_DEVICE": "cpu"})
     assert want.count(b"== seed") == 40
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, REF)
 
 
 @pytest.mark.gpu
@@ -67,7 +99,7 @@ def test_user_fuzz_golden_on_gpu():
 def test_user_fuzz_live_on_gpu():
     need(EXE); need(REF)
     want, got = run(REF, 2000, 40), run(EXE, 2000, 40, drop=("DJB_DEVICE",))
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, REF)
 
 
 # ---------------------------------------------------------------------------------------------- the shipped classes (examples/api_fuzz.cpp)
@@ -133,7 +165,7 @@ def test_fuzz_programs_from_eight_threads_on_host_path(tmp_path):
     got = run(API_EXE, 12000, 32, {"DJB_DEVICE": "cpu"}, scratch=tmp_path, threads=8)
     assert got == want, first_difference(got, want)
     want, got = run(REF, 12000, 32), run(EXE, 12000, 32, {"DJB_DEVICE": "cpu"}, threads=8)
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, REF)
 
 
 @pytest.mark.gpu
@@ -145,4 +177,4 @@ def test_fuzz_programs_from_eight_threads_on_gpu(tmp_path, scalar_on_device):
     got = run(API_EXE, 13000, 48, env, drop=("DJB_DEVICE",), scratch=tmp_path, merl=True, threads=8)
     assert got == want, first_difference(got, want)
     want, got = run(REF, 13000, 64), run(EXE, 13000, 64, env, drop=("DJB_DEVICE",), threads=8)
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, REF)

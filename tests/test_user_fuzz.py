@@ -118,7 +118,7 @@ def test_api_fuzz_live_on_host_path(tmp_path):
     need(API_EXE); need(API_REF)
     want, got = run(API_REF, 5000, 30, scratch=tmp_path), run(API_EXE, 5000, 30, {"DJB_DEVICE": "cpu"}, scratch=tmp_path)
     assert want.count(b"== seed") == 30
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, API_REF, (tmp_path,))
 
 
 @pytest.mark.gpu
@@ -135,7 +135,7 @@ def test_api_fuzz_live_on_gpu(tmp_path, scalar_on_device):
     need(API_EXE); need(API_REF)
     want = run(API_REF, 6000, 30, scratch=tmp_path)
     got = run(API_EXE, 6000, 30, {"DJB_SCALAR_ON_DEVICE": scalar_on_device}, drop=("DJB_DEVICE",), scratch=tmp_path)
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, API_REF, (tmp_path,))
 
 
 def test_api_fuzz_with_merl_files_on_host_path(tmp_path):
@@ -143,7 +143,7 @@ def test_api_fuzz_with_merl_files_on_host_path(tmp_path):
     need(API_EXE); need(API_REF)
     want, got = run(API_REF, 8000, 4, scratch=tmp_path, merl=True), run(API_EXE, 8000, 4, {"DJB_DEVICE": "cpu"}, scratch=tmp_path, merl=True)
     assert want.count(b"tabular(merl") == 4
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, API_REF, (tmp_path, "merl"))
 
 
 @pytest.mark.gpu
@@ -152,7 +152,7 @@ def test_api_fuzz_with_merl_files_on_gpu(tmp_path, scalar_on_device):
     need(API_EXE); need(API_REF)
     want = run(API_REF, 9000, 6, scratch=tmp_path, merl=True)
     got = run(API_EXE, 9000, 6, {"DJB_SCALAR_ON_DEVICE": scalar_on_device}, drop=("DJB_DEVICE",), scratch=tmp_path, merl=True)
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, API_REF, (tmp_path, "merl"))
 
 
 # ---------------------------------------------------------------------------------------------- concurrency: threads=N
@@ -163,7 +163,7 @@ def test_fuzz_programs_from_eight_threads_on_host_path(tmp_path):
     need(API_EXE); need(API_REF); need(EXE); need(REF)
     want = run(API_REF, 12000, 32, scratch=tmp_path)
     got = run(API_EXE, 12000, 32, {"DJB_DEVICE": "cpu"}, scratch=tmp_path, threads=8)
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, API_REF, (tmp_path,))
     want, got = run(REF, 12000, 32), run(EXE, 12000, 32, {"DJB_DEVICE": "cpu"}, threads=8)
     assert_same_as_reference(got, want, REF)
 
@@ -175,6 +175,6 @@ def test_fuzz_programs_from_eight_threads_on_gpu(tmp_path, scalar_on_device):
     env = {"DJB_SCALAR_ON_DEVICE": scalar_on_device}
     want = run(API_REF, 13000, 48, scratch=tmp_path, merl=True)
     got = run(API_EXE, 13000, 48, env, drop=("DJB_DEVICE",), scratch=tmp_path, merl=True, threads=8)
-    assert got == want, first_difference(got, want)
+    assert_same_as_reference(got, want, API_REF, (tmp_path, "merl"))
     want, got = run(REF, 13000, 64), run(EXE, 13000, 64, env, drop=("DJB_DEVICE",), threads=8)
     assert_same_as_reference(got, want, REF)

@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <stdexcept>
 #include <thread>
 
 #define DJ_BRDF_IMPLEMENTATION 1
@@ -129,6 +130,21 @@ private:
 	float m_w, m_tilt;
 };
 
+// ---- user code that throws: its exceptions must reach the caller as they are (type and message), also when the throwing function was
+// called back by the library (an NDF), and the object must stay usable
+class throwing_ndf : public djb::radial {
+public:
+	throwing_ndf(float limit, bool smith) : m_limit(limit), m_smith(smith) {}
+	bool supports_smith_vndf_sampling() const { return m_smith; }        // true without qf2_radial / qf3_radial: the base class throws "Not Implemented"
+	float p22_radial(float r_sqr) const { if (r_sqr > m_limit) throw std::out_of_range("slope beyond the table"); return (float)(1.0 / (M_PI * (1.0 + (double)r_sqr) * (1.0 + (double)r_sqr))); }
+	float sigma_std_radial(float cos_theta_k) const { return 0.5f * (1.0f + cos_theta_k); }
+	float cdf_radial(float r) const { return r * r / (1.0f + r * r); }
+	float qf_radial(float u) const { return (float)std::sqrt((double)u / (1.0 - (double)u)); }
+private:
+	float m_limit;
+	bool m_smith;
+};
+
 void put(float v) { if (v != v) fprintf(out, " nan"); else fprintf(out, " %a", v); }          // the sign of a NaN is not part of the contract
 void show(const char *tag, const djb::vec3 &v) { fprintf(out, "%s", tag); put(v.x); put(v.y); put(v.z); fprintf(out, "\n"); }
 void show_table(const char *tag, const std::vector<djb::float_t> &v)
@@ -240,6 +256,20 @@ void one_seed(unsigned seed)
 		djb::tabular tab(sl, 10 + g.below(20));
 		float ag; djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
 		fprintf(out, "  tabular(sampled_lobe)"); put(ag); fprintf(out, "\n");
+	}
+	// 6. exceptions out of user code
+	{
+		throwing_ndf t(g.log_in(0.05f, 2.0f), g.below(2) != 0);
+		for (int k = 0; k < 4; ++k) {
+			const djb::vec3 i = g.dir(), o = g.dir();
+			try { show("throwing_ndf.eval", t.eval(i, o)); }
+			catch (const std::out_of_range &e) { fprintf(out, "throwing_ndf.eval: out_of_range: %s\n", e.what()); }
+			try { show("  sample", t.sample(g.u(), g.u(), o)); }
+			catch (const djb::exc &e) { fprintf(out, "  sample: djb::exc: %s\n", e.what()); }
+			catch (const std::exception &e) { fprintf(out, "  sample: %s\n", e.what()); }
+		}
+		try { djb::tabular tab(t, 8 + g.below(16)); fprintf(out, "  a fit went through\n"); }
+		catch (const std::out_of_range &e) { fprintf(out, "  fit: out_of_range: %s\n", e.what()); }
 	}
 }
 

@@ -32,6 +32,9 @@
 #include <exception>
 #include <string>
 #include <vector>
+#if __cplusplus >= 201103L
+#	include <mutex>          /* the slot a user callback's exception waits in (class brdf) */
+#endif
 
 #include "djb_hip.h"
 
@@ -293,13 +296,13 @@ public:
 	virtual vec3 sample(float_t u1, float_t u2, const vec3 &o, const void *user_param = NULL) const    // dj_brdf.h:830-840
 	{
 		vec3 r; djb_vec3_view vo = hip::view(&o), vi = hip::view(&r);
-		hip::check(djb_sample_batch(op_ctx(), op_handle(), 1, &u1, &u2, &vo, m_h ? params_of(user_param) : NULL, &vi, DJB_MEM_HOST));
+		checked(djb_sample_batch(op_ctx(), op_handle(), 1, &u1, &u2, &vo, m_h ? params_of(user_param) : NULL, &vi, DJB_MEM_HOST));
 		return r;
 	}
 	virtual float_t pdf(const vec3 &i, const vec3 &o, const void *user_param = NULL) const              // dj_brdf.h:842-845
 	{
 		float_t r = 0; djb_vec3_view vi = hip::view(&i), vo = hip::view(&o);
-		hip::check(djb_pdf_batch(op_ctx(), op_handle(), 1, &vi, &vo, m_h ? params_of(user_param) : NULL, &r, DJB_MEM_HOST));
+		checked(djb_pdf_batch(op_ctx(), op_handle(), 1, &vi, &vo, m_h ? params_of(user_param) : NULL, &r, DJB_MEM_HOST));
 		return r;
 	}
 	static void io_to_hd(const vec3 &i, const vec3 &o, vec3 *h, vec3 *d)
@@ -319,42 +322,42 @@ public:
 	{
 		if (!resident()) { host_eval_batch(false, n, i, o, out, user_param); return; }
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out);
-		hip::check(djb_eval_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+		checked(djb_eval_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 	}
 	void evalp(size_t n, const vec3 *i, const vec3 *o, vec3 *out, const void *user_param = NULL) const
 	{
 		if (!resident()) { host_eval_batch(true, n, i, o, out, user_param); return; }
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(out);
-		hip::check(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+		checked(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 	}
 	void pdf(size_t n, const vec3 *i, const vec3 *o, float_t *out, const void *user_param = NULL) const
 	{
 		if (!overrides_resident_ops()) { for (size_t k = 0; k < n; ++k) out[k] = pdf(i[k], o[k], user_param); return; }
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o);
-		hip::check(djb_pdf_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), out, DJB_MEM_HOST));
+		checked(djb_pdf_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), out, DJB_MEM_HOST));
 	}
 	void sample(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_i,
 	            const void *user_param = NULL) const
 	{
 		if (!overrides_resident_ops()) { for (size_t k = 0; k < n; ++k) out_i[k] = sample(u1[k], u2[k], o[k], user_param); return; }
 		djb_vec3_view vo = hip::view(o), vi = hip::view(out_i);
-		hip::check(djb_sample_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vi, DJB_MEM_HOST));
+		checked(djb_sample_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vi, DJB_MEM_HOST));
 	}
 	void evalp_is(size_t n, const float_t *u1, const float_t *u2, const vec3 *o, vec3 *out_weight,
 	              vec3 *out_i, float_t *out_pdf, const void *user_param = NULL) const
 	{
 		if (!resident()) { host_evalp_is_batch(n, u1, u2, o, out_weight, out_i, out_pdf, user_param); return; }
 		djb_vec3_view vo = hip::view(o), vw = hip::view(out_weight), vi = hip::view(out_i);
-		hip::check(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi,
+		checked(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi,
 		                              out_pdf, DJB_MEM_HOST));
 	}
 	// ---- batch, device-resident (SoA or strided views in HBM; asynchronous on the context stream): resident objects only
 	void eval_device(int64_t n, const djb_vec3_view &i, const djb_vec3_view &o, const djb_vec3_view &out,
 	                 const void *user_param = NULL) const
-	{ need_resident("eval_device"); hip::check(djb_eval_batch(ctx(), m_h, n, &i, &o, params_of(user_param), &out, DJB_MEM_DEVICE)); }
+	{ need_resident("eval_device"); checked(djb_eval_batch(ctx(), m_h, n, &i, &o, params_of(user_param), &out, DJB_MEM_DEVICE)); }
 	void eval_pdf_device(int64_t n, const djb_vec3_view &i, const djb_vec3_view &o, const djb_vec3_view &out,
 	                     float_t *out_pdf, bool cos = false, const void *user_param = NULL) const
-	{ need_resident("eval_pdf_device"); hip::check(djb_eval_pdf_batch(ctx(), m_h, n, &i, &o, params_of(user_param), cos, &out, out_pdf, DJB_MEM_DEVICE)); }
+	{ need_resident("eval_pdf_device"); checked(djb_eval_pdf_batch(ctx(), m_h, n, &i, &o, params_of(user_param), cos, &out, out_pdf, DJB_MEM_DEVICE)); }
 
 	// NULL for a user-derived object; for a microfacet BRDF with a user-defined Fresnel term the handle of its D G part
 	const djb_brdf *handle() const { return m_h; }
@@ -375,20 +378,20 @@ protected:
 	vec3 eval_resident(const vec3 &i, const vec3 &o, const void *user_param) const
 	{
 		vec3 r; djb_vec3_view vi = hip::view(&i), vo = hip::view(&o), vr = hip::view(&r);
-		hip::check(djb_eval_batch(ctx(), m_h, 1, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+		checked(djb_eval_batch(ctx(), m_h, 1, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 		return r;
 	}
 	// one-pair calls on the handle whatever resident() says (the D G part of a microfacet BRDF with a user-defined Fresnel term)
 	vec3 handle_evalp(const vec3 &i, const vec3 &o, const void *user_param) const
 	{
 		vec3 r; djb_vec3_view vi = hip::view(&i), vo = hip::view(&o), vr = hip::view(&r);
-		hip::check(djb_evalp_batch(ctx(), m_h, 1, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+		checked(djb_evalp_batch(ctx(), m_h, 1, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 		return r;
 	}
 	vec3 handle_evalp_is(float_t u1, float_t u2, const vec3 &o, vec3 *i, float_t *pdf, const void *user_param) const
 	{
 		vec3 w; djb_vec3_view vo = hip::view(&o), vw = hip::view(&w), vi = hip::view(i);
-		hip::check(djb_evalp_is_batch(ctx(), m_h, 1, &u1, &u2, &vo, params_of(user_param), &vw, &vi, pdf, DJB_MEM_HOST));
+		checked(djb_evalp_is_batch(ctx(), m_h, 1, &u1, &u2, &vo, params_of(user_param), &vw, &vi, pdf, DJB_MEM_HOST));
 		return w;
 	}
 	// sample / pdf never involve the Fresnel term: a handle answers them even when eval is composed on the host
@@ -402,6 +405,27 @@ protected:
 	{ for (size_t k = 0; k < n; ++k) out_weight[k] = evalp_is(u1[k], u2[k], o[k], &out_i[k], &out_pdf[k], user_param); }
 	void need_resident(const char *what) const
 	{ if (!resident()) throw exc(DJB_ERR_INVALID_ARGUMENT, std::string("djb_error: ") + what + " needs a BRDF resident on the GPU (this object is evaluated by host code)"); }
+	// An exception thrown by the CALLER'S code while the library was calling it back (a user-defined NDF: the cb_* trampolines of
+	// microfacet / radial) must reach the caller as it is -- type and message -- as it does in the reference, where the call is direct.
+	// It cannot travel through the C ABI: the trampoline keeps it here (and hands the library a NaN), and every library call made on
+	// behalf of this object re-throws it when it returns (`checked`).  Callbacks may run on the library's worker threads: one slot per
+	// object, first exception wins.  Before C++11 there is no std::exception_ptr: the exception then crosses the library and arrives as
+	// a djb::exc carrying its message.
+#if __cplusplus >= 201103L
+	void stash_user_exception() const { std::lock_guard<std::mutex> lock(m_exc_mu); if (!m_exc) m_exc = std::current_exception(); }
+	void rethrow_user_exception() const
+	{
+		std::exception_ptr e;
+		{ std::lock_guard<std::mutex> lock(m_exc_mu); e = m_exc; m_exc = std::exception_ptr(); }
+		if (e) std::rethrow_exception(e);
+	}
+	mutable std::exception_ptr m_exc;
+	mutable std::mutex m_exc_mu;
+#else
+	void stash_user_exception() const {}
+	void rethrow_user_exception() const {}
+#endif
+	void checked(djb_status st) const { rethrow_user_exception(); hip::check(st); }
 	djb_brdf *m_h;
 	hip::context *m_ctx;
 	bool m_host_eval;        // eval involves host code beyond the handle (a user-derived brdf; a user-defined Fresnel term)
@@ -450,7 +474,7 @@ public:
 		params(const vec3 &reflectance = vec3(1)) : m_reflectance(reflectance) {}
 		vec3 m_reflectance;
 	};
-	explicit lambert(hip::context *c = NULL) : brdf(c) { hip::check(djb_brdf_create_lambert(ctx(), &m_h)); }
+	explicit lambert(hip::context *c = NULL) : brdf(c) { checked(djb_brdf_create_lambert(ctx(), &m_h)); }
 	DJB_HIP_RESIDENT_EVAL
 protected:
 	const djb_params *params_of(const void *user_param) const   // dj_brdf.h:863-865
@@ -467,9 +491,9 @@ protected:
 class merl : public brdf {
 public:
 	merl(const char *filename, hip::context *c = NULL) : brdf(c)
-	{ hip::check(djb_brdf_create_merl_from_file(ctx(), filename, &m_h)); }
+	{ checked(djb_brdf_create_merl_from_file(ctx(), filename, &m_h)); }
 	merl(const double *samples, int64_t n_per_channel, hip::context *c = NULL) : brdf(c)
-	{ hip::check(djb_brdf_create_merl_from_memory(ctx(), samples, n_per_channel, &m_h)); }
+	{ checked(djb_brdf_create_merl_from_memory(ctx(), samples, n_per_channel, &m_h)); }
 	const std::vector<double> &get_samples() const { return hip::fetch_samples(m_h, m_samples); }   // dj_brdf.h:132
 	DJB_HIP_RESIDENT_EVAL
 private:
@@ -480,7 +504,7 @@ private:
 class utia : public brdf {
 public:
 	utia(const char *filename, hip::context *c = NULL) : brdf(c)
-	{ hip::check(djb_brdf_create_utia_from_file(ctx(), filename, &m_h)); }
+	{ checked(djb_brdf_create_utia_from_file(ctx(), filename, &m_h)); }
 	const std::vector<double> &get_samples() const { return hip::fetch_samples(m_h, m_samples); }   // dj_brdf.h:143
 	DJB_HIP_RESIDENT_EVAL
 private:
@@ -599,7 +623,7 @@ namespace fresnel {
 class sgd : public brdf {
 public:
 	sgd(const char *name, hip::context *c = NULL) : brdf(c), m_fresnel(NULL)
-	{ hip::check(djb_brdf_create_sgd(ctx(), name, &m_h)); m_fresnel = fresnel::from_handle(m_h); }     // fresnel::sgd(f0, f1), dj_brdf.h:3443
+	{ checked(djb_brdf_create_sgd(ctx(), name, &m_h)); m_fresnel = fresnel::from_handle(m_h); }     // fresnel::sgd(f0, f1), dj_brdf.h:3443
 	~sgd() { delete m_fresnel; }
 	const fresnel::impl &get_fresnel() const { return *m_fresnel; }                                   // dj_brdf.h:510
 	DJB_HIP_RESIDENT_EVAL
@@ -611,7 +635,7 @@ protected:
 	vec3 mq(int which, const vec3 &a, const vec3 *b, const vec3 *c) const
 	{
 		vec3 r; djb_vec3_view va = hip::view(&a), vb = hip::view(b ? b : &a), vc = hip::view(c ? c : &a), vr = hip::view(&r);
-		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, &vb, &vc, NULL, &vr, DJB_MEM_HOST));
+		checked(djb_query_batch(ctx(), m_h, which, 1, &va, &vb, &vc, NULL, &vr, DJB_MEM_HOST));
 		return r;
 	}
 private:
@@ -622,7 +646,7 @@ private:
 class abc : public brdf {
 public:
 	abc(const char *name, hip::context *c = NULL) : brdf(c), m_fresnel(NULL)
-	{ hip::check(djb_brdf_create_abc(ctx(), name, &m_h)); m_fresnel = fresnel::from_handle(m_h); }     // fresnel::unpolarized(vec3(ior)), dj_brdf.h:3623
+	{ checked(djb_brdf_create_abc(ctx(), name, &m_h)); m_fresnel = fresnel::from_handle(m_h); }     // fresnel::unpolarized(vec3(ior)), dj_brdf.h:3623
 	~abc() { delete m_fresnel; }
 	const fresnel::impl &get_fresnel() const { return *m_fresnel; }                                   // dj_brdf.h:534
 	DJB_HIP_RESIDENT_EVAL
@@ -633,7 +657,7 @@ protected:
 	vec3 mq(int which, const vec3 &a, const vec3 *b, const vec3 *c) const
 	{
 		vec3 r; djb_vec3_view va = hip::view(&a), vb = hip::view(b ? b : &a), vc = hip::view(c ? c : &a), vr = hip::view(&r);
-		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, &vb, &vc, NULL, &vr, DJB_MEM_HOST));
+		checked(djb_query_batch(ctx(), m_h, which, 1, &va, &vb, &vc, NULL, &vr, DJB_MEM_HOST));
 		return r;
 	}
 private:
@@ -691,7 +715,7 @@ public:
 		return k != DJB_KIND_TABULAR && k != DJB_KIND_TABULAR_ANISO;
 	}
 	int get_shadow() const { return djb_brdf_get_shadow(m_h); }
-	void set_shadow(bool shadow) { hip::check(djb_brdf_set_shadow(m_h, shadow ? 1 : 0)); }          // dj_brdf.h:278
+	void set_shadow(bool shadow) { checked(djb_brdf_set_shadow(m_h, shadow ? 1 : 0)); }          // dj_brdf.h:278
 	void set_fresnel(const fresnel::impl &f)                                                         // dj_brdf.h:1521-1525
 	{
 		const fresnel::impl *copy = f.copy();
@@ -774,7 +798,7 @@ protected:
 		}
 		std::vector<vec3> dg(n);
 		djb_vec3_view vi = hip::view(i), vo = hip::view(o), vr = hip::view(&dg[0]);
-		hip::check(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
+		checked(djb_evalp_batch(ctx(), m_h, (int64_t)n, &vi, &vo, params_of(user_param), &vr, DJB_MEM_HOST));
 		for (size_t k = 0; k < n; ++k) {
 			const float_t s = dg[k].x;
 			if (s == s && s != (float_t)0) {
@@ -790,7 +814,7 @@ protected:
 		if (!n) return;
 		if (m_host_eval && !supports_smith_vndf_sampling()) { brdf::host_evalp_is_batch(n, u1, u2, o, out_weight, out_i, out_pdf, user_param); return; }
 		djb_vec3_view vo = hip::view(o), vw = hip::view(out_weight), vi = hip::view(out_i);
-		hip::check(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi, out_pdf, DJB_MEM_HOST));
+		checked(djb_evalp_is_batch(ctx(), m_h, (int64_t)n, u1, u2, &vo, params_of(user_param), &vw, &vi, out_pdf, DJB_MEM_HOST));
 		if (!m_host_eval) return;
 		for (size_t k = 0; k < n; ++k) {
 			const float_t s = out_weight[k].x;                     // G / G1 under fresnel::ideal
@@ -820,19 +844,30 @@ protected:
 	struct user_tag {};
 	microfacet(user_tag, const fresnel::impl &f) : brdf(&hip::context::host()), m_fresnel(f.copy()) { m_host_only = true; }   // radial's user constructor
 	// the callbacks only forward to the virtuals above.  They are called from the library's host path -- for batches from several of
-	// its worker threads at once (the operators are const, as in the reference) -- and must not throw
-	static int cb_smith(void *u) { return static_cast<const microfacet *>(u)->supports_smith_vndf_sampling() ? 1 : 0; }
-	static float cb_p22_std(void *u, float x, float y) { return static_cast<const microfacet *>(u)->p22_std(x, y); }
-	static float cb_sigma_std(void *u, const float *k) { return static_cast<const microfacet *>(u)->sigma_std(vec3(k[0], k[1], k[2])); }
+	// its worker threads at once (the operators are const, as in the reference).  What the user's code throws is kept in the object
+	// and re-thrown to the caller when the library call returns (brdf::checked); the library is handed a NaN meanwhile
+#if __cplusplus >= 201103L
+#	define DJB_HIP_CB(self, expr, fallback) try { return (expr); } catch (...) { (self)->stash_user_exception(); return fallback; }
+#else
+#	define DJB_HIP_CB(self, expr, fallback) return (expr);
+#endif
+	static float cb_nan() { unsigned int w = 0x7fc00000u; float f; memcpy(&f, &w, 4); return f; }
+	static int cb_smith(void *u) { const microfacet *s = static_cast<const microfacet *>(u); DJB_HIP_CB(s, s->supports_smith_vndf_sampling() ? 1 : 0, 0) }
+	static float cb_p22_std(void *u, float x, float y) { const microfacet *s = static_cast<const microfacet *>(u); DJB_HIP_CB(s, s->p22_std(x, y), cb_nan()) }
+	static float cb_sigma_std(void *u, const float *k) { const microfacet *s = static_cast<const microfacet *>(u); DJB_HIP_CB(s, s->sigma_std(vec3(k[0], k[1], k[2])), cb_nan()) }
 	static void cb_sample_std(void *u, float u1, float u2, const float *k, float *x, float *y)
-	{ static_cast<const microfacet *>(u)->sample_vp22_std_smith(u1, u2, vec3(k[0], k[1], k[2]), x, y); }
+	{
+		const microfacet *s = static_cast<const microfacet *>(u);
+		*x = *y = cb_nan();
+		DJB_HIP_CB(s, (s->sample_vp22_std_smith(u1, u2, vec3(k[0], k[1], k[2]), x, y), void()), void())
+	}
 	void create_user_handle(bool, bool shadow)
 	{
 		djb_user_ndf n = djb_user_ndf();
 		n.user = const_cast<microfacet *>(this);
 		n.supports_smith_vndf_sampling = cb_smith; n.p22_std = cb_p22_std; n.sigma_std = cb_sigma_std; n.sample_vp22_std = cb_sample_std;
 		djb_fresnel_desc d = resident_desc(*m_fresnel, &m_host_eval);
-		hip::check(djb_brdf_create_user_microfacet(ctx(), &n, &d, shadow ? 1 : 0, &m_h));
+		checked(djb_brdf_create_user_microfacet(ctx(), &n, &d, shadow ? 1 : 0, &m_h));
 	}
 	// the term the handle is created with: the library's own, or ideal under a user-defined one (*host = true)
 	static djb_fresnel_desc resident_desc(const fresnel::impl &f, bool *host)
@@ -848,14 +883,14 @@ protected:
 	{
 		vec3 out;
 		djb_vec3_view va = hip::view(a), vb = hip::view(b ? b : a), vc = hip::view(c ? c : a), vo = hip::view(&out);
-		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, b ? &vb : NULL, c ? &vc : NULL, p.desc(), &vo, DJB_MEM_HOST));
+		checked(djb_query_batch(ctx(), m_h, which, 1, &va, b ? &vb : NULL, c ? &vc : NULL, p.desc(), &vo, DJB_MEM_HOST));
 		return out.x;
 	}
 	vec3 q3(int which, const vec3 &a) const
 	{
 		vec3 out;
 		djb_vec3_view va = hip::view(&a), vo = hip::view(&out);
-		hip::check(djb_query_batch(ctx(), m_h, which, 1, &va, NULL, NULL, NULL, &vo, DJB_MEM_HOST));
+		checked(djb_query_batch(ctx(), m_h, which, 1, &va, NULL, NULL, NULL, &vo, DJB_MEM_HOST));
 		return out;
 	}
 	const fresnel::impl *m_fresnel;
@@ -874,7 +909,7 @@ public:
 		n.supports_smith_vndf_sampling = cb_smith_r; n.p22_radial = cb_p22_radial; n.sigma_std_radial = cb_sigma_std_radial;
 		n.cdf_radial = cb_cdf_radial; n.qf_radial = cb_qf_radial; n.qf2_radial = cb_qf2_radial; n.qf3_radial = cb_qf3_radial;
 		djb_fresnel_desc d = resident_desc(*m_fresnel, &m_host_eval);
-		hip::check(djb_brdf_create_user_microfacet(ctx(), &n, &d, shadow ? 1 : 0, &m_h));
+		checked(djb_brdf_create_user_microfacet(ctx(), &n, &d, shadow ? 1 : 0, &m_h));
 	}
 	virtual float_t p22_radial(float_t r_sqr) const = 0;
 	virtual float_t sigma_std_radial(float_t cos_theta_k) const = 0;
@@ -887,13 +922,13 @@ protected:
 	float_t rq(int which, float_t a, float_t b = 0, float_t c = 0) const
 	{ vec3 v(a, b, c); return q(which, &v, NULL, NULL, params::standard()); }
 private:
-	static int cb_smith_r(void *u) { return static_cast<const radial *>(u)->supports_smith_vndf_sampling() ? 1 : 0; }
-	static float cb_p22_radial(void *u, float r) { return static_cast<const radial *>(u)->p22_radial(r); }
-	static float cb_sigma_std_radial(void *u, float c) { return static_cast<const radial *>(u)->sigma_std_radial(c); }
-	static float cb_cdf_radial(void *u, float r) { return static_cast<const radial *>(u)->cdf_radial(r); }
-	static float cb_qf_radial(void *u, float x) { return static_cast<const radial *>(u)->qf_radial(x); }
-	static float cb_qf2_radial(void *u, float x, float c, float sn) { return static_cast<const radial *>(u)->qf2_radial(x, c, sn); }
-	static float cb_qf3_radial(void *u, float x, float q2) { return static_cast<const radial *>(u)->qf3_radial(x, q2); }
+	static int cb_smith_r(void *u) { const radial *s = static_cast<const radial *>(u); DJB_HIP_CB(s, s->supports_smith_vndf_sampling() ? 1 : 0, 0) }
+	static float cb_p22_radial(void *u, float r) { const radial *s = static_cast<const radial *>(u); DJB_HIP_CB(s, s->p22_radial(r), cb_nan()) }
+	static float cb_sigma_std_radial(void *u, float c) { const radial *s = static_cast<const radial *>(u); DJB_HIP_CB(s, s->sigma_std_radial(c), cb_nan()) }
+	static float cb_cdf_radial(void *u, float r) { const radial *s = static_cast<const radial *>(u); DJB_HIP_CB(s, s->cdf_radial(r), cb_nan()) }
+	static float cb_qf_radial(void *u, float x) { const radial *s = static_cast<const radial *>(u); DJB_HIP_CB(s, s->qf_radial(x), cb_nan()) }
+	static float cb_qf2_radial(void *u, float x, float c, float sn) { const radial *s = static_cast<const radial *>(u); DJB_HIP_CB(s, s->qf2_radial(x, c, sn), cb_nan()) }
+	static float cb_qf3_radial(void *u, float x, float q2) { const radial *s = static_cast<const radial *>(u); DJB_HIP_CB(s, s->qf3_radial(x, q2), cb_nan()) }
 };
 /* what the library's radial lobes declare: the radial queries answered from the handle */
 #define DJB_HIP_RESIDENT_RADIAL \

@@ -931,14 +931,23 @@ private:
 	static float cb_qf3_radial(void *u, float x, float q2) { const radial *s = static_cast<const radial *>(u); DJB_HIP_CB(s, s->qf3_radial(x, q2), cb_nan()) }
 };
 /* what the library's radial lobes declare: the radial queries answered from the handle */
+/* The NDF virtuals of the library's own lobes are FINAL (C++11 and later): their operators are answered from the object in HBM, so an
+ * override in a class derived from djb::ggx / beckmann / tabular would be ignored by every operator -- in the reference it would
+ * change them (eval -> p22_std -> p22_radial is virtual all the way).  A compile error instead of a silent difference: a lobe with its
+ * own NDF derives from djb::radial or djb::microfacet (INTEGRATION.md "User-defined classes"). */
+#if __cplusplus >= 201103L
+#	define DJB_HIP_FINAL final
+#else
+#	define DJB_HIP_FINAL
+#endif
 #define DJB_HIP_RESIDENT_RADIAL \
-	float_t p22_radial(float_t r_sqr) const { return rq(DJB_Q_P22_RADIAL, r_sqr); } \
-	float_t sigma_std_radial(float_t cos_theta_k) const { return rq(DJB_Q_SIGMA_STD_RADIAL, cos_theta_k); } \
-	float_t cdf_radial(float_t r) const { return rq(DJB_Q_CDF_RADIAL, r); } \
-	float_t qf_radial(float_t u) const { return rq(DJB_Q_QF_RADIAL, u); }
+	float_t p22_radial(float_t r_sqr) const DJB_HIP_FINAL { return rq(DJB_Q_P22_RADIAL, r_sqr); } \
+	float_t sigma_std_radial(float_t cos_theta_k) const DJB_HIP_FINAL { return rq(DJB_Q_SIGMA_STD_RADIAL, cos_theta_k); } \
+	float_t cdf_radial(float_t r) const DJB_HIP_FINAL { return rq(DJB_Q_CDF_RADIAL, r); } \
+	float_t qf_radial(float_t u) const DJB_HIP_FINAL { return rq(DJB_Q_QF_RADIAL, u); }
 #define DJB_HIP_RESIDENT_RADIAL_SMITH \
-	float_t qf2_radial(float_t u, float_t cos_theta_k, float_t sin_theta_k) const { return rq(DJB_Q_QF2_RADIAL, u, cos_theta_k, sin_theta_k); } \
-	float_t qf3_radial(float_t u, float_t qf2) const { return rq(DJB_Q_QF3_RADIAL, u, qf2); }
+	float_t qf2_radial(float_t u, float_t cos_theta_k, float_t sin_theta_k) const DJB_HIP_FINAL { return rq(DJB_Q_QF2_RADIAL, u, cos_theta_k, sin_theta_k); } \
+	float_t qf3_radial(float_t u, float_t qf2) const DJB_HIP_FINAL { return rq(DJB_Q_QF3_RADIAL, u, qf2); }
 
 /* Beckmann Microfacet NDF, dj_brdf.h:327-371 */
 class beckmann : public radial {

@@ -110,3 +110,18 @@ def test_header_in_several_translation_units(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(tmp_path / "prog")], env=dict(os.environ, DJB_DEVICE="cpu", DJB_QUIET="1"), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "0x1.6d4a2ap-4 0x1.5af378p-4", out.stdout + out.stderr      # what the reference prints for it
+
+
+def test_overriding_the_ndf_of_a_resident_lobe_is_a_compile_error(tmp_path):
+    """In the reference a class derived from djb::ggx that overrides p22_radial changes eval / pdf / sample (virtual all the way down).
+    The library's lobes are answered from HBM and would ignore the override: the facade makes it a compile error (C++11 `final`) instead
+    of a silent difference; deriving without touching the NDF, and deriving from djb::radial with an NDF of one's own, stay legal."""
+    bad = '#include "dj_brdf.h"\nstruct my : djb::ggx { float p22_radial(float r) const { return r; } };\nint main() { my m; return 0; }\n'
+    r, _ = build(tmp_path, bad)
+    assert r.returncode != 0 and ("final" in r.stderr), r.stderr[-1500:]
+    ok = ('#include "dj_brdf.h"\nstruct my : djb::ggx { float twice(const djb::vec3 &i, const djb::vec3 &o) const { return 2 * pdf(i, o); } };\n'
+          'int main() { my m; return m.twice(djb::vec3(0, 0, 1), djb::vec3(0, 0, 1)) > 0 ? 0 : 1; }\n')
+    r, exe = build(tmp_path, ok)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], env=dict(os.environ, DJB_DEVICE="cpu", DJB_QUIET="1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr

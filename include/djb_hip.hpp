@@ -33,6 +33,7 @@
 #include <string>
 #include <vector>
 #if __cplusplus >= 201103L
+#	include <atomic>
 #	include <mutex>          /* the slot a user callback's exception waits in (class brdf) */
 #endif
 
@@ -368,10 +369,10 @@ public:
 	// then its eval() is sampled there and the fit itself runs on the default context (the GPU, where there is one)
 	hip::context &fit_context() const { return m_host_only ? hip::context::standard() : get_context(); }
 	hip::context &get_context() const { return m_ctx ? *m_ctx : hip::context::standard(); }
-	brdf() : m_h(NULL), m_ctx(NULL), m_host_eval(true), m_host_only(false) {}                            // dj_brdf.h:102
+	brdf() : m_h(NULL), m_ctx(NULL), m_host_eval(true), m_host_only(false) { init_exc(); }                            // dj_brdf.h:102
 	virtual ~brdf() { djb_brdf_destroy(m_h); }
 protected:
-	explicit brdf(hip::context *c) : m_h(NULL), m_ctx(c ? c : &hip::context::standard()), m_host_eval(false), m_host_only(false) {}
+	explicit brdf(hip::context *c) : m_h(NULL), m_ctx(c ? c : &hip::context::standard()), m_host_eval(false), m_host_only(false) { init_exc(); }
 	djb_ctx *ctx() const { return get_context().get(); }
 	virtual const djb_params *params_of(const void *) const { return NULL; }   // ignored by merl/utia/...
 	// eval of a resident object: what the library's classes override `eval` with
@@ -412,18 +413,23 @@ protected:
 	// object, first exception wins.  Before C++11 there is no std::exception_ptr: the exception then crosses the library and arrives as
 	// a djb::exc carrying its message.
 #if __cplusplus >= 201103L
-	void stash_user_exception() const { std::lock_guard<std::mutex> lock(m_exc_mu); if (!m_exc) m_exc = std::current_exception(); }
+	void stash_user_exception() const
+	{ std::lock_guard<std::mutex> lock(m_exc_mu); if (!m_exc) { m_exc = std::current_exception(); m_exc_set.store(1, std::memory_order_release); } }
 	void rethrow_user_exception() const
 	{
+		if (!m_exc_set.load(std::memory_order_acquire)) return;          // the common case: one relaxed-cost load, no lock (render threads share a BSDF)
 		std::exception_ptr e;
-		{ std::lock_guard<std::mutex> lock(m_exc_mu); e = m_exc; m_exc = std::exception_ptr(); }
+		{ std::lock_guard<std::mutex> lock(m_exc_mu); e = m_exc; m_exc = std::exception_ptr(); m_exc_set.store(0, std::memory_order_release); }
 		if (e) std::rethrow_exception(e);
 	}
 	mutable std::exception_ptr m_exc;
 	mutable std::mutex m_exc_mu;
+	mutable std::atomic<int> m_exc_set;
+	void init_exc() { m_exc_set.store(0, std::memory_order_relaxed); }
 #else
 	void stash_user_exception() const {}
 	void rethrow_user_exception() const {}
+	void init_exc() {}
 #endif
 	void checked(djb_status st) const { rethrow_user_exception(); hip::check(st); }
 	djb_brdf *m_h;

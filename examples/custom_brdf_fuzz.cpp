@@ -145,6 +145,21 @@ private:
 	bool m_smith;
 };
 
+// ---- an NDF defined at the microfacet level that samples the Smith way: qf2 / qf3 overridden (dj_brdf.h:273-275, 1769-1791)
+class smith_user : public djb::microfacet {
+public:
+	smith_user(float a, const djb::fresnel::impl &f) : djb::microfacet(f), m_a(a) {}
+	bool supports_smith_vndf_sampling() const { return true; }
+	float qf2(float u, const djb::vec3 &k) const { return (float)(((double)u - 0.5) * 2.0 * (double)m_a / (0.2 + (double)k.z)); }
+	float qf3(float u, const djb::vec3 &k, float qf2_) const { return (float)(((double)u - 0.5) * (double)m_a * (1.0 + (double)(qf2_ * qf2_)) + 0.1 * (double)k.y); }
+protected:
+	float sigma_std(const djb::vec3 &k) const { return (float)(0.5 * ((double)k.z + std::sqrt((double)(k.z * k.z) + (double)(m_a * m_a) * (double)(k.x * k.x + k.y * k.y)))); }
+	float p22_std(float x, float y) const { const double t = 1.0 + (double)(x * x + y * y) / (double)(m_a * m_a); return (float)(1.0 / (M_PI * (double)(m_a * m_a) * t * t)); }
+	void sample_vp22_std_nmap(float, float, const djb::vec3 &, float *x, float *y) const { *x = *y = 0.0f; }
+private:
+	float m_a;
+};
+
 void put(float v) { if (v != v) fprintf(out, " nan"); else fprintf(out, " %a", v); }          // the sign of a NaN is not part of the contract
 void show(const char *tag, const djb::vec3 &v) { fprintf(out, "%s", tag); put(v.x); put(v.y); put(v.z); fprintf(out, "\n"); }
 void show_table(const char *tag, const std::vector<djb::float_t> &v)
@@ -256,6 +271,19 @@ void one_seed(unsigned seed)
 		djb::tabular tab(sl, 10 + g.below(20));
 		float ag; djb::tabular::fit_ggx_parameters(tab).get_ellipse(&ag, NULL);
 		fprintf(out, "  tabular(sampled_lobe)"); put(ag); fprintf(out, "\n");
+	}
+	// 7 (placed before 6 for no reason but history). a microfacet-level NDF with its own qf2 / qf3
+	{
+		my_fresnel f(g);
+		smith_user su(g.log_in(0.1f, 1.0f), f);
+		djb::microfacet::params pr = djb::microfacet::params::elliptic(g.log_in(0.1f, 1.0f), g.log_in(0.1f, 1.0f), g.in(0.0f, 3.0f));
+		const djb::vec3 i = g.dir(), o = g.dir();
+		show("smith_user.eval", su.eval(i, o, &pr)); fprintf(out, "  pdf"); put(su.pdf(i, o, &pr)); fprintf(out, " qf2"); put(su.qf2(g.u(), o)); fprintf(out, "\n");
+		show("  sample", su.sample(g.u(), g.u(), o, &pr));
+		djb::vec3 wi; float pdf;
+		show("  evalp_is", su.evalp_is(g.u(), g.u(), o, &wi, &pdf, &pr)); show("    i", wi); fprintf(out, "    pdf"); put(pdf); fprintf(out, "\n");
+		const djb::microfacet &base = su;
+		fprintf(out, "  vndf"); put(base.vndf(djb::normalize(i + o), o, pr)); put(base.vp22(g.in(-1.0f, 1.0f), g.in(-1.0f, 1.0f), o, pr)); put(base.gaf(djb::normalize(i + o), i, o, pr)); fprintf(out, "\n");
 	}
 	// 6. exceptions out of user code
 	{

@@ -125,3 +125,15 @@ def test_overriding_the_ndf_of_a_resident_lobe_is_a_compile_error(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(exe)], env=dict(os.environ, DJB_DEVICE="cpu", DJB_QUIET="1"), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_member_signatures_are_the_reference_ones():
+    """tests/api/api_signature_probe.cpp asserts the exact type of every public member (return type, parameters, const, static), the
+    abstract / noncopyable / convertible properties of the classes, and calls everything once with its default arguments omitted.  It
+    compiles against the reference (which proves the assertions, where the reference is mounted) and must compile against the facade."""
+    src = os.path.join(ROOT, "tests", "api", "api_signature_probe.cpp")
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-DNVERBOSE", "-Wall", "-I", os.path.join(ROOT, "include"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    if os.path.exists("/root/reference/dj_brdf.h"):
+        r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-DNVERBOSE", "-w", "-I", "/root/reference", src], capture_output=True, text=True)
+        assert r.returncode == 0, "the probe does not compile against the reference itself:\n" + r.stderr[-4000:]

@@ -118,7 +118,7 @@ djb_status params_for(const djb_params *in, int brdf_kind, Params *p)
 	// a scalar call costs ~100 ns: do not re-derive params::standard() (cos / sin / sqrt chain, what the reference does
 	// on every call with user_param == NULL, dj_brdf.h:1532-1534) each time, and not at all for the kinds that ignore it
 	const bool uses_params = DJB_IS_MICROFACET(brdf_kind) || brdf_kind == KIND_LAMBERT;
-	if (!uses_params && (!in || in->kind != DJB_PARAMS_LAMBERT)) { memset(p, 0, sizeof *p); return DJB_OK; }
+	if (!uses_params && (!in || DJB_PARAMS_KIND(in->kind) != DJB_PARAMS_LAMBERT)) { memset(p, 0, sizeof *p); return DJB_OK; }
 	if (!in && brdf_kind != KIND_LAMBERT) {
 		static const Params std_p = [] {
 			float v[9]; Params q; memset(&q, 0, sizeof q);
@@ -126,6 +126,13 @@ djb_status params_for(const djb_params *in, int brdf_kind, Params *p)
 			return q;
 		}();
 		*p = std_p;
+		return DJB_OK;
+	}
+	if ((in->kind & DJB_PARAMS_RESOLVED_FOLLOWS) && DJB_PARAMS_KIND(in->kind) != DJB_PARAMS_LAMBERT && brdf_kind != KIND_LAMBERT) {
+		// a parameter set that carries its resolved form (include/djb_hip.h: djb_params_cached; the facade's params objects): read it
+		const djb_params_resolved &r = reinterpret_cast<const djb_params_cached *>(in)->r;
+		p->nx = r.n[0]; p->ny = r.n[1]; p->nz = r.n[2]; p->ax = r.ax; p->ay = r.ay; p->rho = r.rho; p->s = r.sqrt_one_minus_rho_sqr;
+		p->tx = r.tx_n; p->ty = r.ty_n; p->r_ax = 0.0; p->r_t2 = 0.0;
 		return DJB_OK;
 	}
 	float v[9];

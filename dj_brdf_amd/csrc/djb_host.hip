@@ -45,8 +45,12 @@ void resolve_ellipse(djb_params_resolved *p, float a1, float a2, float phi_a)
 
 djb_status resolve_params(const djb_params *in, djb_params_resolved *p)
 {
+	if (in && (in->kind & DJB_PARAMS_RESOLVED_FOLLOWS) && DJB_PARAMS_KIND(in->kind) != DJB_PARAMS_LAMBERT) {
+		*p = reinterpret_cast<const djb_params_cached *>(in)->r;       // resolved once by djb_params_resolve (include/djb_hip.h)
+		return DJB_OK;
+	}
 	memset(p, 0, sizeof *p);
-	int kind = in ? in->kind : DJB_PARAMS_STANDARD;
+	int kind = in ? DJB_PARAMS_KIND(in->kind) : DJB_PARAMS_STANDARD;
 	if (kind == DJB_PARAMS_STANDARD) {
 		resolve_ellipse(p, 1.0f, 1.0f, 0.0f);
 		resolve_location(p, 0.0f, 0.0f);
@@ -77,18 +81,19 @@ djb_status resolve_params(const djb_params *in, djb_params_resolved *p)
 	return DJB_OK;
 }
 
-djb_status device_params(const djb_params *in, Params *out, int brdf_kind)
+djb_status device_params(const djb_params *in, Params *out, int brdf_kind, bool want_reciprocals)
 {
+	const int in_kind = in ? DJB_PARAMS_KIND(in->kind) : DJB_PARAMS_STANDARD;
 	// lambert::params(reflectance) (dj_brdf.h:114-119, 861-868): carried to the kernel in the n slot
 	if (brdf_kind == DJB_KIND_LAMBERT) {
-		if (in && in->kind != DJB_PARAMS_STANDARD && in->kind != DJB_PARAMS_LAMBERT)
+		if (in && in_kind != DJB_PARAMS_STANDARD && in_kind != DJB_PARAMS_LAMBERT)
 			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: a lambert brdf takes lambert::params");
 		memset(out, 0, sizeof *out);
-		const bool has = in && in->kind == DJB_PARAMS_LAMBERT;
+		const bool has = in && in_kind == DJB_PARAMS_LAMBERT;
 		out->nx = has ? in->v[0] : 1.0f; out->ny = has ? in->v[1] : 1.0f; out->nz = has ? in->v[2] : 1.0f;
 		return DJB_OK;
 	}
-	if (in && in->kind == DJB_PARAMS_LAMBERT)
+	if (in && in_kind == DJB_PARAMS_LAMBERT)
 		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: lambert::params passed to a brdf that is not a lambert");
 	djb_params_resolved r;
 	djb_status st = resolve_params(in, &r);
@@ -98,6 +103,8 @@ djb_status device_params(const djb_params *in, Params *out, int brdf_kind)
 	out->tx = r.tx_n; out->ty = r.ty_n;
 	// reciprocals of the two launch-uniform denominators of mf_p22 (djb_device.hpp: fdiv_r): correctly rounded doubles
 	// of exactly the floats the kernel divides by (this TU is built with -ffp-contract=off: no FMA in ax * ay * s)
+	out->r_ax = out->r_t2 = 0.0;
+	if (!want_reciprocals) return DJB_OK;                        // the host path divides
 	const float t2 = out->ax * out->ay * out->s;
 	out->r_ax = 1.0 / (double)out->ax;
 	out->r_t2 = 1.0 / (double)t2;
@@ -738,7 +745,10 @@ DJB_ABI_CATCH
 djb_status djb_params_resolve(const djb_params *params, djb_params_resolved *out)
 try {
 	if (!out) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
-	return resolve_params(params, out);
+	if (!params) return resolve_params(nullptr, out);
+	djb_params plain = *params;                                   // always computed here: this is where a cached form comes from
+	plain.kind = DJB_PARAMS_KIND(plain.kind);
+	return resolve_params(&plain, out);
 }
 DJB_ABI_CATCH
 
@@ -750,7 +760,7 @@ namespace djbk {
 djb_status resolve_device_params(const djb_params *in, float out9[9], int brdf_kind)
 {
 	Params p;
-	djb_status st = device_params(in, &p, brdf_kind);
+	djb_status st = device_params(in, &p, brdf_kind, false);
 	if (st != DJB_OK) return st;
 	out9[0] = p.nx; out9[1] = p.ny; out9[2] = p.nz; out9[3] = p.ax; out9[4] = p.ay; out9[5] = p.rho; out9[6] = p.s; out9[7] = p.tx; out9[8] = p.ty;
 	// (the host path divides: r_ax / r_t2 stay 0 there)

@@ -119,7 +119,7 @@ constexpr long long SCALAR_HOST_MAX = DJB_SCALAR_HOST_MAX;   // scalar-size DJB_
 
 // microfacet::params on the host (djb_host.hip)
 djb_status resolve_params(const djb_params *in, djb_params_resolved *p);
-djb_status device_params(const djb_params *in, Params *out, int brdf_kind = -1);
+djb_status device_params(const djb_params *in, Params *out, int brdf_kind = -1, bool want_reciprocals = true);
 
 // ------------------------------------------------------------------ host <-> HBM staging
 // DJB_MEM_HOST callers: every array is copied to / from HBM **in the caller's own layout** with

@@ -3,13 +3,18 @@
 // process default context (a GPU object answers scalar-size host calls from its host twin, include/djb_hip.h
 // DJB_SCALAR_HOST_MAX) and the aggregate rate of T threads sharing ONE object; exits 0 iff every single-thread
 // figure is below 1 us.      usage: scalar_latency [threads]
+// Written against the reference's interface only: oracle/Makefile builds the same source on the real reference
+// (oracle/_ref/scalar_latency), so the two can be timed side by side on one machine (tools/exp/r05/host_path_o3.sh).
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
-#include "djb_hip.hpp"
+#define DJ_BRDF_IMPLEMENTATION 1
+#include "dj_brdf.h"
 
 int main(int argc, char **argv)
 {
@@ -30,10 +35,11 @@ int main(int argc, char **argv)
 			printf("%-28s %8.0f ns per call\n", what, ns);
 			if (ns > worst) worst = ns;
 		};
-		run("ggx.eval(i, o, &params)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz); return ggx.eval(i, o, &iso).x; });
-		run("ggx.pdf(i, o)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz); return ggx.pdf(i, o); });
-		run("beckmann.sample(u1, u2, o)", [&](int k) { return beck.sample(0.25f + 1e-7f * k, 0.75f, o, &iso).x; });
-		run("tabular.evalp(i, o)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz); return tab.evalp(i, o).x; });
+		// both directions move with k: nothing of a pair is loop-invariant for a compiler that inlines the reference's header
+		run("ggx.eval(i, o, &params)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); return ggx.eval(i, ok, &iso).x; });
+		run("ggx.pdf(i, o)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); return ggx.pdf(i, ok); });
+		run("beckmann.sample(u1, u2, o)", [&](int k) { djb::vec3 ok(-0.4f + 1e-7f * k, 0.1f, oz); return beck.sample(0.25f + 1e-7f * k, 0.75f, ok, &iso).x; });
+		run("tabular.evalp(i, o)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); return tab.evalp(i, ok).x; });
 		// render threads sharing one BSDF: no lock on the scalar path
 		std::vector<std::thread> th;
 		auto t0 = clk::now();

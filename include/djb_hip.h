@@ -51,8 +51,10 @@ extern "C" {
  *        DJB_FRESNEL_HOST.  No existing entry changed.
  *   220  round 5: + djb_brdf_create_user_microfacet / djb_user_ndf (user-defined NDFs on the host path), DJB_KIND_USER,
  *        djb_brdf_get_fresnel.
- *   230  round 5: + djb_helper (the reference's file-static erf / erfinv / xyz_to_theta_phi / uniform_to_concentric / rotate_vector).  */
-#define DJB_HIP_VERSION 230
+ *   230  round 5: + djb_helper (the reference's file-static erf / erfinv / xyz_to_theta_phi / uniform_to_concentric / rotate_vector).
+ *   231  round 5: + DJB_PARAMS_RESOLVED_FOLLOWS / djb_params_cached (a parameter set that carries its resolved form: one-pair calls
+ *        skip the set-up arithmetic).  A plain djb_params means what it always meant.  */
+#define DJB_HIP_VERSION 231
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
 typedef enum {
@@ -105,6 +107,14 @@ typedef struct {
 	float ax, ay, rho, sqrt_one_minus_rho_sqr;
 	float tx_n, ty_n;
 } djb_params_resolved;
+
+/* A parameter set together with its resolved form, as the reference's params object holds it (dj_brdf.h:237-242: the factories do the
+ * cos / sin / sqrt / atan set-up once, eval / pdf / sample copy the result).  `p.kind` carries DJB_PARAMS_RESOLVED_FOLLOWS and `r` is what
+ * djb_params_resolve(&p, &r) returned for the same p (with the flag cleared): every entry point that takes a `const djb_params *` then
+ * reads `r` instead of redoing the set-up -- 40-60 ns of a ~100 ns one-pair call.  The djb:: facade's params objects are of this form. */
+#define DJB_PARAMS_RESOLVED_FOLLOWS 0x100
+#define DJB_PARAMS_KIND(k) ((k) & 0xff)
+typedef struct { djb_params p; djb_params_resolved r; } djb_params_cached;
 
 /* djb::fresnel::{ideal,unpolarized,schlick,sgd,spline} (dj_brdf.h:149-207).
  * DJB_FRESNEL_HOST marks a term only the CALLER can evaluate -- a class a user derived from fresnel::impl

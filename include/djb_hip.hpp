@@ -680,37 +680,42 @@ public:
 		static params isotropic(float_t a) { return elliptic(a, a, 0); }
 		static params elliptic(float_t a1, float_t a2, float_t phi_a = 0.0)
 		{ DJB_USER_ASSERT(a1 > 0.0 && a2 > 0.0 && "Invalid ellipse radii");                                   // dj_brdf.h:1453
-		  params p; p.m_desc.kind = DJB_PARAMS_ELLIPTIC; p.m_desc.v[0] = a1; p.m_desc.v[1] = a2; p.m_desc.v[2] = phi_a; p.resolve(); return p; }
+		  params p; p.m_c.p.kind = DJB_PARAMS_ELLIPTIC; p.m_c.p.v[0] = a1; p.m_c.p.v[1] = a2; p.m_c.p.v[2] = phi_a; p.resolve(); return p; }
 		static params pdfparams(float_t ax, float_t ay, float_t rho = 0.0, float_t tx_n = 0.0, float_t ty_n = 0.0)
 		{
 			DJB_USER_ASSERT(ax > 0.0 && ay > 0.0 && "Invalid scale parameters");                                  // dj_brdf.h:1466
 			DJB_USER_ASSERT(std::fabs(rho) < 1.0 && "Invalid correlation parameter");                            // dj_brdf.h:1467
-			params p; p.m_desc.kind = DJB_PARAMS_PDFPARAMS;
-			p.m_desc.v[0] = ax; p.m_desc.v[1] = ay; p.m_desc.v[2] = rho; p.m_desc.v[3] = tx_n; p.m_desc.v[4] = ty_n;
+			params p; p.m_c.p.kind = DJB_PARAMS_PDFPARAMS;
+			p.m_c.p.v[0] = ax; p.m_c.p.v[1] = ay; p.m_c.p.v[2] = rho; p.m_c.p.v[3] = tx_n; p.m_c.p.v[4] = ty_n;
 			p.resolve(); return p;
 		}
 		void set_ellipse(float_t a1, float_t a2, float_t phi_a = 0.0)
-		{ float_t tx = m_r.tx_n, ty = m_r.ty_n; *this = elliptic(a1, a2, phi_a); if (tx != 0 || ty != 0) set_location(tx, ty); }
+		{ float_t tx = m_c.r.tx_n, ty = m_c.r.ty_n; *this = elliptic(a1, a2, phi_a); if (tx != 0 || ty != 0) set_location(tx, ty); }
 		void set_pdfparams(float_t ax, float_t ay, float_t rho = 0.0, float_t tx_n = 0.0, float_t ty_n = 0.0)
 		{ *this = pdfparams(ax, ay, rho, tx_n, ty_n); }
-		void set_location(float_t tx_n, float_t ty_n) { *this = pdfparams(m_r.ax, m_r.ay, m_r.rho, tx_n, ty_n); }
+		void set_location(float_t tx_n, float_t ty_n) { *this = pdfparams(m_c.r.ax, m_c.r.ay, m_c.r.rho, tx_n, ty_n); }
 		/* dj_brdf.h:1444-1449: tx = -n.x / n.z, ty = -n.y / n.z.  The kernels use the unit normal of
 		 * (tx, ty); it agrees with `n` in direction whenever n.z > 0. */
 		void set_location(const vec3 &n) { set_location(-n.x / n.z, -n.y / n.z); }
 		void get_ellipse(float_t *a1, float_t *a2, float_t *phi_a = NULL) const
-		{ if (a1) *a1 = m_r.a1; if (a2) *a2 = m_r.a2; if (phi_a) *phi_a = m_r.phi_a; }
+		{ if (a1) *a1 = m_c.r.a1; if (a2) *a2 = m_c.r.a2; if (phi_a) *phi_a = m_c.r.phi_a; }
 		void get_pdfparams(float_t *ax, float_t *ay, float_t *rho = NULL, float_t *tx_n = NULL, float_t *ty_n = NULL) const
-		{ if (ax) *ax = m_r.ax; if (ay) *ay = m_r.ay; if (rho) *rho = m_r.rho; if (tx_n) *tx_n = m_r.tx_n; if (ty_n) *ty_n = m_r.ty_n; }
-		void get_location(float_t *tx_n, float_t *ty_n) const { if (tx_n) *tx_n = m_r.tx_n; if (ty_n) *ty_n = m_r.ty_n; }
-		void get_location(vec3 *n) const { if (n) *n = vec3(m_r.n[0], m_r.n[1], m_r.n[2]); }
+		{ if (ax) *ax = m_c.r.ax; if (ay) *ay = m_c.r.ay; if (rho) *rho = m_c.r.rho; if (tx_n) *tx_n = m_c.r.tx_n; if (ty_n) *ty_n = m_c.r.ty_n; }
+		void get_location(float_t *tx_n, float_t *ty_n) const { if (tx_n) *tx_n = m_c.r.tx_n; if (ty_n) *ty_n = m_c.r.ty_n; }
+		void get_location(vec3 *n) const { if (n) *n = vec3(m_c.r.n[0], m_c.r.n[1], m_c.r.n[2]); }
 		params(float_t ax, float_t ay, float_t rho, float_t tx_n, float_t ty_n) { *this = pdfparams(ax, ay, rho, tx_n, ty_n); }   // dj_brdf.h:236
 		params(float_t a1 = 1.0, float_t a2 = 1.0, float_t phi_a = 0.0)
-		{ m_desc.kind = DJB_PARAMS_ELLIPTIC; m_desc.v[0] = a1; m_desc.v[1] = a2; m_desc.v[2] = phi_a; m_desc.v[3] = m_desc.v[4] = 0; resolve(); }
-		const djb_params *desc() const { return &m_desc; }
+		{ m_c.p.kind = DJB_PARAMS_ELLIPTIC; m_c.p.v[0] = a1; m_c.p.v[1] = a2; m_c.p.v[2] = phi_a; m_c.p.v[3] = m_c.p.v[4] = 0; resolve(); }
+		const djb_params *desc() const { return &m_c.p; }
 	private:
-		void resolve() { hip::check(djb_params_resolve(&m_desc, &m_r)); }   // DJB_ASSERT sites -> djb::exc
-		djb_params m_desc;
-		djb_params_resolved m_r;
+		// the set-up arithmetic runs once, here, as in the reference's factories; the calls read the result (djb_params_cached)
+		void resolve()
+		{
+			m_c.p.kind = DJB_PARAMS_KIND(m_c.p.kind);
+			hip::check(djb_params_resolve(&m_c.p, &m_c.r));              // DJB_ASSERT sites -> djb::exc
+			m_c.p.kind |= DJB_PARAMS_RESOLVED_FOLLOWS;
+		}
+		djb_params_cached m_c;
 	};
 
 	// false for the two tabulated classes, which sample with the "nmap" scheme (dj_brdf.h:412, 439); a user-defined NDF class

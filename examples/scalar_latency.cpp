@@ -40,6 +40,15 @@ int main(int argc, char **argv)
 		run("ggx.pdf(i, o)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); return ggx.pdf(i, ok); });
 		run("beckmann.sample(u1, u2, o)", [&](int k) { djb::vec3 ok(-0.4f + 1e-7f * k, 0.1f, oz); return beck.sample(0.25f + 1e-7f * k, 0.75f, ok, &iso).x; });
 		run("tabular.evalp(i, o)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); return tab.evalp(i, ok).x; });
+		// the same call through a base-class pointer the compiler cannot see through (how a renderer holds its BSDFs), first with
+		// independent calls (the core overlaps consecutive ones where it can), then with each call's input depending on the previous
+		// result (the latency of ONE call: what a path tracer's dependent chain of hits sees)
+		{
+			djb::brdf *bp = &ggx; asm volatile("" : "+r"(bp));
+			float prev = 0.0f;
+			run("brdf*->eval, independent", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); return bp->eval(i, ok, &iso).x; });
+			run("brdf*->eval, dependent", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k + 1e-30f * prev, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); prev = bp->eval(i, ok, &iso).x; return prev; });
+		}
 		// render threads sharing one BSDF: no lock on the scalar path
 		std::vector<std::thread> th;
 		auto t0 = clk::now();

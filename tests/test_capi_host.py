@@ -161,3 +161,46 @@ def test_synth_file_format_and_determinism(tmp_path):
     u = synth.uniforms(100000, 9)
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
     assert len(set(synth.MERL_NAMES)) == 100
+
+
+def test_params_that_carry_their_resolved_form():
+    """include/djb_hip.h, ABI 231: a djb_params followed by what djb_params_resolve returned for it (kind | DJB_PARAMS_RESOLVED_FOLLOWS =
+    djb_params_cached, the form of the facade's params objects) gives the bits of the plain djb_params -- one pair and a batch, every
+    operator that takes parameters; djb_params_resolve itself ignores the flag (it is where a cached form comes from); a lambert brdf
+    still refuses microfacet parameters whatever the flag says."""
+    lib = _lib.load()
+    FLAG = 0x100
+
+    class Cached(C.Structure):
+        _fields_ = [("p", _lib.Params), ("r", _lib.ParamsResolved)]
+
+    ctx = djb.Context("cpu")
+    g, bk, lam = djb.ggx(djb.fresnel.schlick((0.9, 0.6, 0.3)), True, ctx=ctx), djb.beckmann(ctx=ctx), djb.lambert(ctx=ctx)
+    for n in (1, 257):
+        i, o = synth.directions_aos(n, 5), synth.directions_aos(n, 6)
+        u1, u2 = synth.uniforms(n, 7), synth.uniforms(n, 8)
+        for case in PARAM_CASES:
+            P = djb.microfacet.params
+            p = getattr(P, case[0])(*case[1:]) if case is not None else P.standard()
+            c = Cached(); c.p = p._p
+            _lib.check(lib.djb_params_resolve(C.byref(c.p), C.byref(c.r)))
+            r0 = _lib.ParamsResolved()
+            c.p.kind |= FLAG
+            poison = Cached(); C.memmove(C.byref(poison), C.byref(c), C.sizeof(c)); poison.r.ax = 123.0   # a stale resolved form next to a flagged kind
+            _lib.check(lib.djb_params_resolve(C.byref(poison.p), C.byref(r0)))                        # ... is not what resolve reads
+            assert bytes(r0) == bytes(c.r)
+
+            Q = P.standard(); Q._p = c.p; Q._keep = c          # the mirror passes byref(_p): a view into `c`, so `r` follows it in memory
+            for b in (g, bk):
+                for op in ("eval", "evalp", "pdf"):
+                    want, got = getattr(b, op)(i, o, p), getattr(b, op)(i, o, Q)
+                    assert np.array_equal(np.asarray(want).view(np.uint32), np.asarray(got).view(np.uint32)), (case, op, n)
+                want, got = b.sample(u1, u2, o, p), b.sample(u1, u2, o, Q)
+                assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (case, "sample", n)
+            if (c.p.kind & 0xff) == 0:                          # params::standard() is what a lambert accepts besides its own
+                assert np.array_equal(lam.eval(i, o, p).view(np.uint32), lam.eval(i, o, Q).view(np.uint32))
+            else:
+                for q in (p, Q):
+                    with pytest.raises(djb.exc):
+                        lam.eval(i, o, q)
+    ctx.close()

@@ -211,7 +211,10 @@ const djb_brdf *scalar_twin(const djb_ctx *ctx, const djb_brdf *b, long long n, 
 {
 	if (mem != DJB_MEM_HOST || n > SCALAR_HOST_MAX || n < 0 || !b || ctx->scalar_on_device) return nullptr;
 	if (b->device != ctx->device) return nullptr;
-	std::call_once(b->twin_once, build_twin, b, const_cast<djb_ctx *>(ctx));
+	if (!b->twin_built.load(std::memory_order_acquire)) {
+		std::call_once(b->twin_once, build_twin, b, const_cast<djb_ctx *>(ctx));       // returns once the twin exists, whoever built it
+		b->twin_built.store(1, std::memory_order_release);
+	}
 	return b->twin;
 }
 

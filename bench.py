@@ -30,7 +30,10 @@ Extra objects in the JSON line:
                                       launch -> alphas, wall time = max over ranks, with the load / fit split
                                       and (N=1) the reference's own merl_params binary timed on a few of the files;
                   merl_fit_100        compute only (tables already resident in HBM);
-                at N=1 also the other single-GPU configs (ggx_eval_pdf, beckmann_sample) and utia_eval
+                at N=1 also the other single-GPU configs (ggx_eval_pdf, beckmann_sample) and utia_eval;
+                  one_pair_calls      ns per ONE call of the facade's virtuals (what a renderer issues): a GPU object answered by
+                                      its host twin, the CPU context, and (cpu_baseline inside it) the real reference built from
+                                      the same source (examples/scalar_latency.cpp, oracle/_ref/scalar_latency)
   roofline      dominant kernel: algorithmic bytes per launch / average launch duration
                 (HIP events on the ctx stream over the timed region) vs the 8 TB/s HBM peak
   cpu_baseline  the CPU path timed on this host (rank 0, N=1 only) on a bounded sample:
@@ -333,6 +336,40 @@ def make_step(name, n, djb, synth, ctx, torch):
             ab, ag, result["timing"] = merl_params.fit_files_on(ctx, paths)
         return step, (paths, result)
     raise ValueError(name)
+
+
+def one_pair_calls(with_reference):
+    """What ONE call of the djb:: surface costs (the reference's real callers make one-pair virtual calls from render threads):
+    examples/scalar_latency on a GPU object (answered by its host twin, no launch) and, as the reported CPU baseline, the same source
+    built on the real reference (oracle/_ref/scalar_latency) on the same host cores."""
+    import subprocess
+
+    def run(exe, env_extra=None):
+        if not os.path.exists(exe):
+            return None
+        env = dict(os.environ, DJB_QUIET="1")
+        env.update(env_extra or {})
+        try:
+            r = subprocess.run([exe, "16"], capture_output=True, text=True, timeout=120, env=env)
+        except Exception:
+            return None
+        out = {}
+        for line in r.stdout.splitlines():
+            if "ns per call" in line:
+                out[" ".join(line.split()[:-4])] = float(line.split()[-4])
+            elif "threads on one ggx object" in line:
+                out["16_threads_one_object_M_calls_per_s"] = float(line.split(":")[1].split("M calls/s")[0])
+        return out or None
+
+    rec = {"unit": "ns per call", "gpu_object_host_twin": run(os.path.join(ROOT, "examples", "scalar_latency")),
+           "cpu_context": run(os.path.join(ROOT, "examples", "scalar_latency"), {"DJB_DEVICE": "cpu"}),
+           "what": "one (i, o) pair per call through the C++ facade's virtuals, single thread; `brdf*->eval, dependent` = each call's input "
+                   "depends on the previous result (the latency of one call); batches are the GPU's business, these are not"}
+    if with_reference:
+        ref = run(os.path.join(ROOT, "oracle", "_ref", "scalar_latency"))
+        if ref:
+            rec["cpu_baseline"] = {"kind": "reference", "cores": 1, "sample": "400k calls per operator, the same source on the reference's header (-O2)", **ref}
+    return rec
 
 
 def cpu_baseline(name, synth, budget_s=12.0):
@@ -784,6 +821,9 @@ def main():
             sec = {"merl_fit_files_100": fitfiles, "merl_fit_100": fit100}
             if fitdir is not None:
                 sec["merl_fit_dir"] = fitdir
+            opc = one_pair_calls(not args.no_cpu_baseline)
+            if opc.get("gpu_object_host_twin"):
+                sec["one_pair_calls"] = opc
             for other in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "ggx_unpolarized_eval_pdf", "ggx_unpolarized_eval_pdf_contract",
                           "sgd_eval", "sgd_eval_contract", "beckmann_sample", "beckmann_sample_contract", "utia_eval", "merl_eval_uniform_bins",
                           "merl_eval_coherent"):

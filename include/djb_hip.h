@@ -111,7 +111,8 @@ typedef struct {
 /* A parameter set together with its resolved form, as the reference's params object holds it (dj_brdf.h:237-242: the factories do the
  * cos / sin / sqrt / atan set-up once, eval / pdf / sample copy the result).  `p.kind` carries DJB_PARAMS_RESOLVED_FOLLOWS and `r` is what
  * djb_params_resolve(&p, &r) returned for the same p (with the flag cleared): every entry point that takes a `const djb_params *` then
- * reads `r` instead of redoing the set-up -- 40-60 ns of a ~100 ns one-pair call.  The djb:: facade's params objects are of this form. */
+ * reads `r` instead of redoing the set-up -- 40-60 ns of a ~100 ns one-pair call.  The djb:: facade's params objects are of this form.
+ * The flag is a promise about the bytes BEHIND the djb_params: a copy of `p` alone must have it cleared (DJB_PARAMS_KIND). */
 #define DJB_PARAMS_RESOLVED_FOLLOWS 0x100
 #define DJB_PARAMS_KIND(k) ((k) & 0xff)
 typedef struct { djb_params p; djb_params_resolved r; } djb_params_cached;

@@ -128,7 +128,7 @@ djb_status params_for(const djb_params *in, int brdf_kind, Params *p)
 		*p = std_p;
 		return DJB_OK;
 	}
-	if ((in->kind & DJB_PARAMS_RESOLVED_FOLLOWS) && DJB_PARAMS_KIND(in->kind) != DJB_PARAMS_LAMBERT && brdf_kind != KIND_LAMBERT) {
+	if (in && brdf_kind != KIND_LAMBERT && (in->kind & DJB_PARAMS_RESOLVED_FOLLOWS) && DJB_PARAMS_KIND(in->kind) != DJB_PARAMS_LAMBERT) {   // (in == NULL reaches here for a lambert)
 		// a parameter set that carries its resolved form (include/djb_hip.h: djb_params_cached; the facade's params objects): read it
 		const djb_params_resolved &r = reinterpret_cast<const djb_params_cached *>(in)->r;
 		p->nx = r.n[0]; p->ny = r.n[1]; p->nz = r.n[2]; p->ax = r.ax; p->ay = r.ay; p->rho = r.rho; p->s = r.sqrt_one_minus_rho_sqr;

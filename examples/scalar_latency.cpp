@@ -40,6 +40,9 @@ int main(int argc, char **argv)
 		run("ggx.pdf(i, o)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); return ggx.pdf(i, ok); });
 		run("beckmann.sample(u1, u2, o)", [&](int k) { djb::vec3 ok(-0.4f + 1e-7f * k, 0.1f, oz); return beck.sample(0.25f + 1e-7f * k, 0.75f, ok, &iso).x; });
 		run("tabular.evalp(i, o)", [&](int k) { djb::vec3 i(0.3f + 1e-7f * k, 0.2f, iz), ok(-0.4f + 1e-7f * k, 0.1f, oz); return tab.evalp(i, ok).x; });
+		// what BSDF::sample() of the plugins issues: direction, weight and pdf in one call
+		run("beckmann.evalp_is(u1, u2, o)", [&](int k) { djb::vec3 ok(-0.4f + 1e-7f * k, 0.1f, oz), i; djb::float_t pdf; return beck.evalp_is(0.25f + 1e-7f * k, 0.75f, ok, &i, &pdf, &iso).x + pdf; });
+		run("tabular.evalp_is(u1, u2, o)", [&](int k) { djb::vec3 ok(-0.4f + 1e-7f * k, 0.1f, oz), i; djb::float_t pdf; return tab.evalp_is(0.25f + 1e-7f * k, 0.75f, ok, &i, &pdf).x + pdf; });
 		// the same call through a base-class pointer the compiler cannot see through (how a renderer holds its BSDFs), first with
 		// independent calls (the core overlaps consecutive ones where it can), then with each call's input depending on the previous
 		// result (the latency of ONE call: what a path tracer's dependent chain of hits sees)

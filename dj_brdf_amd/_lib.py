@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DJB_LIB_PATH") or os.path.join(_HERE, "lib", "libdjb_hip.so")
 
 DJB_OK = 0
-ABI_VERSION = 231          # include/djb_hip.h: DJB_HIP_VERSION (the major digit must match the loaded library)
+ABI_VERSION = 232          # include/djb_hip.h: DJB_HIP_VERSION (the major digit must match the loaded library)
 STATUS_NAMES = {
     0: "DJB_OK", 1: "DJB_ERR_INVALID_ARGUMENT", 2: "DJB_ERR_OPEN_FAILED", 3: "DJB_ERR_BAD_HEADER",
     4: "DJB_ERR_READ_FAILED", 5: "DJB_ERR_NOT_IMPLEMENTED", 6: "DJB_ERR_HIP", 7: "DJB_ERR_NO_DEVICE",

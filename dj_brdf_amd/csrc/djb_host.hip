@@ -209,7 +209,7 @@ void build_twin(const djb_brdf *b, djb_ctx *via)
 // with calls on the same object.
 const djb_brdf *scalar_twin(const djb_ctx *ctx, const djb_brdf *b, long long n, int mem)
 {
-	if (mem != DJB_MEM_HOST || n > SCALAR_HOST_MAX || n < 0 || !b || ctx->scalar_on_device) return nullptr;
+	if (mem != DJB_MEM_HOST || n > ctx->host_batch_max || n < 0 || !b || ctx->scalar_on_device) return nullptr;
 	if (b->device != ctx->device) return nullptr;
 	if (!b->twin_built.load(std::memory_order_acquire)) {
 		std::call_once(b->twin_once, build_twin, b, const_cast<djb_ctx *>(ctx));       // returns once the twin exists, whoever built it
@@ -730,6 +730,7 @@ try {
 	if (is_cpu(ctx)) return DJB_OK;           // the options select GPU code paths
 	if (ctx && option == DJB_OPT_SCALAR_ON_DEVICE) { ctx->scalar_on_device = value != 0; return DJB_OK; }
 	if (ctx && option == DJB_OPT_FIT_FILES_DENSE) { ctx->fit_files_dense = value != 0; return DJB_OK; }
+	if (ctx && option == DJB_OPT_HOST_BATCH_MAX) { ctx->host_batch_max = value < 0 ? 0 : value > 65536 ? 65536 : value; return DJB_OK; }
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	if (option == DJB_OPT_MERL_EXACT_ONLY) { ctx->merl_exact_only = value != 0; return DJB_OK; }
 	if (option == DJB_OPT_ANISO_QF2_ALIGNED) { ctx->aniso_qf2_aligned = value != 0; return DJB_OK; }

@@ -492,7 +492,7 @@ static djb_status hd_common(djb_ctx *ctx, int64_t n, const djb_vec3_view *a, con
 {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	if (is_cpu(ctx)) return djbcpu::io_hd(ctx, n, a, b, c, d, inverse);
-	if (mem == DJB_MEM_HOST && n >= 0 && n <= SCALAR_HOST_MAX && !ctx->scalar_on_device) return djbcpu::io_hd(djbcpu::twin_ctx(), n, a, b, c, d, inverse);
+	if (mem == DJB_MEM_HOST && n >= 0 && n <= ctx->host_batch_max && !ctx->scalar_on_device) return djbcpu::io_hd(djbcpu::twin_ctx(), n, a, b, c, d, inverse);
 	djb_status st = check_call(ctx, nullptr, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
@@ -569,7 +569,7 @@ djb_status djb_merl_index_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i,
 try {
 	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
 	if (is_cpu(ctx)) return djbcpu::merl_index(ctx, n, i, o, out_index);
-	if (mem == DJB_MEM_HOST && n >= 0 && n <= SCALAR_HOST_MAX && !ctx->scalar_on_device) return djbcpu::merl_index(djbcpu::twin_ctx(), n, i, o, out_index);
+	if (mem == DJB_MEM_HOST && n >= 0 && n <= ctx->host_batch_max && !ctx->scalar_on_device) return djbcpu::merl_index(djbcpu::twin_ctx(), n, i, o, out_index);
 	djb_status st = check_call(ctx, nullptr, n, mem);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);

@@ -1232,6 +1232,12 @@ def set_scalar_on_device(ctx: Context, on: bool):
     _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(3), C.c_int(int(on))))
 
 
+def set_host_batch_max(ctx: Context, units: int):
+    """Host-array calls of up to `units` units are answered on the calling thread by the object's host twin instead of a GPU round
+    trip (DJB_OPT_HOST_BATCH_MAX; default DJB_SCALAR_HOST_MAX = 96).  Same bits either way."""
+    _lib.check(_lib.load().djb_ctx_set_option(ctx._h, C.c_int(8), C.c_int(int(units))))
+
+
 def set_utia_exact_only(ctx: Context, on: bool):
     """utia eval / evalp batches run the one-kernel form with the exact fall-backs inline (DJB_OPT_UTIA_EXACT_ONLY)
     instead of the two-tier kernel; same bits."""

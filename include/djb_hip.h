@@ -53,8 +53,9 @@ extern "C" {
  *        djb_brdf_get_fresnel.
  *   230  round 5: + djb_helper (the reference's file-static erf / erfinv / xyz_to_theta_phi / uniform_to_concentric / rotate_vector).
  *   231  round 5: + DJB_PARAMS_RESOLVED_FOLLOWS / djb_params_cached (a parameter set that carries its resolved form: one-pair calls
- *        skip the set-up arithmetic).  A plain djb_params means what it always meant.  */
-#define DJB_HIP_VERSION 231
+ *        skip the set-up arithmetic).  A plain djb_params means what it always meant.
+ *   232  round 5: + DJB_OPT_HOST_BATCH_MAX (the size up to which host-array calls are answered by the host twin; default unchanged).  */
+#define DJB_HIP_VERSION 232
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
 typedef enum {
@@ -204,7 +205,13 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
 /* DJB_OPT_TEST_WORKLIST_CAP = <entries> (tests only; -1 = automatic, the default): overrides the capacity of the tier-2
  * worklist of the two-tier kernels (utia, contract mode; the MERL look-up drains its tier 2 in-kernel and has none), to exercise
  * the overflow path in which the second kernel redoes the whole batch.  Results never depend on the capacity. */
-       DJB_OPT_TEST_WORKLIST_CAP = 7 };
+       DJB_OPT_TEST_WORKLIST_CAP = 7,
+/* DJB_OPT_HOST_BATCH_MAX = <units> (default DJB_SCALAR_HOST_MAX = 96; 0 .. 65536): DJB_MEM_HOST calls of up to that many units are
+ * answered on the CALLING thread by the object's host twin (no staging, no launch, no context lock) instead of a ~22 us GPU round
+ * trip.  96 is the break-even of the most expensive operator (Beckmann sample, ~160 ns per unit on one core); a GGX / tabulated eval
+ * costs ~31 ns per pair, so a caller that submits host batches of a few hundred pairs from several render threads -- where batch
+ * calls on one context also serialise on its lock -- gains from 512 or so.  The results are the same bits either way. */
+       DJB_OPT_HOST_BATCH_MAX = 8 };
 djb_status  djb_ctx_set_option(djb_ctx *ctx, int option, int value);
 /* Observer of the MERL file pipeline (djb_fit_merl_files, both context kinds): `fn(path, user)` is called from the reader thread
  * after a file has passed its size check and has been mapped, before its entries are gathered; NULL removes it.  Diagnostics /

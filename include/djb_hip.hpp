@@ -212,6 +212,9 @@ public:
 	// look-ups and their bin indices, tabular and tabular_anisotropic (fits, eval, sampling), lambert, the queries, LEAN / per-pair
 	// parameter calls, every scalar (one-pair) call, and everything on a CPU context.
 	void set_contract_1e5(bool on) { set_option(DJB_OPT_CONTRACT_1E5, on ? 1 : 0); }
+	// host-array batches of up to `units` units are answered on the calling thread by the host twin (default DJB_SCALAR_HOST_MAX = 96):
+	// a renderer submitting a few hundred pairs per call from several threads gains from ~512 (include/djb_hip.h, DJB_OPT_HOST_BATCH_MAX)
+	void set_host_batch_max(int units) { set_option(DJB_OPT_HOST_BATCH_MAX, units); }
 	void set_option(int option, int value) { check(djb_ctx_set_option(m_ctx, option, value)); }
 	// The process-wide default context, used by every djb:: object that is not given one.  DJB_DEVICE=<n> selects GPU n,
 	// DJB_DEVICE=cpu the host path.  Without the variable it is GPU 0 -- and, ONLY on a machine that has no HIP device at

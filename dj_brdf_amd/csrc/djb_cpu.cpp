@@ -131,6 +131,8 @@ djb_status params_for(const djb_params *in, int brdf_kind, Params *p)
 	if (in && brdf_kind != KIND_LAMBERT && (in->kind & DJB_PARAMS_RESOLVED_FOLLOWS) && DJB_PARAMS_KIND(in->kind) != DJB_PARAMS_LAMBERT) {   // (in == NULL reaches here for a lambert)
 		// a parameter set that carries its resolved form (include/djb_hip.h: djb_params_cached; the facade's params objects): read it
 		const djb_params_resolved &r = reinterpret_cast<const djb_params_cached *>(in)->r;
+		if (!(r.ax > 0.0f && r.ay > 0.0f && r.rho > -1.0f && r.rho < 1.0f))     // a stray flag on a plain djb_params: refuse, do not read garbage as parameters
+			return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: DJB_PARAMS_RESOLVED_FOLLOWS is set but no resolved parameter set follows the djb_params");
 		p->nx = r.n[0]; p->ny = r.n[1]; p->nz = r.n[2]; p->ax = r.ax; p->ay = r.ay; p->rho = r.rho; p->s = r.sqrt_one_minus_rho_sqr;
 		p->tx = r.tx_n; p->ty = r.ty_n; p->r_ax = 0.0; p->r_t2 = 0.0;
 		return DJB_OK;
@@ -863,6 +865,11 @@ djb_status sample(djb_ctx *ctx, const djb_brdf *b_, int64_t n, const float *u1, 
 	const bool is = out_w != nullptr;
 	if (!valid(o) || !valid(out_i) || (is && (!valid(out_w) || !out_pdf)) || ((u1 == nullptr) != (u2 == nullptr)))
 		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument");
+	if (b.kind == KIND_USER) {      // a radial user NDF that samples the Smith way needs qf2_radial / qf3_radial (include/djb_hip.h); the base class of
+		const UserNdf &u = B(b_)->ndf;   // the reference throws "Not Implemented" there (dj_brdf.h:1785-1790), a raw C caller must not jump through NULL
+		if (u.p22_radial && (!u.qf2_radial || !u.qf3_radial) && u.supports_smith_vndf_sampling(u.user))
+			return djbk::set_error(DJB_ERR_NOT_IMPLEMENTED, "djb_error: Not Implemented");
+	}
 	const View vo = view_of(o), vi = view_of(out_i), vw = is ? view_of(out_w) : View{ nullptr, nullptr, nullptr, 0 };
 	parallel_for(C(ctx), n, 2048, [&](long long k0, long long k1) {
 		if (is) { DJB_KIND_SWITCH(b.kind, (sample_loop<K, true>(b, p, k0, k1, u1, u2, s1, s2, start, vo, vi, vw, out_pdf))) }

@@ -47,6 +47,10 @@ djb_status resolve_params(const djb_params *in, djb_params_resolved *p)
 {
 	if (in && (in->kind & DJB_PARAMS_RESOLVED_FOLLOWS) && DJB_PARAMS_KIND(in->kind) != DJB_PARAMS_LAMBERT) {
 		*p = reinterpret_cast<const djb_params_cached *>(in)->r;       // resolved once by djb_params_resolve (include/djb_hip.h)
+		// the flag is a promise about the bytes behind `in`; a stray 0x100 in a plain djb_params must not turn into silently wrong
+		// parameters: what djb_params_resolve writes always satisfies these (three compares, no arithmetic)
+		if (!(p->ax > 0.0f && p->ay > 0.0f && p->rho > -1.0f && p->rho < 1.0f))
+			return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: DJB_PARAMS_RESOLVED_FOLLOWS is set but no resolved parameter set follows the djb_params");
 		return DJB_OK;
 	}
 	memset(p, 0, sizeof *p);

@@ -59,7 +59,7 @@ struct djb_ctx {
 	unsigned int ct_hopeless_calls = 0;        // calls answered by the exact kernel because of ct_key_share: every 16th re-probes
 	long long test_worklist_cap = -1;   // DJB_OPT_TEST_WORKLIST_CAP (tests): >= 0 overrides the tier-2 worklist capacity
 	int contract_1e5 = 0;      // DJB_OPT_CONTRACT_1E5: dense GGX eval batches run the two-tier value-contract kernels
-	long long host_batch_max = DJB_SCALAR_HOST_MAX;   // DJB_OPT_HOST_BATCH_MAX: host-array calls up to this size are answered by the host twin
+	std::atomic<long long> host_batch_max{DJB_SCALAR_HOST_MAX};   // DJB_OPT_HOST_BATCH_MAX: host-array calls up to this size are answered by the host twin
 	int scalar_on_device = 0;  // DJB_OPT_SCALAR_ON_DEVICE: scalar-size host calls go through the GPU too (A/B testing)
 	// HBM staging blocks of the DJB_MEM_HOST path, recycled across calls (hipMalloc costs more than
 	// a small batch); bounded by POOL_MAX_BYTES

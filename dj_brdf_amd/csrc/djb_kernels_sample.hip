@@ -247,7 +247,7 @@ DJB_DEV float bk_qf2_common(float u, float cos_k, float sin_k, const GlibcTabs &
 		inv_erf = ie; b_at = bt;
 		if (last && SHORT_LAST) {
 			const float nt = 0.4431f * (normalization * tan_k);
-			const bool sure = inside & (fabsf(q_step) < 2e-3f) & (nt * (q_step * q_step) < 4e-6f * e_last);
+			const bool sure = inside & (tan_k > 0.0f) & (fabsf(q_step) < 2e-3f) & (nt * (q_step * q_step) < 4e-6f * e_last);   // tan_k > 0: the bound's derivation assumes it (a k.z <= 0 sample is R_DEGENERATE anyway -- this test does not rely on that)
 #ifdef DJB_EXP_TRIP4_CHECK           // measurement: the decision above against the value it stands in for
 			{
 				const float value = normalization * (1 + bt + sqrt_pi_inv * tan_k * expf_main(-ie * ie, gt)) - u;
@@ -456,7 +456,7 @@ DJB_DEV v3 bk_sample_contract(const Params &p, float u1, float u2, v3 o, Rare &r
 				// from the Newton step that led here instead of being computed -- 1/2 |f''| q^2 with room for both sequences' rounding --
 				// and a sample that cannot show it is in doubt (exact path).  E and rder stay those of b2: the error estimate below reads
 				// them within the factor e^(125 |q|) <= 1.28 the step can move them by (it has a factor of five in hand)
-				const bool sure = inside & clear_ends & (fabsf(q_step) < 2e-3f) & ((0.4431f * (N * tan_k)) * (q_step * q_step) < 3e-6f * E);
+				const bool sure = inside & clear_ends & (tan_k > 0.0f) & (fabsf(q_step) < 2e-3f) & ((0.4431f * (N * tan_k)) * (q_step * q_step) < 3e-6f * E);
 				doubt |= !done & !sure;
 				done |= sure;
 				b_at = bt;

@@ -64,18 +64,30 @@ inline SlotPlan make_plan(const std::vector<int32_t> &idx)
 //     also for a foreign SIGBUS on a thread that has never run gather_file.
 struct BusGuard { sigjmp_buf env; const char *lo, *hi; };
 inline thread_local BusGuard *t_bus_guard __attribute__((tls_model("initial-exec"))) = nullptr;
-inline struct sigaction g_prev_sigbus;
+// the handler that was installed before ours: an immutable copy behind an atomic pointer (the handler may read it on any thread while
+// install_sigbus_guard publishes a newer one; the few superseded copies are never freed)
+inline std::atomic<const struct sigaction *> g_prev_sigbus{nullptr};
 inline std::mutex g_sigbus_mu;
+// a foreign fault forwarded once that comes back at the same address on the same thread was not resolved by the chain -- e.g. a
+// handler installed after ours that disables itself and falls back to ours (Python's faulthandler): the second time the default
+// action gets it, instead of bouncing between the two handlers forever
+inline thread_local const void *t_bus_last_addr __attribute__((tls_model("initial-exec"))) = nullptr;
+inline thread_local int t_bus_repeats __attribute__((tls_model("initial-exec"))) = 0;
 inline void on_sigbus(int sig, siginfo_t *si, void *uc)
 {
 	BusGuard *g = t_bus_guard;
 	const char *addr = (const char *)si->si_addr;
 	if (g && addr >= g->lo && addr < g->hi) siglongjmp(g->env, 1);
-	if ((g_prev_sigbus.sa_flags & SA_SIGINFO) && g_prev_sigbus.sa_sigaction) { g_prev_sigbus.sa_sigaction(sig, si, uc); return; }
-	if (!(g_prev_sigbus.sa_flags & SA_SIGINFO) && g_prev_sigbus.sa_handler == SIG_IGN) return;
-	if (!(g_prev_sigbus.sa_flags & SA_SIGINFO) && g_prev_sigbus.sa_handler != SIG_DFL) { g_prev_sigbus.sa_handler(sig); return; }
+	const bool repeat = addr == t_bus_last_addr && ++t_bus_repeats >= 1;
+	if (addr != t_bus_last_addr) { t_bus_last_addr = addr; t_bus_repeats = 0; }
+	const struct sigaction *prev = g_prev_sigbus.load(std::memory_order_acquire);
+	if (!repeat && prev) {
+		if ((prev->sa_flags & SA_SIGINFO) && prev->sa_sigaction && prev->sa_sigaction != on_sigbus) { prev->sa_sigaction(sig, si, uc); return; }
+		if (!(prev->sa_flags & SA_SIGINFO) && prev->sa_handler == SIG_IGN) return;
+		if (!(prev->sa_flags & SA_SIGINFO) && prev->sa_handler != SIG_DFL) { prev->sa_handler(sig); return; }
+	}
 	struct sigaction dfl; memset(&dfl, 0, sizeof dfl); dfl.sa_handler = SIG_DFL; sigemptyset(&dfl.sa_mask);
-	sigaction(SIGBUS, &dfl, nullptr);          // not ours and nobody else's: the faulting access re-executes under the default action
+	sigaction(SIGBUS, &dfl, nullptr);          // not ours and nobody else's (or unresolved by the chain): the faulting access re-executes under the default action
 }
 inline void install_sigbus_guard()
 {
@@ -85,7 +97,7 @@ inline void install_sigbus_guard()
 	if (sigaction(SIGBUS, nullptr, &cur) == 0 && (cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == on_sigbus) return;
 	struct sigaction sa; memset(&sa, 0, sizeof sa);
 	sa.sa_sigaction = on_sigbus; sa.sa_flags = SA_SIGINFO; sigemptyset(&sa.sa_mask);
-	g_prev_sigbus = cur;                       // published before the handler that reads it is installed
+	g_prev_sigbus.store(new struct sigaction(cur), std::memory_order_release);      // published before the handler that reads it is installed
 	sigaction(SIGBUS, &sa, nullptr);
 }
 

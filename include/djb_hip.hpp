@@ -807,7 +807,7 @@ protected:
 		if (!n) return;
 		if (!m_host_eval) {      // a user-defined NDF with one of the library's Fresnel terms: the handle answers the whole batch
 			djb_vec3_view vi0 = hip::view(i), vo0 = hip::view(o), vr0 = hip::view(out);
-			hip::check((cosine ? djb_evalp_batch : djb_eval_batch)(ctx(), m_h, (int64_t)n, &vi0, &vo0, params_of(user_param), &vr0, DJB_MEM_HOST));
+			checked((cosine ? djb_evalp_batch : djb_eval_batch)(ctx(), m_h, (int64_t)n, &vi0, &vo0, params_of(user_param), &vr0, DJB_MEM_HOST));
 			return;
 		}
 		std::vector<vec3> dg(n);

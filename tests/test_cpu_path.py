@@ -346,3 +346,38 @@ def test_every_kind_and_operator_on_hostile_pairs_host_path():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert lines[-1] == "cases with a mismatch: 0" and sum(l.endswith(" ok") for l in lines) >= 240, "\n".join(l for l in lines if not l.endswith(" ok"))
+
+
+BOUNCE = r"""
+import faulthandler, mmap, os, sys
+sys.path.insert(0, {root!r})
+from dj_brdf_amd import djb, synth, merl_params
+cpu = djb.cpu_context()
+p = {path!r}
+synth.write_merl_binary(p, synth.merl_table(0.3))
+merl_params.fit_files_on(cpu, [p])            # installs the library's SIGBUS guard
+faulthandler.enable()                         # a handler installed AFTER ours; when it fires it restores its predecessor (ours) and re-raises
+merl_params.fit_files_on(cpu, [p])            # the guard is re-installed on top, chaining to faulthandler's
+# a SIGBUS that is none of the library's business: touch a mapped page beyond the end of a truncated file
+q = p + ".other"
+open(q, "wb").write(b"x" * 65536)
+f = open(q, "r+b"); m = mmap.mmap(f.fileno(), 65536); os.truncate(q, 0)
+print("touching", flush=True)
+m[40000]                                      # SIGBUS here: the process must die of it, not spin between two handlers
+print("survived", flush=True)
+"""
+
+
+def test_foreign_sigbus_does_not_bounce_between_handlers(tmp_path):
+    """a handler installed after the library's guard that falls back to the guard (faulthandler restores its predecessor and
+    re-raises) used to ping-pong with on_sigbus forever on a SIGBUS outside the library's mappings.  The process must terminate with
+    SIGBUS."""
+    import signal, subprocess, sys
+    src = BOUNCE.format(root=ROOT, path=str(tmp_path / "m.binary"))
+    try:
+        r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, DJB_QUIET="1"))
+    except subprocess.TimeoutExpired:
+        pytest.fail("the process hung on a foreign SIGBUS (handlers bouncing)")
+    assert "touching" in r.stdout and "survived" not in r.stdout
+    assert r.returncode == -signal.SIGBUS, (r.returncode, r.stderr[-500:])

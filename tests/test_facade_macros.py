@@ -137,3 +137,52 @@ def test_member_signatures_are_the_reference_ones():
     if os.path.exists("/root/reference/dj_brdf.h"):
         r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-DNVERBOSE", "-w", "-I", "/root/reference", src], capture_output=True, text=True)
         assert r.returncode == 0, "the probe does not compile against the reference itself:\n" + r.stderr[-4000:]
+
+
+THROWING_BATCH = r"""
+#include <stdexcept>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include "dj_brdf.h"
+// a radial NDF (the reference's extension point, dj_brdf.h:301-324) whose p22_radial throws beyond a slope limit
+class throwing_ndf : public djb::radial {
+public:
+	throwing_ndf(float limit) : m_limit(limit) {}
+	bool supports_smith_vndf_sampling() const { return false; }
+	float p22_radial(float r_sqr) const { if (r_sqr > m_limit) throw std::out_of_range("slope beyond the table"); return (float)(1.0 / (M_PI * (1.0 + (double)r_sqr) * (1.0 + (double)r_sqr))); }
+	float sigma_std_radial(float c) const { return 0.5f * (1.0f + c); }
+	float cdf_radial(float r) const { return r * r / (1.0f + r * r); }
+	float qf_radial(float u) const { return (float)std::sqrt((double)u / (1.0 - (double)u)); }
+private:
+	float m_limit;
+};
+int main()
+{
+	throwing_ndf t(0.5f);
+	const int n = 400;                       // above DJB_SCALAR_HOST_MAX: the batch entry point, not the one-pair path
+	std::vector<djb::vec3> i(n), o(n), out(n);
+	for (int k = 0; k < n; ++k) {
+		const float a = 0.02f + 1.5f * k / n;            // half vectors from the normal to grazing: some slopes exceed the limit
+		i[k] = djb::vec3(std::sin(a), 0, std::cos(a)); o[k] = djb::vec3(std::sin(a) * 0.5f, 0.1f, std::sqrt(1 - 0.25f * std::sin(a) * std::sin(a) - 0.01f));
+	}
+	int caught = 0;
+	try { t.eval((size_t)n, &i[0], &o[0], &out[0]); } catch (const std::out_of_range &e) { ++caught; printf("eval batch: out_of_range: %s\n", e.what()); }
+	try { t.evalp((size_t)n, &i[0], &o[0], &out[0]); } catch (const std::out_of_range &e) { ++caught; printf("evalp batch: out_of_range: %s\n", e.what()); }
+	// the object stays usable, and nothing is left behind to surface on an unrelated call
+	const djb::vec3 v = t.eval(djb::vec3(0, 0, 1), djb::vec3(0, 0, 1));
+	printf("caught=%d after=%d\n", caught, (int)(v.x == v.x));
+	return 0;
+}
+"""
+
+
+def test_user_ndf_exception_in_a_batch_reaches_the_caller(tmp_path):
+    """ADVICE r05: microfacet::host_eval_batch (user NDF + library Fresnel) must re-throw what the user's callback threw during the
+    batch, at that call -- not return NaNs and surface the exception on a later, unrelated call."""
+    r, exe = build(tmp_path, THROWING_BATCH, ["-DNVERBOSE"])
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], env=dict(os.environ, DJB_DEVICE="cpu", DJB_QUIET="1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "eval batch: out_of_range: slope beyond the table" in out.stdout and "evalp batch: out_of_range" in out.stdout
+    assert "caught=2 after=1" in out.stdout

@@ -73,6 +73,23 @@ WORKLOADS = {
     # configs[3] under DJB_OPT_CONTRACT_1E5: every component of the sampled direction within 1e-5 of the reference's
     "beckmann_sample_contract": (1_000_000_000, 24, "samples", "k_sample_bk<sample,rng,contract> (fp32 Newton sequence that follows the reference's; doubtful samples re-done exactly in the same launch)"),
     "utia_eval": (100_000_000, 36, "evals", "k_eval_utia_t1<eval> + k_eval_utia_fix<eval> (two-tier exact)"),
+    # ---- the operators the five Mitsuba plugins issue that have no BASELINE config of their own: driver-run legs
+    # (secondary.plugin_ops at N=1), each also a --workload of its own so that tools/profile_bench.sh can take its counters
+    # dj_sgd / dj_abc: pdf() and sample() come from tabular(model, 90) (mitsuba/dj_abc.cpp:28-32, 77, 89); eval + pdf fused, 40 B
+    "tabular_eval_pdf": (100_000_000, 40, "evals", "k_eval<TABULAR,eval+pdf> on tabular(ggx, 90)"),
+    "tabular_sample": (100_000_000, 24, "samples", "k_sample<TABULAR,sample,rng> on tabular(ggx, 90) (normal-map scheme, dj_brdf.h:1806-1846)"),
+    "tabular_abc_sample": (100_000_000, 24, "samples", "k_sample<TABULAR,sample,rng> on tabular(abc gold-metallic-paint, 90)"),
+    # evalp_is (dj_brdf.h:1734-1765): u1, u2 (8) + o (12) -> weight (12) + i (12) + pdf (4) = 48 B with the uniforms read from HBM
+    "ggx_evalp_is": (100_000_000, 48, "samples", "k_sample<GGX,evalp_is> elliptic(0.2, 0.5, 0.7)"),
+    "beckmann_evalp_is": (100_000_000, 48, "samples", "k_sample_bk<evalp_is> elliptic(0.2, 0.5, 0.7)"),
+    # dj_beckmannconductor's per-hit LEAN path (mitsuba/dj_beckmannconductor.cpp:291-319): i, o (24) + 5 moments (20) -> evalp (12) + pdf (4)
+    "lean_evalp_pdf": (100_000_000, 60, "evals", "k_eval_pp<BECKMANN,lean,evalp+pdf> Schlick Fresnel, base isotropic(0.1)"),
+    "abc_evalp": (100_000_000, 36, "evals", "k_eval<ABC,evalp> gold-metallic-paint (dj_abc::eval)"),
+    "tabular_aniso_eval_pdf": (100_000_000, 40, "evals", "k_eval<TABULAR_ANISO,eval+pdf> on tabular_anisotropic(utia, 90, 90)"),
+    "tabular_aniso_sample": (100_000_000, 24, "samples", "k_sample<TABULAR_ANISO,sample,rng> on tabular_anisotropic(utia, 90, 90)"),
+    # the two fits as timed workloads of their own: one object construction per step (the table of the source resident in HBM)
+    "fit_tabular_90": (1, None, "fits", "k_fit<MERL>: tabular(merl, 90) + both moment fits, ONE material"),
+    "fit_aniso_90x90": (1, None, "fits", "launch_fit_aniso (18 launches): tabular_anisotropic(utia, 90, 90)"),
     "merl_fit": (100, None, "materials", "k_fit<MERL>"),
     # end to end: 100 MERL files (34 992 012 B each) on local disk -> params: pread + PCIe + convert + fit
     "merl_fit_files": (100, None, "materials", "djb_fit_merl_files (reader threads -> pinned ring -> H2D -> k_merl_convert -> k_fit<MERL>)"),
@@ -106,13 +123,24 @@ LAUNCHES = {
     "sgd_eval_contract": ["k_ct_fast_v4", "k_ct_fixup"],
     "beckmann_sample": ["k_sample_bk"], "beckmann_sample_contract": ["k_sample_bk"],
     "utia_eval": ["k_eval_utia_t1", "k_eval_utia_fix"], "merl_fit": ["k_fit"],
+    "tabular_eval_pdf": ["k_eval"], "tabular_aniso_eval_pdf": ["k_eval"], "abc_evalp": ["k_eval"], "lean_evalp_pdf": ["k_eval_pp"],
+    "tabular_sample": ["k_sample"], "tabular_abc_sample": ["k_sample"], "tabular_aniso_sample": ["k_sample"],
+    "ggx_evalp_is": ["k_sample"], "beckmann_evalp_is": ["k_sample_bk"], "fit_tabular_90": ["k_fit"],
 }
+# kernels a workload launches besides (set-up, input generation): never part of a profile summary
+NOT_THE_LEG = ("k_gen_dir", "k_gen_uni", "k_merl_convert", "k_utia_convert", "k_fit_smith_nint", "k_fit_fresnel_dirs", "k_fit_merl_slots")
+
+
+def kernel_short_name(k):
+    """`void djbk::(anonymous namespace)::k_eval<1, 5, 0>(...)` -> `k_eval`"""
+    import re
+    m = re.search(r"\b(ka?_[A-Za-z0-9_]+)", k.replace("(anonymous namespace)::", ""))
+    return m.group(1) if m else None
 
 
 def profile_matches(name, kernel_names):
     """(ok, listed): do the kernels a profile summary lists equal the set this workload launches?"""
-    import re
-    listed = sorted({m.group(1) for k in kernel_names for m in [re.search(r"(k_[A-Za-z0-9_]+)", k.replace("(anonymous namespace)::", ""))] if m})
+    listed = sorted({kernel_short_name(k) for k in kernel_names if kernel_short_name(k)})
     want = sorted(LAUNCHES.get(name, []))
     return bool(want) and listed == want, listed
 
@@ -319,6 +347,8 @@ def make_step(name, n, djb, synth, ctx, torch):
             djb._lib.check(lib.djb_eval_batch(ctx._h, u._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
                                               None, C.byref(vout.view), C.c_int(0)))
         return step, (i, o, u, out, vi, vo, vout)
+    if name in PLUGIN_LEGS:
+        return plugin_leg_step(name, n, djb, synth, ctx, torch)
     if name == "merl_fit":
         which = range(n) if isinstance(n, int) else n          # an explicit list of material indices (sharded fit)
         mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=ctx) for k in which]
@@ -336,6 +366,88 @@ def make_step(name, n, djb, synth, ctx, torch):
             ab, ag, result["timing"] = merl_params.fit_files_on(ctx, paths)
         return step, (paths, result)
     raise ValueError(name)
+
+
+PLUGIN_LEGS = ("tabular_eval_pdf", "tabular_sample", "tabular_abc_sample", "ggx_evalp_is", "beckmann_evalp_is", "lean_evalp_pdf",
+               "abc_evalp", "tabular_aniso_eval_pdf", "tabular_aniso_sample", "fit_tabular_90", "fit_aniso_90x90")
+
+
+def utia_payload():
+    return np.random.default_rng(11).uniform(0.0, 120.0, size=3 * 288 * 288)     # UTIA-format payload (sRGB-coded * 140)
+
+
+def plugin_leg_step(name, n, djb, synth, ctx, torch):
+    """The operators the Mitsuba plugins issue beyond the BASELINE configs, one launch (family) per step, inputs resident in HBM."""
+    lib, C = djb._lib.load(), ctypes
+    chk = djb._lib.check
+    dev = f"cuda:{ctx.device}"
+    if name == "fit_tabular_90":
+        src = djb.merl.from_table(synth.merl_table(*synth.material_recipe(0)), ctx=ctx)
+        def step():
+            djb.tabular(src, 90, True, ctx=ctx).close()
+        return step, (src,)
+    if name == "fit_aniso_90x90":
+        src = djb.utia.from_table(utia_payload(), ctx=ctx)
+        def step():
+            djb.tabular_anisotropic(src, 90, 90, True, ctx=ctx).close()
+        return step, (src,)
+    o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
+    vo = djb._Vec(o)
+    if name.startswith("tabular_aniso"):
+        src = djb.utia.from_table(utia_payload(), ctx=ctx)
+        b = djb.tabular_anisotropic(src, 90, 90, True, ctx=ctx)
+    elif name == "tabular_abc_sample":
+        src = djb.abc("gold-metallic-paint", ctx=ctx)
+        b = djb.tabular(src, 90, True, ctx=ctx)
+    elif name.startswith("tabular"):
+        src = djb.ggx(ctx=ctx)
+        b = djb.tabular(src, 90, True, ctx=ctx)
+    elif name == "ggx_evalp_is":
+        src, b = None, djb.ggx(ctx=ctx)
+    elif name == "beckmann_evalp_is":
+        src, b = None, djb.beckmann(ctx=ctx)
+    elif name == "lean_evalp_pdf":
+        src, b = None, djb.beckmann(djb.fresnel.schlick((1.0, 0.71, 0.29)), True, ctx=ctx)
+    else:
+        src, b = None, djb.abc("gold-metallic-paint", ctx=ctx)
+    out = torch.empty((3, n), dtype=torch.float32, device=dev)
+    vout = djb._Vec(out)
+    if name.endswith("_sample"):           # sample() with on-chip uniforms: o -> i
+        def step():
+            chk(lib.djb_sample_rng_batch(ctx._h, b._h, C.c_int64(n), C.c_uint32(synth.SEED_U1), C.c_uint32(synth.SEED_U2), C.c_uint64(0),
+                                         C.byref(vo.view), None, C.byref(vout.view)))
+        return step, (o, out, b, src, vo, vout)
+    if name.endswith("_evalp_is"):
+        u1 = djb.gen_uniforms(n, synth.SEED_U1, ctx=ctx); u2 = djb.gen_uniforms(n, synth.SEED_U2, ctx=ctx)
+        wi = torch.empty((3, n), dtype=torch.float32, device=dev); pdf = torch.empty((n,), dtype=torch.float32, device=dev)
+        vwi = djb._Vec(wi)
+        p = djb.microfacet.params.elliptic(0.2, 0.5, 0.7)
+        def step():
+            chk(lib.djb_evalp_is_batch(ctx._h, b._h, C.c_int64(n), C.c_void_p(u1.data_ptr()), C.c_void_p(u2.data_ptr()), C.byref(vo.view),
+                                       C.byref(p._p), C.byref(vout.view), C.byref(vwi.view), C.c_void_p(pdf.data_ptr()), C.c_int(0)))
+        return step, (o, out, b, p, u1, u2, wi, pdf, vo, vout, vwi)
+    i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
+    vi = djb._Vec(i)
+    if name == "abc_evalp":
+        def step():
+            chk(lib.djb_evalp_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), None, C.byref(vout.view), C.c_int(0)))
+        return step, (i, o, out, b, vi, vo, vout)
+    pdf = torch.empty((n,), dtype=torch.float32, device=dev)
+    if name == "lean_evalp_pdf":
+        g = torch.Generator(device=dev); g.manual_seed(7)
+        lean = torch.empty((n, 5), dtype=torch.float32, device=dev)
+        lean[:, 0:2] = (torch.rand((n, 2), generator=g, device=dev) - 0.5) * 0.2          # E1, E2: mean slopes
+        lean[:, 2:4] = torch.rand((n, 2), generator=g, device=dev) * 0.05 + 0.01         # E3, E4: second moments
+        lean[:, 4] = (torch.rand((n,), generator=g, device=dev) - 0.5) * 0.01            # E5
+        base = djb.microfacet.params.isotropic(0.1)
+        def step():
+            chk(lib.djb_eval_lean_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), C.byref(base._p), C.c_float(1.0), C.c_int(0),
+                                        C.c_void_p(lean.data_ptr()), C.c_int(6), C.byref(vout.view), C.c_void_p(pdf.data_ptr()), C.c_void_p(0), C.c_int(0)))
+        return step, (i, o, out, pdf, b, base, lean, vi, vo, vout)
+    def step():             # tabular / tabular_anisotropic eval + pdf fused
+        chk(lib.djb_eval_pdf_batch(ctx._h, b._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), None, C.c_int(0), C.byref(vout.view),
+                                   C.c_void_p(pdf.data_ptr()), C.c_int(0)))
+    return step, (i, o, out, pdf, b, src, vi, vo, vout)
 
 
 def one_pair_calls(with_reference):
@@ -557,6 +669,94 @@ def scaling_model_ms(world):
             "source": "model: N=1 terms measured on one MI355X (profiles/r04), 1/N applied to the per-file gather only; NOT a measurement"}
 
 
+def static_profile(name, n, launch_ms):
+    """What the tracked profile summaries say about this leg's kernels (profiles/pmc_<name>.json: separate rocprofv3 --pmc passes of
+    tools/profile_bench.sh; profiles/valu_<name>.json: SQ_INSTS_VALU_* passes of tools/instmix.sh), scaled to this run's batch -- attached
+    only if they list exactly the kernels the leg launches (LAUNCHES); static, NOT measured in this run."""
+    out = {}
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{name}.json")))
+        ok, listed = profile_matches(name, pj.get("kernels", []))
+        if ok and pj.get("hbm_bytes_per_launch") and pj.get("units_per_launch"):
+            per_unit = pj["hbm_bytes_per_launch"] / float(pj["units_per_launch"])
+            out["traffic_bytes_per_unit"] = per_unit
+            ob = WORKLOADS[name][1]
+            if ob:
+                out["traffic_over_algorithmic"] = per_unit / ob
+            out["traffic_source"] = "static: profiles/pmc_%s.json (%s, tree %s)" % (name, pj.get("round", "?"), pj.get("tree", "?"))
+        elif not ok:
+            out["traffic_source"] = "STALE: profiles/pmc_%s.json lists %s, the leg launches %s" % (name, listed, sorted(LAUNCHES.get(name, [])))
+    except Exception:
+        pass
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", f"valu_{name}.json")))
+        ok, listed = profile_matches(name, [k.get("kernel", "") for k in v.get("kernels", [])])
+        if ok:
+            issue_ms = v["slots_per_unit"] * n / 64.0 * 1.155e-6 / 1024.0
+            out["valu"] = {"insts_per_unit": v["insts_per_unit"], "slots_per_unit": v["slots_per_unit"], "frac_of_issue": issue_ms / launch_ms,
+                           "source": "static: profiles/valu_%s.json (%s, tree %s)" % (name, v.get("round", "?"), v.get("tree", "?"))}
+    except Exception:
+        pass
+    return out
+
+
+def gpu_state(device=0):
+    """Shader clock / power / temperature of the GPU as the kernel driver reports them right now (sysfs hwmon of the card; no subprocess,
+    ~0.1 ms).  Called while a leg's launches are in flight, so the figures are those of the loaded chip.  None where a file is absent."""
+    import glob
+    out = {}
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon", "hwmon*", "freq1_input"))]
+    if not cards:
+        return None
+    c = cards[min(device, len(cards) - 1)]
+
+    def rd(path):
+        try:
+            return open(path).read().strip()
+        except Exception:
+            return None
+    for hw in glob.glob(os.path.join(c, "hwmon", "hwmon*")):
+        v = rd(os.path.join(hw, "freq1_input"))
+        if v and v.isdigit():
+            out["sclk_mhz"] = int(v) / 1e6
+        v = rd(os.path.join(hw, "freq2_input"))
+        if v and v.isdigit():
+            out["mclk_mhz"] = int(v) / 1e6
+        v = rd(os.path.join(hw, "power1_average")) or rd(os.path.join(hw, "power1_input"))
+        if v and v.isdigit():
+            out["power_w"] = int(v) / 1e6
+        v = rd(os.path.join(hw, "temp1_input"))
+        if v and v.lstrip("-").isdigit():
+            out["temp_c"] = int(v) / 1e3
+    if "sclk_mhz" not in out:
+        v = rd(os.path.join(c, "pp_dpm_sclk"))
+        for line in (v or "").splitlines():
+            if line.rstrip().endswith("*"):
+                try:
+                    out["sclk_mhz"] = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                except Exception:
+                    pass
+    return out or None
+
+
+def timed_leg(st, torch, device, reps=10, warm=10):
+    """warm untimed launches (steady clocks: the launches are 1-20 ms and the GPU idled during the CPU legs), then reps launches with an
+    event between each on the stream the library launches on (torch's current stream = the context's), so that every launch has its own
+    duration; the GPU's clock / power are read while they are in flight.  -> (mean ms, {min, median, max}, gpu state mid-leg)"""
+    for _ in range(warm):
+        st()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for k in range(reps):
+        st()
+        ev[k + 1].record()
+    state = gpu_state(device)                 # the launches are asynchronous: the chip is busy with them now
+    torch.cuda.synchronize()
+    ms = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(reps))
+    return sum(ms) / reps, {"min": ms[0], "median": ms[reps // 2], "max": ms[-1]}, state
+
+
 def main():
     args = parse()
     import torch
@@ -604,8 +804,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()                       # HIP event on the stream the kernels are launched on
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # the same stream: one mark per step boundary
+    marks[0].record()
+    for k in range(args.steps):
         step()
+        marks[k + 1].record()
+    state_in_flight = gpu_state(local)      # the launches are asynchronous: read while the chip is busy with them
     ev_ms = ctx.timer_stop_ms()             # records + synchronises the closing event
     barrier()
     dt = time.perf_counter() - t0
@@ -779,8 +983,11 @@ def main():
             # latency/VALU-bound; report the achieved rate only
             roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                         "traffic": None, "kernel": kernel, "launch_ms": launch_ms}
+        per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+        roofline["launch_ms_min_median_max"] = {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1]}
+        roofline["gpu_in_flight"] = state_in_flight       # shader clock / power / temperature while the timed launches were executing
         rec = {
-            "metric": "BRDF evals/sec" if not name.startswith("merl_fit") else "MERL materials fitted/sec",
+            "metric": "MERL materials fitted/sec" if name.startswith("merl_fit") else "fits/sec" if name.startswith("fit_") else "BRDF evals/sec",
             "value": value, "unit": f"{unit}/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (f64 transcendentals)", "data": "synthetic",
@@ -800,7 +1007,7 @@ def main():
                                 "ggx_eval_pdf_contract": f"GGX isotropic alpha={args.alpha:g}, {args.fresnel} Fresnel, eval+pdf fused, "
                                                          "DJB_OPT_CONTRACT_1E5 (values within 1e-5 relative of the reference, not bit-identical)",
                                 "merl_eval_uniform_bins": "MERL nearest-bin, look-ups uniform over all 90x90x180 bins",
-                                "merl_eval_coherent": "MERL nearest-bin, renderer-like coherent batch (bumpy plane, one light)"}[name],
+                                "merl_eval_coherent": "MERL nearest-bin, renderer-like coherent batch (bumpy plane, one light)"}.get(name, kernel),
                        "layout": "SoA float32 in HBM", "parallelism": f"independent x{world} (no collective)"
                        + (" -- SELF-TEST batch size (--selftest-n): not the BASELINE configuration" if args.selftest_n else "")
                        + (" -- SELF-TEST: all ranks share GPU 0 (DJB_BENCH_SHARE_GPU), not a scaling measurement" if share_gpu else "")},
@@ -831,17 +1038,13 @@ def main():
                 if other.startswith("merl_eval_"):
                     on //= 4          # 2.5e8 pairs (9 GB of streams, far beyond every cache): same rate as 1e9, a quarter of the set-up time
                 st, kp = make_step(other, on, djb, synth, ctx, torch)
-                for _ in range(10):        # steady clocks: these launches are 1-20 ms, and the GPU idled during the CPU legs
-                    st()
-                torch.cuda.synchronize()
-                ctx.timer_start()
-                for _ in range(10):
-                    st()
-                ms = ctx.timer_stop_ms() / 10
+                ms, spread, state = timed_leg(st, torch, local)
                 finish(st)
-                sec[other] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms, "units_per_step": on,
+                sec[other] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms, "ms_min_median_max": spread, "gpu": state,
+                              "units_per_step": on,
                               "hbm_GBps": (on * ob / (ms * 1e-3) / 1e9) if ob else None,
                               "roofline_frac": (on * ob / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ob else None}
+                sec[other].update(static_profile(other, on, ms))
                 if other == "beckmann_sample_contract":
                     acc = djb.selftest_contract_sample(kp[2], kp[3], n=1 << 28, seed=3, family=0, ctx=ctx)
                     sec[other].update({"max_abs_err_direction": acc["max_abs_dir"], "components_outside_1e-5": acc["outside_1e5"],
@@ -857,6 +1060,22 @@ def main():
                                        "bit-exact tier for ill-conditioned pairs; DJB_OPT_CONTRACT_1E5, off by default"})
                 del st, kp
                 torch.cuda.empty_cache()
+            # the operators the five plugins issue beyond the BASELINE configs: driver-observed throughput per leg, priced
+            # against 8 TB/s with the algorithmic bytes WORKLOADS states; counters per leg: profiles/pmc_<leg>.json, valu_<leg>.json
+            ops = {}
+            for leg in PLUGIN_LEGS:
+                on, ob, ou, kern = WORKLOADS[leg]
+                st, kp = make_step(leg, on, djb, synth, ctx, torch)
+                fit_leg = leg.startswith("fit_")
+                ms, spread, state = timed_leg(st, torch, local, reps=5 if fit_leg else 10, warm=2 if fit_leg else 10)
+                ops[leg] = {"value": on / (ms * 1e-3), "unit": f"{ou}/s", "ms_per_step": ms, "ms_min_median_max": spread, "gpu": state,
+                            "units_per_step": on, "kernel": kern, "algorithmic_bytes_per_unit": ob,
+                            "hbm_GBps": (on * ob / (ms * 1e-3) / 1e9) if ob else None,
+                            "roofline_frac": (on * ob / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ob else None}
+                ops[leg].update(static_profile(leg, on, ms))
+                del st, kp
+                torch.cuda.empty_cache()
+            sec["plugin_ops"] = ops
             rec["secondary"] = sec
         print(json.dumps(rec), flush=True)
     if world > 1:

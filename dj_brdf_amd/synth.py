@@ -57,6 +57,22 @@ def uniforms(n: int, seed: int, start: int = 0) -> np.ndarray:
     return (h >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
 
 
+def rng_uniforms(n: int, seed: int, start: int = 0) -> np.ndarray:
+    """The uniforms the library generates ON CHIP (sample_rng, evalp_is_rng, djb_gen_uniforms): gen_uniform of
+    csrc/djb_device_units.inc restated -- one lowbias32 finaliser over lo32(k) * 0x9E3779B9 + hi32(k) * 0x85EBCA6B + pcg(seed), top 24 bits.
+    (uniforms() above, three chained PCG rounds, stays the generator of test inputs and golden vectors.)"""
+    k = np.arange(start, start + n, dtype=np.uint64)
+    lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (k >> np.uint64(32)).astype(np.uint32)
+    key = _pcg(np.full(1, seed & 0xFFFFFFFF, dtype=np.uint32))[0]
+    with np.errstate(over="ignore"):
+        x = lo * np.uint32(0x9E3779B9) + hi * np.uint32(0x85EBCA6B) + key
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15); x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return (x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
 def directions(n: int, seed: int, start: int = 0):
     """n unit vectors in the upper hemisphere as three float32 arrays (SoA).
 

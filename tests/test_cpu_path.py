@@ -381,3 +381,36 @@ def test_foreign_sigbus_does_not_bounce_between_handlers(tmp_path):
         pytest.fail("the process hung on a foreign SIGBUS (handlers bouncing)")
     assert "touching" in r.stdout and "survived" not in r.stdout
     assert r.returncode == -signal.SIGBUS, (r.returncode, r.stderr[-500:])
+
+
+def test_on_chip_generator_restatement_and_quality(cpu):
+    """The round-6 on-chip uniforms (csrc/djb_device_units.inc: gen_uniform; synth.rng_uniforms restates it): the host path's bits equal
+    the numpy restatement, and the stream behaves like uniforms where the sampler can tell -- 2-D equidistribution of the (u1, u2) pairs
+    the Beckmann bench draws (64 x 64 cells, SURVEY 8d's histogram), serial correlation, per-bit balance, distinct streams per seed."""
+    n = 1 << 20
+    for seed, start in ((synth.SEED_U1, 0), (synth.SEED_U2, (1 << 33) + 7), (0, 123456789)):
+        got = djb.gen_uniforms(n, seed, start=start, ctx=cpu)
+        assert np.array_equal(np.asarray(got, np.float32).view(np.uint32), synth.rng_uniforms(n, seed, start=start).view(np.uint32))
+    n = 1 << 22
+    u1, u2 = synth.rng_uniforms(n, synth.SEED_U1), synth.rng_uniforms(n, synth.SEED_U2)
+    assert 0.0 <= u1.min() and u1.max() < 1.0
+    # 2-D chi-square, 4095 degrees of freedom: mean 4095, sigma 90.5
+    h = np.histogram2d(u1, u2, bins=64, range=((0, 1), (0, 1)))[0]
+    e = n / 4096.0
+    chi2 = float(((h - e) ** 2 / e).sum())
+    assert abs(chi2 - 4095.0) < 5 * 90.5, chi2
+    # pairs of CONSECUTIVE counters of one stream (what a stratified caller would see)
+    h = np.histogram2d(u1[:-1], u1[1:], bins=64, range=((0, 1), (0, 1)))[0]
+    chi2 = float(((h - (n - 1) / 4096.0) ** 2 / ((n - 1) / 4096.0)).sum())
+    assert abs(chi2 - 4095.0) < 5 * 90.5, chi2
+    h = np.histogram2d(u1[:-64], u1[64:], bins=64, range=((0, 1), (0, 1)))[0]          # the same lane of consecutive waves
+    chi2 = float(((h - (n - 64) / 4096.0) ** 2 / ((n - 64) / 4096.0)).sum())
+    assert abs(chi2 - 4095.0) < 5 * 90.5, chi2
+    for a, b in ((u1[:-1], u1[1:]), (u1, u2), (u1[:-64], u1[64:])):       # serial / cross / lane-stride correlation: sigma = 1/sqrt(n)
+        r = float(np.corrcoef(a.astype(np.float64), b.astype(np.float64))[0, 1])
+        assert abs(r) < 5.0 / np.sqrt(n), r
+    bits = (u1 * np.float32(2.0 ** 24)).astype(np.uint32)
+    for b in range(24):                                                    # every one of the 24 bits is fair: sigma = 0.5/sqrt(n)
+        f = float(((bits >> np.uint32(b)) & np.uint32(1)).mean())
+        assert abs(f - 0.5) < 5 * 0.5 / np.sqrt(n), (b, f)
+    assert not np.array_equal(u1, synth.rng_uniforms(n, synth.SEED_U1 + 1))

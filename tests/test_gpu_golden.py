@@ -169,6 +169,41 @@ def test_full_size_merl_eval_properties(gpu_ctx):
     assert total == 1_000_000_000
 
 
+@pytest.mark.parametrize("dist", ["merl_eval_uniform_bins", "merl_eval_coherent"])
+def test_full_size_merl_eval_other_distributions(gpu_ctx, dist):
+    """The two-tier look-up's guard bands are first order + attacked, not proven: the full-size sweep `eval == table[exact index]`
+    over EVERY pair also runs on the two other look-up distributions bench.py times, 2.5e8 pairs each -- look-ups uniform over the
+    1.458 M bins (5.5 % of the pairs on the theta_h snap path) and the renderer-like coherent batch -- plus a strided sample against the
+    CPU oracle, indices and values bit for bit."""
+    import sys
+    import torch
+    import oraclelib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    O = oraclelib.oracle()
+    tab = synth.merl_table_hashed()
+    m = djb.merl.from_table(tab, ctx=gpu_ctx)
+    om = O.merl_from_table(tab)
+    t = torch.from_numpy(np.ascontiguousarray(tab.reshape(3, -1)))
+    scale = torch.tensor(synth.MERL_SCALE, dtype=torch.float64).view(3, 1)
+    pres = (t * scale).float()
+    pres[:, (pres < 0).any(dim=0)] = 0
+    pres = pres.cuda()
+    n = 250_000_000
+    i, o = bench.merl_pairs(dist, n, djb, torch, gpu_ctx)
+    out = m.eval(i, o)
+    idx = djb.merl_index(i, o, ctx=gpu_ctx).long()            # the exact index kernel (merl_index operation by operation)
+    assert int(idx.min()) >= 0 and int(idx.max()) < synth.MERL_N
+    for ch in range(3):
+        assert torch.equal(out[ch], pres[ch][idx]), f"{dist} channel {ch}: eval != table[exact index]"
+    if dist == "merl_eval_uniform_bins":                       # the distribution is what it says: (nearly) every bin is hit
+        assert int(torch.unique(idx).numel()) > 0.95 * synth.MERL_N
+    sel = torch.arange(0, n, 1250, device=i.device)            # 2e5 pairs against the oracle
+    hi, ho = i[:, sel].T.contiguous().cpu().numpy(), o[:, sel].T.contiguous().cpu().numpy()
+    assert np.array_equal(idx[sel].cpu().numpy().astype(np.int32), O.merl_index(hi, ho))
+    assert np.array_equal(out[:, sel].T.contiguous().cpu().numpy().view(np.uint32), O.eval(om, hi, ho).view(np.uint32))
+
+
 def test_merl_eval_one_launch_beyond_2_pow_31_pairs(gpu_ctx):
     """Maximum sizes: one djb_eval_batch call over 2^31 + 4097 pairs (77 GB of directions + results
     in HBM).  Pair indices travel as uint32 inside the two-tier kernel, so the call is chunked at
@@ -232,7 +267,7 @@ def test_full_size_beckmann_sample_histogram(gpu_ctx):
     O = oraclelib.oracle()
     b = djb.beckmann(ctx=gpu_ctx)
     p = djb.microfacet.params.elliptic(0.2, 0.5, 0.7)
-    bins, chunk = 32, 250_000_000
+    bins, chunk = 64, 250_000_000            # 64 x 64 cells
     hist = torch.zeros((bins, bins), dtype=torch.int64, device="cuda")
     for c in range(4):
         o = djb.gen_directions(chunk, synth.SEED_O, start=c * chunk, ctx=gpu_ctx)
@@ -242,6 +277,11 @@ def test_full_size_beckmann_sample_histogram(gpu_ctx):
             m = 1 << 20
             u1 = djb.gen_uniforms(m, synth.SEED_U1, ctx=gpu_ctx); u2 = djb.gen_uniforms(m, synth.SEED_U2, ctx=gpu_ctx)
             assert torch.equal(b.sample(u1, u2, o[:, :m].contiguous(), p), s[:, :m])
+            # ... and the on-chip generator is reproducible on the CPU (synth.rng_uniforms restates it): the oracle fed with the
+            # restated uniforms returns the launch's bits
+            want = O.sample(O.microfacet("beckmann"), synth.rng_uniforms(m, synth.SEED_U1), synth.rng_uniforms(m, synth.SEED_U2),
+                            synth.directions_aos(m, synth.SEED_O), ("elliptic", 0.2, 0.5, 0.7))
+            assert np.array_equal(s[:, :m].cpu().numpy().T.copy().view(np.uint32), np.ascontiguousarray(want, np.float32).view(np.uint32))
         del o, s
     assert int(hist.sum()) == 4 * chunk
     ns = 2_000_000
@@ -254,7 +294,7 @@ def test_full_size_beckmann_sample_histogram(gpu_ctx):
     hg = hist.cpu().numpy().reshape(-1).astype(np.float64)
     pg = hg / hg.sum()
     keep = pg * ns > 20
-    chi2 = (((hc - pg * ns) ** 2) / (pg * ns))[keep].sum()
+    chi2 = (((hc[keep] - pg[keep] * ns) ** 2) / (pg[keep] * ns)).sum()      # cells the lobe never reaches are masked BEFORE the division
     dof = keep.sum() - 1
     assert chi2 < dof + 6 * np.sqrt(2 * dof), f"chi2 {chi2:.1f} for {dof} dof"
 

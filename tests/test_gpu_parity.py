@@ -321,7 +321,7 @@ def test_device_generators_match_numpy(gpu_ctx):
     assert np.array_equal(d[1].view(np.uint32), y.view(np.uint32))
     assert np.array_equal(d[2].view(np.uint32), z.view(np.uint32))
     u = djb.gen_uniforms(n, synth.SEED_U1, start=(1 << 33) + 7, ctx=gpu_ctx).cpu().numpy()
-    assert np.array_equal(u, synth.uniforms(n, synth.SEED_U1, start=(1 << 33) + 7))
+    assert np.array_equal(u, synth.rng_uniforms(n, synth.SEED_U1, start=(1 << 33) + 7))
 
 
 def test_device_tensors_soa_equal_host_aos(gpu_ctx, dirs):

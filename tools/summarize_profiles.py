@@ -24,10 +24,13 @@ except Exception:
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles", RND)
 os.makedirs(DST, exist_ok=True)
-DOMINANT = {"merl_eval": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "merl_eval_uniform_bins": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"),
-            "merl_eval_coherent": ("k_merl_fast_v4", "k_merl_fixup", "k_merl_fast<"), "ggx_eval_pdf_contract": ("k_ct_fast_v4<1, 5", "k_ct_fixup<1, 5"),
-            "ggx_eval_pdf": ("k_eval<1, 5,",),
-            "beckmann_sample": ("k_sample_bk<",), "beckmann_sample_contract": ("k_sample_bk<",), "merl_fit": ("k_fit<3>",), "utia_eval": ("k_eval_utia_t1", "k_eval_utia_fix", "k_eval<4, 1,")}
+sys.path.insert(0, ROOT)
+import bench          # LAUNCHES: the kernels each workload launches in its timed region (the same table bench.py checks a summary against)
+
+
+def dominant(w, kernel):
+    """is `kernel` (a rocprofv3 Kernel_Name) one of the kernels workload w times?"""
+    return bench.kernel_short_name(kernel) in bench.LAUNCHES.get(w, ())
 
 
 def counters(path):
@@ -58,12 +61,12 @@ for w in sorted(os.listdir(SRC)):
         wr = csv.writer(f)
         wr.writerow(["pass", "kernel", "counter", "dispatches", "avg_per_dispatch", "vgpr", "sgpr", "workgroup", "grid", "lds"])
         wr.writerows(rows)
-    fetch_kb = sum(v.get("FETCH_SIZE", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
-    write_kb = sum(v.get("WRITE_SIZE", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
+    fetch_kb = sum(v.get("FETCH_SIZE", 0) for k, v in per_kernel.items() if dominant(w, k))
+    write_kb = sum(v.get("WRITE_SIZE", 0) for k, v in per_kernel.items() if dominant(w, k))
     if fetch_kb or write_kb:
         out = {
             "workload": w, "round": "round %d (profiles/%s)" % (int(RND.lstrip("r") or 0), RND), "tree": TREE,
-            "kernels": [k for k in per_kernel if any(t in k for t in DOMINANT.get(w, ()))],
+            "kernels": [k for k in per_kernel if dominant(w, k)],
             "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
             # MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-B streaming requests as 64 B on gfx950
             # (verified here on k_eval<GGX>: 1.2 GB reported for 2.4 GB read) -> x2; WRITE_SIZE is exact
@@ -78,9 +81,17 @@ for w in sorted(os.listdir(SRC)):
         # bytes per miss" -- FETCH_SIZE / TCC_MISS is 64 by construction -- and reported the gather misses at half their size; round 4
         # corrects it: tools/exp/r04/merl_pair_lines.sh asked for both halves of each line explicitly and changed no counter.)
         # Their stream bytes being known (24 B per pair, read once), the gathers' share is split out.
-        if w.startswith("merl_eval") and os.path.exists(os.path.join(d, "bench_plain.json")):
+        n_units = None
+        try:
+            n_units = json.loads(open(os.path.join(d, "bench_plain.json")).read().strip().splitlines()[-1])["config"]["units_per_gpu_per_step"]
+            out["units_per_launch"] = n_units
+            if bench.WORKLOADS[w][1]:
+                out["algorithmic_bytes_per_launch"] = bench.WORKLOADS[w][1] * n_units
+                out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+        except Exception as e:  # pragma: no cover
+            print("units per launch unknown:", e)
+        if w.startswith("merl_eval") and n_units:
             try:
-                n_units = json.loads(open(os.path.join(d, "bench_plain.json")).read().strip().splitlines()[-1])["config"]["units_per_gpu_per_step"]
                 requests = max(fetch_kb * 1024 / 64.0 - 24.0 * n_units / 128.0, 0.0)
                 out["gather_miss_requests_per_launch"] = requests
                 out["gather_miss_bytes_per_launch"] = 128.0 * requests
@@ -90,8 +101,8 @@ for w in sorted(os.listdir(SRC)):
                                "are served by the Infinity Cache (17.5 MB table), the streams by HBM")
             except Exception as e:  # pragma: no cover
                 print("gather split skipped:", e)
-        hit = sum(v.get("TCC_HIT_sum", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
-        miss = sum(v.get("TCC_MISS_sum", 0) for k, v in per_kernel.items() if any(t in k for t in DOMINANT.get(w, ())))
+        hit = sum(v.get("TCC_HIT_sum", 0) for k, v in per_kernel.items() if dominant(w, k))
+        miss = sum(v.get("TCC_MISS_sum", 0) for k, v in per_kernel.items() if dominant(w, k))
         if hit + miss > 0:
             out["l2_hit_rate"] = hit / (hit + miss)          # TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), MI355X_MICROARCH.md section L2
         json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{w}.json"), "w"), indent=1)

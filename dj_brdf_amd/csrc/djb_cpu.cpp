@@ -1091,6 +1091,7 @@ djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, i
 			load_s += std::chrono::duration<double>(t1 - t0).count();
 		}
 	});
+	djbfile::t_failed_file = first != DJB_OK ? first_file : -1;
 	if (first != DJB_OK) return djbk::set_error(first, "%s", first_msg.c_str());
 	if (timing) {
 		timing[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

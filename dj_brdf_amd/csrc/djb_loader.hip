@@ -339,6 +339,7 @@ djb_status fit_merl_files_sparse(djb_ctx *ctx, int n_files, const char *const *p
 		        1e3 * (t_alloc - t_plan), threads, 1e3 * (t_loaded0 - t_alloc), 1e3 * (t_loaded - t_loaded0), 1e3 * (t_end - t_loaded));
 	reap_mappings(std::move(kept));
 	for (djb_brdf *b : mats) if (b) djb_brdf_destroy(b);
+	djbfile::t_failed_file = status != DJB_OK && status_file < n_files ? status_file : -1;
 	if (status != DJB_OK) return status_msg.empty() ? status : djbk::set_error(status, "%s", status_msg.c_str());
 	if (timing) {
 		timing[0] = t_end - t_begin; timing[1] = t_loaded - t_begin; timing[2] = t_end - t_loaded;
@@ -367,6 +368,60 @@ try {
 }
 catch (const std::bad_alloc &) { return djbk::set_error(DJB_ERR_OUT_OF_MEMORY, "djb_error: out of host memory"); }
 catch (...) { return djbk::set_error(DJB_ERR_INTERNAL, "djb_error: internal error in djb_fit_merl_files"); }
+
+// ---- the same job over SEVERAL contexts (examples/merl_params.cpp:53-69 is the loop it stands for): file k belongs to
+// context k mod n_ctx, every context's share is one fit_merl_files call on a host thread of its own (the calling thread takes context 0),
+// rows come back in input order.  No exchange between contexts -- the fits are independent.
+static djb_status fit_merl_files_multi(djb_ctx *const *ctxs, int n_ctx, int n_files, const char *const *paths, int res, int shadow,
+                                       int reader_threads, float *alpha_beckmann, float *alpha_ggx, double *timing)
+{
+	if (!ctxs || n_ctx < 1 || !paths || n_files < 0 || !alpha_beckmann || !alpha_ggx)
+		return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: invalid argument");
+	for (int g = 0; g < n_ctx; ++g) {
+		if (!ctxs[g]) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: null context in the context list");
+		for (int h = 0; h < g; ++h)
+			if (ctxs[h] == ctxs[g]) return djbk::set_error(DJB_ERR_INVALID_ARGUMENT, "djb_error: a context is listed twice (two shares would serialise on its lock)");
+	}
+	if (timing) for (int k = 0; k < 4 * n_ctx; ++k) timing[k] = 0.0;
+	if (n_files == 0) return DJB_OK;
+	const int used = std::min(n_ctx, n_files);
+	struct Share { std::vector<const char *> paths; std::vector<float> ab, ag; djb_status st = DJB_OK; std::string msg; int bad = -1; };
+	std::vector<Share> shares(used);
+	for (int k = 0; k < n_files; ++k) shares[k % used].paths.push_back(paths[k]);
+	auto run = [&](int g) {
+		Share &s = shares[g];
+		s.ab.resize(s.paths.size()); s.ag.resize(s.paths.size());
+		djbfile::t_failed_file = -1;
+		try { s.st = fit_merl_files(ctxs[g], (int)s.paths.size(), s.paths.data(), res, shadow, reader_threads, s.ab.data(), s.ag.data(), timing ? timing + 4 * g : nullptr); }
+		catch (const std::bad_alloc &) { s.st = djbk::set_error(DJB_ERR_OUT_OF_MEMORY, "djb_error: out of host memory"); }
+		catch (...) { s.st = djbk::set_error(DJB_ERR_INTERNAL, "djb_error: internal error in djb_fit_merl_files_multi"); }
+		if (s.st != DJB_OK) { s.msg = djb_last_error(); s.bad = djbfile::t_failed_file; }     // the message is the worker thread's: carried over below
+	};
+	std::vector<std::thread> workers;
+	for (int g = 1; g < used; ++g) workers.emplace_back(run, g);
+	run(0);
+	for (std::thread &t : workers) t.join();
+	// the reference's loop stops at the first bad file: the error of the lowest-indexed bad file over all shares wins (a failure that is
+	// not a file's -- a device error -- ranks before every file of its context)
+	int best = -1; long long best_index = 0;
+	for (int g = 0; g < used; ++g) {
+		if (shares[g].st == DJB_OK) continue;
+		const long long index = shares[g].bad >= 0 ? (long long)shares[g].bad * used + g : (long long)g - used;
+		if (best < 0 || index < best_index) { best = g; best_index = index; }
+	}
+	if (best >= 0) return djbk::set_error(shares[best].st, "%s", shares[best].msg.c_str());
+	for (int g = 0; g < used; ++g)
+		for (size_t j = 0; j < shares[g].paths.size(); ++j) { alpha_beckmann[j * used + g] = shares[g].ab[j]; alpha_ggx[j * used + g] = shares[g].ag[j]; }
+	return DJB_OK;
+}
+
+extern "C" djb_status djb_fit_merl_files_multi(djb_ctx *const *ctxs, int n_ctx, int n_files, const char *const *paths, int res, int shadow,
+                                               int reader_threads, float *alpha_beckmann, float *alpha_ggx, double *timing)
+try {
+	return fit_merl_files_multi(ctxs, n_ctx, n_files, paths, res, shadow, reader_threads, alpha_beckmann, alpha_ggx, timing);
+}
+catch (const std::bad_alloc &) { return djbk::set_error(DJB_ERR_OUT_OF_MEMORY, "djb_error: out of host memory"); }
+catch (...) { return djbk::set_error(DJB_ERR_INTERNAL, "djb_error: internal error in djb_fit_merl_files_multi"); }
 
 static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *paths, int res, int shadow,
                                  int reader_threads, float *alpha_beckmann, float *alpha_ggx, double *timing)
@@ -534,6 +589,7 @@ static djb_status fit_merl_files(djb_ctx *ctx, int n_files, const char *const *p
 		if (status == DJB_OK && se != hipSuccess) { status = DJB_ERR_HIP; status_msg = "djb_error: stream sync failed"; }
 	}
 	const double t_loaded = now_s();
+	djbfile::t_failed_file = status != DJB_OK && status_file < n_files ? status_file : -1;
 	if (status != DJB_OK) { cleanup(); return djbk::set_error(status, "%s", status_msg.c_str()); }
 
 	// ---- one fit launch for the whole batch

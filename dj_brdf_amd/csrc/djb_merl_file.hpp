@@ -101,6 +101,10 @@ inline void install_sigbus_guard()
 	sigaction(SIGBUS, &sa, nullptr);
 }
 
+// index (within the call's path list) of the file whose error a failed fit_merl_files call reports -- the lowest-indexed bad file --
+// for djb_fit_merl_files_multi, which must pick the lowest index over several contexts' shares; -1: the failure was not a file's
+inline thread_local int t_failed_file = -1;
+
 // Observer of the file pipeline (djb_set_file_map_observer, include/djb_hip.h): called with the path after a file has passed its
 // size check and has been mapped, before the gather.  The library itself never writes to an input file; the tests of the guard
 // above register a callback that truncates the file at exactly this point.

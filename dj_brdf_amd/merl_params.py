@@ -59,42 +59,37 @@ def fit_files_on(ctx: djb.Context, paths, res=90, shadow=True, reader_threads=0)
     return ab, ag, {"total_s": timing[0], "load_s": timing[1], "fit_s": timing[2], "bytes": timing[3]}
 
 
+def fit_files_multi(ctxs, paths, res=90, shadow=True, reader_threads=0):
+    """(alpha_beckmann[n], alpha_ggx[n], [timing dict per context]) for `paths` over several contexts: djb_fit_merl_files_multi --
+    file k on context k mod len(ctxs), one host thread per context INSIDE the library, rows in input order, no exchange."""
+    lib = _lib.load()
+    n = len(paths)
+    arr = (C.c_char_p * max(n, 1))(*[p.encode() for p in paths])
+    handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    ab, ag = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    timing = (C.c_double * (4 * len(ctxs)))()
+    _lib.check(lib.djb_fit_merl_files_multi(handles, C.c_int(len(ctxs)), C.c_int(n), arr, C.c_int(res), C.c_int(int(shadow)),
+                                            C.c_int(reader_threads), C.c_void_p(ab.ctypes.data), C.c_void_p(ag.ctypes.data), timing))
+    per = [{"total_s": timing[4 * g], "load_s": timing[4 * g + 1], "fit_s": timing[4 * g + 2], "bytes": timing[4 * g + 3]} for g in range(len(ctxs))]
+    return ab, ag, per
+
+
 def fit_files(paths, res=90, shadow=True, gpus=None, return_timing=False, cpu=False):
     """[(alpha_beckmann, alpha_ggx)] for every path, in input order, over `gpus` GPUs -- or, with cpu=True / on a
     machine without a HIP device, on the library's host path (one CPU context, the files spread over its threads):
-    the reference's example driver runs without a GPU too (BASELINE configs[0])."""
+    the reference's example driver runs without a GPU too (BASELINE configs[0]).  The multi-GPU job is ONE library call
+    (djb_fit_merl_files_multi: material m -> GPU m mod G, a host thread per context inside the library)."""
     n_dev = djb.device_count()
-    if cpu or n_dev == 0:
-        t0 = time.perf_counter()
-        ab, ag, timing = fit_files_on(djb.Context("cpu"), list(paths), res, shadow)
-        out = [(float(a), float(g)) for a, g in zip(ab, ag)]
-        return (out, {"wall_s": time.perf_counter() - t0, "per_gpu": [timing], "gpus": 0}) if return_timing else out
-    gpus = min(gpus or n_dev, n_dev, max(len(paths), 1))
-    out = [None] * len(paths)
-    errors, timings = [], [None] * gpus
-
-    def worker(rank):
-        try:
-            ctx = djb.Context(rank)
-            mine = shard.round_robin(len(paths), gpus, rank)
-            if not mine:
-                return
-            ab, ag, timings[rank] = fit_files_on(ctx, [paths[k] for k in mine], res, shadow)
-            for k, a, g in zip(mine, ab, ag):
-                out[k] = (float(a), float(g))
-        except Exception as e:  # surfaced on the main thread
-            errors.append(e)
-
     t0 = time.perf_counter()
-    threads = [threading.Thread(target=worker, args=(r,)) for r in range(gpus)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
+    if cpu or n_dev == 0:
+        ctxs = [djb.Context("cpu")]
+    else:
+        gpus = min(gpus or n_dev, n_dev, max(len(paths), 1))
+        ctxs = [djb.Context(r) for r in range(gpus)]
+    ab, ag, timings = fit_files_multi(ctxs, list(paths), res, shadow)
+    out = [(float(a), float(g)) for a, g in zip(ab, ag)]
     if return_timing:
-        return out, {"wall_s": time.perf_counter() - t0, "per_gpu": timings, "gpus": gpus}
+        return out, {"wall_s": time.perf_counter() - t0, "per_gpu": timings, "gpus": 0 if (cpu or n_dev == 0) else len(ctxs)}
     return out
 
 

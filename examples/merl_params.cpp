@@ -79,26 +79,20 @@ int main(int argc, char **argv)
 		const bool share = !on_cpu && share_env && !strcmp(share_env, "1") && n_dev > 0;
 		if (gpus <= 0 || (gpus > n_dev && !share)) gpus = n_dev;
 		if (gpus > n && n > 0) gpus = n;
-		std::vector<std::string> errors(gpus);
-		std::vector<std::thread> workers;
-		for (int g = 0; g < gpus; ++g)
-			workers.push_back(std::thread([&, g]() {
-				std::vector<const char *> mine;            // material m -> GPU m mod G
-				std::vector<int> index;
-				for (int k = g; k < n; k += gpus) { mine.push_back(files[k]); index.push_back(k); }
-				if (mine.empty()) return;
-				std::vector<float> ab(mine.size()), ag(mine.size());
-				djb_ctx *ctx = NULL;
-				djb_status st = djb_ctx_create(on_cpu ? DJB_DEVICE_CPU : share ? g % n_dev : g, &ctx);
-				if (st == DJB_OK)
-					st = djb_fit_merl_files(ctx, (int)mine.size(), &mine[0], 90, 1, 0, &ab[0], &ag[0], NULL);
-				if (st != DJB_OK) errors[g] = djb_last_error();
-				if (ctx) djb_ctx_destroy(ctx);
-				for (size_t j = 0; j < index.size(); ++j) { beckmann[index[j]] = ab[j]; ggx[index[j]] = ag[j]; }
-			}));
-		for (size_t g = 0; g < workers.size(); ++g) workers[g].join();
-		for (int g = 0; g < gpus; ++g)
-			if (!errors[g].empty()) { fprintf(stderr, "%s", errors[g].c_str()); return EXIT_FAILURE; }
+		// ONE library call for the whole job: file k -> context k mod G, a host thread per context inside the library,
+		// rows in input order, no exchange between GPUs
+		std::vector<djb_ctx *> ctxs;
+		djb_status st = DJB_OK;
+		for (int g = 0; g < gpus && st == DJB_OK; ++g) {
+			djb_ctx *c = NULL;
+			st = djb_ctx_create(on_cpu ? DJB_DEVICE_CPU : share ? g % n_dev : g, &c);
+			if (st == DJB_OK) ctxs.push_back(c);
+		}
+		if (st == DJB_OK && n > 0)
+			st = djb_fit_merl_files_multi(&ctxs[0], (int)ctxs.size(), n, &files[0], 90, 1, 0, &beckmann[0], &ggx[0], NULL);
+		const std::string error = st != DJB_OK ? djb_last_error() : "";
+		for (size_t g = 0; g < ctxs.size(); ++g) djb_ctx_destroy(ctxs[g]);
+		if (st != DJB_OK) { fprintf(stderr, "%s", error.c_str()); return EXIT_FAILURE; }
 	}
 
 	FILE *pf = fopen("params.txt", "w");

@@ -54,8 +54,10 @@ extern "C" {
  *   230  round 5: + djb_helper (the reference's file-static erf / erfinv / xyz_to_theta_phi / uniform_to_concentric / rotate_vector).
  *   231  round 5: + DJB_PARAMS_RESOLVED_FOLLOWS / djb_params_cached (a parameter set that carries its resolved form: one-pair calls
  *        skip the set-up arithmetic).  A plain djb_params means what it always meant.
- *   232  round 5: + DJB_OPT_HOST_BATCH_MAX (the size up to which host-array calls are answered by the host twin; default unchanged).  */
-#define DJB_HIP_VERSION 232
+ *   232  round 5: + DJB_OPT_HOST_BATCH_MAX (the size up to which host-array calls are answered by the host twin; default unchanged).
+ *   233  round 6: + djb_fit_merl_files_multi (the file pipeline over several contexts).  The on-chip uniforms of
+ *        djb_sample_rng_batch / djb_gen_uniforms are a cheaper counter hash (dj_brdf_amd/synth.py: rng_uniforms); same interface.  */
+#define DJB_HIP_VERSION 233
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
 typedef enum {
@@ -552,6 +554,15 @@ djb_status djb_fit_brdf_batch(djb_ctx *, int n_materials, const djb_brdf *const 
 djb_status djb_fit_merl_files(djb_ctx *, int n_files, const char *const *paths, int res, int shadow,
                               int reader_threads, float *alpha_beckmann, float *alpha_ggx,
                               double *timing);
+/* The same job over SEVERAL contexts -- one per GPU of a node (BASELINE configs[4]; the loop of examples/merl_params.cpp:53-69 is what it
+ * stands for).  File k belongs to context k mod n_ctx; every context's share is one djb_fit_merl_files on a host thread inside the
+ * library (the calling thread takes context 0); alpha_*[k] are in INPUT order.  The fits are independent: no exchange between
+ * contexts, no collective.  Contexts must be distinct; CPU and GPU contexts may be mixed.  On failure nothing is written and the
+ * error is that of the lowest-indexed bad file over all shares (the reference's loop stops at its first bad file).  timing
+ * (optional): 4 doubles PER CONTEXT, each as in djb_fit_merl_files.                                                             */
+djb_status djb_fit_merl_files_multi(djb_ctx *const *ctxs, int n_ctx, int n_files, const char *const *paths,
+                                    int res, int shadow, int reader_threads, float *alpha_beckmann,
+                                    float *alpha_ggx, double *timing);
 
 /* ---------------------------------------------------------------- synthetic workloads
  * (not reference behaviour: the reference has no RNG).  Bit-identical to

@@ -414,3 +414,38 @@ def test_on_chip_generator_restatement_and_quality(cpu):
         f = float(((bits >> np.uint32(b)) & np.uint32(1)).mean())
         assert abs(f - 0.5) < 5 * 0.5 / np.sqrt(n), (b, f)
     assert not np.array_equal(u1, synth.rng_uniforms(n, synth.SEED_U1 + 1))
+
+
+def test_fit_files_over_several_contexts(tmp_path):
+    """djb_fit_merl_files_multi (ABI 233): file k on context k mod G, one host thread per context inside the library,
+    rows in input order, the lowest-indexed bad file's error wins, a context listed twice is refused.  CPU contexts here; the GPU
+    form of the same test (2 and 3 contexts on one device) is tests/test_gpu_golden.py::test_fit_files_multi_contexts."""
+    recipes = [synth.material_recipe(k) for k in range(4)]
+    paths = []
+    for k in range(7):
+        p = str(tmp_path / f"m{k}.binary")
+        synth.write_merl_binary(p, synth.merl_table(*recipes[k % 4])); paths.append(p)
+    one = djb.Context("cpu")
+    ab1, ag1, _ = merl_params.fit_files_on(one, paths)
+    for g in (1, 2, 3, 9):                              # 9 > number of files: the spare contexts stay idle
+        ctxs = [djb.Context("cpu") for _ in range(g)]
+        ab, ag, per = merl_params.fit_files_multi(ctxs, paths)
+        assert np.array_equal(ab.view(np.uint32), ab1.view(np.uint32)) and np.array_equal(ag.view(np.uint32), ag1.view(np.uint32)), g
+        assert len(per) == g and sum(t["bytes"] for t in per) == 7 * 5545 * 24
+    # errors: files 1 (context 1: bad header) and 2 (context 0: missing) are bad -> the reference's loop would stop at file 1
+    bad = tmp_path / "bad.binary"; bad.write_bytes(np.array([90, 90, 181], np.int32).tobytes() + b"\0" * 100)
+    broken = [paths[0], str(bad), str(tmp_path / "missing.binary")] + paths[3:]
+    ctxs = [djb.Context("cpu"), djb.Context("cpu")]
+    with pytest.raises(djb.exc) as e:
+        merl_params.fit_files_multi(ctxs, broken)
+    assert e.value.status_name == "DJB_ERR_BAD_HEADER", str(e.value)
+    with pytest.raises(djb.exc) as e:
+        merl_params.fit_files_multi(ctxs, [paths[0], paths[1], str(tmp_path / "missing.binary"), str(bad)])
+    assert e.value.status_name == "DJB_ERR_OPEN_FAILED" and "missing.binary" in str(e.value)
+    with pytest.raises(djb.exc) as e:
+        merl_params.fit_files_multi([ctxs[0], ctxs[0]], paths)
+    assert e.value.status_name == "DJB_ERR_INVALID_ARGUMENT"
+    assert merl_params.fit_files_multi(ctxs, [])[0].size == 0
+    # the driver's own entry point goes through the same call
+    out = merl_params.fit_files(paths, cpu=True)
+    assert [a for a, _ in out] == [float(a) for a in ab1]

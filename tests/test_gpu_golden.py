@@ -413,6 +413,37 @@ def test_native_file_pipeline(gpu_ctx, tmp_path):
     assert e.value.status_name == "DJB_ERR_READ_FAILED"
 
 
+def test_fit_files_multi_contexts(gpu_ctx, tmp_path):
+    """djb_fit_merl_files_multi on GPU contexts: 2 and 3 contexts (each its own stream) on the one device of the box stand in for the
+    GPUs of a node -- same alphas as one context, input order, and the C++ driver (examples/merl_params -g N with
+    DJB_EXAMPLE_SHARE_GPU=1) writes the same params.txt through the same call."""
+    import subprocess
+    recipes = [synth.material_recipe(k) for k in range(5)]
+    paths = []
+    for k in range(11):
+        p = str(tmp_path / f"m{k}.binary")
+        synth.write_merl_binary(p, synth.merl_table(*recipes[k % 5])); paths.append(p)
+    ab1, ag1, _ = merl_params.fit_files_on(gpu_ctx, paths)
+    for g in (2, 3):
+        ctxs = [djb.Context(gpu_ctx.device) for _ in range(g)]
+        ab, ag, per = merl_params.fit_files_multi(ctxs, paths)
+        assert np.array_equal(ab.view(np.uint32), ab1.view(np.uint32)) and np.array_equal(ag.view(np.uint32), ag1.view(np.uint32)), g
+        assert all(t["total_s"] > 0 for t in per)
+        with pytest.raises(djb.exc) as e:
+            merl_params.fit_files_multi(ctxs, paths[:4] + [str(tmp_path / "missing.binary")] + paths[5:])
+        assert e.value.status_name == "DJB_ERR_OPEN_FAILED"
+    # a GPU and a CPU context side by side: independent shares, same bits
+    ab, ag, _ = merl_params.fit_files_multi([djb.Context(gpu_ctx.device), djb.Context("cpu")], paths)
+    assert np.array_equal(ab.view(np.uint32), ab1.view(np.uint32)) and np.array_equal(ag.view(np.uint32), ag1.view(np.uint32))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "merl_params")
+    assert os.path.exists(exe), "examples not built: run __graft_entry__.build()"
+    r = subprocess.run([exe, "-g", "3"] + paths, cwd=str(tmp_path), capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, DJB_EXAMPLE_SHARE_GPU="1", DJB_QUIET="1"))
+    assert r.returncode == 0, r.stderr
+    assert open(tmp_path / "params.txt").read() == merl_params.format_params_txt(paths, list(zip(ab1.tolist(), ag1.tolist())))
+
+
 def test_file_that_shrinks_under_the_gather_gpu(gpu_ctx, tmp_path, monkeypatch):
     """as tests/test_cpu_path.py::test_file_that_shrinks_under_the_gather, through the GPU file pipeline's reader threads:
     a file truncated after the size check and the mapping gives "Reading <file> failed" (dj_brdf.h:979-982), not SIGBUS,

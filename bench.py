@@ -709,6 +709,65 @@ def static_profile(name, n, launch_ms):
     return out
 
 
+def merl_order_lever(djb, synth, ctx, torch, local, n=1 << 28, tile=4096):
+    """The one lever the MERL look-up leaves to its caller: the ORDER of the batch.  The same 2^28 random pairs (the headline
+    distribution) evaluated (a) as generated, (b) with every consecutive tile of 4096 pairs ordered by bin key -- the most a per-workgroup
+    LDS bucketing pass inside the kernel could achieve, here done outside the timed region, so the row is an upper bound for it --
+    (c) sorted by bin key over the whole batch (what a wavefront renderer that already sorts its hits gets by appending the key);
+    plus the cost of producing the keys (djb_merl_bin_keys_batch: tier-1 arithmetic only, 28 B per pair)."""
+    lib, C = djb._lib.load(), ctypes
+    dev = f"cuda:{ctx.device}"
+    i = djb.gen_directions(n, synth.SEED_I, ctx=ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
+    m = djb.merl.from_table(synth.merl_table(0.3), ctx=ctx)
+    out = torch.empty((3, n), dtype=torch.float32, device=dev)
+    keys = torch.empty((n,), dtype=torch.int32, device=dev)
+    vout = djb._Vec(out)
+
+    def evaluator(a, b):
+        va, vb = djb._Vec(a), djb._Vec(b)
+
+        def st():
+            djb._lib.check(lib.djb_eval_batch(ctx._h, m._h, C.c_int64(n), C.byref(va.view), C.byref(vb.view), None, C.byref(vout.view), C.c_int(0)))
+        st.keep = (va, vb, a, b)
+        return st
+    vi, vo = djb._Vec(i), djb._Vec(o)
+
+    def key_step():
+        djb._lib.check(lib.djb_merl_bin_keys_batch(ctx._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view), C.c_void_p(keys.data_ptr()), C.c_int(0)))
+    res = {"pairs": n, "tile": tile, "algorithmic_bytes_per_unit": 36}
+
+    def row(ms, spread, bytes_per_unit=36):
+        return {"ms_per_step": ms, "ms_min_median_max": spread, "value": n / (ms * 1e-3), "unit": "evals/s",
+                "roofline_frac": n * bytes_per_unit / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    ms, spread, _ = timed_leg(key_step, torch, local)
+    res["key_kernel"] = dict(row(ms, spread, 28), unit="keys/s", algorithmic_bytes_per_unit=28, kernel="k_merl_keys")
+    ms, spread, _ = timed_leg(evaluator(i, o), torch, local)
+    res["as_generated"] = row(ms, spread)
+    # (b) order inside tiles of `tile` pairs
+    kt = keys.view(n // tile, tile)
+    perm = torch.sort(kt, dim=1).indices + (torch.arange(n // tile, device=dev, dtype=torch.int64) * tile).unsqueeze(1)
+    perm = perm.reshape(-1)
+    ib = torch.stack([i[c][perm] for c in range(3)]).contiguous(); ob = torch.stack([o[c][perm] for c in range(3)]).contiguous()
+    ms, spread, _ = timed_leg(evaluator(ib, ob), torch, local)
+    res["tile_bucketed"] = row(ms, spread)
+    del kt, ib, ob
+    # (c) the whole batch sorted by key
+    perm = torch.sort(keys.to(torch.int64)).indices
+    ig = torch.stack([i[c][perm] for c in range(3)]).contiguous(); og = torch.stack([o[c][perm] for c in range(3)]).contiguous()
+    ms, spread, _ = timed_leg(evaluator(ig, og), torch, local)
+    res["sorted_by_key"] = row(ms, spread)
+    del perm, ig, og
+    torch.cuda.empty_cache()
+    a, b, c = res["as_generated"]["ms_per_step"], res["tile_bucketed"]["ms_per_step"], res["sorted_by_key"]["ms_per_step"]
+    res["what"] = ("the same 2^28 random pairs in three orders; tile_bucketed is an UPPER BOUND for an in-kernel per-workgroup LDS bucketing pass "
+                   "(the ordering was done outside the timed region); a tile of %d pairs touches ~%d distinct table lines of 136 688 either way, so "
+                   "ordering inside it changes neither the lines a launch touches per unit time nor the L2 hit rate" % (tile, tile))
+    res["break_even"] = ("sorting buys %.2f ms per 2^28 pairs (%.2f -> %.2f) and costs the key kernel (%.2f ms) plus a sort of 2^28 (key, index) "
+                         "records and a 24 B/pair gather -- several times the look-up itself on this chip -- so it pays only where the caller "
+                         "sorts anyway (wavefront renderers sorting hits by material: append the 21 key bits)" % (a - c, a, c, res["key_kernel"]["ms_per_step"]))
+    return res
+
+
 def gpu_state(device=0):
     """Shader clock / power / temperature of the GPU as the kernel driver reports them right now (sysfs hwmon of the card; no subprocess,
     ~0.1 ms).  Called while a leg's launches are in flight, so the figures are those of the loaded chip.  None where a file is absent."""
@@ -1085,6 +1144,7 @@ def main():
                 del st, kp
                 torch.cuda.empty_cache()
             sec["plugin_ops"] = ops
+            sec["merl_eval_order_lever"] = merl_order_lever(djb, synth, ctx, torch, local)
             rec["secondary"] = sec
         print(json.dumps(rec), flush=True)
     if world > 1:

@@ -583,6 +583,26 @@ try {
 }
 DJB_ABI_CATCH
 
+djb_status djb_merl_bin_keys_batch(djb_ctx *ctx, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o, uint32_t *out_keys, int mem)
+try {
+	if (!ctx) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null ctx");
+	// the host path has no fast tier: its keys are the exact indices (a key equals merl_index wherever tier 1 is certain -- always, here)
+	if (is_cpu(ctx)) return djbcpu::merl_index(ctx, n, i, o, reinterpret_cast<int32_t *>(out_keys));
+	if (mem == DJB_MEM_HOST && n >= 0 && n <= ctx->host_batch_max && !ctx->scalar_on_device)
+		return djbcpu::merl_index(djbcpu::twin_ctx(), n, i, o, reinterpret_cast<int32_t *>(out_keys));
+	djb_status st = check_call(ctx, nullptr, n, mem);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	Staged sg(ctx, n, mem);
+	View vi, vo; int32_t *dkeys;
+	if ((st = sg.in_vec(i, &vi)) != DJB_OK) return st;
+	if ((st = sg.in_vec(o, &vo)) != DJB_OK) return st;
+	if ((st = sg.out_arr(reinterpret_cast<int32_t *>(out_keys), &dkeys)) != DJB_OK) return st;
+	HIP_TRY(djbk::launch_merl_keys(ctx->stream, n, vi, vo, reinterpret_cast<uint32_t *>(dkeys)));
+	return sg.finish();
+}
+DJB_ABI_CATCH
+
 // ---------------------------------------------------------------- the reference's file-static helpers (host scalars)
 djb_status djb_helper(int which, const float *in, float *out)
 try {

@@ -60,6 +60,7 @@ hipError_t launch_query(hipStream_t s, const Brdf &b, const Params &p, int which
 hipError_t launch_io_to_hd(hipStream_t s, long long n, const View &i, const View &o,
                            const View &h, const View &d, bool inverse);
 hipError_t launch_merl_index(hipStream_t s, long long n, const View &i, const View &o, int32_t *idx);
+hipError_t launch_merl_keys(hipStream_t s, long long n, const View &i, const View &o, uint32_t *keys);     // tier-1 bin keys (djb_kernels_merl.hip)
 
 // two-tier exact MERL lookup (djb_kernels_merl.hip): one kernel, the ambiguous pairs of tier 1 wait in per-wave LDS queues and are
 // drained by the exact path as dense waves (no worklist in HBM, no second launch)

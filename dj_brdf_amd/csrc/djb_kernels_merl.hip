@@ -45,6 +45,22 @@ DJB_DEV void merl_emit(const Brdf &b, int idx, v3 i, long long k, const View &vo
 	if (WANT & 4) out_pdf[k] = F(D(i.z) / DJB_PI);                // brdf::pdf,   dj_brdf.h:842-845
 }
 
+// ---- djb_merl_bin_keys_batch: the 21-bit bin key of every pair from TIER-1 arithmetic only (fp32 closed forms, ~120 VALU, no fp64
+// path, no table access) -- for callers that order a batch before the look-up: the look-up's rate is set by how many distinct table
+// lines a launch touches per unit time (0.23 of the roofline on look-ups uniform over the bins, 0.40 on random directions, 0.67 on a
+// renderer-coherent batch).  The key IS merl_index(i, o) for every pair tier 1 is certain of (99.6 % of random directions) and the
+// neighbouring bin the estimate falls into otherwise: good for ordering, not a substitute for djb_merl_index_batch.
+__global__ __launch_bounds__(BLOCK) void k_merl_keys(long long n, View vi, View vo, uint32_t *keys, MerlGuard g)
+{
+	const long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		int idx;
+		(void)merl_index_fast(load3(vi, k), load3(vo, k), g, idx);
+		idx = idx < 0 ? 0 : idx > 90 * 90 * 180 - 1 ? 90 * 90 * 180 - 1 : idx;      // NaN / stray directions: any valid key
+		keys[k] = (uint32_t)idx;
+	}
+}
+
 // ---- the per-wave queue of ambiguous pairs and its drain.  QCAP: fewer than 64 pairs wait when an iteration starts and an
 // iteration adds at most 4 x 64, so 320 slots always suffice; there is ONE drain site per kernel (the exact path is ~6 000
 // instructions and ~140 registers: every further inlined copy costs both)
@@ -321,6 +337,13 @@ hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const 
 	case 6: return launch_tt<6>(s, b, n, i, o, out, out_pdf, g);
 	}
 	return hipErrorInvalidValue;
+}
+
+hipError_t launch_merl_keys(hipStream_t s, long long n, const View &i, const View &o, uint32_t *keys)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_merl_keys, dim3(grid_for(n, 256LL * 32)), dim3(BLOCK), 0, s, n, i, o, keys, MERL_GUARD_DEFAULT);
+	return hipGetLastError();
 }
 
 hipError_t launch_merl_guard_stats(hipStream_t s, long long n, const View &i, const View &o,

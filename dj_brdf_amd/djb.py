@@ -446,6 +446,18 @@ def merl_index(i, o, ctx: Optional[Context] = None):
     return idx
 
 
+def merl_bin_keys(i, o, ctx: Optional[Context] = None):
+    """21-bit MERL bin keys from the look-up's tier-1 arithmetic (djb_merl_bin_keys_batch): == merl_index where tier 1 is certain
+    (99.6 % of random pairs), the neighbouring bin otherwise.  For ordering a batch before merl.eval; int32 array / tensor."""
+    lib = _lib.load()
+    ctx = ctx or default_context()
+    vi, vo = _Vec(i), _Vec(o)
+    keys, ptr = vi.scalars(np.int32)
+    _lib.check(lib.djb_merl_bin_keys_batch(ctx._h, C.c_int64(vi.n), C.byref(vi.view), C.byref(vo.view),
+                                           C.c_void_p(ptr), C.c_int(vi.mem)))
+    return keys
+
+
 # --------------------------------------------------------------------------- microfacet (dj_brdf.h:210-298)
 class microfacet(brdf):
     class params:

@@ -55,7 +55,7 @@ extern "C" {
  *   231  round 5: + DJB_PARAMS_RESOLVED_FOLLOWS / djb_params_cached (a parameter set that carries its resolved form: one-pair calls
  *        skip the set-up arithmetic).  A plain djb_params means what it always meant.
  *   232  round 5: + DJB_OPT_HOST_BATCH_MAX (the size up to which host-array calls are answered by the host twin; default unchanged).
- *   233  round 6: + djb_fit_merl_files_multi (the file pipeline over several contexts).  The on-chip uniforms of
+ *   233  round 6: + djb_fit_merl_files_multi (the file pipeline over several contexts), djb_merl_bin_keys_batch.  The on-chip uniforms of
  *        djb_sample_rng_batch / djb_gen_uniforms are a cheaper counter hash (dj_brdf_amd/synth.py: rng_uniforms); same interface.  */
 #define DJB_HIP_VERSION 233
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
@@ -425,6 +425,14 @@ djb_status djb_hd_to_io_batch(djb_ctx *, int64_t n, const djb_vec3_view *h, cons
 /* the table index merl::eval composes (diagnostic; dj_brdf.h:997-1002)                  */
 djb_status djb_merl_index_batch(djb_ctx *, int64_t n, const djb_vec3_view *i,
                                 const djb_vec3_view *o, int32_t *out_index, int mem);
+/* The 21-bit MERL bin key of every pair from the look-up's TIER-1 arithmetic only (fp32 closed forms; no fp64 path, no table access):
+ * key == the index djb_merl_index_batch returns for every pair tier 1 is certain of (99.6 % of random directions; all of them on a
+ * CPU context), the neighbouring bin its estimate falls into otherwise.  For ORDERING a batch before djb_eval_batch on a merl object --
+ * the look-up's rate depends on how many distinct 128-byte table lines a launch touches per unit time (bench.py
+ * secondary.merl_eval_order_lever: as generated / bucketed per 4096-pair tile / sorted by key) -- e.g. a wavefront renderer that
+ * already sorts its hits by material can append these bits to its sort key.  Not a substitute for the exact index.   (ABI 233) */
+djb_status djb_merl_bin_keys_batch(djb_ctx *, int64_t n, const djb_vec3_view *i, const djb_vec3_view *o,
+                                   uint32_t *out_keys, int mem);
 
 /* calibration of the two-tier MERL kernel on n device-resident pairs: max over the batch of
  * |fp32 estimate - reference value| / guard band for (theta_h, theta_d, phi_d), and the counters

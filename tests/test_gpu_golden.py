@@ -204,6 +204,36 @@ def test_full_size_merl_eval_other_distributions(gpu_ctx, dist):
     assert np.array_equal(out[:, sel].T.contiguous().cpu().numpy().view(np.uint32), O.eval(om, hi, ho).view(np.uint32))
 
 
+def test_merl_bin_keys(gpu_ctx):
+    """djb_merl_bin_keys_batch (ABI 233): tier-1 keys for ordering batches -- the exact index wherever tier 1 is certain (>= 99 % of random
+    pairs), a valid neighbouring bin otherwise (never out of range, also for stray / NaN directions); a CPU context returns exact indices."""
+    import torch
+    n = 1 << 22
+    i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
+    keys = djb.merl_bin_keys(i, o, ctx=gpu_ctx)
+    idx = djb.merl_index(i, o, ctx=gpu_ctx)
+    assert keys.dtype == torch.int32 and int(keys.min()) >= 0 and int(keys.max()) < synth.MERL_N
+    same = float((keys == idx).float().mean())
+    assert same > 0.99, same
+    off = (keys != idx)
+    # where they differ the key is a neighbour along one coordinate (theta_h: 16200, theta_d: 180, phi_d: 1 or the wrap 179)
+    d = (keys[off].long() - idx[off].long()).abs()
+    ok = (d == 1) | (d == 179) | (d == 180) | (d == 16200)
+    assert float(ok.float().mean()) > 0.9, float(ok.float().mean())
+    # hostile directions: any valid key, no crash
+    bad = np.array([[np.nan, 0, 1], [0, 0, 0], [0, 0, -1], [1e30, 1e30, 1e30], [np.inf, 0, 0], [0, 0, 1]], np.float32)
+    bi = torch.from_numpy(np.ascontiguousarray(bad.T)).cuda(); bo = torch.from_numpy(np.ascontiguousarray(bad[::-1].T.copy())).cuda()
+    kb = djb.merl_bin_keys(bi, bo, ctx=gpu_ctx)
+    assert int(kb.min()) >= 0 and int(kb.max()) < synth.MERL_N
+    # host arrays on a GPU context (staged), and the CPU context: exact indices
+    hi, ho = synth.directions_aos(5000, 5), synth.directions_aos(5000, 6)
+    kh = djb.merl_bin_keys(hi, ho, ctx=gpu_ctx)
+    ex = djb.merl_index(hi, ho, ctx=gpu_ctx)
+    assert (kh == ex).mean() > 0.99
+    cpu = djb.cpu_context()
+    assert np.array_equal(djb.merl_bin_keys(hi, ho, ctx=cpu), djb.merl_index(hi, ho, ctx=cpu))
+
+
 def test_merl_eval_one_launch_beyond_2_pow_31_pairs(gpu_ctx):
     """Maximum sizes: one djb_eval_batch call over 2^31 + 4097 pairs (77 GB of directions + results
     in HBM).  Pair indices travel as uint32 inside the two-tier kernel, so the call is chunked at

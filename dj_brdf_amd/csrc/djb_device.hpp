@@ -451,6 +451,56 @@ DJB_DEV float glibc_powf(float x, float y, const GlibcTabs &) { return djbhostli
 #include "djb_glibc_restated_f32.inc"
 #endif
 
+// (float(double(r) * cos(double(phi))), float(double(r) * sin(double(phi)))): the polar -> slope step of the normal-map sampling scheme
+// (radial::sample_vp22_std_nmap, dj_brdf.h:1806-1816; tabular_anisotropic, :2828; Cline's concentric map, :745-746).
+#if defined(DJB_HOST_MATH)
+DJB_DEV void polar_to_f32(float r, float phi, float &x, float &y) { x = F(D(r) * glibc_cos(D(phi))); y = F(D(r) * glibc_sin(D(phi))); }
+#else
+// Device (round 6): glibc's sin and cos -- table-driven, ~135 fp64 instructions each as restated -- were 270 of the 590 VALU instructions
+// of a tabular `sample`.  Guarded shortcut, the pattern of div_to_f32: sine and cosine from a Cody-Waite reduction by pi/2 (two fma
+// steps; |phi| <= 8, so k <= 5 and the reduced argument keeps full relative accuracy for a float-valued phi) and fdlibm's kernel
+// polynomials (|error| <= 2^-58 on |t| <= pi/4): within 2 ulp64 of the host libm's values for EVERY float phi in [-8, 8]
+// (tools/sincos_fast_check.c, all 2.2e9 arguments, profiles/r06/sincos_fast_check.txt).  The products then differ from the reference's
+// doubles by < 4 ulp64 and round to the same floats unless one sits within 256 ulp64 of a float rounding boundary (near_f32_midpoint,
+// probability 2^-19 per sample); there, for zero / subnormal-range / huge products and for phi outside [-8, 8] or NaN, glibc's own
+// algorithms decide -- the previous code, verbatim.
+DJB_DEV void sincos_fast(double x, double &s, double &c)
+{
+	const double kf = __builtin_rint(x * 0x1.45f306dc9c883p-1);                    // 2 / pi
+	double t = __builtin_fma(-kf, 0x1.921fb54442d18p+0, x);                        // pi / 2: its high 53 bits ...
+	t = __builtin_fma(-kf, 0x1.1a62633145c07p-54, t);                              // ... and the next 53
+	const double z = t * t;
+	double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+	ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+	ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+	ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+	ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+	const double st = __builtin_fma(t * z, ps, t);
+	double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+	pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+	pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+	pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+	pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+	const double ct = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+	const int q = (int)kf & 3;
+	const double a = (q & 1) ? ct : st, b = (q & 1) ? st : ct;                     // the quadrant: sin takes a, cos takes b
+	s = (q & 2) ? -a : a;
+	c = ((q + 1) & 2) ? -b : b;
+}
+DJB_DEV void polar_to_f32(float r, float phi, float &x, float &y)
+{
+	const double ph = D(phi);
+	double s, c;
+	sincos_fast(ph, s, c);
+	const double px = D(r) * c, py = D(r) * s;
+	const double ax = px < 0 ? -px : px, ay = py < 0 ? -py : py;
+	const bool fast = (ph >= -8.0) & (ph <= 8.0) & (ax > 1e-30) & (ax < 1e30) & (ay > 1e-30) & (ay < 1e30)
+	                & !near_f32_midpoint(px) & !near_f32_midpoint(py);
+	if (__builtin_expect(!fast, 0)) { x = F(D(r) * glibc_cos(ph)); y = F(D(r) * glibc_sin(ph)); return; }
+	x = F(px); y = F(py);
+}
+#endif
+
 #include "djb_device_microfacet.inc"
 #include "djb_device_tables.inc"
 #include "djb_device_units.inc"

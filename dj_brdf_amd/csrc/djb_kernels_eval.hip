@@ -37,7 +37,7 @@ inline int grid_full(long long n)
 // load3_dense / store3_dense (djb_device_units.inc): dense batches address their arrays as uniform base + lane offset
 inline bool dense(const View &v) { return v.stride == 1 || v.x == nullptr; }
 
-// min-waves hint per kind, measured (tools/kind_rates.py, ms per 1e8 pairs at 1 / 4 / 8 waves): the analytic /
+// min-waves hint per kind, measured (round 2; ms per 1e8 pairs at 1 / 4 / 8 waves; the rates themselves are bench.py legs now): the analytic /
 // tabulated microfacet kernels fit 128 VGPRs (4); utia 3.34 / 2.93 / 10.5 and sgd 4.46 / 4.17 / 8.3 want 4
 // (left alone they take 172 VGPRs = 2 waves, too few to hide the table gathers; at 8 they spill);
 // abc 1.58 / 1.34 / 1.30 is light enough for 8; the operation-by-operation merl kernel stays unconstrained.

@@ -342,7 +342,8 @@ hipError_t launch_merl_twotier(hipStream_t s, const Brdf &b, long long n, const 
 hipError_t launch_merl_keys(hipStream_t s, long long n, const View &i, const View &o, uint32_t *keys)
 {
 	if (n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k_merl_keys, dim3(grid_for(n, 256LL * 32)), dim3(BLOCK), 0, s, n, i, o, keys, MERL_GUARD_DEFAULT);
+	const MerlGuard g = MERL_GUARD_DEFAULT;
+	hipLaunchKernelGGL(k_merl_keys, dim3(grid_for(n, 256LL * 32)), dim3(BLOCK), 0, s, n, i, o, keys, g);
 	return hipGetLastError();
 }
 

@@ -249,7 +249,7 @@ def test_contract_sgd_all_materials_selftest(gpu_ctx):
     """The SGD fast path (k_ct_fast_v4<SGD>) against the bit-exact per-pair code on the device: the 100 published rows x the
     five input families, 2^22 generated pairs each (k up to 856, c up to 1e38, lambda up to 1.5e7, alpha down to 1.6e-5).
     Its shadowing term is a wall: which share of the pairs the error bound hands to tier 2 depends on the material -- printed
-    per family, and written out by tools/kind_rates.py for profiles/."""
+    per family, and reported per leg by bench.py (secondary.*_contract)."""
     worst = 0.0
     shares = np.zeros((100, 5))
     for k, name in enumerate(synth.MERL_NAMES):

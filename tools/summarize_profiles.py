@@ -44,7 +44,14 @@ def counters(path):
     return acc, meta
 
 
+# gpurun merges every session's gpurun_out/prof/<workload> into the same tree: only the workloads named on the command line (the ones the
+# last session profiled) are summarised -- anything else there is an older kernel's passes
+ONLY = sys.argv[2:]
+if not ONLY:
+    sys.exit("usage: summarize_profiles.py <round> <workload> [<workload> ...]   (the workloads the last profile session ran)")
 for w in sorted(os.listdir(SRC)):
+    if w not in ONLY:
+        continue
     d = os.path.join(SRC, w)
     for f in sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
         shutil.copy(f, os.path.join(DST, f"{w}_kernel_stats.csv"))
@@ -109,7 +116,7 @@ for w in sorted(os.listdir(SRC)):
         print(w, out["hbm_bytes_per_launch"] / 1e9, "GB per launch")
 # the instruction-mix summaries of tools/valu_report.py (written on the GPU box into gpurun_out/): tracked copies, stamped with the tree
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "valu_*.json"))):
-    if os.path.getmtime(f) < os.path.getmtime(SRC):          # older than this round's profile passes: a leftover
+    if os.path.basename(f)[len("valu_"):-len(".json")] not in ONLY:
         continue
     v = json.load(open(f))
     v["tree"] = TREE

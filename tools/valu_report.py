@@ -21,6 +21,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import LAUNCHES, kernel_short_name as short_name      # the kernels each workload times (the table bench.py checks a summary against)
 SLOT_NS = 1.155          # v_mul_f32 wave-instruction per SIMD, profiles/r03/valu_issue_cost.txt
 N_SIMD = 1024            # 256 CUs x 4
 # issue slots per instruction class (profiles/r03/valu_issue_cost.txt); OTHER = what the SQ class counters leave of
@@ -58,6 +60,8 @@ def main():
     kernels = []
     for k, v in agg.items():
         if any(s in k for s in ("gen_dir", "gen_uni", "rocclr", "convert", "at::native", "k_coherent", "k_uniform")):
+            continue
+        if LAUNCHES.get(w) and short_name(k) not in LAUNCHES[w]:       # set-up kernels of the leg (the fit that builds a tabular object ...)
             continue
         c = {n: sum(x) / len(x) for n, x in v.items()}
         if c.get("SQ_INSTS_VALU", 0) < 1e3:

@@ -72,7 +72,9 @@ WORKLOADS = {
     "beckmann_sample": (1_000_000_000, 24, "samples", "k_sample_bk<sample,rng>"),
     # configs[3] under DJB_OPT_CONTRACT_1E5: every component of the sampled direction within 1e-5 of the reference's
     "beckmann_sample_contract": (1_000_000_000, 24, "samples", "k_sample_bk<sample,rng,contract> (fp32 Newton sequence that follows the reference's; doubtful samples re-done exactly in the same launch)"),
-    "utia_eval": (100_000_000, 36, "evals", "k_eval_utia_t1<eval> + k_eval_utia_fix<eval> (two-tier exact)"),
+    "utia_eval": (100_000_000, 36, "evals", "k_utia_v2<eval> + k_eval_utia_fix<eval> (two-tier exact)"),
+    # under DJB_OPT_CONTRACT_1E5: cells, weights and the 16-tap sums stay the reference's bits, the sRGB power runs on v_log / v_exp_f32
+    "utia_eval_contract": (100_000_000, 36, "evals", "k_utia_v2<eval,contract> + k_eval_utia_fix<eval> (1e-5 value contract)"),
     # ---- the operators the five Mitsuba plugins issue that have no BASELINE config of their own: driver-run legs
     # (secondary.plugin_ops at N=1), each also a --workload of its own so that tools/profile_bench.sh can take its counters
     # dj_sgd / dj_abc: pdf() and sample() come from tabular(model, 90) (mitsuba/dj_abc.cpp:28-32, 77, 89); eval + pdf fused, 40 B
@@ -122,7 +124,7 @@ LAUNCHES = {
     "ggx_eval_pdf_contract": ["k_ct_fast_v4", "k_ct_fixup"], "ggx_unpolarized_eval_pdf_contract": ["k_ct_fast_v4", "k_ct_fixup"],
     "sgd_eval_contract": ["k_ct_fast_v4", "k_ct_fixup"],
     "beckmann_sample": ["k_sample_bk"], "beckmann_sample_contract": ["k_sample_bk"],
-    "utia_eval": ["k_eval_utia_t1", "k_eval_utia_fix"], "merl_fit": ["k_fit"],
+    "utia_eval": ["k_utia_v2", "k_eval_utia_fix"], "utia_eval_contract": ["k_utia_v2", "k_eval_utia_fix"], "merl_fit": ["k_fit"],
     "tabular_eval_pdf": ["k_eval"], "tabular_aniso_eval_pdf": ["k_eval"], "abc_evalp": ["k_eval"], "lean_evalp_pdf": ["k_eval_pp"],
     "tabular_sample": ["k_sample"], "tabular_abc_sample": ["k_sample"], "tabular_aniso_sample": ["k_sample"],
     "ggx_evalp_is": ["k_sample"], "beckmann_evalp_is": ["k_sample_bk"], "fit_tabular_90": ["k_fit"],
@@ -264,6 +266,26 @@ def contract_mode(step, name, djb, ctx):
     return step
 
 
+def utia_contract_accuracy(step, keep, djb, ctx, torch):
+    """The contract launch against the bit-exact launch on the leg's own pairs (all of them): the option only changes the sRGB power."""
+    out = keep[3]
+    step(); torch.cuda.synchronize()
+    fast = out.clone()
+    djb.set_contract_1e5(ctx, False)
+    step(); torch.cuda.synchronize()
+    djb.set_contract_1e5(ctx, True)
+    exact = out
+    rel = (fast - exact).abs() / exact.abs().clamp_min(1e-30)
+    rel = torch.where(exact == fast, torch.zeros_like(rel), rel)
+    res = {"max_rel_err_eval": float(rel.max()), "values_outside_1e-5": int((rel > 1e-5).sum()),
+           "zero_pattern_mismatches": int(((exact == 0) != (fast == 0)).sum()), "values_compared": int(exact.numel()),
+           "bit_identical_share": float((exact.view(torch.int32) == fast.view(torch.int32)).float().mean()),
+           "contract": "1e-5 relative (north_star); cells, weights and 16-tap sums are the reference's bits, only the sRGB power is "
+                       "approximate; DJB_OPT_CONTRACT_1E5, off by default"}
+    del fast, rel
+    return res
+
+
 def finish(step):
     getattr(step, "cleanup", lambda: None)()
 
@@ -334,7 +356,7 @@ def make_step(name, n, djb, synth, ctx, torch):
                                                     C.c_uint32(synth.SEED_U2), C.c_uint64(0), C.byref(vo.view),
                                                     C.byref(p._p), C.byref(vout.view)))
         return contract_mode(step, name, djb, ctx), (o, out, b, p, vo, vout)
-    if name == "utia_eval":
+    if name in ("utia_eval", "utia_eval_contract"):
         i = djb.gen_directions(n, synth.SEED_I, ctx=ctx)
         o = djb.gen_directions(n, synth.SEED_O, ctx=ctx)
         tab = np.random.default_rng(11).uniform(0.0, 120.0, size=3 * 288 * 288)   # UTIA-format payload (sRGB-coded * 140)
@@ -346,7 +368,7 @@ def make_step(name, n, djb, synth, ctx, torch):
         def step():
             djb._lib.check(lib.djb_eval_batch(ctx._h, u._h, C.c_int64(n), C.byref(vi.view), C.byref(vo.view),
                                               None, C.byref(vout.view), C.c_int(0)))
-        return step, (i, o, u, out, vi, vo, vout)
+        return contract_mode(step, name, djb, ctx), (i, o, u, out, vi, vo, vout)
     if name in PLUGIN_LEGS:
         return plugin_leg_step(name, n, djb, synth, ctx, torch)
     if name == "merl_fit":
@@ -508,7 +530,7 @@ def cpu_baseline(name, synth, budget_s=12.0):
         b, op = L.sgd("gold-metallic-paint"), "eval"
     elif name in ("beckmann_sample", "beckmann_sample_contract"):
         b, op, par = L.microfacet("beckmann", ("ideal",), True), "sample", ("elliptic", 0.2, 0.5, 0.7)
-    elif name == "utia_eval":
+    elif name in ("utia_eval", "utia_eval_contract"):
         path = "/tmp/djb_bench_cpu_utia.bin"
         np.random.default_rng(11).uniform(0.0, 120.0, size=3 * 288 * 288).tofile(path)
         b, op = L.utia(path), "eval"
@@ -1065,6 +1087,7 @@ def main():
                                 "beckmann_sample": "Beckmann elliptic(0.2,0.5,0.7) VNDF sample, on-chip RNG",
                                 "beckmann_sample_contract": "Beckmann elliptic(0.2,0.5,0.7) VNDF sample, on-chip RNG, DJB_OPT_CONTRACT_1E5 (directions within 1e-5 per component, not bit-identical)",
                                 "utia_eval": "UTIA 6x48x6x48x3 table, 16-tap interpolation + sRGB decode (synthetic payload)",
+                                "utia_eval_contract": "UTIA 6x48x6x48x3 table, 16-tap interpolation + sRGB decode (synthetic payload), DJB_OPT_CONTRACT_1E5",
                                 "merl_fit": "tabular(merl, 90) + fit_beckmann + fit_ggx per material, tables resident in HBM",
                                 "merl_fit_files": "files on local disk -> pread -> PCIe -> k_merl_convert -> "
                                                   "tabular(merl, 90) + both fits (end to end)",
@@ -1100,8 +1123,8 @@ def main():
             if opc.get("gpu_object_host_twin"):
                 sec["one_pair_calls"] = opc
             for other in ("ggx_eval_pdf", "ggx_eval_pdf_contract", "ggx_unpolarized_eval_pdf", "ggx_unpolarized_eval_pdf_contract",
-                          "sgd_eval", "sgd_eval_contract", "beckmann_sample", "beckmann_sample_contract", "utia_eval", "merl_eval_uniform_bins",
-                          "merl_eval_coherent"):
+                          "sgd_eval", "sgd_eval_contract", "beckmann_sample", "beckmann_sample_contract", "utia_eval", "utia_eval_contract",
+                          "merl_eval_uniform_bins", "merl_eval_coherent"):
                 on, ob, ou, _ = WORKLOADS[other]
                 if other.startswith("merl_eval_"):
                     on //= 4          # 2.5e8 pairs (9 GB of streams, far beyond every cache): same rate as 1e9, a quarter of the set-up time
@@ -1119,6 +1142,8 @@ def main():
                                        "exact_path_share": acc["exact_path"] / acc["samples"], "error_bound_used": acc["bound_used"],
                                        "contract": "every component of the sampled unit vector within 1e-5 of the reference's; samples whose decisions "
                                                    "or conditioning are in doubt take the bit-exact path in the same launch; DJB_OPT_CONTRACT_1E5, off by default"})
+                elif other == "utia_eval_contract":
+                    sec[other].update(utia_contract_accuracy(st, kp, djb, ctx, torch))
                 elif other.endswith("_contract"):
                     # measured accuracy of the fast path against the bit-exact per-pair code, same set-up, 2^28 generated pairs
                     acc = djb.selftest_contract(kp[2], kp[3], n=1 << 28, seed=3, family=0, ctx=ctx)

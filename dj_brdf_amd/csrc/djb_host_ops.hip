@@ -308,7 +308,7 @@ djb_status eval_common(djb_ctx *ctx, const djb_brdf *b, int64_t n, const djb_vec
 			unsigned int *count = (unsigned int *)ctx->scratch, *list = count + 4;
 			auto off = [&](const View &v) { return View{ v.x + lo * v.stride, v.y + lo * v.stride, v.z + lo * v.stride, v.stride }; };
 			HIP_TRY(djbk::launch_utia_twotier(ctx->stream, b->dev, m, off(vi), off(vo), off(vout), dpdf ? dpdf + lo : nullptr, want,
-			                                  list, (unsigned int)cap, count));
+			                                  list, (unsigned int)cap, count, ctx->contract_1e5 != 0));
 		}
 		return sg.finish();
 	}

@@ -180,69 +180,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_bk_sharp(Brdf b, Params p, long 
 	if (qn) drain(0u, qn);
 }
 
-// utia::eval, two-tier.  The exact fall-back of the azimuths (glibc's atan2, djb_device.hpp atan2_to_f32) kept inside
-// k_eval<UTIA> as a rarely taken branch doubles the kernel's time (2.8 -> 5.3 ms per 1e8; inline or as a call: its
-// registers and constants land in the loop).  Tier 1 runs the same per-pair code without it (utia_eval_t<true>) and
-// appends the index of every pair with an azimuth that was not decided away from a float rounding boundary (8e-6 of
-// them) to a worklist; tier 2 re-evaluates those with utia_eval and overwrites the result.  If the list overflows,
-// tier 2 redoes the whole batch, so the result never depends on the capacity.
-//
-// Tried and dropped (round 4, profiles/r04/NOTES.md): a wave-cooperative record fetch -- eight neighbouring lanes load the
-// eight 16-byte chunks of one record, 8 lines per load instruction instead of 64, data to their owner lanes through LDS.
-// Bit-identical, but 4.0-4.2 ms per 1e8 against 2.83: the 16 bpermutes, 16 LDS writes and 12 LDS reads per pair-set cost
-// more than the line look-ups they save.
-template <int WANT, bool DENSE>
-__global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_eval_utia_t1(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
-                                                                        unsigned int *list, unsigned int cap, unsigned int *count)
-{
-	const long long stride = (long long)gridDim.x * BLOCK;
-	const unsigned int t = threadIdx.x;
-	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
-		const long long k = k0 + t;
-		if (k >= n) continue;
-		v3 i = DENSE ? load3_dense(vi, k0, t) : load3(vi, k), o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
-		bool ok;
-		v3 e = utia_eval_t<true>(b, i, o, ok);
-		v3 fr = (WANT & 2) ? scale(i.z, e) : e;                                        // brdf::evalp, dj_brdf.h:803-806
-		if (DENSE) store3_dense(vout, k0, t, fr); else store3(vout, k, fr);
-		if (WANT & 4) { float pdf = F(D(i.z) / DJB_PI); if (DENSE) (out_pdf + k0)[t] = pdf; else out_pdf[k] = pdf; }   // dj_brdf.h:842-845
-		if (__builtin_expect(!ok, 0)) {
-			const unsigned int slot = atomicAdd(count, 1u);
-			if (slot < cap) list[slot] = (unsigned int)k;
-		}
-	}
-}
-template <int WANT>
-__global__ __launch_bounds__(BLOCK) void k_eval_utia_fix(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
-                                                         const unsigned int *list, unsigned int cap, const unsigned int *count)
-{
-	const unsigned int c = *count;
-	const bool all = c > cap;                                    // overflow: redo the whole batch
-	const long long m = all ? n : (long long)c;
-	const Params none = {};
-	const long long stride = (long long)gridDim.x * BLOCK;
-	for (long long j = (long long)blockIdx.x * BLOCK + threadIdx.x; j < m; j += stride) {
-		const long long k = all ? j : (long long)list[j];
-		v3 i = load3(vi, k), o = load3(vo, k), fr = mk(0, 0, 0); float pdf = 0.0f;
-		eval_one<KIND_UTIA, WANT>(b, none, i, o, fr, pdf);
-		if (WANT & 3) store3(vout, k, fr);
-		if (WANT & 4) out_pdf[k] = pdf;
-	}
-}
-template <int WANT>
-hipError_t launch_utia_tt(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o, const View &out,
-                          float *out_pdf, unsigned int *list, unsigned int cap, unsigned int *count)
-{
-	hipError_t e = hipMemsetAsync(count, 0, 16, s);
-	if (e != hipSuccess) return e;
-	dim3 g(grid_for(n)), t(BLOCK);
-	if (dense(i) && dense(o) && dense(out)) hipLaunchKernelGGL((k_eval_utia_t1<WANT, true>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-	else hipLaunchKernelGGL((k_eval_utia_t1<WANT, false>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-	if ((e = hipGetLastError()) != hipSuccess) return e;
-	hipLaunchKernelGGL((k_eval_utia_fix<WANT>), dim3(64), t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-	return hipGetLastError();
-}
-
 // k_eval_bk_sharp's domain: no mean-normal offset (the (a) / (b) arguments use m_n = +z), a Fresnel term that cannot be negative or NaN,
 // and a lobe sharp enough for the trivial pairs to pay for the prefix (DJB_BK_SHARP_ALPHA: profiles/r04/beckmann_sharp.txt)
 #ifndef DJB_BK_SHARP_ALPHA
@@ -688,18 +625,6 @@ __global__ __launch_bounds__(BLOCK) void k_hist_xy(long long n, View v, int bins
 
 namespace djbk {
 
-hipError_t launch_utia_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o, const View &out,
-                               float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count)
-{
-	if (n <= 0) return hipSuccess;
-	switch (want) {
-	case 1: return launch_utia_tt<1>(s, b, n, i, o, out, out_pdf, list, cap, count);
-	case 2: return launch_utia_tt<2>(s, b, n, i, o, out, out_pdf, list, cap, count);
-	case 5: return launch_utia_tt<5>(s, b, n, i, o, out, out_pdf, list, cap, count);
-	case 6: return launch_utia_tt<6>(s, b, n, i, o, out, out_pdf, list, cap, count);
-	}
-	return hipErrorInvalidValue;
-}
 hipError_t launch_eval(hipStream_t s, const Brdf &b, const Params &p, long long n, const View &i,
                        const View &o, const View &out, float *out_pdf, int want)
 {

@@ -451,3 +451,71 @@ def test_contract_sample_attack(gpu_ctx, ndf):
         best, c = djb.contract_sample_attack(b, u1, u2, o, mk_params(p), iters=256, seed=9, ctx=gpu_ctx)
         assert c["outside"] == 0 and float(best.max()) < 1.0, (p, c, float(best.max()))
         assert c["accepted"] > 0 and c["evaluations"] >= m * 200
+
+
+# ---------------------------------------------------------------- utia::eval under the contract (round 6)
+def hostile_pairs(n, seed):
+    rng = np.random.default_rng(seed)
+    i = synth.directions_aos(n, 11).copy(); o = synth.directions_aos(n, 12).copy()
+    k = n // 8
+    o[:k, 2] *= -1                                            # below the horizon
+    i[k:2 * k, 2] *= 1e-4; i[k:2 * k] /= np.linalg.norm(i[k:2 * k], axis=1, keepdims=True)       # grazing
+    o[2 * k:3 * k] = i[2 * k:3 * k] * np.array([-1, -1, 1], np.float32)                             # mirror pairs
+    o[3 * k:4 * k] = i[3 * k:4 * k]                                                                  # identical
+    # un-normalised, shorter than 1: |z| > 1, a NaN or an infinite component gives a NaN angle, and the reference then indexes its table
+    # out of bounds -- no defined answer to hold anything against (tools/hostile_parity_sweep.py leaves those out for utia as well)
+    i[4 * k:5 * k] *= rng.uniform(0.1, 1.0, (k, 1)).astype(np.float32)
+    o[5 * k:5 * k + 8] = 0
+    o[5 * k + 24:5 * k + 32, 2] = 1e-20
+    i[6 * k:7 * k, :2] *= 1e-3; i[6 * k:7 * k] /= np.linalg.norm(i[6 * k:7 * k], axis=1, keepdims=True)   # near-normal
+    # azimuths on the cell boundaries of the 7.5-degree grid and polar angles on those of the 15-degree grid
+    m = k // 2
+    phi = np.deg2rad(7.5 * rng.integers(0, 48, m)); th = np.deg2rad(rng.uniform(1, 89, m))
+    o[7 * k:7 * k + m] = np.stack([np.sin(th) * np.cos(phi), np.sin(th) * np.sin(phi), np.cos(th)], 1)
+    th = np.deg2rad(15.0 * rng.integers(0, 7, m)); phi = rng.uniform(0, 2 * np.pi, m)
+    i[7 * k:7 * k + m] = np.stack([np.sin(th) * np.cos(phi), np.sin(th) * np.sin(phi), np.cos(th)], 1)
+    return i.astype(np.float32), o.astype(np.float32)
+
+
+def test_contract_utia_vs_oracle(ct_ctx, oracle, tmp_path):
+    """DJB_OPT_CONTRACT_1E5 on utia::eval: cells, weights and the 16-tap sums remain the reference's bits; the sRGB power runs on the
+    fast transcendentals.  Against the oracle: zeros / NaNs where it has them, everything else within 1e-5 relative -- on the bench
+    pairs and on hostile ones, a rough and a smooth table (the latter with negative samples: clamped at load)."""
+    n = N + 3
+    for name, tab in (("uniform", np.random.default_rng(11).uniform(-5.0, 120.0, size=3 * 288 * 288)), ("smooth", synth.utia_table_smooth())):
+        p = str(tmp_path / f"{name}.bin"); np.asarray(tab, np.float64).tofile(p)
+        u, ou = djb.utia(p, ctx=ct_ctx), oracle.utia(p)
+        for fam, (i, o) in (("bench", (synth.directions_aos(n, synth.SEED_I), synth.directions_aos(n, synth.SEED_O))), ("hostile", hostile_pairs(n, 5))):
+            with np.errstate(all="ignore"):
+                for op in ("eval", "evalp"):
+                    got = getattr(u, op)(soa(i), soa(o)).cpu().numpy().T
+                    mx = check_contract(f"utia {name} {fam} {op}", got, oracle.eval(ou, i, o, None, op))
+                    print(f"utia contract {name:8s} {fam:8s} {op:6s} max rel err {mx:.3e}")
+                fr, pdf = u.eval_pdf(soa(i), soa(o))
+                check_contract(f"utia {name} {fam} eval+pdf", fr.cpu().numpy().T, oracle.eval(ou, i, o, None, "eval"))
+                assert np.array_equal(pdf.cpu().numpy().view(np.uint32), oracle.eval(ou, i, o, None, "pdf").view(np.uint32))
+
+
+def test_contract_utia_full_size_against_the_exact_kernels(gpu_ctx):
+    """5e7 bench pairs: the contract launch against the bit-exact launch -- same zeros, max relative difference inside the contract;
+    strided (array-of-vec3) views as well."""
+    import torch
+    n = 50_000_000
+    i = djb.gen_directions(n, synth.SEED_I, ctx=gpu_ctx); o = djb.gen_directions(n, synth.SEED_O, ctx=gpu_ctx)
+    u = djb.utia.from_table(np.random.default_rng(11).uniform(0.0, 120.0, size=3 * 288 * 288), ctx=gpu_ctx)
+    exact = u.eval(i, o)
+    try:
+        djb.set_contract_1e5(gpu_ctx, True)
+        fast = u.eval(i, o)
+        m = 1_000_001
+        ia = i[:, :m].t().contiguous(); oa = o[:, :m].t().contiguous()
+        fast_aos = u.eval(ia, oa)
+    finally:
+        djb.set_contract_1e5(gpu_ctx, False)
+    assert torch.equal(exact == 0, fast == 0)
+    rel = ((fast - exact).abs() / exact.abs().clamp_min(1e-30)).masked_fill(exact == 0, 0.0)
+    mx = float(rel.max())
+    print(f"utia contract vs exact, {n} pairs: max rel {mx:.3e}, identical bits {float((fast.view(torch.int32) == exact.view(torch.int32)).float().mean()):.4f}")
+    assert mx <= RTOL
+    assert float(exact.abs().sum()) > 0
+    assert torch.equal(fast_aos.t().contiguous().view(torch.int32), fast[:, :m].contiguous().view(torch.int32))

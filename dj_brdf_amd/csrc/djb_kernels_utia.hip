@@ -16,119 +16,75 @@ constexpr int BLOCK = 256;
 inline int grid_for(long long n)
 {
 	long long blocks = (n + BLOCK - 1) / BLOCK;
-	const long long cap = 256LL * 16;   // 256 CUs x 16 resident workgroups' worth, grid-stride beyond
+	const long long cap = 256LL * 64;   // 4 workgroups per CU resident, 16 rounds of them (2.58 ms per 1e8 pairs; 4096: 2.66, 1024: 2.94, one per tile: 2.75)
 	if (blocks > cap) blocks = cap;
 	if (blocks < 1) blocks = 1;
 	return (int)blocks;
 }
 inline bool dense(const View &v) { return v.stride == 1 || v.x == nullptr; }
 
-// utia::eval, two-tier.  The exact fall-back of the azimuths (glibc's atan2, djb_device.hpp atan2_to_f32) kept inside
-// k_eval<UTIA> as a rarely taken branch doubles the kernel's time (2.8 -> 5.3 ms per 1e8; inline or as a call: its
-// registers and constants land in the loop).  Tier 1 runs the same per-pair code without it (utia_eval_t<true>) and
-// appends the index of every pair with an azimuth that was not decided away from a float rounding boundary (8e-6 of
-// them) to a worklist; tier 2 re-evaluates those with utia_eval and overwrites the result.  If the list overflows,
-// tier 2 redoes the whole batch, so the result never depends on the capacity.
+// utia::eval, two-tier.  Tier 1 (k_utia_v2) decides every pair it can with cheap arithmetic and lists the rest (the index of every pair
+// with an angle next to a float rounding boundary, a cell estimate next to a cell boundary, a guarded shortcut that wants its exact
+// form: ~2e-4 of the pairs) on a worklist; tier 2 (k_eval_utia_fix) re-evaluates those with utia_eval -- the reference as written, with
+// glibc's atan2 behind the azimuths -- and overwrites the result.  If the list overflows, tier 2 redoes the whole batch, so the result
+// never depends on the capacity.  (Kept inside one kernel as a rarely taken branch the exact code doubles the kernel's time.)
 //
-// Tried and dropped (round 4, profiles/r04/NOTES.md): a wave-cooperative record fetch -- eight neighbouring lanes load the
-// eight 16-byte chunks of one record, 8 lines per load instruction instead of 64, data to their owner lanes through LDS.
-// Bit-identical, but 4.0-4.2 ms per 1e8 against 2.83: the 16 bpermutes, 16 LDS writes and 12 LDS reads per pair-set cost
-// more than the line look-ups they save.
-template <int WANT, bool DENSE>
-__global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_eval_utia_t1(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
-                                                                        unsigned int *list, unsigned int cap, unsigned int *count)
-{
-	const long long stride = (long long)gridDim.x * BLOCK;
-	const unsigned int t = threadIdx.x;
-	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
-		const long long k = k0 + t;
-		if (k >= n) continue;
-		v3 i = DENSE ? load3_dense(vi, k0, t) : load3(vi, k), o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
-		bool ok;
-		v3 e = utia_eval_t<true>(b, i, o, ok);
-		v3 fr = (WANT & 2) ? scale(i.z, e) : e;                                        // brdf::evalp, dj_brdf.h:803-806
-		if (DENSE) store3_dense(vout, k0, t, fr); else store3(vout, k, fr);
-		if (WANT & 4) { float pdf = F(D(i.z) / DJB_PI); if (DENSE) (out_pdf + k0)[t] = pdf; else out_pdf[k] = pdf; }   // dj_brdf.h:842-845
-		if (__builtin_expect(!ok, 0)) {
-			const unsigned int slot = atomicAdd(count, 1u);
-			if (slot < cap) list[slot] = (unsigned int)k;
-		}
-	}
-}
-// Tier 1, round 6 (k_utia_v2): the record fetch starts from ESTIMATED cells and the reference's angles are computed under it
+// Tier 1, round 6: the record fetch starts from ESTIMATED cells and the reference's angles are computed under it
 // (djb_device_tables.inc: utia_cells_estimate / utia_weights / utia_decode_*).  CT = DJB_OPT_CONTRACT_1E5 (fast sRGB power only:
-// the 16-tap sums stay the reference's bits).  COOP: the two 96-byte payloads of a pair's records are fetched wave-cooperatively,
+// the 16-tap sums stay the reference's bits).  The two 96-byte payloads of a pair's records are fetched wave-cooperatively,
 // straight into LDS (global_load_lds_dwordx4): 384 chunks of 16 bytes per record set = 6 wave-instructions, chunk g = 64 s + lane
-// belongs to lane g / 6 and lands at float4 slot g of the tile, so a wave-instruction touches ~11 table lines instead of 64 and the
-// owner reads its six chunks back from slots 6 L .. 6 L + 5.  TILES = 2: both record sets in flight at once (12 KB of LDS per wave).
-#ifndef DJB_UTIA_V2_WAVES
-#define DJB_UTIA_V2_WAVES 4
-#endif
-#ifndef DJB_UTIA_FORM_DEFAULT
-#define DJB_UTIA_FORM_DEFAULT 2
-#endif
-template <int WANT, bool CT, int COOP, bool DENSE>
-__global__ __launch_bounds__(BLOCK, DJB_UTIA_V2_WAVES) void k_utia_v2(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
-                                                                     unsigned int *list, unsigned int cap, unsigned int *count)
+// belongs to lane g / 6 and lands at float4 slot g of the wave's 6 KB tile, so a wave-instruction touches ~11 table lines instead of
+// 64 and the owner reads its six chunks back from slots 6 L .. 6 L + 5.  Measured forms (profiles/r06/utia_v2_forms.txt, ms per 1e8
+// pairs, exact / contract): angles first + lane-private fetch (rounds 2-5) 2.88 / -; this kernel 2.72 / 2.54 before the angles
+// were rebuilt; lane-private fetch from estimated cells 3.63 / 3.36; two tiles in flight 2.84 / 2.60 (LDS limits it to 3 waves).
+template <int WANT, bool CT, bool DENSE>
+__global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_utia_v2(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
+                                                                      unsigned int *list, unsigned int cap, unsigned int *count)
 {
-	constexpr int TILES = COOP ? COOP : 1;
-	__shared__ float4 s_tile[COOP ? BLOCK / 64 : 1][COOP ? TILES * 384 : 1];
+	__shared__ float4 s_tile[BLOCK / 64][384];
+	__shared__ double s_atan[16];
+	if (threadIdx.x < 9) s_atan[threadIdx.x] = DJB_ATAN_EIGHTHS[threadIdx.x];
+	__syncthreads();
+	const lds_f64p T = (lds_f64p)s_atan;
 	const long long stride = (long long)gridDim.x * BLOCK;
 	const unsigned int t = threadIdx.x, wave = t >> 6, lane = t & 63u;
 	typedef __attribute__((address_space(3))) void lds_void;
 	typedef __attribute__((address_space(1))) const void glb_void;
-	float4 *tile = s_tile[COOP ? wave : 0];
-#if DJB_UTIA_V2_NOLOOP
-	(void)stride;
-	{ const long long k0 = (long long)blockIdx.x * BLOCK;
-#else
+	float4 *tile = s_tile[wave];
 	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
-#endif
 		const long long k = k0 + t;
 		const bool live = k < n;
-		if (!COOP && !live) return;
 		v3 i = mk(0, 0, 1), o = mk(0, 0, 1);
 		if (live) { i = DENSE ? load3_dense(vi, k0, t) : load3(vi, k); o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k); }
 		const UtiaCells c = utia_cells_estimate(i, o);
 		int e[2];
 		utia_record_index(c, e);
-		float4 q0[6], q1[6];
-		auto fetch = [&](int a, float4 *dst) {
+		float4 q[6];
+		auto fetch = [&](int a) {
 #pragma unroll
 			for (unsigned int s = 0; s < 6u; ++s) {
 				const unsigned int g = s * 64u + lane, r = (g * 10923u) >> 16, chunk = g - 6u * r;     // r = g / 6 for g < 384
-				const int e_src = __shfl(e[a], (int)r);
-				const float4 *src = b.utia + 8 * (size_t)e_src + chunk;
-				__builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + s * 64u), 16, 0, 0);
+				const unsigned int e_src = (unsigned int)__shfl(e[a], (int)r);
+				// uniform base + 32-bit byte offset (the table is 10.6 MB): the saddr form of the load, no 64-bit address arithmetic per lane
+				const char *src = (const char *)b.utia + (size_t)((8u * e_src + chunk) << 4);
+				__builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(tile + s * 64u), 16, 0, 0);
 			}
 		};
-		auto take = [&](const float4 *src, float4 (&q)[6]) {
+		auto take = [&]() {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's six LDS-direct loads have landed
 #pragma unroll
-			for (unsigned int j = 0; j < 6u; ++j) q[j] = src[lane * 6u + j];
+			for (unsigned int j = 0; j < 6u; ++j) q[j] = tile[lane * 6u + j];
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // read before the tile is overwritten
 		};
-		if (COOP) {
-			fetch(0, tile);
-			if (TILES == 2) fetch(1, tile + 384);
-		} else {
-			const float4 *r0 = b.utia + 8 * (size_t)e[0], *r1 = b.utia + 8 * (size_t)e[1];
-#pragma unroll
-			for (int j = 0; j < 6; ++j) { q0[j] = r0[j]; q1[j] = r1[j]; }
-		}
+		fetch(0);
 		UtiaTaps u;
-		bool ok = utia_weights(i, o, c, u);                                         // under the fetch
+		bool ok = utia_weights(i, o, c, u, T);                                      // under the fetch
 		float acc[3] = { 0.0f, 0.0f, 0.0f };
-		if (COOP) {
-			if (TILES == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			take(tile, q0);
-			if (TILES == 1) fetch(1, tile);
-		}
-		utia_accumulate(u, 0, q0, acc);
-		if (COOP) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			take(TILES == 2 ? tile + 384 : tile, q1);
-		}
-		utia_accumulate(u, 1, q1, acc);
+		take();
+		fetch(1);                                                                   // in flight while record 0 is accumulated
+		utia_accumulate(u, 0, q, acc);
+		take();
+		utia_accumulate(u, 1, q, acc);
 		const v3 ev = CT ? utia_decode_ct(u, acc, ok) : utia_decode_t1(u, acc, ok);
 		if (live) {
 			v3 fr = (WANT & 2) ? scale(i.z, ev) : ev;                                   // brdf::evalp, dj_brdf.h:803-806
@@ -140,6 +96,49 @@ __global__ __launch_bounds__(BLOCK, DJB_UTIA_V2_WAVES) void k_utia_v2(Brdf b, lo
 			}
 		}
 	}
+}
+// djb_selftest_utia_angles: tier 1's angles against the exact ones.  mode 0: every float z = bits(first + k), k < n, through
+// utia_acos_deg_t1 against acos_deg_f (identical to the host's by exhaustion); mode 1: hash-generated float pairs (y, x) -- unit-circle
+// points, axis-hugging, tiny / huge magnitudes, signs -- through utia_atan2_deg_t1 against atan2_to_f32 (glibc's atan2 behind a guard).
+// counters = {decided, decided but a different float (must be 0), undecided, largest |tier-1 double - device-libm double| in units of 2^-52 of the value over the
+// decided ones: the distance to the reference's double up to the 2 ulp64 between the two libms; the guard is 4096 such units}
+__global__ __launch_bounds__(BLOCK) void k_utia_angles_selftest(long long n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters)
+{
+	__shared__ double s_atan[16];
+	if (threadIdx.x < 9) s_atan[threadIdx.x] = DJB_ATAN_EIGHTHS[threadIdx.x];
+	__syncthreads();
+	const lds_f64p T = (lds_f64p)s_atan;
+	unsigned long long n_ok = 0, n_bad = 0, n_und = 0, worst = 0;
+	const long long stride = (long long)gridDim.x * BLOCK;
+	const double r2d = D(F(180.0 / DJB_PI));
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		bool ok; float got, want; double dl, dd;
+		if (mode == 0) {
+			const float z = __uint_as_float(first + (uint32_t)k);
+			got = utia_acos_deg_t1(z, T, ok, &dd); want = acos_deg_f(z); dl = r2d * acos(D(z));
+		} else {
+			const uint32_t h0 = hash_u32(seed, (uint64_t)k, 1u), h1 = hash_u32(seed, (uint64_t)k, 2u), h2 = hash_u32(seed, (uint64_t)k, 3u);
+			float y, x;
+			const unsigned int fam = h2 & 7u;
+			if (fam < 3u) {                                   // a point of the unit circle scaled by sin(theta): what a direction's (y, x) is
+				const float ph = 6.2831853f * (float)(h0 >> 8) * 0x1p-24f, sc = sqrtf((float)(h1 >> 8) * 0x1p-24f);
+				y = sc * sinf(ph); x = sc * cosf(ph);
+			} else if (fam == 3u) { y = __uint_as_float(h0); x = __uint_as_float(h1); }                                   // any two floats
+			else if (fam == 4u) { y = __uint_as_float((h0 & 0x807fffffu) | 0x3f000000u); x = y * (1.0f + (float)(int)(h1 & 15u) * 0x1p-23f) * ((h2 & 8u) ? -1.0f : 1.0f); }   // |y| ~ |x|
+			else if (fam == 5u) { y = (float)(int)(h0 & 0xffu) * 0x1p-20f * ((h2 & 8u) ? -1.0f : 1.0f); x = __uint_as_float((h1 & 0x807fffffu) | 0x3f000000u); }   // near the x axis
+			else if (fam == 6u) { x = (float)(int)(h0 & 0xffu) * 0x1p-20f * ((h2 & 8u) ? -1.0f : 1.0f); y = __uint_as_float((h1 & 0x807fffffu) | 0x3f000000u); }   // near the y axis
+			else { const float t7 = tanf(0.13089969f * (float)(h0 % 49u)); y = t7 * __uint_as_float((h1 & 0x007fffffu) | 0x3f000000u); x = __uint_as_float((h1 & 0x007fffffu) | 0x3f000000u); if (h2 & 8u) x = -x; if (h2 & 16u) y = -y; }   // on the 7.5-degree grid lines
+			got = utia_atan2_deg_t1(y, x, T, ok, &dd); want = atan2_to_f32(y, x, r2d); dl = r2d * atan2(D(y), D(x));
+		}
+		if (!ok) { ++n_und; continue; }
+		++n_ok;
+		if (__float_as_uint(got) != __float_as_uint(want)) ++n_bad;
+		// distance of the tier-1 double from the device libm's (itself within 2 ulp64 of the host libm's), in ulp64 of the value
+		const double adl = fabs(dl);
+		const unsigned long long q = (unsigned long long)(fabs(dd - dl) / (adl * 0x1p-52 + 1e-300));
+		worst = q > worst ? q : worst;
+	}
+	atomicAdd(&counters[0], n_ok); atomicAdd(&counters[1], n_bad); atomicAdd(&counters[2], n_und); atomicMax(&counters[3], worst);
 }
 template <int WANT>
 __global__ __launch_bounds__(BLOCK) void k_eval_utia_fix(Brdf b, long long n, View vi, View vo, View vout, float *out_pdf,
@@ -158,13 +157,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_utia_fix(Brdf b, long long n, Vi
 		if (WANT & 4) out_pdf[k] = pdf;
 	}
 }
-template <int WANT, bool CT, int COOP>
-void launch_utia_v2(hipStream_t s, dim3 g, dim3 t, bool dn, const Brdf &b, long long n, const View &i, const View &o, const View &out,
-                    float *out_pdf, unsigned int *list, unsigned int cap, unsigned int *count)
-{
-	if (dn) hipLaunchKernelGGL((k_utia_v2<WANT, CT, COOP, true>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-	else hipLaunchKernelGGL((k_utia_v2<WANT, CT, COOP, false>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-}
 template <int WANT>
 hipError_t launch_utia_tt(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o, const View &out,
                           float *out_pdf, unsigned int *list, unsigned int cap, unsigned int *count, bool contract)
@@ -173,20 +165,12 @@ hipError_t launch_utia_tt(hipStream_t s, const Brdf &b, long long n, const View 
 	if (e != hipSuccess) return e;
 	dim3 g(grid_for(n)), t(BLOCK);
 	const bool dn = dense(i) && dense(o) && dense(out);
-	// tier-1 form (A/B switch of round 6, profiles/r06/utia_v2.txt): 0 = k_eval_utia_t1 (angles first), 1 = k_utia_v2 lane-private fetch,
-	// 2 / 3 = k_utia_v2 with the wave-cooperative fetch through one / two LDS tiles
-	static const int form = getenv("DJB_UTIA_FORM") ? atoi(getenv("DJB_UTIA_FORM")) : DJB_UTIA_FORM_DEFAULT;
-	if (form == 0 && !contract) {
-		if (dn) hipLaunchKernelGGL((k_eval_utia_t1<WANT, true>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-		else hipLaunchKernelGGL((k_eval_utia_t1<WANT, false>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
-	} else if (contract) {
-		if (form == 2) launch_utia_v2<WANT, true, 1>(s, g, t, dn, b, n, i, o, out, out_pdf, list, cap, count);
-		else if (form == 3) launch_utia_v2<WANT, true, 2>(s, g, t, dn, b, n, i, o, out, out_pdf, list, cap, count);
-		else launch_utia_v2<WANT, true, 0>(s, g, t, dn, b, n, i, o, out, out_pdf, list, cap, count);
+	if (contract) {
+		if (dn) hipLaunchKernelGGL((k_utia_v2<WANT, true, true>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
+		else hipLaunchKernelGGL((k_utia_v2<WANT, true, false>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
 	} else {
-		if (form == 2) launch_utia_v2<WANT, false, 1>(s, g, t, dn, b, n, i, o, out, out_pdf, list, cap, count);
-		else if (form == 3) launch_utia_v2<WANT, false, 2>(s, g, t, dn, b, n, i, o, out, out_pdf, list, cap, count);
-		else launch_utia_v2<WANT, false, 0>(s, g, t, dn, b, n, i, o, out, out_pdf, list, cap, count);
+		if (dn) hipLaunchKernelGGL((k_utia_v2<WANT, false, true>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
+		else hipLaunchKernelGGL((k_utia_v2<WANT, false, false>), g, t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
 	}
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL((k_eval_utia_fix<WANT>), dim3(64), t, 0, s, b, n, i, o, out, out_pdf, list, cap, count);
@@ -208,6 +192,13 @@ hipError_t launch_utia_twotier(hipStream_t s, const Brdf &b, long long n, const 
 	case 6: return launch_utia_tt<6>(s, b, n, i, o, out, out_pdf, list, cap, count, contract);
 	}
 	return hipErrorInvalidValue;
+}
+
+hipError_t launch_utia_angles_selftest(hipStream_t s, long long n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_utia_angles_selftest, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, mode, first, seed, counters4);
+	return hipGetLastError();
 }
 
 } // namespace djbk

@@ -1322,6 +1322,16 @@ def host_libm_status():
     return int(lib.djb_ctx_libm_matches_host(None)), int(lib.djb_host_libm_mode()), int(lib.djb_host_atan_log_kat())
 
 
+def selftest_utia_angles(n: int, mode: int, first: int = 0, seed: int = 1, ctx: Optional[Context] = None):
+    """Tier 1 of the utia::eval kernel takes its angles from one fp64 arctangent core and keeps only decided values
+    (djb_selftest_utia_angles): mode 0 = the n floats after bit pattern `first` as cosines, mode 1 = n generated (y, x) pairs.
+    Returns {decided, mismatch (must be 0), undecided, worst_ulp64 (distance of a decided tier-1 double from the device libm's)}."""
+    ctx = ctx or default_context()
+    c = (C.c_ulonglong * 4)()
+    _lib.check(_lib.load().djb_selftest_utia_angles(ctx._h, C.c_int64(n), C.c_int(mode), C.c_uint32(first), C.c_uint32(seed), c))
+    return {"decided": c[0], "mismatch": c[1], "undecided": c[2], "worst_ulp64": int(c[3])}
+
+
 def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):
     """Self-test of the kernels' guarded fp64 shortcuts against the exact double sequences on n
     hash-generated inputs (see djb_selftest_guarded_math).  Mismatch counters must be 0."""

@@ -430,3 +430,21 @@ def test_merl_two_tier_every_output_set_and_launch_shape(gpu_ctx):
             pdf = (iz / np.pi).astype(np.float32)
             assert np.array_equal(got["eval_pdf"][1].cpu().numpy().view(np.uint32), pdf.view(np.uint32)), (n, layout, "pdf")
             assert torch.equal(bits(got["eval_pdf"][0]), bits(got["eval"])) and torch.equal(bits(got["evalp_pdf"][0]), bits(got["evalp"]))
+
+
+def test_utia_tier1_angles_against_the_exact_forms(gpu_ctx):
+    """k_utia_v2 takes its angles from one branch-free fp64 arctangent core and keeps a value only where it is decided (further from a
+    float rounding boundary than the core's error).  Every float z in (0, 1] as a polar cosine against acos_deg_f (identical to the
+    host's by exhaustion), 2^33 generated (y, x) pairs against atan2_to_f32 (glibc's atan2 behind a guard): no decided value differs."""
+    first = int(np.float32(1e-17).view(np.uint32))
+    n = 0x3F800000 - first + 1                                                      # every float in [1e-17, 1]
+    r = djb.selftest_utia_angles(n, 0, first=first, ctx=gpu_ctx)
+    print("acos:", r)
+    assert r["mismatch"] == 0 and r["decided"] > 0.9999 * n and r["worst_ulp64"] < 256          # the guard is 4096
+    tot = {"decided": 0, "mismatch": 0, "undecided": 0, "worst_ulp64": 0}
+    for seed in range(1, 5):
+        r = djb.selftest_utia_angles(1 << 31, 1, seed=seed, ctx=gpu_ctx)
+        for k in ("decided", "mismatch", "undecided"): tot[k] += r[k]
+        tot["worst_ulp64"] = max(tot["worst_ulp64"], r["worst_ulp64"])
+    print("atan2:", tot)
+    assert tot["mismatch"] == 0 and tot["decided"] > 0.8 * (1 << 33) and tot["worst_ulp64"] < 256

@@ -58,7 +58,7 @@ EXPORTS = [
     "djb_brdf_create_beckmann", "djb_brdf_create_ggx", "djb_brdf_create_merl_from_file",
     "djb_brdf_create_merl_from_memory", "djb_brdf_create_utia_from_file",
     "djb_brdf_create_utia_from_memory", "djb_brdf_create_lambert", "djb_brdf_create_tabular",
-    "djb_fit_merl_files", "djb_fit_merl_files_multi", "djb_merl_bin_keys_batch", "djb_selftest_guarded_math", "djb_selftest_utia_angles", "djb_selftest_contract", "djb_selftest_contract_sample", "djb_contract_sample_attack", "djb_ctx_libm_matches_host", "djb_host_libm_mode", "djb_host_atan_log_kat", "djb_selftest_libm", "djb_selftest_trig_sweep", "djb_brdf_create_tabular_anisotropic", "djb_tabular_anisotropic_get", "djb_tabular_anisotropic_fit",
+    "djb_fit_merl_files", "djb_fit_merl_files_multi", "djb_merl_bin_keys_batch", "djb_selftest_guarded_math", "djb_selftest_fast_trig", "djb_selftest_contract", "djb_selftest_contract_sample", "djb_contract_sample_attack", "djb_ctx_libm_matches_host", "djb_host_libm_mode", "djb_host_atan_log_kat", "djb_selftest_libm", "djb_selftest_trig_sweep", "djb_brdf_create_tabular_anisotropic", "djb_tabular_anisotropic_get", "djb_tabular_anisotropic_fit",
     "djb_eval_pp_batch", "djb_eval_lean_batch", "djb_sample_pp_batch", "djb_sample_lean_batch", "djb_lrep_op", "djb_params_to_lrep", "djb_lrep_to_params",
     "djb_brdf_create_sgd", "djb_brdf_create_abc", "djb_brdf_create_sgd_from_params",
     "djb_brdf_create_abc_from_params",

@@ -96,6 +96,7 @@ struct Brdf {
 	// where glibc_exp() / glibc_pow() / glibc_acos() read their tables (LdsTab: 0 = the global copy, else 1 + the LDS byte offset
 	// of a copy staged by the kernel, which sets these on its own copy of the struct; the host leaves them 0)
 	unsigned int exp_lds, pow_lds, acos_lds;
+	unsigned int atan_lds;                  // the arctangent core's table (atan_tab_to_lds), 0 = not staged: the trig sites keep their previous forms
 	// KIND_USER (host path only): the callbacks of a user-defined NDF (UserNdf below); never set on an object a kernel sees
 	const void *user_ndf;
 };
@@ -499,6 +500,145 @@ DJB_DEV void polar_to_f32(float r, float phi, float &x, float &y)
 	if (__builtin_expect(!fast, 0)) { x = F(D(r) * glibc_cos(ph)); y = F(D(r) * glibc_sin(ph)); return; }
 	x = F(px); y = F(py);
 }
+#endif
+
+// ---- one branch-free fp64 arctangent for every float -> float trig site of the table-driven kinds (round 6).  The device libm's fp64
+// acos / atan / atan2 were 436 of the utia kernel's ~850 VALU instructions per pair and a third of the tabulated lobes' (both arms of
+// acos under divergent exec masks; an IEEE division inside atan2; Horner steps as v_fmac_f64, whose tied accumulator makes the compiler
+// move every coefficient into a VGPR pair first: 3 issue slots per step).  A site only needs a double within a guard of the libm's --
+// anything further from a float rounding boundary than the core's own error rounds to the same float, the rest takes the site's
+// previous form (djb_device.hpp above: the forms the exhaustive sweeps were run on) -- so all of them share
+//     atan(mn / mx), 0 <= mn <= mx:  centre c = j / 8 from an fp32 estimate of the quotient (j = 0..8), then
+//     atan(mn / mx) = atan(c) + atan(r),  r = (mn - c mx) / (mx + c mn),  |r| <= 1/16 (+ the estimate's error)
+// with atan(c) from a 9-entry table in LDS, ONE division (v_rcp_f32 seed, two Newton steps) and r (1 - s/3 + s^2/5 - s^3/7 + s^4/9 -
+// s^5/11), s = r^2 (truncation 2^-51); the coefficients ride in SGPRs (fma_sk).  acos(z) = atan2(sqrt(1 - z^2), z).  Error of the
+// double: a few 2^-52 relative (division 2^-51, polynomial 2^-50, sqrt 2^-50, ~20 roundings) against a guard of 4096 ulp64 = 2^-40.
+// Measured by djb_selftest_fast_trig: the one-argument sites against their previous forms over ALL 2^32 floats -- identical, decided
+// or not -- and 2^33 (y, x) pairs for atan2; largest distance of a decided double from the device libm's: 3 ulp64
+// (profiles/r06/fast_trig_selftest.txt; tests/test_gpu_verification.py).
+#if !defined(DJB_HOST_MATH)
+constexpr double DJB_ATAN_EIGHTHS[9] = { 0.0, 0x1.fd5ba9aac2f6ep-4, 0x1.f5b75f92c80ddp-3, 0x1.6f61941e4def1p-2, 0x1.dac670561bb4fp-2,
+                                         0x1.1e00babdefeb4p-1, 0x1.4978fa3269ee1p-1, 0x1.700a7c5784634p-1, 0x1.921fb54442d18p-1 };
+constexpr int ATAN_GUARD = 4096;
+// the table staged in LDS by a kernel: 16 doubles reserved, caller: __syncthreads() afterwards.  Brdf::atan_lds carries the handle (LdsTab)
+DJB_DEV LdsTab atan_tab_to_lds(double *lds, int tid)
+{
+	if (tid < 9) lds[tid] = DJB_ATAN_EIGHTHS[tid];
+	return 1u + (unsigned int)(uintptr_t)(lds_f64p)lds;
+}
+DJB_DEV lds_f64p atan_tab(LdsTab AT) { return (lds_f64p)(uintptr_t)(AT - 1u); }
+DJB_DEV double fma_sk(double a, double b, double k)          // fma(a, b, k), k a literal: held in an SGPR pair, no VGPR moves
+{
+	double r;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+	return r;
+}
+DJB_DEV double atan_core(double mn, double mx, lds_f64p T)
+{
+	const float jf = __builtin_rintf(8.0f * (F(mn) * __builtin_amdgcn_rcpf(F(mx))));
+	const int j = (int)fminf(fmaxf(jf, 0.0f), 8.0f);
+	const double c = 0.125 * D((float)j);
+	const double num = __builtin_fma(-c, mx, mn), den = __builtin_fma(c, mn, mx);
+	double rc = D(__builtin_amdgcn_rcpf(F(den)));
+	double e = __builtin_fma(-den, rc, 1.0);
+	rc = __builtin_fma(rc, e, rc);
+	e = __builtin_fma(-den, rc, 1.0);
+	rc = __builtin_fma(rc, e, rc);
+	const double r = num * rc, s = r * r;
+	double p = s * (-1.0 / 11.0) + (1.0 / 9.0);
+	p = fma_sk(p, s, -1.0 / 7.0);
+	p = fma_sk(p, s, 1.0 / 5.0);
+	p = fma_sk(p, s, -1.0 / 3.0);
+	return T[j] + __builtin_fma(r * s, p, r);
+}
+// acos(x) for -1 <= x <= 1 and atan(r) for 0 <= r < 1e18, as doubles; ok = false outside (and where 1 - x^2 is too small for the core)
+DJB_DEV double acos_fast(float x, lds_f64p T, bool &ok)
+{
+	const double zd = D(fabsf(x));
+	const double w = __builtin_fma(-zd, zd, 1.0);            // 1 - x^2: one rounding (exact where it is small)
+	const double sn = sqrt_fast(w);
+	const bool swap = sn > zd;
+	double a = atan_core(swap ? zd : sn, swap ? sn : zd, T);
+	a = swap ? 0x1.921fb54442d18p+0 - a : a;
+	ok = w > 1e-18;                                          // false for |x| > 1 and NaN as well
+	return x < 0.0f ? 0x1.921fb54442d18p+1 - a : a;
+}
+DJB_DEV double atan_fast(double r, lds_f64p T, bool &ok)
+{
+	const bool swap = r > 1.0;
+	double a = atan_core(swap ? 1.0 : r, swap ? r : 1.0, T);
+	ok = (r >= 0.0) & (r < 1e18);
+	return swap ? 0x1.921fb54442d18p+0 - a : a;
+}
+DJB_DEV bool fast_decided(double d) { const double ad = d < 0.0 ? -d : d; return !near_f32_midpoint(d, ATAN_GUARD) & (ad > 1e-30) & (ad < 1e30); }
+// the one-argument sites: the site's float from the core (ok = decided), its previous form, and the two together
+// (AT = Brdf::atan_lds; 0: the kernel staged no table -- the previous form)
+enum { FT_ACOS = 0, FT_ACOS_U, FT_ACOS_U32, FT_ATAN_U, FT_ATAN_SQU, FT_ATAN_SQRT, FT_SITES };
+template <int S> DJB_DEV float trig_fast(float x, lds_f64p T, bool &ok)
+{
+	bool in;
+	double d;
+	if (S == FT_ACOS) d = acos_fast(x, T, in);                                                           // float(acos(double x))
+	else if (S == FT_ACOS_U) d = (2.0 * acos_fast(x, T, in)) * 0x1.45f306dc9c883p-2;                       // float(2 acos(x) / pi)
+	else if (S == FT_ACOS_U32) d = (2.0 * acos_fast(x, T, in)) * 0x1.45f306446f9b4p-2;                     // float(2 acos(x) / double(float(pi)))
+	else if (S == FT_ATAN_U) d = (atan_fast(D(x), T, in) * 2.0) * 0x1.45f306446f9b4p-2;                    // float(atan(x) 2 / double(float(pi)))
+	else if (S == FT_ATAN_SQU) {                                                                          // float(sqrt(2 atan(x) / double(float(pi))))
+		const double v = (2.0 * atan_fast(D(x), T, in)) * 0x1.45f306446f9b4p-2;
+		d = sqrt_fast(v);
+		in &= v > 1e-30;
+	} else {                                                                                              // float(atan(sqrt(double x)))
+		const double xd = D(x);
+		d = atan_fast(sqrt_fast(xd), T, in);
+		in &= (xd > 1e-30) & (xd < 1e30);
+	}
+	ok = in & fast_decided(d);
+	return F(d);
+}
+template <int S> DJB_DEV float trig_prev(float x)
+{
+	return S == FT_ACOS ? acos_f(x) : S == FT_ACOS_U ? acos_u_f(x) : S == FT_ACOS_U32 ? acos_u32_f(x) : S == FT_ATAN_U ? atan_u_f(x)
+	     : S == FT_ATAN_SQU ? atan_squ_f(x) : atan_sqrt_f(x);
+}
+template <int S> DJB_DEV float trig_at(float x, LdsTab AT)
+{
+	if (AT) { bool ok; const float r = trig_fast<S>(x, atan_tab(AT), ok); if (__builtin_expect(ok, 1)) return r; }
+	return trig_prev<S>(x);
+}
+DJB_DEV float acos_f(float x, LdsTab AT) { return trig_at<FT_ACOS>(x, AT); }                 // dj_brdf.h:650-661 (aniso sigma)
+DJB_DEV float acos_u_f(float c, LdsTab AT) { return trig_at<FT_ACOS_U>(c, AT); }            // dj_brdf.h:1341
+DJB_DEV float acos_u32_f(float c, LdsTab AT) { return trig_at<FT_ACOS_U32>(c, AT); }        // dj_brdf.h:2158
+DJB_DEV float atan_u_f(float r, LdsTab AT) { return trig_at<FT_ATAN_U>(r, AT); }            // dj_brdf.h:2165
+DJB_DEV float atan_squ_f(float r, LdsTab AT) { return trig_at<FT_ATAN_SQU>(r, AT); }        // dj_brdf.h:2152
+DJB_DEV float atan_sqrt_f(float x, LdsTab AT) { return trig_at<FT_ATAN_SQRT>(x, AT); }      // dj_brdf.h:2285
+// float(scale * atan2(double y, double x)) decided by the core, or ok = false
+DJB_DEV float atan2_fast_f32(float y, float x, double scale, lds_f64p T, bool &ok, double *as_double = nullptr)
+{
+	const float ayf = fabsf(y), axf = fabsf(x);
+	const bool swap = ayf > axf;
+	const double mx = D(swap ? ayf : axf), mn = D(swap ? axf : ayf);
+	double a = atan_core(mn, mx, T);
+	a = swap ? 0x1.921fb54442d18p+0 - a : a;
+	a = x < 0.0f ? 0x1.921fb54442d18p+1 - a : a;
+	a = (__float_as_uint(y) >> 31) ? -a : a;                  // the sign BIT: atan2(-0, x < 0) is -pi
+	const double d = scale * a;
+	ok = (mx > 1e-18) & (mx < 1e18) & fast_decided(d);
+	if (as_double) *as_double = d;
+	return F(d);
+}
+DJB_DEV float atan2_to_f32(float y, float x, double scale, LdsTab AT)                                      // dj_brdf.h:659, 1634
+{
+	if (AT) { bool ok; const float r = atan2_fast_f32(y, x, scale, atan_tab(AT), ok); if (__builtin_expect(ok, 1)) return r; }
+	return atan2_to_f32(y, x, scale);
+}
+#else
+// host: the expressions themselves
+DJB_DEV float acos_f(float x, LdsTab) { return acos_f(x); }
+DJB_DEV float acos_u_f(float c, LdsTab) { return acos_u_f(c); }
+DJB_DEV float acos_u32_f(float c, LdsTab) { return acos_u32_f(c); }
+DJB_DEV float atan_u_f(float r, LdsTab) { return atan_u_f(r); }
+DJB_DEV float atan_squ_f(float r, LdsTab) { return atan_squ_f(r); }
+DJB_DEV float atan_sqrt_f(float x, LdsTab) { return atan_sqrt_f(x); }
+DJB_DEV float atan2_to_f32(float y, float x, double scale, LdsTab) { return atan2_to_f32(y, x, scale); }
 #endif
 
 #include "djb_device_microfacet.inc"

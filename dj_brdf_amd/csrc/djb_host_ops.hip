@@ -937,17 +937,17 @@ try {
 }
 DJB_ABI_CATCH
 
-djb_status djb_selftest_utia_angles(djb_ctx *ctx, int64_t n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4)
+djb_status djb_selftest_fast_trig(djb_ctx *ctx, int64_t n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4)
 try {
 	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
-	if (!counters4 || (mode != 0 && mode != 1)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument / unknown mode");
+	if (!counters4 || (mode < 0 || mode > 8)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument / unknown mode");
 	unsigned long long *d = nullptr;
 	HIP_TRY(hipMalloc((void **)&d, 32));
 	hipError_t e = hipMemsetAsync(d, 0, 32, ctx->stream);
-	if (e == hipSuccess) e = djbk::launch_utia_angles_selftest(ctx->stream, n, mode, first, seed, d);
+	if (e == hipSuccess) e = djbk::launch_fast_trig_selftest(ctx->stream, n, mode, first, seed, d);
 	if (e == hipSuccess) e = hipMemcpyAsync(counters4, d, 32, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	(void)hipFree(d);

@@ -88,7 +88,7 @@ hipError_t launch_gen_uniforms(hipStream_t s, long long n, uint32_t seed, unsign
 // sRGB power of the decode on the fast transcendentals, everything else (cells, weights, the 16-tap sums) the reference's bits
 hipError_t launch_utia_twotier(hipStream_t s, const Brdf &b, long long n, const View &i, const View &o, const View &out,
                                float *out_pdf, int want, unsigned int *list, unsigned int cap, unsigned int *count, bool contract);
-hipError_t launch_utia_angles_selftest(hipStream_t s, long long n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4);
+hipError_t launch_fast_trig_selftest(hipStream_t s, long long n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4);
 // DJB_OPT_CONTRACT_1E5 (djb_kernels_contract.hip): GGX eval / evalp / pdf inside the 1e-5 value contract, two-tier like
 // the MERL lookup, with a sharded worklist (list: cap records of 32 bytes in total, count: CONTRACT_SHARDS uint32, CONTRACT_COUNTER_STRIDE words apart: the record
 // list is cut into that many equal segments).  Views must be dense (stride 1) and 16-byte aligned.

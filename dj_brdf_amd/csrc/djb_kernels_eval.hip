@@ -65,7 +65,11 @@ __global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Pa
 	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
 	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
 	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BLOCK);
-	if (EXPT || POWT) __syncthreads();
+	// the tabulated lobes' table coordinates (acos / atan / atan2 of a float, rounded to float) from the arctangent core (djb_device.hpp)
+	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO;
+	__shared__ double s_atan[ATANT ? 16 : 1];
+	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
+	if (EXPT || POWT || ATANT) __syncthreads();
 	const long long stride = (long long)gridDim.x * BLOCK;
 	const unsigned int t = threadIdx.x;
 	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void k_fit(const Brdf *srcs, Params std_
 	self.fr.kind = FR_IDEAL; self.fr.pts = nullptr; self.fr.npts = 0;
 	self.p22 = p22; self.sigma = sigma; self.cdf = cdf; self.qf = qf;
 	self.n_p22 = res; self.n_sigma = res; self.n_cdf = res; self.n_qf = res;
-	self.merl = nullptr; self.merl_sparse = 0; self.utia = nullptr; self.exp_lds = 0u; self.pow_lds = 0u;
+	self.merl = nullptr; self.merl_sparse = 0; self.utia = nullptr; self.exp_lds = 0u; self.pow_lds = 0u; self.atan_lds = 0u;
 
 	DJB_FIT_TS(0);
 	// ================================================================ compute_p22_smith (dj_brdf.h:2482-2522)

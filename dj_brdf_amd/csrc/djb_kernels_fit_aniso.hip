@@ -31,7 +31,7 @@ DJB_DEV Brdf self_view(const AnisoScratch &S, int shadow)
 	b.fr.kind = FR_IDEAL; b.fr.pts = nullptr; b.fr.npts = 0;
 	b.p22 = S.p22; b.sigma = S.sigma; b.cdf = nullptr; b.qf = nullptr;
 	b.n_p22 = b.n_sigma = S.elev * S.azim; b.n_cdf = b.n_qf = 0;
-	b.merl = nullptr; b.merl_sparse = 0; b.utia = nullptr; b.model = nullptr; b.exp_lds = 0u; b.pow_lds = 0u;
+	b.merl = nullptr; b.merl_sparse = 0; b.utia = nullptr; b.model = nullptr; b.exp_lds = 0u; b.pow_lds = 0u; b.atan_lds = 0u;
 	b.a_pdf1 = S.pdf1; b.a_cdf1 = S.cdf1; b.a_qf1 = S.qf1; b.a_pdf2 = S.pdf2; b.a_cdf2 = S.cdf2; b.a_qf2 = S.qf2;
 	b.elev = S.elev; b.azim = S.azim; b.n_a_cdf1 = S.azim; b.n_a_qf1 = S.azim;
 	return b;

@@ -43,9 +43,8 @@ __global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_utia_v2(Brdf b, l
 {
 	__shared__ float4 s_tile[BLOCK / 64][384];
 	__shared__ double s_atan[16];
-	if (threadIdx.x < 9) s_atan[threadIdx.x] = DJB_ATAN_EIGHTHS[threadIdx.x];
+	const lds_f64p T = atan_tab(atan_tab_to_lds(s_atan, threadIdx.x));
 	__syncthreads();
-	const lds_f64p T = (lds_f64p)s_atan;
 	const long long stride = (long long)gridDim.x * BLOCK;
 	const unsigned int t = threadIdx.x, wave = t >> 6, lane = t & 63u;
 	typedef __attribute__((address_space(3))) void lds_void;
@@ -97,21 +96,44 @@ __global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_utia_v2(Brdf b, l
 		}
 	}
 }
-// djb_selftest_utia_angles: tier 1's angles against the exact ones.  mode 0: every float z = bits(first + k), k < n, through
-// utia_acos_deg_t1 against acos_deg_f (identical to the host's by exhaustion); mode 1: hash-generated float pairs (y, x) -- unit-circle
-// points, axis-hugging, tiny / huge magnitudes, signs -- through utia_atan2_deg_t1 against atan2_to_f32 (glibc's atan2 behind a guard).
-// counters = {decided, decided but a different float (must be 0), undecided, largest |tier-1 double - device-libm double| in units of 2^-52 of the value over the
-// decided ones: the distance to the reference's double up to the 2 ulp64 between the two libms; the guard is 4096 such units}
-__global__ __launch_bounds__(BLOCK) void k_utia_angles_selftest(long long n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters)
+// djb_selftest_fast_trig: the arctangent core's sites against their previous forms.
+//   mode 0: the floats bits(first + k), k < n, as polar cosines through utia_acos_deg_t1 against acos_deg_f (identical to the host's by
+//           exhaustion); counted over the decided ones;
+//   mode 1 / 8: hash-generated float pairs (y, x) -- unit-circle points, axis-hugging, tiny / huge magnitudes, signed zeros, grid lines --
+//           through atan2_fast_f32 with scale r2d / 1 against atan2_to_f32 (glibc's atan2 behind a guard); decided ones;
+//   mode 2..7: site FT_ACOS .. FT_ATAN_SQRT: the floats bits(first + k) through the site WITH the table against the site without it --
+//           every float, decided or not (an undecided one takes the previous form: it can only differ if the plumbing is wrong).
+// counters = {decided, different floats (must be 0), undecided, largest |core double - device-libm double| in units of 2^-52 of the value
+// over the decided ones (modes 0, 1, 8): the distance to the reference's double up to the 2 ulp64 between the two libms; the guard is 4096}
+template <int S> __device__ void ft_site(float x, LdsTab AT, unsigned long long &n_ok, unsigned long long &n_bad, unsigned long long &n_und)
+{
+	bool ok;
+	(void)trig_fast<S>(x, atan_tab(AT), ok);
+	if (ok) ++n_ok; else ++n_und;
+	if (__float_as_uint(trig_at<S>(x, AT)) != __float_as_uint(trig_prev<S>(x))) ++n_bad;
+}
+__global__ __launch_bounds__(BLOCK) void k_fast_trig_selftest(long long n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters)
 {
 	__shared__ double s_atan[16];
-	if (threadIdx.x < 9) s_atan[threadIdx.x] = DJB_ATAN_EIGHTHS[threadIdx.x];
+	const LdsTab AT = atan_tab_to_lds(s_atan, threadIdx.x);
 	__syncthreads();
-	const lds_f64p T = (lds_f64p)s_atan;
+	const lds_f64p T = atan_tab(AT);
 	unsigned long long n_ok = 0, n_bad = 0, n_und = 0, worst = 0;
 	const long long stride = (long long)gridDim.x * BLOCK;
-	const double r2d = D(F(180.0 / DJB_PI));
+	const double r2d = (mode == 8) ? 1.0 : D(F(180.0 / DJB_PI));
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		if (mode >= 2 && mode <= 7) {
+			const float x = __uint_as_float(first + (uint32_t)k);
+			switch (mode) {
+			case 2: ft_site<FT_ACOS>(x, AT, n_ok, n_bad, n_und); break;
+			case 3: ft_site<FT_ACOS_U>(x, AT, n_ok, n_bad, n_und); break;
+			case 4: ft_site<FT_ACOS_U32>(x, AT, n_ok, n_bad, n_und); break;
+			case 5: ft_site<FT_ATAN_U>(x, AT, n_ok, n_bad, n_und); break;
+			case 6: ft_site<FT_ATAN_SQU>(x, AT, n_ok, n_bad, n_und); break;
+			default: ft_site<FT_ATAN_SQRT>(x, AT, n_ok, n_bad, n_und); break;
+			}
+			continue;
+		}
 		bool ok; float got, want; double dl, dd;
 		if (mode == 0) {
 			const float z = __uint_as_float(first + (uint32_t)k);
@@ -125,15 +147,14 @@ __global__ __launch_bounds__(BLOCK) void k_utia_angles_selftest(long long n, int
 				y = sc * sinf(ph); x = sc * cosf(ph);
 			} else if (fam == 3u) { y = __uint_as_float(h0); x = __uint_as_float(h1); }                                   // any two floats
 			else if (fam == 4u) { y = __uint_as_float((h0 & 0x807fffffu) | 0x3f000000u); x = y * (1.0f + (float)(int)(h1 & 15u) * 0x1p-23f) * ((h2 & 8u) ? -1.0f : 1.0f); }   // |y| ~ |x|
-			else if (fam == 5u) { y = (float)(int)(h0 & 0xffu) * 0x1p-20f * ((h2 & 8u) ? -1.0f : 1.0f); x = __uint_as_float((h1 & 0x807fffffu) | 0x3f000000u); }   // near the x axis
-			else if (fam == 6u) { x = (float)(int)(h0 & 0xffu) * 0x1p-20f * ((h2 & 8u) ? -1.0f : 1.0f); y = __uint_as_float((h1 & 0x807fffffu) | 0x3f000000u); }   // near the y axis
+			else if (fam == 5u) { y = (float)(int)(h0 & 0xffu) * 0x1p-20f * ((h2 & 8u) ? -1.0f : 1.0f); x = __uint_as_float((h1 & 0x807fffffu) | 0x3f000000u); }   // near the x axis, +-0 included
+			else if (fam == 6u) { x = (float)(int)(h0 & 0xffu) * 0x1p-20f * ((h2 & 8u) ? -1.0f : 1.0f); y = __uint_as_float((h1 & 0x807fffffu) | 0x3f000000u); }   // near the y axis, +-0 included
 			else { const float t7 = tanf(0.13089969f * (float)(h0 % 49u)); y = t7 * __uint_as_float((h1 & 0x007fffffu) | 0x3f000000u); x = __uint_as_float((h1 & 0x007fffffu) | 0x3f000000u); if (h2 & 8u) x = -x; if (h2 & 16u) y = -y; }   // on the 7.5-degree grid lines
-			got = utia_atan2_deg_t1(y, x, T, ok, &dd); want = atan2_to_f32(y, x, r2d); dl = r2d * atan2(D(y), D(x));
+			got = atan2_fast_f32(y, x, r2d, T, ok, &dd); want = atan2_to_f32(y, x, r2d); dl = r2d * atan2(D(y), D(x));
 		}
 		if (!ok) { ++n_und; continue; }
 		++n_ok;
 		if (__float_as_uint(got) != __float_as_uint(want)) ++n_bad;
-		// distance of the tier-1 double from the device libm's (itself within 2 ulp64 of the host libm's), in ulp64 of the value
 		const double adl = fabs(dl);
 		const unsigned long long q = (unsigned long long)(fabs(dd - dl) / (adl * 0x1p-52 + 1e-300));
 		worst = q > worst ? q : worst;
@@ -194,10 +215,10 @@ hipError_t launch_utia_twotier(hipStream_t s, const Brdf &b, long long n, const 
 	return hipErrorInvalidValue;
 }
 
-hipError_t launch_utia_angles_selftest(hipStream_t s, long long n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4)
+hipError_t launch_fast_trig_selftest(hipStream_t s, long long n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4)
 {
 	if (n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k_utia_angles_selftest, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, mode, first, seed, counters4);
+	hipLaunchKernelGGL(k_fast_trig_selftest, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, mode, first, seed, counters4);
 	return hipGetLastError();
 }
 

@@ -1322,13 +1322,14 @@ def host_libm_status():
     return int(lib.djb_ctx_libm_matches_host(None)), int(lib.djb_host_libm_mode()), int(lib.djb_host_atan_log_kat())
 
 
-def selftest_utia_angles(n: int, mode: int, first: int = 0, seed: int = 1, ctx: Optional[Context] = None):
-    """Tier 1 of the utia::eval kernel takes its angles from one fp64 arctangent core and keeps only decided values
-    (djb_selftest_utia_angles): mode 0 = the n floats after bit pattern `first` as cosines, mode 1 = n generated (y, x) pairs.
-    Returns {decided, mismatch (must be 0), undecided, worst_ulp64 (distance of a decided tier-1 double from the device libm's)}."""
+def selftest_fast_trig(n: int, mode: int, first: int = 0, seed: int = 1, ctx: Optional[Context] = None):
+    """The arctangent core behind the trig sites of the table-driven kinds against the sites' previous forms (djb_selftest_fast_trig):
+    mode 0 = the n floats after bit pattern `first` as utia's polar cosines, 1 / 8 = n generated (y, x) pairs (scale r2d / 1),
+    2..7 = the n floats after `first` through one site with and without the core.
+    Returns {decided, mismatch (must be 0), undecided, worst_ulp64 (a decided double's distance from the device libm's)}."""
     ctx = ctx or default_context()
     c = (C.c_ulonglong * 4)()
-    _lib.check(_lib.load().djb_selftest_utia_angles(ctx._h, C.c_int64(n), C.c_int(mode), C.c_uint32(first), C.c_uint32(seed), c))
+    _lib.check(_lib.load().djb_selftest_fast_trig(ctx._h, C.c_int64(n), C.c_int(mode), C.c_uint32(first), C.c_uint32(seed), c))
     return {"decided": c[0], "mismatch": c[1], "undecided": c[2], "worst_ulp64": int(c[3])}
 
 

@@ -57,7 +57,7 @@ extern "C" {
  *   232  round 5: + DJB_OPT_HOST_BATCH_MAX (the size up to which host-array calls are answered by the host twin; default unchanged).
  *   233  round 6: + djb_fit_merl_files_multi (the file pipeline over several contexts), djb_merl_bin_keys_batch.  The on-chip uniforms of
  *        djb_sample_rng_batch / djb_gen_uniforms are a cheaper counter hash (dj_brdf_amd/synth.py: rng_uniforms); same interface.
- *   234  round 6: + djb_selftest_utia_angles; DJB_OPT_CONTRACT_1E5 also covers utia eval / evalp (the sRGB power of the decode only). */
+ *   234  round 6: + djb_selftest_fast_trig; DJB_OPT_CONTRACT_1E5 also covers utia eval / evalp (the sRGB power of the decode only). */
 #define DJB_HIP_VERSION 234
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
@@ -458,12 +458,16 @@ djb_status djb_merl_guard_attack(djb_ctx *, int64_t n, const djb_vec3_view *i, c
  * mismatches of float(num / den) for two doubles (the quotient of GGX's quantile function), its fallbacks};
  * every mismatch count must be 0. */
 djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsigned long long *counters12);
-/* tier 1 of the utia::eval batch kernel takes its four angles from one branch-free fp64 arctangent core and keeps a value only
- * where it is decided: this runs it against the exact forms.  mode 0: the n floats whose bit patterns follow `first`
- * as polar-angle cosines (float(r2d * acos(z)), dj_brdf.h:1066); mode 1: n hash-generated float pairs as (y, x) of an azimuth
- * (float(r2d * atan2(y, x)), :1068).  counters4 = {decided, decided but not the exact float (must be 0), left to tier 2,
- * the largest distance of a decided tier-1 double from the device libm's in units of 2^-52 of the value (the guard is 4096)}. */
-djb_status djb_selftest_utia_angles(djb_ctx *, int64_t n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4);
+/* The table-driven kinds take their float -> float trig sites (the polar / azimuth angles of utia::eval, the table coordinates of
+ * tabular and tabular_anisotropic) from one branch-free fp64 arctangent core and keep a value only where it is decided -- further from
+ * a float rounding boundary than the core's error -- otherwise the site's previous form answers.  This runs the sites
+ * against those forms.  mode 0: the n floats whose bit patterns follow `first` as polar cosines (float(r2d * acos(z)), dj_brdf.h:1066),
+ * decided ones; mode 1 / 8: n hash-generated float pairs as (y, x) of float(r2d * atan2(y, x)) (:1068) / float(atan2(y, x)) (:659),
+ * decided ones; mode 2..7: the n floats after `first` through the site with the core against the site without it, every one of them
+ * (acos, 2 acos / pi, 2 acos / float(pi), 2 atan / float(pi), sqrt(2 atan / float(pi)), atan(sqrt)).  counters4 = {decided, different
+ * (must be 0), left to the previous form, the largest distance of a decided double from the device libm's in units of 2^-52 of the
+ * value (modes 0, 1, 8; the guard is 4096)}. */
+djb_status djb_selftest_fast_trig(djb_ctx *, int64_t n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4);
 /* the DJB_OPT_CONTRACT_1E5 fast path against the bit-exact per-pair code on n generated pairs (family 0: the bench
  * distribution; 1: grazing with opposite azimuths; 2: near-normal incidence; 3: o at the horizon; 4: un-normalised):
  * max_rel2 = {max relative difference of the eval rgb, of the pdf} over the fast-path pairs, counters4 = {pairs, pairs

@@ -432,19 +432,29 @@ def test_merl_two_tier_every_output_set_and_launch_shape(gpu_ctx):
             assert torch.equal(bits(got["eval_pdf"][0]), bits(got["eval"])) and torch.equal(bits(got["evalp_pdf"][0]), bits(got["evalp"]))
 
 
-def test_utia_tier1_angles_against_the_exact_forms(gpu_ctx):
-    """k_utia_v2 takes its angles from one branch-free fp64 arctangent core and keeps a value only where it is decided (further from a
-    float rounding boundary than the core's error).  Every float z in (0, 1] as a polar cosine against acos_deg_f (identical to the
-    host's by exhaustion), 2^33 generated (y, x) pairs against atan2_to_f32 (glibc's atan2 behind a guard): no decided value differs."""
+def test_fast_trig_sites_against_their_previous_forms(gpu_ctx):
+    """The table-driven kinds take their trig sites from one branch-free fp64 arctangent core and keep a value only where it is decided
+    (further from a float rounding boundary than the core's error); otherwise the previous form answers.  utia's polar angle for every
+    float cosine in [1e-17, 1] against acos_deg_f (identical to the host's by exhaustion); its azimuth and xyz_to_theta_phi's for 2^33
+    generated (y, x) pairs against atan2_to_f32 (glibc's atan2 behind a guard); the six one-argument sites over ALL 2^32 floats against the
+    forms the exhaustive sweeps (tools/exhaustive_trig.py) were run on: not one different float."""
     first = int(np.float32(1e-17).view(np.uint32))
     n = 0x3F800000 - first + 1                                                      # every float in [1e-17, 1]
-    r = djb.selftest_utia_angles(n, 0, first=first, ctx=gpu_ctx)
-    print("acos:", r)
+    r = djb.selftest_fast_trig(n, 0, first=first, ctx=gpu_ctx)
+    print("utia acos_deg:", r)
     assert r["mismatch"] == 0 and r["decided"] > 0.9999 * n and r["worst_ulp64"] < 256          # the guard is 4096
-    tot = {"decided": 0, "mismatch": 0, "undecided": 0, "worst_ulp64": 0}
-    for seed in range(1, 5):
-        r = djb.selftest_utia_angles(1 << 31, 1, seed=seed, ctx=gpu_ctx)
-        for k in ("decided", "mismatch", "undecided"): tot[k] += r[k]
-        tot["worst_ulp64"] = max(tot["worst_ulp64"], r["worst_ulp64"])
-    print("atan2:", tot)
-    assert tot["mismatch"] == 0 and tot["decided"] > 0.8 * (1 << 33) and tot["worst_ulp64"] < 256
+    for mode in (1, 8):
+        tot = {"decided": 0, "mismatch": 0, "undecided": 0, "worst_ulp64": 0}
+        for seed in range(1, 5):
+            r = djb.selftest_fast_trig(1 << 31, mode, seed=seed, ctx=gpu_ctx)
+            for k in ("decided", "mismatch", "undecided"): tot[k] += r[k]
+            tot["worst_ulp64"] = max(tot["worst_ulp64"], r["worst_ulp64"])
+        print("atan2 (scale %s):" % ("r2d" if mode == 1 else "1"), tot)
+        assert tot["mismatch"] == 0 and tot["decided"] > 0.8 * (1 << 33) and tot["worst_ulp64"] < 256
+    for mode, name in ((2, "acos_f"), (3, "acos_u_f"), (4, "acos_u32_f"), (5, "atan_u_f"), (6, "atan_squ_f"), (7, "atan_sqrt_f")):
+        tot = {"decided": 0, "mismatch": 0, "undecided": 0}
+        for half in (0, 1):                                                         # all 2^32 bit patterns, two launches
+            r = djb.selftest_fast_trig(1 << 31, mode, first=half << 31, ctx=gpu_ctx)
+            for k in tot: tot[k] += r[k]
+        print("%-12s" % name, tot)
+        assert tot["mismatch"] == 0 and tot["decided"] + tot["undecided"] == 1 << 32 and tot["decided"] > 0.2 * (1 << 32)

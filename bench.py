@@ -269,11 +269,13 @@ def contract_mode(step, name, djb, ctx):
 def utia_contract_accuracy(step, keep, djb, ctx, torch):
     """The contract launch against the bit-exact launch on the leg's own pairs (all of them): the option only changes the sRGB power."""
     out = keep[3]
+    try:
+        djb.set_contract_1e5(ctx, True)           # the leg is over (finish() has switched the option off): on for one launch, off again
+        step(); torch.cuda.synchronize()
+        fast = out.clone()
+    finally:
+        djb.set_contract_1e5(ctx, False)
     step(); torch.cuda.synchronize()
-    fast = out.clone()
-    djb.set_contract_1e5(ctx, False)
-    step(); torch.cuda.synchronize()
-    djb.set_contract_1e5(ctx, True)
     exact = out
     rel = (fast - exact).abs() / exact.abs().clamp_min(1e-30)
     rel = torch.where(exact == fast, torch.zeros_like(rel), rel)

@@ -201,8 +201,10 @@ enum { DJB_OPT_MERL_EXACT_ONLY = 1,
  * (djb_sample_batch / djb_sample_rng_batch; 1e-3 <= ax, ay <= 100, |rho| <= 0.99): every component of the returned unit vector
  * within 1e-5 of the reference's, samples whose decisions or conditioning are in doubt re-done by the bit-exact code in the same
  * launch; and evalp_is of GGX / Beckmann (same Fresnel / params domain as eval): the sampled direction stays the reference's
- * bit for bit -- its pdf moves by 1e-3 for a 1e-5 change of direction -- weight and pdf within 1e-5 relative.  Everything
- * else -- MERL / UTIA look-ups and their bin decisions, the fitters, other lobes and layouts -- is unaffected and stays bit-identical.  djb_selftest_contract and
+ * bit for bit -- its pdf moves by 1e-3 for a 1e-5 change of direction -- weight and pdf within 1e-5 relative.  Since ABI 234 also
+ * utia eval / evalp: the grid cells, the weights and the 16-tap sums remain the reference's bits (so do the sRGB knee and the clamp
+ * decisions), only pow(t, 2.4f) of the decode runs on the fast transcendentals (<= 1.5e-6 relative).  Everything else -- MERL look-ups,
+ * every MERL / UTIA bin decision, the fitters, other lobes and layouts -- is unaffected and stays bit-identical.  djb_selftest_contract and
  * djb_selftest_contract_sample measure the actual maximum difference. */
        DJB_OPT_CONTRACT_1E5 = 6,
 /* DJB_OPT_TEST_WORKLIST_CAP = <entries> (tests only; -1 = automatic, the default): overrides the capacity of the tier-2

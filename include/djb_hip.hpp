@@ -208,8 +208,9 @@ public:
 	// within 1e-5), zeros and NaNs exactly where the reference has them -- the north star's tolerance, spent on speed (GGX eval+pdf
 	// 0.53 -> 0.76 of the HBM roofline).  What changes bits under it: eval / evalp / pdf / eval_pdf batches of ggx and beckmann
 	// (ideal, Schlick f0 >= 0.01, unpolarized ior >= 1.05; no mean-normal offset, |rho| <= 0.9), sgd and abc eval, sample and the
-	// weights / pdfs of evalp_is of ggx and beckmann (evalp_is directions stay bit-identical).  What never changes: MERL / UTIA
-	// look-ups and their bin indices, tabular and tabular_anisotropic (fits, eval, sampling), lambert, the queries, LEAN / per-pair
+	// weights / pdfs of evalp_is of ggx and beckmann (evalp_is directions stay bit-identical), utia eval / evalp (the sRGB power of
+	// the decode only: cells, weights and the 16-tap sums stay the reference's bits).  What never changes: MERL look-ups, every
+	// MERL / UTIA bin index, tabular and tabular_anisotropic (fits, eval, sampling), lambert, the queries, LEAN / per-pair
 	// parameter calls, every scalar (one-pair) call, and everything on a CPU context.
 	void set_contract_1e5(bool on) { set_option(DJB_OPT_CONTRACT_1E5, on ? 1 : 0); }
 	// host-array batches of up to `units` units are answered on the calling thread by the host twin (default DJB_SCALAR_HOST_MAX = 96):

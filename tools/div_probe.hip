@@ -1,6 +1,6 @@
 // div_probe.hip -- exact fp32 division through fp64 on gfx950: cost and exhaustive-style verification.
 //
-// Claim (profiles/r03/NOTES.md 4.1, "exact division by a shared or uniform denominator"): for floats a, b with a normal (or zero /
+// Claim (profiles/archive/r03_NOTES.md 4.1, "exact division by a shared or uniform denominator"): for floats a, b with a normal (or zero /
 // inf / NaN) quotient,   float(double(a) * R) == a / b   whenever R is within 2^-52 (relative) of 1/b.  Reason: a/b can
 // never lie within 2^-49 (relative) of the midpoint m of two adjacent floats -- a - m*b is a non-zero multiple of
 // ulp(m)*ulp(b), i.e. |a/b - m| >= |a/b| / (M*B) > 2^-49 |a/b| for the integer significands M < 2^25, B < 2^24 -- and an

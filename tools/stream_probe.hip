@@ -280,11 +280,11 @@ static void run_sg(unsigned int entries, float **d, Texel *tab, long long n, int
 	       entries * 12.0 / 1048576.0, ms, n / ms / 1e6);
 }
 
-// ---- round 3, the last untested lever of profiles/r03/NOTES.md 4.2: serve the hottest table lines from LDS.  HOTPCT % of the look-ups
+// ---- round 3, the last untested lever of profiles/archive/r03_NOTES.md 4.2: serve the hottest table lines from LDS.  HOTPCT % of the look-ups
 // go to the first HOT_N texels of the table (128 KB: what one workgroup can hold next to nothing else), the rest
 // uniformly to the remainder; LDS = true answers the hot ones from a per-workgroup LDS copy, false from the table (where
 // they hit L2).  1024-thread workgroups, one per CU (the LDS copy allows no more), grid-stride.  The bench distribution
-// puts 11 % of its look-ups into its hottest 160 KB of lines (CPU histogram, profiles/r03/NOTES.md 4.2); 30 % is an optimistic case.
+// puts 11 % of its look-ups into its hottest 160 KB of lines (CPU histogram, profiles/archive/r03_NOTES.md 4.2); 30 % is an optimistic case.
 constexpr unsigned int HOT_N = 10922;      // 128 KB of 12-byte texels
 template <bool LDS, int HOTPCT>
 __global__ __launch_bounds__(1024) void k_sg_hot(const Texel *tab, unsigned int entries, const v4f *a0, const v4f *a1,

@@ -630,8 +630,28 @@ DJB_DEV float atan2_to_f32(float y, float x, double scale, LdsTab AT)           
 	if (AT) { bool ok; const float r = atan2_fast_f32(y, x, scale, atan_tab(AT), ok); if (__builtin_expect(ok, 1)) return r; }
 	return atan2_to_f32(y, x, scale);
 }
+// float(tan(double x)) (the quantile -> slope step of the tabulated lobes' sampling, dj_brdf.h:2171-2176, 2828): sine over cosine from
+// sincos_fast (2 ulp64 each for |x| <= 8) through one reciprocal, decided like the sites above; the device libm's tan otherwise.
+// djb_selftest_fast_trig mode 9: identical to tan_f over all 2^32 floats.
+DJB_DEV float tan_fast_f32(float x, bool &ok)
+{
+	const double xd = D(x);
+	double sn, cs;
+	sincos_fast(xd, sn, cs);
+	const double q = sn * recip_fast(cs), ac = cs < 0.0 ? -cs : cs;
+	ok = (xd >= -8.0) & (xd <= 8.0) & (ac > 1e-30) & fast_decided(q);
+	return F(q);
+}
+DJB_DEV float tan_fast_f(float x)
+{
+	bool ok;
+	const float r = tan_fast_f32(x, ok);
+	if (__builtin_expect(ok, 1)) return r;
+	return tan_f(x);
+}
 #else
 // host: the expressions themselves
+DJB_DEV float tan_fast_f(float x) { return tan_f(x); }
 DJB_DEV float acos_f(float x, LdsTab) { return acos_f(x); }
 DJB_DEV float acos_u_f(float c, LdsTab) { return acos_u_f(c); }
 DJB_DEV float acos_u32_f(float c, LdsTab) { return acos_u32_f(c); }

@@ -943,7 +943,7 @@ try {
 	djb_status st = check_call(ctx, nullptr, n, DJB_MEM_DEVICE);
 	if (st != DJB_OK) return st;
 	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
-	if (!counters4 || (mode < 0 || mode > 8)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument / unknown mode");
+	if (!counters4 || (mode < 0 || mode > 9)) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null argument / unknown mode");
 	unsigned long long *d = nullptr;
 	HIP_TRY(hipMalloc((void **)&d, 32));
 	hipError_t e = hipMemsetAsync(d, 0, 32, ctx->stream);

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_utia_v2(Brdf b, l
 //   mode 1 / 8: hash-generated float pairs (y, x) -- unit-circle points, axis-hugging, tiny / huge magnitudes, signed zeros, grid lines --
 //           through atan2_fast_f32 with scale r2d / 1 against atan2_to_f32 (glibc's atan2 behind a guard); decided ones;
 //   mode 2..7: site FT_ACOS .. FT_ATAN_SQRT: the floats bits(first + k) through the site WITH the table against the site without it --
-//           every float, decided or not (an undecided one takes the previous form: it can only differ if the plumbing is wrong).
+//           every float, decided or not (an undecided one takes the previous form: it can only differ if the plumbing is wrong);
+//   mode 9: float(tan(double x)) from sincos_fast against the device libm's, every float the same way.
 // counters = {decided, different floats (must be 0), undecided, largest |core double - device-libm double| in units of 2^-52 of the value
 // over the decided ones (modes 0, 1, 8): the distance to the reference's double up to the 2 ulp64 between the two libms; the guard is 4096}
 template <int S> __device__ void ft_site(float x, LdsTab AT, unsigned long long &n_ok, unsigned long long &n_bad, unsigned long long &n_und)
@@ -122,6 +123,14 @@ __global__ __launch_bounds__(BLOCK) void k_fast_trig_selftest(long long n, int m
 	const long long stride = (long long)gridDim.x * BLOCK;
 	const double r2d = (mode == 8) ? 1.0 : D(F(180.0 / DJB_PI));
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		if (mode == 9) {                                   // float(tan(double x)): sincos_fast quotient against the device libm's tan, every float
+			const float x = __uint_as_float(first + (uint32_t)k);
+			bool ok;
+			(void)tan_fast_f32(x, ok);
+			if (ok) ++n_ok; else ++n_und;
+			if (__float_as_uint(tan_fast_f(x)) != __float_as_uint(tan_f(x))) ++n_bad;
+			continue;
+		}
 		if (mode >= 2 && mode <= 7) {
 			const float x = __uint_as_float(first + (uint32_t)k);
 			switch (mode) {

@@ -466,7 +466,8 @@ djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsign
  * against those forms.  mode 0: the n floats whose bit patterns follow `first` as polar cosines (float(r2d * acos(z)), dj_brdf.h:1066),
  * decided ones; mode 1 / 8: n hash-generated float pairs as (y, x) of float(r2d * atan2(y, x)) (:1068) / float(atan2(y, x)) (:659),
  * decided ones; mode 2..7: the n floats after `first` through the site with the core against the site without it, every one of them
- * (acos, 2 acos / pi, 2 acos / float(pi), 2 atan / float(pi), sqrt(2 atan / float(pi)), atan(sqrt)).  counters4 = {decided, different
+ * (acos, 2 acos / pi, 2 acos / float(pi), 2 atan / float(pi), sqrt(2 atan / float(pi)), atan(sqrt)); mode 9: float(tan(double x)) of the
+ * tabulated lobes' samplers the same way.  counters4 = {decided, different
  * (must be 0), left to the previous form, the largest distance of a decided double from the device libm's in units of 2^-52 of the
  * value (modes 0, 1, 8; the guard is 4096)}. */
 djb_status djb_selftest_fast_trig(djb_ctx *, int64_t n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4);

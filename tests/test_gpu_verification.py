@@ -451,10 +451,10 @@ def test_fast_trig_sites_against_their_previous_forms(gpu_ctx):
             tot["worst_ulp64"] = max(tot["worst_ulp64"], r["worst_ulp64"])
         print("atan2 (scale %s):" % ("r2d" if mode == 1 else "1"), tot)
         assert tot["mismatch"] == 0 and tot["decided"] > 0.8 * (1 << 33) and tot["worst_ulp64"] < 256
-    for mode, name in ((2, "acos_f"), (3, "acos_u_f"), (4, "acos_u32_f"), (5, "atan_u_f"), (6, "atan_squ_f"), (7, "atan_sqrt_f")):
+    for mode, name in ((2, "acos_f"), (3, "acos_u_f"), (4, "acos_u32_f"), (5, "atan_u_f"), (6, "atan_squ_f"), (7, "atan_sqrt_f"), (9, "tan_f")):
         tot = {"decided": 0, "mismatch": 0, "undecided": 0}
         for half in (0, 1):                                                         # all 2^32 bit patterns, two launches
             r = djb.selftest_fast_trig(1 << 31, mode, first=half << 31, ctx=gpu_ctx)
             for k in tot: tot[k] += r[k]
         print("%-12s" % name, tot)
-        assert tot["mismatch"] == 0 and tot["decided"] + tot["undecided"] == 1 << 32 and tot["decided"] > 0.2 * (1 << 32)
+        assert tot["mismatch"] == 0 and tot["decided"] + tot["undecided"] == 1 << 32 and tot["decided"] > 0.2 * (1 << 32)   # (the rest: |x| > 1, NaN, ...)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Pa
 	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
 	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BLOCK);
 	// the tabulated lobes' table coordinates (acos / atan / atan2 of a float, rounded to float) from the arctangent core (djb_device.hpp)
-	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO;
+	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || FRK == FR_SPLINE;      // ... and the Fresnel spline's (dj_brdf.h:1341)
 	__shared__ double s_atan[ATANT ? 16 : 1];
 	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
 	if (EXPT || POWT || ATANT) __syncthreads();
@@ -274,7 +274,11 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi,
                                                    LeanCfg base, View vout, float *out_pdf, float *out_pp)
 {
 	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];     // as in k_eval
-	if (KIND == KIND_BECKMANN) { b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK); __syncthreads(); }
+	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || FRK == FR_SPLINE;
+	__shared__ double s_atan[ATANT ? 16 : 1];
+	if (KIND == KIND_BECKMANN) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
+	if (KIND == KIND_BECKMANN || ATANT) __syncthreads();
 	long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
 		v3 fr = mk(0, 0, 0); float pdf = 0.0f;
@@ -360,11 +364,15 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 	__shared__ double s_glibc[KIND == KIND_BECKMANN ? GLIBC_LDS_WORDS : 1];
 	GlibcTabs gt = glibc_tabs_global();
 	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];     // the fp64 exp table, as in k_eval
+	// evalp_is evaluates the lobe at the sampled direction: the table coordinates of a tabulated lobe / of a Fresnel spline (as in k_eval)
+	constexpr bool ATANT = IS && (KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || FRK == FR_SPLINE);
+	__shared__ double s_atan[ATANT ? 16 : 1];
 	if (KIND == KIND_BECKMANN) {
 		gt = glibc_tabs_to_lds(s_glibc, threadIdx.x, BLOCK);
 		gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
-		__syncthreads();
 	}
+	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
+	if (KIND == KIND_BECKMANN || ATANT) __syncthreads();
 	const long long stride = (long long)gridDim.x * BLOCK;
 	const unsigned int t = threadIdx.x;
 	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform

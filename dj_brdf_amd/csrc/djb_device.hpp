@@ -465,23 +465,32 @@ DJB_DEV void polar_to_f32(float r, float phi, float &x, float &y) { x = F(D(r) *
 // doubles by < 4 ulp64 and round to the same floats unless one sits within 256 ulp64 of a float rounding boundary (near_f32_midpoint,
 // probability 2^-19 per sample); there, for zero / subnormal-range / huge products and for phi outside [-8, 8] or NaN, glibc's own
 // algorithms decide -- the previous code, verbatim.
+// fma(a, b, k) with a literal addend k held in an SGPR pair.  The compiler selects v_fmac_f64 for a Horner step -- a tied accumulator, so
+// the coefficient is first moved into a VGPR pair (two v_mov_b32: 3 issue slots per step instead of 1.6); v_fma_f64 takes it as an SGPR
+// operand.  The same operation, the same bits.  Only for literals (an "s" operand that is not uniform would be read from one lane).
+DJB_DEV double fma_sk(double a, double b, double k)
+{
+	double r;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+	return r;
+}
 DJB_DEV void sincos_fast(double x, double &s, double &c)
 {
 	const double kf = __builtin_rint(x * 0x1.45f306dc9c883p-1);                    // 2 / pi
 	double t = __builtin_fma(-kf, 0x1.921fb54442d18p+0, x);                        // pi / 2: its high 53 bits ...
 	t = __builtin_fma(-kf, 0x1.1a62633145c07p-54, t);                              // ... and the next 53
 	const double z = t * t;
-	double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-	ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-	ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-	ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-	ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+	double ps = fma_sk(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);   // the coefficients as SGPR operands (fma_sk): same operations
+	ps = fma_sk(z, ps, 2.75573137070700676789e-06);
+	ps = fma_sk(z, ps, -1.98412698298579493134e-04);
+	ps = fma_sk(z, ps, 8.33333333332248946124e-03);
+	ps = fma_sk(z, ps, -1.66666666666666324348e-01);
 	const double st = __builtin_fma(t * z, ps, t);
-	double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-	pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-	pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-	pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-	pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+	double pc = fma_sk(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+	pc = fma_sk(z, pc, -2.75573143513906633035e-07);
+	pc = fma_sk(z, pc, 2.48015872894767294178e-05);
+	pc = fma_sk(z, pc, -1.38888888888741095749e-03);
+	pc = fma_sk(z, pc, 4.16666666666666019037e-02);
 	const double ct = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
 	const int q = (int)kf & 3;
 	const double a = (q & 1) ? ct : st, b = (q & 1) ? st : ct;                     // the quadrant: sin takes a, cos takes b
@@ -527,12 +536,6 @@ DJB_DEV LdsTab atan_tab_to_lds(double *lds, int tid)
 	return 1u + (unsigned int)(uintptr_t)(lds_f64p)lds;
 }
 DJB_DEV lds_f64p atan_tab(LdsTab AT) { return (lds_f64p)(uintptr_t)(AT - 1u); }
-DJB_DEV double fma_sk(double a, double b, double k)          // fma(a, b, k), k a literal: held in an SGPR pair, no VGPR moves
-{
-	double r;
-	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
-	return r;
-}
 DJB_DEV double atan_core(double mn, double mx, lds_f64p T)
 {
 	const float jf = __builtin_rintf(8.0f * (F(mn) * __builtin_amdgcn_rcpf(F(mx))));

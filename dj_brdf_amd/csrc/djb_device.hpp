@@ -268,6 +268,7 @@ DJB_DEV float recip_to_f32(double q) { return F(1.0 / q); }
 DJB_DEV float sqrt_to_f32(double a) { return F(sqrt(a)); }
 DJB_DEV float div_to_f32(double num, double den) { return F(num / den); }
 DJB_DEV float div_pi_to_f32(double num) { return F(num / DJB_PI); }
+DJB_DEV float div_2pi_to_f32(double num) { return F(num / (2.0 * DJB_PI)); }
 DJB_DEV float inv_sqrt_pi_f() { return inversesqrt_(F(DJB_PI)); }
 #else
 // ---- guarded fast paths for float(<double expression>) -----------------------------------------
@@ -336,6 +337,14 @@ DJB_DEV float div_pi_to_f32(double num)
 	const double q = num * 0x1.45f306dc9c883p-2;
 	const double aq = q < 0 ? -q : q;
 	if (__builtin_expect(near_f32_midpoint(q) || !(aq > 1e-30 && aq < 1e30), 0)) return F(num / DJB_PI);
+	return F(q);
+}
+// float(num / (2.0 * pi)) (the azimuth coordinate of tabular_anisotropic's quantile grid, dj_brdf.h:2814): 2 pi and RN(1 / pi) / 2 are exact scalings
+DJB_DEV float div_2pi_to_f32(double num)
+{
+	const double q = num * 0x1.45f306dc9c883p-3;
+	const double aq = q < 0 ? -q : q;
+	if (__builtin_expect(near_f32_midpoint(q) || !(aq > 1e-30 && aq < 1e30), 0)) return F(num / (2.0 * DJB_PI));
 	return F(q);
 }
 // inversesqrt(float(pi)) = float(1.0 / sqrt(double(3.14159274f))): a constant (the compiler does not fold v_rsq_f32 of a literal)

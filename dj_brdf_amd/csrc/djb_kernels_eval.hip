@@ -50,10 +50,15 @@ constexpr int eval_min_waves(int kind)
 	     : (kind <= KIND_TABULAR || kind == KIND_TABULAR_ANISO || kind == KIND_SGD) ? 4
 	     : kind == KIND_ABC ? 8 : 1;
 }
+// workgroup size: 1024 for tabular_anisotropic -- its two elev x azim grids (2 x 32 KB at 90 x 90) are staged in LDS, and sixteen waves
+// sharing one copy keep two workgroups = 8 waves per SIMD resident (256-thread workgroups with 65 KB each: 2 per SIMD, 3.7 ms per 1e8 pairs
+// against 2.8 with sigma's grid alone and 3.06 without LDS)
+constexpr int eval_block(int kind) { return kind == KIND_TABULAR_ANISO ? 1024 : BLOCK; }
 template <int KIND, int WANT, int FRK, bool DENSE>
-__global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
+__global__ __launch_bounds__(eval_block(KIND), eval_min_waves(KIND)) void k_eval(Brdf b, Params p, long long n, View vi, View vo,
                                                    View vout, float *out_pdf)
 {
+	constexpr int BS = eval_block(KIND);
 	// Beckmann evaluates the fp64 exp of glibc (djb_device.hpp) three times per pair: its 2 KB table goes to LDS
 	// (sgd: 9 exp + 9 pow per pair, abc: one pow -- both tables)
 	// (sgd also calls glibc's acos twice per pair: its 21 KB of tables)
@@ -62,17 +67,35 @@ __global__ __launch_bounds__(BLOCK, eval_min_waves(KIND)) void k_eval(Brdf b, Pa
 	__shared__ unsigned long long s_exp[EXPT ? 256 : 1];
 	__shared__ double s_pow[POWT ? 384 : 1];
 	__shared__ double s_acos[ACOST ? 2568 + 128 : 1];
-	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
-	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
-	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BLOCK);
+	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BS);
+	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BS);
+	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BS);
 	// the tabulated lobes' table coordinates (acos / atan / atan2 of a float, rounded to float) from the arctangent core (djb_device.hpp)
 	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || FRK == FR_SPLINE;      // ... and the Fresnel spline's (dj_brdf.h:1341)
 	__shared__ double s_atan[ATANT ? 16 : 1];
 	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
-	if (EXPT || POWT || ATANT) __syncthreads();
-	const long long stride = (long long)gridDim.x * BLOCK;
+	// a fitted lobe's tables in LDS (north star: "LDS-staged tiles of the tables"): the slope-pdf and sigma tables of tabular (float[res]
+	// each), sigma's elev x azim grid of tabular_anisotropic (two of the pair's three grid look-ups), the Fresnel spline's points -- 12-20
+	// divergent 4-byte look-ups per pair otherwise go through the texture path.  Staged when they fit TAB_LDS floats; the per-unit code
+	// reads through the same pointers (the address space is inferred after inlining)
+	constexpr int TAB_LDS = KIND == KIND_TABULAR ? 3072 : KIND == KIND_TABULAR_ANISO ? 16384 + 768 : FRK == FR_SPLINE ? 768 : 0;
+	__shared__ float s_tab[TAB_LDS ? TAB_LDS : 1];
+	if (TAB_LDS) {
+		int used = 0;
+		auto stage = [&](const float *&src, int count) {
+			if (src == nullptr || count <= 0 || used + count > TAB_LDS) return;
+			float *dst = s_tab + used;
+			for (int k = threadIdx.x; k < count; k += BS) dst[k] = src[k];
+			src = dst; used += count;
+		};
+		if (KIND == KIND_TABULAR) { stage(b.p22, b.n_p22); stage(b.sigma, b.n_sigma); }
+		if (KIND == KIND_TABULAR_ANISO) { stage(b.sigma, b.elev * b.azim); stage(b.p22, b.elev * b.azim); }
+		if (FRK == FR_SPLINE) stage(b.fr.pts, 3 * b.fr.npts);
+	}
+	if (EXPT || POWT || ATANT || TAB_LDS) __syncthreads();
+	const long long stride = (long long)gridDim.x * BS;
 	const unsigned int t = threadIdx.x;
-	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
+	for (long long k0 = (long long)blockIdx.x * BS; k0 < n; k0 += stride) {     // k0: workgroup-uniform
 		const long long k = k0 + t;
 		if (k >= n) continue;
 		v3 i = DENSE ? load3_dense(vi, k0, t) : load3(vi, k), o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
@@ -205,7 +228,8 @@ template <int KIND, int FRK>
 hipError_t launch_eval_kind_fr(hipStream_t s, const Brdf &b, const Params &p, long long n,
                                const View &i, const View &o, const View &out, float *out_pdf, int want)
 {
-	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(BLOCK);
+	dim3 g((KIND == KIND_BECKMANN || KIND == KIND_GGX) ? grid_full(n) : grid_for(n)), t(eval_block(KIND));
+	if (eval_block(KIND) != BLOCK) { long long bl = (n + eval_block(KIND) - 1) / eval_block(KIND); g = dim3((unsigned int)(bl < 1 ? 1 : bl > 2048 ? 2048 : bl)); }
 	const bool dn = dense(i) && dense(o) && dense(out);
 	if constexpr (KIND == KIND_BECKMANN && (FRK == FR_IDEAL || FRK == FR_SCHLICK || FRK == FR_UNPOLARIZED)) {
 		if (beckmann_sharp_supported(b, p) && n >= (1LL << 16)) {
@@ -372,7 +396,21 @@ __global__ __launch_bounds__(BLOCK) void k_sample(Brdf b, Params p, long long n,
 		gt.exp64 = b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
 	}
 	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
-	if (KIND == KIND_BECKMANN || ATANT) __syncthreads();
+	// the quantile tables of a fitted lobe in LDS (as k_eval does for its tables): qf of tabular, qf1 and the qf2 grid of tabular_anisotropic
+	constexpr int TAB_LDS = KIND == KIND_TABULAR ? 2048 : KIND == KIND_TABULAR_ANISO ? 8192 + 1024 : 0;
+	__shared__ float s_tab[TAB_LDS ? TAB_LDS : 1];
+	if (TAB_LDS) {
+		int used = 0;
+		auto stage = [&](const float *&src, int count) {
+			if (src == nullptr || count <= 0 || used + count > TAB_LDS) return;
+			float *dst = s_tab + used;
+			for (int k = threadIdx.x; k < count; k += BLOCK) dst[k] = src[k];
+			src = dst; used += count;
+		};
+		if (KIND == KIND_TABULAR) stage(b.qf, b.n_qf);
+		if (KIND == KIND_TABULAR_ANISO) { stage(b.a_qf2, b.elev * b.azim); stage(b.a_qf1, b.n_a_qf1); }
+	}
+	if (KIND == KIND_BECKMANN || ATANT || TAB_LDS) __syncthreads();
 	const long long stride = (long long)gridDim.x * BLOCK;
 	const unsigned int t = threadIdx.x;
 	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform

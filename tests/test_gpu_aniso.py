@@ -126,3 +126,23 @@ def test_anisotropic_queries_reject_other_kinds(gpu_ctx):
         djb.tabular_anisotropic.pdf1(g, np.zeros(4, np.float32))
     with pytest.raises(djb.exc):
         djb.tabular_anisotropic(g, 1, 8, ctx=gpu_ctx)              # "Invalid Resolution", dj_brdf.h:2244
+
+
+def test_anisotropic_grids_beyond_the_lds_budget(gpu_ctx):
+    """k_eval / k_sample stage a fitted lobe's tables in LDS when they fit (two 90 x 90 grids do); at 136 x 128 sigma's grid fits and
+    the slope-pdf grid does not, at 160 x 128 neither does: every combination must give what the per-unit code gives without any staging --
+    the host twin that answers calls of <= 96 units (same object, tables read back from HBM)."""
+    n = 1 << 15
+    i, o = synth.directions_aos(n, synth.SEED_I), synth.directions_aos(n, synth.SEED_O)
+    u1, u2 = synth.uniforms(n, synth.SEED_U1), synth.uniforms(n, synth.SEED_U2)
+    for elev, azim in ((136, 128), (160, 128)):
+        t = djb.tabular_anisotropic(djb.ggx(ctx=gpu_ctx), elev, azim, True, ctx=gpu_ctx)
+        fr, pdf = t.eval_pdf(i, o)                                   # batch: the kernels
+        s = t.sample(u1, u2, o)
+        assert np.isfinite(fr).all() and float(np.abs(fr).sum()) > 0
+        for lo in (0, 7777, n - 64):                                 # 64 units per call: answered by the host twin
+            sl = slice(lo, lo + 64)
+            fr_h, pdf_h = t.eval_pdf(i[sl], o[sl])
+            assert np.array_equal(fr[sl].view(np.uint32), fr_h.view(np.uint32)), (elev, azim, lo)
+            assert np.array_equal(pdf[sl].view(np.uint32), pdf_h.view(np.uint32)), (elev, azim, lo)
+            assert np.array_equal(s[sl].view(np.uint32), t.sample(u1[sl], u2[sl], o[sl]).view(np.uint32)), (elev, azim, lo)

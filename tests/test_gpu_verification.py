@@ -202,7 +202,7 @@ def _rank_main(rank, world, port, n_pairs, n_mat, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_run_the_hip_path(gpu_ctx):
+def test_two_ranks_run_the_hip_path(gpu_ctx, oracle):
     import torch
     import torch.multiprocessing as mp
     world, n_pairs, n_mat = 2, 1_000_003, 7
@@ -223,6 +223,13 @@ def test_two_ranks_run_the_hip_path(gpu_ctx):
     want = torch.cat([m.eval(i, o), g.eval(i, o, djb.microfacet.params.isotropic(0.3))]).cpu().numpy()
     got = np.concatenate(res[0][0], axis=1)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "sharded pair ranges != unsharded batch"
+    # ... and the sharded result against the ORACLE (not only against another HIP run): every 97th pair
+    sub = np.arange(0, n_pairs, 97)
+    ih = np.ascontiguousarray(i.cpu().numpy().T[sub]); oh = np.ascontiguousarray(o.cpu().numpy().T[sub])
+    om = oracle.merl_from_table(synth.merl_table_hashed())
+    og = oracle.microfacet("ggx", ("schlick", 1.0, 0.71, 0.29), True)
+    want_o = np.concatenate([oracle.eval(om, ih, oh).T, oracle.eval(og, ih, oh, ("elliptic", 0.3, 0.3, 0.0)).T])
+    assert np.array_equal(np.ascontiguousarray(got[:, sub]).view(np.uint32), np.ascontiguousarray(want_o).view(np.uint32)), "sharded HIP result != oracle"
     mats = [djb.merl.from_table(synth.merl_table(*synth.material_recipe(k)), ctx=gpu_ctx) for k in range(n_mat)]
     ab, ag = djb.fit_brdf_batch(mats, 90, True, ctx=gpu_ctx)
     for r in range(world):

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(eval_block(KIND), eval_min_waves(KIND)) void k_eval
 	__shared__ double s_atan[ATANT ? 16 : 1];
 	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
 	// a fitted lobe's tables in LDS (north star: "LDS-staged tiles of the tables"): the slope-pdf and sigma tables of tabular (float[res]
-	// each), sigma's elev x azim grid of tabular_anisotropic (two of the pair's three grid look-ups), the Fresnel spline's points -- 12-20
+	// each), the sigma and slope-pdf grids of tabular_anisotropic (elev x azim each), the Fresnel spline's points -- 12-20
 	// divergent 4-byte look-ups per pair otherwise go through the texture path.  Staged when they fit TAB_LDS floats; the per-unit code
 	// reads through the same pointers (the address space is inferred after inlining)
 	constexpr int TAB_LDS = KIND == KIND_TABULAR ? 3072 : KIND == KIND_TABULAR_ANISO ? 16384 + 768 : FRK == FR_SPLINE ? 768 : 0;

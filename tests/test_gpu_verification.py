@@ -465,3 +465,30 @@ def test_fast_trig_sites_against_their_previous_forms(gpu_ctx):
             for k in tot: tot[k] += r[k]
         print("%-12s" % name, tot)
         assert tot["mismatch"] == 0 and tot["decided"] + tot["undecided"] == 1 << 32 and tot["decided"] > 0.2 * (1 << 32)   # (the rest: |x| > 1, NaN, ...)
+
+
+def test_utia_two_tier_on_ragged_batch_sizes(gpu_ctx):
+    """k_utia_v2 fetches its records wave-cooperatively (every lane of a wave takes part, also the ones past the end of the batch): device
+    batches of 1 .. 100003 pairs, eval and evalp, against the one-kernel form; under DJB_OPT_CONTRACT_1E5 within the contract; the fused
+    eval + pdf call gives eval's bits."""
+    import torch
+    u = djb.utia.from_table(np.random.default_rng(3).uniform(-5, 120, 3 * 288 * 288), ctx=gpu_ctx)
+    try:
+        for n in (1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097, 100003):
+            i = djb.gen_directions(n, 7, ctx=gpu_ctx); o = djb.gen_directions(n, 8, ctx=gpu_ctx)
+            for op in ("eval", "evalp"):
+                djb.set_utia_exact_only(gpu_ctx, True)
+                one = getattr(u, op)(i, o)
+                djb.set_utia_exact_only(gpu_ctx, False)
+                two = getattr(u, op)(i, o)
+                assert torch.equal(two.view(torch.int32), one.view(torch.int32)), (n, op)
+                djb.set_contract_1e5(gpu_ctx, True)
+                fast = getattr(u, op)(i, o)
+                djb.set_contract_1e5(gpu_ctx, False)
+                assert bool(((fast == 0) == (one == 0)).all()), (n, op)
+                rel = ((fast - one).abs() / one.abs().clamp_min(1e-30)).masked_fill(one == 0, 0.0)
+                assert float(rel.max()) <= 1e-5, (n, op, float(rel.max()))
+            fr, _ = u.eval_pdf(i, o)
+            assert torch.equal(fr.view(torch.int32), u.eval(i, o).view(torch.int32)), n
+    finally:
+        djb.set_utia_exact_only(gpu_ctx, False); djb.set_contract_1e5(gpu_ctx, False)

@@ -1,8 +1,9 @@
 #!/bin/bash
 # kernel_resources.sh <file.hip> [filter] [extra flags]: VGPRs / spills / scratch / occupancy / LDS of every kernel of one translation unit
-# (hipcc -Rpass-analysis=kernel-resource-usage), demangled, one line per kernel.  Build container; no GPU.
+# (hipcc -Rpass-analysis=kernel-resource-usage with the Makefile's flags; add e.g. "-mllvm -disable-machine-licm=false" as the third argument to see the
+# hoisting MachineLICM would do), demangled, one line per kernel.  Build container; no GPU.
 cd "$(dirname "$0")/../dj_brdf_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fno-slp-vectorize $3 \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fno-slp-vectorize -mllvm -disable-machine-licm $3 \
   -Rpass-analysis=kernel-resource-usage -c "$1" -o /tmp/kres.o 2>&1 | python3 -c "
 import sys, re, subprocess
 rows, cur = [], None

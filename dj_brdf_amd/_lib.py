@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DJB_LIB_PATH") or os.path.join(_HERE, "lib", "libdjb_hip.so")
 
 DJB_OK = 0
-ABI_VERSION = 234          # include/djb_hip.h: DJB_HIP_VERSION (the major digit must match the loaded library)
+ABI_VERSION = 235          # include/djb_hip.h: DJB_HIP_VERSION (the major digit must match the loaded library)
 STATUS_NAMES = {
     0: "DJB_OK", 1: "DJB_ERR_INVALID_ARGUMENT", 2: "DJB_ERR_OPEN_FAILED", 3: "DJB_ERR_BAD_HEADER",
     4: "DJB_ERR_READ_FAILED", 5: "DJB_ERR_NOT_IMPLEMENTED", 6: "DJB_ERR_HIP", 7: "DJB_ERR_NO_DEVICE",
@@ -58,7 +58,7 @@ EXPORTS = [
     "djb_brdf_create_beckmann", "djb_brdf_create_ggx", "djb_brdf_create_merl_from_file",
     "djb_brdf_create_merl_from_memory", "djb_brdf_create_utia_from_file",
     "djb_brdf_create_utia_from_memory", "djb_brdf_create_lambert", "djb_brdf_create_tabular",
-    "djb_fit_merl_files", "djb_fit_merl_files_multi", "djb_merl_bin_keys_batch", "djb_selftest_guarded_math", "djb_selftest_fast_trig", "djb_selftest_contract", "djb_selftest_contract_sample", "djb_contract_sample_attack", "djb_ctx_libm_matches_host", "djb_host_libm_mode", "djb_host_atan_log_kat", "djb_selftest_libm", "djb_selftest_trig_sweep", "djb_brdf_create_tabular_anisotropic", "djb_tabular_anisotropic_get", "djb_tabular_anisotropic_fit",
+    "djb_fit_merl_files", "djb_fit_merl_files_multi", "djb_merl_bin_keys_batch", "djb_selftest_guarded_math", "djb_selftest_fast_trig", "djb_selftest_model_fast", "djb_selftest_contract", "djb_selftest_contract_sample", "djb_contract_sample_attack", "djb_ctx_libm_matches_host", "djb_host_libm_mode", "djb_host_atan_log_kat", "djb_selftest_libm", "djb_selftest_trig_sweep", "djb_brdf_create_tabular_anisotropic", "djb_tabular_anisotropic_get", "djb_tabular_anisotropic_fit",
     "djb_eval_pp_batch", "djb_eval_lean_batch", "djb_sample_pp_batch", "djb_sample_lean_batch", "djb_lrep_op", "djb_params_to_lrep", "djb_lrep_to_params",
     "djb_brdf_create_sgd", "djb_brdf_create_abc", "djb_brdf_create_sgd_from_params",
     "djb_brdf_create_abc_from_params",

@@ -593,9 +593,19 @@ static djb_status create_model(djb_ctx *ctx, int kind, const double *row, int co
 	djb_brdf *b;
 	alloc_brdf(ctx, kind, &b);
 	b->model_host.assign(row, row + count);
+	// sgd: the device copy carries, behind the row, the constants of the decided fast tier (djb_fast_models.inc: logarithms, a reciprocal and
+	// the bound's coefficients per channel; [33] = 0 when the row is outside that tier's domain -- the kernels then run the exact chains only)
+	double ext[djbdev::SGD_FAST_ROW];
+	const double *src = row;
+	int n_dev = count;
+	if (kind == DJB_KIND_SGD) {
+		(void)djbdev::sgd_fast_row(row, ext); src = ext; n_dev = djbdev::SGD_FAST_ROW;
+		const char *ev = getenv("DJB_SGD_FAST");                 // "0": objects created from here on run the exact chains only (tests, A/B timing)
+		if (ev && ev[0] == '0') ext[djbdev::SGD_FAST_FLAG] = 0.0;
+	}
 	double *d = nullptr;
-	hipError_t e = hipMalloc((void **)&d, sizeof(double) * count);
-	if (e == hipSuccess) e = hipMemcpy(d, row, sizeof(double) * count, hipMemcpyHostToDevice);
+	hipError_t e = hipMalloc((void **)&d, sizeof(double) * n_dev);
+	if (e == hipSuccess) e = hipMemcpy(d, src, sizeof(double) * n_dev, hipMemcpyHostToDevice);
 	if (e != hipSuccess) { if (d) (void)hipFree(d); delete b; return fail(DJB_ERR_HIP, "djb_error: %s", hipGetErrorString(e)); }
 	b->allocs.push_back(d);
 	b->dev.model = d;

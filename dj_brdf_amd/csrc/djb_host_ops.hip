@@ -956,6 +956,27 @@ try {
 }
 DJB_ABI_CATCH
 
+djb_status djb_selftest_model_fast(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint32_t seed, unsigned long long *counters6)
+try {
+	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
+	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
+	djb_status st = check_call(ctx, b, n, DJB_MEM_DEVICE);
+	if (st != DJB_OK) return st;
+	std::lock_guard<std::recursive_mutex> call_lock(ctx->call_mu);
+	if (!counters6 || (b->dev.kind != DJB_KIND_SGD && b->dev.kind != DJB_KIND_ABC))
+		return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: djb_selftest_model_fast needs an sgd or abc brdf");
+	unsigned long long *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 48));
+	hipError_t e = hipMemsetAsync(d, 0, 48, ctx->stream);
+	if (e == hipSuccess) e = djbk::launch_model_fast_selftest(ctx->stream, b->dev, n, seed, d);
+	if (e == hipSuccess) e = hipMemcpyAsync(counters6, d, 48, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(DJB_ERR_HIP, "djb_error: selftest: %s", hipGetErrorString(e));
+	return DJB_OK;
+}
+DJB_ABI_CATCH
+
 djb_status djb_selftest_contract(djb_ctx *ctx, const djb_brdf *b, const djb_params *params, int64_t n, uint32_t seed, int family,
                                  float *max_rel2, unsigned long long *counters4)
 try {

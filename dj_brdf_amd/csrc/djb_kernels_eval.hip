@@ -62,6 +62,8 @@ __global__ __launch_bounds__(eval_block(KIND), eval_min_waves(KIND)) void k_eval
 	// Beckmann evaluates the fp64 exp of glibc (djb_device.hpp) three times per pair: its 2 KB table goes to LDS
 	// (sgd: 9 exp + 9 pow per pair, abc: one pow -- both tables)
 	// (sgd also calls glibc's acos twice per pair: its 21 KB of tables)
+	// (round 6: sgd's polar angles come from the arctangent core below; glibc's acos only answers for the units the decided fast tier leaves,
+	// djb_fast_models.inc -- its 21 KB of tables are staged only for a row outside that tier's domain: 3.99 ms per 1e8 pairs, 5.17 from global)
 	constexpr bool EXPT = KIND == KIND_BECKMANN || KIND == KIND_SGD || KIND == KIND_ABC, POWT = KIND == KIND_SGD || KIND == KIND_ABC,
 	               ACOST = KIND == KIND_SGD;
 	__shared__ unsigned long long s_exp[EXPT ? 256 : 1];
@@ -69,9 +71,9 @@ __global__ __launch_bounds__(eval_block(KIND), eval_min_waves(KIND)) void k_eval
 	__shared__ double s_acos[ACOST ? 2568 + 128 : 1];
 	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BS);
 	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BS);
-	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BS);
+	if (ACOST && b.model[SGD_FAST_FLAG] == 0.0) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BS);
 	// the tabulated lobes' table coordinates (acos / atan / atan2 of a float, rounded to float) from the arctangent core (djb_device.hpp)
-	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || FRK == FR_SPLINE;      // ... and the Fresnel spline's (dj_brdf.h:1341)
+	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || KIND == KIND_SGD || FRK == FR_SPLINE;      // ... and the Fresnel spline's (dj_brdf.h:1341)
 	__shared__ double s_atan[ATANT ? 16 : 1];
 	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
 	// a fitted lobe's tables in LDS (north star: "LDS-staged tiles of the tables"): the slope-pdf and sigma tables of tabular (float[res]
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pp(Brdf b, long long n, View vi,
                                                    LeanCfg base, View vout, float *out_pdf, float *out_pp)
 {
 	__shared__ unsigned long long s_exp[KIND == KIND_BECKMANN ? 256 : 1];     // as in k_eval
-	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || FRK == FR_SPLINE;
+	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || KIND == KIND_SGD || FRK == FR_SPLINE;
 	__shared__ double s_atan[ATANT ? 16 : 1];
 	if (KIND == KIND_BECKMANN) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
 	b.atan_lds = ATANT ? atan_tab_to_lds(s_atan, threadIdx.x) : 0u;
@@ -877,6 +879,85 @@ hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n,
 {
 	if (n <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k_trig_sweep, dim3(grid_for(n)), dim3(BLOCK), 0, s, fn, first, n, out);
+	return hipGetLastError();
+}
+
+// djb_selftest_model_fast: the decided fast tier of the sgd / abc models (djb_fast_models.inc) against the reference's chains, on the device.
+// Unit k draws a polar cosine (family k & 3: uniform; hugging the wall theta_k = theta0 of channel (k >> 2) % 3 [sgd]; grazing; next to the
+// normal) and evaluates sgd::g1 and sgd::ndf (abc: ndf) of the direction (0, 0, z) twice: through the product's functions (fast tier, what
+// it leaves to the exact chain) and through the exact chains alone.  counters = {values, values the fast tier left undecided, values
+// whose two floats differ (must be 0)} for g1 and for ndf.
+__global__ __launch_bounds__(BLOCK) void k_model_fast_selftest(Brdf b, long long n, uint32_t seed, unsigned long long *counters)
+{
+	__shared__ unsigned long long s_exp[256];
+	__shared__ double s_pow[384];
+	__shared__ double s_atan[16];
+	b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BLOCK);
+	b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BLOCK);
+	b.atan_lds = atan_tab_to_lds(s_atan, threadIdx.x);
+	__syncthreads();
+	const double *m = b.model;
+	unsigned long long c[6] = { 0, 0, 0, 0, 0, 0 };
+	const long long stride = (long long)gridDim.x * BLOCK;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+		const uint32_t h0 = hash_u32(seed, (uint64_t)k, 1u), h1 = hash_u32(seed, (uint64_t)k, 2u);
+		const float u = (float)(h0 >> 8) * 0x1p-24f, v = (float)(h1 >> 8) * 0x1p-24f;
+		const unsigned int fam = (unsigned int)k & 3u, ch = ((unsigned int)k >> 2) % 3u;
+		float z;
+		if (fam == 0u) z = u;
+		else if (fam == 1u) z = b.kind == KIND_SGD ? F(cos(m[30 + ch] + (D(u) - 0.3) * exp2(-30.0 * D(v)))) : sqrtf(u);
+		else if (fam == 2u) z = 0.05f * u;
+		else z = 1.0f - u * exp2f(-24.0f * v);
+		if (!(z > 0.0f)) z = 1e-3f;
+		if (z > 1.0f) z = 1.0f;
+		const v3 d = mk(0.0f, 0.0f, z);
+		if (b.kind == KIND_SGD) {
+			const v3 got = sgd_g1_rgb(b, d);
+			const double theta_k = glibc_acos(D(z), 0u);
+			const float gg[3] = { got.x, got.y, got.z };
+			bool in;
+			const double th = acos_fast(z, atan_tab(b.atan_lds), in), dth = 1.01 * 0x1p-48 * th;
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				const float want = F(sgd_g1(b, theta_k, m[30 + j], m[24 + j], m[27 + j], m[21 + j]));
+				bool dec;
+				(void)sgd_g1_fast<true>(m, j, th - m[30 + j], dth, b.pow_lds, b.exp_lds, dec);
+				++c[0]; if (!(dec & in) || m[SGD_FAST_FLAG] == 0.0) ++c[1];
+				if (__float_as_uint(gg[j]) != __float_as_uint(want)) ++c[2];
+			}
+			const v3 gn = sgd_ndf_rgb(b, d);
+			const float nn[3] = { gn.x, gn.y, gn.z };
+			const double chd = D(z), c2 = chd * chd, rc = recip_fast(c2);
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				const float want = sgd_ndf(b, chd, m[6 + j], m[9 + j], m[18 + j]);
+				bool dec;
+				(void)sgd_ndf_fast(m, j, c2, (1.0 - c2) * rc, rc * rc, b.pow_lds, b.exp_lds, dec);
+				++c[3]; if (!dec || m[SGD_FAST_FLAG] == 0.0) ++c[4];
+				if (__float_as_uint(nn[j]) != __float_as_uint(want)) ++c[5];
+			}
+		} else {
+			const v3 gn = abc_ndf_rgb(b, d);
+			const float nn[3] = { gn.x, gn.y, gn.z };
+			const double w = 1.0 + m[6] * (1.0 - D(z));
+			const double den = glibc_pow(w, m[7], 0u, 0u);
+			float fv[3]; bool dec[3];
+			abc_ndf_fast(m, w, b.pow_lds, b.exp_lds, fv, dec);
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				const float want = F(m[3 + j] / den);
+				++c[3]; if (!dec[j]) ++c[4];
+				if (__float_as_uint(nn[j]) != __float_as_uint(want)) ++c[5];
+			}
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < 6; ++j) if (c[j]) atomicAdd(&counters[j], c[j]);
+}
+hipError_t launch_model_fast_selftest(hipStream_t s, const Brdf &b, long long n, uint32_t seed, unsigned long long *counters6)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_model_fast_selftest, dim3(grid_for(n)), dim3(BLOCK), 0, s, b, n, seed, counters6);
 	return hipGetLastError();
 }
 

@@ -1333,6 +1333,15 @@ def selftest_fast_trig(n: int, mode: int, first: int = 0, seed: int = 1, ctx: Op
     return {"decided": c[0], "mismatch": c[1], "undecided": c[2], "worst_ulp64": int(c[3])}
 
 
+def selftest_model_fast(brdf, n: int, seed: int = 1, ctx: Optional[Context] = None):
+    """The decided fast tier of an sgd / abc model's fp64 terms against the reference's chains on n generated polar cosines
+    (djb_selftest_model_fast).  The `*_mismatch` counters must be 0."""
+    ctx = ctx or brdf.ctx
+    c = (C.c_ulonglong * 6)()
+    _lib.check(_lib.load().djb_selftest_model_fast(ctx._h, brdf._h, C.c_int64(n), C.c_uint32(seed), c))
+    return {"g1": c[0], "g1_undecided": c[1], "g1_mismatch": c[2], "ndf": c[3], "ndf_undecided": c[4], "ndf_mismatch": c[5]}
+
+
 def selftest_guarded_math(n: int, seed: int = 1, ctx: Optional[Context] = None):
     """Self-test of the kernels' guarded fp64 shortcuts against the exact double sequences on n
     hash-generated inputs (see djb_selftest_guarded_math).  Mismatch counters must be 0."""

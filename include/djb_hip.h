@@ -57,8 +57,9 @@ extern "C" {
  *   232  round 5: + DJB_OPT_HOST_BATCH_MAX (the size up to which host-array calls are answered by the host twin; default unchanged).
  *   233  round 6: + djb_fit_merl_files_multi (the file pipeline over several contexts), djb_merl_bin_keys_batch.  The on-chip uniforms of
  *        djb_sample_rng_batch / djb_gen_uniforms are a cheaper counter hash (dj_brdf_amd/synth.py: rng_uniforms); same interface.
- *   234  round 6: + djb_selftest_fast_trig; DJB_OPT_CONTRACT_1E5 also covers utia eval / evalp (the sRGB power of the decode only). */
-#define DJB_HIP_VERSION 234
+ *   234  round 6: + djb_selftest_fast_trig; DJB_OPT_CONTRACT_1E5 also covers utia eval / evalp (the sRGB power of the decode only).
+ *   235  round 6: + djb_selftest_model_fast (the decided fast tier of the sgd / abc models). */
+#define DJB_HIP_VERSION 235
 #define DJB_HIP_VERSION_MAJOR(v) ((v) / 100)
 
 typedef enum {
@@ -471,6 +472,13 @@ djb_status djb_selftest_guarded_math(djb_ctx *, int64_t n, uint32_t seed, unsign
  * (must be 0), left to the previous form, the largest distance of a decided double from the device libm's in units of 2^-52 of the
  * value (modes 0, 1, 8; the guard is 4096)}. */
 djb_status djb_selftest_fast_trig(djb_ctx *, int64_t n, int mode, uint32_t first, uint32_t seed, unsigned long long *counters4);
+/* The sgd and abc models round the ends of fp64 chains (glibc's pow and exp) to float: nine values per sgd pair, three per abc pair.  The
+ * kernels evaluate each chain once in plain double together with a bound on its distance from the reference's own double, and keep the
+ * float only when both ends of that interval round to it; the reference's chain answers for the rest (csrc/djb_fast_models.inc,
+ * DESIGN.md 4.2).  This runs n generated polar cosines (uniform, hugging the wall of sgd's shadowing term, grazing, next to the normal)
+ * through the product's g1 / ndf and through the exact chains alone: counters6 = {g1 values, g1 values left to the exact chain, g1 values
+ * that differ (must be 0), ndf values, left, different (must be 0)} (abc: the ndf half only). */
+djb_status djb_selftest_model_fast(djb_ctx *, const djb_brdf *, int64_t n, uint32_t seed, unsigned long long *counters6);
 /* the DJB_OPT_CONTRACT_1E5 fast path against the bit-exact per-pair code on n generated pairs (family 0: the bench
  * distribution; 1: grazing with opposite azimuths; 2: near-normal incidence; 3: o at the horizon; 4: un-normalised):
  * max_rel2 = {max relative difference of the eval rgb, of the pdf} over the fast-path pairs, counters4 = {pairs, pairs

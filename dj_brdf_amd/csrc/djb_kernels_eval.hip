@@ -62,16 +62,17 @@ __global__ __launch_bounds__(eval_block(KIND), eval_min_waves(KIND)) void k_eval
 	// Beckmann evaluates the fp64 exp of glibc (djb_device.hpp) three times per pair: its 2 KB table goes to LDS
 	// (sgd: 9 exp + 9 pow per pair, abc: one pow -- both tables)
 	// (sgd also calls glibc's acos twice per pair: its 21 KB of tables)
-	// (round 6: sgd's polar angles come from the arctangent core below; glibc's acos only answers for the units the decided fast tier leaves,
-	// djb_fast_models.inc -- its 21 KB of tables are staged only for a row outside that tier's domain: 3.99 ms per 1e8 pairs, 5.17 from global)
+	// (round 6: sgd's polar angles come from the arctangent core below; glibc's acos -- its 21 KB of tables stay in global memory -- only
+	// answers for the units the decided fast tier leaves, djb_fast_models.inc; a row outside that tier's domain pays for it: 5.2 ms per 1e8
+	// pairs instead of 4.0.  Occupancy: 87 VGPRs = 5 waves per SIMD; 6 (16 B of scratch): the same time, 8 (80 B): 3.59 against 3.12 ms)
 	constexpr bool EXPT = KIND == KIND_BECKMANN || KIND == KIND_SGD || KIND == KIND_ABC, POWT = KIND == KIND_SGD || KIND == KIND_ABC,
-	               ACOST = KIND == KIND_SGD;
+	               ACOST = false;
 	__shared__ unsigned long long s_exp[EXPT ? 256 : 1];
 	__shared__ double s_pow[POWT ? 384 : 1];
 	__shared__ double s_acos[ACOST ? 2568 + 128 : 1];
 	if (EXPT) b.exp_lds = glibc_exp_tab_to_lds(s_exp, threadIdx.x, BS);
 	if (POWT) b.pow_lds = glibc_pow_tab_to_lds(s_pow, threadIdx.x, BS);
-	if (ACOST && b.model[SGD_FAST_FLAG] == 0.0) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BS);
+	if (ACOST) b.acos_lds = glibc_acos_tab_to_lds(s_acos, threadIdx.x, BS);
 	// the tabulated lobes' table coordinates (acos / atan / atan2 of a float, rounded to float) from the arctangent core (djb_device.hpp)
 	constexpr bool ATANT = KIND == KIND_TABULAR || KIND == KIND_TABULAR_ANISO || KIND == KIND_SGD || FRK == FR_SPLINE;      // ... and the Fresnel spline's (dj_brdf.h:1341)
 	__shared__ double s_atan[ATANT ? 16 : 1];

@@ -98,12 +98,20 @@ __global__ __launch_bounds__(eval_block(KIND), eval_min_waves(KIND)) void k_eval
 	if (EXPT || POWT || ATANT || TAB_LDS) __syncthreads();
 	const long long stride = (long long)gridDim.x * BS;
 	const unsigned int t = threadIdx.x;
+	constexpr bool STDK = KIND == KIND_BECKMANN || KIND == KIND_GGX || KIND == KIND_TABULAR;     // same-box A/B: GGX eval+pdf 1.060 -> 1.051 ms per 1e8, tabular 1.804 -> 1.769
+	const bool std_frame = STDK && p.rho == 0.0f && p.s == 1.0f && p.tx == 0.0f && p.ty == 0.0f && p.nx == 0.0f && p.ny == 0.0f && p.nz == 1.0f;
 	for (long long k0 = (long long)blockIdx.x * BS; k0 < n; k0 += stride) {     // k0: workgroup-uniform
 		const long long k = k0 + t;
 		if (k >= n) continue;
 		v3 i = DENSE ? load3_dense(vi, k0, t) : load3(vi, k), o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
 		v3 fr = mk(0, 0, 0); float pdf = 0.0f;
-		eval_one<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
+		if (STDK) {
+			// a standard frame (launch-uniform) and finite x, y of both directions (per lane; v_max ignores a NaN, which both forms propagate):
+			// the parameter arithmetic without its zero terms (djb_device_microfacet.inc, STD) -- the same floats
+			const bool fin = fmaxf(fmaxf(fabsf(i.x), fabsf(i.y)), fmaxf(fabsf(o.x), fabsf(o.y))) < __builtin_inff();
+			if (__builtin_expect(std_frame & fin, 1)) eval_one<KIND, WANT, FRK, true>(b, p, i, o, fr, pdf);
+			else eval_one<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
+		} else eval_one<KIND, WANT, FRK>(b, p, i, o, fr, pdf);
 		if (WANT & 3) { if (DENSE) store3_dense(vout, k0, t, fr); else store3(vout, k, fr); }
 		if (WANT & 4) { if (DENSE) (out_pdf + k0)[t] = pdf; else out_pdf[k] = pdf; }
 	}

@@ -436,15 +436,22 @@ DJB_DEV float atan2_to_f32(float y, float x, double scale) { return F(scale * gl
 // A&S 7.1.26 as the reference writes it, dj_brdf.h:667-688
 // e must be exp(double(-x*x)) (the same for +x and -x): callers that need that exponential
 // themselves (beckmann_qf2_radial) evaluate the fp64 exp once
-DJB_DEV float erf_given_exp(float x, double e)
+// the part before the exponential: poly(t) t as the reference rounds it, and the sign
+DJB_DEV float erf_poly_t(float x, float &sign)
 {
 	const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f,
 	            a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
-	float sign = x < 0 ? -1.0f : 1.0f;
+	sign = x < 0 ? -1.0f : 1.0f;
 	x = fabsf(x);
 	float t = recip_to_f32(1.0 + D(p * x));
 	float poly = ((((a5 * t + a4) * t) + a3) * t + a2) * t + a1;
-	float y = F(1.0 - D(poly * t) * e);
+	return poly * t;
+}
+DJB_DEV float erf_given_exp(float x, double e)
+{
+	float sign;
+	const float pt = erf_poly_t(x, sign);
+	float y = F(1.0 - D(pt) * e);
 	return sign * y;
 }
 DJB_DEV float erf_(float x, LdsTab T = 0u) { return erf_given_exp(x, glibc_exp(D(-x * x), T)); }
@@ -673,6 +680,9 @@ DJB_DEV float atan_sqrt_f(float x, LdsTab) { return atan_sqrt_f(x); }
 DJB_DEV float atan2_to_f32(float y, float x, double scale, LdsTab) { return atan2_to_f32(y, x, scale); }
 #endif
 
+#if !defined(DJB_HOST_MATH) || defined(DJB_HOST_RESTATED)
+#include "djb_fast_models.inc"      // flog / fexp and the decided fast tier of the sgd / abc chains (device; the host only compiles it for tools/sgd_fast_check.cpp)
+#endif
 #include "djb_device_microfacet.inc"
 #include "djb_device_tables.inc"
 #include "djb_device_units.inc"

@@ -956,7 +956,7 @@ try {
 }
 DJB_ABI_CATCH
 
-djb_status djb_selftest_model_fast(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint32_t seed, unsigned long long *counters6)
+djb_status djb_selftest_model_fast(djb_ctx *ctx, const djb_brdf *b, int64_t n, uint32_t seed, uint32_t first, unsigned long long *counters6)
 try {
 	if (is_cpu(ctx)) return fail(DJB_ERR_NOT_IMPLEMENTED, "djb_error: this diagnostic needs a GPU context");
 	if (!b) return fail(DJB_ERR_INVALID_ARGUMENT, "djb_error: null brdf");
@@ -968,7 +968,7 @@ try {
 	unsigned long long *d = nullptr;
 	HIP_TRY(hipMalloc((void **)&d, 48));
 	hipError_t e = hipMemsetAsync(d, 0, 48, ctx->stream);
-	if (e == hipSuccess) e = djbk::launch_model_fast_selftest(ctx->stream, b->dev, n, seed, d);
+	if (e == hipSuccess) e = djbk::launch_model_fast_selftest(ctx->stream, b->dev, n, seed, first, d);
 	if (e == hipSuccess) e = hipMemcpyAsync(counters6, d, 48, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	(void)hipFree(d);

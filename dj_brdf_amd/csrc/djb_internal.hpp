@@ -126,7 +126,7 @@ hipError_t launch_eval_contract(hipStream_t s, const Brdf &b, const Params &p, c
 hipError_t launch_contract_selftest(hipStream_t s, const Brdf &b, const Params &p, const double *model_host, long long n, uint32_t seed_i, uint32_t seed_o,
                                     unsigned long long start, int family, unsigned int *max_bits, unsigned long long *counters);
 hipError_t launch_guard_selftest(hipStream_t s, long long n, uint32_t seed, unsigned long long *counters);
-hipError_t launch_model_fast_selftest(hipStream_t s, const Brdf &b, long long n, uint32_t seed, unsigned long long *counters6);
+hipError_t launch_model_fast_selftest(hipStream_t s, const Brdf &b, long long n, uint32_t seed, uint32_t first, unsigned long long *counters6);
 hipError_t launch_libm_probe(hipStream_t s, int fn, long long n, const double *x, const double *y, double *out);
 hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n, void *out);
 hipError_t launch_histogram_xy(hipStream_t s, long long n, const View &v, int bins,

@@ -892,11 +892,12 @@ hipError_t launch_trig_sweep(hipStream_t s, int fn, uint32_t first, long long n,
 }
 
 // djb_selftest_model_fast: the decided fast tier of the sgd / abc models (djb_fast_models.inc) against the reference's chains, on the device.
-// Unit k draws a polar cosine (family k & 3: uniform; hugging the wall theta_k = theta0 of channel (k >> 2) % 3 [sgd]; grazing; next to the
+// seed == 0: unit k takes the float whose bit pattern is first + k (every float polar cosine of (0, 1] is bits 1 .. 0x3f800000); else unit k
+// draws a polar cosine (family k & 3: uniform; hugging the wall theta_k = theta0 of channel (k >> 2) % 3 [sgd]; grazing; next to the
 // normal) and evaluates sgd::g1 and sgd::ndf (abc: ndf) of the direction (0, 0, z) twice: through the product's functions (fast tier, what
 // it leaves to the exact chain) and through the exact chains alone.  counters = {values, values the fast tier left undecided, values
 // whose two floats differ (must be 0)} for g1 and for ndf.
-__global__ __launch_bounds__(BLOCK) void k_model_fast_selftest(Brdf b, long long n, uint32_t seed, unsigned long long *counters)
+__global__ __launch_bounds__(BLOCK) void k_model_fast_selftest(Brdf b, long long n, uint32_t seed, uint32_t first, unsigned long long *counters)
 {
 	__shared__ unsigned long long s_exp[256];
 	__shared__ double s_pow[384];
@@ -913,7 +914,8 @@ __global__ __launch_bounds__(BLOCK) void k_model_fast_selftest(Brdf b, long long
 		const float u = (float)(h0 >> 8) * 0x1p-24f, v = (float)(h1 >> 8) * 0x1p-24f;
 		const unsigned int fam = (unsigned int)k & 3u, ch = ((unsigned int)k >> 2) % 3u;
 		float z;
-		if (fam == 0u) z = u;
+		if (seed == 0u) z = __uint_as_float(first + (uint32_t)k);            // exhaustive mode: the float with bit pattern first + k
+		else if (fam == 0u) z = u;
 		else if (fam == 1u) z = b.kind == KIND_SGD ? F(cos(m[30 + ch] + (D(u) - 0.3) * exp2(-30.0 * D(v)))) : sqrtf(u);
 		else if (fam == 2u) z = 0.05f * u;
 		else z = 1.0f - u * exp2f(-24.0f * v);
@@ -963,10 +965,10 @@ __global__ __launch_bounds__(BLOCK) void k_model_fast_selftest(Brdf b, long long
 #pragma unroll
 	for (int j = 0; j < 6; ++j) if (c[j]) atomicAdd(&counters[j], c[j]);
 }
-hipError_t launch_model_fast_selftest(hipStream_t s, const Brdf &b, long long n, uint32_t seed, unsigned long long *counters6)
+hipError_t launch_model_fast_selftest(hipStream_t s, const Brdf &b, long long n, uint32_t seed, uint32_t first, unsigned long long *counters6)
 {
 	if (n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k_model_fast_selftest, dim3(grid_for(n)), dim3(BLOCK), 0, s, b, n, seed, counters6);
+	hipLaunchKernelGGL(k_model_fast_selftest, dim3(grid_for(n)), dim3(BLOCK), 0, s, b, n, seed, first, counters6);
 	return hipGetLastError();
 }
 

@@ -1333,12 +1333,13 @@ def selftest_fast_trig(n: int, mode: int, first: int = 0, seed: int = 1, ctx: Op
     return {"decided": c[0], "mismatch": c[1], "undecided": c[2], "worst_ulp64": int(c[3])}
 
 
-def selftest_model_fast(brdf, n: int, seed: int = 1, ctx: Optional[Context] = None):
-    """The decided fast tier of an sgd / abc model's fp64 terms against the reference's chains on n generated polar cosines
-    (djb_selftest_model_fast).  The `*_mismatch` counters must be 0."""
+def selftest_model_fast(brdf, n: int, seed: int = 1, first: int = 0, ctx: Optional[Context] = None):
+    """The decided fast tier of an sgd / abc model's fp64 terms against the reference's chains (djb_selftest_model_fast): n generated
+    polar cosines, or -- seed = 0 -- the n floats whose bit patterns follow `first` (first = 1, n = 0x3f800000: every float of (0, 1]).
+    The `*_mismatch` counters must be 0."""
     ctx = ctx or brdf.ctx
     c = (C.c_ulonglong * 6)()
-    _lib.check(_lib.load().djb_selftest_model_fast(ctx._h, brdf._h, C.c_int64(n), C.c_uint32(seed), c))
+    _lib.check(_lib.load().djb_selftest_model_fast(ctx._h, brdf._h, C.c_int64(n), C.c_uint32(seed), C.c_uint32(first), c))
     return {"g1": c[0], "g1_undecided": c[1], "g1_mismatch": c[2], "ndf": c[3], "ndf_undecided": c[4], "ndf_mismatch": c[5]}
 
 

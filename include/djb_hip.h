@@ -477,8 +477,9 @@ djb_status djb_selftest_fast_trig(djb_ctx *, int64_t n, int mode, uint32_t first
  * float only when both ends of that interval round to it; the reference's chain answers for the rest (csrc/djb_fast_models.inc,
  * DESIGN.md 4.2).  This runs n generated polar cosines (uniform, hugging the wall of sgd's shadowing term, grazing, next to the normal)
  * through the product's g1 / ndf and through the exact chains alone: counters6 = {g1 values, g1 values left to the exact chain, g1 values
- * that differ (must be 0), ndf values, left, different (must be 0)} (abc: the ndf half only). */
-djb_status djb_selftest_model_fast(djb_ctx *, const djb_brdf *, int64_t n, uint32_t seed, unsigned long long *counters6);
+ * that differ (must be 0), ndf values, left, different (must be 0)} (abc: the ndf half only).  seed == 0: the n floats whose bit patterns follow
+ * `first` instead (bits 1 .. 0x3f800000 are every float polar cosine of (0, 1]: an exhaustive run per row takes ~0.1 s). */
+djb_status djb_selftest_model_fast(djb_ctx *, const djb_brdf *, int64_t n, uint32_t seed, uint32_t first, unsigned long long *counters6);
 /* the DJB_OPT_CONTRACT_1E5 fast path against the bit-exact per-pair code on n generated pairs (family 0: the bench
  * distribution; 1: grazing with opposite azimuths; 2: near-normal incidence; 3: o at the horizon; 4: un-normalised):
  * max_rel2 = {max relative difference of the eval rgb, of the pdf} over the fast-path pairs, counters4 = {pairs, pairs

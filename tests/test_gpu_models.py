@@ -109,6 +109,11 @@ def test_model_fast_tier_selftest(gpu_ctx, kind):
         assert r["ndf"] == 3 << 22 and (kind == "abc" or r["g1"] == 3 << 22)
         worst = max(worst, r["ndf_undecided"] / r["ndf"])
     assert worst < 0.01, worst          # the tier does decide (the wall-hugging family of sgd's g1 is undecided by design: not asserted)
+    # ... and over EVERY float polar cosine of (0, 1] (bit patterns 1 .. 0x3f800000) for a few rows (tools/model_fast_exhaustive.py: all of them)
+    for name in ("gold-metallic-paint", "green-acrylic", "alum-bronze", "white-marble"):
+        b = getattr(djb, kind)(name, ctx=gpu_ctx)
+        r = djb.selftest_model_fast(b, 0x3f800000, seed=0, first=1, ctx=gpu_ctx)
+        assert r["g1_mismatch"] == 0 and r["ndf_mismatch"] == 0 and r["ndf"] == 3 * 0x3f800000, (name, r)
 
 
 def test_sgd_fast_tier_equals_exact_chain(gpu_ctx, monkeypatch):

@@ -5,7 +5,7 @@
  *       random rows: |fast double - reference double| / bound (must stay below 1; the bounds carry a factor 2), decided values that
  *       differ from the reference's float (must be 0), share of undecided values.
  *     g++ -O2 -std=c++17 -mfma -ffp-contract=off -fopenmp -I dj_brdf_amd/csrc tools/sgd_fast_check.cpp -o /tmp/sgd_fast_check -lquadmath
- *     /tmp/sgd_fast_check dj_brdf_amd/data/sgd_params.csv [samples per row, default 2e6]
+ *     /tmp/sgd_fast_check dj_brdf_amd/data/sgd_params.csv [samples per row, default 2e6] [abc table] [flog / fexp arguments, default 4e8]
  */
 #define DJB_HOST_MATH 1
 #define DJB_HOST_RESTATED 1
@@ -43,6 +43,7 @@ int main(int argc, char **argv)
 {
 	const char *csv = argc > 1 ? argv[1] : "dj_brdf_amd/data/sgd_params.csv";
 	const long long per_row = argc > 2 ? atoll(argv[2]) : 2000000;
+	const long long n_unit = argc > 4 ? atoll(argv[4]) : 400000000ll;       // arguments of the flog / fexp part
 	// ---- (1) flog / fexp against __float128
 	{
 		double wl_rel = 0, wl_abs = 0, we = 0;
@@ -51,7 +52,7 @@ int main(int argc, char **argv)
 			double l_rel = 0, l_abs = 0, e_ = 0;
 			uint64_t s = 1234567ull * (omp_get_thread_num() + 1);
 #pragma omp for
-			for (long long n = 0; n < 400000000ll; ++n) {
+			for (long long n = 0; n < n_unit; ++n) {
 				const int fam = (int)(n & 3);
 				double x;
 				if (fam == 0) x = exp2(2000.0 * u01(s) - 1000.0);              // any magnitude

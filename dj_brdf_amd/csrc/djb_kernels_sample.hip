@@ -650,8 +650,8 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 		const bool live = k < n;
 		float u1 = 0.5f, u2 = 0.5f; v3 o = mk(0, 0, 1);
 		if (live) {
-			u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : (DENSE ? (u1a + k0)[t] : u1a[k]);
-			u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : (DENSE ? (u2a + k0)[t] : u2a[k]);
+			u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : (DENSE ? (*dense_at(u1a + k0, t)) : u1a[k]);
+			u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : (DENSE ? (*dense_at(u2a + k0, t)) : u2a[k]);
 			o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
 		}
 		Rare why;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 		if (live && !rare) {
 			if (DENSE) store3_dense(vi_out, k0, t, i_out); else store3(vi_out, k, i_out);
 			if (IS) {
-				if (DENSE) { store3_dense(vw_out, k0, t, w); (out_pdf + k0)[t] = pdf; }
+				if (DENSE) { store3_dense(vw_out, k0, t, w); (*dense_at(out_pdf + k0, t)) = pdf; }
 				else { store3(vw_out, k, w); out_pdf[k] = pdf; }
 			}
 		}

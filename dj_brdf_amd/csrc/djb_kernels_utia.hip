@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK, DJB_UTIA_MIN_WAVES) void k_utia_v2(Brdf b, l
 		if (live) {
 			v3 fr = (WANT & 2) ? scale(i.z, ev) : ev;                                   // brdf::evalp, dj_brdf.h:803-806
 			if (DENSE) store3_dense_nt(vout, k0, t, fr); else store3(vout, k, fr);
-			if (WANT & 4) { float pdf = F(D(i.z) / DJB_PI); if (DENSE) (out_pdf + k0)[t] = pdf; else out_pdf[k] = pdf; }   // dj_brdf.h:842-845
+			if (WANT & 4) { float pdf = F(D(i.z) / DJB_PI); if (DENSE) (*dense_at(out_pdf + k0, t)) = pdf; else out_pdf[k] = pdf; }   // dj_brdf.h:842-845
 			if (__builtin_expect(!ok, 0)) {
 				const unsigned int slot = atomicAdd(count, 1u);
 				if (slot < cap) list[slot] = (unsigned int)k;

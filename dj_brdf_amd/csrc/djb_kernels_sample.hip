@@ -647,12 +647,15 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 	const long long stride = (long long)gridDim.x * BLOCK;
 	for (long long k0 = (long long)blockIdx.x * BLOCK; k0 < n; k0 += stride) {     // k0: workgroup-uniform
 		const long long k = k0 + t;
-		const bool live = k < n;
+		// the tile's live lanes from a scalar bound; dense accesses as SGPR base + 32-bit lane offset (djb_device_units.inc: lane_byte_offset)
+		const unsigned int rem = n - k0 >= (long long)BLOCK ? (unsigned int)BLOCK : (unsigned int)(n - k0);
+		const bool live = t < rem;
 		float u1 = 0.5f, u2 = 0.5f; v3 o = mk(0, 0, 1);
 		if (live) {
-			u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : (DENSE ? (*dense_at(u1a + k0, t)) : u1a[k]);
-			u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : (DENSE ? (*dense_at(u2a + k0, t)) : u2a[k]);
-			o = DENSE ? load3_dense(vo, k0, t) : load3(vo, k);
+			const unsigned int toff = lane_byte_offset(t);
+			u1 = RNG ? gen_uniform(seed1, start + (unsigned long long)k) : (DENSE ? (*dense_off(u1a + k0, toff)) : u1a[k]);
+			u2 = RNG ? gen_uniform(seed2, start + (unsigned long long)k) : (DENSE ? (*dense_off(u2a + k0, toff)) : u2a[k]);
+			o = DENSE ? load3_dense_off(vo, k0, toff) : load3(vo, k);
 		}
 		Rare why;
 		v3 i_;
@@ -672,9 +675,10 @@ __global__ __launch_bounds__(BLOCK) void k_sample_bk(Brdf b, Params p, long long
 		const bool rare = why.any & live;
 #endif
 		if (live && !rare) {
-			if (DENSE) store3_dense(vi_out, k0, t, i_out); else store3(vi_out, k, i_out);
+			const unsigned int soff = lane_byte_offset(t);
+			if (DENSE) store3_dense_off(vi_out, k0, soff, i_out); else store3(vi_out, k, i_out);
 			if (IS) {
-				if (DENSE) { store3_dense(vw_out, k0, t, w); (*dense_at(out_pdf + k0, t)) = pdf; }
+				if (DENSE) { store3_dense_off(vw_out, k0, soff, w); (*dense_off(out_pdf + k0, soff)) = pdf; }
 				else { store3(vw_out, k, w); out_pdf[k] = pdf; }
 			}
 		}
